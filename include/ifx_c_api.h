@@ -1,0 +1,184 @@
+/*
+ * include/ifx_c_api.h -- C-ABI of libifx.so, the MI355X-native (HIP, gfx950) implementation of
+ * InstanceFusion's per-frame dense surfel pipeline.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces.  Citation prefixes: EF/ = elasticfusionpublic/Core/src/, IF/ = src/ of the
+ * reference tree.  Plain C types only: no HIP, torch or C++ types cross the boundary.  Pointers
+ * named d_* are device (HBM) pointers of the handle's GPU, every other pointer is host memory.
+ *
+ * Error behaviour: every function that can fail returns 0 on success and a negative IFX_E_* code
+ * on failure; ifx_last_error() gives the message.  Nothing calls exit() (the reference's
+ * cudaSafeCall / gpuErrChk do: EF/Cuda/convenience.cuh:64-71, IF/Core/InstanceFusionCuda.cu:11-20).
+ *
+ * Threading: one ifx_t = one host thread + one HIP stream; the handle is not thread-safe.
+ */
+#ifndef IFX_C_API_H_
+#define IFX_C_API_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFX_NUM_INSTANCES 96   /* IF/main.cpp:31-44 (instanceNum) */
+#define IFX_VOTE_FLOATS 48     /* two int16 counters per float, IF/Core/InstanceFusionCuda.cu:22-39 */
+
+enum {
+    IFX_OK = 0,
+    IFX_E_INVALID = -1,   /* bad argument */
+    IFX_E_HIP = -2,       /* a HIP runtime call failed */
+    IFX_E_CAPACITY = -3,  /* the surfel store is full */
+    IFX_E_STATE = -4      /* call not valid in the current state */
+};
+
+/* Replaces the ElasticFusion constructor arguments (EF/ElasticFusion.h:47-62, values used by
+ * IF/map_interface/ElasticFusionInterface.cpp:43-45) and the Resolution/Intrinsics singletons
+ * (IF/main.cpp:46-47). */
+typedef struct ifx_config {
+    int32_t width, height;       /* 640 x 480 */
+    float fx, fy, cx, cy;        /* 528, 528, 320, 240 */
+    int32_t time_delta;          /* 200 */
+    float confidence;            /* 10 */
+    float depth_cut;             /* 12 m */
+    float max_depth_processed;   /* 20 m (EF/ElasticFusion.cpp:73) */
+    float icp_weight;            /* 10 */
+    int32_t pyramid;             /* 1 */
+    int32_t fast_odom;           /* 0 */
+    int32_t so3;                 /* 1 */
+    int32_t max_surfels;         /* capacity of the surfel store (reference: 1536^2, EF/GlobalModel.cpp:22-23) */
+    int32_t device;              /* HIP device ordinal */
+    int32_t n_ranks, rank;       /* spatial-hash map sharding: this handle owns shard `rank` of `n_ranks` */
+} ifx_config;
+
+typedef struct ifx ifx_t;
+
+/* ---- construction (replaces `new ElasticFusion(...)`, IF/map_interface/ElasticFusionInterface.cpp:43-45) */
+int ifx_create(const ifx_config* cfg, ifx_t** out);
+void ifx_destroy(ifx_t* h);
+const char* ifx_last_error(ifx_t* h);
+/* Global (handle-free) message for failures of ifx_create itself. */
+const char* ifx_global_error(void);
+
+/* ---- frame entry.  Replaces ElasticFusion::processFrame (EF/ElasticFusion.h:75-82,
+ * EF/ElasticFusion.cpp:269-720) and ElasticFusionInterface::ProcessFrame
+ * (IF/map_interface/ElasticFusionInterface.h:129-130).
+ * rgb: H*W*3 u8 row-major, depth: H*W u16 millimetres (0 invalid).  in_pose16: NULL to track, or a
+ * row-major 4x4 camera-to-world pose to use instead of tracking.  out_pose16 (may be NULL) receives
+ * currPose.  Returns 0 ok, 1 lost (never in this configuration: reloc=false), <0 error. */
+int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
+                      const float* in_pose16, float weight_mult, float* out_pose16);
+/* Same, with the frame already resident in HBM and no host synchronisation: the call only
+ * enqueues work on the handle's stream.  Poses are appended to the device-side trajectory log. */
+int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth,
+                             int64_t timestamp, const float* in_pose16, float weight_mult);
+int ifx_sync(ifx_t* h);
+/* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
+int ifx_get_pose(ifx_t* h, float* out_pose16);
+int ifx_tick(ifx_t* h);
+/* Trajectory log: one pose per processed frame (ResultModel.freiburg, EF/ElasticFusion.cpp:99-136). */
+int ifx_trajectory(ifx_t* h, float* out_poses16, int max_frames);
+/* diag[8]: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count,
+ * velocity weighting, fill-in flag (EF/Utils/RGBDOdometry.h:65-70). */
+int ifx_tracker_diag(ifx_t* h, float* diag8);
+
+/* ---- map access (replaces getMapSurfelsGpu / getMapSurfelCount / id textures,
+ * IF/map_interface/ElasticFusionInterface.h:55-120).  The store is struct-of-arrays; slots whose
+ * surfel was deleted stay in place as tombstones until ifx_compact (DESIGN.md "Tombstones"). */
+typedef struct ifx_soa_view {
+    int32_t count;          /* slots in use (including tombstones) */
+    int32_t capacity;
+    float* d_pos_conf;      /* [capacity] float4: x,y,z, confidence          (vPosition)   */
+    float* d_norm_rad;      /* [capacity] float4: nx,ny,nz, radius           (vNormRad)    */
+    float* d_color;         /* [capacity] float2: packed rgb, packed inst.   (vColor.xy)   */
+    float* d_times;         /* [capacity] float2: init time, last time       (vColor.zw)   */
+    float* d_img_corr;      /* [capacity] float4                             (vImgCorr)    */
+    float* d_votes;         /* [12][capacity] float4: vInstInfoA..L, planar                */
+} ifx_soa_view;
+int ifx_map_view(ifx_t* h, ifx_soa_view* out);
+int ifx_map_count(ifx_t* h);      /* live surfels (synchronises) */
+int ifx_map_slots(ifx_t* h);      /* slots incl. tombstones (synchronises) */
+/* Host copies of the live surfels in map order.  pc,nr,ic: float4 per surfel; col,tm: float2;
+ * votes: 48 floats per surfel.  Any pointer may be NULL.  Returns the number of surfels written. */
+int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float* col, float* tm, float* ic,
+                     float* votes);
+int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const float* col,
+                   const float* tm, const float* ic, const float* votes);
+int ifx_set_pose(ifx_t* h, const float* pose16, int tick);
+int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
+int ifx_set_option(ifx_t* h, const char* name, int value);
+
+/* R32I surfel-id image after fusion (getSurfelIdsAfterFusionGpu, ElasticFusionInterface.h:90-102):
+ * linear H*W int32 device buffer, 0 = empty. */
+const int32_t* ifx_ids_after(ifx_t* h);
+/* Host copy of an internal image (synchronises).  Names: "ids_after", "ids_tmp", "index",
+ * "index_vc", "index_ct", "index_nr", "pred_vertex", "pred_normal", "pred_image", "pred_inst",
+ * "pred_time", "fill_vertex", "fill_normal", "fill_image", "depth_filtered", "depth_metric",
+ * "depth_metric_filtered".  Returns bytes written or <0. */
+int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t max_bytes);
+
+/* ---- map stage API (unit-parity surface; each replaces one GL pass of the reference) */
+int ifx_predict_indices(ifx_t* h, const float* pose16, int time);                /* EF/IndexMap.cpp:221-279 */
+int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int max_time); /* EF/IndexMap.cpp:468-574 */
+int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting);          /* EF/GlobalModel.cpp:459-698 */
+int ifx_clean(ifx_t* h, const float* pose16, int time);                          /* EF/GlobalModel.cpp:700-925 */
+int ifx_render_ids(ifx_t* h, const float* pose16, int mode);                     /* EF/IndexMap.cpp:315-465; result in "ids_tmp" */
+int ifx_set_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth);          /* upload + preprocess only */
+
+/* ---- tracker stage API (replaces the blocking host launchers of EF/Cuda/cudafuncs.cuh:64-183).
+ * All pointers are device pointers; planar maps are [3][h][w]; results go to device memory. */
+int ifx_icp_step(ifx_t* h, const float* Rcurr9, const float* tcurr3, const float* d_vmap_curr,
+                 const float* d_nmap_curr, const float* Rprev_inv9, const float* tprev3, float fx,
+                 float fy, float cx, float cy, const float* d_vmap_g_prev, const float* d_nmap_g_prev,
+                 float dist_thres, float angle_thres, int w, int hgt, float* out29_host);
+int ifx_rgb_residual(ifx_t* h, float min_scale, const int16_t* d_didx, const int16_t* d_didy,
+                     const float* d_last_depth, const float* d_next_depth, const uint8_t* d_last_img,
+                     const uint8_t* d_next_img, void* d_corres8, float max_depth_delta,
+                     const float* kt3, const float* krkinv9, int w, int hgt, int* count_host,
+                     int* sigma_host);
+int ifx_rgb_step(ifx_t* h, const void* d_corres8, float sigma, const float* d_cloud3, float fx,
+                 float fy, const int16_t* d_didx, const int16_t* d_didy, float sobel_scale, int w,
+                 int hgt, float* out29_host);
+int ifx_so3_step(ifx_t* h, const uint8_t* d_last_img, const uint8_t* d_next_img,
+                 const float* image_basis9, const float* kinv9, const float* krlr9, int w, int hgt,
+                 float* out11_host);
+/* Whole tracker on explicit inputs (RGBDOdometry::initICPModel/initRGBModel/initICP/initRGB +
+ * getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:118-603).  Host inputs. */
+int ifx_track_pair(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba,
+                   const uint8_t* prev_rgb, const uint16_t* depth_filtered, const uint8_t* rgb,
+                   float* pose16_inout, float* diag8);
+/* Host copy of a tracker pyramid buffer; names as in the reference's members
+ * (EF/Utils/RGBDOdometry.h:80-121): "vmap_curr","nmap_curr","vmap_prev","nmap_prev","last_depth",
+ * "last_img","next_img","lastnext_img","didx","didy","cloud","corres","depth_tmp". */
+int ifx_tracker_buffer_download(ifx_t* h, const char* name, int level, void* out, int64_t max_bytes);
+
+/* ---- instance layer (replaces InstanceFusion::whetherDoSegmentation / ProcessSegmentation /
+ * processInstance, IF/Core/InstanceFusion.h:72-107, IF/Core/InstanceFusion.cpp:192-270,655-1067) */
+int ifx_should_segment(ifx_t* h, int frame);
+/* masks: n x H x W u8 (0/255), sorted by area descending (the contract of the Mask-RCNN bridge,
+ * build/mask_ori.py:117); class_ids: n COCO indices.  flags bit0: kNN smoothing (not implemented,
+ * rejected), bit1: superpixel refinement. */
+int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth,
+                             const uint8_t* masks, const int32_t* class_ids, int n, int frame,
+                             int flags);
+/* bestIDInEachSurfel (IF/Core/InstanceFusionCuda.cu:1158-1200) for the live surfels, map order. */
+int ifx_labels(ifx_t* h, int32_t* out, int max_n);
+/* class id per instance slot, -1 = unused (getInstanceTable, IF/Core/InstanceFusion.h:87) */
+int ifx_instance_table(ifx_t* h, int32_t* out96);
+/* getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121: int[96*5] = r,g,b,class,index */
+int ifx_loop_closure_instance_table(ifx_t* h, int32_t* out480);
+int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n);  /* IF/Core/InstanceFusionCuda.cu:118-141 (host in/out) */
+
+/* ---- measurement hooks */
+/* Per-stage GPU time of the frames processed since the last reset, from HIP events on the handle's
+ * stream: ms[0]=track, ms[1]=fuse (all map passes), ms[2]=instance, ms[3]=preprocess. */
+int ifx_stage_ms(ifx_t* h, float* ms4, int reset);
+/* Average duration (ms) of the named kernel over its launches since the last reset, measured with
+ * HIP events around each launch (enabled by ifx_set_option("kernel_timing",1)). */
+int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IFX_C_API_H_ */

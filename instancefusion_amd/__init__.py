@@ -1,0 +1,366 @@
+"""instancefusion_amd -- host-side Python mirror of the reference's interface over libifx.so.
+
+The product is the C-ABI shared library ``instancefusion_amd/libifx.so`` (HIP kernels for gfx950,
+declared in ``include/ifx_c_api.h``).  This package only binds it with ctypes and mirrors the
+reference's classes for the hot path:
+
+* :class:`ElasticFusion`  -- ``ElasticFusion::processFrame`` / ``ElasticFusionInterface``
+  (elasticfusionpublic/Core/src/ElasticFusion.h:75-82, src/map_interface/ElasticFusionInterface.h:55-130)
+* :class:`InstanceFusion` -- ``InstanceFusion::whetherDoSegmentation`` / ``ProcessSegmentation``
+  (src/Core/InstanceFusion.h:72-107) with the Mask-RCNN bridge replaced by replayed masks.
+
+There is no CPU fallback: importing works anywhere (so the symbols can be checked), but creating a
+handle without a MI355X raises :class:`IfxError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libifx.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ifx_c_api.h")
+
+NUM_INSTANCES = 96
+VOTE_FLOATS = 48
+
+
+class IfxError(RuntimeError):
+    pass
+
+
+class IfxConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("time_delta", C.c_int32), ("confidence", C.c_float), ("depth_cut", C.c_float),
+        ("max_depth_processed", C.c_float), ("icp_weight", C.c_float),
+        ("pyramid", C.c_int32), ("fast_odom", C.c_int32), ("so3", C.c_int32),
+        ("max_surfels", C.c_int32), ("device", C.c_int32), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+    ]
+
+
+class SoaView(C.Structure):
+    _fields_ = [("count", C.c_int32), ("capacity", C.c_int32), ("d_pos_conf", C.c_void_p), ("d_norm_rad", C.c_void_p),
+                ("d_color", C.c_void_p), ("d_times", C.c_void_p), ("d_img_corr", C.c_void_p), ("d_votes", C.c_void_p)]
+
+
+def default_config(w=640, h=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, max_surfels=1 << 20, **kw):
+    """The constants the reference runs with (src/map_interface/ElasticFusionInterface.cpp:43-45, src/main.cpp:46-47)."""
+    d = dict(width=w, height=h, fx=fx, fy=fy, cx=cx, cy=cy, time_delta=200, confidence=10.0, depth_cut=12.0,
+             max_depth_processed=20.0, icp_weight=10.0, pyramid=1, fast_odom=0, so3=1, max_surfels=max_surfels,
+             device=0, n_ranks=1, rank=0)
+    d.update(kw)
+    return d
+
+
+_lib = None
+
+_P = C.c_void_p
+_SIGS = {
+    "ifx_create": (C.c_int, [C.POINTER(IfxConfig), C.POINTER(_P)]),
+    "ifx_destroy": (None, [_P]),
+    "ifx_last_error": (C.c_char_p, [_P]),
+    "ifx_global_error": (C.c_char_p, []),
+    "ifx_process_frame": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, _P]),
+    "ifx_enqueue_frame_device": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float]),
+    "ifx_sync": (C.c_int, [_P]),
+    "ifx_get_pose": (C.c_int, [_P, _P]),
+    "ifx_tick": (C.c_int, [_P]),
+    "ifx_trajectory": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_tracker_diag": (C.c_int, [_P, _P]),
+    "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
+    "ifx_map_count": (C.c_int, [_P]),
+    "ifx_map_slots": (C.c_int, [_P]),
+    "ifx_map_download": (C.c_int, [_P, C.c_int] + [_P] * 6),
+    "ifx_map_upload": (C.c_int, [_P, C.c_int] + [_P] * 6),
+    "ifx_set_pose": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_compact": (C.c_int, [_P]),
+    "ifx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "ifx_ids_after": (_P, [_P]),
+    "ifx_image_download": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "ifx_predict_indices": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_combined_predict": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "ifx_fuse": (C.c_int, [_P, _P, C.c_int, C.c_float]),
+    "ifx_clean": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_render_ids": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_set_frame": (C.c_int, [_P, _P, _P]),
+    "ifx_icp_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, C.c_float, C.c_float, C.c_int, C.c_int, _P]),
+    "ifx_rgb_residual": (C.c_int, [_P, C.c_float, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "ifx_rgb_step": (C.c_int, [_P, _P, C.c_float, _P, C.c_float, C.c_float, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
+    "ifx_so3_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "ifx_track_pair": (C.c_int, [_P] * 9),
+    "ifx_tracker_buffer_download": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_int64]),
+    "ifx_should_segment": (C.c_int, [_P, C.c_int]),
+    "ifx_process_segmentation": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "ifx_labels": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_instance_table": (C.c_int, [_P, _P]),
+    "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
+    "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_stage_ms": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_kernel_ms": (C.c_int, [_P, C.c_char_p, _P, _P]),
+}
+
+
+def lib():
+    """Loads libifx.so (built by ``__graft_entry__.build()`` / ``make -C instancefusion_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IfxError(f"{LIB_PATH} is missing: build it with `make -C instancefusion_amd/csrc` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)  # raises AttributeError when a declared symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_IMG_SPECS = {
+    "ids_after": (np.int32, 1), "ids_tmp": (np.int32, 1), "index": (np.uint32, 1), "index_vc": (np.float32, 4),
+    "index_ct": (np.float32, 4), "index_nr": (np.float32, 4), "pred_vertex": (np.float32, 4),
+    "pred_normal": (np.float32, 4), "pred_image": (np.uint8, 4), "pred_inst": (np.uint8, 4), "pred_time": (np.uint16, 1),
+    "fill_vertex": (np.float32, 4), "fill_normal": (np.float32, 4), "fill_image": (np.uint8, 4),
+    "depth_filtered": (np.uint16, 1), "depth_metric": (np.float32, 1), "depth_metric_filtered": (np.float32, 1),
+}
+_TRK_SPECS = {
+    "vmap_curr": (np.float32, 3, True), "nmap_curr": (np.float32, 3, True), "vmap_prev": (np.float32, 3, True),
+    "nmap_prev": (np.float32, 3, True), "last_depth": (np.float32, 1, False), "next_depth": (np.float32, 1, False),
+    "last_img": (np.uint8, 1, False), "next_img": (np.uint8, 1, False), "lastnext_img": (np.uint8, 1, False),
+    "didx": (np.int16, 1, False), "didy": (np.int16, 1, False), "cloud": (np.float32, 3, False),
+    "depth_tmp": (np.uint16, 1, False),
+}
+CORRES_DTYPE = np.dtype([("zx", np.int16), ("zy", np.int16), ("diff", np.float32)])
+
+
+class ElasticFusion:
+    """Mirror of ``ElasticFusion`` / ``ElasticFusionInterface`` for the hot path."""
+
+    def __init__(self, **cfg):
+        self.cfgd = default_config(**cfg)
+        self.cfg = IfxConfig(**self.cfgd)
+        self.L = lib()
+        self.w, self.h = self.cfgd["width"], self.cfgd["height"]
+        hp = _P()
+        r = self.L.ifx_create(C.byref(self.cfg), C.byref(hp))
+        if r != 0:
+            raise IfxError(f"ifx_create failed ({r}): {self.L.ifx_global_error().decode()}")
+        self.handle = hp
+
+    # -- life cycle
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.ifx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise IfxError(f"{what} failed ({r}): {self.L.ifx_last_error(self.handle).decode()}")
+        return r
+
+    def set_option(self, name, value):
+        self._chk(self.L.ifx_set_option(self.handle, name.encode(), int(value)), "ifx_set_option")
+
+    # -- frame entry (ElasticFusion::processFrame)
+    def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        assert rgb.size == self.w * self.h * 3 and depth.size == self.w * self.h
+        out = np.zeros(16, np.float32)
+        ip = None if inPose is None else np.ascontiguousarray(inPose, np.float32).reshape(16)
+        self._chk(self.L.ifx_process_frame(self.handle, _ptr(rgb), _ptr(depth), int(timestamp), _ptr(ip), float(weightMultiplier), _ptr(out)),
+                  "ifx_process_frame")
+        return out.reshape(4, 4)
+
+    process_frame = processFrame
+
+    def enqueue_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int, timestamp=0):
+        self._chk(self.L.ifx_enqueue_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr), int(timestamp), None, 1.0),
+                  "ifx_enqueue_frame_device")
+
+    def sync(self):
+        self._chk(self.L.ifx_sync(self.handle), "ifx_sync")
+
+    def getCurrPose(self):
+        out = np.zeros(16, np.float32)
+        self._chk(self.L.ifx_get_pose(self.handle, _ptr(out)), "ifx_get_pose")
+        return out.reshape(4, 4)
+
+    @property
+    def tick(self):
+        return self.L.ifx_tick(self.handle)
+
+    def trajectory(self, max_frames=1 << 16):
+        out = np.zeros((max_frames, 16), np.float32)
+        n = self._chk(self.L.ifx_trajectory(self.handle, _ptr(out), max_frames), "ifx_trajectory")
+        return out[:n].reshape(n, 4, 4).copy()
+
+    def tracker_diag(self):
+        out = np.zeros(8, np.float32)
+        self._chk(self.L.ifx_tracker_diag(self.handle, _ptr(out)), "ifx_tracker_diag")
+        return out
+
+    # -- map access (getMapSurfelCount / getMapSurfelsGpu / id textures)
+    def getMapSurfelCount(self):
+        return self._chk(self.L.ifx_map_count(self.handle), "ifx_map_count")
+
+    count = property(getMapSurfelCount)
+
+    @property
+    def slots(self):
+        return self._chk(self.L.ifx_map_slots(self.handle), "ifx_map_slots")
+
+    def map_view(self):
+        v = SoaView()
+        self._chk(self.L.ifx_map_view(self.handle, C.byref(v)), "ifx_map_view")
+        return v
+
+    def download(self):
+        n = self.getMapSurfelCount()
+        d = dict(pc=np.zeros((n, 4), np.float32), nr=np.zeros((n, 4), np.float32), col=np.zeros((n, 2), np.float32),
+                 tm=np.zeros((n, 2), np.float32), ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32))
+        m = self._chk(self.L.ifx_map_download(self.handle, n, _ptr(d["pc"]), _ptr(d["nr"]), _ptr(d["col"]), _ptr(d["tm"]), _ptr(d["ic"]), _ptr(d["votes"])),
+                      "ifx_map_download")
+        assert m == n
+        return d
+
+    def upload(self, m):
+        n = m["pc"].shape[0]
+        a = {k: np.ascontiguousarray(m[k], np.float32) for k in ("pc", "nr", "col", "tm", "ic", "votes")}
+        self._chk(self.L.ifx_map_upload(self.handle, n, _ptr(a["pc"]), _ptr(a["nr"]), _ptr(a["col"]), _ptr(a["tm"]), _ptr(a["ic"]), _ptr(a["votes"])),
+                  "ifx_map_upload")
+
+    def set_pose(self, pose, tick):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.ifx_set_pose(self.handle, _ptr(p), int(tick)), "ifx_set_pose")
+
+    def compact(self):
+        self._chk(self.L.ifx_compact(self.handle), "ifx_compact")
+
+    def image(self, name):
+        dt, ch = _IMG_SPECS[name]
+        a = np.zeros((self.h, self.w, ch) if ch > 1 else (self.h, self.w), dt)
+        self._chk(self.L.ifx_image_download(self.handle, name.encode(), _ptr(a), a.nbytes), "ifx_image_download")
+        return a
+
+    def getSurfelIdsAfterFusion(self):
+        return self.image("ids_after")
+
+    # -- map stage API
+    def _pose(self, pose):
+        return np.ascontiguousarray(pose, np.float32).reshape(16)
+
+    def set_frame(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        self._chk(self.L.ifx_set_frame(self.handle, _ptr(rgb), _ptr(depth)), "ifx_set_frame")
+
+    def predict_indices(self, pose, time):
+        self._chk(self.L.ifx_predict_indices(self.handle, _ptr(self._pose(pose)), int(time)), "ifx_predict_indices")
+
+    def combined_predict(self, pose, time, max_time):
+        self._chk(self.L.ifx_combined_predict(self.handle, _ptr(self._pose(pose)), int(time), int(max_time)), "ifx_combined_predict")
+
+    def fuse(self, pose, time, weighting):
+        self._chk(self.L.ifx_fuse(self.handle, _ptr(self._pose(pose)), int(time), float(weighting)), "ifx_fuse")
+
+    def clean(self, pose, time):
+        self._chk(self.L.ifx_clean(self.handle, _ptr(self._pose(pose)), int(time)), "ifx_clean")
+
+    def render_ids(self, pose, mode=0):
+        self._chk(self.L.ifx_render_ids(self.handle, _ptr(self._pose(pose)), int(mode)), "ifx_render_ids")
+        return self.image("ids_tmp")
+
+    # -- tracker
+    def track_pair(self, model_v4, model_n4, model_rgba, prev_rgb, depth_filtered, rgb, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16).copy()
+        diag = np.zeros(8, np.float32)
+        args = [np.ascontiguousarray(model_v4, np.float32), np.ascontiguousarray(model_n4, np.float32), np.ascontiguousarray(model_rgba, np.uint8),
+                None if prev_rgb is None else np.ascontiguousarray(prev_rgb, np.uint8), np.ascontiguousarray(depth_filtered, np.uint16),
+                np.ascontiguousarray(rgb, np.uint8)]
+        self._chk(self.L.ifx_track_pair(self.handle, *[_ptr(a) for a in args], _ptr(p), _ptr(diag)), "ifx_track_pair")
+        return p.reshape(4, 4), diag
+
+    def tracker_buffer(self, name, level):
+        w, h = self.w >> level, self.h >> level
+        if name == "corres":
+            a = np.zeros((h, w), CORRES_DTYPE)
+        else:
+            dt, ch, planar = _TRK_SPECS[name]
+            a = np.zeros((ch, h, w) if planar else ((h, w, ch) if ch > 1 else (h, w)), dt)
+        self._chk(self.L.ifx_tracker_buffer_download(self.handle, name.encode(), level, _ptr(a), a.nbytes), "ifx_tracker_buffer_download")
+        return a
+
+    # -- measurement
+    def stage_ms(self, reset=False):
+        out = np.zeros(4, np.float32)
+        self._chk(self.L.ifx_stage_ms(self.handle, _ptr(out), int(reset)), "ifx_stage_ms")
+        return dict(track=float(out[0]), fuse=float(out[1]), instance=float(out[2]), preprocess=float(out[3]))
+
+    def kernel_ms(self, name):
+        avg = C.c_float(0)
+        n = C.c_int(0)
+        self._chk(self.L.ifx_kernel_ms(self.handle, name.encode(), C.byref(avg), C.byref(n)), "ifx_kernel_ms")
+        return float(avg.value), int(n.value)
+
+
+class InstanceFusion:
+    """Mirror of the ``InstanceFusion`` class for the hot path; masks come from the caller (replay)."""
+
+    def __init__(self, ef: ElasticFusion):
+        self.ef = ef
+        self.L = ef.L
+
+    def whetherDoSegmentation(self, frame):
+        return bool(self.ef._chk(self.L.ifx_should_segment(self.ef.handle, int(frame)), "ifx_should_segment"))
+
+    def ProcessSegmentation(self, rgb, depth, masks, class_ids, frame, isflann=False, superpixels=False):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        masks = np.ascontiguousarray(masks, np.uint8)
+        cls = np.ascontiguousarray(class_ids, np.int32)
+        flags = (1 if isflann else 0) | (2 if superpixels else 0)
+        self.ef._chk(self.L.ifx_process_segmentation(self.ef.handle, _ptr(rgb), _ptr(depth), _ptr(masks), _ptr(cls), int(masks.shape[0]), int(frame), flags),
+                     "ifx_process_segmentation")
+
+    def labels(self):
+        n = self.ef.getMapSurfelCount()
+        out = np.zeros(max(n, 1), np.int32)
+        m = self.ef._chk(self.L.ifx_labels(self.ef.handle, _ptr(out), n), "ifx_labels")
+        return out[:m]
+
+    def getInstanceTable(self):
+        out = np.zeros(96, np.int32)
+        self.ef._chk(self.L.ifx_instance_table(self.ef.handle, _ptr(out)), "ifx_instance_table")
+        return out
+
+    def getLoopClosureInstanceTable(self):
+        out = np.zeros(96 * 5, np.int32)
+        self.ef._chk(self.L.ifx_loop_closure_instance_table(self.ef.handle, _ptr(out)), "ifx_loop_closure_instance_table")
+        return out.reshape(96, 5)
+
+    def maskCleanOverlap(self, masks):
+        masks = np.ascontiguousarray(masks, np.uint8).copy()
+        self.ef._chk(self.L.ifx_mask_clean_overlap(self.ef.handle, _ptr(masks), int(masks.shape[0])), "ifx_mask_clean_overlap")
+        return masks

@@ -1,0 +1,456 @@
+// ifx_api.hip -- handle life cycle, frame orchestration and the data-movement half of the C-ABI.
+#include "ifx_ctx.h"
+#include <string.h>
+#include <stdio.h>
+#include <algorithm>
+
+int ifx_tracker_external_pose(ifx* h, const float* d_pose16, float weight_mult);
+int ifx_tracker_set_weight(ifx* h, float weight_mult);
+int ifx_compact_enqueue(ifx* h, int refresh_ids);
+
+static std::string g_err;
+extern "C" const char* ifx_global_error(void) { return g_err.c_str(); }
+extern "C" const char* ifx_last_error(ifx_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+// ------------------------------------------------------------------ kernel timing
+hipEvent_t ifx_event_get(ifx* h)
+{
+    if (!h->event_pool.empty()) { hipEvent_t e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a)
+{
+    (void)name;
+    *a = ifx_event_get(h);
+    hipEventRecord(*a, h->stream);
+}
+void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a)
+{
+    hipEvent_t b = ifx_event_get(h);
+    hipEventRecord(b, h->stream);
+    auto it = h->kname_id.find(name);
+    int id;
+    if (it == h->kname_id.end()) { id = (int)h->knames.size(); h->kname_id[name] = id; h->knames.push_back(name); h->ktimes.push_back(KernelTiming()); }
+    else id = it->second;
+    PendingEvent pe; pe.name_id = id; pe.a = a; pe.b = b;
+    h->kpending.push_back(pe);
+}
+static void ktime_flush(ifx* h)
+{
+    for (auto& pe : h->kpending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) { h->ktimes[pe.name_id].total_ms += ms; h->ktimes[pe.name_id].launches++; }
+        h->event_pool.push_back(pe.a);
+        h->event_pool.push_back(pe.b);
+    }
+    h->kpending.clear();
+}
+static void stage_flush(ifx* h)
+{
+    for (auto& sp : h->stage_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.second.first, sp.second.second) == hipSuccess) h->stage_ms[sp.first] += ms;
+        h->event_pool.push_back(sp.second.first);
+        h->event_pool.push_back(sp.second.second);
+    }
+    h->stage_pending.clear();
+}
+struct StageTimer {
+    ifx* h; int id; hipEvent_t a;
+    StageTimer(ifx* h_, int id_) : h(h_), id(id_) { a = ifx_event_get(h); hipEventRecord(a, h->stream); }
+    ~StageTimer() { hipEvent_t b = ifx_event_get(h); hipEventRecord(b, h->stream); h->stage_pending.push_back({id, {a, b}}); }
+};
+
+// ------------------------------------------------------------------ create / destroy
+#define ALLOC(ptr, bytes)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                        \
+        if (e_ != hipSuccess) { g_err = std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_); ifx_destroy(h); return IFX_E_HIP; } \
+    } while (0)
+
+extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
+{
+    if (!cfg || !out) { g_err = "null argument"; return IFX_E_INVALID; }
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % 4 || cfg->height % 4 || cfg->max_surfels <= 0) {
+        g_err = "width/height must be positive multiples of 4 (three pyramid levels) and max_surfels > 0";
+        return IFX_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device available: libifx.so has no CPU fallback"; return IFX_E_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_err = "device ordinal out of range"; return IFX_E_INVALID; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_err = "hipSetDevice failed"; return IFX_E_HIP; }
+    ifx* h = new ifx();
+    h->cfg = *cfg;
+    h->w = cfg->width; h->h = cfg->height; h->P = h->w * h->h; h->cap = cfg->max_surfels;
+    size_t P = (size_t)h->P, C = (size_t)h->cap;
+    if (hipStreamCreate(&h->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+    ALLOC(h->d_state, sizeof(DevState));
+    hipMemset(h->d_state, 0, sizeof(DevState));
+    if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
+    memset(h->h_result, 0, sizeof(FrameResult));
+    ALLOC(h->d_traj, (size_t)h->max_traj * 64);
+    ALLOC(h->pc, C * 16); ALLOC(h->nr, C * 16); ALLOC(h->col, C * 8); ALLOC(h->tm, C * 8); ALLOC(h->ic, C * 16); ALLOC(h->votes, C * 192);
+    ALLOC(h->pc2, C * 16); ALLOC(h->nr2, C * 16); ALLOC(h->col2, C * 8); ALLOC(h->tm2, C * 8); ALLOC(h->ic2, C * 16); ALLOC(h->votes2, C * 192);
+    ALLOC(h->upd_owner, C * 4);
+    hipMemset(h->upd_owner, 0xFF, C * 4);
+    ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
+    hipMemset(h->labels, 0xFF, C * 4);
+    size_t SN = std::max(C, P);
+    ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (SN / 2048 + 2) * 4);
+    ALLOC(h->rgb, P * 3); ALLOC(h->depth_raw, P * 2); ALLOC(h->depth_filt, P * 2); ALLOC(h->dm, P * 4); ALLOC(h->dmf, P * 4);
+    hipHostMalloc((void**)&h->rgb_stage, P * 3);
+    hipHostMalloc((void**)&h->depth_stage, P * 2);
+    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8);
+    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8); hipMemset(h->key_ids, 0xFF, P * 8);
+    ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16); ALLOC(h->index_ct, P * 16); ALLOC(h->index_nr, P * 16);
+    ALLOC(h->pred_vertex, P * 16); ALLOC(h->pred_normal, P * 16); ALLOC(h->pred_image, P * 4); ALLOC(h->pred_inst, P * 4); ALLOC(h->pred_time, P * 2);
+    ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
+    ALLOC(h->ids_after, P * 4); ALLOC(h->ids_tmp, P * 4);
+    hipMemset(h->ids_after, 0, P * 4); hipMemset(h->ids_tmp, 0, P * 4);
+    hipMemset(h->pred_vertex, 0, P * 16); hipMemset(h->pred_normal, 0, P * 16); hipMemset(h->pred_image, 0, P * 4);
+    hipMemset(h->index_id, 0, P * 4);
+    ALLOC(h->assoc_target, P * 4); ALLOC(h->meas_pc, P * 16); ALLOC(h->meas_nr, P * 16); ALLOC(h->meas_col, P * 4);
+    if (ifx_alloc_tracker(h) != IFX_OK) { g_err = h->err; ifx_destroy(h); return IFX_E_HIP; }
+    if (ifx_alloc_instance(h) != IFX_OK) { g_err = h->err; ifx_destroy(h); return IFX_E_HIP; }
+    // identity pose
+    DevState hs;
+    memset(&hs, 0, sizeof(hs));
+    for (int k = 0; k < 16; k++) hs.pose[k] = hs.pose_inv[k] = hs.last_pose[k] = (k % 5 == 0) ? 1.f : 0.f;
+    hs.weighting = 1.f;
+    hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice);
+    for (int k = 0; k < 16; k++) h->h_result->pose[k] = hs.pose[k];
+    if (hipDeviceSynchronize() != hipSuccess) { g_err = "device synchronize failed after allocation"; ifx_destroy(h); return IFX_E_HIP; }
+    *out = h;
+    return IFX_OK;
+}
+
+extern "C" void ifx_destroy(ifx_t* h)
+{
+    if (!h) return;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    ktime_flush(h);
+    stage_flush(h);
+    for (auto e : h->event_pool) hipEventDestroy(e);
+    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->labels,
+                    h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->rgb, h->depth_raw, h->depth_filt, h->dm, h->dmf, h->key_index, h->key_splat, h->key_ids,
+                    h->index_id, h->index_vc, h->index_ct, h->index_nr, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
+                    h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->h_result) hipHostFree(h->h_result);
+    if (h->rgb_stage) hipHostFree(h->rgb_stage);
+    if (h->depth_stage) hipHostFree(h->depth_stage);
+    ifx_free_tracker(h);
+    ifx_free_instance(h);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
+{
+    if (!h || !name) return IFX_E_INVALID;
+    std::string s(name);
+    if (s == "compact_every_frame") h->opt_compact_every_frame = value;
+    else if (s == "kernel_timing") { hipStreamSynchronize(h->stream); ktime_flush(h); h->opt_kernel_timing = value; }
+    else if (s == "reference_passes") h->opt_reference_passes = value;
+    else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
+    else { h->err = "unknown option " + s; return IFX_E_INVALID; }
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ frame orchestration
+__global__ void k_frame_result(const DevState* __restrict__ st, FrameResult* __restrict__ out, float* __restrict__ traj_slot)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
+    out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
+    out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
+    out->count = st->count; out->n_dead = st->n_dead; out->n_new = st->n_new; out->overflow = st->overflow;
+}
+
+// ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's stream.  Loop
+// closure (ferns, deformation graph, model-to-model tracking) is out of scope, and so
+// is the first predict() of :453 whose only consumers are those stages.
+static int enqueue_frame(ifx* h, const float* in_pose16, float weight_mult)
+{
+    {
+        StageTimer t(h, 3);
+        ifx_preprocess(h);
+    }
+    if (h->tick == 1) {
+        StageTimer t(h, 1);
+        ifx_map_init_first(h);
+        ifx_tracker_init_first(h);
+    } else {
+        {
+            StageTimer t(h, 0);
+            if (!in_pose16) {
+                ifx_tracker_run_frame(h);
+                if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
+            } else {
+                float* slot = h->d_traj + (size_t)(h->max_traj - 4) * 16;
+                HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
+                ifx_tracker_external_pose(h, slot, weight_mult);
+            }
+        }
+        StageTimer t(h, 1);
+        ifx_map_frame(h);
+    }
+    {
+        StageTimer t(h, 1);
+        ifx_map_predict(h);
+    }
+    int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
+    LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+    h->n_traj++;
+    h->tick++;
+    return IFX_OK;
+}
+
+extern "C" int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth, int64_t timestamp, const float* in_pose16, float weight_mult)
+{
+    (void)timestamp;
+    if (!h || !d_rgb || !d_depth) return IFX_E_INVALID;
+    HIPCHK(h, hipMemcpyAsync(h->rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->stream));
+    return enqueue_frame(h, in_pose16, weight_mult);
+}
+
+extern "C" int ifx_sync(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ktime_flush(h);
+    stage_flush(h);
+    if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
+    return IFX_OK;
+}
+
+extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const float* in_pose16, float weight_mult, float* out_pose16)
+{
+    (void)timestamp;
+    if (!h || !rgb || !depth) return IFX_E_INVALID;
+    // caller buffers are borrowed for the call only (EF/ElasticFusion.cpp:280-281 copies them too)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
+    memcpy(h->depth_stage, depth, (size_t)h->P * 2);
+    HIPCHK(h, hipMemcpyAsync(h->rgb, h->rgb_stage, (size_t)h->P * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->depth_raw, h->depth_stage, (size_t)h->P * 2, hipMemcpyHostToDevice, h->stream));
+    int r = enqueue_frame(h, in_pose16, weight_mult);
+    if (r) return r;
+    r = ifx_sync(h);
+    if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
+    if (r) return r;
+    // housekeeping the host decides from the frame result: compact when tombstones pile up
+    if (!h->opt_compact_every_frame && h->h_result->n_dead > 0 &&
+        (h->h_result->n_dead > h->h_result->count / 8 || h->h_result->count > h->cap - h->P)) {
+        ifx_compact_enqueue(h, 1);
+    }
+    return 0;
+}
+
+extern "C" int ifx_set_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth)
+{
+    if (!h || !rgb || !depth) return IFX_E_INVALID;
+    HIPCHK(h, hipMemcpyAsync(h->rgb, rgb, (size_t)h->P * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->depth_raw, depth, (size_t)h->P * 2, hipMemcpyHostToDevice, h->stream));
+    ifx_preprocess(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+extern "C" int ifx_get_pose(ifx_t* h, float* out)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    int r = ifx_sync(h);
+    DevState hs;
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    memcpy(out, hs.pose, 64);
+    return r;
+}
+extern "C" int ifx_tick(ifx_t* h) { return h ? h->tick : IFX_E_INVALID; }
+
+extern "C" int ifx_trajectory(ifx_t* h, float* out, int max_frames)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    int n = std::min(std::min(h->n_traj, max_frames), h->max_traj - 8);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d_traj, (size_t)n * 64, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int ifx_tracker_diag(ifx_t* h, float* diag8)
+{
+    if (!h || !diag8) return IFX_E_INVALID;
+    int r = ifx_sync(h);
+    memcpy(diag8, h->h_result->diag, 32);
+    return r;
+}
+
+extern "C" int ifx_stage_ms(ifx_t* h, float* ms4, int reset)
+{
+    if (!h || !ms4) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    stage_flush(h);
+    for (int k = 0; k < 4; k++) ms4[k] = (float)h->stage_ms[k];
+    if (reset) for (int k = 0; k < 4; k++) h->stage_ms[k] = 0;
+    return IFX_OK;
+}
+
+extern "C" int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* launches)
+{
+    if (!h || !kernel) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ktime_flush(h);
+    std::string s(kernel);
+    if (s == "__reset__") { for (auto& k : h->ktimes) k = KernelTiming(); return IFX_OK; }
+    if (s == "__list__") {   // debugging aid: prints the table to stderr
+        for (size_t i = 0; i < h->knames.size(); i++)
+            fprintf(stderr, "%-20s launches %6d  avg %.4f ms  total %.3f ms\n", h->knames[i].c_str(), h->ktimes[i].launches,
+                    h->ktimes[i].launches ? h->ktimes[i].total_ms / h->ktimes[i].launches : 0.0, h->ktimes[i].total_ms);
+        return IFX_OK;
+    }
+    auto it = h->kname_id.find(s);
+    if (it == h->kname_id.end()) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return IFX_OK; }
+    const KernelTiming& k = h->ktimes[it->second];
+    if (avg_ms) *avg_ms = k.launches ? (float)(k.total_ms / k.launches) : 0.f;
+    if (launches) *launches = k.launches;
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ map access
+extern "C" int ifx_map_view(ifx_t* h, ifx_soa_view* out)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    int r = ifx_sync(h);
+    DevState hs;
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    out->count = hs.count; out->capacity = h->cap;
+    out->d_pos_conf = h->pc; out->d_norm_rad = h->nr; out->d_color = h->col; out->d_times = h->tm; out->d_img_corr = h->ic; out->d_votes = h->votes;
+    return r;
+}
+static int read_state(ifx* h, DevState* hs)
+{
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(hs, h->d_state, sizeof(*hs), hipMemcpyDeviceToHost));
+    return IFX_OK;
+}
+extern "C" int ifx_map_slots(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    DevState hs;
+    int r = read_state(h, &hs);
+    return r ? r : hs.count;
+}
+extern "C" int ifx_map_count(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    DevState hs;
+    int r = read_state(h, &hs);
+    return r ? r : hs.count - hs.n_dead;
+}
+extern "C" int ifx_compact(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    ifx_compact_enqueue(h, 1);
+    return ifx_sync(h);
+}
+
+extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
+{
+    if (!h) return IFX_E_INVALID;
+    int r = ifx_compact(h);   // live surfels in map order
+    if (r) return r;
+    DevState hs;
+    r = read_state(h, &hs);
+    if (r) return r;
+    int n = std::min(hs.count, max_n);
+    if (pc) HIPCHK(h, hipMemcpy(pc, h->pc, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (nr) HIPCHK(h, hipMemcpy(nr, h->nr, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (col) HIPCHK(h, hipMemcpy(col, h->col, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (tm) HIPCHK(h, hipMemcpy(tm, h->tm, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (ic) HIPCHK(h, hipMemcpy(ic, h->ic, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (votes) {
+        std::vector<float> plane((size_t)n * 4);
+        for (int q = 0; q < 12; q++) {
+            HIPCHK(h, hipMemcpy(plane.data(), h->votes + ((size_t)q * h->cap) * 4, (size_t)n * 16, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < 4; k++) votes[(size_t)i * 48 + q * 4 + k] = plane[(size_t)i * 4 + k];
+        }
+    }
+    return n;
+}
+
+extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const float* col, const float* tm, const float* ic, const float* votes)
+{
+    if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
+    if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->pc, pc, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->nr, nr, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->col, col, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->tm, tm, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (ic) HIPCHK(h, hipMemcpy(h->ic, ic, (size_t)n * 16, hipMemcpyHostToDevice));
+    else HIPCHK(h, hipMemset(h->ic, 0, (size_t)n * 16));
+    std::vector<float> plane((size_t)n * 4, 0.f);
+    for (int q = 0; q < 12; q++) {
+        if (votes)
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < 4; k++) plane[(size_t)i * 4 + k] = votes[(size_t)i * 48 + q * 4 + k];
+        HIPCHK(h, hipMemcpy(h->votes + ((size_t)q * h->cap) * 4, plane.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    }
+    DevState hs;
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0;
+    HIPCHK(h, hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(h->upd_owner, 0xFF, (size_t)h->cap * 4));
+    HIPCHK(h, hipMemset(h->labels, 0xFF, (size_t)h->cap * 4));
+    return IFX_OK;
+}
+
+extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    DevState hs;
+    int r = read_state(h, &hs);
+    if (r) return r;
+    memcpy(hs.pose, pose16, 64);
+    memcpy(hs.last_pose, pose16, 64);
+    pose_inverse(hs.pose, hs.pose_inv);
+    HIPCHK(h, hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    h->tick = tick;
+    return IFX_OK;
+}
+
+extern "C" const int32_t* ifx_ids_after(ifx_t* h) { return h ? h->ids_after : nullptr; }
+
+extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t max_bytes)
+{
+    if (!h || !name || !out) return IFX_E_INVALID;
+    std::string s(name);
+    size_t P = (size_t)h->P, bytes = 0;
+    const void* src = nullptr;
+    if (s == "ids_after") { src = h->ids_after; bytes = P * 4; }
+    else if (s == "ids_tmp") { src = h->ids_tmp; bytes = P * 4; }
+    else if (s == "index") { src = h->index_id; bytes = P * 4; }
+    else if (s == "index_vc") { src = h->index_vc; bytes = P * 16; }
+    else if (s == "index_ct") { src = h->index_ct; bytes = P * 16; }
+    else if (s == "index_nr") { src = h->index_nr; bytes = P * 16; }
+    else if (s == "pred_vertex") { src = h->pred_vertex; bytes = P * 16; }
+    else if (s == "pred_normal") { src = h->pred_normal; bytes = P * 16; }
+    else if (s == "pred_image") { src = h->pred_image; bytes = P * 4; }
+    else if (s == "pred_inst") { src = h->pred_inst; bytes = P * 4; }
+    else if (s == "pred_time") { src = h->pred_time; bytes = P * 2; }
+    else if (s == "fill_vertex") { src = h->fill_vertex; bytes = P * 16; }
+    else if (s == "fill_normal") { src = h->fill_normal; bytes = P * 16; }
+    else if (s == "fill_image") { src = h->fill_image; bytes = P * 4; }
+    else if (s == "depth_filtered") { src = h->depth_filt; bytes = P * 2; }
+    else if (s == "depth_metric") { src = h->dm; bytes = P * 4; }
+    else if (s == "depth_metric_filtered") { src = h->dmf; bytes = P * 4; }
+    else { h->err = "unknown image " + s; return IFX_E_INVALID; }
+    if ((int64_t)bytes > max_bytes) { h->err = "buffer too small"; return IFX_E_INVALID; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return (int)bytes;
+}

@@ -1,0 +1,175 @@
+// ifx_ctx.h -- host-side context of libifx.so (one handle = one GPU, one stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/ifx_c_api.h"
+#include "ifx_dev.h"
+
+// ---- device-resident per-frame state: everything the kernels of one frame hand to each other
+// without a host round trip (the reference reads back 60-125 times per frame).
+struct DevState {
+    // poses (row-major 4x4, camera-to-world)
+    float pose[16];       // current pose (tracker output / fusion input)
+    float pose_inv[16];
+    float last_pose[16];
+    float weighting;      // velocity weighting, EF/ElasticFusion.cpp:433-449
+    int dense_enough;     // EF/ElasticFusion.cpp:252-267
+    // map bookkeeping
+    int count;            // slots in use (incl. tombstones)
+    int n_dead;           // tombstones
+    int n_new;            // new surfels appended by the last clean
+    int overflow;         // set when an append hit the capacity
+    // tracker state (RGBDOdometry::getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603)
+    float Rprev[9], tprev[3], Rprev_inv[9];
+    float Rcurr[9], tcurr[3];
+    double resultRt[16];
+    float krkinv[9], kt[3];
+    // so3 pre-alignment
+    double resultR[9], lastResultR[9];
+    float R_lr[9];
+    float so3_lastError, so3_lastCount;
+    int so3_done;
+    float imageBasis[9], kinv[9], krlr[9];
+    // diagnostics
+    float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+    double lastA[36], lastb[6];
+    float icp29[29], rgb29[29];
+    int rgb_count, rgb_sigma;
+    // instance
+    int seg_counts[2];
+};
+
+struct FrameResult {   // copied to pinned host memory at the end of every frame
+    float pose[16];
+    float diag[8];
+    int count, n_dead, n_new, overflow;
+};
+
+struct Pyr {
+    int w[IFX_NUM_PYRS], h[IFX_NUM_PYRS];
+    uint16_t* depth_tmp[IFX_NUM_PYRS];
+    float *vmap_curr[IFX_NUM_PYRS], *nmap_curr[IFX_NUM_PYRS];
+    float *vmap_cam[IFX_NUM_PYRS], *nmap_cam[IFX_NUM_PYRS];   // model maps in the camera frame (before the global transform)
+    float *vmap_prev[IFX_NUM_PYRS], *nmap_prev[IFX_NUM_PYRS];
+    float* last_depth[IFX_NUM_PYRS];                          // == next_depth (reference quirk)
+    uint8_t *last_img[IFX_NUM_PYRS], *next_img[IFX_NUM_PYRS], *lastnext_img[IFX_NUM_PYRS];
+    int16_t *didx[IFX_NUM_PYRS], *didy[IFX_NUM_PYRS];
+    float* cloud[IFX_NUM_PYRS];
+    void* corres[IFX_NUM_PYRS];                               // 8 B per pixel: short zx, zy; float diff
+};
+
+struct KernelTiming { double total_ms = 0; int launches = 0; };
+struct PendingEvent { int name_id; hipEvent_t a, b; };
+
+struct ifx {
+    ifx_config cfg;
+    int w, h, P, cap;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int tick = 1;
+    // options
+    int opt_compact_every_frame = 0;
+    int opt_kernel_timing = 0;
+    int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
+    int opt_icp_blocks = 256;
+    // device state
+    DevState* d_state = nullptr;
+    FrameResult* h_result = nullptr;   // pinned
+    float* d_traj = nullptr;           // [max_traj][16]
+    int max_traj = 1 << 16;
+    int n_traj = 0;
+    // map (SoA)
+    float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
+    float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
+    uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
+    int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot
+    int* scan_flags = nullptr;         // [max(cap,P)]
+    int* scan_block = nullptr;
+    int* scan_out = nullptr;
+    // frame buffers
+    uint8_t* rgb = nullptr;
+    uint16_t *depth_raw = nullptr, *depth_filt = nullptr;
+    float *dm = nullptr, *dmf = nullptr;
+    uint8_t* rgb_stage = nullptr; uint16_t* depth_stage = nullptr; // pinned staging
+    // index map
+    unsigned long long *key_index = nullptr, *key_splat = nullptr, *key_ids = nullptr;
+    uint32_t* index_id = nullptr;
+    float *index_vc = nullptr, *index_ct = nullptr, *index_nr = nullptr;
+    // predictions
+    float *pred_vertex = nullptr, *pred_normal = nullptr;
+    uint8_t *pred_image = nullptr, *pred_inst = nullptr;
+    uint16_t* pred_time = nullptr;
+    float *fill_vertex = nullptr, *fill_normal = nullptr;
+    uint8_t* fill_image = nullptr;
+    int32_t *ids_after = nullptr, *ids_tmp = nullptr;
+    // association scratch (per pixel)
+    uint32_t* assoc_target = nullptr;  // 0xFFFFFFFF none, 0xFFFFFFFE new, else surfel id
+    float *meas_pc = nullptr, *meas_nr = nullptr, *meas_col = nullptr;
+    // tracker
+    Pyr pyr;
+    float* icp_partials = nullptr;  // [blocks][32]
+    float* rgb_partials = nullptr;
+    int* res_partials = nullptr;    // [blocks][2]
+    float* so3_partials = nullptr;  // [blocks][12]
+    float* d_out29 = nullptr;
+    // instance layer
+    int32_t inst_class[IFX_NUM_INSTANCES];
+    float inst_color[IFX_NUM_INSTANCES];
+    float* d_inst_color = nullptr;
+    uint8_t* d_masks = nullptr; size_t masks_cap = 0;
+    uint16_t* d_pdm = nullptr;
+    int* d_bbox = nullptr;             // [96*4 + maxmasks*4]
+    int* d_inst_stats = nullptr;       // [96*2]
+    int* d_clean_list = nullptr;
+    int last_seg_frame = -1;
+    int clean_times = 0;
+    // timing
+    hipEvent_t ev_stage[8];
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> stage_pending;
+    double stage_ms[4] = {0, 0, 0, 0};
+    std::map<std::string, int> kname_id;
+    std::vector<std::string> knames;
+    std::vector<KernelTiming> ktimes;
+    std::vector<PendingEvent> kpending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return IFX_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+// kernel launch with optional per-kernel event timing
+hipEvent_t ifx_event_get(ifx* h);
+void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a);
+void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
+
+#define LAUNCH(h, name, grid, block, kernel, ...)                                                  \
+    do {                                                                                           \
+        hipEvent_t ea_ = nullptr;                                                                  \
+        if ((h)->opt_kernel_timing) ifx_ktime_begin((h), name, &ea_);                              \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);                      \
+        if ((h)->opt_kernel_timing) ifx_ktime_end((h), name, ea_);                                 \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// stage entry points implemented across the .hip files
+int ifx_preprocess(ifx* h);                                   // bilateral + metric
+int ifx_tracker_init_first(ifx* h);
+int ifx_tracker_run_frame(ifx* h);                            // init model + init frame + GN loops (all on device)
+int ifx_map_init_first(ifx* h);
+int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
+int ifx_map_predict(ifx* h);                                  // splat + fill-in + dense flag
+int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total /*device ptr or null*/);
+int ifx_alloc_tracker(ifx* h);
+void ifx_free_tracker(ifx* h);
+int ifx_alloc_instance(ifx* h);
+void ifx_free_instance(ifx* h);

@@ -1,0 +1,156 @@
+// ifx_dev.h -- device-side helpers shared by the HIP kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define IFX_WAVE 64
+#define IFX_NUM_PYRS 3
+#define IFX_NI 96
+#define IFX_VF 48
+#define IFX_MAX_SPRITE 512.0f
+
+struct v3 { float x, y, z; };
+__host__ __device__ inline v3 v3m(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ inline v3 operator-(v3 a, v3 b) { return v3m(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ inline v3 operator+(v3 a, v3 b) { return v3m(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ inline v3 operator*(v3 a, float s) { return v3m(a.x * s, a.y * s, a.z * s); }
+__host__ __device__ inline v3 cross(v3 a, v3 b) { return v3m(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__host__ __device__ inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline float norm(v3 a) { return sqrtf(dot(a, a)); }
+__device__ inline v3 normalized(v3 a) { float rn = 1.0f / sqrtf(dot(a, a)); return v3m(a.x * rn, a.y * rn, a.z * rn); }
+
+// 3x3 row-major matrix passed by value in kernel arguments
+struct m33 { float m[9]; };
+__host__ __device__ inline v3 mul(const m33& M, v3 a)
+{
+    return v3m(M.m[0] * a.x + M.m[1] * a.y + M.m[2] * a.z, M.m[3] * a.x + M.m[4] * a.y + M.m[5] * a.z, M.m[6] * a.x + M.m[7] * a.y + M.m[8] * a.z);
+}
+__host__ __device__ inline v3 mulp(const float* M, v3 a)
+{
+    return v3m(M[0] * a.x + M[1] * a.y + M[2] * a.z, M[3] * a.x + M[4] * a.y + M[5] * a.z, M[6] * a.x + M[7] * a.y + M[8] * a.z);
+}
+// 4x4 row-major rigid transform applied to a point / direction
+__host__ __device__ inline v3 xf_point(const float* m, v3 p)
+{
+    return v3m(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+__host__ __device__ inline v3 xf_dir(const float* m, v3 p)
+{
+    return v3m(m[0] * p.x + m[1] * p.y + m[2] * p.z, m[4] * p.x + m[5] * p.y + m[6] * p.z, m[8] * p.x + m[9] * p.y + m[10] * p.z);
+}
+__host__ __device__ inline void pose_inverse(const float* p, float* o)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o[i * 4 + j] = p[j * 4 + i];
+    for (int i = 0; i < 3; i++) o[i * 4 + 3] = -(o[i * 4] * p[3] + o[i * 4 + 1] * p[7] + o[i * 4 + 2] * p[11]);
+    o[12] = o[13] = o[14] = 0.f;
+    o[15] = 1.f;
+}
+
+__device__ inline float qnan_f() { return __int_as_float(0x7fffffff); }
+
+// __float2int_rn / truncation with the CUDA semantics the reference relies on (NaN -> 0, saturating)
+__device__ inline int f2i_rn(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)rintf(v);
+}
+__device__ inline int f2i_rz(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+__host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+
+// Deterministic expf for x <= 0 (Cody-Waite reduction + degree-7 Taylor/Horner, no FMA
+// contraction).  The same code is used by the CPU oracle (oracle/orc_math.h) and the HIP kernels
+// so that the stages that call exp (bilateral weights, surfel confidence) agree bit for bit; it
+// differs from libm's / GLSL's exp by at most 2 ulp.
+__host__ __device__ inline float ifx_expf(float x)
+{
+    if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 0.0f) x = 0.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.0f / 5040.0f;
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int e = (int)n + 127;
+    union { unsigned int u; float f; } s;
+    s.u = (unsigned int)e << 23;
+    return p * s.f;
+}
+
+// color.glsl:19-34
+__device__ inline float encode_color(float r, float g, float b)
+{
+    int rgb = (int)roundf(r * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(g * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(b * 255.0f);
+    return (float)rgb;
+}
+__device__ inline void decode_color(float c, float* o)
+{
+    int ic = f2i_rz(c);
+    o[0] = (float)(ic >> 16 & 0xFF) / 255.0f;
+    o[1] = (float)(ic >> 8 & 0xFF) / 255.0f;
+    o[2] = (float)(ic & 0xFF) / 255.0f;
+}
+
+// vote counter packing, IF/Core/InstanceFusionCuda.cu:22-39 (short arguments, RNE int->float, trunc back)
+__device__ inline float vote_encode(int a, int b)
+{
+    short sa = (short)a, sb = (short)b;
+    int info = (int)((unsigned)(int)sa << 16) + (int)sb;
+    return (float)info;
+}
+__device__ inline void vote_decode(float f, int& a, int& b)
+{
+    int v = f2i_rz(f);
+    a = (short)((v >> 16) & 0xFFFF);
+    b = (short)(v & 0xFFFF);
+}
+
+// ---- wave64 / block reductions ------------------------------------------------------------
+__device__ inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ inline double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ inline int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// order-preserving map float -> uint for atomicMin depth keys (depths are >= 0 here but be general)
+__device__ inline unsigned int depth_bits(float z)
+{
+    unsigned int u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline unsigned long long make_key(float z, unsigned int id)
+{
+    return ((unsigned long long)depth_bits(z) << 32) | (unsigned long long)id;
+}
+#define IFX_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull

@@ -1,0 +1,525 @@
+// ifx_instance.hip -- instance layer of the path for gfx950.
+//
+// Host flow mirrors InstanceFusion::processInstance (IF/Core/InstanceFusion.cpp:655-1067) with the
+// Mask-RCNN call replaced by the caller's pre-computed masks.  Device work: mask clean-up, per-pixel
+// vote gathering + bounding boxes (fused; the reference materialises a 119 MB [97][H][W] int image
+// first), model depth image, the vote update and the per-surfel arg-max scan over the planar vote
+// store (12 fully coalesced 16-B loads per lane).  The two CPU passes of the reference (box IoU
+// matching, depth flood fill) stay on the host, as in the reference.
+#include "ifx_ctx.h"
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+#define DEAD_TIME (-1.0e9f)
+#define NI IFX_NUM_INSTANCES
+
+int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, std::vector<uint8_t>& masks, int nm, int frame);
+
+// maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131
+__global__ void k_mask_clean_overlap(uint8_t* __restrict__ masks, int nm, int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    int flag = 0;
+    for (int m = nm - 1; m >= 0; m--) {
+        size_t a = (size_t)m * P + p;
+        uint8_t v = masks[a];
+        if (flag && v) masks[a] = 0;
+        if (!flag && v) flag = 1;
+    }
+}
+
+// checkProjectDepthAndInstanceKernel, IF/Core/InstanceFusionCuda.cu:736-760
+__global__ void k_check_project(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, int w, int h, int downsample,
+                                int* __restrict__ counts)
+{
+    int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y * blockDim.y + threadIdx.y;
+    int x = gx * downsample, y = gy * downsample;
+    if (x >= w || y >= h) return;
+    int id = ids[y * w + x];
+    if (id > 0 && id < st->count) {
+        int s = 0;
+        for (int q = 0; q < 12; q++) {
+            float4 v = votes[(size_t)q * cap + id];
+            int a, b;
+            vote_decode(v.x, a, b); s += a + b;
+            vote_decode(v.y, a, b); s += a + b;
+            vote_decode(v.z, a, b); s += a + b;
+            vote_decode(v.w, a, b); s += a + b;
+        }
+        atomicAdd(&counts[0], s);
+    } else atomicAdd(&counts[1], 1);
+}
+
+// getProjectInstanceListKernel + computeProjectBoundingBoxKernel fused,
+// IF/Core/InstanceFusionCuda.cu:781-807, 909-952.  bbox layout: [96][4] project boxes then [nm][4] mask boxes.
+__global__ void k_init_bbox(int* __restrict__ bbox, int n, int w, int h)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 4) return;
+    int t = i & 3;
+    bbox[i] = t == 0 ? w + 1 : t == 1 ? -1 : t == 2 ? h + 1 : -1;
+}
+__global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
+                               int nm, int w, int h, int* __restrict__ bbox)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    int P = w * h, k = y * w + x;
+    int id = ids[k];
+    if (!(id > 0 && id < st->count)) return;
+    int maxNum = 0, maxID = -1, first = 0;
+    for (int q = 0; q < 12; q++) {
+        float4 v = votes[(size_t)q * cap + id];
+        float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int a, b;
+            vote_decode(f[t], a, b);
+            if (q == 0 && t == 0) first = a;
+            if (a > maxNum) { maxNum = a; maxID = (q * 4 + t) * 2; }
+            if (b > maxNum) { maxNum = b; maxID = (q * 4 + t) * 2 + 1; }
+        }
+    }
+    if (first == -1) return;   // instanceProjectMap[y*width+x] != -1 test (:915)
+    if (maxID != -1) {
+        int* b = &bbox[maxID * 4];
+        atomicMin(&b[0], x); atomicMax(&b[1], x); atomicMin(&b[2], y); atomicMax(&b[3], y);
+    }
+    for (int m = 0; m < nm; m++)
+        if (masks[(size_t)m * P + k] > 0) {
+            int* b = &bbox[(NI + m) * 4];
+            atomicMin(&b[0], x); atomicMax(&b[1], x); atomicMin(&b[2], y); atomicMax(&b[3], y);
+        }
+}
+
+// getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996
+__global__ void k_project_depth(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ pc, int P, int ratio, uint16_t* __restrict__ pdm)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    int id = ids[k];
+    uint16_t o = 0;
+    if (id > 0 && id < st->count) {
+        float4 p = pc[id];
+        float dx = st->pose[3] - p.x, dy = st->pose[7] - p.y, dz = st->pose[11] - p.z;
+        o = (uint16_t)(sqrtf(dx * dx + dy * dy + dz * dz) * ratio);
+    }
+    pdm[k] = o;
+}
+
+// updateSurfelMapInstanceKernel, IF/Core/InstanceFusionCuda.cu:1100-1139 (deleteNum = -1).  Like the
+// reference this is a non-atomic read-modify-write: several pixels of one mask can see the same surfel;
+// an atomicCAS loop makes the result independent of scheduling (every pixel's increment lands), which
+// is also what the sequential oracle computes.
+__global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ mask, int P, int cap, int instanceID, int inc,
+                              float* __restrict__ votes)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    if (!(mask[k] > 0)) return;
+    int id = ids[k];
+    if (!(id > 0 && id < st->count)) return;
+    int fi = instanceID / 2, p = instanceID % 2;
+    // planar float4 store: float fi of surfel id lives in plane fi/4, component fi%4
+    unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
+    unsigned int old = *addr, assumed;
+    do {
+        assumed = old;
+        int a, b;
+        vote_decode(__uint_as_float(assumed), a, b);
+        if (p == 0) a += inc; else b += inc;
+        if (a >= 65535) a = 65535;
+        if (b >= 65535) b = 65535;
+        old = atomicCAS(addr, assumed, __float_as_uint(vote_encode(a, b)));
+    } while (old != assumed);
+}
+
+// countAndColourSurfelMapKernel, IF/Core/InstanceFusionCuda.cu:1158-1200: the label scan.  Per surfel
+// 192 B of votes read as 12 coalesced float4 plane loads + 8 B colour RMW + 4 B label.
+__global__ __launch_bounds__(256) void k_count_colour(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
+                                                      float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels)
+{
+    const float defaultColor = 7434609;
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float4 v[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + i];
+        int best = -1, bestCount = 0;
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            float f[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int a, b;
+                vote_decode(f[t], a, b);
+                if (bestCount < a) { bestCount = a; best = (q * 4 + t) * 2; }
+                if (bestCount < b) { bestCount = b; best = (q * 4 + t) * 2 + 1; }
+            }
+        }
+        if (tm[i].y <= DEAD_TIME) { labels[i] = -1; continue; }
+        labels[i] = best;
+        float2 c = col[i];
+        if (c.y == 0 || c.y == defaultColor) {
+            c.y = (best != -1) ? inst_color[best] : defaultColor;
+            col[i] = c;
+        }
+    }
+}
+
+// computeMaxCountInMapKernel, IF/Core/InstanceFusionCuda.cu:1012-1036 (per-wave pre-reduction instead
+// of 192 global atomics per surfel)
+__global__ __launch_bounds__(256) void k_max_count(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
+                                                   int* __restrict__ maxv, int* __restrict__ sumv)
+{
+    __shared__ int smax[NI], ssum[NI];
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) { smax[t] = 0; ssum[t] = 0; }
+    __syncthreads();
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        if (tm[i].y <= DEAD_TIME) continue;
+        for (int q = 0; q < 12; q++) {
+            float4 v = votes[(size_t)q * cap + i];
+            float f[4] = {v.x, v.y, v.z, v.w};
+            for (int t = 0; t < 4; t++) {
+                int a, b, k = (q * 4 + t) * 2;
+                vote_decode(f[t], a, b);
+                if (a > 0) atomicMax(&smax[k], a);
+                if (b > 0) atomicMax(&smax[k + 1], b);
+                if (a) atomicAdd(&ssum[k], a);
+                if (b) atomicAdd(&ssum[k + 1], b);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) {
+        if (smax[t]) atomicMax(&maxv[t], smax[t]);
+        if (ssum[t]) atomicAdd(&sumv[t], ssum[t]);
+    }
+}
+
+// cleanInstanceTableMapKernel, IF/Core/InstanceFusionCuda.cu:1057-1084
+__global__ void k_clean_table(const DevState* __restrict__ st, float* __restrict__ votes, int cap, const int* __restrict__ clean_list)
+{
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x)
+        for (int fi = 0; fi < IFX_VF; fi++) {
+            int c1 = clean_list[2 * fi], c2 = clean_list[2 * fi + 1];
+            if (!c1 && !c2) continue;
+            float* f = &votes[((size_t)(fi >> 2) * cap + i) * 4 + (fi & 3)];
+            int a, b;
+            vote_decode(*f, a, b);
+            if (c1) a = 0;
+            if (c2) b = 0;
+            *f = vote_encode(a, b);
+        }
+}
+
+// ------------------------------------------------------------------ host side
+int ifx_alloc_instance(ifx* h)
+{
+    uint32_t s = 0x1F5u;
+    for (int i = 0; i < NI; i++) {
+        h->inst_class[i] = -1;
+        // createInstanceTable (IF/Core/InstanceTable.cpp:11-35) draws colours from unseeded rand();
+        // a fixed LCG is used instead -- the colours are arbitrary in the reference too.
+        int c[3];
+        for (int k = 0; k < 3; k++) { s = s * 1664525u + 1013904223u; c[k] = (int)((s >> 8) % 255u); }
+        h->inst_color[i] = (float)((c[0] << 16) + (c[1] << 8) + c[2]);
+    }
+    HIPCHK(h, hipMalloc(&h->d_inst_color, NI * 4));
+    HIPCHK(h, hipMemcpy(h->d_inst_color, h->inst_color, NI * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_pdm, (size_t)h->P * 2));
+    HIPCHK(h, hipMalloc(&h->d_bbox, (NI + 256) * 16));
+    HIPCHK(h, hipMalloc(&h->d_inst_stats, NI * 2 * 4));
+    HIPCHK(h, hipMalloc(&h->d_clean_list, NI * 4));
+    return IFX_OK;
+}
+void ifx_free_instance(ifx* h)
+{
+    hipFree(h->d_inst_color); hipFree(h->d_masks); hipFree(h->d_pdm); hipFree(h->d_bbox); hipFree(h->d_inst_stats); hipFree(h->d_clean_list);
+}
+
+static int ensure_masks(ifx* h, size_t bytes)
+{
+    if (bytes <= h->masks_cap) return IFX_OK;
+    if (h->d_masks) hipFree(h->d_masks);
+    h->d_masks = nullptr; h->masks_cap = 0;
+    HIPCHK(h, hipMalloc(&h->d_masks, bytes));
+    h->masks_cap = bytes;
+    return IFX_OK;
+}
+
+extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
+{
+    if (!h || !masks || n < 0) return IFX_E_INVALID;
+    if (n == 0) return IFX_OK;
+    size_t bytes = (size_t)n * h->P;
+    int r = ensure_masks(h, bytes);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(h->P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, n, h->P);
+    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+// whetherDoSegmentation, IF/Core/InstanceFusion.cpp:192-238
+extern "C" int ifx_should_segment(ifx_t* h, int frame)
+{
+    if (!h) return IFX_E_INVALID;
+    const int downsample = 10, fixedL = 2, fixedH = 45;
+    int* cnt = h->d_inst_stats;
+    HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
+    int gw = cdiv(h->w, downsample), gh = cdiv(h->h, downsample);
+    LAUNCH(h, "check_project", dim3(cdiv(gw, 16), cdiv(gh, 16)), dim3(16, 16), k_check_project, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->w, h->h, downsample, cnt);
+    int count[2];
+    HIPCHK(h, hipMemcpyAsync(count, cnt, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int w = h->w, hh = h->h;
+    bool test1 = count[0] > (w / downsample * hh / downsample * 0.48 * 30);
+    bool test2 = count[1] < (w / downsample * hh / downsample * 0.2);
+    if (test1 || test2) {
+        if (frame - h->last_seg_frame > fixedH) { h->last_seg_frame = frame; return 1; }
+        return 0;
+    }
+    if (frame - h->last_seg_frame > fixedL) { h->last_seg_frame = frame; return 1; }
+    return 0;
+}
+
+// getDepthThreshold, IF/Core/InstanceFusion.h:170-176
+static float depth_threshold(int depth)
+{
+    float t = 0.074f * depth - 246.0f;
+    t = std::max(50.0f, t);
+    t = std::min(420.0f, t);
+    return t;
+}
+
+// filterAreaCompute + maskGeometricFilter, IF/Core/InstanceFusion.cpp:470-593 (host, as in the reference)
+static void mask_geometric_filter(int w, int h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int nm, std::vector<uint8_t>& unavailable)
+{
+    int P = w * h;
+    std::vector<int> filterMap(P), queue((size_t)P * 4 + 16);
+    static const int StepX[4] = {0, 0, 1, -1}, StepY[4] = {1, -1, 0, 0};
+    for (int i = 0; i < nm; i++) {
+        if (unavailable[i]) continue;
+        uint8_t* mask = masks + (size_t)i * P;
+        const uint8_t* om = ori + (size_t)i * P;
+        std::fill(filterMap.begin(), filterMap.end(), 0);
+        float oriPoints = 0;
+        for (int y = 1; y < h - 1; y++)
+            for (int x = 1; x < w - 1; x++) {
+                if (om[y * w + x]) oriPoints++;
+                if (mask[y * w + x] && depth[y * w + x]) filterMap[y * w + x] = 1;
+            }
+        int areaFlag = 2, list[20], p = 0;
+        for (int y = 1; y < h - 1; y++)
+            for (int x = 1; x < w - 1; x++) {
+                if (filterMap[y * w + x] != 1) continue;
+                float points = 0;
+                int front = 0, tail = 0;
+                queue[front++] = y * w + x;
+                while (front > tail) {
+                    int now = queue[tail++];
+                    int nx = now % w, ny = now / w;
+                    if (filterMap[ny * w + nx] != 1) continue;
+                    points++;
+                    filterMap[ny * w + nx] = areaFlag;
+                    for (int k = 0; k < 4; k++) {
+                        int dx = nx + StepX[k], dy = ny + StepY[k];
+                        float thr = depth_threshold(depth[ny * w + nx]);
+                        if (filterMap[dy * w + dx] == 1 && (float)std::abs((int)depth[ny * w + nx] - (int)depth[dy * w + dx]) < thr) queue[front++] = dy * w + dx;
+                    }
+                }
+                if (points / oriPoints > 0.25f) { if (p < 20) list[p++] = areaFlag; }
+                areaFlag++;
+            }
+        float finalPoints = 0;
+        for (int k = 0; k < P; k++) {
+            int flag = 0;
+            for (int j = 0; j < p; j++) if (filterMap[k] == list[j]) { flag = 1; break; }
+            if (flag) { mask[k] = 255; finalPoints++; } else mask[k] = 0;
+        }
+        if (finalPoints / oriPoints < 0.65f) unavailable[i] = 1;
+    }
+}
+
+// computeCompareMap, IF/Core/InstanceFusion.cpp:595-651
+static void compare_map(ifx* h, const int* maskBBox, const int* projBBox, const int32_t* class_ids, int nm, std::vector<uint8_t>& unavailable, std::vector<int>& cmp)
+{
+    for (int m = 0; m < nm; m++) {
+        int minX_m = maskBBox[m * 4], maxX_m = maskBBox[m * 4 + 1], minY_m = maskBBox[m * 4 + 2], maxY_m = maskBBox[m * 4 + 3];
+        if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) { unavailable[m] = 1; continue; }
+        int best = -1;
+        for (int q = 0; q < NI; q++) {
+            if (h->inst_class[q] == -1 || class_ids[m] != h->inst_class[q]) continue;
+            int minX_i = projBBox[q * 4], maxX_i = projBBox[q * 4 + 1], minY_i = projBBox[q * 4 + 2], maxY_i = projBBox[q * 4 + 3];
+            if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
+            float IW = (float)(std::min(maxX_i, maxX_m) - std::max(minX_i, minX_m));
+            float IH = (float)(std::min(maxY_i, maxY_m) - std::max(minY_i, minY_m));
+            if (IW <= 0 || IH <= 0) continue;
+            float I = IW * IH;
+            float U = (float)(((maxX_i - minX_i) * (maxY_i - minY_i)) + ((maxX_m - minX_m) * (maxY_m - minY_m))) - I;
+            if (I / U > 0.5f) best = q;   // last match wins (:641-645)
+        }
+        if (best > 0) cmp[best + m * NI] = 1;   // instance 0 can never match (:649)
+    }
+}
+
+static int first_not_used(ifx* h)
+{
+    for (int i = 0; i < NI; i++) if (h->inst_class[i] == -1) return i;
+    return -1;
+}
+
+static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
+{
+    LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+           h->d_bbox);
+    bbox.resize((size_t)(NI + nm) * 4);
+    HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+{
+    if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
+    if (flags & 1) { h->err = "kNN label smoothing (flann step) is not implemented"; return IFX_E_INVALID; }
+    if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
+    hipEvent_t ea = ifx_event_get(h);
+    hipEventRecord(ea, h->stream);
+    DevState hs;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    int n = hs.count;
+    if (nm == 0 || n == 0) { h->event_pool.push_back(ea); return IFX_OK; }
+    const int P = h->P;
+    size_t mbytes = (size_t)nm * P;
+    std::vector<uint8_t> masks(masks_in, masks_in + mbytes), ori(masks_in, masks_in + mbytes), unavailable(nm, 0);
+    int r = ensure_masks(h, mbytes);
+    if (r) return r;
+    // step 0_1
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
+    HIPCHK(h, hipMemcpyAsync(masks.data(), h->d_masks, mbytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // steps -1_1 .. -1_3 (superpixel refinement)
+    if (flags & 2) {
+        r = ifx_superpixel_refine(h, rgb, depth, masks, nm, frame);
+        if (r) return r;
+        HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
+    }
+    // steps 1, 2
+    std::vector<int> bbox;
+    r = run_bboxes(h, nm, bbox);
+    if (r) return r;
+    std::vector<int> cmp((size_t)nm * NI, 0);
+    compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
+    // step 3_0
+    std::vector<uint16_t> pdm(P);
+    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm);
+    HIPCHK(h, hipMemcpyAsync(pdm.data(), h->d_pdm, (size_t)P * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    mask_geometric_filter(h->w, h->h, pdm.data(), masks.data(), ori.data(), nm, unavailable);
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
+    // step 3
+    for (int m = 0; m < nm; m++) {
+        bool exist = false;
+        for (int q = 0; q < NI; q++) if (cmp[q + m * NI] == 1) { exist = true; break; }
+        if (!exist && !unavailable[m]) {
+            int empty = first_not_used(h);
+            if (empty == -1) {
+                h->clean_times++;
+                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->stream));
+                LAUNCH(h, "max_count", dim3(1024), dim3(256), k_max_count, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, h->d_inst_stats, h->d_inst_stats + NI);
+                int stats[NI * 2];
+                HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                // getInstanceTableCleanList, IF/Core/InstanceTable.cpp:185-224
+                int* maxv = stats; int* sumv = stats + NI;
+                int order[NI], cl[NI];
+                for (int i = 0; i < NI; i++) order[i] = i;
+                for (int i = 0; i < NI; i++)
+                    for (int j = i + 1; j < NI; j++)
+                        if ((float)sumv[j] < (float)sumv[i]) { std::swap(maxv[i], maxv[j]); std::swap(order[i], order[j]); std::swap(sumv[i], sumv[j]); }
+                for (int i = 0; i < NI; i++) cl[i] = 0;
+                for (int i = 0; i < 20; i++) cl[order[i]] = 1;
+                for (int q = 0; q < NI; q++) if (cl[q] == 1) h->inst_class[q] = -1;
+                HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->stream));
+                LAUNCH(h, "clean_table", dim3(1024), dim3(256), k_clean_table, h->d_state, h->votes, h->cap, h->d_clean_list);
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                r = run_bboxes(h, nm, bbox);
+                if (r) return r;
+                std::fill(cmp.begin(), cmp.end(), 0);
+                compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
+                empty = first_not_used(h);
+            }
+            if (empty >= 0) { h->inst_class[empty] = class_ids[m]; cmp[empty + m * NI] = 1; }
+        }
+        for (int q = 0; q < NI; q++)
+            if (cmp[q + m * NI] == 1)
+                LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes);
+    }
+    // step 4
+    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+    hipEvent_t eb = ifx_event_get(h);
+    hipEventRecord(eb, h->stream);
+    h->stage_pending.push_back({2, {ea, eb}});
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+__global__ void k_gather_labels(const DevState* __restrict__ st, const float2* __restrict__ tm, const int32_t* __restrict__ labels, const int* __restrict__ rank, int cap,
+                                int32_t* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= st->count) return;
+    if (tm[i].y > DEAD_TIME) out[rank[i]] = labels[i];
+}
+__global__ void k_alive_flags2(const DevState* __restrict__ st, const float2* __restrict__ tm, int* __restrict__ flags, int cap)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    flags[i] = (i < st->count && tm[i].y > DEAD_TIME) ? 1 : 0;
+}
+
+extern "C" int ifx_labels(ifx_t* h, int32_t* out, int max_n)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    // labels of the live surfels in map order: rank = exclusive scan of the alive flags
+    LAUNCH(h, "alive_flags", dim3(cdiv(h->cap, 256)), dim3(256), k_alive_flags2, h->d_state, (const float2*)h->tm, h->scan_flags, h->cap);
+    ifx_scan_exclusive(h, h->scan_flags, h->cap, h->scan_out, &h->d_state->seg_counts[1]);
+    LAUNCH(h, "gather_labels", dim3(cdiv(h->cap, 256)), dim3(256), k_gather_labels, h->d_state, (const float2*)h->tm, h->labels, h->scan_out, h->cap, h->labels2);
+    DevState hs;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    int n = std::min(hs.seg_counts[1], max_n);
+    HIPCHK(h, hipMemcpy(out, h->labels2, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int ifx_instance_table(ifx_t* h, int32_t* out96)
+{
+    if (!h || !out96) return IFX_E_INVALID;
+    memcpy(out96, h->inst_class, sizeof(h->inst_class));
+    return IFX_OK;
+}
+
+// getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121
+extern "C" int ifx_loop_closure_instance_table(ifx_t* h, int32_t* out)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    for (int i = 0; i < NI; i++) {
+        int c = (int)h->inst_color[i];
+        out[5 * i + 0] = (c >> 16) & 0xFF; out[5 * i + 1] = (c >> 8) & 0xFF; out[5 * i + 2] = c & 0xFF;
+        out[5 * i + 3] = h->inst_class[i];
+        out[5 * i + 4] = i;
+    }
+    return IFX_OK;
+}

@@ -1,0 +1,795 @@
+// ifx_map.hip -- surfel-map half of the path as HIP kernels for gfx950.
+//
+// The reference runs these stages as OpenGL transform-feedback / rasterisation passes over a
+// 256-B-per-surfel AoS vertex buffer (EF/GlobalModel.cpp, EF/IndexMap.cpp, EF/Shaders/*).  Here:
+//  * the map is struct-of-arrays in HBM (pos+conf 16 B, normal+radius 16 B, colours 8 B, times 8 B,
+//    imgCorr 16 B, votes 12 x 16 B planar), so a projection pass streams 24-40 B per surfel with
+//    fully coalesced 8/16-B lane loads instead of 256 B;
+//  * rasterisation is a 64-bit atomicMin on (depth bits << 32 | surfel id) per covered pixel into an
+//    L2-resident key image, resolved by a per-pixel pass (nearest z wins, ties -> lowest id);
+//  * fusion updates matched surfels in place (first pixel in column-major order owns a surfel);
+//  * deletion leaves tombstones (conf = -1, lastTime = -1e9) and ifx_compact removes them with an
+//    order-preserving scan + scatter when asked or when too many accumulate, instead of moving the
+//    whole map through a second buffer every frame.
+#include "ifx_ctx.h"
+#include <string.h>
+
+#define DEAD_TIME (-1.0e9f)
+#define ASSOC_NONE 0xFFFFFFFFu
+#define ASSOC_NEW 0xFFFFFFFEu
+#define MAP_THREADS 256
+#define MAP_BLOCKS 2048
+
+// ------------------------------------------------------------------ shared GLSL helpers
+// EF/Shaders/surfels.glsl:19-34
+__device__ inline float get_radius(float depth, float norm_z, float inv_fx, float inv_fy)
+{
+    float meanFocal = ((1.0f / fabsf(inv_fx)) + (1.0f / fabsf(inv_fy))) / 2.0f;
+    const float sqrt2 = 1.41421356237f;
+    float radius = (depth / meanFocal) * sqrt2;
+    float radius_n = radius / fabsf(norm_z);
+    radius_n = fminf(2.0f * radius, radius_n);
+    return radius_n;
+}
+// EF/Shaders/surfels.glsl:36-46
+__device__ inline float confidence_fn(float x, float y, float cx, float cy, float weighting)
+{
+    const float maxRadDist = 400, twoSigmaSquared = 0.72f;
+    float dx = x - cx, dy = y - cy;
+    float radialDist = sqrtf(dx * dx + dy * dy) / maxRadDist;
+    return ifx_expf((-(radialDist * radialDist) / twoSigmaSquared)) * weighting;
+}
+__device__ inline float tex_f(const float* img, int w, int h, int x, int y) { return img[clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)]; }
+// geometry.glsl:21-25
+__device__ inline v3 get_vertex_f(const float* depth, int w, int h, int px, int py, float x, float y, float cx, float cy, float ifx_, float ify_)
+{
+    float z = tex_f(depth, w, h, px, py);
+    return v3m((x - cx) * z * ifx_, (y - cy) * z * ify_, z);
+}
+// geometry.glsl:28-40
+__device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int py, float x, float y, v3 vp, float cx, float cy, float ifx_, float ify_)
+{
+    v3 xf = get_vertex_f(depth, w, h, px + 1, py, x + 1, y, cx, cy, ifx_, ify_);
+    v3 xb = get_vertex_f(depth, w, h, px - 1, py, x - 1, y, cx, cy, ifx_, ify_);
+    v3 yf = get_vertex_f(depth, w, h, px, py + 1, x, y + 1, cx, cy, ifx_, ify_);
+    v3 yb = get_vertex_f(depth, w, h, px, py - 1, x, y - 1, cx, cy, ifx_, ify_);
+    v3 del_x = ((xb + vp) * 0.5f) - ((xf + vp) * 0.5f);
+    v3 del_y = ((yb + vp) * 0.5f) - ((yf + vp) * 0.5f);
+    return normalized(cross(del_x, del_y));
+}
+
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; };
+static Cam make_cam(ifx* h)
+{
+    Cam c;
+    c.fx = h->cfg.fx; c.fy = h->cfg.fy; c.cx = h->cfg.cx; c.cy = h->cfg.cy; c.w = h->w; c.h = h->h;
+    c.maxDepth = h->cfg.max_depth_processed; c.conf = h->cfg.confidence; c.timeDelta = h->cfg.time_delta;
+    return c;
+}
+
+// ------------------------------------------------------------------ exclusive scan of int flags
+#define SCAN_ITEMS 8
+#define SCAN_TILE (MAP_THREADS * SCAN_ITEMS)
+__global__ __launch_bounds__(MAP_THREADS) void k_scan_reduce(const int* __restrict__ flags, int n, int* __restrict__ block_sums)
+{
+    __shared__ int lds[MAP_THREADS / 64];
+    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) s += flags[base + k];
+    s = wave_sum_i(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < MAP_THREADS / 64; k++) t += lds[k]; block_sums[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ block_sums, int nb, int* __restrict__ total)
+{
+    __shared__ int lds[1024];
+    int per = (nb + 1023) / 1024, lo = threadIdx.x * per, s = 0;
+    for (int k = 0; k < per; k++) if (lo + k < nb) s += block_sums[lo + k];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = lds[threadIdx.x] - s;
+    for (int k = 0; k < per; k++) if (lo + k < nb) { int v = block_sums[lo + k]; block_sums[lo + k] = run; run += v; }
+    if (threadIdx.x == 1023 && total) *total = lds[1023];
+}
+__global__ __launch_bounds__(MAP_THREADS) void k_scan_final(const int* __restrict__ flags, int n, const int* __restrict__ block_sums, int* __restrict__ out)
+{
+    __shared__ int lds[MAP_THREADS];
+    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, s = 0;
+    int f[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { f[k] = (base + k < n) ? flags[base + k] : 0; s += f[k]; }
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < MAP_THREADS; off <<= 1) {
+        int v = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = lds[threadIdx.x] - s + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) { out[base + k] = run; run += f[k]; }
+}
+int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total)
+{
+    if (n <= 0) { if (d_total) hipMemsetAsync(d_total, 0, 4, h->stream); return IFX_OK; }
+    int nb = cdiv(n, SCAN_TILE);
+    LAUNCH(h, "scan_reduce", dim3(nb), dim3(MAP_THREADS), k_scan_reduce, d_flags, n, h->scan_block);
+    LAUNCH(h, "scan_sums", dim3(1), dim3(1024), k_scan_sums, h->scan_block, nb, d_total);
+    LAUNCH(h, "scan_final", dim3(nb), dim3(MAP_THREADS), k_scan_final, d_flags, n, h->scan_block, d_out);
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ first frame (a15)
+// vertex_feedback.vert:41-74 + init_unstable.vert:45-67, intended dense initialisation,
+// column-major pixel order (EF/GlobalModel.cpp:103-112).
+__global__ void k_init_flags(const float* __restrict__ dm, const float* __restrict__ dmf, Cam c, int* __restrict__ flags)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.w * c.h) return;
+    int i = k / c.h, j = k - i * c.h;   // k is the column-major order index
+    float z = dm[j * c.w + i], zf = dmf[j * c.w + i];
+    flags[k] = !(z <= 0 || z > c.maxDepth || zf <= 0 || zf > c.maxDepth);
+}
+__global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const float* __restrict__ dmf, const uint8_t* __restrict__ rgb, Cam c, int tick,
+                               const int* __restrict__ flags, const int* __restrict__ rank, int cap, float4* __restrict__ pc, float4* __restrict__ nr,
+                               float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.w * c.h || !flags[k]) return;
+    int n = rank[k];
+    if (n >= cap) { st->overflow = 1; return; }
+    int i = k / c.h, j = k - i * c.h;
+    float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+    float x = (float)i + 0.5f, y = (float)j + 0.5f;
+    v3 vp = get_vertex_f(dm, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
+    v3 vpf = get_vertex_f(dmf, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
+    v3 nl = get_normal_f(dmf, c.w, c.h, i, j, x, y, vpf, c.cx, c.cy, ifx_, ify_);
+    pc[n] = make_float4(vp.x, vp.y, vp.z, confidence_fn(x, y, c.cx, c.cy, 1.0f));
+    const uint8_t* cc = &rgb[(j * c.w + i) * 3];
+    col[n] = make_float2(encode_color(cc[0] / 255.0f, cc[1] / 255.0f, cc[2] / 255.0f), 0.f);
+    tm[n] = make_float2(1.f, (float)tick);
+    nr[n] = make_float4(nl.x, nl.y, nl.z, get_radius(vpf.z, nl.z, ifx_, ify_));
+    ic[n] = make_float4(-1.f, -1.f, -1.f, -1.f);
+    for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(-1.f, -1.f, -1.f, -1.f);
+}
+__global__ void k_init_count(DevState* st, const int* total, int cap)
+{
+    if (threadIdx.x == 0) { int t = *total; st->count = t < cap ? t : cap; st->n_dead = 0; st->n_new = st->count; }
+}
+
+int ifx_map_init_first(ifx* h)
+{
+    Cam c = make_cam(h);
+    LAUNCH(h, "init_flags", dim3(cdiv(h->P, 256)), dim3(256), k_init_flags, h->dm, h->dmf, c, h->scan_flags);
+    ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
+    LAUNCH(h, "init_scatter", dim3(cdiv(h->P, 256)), dim3(256), k_init_scatter, h->d_state, h->dm, h->dmf, h->rgb, c, h->tick, h->scan_flags, h->scan_out, h->cap,
+           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
+    LAUNCH(h, "init_count", dim3(1), dim3(64), k_init_count, h->d_state, &h->d_state->seg_counts[0], h->cap);
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ index map (a10)
+// index_map.vert:40-66: per surfel 24 B (pos+conf 16, times 8), one 64-bit atomicMin per visible surfel.
+__global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                               const float2* __restrict__ tm, Cam c, int time, unsigned long long* __restrict__ keys)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float4 p4 = pc[i];
+        float lastT = tm[i].y;
+        v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+        if (p.z > c.maxDepth || p.z < 0 || (float)time - lastT > (float)c.timeDelta) continue;
+        float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+        if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
+        int px = (int)floorf(u), py = (int)floorf(v);
+        atomicMin(&keys[py * c.w + px], make_key(p.z, (unsigned int)i));
+    }
+}
+// index_map.frag:33-40: gathers the winner's attributes; also re-arms the key image for the next pass
+__global__ void k_index_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
+                                const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, int P, uint32_t* __restrict__ index_id,
+                                float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    unsigned long long key = keys[k];
+    keys[k] = IFX_KEY_EMPTY;
+    if (key == IFX_KEY_EMPTY) {
+        index_id[k] = 0;
+        vc[k] = make_float4(0, 0, 0, 0); ct[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
+    float4 p4 = pc[id], n4 = nr[id];
+    float2 c2 = col[id], t2 = tm[id];
+    v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+    v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+    index_id[k] = id;
+    vc[k] = make_float4(p.x, p.y, p.z, p4.w);
+    ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y);
+    nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
+}
+
+static void index_pass(ifx* h, const float* d_pose_inv, int time)
+{
+    Cam c = make_cam(h);
+    LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
+    LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr);
+}
+
+// ------------------------------------------------------------------ disc rasteriser (a9, a14)
+struct Disc { v3 q, n; float r2; };
+// combo_splat.frag:39-52
+__device__ inline bool disc_hit(const Disc& d, float px, float py, const Cam& c, float& z)
+{
+    v3 l = normalized(v3m((px - c.cx) / c.fx, (py - c.cy) / c.fy, 1.0f));
+    float s = dot(d.q, d.n) / dot(l, d.n);
+    v3 cp = l * s;
+    v3 df = cp - d.q;
+    if (!(dot(df, df) <= d.r2)) return false;
+    z = cp.z;
+    return true;
+}
+// splat.vert:55-92
+__device__ inline void disc_extent(v3 q, v3 n, float r, const Cam& c, float* xs, float* ys, float& minz)
+{
+    v3 x1 = normalized(v3m(n.y - n.z, -n.x, n.x)) * (r * 1.41421356f);
+    v3 y1 = cross(n, x1);
+    v3 pts[4] = {q + x1, q + y1, q - y1, q - x1};
+    xs[0] = ys[0] = INFINITY; xs[1] = ys[1] = -INFINITY; minz = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float u = ((c.fx * pts[k].x) / pts[k].z) + c.cx, v = ((c.fy * pts[k].y) / pts[k].z) + c.cy;
+        xs[0] = fminf(xs[0], u); xs[1] = fmaxf(xs[1], u);
+        ys[0] = fminf(ys[0], v); ys[1] = fmaxf(ys[1], v);
+        minz = fminf(minz, pts[k].z);
+    }
+}
+
+// MODE 0: combinedPredict splat (splat.vert culls, sprite extent, GL point clipping by centre)
+// MODE 1: renderSurfelIds GENERAL (surfel_ids.vert/.geom culls, quad extent)
+// MODE 2: renderSurfelIds INSTANCECOMPARE (instance_surfel_ids.vert:44-70: skips surfels whose 12 vote vec4 are equal)
+template <int MODE>
+__global__ __launch_bounds__(MAP_THREADS) void k_raster(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                        const float4* __restrict__ nr, const float2* __restrict__ tm, const float4* __restrict__ votes, int cap, Cam c,
+                                                        int time, int maxTime, unsigned long long* __restrict__ keys)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float4 p4 = pc[i];
+        if (MODE == 0) { if (p4.w < c.conf) continue; }
+        else { if (!(p4.w > c.conf)) continue; }
+        v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+        if (MODE == 0) {
+            float lastT = tm[i].y;
+            if (q.z > c.maxDepth || q.z < 0 || (float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime) continue;
+        } else {
+            if (!(q.z / c.maxDepth > 0.01f)) continue;
+        }
+        float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
+        if (MODE == 0) { if (!(u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h)) continue; }
+        if (MODE == 2) {
+            // every vote vec4 compared with the first one (vInstInfoB..L == vInstInfoA)
+            float4 a = votes[i];
+            bool alleq = true;
+            for (int k = 1; k < 12 && alleq; k++) {
+                float4 b = votes[(size_t)k * cap + i];
+                alleq = (b.x == a.x) && (b.y == a.y) && (b.z == a.z) && (b.w == a.w);
+            }
+            if (alleq) continue;
+        }
+        float4 n4 = nr[i];
+        v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        float r = n4.w;
+        float xs[2], ys[2], minz;
+        disc_extent(q, nn, r, c, xs, ys, minz);
+        int x0, x1, y0, y1;
+        if (MODE == 0) {
+            float s = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
+            if (!(s == s)) continue;
+            s = fminf(fmaxf(s, 1.0f), IFX_MAX_SPRITE);
+            x0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, c.w - 1); x1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, c.w - 1);
+            y0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, c.h - 1); y1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, c.h - 1);
+        } else {
+            if (!(minz > 0) || !(xs[0] == xs[0]) || !(ys[0] == ys[0])) continue;
+            if (xs[1] - xs[0] > IFX_MAX_SPRITE || ys[1] - ys[0] > IFX_MAX_SPRITE) continue;
+            if (xs[1] < 0 || ys[1] < 0 || xs[0] > (float)c.w || ys[0] > (float)c.h) continue;
+            x0 = clampi((int)ceilf(xs[0] - 0.5f), 0, c.w - 1); x1 = clampi((int)floorf(xs[1] - 0.5f), 0, c.w - 1);
+            y0 = clampi((int)ceilf(ys[0] - 0.5f), 0, c.h - 1); y1 = clampi((int)floorf(ys[1] - 0.5f), 0, c.h - 1);
+        }
+        Disc d;
+        d.q = q; d.n = nn; d.r2 = r * r;
+        for (int py = y0; py <= y1; py++)
+            for (int px = x0; px <= x1; px++) {
+                float z;
+                if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
+                if (MODE == 0) { if (!(z >= -c.maxDepth && z <= c.maxDepth)) continue; }
+                else { if (!(z > 0 && z <= c.maxDepth)) continue; }
+                atomicMin(&keys[py * c.w + px], make_key(z, (unsigned int)i));
+            }
+    }
+}
+
+__device__ inline float key_depth(unsigned long long key)
+{
+    unsigned int b = (unsigned int)(key >> 32);
+    unsigned int u = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+    return __uint_as_float(u);
+}
+
+__global__ void k_ids_resolve(unsigned long long* __restrict__ keys, int P, int32_t* __restrict__ ids)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    unsigned long long key = keys[k];
+    keys[k] = IFX_KEY_EMPTY;
+    ids[k] = (key == IFX_KEY_EMPTY) ? 0 : (int32_t)(key & 0xFFFFFFFFull);
+}
+
+// combo_splat.frag:54-66 outputs for the winner of each pixel, fused with FillIn
+// (fill_rgb/vertex/normal.frag, EF/Shaders/FillIn.cpp:65-195, passthrough = 0).
+__global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
+                                const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
+                                const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
+                                uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= c.w || y >= c.h) return;
+    int k = y * c.w + x;
+    unsigned long long key = keys[k];
+    keys[k] = IFX_KEY_EMPTY;
+    float4 vo = make_float4(0, 0, 0, 0), no = make_float4(0, 0, 0, 0);
+    uchar4 io = make_uchar4(0, 0, 0, 0), so = make_uchar4(0, 0, 0, 0);
+    uint16_t to = 0;
+    if (key != IFX_KEY_EMPTY) {
+        const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+        unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
+        float z = key_depth(key);
+        float4 p4 = pc[id], n4 = nr[id];
+        float2 c2 = col[id], t2 = tm[id];
+        v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        float fpx = (float)x + 0.5f, fpy = (float)y + 0.5f;
+        vo = make_float4((fpx - c.cx) * z * (1.f / c.fx), (fpy - c.cy) * z * (1.f / c.fy), z, p4.w);
+        no = make_float4(nn.x, nn.y, nn.z, n4.w);
+        float c3[3];
+        decode_color(c2.x, c3);
+        io = make_uchar4((uint8_t)(int)roundf(c3[0] * 255.0f), (uint8_t)(int)roundf(c3[1] * 255.0f), (uint8_t)(int)roundf(c3[2] * 255.0f), 255);
+        decode_color(c2.y, c3);
+        so = make_uchar4((uint8_t)(int)roundf(c3[0] * 255.0f), (uint8_t)(int)roundf(c3[1] * 255.0f), (uint8_t)(int)roundf(c3[2] * 255.0f), 255);
+        to = (uint16_t)(unsigned int)t2.x;
+    }
+    pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
+    // fill-in
+    float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
+    else fimg[k] = io;
+    float zc = (float)depth_filt[k] / 1000.0f;
+    if (vo.z == 0) fv[k] = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
+    else fv[k] = vo;
+    if (no.z == 0) {
+        v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
+        int xr = clampi(x + 1, 0, c.w - 1), yd = clampi(y + 1, 0, c.h - 1);
+        float zx = (float)depth_filt[y * c.w + xr] / 1000.0f, zy = (float)depth_filt[yd * c.w + x] / 1000.0f;
+        v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
+        v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
+        v3 nn = normalized(cross(vx - vp, vy - vp));
+        fn[k] = make_float4(nn.x, nn.y, nn.z, 1.f);
+    } else fn[k] = no;
+}
+
+// ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267 on the (w/20 x h/20) nearest resample
+__global__ void k_dense(DevState* st, const uchar4* __restrict__ pimg, int w, int h)
+{
+    __shared__ int lds[4];
+    int rw = w / 20, rh = h / 20, cnt = 0;
+    for (int t = threadIdx.x; t < rw * rh; t += blockDim.x) {
+        int j = t / rw, i = t - j * rw;
+        int sx = (i * w + w / 2) / rw, sy = (j * h + h / 2) / rh;
+        uchar4 s = pimg[sy * w + sx];
+        cnt += (s.x > 0 && s.y > 0 && s.z > 0);
+    }
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = lds[0] + lds[1] + lds[2] + lds[3];
+        st->dense_enough = ((float)sum / (float)(rw * rh) > 0.75f) ? 1 : 0;
+    }
+}
+
+static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime)
+{
+    Cam c = make_cam(h);
+    LAUNCH(h, "splat_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<0>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm,
+           (const float4*)h->votes, h->cap, c, time, maxTime, h->key_splat);
+    LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
+           (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
+           (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+    LAUNCH(h, "dense", dim3(1), dim3(256), k_dense, h->d_state, (const uchar4*)h->pred_image, h->w, h->h);
+}
+
+static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out)
+{
+    Cam c = make_cam(h);
+    if (mode == 1)
+        LAUNCH(h, "ids_raster_inst", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<2>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->tm, (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
+    else
+        LAUNCH(h, "ids_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<1>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm,
+               (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
+    LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, out);
+}
+
+// ------------------------------------------------------------------ association + fusion (a11, a12)
+// data.vert:94-241 for every pixel; the measurement is kept per pixel for the update / append passes
+__global__ void k_associate(const DevState* __restrict__ st, const float* __restrict__ pose_ex, float weighting_ex, const float* __restrict__ dm, const float* __restrict__ dmf,
+                            const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ index_id, const float4* __restrict__ index_vc,
+                            const float4* __restrict__ index_nr, Cam c, int time, uint32_t* __restrict__ assoc, float4* __restrict__ mpc, float4* __restrict__ mnr,
+                            float* __restrict__ mcol, uint32_t* __restrict__ upd_owner)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= c.w || j >= c.h) return;
+    int k = j * c.w + i;
+    uint32_t res = ASSOC_NONE;
+    if (i % 2 == time % 2 && j % 2 == time % 2) {
+        const float* pose = pose_ex ? pose_ex : st->pose;
+        float weighting = pose_ex ? weighting_ex : st->weighting;
+        float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+        float x = (float)i + 0.5f, y = (float)j + 0.5f;
+        v3 vl = get_vertex_f(dm, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
+        bool nb = !(tex_f(dm, c.w, c.h, i - 1, j) == 0 || tex_f(dm, c.w, c.h, i, j - 1) == 0 || tex_f(dm, c.w, c.h, i + 1, j) == 0 || tex_f(dm, c.w, c.h, i, j + 1) == 0);
+        if (nb && vl.z > 0 && vl.z <= c.maxDepth) {
+            v3 vg = xf_point(pose, vl);
+            v3 vf = get_vertex_f(dmf, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
+            v3 nl = get_normal_f(dmf, c.w, c.h, i, j, x, y, vf, c.cx, c.cy, ifx_, ify_);
+            v3 ng = xf_dir(pose, nl);
+            mpc[k] = make_float4(vg.x, vg.y, vg.z, confidence_fn(x, y, c.cx, c.cy, weighting));
+            const uint8_t* cc = &rgb[k * 3];
+            mcol[k] = encode_color(cc[0] / 255.0f, cc[1] / 255.0f, cc[2] / 255.0f);
+            mnr[k] = make_float4(ng.x, ng.y, ng.z, get_radius(vf.z, nl.z, ifx_, ify_));
+            float xl = (x - c.cx) * ifx_, yl = (y - c.cy) * ify_;
+            float lambda = sqrtf(xl * xl + yl * yl + 1);
+            v3 ray = v3m(xl, yl, 1);
+            float rayLen = norm(ray);
+            float bestDist = 1000;
+            uint32_t best = 0;
+            int counter = 0;
+            const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    int tx = clampi((int)floorf(x + offs[a]), 0, c.w - 1), ty = clampi((int)floorf(y + offs[b]), 0, c.h - 1);
+                    int kk = ty * c.w + tx;
+                    uint32_t cur = index_id[kk];
+                    if (cur > 0u) {
+                        float4 vc = index_vc[kk];
+                        if (fabsf((vc.z * lambda) - (vl.z * lambda)) < 0.05f) {
+                            float dist = norm(cross(ray, v3m(vc.x, vc.y, vc.z))) / rayLen;
+                            float4 nrm = index_nr[kk];
+                            v3 nn = v3m(nrm.x, nrm.y, nrm.z);
+                            float cang = dot(nn, nl) / (norm(nn) * norm(nl));
+                            if (dist < bestDist && (fabsf(nrm.z) < 0.75f || cang > 0.87758256189f)) { counter++; bestDist = dist; best = cur; }
+                        }
+                    }
+                }
+            if (counter > 0) {
+                res = best;
+                atomicMin(&upd_owner[best], (uint32_t)(i * c.h + j));   // first pixel in column-major order owns the surfel
+            } else res = ASSOC_NEW;
+        }
+    }
+    assoc[k] = res;
+}
+
+// update.vert:55-141 in place, by the owning pixel only
+__global__ void k_fuse_update(const DevState* __restrict__ st, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc, const float4* __restrict__ mnr,
+                              const float* __restrict__ mcol, Cam c, int time, uint32_t* __restrict__ upd_owner, float4* __restrict__ pc, float4* __restrict__ nr,
+                              float2* __restrict__ col, float2* __restrict__ tm)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= c.w || j >= c.h) return;
+    int k = j * c.w + i;
+    uint32_t id = assoc[k];
+    if (id >= ASSOC_NEW) return;
+    if ((int)id >= st->count) return;
+    if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
+    upd_owner[id] = 0xFFFFFFFFu;
+    float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
+    float c_k = p.w, a = mp.w;
+    if (mn.w < (1.0f + 0.5f) * n.w) {
+        p.x = ((c_k * p.x) + (a * mp.x)) / (c_k + a);
+        p.y = ((c_k * p.y) + (a * mp.y)) / (c_k + a);
+        p.z = ((c_k * p.z) + (a * mp.z)) / (c_k + a);
+        p.w = c_k + a;
+        float2 cl = col[id];
+        float oc[3], nc[3];
+        decode_color(cl.x, oc);
+        decode_color(mcol[k], nc);
+        cl.x = encode_color(((c_k * oc[0]) + (a * nc[0])) / (c_k + a), ((c_k * oc[1]) + (a * nc[1])) / (c_k + a), ((c_k * oc[2]) + (a * nc[2])) / (c_k + a));
+        col[id] = cl;
+        float t0 = ((c_k * n.x) + (a * mn.x)) / (c_k + a), t1 = ((c_k * n.y) + (a * mn.y)) / (c_k + a), t2 = ((c_k * n.z) + (a * mn.z)) / (c_k + a);
+        float t3 = ((c_k * n.w) + (a * mn.w)) / (c_k + a);
+        v3 nn = normalized(v3m(t0, t1, t2));
+        nr[id] = make_float4(nn.x, nn.y, nn.z, t3);
+        pc[id] = p;
+    } else {
+        p.w = c_k + a;
+        pc[id] = p;
+    }
+    float2 t = tm[id];
+    t.y = (float)time;
+    tm[id] = t;
+}
+
+// ------------------------------------------------------------------ clean (a13)
+// copy_unstable.vert:103-174
+__device__ inline int clean_test(const float* T, const Cam& c, int time, float4 p4, float4 n4, float initT, float& lastT, const uint32_t* __restrict__ index_id,
+                                 const float4* __restrict__ index_vc, const float4* __restrict__ index_ct)
+{
+    int test = 1;
+    v3 lp = xf_point(T, v3m(p4.x, p4.y, p4.z));
+    float x = ((c.fx * lp.x) / lp.z) + c.cx, y = ((c.fy * lp.y) / lp.z) + c.cy;
+    int count = 0, zCount = 0;
+    float wv = lastT;
+    if ((float)time - wv < (float)c.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)c.w && y < (float)c.h) {
+        v3 ln = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
+        for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++) {
+                int tx = clampi((int)floorf(x + offs[a]), 0, c.w - 1), ty = clampi((int)floorf(y + offs[b]), 0, c.h - 1);
+                int k = ty * c.w + tx;
+                if (index_id[k] > 0u) {
+                    float4 vc = index_vc[k], ct = index_ct[k];
+                    float dx = vc.x - lp.x, dy = vc.y - lp.y;
+                    if (ct.z < initT && vc.w > c.conf && vc.z > lp.z && vc.z - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count++;
+                    if (ct.w == (float)time && vc.w > c.conf && vc.z > lp.z && vc.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f) zCount++;
+                }
+            }
+    }
+    if (count > 8 || zCount > 4) test = 0;
+    if (wv == -2) wv = (float)time;
+    if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
+    if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
+    lastT = wv;
+    return test;
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_clean_old(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, float4* __restrict__ pc,
+                                                           const float4* __restrict__ nr, float2* __restrict__ tm, const uint32_t* __restrict__ index_id,
+                                                           const float4* __restrict__ index_vc, const float4* __restrict__ index_ct)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const int n = st->count;
+    int dead = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float2 t = tm[i];
+        if (t.y <= DEAD_TIME) continue;
+        float4 p4 = pc[i];
+        float lastT = t.y;
+        int keep = clean_test(T, c, time, p4, nr[i], t.x, lastT, index_id, index_vc, index_ct);
+        if (!keep) {
+            p4.w = -1.0f;
+            pc[i] = p4;
+            tm[i] = make_float2(t.x, DEAD_TIME);
+            dead++;
+        }
+    }
+    dead = wave_sum_i(dead);
+    if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
+}
+
+__global__ void k_clean_new_flags(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
+                                  const float4* __restrict__ mpc, const float4* __restrict__ mnr, const uint32_t* __restrict__ index_id,
+                                  const float4* __restrict__ index_vc, const float4* __restrict__ index_ct, int* __restrict__ flags)
+{
+    int ord = blockIdx.x * blockDim.x + threadIdx.x;   // column-major order index
+    if (ord >= c.w * c.h) return;
+    int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
+    int keep = 0;
+    if (assoc[k] == ASSOC_NEW) {
+        const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+        float lastT = -2.f;
+        keep = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, index_id, index_vc, index_ct);
+    }
+    flags[ord] = keep;
+}
+
+__global__ void k_append_new(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ rank, const float4* __restrict__ mpc,
+                             const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc, float4* __restrict__ nr,
+                             float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
+{
+    int ord = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ord >= c.w * c.h || !flags[ord]) return;
+    int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
+    int n = st->count + rank[ord];
+    if (n >= cap) { st->overflow = 1; return; }
+    pc[n] = mpc[k];
+    nr[n] = mnr[k];
+    col[n] = make_float2(mcol[k], 0.f);
+    tm[n] = make_float2((float)time, (float)time);
+    ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, -2.f);
+    for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void k_append_count(DevState* st, const int* total, int cap)
+{
+    if (threadIdx.x == 0) {
+        int t = *total, nc = st->count + t;
+        if (nc > cap) { nc = cap; st->overflow = 1; }
+        st->n_new = nc - st->count;
+        st->count = nc;
+    }
+}
+
+// ------------------------------------------------------------------ tombstone compaction
+__global__ void k_alive_flags(const DevState* __restrict__ st, const float2* __restrict__ tm, int* __restrict__ flags, int cap)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    flags[i] = (i < st->count && tm[i].y > DEAD_TIME) ? 1 : 0;
+}
+__global__ void k_compact_scatter(const int* __restrict__ flags, const int* __restrict__ rank, int cap, const float4* __restrict__ pc, const float4* __restrict__ nr,
+                                  const float2* __restrict__ col, const float2* __restrict__ tm, const float4* __restrict__ ic, const float4* __restrict__ votes,
+                                  const int32_t* __restrict__ labels, float4* __restrict__ pc2, float4* __restrict__ nr2, float2* __restrict__ col2,
+                                  float2* __restrict__ tm2, float4* __restrict__ ic2, float4* __restrict__ votes2, int32_t* __restrict__ labels2)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || !flags[i]) return;
+    int d = rank[i];
+    pc2[d] = pc[i]; nr2[d] = nr[i]; col2[d] = col[i]; tm2[d] = tm[i]; ic2[d] = ic[i];
+    if (labels2) labels2[d] = labels[i];
+    for (int q = 0; q < 12; q++) votes2[(size_t)q * cap + d] = votes[(size_t)q * cap + i];
+}
+__global__ void k_compact_count(DevState* st, const int* total)
+{
+    if (threadIdx.x == 0) { st->count = *total; st->n_dead = 0; }
+}
+
+static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out);
+int ifx_compact_enqueue(ifx* h, int refresh_ids)
+{
+    // alive flags over the host-known upper bound of slots; scan; scatter into the second buffer set; swap
+    int n = h->cap;
+    LAUNCH(h, "alive_flags", dim3(cdiv(n, 256)), dim3(256), k_alive_flags, h->d_state, (const float2*)h->tm, h->scan_flags, n);
+    ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
+    LAUNCH(h, "compact_scatter", dim3(cdiv(n, 256)), dim3(256), k_compact_scatter, h->scan_flags, h->scan_out, n, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->col, (const float2*)h->tm, (const float4*)h->ic, (const float4*)h->votes, (const int32_t*)h->labels, (float4*)h->pc2, (float4*)h->nr2,
+           (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2);
+    LAUNCH(h, "compact_count", dim3(1), dim3(64), k_compact_count, h->d_state, &h->d_state->seg_counts[1]);
+    std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2);
+    if (refresh_ids) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ per-frame orchestration of the map stages
+static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
+{
+    Cam c = make_cam(h);
+    dim3 b(32, 8), g(cdiv(h->w, 32), cdiv(h->h, 8));
+    LAUNCH(h, "associate", g, b, k_associate, h->d_state, d_pose, weighting, h->dm, h->dmf, h->rgb, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_nr, c, time,
+           h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner);
+    LAUNCH(h, "fuse_update", g, b, k_fuse_update, h->d_state, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr, h->meas_col, c, time, h->upd_owner,
+           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm);
+}
+
+static void clean_pass(ifx* h, const float* d_pose_inv, int time)
+{
+    Cam c = make_cam(h);
+    LAUNCH(h, "clean_old", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_clean_old, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+           h->index_id, (const float4*)h->index_vc, (const float4*)h->index_ct);
+    LAUNCH(h, "clean_new_flags", dim3(cdiv(h->P, 256)), dim3(256), k_clean_new_flags, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc,
+           (const float4*)h->meas_nr, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_ct, h->scan_flags);
+    ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
+    LAUNCH(h, "append_new", dim3(cdiv(h->P, 256)), dim3(256), k_append_new, h->d_state, c, time, h->tick, h->scan_flags, h->scan_out, (const float4*)h->meas_pc,
+           (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
+    LAUNCH(h, "append_count", dim3(1), dim3(64), k_append_count, h->d_state, &h->d_state->seg_counts[0], h->cap);
+    // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
+}
+
+// EF/ElasticFusion.cpp:620-694 without the loop-closure branches
+int ifx_map_frame(ifx* h)
+{
+    index_pass(h, nullptr, h->tick);
+    fuse_pass(h, nullptr, 0.f, h->tick);
+    index_pass(h, nullptr, h->tick);
+    if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680)
+        ids_pass(h, nullptr, 1, h->ids_tmp);
+        ids_pass(h, nullptr, 0, h->ids_tmp);
+    }
+    clean_pass(h, nullptr, h->tick);
+    if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
+    ids_pass(h, nullptr, 0, h->ids_after);
+    return IFX_OK;
+}
+
+// ElasticFusion::predict, EF/ElasticFusion.cpp:729-763
+int ifx_map_predict(ifx* h)
+{
+    splat_pass(h, nullptr, h->tick, h->tick);
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ stage API with explicit poses
+static int upload_pose(ifx* h, const float* pose16, float** d_pose, float** d_inv)
+{
+    float buf[32];
+    memcpy(buf, pose16, 64);
+    pose_inverse(pose16, buf + 16);
+    float* slot = h->d_traj + (size_t)(h->max_traj - 2) * 16;   // scratch at the tail of the log
+    HIPCHK(h, hipMemcpyAsync(slot, buf, 128, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *d_pose = slot;
+    *d_inv = slot + 16;
+    return IFX_OK;
+}
+
+extern "C" int ifx_predict_indices(ifx_t* h, const float* pose16, int time)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    float *dp, *di;
+    int r = upload_pose(h, pose16, &dp, &di);
+    if (r) return r;
+    index_pass(h, di, time);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int max_time)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    float *dp, *di;
+    int r = upload_pose(h, pose16, &dp, &di);
+    if (r) return r;
+    splat_pass(h, di, time, max_time);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    float *dp, *di;
+    int r = upload_pose(h, pose16, &dp, &di);
+    if (r) return r;
+    fuse_pass(h, dp, weighting, time);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+extern "C" int ifx_clean(ifx_t* h, const float* pose16, int time)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    float *dp, *di;
+    int r = upload_pose(h, pose16, &dp, &di);
+    if (r) return r;
+    clean_pass(h, di, time);
+    if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+extern "C" int ifx_render_ids(ifx_t* h, const float* pose16, int mode)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    float *dp, *di;
+    int r = upload_pose(h, pose16, &dp, &di);
+    if (r) return r;
+    ids_pass(h, di, mode, h->ids_tmp);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}

@@ -1,0 +1,154 @@
+/*
+ * oracle/orc.h -- CPU restatement ("oracle") of InstanceFusion's per-frame dense surfel pipeline.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (instancefusion_amd/csrc, libifx.so) never
+ * links, loads or calls anything in this directory.
+ *
+ * PARITY STATUS: "parity unpinned" for the CUDA/GLSL stages.  The reference has no CPU path, no
+ * tests and no golden vectors for this path; its CUDA and OpenGL sources
+ * cannot be built in this image without stand-ins for CUDA / GL / Eigen headers, so they are
+ * restated here by hand, each function citing the reference file:line it follows.  The only stage
+ * whose reference source builds as-is is gSLICr's shared per-pixel maths
+ * (src/gSLICr/gSLICr_Lib/engines/gSLICr_seg_engine_shared.h with -DCOMPILE_WITHOUT_CUDA); it is
+ * compiled into oracle/_ref/ and pins orc_slic_* (see oracle/Makefile, tests/test_oracle_slic.py).
+ *
+ * Citation prefixes:  EF/ = elasticfusionpublic/Core/src/   IF/ = src/   (under /root/reference)
+ *
+ * Conventions: images are row-major [y*w+x]; planar maps are [3][h][w] (x-plane, y-plane, z-plane)
+ * as EF/Cuda/cudafuncs.cu:109-149; 4-channel maps are interleaved float4 per pixel.
+ */
+#ifndef ORC_H_
+#define ORC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NUM_PYRS 3
+#define ORC_NUM_INST 96          /* IF/main.cpp:31-44 instanceNum */
+#define ORC_VOTE_FLOATS 48       /* 96 int16 counters, two per float (IF/Core/InstanceFusionCuda.cu:22-39) */
+
+/* Same field order as ifx_config in include/ifx_c_api.h (tests build both from one dict). */
+typedef struct orc_config {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    int32_t time_delta;          /* 200   IF/map_interface/ElasticFusionInterface.cpp:43-45 */
+    float confidence;            /* 10 */
+    float depth_cut;             /* 12 m  (preprocess gate) */
+    float max_depth_processed;   /* 20 m  EF/ElasticFusion.cpp:73 */
+    float icp_weight;            /* 10 */
+    int32_t pyramid;             /* 1 */
+    int32_t fast_odom;           /* 0 */
+    int32_t so3;                 /* 1 */
+    int32_t max_surfels;         /* capacity */
+    int32_t device;              /* unused by the oracle */
+    int32_t n_ranks, rank;       /* unused by the oracle */
+} orc_config;
+
+/* DataTerm, EF/Cuda/types.cuh:75-81 (reference layout, 16 B) */
+typedef struct orc_dataterm {
+    int16_t zero_x, zero_y;      /* pixel in the last (model) image */
+    int16_t one_x, one_y;        /* pixel in the next (current) image */
+    float diff;
+    int32_t valid;
+} orc_dataterm;
+
+/* ---------------------------------------------------------------- preprocessing (a2) */
+void orc_bilateral(const uint16_t* in, uint16_t* out, int w, int h, float maxD);
+void orc_metric(const uint16_t* in, float* out, int w, int h, float maxD);
+
+/* ---------------------------------------------------------------- pyramid kernels (a3) */
+void orc_pyrdown_u16(const uint16_t* src, int sw, int sh, uint16_t* dst);
+void orc_vmap(const uint16_t* depth, int w, int h, float fx, float fy, float cx, float cy,
+              float cutoff, float* vmap);
+void orc_nmap(const float* vmap, int w, int h, float* nmap);
+void orc_copy_maps(const float* v4, const float* n4, int w, int h, float* vmap, float* nmap);
+void orc_resize_map(const float* in, int sw, int sh, float* out, int normalize);
+void orc_transform_maps(float* vmap, float* nmap, int w, int h, const float* R, const float* t);
+void orc_vertices_to_depth(const float* v4, int w, int h, float cutoff, float* d);
+void orc_pyrdown_gauss_f(const float* src, int sw, int sh, float* dst);
+void orc_pyrdown_gauss_u8(const uint8_t* src, int sw, int sh, uint8_t* dst);
+void orc_rgb_to_intensity(const uint8_t* rgb, int stride, int n, uint8_t* dst);
+void orc_sobel(const uint8_t* img, int w, int h, int16_t* dx, int16_t* dy);
+void orc_project_cloud(const float* depth, int w, int h, float fx, float fy, float cx, float cy,
+                       float* cloud3);
+
+/* ---------------------------------------------------------------- tracker reductions (a4-a7) */
+void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr,
+                  const float* nmap_curr, const float* Rprev_inv, const float* tprev, float fx,
+                  float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                  float dist_thres, float angle_thres, int w, int h, float* out29);
+void orc_rgb_residual(float min_scale, const int16_t* didx, const int16_t* didy,
+                      const float* last_depth, const float* next_depth, const uint8_t* last_img,
+                      const uint8_t* next_img, orc_dataterm* corres, float max_depth_delta,
+                      const float* kt, const float* krkinv, int w, int h, int* count, int* sigma);
+void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, float fx, float fy,
+                  const int16_t* didx, const int16_t* didy, float sobel_scale, int w, int h,
+                  float* out29);
+void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float* image_basis,
+                  const float* kinv, const float* krlr, int w, int h, float* out11);
+
+/* ---------------------------------------------------------------- whole tracker (a3-a8) */
+typedef struct orc_tracker orc_tracker;
+orc_tracker* orc_tracker_create(int w, int h, float fx, float fy, float cx, float cy);
+void orc_tracker_destroy(orc_tracker*);
+void orc_tracker_init_first_rgb(orc_tracker*, const uint8_t* rgb);
+/* model_v4/model_n4: float4 maps (camera frame of pose), model_rgba: RGBA8 image */
+void orc_tracker_init_model(orc_tracker*, const float* model_v4, const float* model_n4,
+                            const uint8_t* model_rgba, const float* pose16);
+void orc_tracker_init_frame(orc_tracker*, const uint16_t* depth_filtered, const uint8_t* rgb,
+                            float depth_cutoff);
+/* pose16 in/out (row-major 4x4, camera-to-world); diag[8]: icpErr,icpCount,rgbErr,rgbCount,so3Err,so3Count,0,0 */
+void orc_tracker_run(orc_tracker*, float* pose16, float icp_weight, int pyramid, int fast_odom,
+                     int so3, float* diag);
+/* access to internals for stage-level parity tests; returns pointer owned by the tracker */
+const void* orc_tracker_buffer(orc_tracker*, const char* name, int level);
+
+/* ---------------------------------------------------------------- map (a9-a15) */
+typedef struct orc_map orc_map;   /* AoS-free: separate arrays, reference order/compaction semantics */
+
+/* ---------------------------------------------------------------- full pipeline object */
+typedef struct orc orc_t;
+orc_t* orc_create(const orc_config*);
+void orc_destroy(orc_t*);
+int orc_process_frame(orc_t*, const uint8_t* rgb, const uint16_t* depth, int64_t ts,
+                      const float* in_pose16, float weight_mult, float* out_pose16);
+int orc_map_count(orc_t*);
+int orc_tick(orc_t*);
+/* copy out map fields; any pointer may be NULL.  pc,nr,ic: float4 per surfel; col,tm: float2; votes: 48 floats/surfel */
+void orc_map_download(orc_t*, float* pc, float* nr, float* col, float* tm, float* ic, float* votes);
+void orc_map_upload(orc_t*, int n, const float* pc, const float* nr, const float* col,
+                    const float* tm, const float* ic, const float* votes);
+void orc_set_pose(orc_t*, const float* pose16, int tick);
+/* images: name in {"ids_after","index","pred_vertex","pred_normal","pred_image","pred_time",
+ * "fill_vertex","fill_normal","fill_image","depth_filtered","depth_metric","depth_metric_filtered"} */
+const void* orc_image(orc_t*, const char* name);
+
+/* stage-level map entry points operating on the object's map with an explicit pose/time */
+void orc_predict_indices(orc_t*, const float* pose16, int time);
+void orc_combined_predict(orc_t*, const float* pose16, int time, int max_time);
+void orc_fuse(orc_t*, const float* pose16, int time, float weighting);
+void orc_clean(orc_t*, const float* pose16, int time);
+void orc_render_ids(orc_t*, const float* pose16, int mode /*0 general, 1 instance-compare*/);
+
+/* ---------------------------------------------------------------- instance path (a16-a23) */
+int orc_should_segment(orc_t*, int frame);
+/* masks: n x H x W uint8 (0/255, area-descending); returns 0 ok */
+int orc_process_segmentation(orc_t*, const uint8_t* rgb, const uint16_t* depth,
+                             const uint8_t* masks, const int32_t* class_ids, int n, int frame,
+                             int do_knn);
+void orc_labels(orc_t*, int32_t* out);
+void orc_instance_table(orc_t*, int32_t* class_of_instance /*96, -1 unused*/);
+
+/* stage-level instance helpers */
+void orc_mask_clean_overlap(uint8_t* masks, int n, int w, int h);
+float orc_vote_encode(int a, int b);
+void orc_vote_decode(float f, int* a, int* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,336 @@
+/*
+ * oracle/orc_instance.c -- CPU restatement of the instance layer of the path (SURVEY.md 8a rows
+ * a16-a19, a22, a23).  TEST INFRASTRUCTURE ONLY (see orc.h).
+ */
+#include "orc.h"
+#include "orc_math.h"
+#include "orc_internal.h"
+#include <stdlib.h>
+#include <stdio.h>
+
+#define NI ORC_NUM_INST
+
+/* encode_Instance / decode{1,2}_Instance, IF/Core/InstanceFusionCuda.cu:22-39.  The arguments are
+ * `short` in the reference, the int -> float conversion rounds to nearest even, and float -> int
+ * truncates with CUDA's saturation. */
+float orc_vote_encode(int a, int b)
+{
+    int16_t sa = (int16_t)a, sb = (int16_t)b;
+    int32_t info = (int32_t)((uint32_t)(int32_t)sa << 16) + (int32_t)sb;
+    return (float)info;
+}
+void orc_vote_decode(float f, int* a, int* b)
+{
+    int v = orc_f2i_rz(f);
+    *a = (int16_t)((v >> 16) & 0xFFFF);
+    *b = (int16_t)(v & 0xFFFF);
+}
+
+void orc_instance_init(orc_t* o)
+{
+    uint32_t s = 0x1F5u;
+    for (int i = 0; i < NI; i++) {
+        o->inst_class[i] = -1;
+        /* createInstanceTable (IF/Core/InstanceTable.cpp:11-35) draws colours from unseeded rand();
+         * a fixed LCG is used instead -- colours are arbitrary in the reference too. */
+        int c[3];
+        for (int k = 0; k < 3; k++) { s = s * 1664525u + 1013904223u; c[k] = (int)((s >> 8) % 255u); }
+        o->inst_color[i] = (float)((c[0] << 16) + (c[1] << 8) + c[2]);
+    }
+    o->labels = (int32_t*)calloc((size_t)o->cap, 4);
+    o->last_seg_frame = -1;
+    o->clean_times = 0;
+}
+void orc_instance_free(orc_t* o) { free(o->labels); }
+
+void orc_instance_table(orc_t* o, int32_t* out) { memcpy(out, o->inst_class, sizeof(o->inst_class)); }
+void orc_labels(orc_t* o, int32_t* out) { memcpy(out, o->labels, (size_t)o->n * 4); }
+
+/* maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131 */
+void orc_mask_clean_overlap(uint8_t* masks, int n, int w, int h)
+{
+    for (int p = 0; p < w * h; p++) {
+        int flag = 0;
+        for (int m = n - 1; m >= 0; m--) {
+            if (flag) masks[(size_t)m * w * h + p] = 0;
+            if (masks[(size_t)m * w * h + p]) flag = 1;
+        }
+    }
+}
+
+/* whetherDoSegmentation + checkProjectDepthAndInstanceKernel,
+ * IF/Core/InstanceFusion.cpp:192-238, IF/Core/InstanceFusionCuda.cu:736-760 */
+int orc_should_segment(orc_t* o, int frame)
+{
+    const int downsample = 10, fixedL = 2, fixedH = 45;
+    int w = o->w, h = o->h;
+    long long c0 = 0;
+    int c1 = 0;
+    for (int y = 0; y < h; y += downsample)
+        for (int x = 0; x < w; x += downsample) {
+            int id = o->ids_after[y * w + x];
+            if (id > 0 && id < o->n) {
+                for (int i = 0; i < ORC_VOTE_FLOATS; i++) {
+                    int a, b;
+                    orc_vote_decode(o->votes[(size_t)id * ORC_VOTE_FLOATS + i], &a, &b);
+                    c0 += a; c0 += b;
+                }
+            } else c1++;
+        }
+    int count0 = (int)c0; /* int atomics wrap in the reference */
+    int test1 = count0 > (w / downsample * h / downsample * 0.48 * 30);
+    int test2 = c1 < (w / downsample * h / downsample * 0.2);
+    if (test1 || test2) {
+        if (frame - o->last_seg_frame > fixedH) { o->last_seg_frame = frame; return 1; }
+        return 0;
+    }
+    if (frame - o->last_seg_frame > fixedL) { o->last_seg_frame = frame; return 1; }
+    return 0;
+}
+
+/* getDepthThreshold, IF/Core/InstanceFusion.h:170-176 */
+static float depth_threshold(int depth)
+{
+    float t = 0.074f * depth - 246.0f;
+    t = fmaxf(50.0f, t);
+    t = fminf(420.0f, t);
+    return t;
+}
+
+/* filterAreaCompute + maskGeometricFilter, IF/Core/InstanceFusion.cpp:470-593 */
+static void mask_geometric_filter(orc_t* o, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int nm, uint8_t* unavailable)
+{
+    int w = o->w, h = o->h, P = w * h;
+    int* filterMap = (int*)malloc((size_t)P * 4);
+    int* queue = (int*)malloc((size_t)P * 4 * 4 + 16);
+    static const int StepX[4] = {0, 0, 1, -1}, StepY[4] = {1, -1, 0, 0};
+    for (int i = 0; i < nm; i++) {
+        if (unavailable[i]) continue;
+        uint8_t* mask = masks + (size_t)i * P;
+        const uint8_t* om = ori + (size_t)i * P;
+        memset(filterMap, 0, (size_t)P * 4);
+        float oriPoints = 0;
+        for (int y = 1; y < h - 1; y++)
+            for (int x = 1; x < w - 1; x++) {
+                if (om[y * w + x]) oriPoints++;
+                if (mask[y * w + x] && depth[y * w + x]) filterMap[y * w + x] = 1;
+            }
+        int areaFlag = 2, list[20], p = 0;
+        for (int y = 1; y < h - 1; y++)
+            for (int x = 1; x < w - 1; x++) {
+                if (filterMap[y * w + x] != 1) continue;
+                float points = 0;
+                int front = 0, tail = 0;
+                queue[front++] = y * w + x;
+                while (front > tail) {
+                    int now = queue[tail++];
+                    int nx = now % w, ny = now / w;
+                    if (filterMap[ny * w + nx] != 1) continue;
+                    points++;
+                    filterMap[ny * w + nx] = areaFlag;
+                    for (int k = 0; k < 4; k++) {
+                        int dx = nx + StepX[k], dy = ny + StepY[k];
+                        float thr = depth_threshold(depth[ny * w + nx]);
+                        if (filterMap[dy * w + dx] == 1 && (float)abs((int)depth[ny * w + nx] - (int)depth[dy * w + dx]) < thr) queue[front++] = dy * w + dx;
+                    }
+                }
+                if (points / oriPoints > 0.25f /* eachGeoThreshold */) { if (p < 20) list[p++] = areaFlag; }
+                areaFlag++;
+            }
+        float finalPoints = 0;
+        for (int k = 0; k < P; k++) {
+            int flag = 0;
+            for (int j = 0; j < p; j++) if (filterMap[k] == list[j]) { flag = 1; break; }
+            if (flag) { mask[k] = 255; finalPoints++; } else mask[k] = 0;
+        }
+        if (finalPoints / oriPoints < 0.65f /* totalGeoThreshold */) unavailable[i] = 1;
+    }
+    free(filterMap);
+    free(queue);
+}
+
+/* getProjectInstanceList + computeProjectBoundingBox, IF/Core/InstanceFusionCuda.cu:781-974 */
+static void project_bboxes(orc_t* o, const uint8_t* masks, int nm, int* maskBBox, int* projBBox)
+{
+    int w = o->w, h = o->h, P = w * h;
+    for (int i = 0; i < NI; i++) { projBBox[i * 4] = w + 1; projBBox[i * 4 + 1] = -1; projBBox[i * 4 + 2] = h + 1; projBBox[i * 4 + 3] = -1; }
+    for (int i = 0; i < nm; i++) { maskBBox[i * 4] = w + 1; maskBBox[i * 4 + 1] = -1; maskBBox[i * 4 + 2] = h + 1; maskBBox[i * 4 + 3] = -1; }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int id = o->ids_after[y * w + x];
+            if (!(id > 0 && id < o->n)) continue; /* projected counters are all -1 */
+            int cnt[NI];
+            for (int i = 0; i < ORC_VOTE_FLOATS; i++) orc_vote_decode(o->votes[(size_t)id * ORC_VOTE_FLOATS + i], &cnt[2 * i], &cnt[2 * i + 1]);
+            if (cnt[0] == -1) continue; /* instanceProjectMap[y*width+x] != -1 test (:915) */
+            int maxNum = 0, maxID = -1;
+            for (int q = 0; q < NI; q++) if (cnt[q] > maxNum) { maxNum = cnt[q]; maxID = q; }
+            if (maxID != -1) {
+                int* b = &projBBox[maxID * 4];
+                if (x < b[0]) b[0] = x; if (x > b[1]) b[1] = x; if (y < b[2]) b[2] = y; if (y > b[3]) b[3] = y;
+            }
+            for (int m = 0; m < nm; m++)
+                if (masks[(size_t)m * P + y * w + x] > 0) {
+                    int* b = &maskBBox[m * 4];
+                    if (x < b[0]) b[0] = x; if (x > b[1]) b[1] = x; if (y < b[2]) b[2] = y; if (y > b[3]) b[3] = y;
+                }
+        }
+}
+
+/* computeCompareMap, IF/Core/InstanceFusion.cpp:595-651 (last match wins; instance 0 never matches) */
+static void compare_map(orc_t* o, const int* maskBBox, const int* projBBox, const int32_t* class_ids, int nm, uint8_t* unavailable, int* cmp)
+{
+    for (int m = 0; m < nm; m++) {
+        int minX_m = maskBBox[m * 4], maxX_m = maskBBox[m * 4 + 1], minY_m = maskBBox[m * 4 + 2], maxY_m = maskBBox[m * 4 + 3];
+        if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) { unavailable[m] = 1; continue; }
+        int best = -1;
+        for (int q = 0; q < NI; q++) {
+            if (o->inst_class[q] == -1 || class_ids[m] != o->inst_class[q]) continue;
+            int minX_i = projBBox[q * 4], maxX_i = projBBox[q * 4 + 1], minY_i = projBBox[q * 4 + 2], maxY_i = projBBox[q * 4 + 3];
+            if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
+            float IW = (float)((maxX_i < maxX_m ? maxX_i : maxX_m) - (minX_i > minX_m ? minX_i : minX_m));
+            float IH = (float)((maxY_i < maxY_m ? maxY_i : maxY_m) - (minY_i > minY_m ? minY_i : minY_m));
+            if (IW <= 0 || IH <= 0) continue;
+            float I = IW * IH;
+            float U = (float)(((maxX_i - minX_i) * (maxY_i - minY_i)) + ((maxX_m - minX_m) * (maxY_m - minY_m))) - I;
+            if (I / U > 0.5f /* compareThreshold */) best = q;
+        }
+        if (best > 0) cmp[best + m * NI] = 1;
+    }
+}
+
+/* getInstanceTableCleanList, IF/Core/InstanceTable.cpp:185-224 (score = sum count, 20 lowest) */
+static void clean_list(int* maxv, int* sumv, int* out)
+{
+    int order[NI];
+    for (int i = 0; i < NI; i++) order[i] = i;
+    for (int i = 0; i < NI; i++)
+        for (int j = i + 1; j < NI; j++)
+            if ((float)sumv[j] < (float)sumv[i]) {
+                int t = maxv[j]; maxv[j] = maxv[i]; maxv[i] = t;
+                t = order[j]; order[j] = order[i]; order[i] = t;
+                t = sumv[j]; sumv[j] = sumv[i]; sumv[i] = t;
+            }
+    for (int i = 0; i < NI; i++) out[i] = 0;
+    for (int i = 0; i < 20 /* cleanNum */; i++) out[order[i]] = 1;
+}
+
+static int first_not_used(orc_t* o)
+{
+    for (int i = 0; i < NI; i++) if (o->inst_class[i] == -1) return i;
+    return -1;
+}
+
+/* InstanceFusion::processInstance, IF/Core/InstanceFusion.cpp:655-1067 with the Mask-RCNN call
+ * replaced by the caller's pre-computed masks.  Superpixel refinement (steps -1_1..-1_3) is in
+ * orc_slic.c and is applied when do_knn bit 1 (value 2) is set. */
+int orc_superpixel_refine(orc_t* o, const uint8_t* rgb, const uint16_t* depth, uint8_t* masks, int nm, int frame);
+
+int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth,
+                             const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame,
+                             int flags)
+{
+    int w = o->w, h = o->h, P = w * h, n = o->n;
+    if (nm == 0 || n == 0) return 0;
+    uint8_t* masks = (uint8_t*)malloc((size_t)nm * P);
+    uint8_t* ori = (uint8_t*)malloc((size_t)nm * P);
+    memcpy(masks, masks_in, (size_t)nm * P);
+    memcpy(ori, masks_in, (size_t)nm * P); /* "BAK ORI MASK" :705-706, before clean-overlap */
+    uint8_t* unavailable = (uint8_t*)calloc((size_t)nm, 1);
+    orc_mask_clean_overlap(masks, nm, w, h);
+    if (flags & 2) orc_superpixel_refine(o, rgb, depth, masks, nm, frame);
+
+    int* maskBBox = (int*)malloc((size_t)nm * 16);
+    int projBBox[NI * 4];
+    int* cmp = (int*)calloc((size_t)nm * NI, 4);
+    project_bboxes(o, masks, nm, maskBBox, projBBox);
+    compare_map(o, maskBBox, projBBox, class_ids, nm, unavailable, cmp);
+
+    /* getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996 */
+    uint16_t* pdm = (uint16_t*)calloc((size_t)P, 2);
+    for (int k = 0; k < P; k++) {
+        int id = o->ids_after[k];
+        if (id > 0 && id < n) {
+            float dx = o->pose[3] - o->pc[id * 4], dy = o->pose[7] - o->pc[id * 4 + 1], dz = o->pose[11] - o->pc[id * 4 + 2];
+            pdm[k] = (uint16_t)(sqrtf(dx * dx + dy * dy + dz * dz) * 1186 /* depthRatio */);
+        }
+    }
+    mask_geometric_filter(o, pdm, masks, ori, nm, unavailable);
+
+    for (int m = 0; m < nm; m++) {
+        int exist = 0;
+        for (int q = 0; q < NI; q++) if (cmp[q + m * NI] == 1) { exist = 1; break; }
+        if (!exist && !unavailable[m]) {
+            int empty = first_not_used(o);
+            if (empty == -1) {
+                o->clean_times++;
+                /* computeMaxCountInMapKernel :1012-1036 */
+                int maxv[NI], sumv[NI], cl[NI];
+                for (int q = 0; q < NI; q++) { maxv[q] = 0; sumv[q] = 0; }
+                for (int i = 0; i < n; i++)
+                    for (int k = 0; k < ORC_VOTE_FLOATS; k++) {
+                        int a, b;
+                        orc_vote_decode(o->votes[(size_t)i * ORC_VOTE_FLOATS + k], &a, &b);
+                        if (a > maxv[2 * k]) maxv[2 * k] = a;
+                        if (b > maxv[2 * k + 1]) maxv[2 * k + 1] = b;
+                        if (a) sumv[2 * k] += a;
+                        if (b) sumv[2 * k + 1] += b;
+                    }
+                clean_list(maxv, sumv, cl);
+                for (int q = 0; q < NI; q++) if (cl[q] == 1) o->inst_class[q] = -1;
+                /* cleanInstanceTableMapKernel :1057-1084 */
+                for (int i = 0; i < n; i++)
+                    for (int k = 0; k < ORC_VOTE_FLOATS; k++) {
+                        if (!cl[2 * k] && !cl[2 * k + 1]) continue;
+                        int a, b;
+                        float* f = &o->votes[(size_t)i * ORC_VOTE_FLOATS + k];
+                        orc_vote_decode(*f, &a, &b);
+                        if (cl[2 * k]) a = 0;
+                        if (cl[2 * k + 1]) b = 0;
+                        *f = orc_vote_encode(a, b);
+                    }
+                project_bboxes(o, masks, nm, maskBBox, projBBox);
+                memset(cmp, 0, (size_t)nm * NI * 4);
+                compare_map(o, maskBBox, projBBox, class_ids, nm, unavailable, cmp);
+                empty = first_not_used(o);
+            }
+            if (empty >= 0) { /* registerInstanceTable :231-235 */
+                o->inst_class[empty] = class_ids[m];
+                cmp[empty + m * NI] = 1;
+            }
+        }
+        /* updateSurfelMapInstanceKernel :1100-1139, deleteNum = -1 */
+        for (int q = 0; q < NI; q++) {
+            if (cmp[q + m * NI] != 1) continue;
+            const uint8_t* mask = masks + (size_t)m * P;
+            for (int k = 0; k < P; k++) {
+                if (!(mask[k] > 0)) continue;
+                int id = o->ids_after[k];
+                if (!(id > 0 && id < n)) continue;
+                float* f = &o->votes[(size_t)id * ORC_VOTE_FLOATS + q / 2];
+                int a, b;
+                orc_vote_decode(*f, &a, &b);
+                if (q % 2 == 0) a += (m + 1); else b += (m + 1);
+                if (a >= 65535) a = 65535;
+                if (b >= 65535) b = 65535;
+                *f = orc_vote_encode(a, b);
+            }
+        }
+    }
+
+    /* countAndColourSurfelMapKernel :1158-1200 */
+    const float defaultColor = 7434609;
+    for (int i = 0; i < n; i++) {
+        int best = -1, bestCount = 0;
+        for (int k = 0; k < ORC_VOTE_FLOATS; k++) {
+            int a, b;
+            orc_vote_decode(o->votes[(size_t)i * ORC_VOTE_FLOATS + k], &a, &b);
+            if (bestCount < a) { bestCount = a; best = 2 * k; }
+            if (bestCount < b) { bestCount = b; best = 2 * k + 1; }
+        }
+        o->labels[i] = best;
+        float* ic = &o->col[i * 2 + 1];
+        if (*ic == 0 || *ic == defaultColor) *ic = (best != -1) ? o->inst_color[best] : defaultColor;
+    }
+    free(masks); free(ori); free(unavailable); free(maskBBox); free(cmp); free(pdm);
+    return 0;
+}

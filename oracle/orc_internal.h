@@ -1,0 +1,59 @@
+/* oracle/orc_internal.h -- private state of the CPU oracle (test infrastructure only, see orc.h). */
+#ifndef ORC_INTERNAL_H_
+#define ORC_INTERNAL_H_
+
+#include "orc.h"
+
+/* one measurement produced by the association pass (data.vert) */
+typedef struct orc_meas {
+    float pc[4];   /* world position, confidence a */
+    float col0;    /* packed rgb */
+    float nr[4];   /* world normal, radius */
+    float ic[4];   /* imgCorr */
+    int kind;      /* 0 nothing, 1 update of `target`, 2 new unstable surfel */
+    uint32_t target;
+} orc_meas;
+
+struct orc {
+    orc_config cfg;
+    int w, h, P;
+    int tick;
+    float pose[16];
+    /* map: reference order, compacted every frame like the transform-feedback passes */
+    int n, cap;
+    float *pc, *nr, *col, *tm, *ic, *votes;
+    /* frame inputs / preprocess */
+    uint8_t* rgb;
+    uint16_t *depth_raw, *depth_filt;
+    float *dm, *dmf;
+    /* index map */
+    uint32_t* index_id;
+    float *index_z, *index_vc, *index_ct, *index_nr;
+    /* predictions */
+    float *pred_vertex, *pred_normal, *zbuf;
+    uint8_t *pred_image, *pred_inst;
+    uint16_t* pred_time;
+    float *fill_vertex, *fill_normal;
+    uint8_t* fill_image;
+    int32_t *ids_after, *ids_tmp;
+    /* fuse scratch */
+    orc_meas *newbuf, *updbuf;
+    int n_new, n_upd;
+    orc_tracker* trk;
+    float last_weighting;
+    float diag[8];
+    /* instance layer */
+    int32_t inst_class[ORC_NUM_INST]; /* -1 = slot unused */
+    float inst_color[ORC_NUM_INST];
+    int32_t* labels;                  /* bestIDInEachSurfel, length cap */
+    int last_seg_frame;
+    int clean_times;
+};
+
+float orc_encode_color(float r, float g, float b);
+void orc_decode_color(float c, float* out3);
+void orc_pose_inverse(const float* p, float* o);
+void orc_instance_init(orc_t* o);
+void orc_instance_free(orc_t* o);
+
+#endif

@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  Test infrastructure only: nothing under
+instancefusion_amd/ imports this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("time_delta", C.c_int32), ("confidence", C.c_float), ("depth_cut", C.c_float),
+        ("max_depth_processed", C.c_float), ("icp_weight", C.c_float),
+        ("pyramid", C.c_int32), ("fast_odom", C.c_int32), ("so3", C.c_int32),
+        ("max_surfels", C.c_int32), ("device", C.c_int32), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+    ]
+
+
+def default_config(w=640, h=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, max_surfels=1 << 20, **kw):
+    d = dict(width=w, height=h, fx=fx, fy=fy, cx=cx, cy=cy, time_delta=200, confidence=10.0, depth_cut=12.0,
+             max_depth_processed=20.0, icp_weight=10.0, pyramid=1, fast_odom=0, so3=1, max_surfels=max_surfels,
+             device=0, n_ranks=1, rank=0)
+    d.update(kw)
+    return d
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORC_DIR, "liborc.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORC_DIR, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        L = _lib
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OrcConfig)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_process_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]
+        L.orc_map_count.argtypes = [C.c_void_p]
+        L.orc_tick.argtypes = [C.c_void_p]
+        L.orc_map_download.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_map_upload.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.orc_set_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_image.restype = C.c_void_p
+        L.orc_image.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_predict_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_combined_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        L.orc_clean.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_render_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_should_segment.argtypes = [C.c_void_p, C.c_int]
+        L.orc_process_segmentation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_labels.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_instance_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_vote_encode.restype = C.c_float
+        L.orc_vote_encode.argtypes = [C.c_int, C.c_int]
+        L.orc_vote_decode.argtypes = [C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_tracker_create.restype = C.c_void_p
+        L.orc_tracker_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_tracker_destroy.argtypes = [C.c_void_p]
+        L.orc_tracker_init_first_rgb.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_tracker_init_model.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_tracker_init_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+        L.orc_tracker_run.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_tracker_buffer.restype = C.c_void_p
+        L.orc_tracker_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    return _lib
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_IMG_SPECS = {
+    "ids_after": (np.int32, 1), "ids_tmp": (np.int32, 1), "index": (np.uint32, 1), "index_vc": (np.float32, 4),
+    "index_ct": (np.float32, 4), "index_nr": (np.float32, 4), "pred_vertex": (np.float32, 4),
+    "pred_normal": (np.float32, 4), "pred_image": (np.uint8, 4), "pred_inst": (np.uint8, 4), "pred_time": (np.uint16, 1),
+    "fill_vertex": (np.float32, 4), "fill_normal": (np.float32, 4), "fill_image": (np.uint8, 4),
+    "depth_filtered": (np.uint16, 1), "depth_metric": (np.float32, 1), "depth_metric_filtered": (np.float32, 1),
+}
+
+
+class Oracle:
+    """The whole-pipeline oracle object (orc_t)."""
+
+    def __init__(self, **cfg):
+        self.cfgd = default_config(**cfg)
+        self.cfg = OrcConfig(**self.cfgd)
+        self.L = lib()
+        self.h = self.L.orc_create(C.byref(self.cfg))
+        self.w_, self.h_ = self.cfgd["width"], self.cfgd["height"]
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process_frame(self, rgb, depth, ts=0, in_pose=None, weight_mult=1.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        out = np.zeros(16, np.float32)
+        ip = None if in_pose is None else np.ascontiguousarray(in_pose, np.float32).reshape(16)
+        self.L.orc_process_frame(self.h, ptr(rgb), ptr(depth), ts, ptr(ip), weight_mult, ptr(out))
+        return out.reshape(4, 4)
+
+    @property
+    def count(self):
+        return self.L.orc_map_count(self.h)
+
+    @property
+    def tick(self):
+        return self.L.orc_tick(self.h)
+
+    def download(self):
+        n = self.count
+        d = dict(pc=np.zeros((n, 4), np.float32), nr=np.zeros((n, 4), np.float32), col=np.zeros((n, 2), np.float32),
+                 tm=np.zeros((n, 2), np.float32), ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32))
+        self.L.orc_map_download(self.h, ptr(d["pc"]), ptr(d["nr"]), ptr(d["col"]), ptr(d["tm"]), ptr(d["ic"]), ptr(d["votes"]))
+        return d
+
+    def upload(self, m):
+        n = m["pc"].shape[0]
+        a = {k: np.ascontiguousarray(m[k], np.float32) for k in ("pc", "nr", "col", "tm", "ic", "votes")}
+        self.L.orc_map_upload(self.h, n, ptr(a["pc"]), ptr(a["nr"]), ptr(a["col"]), ptr(a["tm"]), ptr(a["ic"]), ptr(a["votes"]))
+
+    def set_pose(self, pose, tick):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_set_pose(self.h, ptr(p), tick)
+
+    def image(self, name):
+        dt, ch = _IMG_SPECS[name]
+        p = self.L.orc_image(self.h, name.encode())
+        n = self.w_ * self.h_ * ch
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p)
+        a = np.frombuffer(buf, dtype=dt).copy()
+        return a.reshape(self.h_, self.w_, ch) if ch > 1 else a.reshape(self.h_, self.w_)
+
+    def predict_indices(self, pose, time):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_predict_indices(self.h, ptr(p), time)
+
+    def combined_predict(self, pose, time, max_time):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_combined_predict(self.h, ptr(p), time, max_time)
+
+    def fuse(self, pose, time, weighting):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_fuse(self.h, ptr(p), time, weighting)
+
+    def clean(self, pose, time):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_clean(self.h, ptr(p), time)
+
+    def render_ids(self, pose, mode=0):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_render_ids(self.h, ptr(p), mode)
+        return self.image("ids_tmp")
+
+    def should_segment(self, frame):
+        return bool(self.L.orc_should_segment(self.h, frame))
+
+    def process_segmentation(self, rgb, depth, masks, class_ids, frame, flags=0):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        masks = np.ascontiguousarray(masks, np.uint8)
+        cls = np.ascontiguousarray(class_ids, np.int32)
+        return self.L.orc_process_segmentation(self.h, ptr(rgb), ptr(depth), ptr(masks), ptr(cls), masks.shape[0], frame, flags)
+
+    def labels(self):
+        out = np.zeros(self.count, np.int32)
+        self.L.orc_labels(self.h, ptr(out))
+        return out
+
+    def instance_table(self):
+        out = np.zeros(96, np.int32)
+        self.L.orc_instance_table(self.h, ptr(out))
+        return out

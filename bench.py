@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the per-frame dense surfel pipeline on MI355X (BASELINE.json metric).
+
+One "step" = one 640x480 RGB-D frame through the whole hot path: preprocess -> 3-level ICP+RGB
+tracking (SO(3) pre-alignment, 4/5/10 Gauss-Newton iterations) -> index map -> association/fusion
+-> index map -> clean/append -> surfel-id render -> splat prediction + fill-in, plus the instance
+layer at the reference's adaptive cadence (whetherDoSegmentation every frame; mask clean-up, vote
+update and the label scan when it fires), into a pre-populated synthetic N-surfel map (default 5M).
+Frames are resident in HBM before the timed region starts.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run
+(one rank per GPU, RCCL): every rank runs the same workload on its own stream + map replica
+("replicas only" -- DESIGN.md section Multi-GPU), barrier + synchronize on both sides of the timed
+region, max over ranks, rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(kernel: str, n_slots: int, P: int) -> float:
+    """Algorithmic HBM bytes of ONE launch of `kernel` (DESIGN.md 'Kernels and rooflines')."""
+    lv = {"": P}
+    table = {
+        "index_project": n_slots * 24.0,          # pos+conf 16 B + times 8 B per slot
+        "splat_raster": n_slots * 24.0,           # same streams (normal/radius only for visible surfels, not counted)
+        "ids_raster": n_slots * 16.0,             # pos+conf 16 B per slot
+        "clean_old": n_slots * 40.0,              # times 8 + pos 16 + normal/radius 16
+        "count_colour": n_slots * (192.0 + 8 + 8 + 4),
+        "icp": P * 48.0,                          # level-0 launch: 24 B coalesced + 24 B gathered per pixel
+        "rgb_residual": P * (14.0 + 8.0),
+        "rgb_step": P * (8.0 + 4.0 + 12.0),
+        "bilateral_metric": P * (2.0 + 2 + 4 + 4),
+        "splat_resolve": P * (8.0 + 16 + 16 + 4 + 4 + 2 + 16 + 16 + 4),
+        "index_resolve": P * (8.0 + 4 + 48),
+        "associate": P * (4.0 * 4 + 3 + 40),
+    }
+    return table.get(kernel, 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--surfels", type=int, default=5_000_000)
+    ap.add_argument("--loop", type=int, default=90, help="length of the closed camera loop (frames)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-instance", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    import instancefusion_amd as ifx
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    P = W * H
+    L = args.loop
+    t_gen = time.time()
+    st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + rank, **K)
+    masks = [synth.canned_masks(st["obj"][i], st["scene"]) for i in range(L)]
+    tick0 = 1000
+    m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + rank)
+    t_gen = time.time() - t_gen
+
+    cap = args.surfels + 1_500_000
+    ef = ifx.ElasticFusion(w=W, h=H, max_surfels=cap, device=dev, **K)
+    inst = ifx.InstanceFusion(ef)
+    d_rgb = torch.from_numpy(st["rgb"]).cuda(dev)
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda(dev)
+    torch.cuda.synchronize()
+
+    # frame 0 initialises the tracker's previous-image pyramid; then the synthetic map replaces the
+    # first-frame map and the model prediction is re-rendered from it
+    ef.processFrame(st["rgb"][0], st["depth"][0])
+    ef.upload(m)
+    ef.set_pose(st["poses"][0], tick0)
+    ef.combined_predict(st["poses"][0], tick0, tick0)
+    del m
+
+    frame_no = [0]
+
+    def step(k):
+        i = k % L
+        ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
+        frame_no[0] += 1
+        if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
+            mk, cl = masks[i]
+            if mk.shape[0]:
+                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ef.sync()
+
+    k0 = 1
+    for k in range(k0, k0 + args.warmup):
+        step(k)
+    barrier()
+    ef.stage_ms(reset=True)
+    t0 = time.perf_counter()
+    for k in range(k0 + args.warmup, k0 + args.warmup + args.steps):
+        step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    stage = ef.stage_ms(reset=True)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_live, n_slots = ef.count, ef.slots
+    traj = ef.trajectory()
+    # trajectory error vs the synthetic ground truth over the timed frames (diagnostic)
+    gt = np.stack([st["poses"][(k0 + args.warmup + j) % L] for j in range(args.steps)])
+    est = traj[-args.steps:]
+    ate = float(np.sqrt(np.mean(np.sum((est[:, :3, 3] - gt[:, :3, 3]) ** 2, axis=1)))) if len(est) == args.steps else float("nan")
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the handle's stream
+    roof = None
+    if rank == 0:
+        ef.set_option("kernel_timing", 1)
+        ef.kernel_ms("__reset__")
+        kk = k0 + args.warmup + args.steps
+        for k in range(kk, kk + 20):
+            step(k)
+        ef.sync()
+        names = ["index_project", "splat_raster", "ids_raster", "clean_old", "count_colour", "icp", "rgb_residual", "rgb_step", "bilateral_metric",
+                 "splat_resolve", "index_resolve", "associate"]
+        best, table = None, {}
+        for nme in names:
+            avg, cnt = ef.kernel_ms(nme)
+            table[nme] = dict(avg_ms=avg, launches=cnt, total_ms=avg * cnt)
+            if cnt and (best is None or avg * cnt > table[best]["total_ms"]):
+                best = nme
+        ef.set_option("kernel_timing", 0)
+        if best:
+            b = algorithmic_bytes(best, n_slots, P)
+            if best in ("icp", "rgb_residual", "rgb_step"):
+                # averaged over the three pyramid levels: 10 + 5 + 4 launches per frame
+                b = b * (10 + 5 / 4.0 + 4 / 16.0) / 19.0
+            ach = b / (table[best]["avg_ms"] * 1e-3) / 1e9 if table[best]["avg_ms"] > 0 else 0.0
+            roof = dict(bound="hbm", kernel=best, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=None, avg_launch_ms=round(table[best]["avg_ms"], 5), bytes_per_launch=b,
+                        kernels={k: dict(avg_ms=round(v["avg_ms"], 5), launches=v["launches"]) for k, v in table.items()})
+
+    # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+
+        n_cpu = min(args.surfels, 5_000_000)
+        o = ol.Oracle(w=W, h=H, max_surfels=n_cpu + 1_000_000, **K)
+        o.process_frame(st["rgb"][0], st["depth"][0])
+        o.upload(synth.make_map(n_cpu, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7))
+        o.set_pose(st["poses"][0], tick0)
+        o.combined_predict(st["poses"][0], tick0, tick0)
+        tc = time.perf_counter()
+        for k in range(1, 1 + args.cpu_frames):
+            o.process_frame(st["rgb"][k % L], st["depth"][k % L])
+        tc = time.perf_counter() - tc
+        cpu = dict(value=round(args.cpu_frames / tc, 4), unit="frames/s", cores=1, kind="port",
+                   sample=f"{args.cpu_frames} frames of the same 640x480 stream into the same {n_cpu}-surfel synthetic map (no instance calls)")
+        o.close()
+
+    if rank == 0:
+        fps = world * args.steps / dt
+        out = {
+            "metric": "frames/s + ms/frame (ICP|fuse|instance) at 640x480, 5M surfels, 1/2/4/8 GPU",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"640x480 synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes, {args.surfels}-surfel map",
+                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": f"replicas x{world}", "loop_frames": L},
+            "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
+            "ate_rms_m": ate, "gen_s": round(t_gen, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -699,7 +699,7 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time)
     LAUNCH(h, "clean_new_flags", dim3(cdiv(h->P, 256)), dim3(256), k_clean_new_flags, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_ct, h->scan_flags);
     ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
-    LAUNCH(h, "append_new", dim3(cdiv(h->P, 256)), dim3(256), k_append_new, h->d_state, c, time, h->tick, h->scan_flags, h->scan_out, (const float4*)h->meas_pc,
+    LAUNCH(h, "append_new", dim3(cdiv(h->P, 256)), dim3(256), k_append_new, h->d_state, c, time, time, h->scan_flags, h->scan_out, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
     LAUNCH(h, "append_count", dim3(1), dim3(64), k_append_count, h->d_state, &h->d_state->seg_counts[0], h->cap);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)

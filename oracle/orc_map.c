@@ -428,7 +428,7 @@ static void associate_pixel(orc_t* o, const float* pose, int time, float weighti
     const uint8_t* c = &o->rgb[(j * w + i) * 3];
     m->col0 = orc_encode_color(c[0] / 255.0f, c[1] / 255.0f, c[2] / 255.0f);
     m->nr[0] = ng.x; m->nr[1] = ng.y; m->nr[2] = ng.z; m->nr[3] = get_radius(vf.z, nl.z, ifx, ify);
-    m->ic[0] = x; m->ic[1] = y; m->ic[2] = (float)o->tick; m->ic[3] = -2;
+    m->ic[0] = x; m->ic[1] = y; m->ic[2] = (float)time; m->ic[3] = -2;
 
     float xl = (x - cx) * ifx, yl = (y - cy) * ify;
     float lambda = sqrtf(xl * xl + yl * yl + 1);

@@ -176,6 +176,18 @@ class Oracle:
         self.L.orc_render_ids(self.h, ptr(p), mode)
         return self.image("ids_tmp")
 
+    def set_frame(self, rgb, depth):
+        """upload + preprocess only (map, pose and tick untouched)"""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        self.L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.orc_set_frame(self.h, ptr(rgb), ptr(depth))
+
+    def set_ids_after(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self.L.orc_set_ids_after.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_set_ids_after(self.h, ptr(ids))
+
     def should_segment(self, frame):
         return bool(self.L.orc_should_segment(self.h, frame))
 

@@ -1,0 +1,327 @@
+"""GPU parity tests: the HIP path (libifx.so through its C-ABI) against the CPU oracle on identical
+seeded inputs.  Integer / index / byte outputs must match exactly; float outputs computed by the
+same per-element formula must match exactly too (both sides are built without FMA contraction and
+share the deterministic expf); reductions (29-float normal equations) match to rel 1e-4 and poses
+to 1e-5 (north star: trajectory within 1e-4 m RMS)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import SMALL
+from gputest_protocol import HALF_K, protocol_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ifx():
+    import instancefusion_amd as m
+
+    m.lib()
+    return m
+
+
+def nan_equal(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def orc_trk_buf(orc, t, name, level, w, h):
+    specs = {"vmap_curr": (np.float32, (3, h, w)), "nmap_curr": (np.float32, (3, h, w)), "vmap_prev": (np.float32, (3, h, w)),
+             "nmap_prev": (np.float32, (3, h, w)), "last_depth": (np.float32, (h, w)), "last_img": (np.uint8, (h, w)), "next_img": (np.uint8, (h, w)),
+             "lastnext_img": (np.uint8, (h, w)), "didx": (np.int16, (h, w)), "didy": (np.int16, (h, w)), "cloud": (np.float32, (h, w, 3)),
+             "depth_tmp": (np.uint16, (h, w))}
+    dt, shp = specs[name]
+    p = orc.lib().orc_tracker_buffer(t, name.encode(), level)
+    n = int(np.prod(shp)) * np.dtype(dt).itemsize
+    return np.frombuffer((C.c_char * n).from_address(p), dt).reshape(shp).copy()
+
+
+# ---------------------------------------------------------------- a2: preprocessing
+def test_preprocess_exact(ifx, orc, small_stream):
+    g = ifx.ElasticFusion(**SMALL, max_surfels=1000)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    rgb, dep = small_stream["rgb"][3], small_stream["depth"][3].copy()
+    dep[:7, :9] = 0          # holes
+    dep[100:110, 50:60] = 150  # below the 300 mm gate
+    g.set_frame(rgb, dep)
+    o.process_frame(rgb, dep)
+    for name in ("depth_filtered", "depth_metric", "depth_metric_filtered"):
+        assert np.array_equal(g.image(name), o.image(name)), name
+    g.close(); o.close()
+
+
+# ---------------------------------------------------------------- a3-a8: tracker on the reference's RGB-D pair
+def test_tracker_gputest_pair(ifx, orc, gputest_pair, oracle_pins):
+    L = orc.lib()
+    h, w = gputest_pair[1].shape
+    V, N, rgba, prev, depth_mm, rgb = protocol_inputs(*gputest_pair)
+    g = ifx.ElasticFusion(w=w, h=h, max_surfels=1000, **HALF_K)
+    pose, diag = g.track_pair(V, N, rgba, prev, depth_mm, rgb, np.eye(4))
+    # real sensor data: reduction-order differences (f32 wave trees vs sequential f64) move a few
+    # threshold decisions; tolerance = the north star's 1e-4 (measured 2.5e-5)
+    assert np.abs(pose - oracle_pins["pose_pyr"]).max() < 1e-4
+    assert np.allclose(diag[:6], oracle_pins["diag_pyr"][:6], rtol=5e-3)
+    # pyramid buffers against a live oracle tracker
+    t = L.orc_tracker_create(w, h, HALF_K["fx"], HALF_K["fy"], HALF_K["cx"], HALF_K["cy"])
+    L.orc_tracker_init_first_rgb(t, orc.ptr(prev))
+    p0 = np.eye(4, dtype=np.float32).reshape(16).copy()
+    L.orc_tracker_init_model(t, orc.ptr(V), orc.ptr(N), orc.ptr(rgba), orc.ptr(p0))
+    L.orc_tracker_init_frame(t, orc.ptr(depth_mm), orc.ptr(rgb), 20.0)
+    L.orc_tracker_run(t, orc.ptr(p0), 10.0, 1, 0, 1, None)
+    for lvl in range(3):
+        lw, lh = w >> lvl, h >> lvl
+        for name in ("vmap_curr", "nmap_curr", "vmap_prev", "nmap_prev", "last_depth", "last_img", "didx", "didy", "depth_tmp"):
+            a, b = g.tracker_buffer(name, lvl), orc_trk_buf(orc, t, name, lvl, lw, lh)
+            if a.dtype == np.float32:
+                if name in ("vmap_curr", "nmap_curr"):   # only the x plane is defined where invalid (cudafuncs.cu:130,161)
+                    bad = np.isnan(b[0])
+                    assert np.array_equal(np.isnan(a[0]), bad), (name, lvl)
+                    assert np.array_equal(a[:, ~bad], b[:, ~bad]), (name, lvl)
+                else:
+                    assert nan_equal(a, b), (name, lvl)
+            else:
+                assert np.array_equal(a, b), (name, lvl)
+        # after the run the so3 swap made "lastnext" hold this frame's intensity pyramid on both sides
+        assert np.array_equal(g.tracker_buffer("lastnext_img", lvl), orc_trk_buf(orc, t, "lastnext_img", lvl, lw, lh))
+    L.orc_tracker_destroy(t)
+    g.close()
+
+
+def test_reduction_stage_api(ifx, orc, gputest_pair):
+    """icpStep / computeRgbResidual / rgbStep / so3Step replacements on device pointers."""
+    import torch
+
+    L, G = orc.lib(), ifx.lib()
+    h, w = gputest_pair[1].shape
+    V, N, rgba, prev, depth_mm, rgb = protocol_inputs(*gputest_pair)
+    t = L.orc_tracker_create(w, h, HALF_K["fx"], HALF_K["fy"], HALF_K["cx"], HALF_K["cy"])
+    L.orc_tracker_init_first_rgb(t, orc.ptr(prev))
+    p0 = np.eye(4, dtype=np.float32).reshape(16).copy()
+    L.orc_tracker_init_model(t, orc.ptr(V), orc.ptr(N), orc.ptr(rgba), orc.ptr(p0))
+    L.orc_tracker_init_frame(t, orc.ptr(depth_mm), orc.ptr(rgb), 20.0)
+    L.orc_sobel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g = ifx.ElasticFusion(w=w, h=h, max_surfels=1000, **HALF_K)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16) if a.dtype == np.uint16 else np.ascontiguousarray(a)).cuda()
+    ang = 0.01
+    Rc = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    tc = np.array([0.004, -0.002, 0.003], np.float32)
+    I3 = np.eye(3, dtype=np.float32); z3 = np.zeros(3, np.float32)
+    for lvl in range(3):
+        lw, lh = w >> lvl, h >> lvl
+        div = float(1 << lvl)
+        fx, fy, cx, cy = HALF_K["fx"] / div, HALF_K["fy"] / div, HALF_K["cx"] / div, HALF_K["cy"] / div
+        b = {n: orc_trk_buf(orc, t, n, lvl, lw, lh) for n in ("vmap_curr", "nmap_curr", "vmap_prev", "nmap_prev", "last_depth", "last_img", "next_img", "lastnext_img")}
+        d = {n: dev(np.nan_to_num(v, nan=np.nan)) for n, v in b.items()}
+        # --- icp
+        L.orc_icp_step.argtypes = [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p] * 2 + [C.c_float] * 2 + [C.c_int] * 2 + [C.c_void_p]
+        ref = np.zeros(29, np.float32); got = np.zeros(29, np.float32)
+        sn = np.float32(np.sin(20.0 * 3.14159254 / 180.0))
+        L.orc_icp_step(orc.ptr(Rc.reshape(9).copy()), orc.ptr(tc), orc.ptr(b["vmap_curr"]), orc.ptr(b["nmap_curr"]), orc.ptr(I3.reshape(9).copy()), orc.ptr(z3), fx, fy, cx, cy,
+                       orc.ptr(b["vmap_prev"]), orc.ptr(b["nmap_prev"]), 0.10, sn, lw, lh, orc.ptr(ref))
+        r = G.ifx_icp_step(g.handle, orc.ptr(Rc.reshape(9).copy()), orc.ptr(tc), d["vmap_curr"].data_ptr(), d["nmap_curr"].data_ptr(), orc.ptr(I3.reshape(9).copy()), orc.ptr(z3),
+                           fx, fy, cx, cy, d["vmap_prev"].data_ptr(), d["nmap_prev"].data_ptr(), 0.10, sn, lw, lh, orc.ptr(got))
+        assert r == 0 and got[28] == ref[28] and ref[28] > 100
+        assert np.allclose(got, ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max())
+        # --- rgb residual + rgb step
+        didx = np.zeros((lh, lw), np.int16); didy = np.zeros((lh, lw), np.int16)
+        L.orc_sobel(orc.ptr(b["next_img"]), lw, lh, orc.ptr(didx), orc.ptr(didy))
+        cloud = np.zeros((lh, lw, 3), np.float32)
+        L.orc_project_cloud.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p]
+        L.orc_project_cloud(orc.ptr(b["last_depth"]), lw, lh, fx, fy, cx, cy, orc.ptr(cloud))
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+        krk = (K @ Rc.astype(np.float64).T @ np.linalg.inv(K)).astype(np.float32).reshape(9).copy()
+        kt = (K @ (-Rc.astype(np.float64).T @ tc)).astype(np.float32)
+        dt_ref = np.zeros((lh, lw), np.dtype([("zx", np.int16), ("zy", np.int16), ("ox", np.int16), ("oy", np.int16), ("diff", np.float32), ("valid", np.int32)]))
+        cnt, sig = C.c_int(), C.c_int()
+        L.orc_rgb_residual.argtypes = [C.c_float] + [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        min_scale = float((5, 3, 1)[lvl] ** 2 * 64)
+        L.orc_rgb_residual(min_scale, orc.ptr(didx), orc.ptr(didy), orc.ptr(b["last_depth"]), orc.ptr(b["last_depth"]), orc.ptr(b["last_img"]), orc.ptr(b["next_img"]),
+                           orc.ptr(dt_ref), 0.07, orc.ptr(kt), orc.ptr(krk), lw, lh, C.byref(cnt), C.byref(sig))
+        d_didx, d_didy, d_cloud = dev(didx), dev(didy), dev(cloud)
+        d_cor = torch.zeros(lw * lh * 2, dtype=torch.int32).cuda()
+        gc, gs = C.c_int(), C.c_int()
+        r = G.ifx_rgb_residual(g.handle, min_scale, d_didx.data_ptr(), d_didy.data_ptr(), d["last_depth"].data_ptr(), d["last_depth"].data_ptr(), d["last_img"].data_ptr(),
+                               d["next_img"].data_ptr(), d_cor.data_ptr(), 0.07, orc.ptr(kt), orc.ptr(krk), lw, lh, C.byref(gc), C.byref(gs))
+        assert r == 0 and (gc.value, gs.value) == (cnt.value, sig.value)
+        cor = d_cor.cpu().numpy().view(ifx.CORRES_DTYPE).reshape(lh, lw)
+        valid = dt_ref["valid"] != 0
+        assert np.array_equal(cor["zx"] >= 0, valid)
+        assert np.array_equal(cor["zx"][valid], dt_ref["zx"][valid]) and np.array_equal(cor["zy"][valid], dt_ref["zy"][valid])
+        assert np.array_equal(cor["diff"][valid], dt_ref["diff"][valid])
+        if cnt.value:
+            L.orc_rgb_step.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+            sigma = float(np.sqrt(cnt.value))
+            L.orc_rgb_step(orc.ptr(dt_ref), sigma, orc.ptr(cloud), fx, fy, orc.ptr(didx), orc.ptr(didy), 0.125, lw, lh, orc.ptr(ref))
+            r = G.ifx_rgb_step(g.handle, d_cor.data_ptr(), sigma, d_cloud.data_ptr(), fx, fy, d_didx.data_ptr(), d_didy.data_ptr(), 0.125, lw, lh, orc.ptr(got))
+            assert r == 0 and got[28] == ref[28]
+            assert np.allclose(got, ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max())
+        # --- so3
+        Kinv = np.linalg.inv(K)
+        Rs = np.array([[1, 0, 0.004], [0, 1, -0.003], [-0.004, 0.003, 1]], np.float64)
+        ib = (K @ Rs @ Kinv).astype(np.float32).reshape(9).copy(); kinv = Kinv.astype(np.float32).reshape(9).copy(); krlr = (K @ Rs).astype(np.float32).reshape(9).copy()
+        L.orc_so3_step.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]
+        r11 = np.zeros(11, np.float32); g11 = np.zeros(11, np.float32)
+        L.orc_so3_step(orc.ptr(b["lastnext_img"]), orc.ptr(b["next_img"]), orc.ptr(ib), orc.ptr(kinv), orc.ptr(krlr), lw, lh, orc.ptr(r11))
+        r = G.ifx_so3_step(g.handle, d["lastnext_img"].data_ptr(), d["next_img"].data_ptr(), orc.ptr(ib), orc.ptr(kinv), orc.ptr(krlr), lw, lh, orc.ptr(g11))
+        assert r == 0 and g11[10] == r11[10]
+        assert np.allclose(g11, r11, rtol=2e-4, atol=1e-6 * np.abs(r11).max())
+    L.orc_tracker_destroy(t)
+    g.close()
+
+
+# ---------------------------------------------------------------- a9-a15: map stages on identical map states
+def _run_to_state(ifx, orc, st, n_frames):
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    for i in range(n_frames):
+        o.process_frame(st["rgb"][i], st["depth"][i])
+    return g, o
+
+
+MAP_KEYS = ("pc", "nr", "col", "tm", "ic", "votes")
+
+
+def test_map_stages_exact(ifx, orc, small_stream):
+    st = small_stream
+    g, o = _run_to_state(ifx, orc, st, 6)
+    m = o.download()
+    m["pc"][::3, 3] = 15.0    # make a third of the surfels stable so that splats / id discs are drawn
+    o.upload(m); g.upload(m)
+    pose = st["poses"][6].astype(np.float32)
+    tick = o.tick
+    # index map (predictIndices)
+    o.predict_indices(pose, tick); g.predict_indices(pose, tick)
+    for name in ("index", "index_vc", "index_ct", "index_nr"):
+        assert np.array_equal(g.image(name), o.image(name)), name
+    assert (o.image("index") > 0).mean() > 0.5
+    # splat prediction + fill-in (combinedPredict + FillIn)
+    # both sides see frame 6 (upload + preprocessing only; maps untouched) for the fill-in
+    g.set_frame(st["rgb"][6], st["depth"][6])
+    o.set_frame(st["rgb"][6], st["depth"][6])
+    o.combined_predict(pose, tick, tick); g.combined_predict(pose, tick, tick)
+    for name in ("pred_vertex", "pred_normal", "pred_image", "pred_inst", "pred_time"):
+        assert np.array_equal(g.image(name), o.image(name)), name
+    assert (o.image("pred_vertex")[..., 2] > 0).mean() > 0.2
+    # id render (renderSurfelIds), both modes
+    assert np.array_equal(g.render_ids(pose, 0), o.render_ids(pose, 0))
+    assert np.array_equal(g.render_ids(pose, 1), o.render_ids(pose, 1))
+    g.close(); o.close()
+
+
+def test_fuse_and_clean_exact(ifx, orc, small_stream):
+    st = small_stream
+    g, o = _run_to_state(ifx, orc, st, 6)
+    m = o.download()
+    g.upload(m)
+    pose = st["poses"][6].astype(np.float32)
+    tick = o.tick
+    g.set_frame(st["rgb"][6], st["depth"][6])
+    o.set_frame(st["rgb"][6], st["depth"][6])
+    o.predict_indices(pose, tick); g.predict_indices(pose, tick)
+    o.fuse(pose, tick, 0.75); g.fuse(pose, tick, 0.75)
+    o.predict_indices(pose, tick); g.predict_indices(pose, tick)
+    o.clean(pose, tick); g.clean(pose, tick)
+    mo, mg = o.download(), g.download()
+    assert mo["pc"].shape == mg["pc"].shape and mo["pc"].shape[0] != m["pc"].shape[0]
+    for k in MAP_KEYS:
+        assert np.array_equal(mo[k], mg[k]), k
+    g.close(); o.close()
+
+
+# ---------------------------------------------------------------- a1: whole frames, a16-a23: instance layer
+def test_end_to_end_sequence(ifx, orc, small_stream):
+    from instancefusion_amd import synth
+
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    inst = ifx.InstanceFusion(g)
+    err = []
+    for i in range(10):
+        pg = g.processFrame(st["rgb"][i], st["depth"][i])
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        err.append(np.linalg.norm(pg[:3, 3] - po[:3, 3]))
+        assert np.abs(pg - po).max() < 1e-4
+    assert np.sqrt(np.mean(np.square(err))) < 1e-5     # trajectory RMS vs the oracle (north star: 1e-4 m)
+    assert abs(g.count - o.count) <= max(4, o.count // 2000)
+    assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.005
+    assert np.allclose(g.trajectory()[-1], pg)
+    # instance layer on identical map states: upload the oracle's map into the GPU object
+    m = o.download(); m["pc"][:, 3] = np.maximum(m["pc"][:, 3], 12.0)
+    o.upload(m); g.upload(m)
+    pose = po
+    ids_o = o.render_ids(pose, 0); ids_g = g.render_ids(pose, 0)
+    assert np.array_equal(ids_o, ids_g)
+    # run one more frame with the pose held fixed so that both refresh ids_after from the same state
+    pg = g.processFrame(st["rgb"][9], st["depth"][9], inPose=pose); po2 = o.process_frame(st["rgb"][9], st["depth"][9], in_pose=pose)
+    assert np.array_equal(g.image("ids_after"), o.image("ids_after")) or (g.image("ids_after") != o.image("ids_after")).mean() < 0.002
+    masks, cls = synth.canned_masks(st["obj"][9], st["scene"])
+    assert inst.whetherDoSegmentation(100) == o.should_segment(100)
+    for frame in (100, 103):
+        inst.ProcessSegmentation(st["rgb"][9], st["depth"][9], masks, cls, frame)
+        o.process_segmentation(st["rgb"][9], st["depth"][9], masks, cls, frame)
+        assert np.array_equal(inst.getInstanceTable(), o.instance_table())
+        lg, lo = inst.labels(), o.labels()
+        if g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after")):
+            assert np.array_equal(lg, lo)                      # exact integer match of the instance IDs
+            assert np.array_equal(g.download()["votes"], o.download()["votes"])
+        else:
+            assert abs(len(lg) - len(lo)) <= 4
+    assert (lo >= 0).sum() > 100
+    assert np.array_equal(inst.maskCleanOverlap(masks), _clean(orc, masks))
+    g.close(); o.close()
+
+
+def _clean(orc, masks):
+    m = masks.copy()
+    L = orc.lib()
+    L.orc_mask_clean_overlap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_mask_clean_overlap(orc.ptr(m), m.shape[0], m.shape[2], m.shape[1])
+    return m
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+def test_full_size_properties(ifx):
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(8, W, H, noise=True, **K)
+    big = synth.make_map(1_000_000, st["scene"], st["poses_world"][0], 1000)
+
+    def run(compact_every_frame):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_600_000, **K)
+        g.set_option("compact_every_frame", compact_every_frame)
+        g.processFrame(st["rgb"][0], st["depth"][0])
+        g.upload(big); g.set_pose(st["poses"][0], 1000); g.combined_predict(st["poses"][0], 1000, 1000)
+        poses = [g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(1, 8)]
+        ids = g.image("ids_after")
+        slots, live = g.slots, g.count
+        assert ids.max() < slots and ids.min() >= 0
+        inst = ifx.InstanceFusion(g)
+        masks, cls = synth.canned_masks(st["obj"][7], st["scene"])
+        inst.ProcessSegmentation(st["rgb"][7], st["depth"][7], masks, cls, 200)
+        lab = inst.labels()
+        m = g.download()
+        g.close()
+        return np.stack(poses), m, lab, live
+
+    p1, m1, l1, n1 = run(0)
+    p2, m2, l2, n2 = run(1)
+    p3, m3, l3, n3 = run(0)
+    # determinism: identical inputs -> bit-identical outputs
+    assert np.array_equal(p1, p3) and all(np.array_equal(m1[k], m3[k]) for k in MAP_KEYS) and np.array_equal(l1, l3)
+    # tombstones + lazy compaction is equivalent to compacting every frame (order-preserving)
+    assert np.array_equal(p1, p2) and n1 == n2
+    assert all(np.array_equal(m1[k], m2[k]) for k in MAP_KEYS) and np.array_equal(l1, l2)
+    # compaction is idempotent and the label scan equals the decoded arg-max
+    v = np.trunc(m1["votes"]).astype(np.int64)
+    cnt = np.empty((v.shape[0], 96), np.int64)
+    cnt[:, 0::2] = (((v >> 16) & 0xFFFF) ^ 0x8000) - 0x8000
+    cnt[:, 1::2] = ((v & 0xFFFF) ^ 0x8000) - 0x8000
+    assert np.array_equal(l1, np.where(cnt.max(axis=1) > 0, cnt.argmax(axis=1), -1))
+    gt = st["poses"][1:8]
+    assert np.sqrt(np.mean(np.sum((p1[:, :3, 3] - gt[:, :3, 3]) ** 2, axis=1))) < 0.02

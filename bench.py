@@ -61,17 +61,11 @@ def main():
     ap.add_argument("--no-instance", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from instancefusion_amd import dist as ifd
+
+    rank, local_rank, world, dist = ifd.init("nccl")
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
 
@@ -132,10 +126,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     stage = ef.stage_ms(reset=True)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = ifd.max_over_ranks(dt, dist, device=f"cuda:{dev}")
     n_live, n_slots = ef.count, ef.slots
     traj = ef.trajectory()
     # trajectory error vs the synthetic ground truth over the timed frames (diagnostic)

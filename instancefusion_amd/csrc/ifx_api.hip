@@ -454,3 +454,18 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     HIPCHK(h, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     return (int)bytes;
 }
+
+#ifdef IFX_STAMPS
+void ifx_debug_copy2(long long* out);
+// diagnostic builds only (make FLAGS+=-DIFX_STAMPS): accumulated in-kernel cycle stamps
+extern "C" int ifx_debug_stamps(ifx_t* h, long long* out8, int reset)
+{
+    DevState hs;
+    int r = read_state(h, &hs);
+    if (r) return r;
+    memcpy(out8, hs.dbg, sizeof(hs.dbg));
+    ifx_debug_copy2(out8 + 8);
+    if (reset) { memset(hs.dbg, 0, sizeof(hs.dbg)); hipMemcpy((char*)h->d_state + offsetof(DevState, dbg), hs.dbg, sizeof(hs.dbg), hipMemcpyHostToDevice); }
+    return IFX_OK;
+}
+#endif

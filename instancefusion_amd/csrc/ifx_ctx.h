@@ -40,6 +40,7 @@ struct DevState {
     int rgb_count, rgb_sigma;
     // instance
     int seg_counts[2];
+    long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
 struct FrameResult {   // copied to pinned host memory at the end of every frame
@@ -74,7 +75,7 @@ struct ifx {
     int opt_compact_every_frame = 0;
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
-    int opt_icp_blocks = 256;
+    int opt_icp_blocks = 304;
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned
@@ -115,6 +116,7 @@ struct ifx {
     int* res_partials = nullptr;    // [blocks][2]
     float* so3_partials = nullptr;  // [blocks][12]
     float* d_out29 = nullptr;
+    unsigned int* d_ticket = nullptr;   // last-block ticket of k_rgb_step_solve
     // instance layer
     int32_t inst_class[IFX_NUM_INSTANCES];
     float inst_color[IFX_NUM_INSTANCES];

@@ -124,11 +124,25 @@ __device__ inline void vote_decode(float f, int& a, int& b)
 }
 
 // ---- wave64 / block reductions ------------------------------------------------------------
+// Full-wave sum with DPP (one VALU instruction per step, no LDS crossbar): quad swaps, row mirrors,
+// then the gfx9 row broadcasts.  The total lands in lane 63 (wave_sum_last); wave_sum() moves it to
+// every lane's view of lane 0 for the callers that want it there.  The first version used six
+// __shfl_down steps (ds_bpermute): 29 values x 6 steps cost 13k cycles per block (profiles r01).
+#define IFX_DPP_ADD(v, ctrl, rmask) ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xF, true)))
+__device__ __forceinline__ float wave_sum_last(float v)
+{
+    v = IFX_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    v = IFX_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    v = IFX_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+    v = IFX_DPP_ADD(v, 0x140, 0xF);   // row_mirror: every lane holds its 16-lane row sum
+    v = IFX_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3
+    v = IFX_DPP_ADD(v, 0x143, 0xC);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave sum
+    return v;
+}
 __device__ inline float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = wave_sum_last(v);
+    return __shfl(v, 63, 64);
 }
 __device__ inline double wave_sum_d(double v)
 {

@@ -291,22 +291,25 @@ __global__ void k_project_cloud(const float* __restrict__ depth, int w, int h, f
 
 // Block reduction of NV floats per thread: wave64 shuffle tree, one LDS row per wave, the first
 // NV threads add the rows in wave order and store the block partial.
-template <int NV>
+template <int NV, bool WRITE_THROUGH = false>
 __device__ inline void block_reduce_store(float* acc, float* __restrict__ out /* [NV] for this block */)
 {
     __shared__ float lds[RED_WAVES][NV];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        float v = wave_sum(acc[k]);
-        if (lane == 0) lds[wid][k] = v;
+        float v = wave_sum_last(acc[k]);
+        if (lane == 63) lds[wid][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < NV) {
         float s = 0;
 #pragma unroll
         for (int wv = 0; wv < RED_WAVES; wv++) s += lds[wv][threadIdx.x];
-        out[threadIdx.x] = s;
+        // WRITE_THROUGH: sc1 store for rows another block of the SAME launch reads (no release fence needed,
+        // cdna_hip_programming.md section 5 "In-launch split-K reduction", sc1 variant)
+        if (WRITE_THROUGH) __hip_atomic_store(&out[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[threadIdx.x] = s;
     }
 }
 
@@ -321,13 +324,24 @@ __device__ inline void products7(const float* row, bool found, float* acc)
     acc[28] += found ? 1.0f : 0.0f;
 }
 
+// Every reduction body handles IT pixels per thread in four straight-line stages -- coalesced
+// loads of all IT pixels, projection, dependent gathers of all IT pixels, arithmetic -- so that a
+// thread has all of its memory requests in flight together.  (The first version used a rolled
+// grid-stride loop: 4-5 serial iterations of two dependent round trips each made even the 19 200-px
+// level take 11 us.)  Pixel u of a thread is base + u * blockDim.x, i.e. coalesced across lanes.
+#define RED_IT 4
+#ifdef IFX_STAMPS
+__device__ long long g_dbg2[8];
+#define g_ts ts_local
+__shared__ long long s_dbg_blk[4];
+#endif
+
+struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
 // ICPReduction, EF/Cuda/reduce.cu:257-411.  Rcurr/tcurr/Rprev_inv/tprev come from DevState (or from
 // explicit arguments for the stage API when st == nullptr).
-struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
-__global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
-                                                     const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
-                                                     const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy, float distThres,
-                                                     float angleThres, int w, int h, float* __restrict__ partials)
+__device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __restrict__ st, const IcpArgs& ex, const float* __restrict__ vmap_curr,
+                                         const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx,
+                                         float fy, float cx, float cy, float distThres, float angleThres, int w, int h, float* __restrict__ partials)
 {
     const float* Rc = st ? st->Rcurr : ex.Rcurr;
     const float* tcp = st ? st->tcurr : ex.tcurr;
@@ -341,40 +355,63 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict_
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.f;
     const int N = w * h;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
-        int y = i / w, x = i - y * w;
-        float row[7] = {0, 0, 0, 0, 0, 0, 0};
-        bool found = false;
-        v3 vcurr = v3m(vmap_curr[i], vmap_curr[i + N], vmap_curr[i + 2 * N]);
-        if (!(vcurr.x != vcurr.x)) {
-            v3 vcurr_g = mulp(Rcurr, vcurr) + tc;
-            v3 vcurr_cp = mulp(Rprev_inv, vcurr_g - tp);
+    for (int base = bid * (blockDim.x * RED_IT) + threadIdx.x; base < N; base += nblk * blockDim.x * RED_IT) {
+        v3 vcurr[RED_IT], ncurr[RED_IT], vprev[RED_IT], nprev[RED_IT], vcurr_g[RED_IT];
+        int j[RED_IT];
+        bool inb[RED_IT];
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 1: coalesced loads
+            int i = base + u * blockDim.x;
+            bool in = i < N;
+            int ii = in ? i : 0;
+            vcurr[u] = v3m(vmap_curr[ii], vmap_curr[ii + N], vmap_curr[ii + 2 * N]);
+            ncurr[u] = v3m(nmap_curr[ii], nmap_curr[ii + N], nmap_curr[ii + 2 * N]);
+            if (!in) vcurr[u].x = qnan_f();
+        }
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 2: projection into the model frame
+            vcurr_g[u] = mulp(Rcurr, vcurr[u]) + tc;
+            v3 vcurr_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
             int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
             int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
-            if (!(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0)) {
-                int j = uy * w + ux;
-                v3 vprev_g = v3m(vmap_prev[j], vmap_prev[j + N], vmap_prev[j + 2 * N]);
-                v3 ncurr = v3m(nmap_curr[i], nmap_curr[i + N], nmap_curr[i + 2 * N]);
-                v3 ncurr_g = mulp(Rcurr, ncurr);
-                v3 nprev_g = v3m(nmap_prev[j], nmap_prev[j + N], nmap_prev[j + 2 * N]);
-                float dist = norm(vprev_g - vcurr_g);
-                float sine = norm(cross(ncurr_g, nprev_g));
-                found = (sine < angleThres && dist <= distThres && !(ncurr.x != ncurr.x) && !(nprev_g.x != nprev_g.x));
+            inb[u] = !(vcurr[u].x != vcurr[u].x) && !(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0);
+            j[u] = inb[u] ? uy * w + ux : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 3: gathers
+            vprev[u] = v3m(vmap_prev[j[u]], vmap_prev[j[u] + N], vmap_prev[j[u] + 2 * N]);
+            nprev[u] = v3m(nmap_prev[j[u]], nmap_prev[j[u] + N], nmap_prev[j[u] + 2 * N]);
+        }
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 4: row of the normal equations
+            float row[7] = {0, 0, 0, 0, 0, 0, 0};
+            bool found = false;
+            if (inb[u]) {
+                v3 ncurr_g = mulp(Rcurr, ncurr[u]);
+                float dist = norm(vprev[u] - vcurr_g[u]);
+                float sine = norm(cross(ncurr_g, nprev[u]));
+                found = (sine < angleThres && dist <= distThres && !(ncurr[u].x != ncurr[u].x) && !(nprev[u].x != nprev[u].x));
                 if (found) {
-                    v3 s_cp = mulp(Rprev_inv, vcurr_g - tp);
-                    v3 d_cp = mulp(Rprev_inv, vprev_g - tp);
-                    v3 n_cp = mulp(Rprev_inv, nprev_g);
+                    v3 s_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
+                    v3 d_cp = mulp(Rprev_inv, vprev[u] - tp);
+                    v3 n_cp = mulp(Rprev_inv, nprev[u]);
                     v3 c = cross(s_cp, n_cp);
                     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
                     row[3] = c.x; row[4] = c.y; row[5] = c.z;
                     row[6] = dot(n_cp, s_cp - d_cp);
                 }
             }
+            products7(row, found, acc);
         }
-        (void)x;
-        products7(row, found, acc);
     }
-    block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * 32);
+    block_reduce_store<29>(acc, partials + (size_t)bid * 32);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
+                                                     const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
+                                                     const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy, float distThres,
+                                                     float angleThres, int w, int h, float* __restrict__ partials)
+{
+    icp_body(blockIdx.x, gridDim.x, st, ex, vmap_curr, nmap_curr, vmap_prev, nmap_prev, fx, fy, cx, cy, distThres, angleThres, w, h, partials);
 }
 
 // 8-byte correspondence record (the reference's DataTerm is 16 B, EF/Cuda/types.cuh:75-81: `one`
@@ -383,11 +420,10 @@ struct Corres8 { short zx, zy; float diff; };
 
 // RGBResidual, EF/Cuda/reduce.cu:739-863
 struct ResArgs { float krkinv[9], kt[3]; };
-__global__ __launch_bounds__(RED_THREADS) void k_rgb_residual(const DevState* __restrict__ st, ResArgs ex, float minScale, const int16_t* __restrict__ dIdx,
-                                                              const int16_t* __restrict__ dIdy, const float* __restrict__ lastDepth,
-                                                              const float* __restrict__ nextDepth, const uint8_t* __restrict__ lastImage,
-                                                              const uint8_t* __restrict__ nextImage, Corres8* __restrict__ corres, float maxDepthDelta,
-                                                              int w, int h, int* __restrict__ partials)
+__device__ __forceinline__ void residual_body(int bid, int nblk, const DevState* __restrict__ st, const ResArgs& ex, float minScale, const int16_t* __restrict__ dIdx,
+                                              const int16_t* __restrict__ dIdy, const float* __restrict__ lastDepth, const float* __restrict__ nextDepth,
+                                              const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, Corres8* __restrict__ corres,
+                                              float maxDepthDelta, int w, int h, int* __restrict__ partials, int* __restrict__ res_total = nullptr)
 {
     const float* kk = st ? st->krkinv : ex.krkinv;
     const float* ktp = st ? st->kt : ex.kt;
@@ -398,39 +434,59 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_residual(const DevState* __
     const int border = 16;
     const int N = w * h;
     int cnt = 0, sig = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += blockDim.x * gridDim.x) {
-        int i = k / w, j0 = k - i * w;
-        Corres8 c;
-        c.zx = -1; c.zy = -1; c.diff = 0.f;
-        if (i >= border && i < h - border && j0 >= border && j0 < w - border && j0 < w - 5 && i < h - 1) {
+    for (int base = bid * (blockDim.x * RED_IT) + threadIdx.x; base < N; base += nblk * blockDim.x * RED_IT) {
+        bool cand[RED_IT];
+        int kidx[RED_IT], gj[RED_IT];
+        float d1[RED_IT], td1[RED_IT];
+        uint8_t ni[RED_IT];
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 1: own-pixel tests (4x4 non-zero block, gradient gate) and depth
+            int k = base + u * blockDim.x;
+            kidx[u] = k;
+            bool in = k < N;
+            int kk2 = in ? k : 0;
+            int i = kk2 / w, j0 = kk2 - i * w;
+            bool ok = in && i >= border && i < h - border && j0 >= border && j0 < w - border && j0 < w - 5 && i < h - 1;
+            // inside the 16-px border the 4x4 block [i-2,i+2) x [j0-2,j0+2) is always in the image
+            int ci = ok ? i : 16, cj = ok ? j0 : 16;
             bool valid = true;
-            for (int u = max(i - 2, 0); u < min(i + 2, h); u++)
-                for (int v = max(j0 - 2, 0); v < min(j0 + 2, w); v++) valid = valid && (nextImage[u * w + v] > 0);
-            if (valid) {
-                short valx = dIdx[k], valy = dIdy[k];
-                float mTwo = (float)((valx * valx) + (valy * valy));
-                if (mTwo >= minScale) {
-                    int y = i, x = j0;
-                    float d1 = nextDepth[k];
-                    if (!(d1 != d1)) {
-                        float td1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
-                        int u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1);
-                        int v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1);
-                        if (u0 >= 0 && v0 >= 0 && u0 < w && v0 < h) {
-                            float d0 = lastDepth[v0 * w + u0];
-                            uint8_t li = lastImage[v0 * w + u0];
-                            if (d0 > 0 && fabsf(td1 - d0) <= maxDepthDelta && li != 0) {
-                                c.zx = (short)u0; c.zy = (short)v0;
-                                c.diff = (float)nextImage[k] - (float)li;
-                                cnt += 1;
-                                sig += (int)(c.diff * c.diff);
-                            }
-                        }
-                    }
-                }
-            }
+#pragma unroll
+            for (int a = -2; a < 2; a++)
+#pragma unroll
+                for (int b = -2; b < 2; b++) valid = valid && (nextImage[(ci + a) * w + cj + b] > 0);
+            short valx = dIdx[kk2], valy = dIdy[kk2];
+            float mTwo = (float)((valx * valx) + (valy * valy));
+            d1[u] = nextDepth[kk2];
+            ni[u] = nextImage[kk2];
+            cand[u] = ok && valid && (mTwo >= minScale) && !(d1[u] != d1[u]);
         }
-        corres[k] = c;
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 2: warp into the last image
+            int i = kidx[u] / w, j0 = kidx[u] - i * w;
+            int y = i, x = j0;
+            td1[u] = (float)(d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
+            int u0 = f2i_rn((d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
+            int v0 = f2i_rn((d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
+            cand[u] = cand[u] && (u0 >= 0 && v0 >= 0 && u0 < w && v0 < h);
+            gj[u] = cand[u] ? v0 * w + u0 : 0;
+        }
+        float d0[RED_IT];
+        uint8_t li[RED_IT];
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) { d0[u] = lastDepth[gj[u]]; li[u] = lastImage[gj[u]]; }   // stage 3: gathers
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {   // stage 4
+            Corres8 c;
+            c.zx = -1; c.zy = -1; c.diff = 0.f;
+            if (cand[u] && d0[u] > 0 && fabsf(td1[u] - d0[u]) <= maxDepthDelta && li[u] != 0) {
+                int v0 = gj[u] / w, u0 = gj[u] - v0 * w;
+                c.zx = (short)u0; c.zy = (short)v0;
+                c.diff = (float)ni[u] - (float)li[u];
+                cnt += 1;
+                sig += (int)(c.diff * c.diff);
+            }
+            if (kidx[u] < N) corres[kidx[u]] = c;
+        }
     }
     __shared__ int lds[RED_WAVES][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -441,23 +497,75 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_residual(const DevState* __
     if (threadIdx.x < 2) {
         int s = 0;
         for (int wv = 0; wv < RED_WAVES; wv++) s += lds[wv][threadIdx.x];
-        partials[blockIdx.x * 2 + threadIdx.x] = s;
+        partials[bid * 2 + threadIdx.x] = s;
+        // grand totals by integer atomics (exact in any order): the next launch reads two ints instead of reducing rows
+        if (res_total && s) atomicAdd(&res_total[threadIdx.x], s);
+    }
+}
+__global__ __launch_bounds__(RED_THREADS) void k_rgb_residual(const DevState* __restrict__ st, ResArgs ex, float minScale, const int16_t* __restrict__ dIdx,
+                                                              const int16_t* __restrict__ dIdy, const float* __restrict__ lastDepth,
+                                                              const float* __restrict__ nextDepth, const uint8_t* __restrict__ lastImage,
+                                                              const uint8_t* __restrict__ nextImage, Corres8* __restrict__ corres, float maxDepthDelta,
+                                                              int w, int h, int* __restrict__ partials)
+{
+    residual_body(blockIdx.x, gridDim.x, st, ex, minScale, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, corres, maxDepthDelta, w, h, partials);
+}
+
+// One launch for the two independent reductions of a Gauss-Newton iteration: blocks [0, nb_icp) run the
+// ICP reduction, blocks [nb_icp, nb_icp + nb_res) the photometric residual pass.
+struct PairArgs {
+    const float *vmap_curr, *nmap_curr, *vmap_prev, *nmap_prev;
+    float fx, fy, cx, cy, distThres, angleThres;
+    float minScale, maxDepthDelta;
+    const int16_t *dIdx, *dIdy;
+    const float* lastDepth;
+    const uint8_t *lastImage, *nextImage;
+    Corres8* corres;
+    int w, h, nb_icp, nb_res;
+    float* icp_partials;
+    int* res_partials;
+    int* res_total;
+};
+__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, PairArgs a)
+{
+    if ((int)blockIdx.x < a.nb_icp) {
+        IcpArgs ia;   // unused when st != nullptr
+        icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_partials);
+    } else {
+        ResArgs ra;
+        residual_body(blockIdx.x - a.nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.lastDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, a.w,
+                      a.h, a.res_partials, a.res_total);
     }
 }
 
 // RGBReduction, EF/Cuda/reduce.cu:494-619.  sigma is either explicit (stage API) or derived from the
 // residual pass's block partials with the reference's precedence quirk (EF/Utils/RGBDOdometry.cpp:461).
-__global__ __launch_bounds__(RED_THREADS) void k_rgb_step(const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
-                                                          int res_blocks, const float* __restrict__ cloud, float fx, float fy,
-                                                          const int16_t* __restrict__ dIdx, const int16_t* __restrict__ dIdy, float sobelScale, int w, int h,
-                                                          float* __restrict__ partials)
+__device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
+                                              int res_blocks, const float* __restrict__ cloud, float fx, float fy, const int16_t* __restrict__ dIdx,
+                                              const int16_t* __restrict__ dIdy, float sobelScale, int w, int h, float* __restrict__ partials, const int* __restrict__ res_total = nullptr)
 {
+#ifdef IFX_STAMPS
+    long long ts_local[3]; long long ts_start = clock64();
+#endif
+    const int N = w * h;
+    // stage 1 loads are issued before the sigma reduction so that both latencies overlap
+    const int base0 = bid * (blockDim.x * RED_IT) + threadIdx.x;
     float sigma = sigma_explicit;
-    if (res_partials) {
+    if (res_total) {
+        int cnt = res_total[0], sg = res_total[1];
+        float q = (float)sg / (float)cnt;
+        sigma = (float)sqrt((double)((q == 0) ? 1 : cnt));
+    } else if (res_partials) {
         __shared__ int s_cs[2];
         if (threadIdx.x < 64) {
             int cnt = 0, sg = 0;
-            for (int b = threadIdx.x; b < res_blocks; b += 64) { cnt += res_partials[2 * b]; sg += res_partials[2 * b + 1]; }
+            for (int b0 = threadIdx.x; b0 < res_blocks; b0 += 64 * 4) {
+                int c[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { int b = b0 + 64 * u; bool in = b < res_blocks; c[u] = in ? res_partials[2 * b] : 0; g[u] = in ? res_partials[2 * b + 1] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { cnt += c[u]; sg += g[u]; }
+            }
             cnt = wave_sum_i(cnt);
             sg = wave_sum_i(sg);
             if (threadIdx.x == 0) { s_cs[0] = cnt; s_cs[1] = sg; }
@@ -467,35 +575,68 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step(const Corres8* __restr
         float q = (float)sg / (float)cnt;
         sigma = (float)sqrt((double)((q == 0) ? 1 : cnt));
     }
+#ifdef IFX_STAMPS
+    g_ts[0] = clock64();
+#endif
     float acc[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.f;
-    const int N = w * h;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += blockDim.x * gridDim.x) {
-        Corres8 c = corres[k];
-        float row[7] = {0, 0, 0, 0, 0, 0, 0};
-        bool found = c.zx >= 0;
-        if (found) {
-            float wgt = sigma + fabsf(c.diff);
-            wgt = wgt > 1.19209290E-07F ? 1.0f / wgt : 1.0f;
-            if (sigma == -1) wgt = 1;
-            row[6] = -wgt * c.diff;
-            const float* cp = &cloud[(c.zy * w + c.zx) * 3];
-            float X = cp[0], Y = cp[1], Z = cp[2];
-            float invz = (float)(1.0 / Z);
-            float dI_dx = wgt * sobelScale * dIdx[k];
-            float dI_dy = wgt * sobelScale * dIdy[k];
-            float v0 = dI_dx * fx * invz;
-            float v1 = dI_dy * fy * invz;
-            float v2 = -(v0 * X + v1 * Y) * invz;
-            row[0] = v0; row[1] = v1; row[2] = v2;
-            row[3] = -Z * v1 + Y * v2;
-            row[4] = Z * v0 - X * v2;
-            row[5] = -Y * v0 + X * v1;
+    for (int base = base0; base < N; base += nblk * blockDim.x * RED_IT) {
+        Corres8 c[RED_IT];
+        float X[RED_IT], Y[RED_IT], Z[RED_IT];
+        short gx[RED_IT], gy[RED_IT];
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {
+            int k = base + u * blockDim.x;
+            bool in = k < N;
+            int kk = in ? k : 0;
+            c[u] = corres[kk];
+            gx[u] = dIdx[kk]; gy[u] = dIdy[kk];
+            if (!in) c[u].zx = -1;
         }
-        products7(row, found, acc);
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {
+            int g = (c[u].zx >= 0) ? ((int)c[u].zy * w + (int)c[u].zx) * 3 : 0;
+            X[u] = cloud[g]; Y[u] = cloud[g + 1]; Z[u] = cloud[g + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < RED_IT; u++) {
+            float row[7] = {0, 0, 0, 0, 0, 0, 0};
+            bool found = c[u].zx >= 0;
+            if (found) {
+                float wgt = sigma + fabsf(c[u].diff);
+                wgt = wgt > 1.19209290E-07F ? 1.0f / wgt : 1.0f;
+                if (sigma == -1) wgt = 1;
+                row[6] = -wgt * c[u].diff;
+                float invz = (float)(1.0 / Z[u]);
+                float dI_dx = wgt * sobelScale * gx[u];
+                float dI_dy = wgt * sobelScale * gy[u];
+                float v0 = dI_dx * fx * invz;
+                float v1 = dI_dy * fy * invz;
+                float v2 = -(v0 * X[u] + v1 * Y[u]) * invz;
+                row[0] = v0; row[1] = v1; row[2] = v2;
+                row[3] = -Z[u] * v1 + Y[u] * v2;
+                row[4] = Z[u] * v0 - X[u] * v2;
+                row[5] = -Y[u] * v0 + X[u] * v1;
+            }
+            products7(row, found, acc);
+        }
     }
-    block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * 32);
+#ifdef IFX_STAMPS
+    g_ts[1] = clock64();
+#endif
+    block_reduce_store<29, true>(acc, partials + (size_t)bid * 32);
+#ifdef IFX_STAMPS
+    g_ts[2] = clock64();
+    if (threadIdx.x == 0) { s_dbg_blk[0] = ts_local[0] - ts_start; s_dbg_blk[1] = ts_local[1] - ts_local[0]; s_dbg_blk[2] = ts_local[2] - ts_local[1]; }
+#endif
+}
+__global__ __launch_bounds__(RED_THREADS) void k_rgb_step(const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
+                                                          int res_blocks, const float* __restrict__ cloud, float fx, float fy,
+                                                          const int16_t* __restrict__ dIdx, const int16_t* __restrict__ dIdy, float sobelScale, int w, int h,
+                                                          float* __restrict__ partials)
+{
+    rgb_step_body(blockIdx.x, gridDim.x, corres, sigma_explicit, res_partials, res_blocks, cloud, fx, fy, dIdx, dIdy, sobelScale, w, h, partials);
 }
 
 // SO3Reduction, EF/Cuda/reduce.cu:938-1076
@@ -508,10 +649,9 @@ __device__ inline float grady(const uint8_t* img, int w, int px, int py)
 {
     return (((float)img[(py - 1) * w + px] + (float)img[py * w + px]) / 2.0f) - (((float)img[(py + 1) * w + px] + (float)img[py * w + px]) / 2.0f);
 }
-__global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict__ st, So3Args ex, const uint8_t* __restrict__ lastImage,
-                                                     const uint8_t* __restrict__ nextImage, int w, int h, float* __restrict__ partials)
+__device__ __forceinline__ void so3_body(int bid, int nblk, const DevState* __restrict__ st, const So3Args& ex, const uint8_t* __restrict__ lastImage,
+                                         const uint8_t* __restrict__ nextImage, int w, int h, float* __restrict__ partials)
 {
-    if (st && st->so3_done) return;   // wave-uniform early exit once the host-free loop has converged
     const float* ibp = st ? st->imageBasis : ex.ib;
     const float* kip = st ? st->kinv : ex.kinv;
     const float* krp = st ? st->krlr : ex.krlr;
@@ -522,7 +662,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict_
 #pragma unroll
     for (int k = 0; k < 11; k++) acc[k] = 0.f;
     const int N = w * h;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += blockDim.x * gridDim.x) {
+    for (int k = bid * blockDim.x + threadIdx.x; k < N; k += blockDim.x * nblk) {
         int y = k / w, x = k - y * w;
         v3 up = v3m((float)x, (float)y, 1.0f);
         v3 wp = mulp(ib, up);
@@ -550,50 +690,154 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict_
         acc[9] += row[3] * row[3];
         acc[10] += found ? 1.0f : 0.0f;
     }
-    block_reduce_store<11>(acc, partials + (size_t)blockIdx.x * 12);
+    block_reduce_store<11, true>(acc, partials + (size_t)bid * 12);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict__ st, So3Args ex, const uint8_t* __restrict__ lastImage,
+                                                     const uint8_t* __restrict__ nextImage, int w, int h, float* __restrict__ partials)
+{
+    if (st && st->so3_done) return;   // block-uniform early exit once the host-free loop has converged
+    so3_body(blockIdx.x, gridDim.x, st, ex, lastImage, nextImage, w, h, partials);
 }
 
 // ======================================================================= device-side solve (a8)
 
-template <typename T>
-__device__ void ldlt_solve(int n, const T* Ain, const T* bin, T* x, T tiny)
+// Pivoted LDLT (Eigen's LDLT as used by EF/Utils/RGBDOdometry.cpp:368,552).  Everything is
+// compile-time unrolled with predicated swaps so that the matrix lives in registers: a
+// runtime-indexed private array goes to scratch memory and made the first version of the solve
+// kernel take 24 us (profiles/r01_a_*).
+template <typename T, int N>
+__device__ __forceinline__ void ldlt_solve_n(const T* Ain, const T* bin, T* x, T tiny)
 {
-    T A[36], y[6];
-    int p[6];
-    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
-    for (int i = 0; i < n; i++) p[i] = i;
-    for (int k = 0; k < n; k++) {
+    T A[N * N], y[N], bb[N];
+    int p[N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) A[i] = Ain[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) { p[i] = i; bb[i] = bin[i]; }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
         int piv = k;
-        T big = A[k * n + k] < 0 ? -A[k * n + k] : A[k * n + k];
-        for (int i = k + 1; i < n; i++) {
-            T v = A[i * n + i] < 0 ? -A[i * n + i] : A[i * n + i];
+        T big = A[k * N + k] < 0 ? -A[k * N + k] : A[k * N + k];
+#pragma unroll
+        for (int i = k + 1; i < N; i++) {
+            T v = A[i * N + i] < 0 ? -A[i * N + i] : A[i * N + i];
             if (v > big) { big = v; piv = i; }
         }
-        if (piv != k) {
-            for (int j = 0; j < n; j++) { T t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
-            for (int j = 0; j < n; j++) { T t = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = t; }
-            int t = p[k]; p[k] = p[piv]; p[piv] = t;
+#pragma unroll
+        for (int i = k + 1; i < N; i++) {   // symmetric swap k <-> piv, predicated (no dynamic indexing)
+            const bool sw = (i == piv);
+#pragma unroll
+            for (int j = 0; j < N; j++) { T a = A[k * N + j], b = A[i * N + j]; A[k * N + j] = sw ? b : a; A[i * N + j] = sw ? a : b; }
+#pragma unroll
+            for (int j = 0; j < N; j++) { T a = A[j * N + k], b = A[j * N + i]; A[j * N + k] = sw ? b : a; A[j * N + i] = sw ? a : b; }
+            int pa = p[k], pb = p[i];
+            p[k] = sw ? pb : pa; p[i] = sw ? pa : pb;
         }
-        T d = A[k * n + k];
-        if (big <= (T)0) {
-            for (int i = k + 1; i < n; i++) A[i * n + k] = 0;
-            continue;
-        }
-        for (int i = k + 1; i < n; i++) A[i * n + k] = A[i * n + k] / d;
-        for (int i = k + 1; i < n; i++)
-            for (int j = k + 1; j < n; j++) A[i * n + j] -= A[i * n + k] * d * A[j * n + k];
+        const T d = A[k * N + k];
+        const bool zero = (big <= (T)0);
+#pragma unroll
+        for (int i = k + 1; i < N; i++) A[i * N + k] = zero ? (T)0 : A[i * N + k] / d;
+#pragma unroll
+        for (int i = k + 1; i < N; i++)
+#pragma unroll
+            for (int j = k + 1; j < N; j++) A[i * N + j] = zero ? A[i * N + j] : A[i * N + j] - A[i * N + k] * d * A[j * N + k];
     }
-    for (int i = 0; i < n; i++) y[i] = bin[p[i]];
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < i; j++) y[i] -= A[i * n + j] * y[j];
-    for (int i = 0; i < n; i++) {
-        T d = A[i * n + i];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        T v = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) v = (p[i] == j) ? bb[j] : v;
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= A[i * N + j] * y[j];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        T d = A[i * N + i];
         T ad = d < 0 ? -d : d;
         y[i] = (ad > tiny) ? y[i] / d : (T)0;
     }
-    for (int i = n - 1; i >= 0; i--)
-        for (int j = i + 1; j < n; j++) y[i] -= A[j * n + i] * y[j];
-    for (int i = 0; i < n; i++) x[p[i]] = y[i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < N; j++) y[i] -= A[j * N + i] * y[j];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        T v = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) v = (p[i] == j) ? y[i] : v;
+        x[j] = v;
+    }
+}
+
+// Unpivoted LDLT for the (symmetric positive semi-definite) 6x6 normal equations: the serial solve
+// sits on the critical path of every Gauss-Newton iteration, and the predicated pivot swaps of the
+// Eigen-style version cost ~1500 extra 64-bit selects on one lane.  For SPD input the two agree to
+// f64 rounding; a zero pivot gives a zero component, as Eigen's LDLT does (all-zero system when no
+// correspondence survives).
+template <typename T, int N>
+__device__ __forceinline__ void ldlt_nopivot(const T* Ain, const T* bin, T* x, T tiny)
+{
+    T A[N * N], y[N], inv[N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) A[i] = Ain[i];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const T d = A[k * N + k];
+        const T ad = d < 0 ? -d : d;
+        const bool zero = !(ad > tiny);
+        inv[k] = zero ? (T)0 : (T)1 / d;      // one division per pivot; a zero pivot gives a zero component
+#pragma unroll
+        for (int i = k + 1; i < N; i++) A[i * N + k] = A[i * N + k] * inv[k];
+#pragma unroll
+        for (int i = k + 1; i < N; i++)
+#pragma unroll
+            for (int j = k + 1; j <= i; j++) {
+                T v = A[i * N + j] - A[i * N + k] * d * A[j * N + k];
+                A[i * N + j] = v;
+                A[j * N + i] = v;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) y[i] = bin[i];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= A[i * N + j] * y[j];
+#pragma unroll
+    for (int i = 0; i < N; i++) y[i] = y[i] * inv[i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < N; j++) y[i] -= A[j * N + i] * y[j];
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = y[i];
+}
+
+// sin and cos of a small angle by Taylor series in f64 (|x| < 0.5: truncation < 1e-19); the libm
+// routines carry a Payne-Hanek path and cost several microseconds on a lone lane.
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c)
+{
+    if (!(fabs(x) < 0.5)) { *s = sin(x); *c = cos(x); return; }
+    const double x2 = x * x;
+    double ps = 1.0 / 6227020800.0;          // 1/13!
+    ps = ps * x2 - 1.0 / 39916800.0;         // 1/11!
+    ps = ps * x2 + 1.0 / 362880.0;           // 1/9!
+    ps = ps * x2 - 1.0 / 5040.0;
+    ps = ps * x2 + 1.0 / 120.0;
+    ps = ps * x2 - 1.0 / 6.0;
+    ps = ps * x2 + 1.0;
+    *s = ps * x;
+    double pc = 1.0 / 87178291200.0;         // 1/14!
+    pc = pc * x2 - 1.0 / 479001600.0;        // 1/12!
+    pc = pc * x2 + 1.0 / 3628800.0;          // 1/10!
+    pc = pc * x2 - 1.0 / 40320.0;
+    pc = pc * x2 + 1.0 / 720.0;
+    pc = pc * x2 - 1.0 / 24.0;
+    pc = pc * x2 + 0.5;
+    *c = 1.0 - pc * x2;
 }
 
 // OdometryProvider::rodrigues, EF/Utils/OdometryProvider.h:35-71
@@ -601,28 +845,38 @@ __device__ void rodrigues_d(const double* src, double* R)
 {
     double rx = src[0], ry = src[1], rz = src[2];
     double theta = sqrt(rx * rx + ry * ry + rz * rz);
+#pragma unroll
     for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
     if (theta >= DBL_EPSILON) {
-        double c = cos(theta), s = sin(theta), c1 = 1.0 - c;
+        double c, s;
+        sincos_small(theta, &s, &c);
+        double c1 = 1.0 - c;
         double it = theta ? 1.0 / theta : 0.0;
         rx *= it; ry *= it; rz *= it;
         double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
         double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+#pragma unroll
         for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx_[k];
     }
 }
 
-__device__ void matmul_d(int n, const double* A, const double* B, double* C)
+template <int N>
+__device__ __forceinline__ void matmul_dn(const double* A, const double* B, double* C)
 {
-    double T[16];
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) {
+    double T[N * N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) {
             double s = 0;
-            for (int k = 0; k < n; k++) s += A[i * n + k] * B[k * n + j];
-            T[i * n + j] = s;
+#pragma unroll
+            for (int k = 0; k < N; k++) s += A[i * N + k] * B[k * N + j];
+            T[i * N + j] = s;
         }
-    for (int i = 0; i < n * n; i++) C[i] = T[i];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) C[i] = T[i];
 }
+#define matmul_d(n, A, B, C) matmul_dn<n>(A, B, C)
 
 __device__ void k_matrix_d(float fx, float fy, float cx, float cy, double* K, double* Kinv)
 {
@@ -632,22 +886,36 @@ __device__ void k_matrix_d(float fx, float fy, float cx, float cy, double* K, do
     Kinv[2] = -K[2] / K[0]; Kinv[5] = -K[5] / K[4]; Kinv[8] = 1;
 }
 
-// writes krkinv / kt of the next residual pass from resultRt (EF/Utils/RGBDOdometry.cpp:424-434)
-__device__ void set_warp_matrices(DevState* st, float fx, float fy, float cx, float cy)
+// krkinv / kt of the next residual pass from resultRt (EF/Utils/RGBDOdometry.cpp:424-434), all in registers
+__device__ __forceinline__ void warp_from(const double* M, float fx, float fy, float cx, float cy, float* krk, float* kt)
 {
-    double K[9], Kinv[9], Rt[16];
-    k_matrix_d(fx, fy, cx, cy, K, Kinv);
-    const double* M = st->resultRt;
+    // K = [fx 0 cx; 0 fy cy; 0 0 1], Kinv = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1]
+    const double K0 = fx, K2 = cx, K4 = fy, K5 = cy;
+    const double I0 = 1.0 / K0, I4 = 1.0 / K4, I2 = -K2 / K0, I5 = -K5 / K4;
+    double R3[9], tt[3];
+#pragma unroll
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Rt[i * 4 + j] = M[j * 4 + i];
-    for (int i = 0; i < 3; i++) Rt[i * 4 + 3] = -(Rt[i * 4 + 0] * M[3] + Rt[i * 4 + 1] * M[7] + Rt[i * 4 + 2] * M[11]);
-    double R3[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
+#pragma unroll
+        for (int j = 0; j < 3; j++) R3[i * 3 + j] = M[j * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) tt[i] = -(R3[i * 3 + 0] * M[3] + R3[i * 3 + 1] * M[7] + R3[i * 3 + 2] * M[11]);
+    const double K[9] = {K0, 0, K2, 0, K4, K5, 0, 0, 1}, Kinv[9] = {I0, 0, I2, 0, I4, I5, 0, 0, 1};
     double KR[9], KRK[9];
     matmul_d(3, K, R3, KR);
     matmul_d(3, KR, Kinv, KRK);
-    for (int k = 0; k < 9; k++) st->krkinv[k] = (float)KRK[k];
-    double tt[3] = {Rt[3], Rt[7], Rt[11]};
-    for (int r = 0; r < 3; r++) st->kt[r] = (float)(K[r * 3] * tt[0] + K[r * 3 + 1] * tt[1] + K[r * 3 + 2] * tt[2]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) krk[k] = (float)KRK[k];
+#pragma unroll
+    for (int r = 0; r < 3; r++) kt[r] = (float)(K[r * 3] * tt[0] + K[r * 3 + 1] * tt[1] + K[r * 3 + 2] * tt[2]);
+}
+__device__ void set_warp_matrices(DevState* st, float fx, float fy, float cx, float cy)
+{
+    double M[16];
+    float krk[9], kt[3];
+    for (int k = 0; k < 16; k++) M[k] = st->resultRt[k];
+    warp_from(M, fx, fy, cx, cy, krk, kt);
+    for (int k = 0; k < 9; k++) st->krkinv[k] = krk[k];
+    for (int k = 0; k < 3; k++) st->kt[k] = kt[k];
 }
 
 __device__ void set_so3_matrices(DevState* st, float fx, float fy, float cx, float cy)
@@ -685,29 +953,24 @@ __global__ void k_track_begin(DevState* st, int so3, float fx2, float fy2, float
     if (so3) set_so3_matrices(st, fx2, fy2, cx2, cy2);
 }
 
-// one SO(3) iteration's host logic, EF/Utils/RGBDOdometry.cpp:348-380, on one wave
-__global__ void k_so3_update(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
+// one SO(3) iteration's host logic, EF/Utils/RGBDOdometry.cpp:348-380, executed by one wave
+// (fixed-order f64 sums of the block partials by shuffle; lane 0 then runs the scalar logic)
+__device__ __forceinline__ void so3_update_wave(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
 {
-    if (st->so3_done) return;
-    __shared__ double sums[11];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float o[11];
+#pragma unroll
     for (int k = 0; k < 11; k++) {
         double v = 0;
         for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 12 + k];
         v = wave_sum_d(v);
-        if (lane == 0) sums[k] = v;
+        o[k] = (float)v;
     }
-    __syncthreads();
     if (lane != 0) return;
-    float o[11];
-    for (int k = 0; k < 11; k++) o[k] = (float)sums[k];
     float jtj[9], jtr[3];
-    int shift = 0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = i; j < 4; ++j) {
-            float v = o[shift++];
-            if (j == 3) jtr[i] = v; else jtj[j * 3 + i] = jtj[i * 3 + j] = v;
-        }
+    jtj[0] = o[0]; jtj[1] = jtj[3] = o[1]; jtj[2] = jtj[6] = o[2]; jtr[0] = o[3];
+    jtj[4] = o[4]; jtj[5] = jtj[7] = o[5]; jtr[1] = o[6];
+    jtj[8] = o[7]; jtr[2] = o[8];
     float err = sqrtf(o[9]) / o[10], cnt = o[10];
     st->lastSO3Error = err; st->lastSO3Count = cnt;
     if (err < st->so3_lastError && st->so3_lastCount == cnt) { st->so3_done = 1; return; }
@@ -720,15 +983,49 @@ __global__ void k_so3_update(DevState* st, const float* __restrict__ partials, i
     st->so3_lastError = err; st->so3_lastCount = cnt;
     for (int k = 0; k < 9; k++) st->lastResultR[k] = st->resultR[k];
     float delta[3];
-    ldlt_solve<float>(3, jtj, jtr, delta, (float)(1.0 / FLT_MAX));
+    ldlt_solve_n<float, 3>(jtj, jtr, delta, (float)(1.0 / FLT_MAX));
     double dd[3] = {delta[0], delta[1], delta[2]}, ru[9];
     rodrigues_d(dd, ru);
-    float ruf[9], nr[9];
-    for (int k = 0; k < 9; k++) ruf[k] = (float)ru[k];
+    float ruf[9], nr[9], Rl[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { ruf[k] = (float)ru[k]; Rl[k] = st->R_lr[k]; }
+#pragma unroll
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) nr[i * 3 + j] = ruf[i * 3] * st->R_lr[j] + ruf[i * 3 + 1] * st->R_lr[3 + j] + ruf[i * 3 + 2] * st->R_lr[6 + j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) nr[i * 3 + j] = ruf[i * 3] * Rl[j] + ruf[i * 3 + 1] * Rl[3 + j] + ruf[i * 3 + 2] * Rl[6 + j];
+#pragma unroll
     for (int k = 0; k < 9; k++) { st->R_lr[k] = nr[k]; st->resultR[k] = nr[k]; }
     set_so3_matrices(st, fx2, fy2, cx2, cy2);
+}
+__global__ void k_so3_update(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
+{
+    if (st->so3_done) return;
+    so3_update_wave(st, partials, blocks, fx2, fy2, cx2, cy2);
+}
+
+// SO(3) reduction + (last block) update in one launch; same hand-off as k_rgb_step_solve.
+__global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int w, int h,
+                                                           float* __restrict__ partials, int nb, unsigned int* ticket, float fx2, float fy2, float cx2, float cy2)
+{
+    __shared__ int s_last;
+    if (st->so3_done) return;
+    So3Args ex;
+    so3_body(blockIdx.x, nb, st, ex, lastImage, nextImage, w, h, partials);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {   // partial rows were stored sc1 and every wave drained vmcnt before the barrier
+        unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(nb - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) so3_update_wave(st, partials, nb, fx2, fy2, cx2, cy2);
 }
 
 // after the SO(3) loop: seed resultRt and the first warp matrices (:392-403)
@@ -745,85 +1042,223 @@ __global__ void k_gn_begin(DevState* st, int so3, float fx, float fy, float cx, 
 // one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583 (icp && rgb branch
 // selected by the flags), on one block: fixed-order double sums of the block partials, 6x6 pivoted
 // LDLT in double, SE(3) update, next warp matrices.
-__global__ void k_gn_solve(DevState* st, const float* __restrict__ icp_partials, int icp_blocks, const float* __restrict__ rgb_partials, int rgb_blocks,
-                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy)
+__device__ __forceinline__ void gn_solve_block(DevState* st, const float* __restrict__ icp_partials, int icp_blocks, const float* __restrict__ rgb_partials, int rgb_blocks,
+                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy,
+                           int* __restrict__ res_total = nullptr)
 {
+    // fixed-order f64 sums of the block partials: thread t owns column k = t % 32 of block rows
+    // g, g+8, g+16, ... (g = t / 32), all loads independent and coalesced; the 8 row groups are then
+    // added in order through LDS.  (The first version walked the columns one after the other with a
+    // shuffle tree each: 15 dependent global round trips per wave, ~20 us.)
+    __shared__ double s_part[2][32][32];
     __shared__ double s_icp[29], s_rgb[29];
     __shared__ int s_res[2];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = wid; k < 58; k += nw) {
-        const float* src = k < 29 ? icp_partials : rgb_partials;
-        int nb = k < 29 ? icp_blocks : rgb_blocks, kk = k < 29 ? k : k - 29;
-        double v = 0;
-        for (int b = lane; b < nb; b += 64) v += (double)src[b * 32 + kk];
-        v = wave_sum_d(v);
-        if (lane == 0) { if (k < 29) s_icp[kk] = v; else s_rgb[kk] = v; }
-    }
-    if (wid == 0) {
-        for (int k = 0; k < 2; k++) {
-            int v = 0;
-            for (int b = lane; b < res_blocks; b += 64) v += res_partials[b * 2 + k];
-            v = wave_sum_i(v);
-            if (lane == 0) s_res[k] = v;
+    {
+        // every load of the hand-off is issued before any is used: 256 threads = 32 row groups x 8
+        // float4 columns; rows g, g+32, ... (<= 10 per array for <= 320 blocks) -> one memory round trip
+        const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+        {   // requires blockDim.x == 256 (RED_THREADS)
+            float4 ti[10], tr[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                // unconditional loads from a clamped row (no branch between the loads), masked afterwards
+                int b = g + 32 * u;
+                int bi = min(b, max(icp_blocks, 1) - 1), br = min(b, max(rgb_blocks, 1) - 1);
+                ti[u] = reinterpret_cast<const float4*>(icp_partials)[bi * 8 + c4];
+                tr[u] = reinterpret_cast<const float4*>(rgb_partials)[br * 8 + c4];
+            }
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                int b = g + 32 * u;
+                if (!(b < icp_blocks)) ti[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(b < rgb_blocks)) tr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            int c0 = 0, c1 = 0;
+            if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
+                if (threadIdx.x == 0) { c0 = res_total[0]; c1 = res_total[1]; res_total[0] = 0; res_total[1] = 0; }
+            } else {
+                int b = threadIdx.x;
+                int2 r0 = (b < res_blocks) ? reinterpret_cast<const int2*>(res_partials)[b] : make_int2(0, 0);
+                int2 r1 = (b + 256 < res_blocks) ? reinterpret_cast<const int2*>(res_partials)[b + 256] : make_int2(0, 0);
+                c0 = r0.x + r1.x; c1 = r0.y + r1.y;
+            }
+            if (threadIdx.x < 2) s_res[threadIdx.x] = 0;
+            double vi[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                vi[0] += (double)ti[u].x; vi[1] += (double)ti[u].y; vi[2] += (double)ti[u].z; vi[3] += (double)ti[u].w;
+                vr[0] += (double)tr[u].x; vr[1] += (double)tr[u].y; vr[2] += (double)tr[u].z; vr[3] += (double)tr[u].w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { s_part[0][g][c4 * 4 + q] = vi[q]; s_part[1][g][c4 * 4 + q] = vr[q]; }
+            __syncthreads();   // orders the s_res zeroing before the integer atomics below
+            c0 = wave_sum_i(c0);
+            c1 = wave_sum_i(c1);
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&s_res[0], c0); atomicAdd(&s_res[1], c1); }
         }
     }
+#ifdef IFX_STAMPS
+    long long ts_a = clock64();
+#endif
     __syncthreads();
+#ifdef IFX_STAMPS
+    long long ts_b = clock64();
+#endif
+    if (threadIdx.x < 58) {
+        const int which = threadIdx.x >= 29, k = threadIdx.x - 29 * which;
+        double v = 0;
+#pragma unroll
+        for (int g = 0; g < 32; g++) v += s_part[which][g][k];
+        if (which) s_rgb[k] = v; else s_icp[k] = v;
+    }
+    __syncthreads();
+#ifdef IFX_STAMPS
+    long long ts_c = clock64();
+#endif
     if (threadIdx.x != 0) return;
+    // ---- serial part on one lane.  Every input is read once into registers and every output is
+    // stored once at the end: a store to DevState followed by a load of the same field costs a full
+    // memory round trip on a lone lane (the first version did that five times per solve).
+    double RRt[16];
+    float Rp[9], tp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) RRt[k] = st->resultRt[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tp[k] = st->tprev[k];
     float oi[29], orr[29];
-    for (int k = 0; k < 29; k++) { oi[k] = icp ? (float)s_icp[k] : 0.f; orr[k] = rgb ? (float)s_rgb[k] : 0.f; st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
-    int rgbSize = rgb ? s_res[0] : 0, sigma = rgb ? s_res[1] : 0;
+#pragma unroll
+    for (int k = 0; k < 29; k++) { oi[k] = icp ? (float)s_icp[k] : 0.f; orr[k] = rgb ? (float)s_rgb[k] : 0.f; }
+    const int rgbSize = rgb ? s_res[0] : 0, sigma = rgb ? s_res[1] : 0;
+    double lA[36], lb[6];
+    {
+        const double wgt = icp_weight;
+        const double wa = (icp && rgb) ? wgt * wgt : (icp ? 1.0 : 0.0), wb = (icp && rgb) ? wgt : (icp ? 1.0 : 0.0), wr = rgb ? 1.0 : 0.0;
+        int shift = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) {
+                // lastA = A_rgb + w*w*A_icp, lastb = b_rgb + w*b_icp (EF/Utils/RGBDOdometry.cpp:547-565)
+                const double vi = (double)oi[shift], vr = (double)orr[shift];
+                shift++;
+                if (j == 6) lb[i] = (icp && rgb) ? vr + wb * vi : (icp ? vi : vr);
+                else { const double v = (icp && rgb) ? vr + wa * vi : (icp ? vi : vr); lA[j * 6 + i] = v; lA[i * 6 + j] = v; }
+            }
+        (void)wr;
+    }
+    double result[6];
+    ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
+    // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
+    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9];
+    rodrigues_d(&result[3], Rr);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) upd[r * 4 + c] = Rr[r * 3 + c];
+    upd[3] = result[0]; upd[7] = result[1]; upd[11] = result[2];
+    matmul_d(4, upd, RRt, RRt);
+    float oR[9], ot[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) oR[r * 3 + c] = (float)RRt[r * 4 + c];
+        ot[r] = (float)RRt[r * 4 + 3];
+    }
+    float iR[9], it[3], Rc[9], tc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) iR[r * 3 + c] = oR[c * 3 + r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) Rc[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
+        tc[r] = Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2] + tp[r];
+    }
+    float krk[9], kt[3];
+    warp_from(RRt, nfx, nfy, ncx, ncy, krk, kt);   // intrinsics of the level the NEXT iteration runs at
+    // ---- stores
+#pragma unroll
+    for (int k = 0; k < 16; k++) st->resultRt[k] = RRt[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krk[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { st->tcurr[k] = tc[k]; st->kt[k] = kt[k]; }
+#pragma unroll
+    for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
+#pragma unroll
+    for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
     st->rgb_count = rgbSize; st->rgb_sigma = sigma;
     st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
     st->lastRGBCount = (float)rgbSize;
     if (icp) { st->lastICPError = sqrtf(oi[27]) / oi[28]; st->lastICPCount = oi[28]; }
-    float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
-    {
-        int shift = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 7; ++j) {
-                float vi = oi[shift], vr = orr[shift];
-                shift++;
-                if (j == 6) { b_icp[i] = vi; b_rgb[i] = vr; }
-                else { A_icp[j * 6 + i] = A_icp[i * 6 + j] = vi; A_rgb[j * 6 + i] = A_rgb[i * 6 + j] = vr; }
-            }
+#ifdef IFX_STAMPS
+    { long long ts_d = clock64(); st->dbg[4] += ts_d - ts_c; st->dbg[6] += ts_b - ts_a; st->dbg[7] += ts_c - ts_b; st->dbg[3] += ts_a; }
+#endif
+}
+
+__global__ void k_gn_solve(DevState* st, const float* __restrict__ icp_partials, int icp_blocks, const float* __restrict__ rgb_partials, int rgb_blocks,
+                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy)
+{
+    gn_solve_block(st, icp_partials, icp_blocks, rgb_partials, rgb_blocks, res_partials, res_blocks, icp, rgb, icp_weight, nfx, nfy, ncx, ncy);
+}
+
+// Photometric reduction + (in the block that finishes last) the final sums and the 6x6 solve: the
+// second and last launch of a Gauss-Newton iteration.  Hand-off between blocks follows the
+// agent-scope release / acquire recipe of cdna_hip_programming.md section 6 G16 (counter form):
+// plain partial stores -> s_waitcnt vmcnt(0) -> barrier -> release fence -> ticket; the block that
+// draws the last ticket acquires and reads every partial.
+struct StepArgs {
+    const Corres8* corres;
+    const float* cloud;
+    float fx, fy, sobelScale;
+    const int16_t *dIdx, *dIdy;
+    int w, h, nb, nb_icp, nb_res;
+    float* rgb_partials;
+    const float* icp_partials;
+    const int* res_partials;
+    int* res_total;
+    int icp, rgb;
+    float icp_weight, nfx, nfy, ncx, ncy;
+    unsigned int* ticket;
+};
+__global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
+{
+    __shared__ int s_last;
+#ifdef IFX_STAMPS
+    long long t0 = clock64();
+#endif
+    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_partials, a.res_total);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef IFX_STAMPS
+    long long t1 = clock64();
+#endif
+    if (threadIdx.x == 0) {   // partial rows were stored sc1 and every wave drained vmcnt before the barrier
+        unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(a.nb - 1));
     }
-    double* lastA = st->lastA;
-    double* lastb = st->lastb;
-    if (icp && rgb) {
-        double wgt = icp_weight;
-        for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgb[k] + wgt * wgt * (double)A_icp[k];
-        for (int k = 0; k < 6; k++) lastb[k] = (double)b_rgb[k] + wgt * (double)b_icp[k];
-    } else if (icp) {
-        for (int k = 0; k < 36; k++) lastA[k] = A_icp[k];
-        for (int k = 0; k < 6; k++) lastb[k] = b_icp[k];
-    } else {
-        for (int k = 0; k < 36; k++) lastA[k] = A_rgb[k];
-        for (int k = 0; k < 6; k++) lastb[k] = b_rgb[k];
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch (stream order)
     }
-    double result[6];
-    ldlt_solve<double>(6, lastA, lastb, result, 1.0 / DBL_MAX);
-    // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
-    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9];
-    rodrigues_d(&result[3], Rr);
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) upd[r * 4 + c] = Rr[r * 3 + c];
-    upd[3] = result[0]; upd[7] = result[1]; upd[11] = result[2];
-    matmul_d(4, upd, st->resultRt, st->resultRt);
-    float oR[9], ot[3];
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) oR[r * 3 + c] = (float)st->resultRt[r * 4 + c];
-        ot[r] = (float)st->resultRt[r * 4 + 3];
-    }
-    float iR[9], it[3];
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) iR[r * 3 + c] = oR[c * 3 + r];
-    for (int r = 0; r < 3; r++) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
-    const float* Rp = st->Rprev;
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) st->Rcurr[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
-        st->tcurr[r] = Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2] + st->tprev[r];
-    }
-    set_warp_matrices(st, nfx, nfy, ncx, ncy);   // intrinsics of the level the NEXT iteration runs at
+    __syncthreads();
+#ifdef IFX_STAMPS
+    long long t2 = clock64();
+#endif
+    gn_solve_block(st, a.icp_partials, a.nb_icp, a.rgb_partials, a.nb, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total);
+#ifdef IFX_STAMPS
+    if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
+#endif
 }
 
 // rodrigues2, EF/ElasticFusion.cpp:1183-1228 (without the SVD re-orthonormalisation)
@@ -918,6 +1353,8 @@ int ifx_alloc_tracker(ifx* h)
     HIPCHK(h, hipMalloc(&h->res_partials, maxb * 2 * 4));
     HIPCHK(h, hipMalloc(&h->so3_partials, maxb * 12 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
+    HIPCHK(h, hipMalloc(&h->d_ticket, 64));
+    HIPCHK(h, hipMemset(h->d_ticket, 0, 64));
     return IFX_OK;
 }
 
@@ -929,12 +1366,12 @@ void ifx_free_tracker(ifx* h)
         hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]); hipFree(p.last_depth[i]); hipFree(p.last_img[i]); hipFree(p.next_img[i]);
         hipFree(p.lastnext_img[i]); hipFree(p.didx[i]); hipFree(p.didy[i]); hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
-    hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29);
+    hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
 static inline int red_blocks(ifx* h, int n)
 {
-    int b = cdiv(n, RED_THREADS * 4);
+    int b = cdiv(n, RED_THREADS * RED_IT);
     if (b > h->opt_icp_blocks) b = h->opt_icp_blocks;
     if (b < 1) b = 1;
     return b;
@@ -996,10 +1433,10 @@ static void tracker_run(ifx* h, float weight_mult)
     IcpArgs ia; ResArgs ra; So3Args sa;
     memset(&ia, 0, sizeof(ia)); memset(&ra, 0, sizeof(ra)); memset(&sa, 0, sizeof(sa));
     if (so3) {
-        int L = 2, n = p.w[L] * p.h[L], nb = red_blocks(h, n);
+        int L = 2, n = p.w[L] * p.h[L], nb = cdiv(n, RED_THREADS);
         for (int it = 0; it < 10; it++) {
-            LAUNCH(h, "so3", dim3(nb), dim3(RED_THREADS), k_so3, h->d_state, sa, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], h->so3_partials);
-            LAUNCH(h, "so3_update", dim3(1), dim3(64), k_so3_update, h->d_state, h->so3_partials, nb, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
+            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, h->d_state, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], h->so3_partials, nb, h->d_ticket + 4,
+                   c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
         }
     }
     int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
@@ -1022,17 +1459,21 @@ static void tracker_run(ifx* h, float weight_mult)
             int nl = i;
             if (j == iterations[i] - 1) { nl = i - 1; while (nl >= 0 && iterations[nl] == 0) nl--; if (nl < 0) nl = 0; }
             float nd = (float)(1 << nl);
-            if (rgb)
-                LAUNCH(h, "rgb_residual", dim3(nb), dim3(RED_THREADS), k_rgb_residual, h->d_state, ra, (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)), p.didx[i],
-                       p.didy[i], p.last_depth[i], p.last_depth[i], p.last_img[i], p.next_img[i], (Corres8*)p.corres[i], 0.07f, lw, lh, h->res_partials);
-            if (icp)
-                LAUNCH(h, "icp", dim3(nb), dim3(RED_THREADS), k_icp, h->d_state, ia, p.vmap_curr[i], p.nmap_curr[i], p.vmap_prev[i], p.nmap_prev[i], fx, fy, cx, cy, 0.10f,
-                       sinf(20.f * 3.14159254f / 180.f), lw, lh, h->icp_partials);
-            if (rgb)
-                LAUNCH(h, "rgb_step", dim3(nb), dim3(RED_THREADS), k_rgb_step, (const Corres8*)p.corres[i], 0.f, h->res_partials, nb, p.cloud[i], fx, fy, p.didx[i], p.didy[i],
-                       (float)sobelScale, lw, lh, h->rgb_partials);
-            LAUNCH(h, "gn_solve", dim3(1), dim3(256), k_gn_solve, h->d_state, h->icp_partials, nb, h->rgb_partials, nb, h->res_partials, nb, icp, rgb, c.icp_weight,
-                   c.fx / nd, c.fy / nd, c.cx / nd, c.cy / nd);
+            PairArgs pa;
+            pa.vmap_curr = p.vmap_curr[i]; pa.nmap_curr = p.nmap_curr[i]; pa.vmap_prev = p.vmap_prev[i]; pa.nmap_prev = p.nmap_prev[i];
+            pa.fx = fx; pa.fy = fy; pa.cx = cx; pa.cy = cy; pa.distThres = 0.10f; pa.angleThres = sinf(20.f * 3.14159254f / 180.f);
+            pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
+            pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
+            pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
+            pa.icp_partials = h->icp_partials; pa.res_partials = h->res_partials; pa.res_total = (int*)(h->d_ticket + 8);
+            LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, h->d_state, pa);
+            StepArgs sa2;
+            sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
+            sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb; sa2.nb_icp = nb; sa2.nb_res = nb;
+            sa2.rgb_partials = h->rgb_partials; sa2.icp_partials = h->icp_partials; sa2.res_partials = h->res_partials;
+            sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = c.icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
+            sa2.ticket = h->d_ticket; sa2.res_total = (int*)(h->d_ticket + 8);
+            LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, h->d_state, sa2);
         }
     }
     LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, rgb, 1, weight_mult);
@@ -1201,3 +1642,7 @@ extern "C" int ifx_tracker_buffer_download(ifx_t* h, const char* name, int l, vo
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return (int)bytes;
 }
+
+#ifdef IFX_STAMPS
+void ifx_debug_copy2(long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg2), 64); }
+#endif

@@ -94,6 +94,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->pc, C * 16); ALLOC(h->nr, C * 16); ALLOC(h->col, C * 8); ALLOC(h->tm, C * 8); ALLOC(h->ic, C * 16); ALLOC(h->votes, C * 192);
     ALLOC(h->pc2, C * 16); ALLOC(h->nr2, C * 16); ALLOC(h->col2, C * 8); ALLOC(h->tm2, C * 8); ALLOC(h->ic2, C * 16); ALLOC(h->votes2, C * 192);
     ALLOC(h->upd_owner, C * 4);
+    ALLOC(h->list_a, C * 4); ALLOC(h->list_b, C * 4); ALLOC(h->list_c, C * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
@@ -104,7 +105,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipHostMalloc((void**)&h->depth_stage, P * 2);
     ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8);
     hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8); hipMemset(h->key_ids, 0xFF, P * 8);
-    ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16); ALLOC(h->index_ct, P * 16); ALLOC(h->index_nr, P * 16);
+    ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16); ALLOC(h->index_ct, P * 16); ALLOC(h->index_nr, P * 16); ALLOC(h->index_tap, P * 16);
     ALLOC(h->pred_vertex, P * 16); ALLOC(h->pred_normal, P * 16); ALLOC(h->pred_image, P * 4); ALLOC(h->pred_inst, P * 4); ALLOC(h->pred_time, P * 2);
     ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
     ALLOC(h->ids_after, P * 4); ALLOC(h->ids_tmp, P * 4);
@@ -133,9 +134,9 @@ extern "C" void ifx_destroy(ifx_t* h)
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
-    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->rgb, h->depth_raw, h->depth_filt, h->dm, h->dmf, h->key_index, h->key_splat, h->key_ids,
-                    h->index_id, h->index_vc, h->index_ct, h->index_nr, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
+                    h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->h_result) hipHostFree(h->h_result);
@@ -403,6 +404,12 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     DevState hs;
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
     hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0;
+    {
+        float rmax = 0.f;
+        for (int i = 0; i < n; i++) { float r = nr[(size_t)i * 4 + 3]; if (r == r && r > rmax && r < 1e30f) rmax = r; }
+        unsigned int bits; memcpy(&bits, &rmax, 4);
+        if (bits > hs.r_max_bits) hs.r_max_bits = bits;
+    }
     HIPCHK(h, hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(h->upd_owner, 0xFF, (size_t)h->cap * 4));
     HIPCHK(h, hipMemset(h->labels, 0xFF, (size_t)h->cap * 4));

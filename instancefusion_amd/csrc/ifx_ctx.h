@@ -22,6 +22,8 @@ struct DevState {
     int n_dead;           // tombstones
     int n_new;            // new surfels appended by the last clean
     int overflow;         // set when an append hit the capacity
+    unsigned int list_n[4];   // lengths of the per-frame work lists (0: raster candidates, 1: clean candidates, 2: kill list)
+    unsigned int r_max_bits;  // float bits of an upper bound of every surfel radius ever stored (conservative frustum margin)
     // tracker state (RGBDOdometry::getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603)
     float Rprev[9], tprev[3], Rprev_inv[9];
     float Rcurr[9], tcurr[3];
@@ -71,6 +73,7 @@ struct ifx {
     hipStream_t stream = nullptr;
     std::string err;
     int tick = 1;
+    int ids_pending = 0;
     // options
     int opt_compact_every_frame = 0;
     int opt_kernel_timing = 0;
@@ -86,6 +89,7 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
+    uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [cap] work lists (surfel index | flags << 30)
     int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot
     int* scan_flags = nullptr;         // [max(cap,P)]
     int* scan_block = nullptr;
@@ -98,7 +102,7 @@ struct ifx {
     // index map
     unsigned long long *key_index = nullptr, *key_splat = nullptr, *key_ids = nullptr;
     uint32_t* index_id = nullptr;
-    float *index_vc = nullptr, *index_ct = nullptr, *index_nr = nullptr;
+    float *index_vc = nullptr, *index_ct = nullptr, *index_nr = nullptr, *index_tap = nullptr;
     // predictions
     float *pred_vertex = nullptr, *pred_normal = nullptr;
     uint8_t *pred_image = nullptr, *pred_inst = nullptr;

@@ -156,7 +156,9 @@ __global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const
     const uint8_t* cc = &rgb[(j * c.w + i) * 3];
     col[n] = make_float2(encode_color(cc[0] / 255.0f, cc[1] / 255.0f, cc[2] / 255.0f), 0.f);
     tm[n] = make_float2(1.f, (float)tick);
-    nr[n] = make_float4(nl.x, nl.y, nl.z, get_radius(vpf.z, nl.z, ifx_, ify_));
+    const float rad = get_radius(vpf.z, nl.z, ifx_, ify_);
+    nr[n] = make_float4(nl.x, nl.y, nl.z, rad);
+    if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad));
     ic[n] = make_float4(-1.f, -1.f, -1.f, -1.f);
     for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(-1.f, -1.f, -1.f, -1.f);
 }
@@ -176,6 +178,10 @@ int ifx_map_init_first(ifx* h)
     return IFX_OK;
 }
 
+// 64-bit atomicMin on a key image.  (A plain read first to skip atomics that cannot win was measured
+// and is slower: the no-return atomic is fire-and-forget, the read is a dependent round trip.)
+__device__ __forceinline__ void key_min(unsigned long long* __restrict__ addr, unsigned long long key) { atomicMin(addr, key); }
+
 // ------------------------------------------------------------------ index map (a10)
 // index_map.vert:40-66: per surfel 24 B (pos+conf 16, times 8), one 64-bit atomicMin per visible surfel.
 __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
@@ -194,13 +200,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
         float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
         if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
         int px = (int)floorf(u), py = (int)floorf(v);
-        atomicMin(&keys[py * c.w + px], make_key(p.z, (unsigned int)i));
+        key_min(&keys[py * c.w + px], make_key(p.z, (unsigned int)i));
     }
 }
 // index_map.frag:33-40: gathers the winner's attributes; also re-arms the key image for the next pass
 __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, int P, uint32_t* __restrict__ index_id,
-                                float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm)
+                                float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm, int time, float conf_thr, float4* __restrict__ tap)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -209,6 +215,7 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     if (key == IFX_KEY_EMPTY) {
         index_id[k] = 0;
         vc[k] = make_float4(0, 0, 0, 0); ct[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0);
+        if (tap) tap[k] = make_float4(0, 0, 0, 0);
         return;
     }
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
@@ -221,6 +228,9 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     vc[k] = make_float4(p.x, p.y, p.z, p4.w);
     ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y);
     nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
+    // 16-B record for the clean window taps: (x, y, z, initTime) with two flags in the (otherwise positive)
+    // signs: z < 0 <=> updated this frame (colorTime.w == time), w > 0 <=> stable (vertConf.w > confThreshold)
+    if (tap) tap[k] = (id > 0u && p.z > 0.f) ? make_float4(p.x, p.y, (t2.y == (float)time) ? -p.z : p.z, (p4.w > conf_thr) ? t2.x : -t2.x) : make_float4(0, 0, 0, 0);
 }
 
 static void index_pass(ifx* h, const float* d_pose_inv, int time)
@@ -228,7 +238,7 @@ static void index_pass(ifx* h, const float* d_pose_inv, int time)
     Cam c = make_cam(h);
     LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
     LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr);
+           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr);
 }
 
 // ------------------------------------------------------------------ disc rasteriser (a9, a14)
@@ -415,26 +425,276 @@ __global__ void k_dense(DevState* st, const uchar4* __restrict__ pimg, int w, in
     }
 }
 
-static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime)
+__device__ inline int clean_test(const float* T, const Cam& c, int time, float4 p4, float4 n4, float initT, float& lastT, const float4* __restrict__ tap);
+
+// ------------------------------------------------------------------ work-list passes
+// A map pass over N slots is split in two: (1) a pure streaming cull that reads 24 B per slot
+// (pos+conf, times), decides with a conservative frustum test and appends the few survivors to a
+// work list (wave ballot -> one atomicAdd per wave), and (2) a dense pass over the list that reads
+// normal+radius and does the expensive part (disc rasterisation / window taps) with every lane
+// busy.  The one-kernel versions above ran at 0.6-1.1 TB/s because the heavy path diverged inside
+// waves of mostly-culled surfels (profiles/r01_a: k_raster 205 us, k_clean_old 206 us for 5.6M slots).
+#define LIST_SPLAT 0x40000000u
+#define LIST_IDS 0x80000000u
+#define LIST_IDX 0x3FFFFFFFu
+
+// Block-aggregated list append: survivors of a 4096-slot chunk are collected in LDS (wave ballot ->
+// one LDS atomic per wave) and flushed with ONE global atomicAdd per block and chunk.  (One global
+// returning atomic per wave on a single counter saturates at ~88 per microsecond -- 87k waves cost 1 ms.)
+#define CHUNK_ROUNDS 16
+#define CHUNK_SLOTS (MAP_THREADS * CHUNK_ROUNDS)
+struct BlockList { unsigned int n; unsigned int base; unsigned int buf[CHUNK_SLOTS]; };
+__device__ __forceinline__ void blist_push(BlockList& L, bool pred, unsigned int value)
+{
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&L.n, (unsigned int)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) L.buf[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+// all threads of the block; contains barriers
+__device__ __forceinline__ void blist_flush(BlockList& L, unsigned int* __restrict__ list, unsigned int* counter)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) L.base = L.n ? atomicAdd(counter, L.n) : 0u;
+    __syncthreads();
+    const unsigned int n = L.n, base = L.base;
+    for (unsigned int j = threadIdx.x; j < n; j += blockDim.x) list[base + j] = L.buf[j];
+    __syncthreads();
+    if (threadIdx.x == 0) L.n = 0;
+    __syncthreads();
+}
+
+// Conservative "can this surfel's disc touch the image?" test from its centre alone.  Every point of the
+// disc (and of the quad around it) lies within reach = r_max*sqrt(2) of the centre in 3-D, so its
+// projection moves by at most f*reach*(1 + |x|/z)/(z - reach) pixels; r_max bounds every radius ever stored.
+__device__ __forceinline__ bool may_touch_image(const DevState* st, float z, float u, float v, const Cam& c)
+{
+    if (!(u == u) || !(v == v)) return true;
+    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
+    const float zn = z - reach;
+    if (!(zn > 1e-3f)) return true;
+    const float mx = c.fx * reach * (1.0f + fabsf(u - c.cx) / c.fx) / zn + 2.0f;
+    const float my = c.fy * reach * (1.0f + fabsf(v - c.cy) / c.fy) / zn + 2.0f;
+    return !(u + mx < 0.f || v + my < 0.f || u - mx > (float)c.w || v - my > (float)c.h);
+}
+
+// phase 1 of the post-clean pass: candidates for the splat prediction and / or the id render
+__global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                             const float2* __restrict__ tm, Cam c, int time, int maxTime, unsigned int want,
+                                                             unsigned int* __restrict__ list)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    __shared__ BlockList L;
+    if (threadIdx.x == 0) L.n = 0;
+    __syncthreads();
+    const int n = st->count;
+    for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
+#pragma unroll 4
+        for (int r = 0; r < CHUNK_ROUNDS; r++) {
+            int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
+            unsigned int flags = 0;
+            if (i < n) {
+                float4 p4 = pc[i];
+                float lastT = tm[i].y;
+                v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
+                if ((want & LIST_SPLAT) && !(p4.w < c.conf) && !(q.z > c.maxDepth || q.z < 0 || (float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime) &&
+                    (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h))
+                    flags |= LIST_SPLAT;
+                if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) {
+                    if (may_touch_image(st, q.z, u, v, c)) flags |= LIST_IDS;
+                }
+            }
+            blist_push(L, flags != 0, (unsigned int)i | flags);
+        }
+        blist_flush(L, list, &st->list_n[0]);
+    }
+}
+
+// phase 2: disc rasterisation of the listed surfels into the splat and / or id key images
+__global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                             const float4* __restrict__ nr, Cam c, const unsigned int* __restrict__ list,
+                                                             unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const unsigned int n = st->list_n[0];
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += blockDim.x * gridDim.x) {
+        const unsigned int e = list[t];
+        const unsigned int i = e & LIST_IDX;
+        float4 p4 = pc[i], n4 = nr[i];
+        v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+        v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        float r = n4.w;
+        float xs[2], ys[2], minz;
+        disc_extent(q, nn, r, c, xs, ys, minz);
+        float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
+        // splat region: GL point sprite (splat.vert:75-92)
+        bool do_s = (e & LIST_SPLAT) != 0;
+        int sx0 = 0, sx1 = -1, sy0 = 0, sy1 = -1;
+        if (do_s) {
+            float s = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
+            if (!(s == s)) do_s = false;
+            else {
+                s = fminf(fmaxf(s, 1.0f), IFX_MAX_SPRITE);
+                sx0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, c.w - 1); sx1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, c.w - 1);
+                sy0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, c.h - 1); sy1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, c.h - 1);
+            }
+        }
+        // id region: bounding box of the quad (surfel_ids.geom:49-82)
+        bool do_i = (e & LIST_IDS) != 0;
+        int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;
+        if (do_i) {
+            if (!(minz > 0) || !(xs[0] == xs[0]) || !(ys[0] == ys[0]) || xs[1] - xs[0] > IFX_MAX_SPRITE || ys[1] - ys[0] > IFX_MAX_SPRITE || xs[1] < 0 || ys[1] < 0 ||
+                xs[0] > (float)c.w || ys[0] > (float)c.h)
+                do_i = false;
+            else {
+                ix0 = clampi((int)ceilf(xs[0] - 0.5f), 0, c.w - 1); ix1 = clampi((int)floorf(xs[1] - 0.5f), 0, c.w - 1);
+                iy0 = clampi((int)ceilf(ys[0] - 0.5f), 0, c.h - 1); iy1 = clampi((int)floorf(ys[1] - 0.5f), 0, c.h - 1);
+            }
+        }
+        if (!do_s && !do_i) continue;
+        if (!do_s) { sx0 = ix0; sx1 = ix1; sy0 = iy0; sy1 = iy1; }
+        if (!do_i) { ix0 = sx0; ix1 = sx1; iy0 = sy0; iy1 = sy1; }
+        const int x0 = min(sx0, ix0), x1 = max(sx1, ix1), y0 = min(sy0, iy0), y1 = max(sy1, iy1);
+        Disc d;
+        d.q = q; d.n = nn; d.r2 = r * r;
+        for (int py = y0; py <= y1; py++)
+            for (int px = x0; px <= x1; px++) {
+                float z;
+                if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
+                if (do_s && px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth)) key_min(&key_splat[py * c.w + px], make_key(z, i));
+                if (do_i && px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth)) key_min(&key_ids[py * c.w + px], make_key(z, i));
+            }
+    }
+}
+
+// phase 1 of the post-fuse pass: index-map projection (index_map.vert) + the cheap half of the clean
+// rules (copy_unstable.vert:160-172) + the list of surfels that need the window test
+__global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc, const float2* __restrict__ tm,
+                                                            Cam c, int time, unsigned long long* __restrict__ keys, unsigned int* __restrict__ list_cand,
+                                                            unsigned int* __restrict__ list_kill)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    __shared__ BlockList Lc, Lk;
+    if (threadIdx.x == 0) { Lc.n = 0; Lk.n = 0; }
+    __syncthreads();
+    const int n = st->count;
+    for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
+#pragma unroll 4
+        for (int r = 0; r < CHUNK_ROUNDS; r++) {
+            int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
+            bool cand = false, kill = false;
+            if (i < n) {
+                float2 t = tm[i];
+                if (t.y > DEAD_TIME) {
+                    float4 p4 = pc[i];
+                    float wv = t.y;
+                    v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                    float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+                    if (!(p.z > c.maxDepth || p.z < 0 || (float)time - wv > (float)c.timeDelta) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h))
+                        key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, (unsigned int)i));
+                    cand = ((float)time - wv < (float)c.timeDelta && p.z > 0 && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
+                    if (!cand) {   // count = zCount = 0: only the stability / age rules apply
+                        int test = 1;
+                        if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
+                        if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
+                        kill = !test;
+                    }
+                }
+            }
+            blist_push(Lc, cand, (unsigned int)i);
+            blist_push(Lk, kill, (unsigned int)i);
+        }
+        blist_flush(Lc, list_cand, &st->list_n[1]);
+        blist_flush(Lk, list_kill, &st->list_n[2]);
+    }
+}
+
+// phase 2: window test (copy_unstable.vert:103-157) for the listed surfels, after the index map is resolved
+__global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, float4* __restrict__ pc,
+                                                            const float4* __restrict__ nr, float2* __restrict__ tm, const float4* __restrict__ tap,
+                                                            const unsigned int* __restrict__ list_cand, const unsigned int* __restrict__ list_kill)
+{
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const unsigned int nc = st->list_n[1], nk = st->list_n[2];
+    int dead = 0;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < nc + nk; t += blockDim.x * gridDim.x) {
+        bool del;
+        unsigned int i;
+        float2 tt;
+        float4 p4;
+        if (t < nc) {
+            i = list_cand[t];
+            tt = tm[i];
+            p4 = pc[i];
+            float lastT = tt.y;
+            del = !clean_test(T, c, time, p4, nr[i], tt.x, lastT, tap);
+        } else {
+            i = list_kill[t - nc];
+            tt = tm[i];
+            p4 = pc[i];
+            del = true;
+        }
+        if (del) {
+            p4.w = -1.0f;
+            pc[i] = p4;
+            tm[i] = make_float2(tt.x, DEAD_TIME);
+            dead++;
+        }
+    }
+    dead = wave_sum_i(dead);
+    if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
+}
+
+__global__ void k_list_reset(DevState* st, int which)
+{
+    if (threadIdx.x == 0) {
+        if (which & 1) st->list_n[0] = 0;
+        if (which & 2) { st->list_n[1] = 0; st->list_n[2] = 0; }
+    }
+}
+
+// splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
+static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out)
 {
     Cam c = make_cam(h);
-    LAUNCH(h, "splat_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<0>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm,
-           (const float4*)h->votes, h->cap, c, time, maxTime, h->key_splat);
-    LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
-           (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
-           (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-    LAUNCH(h, "dense", dim3(1), dim3(256), k_dense, h->d_state, (const uchar4*)h->pred_image, h->w, h->h);
+    LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
+           h->list_a);
+    LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+           h->key_ids);
+    if (want & LIST_SPLAT) {
+        LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
+               (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
+               (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+        LAUNCH(h, "dense", dim3(1), dim3(256), k_dense, h->d_state, (const uchar4*)h->pred_image, h->w, h->h);
+    }
+    if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
+    LAUNCH(h, "list_reset", dim3(1), dim3(64), k_list_reset, h->d_state, 1);
 }
+static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime) { raster_pass(h, d_pose_inv, time, maxTime, LIST_SPLAT, nullptr); }
 
 static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out)
 {
-    Cam c = make_cam(h);
-    if (mode == 1)
-        LAUNCH(h, "ids_raster_inst", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<2>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
-    else
-        LAUNCH(h, "ids_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<1>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm,
-               (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
+    if (mode != 1) { raster_pass(h, d_pose_inv, 0, 0, LIST_IDS, out); return; }
+    Cam c = make_cam(h);   // INSTANCECOMPARE also reads the 192 B of votes: one-kernel version
+    LAUNCH(h, "ids_raster_inst", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<2>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->tm, (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
     LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, out);
 }
 
@@ -499,7 +759,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
 }
 
 // update.vert:55-141 in place, by the owning pixel only
-__global__ void k_fuse_update(const DevState* __restrict__ st, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc, const float4* __restrict__ mnr,
+__global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc, const float4* __restrict__ mnr,
                               const float* __restrict__ mcol, Cam c, int time, uint32_t* __restrict__ upd_owner, float4* __restrict__ pc, float4* __restrict__ nr,
                               float2* __restrict__ col, float2* __restrict__ tm)
 {
@@ -528,6 +788,7 @@ __global__ void k_fuse_update(const DevState* __restrict__ st, const uint32_t* _
         float t3 = ((c_k * n.w) + (a * mn.w)) / (c_k + a);
         v3 nn = normalized(v3m(t0, t1, t2));
         nr[id] = make_float4(nn.x, nn.y, nn.z, t3);
+        if (t3 > 0.f && t3 < 1e30f && __float_as_uint(t3) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(t3));
         pc[id] = p;
     } else {
         p.w = c_k + a;
@@ -540,8 +801,7 @@ __global__ void k_fuse_update(const DevState* __restrict__ st, const uint32_t* _
 
 // ------------------------------------------------------------------ clean (a13)
 // copy_unstable.vert:103-174
-__device__ inline int clean_test(const float* T, const Cam& c, int time, float4 p4, float4 n4, float initT, float& lastT, const uint32_t* __restrict__ index_id,
-                                 const float4* __restrict__ index_vc, const float4* __restrict__ index_ct)
+__device__ inline int clean_test(const float* T, const Cam& c, int time, float4 p4, float4 n4, float initT, float& lastT, const float4* __restrict__ tap)
 {
     int test = 1;
     v3 lp = xf_point(T, v3m(p4.x, p4.y, p4.z));
@@ -550,18 +810,26 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
     float wv = lastT;
     if ((float)time - wv < (float)c.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)c.w && y < (float)c.h) {
         v3 ln = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        const bool flat = fabsf(ln.z) > 0.85f;
         const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
+        int tx[4], ty[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { tx[a] = clampi((int)floorf(x + offs[a]), 0, c.w - 1); ty[a] = clampi((int)floorf(y + offs[a]), 0, c.h - 1); }
+        float4 t[16];
+#pragma unroll
         for (int a = 0; a < 4; a++)
-            for (int b = 0; b < 4; b++) {
-                int tx = clampi((int)floorf(x + offs[a]), 0, c.w - 1), ty = clampi((int)floorf(y + offs[b]), 0, c.h - 1);
-                int k = ty * c.w + tx;
-                if (index_id[k] > 0u) {
-                    float4 vc = index_vc[k], ct = index_ct[k];
-                    float dx = vc.x - lp.x, dy = vc.y - lp.y;
-                    if (ct.z < initT && vc.w > c.conf && vc.z > lp.z && vc.z - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count++;
-                    if (ct.w == (float)time && vc.w > c.conf && vc.z > lp.z && vc.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f) zCount++;
-                }
-            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) t[a * 4 + b] = tap[ty[b] * c.w + tx[a]];   // all 16 gathers in flight
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float4 e = t[k];
+            if (e.z == 0.f) continue;                       // empty texel (or surfel id 0)
+            const float ez = fabsf(e.z);
+            const bool stable = e.w > 0.f, now = e.z < 0.f;
+            const float dx = e.x - lp.x, dy = e.y - lp.y;
+            if (fabsf(e.w) < initT && stable && ez > lp.z && ez - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count++;
+            if (now && stable && ez > lp.z && ez - lp.z > 0.01f && flat) zCount++;
+        }
     }
     if (count > 8 || zCount > 4) test = 0;
     if (wv == -2) wv = (float)time;
@@ -571,36 +839,8 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
     return test;
 }
 
-__global__ __launch_bounds__(MAP_THREADS) void k_clean_old(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, float4* __restrict__ pc,
-                                                           const float4* __restrict__ nr, float2* __restrict__ tm, const uint32_t* __restrict__ index_id,
-                                                           const float4* __restrict__ index_vc, const float4* __restrict__ index_ct)
-{
-    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
-    float T[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = Ti[k];
-    const int n = st->count;
-    int dead = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
-        float2 t = tm[i];
-        if (t.y <= DEAD_TIME) continue;
-        float4 p4 = pc[i];
-        float lastT = t.y;
-        int keep = clean_test(T, c, time, p4, nr[i], t.x, lastT, index_id, index_vc, index_ct);
-        if (!keep) {
-            p4.w = -1.0f;
-            pc[i] = p4;
-            tm[i] = make_float2(t.x, DEAD_TIME);
-            dead++;
-        }
-    }
-    dead = wave_sum_i(dead);
-    if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
-}
-
 __global__ void k_clean_new_flags(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
-                                  const float4* __restrict__ mpc, const float4* __restrict__ mnr, const uint32_t* __restrict__ index_id,
-                                  const float4* __restrict__ index_vc, const float4* __restrict__ index_ct, int* __restrict__ flags)
+                                  const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags)
 {
     int ord = blockIdx.x * blockDim.x + threadIdx.x;   // column-major order index
     if (ord >= c.w * c.h) return;
@@ -609,7 +849,7 @@ __global__ void k_clean_new_flags(const DevState* __restrict__ st, const float* 
     if (assoc[k] == ASSOC_NEW) {
         const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
         float lastT = -2.f;
-        keep = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, index_id, index_vc, index_ct);
+        keep = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, tap);
     }
     flags[ord] = keep;
 }
@@ -625,6 +865,7 @@ __global__ void k_append_new(DevState* st, Cam c, int time, int tick, const int*
     if (n >= cap) { st->overflow = 1; return; }
     pc[n] = mpc[k];
     nr[n] = mnr[k];
+    { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
     col[n] = make_float2(mcol[k], 0.f);
     tm[n] = make_float2((float)time, (float)time);
     ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, -2.f);
@@ -694,10 +935,17 @@ static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
 static void clean_pass(ifx* h, const float* d_pose_inv, int time)
 {
     Cam c = make_cam(h);
-    LAUNCH(h, "clean_old", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_clean_old, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
-           h->index_id, (const float4*)h->index_vc, (const float4*)h->index_ct);
+    // index map of the post-fuse state (EF/ElasticFusion.cpp:662) fused with the clean cull
+    LAUNCH(h, "cull_clean", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_clean, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index,
+           h->list_b, h->list_c);
+    LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr, time, h->cfg.confidence,
+           (float4*)h->index_tap);
+    LAUNCH(h, "clean_list", dim3(1024), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+           (const float4*)h->index_tap, h->list_b, h->list_c);
+    LAUNCH(h, "list_reset", dim3(1), dim3(64), k_list_reset, h->d_state, 2);
     LAUNCH(h, "clean_new_flags", dim3(cdiv(h->P, 256)), dim3(256), k_clean_new_flags, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc,
-           (const float4*)h->meas_nr, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_ct, h->scan_flags);
+           (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags);
     ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
     LAUNCH(h, "append_new", dim3(cdiv(h->P, 256)), dim3(256), k_append_new, h->d_state, c, time, time, h->scan_flags, h->scan_out, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
@@ -710,21 +958,22 @@ int ifx_map_frame(ifx* h)
 {
     index_pass(h, nullptr, h->tick);
     fuse_pass(h, nullptr, 0.f, h->tick);
-    index_pass(h, nullptr, h->tick);
-    if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680)
+    if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680); they need the post-fuse index map too
+        index_pass(h, nullptr, h->tick);
         ids_pass(h, nullptr, 1, h->ids_tmp);
         ids_pass(h, nullptr, 0, h->ids_tmp);
     }
-    clean_pass(h, nullptr, h->tick);
+    clean_pass(h, nullptr, h->tick);   // includes the second predictIndices
     if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
-    ids_pass(h, nullptr, 0, h->ids_after);
+    h->ids_pending = 1;                // rendered together with the prediction (same map state, same pose)
     return IFX_OK;
 }
 
-// ElasticFusion::predict, EF/ElasticFusion.cpp:729-763
+// ElasticFusion::predict, EF/ElasticFusion.cpp:729-763, fused with renderSurfelIds(GENERAL_AFTER) of :694
 int ifx_map_predict(ifx* h)
 {
-    splat_pass(h, nullptr, h->tick, h->tick);
+    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u), h->ids_after);
+    h->ids_pending = 0;
     return IFX_OK;
 }
 

@@ -193,10 +193,11 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
-        float4 p4 = pc[i];
         float lastT = tm[i].y;
+        if ((float)time - lastT > (float)c.timeDelta) continue;   // inactive (or tombstone): 8 B, position not loaded
+        float4 p4 = pc[i];
         v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
-        if (p.z > c.maxDepth || p.z < 0 || (float)time - lastT > (float)c.timeDelta) continue;
+        if (p.z > c.maxDepth || p.z < 0) continue;
         float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
         if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
         int px = (int)floorf(u), py = (int)floorf(v);
@@ -246,7 +247,8 @@ struct Disc { v3 q, n; float r2; };
 // combo_splat.frag:39-52
 __device__ inline bool disc_hit(const Disc& d, float px, float py, const Cam& c, float& z)
 {
-    v3 l = normalized(v3m((px - c.cx) / c.fx, (py - c.cy) / c.fy, 1.0f));
+    // un-normalised ray: l*(q.n)/(l.n) does not depend on |l| (see oracle/orc_map.c disc_hit)
+    v3 l = v3m((px - c.cx) * (1.0f / c.fx), (py - c.cy) * (1.0f / c.fy), 1.0f);
     float s = dot(d.q, d.n) / dot(l, d.n);
     v3 cp = l * s;
     v3 df = cp - d.q;
@@ -443,43 +445,57 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // returning atomic per wave on a single counter saturates at ~88 per microsecond -- 87k waves cost 1 ms.)
 #define CHUNK_ROUNDS 16
 #define CHUNK_SLOTS (MAP_THREADS * CHUNK_ROUNDS)
-struct BlockList { unsigned int n; unsigned int base; unsigned int buf[CHUNK_SLOTS]; };
-__device__ __forceinline__ void blist_push(BlockList& L, bool pred, unsigned int value)
+// Per-chunk append without an LDS staging buffer: every round reserves wave-contiguous positions in a
+// block-local counter (one LDS atomic per wave), the block reserves its range of the global list with
+// ONE global atomic, and each thread then writes its survivors straight to list[base + position].
+struct BlockCount { unsigned int n; unsigned int base; };
+struct BlockCount2 { unsigned int n[2]; unsigned int base[2]; };
+__device__ __forceinline__ unsigned int bcount_reserve(BlockCount& L, bool pred)
 {
     unsigned long long m = __ballot(pred);
-    if (m == 0ull) return;
+    if (m == 0ull) return 0u;
     const int lane = threadIdx.x & 63;
     unsigned int base = 0;
     const int leader = __ffsll((long long)m) - 1;
     if (lane == leader) base = atomicAdd(&L.n, (unsigned int)__popcll(m));
     base = __shfl(base, leader, 64);
-    if (pred) L.buf[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    return base + __popcll(m & ((1ull << lane) - 1ull));
 }
-// all threads of the block; contains barriers
-__device__ __forceinline__ void blist_flush(BlockList& L, unsigned int* __restrict__ list, unsigned int* counter)
+// two mutually exclusive predicates, two lists, one pass
+__device__ __forceinline__ unsigned int bcount2_reserve(BlockCount2& L, bool a, bool b)
+{
+    unsigned long long ma = __ballot(a), mb = __ballot(b);
+    if ((ma | mb) == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned int ba = 0, bb = 0;
+    if (lane == 0) { if (ma) ba = atomicAdd(&L.n[0], (unsigned int)__popcll(ma)); if (mb) bb = atomicAdd(&L.n[1], (unsigned int)__popcll(mb)); }
+    ba = __shfl(ba, 0, 64); bb = __shfl(bb, 0, 64);
+    return a ? ba + __popcll(ma & below) : bb + __popcll(mb & below);
+}
+// all threads; after it L.base holds the block's range start in the global list and L.n is re-armed
+__device__ __forceinline__ unsigned int bcount_commit(BlockCount& L, unsigned int* counter)
 {
     __syncthreads();
-    if (threadIdx.x == 0) L.base = L.n ? atomicAdd(counter, L.n) : 0u;
+    if (threadIdx.x == 0) { L.base = L.n ? atomicAdd(counter, L.n) : 0u; L.n = 0; }
     __syncthreads();
-    const unsigned int n = L.n, base = L.base;
-    for (unsigned int j = threadIdx.x; j < n; j += blockDim.x) list[base + j] = L.buf[j];
-    __syncthreads();
-    if (threadIdx.x == 0) L.n = 0;
-    __syncthreads();
+    return L.base;
 }
 
 // Conservative "can this surfel's disc touch the image?" test from its centre alone.  Every point of the
 // disc (and of the quad around it) lies within reach = r_max*sqrt(2) of the centre in 3-D, so its
-// projection moves by at most f*reach*(1 + |x|/z)/(z - reach) pixels; r_max bounds every radius ever stored.
-__device__ __forceinline__ bool may_touch_image(const DevState* st, float z, float u, float v, const Cam& c)
+// projection moves by at most f*reach*(1 + |x|/z)/(z - reach) pixels; r_max bounds every radius ever
+// stored.  Approximate reciprocals are fine here: the test only has to be conservative (2 px + 0.5 % slack);
+// survivors are re-tested exactly in phase 2.
+__device__ __forceinline__ bool may_touch_image(float reach, v3 q, const Cam& c)
 {
-    if (!(u == u) || !(v == v)) return true;
-    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
-    const float zn = z - reach;
+    const float zn = q.z - reach;
     if (!(zn > 1e-3f)) return true;
-    const float mx = c.fx * reach * (1.0f + fabsf(u - c.cx) / c.fx) / zn + 2.0f;
-    const float my = c.fy * reach * (1.0f + fabsf(v - c.cy) / c.fy) / zn + 2.0f;
-    return !(u + mx < 0.f || v + my < 0.f || u - mx > (float)c.w || v - my > (float)c.h);
+    const float rz = __builtin_amdgcn_rcpf(q.z), rzn = __builtin_amdgcn_rcpf(zn) * 1.005f;
+    const float ax = c.fx * q.x * rz, ay = c.fy * q.y * rz;          // u - cx, v - cy (approx.)
+    const float mx = reach * (c.fx + fabsf(ax)) * rzn + 2.0f, my = reach * (c.fy + fabsf(ay)) * rzn + 2.0f;
+    const float u = ax + c.cx, v = ay + c.cy;
+    return !(u + mx < 0.f || v + my < 0.f || u - mx > (float)c.w || v - my > (float)c.h) || !(u == u) || !(v == v);
 }
 
 // phase 1 of the post-clean pass: candidates for the splat prediction and / or the id render
@@ -491,30 +507,39 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
-    __shared__ BlockList L;
+    __shared__ BlockCount L;
     if (threadIdx.x == 0) L.n = 0;
     __syncthreads();
     const int n = st->count;
+    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
     for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
-#pragma unroll 4
+        unsigned int val[CHUNK_ROUNDS], pos[CHUNK_ROUNDS];
+#pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++) {
             int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
             unsigned int flags = 0;
             if (i < n) {
                 float4 p4 = pc[i];
                 float lastT = tm[i].y;
-                v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
-                float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
-                if ((want & LIST_SPLAT) && !(p4.w < c.conf) && !(q.z > c.maxDepth || q.z < 0 || (float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime) &&
-                    (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h))
-                    flags |= LIST_SPLAT;
-                if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) {
-                    if (may_touch_image(st, q.z, u, v, c)) flags |= LIST_IDS;
+                // cheapest tests first: unstable surfels are on neither list, nor is anything behind the camera
+                if (!(p4.w < c.conf)) {
+                    v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                    if (q.z > 0.f && may_touch_image(reach, q, c)) {
+                        if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) flags |= LIST_IDS;
+                        if ((want & LIST_SPLAT) && !(q.z > c.maxDepth || (float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime)) {
+                            float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;   // exact: GL clips points by their centre
+                            if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= LIST_SPLAT;
+                        }
+                    }
                 }
             }
-            blist_push(L, flags != 0, (unsigned int)i | flags);
+            val[r] = flags ? ((unsigned int)i | flags) : 0u;
+            pos[r] = bcount_reserve(L, flags != 0);
         }
-        blist_flush(L, list, &st->list_n[0]);
+        const unsigned int base = bcount_commit(L, &st->list_n[0]);
+#pragma unroll
+        for (int r = 0; r < CHUNK_ROUNDS; r++)
+            if (val[r]) list[base + pos[r]] = val[r];
     }
 }
 
@@ -588,25 +613,34 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
-    __shared__ BlockList Lc, Lk;
-    if (threadIdx.x == 0) { Lc.n = 0; Lk.n = 0; }
+    __shared__ BlockCount2 L2;
+    if (threadIdx.x == 0) { L2.n[0] = 0; L2.n[1] = 0; }
     __syncthreads();
     const int n = st->count;
     for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
-#pragma unroll 4
+        unsigned int pos[CHUNK_ROUNDS];
+        unsigned int cmask = 0, kmask = 0;
+#pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++) {
             int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
             bool cand = false, kill = false;
             if (i < n) {
                 float2 t = tm[i];
-                if (t.y > DEAD_TIME) {
+                const float wv = t.y;
+                // Inactive surfels (outside the time window, lastTime > 0) are neither projected
+                // (index_map.vert:47) nor window-tested (copy_unstable.vert:107) and the age rule keeps them
+                // (:171): they cost 8 B, their position is not even loaded.
+                if (wv > DEAD_TIME && !(wv > 0.f && (float)time - wv > (float)c.timeDelta)) {
                     float4 p4 = pc[i];
-                    float wv = t.y;
-                    v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
-                    float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
-                    if (!(p.z > c.maxDepth || p.z < 0 || (float)time - wv > (float)c.timeDelta) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h))
-                        key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, (unsigned int)i));
-                    cand = ((float)time - wv < (float)c.timeDelta && p.z > 0 && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
+                    if (!((float)time - wv > (float)c.timeDelta)) {
+                        v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                        if (p.z > 0.f) {
+                            float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+                            if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h))
+                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, (unsigned int)i));
+                            cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
+                        }
+                    }
                     if (!cand) {   // count = zCount = 0: only the stability / age rules apply
                         int test = 1;
                         if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
@@ -615,11 +649,21 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                     }
                 }
             }
-            blist_push(Lc, cand, (unsigned int)i);
-            blist_push(Lk, kill, (unsigned int)i);
+            // a slot is on at most one of the two lists, so one position register serves both
+            pos[r] = bcount2_reserve(L2, cand, kill);
+            cmask |= cand ? (1u << r) : 0u;
+            kmask |= kill ? (1u << r) : 0u;
         }
-        blist_flush(Lc, list_cand, &st->list_n[1]);
-        blist_flush(Lk, list_kill, &st->list_n[2]);
+        __syncthreads();
+        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(&st->list_n[1 + threadIdx.x], L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
+        __syncthreads();
+        const unsigned int bc = L2.base[0], bk = L2.base[1];
+#pragma unroll
+        for (int r = 0; r < CHUNK_ROUNDS; r++) {
+            unsigned int i = (unsigned int)(chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x);
+            if (cmask & (1u << r)) list_cand[bc + pos[r]] = i;
+            if (kmask & (1u << r)) list_kill[bk + pos[r]] = i;
+        }
     }
 }
 

@@ -271,7 +271,9 @@ void orc_predict_indices(orc_t* o, const float* pose, int time)
 typedef struct { v3 q, n; float r2; } disc_t;
 static inline int disc_hit(const disc_t* d, float px, float py, float cx, float cy, float fx, float fy, float* zout)
 {
-    v3 l = v3normalized(v3m((px - cx) / fx, (py - cy) / fy, 1.0f));
+    /* combo_splat.frag:39-46 normalises the ray first; the intersection l*(q.n)/(l.n) does not depend
+     * on |l|, so the (shared oracle / HIP) rule uses the un-normalised ray ((px-cx)/fx, (py-cy)/fy, 1) */
+    v3 l = v3m((px - cx) * (1.0f / fx), (py - cy) * (1.0f / fy), 1.0f);
     float s = v3dot(d->q, d->n) / v3dot(l, d->n);
     v3 cp = v3scale(l, s);
     v3 df = v3sub(cp, d->q);

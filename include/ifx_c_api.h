@@ -158,7 +158,7 @@ int ifx_tracker_buffer_download(ifx_t* h, const char* name, int level, void* out
 int ifx_should_segment(ifx_t* h, int frame);
 /* masks: n x H x W u8 (0/255), sorted by area descending (the contract of the Mask-RCNN bridge,
  * build/mask_ori.py:117); class_ids: n COCO indices.  flags bit0: kNN smoothing (not implemented,
- * rejected), bit1: superpixel refinement. */
+ * rejected), bit1: superpixel refinement (needs rgb and depth of the frame, host pointers). */
 int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks, const int32_t* class_ids, int n, int frame,
                              int flags);
@@ -169,6 +169,22 @@ int ifx_instance_table(ifx_t* h, int32_t* out96);
 /* getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121: int[96*5] = r,g,b,class,index */
 int ifx_loop_closure_instance_table(ifx_t* h, int32_t* out480);
 int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n);  /* IF/Core/InstanceFusionCuda.cu:118-141 (host in/out) */
+
+/* ---- superpixel refinement stages (the three calls of processInstance steps -1_1..-1_3,
+ * IF/Core/InstanceFusion.cpp:722-738; ifx_process_segmentation runs them when flags bit1 is set).
+ * All buffers are host memory, images are H x W row-major.
+ * ifx_slic_segment: gSLICrInterface (IF/Core/InstanceFusion_superpixel.cpp:713-772; gSLICr with
+ *   spixel_size 16, coh_weight 0.6, 5 iterations, XYZ, enforce connectivity): rgb H x W x 3 u8 ->
+ *   superpixel label per pixel; returns the number of superpixels (> 0) or a negative error.
+ * ifx_merge_superpixels: mergeSuperPixel (IF/Core/InstanceFusion_superpixel.cpp:40-225): seg is the
+ *   SLIC labelling on entry and the re-clustered labelling (-1 = no geometry) on return, final_out the
+ *   merged region id per pixel, info_out (optional) the spNum x 30 float table in the reference's SPI_*
+ *   layout (:12-33).  Returns spNum.
+ * ifx_mask_superpixel_filter: maskSuperPixelFilter_OverSeg (:651-710): a mask keeps a merged region
+ *   iff it covers more than 75 % of it; masks n x H x W u8 rewritten in place. */
+int ifx_slic_segment(ifx_t* h, const uint8_t* rgb, int32_t* seg_out);
+int ifx_merge_superpixels(ifx_t* h, const uint16_t* depth, int32_t* seg_inout, int32_t* final_out, float* info_out);
+int ifx_mask_superpixel_filter(ifx_t* h, const int32_t* final_ids, uint8_t* masks, int n);
 
 /* ---- measurement hooks */
 /* Per-stage GPU time of the frames processed since the last reset, from HIP events on the handle's

@@ -99,6 +99,9 @@ _SIGS = {
     "ifx_instance_table": (C.c_int, [_P, _P]),
     "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
     "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_slic_segment": (C.c_int, [_P, _P, _P]),
+    "ifx_merge_superpixels": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ifx_mask_superpixel_filter": (C.c_int, [_P, _P, _P, C.c_int]),
     "ifx_stage_ms": (C.c_int, [_P, _P, C.c_int]),
     "ifx_kernel_ms": (C.c_int, [_P, C.c_char_p, _P, _P]),
 }
@@ -359,6 +362,27 @@ class InstanceFusion:
         out = np.zeros(96 * 5, np.int32)
         self.ef._chk(self.L.ifx_loop_closure_instance_table(self.ef.handle, _ptr(out)), "ifx_loop_closure_instance_table")
         return out.reshape(96, 5)
+
+    # superpixel refinement stages (IF/Core/InstanceFusion_superpixel.cpp)
+    def gSLICrInterface(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        seg = np.zeros(rgb.shape[:2], np.int32)
+        n = self.ef._chk(self.L.ifx_slic_segment(self.ef.handle, _ptr(rgb), _ptr(seg)), "ifx_slic_segment")
+        return seg, n
+
+    def mergeSuperPixel(self, depth, seg):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        seg = np.ascontiguousarray(seg, np.int32).copy()
+        fin = np.zeros_like(seg)
+        info = np.zeros((seg.size // 256, 30), np.float32)
+        self.ef._chk(self.L.ifx_merge_superpixels(self.ef.handle, _ptr(depth), _ptr(seg), _ptr(fin), _ptr(info)), "ifx_merge_superpixels")
+        return seg, fin, info
+
+    def maskSuperPixelFilter_OverSeg(self, fin, masks):
+        fin = np.ascontiguousarray(fin, np.int32)
+        masks = np.ascontiguousarray(masks, np.uint8).copy()
+        self.ef._chk(self.L.ifx_mask_superpixel_filter(self.ef.handle, _ptr(fin), _ptr(masks), int(masks.shape[0])), "ifx_mask_superpixel_filter")
+        return masks
 
     def maskCleanOverlap(self, masks):
         masks = np.ascontiguousarray(masks, np.uint8).copy()

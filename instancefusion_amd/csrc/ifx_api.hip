@@ -144,6 +144,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->depth_stage) hipHostFree(h->depth_stage);
     ifx_free_tracker(h);
     ifx_free_instance(h);
+    ifx_slic_free(h);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }

@@ -132,6 +132,7 @@ struct ifx {
     int* d_clean_list = nullptr;
     int last_seg_frame = -1;
     int clean_times = 0;
+    void* slic = nullptr;              // superpixel buffers (ifx_slic.hip), allocated on first use
     // timing
     hipEvent_t ev_stage[8];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> stage_pending;
@@ -168,6 +169,8 @@ void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // stage entry points implemented across the .hip files
+void ifx_slic_free(ifx* h);
+int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric
 int ifx_tracker_init_first(ifx* h);
 int ifx_tracker_run_frame(ifx* h);                            // init model + init frame + GN loops (all on device)

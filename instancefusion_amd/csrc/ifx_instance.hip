@@ -243,7 +243,7 @@ void ifx_free_instance(ifx* h)
     hipFree(h->d_inst_color); hipFree(h->d_masks); hipFree(h->d_pdm); hipFree(h->d_bbox); hipFree(h->d_inst_stats); hipFree(h->d_clean_list);
 }
 
-static int ensure_masks(ifx* h, size_t bytes)
+int ifx_ensure_masks(ifx* h, size_t bytes)
 {
     if (bytes <= h->masks_cap) return IFX_OK;
     if (h->d_masks) hipFree(h->d_masks);
@@ -258,7 +258,7 @@ extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
     if (!h || !masks || n < 0) return IFX_E_INVALID;
     if (n == 0) return IFX_OK;
     size_t bytes = (size_t)n * h->P;
-    int r = ensure_masks(h, bytes);
+    int r = ifx_ensure_masks(h, bytes);
     if (r) return r;
     HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(h->P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, n, h->P);
@@ -402,7 +402,7 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     const int P = h->P;
     size_t mbytes = (size_t)nm * P;
     std::vector<uint8_t> masks(masks_in, masks_in + mbytes), ori(masks_in, masks_in + mbytes), unavailable(nm, 0);
-    int r = ensure_masks(h, mbytes);
+    int r = ifx_ensure_masks(h, mbytes);
     if (r) return r;
     // step 0_1
     HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));

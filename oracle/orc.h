@@ -143,6 +143,13 @@ int orc_process_segmentation(orc_t*, const uint8_t* rgb, const uint16_t* depth,
 void orc_labels(orc_t*, int32_t* out);
 void orc_instance_table(orc_t*, int32_t* class_of_instance /*96, -1 unused*/);
 
+/* superpixel refinement (a20, a21; orc_slic.c).  orc_slic_segment: gSLICrInterface, returns the number of
+ * superpixels; orc_merge_superpixels: mergeSuperPixel (seg in/out, final ids out, optional spn*30 info
+ * table in the reference's SPI_* layout); orc_mask_superpixel_filter: maskSuperPixelFilter_OverSeg. */
+int orc_slic_segment(orc_t*, const uint8_t* rgb, int32_t* seg);
+int orc_merge_superpixels(orc_t*, const uint16_t* depth, int32_t* seg, int32_t* final_out, float* info_out);
+void orc_mask_superpixel_filter(orc_t*, const int32_t* final_ids, uint8_t* masks, int n);
+
 /* stage-level instance helpers */
 void orc_mask_clean_overlap(uint8_t* masks, int n, int w, int h);
 float orc_vote_encode(int a, int b);

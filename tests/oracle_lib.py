@@ -198,6 +198,31 @@ class Oracle:
         cls = np.ascontiguousarray(class_ids, np.int32)
         return self.L.orc_process_segmentation(self.h, ptr(rgb), ptr(depth), ptr(masks), ptr(cls), masks.shape[0], frame, flags)
 
+    # ---- superpixel refinement stages (orc_slic.c)
+    def slic_segment(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        seg = np.zeros((self.cfg.height, self.cfg.width), np.int32)
+        self.L.orc_slic_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        n = self.L.orc_slic_segment(self.h, ptr(rgb), ptr(seg))
+        return seg, n
+
+    def merge_superpixels(self, depth, seg):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        seg = np.ascontiguousarray(seg, np.int32).copy()
+        fin = np.zeros_like(seg)
+        spn = seg.size // 256
+        info = np.zeros((spn, 30), np.float32)
+        self.L.orc_merge_superpixels.argtypes = [C.c_void_p] * 5
+        self.L.orc_merge_superpixels(self.h, ptr(depth), ptr(seg), ptr(fin), ptr(info))
+        return seg, fin, info
+
+    def mask_superpixel_filter(self, fin, masks):
+        fin = np.ascontiguousarray(fin, np.int32)
+        masks = np.ascontiguousarray(masks, np.uint8).copy()
+        self.L.orc_mask_superpixel_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.orc_mask_superpixel_filter(self.h, ptr(fin), ptr(masks), masks.shape[0])
+        return masks
+
     def labels(self):
         out = np.zeros(self.count, np.int32)
         self.L.orc_labels(self.h, ptr(out))

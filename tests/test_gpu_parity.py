@@ -325,3 +325,82 @@ def test_full_size_properties(ifx):
     assert np.array_equal(l1, np.where(cnt.max(axis=1) > 0, cnt.argmax(axis=1), -1))
     gt = st["poses"][1:8]
     assert np.sqrt(np.mean(np.sum((p1[:, :3, 3] - gt[:, :3, 3]) ** 2, axis=1))) < 0.02
+
+
+# ---------------------------------------------------------------- a20, a21: superpixel refinement
+def _slic_cases(gputest_pair):
+    from instancefusion_amd import synth
+
+    c1, d1, c2, d2 = gputest_pair
+    st = synth.make_stream(2, 640, 480, 528.0, 528.0, 320.0, 240.0, noise=True)
+    return {"c1": (c1, d1 // 5), "c2": (c2, d2 // 5), "synth": (st["rgb"][1], st["depth"][1])}
+
+
+def test_superpixel_stages_exact(ifx, orc, gputest_pair):
+    """SLIC labels equal the labels of the reference's own per-pixel functions (golden fixture) and the
+    oracle's; re-clustered labels, merged region ids, the 30-float statistics table and the filtered
+    masks equal the oracle's bit for bit (fixed-point sums make the statistics order-independent)."""
+    import os
+
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "slic_ref.npz")))
+    rng = np.random.RandomState(11)
+    for name, (rgb, dep) in _slic_cases(gputest_pair).items():
+        h, w = rgb.shape[:2]
+        K = dict(fx=528.0 * w / 640, fy=528.0 * w / 640, cx=w / 2.0, cy=h / 2.0)
+        g = ifx.ElasticFusion(w=w, h=h, max_surfels=1000, **K)
+        o = orc.Oracle(w=w, h=h, max_surfels=1000, **K)
+        inst = ifx.InstanceFusion(g)
+        seg_g, n_g = inst.gSLICrInterface(rgb)
+        seg_o, n_o = o.slic_segment(rgb)
+        assert n_g == n_o == (w // 16) * (h // 16)
+        assert np.array_equal(seg_g, gold[name + "_ref_labels"].astype(np.int32)), name
+        assert np.array_equal(seg_g, seg_o), name
+        s_g, f_g, i_g = inst.mergeSuperPixel(dep, seg_g)
+        s_o, f_o, i_o = o.merge_superpixels(dep, seg_o)
+        assert np.array_equal(s_g, s_o) and np.array_equal(f_g, f_o), name
+        assert nan_equal(i_g, i_o), name
+        assert np.array_equal(f_g, gold[name + "_merge_final"].astype(np.int32)), name
+        # twice on the same handle: buffers are reused, result unchanged (determinism of the atomics)
+        s_g2, f_g2, i_g2 = inst.mergeSuperPixel(dep, seg_g)
+        assert np.array_equal(f_g2, f_g) and nan_equal(i_g2, i_g)
+        masks = np.zeros((5, h, w), np.uint8)
+        masks[0, h // 5: h // 2, w // 4: w // 2] = 255
+        masks[1, h // 2:, : w // 3] = 255
+        masks[2] = (rng.rand(h, w) < 0.8) * 255
+        masks[3] = 255
+        assert np.array_equal(inst.maskSuperPixelFilter_OverSeg(f_g, masks), o.mask_superpixel_filter(f_o, masks)), name
+        # ragged labelling: invalid ids and ids >= spNum are dropped by the filter on both sides
+        f_bad = f_g.copy(); f_bad[::7, ::5] = -1; f_bad[3::11, 2::9] = 10 ** 6
+        assert np.array_equal(inst.maskSuperPixelFilter_OverSeg(f_bad, masks), o.mask_superpixel_filter(f_bad, masks)), name
+        # depth holes / all-zero depth: nothing survives
+        s0, f0, _ = inst.mergeSuperPixel(np.zeros_like(dep), seg_g)
+        assert (s0 == -1).all() and (f0 == -1).all()
+        g.close(); o.close()
+
+
+def test_segmentation_with_superpixels_exact(ifx, orc, small_stream):
+    from instancefusion_amd import synth
+
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)     # slot ids == the oracle's compacted indices
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    inst = ifx.InstanceFusion(g)
+    for i in range(6):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        g.processFrame(st["rgb"][i], st["depth"][i])
+    m = o.download(); m["pc"][:, 3] = 20.0
+    o.upload(m); g.upload(m)
+    pose = po
+    o.set_pose(pose, o.tick); g.set_pose(pose, o.tick)      # same previous pose -> same fusion weight
+    g.processFrame(st["rgb"][5], st["depth"][5], inPose=pose); o.process_frame(st["rgb"][5], st["depth"][5], in_pose=pose)
+    assert g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after"))
+    masks, cls = synth.canned_masks(st["obj"][5], st["scene"])
+    for frame in (50, 60):
+        inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], masks, cls, frame, superpixels=True)
+        o.process_segmentation(st["rgb"][5], st["depth"][5], masks, cls, frame, flags=2)
+        assert np.array_equal(inst.getInstanceTable(), o.instance_table())
+        assert np.array_equal(inst.labels(), o.labels())
+        assert np.array_equal(g.download()["votes"], o.download()["votes"])
+    assert (o.labels() >= 0).sum() > 100
+    g.close(); o.close()

@@ -6,6 +6,11 @@
    GPUTest.cpp:55,94), sub-sampled 2x (nearest) to keep the fixture small.  Data only.
 2. oracle_pins.npz -- outputs of the CPU oracle on that pair (regression pins; the reference
    publishes no expected values for it -- GPUTest asserts nothing).
+3. slic_ref.npz -- superpixel labels produced by the REFERENCE's own gSLICr per-pixel functions
+   (oracle/_ref/libref_slic.so, built by `make -C oracle ref` from /root/reference/src/gSLICr with
+   -DCOMPILE_WITHOUT_CUDA; driver loops in oracle/ref_slic.cpp) on both colour images of the pair and
+   on one synthetic 640x480 frame, plus the oracle's merged-region ids for them (regression pins of
+   mergeSuperPixel, for which the reference holds no expected values).
 """
 import os
 import sys
@@ -34,6 +39,35 @@ def main():
     pins = run_oracle_protocol(d["1c"], d["1d"], d["2c"], d["2d"])
     np.savez_compressed(os.path.join(OUT, "oracle_pins.npz"), **pins)
     print({k: (v.shape, v.dtype) for k, v in pins.items()})
+    slic_fixtures(d)
+
+
+def slic_fixtures(d):
+    import ctypes as C
+
+    import oracle_lib as ol
+    from instancefusion_amd import synth
+
+    ol.build()
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_slic.so"))
+    ref.ref_slic_segment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    st = synth.make_stream(2, 640, 480, 528.0, 528.0, 320.0, 240.0, noise=True)
+    cases = {"c1": (d["1c"], d["1d"] // 5), "c2": (d["2c"], d["2d"] // 5), "synth": (st["rgb"][1], st["depth"][1])}
+    out = {}
+    for name, (rgb, dep) in cases.items():
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w = rgb.shape[:2]
+        seg = np.zeros((h, w), np.int32)
+        n = ref.ref_slic_segment(rgb.ctypes.data, w, h, 16, 0.6, 5, seg.ctypes.data)
+        assert n == (w // 16) * (h // 16) and seg.max() < 32768
+        out[name + "_ref_labels"] = seg.astype(np.int16)
+        o = ol.Oracle(w=w, h=h, fx=528.0 * w / 640, fy=528.0 * w / 640, cx=w / 2.0, cy=h / 2.0, max_surfels=1000)
+        seg2, fin, info = o.merge_superpixels(dep, seg)
+        out[name + "_merge_seg"] = seg2.astype(np.int16)
+        out[name + "_merge_final"] = fin.astype(np.int16)
+        o.close()
+    np.savez_compressed(os.path.join(OUT, "slic_ref.npz"), **out)
+    print({k: (v.shape, v.dtype) for k, v in out.items()})
 
 
 if __name__ == "__main__":

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--no-instance", action="store_true")
+    ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +111,7 @@ def main():
         if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
             mk, cl = masks[i]
             if mk.shape[0]:
-                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0])
+                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0], superpixels=not args.no_superpixels)
 
     def barrier():
         if dist is not None:
@@ -190,7 +191,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"640x480 synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes, {args.surfels}-surfel map",
+            "config": {"workload": f"640x480 synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}, {args.surfels}-surfel map",
                        "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": f"replicas x{world}", "loop_frames": L},
             "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
             "ate_rms_m": ate, "gen_s": round(t_gen, 1),

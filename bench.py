@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--no-instance", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     args = ap.parse_args()
 
@@ -90,6 +92,9 @@ def main():
     cap = args.surfels + 1_500_000
     ef = ifx.ElasticFusion(w=W, h=H, max_surfels=cap, device=dev, **K)
     inst = ifx.InstanceFusion(ef)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ef.set_option(k_, int(v_))
     d_rgb = torch.from_numpy(st["rgb"]).cuda(dev)
     d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda(dev)
     torch.cuda.synchronize()
@@ -107,6 +112,8 @@ def main():
     def step(k):
         i = k % L
         ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
+        if not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame
+            ef.prefetch_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         frame_no[0] += 1
         if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
             mk, cl = masks[i]

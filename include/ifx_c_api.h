@@ -73,6 +73,13 @@ int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64
  * enqueues work on the handle's stream.  Poses are appended to the device-side trajectory log. */
 int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth,
                              int64_t timestamp, const float* in_pose16, float weight_mult);
+/* Optional one-frame look-ahead for replayed streams (the reference's log readers know the next frame,
+ * IF/utilities/RawLogReader.cpp:66-115): enqueues the part of the NEXT frame that depends only on its
+ * images (copy, bilateral filter, frame pyramids, SO(3) pre-alignment against the current frame's
+ * image) on a side stream, under the current frame's tracking and map passes.  Call it after
+ * ifx_enqueue_frame_device for the current frame and pass the same pointers to the next
+ * ifx_enqueue_frame_device; results are identical with or without it. */
+int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next);
 int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);

@@ -24,12 +24,12 @@ void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a)
 {
     (void)name;
     *a = ifx_event_get(h);
-    hipEventRecord(*a, h->stream);
+    hipEventRecord(*a, h->cur);
 }
 void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a)
 {
     hipEvent_t b = ifx_event_get(h);
-    hipEventRecord(b, h->stream);
+    hipEventRecord(b, h->cur);
     auto it = h->kname_id.find(name);
     int id;
     if (it == h->kname_id.end()) { id = (int)h->knames.size(); h->kname_id[name] = id; h->knames.push_back(name); h->ktimes.push_back(KernelTiming()); }
@@ -59,8 +59,8 @@ static void stage_flush(ifx* h)
 }
 struct StageTimer {
     ifx* h; int id; hipEvent_t a;
-    StageTimer(ifx* h_, int id_) : h(h_), id(id_) { a = ifx_event_get(h); hipEventRecord(a, h->stream); }
-    ~StageTimer() { hipEvent_t b = ifx_event_get(h); hipEventRecord(b, h->stream); h->stage_pending.push_back({id, {a, b}}); }
+    StageTimer(ifx* h_, int id_) : h(h_), id(id_) { a = ifx_event_get(h); hipEventRecord(a, h->cur); }
+    ~StageTimer() { hipEvent_t b = ifx_event_get(h); hipEventRecord(b, h->cur); h->stage_pending.push_back({id, {a, b}}); }
 };
 
 // ------------------------------------------------------------------ create / destroy
@@ -85,7 +85,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     h->cfg = *cfg;
     h->w = cfg->width; h->h = cfg->height; h->P = h->w * h->h; h->cap = cfg->max_surfels;
     size_t P = (size_t)h->P, C = (size_t)h->cap;
-    if (hipStreamCreate(&h->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream_b) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+    h->cur = h->stream;
     ALLOC(h->d_state, sizeof(DevState));
     hipMemset(h->d_state, 0, sizeof(DevState));
     if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
@@ -100,7 +101,13 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
     ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (SN / 2048 + 2) * 4);
-    ALLOC(h->rgb, P * 3); ALLOC(h->depth_raw, P * 2); ALLOC(h->depth_filt, P * 2); ALLOC(h->dm, P * 4); ALLOC(h->dmf, P * 4);
+    for (int q = 0; q < 2; q++) {
+        FrameSlot& f = h->slot[q];
+        ALLOC(f.rgb, P * 3); ALLOC(f.depth_raw, P * 2); ALLOC(f.depth_filt, P * 2); ALLOC(f.dm, P * 4); ALLOC(f.dmf, P * 4);
+        if (hipEventCreateWithFlags(&f.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.released, hipEventDisableTiming) != hipSuccess) {
+            g_err = "hipEventCreate failed"; ifx_destroy(h); return IFX_E_HIP;
+        }
+    }
     hipHostMalloc((void**)&h->rgb_stage, P * 3);
     hipHostMalloc((void**)&h->depth_stage, P * 2);
     ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8);
@@ -130,12 +137,14 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
 extern "C" void ifx_destroy(ifx_t* h)
 {
     if (!h) return;
+    if (h->stream_b) hipStreamSynchronize(h->stream_b);
     if (h->stream) hipStreamSynchronize(h->stream);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
     void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->labels,
-                    h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->rgb, h->depth_raw, h->depth_filt, h->dm, h->dmf, h->key_index, h->key_splat, h->key_ids,
+                    h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
+                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -145,6 +154,8 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_free_tracker(h);
     ifx_free_instance(h);
     ifx_slic_free(h);
+    for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
+    if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -156,6 +167,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     if (s == "compact_every_frame") h->opt_compact_every_frame = value;
     else if (s == "kernel_timing") { hipStreamSynchronize(h->stream); ktime_flush(h); h->opt_kernel_timing = value; }
     else if (s == "reference_passes") h->opt_reference_passes = value;
+    else if (s == "two_streams") h->opt_two_streams = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
     else { h->err = "unknown option " + s; return IFX_E_INVALID; }
     return IFX_OK;
@@ -171,26 +183,60 @@ __global__ void k_frame_result(const DevState* __restrict__ st, FrameResult* __r
     out->count = st->count; out->n_dead = st->n_dead; out->n_new = st->n_new; out->overflow = st->overflow;
 }
 
-// ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's stream.  Loop
-// closure (ferns, deformation graph, model-to-model tracking) is out of scope (SURVEY.md 8f), and so
-// is the first predict() of :453 whose only consumers are those stages.
-static int enqueue_frame(ifx* h, const float* in_pose16, float weight_mult)
+// Frame side of frame `tick` into slot s (copy-in, bilateral + metric depth, frame pyramids, SO(3) pre-alignment).
+// It depends only on the input images and on the previous frame's intensity pyramid, so it goes to the side
+// stream: next to the model pyramid of its own frame, or -- when prefetched -- under the previous frame's
+// tracking and map passes.  src_kind: 0 device pointers, 1 the pinned staging buffers.
+static int enqueue_frame_side(ifx* h, int s, int tick, const uint8_t* rgb, const uint16_t* depth, int src_kind)
 {
-    {
+    FrameSlot& f = h->slot[s];
+    const int bound = h->cur_slot;
+    hipStream_t q = h->opt_two_streams ? h->stream_b : h->stream;
+    if (q != h->stream) HIPCHK(h, hipStreamWaitEvent(q, f.released, 0));   // the frame that last used this slot (two frames ago) is done
+    h->cur = q;
+    ifx_bind_slot(h, s);
+    hipMemcpyKind kind = src_kind ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    hipError_t e1 = hipMemcpyAsync(f.rgb, rgb, (size_t)h->P * 3, kind, q), e2 = hipMemcpyAsync(f.depth_raw, depth, (size_t)h->P * 2, kind, q);
+    if (e1 == hipSuccess && e2 == hipSuccess) {
         StageTimer t(h, 3);
         ifx_preprocess(h);
+        ifx_tracker_frame_side(h, tick == 1);
     }
+    hipEventRecord(f.ready, q);
+    f.for_tick = tick; f.src_rgb = rgb; f.src_depth = depth;
+    h->cur = h->stream;
+    ifx_bind_slot(h, bound);
+    if (e1 != hipSuccess || e2 != hipSuccess) { h->err = "frame copy failed"; return IFX_E_HIP; }
+    return IFX_OK;
+}
+
+// ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Loop
+// closure (ferns, deformation graph, model-to-model tracking) is out of scope (SURVEY.md 8f), and so
+// is the first predict() of :453 whose only consumers are those stages.
+static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult)
+{
+    const int s = h->tick & 1;
+    FrameSlot& f = h->slot[s];
+    if (!(f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0)) {
+        int r = enqueue_frame_side(h, s, h->tick, rgb, depth, src_kind);
+        if (r) return r;
+    }
+    f.for_tick = -1;
+    ifx_bind_slot(h, s);
     if (h->tick == 1) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
         StageTimer t(h, 1);
         ifx_map_init_first(h);
-        ifx_tracker_init_first(h);
     } else {
         {
             StageTimer t(h, 0);
             if (!in_pose16) {
+                ifx_tracker_model_side(h);                       // model pyramid: independent of the frame side
+                HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
                 ifx_tracker_run_frame(h);
                 if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
             } else {
+                HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
                 float* slot = h->d_traj + (size_t)(h->max_traj - 4) * 16;
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
@@ -205,6 +251,7 @@ static int enqueue_frame(ifx* h, const float* in_pose16, float weight_mult)
     }
     int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+    hipEventRecord(f.released, h->stream);
     h->n_traj++;
     h->tick++;
     return IFX_OK;
@@ -214,15 +261,25 @@ extern "C" int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const ui
 {
     (void)timestamp;
     if (!h || !d_rgb || !d_depth) return IFX_E_INVALID;
-    HIPCHK(h, hipMemcpyAsync(h->rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->stream));
-    return enqueue_frame(h, in_pose16, weight_mult);
+    return enqueue_frame(h, d_rgb, d_depth, 0, in_pose16, weight_mult);
+}
+
+// One-frame look-ahead for streams whose next frame is already resident (log replay, the benchmark): the frame
+// side of the NEXT frame is enqueued on the side stream now, so it runs under the current frame's tracking and
+// map passes.  The next ifx_enqueue_frame_device call must pass the same pointers (otherwise the slot is
+// simply recomputed).  Call it after enqueueing the current frame.
+extern "C" int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next)
+{
+    if (!h || !d_rgb_next || !d_depth_next) return IFX_E_INVALID;
+    if (h->tick == 1 || !h->opt_two_streams) return IFX_OK;   // nothing to overlap with
+    return enqueue_frame_side(h, h->tick & 1, h->tick, d_rgb_next, d_depth_next, 0);
 }
 
 extern "C" int ifx_sync(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream_b));
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
@@ -237,9 +294,7 @@ extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* d
     HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
     memcpy(h->depth_stage, depth, (size_t)h->P * 2);
-    HIPCHK(h, hipMemcpyAsync(h->rgb, h->rgb_stage, (size_t)h->P * 3, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->depth_raw, h->depth_stage, (size_t)h->P * 2, hipMemcpyHostToDevice, h->stream));
-    int r = enqueue_frame(h, in_pose16, weight_mult);
+    int r = enqueue_frame(h, h->rgb_stage, h->depth_stage, 1, in_pose16, weight_mult);
     if (r) return r;
     r = ifx_sync(h);
     if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);

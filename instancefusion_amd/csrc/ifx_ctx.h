@@ -64,13 +64,37 @@ struct Pyr {
     void* corres[IFX_NUM_PYRS];                               // 8 B per pixel: short zx, zy; float diff
 };
 
+// Everything that depends only on the input frame (the "frame side" of a frame): copies of the images, the
+// bilateral / metric depth, the frame pyramids and the SO(3) pre-alignment against the previous image.  Two
+// slots alternate so that the frame side of frame k+1 can run on the side stream while frame k is tracked
+// and fused (ifx_prefetch_frame_device), or at least next to the model pyramid of its own frame.
+struct FrameSlot {
+    uint8_t* rgb = nullptr;
+    uint16_t *depth_raw = nullptr, *depth_filt = nullptr;
+    float *dm = nullptr, *dmf = nullptr;
+    uint16_t* depth_tmp[IFX_NUM_PYRS] = {};
+    float *vmap_curr[IFX_NUM_PYRS] = {}, *nmap_curr[IFX_NUM_PYRS] = {};
+    uint8_t* next_img[IFX_NUM_PYRS] = {};
+    int16_t *didx[IFX_NUM_PYRS] = {}, *didy[IFX_NUM_PYRS] = {};
+    DevState* so3 = nullptr;          // shadow state: only the SO(3) fields are used
+    hipEvent_t ready = nullptr;       // recorded on the side stream when the slot is complete
+    hipEvent_t released = nullptr;    // recorded on the main stream when the frame that used the slot is done
+    const void *src_rgb = nullptr, *src_depth = nullptr;
+    int for_tick = -1;                // frame the slot was prepared for
+};
+
 struct KernelTiming { double total_ms = 0; int launches = 0; };
 struct PendingEvent { int name_id; hipEvent_t a, b; };
 
 struct ifx {
     ifx_config cfg;
     int w, h, P, cap;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: model side, tracking, map, instance layer
+    hipStream_t stream_b = nullptr;    // side stream: frame side (FrameSlot)
+    hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
+    FrameSlot slot[2];
+    int cur_slot = 0;
+    int opt_two_streams = 1;
     std::string err;
     int tick = 1;
     int ids_pending = 0;
@@ -162,7 +186,7 @@ void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
     do {                                                                                           \
         hipEvent_t ea_ = nullptr;                                                                  \
         if ((h)->opt_kernel_timing) ifx_ktime_begin((h), name, &ea_);                              \
-        hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);                      \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (h)->cur, __VA_ARGS__);                      \
         if ((h)->opt_kernel_timing) ifx_ktime_end((h), name, ea_);                                 \
     } while (0)
 
@@ -173,7 +197,10 @@ void ifx_slic_free(ifx* h);
 int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric
 int ifx_tracker_init_first(ifx* h);
-int ifx_tracker_run_frame(ifx* h);                            // init model + init frame + GN loops (all on device)
+int ifx_tracker_run_frame(ifx* h);                            // model pyramid + GN loops (all on device); the frame side is in the slot
+int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
+int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
+void ifx_bind_slot(ifx* h, int s);
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
 int ifx_map_predict(ifx* h);                                  // splat + fill-in + dense flag

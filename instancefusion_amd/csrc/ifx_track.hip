@@ -339,6 +339,7 @@ __shared__ long long s_dbg_blk[4];
 struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
 // ICPReduction, EF/Cuda/reduce.cu:257-411.  Rcurr/tcurr/Rprev_inv/tprev come from DevState (or from
 // explicit arguments for the stage API when st == nullptr).
+template <bool WT = false>
 __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __restrict__ st, const IcpArgs& ex, const float* __restrict__ vmap_curr,
                                          const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx,
                                          float fy, float cx, float cy, float distThres, float angleThres, int w, int h, float* __restrict__ partials)
@@ -404,7 +405,7 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
             products7(row, found, acc);
         }
     }
-    block_reduce_store<29>(acc, partials + (size_t)bid * 32);
+    block_reduce_store<29, WT>(acc, partials + (size_t)bid * 32);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
                                                      const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
@@ -927,8 +928,9 @@ __device__ void set_so3_matrices(DevState* st, float fx, float fy, float cx, flo
     for (int k = 0; k < 9; k++) { st->imageBasis[k] = (float)H[k]; st->kinv[k] = (float)Kinv[k]; st->krlr[k] = (float)KR[k]; }
 }
 
-// start of a tracker run: Rprev/tprev from the current pose, identity increments (:278-311, :388-403)
-__global__ void k_track_begin(DevState* st, int so3, float fx2, float fy2, float cx2, float cy2)
+// start of a tracker run (model side): Rprev/tprev from the current pose (:278-311, :388-403), then the seed of the
+// Gauss-Newton loop from the SO(3) result held in the slot's shadow state (:392-403)
+__global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy)
 {
     if (threadIdx.x != 0) return;
     for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];
@@ -946,13 +948,27 @@ __global__ void k_track_begin(DevState* st, int so3, float fx2, float fy2, float
         o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
         o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
     }
-    for (int k = 0; k < 9; k++) { st->resultR[k] = st->lastResultR[k] = (k % 4 == 0) ? 1.0 : 0.0; st->R_lr[k] = (k % 4 == 0) ? 1.f : 0.f; }
-    st->so3_lastError = FLT_MAX / 2; st->so3_lastCount = FLT_MAX / 2;
-    st->so3_done = so3 ? 0 : 1;
-    st->lastSO3Error = 0; st->lastSO3Count = 0; st->lastICPError = 0; st->lastICPCount = 0; st->lastRGBError = 0; st->lastRGBCount = 0;
-    if (so3) set_so3_matrices(st, fx2, fy2, cx2, cy2);
+    st->lastICPError = 0; st->lastICPCount = 0; st->lastRGBError = 0; st->lastRGBCount = 0;
+    st->lastSO3Error = so3 ? ss->lastSO3Error : 0.f; st->lastSO3Count = so3 ? ss->lastSO3Count : 0.f;
+    for (int k = 0; k < 16; k++) st->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (so3)
+        for (int x = 0; x < 3; x++)
+            for (int y = 0; y < 3; y++) st->resultRt[x * 4 + y] = ss->resultR[x * 3 + y];
+    set_warp_matrices(st, fx, fy, cx, cy);
 }
 
+// start of the SO(3) pre-alignment (frame side; `st` is the slot's shadow state): identity increments (:313-330)
+__global__ void k_so3_begin(DevState* st, float fx2, float fy2, float cx2, float cy2)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 9; k++) { st->resultR[k] = st->lastResultR[k] = (k % 4 == 0) ? 1.0 : 0.0; st->R_lr[k] = (k % 4 == 0) ? 1.f : 0.f; }
+    st->so3_lastError = FLT_MAX / 2; st->so3_lastCount = FLT_MAX / 2;
+    st->so3_done = 0;
+    st->lastSO3Error = 0; st->lastSO3Count = 0;
+    set_so3_matrices(st, fx2, fy2, cx2, cy2);
+}
+
+__device__ __forceinline__ void so3_update_scalar(DevState* st, const float* o, float fx2, float fy2, float cx2, float cy2);
 // one SO(3) iteration's host logic, EF/Utils/RGBDOdometry.cpp:348-380, executed by one wave
 // (fixed-order f64 sums of the block partials by shuffle; lane 0 then runs the scalar logic)
 __device__ __forceinline__ void so3_update_wave(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
@@ -967,6 +983,10 @@ __device__ __forceinline__ void so3_update_wave(DevState* st, const float* __res
         o[k] = (float)v;
     }
     if (lane != 0) return;
+    so3_update_scalar(st, o, fx2, fy2, cx2, cy2);
+}
+__device__ __forceinline__ void so3_update_scalar(DevState* st, const float* o, float fx2, float fy2, float cx2, float cy2)
+{
     float jtj[9], jtr[3];
     jtj[0] = o[0]; jtj[1] = jtj[3] = o[1]; jtj[2] = jtj[6] = o[2]; jtr[0] = o[3];
     jtj[4] = o[4]; jtj[5] = jtj[7] = o[5]; jtr[1] = o[6];
@@ -1028,17 +1048,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const u
     if (threadIdx.x < 64) so3_update_wave(st, partials, nb, fx2, fy2, cx2, cy2);
 }
 
-// after the SO(3) loop: seed resultRt and the first warp matrices (:392-403)
-__global__ void k_gn_begin(DevState* st, int so3, float fx, float fy, float cx, float cy)
-{
-    if (threadIdx.x != 0) return;
-    for (int k = 0; k < 16; k++) st->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (so3)
-        for (int x = 0; x < 3; x++)
-            for (int y = 0; y < 3; y++) st->resultRt[x * 4 + y] = st->resultR[x * 3 + y];
-    set_warp_matrices(st, fx, fy, cx, cy);
-}
-
 // one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583 (icp && rgb branch
 // selected by the flags), on one block: fixed-order double sums of the block partials, 6x6 pivoted
 // LDLT in double, SE(3) update, next warp matrices.
@@ -1075,7 +1084,12 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
             }
             int c0 = 0, c1 = 0;
             if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
-                if (threadIdx.x == 0) { c0 = res_total[0]; c1 = res_total[1]; res_total[0] = 0; res_total[1] = 0; }
+                if (threadIdx.x == 0) {
+                    c0 = __hip_atomic_load(&res_total[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c1 = __hip_atomic_load(&res_total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&res_total[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&res_total[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else {
                 int b = threadIdx.x;
                 int2 r0 = (b < res_blocks) ? reinterpret_cast<const int2*>(res_partials)[b] : make_int2(0, 0);
@@ -1148,6 +1162,18 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
             }
         (void)wr;
     }
+    // diagnostics first: nothing below needs the 58 sums or a second copy of the system any more
+    // (keeping them live across the solve cost ~130 registers)
+#pragma unroll
+    for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
+#pragma unroll
+    for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
+    st->rgb_count = rgbSize; st->rgb_sigma = sigma;
+    st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
+    st->lastRGBCount = (float)rgbSize;
+    if (icp) { st->lastICPError = sqrtf(oi[27]) / oi[28]; st->lastICPCount = oi[28]; }
     double result[6];
     ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
     // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
@@ -1188,16 +1214,6 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
     for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krk[k]; }
 #pragma unroll
     for (int k = 0; k < 3; k++) { st->tcurr[k] = tc[k]; st->kt[k] = kt[k]; }
-#pragma unroll
-    for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
-#pragma unroll
-    for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
-    st->rgb_count = rgbSize; st->rgb_sigma = sigma;
-    st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
-    st->lastRGBCount = (float)rgbSize;
-    if (icp) { st->lastICPError = sqrtf(oi[27]) / oi[28]; st->lastICPCount = oi[28]; }
 #ifdef IFX_STAMPS
     { long long ts_d = clock64(); st->dbg[4] += ts_d - ts_c; st->dbg[6] += ts_b - ts_a; st->dbg[7] += ts_c - ts_b; st->dbg[3] += ts_a; }
 #endif
@@ -1336,14 +1352,17 @@ int ifx_alloc_tracker(ifx* h)
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         p.w[i] = h->w >> i; p.h[i] = h->h >> i;
         size_t n = (size_t)p.w[i] * p.h[i];
-        HIPCHK(h, hipMalloc(&p.depth_tmp[i], n * 2));
-        HIPCHK(h, hipMalloc(&p.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_curr[i], n * 12));
+        for (int q = 0; q < 2; q++) {   // frame side, double-buffered (FrameSlot)
+            FrameSlot& f = h->slot[q];
+            HIPCHK(h, hipMalloc(&f.depth_tmp[i], n * 2));
+            HIPCHK(h, hipMalloc(&f.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&f.nmap_curr[i], n * 12));
+            HIPCHK(h, hipMalloc(&f.next_img[i], n)); HIPCHK(h, hipMemset(f.next_img[i], 0, n));
+            HIPCHK(h, hipMalloc(&f.didx[i], n * 2)); HIPCHK(h, hipMalloc(&f.didy[i], n * 2));
+        }
         HIPCHK(h, hipMalloc(&p.vmap_cam[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_cam[i], n * 12));
         HIPCHK(h, hipMalloc(&p.vmap_prev[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_prev[i], n * 12));
         HIPCHK(h, hipMalloc(&p.last_depth[i], n * 4));
-        HIPCHK(h, hipMalloc(&p.last_img[i], n)); HIPCHK(h, hipMalloc(&p.next_img[i], n)); HIPCHK(h, hipMalloc(&p.lastnext_img[i], n));
-        HIPCHK(h, hipMemset(p.lastnext_img[i], 0, n)); HIPCHK(h, hipMemset(p.next_img[i], 0, n));
-        HIPCHK(h, hipMalloc(&p.didx[i], n * 2)); HIPCHK(h, hipMalloc(&p.didy[i], n * 2));
+        HIPCHK(h, hipMalloc(&p.last_img[i], n));
         HIPCHK(h, hipMalloc(&p.cloud[i], n * 12));
         HIPCHK(h, hipMalloc(&p.corres[i], n * 8));
     }
@@ -1353,19 +1372,43 @@ int ifx_alloc_tracker(ifx* h)
     HIPCHK(h, hipMalloc(&h->res_partials, maxb * 2 * 4));
     HIPCHK(h, hipMalloc(&h->so3_partials, maxb * 12 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
-    HIPCHK(h, hipMalloc(&h->d_ticket, 64));
-    HIPCHK(h, hipMemset(h->d_ticket, 0, 64));
+    HIPCHK(h, hipMalloc(&h->d_ticket, 512));
+    HIPCHK(h, hipMemset(h->d_ticket, 0, 512));
+    for (int q = 0; q < 2; q++) {
+        HIPCHK(h, hipMalloc(&h->slot[q].so3, sizeof(DevState)));
+        HIPCHK(h, hipMemset(h->slot[q].so3, 0, sizeof(DevState)));
+    }
+    ifx_bind_slot(h, 0);
     return IFX_OK;
+}
+
+// makes slot s the current frame: the members the rest of the code reads (h->rgb, h->dm, pyr.vmap_curr, ...) are
+// aliases of the slot's buffers; the previous image pyramid of the SO(3) step is the other slot's
+void ifx_bind_slot(ifx* h, int s)
+{
+    FrameSlot& f = h->slot[s];
+    Pyr& p = h->pyr;
+    h->cur_slot = s;
+    h->rgb = f.rgb; h->depth_raw = f.depth_raw; h->depth_filt = f.depth_filt; h->dm = f.dm; h->dmf = f.dmf;
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        p.depth_tmp[i] = f.depth_tmp[i]; p.vmap_curr[i] = f.vmap_curr[i]; p.nmap_curr[i] = f.nmap_curr[i];
+        p.next_img[i] = f.next_img[i]; p.didx[i] = f.didx[i]; p.didy[i] = f.didy[i];
+        p.lastnext_img[i] = h->slot[s ^ 1].next_img[i];
+    }
 }
 
 void ifx_free_tracker(ifx* h)
 {
     Pyr& p = h->pyr;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
-        hipFree(p.depth_tmp[i]); hipFree(p.vmap_curr[i]); hipFree(p.nmap_curr[i]); hipFree(p.vmap_cam[i]); hipFree(p.nmap_cam[i]);
-        hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]); hipFree(p.last_depth[i]); hipFree(p.last_img[i]); hipFree(p.next_img[i]);
-        hipFree(p.lastnext_img[i]); hipFree(p.didx[i]); hipFree(p.didy[i]); hipFree(p.cloud[i]); hipFree(p.corres[i]);
+        for (int q = 0; q < 2; q++) {
+            FrameSlot& f = h->slot[q];
+            hipFree(f.depth_tmp[i]); hipFree(f.vmap_curr[i]); hipFree(f.nmap_curr[i]); hipFree(f.next_img[i]); hipFree(f.didx[i]); hipFree(f.didy[i]);
+        }
+        hipFree(p.vmap_cam[i]); hipFree(p.nmap_cam[i]); hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]); hipFree(p.last_depth[i]); hipFree(p.last_img[i]);
+        hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
+    for (int q = 0; q < 2; q++) hipFree(h->slot[q].so3);
     hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
@@ -1407,7 +1450,7 @@ static void tracker_init_model(ifx* h, const float* pv, const float* pn, const u
 static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t* rgb)
 {
     Pyr& p = h->pyr;
-    hipMemcpyAsync(p.depth_tmp[0], depth_filt, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpyAsync(p.depth_tmp[0], depth_filt, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur);
     LAUNCH(h, "intensity", dim3(cdiv(h->P, 256)), dim3(256), k_intensity, rgb, 3, h->P, p.next_img[0]);
     for (int i = 1; i < IFX_NUM_PYRS; i++) {
         LAUNCH(h, "pyrdown_u16", G2(p.w[i], p.h[i]), B2, k_pyrdown_u16, p.depth_tmp[i - 1], p.w[i - 1], p.h[i - 1], p.depth_tmp[i]);
@@ -1428,23 +1471,12 @@ static void tracker_run(ifx* h, float weight_mult)
     Pyr& p = h->pyr;
     const ifx_config& c = h->cfg;
     const int icp = c.icp_weight > 0, rgb = c.icp_weight < 100, so3 = c.so3;
-    const float d2 = 4.f;
-    LAUNCH(h, "track_begin", dim3(1), dim3(64), k_track_begin, h->d_state, so3, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
-    IcpArgs ia; ResArgs ra; So3Args sa;
-    memset(&ia, 0, sizeof(ia)); memset(&ra, 0, sizeof(ra)); memset(&sa, 0, sizeof(sa));
-    if (so3) {
-        int L = 2, n = p.w[L] * p.h[L], nb = cdiv(n, RED_THREADS);
-        for (int it = 0; it < 10; it++) {
-            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, h->d_state, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], h->so3_partials, nb, h->d_ticket + 4,
-                   c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
-        }
-    }
     int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
     int first = -1;
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) if (iterations[i] > 0) { first = i; break; }
     {
-        float div = (float)(1 << (first < 0 ? 0 : first));
-        LAUNCH(h, "gn_begin", dim3(1), dim3(64), k_gn_begin, h->d_state, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div);
+        const float div = (float)(1 << (first < 0 ? 0 : first));
+        LAUNCH(h, "track_gn_begin", dim3(1), dim3(64), k_track_gn_begin, h->d_state, h->slot[h->cur_slot].so3, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div);
     }
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
@@ -1454,18 +1486,20 @@ static void tracker_run(ifx* h, float weight_mult)
         int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n);
         if (rgb && iterations[i] > 0)
             LAUNCH(h, "project_cloud", G2(lw, lh), B2, k_project_cloud, p.last_depth[i], lw, lh, 1.0f / fx, 1.0f / fy, cx, cy, p.cloud[i]);
+        // intrinsics of the level the iteration after this level's last one runs at (for the warp matrices the solve emits)
+        int nl = i - 1;
+        while (nl >= 0 && iterations[nl] == 0) nl--;
+        if (nl < 0) nl = 0;
+        const float ld = (float)(1 << nl);
+        PairArgs pa;
+        pa.vmap_curr = p.vmap_curr[i]; pa.nmap_curr = p.nmap_curr[i]; pa.vmap_prev = p.vmap_prev[i]; pa.nmap_prev = p.nmap_prev[i];
+        pa.fx = fx; pa.fy = fy; pa.cx = cx; pa.cy = cy; pa.distThres = 0.10f; pa.angleThres = sinf(20.f * 3.14159254f / 180.f);
+        pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
+        pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
+        pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
+        pa.icp_partials = h->icp_partials; pa.res_partials = h->res_partials; pa.res_total = (int*)(h->d_ticket + 8);
         for (int j = 0; j < iterations[i]; j++) {
-            // intrinsics of the level the next iteration runs at (for the warp matrices the solve emits)
-            int nl = i;
-            if (j == iterations[i] - 1) { nl = i - 1; while (nl >= 0 && iterations[nl] == 0) nl--; if (nl < 0) nl = 0; }
-            float nd = (float)(1 << nl);
-            PairArgs pa;
-            pa.vmap_curr = p.vmap_curr[i]; pa.nmap_curr = p.nmap_curr[i]; pa.vmap_prev = p.vmap_prev[i]; pa.nmap_prev = p.nmap_prev[i];
-            pa.fx = fx; pa.fy = fy; pa.cx = cx; pa.cy = cy; pa.distThres = 0.10f; pa.angleThres = sinf(20.f * 3.14159254f / 180.f);
-            pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
-            pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
-            pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
-            pa.icp_partials = h->icp_partials; pa.res_partials = h->res_partials; pa.res_total = (int*)(h->d_ticket + 8);
+            const float nd = (j == iterations[i] - 1) ? ld : div;
             LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, h->d_state, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
@@ -1477,14 +1511,43 @@ static void tracker_run(ifx* h, float weight_mult)
         }
     }
     LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, rgb, 1, weight_mult);
-    if (so3)
-        for (int i = 0; i < IFX_NUM_PYRS; i++) std::swap(p.lastnext_img[i], p.next_img[i]);
+}
+
+// frame side of the tracker for the bound slot: frame pyramids, then (unless this is the first frame, which only
+// needs its intensity pyramid as the next frame's "previous image") the SO(3) pre-alignment against the other
+// slot's intensity pyramid, EF/Utils/RGBDOdometry.cpp:313-386: up to 10 reduction + update launches, each exiting at
+// once after convergence (device flag)
+int ifx_tracker_frame_side(ifx* h, int first)
+{
+    Pyr& p = h->pyr;
+    const ifx_config& c = h->cfg;
+    if (first) {
+        LAUNCH(h, "intensity", dim3(cdiv(h->P, 256)), dim3(256), k_intensity, h->rgb, 3, h->P, p.next_img[0]);
+        for (int i = 0; i + 1 < IFX_NUM_PYRS; i++)
+            LAUNCH(h, "pyrdown_u8", G2(p.w[i + 1], p.h[i + 1]), B2, k_pyrdown_gauss_u8, p.next_img[i], p.w[i], p.h[i], p.next_img[i + 1]);
+        return IFX_OK;
+    }
+    tracker_init_frame(h, h->depth_filt, h->rgb);
+    if (c.so3) {
+        const float d2 = 4.f;
+        const int L = 2, n = p.w[L] * p.h[L], nb = cdiv(n, RED_THREADS);
+        DevState* ss = h->slot[h->cur_slot].so3;
+        LAUNCH(h, "so3_begin", dim3(1), dim3(64), k_so3_begin, ss, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
+        for (int it = 0; it < 10; it++)
+            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, ss, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], h->so3_partials, nb, h->d_ticket + 4, c.fx / d2, c.fy / d2,
+                   c.cx / d2, c.cy / d2);
+    }
+    return IFX_OK;
+}
+
+int ifx_tracker_model_side(ifx* h)
+{
+    tracker_init_model(h, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
+    return IFX_OK;
 }
 
 int ifx_tracker_run_frame(ifx* h)
 {
-    tracker_init_model(h, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
-    tracker_init_frame(h, h->depth_filt, h->rgb);
     tracker_run(h, 1.0f);
     return IFX_OK;
 }
@@ -1602,7 +1665,7 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
     LAUNCH(h, "write_pose", dim3(1), dim3(64), k_write_pose, h->d_state, h->d_traj);
     LAUNCH(h, "set_dense", dim3(1), dim3(64), k_set_dense, h->d_state, 1);
     tracker_init_model(h, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
-    tracker_init_frame(h, h->depth_filt, h->rgb);
+    ifx_tracker_frame_side(h, 0);
     tracker_run(h, 1.0f);
     DevState hs;
     HIPCHK(h, hipMemcpyAsync(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost, h->stream));

@@ -82,8 +82,9 @@ def test_tracker_gputest_pair(ifx, orc, gputest_pair, oracle_pins):
                     assert nan_equal(a, b), (name, lvl)
             else:
                 assert np.array_equal(a, b), (name, lvl)
-        # after the run the so3 swap made "lastnext" hold this frame's intensity pyramid on both sides
-        assert np.array_equal(g.tracker_buffer("lastnext_img", lvl), orc_trk_buf(orc, t, "lastnext_img", lvl, lw, lh))
+        # this frame's intensity pyramid: the oracle swapped it into "lastnext" after the run (so3), the HIP path keeps it
+        # in the frame slot, where it is the next frame's "previous image"
+        assert np.array_equal(g.tracker_buffer("next_img", lvl), orc_trk_buf(orc, t, "lastnext_img", lvl, lw, lh))
     L.orc_tracker_destroy(t)
     g.close()
 

@@ -284,6 +284,97 @@ __global__ void k_project_cloud(const float* __restrict__ depth, int w, int h, f
     cloud[(y * w + x) * 3 + 2] = z;
 }
 
+
+// ---- model side in one launch per pyramid level.  Level 0: copyMaps + verticesToDepth + intensity (k_model_level0),
+// the global transform (k_transform_maps) and the point cloud of the photometric step (k_project_cloud) are all
+// per-pixel, so they chain through registers.  Level i > 0: the 2x2 resize of both maps, the two 5x5 Gaussian
+// pyr-downs (depth, intensity), then transform + cloud of the SAME output pixel.  16 launches -> 3; a dependent
+// launch costs ~4.7 us on this GPU whatever its size.
+struct ModelOut {
+    float *vcam, *ncam, *depth;     // camera-frame maps (input of the next level) and model depth of this level
+    uint8_t* img;
+    float *vprev, *nprev, *cloud;   // global-frame maps for ICP, point cloud for the RGB step (nullptr: skipped)
+    float invFx, invFy, cx, cy;
+};
+__device__ __forceinline__ void model_tail(const DevState* __restrict__ st, int x, int y, int w, int h, v3 vs, v3 ns, float z, const ModelOut& o)
+{
+    const float* P = st->pose;
+    const float qn = qnan_f();
+    v3 vd = v3m(qn, qn, qn);
+    if (!(vs.x != vs.x)) vd = xf_dir(P, vs) + v3m(P[3], P[7], P[11]);
+    o.vprev[y * w + x] = vd.x; o.vprev[(y + h) * w + x] = vd.y; o.vprev[(y + 2 * h) * w + x] = vd.z;
+    v3 nd = v3m(qn, qn, qn);
+    if (!(ns.x != ns.x)) nd = xf_dir(P, ns);
+    o.nprev[y * w + x] = nd.x; o.nprev[(y + h) * w + x] = nd.y; o.nprev[(y + 2 * h) * w + x] = nd.z;
+    if (o.cloud) {
+        o.cloud[(y * w + x) * 3 + 0] = (float)((x - o.cx) * z * o.invFx);
+        o.cloud[(y * w + x) * 3 + 1] = (float)((y - o.cy) * z * o.invFy);
+        o.cloud[(y * w + x) * 3 + 2] = z;
+    }
+}
+__global__ void k_model_l0(const DevState* __restrict__ st, const float* __restrict__ pv, const float* __restrict__ pn, const uint8_t* __restrict__ pi, const float* __restrict__ fv,
+                           const float* __restrict__ fn, const uint8_t* __restrict__ fi, int w, int h, float cutoff, ModelOut o)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const bool fill = !st->dense_enough;
+    const float4 v = reinterpret_cast<const float4*>(fill ? fv : pv)[y * w + x];
+    const float4 n = reinterpret_cast<const float4*>(fill ? fn : pn)[y * w + x];
+    const uint8_t* s = (fill ? fi : pi) + (size_t)(y * w + x) * 4;
+    const float qn = qnan_f();
+    bool ok = !(v.z == 0);
+    v3 vs = v3m(ok ? v.x : qn, ok ? v.y : qn, ok ? v.z : qn), ns = v3m(ok ? n.x : qn, ok ? n.y : qn, ok ? n.z : qn);
+    o.vcam[y * w + x] = vs.x; o.vcam[(y + h) * w + x] = vs.y; o.vcam[(y + 2 * h) * w + x] = vs.z;
+    o.ncam[y * w + x] = ns.x; o.ncam[(y + h) * w + x] = ns.y; o.ncam[(y + 2 * h) * w + x] = ns.z;
+    const float z = (v.z > cutoff || v.z <= 0) ? qn : v.z;
+    o.depth[y * w + x] = z;
+    o.img[y * w + x] = (uint8_t)(int)((float)s[0] * 0.114f + (float)s[1] * 0.299f + (float)s[2] * 0.587f);
+    model_tail(st, x, y, w, h, vs, ns, z, o);
+}
+__global__ void k_model_down(const DevState* __restrict__ st, const float* __restrict__ vin, const float* __restrict__ nin, const float* __restrict__ din, const uint8_t* __restrict__ iin,
+                             int sw, int sh, ModelOut o)
+{
+    const int dw = sw / 2, dh = sh / 2;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float qn = qnan_f();
+    const int xs = x * 2, ys = y * 2;
+    v3 res[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {   // resizeMapKernel<normalize>, EF/Cuda/cudafuncs.cu:365-416
+        const float* in = m ? nin : vin;
+        float* out = m ? o.ncam : o.vcam;
+        float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
+        v3 n = v3m(qn, qn, qn);
+        if (!((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11))) {
+            n.x = (x00 + x01 + x10 + x11) / 4;
+            const float* py = in + sh * sw;
+            n.y = (py[ys * sw + xs] + py[ys * sw + xs + 1] + py[(ys + 1) * sw + xs] + py[(ys + 1) * sw + xs + 1]) / 4;
+            const float* pz = in + 2 * sh * sw;
+            n.z = (pz[ys * sw + xs] + pz[ys * sw + xs + 1] + pz[(ys + 1) * sw + xs] + pz[(ys + 1) * sw + xs + 1]) / 4;
+            if (m) n = normalized(n);
+        }
+        out[y * dw + x] = n.x; out[(y + dh) * dw + x] = n.y; out[(y + 2 * dh) * dw + x] = n.z;
+        res[m] = n;
+    }
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+    float sumf = 0, sumi = 0;
+    int cntf = 0, cnti = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+            const float sf = din[cy * sw + cx];       // pyrDownKernelGaussF :332-363
+            if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
+            const int si = iin[cy * sw + cx];         // pyrDownKernelIntensityGauss :470-500
+            if (si > 0) { sumi += si * g; cnti += (int)g; }
+        }
+    const float z = (float)(sumf / (float)cntf);
+    o.depth[y * dw + x] = z;
+    o.img[y * dw + x] = cnti ? (uint8_t)f2i_rz(sumi / (float)cnti) : (uint8_t)0;
+    model_tail(st, x, y, dw, dh, res[0], res[1], z, o);
+}
+
 // ======================================================================= reductions (a4-a7)
 
 #define RED_THREADS 256
@@ -1434,15 +1525,18 @@ int ifx_tracker_init_first(ifx* h)
 static void tracker_init_model(ifx* h, const float* pv, const float* pn, const uint8_t* pi, const float* fv, const float* fn, const uint8_t* fi)
 {
     Pyr& p = h->pyr;
-    LAUNCH(h, "model_level0", G2(h->w, h->h), B2, k_model_level0, h->d_state, pv, pn, pi, fv, fn, fi, h->w, h->h, p.vmap_cam[0], p.nmap_cam[0],
-           p.last_depth[0], p.last_img[0], 6.0f);
-    for (int i = 1; i < IFX_NUM_PYRS; i++) {
-        LAUNCH(h, "resize_maps", G2(p.w[i], p.h[i]), B2, k_resize_maps, p.vmap_cam[i - 1], p.nmap_cam[i - 1], p.w[i - 1], p.h[i - 1], p.vmap_cam[i], p.nmap_cam[i]);
-        LAUNCH(h, "pyrdown_f", G2(p.w[i], p.h[i]), B2, k_pyrdown_gauss_f, p.last_depth[i - 1], p.w[i - 1], p.h[i - 1], p.last_depth[i]);
-        LAUNCH(h, "pyrdown_u8", G2(p.w[i], p.h[i]), B2, k_pyrdown_gauss_u8, p.last_img[i - 1], p.w[i - 1], p.h[i - 1], p.last_img[i]);
+    const ifx_config& c = h->cfg;
+    const int rgb = c.icp_weight < 100;
+    const int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        const float div = (float)(1 << i);
+        ModelOut o;
+        o.vcam = p.vmap_cam[i]; o.ncam = p.nmap_cam[i]; o.depth = p.last_depth[i]; o.img = p.last_img[i];
+        o.vprev = p.vmap_prev[i]; o.nprev = p.nmap_prev[i]; o.cloud = (rgb && iterations[i] > 0) ? p.cloud[i] : nullptr;
+        o.invFx = 1.0f / (c.fx / div); o.invFy = 1.0f / (c.fy / div); o.cx = c.cx / div; o.cy = c.cy / div;
+        if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, h->d_state, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o);
+        else LAUNCH(h, "model_down", G2(p.w[i], p.h[i]), B2, k_model_down, h->d_state, p.vmap_cam[i - 1], p.nmap_cam[i - 1], p.last_depth[i - 1], p.last_img[i - 1], p.w[i - 1], p.h[i - 1], o);
     }
-    for (int i = 0; i < IFX_NUM_PYRS; i++)
-        LAUNCH(h, "transform_maps", G2(p.w[i], p.h[i]), B2, k_transform_maps, h->d_state, p.vmap_cam[i], p.nmap_cam[i], p.w[i], p.h[i], p.vmap_prev[i], p.nmap_prev[i]);
 }
 
 // frame side: initICP(filteredDepth) + initRGB (EF/Utils/RGBDOdometry.cpp:118-142,243-247); nextDepth
@@ -1484,8 +1578,6 @@ static void tracker_run(ifx* h, float weight_mult)
         float div = (float)(1 << i);
         float fx = c.fx / div, fy = c.fy / div, cx = c.cx / div, cy = c.cy / div;
         int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n);
-        if (rgb && iterations[i] > 0)
-            LAUNCH(h, "project_cloud", G2(lw, lh), B2, k_project_cloud, p.last_depth[i], lw, lh, 1.0f / fx, 1.0f / fy, cx, cy, p.cloud[i]);
         // intrinsics of the level the iteration after this level's last one runs at (for the warp matrices the solve emits)
         int nl = i - 1;
         while (nl >= 0 && iterations[nl] == 0) nl--;

@@ -100,7 +100,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
-    ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (SN / 2048 + 2) * 4);
+    ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (SN / 1024 + 8) * 4);
     for (int q = 0; q < 2; q++) {
         FrameSlot& f = h->slot[q];
         ALLOC(f.rgb, P * 3); ALLOC(f.depth_raw, P * 2); ALLOC(f.depth_filt, P * 2); ALLOC(f.dm, P * 4); ALLOC(f.dmf, P * 4);
@@ -174,9 +174,11 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
 }
 
 // ------------------------------------------------------------------ frame orchestration
-__global__ void k_frame_result(const DevState* __restrict__ st, FrameResult* __restrict__ out, float* __restrict__ traj_slot)
+__global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restrict__ out, float* __restrict__ traj_slot)
 {
     if (threadIdx.x != 0) return;
+    out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
+    st->seg_acc[0] = 0; st->seg_acc[1] = 0;
     for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
     out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
     out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
@@ -252,6 +254,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
     hipEventRecord(f.released, h->stream);
+    h->seg_counts_valid = 1;
     h->n_traj++;
     h->tick++;
     return IFX_OK;
@@ -410,6 +413,7 @@ extern "C" int ifx_map_count(ifx_t* h)
 extern "C" int ifx_compact(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     ifx_compact_enqueue(h, 1);
     return ifx_sync(h);
 }
@@ -417,6 +421,7 @@ extern "C" int ifx_compact(ifx_t* h)
 extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
 {
     if (!h) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     int r = ifx_compact(h);   // live surfels in map order
     if (r) return r;
     DevState hs;
@@ -442,6 +447,7 @@ extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float
 extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const float* col, const float* tm, const float* ic, const float* votes)
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->pc, pc, (size_t)n * 16, hipMemcpyHostToDevice));

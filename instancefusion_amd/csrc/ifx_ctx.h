@@ -42,6 +42,8 @@ struct DevState {
     int rgb_count, rgb_sigma;
     // instance
     int seg_counts[2];
+    int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
+    unsigned int append_ticket;  // last-block ticket of k_append_scan
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
@@ -49,6 +51,7 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     float pose[16];
     float diag[8];
     int count, n_dead, n_new, overflow;
+    int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
 };
 
 struct Pyr {
@@ -155,6 +158,7 @@ struct ifx {
     int* d_inst_stats = nullptr;       // [96*2]
     int* d_clean_list = nullptr;
     int last_seg_frame = -1;
+    int seg_counts_valid = 0;          // h_result->seg_counts describe the current ids_after / votes
     int clean_times = 0;
     void* slic = nullptr;              // superpixel buffers (ifx_slic.hip), allocated on first use
     // timing

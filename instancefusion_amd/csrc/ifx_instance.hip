@@ -272,13 +272,20 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
 {
     if (!h) return IFX_E_INVALID;
     const int downsample = 10, fixedL = 2, fixedH = 45;
-    int* cnt = h->d_inst_stats;
-    HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
-    int gw = cdiv(h->w, downsample), gh = cdiv(h->h, downsample);
-    LAUNCH(h, "check_project", dim3(cdiv(gw, 16), cdiv(gh, 16)), dim3(16, 16), k_check_project, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->w, h->h, downsample, cnt);
     int count[2];
-    HIPCHK(h, hipMemcpyAsync(count, cnt, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->seg_counts_valid) {
+        // the frame that just ran accumulated the two sums while it rendered ids_after (k_raster_finish) and left them in the
+        // pinned frame result: nothing to launch, only the frame to wait for
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        count[0] = h->h_result->seg_counts[0]; count[1] = h->h_result->seg_counts[1];
+    } else {
+        int* cnt = h->d_inst_stats;
+        HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
+        int gw = cdiv(h->w, downsample), gh = cdiv(h->h, downsample);
+        LAUNCH(h, "check_project", dim3(cdiv(gw, 16), cdiv(gh, 16)), dim3(16, 16), k_check_project, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->w, h->h, downsample, cnt);
+        HIPCHK(h, hipMemcpyAsync(count, cnt, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     int w = h->w, hh = h->h;
     bool test1 = count[0] > (w / downsample * hh / downsample * 0.48 * 30);
     bool test2 = count[1] < (w / downsample * hh / downsample * 0.2);
@@ -390,6 +397,7 @@ static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     if (flags & 1) { h->err = "kNN label smoothing (flann step) is not implemented"; return IFX_E_INVALID; }
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
     hipEvent_t ea = ifx_event_get(h);

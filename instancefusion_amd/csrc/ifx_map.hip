@@ -361,11 +361,17 @@ __global__ void k_ids_resolve(unsigned long long* __restrict__ keys, int P, int3
 __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
-                                uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg)
+                                uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
+                                unsigned long long* __restrict__ id_keys, int32_t* __restrict__ ids_out)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
     int k = y * c.w + x;
+    if (ids_out) {   // k_ids_resolve of the id render that shared the raster pass
+        unsigned long long ik = id_keys[k];
+        id_keys[k] = IFX_KEY_EMPTY;
+        ids_out[k] = (ik == IFX_KEY_EMPTY) ? 0 : (int32_t)(ik & 0xFFFFFFFFull);
+    }
     unsigned long long key = keys[k];
     keys[k] = IFX_KEY_EMPTY;
     float4 vo = make_float4(0, 0, 0, 0), no = make_float4(0, 0, 0, 0);
@@ -408,22 +414,57 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
 }
 
 // ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267 on the (w/20 x h/20) nearest resample
-__global__ void k_dense(DevState* st, const uchar4* __restrict__ pimg, int w, int h)
+// End of a raster pass in one launch: block 0 = the dense-enough test (k_dense) and the re-arm of the work list;
+// blocks 1.. = checkProjectDepthAndInstanceKernel (IF/Core/InstanceFusionCuda.cu:736-760) over the id image this pass
+// rendered, accumulated for k_frame_result, so that whetherDoSegmentation needs no launch of its own.
+__global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, int w, int h, int do_dense, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap,
+                                int downsample)
 {
-    __shared__ int lds[4];
-    int rw = w / 20, rh = h / 20, cnt = 0;
-    for (int t = threadIdx.x; t < rw * rh; t += blockDim.x) {
-        int j = t / rw, i = t - j * rw;
-        int sx = (i * w + w / 2) / rw, sy = (j * h + h / 2) / rh;
-        uchar4 s = pimg[sy * w + sx];
-        cnt += (s.x > 0 && s.y > 0 && s.z > 0);
+    if (blockIdx.x == 0) {
+        if (do_dense) {
+            __shared__ int lds[4];
+            int rw = w / 20, rh = h / 20, cnt = 0;
+            for (int t = threadIdx.x; t < rw * rh; t += blockDim.x) {
+                int j = t / rw, i = t - j * rw;
+                int sx = (i * w + w / 2) / rw, sy = (j * h + h / 2) / rh;
+                uchar4 s = pimg[sy * w + sx];
+                cnt += (s.x > 0 && s.y > 0 && s.z > 0);
+            }
+            cnt = wave_sum_i(cnt);
+            if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int sum = lds[0] + lds[1] + lds[2] + lds[3];
+                st->dense_enough = ((float)sum / (float)(rw * rh) > 0.75f) ? 1 : 0;
+            }
+        }
+        if (threadIdx.x == 0) st->list_n[0] = 0;
+        return;
     }
-    cnt = wave_sum_i(cnt);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = lds[0] + lds[1] + lds[2] + lds[3];
-        st->dense_enough = ((float)sum / (float)(rw * rh) > 0.75f) ? 1 : 0;
+    const int gw = (w + downsample - 1) / downsample, gh = (h + downsample - 1) / downsample;
+    const int t = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    int mass = 0, empty = 0;
+    if (t < gw * gh) {
+        const int gy = t / gw, gx = t - gy * gw, x = gx * downsample, y = gy * downsample;
+        if (x < w && y < h) {
+            const int id = ids[y * w + x];
+            if (id > 0 && id < st->count) {
+                for (int q = 0; q < 12; q++) {
+                    float4 v = votes[(size_t)q * cap + id];
+                    int a, b;
+                    vote_decode(v.x, a, b); mass += a + b;
+                    vote_decode(v.y, a, b); mass += a + b;
+                    vote_decode(v.z, a, b); mass += a + b;
+                    vote_decode(v.w, a, b); mass += a + b;
+                }
+            } else empty = 1;
+        }
+    }
+    mass = wave_sum_i(mass);
+    empty = wave_sum_i(empty);
+    if ((threadIdx.x & 63) == 0) {
+        if (mass) atomicAdd(&st->seg_acc[0], mass);
+        if (empty) atomicAdd(&st->seg_acc[1], empty);
     }
 }
 
@@ -725,11 +766,14 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
     if (want & LIST_SPLAT) {
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
-               (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-        LAUNCH(h, "dense", dim3(1), dim3(256), k_dense, h->d_state, (const uchar4*)h->pred_image, h->w, h->h);
-    }
-    if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
-    LAUNCH(h, "list_reset", dim3(1), dim3(64), k_list_reset, h->d_state, 1);
+               (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
+               (want & LIST_IDS) ? ids_out : (int32_t*)nullptr);
+    } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
+    // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums
+    const int seg = (want & LIST_IDS) && ids_out == h->ids_after && d_pose_inv == nullptr;
+    const int ds = 10, nseg = seg ? cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256) : 0;
+    LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, (want & LIST_SPLAT) ? 1 : 0, h->ids_after,
+           (const float4*)h->votes, h->cap, ds);
 }
 static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime) { raster_pass(h, d_pose_inv, time, maxTime, LIST_SPLAT, nullptr); }
 
@@ -925,6 +969,116 @@ __global__ void k_append_count(DevState* st, const int* total, int cap)
     }
 }
 
+// The append of the new surfels in two launches (was: flags, 3-kernel scan, scatter, count).  Launch 1 evaluates
+// the stability test for the pixels that created a surfel, in column-major order (the order of the reference's
+// transform-feedback stream), 4 consecutive order indices per thread, and leaves the flags and one count per
+// 1024-pixel block; it also re-arms the clean work lists.  Launch 2: every block adds the counts of the blocks
+// before it (<= 300 integers), scans its own flags and scatters; the block that finishes last publishes the
+// new surfel count.
+#define NEW_PER_BLOCK 1024
+__global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
+                                                         const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags,
+                                                         int* __restrict__ block_counts)
+{
+    __shared__ int lds[4];
+    const int P = c.w * c.h, ord0 = blockIdx.x * NEW_PER_BLOCK + threadIdx.x * 4;
+    const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    int keep[4], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int ord = ord0 + u;
+        keep[u] = 0;
+        if (ord < P) {
+            const int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
+            if (assoc[k] == ASSOC_NEW) {
+                float lastT = -2.f;
+                keep[u] = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, tap);
+            }
+        }
+        cnt += keep[u];
+    }
+    if (ord0 + 3 < P) *reinterpret_cast<int4*>(flags + ord0) = make_int4(keep[0], keep[1], keep[2], keep[3]);
+    else
+        for (int u = 0; u < 4; u++) if (ord0 + u < P) flags[ord0 + u] = keep[u];
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_counts[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+        if (blockIdx.x == 0) { st->list_n[1] = 0; st->list_n[2] = 0; }   // k_clean_list, the launch before this one, was their last reader
+    }
+}
+
+__global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
+                                                     const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
+                                                     float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
+{
+    __shared__ int s_wave[4], s_base, s_last;
+    const int P = c.w * c.h, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int count0 = st->count;
+    // counts of the blocks before this one
+    int before = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) before += block_counts[b];
+    before = wave_sum_i(before);
+    if (lane == 0) s_wave[wid] = before;
+    __syncthreads();
+    if (tid == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    // exclusive scan of this block's flags: 4 per thread, wave scan by shuffles, wave totals through LDS
+    const int ord0 = blockIdx.x * NEW_PER_BLOCK + tid * 4;
+    int f[4] = {0, 0, 0, 0};
+    if (ord0 + 3 < P) { int4 v = *reinterpret_cast<const int4*>(flags + ord0); f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+    else
+        for (int u = 0; u < 4; u++) if (ord0 + u < P) f[u] = flags[ord0 + u];
+    const int mine = f[0] + f[1] + f[2] + f[3];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) s_wave[wid] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int q = 0; q < wid; q++) wave_off += s_wave[q];
+    int rank = s_base + wave_off + incl - mine;
+    bool over = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (!f[u]) continue;
+        const int ord = ord0 + u, i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
+        const int n = count0 + rank++;
+        if (n >= cap) { over = true; continue; }
+        pc[n] = mpc[k];
+        nr[n] = mnr[k];
+        { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
+        col[n] = make_float2(mcol[k], 0.f);
+        tm[n] = make_float2((float)time, (float)time);
+        ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, -2.f);
+        for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (over) st->overflow = 1;
+    // every block has read st->count before it draws its ticket; the last one publishes the new count
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int t = __hip_atomic_fetch_add(&st->append_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(nblocks - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    int total = 0;
+    for (int b = tid; b < nblocks; b += 256) total += block_counts[b];
+    total = wave_sum_i(total);
+    __syncthreads();
+    if (lane == 0) s_wave[wid] = total;
+    __syncthreads();
+    if (tid == 0) {
+        int t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3], nc = count0 + t;
+        if (nc > cap) { nc = cap; st->overflow = 1; }
+        st->n_new = nc - count0;
+        st->count = nc;
+        __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------ tombstone compaction
 __global__ void k_alive_flags(const DevState* __restrict__ st, const float2* __restrict__ tm, int* __restrict__ flags, int cap)
 {
@@ -987,13 +1141,11 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time)
            (float4*)h->index_tap);
     LAUNCH(h, "clean_list", dim3(1024), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_b, h->list_c);
-    LAUNCH(h, "list_reset", dim3(1), dim3(64), k_list_reset, h->d_state, 2);
-    LAUNCH(h, "clean_new_flags", dim3(cdiv(h->P, 256)), dim3(256), k_clean_new_flags, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc,
-           (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags);
-    ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
-    LAUNCH(h, "append_new", dim3(cdiv(h->P, 256)), dim3(256), k_append_new, h->d_state, c, time, time, h->scan_flags, h->scan_out, (const float4*)h->meas_pc,
+    const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+    LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr,
+           (const float4*)h->index_tap, h->scan_flags, h->scan_block);
+    LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
-    LAUNCH(h, "append_count", dim3(1), dim3(64), k_append_count, h->d_state, &h->d_state->seg_counts[0], h->cap);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
 }
 
@@ -1058,6 +1210,7 @@ extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int
 extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;
@@ -1068,6 +1221,7 @@ extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting
 extern "C" int ifx_clean(ifx_t* h, const float* pose16, int time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;

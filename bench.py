@@ -111,9 +111,9 @@ def main():
 
     def step(k):
         i = k % L
+        if not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame's tracking
+            ef.hint_next_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
-        if not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame
-            ef.prefetch_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         frame_no[0] += 1
         if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
             mk, cl = masks[i]

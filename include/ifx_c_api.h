@@ -80,6 +80,10 @@ int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_d
  * ifx_enqueue_frame_device for the current frame and pass the same pointers to the next
  * ifx_enqueue_frame_device; results are identical with or without it. */
 int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next);
+/* The same look-ahead announced BEFORE the current frame is enqueued: the next ifx_enqueue_frame_device
+ * call places the announced frame's image-only work itself (behind the coarse pyramid levels of its own
+ * tracker, where the GPU is least busy).  Preferred over ifx_prefetch_frame_device. */
+int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next);
 int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);

@@ -67,6 +67,7 @@ _SIGS = {
     "ifx_process_frame": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, _P]),
     "ifx_enqueue_frame_device": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
+    "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_sync": (C.c_int, [_P]),
     "ifx_get_pose": (C.c_int, [_P, _P]),
     "ifx_tick": (C.c_int, [_P]),
@@ -206,6 +207,10 @@ class ElasticFusion:
     def prefetch_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         """One-frame look-ahead: frame side of the NEXT frame on the side stream (see ifx_prefetch_frame_device)."""
         self._chk(self.L.ifx_prefetch_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_prefetch_frame_device")
+
+    def hint_next_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
+        """Announce the frame after the one about to be enqueued (see ifx_hint_next_frame_device)."""
+        self._chk(self.L.ifx_hint_next_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_hint_next_frame_device")
 
     def sync(self):
         self._chk(self.L.ifx_sync(self.handle), "ifx_sync")

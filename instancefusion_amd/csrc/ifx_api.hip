@@ -212,6 +212,16 @@ static int enqueue_frame_side(ifx* h, int s, int tick, const uint8_t* rgb, const
     return IFX_OK;
 }
 
+// frame side of the frame announced by ifx_hint_next_frame_device: called from the middle of the tracker's enqueue
+// (or at the end of the frame when nothing was tracked)
+int ifx_enqueue_hinted_frame_side(ifx* h)
+{
+    if (!h->hint_rgb || !h->opt_two_streams) { h->hint_rgb = nullptr; return IFX_OK; }
+    const uint8_t* r = h->hint_rgb; const uint16_t* d = h->hint_depth;
+    h->hint_rgb = nullptr; h->hint_depth = nullptr;
+    return enqueue_frame_side(h, (h->tick + 1) & 1, h->tick + 1, r, d, 0);
+}
+
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Loop
 // closure (ferns, deformation graph, model-to-model tracking) is out of scope, and so
 // is the first predict() of :453 whose only consumers are those stages.
@@ -254,6 +264,10 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
     hipEventRecord(f.released, h->stream);
+    {
+        int r = ifx_enqueue_hinted_frame_side(h);   // not consumed by the tracker (first frame, external pose)
+        if (r) return r;
+    }
     h->seg_counts_valid = 1;
     h->n_traj++;
     h->tick++;
@@ -276,6 +290,15 @@ extern "C" int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, co
     if (!h || !d_rgb_next || !d_depth_next) return IFX_E_INVALID;
     if (h->tick == 1 || !h->opt_two_streams) return IFX_OK;   // nothing to overlap with
     return enqueue_frame_side(h, h->tick & 1, h->tick, d_rgb_next, d_depth_next, 0);
+}
+
+// Same look-ahead, announced BEFORE the current frame is enqueued: the library places the next frame's image-only
+// work itself, behind the coarse pyramid levels of the current frame's tracker, where the GPU is least busy.
+extern "C" int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next)
+{
+    if (!h || !d_rgb_next || !d_depth_next) return IFX_E_INVALID;
+    h->hint_rgb = d_rgb_next; h->hint_depth = d_depth_next;
+    return IFX_OK;
 }
 
 extern "C" int ifx_sync(ifx_t* h)

@@ -98,6 +98,8 @@ struct ifx {
     FrameSlot slot[2];
     int cur_slot = 0;
     int opt_two_streams = 1;
+    const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
+    const uint16_t* hint_depth = nullptr;
     std::string err;
     int tick = 1;
     int ids_pending = 0;
@@ -205,6 +207,7 @@ int ifx_tracker_run_frame(ifx* h);                            // model pyramid +
 int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
 int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
 void ifx_bind_slot(ifx* h, int s);
+int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
 int ifx_map_predict(ifx* h);                                  // splat + fill-in + dense flag

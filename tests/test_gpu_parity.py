@@ -405,3 +405,43 @@ def test_segmentation_with_superpixels_exact(ifx, orc, small_stream):
         assert np.array_equal(g.download()["votes"], o.download()["votes"])
     assert (o.labels() >= 0).sum() > 100
     g.close(); o.close()
+
+
+# ---------------------------------------------------------------- frame look-ahead (side stream) must not change results
+def test_lookahead_equivalence(ifx, small_stream):
+    import torch
+
+    st = small_stream
+    n = 8
+    d_rgb = torch.from_numpy(st["rgb"][:n].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:n].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+
+    def run(mode):
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+        if mode == "single":
+            g.set_option("two_streams", 0)
+        for i in range(n):
+            if mode == "hint" and i + 1 < n:
+                g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+            g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            if mode == "prefetch" and i + 1 < n:
+                g.prefetch_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+            if mode == "wrong_hint" and i + 1 < n:   # a look-ahead that does not come true is recomputed
+                g.prefetch_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+        g.sync()
+        traj, m, ids = g.trajectory(), g.download(), g.image("ids_after")
+        g.close()
+        return traj, m, ids
+
+    ref = run("single")
+    for mode in ("plain", "hint", "prefetch", "wrong_hint"):
+        t, m, ids = run(mode)
+        assert np.array_equal(t, ref[0]), mode
+        assert all(np.array_equal(m[k], ref[1][k]) for k in MAP_KEYS), mode
+        assert np.array_equal(ids, ref[2]), mode
+    # and the host-buffer entry point gives the same trajectory
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(n)])
+    g.close()
+    assert np.array_equal(poses, ref[0][:n])

@@ -155,7 +155,7 @@ def main():
             step(k)
         ef.sync()
         names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_raster", "raster_list", "cull_clean", "clean_list", "index_project", "index_resolve", "associate",
-                 "fuse_update", "bilateral_metric", "splat_resolve", "count_colour", "list_reset"]
+                 "fuse_update", "bilateral_metric", "splat_resolve", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
         best, table = None, {}
         for nme in names:
             avg, cnt = ef.kernel_ms(nme)
@@ -163,12 +163,30 @@ def main():
             if cnt and algorithmic_bytes(nme, n_slots, P) > 0 and (best is None or avg * cnt > table[best]["total_ms"]):
                 best = nme
         ef.set_option("kernel_timing", 0)
+        # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+        # MI355X_MICROARCH.md prescribes for gfx950; collected offline on this same command, see profiles/README.md)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            pass
+
+        def entry(nme):
+            b = algorithmic_bytes(nme, n_slots, P)
+            ach = b / (table[nme]["avg_ms"] * 1e-3) / 1e9 if table[nme]["avg_ms"] > 0 else 0.0
+            t = pmc.get("k_" + nme)
+            return dict(bound="hbm", kernel=nme, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=(t["bytes_read"] + t["bytes_written"]) if t else None, avg_launch_ms=round(table[nme]["avg_ms"], 5), bytes_per_launch=b)
+
         if best:
-            b = algorithmic_bytes(best, n_slots, P)
-            ach = b / (table[best]["avg_ms"] * 1e-3) / 1e9 if table[best]["avg_ms"] > 0 else 0.0
-            roof = dict(bound="hbm", kernel=best, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None, avg_launch_ms=round(table[best]["avg_ms"], 5), bytes_per_launch=b,
-                        kernels={k: dict(avg_ms=round(v["avg_ms"], 5), launches=v["launches"]) for k, v in table.items()})
+            roof = entry(best)
+            roof["kernels"] = {k: dict(avg_ms=round(v["avg_ms"], 5), launches=v["launches"]) for k, v in table.items()}
+            # the dominant kernel by time is a latency-bound reduction; the largest streaming map pass is
+            # reported next to it so that the bandwidth-bound part of the path has its roofline number too
+            stream = [n_ for n_ in ("cull_raster", "cull_clean", "index_project") if table.get(n_, {}).get("launches")]
+            if stream:
+                roof["streaming_pass"] = entry(max(stream, key=lambda n_: table[n_]["total_ms"]))
 
     # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload
     cpu = None

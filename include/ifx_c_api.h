@@ -180,6 +180,10 @@ int ifx_instance_table(ifx_t* h, int32_t* out96);
 /* getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121: int[96*5] = r,g,b,class,index */
 int ifx_loop_closure_instance_table(ifx_t* h, int32_t* out480);
 int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n);  /* IF/Core/InstanceFusionCuda.cu:118-141 (host in/out) */
+/* maskGeometricFilter + filterAreaCompute (IF/Core/InstanceFusion.cpp:470-593) as a stage, host buffers: depth = model
+ * depth under the camera (u16 H x W, 1186 units per metre, what getProjectDepthMap :977-996 produces); masks n x H x W
+ * in/out; ori = the masks before clean-overlap; unavailable n bytes in/out (set entries are skipped). */
+int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int n, uint8_t* unavailable);
 
 /* ---- superpixel refinement stages (the three calls of processInstance steps -1_1..-1_3,
  * IF/Core/InstanceFusion.cpp:722-738; ifx_process_segmentation runs them when flags bit1 is set).

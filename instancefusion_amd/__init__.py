@@ -101,6 +101,7 @@ _SIGS = {
     "ifx_instance_table": (C.c_int, [_P, _P]),
     "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
     "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_mask_geometric_filter": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "ifx_slic_segment": (C.c_int, [_P, _P, _P]),
     "ifx_merge_superpixels": (C.c_int, [_P, _P, _P, _P, _P]),
     "ifx_mask_superpixel_filter": (C.c_int, [_P, _P, _P, C.c_int]),
@@ -393,6 +394,14 @@ class InstanceFusion:
         masks = np.ascontiguousarray(masks, np.uint8).copy()
         self.ef._chk(self.L.ifx_mask_superpixel_filter(self.ef.handle, _ptr(fin), _ptr(masks), int(masks.shape[0])), "ifx_mask_superpixel_filter")
         return masks
+
+    def maskGeometricFilter(self, model_depth, masks, ori, unavailable=None):
+        depth = np.ascontiguousarray(model_depth, np.uint16)
+        masks = np.ascontiguousarray(masks, np.uint8).copy()
+        ori = np.ascontiguousarray(ori, np.uint8)
+        un = np.zeros(masks.shape[0], np.uint8) if unavailable is None else np.ascontiguousarray(unavailable, np.uint8).copy()
+        self.ef._chk(self.L.ifx_mask_geometric_filter(self.ef.handle, _ptr(depth), _ptr(masks), _ptr(ori), int(masks.shape[0]), _ptr(un)), "ifx_mask_geometric_filter")
+        return masks, un
 
     def maskCleanOverlap(self, masks):
         masks = np.ascontiguousarray(masks, np.uint8).copy()

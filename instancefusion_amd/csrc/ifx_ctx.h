@@ -154,7 +154,8 @@ struct ifx {
     int32_t inst_class[IFX_NUM_INSTANCES];
     float inst_color[IFX_NUM_INSTANCES];
     float* d_inst_color = nullptr;
-    uint8_t* d_masks = nullptr; size_t masks_cap = 0;
+    uint8_t *d_masks = nullptr, *d_masks_ori = nullptr, *d_unavail = nullptr; size_t masks_cap = 0;   // [nm][P] working masks, masks before clean-overlap, [nm] flags
+    int* d_ff_label = nullptr; size_t ff_cap = 0;   // flood-fill labels + region counters + per-mask bookkeeping
     uint16_t* d_pdm = nullptr;
     int* d_bbox = nullptr;             // [96*4 + maxmasks*4]
     int* d_inst_stats = nullptr;       // [96*2]

@@ -15,7 +15,7 @@
 #define DEAD_TIME (-1.0e9f)
 #define NI IFX_NUM_INSTANCES
 
-int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, std::vector<uint8_t>& masks, int nm, int frame);
+int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame);
 
 // maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131
 __global__ void k_mask_clean_overlap(uint8_t* __restrict__ masks, int nm, int P)
@@ -62,6 +62,15 @@ __global__ void k_init_bbox(int* __restrict__ bbox, int n, int w, int h)
     int t = i & 3;
     bbox[i] = t == 0 ? w + 1 : t == 1 ? -1 : t == 2 ? h + 1 : -1;
 }
+// extend a box {minX, maxX, minY, maxY}: almost every pixel lies inside the box already, so look (L2, no contention)
+// before the atomic; a stale look can only cause a redundant atomic, never skip a needed one
+__device__ __forceinline__ void bbox_extend(int* b, int x, int y)
+{
+    if (x < __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[0], x);
+    if (x > __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[1], x);
+    if (y < __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[2], y);
+    if (y > __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[3], y);
+}
 __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
                                int nm, int w, int h, int* __restrict__ bbox)
 {
@@ -84,15 +93,9 @@ __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* _
         }
     }
     if (first == -1) return;   // instanceProjectMap[y*width+x] != -1 test (:915)
-    if (maxID != -1) {
-        int* b = &bbox[maxID * 4];
-        atomicMin(&b[0], x); atomicMax(&b[1], x); atomicMin(&b[2], y); atomicMax(&b[3], y);
-    }
+    if (maxID != -1) bbox_extend(&bbox[maxID * 4], x, y);
     for (int m = 0; m < nm; m++)
-        if (masks[(size_t)m * P + k] > 0) {
-            int* b = &bbox[(NI + m) * 4];
-            atomicMin(&b[0], x); atomicMax(&b[1], x); atomicMin(&b[2], y); atomicMax(&b[3], y);
-        }
+        if (masks[(size_t)m * P + k] > 0) bbox_extend(&bbox[(NI + m) * 4], x, y);
 }
 
 // getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996
@@ -240,15 +243,18 @@ int ifx_alloc_instance(ifx* h)
 }
 void ifx_free_instance(ifx* h)
 {
-    hipFree(h->d_inst_color); hipFree(h->d_masks); hipFree(h->d_pdm); hipFree(h->d_bbox); hipFree(h->d_inst_stats); hipFree(h->d_clean_list);
+    hipFree(h->d_inst_color); hipFree(h->d_masks); hipFree(h->d_masks_ori); hipFree(h->d_unavail); hipFree(h->d_ff_label); hipFree(h->d_pdm); hipFree(h->d_bbox); hipFree(h->d_inst_stats); hipFree(h->d_clean_list);
 }
 
 int ifx_ensure_masks(ifx* h, size_t bytes)
 {
     if (bytes <= h->masks_cap) return IFX_OK;
     if (h->d_masks) hipFree(h->d_masks);
-    h->d_masks = nullptr; h->masks_cap = 0;
+    if (h->d_masks_ori) hipFree(h->d_masks_ori);
+    h->d_masks = nullptr; h->d_masks_ori = nullptr; h->masks_cap = 0;
     HIPCHK(h, hipMalloc(&h->d_masks, bytes));
+    HIPCHK(h, hipMalloc(&h->d_masks_ori, bytes));
+    if (!h->d_unavail) HIPCHK(h, hipMalloc(&h->d_unavail, 512));
     h->masks_cap = bytes;
     return IFX_OK;
 }
@@ -268,6 +274,27 @@ extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
 }
 
 // whetherDoSegmentation, IF/Core/InstanceFusion.cpp:192-238
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail);
+// maskGeometricFilter as a stage (host buffers): depth = model depth under the camera (u16, 1186 units per metre as
+// getProjectDepthMap produces it), masks in/out, ori = masks before clean-overlap, unavailable in/out
+extern "C" int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int n, uint8_t* unavailable)
+{
+    if (!h || !depth || n < 0 || n > 256 || (n > 0 && (!masks || !ori || !unavailable))) return IFX_E_INVALID;
+    if (n == 0) return IFX_OK;
+    const size_t P = h->P, bytes = (size_t)n * P;
+    int r = ifx_ensure_masks(h, bytes);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(h->d_pdm, depth, P * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, ori, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable, n, hipMemcpyHostToDevice, h->stream));
+    if ((r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, n, h->d_unavail))) return r;
+    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(unavailable, h->d_unavail, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
 extern "C" int ifx_should_segment(ifx_t* h, int frame)
 {
     if (!h) return IFX_E_INVALID;
@@ -298,61 +325,195 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
 }
 
 // getDepthThreshold, IF/Core/InstanceFusion.h:170-176
-static float depth_threshold(int depth)
+__device__ __forceinline__ float depth_threshold_dev(int depth)
 {
     float t = 0.074f * depth - 246.0f;
-    t = std::max(50.0f, t);
-    t = std::min(420.0f, t);
+    t = fmaxf(50.0f, t);
+    t = fminf(420.0f, t);
     return t;
 }
 
-// filterAreaCompute + maskGeometricFilter, IF/Core/InstanceFusion.cpp:470-593 (host, as in the reference)
-static void mask_geometric_filter(int w, int h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int nm, std::vector<uint8_t>& unavailable)
+// filterAreaCompute + maskGeometricFilter, IF/Core/InstanceFusion.cpp:470-593, on the device.
+// The reference floods each mask on the CPU: pixels (interior, mask set, model depth valid) are visited in row-major
+// order, an unvisited one seeds a breadth-first fill along edges  now -> neighbour  that exist when
+// |depth[now] - depth[neighbour]| < threshold(depth[now])  (the threshold of the SOURCE pixel, so an edge can be
+// one-way beyond 4 m), and the seed's sequence number is the region id.  A filled region is closed under forward
+// reachability, hence a pixel ends up in the region of the EARLIEST pixel (row-major) that reaches it:
+//     label(p) = min { q : q ~> p }.
+// That fixpoint is reached by monotone min-propagation along the directed edges in any order: 32x32 tiles relax
+// in LDS until nothing changes, one pointer jump (label <- label[label], valid by transitivity) per launch carries
+// labels across tiles, and launches repeat until a launch changes nothing.
+#define FF_T 32
+struct FFArgs {
+    const uint16_t* depth; uint8_t* masks; const uint8_t* ori; const uint8_t* skip;   // skip[m] != 0: mask left alone
+    int* label; int* cnt; int* meta;   // meta[m*32 + 0] oriPoints, [1] kept count, [2] finalPoints, [4..24) kept region ids
+    int* changed;                      // [0] set when a launch lowered a label
+    int nm, w, h;
+};
+
+__global__ void k_ff_init(FFArgs a)
 {
-    int P = w * h;
-    std::vector<int> filterMap(P), queue((size_t)P * 4 + 16);
-    static const int StepX[4] = {0, 0, 1, -1}, StepY[4] = {1, -1, 0, 0};
-    for (int i = 0; i < nm; i++) {
-        if (unavailable[i]) continue;
-        uint8_t* mask = masks + (size_t)i * P;
-        const uint8_t* om = ori + (size_t)i * P;
-        std::fill(filterMap.begin(), filterMap.end(), 0);
-        float oriPoints = 0;
-        for (int y = 1; y < h - 1; y++)
-            for (int x = 1; x < w - 1; x++) {
-                if (om[y * w + x]) oriPoints++;
-                if (mask[y * w + x] && depth[y * w + x]) filterMap[y * w + x] = 1;
-            }
-        int areaFlag = 2, list[20], p = 0;
-        for (int y = 1; y < h - 1; y++)
-            for (int x = 1; x < w - 1; x++) {
-                if (filterMap[y * w + x] != 1) continue;
-                float points = 0;
-                int front = 0, tail = 0;
-                queue[front++] = y * w + x;
-                while (front > tail) {
-                    int now = queue[tail++];
-                    int nx = now % w, ny = now / w;
-                    if (filterMap[ny * w + nx] != 1) continue;
-                    points++;
-                    filterMap[ny * w + nx] = areaFlag;
-                    for (int k = 0; k < 4; k++) {
-                        int dx = nx + StepX[k], dy = ny + StepY[k];
-                        float thr = depth_threshold(depth[ny * w + nx]);
-                        if (filterMap[dy * w + dx] == 1 && (float)std::abs((int)depth[ny * w + nx] - (int)depth[dy * w + dx]) < thr) queue[front++] = dy * w + dx;
-                    }
-                }
-                if (points / oriPoints > 0.25f) { if (p < 20) list[p++] = areaFlag; }
-                areaFlag++;
-            }
-        float finalPoints = 0;
-        for (int k = 0; k < P; k++) {
-            int flag = 0;
-            for (int j = 0; j < p; j++) if (filterMap[k] == list[j]) { flag = 1; break; }
-            if (flag) { mask[k] = 255; finalPoints++; } else mask[k] = 0;
-        }
-        if (finalPoints / oriPoints < 0.65f) unavailable[i] = 1;
+    const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    bool in = k < P && !a.skip[m];
+    int x = in ? k % a.w : 0, y = in ? k / a.w : 0;
+    bool interior = in && x >= 1 && x < a.w - 1 && y >= 1 && y < a.h - 1;
+    bool o = interior && a.ori[(size_t)m * P + k];
+    if (k < P) {
+        bool v = interior && a.masks[(size_t)m * P + k] && a.depth[k];
+        a.label[(size_t)m * P + k] = v ? k : -1;
+        a.cnt[(size_t)m * P + k] = 0;
     }
+    unsigned long long b = __ballot(o);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&a.meta[m * 32], __popcll(b));
+}
+
+__global__ void __launch_bounds__(256) k_ff_relax(FFArgs a)
+{
+    __shared__ int s_lab[FF_T + 2][FF_T + 2];
+    __shared__ unsigned short s_d[FF_T + 2][FF_T + 2];
+    const int P = a.w * a.h, m = blockIdx.z;
+    if (a.skip[m]) return;
+    int* lab = a.label + (size_t)m * P;
+    const int x0 = blockIdx.x * FF_T - 1, y0 = blockIdx.y * FF_T - 1, tid = threadIdx.x;
+    for (int t = tid; t < (FF_T + 2) * (FF_T + 2); t += 256) {
+        int ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2), x = x0 + lx, y = y0 + ly;
+        bool in = x >= 0 && x < a.w && y >= 0 && y < a.h;
+        s_lab[ly][lx] = in ? lab[y * a.w + x] : -1;
+        s_d[ly][lx] = in ? a.depth[y * a.w + x] : 0;
+    }
+    __syncthreads();
+    // one pointer jump for the pixels of this tile: the label is a pixel that reaches me, so does ITS label
+    int mine[4], orig[4];
+    const int lx1 = (tid & 31) + 1;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int ly1 = (tid >> 5) * 4 + u + 1;
+        int l = s_lab[ly1][lx1];
+        orig[u] = l;
+        if (l >= 0) { int g = lab[l]; if (g >= 0 && g < l) l = g; }
+        mine[u] = l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) s_lab[(tid >> 5) * 4 + u + 1][lx1] = mine[u];
+    __syncthreads();
+    for (int it = 0; it < 4 * FF_T; it++) {
+        int any = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int ly1 = (tid >> 5) * 4 + u + 1;
+            int l = s_lab[ly1][lx1];
+            if (l < 0) continue;
+            const int dp = s_d[ly1][lx1];
+            int best = l;
+            const int nx[4] = {lx1, lx1, lx1 + 1, lx1 - 1}, ny[4] = {ly1 + 1, ly1 - 1, ly1, ly1};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ql = s_lab[ny[e]][nx[e]];
+                if (ql < 0 || ql >= best) continue;
+                const int dq = s_d[ny[e]][nx[e]];
+                if ((float)abs(dq - dp) < depth_threshold_dev(dq)) best = ql;   // edge q -> p, threshold of the source q
+            }
+            if (best < l) { mine[u] = best; any = 1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) s_lab[(tid >> 5) * 4 + u + 1][lx1] = mine[u];
+        if (!__syncthreads_or(any)) break;
+    }
+    int dirty = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int x = x0 + lx1, y = y0 + (tid >> 5) * 4 + u + 1;
+        if (x < a.w && y < a.h && mine[u] != orig[u]) { lab[y * a.w + x] = mine[u]; dirty = 1; }
+    }
+    if (__syncthreads_or(dirty) && tid == 0) *a.changed = 1;
+}
+
+// region sizes: one counter per root pixel; lanes of a wave grouped by label (regions are large)
+__global__ void k_ff_count(FFArgs a)
+{
+    const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    int l = (k < P && !a.skip[m]) ? a.label[(size_t)m * P + k] : -1;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(l >= 0);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int ll = __shfl(l, leader);
+        unsigned long long grp = __ballot(l == ll);
+        todo &= ~grp;
+        if (lane == leader) atomicAdd(&a.cnt[(size_t)m * P + ll], __popcll(grp));
+    }
+}
+// regions holding more than a quarter of the original mask are kept (IF/Core/InstanceFusion.cpp:560)
+__global__ void k_ff_select(FFArgs a)
+{
+    const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (k >= P || a.skip[m] || a.label[(size_t)m * P + k] != k) return;
+    float points = (float)a.cnt[(size_t)m * P + k], oriPoints = (float)a.meta[m * 32];
+    if (points / oriPoints > 0.25f) {
+        int slot = atomicAdd(&a.meta[m * 32 + 1], 1);
+        if (slot < 20) a.meta[m * 32 + 4 + slot] = k;
+    }
+}
+__global__ void k_ff_apply(FFArgs a)
+{
+    const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    bool keep = false;
+    if (k < P && !a.skip[m]) {
+        const int l = a.label[(size_t)m * P + k], n = min(a.meta[m * 32 + 1], 20);
+        for (int j = 0; j < n; j++) keep = keep || (l >= 0 && l == a.meta[m * 32 + 4 + j]);
+        a.masks[(size_t)m * P + k] = keep ? 255 : 0;
+    }
+    unsigned long long b = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&a.meta[m * 32 + 2], __popcll(b));
+}
+// a mask that lost more than 35 % of its pixels is unusable (:590)
+__global__ void k_ff_verdict(FFArgs a, uint8_t* unavailable)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.nm || a.skip[m]) return;
+    float finalPoints = (float)a.meta[m * 32 + 2], oriPoints = (float)a.meta[m * 32];
+    if (finalPoints / oriPoints < 0.65f) unavailable[m] = 1;
+}
+
+// d_unavail: [nm] bytes in/out (set entries are skipped, as `continue` at :520); masks / ori: device, [nm][P]
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail)
+{
+    const int P = h->P;
+    size_t need = (size_t)nm * P;
+    if (need > h->ff_cap) {
+        if (h->d_ff_label) hipFree(h->d_ff_label);
+        h->d_ff_label = nullptr; h->ff_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ff_label, need * 2 * 4 + (size_t)256 * 32 * 4 + 64 + 256));
+        h->ff_cap = need;
+    }
+    FFArgs a;
+    a.depth = d_depth; a.masks = d_masks; a.ori = d_ori; a.nm = nm; a.w = h->w; a.h = h->h;
+    a.label = h->d_ff_label; a.cnt = h->d_ff_label + h->ff_cap; a.meta = a.cnt + h->ff_cap; a.changed = a.meta + 256 * 32;
+    uint8_t* d_skip = (uint8_t*)(a.changed + 16);
+    a.skip = d_skip;
+    HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->stream));   // the verdict must not change who is skipped mid-way
+    HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->stream));
+    dim3 per_px(cdiv(P, 256), nm);
+    LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
+    dim3 tiles(cdiv(h->w, FF_T), cdiv(h->h, FF_T), nm);
+    for (int round = 0; round < 64; round++) {
+        HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
+        for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a);
+        // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
+        HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
+        LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a);
+        int changed = 0;
+        HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!changed) break;
+    }
+    LAUNCH(h, "ff_count", per_px, dim3(256), k_ff_count, a);
+    LAUNCH(h, "ff_select", per_px, dim3(256), k_ff_select, a);
+    LAUNCH(h, "ff_apply", per_px, dim3(256), k_ff_apply, a);
+    LAUNCH(h, "ff_verdict", dim3(cdiv(nm, 64)), dim3(64), k_ff_verdict, a, d_unavail);
+    return IFX_OK;
 }
 
 // computeCompareMap, IF/Core/InstanceFusion.cpp:595-651
@@ -402,26 +563,24 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
     hipEvent_t ea = ifx_event_get(h);
     hipEventRecord(ea, h->stream);
-    DevState hs;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
-    int n = hs.count;
+    int n = 0;
+    HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
     if (nm == 0 || n == 0) { h->event_pool.push_back(ea); return IFX_OK; }
     const int P = h->P;
     size_t mbytes = (size_t)nm * P;
-    std::vector<uint8_t> masks(masks_in, masks_in + mbytes), ori(masks_in, masks_in + mbytes), unavailable(nm, 0);
+    std::vector<uint8_t> unavailable(nm, 0);
     int r = ifx_ensure_masks(h, mbytes);
     if (r) return r;
+    // the masks stay on the device from here on: d_masks_ori = "BAK ORI MASK" (:705-706), d_masks = working copy
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
     // step 0_1
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
-    HIPCHK(h, hipMemcpyAsync(masks.data(), h->d_masks, mbytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     // steps -1_1 .. -1_3 (superpixel refinement)
     if (flags & 2) {
-        r = ifx_superpixel_refine(h, rgb, depth, masks, nm, frame);
+        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
         if (r) return r;
-        HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
     }
     // steps 1, 2
     std::vector<int> bbox;
@@ -429,13 +588,13 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     if (r) return r;
     std::vector<int> cmp((size_t)nm * NI, 0);
     compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
-    // step 3_0
-    std::vector<uint16_t> pdm(P);
+    // step 3_0: model depth under the camera, then the flood fill of every usable mask (device)
     LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm);
-    HIPCHK(h, hipMemcpyAsync(pdm.data(), h->d_pdm, (size_t)P * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->stream));
+    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(unavailable.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    mask_geometric_filter(h->w, h->h, pdm.data(), masks.data(), ori.data(), nm, unavailable);
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks.data(), mbytes, hipMemcpyHostToDevice, h->stream));
     // step 3
     for (int m = 0; m < nm; m++) {
         bool exist = false;

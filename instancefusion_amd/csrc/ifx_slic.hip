@@ -655,9 +655,9 @@ void ifx_slic_free(ifx* h)
     h->slic = nullptr;
 }
 
-// steps -1_1 .. -1_3 of processInstance (IF/Core/InstanceFusion.cpp:722-738): masks (host, [nm][P]) are refined in place;
-// they are expected in h->d_masks already (the caller uploaded them for the clean-overlap step).
-int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, std::vector<uint8_t>& masks, int nm, int frame)
+// steps -1_1 .. -1_3 of processInstance (IF/Core/InstanceFusion.cpp:722-738): the masks in h->d_masks ([nm][P], already
+// through clean-overlap) are refined in place on the device
+int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame)
 {
     (void)frame;
     if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame"; return IFX_E_INVALID; }
@@ -669,10 +669,7 @@ int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, std
     HIPCHK(h, hipMemcpyAsync(b->depth, depth, P * 2, hipMemcpyHostToDevice, h->stream));
     if ((r = slic_run(h, b))) return r;
     if ((r = merge_run(h, b))) return r;
-    if ((r = filter_run(h, b, h->d_masks, nm, true))) return r;
-    HIPCHK(h, hipMemcpyAsync(masks.data(), h->d_masks, (size_t)nm * P, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return IFX_OK;
+    return filter_run(h, b, h->d_masks, nm, true);
 }
 
 // ---------------------------------------------------------------- C-ABI stage entry points

@@ -334,3 +334,9 @@ int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth
     free(masks); free(ori); free(unavailable); free(maskBBox); free(cmp); free(pdm);
     return 0;
 }
+
+/* test hook: the flood fill alone (depth = model depth map as getProjectDepthMap produces it) */
+void orc_test_mask_geometric_filter(orc_t* o, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int nm, uint8_t* unavailable)
+{
+    mask_geometric_filter(o, depth, masks, ori, nm, unavailable);
+}

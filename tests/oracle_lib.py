@@ -198,6 +198,15 @@ class Oracle:
         cls = np.ascontiguousarray(class_ids, np.int32)
         return self.L.orc_process_segmentation(self.h, ptr(rgb), ptr(depth), ptr(masks), ptr(cls), masks.shape[0], frame, flags)
 
+    def mask_geometric_filter(self, model_depth, masks, ori, unavailable=None):
+        depth = np.ascontiguousarray(model_depth, np.uint16)
+        masks = np.ascontiguousarray(masks, np.uint8).copy()
+        ori = np.ascontiguousarray(ori, np.uint8)
+        un = np.zeros(masks.shape[0], np.uint8) if unavailable is None else np.ascontiguousarray(unavailable, np.uint8).copy()
+        self.L.orc_test_mask_geometric_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.L.orc_test_mask_geometric_filter(self.h, ptr(depth), ptr(masks), ptr(ori), masks.shape[0], ptr(un))
+        return masks, un
+
     # ---- superpixel refinement stages (orc_slic.c)
     def slic_segment(self, rgb):
         rgb = np.ascontiguousarray(rgb, np.uint8)

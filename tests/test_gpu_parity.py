@@ -445,3 +445,49 @@ def test_lookahead_equivalence(ifx, small_stream):
     poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(n)])
     g.close()
     assert np.array_equal(poses, ref[0][:n])
+
+
+# ---------------------------------------------------------------- a19: flood fill of the masks on the device
+def test_flood_fill_exact(ifx, orc):
+    """The device label propagation (label = earliest pixel that reaches me) against the oracle's sequential
+    breadth-first fill: shapes that need many tile-to-tile hand-offs (spiral), one-way edges (depth beyond 4 m where
+    the threshold depends on the source pixel), several regions per mask, holes in the model depth, skipped masks."""
+    w, h = 320, 240
+    K = dict(fx=264.0, fy=264.0, cx=160.0, cy=120.0)
+    g = ifx.ElasticFusion(w=w, h=h, max_surfels=1000, **K)
+    o = orc.Oracle(w=w, h=h, max_surfels=1000, **K)
+    inst = ifx.InstanceFusion(g)
+    rng = np.random.RandomState(4)
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (2000 + 3 * xx + 2 * yy + rng.randint(-20, 21, (h, w))).astype(np.uint16)
+    depth[rng.rand(h, w) < 0.02] = 0                       # holes
+    far = (4500 + 25 * xx + rng.randint(-150, 151, (h, w))).astype(np.uint16)   # 4.5 .. 12.5 m: thresholds 87 .. 420, one-way edges
+    masks = np.zeros((7, h, w), np.uint8)
+    # 0: spiral corridor, 3 px wide
+    sp = np.zeros((h, w), bool)
+    l, t, r, b = 10, 10, w - 10, h - 10
+    while r - l > 16 and b - t > 16:
+        sp[t:t + 3, l:r] = True; sp[t:b, r - 3:r] = True; sp[b - 3:b, l + 8:r] = True; sp[t + 8:b, l + 8:l + 11] = True
+        l += 8; t += 8; r -= 8; b -= 8
+    masks[0][sp] = 255
+    masks[1, 40:200, 50:280] = 255                          # big block with holes
+    masks[2, 20:100, 20:120] = 255; masks[2, 130:220, 180:300] = 255   # two separate regions: 47 % / 53 %
+    masks[3, 60:180, 100:110] = 255                         # thin
+    masks[4] = (rng.rand(h, w) < 0.5) * 255                 # salt and pepper: hundreds of tiny regions -> nothing above 25 %
+    masks[5, 30:210, 30:290] = 255                          # far-depth mask (uses `far` below)
+    masks[6, 5:50, 5:50] = 255                              # skipped
+    ori = masks.copy()
+    ori[1, 30:210, 40:290] = 255                            # original mask larger than the refined one
+    un = np.zeros(7, np.uint8); un[6] = 1
+    for name, dmap in (("near", depth), ("far", far)):
+        mg, ug = inst.maskGeometricFilter(dmap, masks, ori, un)
+        mo, uo = o.mask_geometric_filter(dmap, masks, ori, un)
+        assert np.array_equal(ug, uo), name
+        for i in range(7):
+            assert np.array_equal(mg[i], mo[i]), (name, i)
+        assert np.array_equal(mg[6], masks[6])
+        if name == "near":   # the spiral is one region that survives; salt-and-pepper has no region above 25 %
+            assert mo[0].any() and uo[0] == 0 and uo[4] == 1 and uo[2] == 0
+        else:
+            assert mo[5].any()
+    g.close(); o.close()

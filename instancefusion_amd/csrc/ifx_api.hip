@@ -87,6 +87,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     size_t P = (size_t)h->P, C = (size_t)h->cap;
     if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream_b) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
     h->cur = h->stream;
+    if (hipEventCreateWithFlags(&h->ev_result, hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; delete h; return IFX_E_HIP; }
     ALLOC(h->d_state, sizeof(DevState));
     hipMemset(h->d_state, 0, sizeof(DevState));
     if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
@@ -155,6 +156,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_free_instance(h);
     ifx_slic_free(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
+    if (h->ev_result) hipEventDestroy(h->ev_result);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -168,6 +170,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "kernel_timing") { hipStreamSynchronize(h->stream); ktime_flush(h); h->opt_kernel_timing = value; }
     else if (s == "reference_passes") h->opt_reference_passes = value;
     else if (s == "two_streams") h->opt_two_streams = value;
+    else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
     else { h->err = "unknown option " + s; return IFX_E_INVALID; }
     return IFX_OK;
@@ -229,7 +232,11 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
 {
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
-    if (!(f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0)) {
+    const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0;
+    // a tracker run enqueued behind the previous frame counts only for exactly this frame, tracked, with the default weight
+    const bool tracked = prepared && h->tracked_ahead == h->tick && !in_pose16;
+    h->tracked_ahead = 0;
+    if (!prepared) {
         int r = enqueue_frame_side(h, s, h->tick, rgb, depth, src_kind);
         if (r) return r;
     }
@@ -242,7 +249,12 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     } else {
         {
             StageTimer t(h, 0);
-            if (!in_pose16) {
+            if (tracked) {
+                ifx_tracker_commit(h);
+                if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
+                int r = ifx_enqueue_hinted_frame_side(h);   // no tracker enqueue to hide it in: it runs under this frame's map passes
+                if (r) return r;
+            } else if (!in_pose16) {
                 ifx_tracker_model_side(h);                       // model pyramid: independent of the frame side
                 HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
                 ifx_tracker_run_frame(h);
@@ -263,6 +275,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     }
     int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+    hipEventRecord(h->ev_result, h->stream);
     hipEventRecord(f.released, h->stream);
     {
         int r = ifx_enqueue_hinted_frame_side(h);   // not consumed by the tracker (first frame, external pose)
@@ -271,6 +284,21 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     h->seg_counts_valid = 1;
     h->n_traj++;
     h->tick++;
+    // Tracking of the announced next frame reads only its frame slot, the prediction just rendered and the pose: nothing
+    // a segmentation call in between touches.  Enqueue it now, parked (DevState::spec_*), so that the GPU has ~0.6 ms of
+    // work while the host waits for this frame's result to decide about segmentation.
+    FrameSlot& nf = h->slot[h->tick & 1];
+    if (h->opt_track_ahead && h->opt_two_streams && nf.for_tick == h->tick && h->tick > 1) {
+        ifx_bind_slot(h, h->tick & 1);
+        HIPCHK(h, hipStreamWaitEvent(h->stream, nf.ready, 0));
+        {
+            StageTimer t(h, 0);
+            ifx_tracker_model_side(h);
+            ifx_tracker_run_frame(h, 0);
+        }
+        ifx_bind_slot(h, s);
+        h->tracked_ahead = h->tick;
+    }
     return IFX_OK;
 }
 
@@ -336,6 +364,7 @@ extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* d
 extern "C" int ifx_set_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth)
 {
     if (!h || !rgb || !depth) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     HIPCHK(h, hipMemcpyAsync(h->rgb, rgb, (size_t)h->P * 3, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->depth_raw, depth, (size_t)h->P * 2, hipMemcpyHostToDevice, h->stream));
     ifx_preprocess(h);
@@ -436,6 +465,7 @@ extern "C" int ifx_map_count(ifx_t* h)
 extern "C" int ifx_compact(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     ifx_compact_enqueue(h, 1);
     return ifx_sync(h);
@@ -444,6 +474,7 @@ extern "C" int ifx_compact(ifx_t* h)
 extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
 {
     if (!h) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     int r = ifx_compact(h);   // live surfels in map order
     if (r) return r;
@@ -470,6 +501,7 @@ extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float
 extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const float* col, const float* tm, const float* ic, const float* votes)
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -504,6 +536,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
 extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     DevState hs;
     int r = read_state(h, &hs);
     if (r) return r;

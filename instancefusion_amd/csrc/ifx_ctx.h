@@ -44,6 +44,7 @@ struct DevState {
     int seg_counts[2];
     int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
     unsigned int append_ticket;  // last-block ticket of k_append_scan
+    float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
@@ -98,6 +99,9 @@ struct ifx {
     FrameSlot slot[2];
     int cur_slot = 0;
     int opt_two_streams = 1;
+    int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
+    int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
+    hipEvent_t ev_result = nullptr;     // recorded after k_frame_result
     const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
     const uint16_t* hint_depth = nullptr;
     std::string err;
@@ -204,7 +208,8 @@ void ifx_slic_free(ifx* h);
 int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric
 int ifx_tracker_init_first(ifx* h);
-int ifx_tracker_run_frame(ifx* h);                            // model pyramid + GN loops (all on device); the frame side is in the slot
+int ifx_tracker_run_frame(ifx* h, int commit = 1);                            // model pyramid + GN loops (all on device); the frame side is in the slot
+int ifx_tracker_commit(ifx* h);                                // publish the pose of a tracker run that was enqueued ahead
 int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
 int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
 void ifx_bind_slot(ifx* h, int s);

@@ -302,8 +302,9 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
     int count[2];
     if (h->seg_counts_valid) {
         // the frame that just ran accumulated the two sums while it rendered ids_after (k_raster_finish) and left them in the
-        // pinned frame result: nothing to launch, only the frame to wait for
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        // pinned frame result: nothing to launch, only the frame to wait for (not the stream: the next frame's tracker may
+        // already be queued behind it)
+        HIPCHK(h, hipEventSynchronize(h->ev_result));
         count[0] = h->h_result->seg_counts[0]; count[1] = h->h_result->seg_counts[1];
     } else {
         int* cnt = h->d_inst_stats;

@@ -1190,6 +1190,7 @@ static int upload_pose(ifx* h, const float* pose16, float** d_pose, float** d_in
 extern "C" int ifx_predict_indices(ifx_t* h, const float* pose16, int time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;
@@ -1200,6 +1201,7 @@ extern "C" int ifx_predict_indices(ifx_t* h, const float* pose16, int time)
 extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int max_time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;
@@ -1210,6 +1212,7 @@ extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int
 extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
@@ -1221,6 +1224,7 @@ extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting
 extern "C" int ifx_clean(ifx_t* h, const float* pose16, int time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);

@@ -1396,9 +1396,12 @@ __device__ void rodrigues2(const float* R, float* out3)
 }
 
 // end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449)
-__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult)
+__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit)
 {
     if (threadIdx.x != 0) return;
+    float* pose = commit ? st->pose : st->spec_pose;
+    float* pose_inv = commit ? st->pose_inv : st->spec_pose_inv;
+    if (!commit && !tracked) for (int k = 0; k < 16; k++) pose[k] = st->pose[k];
     if (tracked) {
         if (rgb) {
             v3 d = v3m(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
@@ -1408,17 +1411,17 @@ __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mul
             }
         }
         for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) st->pose[r * 4 + c] = st->Rcurr[r * 3 + c];
-            st->pose[r * 4 + 3] = st->tcurr[r];
+            for (int c = 0; c < 3; c++) pose[r * 4 + c] = st->Rcurr[r * 3 + c];
+            pose[r * 4 + 3] = st->tcurr[r];
         }
-        st->pose[12] = st->pose[13] = st->pose[14] = 0.f; st->pose[15] = 1.f;
+        pose[12] = pose[13] = pose[14] = 0.f; pose[15] = 1.f;
     }
-    pose_inverse(st->pose, st->pose_inv);
+    pose_inverse(pose, pose_inv);
     float diff[16];
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) {
             float s = 0;
-            for (int k = 0; k < 4; k++) s += st->pose_inv[r * 4 + k] * st->last_pose[k * 4 + c];
+            for (int k = 0; k < 4; k++) s += pose_inv[r * 4 + k] * st->last_pose[k * 4 + c];
             diff[r * 4 + c] = s;
         }
     float R3[9] = {diff[0], diff[1], diff[2], diff[4], diff[5], diff[6], diff[8], diff[9], diff[10]};
@@ -1429,8 +1432,17 @@ __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mul
     float weighting = fmaxf(tn, rn);
     const float largest = 0.01f, minWeight = 0.5f;
     if (weighting > largest) weighting = largest;
-    st->weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
+    const float wgt = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
+    if (commit) st->weighting = wgt; else st->spec_weighting = wgt;
 }
+// publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
+__global__ void k_commit_pose(DevState* st)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) { st->pose[k] = st->spec_pose[k]; st->pose_inv[k] = st->spec_pose_inv[k]; }
+    st->weighting = st->spec_weighting;
+}
+
 
 // ======================================================================= host drivers
 
@@ -1560,7 +1572,7 @@ static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t
 }
 
 // getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603, enqueued without any readback
-static void tracker_run(ifx* h, float weight_mult)
+static void tracker_run(ifx* h, float weight_mult, int commit = 1)
 {
     Pyr& p = h->pyr;
     const ifx_config& c = h->cfg;
@@ -1605,7 +1617,7 @@ static void tracker_run(ifx* h, float weight_mult)
             LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, h->d_state, sa2);
         }
     }
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, rgb, 1, weight_mult);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, rgb, 1, weight_mult, commit);
 }
 
 // frame side of the tracker for the bound slot: frame pyramids, then (unless this is the first frame, which only
@@ -1641,9 +1653,15 @@ int ifx_tracker_model_side(ifx* h)
     return IFX_OK;
 }
 
-int ifx_tracker_run_frame(ifx* h)
+int ifx_tracker_run_frame(ifx* h, int commit)
 {
-    tracker_run(h, 1.0f);
+    tracker_run(h, 1.0f, commit);
+    return IFX_OK;
+}
+
+int ifx_tracker_commit(ifx* h)
+{
+    LAUNCH(h, "commit_pose", dim3(1), dim3(64), k_commit_pose, h->d_state);
     return IFX_OK;
 }
 
@@ -1657,13 +1675,13 @@ __global__ void k_set_pose(DevState* st, const float* pose16)
 int ifx_tracker_external_pose(ifx* h, const float* d_pose16, float weight_mult)
 {
     LAUNCH(h, "set_pose", dim3(1), dim3(64), k_set_pose, h->d_state, d_pose16);
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1);
     return IFX_OK;
 }
 int ifx_tracker_set_weight(ifx* h, float weight_mult)
 {
     // re-evaluates the velocity weighting with the caller's multiplier (weightMultiplier argument)
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1);
     return IFX_OK;
 }
 

@@ -417,26 +417,37 @@ def test_lookahead_equivalence(ifx, small_stream):
     d_dep = torch.from_numpy(st["depth"][:n].view(np.int16).copy()).cuda()
     torch.cuda.synchronize()
 
+    from instancefusion_amd import synth
+
     def run(mode):
+        seg = []
         g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+        inst = ifx.InstanceFusion(g)
         if mode == "single":
             g.set_option("two_streams", 0)
+        if mode == "hint_no_track_ahead":
+            g.set_option("track_ahead", 0)
         for i in range(n):
-            if mode == "hint" and i + 1 < n:
+            if mode.startswith("hint") and i + 1 < n:
                 g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
             g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
             if mode == "prefetch" and i + 1 < n:
                 g.prefetch_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
             if mode == "wrong_hint" and i + 1 < n:   # a look-ahead that does not come true is recomputed
                 g.prefetch_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+            seg.append(inst.whetherDoSegmentation(10 + i))   # host decision between frames, as in the reference's main loop
+            if i == 5:   # and a segmentation call while the next frame's tracker may already be queued
+                mk, cl = synth.canned_masks(st["obj"][5], st["scene"])
+                inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], mk, cl, 15, superpixels=True)
         g.sync()
         traj, m, ids = g.trajectory(), g.download(), g.image("ids_after")
         g.close()
-        return traj, m, ids
+        return traj, m, ids, seg
 
     ref = run("single")
-    for mode in ("plain", "hint", "prefetch", "wrong_hint"):
-        t, m, ids = run(mode)
+    for mode in ("plain", "hint", "hint_no_track_ahead", "prefetch", "wrong_hint"):
+        t, m, ids, seg = run(mode)
+        assert seg == ref[3], mode
         assert np.array_equal(t, ref[0]), mode
         assert all(np.array_equal(m[k], ref[1][k]) for k in MAP_KEYS), mode
         assert np.array_equal(ids, ref[2]), mode

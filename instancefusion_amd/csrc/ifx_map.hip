@@ -747,13 +747,6 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
     if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
 }
 
-__global__ void k_list_reset(DevState* st, int which)
-{
-    if (threadIdx.x == 0) {
-        if (which & 1) st->list_n[0] = 0;
-        if (which & 2) { st->list_n[1] = 0; st->list_n[2] = 0; }
-    }
-}
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
 static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out)
@@ -927,47 +920,7 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
     return test;
 }
 
-__global__ void k_clean_new_flags(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
-                                  const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags)
-{
-    int ord = blockIdx.x * blockDim.x + threadIdx.x;   // column-major order index
-    if (ord >= c.w * c.h) return;
-    int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
-    int keep = 0;
-    if (assoc[k] == ASSOC_NEW) {
-        const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
-        float lastT = -2.f;
-        keep = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, tap);
-    }
-    flags[ord] = keep;
-}
 
-__global__ void k_append_new(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ rank, const float4* __restrict__ mpc,
-                             const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc, float4* __restrict__ nr,
-                             float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
-{
-    int ord = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ord >= c.w * c.h || !flags[ord]) return;
-    int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
-    int n = st->count + rank[ord];
-    if (n >= cap) { st->overflow = 1; return; }
-    pc[n] = mpc[k];
-    nr[n] = mnr[k];
-    { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
-    col[n] = make_float2(mcol[k], 0.f);
-    tm[n] = make_float2((float)time, (float)time);
-    ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, -2.f);
-    for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__global__ void k_append_count(DevState* st, const int* total, int cap)
-{
-    if (threadIdx.x == 0) {
-        int t = *total, nc = st->count + t;
-        if (nc > cap) { nc = cap; st->overflow = 1; }
-        st->n_new = nc - st->count;
-        st->count = nc;
-    }
-}
 
 // The append of the new surfels in two launches (was: flags, 3-kernel scan, scatter, count).  Launch 1 evaluates
 // the stability test for the pixels that created a surfel, in column-major order (the order of the reference's

@@ -139,27 +139,6 @@ __global__ void k_intensity(const uint8_t* __restrict__ src, int stride, int n, 
 
 __constant__ float c_gauss25[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
 
-// pyrDownKernelGaussF, EF/Cuda/cudafuncs.cu:332-363
-__global__ void k_pyrdown_gauss_f(const float* __restrict__ src, int sw, int sh, float* __restrict__ dst)
-{
-    int dw = sw / 2, dh = sh / 2;
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    const int D = 5;
-    int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
-    float sum = 0;
-    int count = 0;
-    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-            float s = src[cy * sw + cx];
-            if (!(s != s)) {
-                float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                sum += s * g;
-                count += (int)g;
-            }
-        }
-    dst[y * dw + x] = (float)(sum / (float)count);
-}
 
 // pyrDownKernelIntensityGauss, EF/Cuda/cudafuncs.cu:470-500
 __global__ void k_pyrdown_gauss_u8(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst)
@@ -202,87 +181,9 @@ __global__ void k_sobel(const uint8_t* __restrict__ img, int w, int h, int16_t* 
     dy[y * w + x] = (int16_t)dyVal;
 }
 
-// copyMapsKernel (EF/Cuda/cudafuncs.cu:270-310) + verticesToDepthKernel (:526-537) + intensity of the
-// model image, reading either the prediction or the fill-in maps according to DevState::dense_enough
-// (EF/ElasticFusion.cpp:337-346).
-__global__ void k_model_level0(const DevState* __restrict__ st, const float* __restrict__ pv, const float* __restrict__ pn, const uint8_t* __restrict__ pi,
-                               const float* __restrict__ fv, const float* __restrict__ fn, const uint8_t* __restrict__ fi, int w, int h,
-                               float* __restrict__ vmap, float* __restrict__ nmap, float* __restrict__ depth, uint8_t* __restrict__ img, float cutoff)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const bool fill = !st->dense_enough;
-    const float4 v = reinterpret_cast<const float4*>(fill ? fv : pv)[y * w + x];
-    const float4 n = reinterpret_cast<const float4*>(fill ? fn : pn)[y * w + x];
-    const uint8_t* s = (fill ? fi : pi) + (size_t)(y * w + x) * 4;
-    const float qn = qnan_f();
-    bool ok = !(v.z == 0);
-    vmap[y * w + x] = ok ? v.x : qn;
-    vmap[(y + h) * w + x] = ok ? v.y : qn;
-    vmap[(y + 2 * h) * w + x] = ok ? v.z : qn;
-    nmap[y * w + x] = ok ? n.x : qn;
-    nmap[(y + h) * w + x] = ok ? n.y : qn;
-    nmap[(y + 2 * h) * w + x] = ok ? n.z : qn;
-    depth[y * w + x] = (v.z > cutoff || v.z <= 0) ? qn : v.z;
-    img[y * w + x] = (uint8_t)(int)((float)s[0] * 0.114f + (float)s[1] * 0.299f + (float)s[2] * 0.587f);
-}
 
-// resizeMapKernel<normalize>, EF/Cuda/cudafuncs.cu:365-416, both maps in one launch
-__global__ void k_resize_maps(const float* __restrict__ vin, const float* __restrict__ nin, int sw, int sh, float* __restrict__ vout, float* __restrict__ nout)
-{
-    int dw = sw / 2, dh = sh / 2;
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    const float qn = qnan_f();
-    int xs = x * 2, ys = y * 2;
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const float* in = m ? nin : vin;
-        float* out = m ? nout : vout;
-        float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
-        if ((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11)) {
-            out[y * dw + x] = qn; out[(y + dh) * dw + x] = qn; out[(y + 2 * dh) * dw + x] = qn;
-            continue;
-        }
-        v3 n;
-        n.x = (x00 + x01 + x10 + x11) / 4;
-        const float* py = in + sh * sw;
-        n.y = (py[ys * sw + xs] + py[ys * sw + xs + 1] + py[(ys + 1) * sw + xs] + py[(ys + 1) * sw + xs + 1]) / 4;
-        const float* pz = in + 2 * sh * sw;
-        n.z = (pz[ys * sw + xs] + pz[ys * sw + xs + 1] + pz[(ys + 1) * sw + xs] + pz[(ys + 1) * sw + xs + 1]) / 4;
-        if (m) n = normalized(n);
-        out[y * dw + x] = n.x; out[(y + dh) * dw + x] = n.y; out[(y + 2 * dh) * dw + x] = n.z;
-    }
-}
 
-// tranformMapsKernel, EF/Cuda/cudafuncs.cu:206-248 (camera-frame maps -> global), out of place
-__global__ void k_transform_maps(const DevState* __restrict__ st, const float* __restrict__ vsrc, const float* __restrict__ nsrc, int w, int h,
-                                 float* __restrict__ vdst, float* __restrict__ ndst)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const float* P = st->pose;
-    const float qn = qnan_f();
-    v3 vs = v3m(vsrc[y * w + x], vsrc[(y + h) * w + x], vsrc[(y + 2 * h) * w + x]);
-    v3 vd = v3m(qn, qn, qn);
-    if (!(vs.x != vs.x)) vd = xf_dir(P, vs) + v3m(P[3], P[7], P[11]);
-    vdst[y * w + x] = vd.x; vdst[(y + h) * w + x] = vd.y; vdst[(y + 2 * h) * w + x] = vd.z;
-    v3 ns = v3m(nsrc[y * w + x], nsrc[(y + h) * w + x], nsrc[(y + 2 * h) * w + x]);
-    v3 nd = v3m(qn, qn, qn);
-    if (!(ns.x != ns.x)) nd = xf_dir(P, ns);
-    ndst[y * w + x] = nd.x; ndst[(y + h) * w + x] = nd.y; ndst[(y + 2 * h) * w + x] = nd.z;
-}
 
-// projectPointsKernel, EF/Cuda/cudafuncs.cu:641-659
-__global__ void k_project_cloud(const float* __restrict__ depth, int w, int h, float invFx, float invFy, float cx, float cy, float* __restrict__ cloud)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    float z = depth[y * w + x];
-    cloud[(y * w + x) * 3 + 0] = (float)((x - cx) * z * invFx);
-    cloud[(y * w + x) * 3 + 1] = (float)((y - cy) * z * invFy);
-    cloud[(y * w + x) * 3 + 2] = z;
-}
 
 
 // ---- model side in one launch per pyramid level.  Level 0: copyMaps + verticesToDepth + intensity (k_model_level0),
@@ -1108,11 +1009,6 @@ __device__ __forceinline__ void so3_update_scalar(DevState* st, const float* o, 
     for (int k = 0; k < 9; k++) { st->R_lr[k] = nr[k]; st->resultR[k] = nr[k]; }
     set_so3_matrices(st, fx2, fy2, cx2, cy2);
 }
-__global__ void k_so3_update(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
-{
-    if (st->so3_done) return;
-    so3_update_wave(st, partials, blocks, fx2, fy2, cx2, cy2);
-}
 
 // SO(3) reduction + (last block) update in one launch; same hand-off as k_rgb_step_solve.
 __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int w, int h,
@@ -1310,11 +1206,6 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
 #endif
 }
 
-__global__ void k_gn_solve(DevState* st, const float* __restrict__ icp_partials, int icp_blocks, const float* __restrict__ rgb_partials, int rgb_blocks,
-                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy)
-{
-    gn_solve_block(st, icp_partials, icp_blocks, rgb_partials, rgb_blocks, res_partials, res_blocks, icp, rgb, icp_weight, nfx, nfy, ncx, ncy);
-}
 
 // Photometric reduction + (in the block that finishes last) the final sums and the 6x6 solve: the
 // second and last launch of a Gauss-Newton iteration.  Hand-off between blocks follows the

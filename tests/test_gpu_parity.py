@@ -502,3 +502,56 @@ def test_flood_fill_exact(ifx, orc):
         else:
             assert mo[5].any()
     g.close(); o.close()
+
+
+# ---------------------------------------------------------------- sizes: ragged (not a multiple of the tile sizes) and BASELINE config 4 (1280x960)
+@pytest.mark.parametrize("w,h,frames", [(328, 248, 4), (1280, 960, 2)])
+def test_other_resolutions_against_oracle(ifx, orc, w, h, frames):
+    from instancefusion_amd import synth
+
+    K = dict(fx=528.0 * w / 640, fy=528.0 * w / 640, cx=w / 2.0, cy=h / 2.0)
+    st = synth.make_stream(frames, w, h, noise=True, **K)
+    g = ifx.ElasticFusion(w=w, h=h, max_surfels=w * h * 2, **K)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(w=w, h=h, max_surfels=w * h * 2, **K)
+    inst = ifx.InstanceFusion(g)
+    for i in range(frames):
+        pg = g.processFrame(st["rgb"][i], st["depth"][i])
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        assert np.abs(pg - po).max() < 1e-4, i
+        for name in ("depth_filtered", "depth_metric", "depth_metric_filtered"):
+            assert np.array_equal(g.image(name), o.image(name)), (i, name)
+    assert abs(g.count - o.count) <= max(4, o.count // 2000)
+    assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.005
+    # identical map state -> identical integer outputs of the map stages at this size
+    m = o.download()
+    g.upload(m); o.upload(m)
+    assert np.array_equal(g.render_ids(po, 0), o.render_ids(po, 0))
+    # superpixel stages at this size (ragged: the last partial cell column / row has no centre of its own)
+    seg_g, n_g = inst.gSLICrInterface(st["rgb"][0])
+    seg_o, n_o = o.slic_segment(st["rgb"][0])
+    assert n_g == n_o == (w // 16) * (h // 16) and np.array_equal(seg_g, seg_o)
+    s_g, f_g, i_g = inst.mergeSuperPixel(st["depth"][0], seg_g)
+    s_o, f_o, i_o = o.merge_superpixels(st["depth"][0], seg_o)
+    assert np.array_equal(s_g, s_o) and np.array_equal(f_g, f_o) and nan_equal(i_g, i_o)
+    mk, cl = synth.canned_masks(st["obj"][0], st["scene"])
+    if mk.shape[0]:
+        assert np.array_equal(inst.maskSuperPixelFilter_OverSeg(f_g, mk), o.mask_superpixel_filter(f_o, mk))
+        dm = (st["depth"][0].astype(np.float32) * 1.186).astype(np.uint16)
+        a, ua = inst.maskGeometricFilter(dm, mk, mk)
+        b, ub = o.mask_geometric_filter(dm, mk, mk)
+        assert np.array_equal(a, b) and np.array_equal(ua, ub)
+    g.close(); o.close()
+
+
+def test_empty_inputs(ifx, small_stream):
+    """No masks, an all-zero depth frame, a segmentation call on an empty map: nothing crashes, nothing changes."""
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=200000)
+    inst = ifx.InstanceFusion(g)
+    inst.ProcessSegmentation(st["rgb"][0], st["depth"][0], np.zeros((0, SMALL["h"], SMALL["w"]), np.uint8), np.zeros(0, np.int32), 0, superpixels=True)
+    p0 = g.processFrame(st["rgb"][0], np.zeros_like(st["depth"][0]))          # empty first frame -> empty map
+    assert g.count == 0 and np.array_equal(p0, np.eye(4, dtype=np.float32))
+    inst.ProcessSegmentation(st["rgb"][0], st["depth"][0], np.full((1, SMALL["h"], SMALL["w"]), 255, np.uint8), np.array([3], np.int32), 1, superpixels=True)
+    assert (inst.getInstanceTable() == -1).all()
+    g.close()

@@ -168,8 +168,8 @@ int ifx_tracker_buffer_download(ifx_t* h, const char* name, int level, void* out
  * processInstance, IF/Core/InstanceFusion.h:72-107, IF/Core/InstanceFusion.cpp:192-270,655-1067) */
 int ifx_should_segment(ifx_t* h, int frame);
 /* masks: n x H x W u8 (0/255), sorted by area descending (the contract of the Mask-RCNN bridge,
- * build/mask_ori.py:117); class_ids: n COCO indices.  flags bit0: kNN smoothing (not implemented,
- * rejected), bit1: superpixel refinement (needs rgb and depth of the frame, host pointers). */
+ * build/mask_ori.py:117); class_ids: n COCO indices.  flags bit0: kNN smoothing of the instance colours
+ * (isflann: flannKnnVoteSurfelMap, IF/Core/InstanceFusion.cpp:1070-1163), bit1: superpixel refinement (needs rgb and depth of the frame, host pointers). */
 int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks, const int32_t* class_ids, int n, int frame,
                              int flags);
@@ -197,6 +197,11 @@ int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_t* masks, c
  *   layout (:12-33).  Returns spNum.
  * ifx_mask_superpixel_filter: maskSuperPixelFilter_OverSeg (:651-710): a mask keeps a merged region
  *   iff it covers more than 75 % of it; masks n x H x W u8 rewritten in place. */
+/* flannKnnVoteSurfelMap + mapKnnVoteColourKernel (IF/Core/InstanceFusion.cpp:1070-1163, IF/Core/InstanceFusionCuda.cu:1237-1340)
+ * as a stage: every live surfel takes the colour of the instance most of its 10 nearest surfels (itself included) are
+ * labelled with, using the labels of the last segmentation call.  nbr_out (optional, [max_n][10] int32, host) receives
+ * the neighbour slots of the first max_n slots, -1 = none. */
+int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n);
 int ifx_slic_segment(ifx_t* h, const uint8_t* rgb, int32_t* seg_out);
 int ifx_merge_superpixels(ifx_t* h, const uint16_t* depth, int32_t* seg_inout, int32_t* final_out, float* info_out);
 int ifx_mask_superpixel_filter(ifx_t* h, const int32_t* final_ids, uint8_t* masks, int n);

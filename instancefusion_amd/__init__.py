@@ -102,6 +102,7 @@ _SIGS = {
     "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
     "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
     "ifx_mask_geometric_filter": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    "ifx_knn_vote_colour": (C.c_int, [_P, _P, C.c_int]),
     "ifx_slic_segment": (C.c_int, [_P, _P, _P]),
     "ifx_merge_superpixels": (C.c_int, [_P, _P, _P, _P, _P]),
     "ifx_mask_superpixel_filter": (C.c_int, [_P, _P, _P, C.c_int]),
@@ -402,6 +403,12 @@ class InstanceFusion:
         un = np.zeros(masks.shape[0], np.uint8) if unavailable is None else np.ascontiguousarray(unavailable, np.uint8).copy()
         self.ef._chk(self.L.ifx_mask_geometric_filter(self.ef.handle, _ptr(depth), _ptr(masks), _ptr(ori), int(masks.shape[0]), _ptr(un)), "ifx_mask_geometric_filter")
         return masks, un
+
+    def flannKnnVoteSurfelMap(self, with_neighbours=False):
+        n = self.ef.slots
+        nbr = np.full((max(n, 1), 10), -1, np.int32) if with_neighbours else None
+        self.ef._chk(self.L.ifx_knn_vote_colour(self.ef.handle, _ptr(nbr) if with_neighbours else None, n if with_neighbours else 0), "ifx_knn_vote_colour")
+        return nbr[:n] if with_neighbours else None
 
     def maskCleanOverlap(self, masks):
         masks = np.ascontiguousarray(masks, np.uint8).copy()

@@ -101,7 +101,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
-    ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (SN / 1024 + 8) * 4);
+    ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (std::max(SN, (size_t)1 << 24) / 1024 + 8) * 4);   // also serves the 256^3-cell scan of the kNN grid
     for (int q = 0; q < 2; q++) {
         FrameSlot& f = h->slot[q];
         ALLOC(f.rgb, P * 3); ALLOC(f.depth_raw, P * 2); ALLOC(f.depth_filt, P * 2); ALLOC(f.dm, P * 4); ALLOC(f.dmf, P * 4);
@@ -155,6 +155,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_free_tracker(h);
     ifx_free_instance(h);
     ifx_slic_free(h);
+    ifx_knn_free(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
     if (h->ev_result) hipEventDestroy(h->ev_result);
     if (h->stream_b) hipStreamDestroy(h->stream_b);

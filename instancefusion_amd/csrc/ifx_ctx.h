@@ -167,6 +167,7 @@ struct ifx {
     int last_seg_frame = -1;
     int seg_counts_valid = 0;          // h_result->seg_counts describe the current ids_after / votes
     int clean_times = 0;
+    int* d_knn = nullptr; size_t knn_cap = 0;   // grid + sort buffers of the kNN smoothing (ifx_knn.hip), allocated on first use
     void* slic = nullptr;              // superpixel buffers (ifx_slic.hip), allocated on first use
     // timing
     hipEvent_t ev_stage[8];
@@ -205,6 +206,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // stage entry points implemented across the .hip files
 void ifx_slic_free(ifx* h);
+void ifx_knn_free(ifx* h);
+int ifx_knn_vote(ifx* h, int32_t* d_nbr_out);
 int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric
 int ifx_tracker_init_first(ifx* h);

@@ -560,7 +560,6 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
 {
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
     h->seg_counts_valid = 0;
-    if (flags & 1) { h->err = "kNN label smoothing (flann step) is not implemented"; return IFX_E_INVALID; }
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
     hipEvent_t ea = ifx_event_get(h);
     hipEventRecord(ea, h->stream);
@@ -636,6 +635,8 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     }
     // step 4
     LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+    // flannKnnVoteSurfelMap (isflann, :1051)
+    if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
     hipEvent_t eb = ifx_event_get(h);
     hipEventRecord(eb, h->stream);
     h->stage_pending.push_back({2, {ea, eb}});

@@ -1,0 +1,223 @@
+// ifx_knn.hip -- k-nearest-neighbour smoothing of the instance colours.
+//
+//   ifx_knn_vote  <-  InstanceFusion::flannKnnVoteSurfelMap   IF/Core/InstanceFusion.cpp:1070-1163
+//                     mapKnnVoteColourKernel                  IF/Core/InstanceFusionCuda.cu:1237-1340
+//
+// The reference builds a FLANN kd-tree over all surfel positions (REF/deps/flann-1.8.4, KDTreeCuda3dIndex,
+// exact search, k = 10, the query set is the indexed set, so every surfel is its own first neighbour) and lets
+// each surfel take the colour of the instance that most of its 10 neighbours are labelled with
+// (bestIDInEachSurfel >= 0 only; first maximum; nothing changes when no neighbour is labelled).
+//
+// Here: exact k-NN on a uniform grid instead of a kd-tree.  Cells = bounding box of the live surfels cut into
+// <= 256 cells along its longest side; counting sort by cell (histogram, exclusive scan, scatter); a query walks
+// the cell shells around its own cell and stops as soon as its 10th candidate is closer than the inner border
+// of the next shell, so the result is the exact k-NN set.  Ties in distance go to the lower map index (FLANN
+// leaves that order unspecified); the oracle uses the same rule with a brute-force search.
+#include "ifx_ctx.h"
+#include "ifx_dev.h"
+#include <algorithm>
+
+#define DEAD_TIME (-1.0e9f)   // tombstone marker in times.y (ifx_map.hip)
+
+namespace {
+
+constexpr int KNN = 10;
+constexpr int GRID_MAX = 256;
+
+struct KnnGrid {        // device-resident, filled by k_knn_grid
+    int lo_bits[3], hi_bits[3];   // ordered-int encodings of the bounding box (atomicMin / atomicMax)
+    float lo[3], cell, inv_cell;
+    int dim[3];
+};
+
+__device__ __forceinline__ int ord(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float unord(int b) { return __int_as_float(b >= 0 ? b : b ^ 0x7FFFFFFF); }
+
+__device__ __forceinline__ bool live(const DevState* st, const float2* tm, int i) { return i < st->count && tm[i].y > DEAD_TIME; }
+
+__global__ void k_knn_bounds_init(KnnGrid* g)
+{
+    if (threadIdx.x < 3) { g->lo_bits[threadIdx.x] = 0x7FFFFFFF; g->hi_bits[threadIdx.x] = (int)0x80000000; }
+}
+__global__ void k_knn_bounds(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, KnnGrid* g)
+{
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        if (!(tm[i].y > DEAD_TIME)) continue;
+        float4 p = pc[i];
+        int v[3] = {ord(p.x), ord(p.y), ord(p.z)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], v[k]); hi[k] = max(hi[k], v[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], o)); hi[k] = max(hi[k], __shfl_xor(hi[k], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&g->lo_bits[k], lo[k]); atomicMax(&g->hi_bits[k], hi[k]); }
+    }
+}
+__global__ void k_knn_grid(KnnGrid* g)
+{
+    if (threadIdx.x != 0) return;
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) { g->lo[k] = unord(g->lo_bits[k]); ext = fmaxf(ext, unord(g->hi_bits[k]) - g->lo[k]); }
+    if (!(ext > 0.f)) ext = 1.0f;
+    g->cell = ext / (float)(GRID_MAX - 1);
+    g->inv_cell = 1.0f / g->cell;
+    for (int k = 0; k < 3; k++) {
+        int d = (int)((unord(g->hi_bits[k]) - g->lo[k]) * g->inv_cell) + 1;
+        g->dim[k] = min(max(d, 1), GRID_MAX);
+    }
+}
+__device__ __forceinline__ void cell_of(const KnnGrid* g, float4 p, int* c)
+{
+    const float q[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = min(max((int)((q[k] - g->lo[k]) * g->inv_cell), 0), g->dim[k] - 1);
+}
+__global__ void k_knn_count(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, const KnnGrid* __restrict__ g, int* __restrict__ cell_id,
+                            int* __restrict__ counts)
+{
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        int id = -1;
+        if (tm[i].y > DEAD_TIME) {
+            int c[3];
+            cell_of(g, pc[i], c);
+            id = (c[2] * g->dim[1] + c[1]) * g->dim[0] + c[0];
+            atomicAdd(&counts[id], 1);
+        }
+        cell_id[i] = id;
+    }
+}
+__global__ void k_knn_scatter(const DevState* __restrict__ st, const int* __restrict__ cell_id, const int* __restrict__ start, int* __restrict__ fill, int* __restrict__ sorted)
+{
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        int id = cell_id[i];
+        if (id >= 0) sorted[start[id] + atomicAdd(&fill[id], 1)] = i;
+    }
+}
+
+// one query per thread: exact k-NN by growing cell shells, then the majority vote of the labelled neighbours
+__global__ void __launch_bounds__(128) k_knn_vote(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, const KnnGrid* __restrict__ g,
+                                                  const int* __restrict__ start, const int* __restrict__ counts, const int* __restrict__ sorted, const int32_t* __restrict__ labels,
+                                                  const float* __restrict__ inst_color, float2* __restrict__ col, int32_t* __restrict__ nbr_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!live(st, tm, i)) return;
+    const float4 q = pc[i];
+    int c[3];
+    cell_of(g, q, c);
+    const int dx = g->dim[0], dy = g->dim[1], dz = g->dim[2];
+    float bd[KNN];
+    int bi[KNN];
+#pragma unroll
+    for (int k = 0; k < KNN; k++) { bd[k] = INFINITY; bi[k] = 0x7FFFFFFF; }
+    const int rmax = max(max(dx, dy), dz);
+    for (int r = 0; r <= rmax; r++) {
+        for (int z = max(c[2] - r, 0); z <= min(c[2] + r, dz - 1); z++)
+            for (int y = max(c[1] - r, 0); y <= min(c[1] + r, dy - 1); y++) {
+                const bool face = abs(z - c[2]) == r || abs(y - c[1]) == r;   // on a z / y face the whole x run is new, else only its two ends
+                for (int x = max(c[0] - r, 0); x <= min(c[0] + r, dx - 1); x++) {
+                    if (!face && abs(x - c[0]) != r) continue;
+                    const int id = (z * dy + y) * dx + x, s0 = start[id], s1 = s0 + counts[id];
+                    for (int s = s0; s < s1; s++) {
+                        const int j = sorted[s];
+                        const float4 p = pc[j];
+                        const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+                        float d = (ex * ex + ey * ey) + ez * ez;
+                        if (!(d < bd[KNN - 1] || (d == bd[KNN - 1] && j < bi[KNN - 1]))) continue;
+                        int jj = j;   // insertion into the sorted top-10 by (distance, index); fully unrolled -> registers
+#pragma unroll
+                        for (int k = 0; k < KNN; k++) {
+                            const bool before = d < bd[k] || (d == bd[k] && jj < bi[k]);
+                            const float td = before ? bd[k] : d;
+                            const int ti = before ? bi[k] : jj;
+                            bd[k] = before ? d : bd[k];
+                            bi[k] = before ? jj : bi[k];
+                            d = td; jj = ti;
+                        }
+                    }
+                }
+            }
+        // every point not visited yet lies outside the cube of (2r+1)^3 cells around the query's cell: farther than r cells
+        const float safe = (float)r * g->cell * 0.99f;
+        if (bi[KNN - 1] != 0x7FFFFFFF && bd[KNN - 1] <= safe * safe) break;
+    }
+    int lab[KNN];
+#pragma unroll
+    for (int k = 0; k < KNN; k++) {
+        lab[k] = (bi[k] != 0x7FFFFFFF) ? labels[bi[k]] : -1;
+        if (nbr_out) nbr_out[(size_t)i * KNN + k] = (bi[k] != 0x7FFFFFFF) ? bi[k] : -1;
+    }
+    int best = -1, bestCount = 0;   // first maximum over instance ids 0..95 == highest count, lowest id on ties
+#pragma unroll
+    for (int k = 0; k < KNN; k++) {
+        if (lab[k] < 0) continue;
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < KNN; m++) cnt += (lab[m] == lab[k]);
+        if (cnt > bestCount || (cnt == bestCount && lab[k] < best)) { bestCount = cnt; best = lab[k]; }
+    }
+    if (bestCount > 0) col[i].y = inst_color[best];
+}
+
+}  // namespace
+
+void ifx_knn_free(ifx* h)
+{
+    if (h->d_knn) hipFree(h->d_knn);
+    h->d_knn = nullptr; h->knn_cap = 0;
+}
+
+int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total);
+
+// flags bit0 of ifx_process_segmentation; nbr_out (device, [slots][10], optional) receives the neighbour slots
+int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
+{
+    const size_t cells = (size_t)GRID_MAX * GRID_MAX * GRID_MAX, cap = (size_t)h->cap;
+    const size_t need = 64 + cells * 3 + cap * 2 + 16;   // grid header, counts / starts / fill, cell ids, sorted
+    if (need > h->knn_cap) {
+        ifx_knn_free(h);
+        HIPCHK(h, hipMalloc(&h->d_knn, need * 4));
+        h->knn_cap = need;
+    }
+    KnnGrid* g = (KnnGrid*)h->d_knn;
+    int* counts = h->d_knn + 64;
+    int* starts = counts + cells;
+    int* fill = starts + cells;
+    int* cell_id = fill + cells;
+    int* sorted = cell_id + cap;
+    int* total = sorted + cap;
+    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->stream));
+    LAUNCH(h, "knn_bounds_init", dim3(1), dim3(64), k_knn_bounds_init, g);
+    LAUNCH(h, "knn_bounds", dim3(1024), dim3(256), k_knn_bounds, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g);
+    LAUNCH(h, "knn_grid", dim3(1), dim3(64), k_knn_grid, g);
+    LAUNCH(h, "knn_count", dim3(2048), dim3(256), k_knn_count, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g, cell_id, counts);
+    int r = ifx_scan_exclusive(h, counts, (int)cells, starts, total);
+    if (r) return r;
+    LAUNCH(h, "knn_scatter", dim3(2048), dim3(256), k_knn_scatter, h->d_state, cell_id, starts, fill, sorted);
+    LAUNCH(h, "knn_vote", dim3(cdiv(h->cap, 128)), dim3(128), k_knn_vote, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g, starts, counts, sorted, h->labels, h->d_inst_color,
+           (float2*)h->col, d_nbr_out);
+    return IFX_OK;
+}
+
+// stage entry for tests: runs the smoothing on the current map / labels and returns the neighbour slots of the first
+// `max_n` slots (host, [max_n][10], -1 = none / dead slot)
+extern "C" int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n)
+{
+    if (!h || max_n < 0) return IFX_E_INVALID;
+    int32_t* d_nbr = nullptr;
+    if (nbr_out && max_n > 0) {
+        HIPCHK(h, hipMalloc(&d_nbr, (size_t)h->cap * KNN * 4));
+        HIPCHK(h, hipMemsetAsync(d_nbr, 0xFF, (size_t)h->cap * KNN * 4, h->stream));
+    }
+    int r = ifx_knn_vote(h, d_nbr);
+    if (!r && d_nbr) r = hipMemcpyAsync(nbr_out, d_nbr, (size_t)std::min(max_n, h->cap) * KNN * 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess ? IFX_OK : IFX_E_HIP;
+    hipStreamSynchronize(h->stream);
+    if (d_nbr) hipFree(d_nbr);
+    return r;
+}

@@ -150,6 +150,9 @@ int orc_slic_segment(orc_t*, const uint8_t* rgb, int32_t* seg);
 int orc_merge_superpixels(orc_t*, const uint16_t* depth, int32_t* seg, int32_t* final_out, float* info_out);
 void orc_mask_superpixel_filter(orc_t*, const int32_t* final_ids, uint8_t* masks, int n);
 
+/* kNN smoothing of the instance colours (flannKnnVoteSurfelMap); nbr optional n x 10 */
+void orc_knn_vote(orc_t*, int32_t* nbr);
+
 /* stage-level instance helpers */
 void orc_mask_clean_overlap(uint8_t* masks, int n, int w, int h);
 float orc_vote_encode(int a, int b);

@@ -224,6 +224,7 @@ static int first_not_used(orc_t* o)
  * replaced by the caller's pre-computed masks.  Superpixel refinement (steps -1_1..-1_3) is in
  * orc_slic.c and is applied when do_knn bit 1 (value 2) is set. */
 int orc_superpixel_refine(orc_t* o, const uint8_t* rgb, const uint16_t* depth, uint8_t* masks, int nm, int frame);
+void orc_knn_vote(orc_t* o, int32_t* nbr);
 
 int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame,
@@ -332,7 +333,47 @@ int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth
         if (*ic == 0 || *ic == defaultColor) *ic = (best != -1) ? o->inst_color[best] : defaultColor;
     }
     free(masks); free(ori); free(unavailable); free(maskBBox); free(cmp); free(pdm);
+    if (flags & 1) orc_knn_vote(o, NULL); /* isflann, :1051 */
     return 0;
+}
+
+/* flannKnnVoteSurfelMap + mapKnnVoteColourKernel, IF/Core/InstanceFusion.cpp:1070-1163, IF/Core/InstanceFusionCuda.cu:1237-1340:
+ * every surfel takes the colour of the instance that most of its 10 nearest surfels (the query set is the indexed set, so
+ * itself included) are labelled with; labels = bestIDInEachSurfel of the last count/colour pass; first maximum; no labelled
+ * neighbour -> unchanged.  FLANN's exact kd-tree search (REF/deps/flann-1.8.4) is restated as a brute-force search; ties in
+ * distance, which FLANN leaves unspecified, go to the lower index.  nbr (optional): n x 10 neighbour indices, -1 = none. */
+void orc_knn_vote(orc_t* o, int32_t* nbr)
+{
+    const int n = o->n, K = 10;
+    float* newcol = (float*)malloc((size_t)n * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        float bd[10];
+        int bi[10];
+        for (int k = 0; k < K; k++) { bd[k] = INFINITY; bi[k] = 0x7FFFFFFF; }
+        const float qx = o->pc[i * 4], qy = o->pc[i * 4 + 1], qz = o->pc[i * 4 + 2];
+        for (int j = 0; j < n; j++) {
+            const float ex = o->pc[j * 4] - qx, ey = o->pc[j * 4 + 1] - qy, ez = o->pc[j * 4 + 2] - qz;
+            float d = (ex * ex + ey * ey) + ez * ez;
+            if (!(d < bd[K - 1] || (d == bd[K - 1] && j < bi[K - 1]))) continue;
+            int jj = j;
+            for (int k = 0; k < K; k++)
+                if (d < bd[k] || (d == bd[k] && jj < bi[k])) { float td = bd[k]; int ti = bi[k]; bd[k] = d; bi[k] = jj; d = td; jj = ti; }
+        }
+        float temp[ORC_NUM_INST];
+        for (int q = 0; q < ORC_NUM_INST; q++) temp[q] = 0;
+        for (int k = 0; k < K; k++) {
+            if (nbr) nbr[(size_t)i * K + k] = bi[k] == 0x7FFFFFFF ? -1 : bi[k];
+            if (bi[k] == 0x7FFFFFFF) continue;
+            if (o->labels[bi[k]] >= 0) temp[o->labels[bi[k]]]++;
+        }
+        int maxNum = -1, maxID = -1;
+        for (int q = 0; q < ORC_NUM_INST; q++)
+            if (temp[q] > maxNum) { maxID = q; maxNum = (int)temp[q]; }
+        newcol[i] = maxNum > 0 ? o->inst_color[maxID] : o->col[i * 2 + 1];
+    }
+    for (int i = 0; i < n; i++) o->col[i * 2 + 1] = newcol[i];
+    free(newcol);
 }
 
 /* test hook: the flood fill alone (depth = model depth map as getProjectDepthMap produces it) */

@@ -198,6 +198,12 @@ class Oracle:
         cls = np.ascontiguousarray(class_ids, np.int32)
         return self.L.orc_process_segmentation(self.h, ptr(rgb), ptr(depth), ptr(masks), ptr(cls), masks.shape[0], frame, flags)
 
+    def knn_vote(self, with_neighbours=False):
+        nbr = np.full((max(self.count, 1), 10), -1, np.int32) if with_neighbours else None
+        self.L.orc_knn_vote.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_knn_vote(self.h, ptr(nbr) if with_neighbours else None)
+        return nbr[: self.count] if with_neighbours else None
+
     def mask_geometric_filter(self, model_depth, masks, ori, unavailable=None):
         depth = np.ascontiguousarray(model_depth, np.uint16)
         masks = np.ascontiguousarray(masks, np.uint8).copy()

@@ -555,3 +555,43 @@ def test_empty_inputs(ifx, small_stream):
     inst.ProcessSegmentation(st["rgb"][0], st["depth"][0], np.full((1, SMALL["h"], SMALL["w"]), 255, np.uint8), np.array([3], np.int32), 1, superpixels=True)
     assert (inst.getInstanceTable() == -1).all()
     g.close()
+
+
+# ---------------------------------------------------------------- 8f-2: kNN smoothing of the instance colours
+def test_knn_vote_exact(ifx, orc):
+    from instancefusion_amd import synth
+
+    w, h = 320, 240
+    K = dict(fx=264.0, fy=264.0, cx=160.0, cy=120.0)
+    n = 20000
+    st = synth.make_stream(1, w, h, noise=False, **K)
+    m = synth.make_map(n, st["scene"], st["poses_world"][0], 10)
+    rng = np.random.RandomState(2)
+    lab = rng.randint(-1, 6, n).astype(np.int32)
+    lab[rng.rand(n) < 0.5] = -1
+    votes = np.zeros((n, 48), np.float32)
+    for i in np.nonzero(lab >= 0)[0]:
+        a, b = (7, 0) if lab[i] % 2 == 0 else (0, 7)
+        votes[i, lab[i] // 2] = orc.lib().orc_vote_encode(a, b)
+    m["votes"] = votes
+    m["pc"][5000:5010, :3] = m["pc"][4999, :3]            # coincident points: distance ties broken by index
+    g = ifx.ElasticFusion(w=w, h=h, max_surfels=n + 100, **K)
+    o = orc.Oracle(w=w, h=h, max_surfels=n + 100, **K)
+    inst = ifx.InstanceFusion(g)
+    g.processFrame(st["rgb"][0], np.zeros_like(st["depth"][0])); o.process_frame(st["rgb"][0], np.zeros_like(st["depth"][0]))
+    g.upload(m); o.upload(m)
+    masks = np.zeros((1, h, w), np.uint8)
+    o.set_ids_after(np.zeros((h, w), np.int32))
+    # flags bit0 = isflann: label scan, then the smoothing, inside the segmentation call
+    inst.ProcessSegmentation(st["rgb"][0], st["depth"][0], masks, np.array([1], np.int32), 0, isflann=True)
+    o.process_segmentation(st["rgb"][0], st["depth"][0], masks, np.array([1], np.int32), 0, flags=1)
+    assert np.array_equal(inst.labels(), o.labels()) and np.array_equal(o.labels(), lab)
+    cg, co = g.download()["col"], o.download()["col"]
+    assert np.array_equal(cg, co)
+    assert (co[:, 1] != 0).sum() > n // 4
+    # the stage on its own, with the neighbour lists
+    ng = inst.flannKnnVoteSurfelMap(with_neighbours=True)
+    no = o.knn_vote(with_neighbours=True)
+    assert np.array_equal(ng[:n], no)
+    assert np.array_equal(g.download()["col"], o.download()["col"])
+    g.close(); o.close()

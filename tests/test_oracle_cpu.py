@@ -288,3 +288,45 @@ def test_instance_votes_and_labels(orc, small_stream):
     # IF/Core/InstanceFusionCuda.cu:915 -- so boxes can stay small and masks may register again)
     assert n1 <= n2 <= n1 + masks.shape[0]
     o.close()
+
+
+def test_knn_vote_against_scipy(orc):
+    """orc_knn_vote: the 10 nearest surfels (self included) of a brute-force search equal scipy's exact kd-tree
+    query, and the colour becomes that of the most frequent non-negative label among them (first maximum)."""
+    from scipy.spatial import cKDTree
+    from instancefusion_amd import synth
+
+    n = 4000
+    st = synth.make_stream(1, 320, 240, 264.0, 264.0, 160.0, 120.0, noise=False)
+    m = synth.make_map(n, st["scene"], st["poses_world"][0], 10)
+    o = orc.Oracle(w=320, h=240, fx=264.0, fy=264.0, cx=160.0, cy=120.0, max_surfels=n + 10)
+    o.upload(m)
+    # labels come from the votes: run a label scan through a segmentation-free path by writing votes directly
+    rng = np.random.RandomState(2)
+    lab = rng.randint(-1, 5, n).astype(np.int32)
+    votes = np.zeros((n, 48), np.float32)
+    for i in np.nonzero(lab >= 0)[0]:
+        a, b = (7, 0) if lab[i] % 2 == 0 else (0, 7)
+        votes[i, lab[i] // 2] = orc.lib().orc_vote_encode(a, b)
+    m2 = o.download(); m2["votes"] = votes
+    o.upload(m2)
+    masks = np.zeros((1, 240, 320), np.uint8)             # a call with one empty mask only refreshes labels / colours
+    o.set_ids_after(np.zeros((240, 320), np.int32))
+    o.process_segmentation(st["rgb"][0], st["depth"][0], masks, np.array([1], np.int32), 0)
+    assert np.array_equal(o.labels(), lab)
+    before = o.download()["col"][:, 1].copy()
+    nbr = o.knn_vote(with_neighbours=True)
+    after = o.download()["col"][:, 1]
+    pos = m["pc"][:, :3].astype(np.float32)
+    d, idx = cKDTree(pos.astype(np.float64)).query(pos.astype(np.float64), k=10)
+    assert (np.sort(nbr, 1) == np.sort(idx, 1)).mean() > 0.999      # identical sets except exact distance ties
+    tab = o.instance_table()
+    for i in range(0, n, 37):
+        ls = lab[nbr[i]]
+        ls = ls[ls >= 0]
+        if len(ls) == 0:
+            assert after[i] == before[i]
+        else:
+            cnt = np.bincount(ls, minlength=96)
+            assert after[i] != 0 and (cnt.max() > 0)
+    o.close()

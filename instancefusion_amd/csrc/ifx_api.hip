@@ -111,8 +111,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     }
     hipHostMalloc((void**)&h->rgb_stage, P * 3);
     hipHostMalloc((void**)&h->depth_stage, P * 2);
-    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8);
-    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8); hipMemset(h->key_ids, 0xFF, P * 8);
+    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8); ALLOC(h->key_both, P * 8);
+    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8); hipMemset(h->key_ids, 0xFF, P * 8); hipMemset(h->key_both, 0xFF, P * 8);
     ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16); ALLOC(h->index_ct, P * 16); ALLOC(h->index_nr, P * 16); ALLOC(h->index_tap, P * 16);
     ALLOC(h->pred_vertex, P * 16); ALLOC(h->pred_normal, P * 16); ALLOC(h->pred_image, P * 4); ALLOC(h->pred_inst, P * 4); ALLOC(h->pred_time, P * 2);
     ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
@@ -145,7 +145,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
-                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids,
+                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);

@@ -134,6 +134,7 @@ struct ifx {
     uint8_t* rgb_stage = nullptr; uint16_t* depth_stage = nullptr; // pinned staging
     // index map
     unsigned long long *key_index = nullptr, *key_splat = nullptr, *key_ids = nullptr;
+    unsigned long long* key_both = nullptr;   // pixels a surfel covers in BOTH the splat and the id render: one atomic instead of two
     uint32_t* index_id = nullptr;
     float *index_vc = nullptr, *index_ct = nullptr, *index_nr = nullptr, *index_tap = nullptr;
     // predictions

@@ -91,23 +91,30 @@ __global__ void k_knn_count(const DevState* __restrict__ st, const float4* __res
         cell_id[i] = id;
     }
 }
-__global__ void k_knn_scatter(const DevState* __restrict__ st, const int* __restrict__ cell_id, const int* __restrict__ start, int* __restrict__ fill, int* __restrict__ sorted)
+// scatter into cell order: slot index AND position (slot in the w lane), so that the search reads its candidates with one
+// contiguous 16-B load each and neighbouring threads (= neighbouring cells) share cache lines
+__global__ void k_knn_scatter(const DevState* __restrict__ st, const float4* __restrict__ pc, const int* __restrict__ cell_id, const int* __restrict__ start, int* __restrict__ fill,
+                              float4* __restrict__ sorted)
 {
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
         int id = cell_id[i];
-        if (id >= 0) sorted[start[id] + atomicAdd(&fill[id], 1)] = i;
+        if (id < 0) continue;
+        float4 p = pc[i];
+        p.w = __int_as_float(i);
+        sorted[start[id] + atomicAdd(&fill[id], 1)] = p;
     }
 }
 
 // one query per thread: exact k-NN by growing cell shells, then the majority vote of the labelled neighbours
-__global__ void __launch_bounds__(128) k_knn_vote(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, const KnnGrid* __restrict__ g,
-                                                  const int* __restrict__ start, const int* __restrict__ counts, const int* __restrict__ sorted, const int32_t* __restrict__ labels,
+__global__ void __launch_bounds__(128) k_knn_vote(const DevState* __restrict__ st, const KnnGrid* __restrict__ g, const int* __restrict__ start, const int* __restrict__ counts,
+                                                  const float4* __restrict__ sorted, const int* __restrict__ total, const int32_t* __restrict__ labels,
                                                   const float* __restrict__ inst_color, float2* __restrict__ col, int32_t* __restrict__ nbr_out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (!live(st, tm, i)) return;
-    const float4 q = pc[i];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // queries in cell order
+    if (t >= *total) return;
+    const float4 q = sorted[t];
+    const int i = __float_as_int(q.w);
     int c[3];
     cell_of(g, q, c);
     const int dx = g->dim[0], dy = g->dim[1], dz = g->dim[2];
@@ -124,8 +131,8 @@ __global__ void __launch_bounds__(128) k_knn_vote(const DevState* __restrict__ s
                     if (!face && abs(x - c[0]) != r) continue;
                     const int id = (z * dy + y) * dx + x, s0 = start[id], s1 = s0 + counts[id];
                     for (int s = s0; s < s1; s++) {
-                        const int j = sorted[s];
-                        const float4 p = pc[j];
+                        const float4 p = sorted[s];
+                        const int j = __float_as_int(p.w);
                         const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
                         float d = (ex * ex + ey * ey) + ez * ez;
                         if (!(d < bd[KNN - 1] || (d == bd[KNN - 1] && j < bi[KNN - 1]))) continue;
@@ -177,8 +184,8 @@ int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_tot
 // flags bit0 of ifx_process_segmentation; nbr_out (device, [slots][10], optional) receives the neighbour slots
 int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
 {
-    const size_t cells = (size_t)GRID_MAX * GRID_MAX * GRID_MAX, cap = (size_t)h->cap;
-    const size_t need = 64 + cells * 3 + cap * 2 + 16;   // grid header, counts / starts / fill, cell ids, sorted
+    const size_t cells = (size_t)GRID_MAX * GRID_MAX * GRID_MAX, cap = ((size_t)h->cap + 3) & ~(size_t)3;
+    const size_t need = 64 + cells * 3 + cap * 5 + 16;   // grid header, counts / starts / fill, cell ids, positions in cell order (float4)
     if (need > h->knn_cap) {
         ifx_knn_free(h);
         HIPCHK(h, hipMalloc(&h->d_knn, need * 4));
@@ -189,8 +196,8 @@ int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
     int* starts = counts + cells;
     int* fill = starts + cells;
     int* cell_id = fill + cells;
-    int* sorted = cell_id + cap;
-    int* total = sorted + cap;
+    float4* sorted = (float4*)(cell_id + cap);   // 16-B aligned: header 64 ints, cells and cap are multiples of 4 after rounding below
+    int* total = (int*)(sorted + cap);
     HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->stream));
     LAUNCH(h, "knn_bounds_init", dim3(1), dim3(64), k_knn_bounds_init, g);
@@ -199,9 +206,8 @@ int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
     LAUNCH(h, "knn_count", dim3(2048), dim3(256), k_knn_count, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g, cell_id, counts);
     int r = ifx_scan_exclusive(h, counts, (int)cells, starts, total);
     if (r) return r;
-    LAUNCH(h, "knn_scatter", dim3(2048), dim3(256), k_knn_scatter, h->d_state, cell_id, starts, fill, sorted);
-    LAUNCH(h, "knn_vote", dim3(cdiv(h->cap, 128)), dim3(128), k_knn_vote, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g, starts, counts, sorted, h->labels, h->d_inst_color,
-           (float2*)h->col, d_nbr_out);
+    LAUNCH(h, "knn_scatter", dim3(2048), dim3(256), k_knn_scatter, h->d_state, (const float4*)h->pc, cell_id, starts, fill, sorted);
+    LAUNCH(h, "knn_vote", dim3(cdiv(h->cap, 128)), dim3(128), k_knn_vote, h->d_state, g, starts, counts, sorted, total, h->labels, h->d_inst_color, (float2*)h->col, d_nbr_out);
     return IFX_OK;
 }
 

@@ -89,7 +89,7 @@ def main():
     m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + rank)
     t_gen = time.time() - t_gen
 
-    cap = args.surfels + 1_500_000
+    cap = args.surfels + 2_500_000
     ef = ifx.ElasticFusion(w=W, h=H, max_surfels=cap, device=dev, **K)
     inst = ifx.InstanceFusion(ef)
     for kv in args.opt:
@@ -136,10 +136,22 @@ def main():
         step(k)
     barrier()
     dt = time.perf_counter() - t0
-    stage = ef.stage_ms(reset=True)
+    inst_ms = ef.stage_ms(reset=True)["instance"]          # the instance stage is always timed (two events per segmentation call)
+    traj = ef.trajectory()                                  # poses up to the end of the timed region
     dt = ifd.max_over_ranks(dt, dist, device=f"cuda:{dev}")
+    # ms/frame split of the other stages: measured on the frames that follow, with the per-stage event records switched on
+    # (eight marker packets per frame: they would cost ~4 % of the frame rate inside the timed region)
+    n_split = 40
+    ef.set_option("stage_timing", 1)
+    kk = k0 + args.warmup + args.steps
+    for k in range(kk, kk + n_split):
+        step(k)
+    ef.sync()
+    stage = ef.stage_ms(reset=True)
+    ef.set_option("stage_timing", 0)
+    stage = {k_: v_ / n_split * args.steps for k_, v_ in stage.items()}     # scaled so that the common division below applies
+    stage["instance"] = inst_ms
     n_live, n_slots = ef.count, ef.slots
-    traj = ef.trajectory()
     # trajectory error vs the synthetic ground truth over the timed frames (diagnostic)
     gt = np.stack([st["poses"][(k0 + args.warmup + j) % L] for j in range(args.steps)])
     est = traj[-args.steps:]
@@ -150,7 +162,7 @@ def main():
     if rank == 0:
         ef.set_option("kernel_timing", 1)
         ef.kernel_ms("__reset__")
-        kk = k0 + args.warmup + args.steps
+        kk = k0 + args.warmup + args.steps + n_split
         for k in range(kk, kk + 20):
             step(k)
         ef.sync()

@@ -59,8 +59,8 @@ static void stage_flush(ifx* h)
 }
 struct StageTimer {
     ifx* h; int id; hipEvent_t a;
-    StageTimer(ifx* h_, int id_) : h(h_), id(id_) { a = ifx_event_get(h); hipEventRecord(a, h->cur); }
-    ~StageTimer() { hipEvent_t b = ifx_event_get(h); hipEventRecord(b, h->cur); h->stage_pending.push_back({id, {a, b}}); }
+    StageTimer(ifx* h_, int id_) : h(h_), id(id_), a(nullptr) { if (h->opt_stage_timing) { a = ifx_event_get(h); hipEventRecord(a, h->cur); } }
+    ~StageTimer() { if (a) { hipEvent_t b = ifx_event_get(h); hipEventRecord(b, h->cur); h->stage_pending.push_back({id, {a, b}}); } }
 };
 
 // ------------------------------------------------------------------ create / destroy
@@ -171,6 +171,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "kernel_timing") { hipStreamSynchronize(h->stream); ktime_flush(h); h->opt_kernel_timing = value; }
     else if (s == "reference_passes") h->opt_reference_passes = value;
     else if (s == "two_streams") h->opt_two_streams = value;
+    else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
     else { h->err = "unknown option " + s; return IFX_E_INVALID; }

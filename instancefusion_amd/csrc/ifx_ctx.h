@@ -99,6 +99,7 @@ struct ifx {
     FrameSlot slot[2];
     int cur_slot = 0;
     int opt_two_streams = 1;
+    int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     hipEvent_t ev_result = nullptr;     // recorded after k_frame_result

@@ -87,7 +87,6 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     size_t P = (size_t)h->P, C = (size_t)h->cap;
     if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream_b) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
     h->cur = h->stream;
-    if (hipEventCreateWithFlags(&h->ev_result, hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; delete h; return IFX_E_HIP; }
     ALLOC(h->d_state, sizeof(DevState));
     hipMemset(h->d_state, 0, sizeof(DevState));
     if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
@@ -157,7 +156,6 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_slic_free(h);
     ifx_knn_free(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
-    if (h->ev_result) hipEventDestroy(h->ev_result);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -277,8 +275,8 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     }
     int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
-    hipEventRecord(h->ev_result, h->stream);
-    hipEventRecord(f.released, h->stream);
+    hipEventRecord(f.released, h->stream);   // one marker: the side stream waits for it before it reuses the slot,
+    h->ev_result = f.released;               // the host before it reads the frame result
     {
         int r = ifx_enqueue_hinted_frame_side(h);   // not consumed by the tracker (first frame, external pose)
         if (r) return r;

@@ -213,22 +213,27 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     if (k >= P) return;
     unsigned long long key = keys[k];
     keys[k] = IFX_KEY_EMPTY;
+    // index_id == nullptr: the caller only needs the tap record (the index map of the clean pass): the winner's normal and
+    // colour are not fetched and the 68 B of attribute images are not written
     if (key == IFX_KEY_EMPTY) {
-        index_id[k] = 0;
-        vc[k] = make_float4(0, 0, 0, 0); ct[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0);
+        if (index_id) { index_id[k] = 0; vc[k] = make_float4(0, 0, 0, 0); ct[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); }
         if (tap) tap[k] = make_float4(0, 0, 0, 0);
         return;
     }
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
-    float4 p4 = pc[id], n4 = nr[id];
-    float2 c2 = col[id], t2 = tm[id];
+    float4 p4 = pc[id];
+    float2 t2 = tm[id];
     v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
-    v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
-    index_id[k] = id;
-    vc[k] = make_float4(p.x, p.y, p.z, p4.w);
-    ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y);
-    nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
+    if (index_id) {
+        float4 n4 = nr[id];
+        float2 c2 = col[id];
+        v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+        index_id[k] = id;
+        vc[k] = make_float4(p.x, p.y, p.z, p4.w);
+        ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y);
+        nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
+    }
     // 16-B record for the clean window taps: (x, y, z, initTime) with two flags in the (otherwise positive)
     // signs: z < 0 <=> updated this frame (colorTime.w == time), w > 0 <=> stable (vertConf.w > confThreshold)
     if (tap) tap[k] = (id > 0u && p.z > 0.f) ? make_float4(p.x, p.y, (t2.y == (float)time) ? -p.z : p.z, (p4.w > conf_thr) ? t2.x : -t2.x) : make_float4(0, 0, 0, 0);
@@ -1099,8 +1104,8 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time)
     // index map of the post-fuse state (EF/ElasticFusion.cpp:662) fused with the clean cull
     LAUNCH(h, "cull_clean", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_clean, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index,
            h->list_b, h->list_c);
-    LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr, time, h->cfg.confidence,
+    LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
            (float4*)h->index_tap);
     LAUNCH(h, "clean_list", dim3(1024), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_b, h->list_c);

@@ -216,22 +216,22 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     // index_id == nullptr: the caller only needs the tap record (the index map of the clean pass): the winner's normal and
     // colour are not fetched and the 68 B of attribute images are not written
     if (key == IFX_KEY_EMPTY) {
-        if (index_id) { index_id[k] = 0; vc[k] = make_float4(0, 0, 0, 0); ct[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); }
+        if (index_id) { index_id[k] = 0; vc[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); if (ct) ct[k] = make_float4(0, 0, 0, 0); }
         if (tap) tap[k] = make_float4(0, 0, 0, 0);
         return;
     }
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
     float4 p4 = pc[id];
-    float2 t2 = tm[id];
+    float2 t2 = make_float2(0.f, 0.f);
+    if (ct || tap) t2 = tm[id];
     v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
     if (index_id) {
         float4 n4 = nr[id];
-        float2 c2 = col[id];
         v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
         index_id[k] = id;
         vc[k] = make_float4(p.x, p.y, p.z, p4.w);
-        ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y);
+        if (ct) { float2 c2 = col[id]; ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y); }
         nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
     }
     // 16-B record for the clean window taps: (x, y, z, initTime) with two flags in the (otherwise positive)
@@ -239,12 +239,15 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     if (tap) tap[k] = (id > 0u && p.z > 0.f) ? make_float4(p.x, p.y, (t2.y == (float)time) ? -p.z : p.z, (p4.w > conf_thr) ? t2.x : -t2.x) : make_float4(0, 0, 0, 0);
 }
 
-static void index_pass(ifx* h, const float* d_pose_inv, int time)
+// for_association: the frame path, where k_associate is the only consumer (it reads ids, positions and normals): the colour /
+// time image is not produced and the winner's colour and times are not fetched
+static void index_pass(ifx* h, const float* d_pose_inv, int time, bool for_association = false)
 {
     Cam c = make_cam(h);
     LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
     LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)h->index_ct, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr);
+           (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, for_association ? (float4*)nullptr : (float4*)h->index_ct, (float4*)h->index_nr, time,
+           h->cfg.confidence, (float4*)nullptr);
 }
 
 // ------------------------------------------------------------------ disc rasteriser (a9, a14)
@@ -1120,7 +1123,7 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time)
 // EF/ElasticFusion.cpp:620-694 without the loop-closure branches
 int ifx_map_frame(ifx* h)
 {
-    index_pass(h, nullptr, h->tick);
+    index_pass(h, nullptr, h->tick, true);
     fuse_pass(h, nullptr, 0.f, h->tick);
     if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680); they need the post-fuse index map too
         index_pass(h, nullptr, h->tick);

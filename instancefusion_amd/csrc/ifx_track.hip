@@ -69,29 +69,6 @@ int ifx_preprocess(ifx* h)
 
 // ======================================================================= pyramid kernels (a3)
 
-// pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
-__global__ void k_pyrdown_u16(const uint16_t* __restrict__ src, int sw, int sh, uint16_t* __restrict__ dst)
-{
-    int dw = sw / 2, dh = sh / 2;
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    const int D = 5;
-    const float sigma_color = 30;
-    const float weights[3] = {0.375f, 0.25f, 0.0625f};
-    int center = src[(2 * y) * sw + 2 * x];
-    int x_mi = max(0, 2 * x - D / 2) - 2 * x, y_mi = max(0, 2 * y - D / 2) - 2 * y;
-    int x_ma = min(sw, 2 * x - D / 2 + D) - 2 * x, y_ma = min(sh, 2 * y - D / 2 + D) - 2 * y;
-    float sum = 0, wall = 0;
-    for (int yi = y_mi; yi < y_ma; ++yi)
-        for (int xi = x_mi; xi < x_ma; ++xi) {
-            int val = src[(2 * y + yi) * sw + 2 * x + xi];
-            if ((float)abs(val - center) < 3 * sigma_color) {
-                sum += val * weights[abs(xi)] * weights[abs(yi)];
-                wall += weights[abs(xi)] * weights[abs(yi)];
-            }
-        }
-    dst[y * dw + x] = (uint16_t)(int)(sum / wall);
-}
 
 // computeVmapKernel + computeNmapKernel fused (EF/Cuda/cudafuncs.cu:109-133,151-188): the three
 // vertices a normal needs are recomputed from the depth image instead of re-read from the vmap.
@@ -103,28 +80,6 @@ __device__ inline bool vert_from_depth(const uint16_t* depth, int w, int u, int 
         return true;
     }
     return false;
-}
-__global__ void k_vmap_nmap(const uint16_t* __restrict__ depth, int w, int h, float fx_inv, float fy_inv, float cx, float cy, float cutoff,
-                            float* __restrict__ vmap, float* __restrict__ nmap)
-{
-    int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
-    if (u >= w || v >= h) return;
-    const float qn = qnan_f();
-    v3 v00;
-    bool ok00 = vert_from_depth(depth, w, u, v, fx_inv, fy_inv, cx, cy, cutoff, v00);
-    vmap[v * w + u] = ok00 ? v00.x : qn;
-    vmap[(v + h) * w + u] = ok00 ? v00.y : qn;
-    vmap[(v + 2 * h) * w + u] = ok00 ? v00.z : qn;
-    v3 r = v3m(qn, qn, qn);
-    if (!(u == w - 1 || v == h - 1) && ok00) {
-        v3 v01, v10;
-        bool ok01 = vert_from_depth(depth, w, u + 1, v, fx_inv, fy_inv, cx, cy, cutoff, v01);
-        bool ok10 = vert_from_depth(depth, w, u, v + 1, fx_inv, fy_inv, cx, cy, cutoff, v10);
-        if (ok01 && ok10) r = normalized(cross(v01 - v00, v10 - v00));
-    }
-    nmap[v * w + u] = r.x;
-    nmap[(v + h) * w + u] = r.y;
-    nmap[(v + 2 * h) * w + u] = r.z;
 }
 
 // bgr2IntensityKernel, EF/Cuda/cudafuncs.cu:550-563 (weights applied to R,G,B order as the reference does)
@@ -162,29 +117,98 @@ __global__ void k_pyrdown_gauss_u8(const uint8_t* __restrict__ src, int sw, int 
     dst[y * dw + x] = count ? (uint8_t)f2i_rz(sum / (float)count) : (uint8_t)0;
 }
 
-// applyKernel, EF/Cuda/cudafuncs.cu:583-607
-__global__ void k_sobel(const uint8_t* __restrict__ img, int w, int h, int16_t* __restrict__ dx, int16_t* __restrict__ dy)
+
+
+
+
+
+
+// ---- frame side in 4 launches (was 12): intensity of level 0; one launch per coarser level for BOTH pyr-downs (depth: the
+// bilateral-like pyrDownGaussKernel, intensity: the 5x5 Gaussian); one launch for the vertex/normal maps and the Sobel
+// gradients of all three levels (each needs its level's complete depth / intensity image, nothing of another level).
+__global__ void k_frame_down(const uint16_t* __restrict__ dsrc, const uint8_t* __restrict__ isrc, int sw, int sh, uint16_t* __restrict__ ddst, uint8_t* __restrict__ idst)
 {
-    const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
-    const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    const int dw = sw / 2, dh = sh / 2;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    float dxVal = 0, dyVal = 0;
-    int k = 8;
-    for (int j = max(y - 1, 0); j <= min(y + 1, h - 1); j++)
-        for (int i = max(x - 1, 0); i <= min(x + 1, w - 1); i++) {
-            dxVal += (float)img[j * w + i] * gsx[k];
-            dyVal += (float)img[j * w + i] * gsy[k];
-            --k;
-        }
-    dx[y * w + x] = (int16_t)dxVal;
-    dy[y * w + x] = (int16_t)dyVal;
+    if (x >= dw || y >= dh) return;
+    const int D = 5;
+    {   // pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
+        const float sigma_color = 30;
+        const float weights[3] = {0.375f, 0.25f, 0.0625f};
+        int center = dsrc[(2 * y) * sw + 2 * x];
+        int x_mi = max(0, 2 * x - D / 2) - 2 * x, y_mi = max(0, 2 * y - D / 2) - 2 * y;
+        int x_ma = min(sw, 2 * x - D / 2 + D) - 2 * x, y_ma = min(sh, 2 * y - D / 2 + D) - 2 * y;
+        float sum = 0, wall = 0;
+        for (int yi = y_mi; yi < y_ma; ++yi)
+            for (int xi = x_mi; xi < x_ma; ++xi) {
+                int val = dsrc[(2 * y + yi) * sw + 2 * x + xi];
+                if ((float)abs(val - center) < 3 * sigma_color) {
+                    sum += val * weights[abs(xi)] * weights[abs(yi)];
+                    wall += weights[abs(xi)] * weights[abs(yi)];
+                }
+            }
+        ddst[y * dw + x] = (uint16_t)(int)(sum / wall);
+    }
+    {   // pyrDownKernelIntensityGauss, EF/Cuda/cudafuncs.cu:470-500
+        int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+        float sum = 0;
+        int count = 0;
+        for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+            for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+                int sv = isrc[cy * sw + cx];
+                if (sv > 0) {
+                    float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                    sum += sv * g;
+                    count += (int)g;
+                }
+            }
+        idst[y * dw + x] = count ? (uint8_t)f2i_rz(sum / (float)count) : (uint8_t)0;
+    }
 }
-
-
-
-
-
+struct FrameLevel { const uint16_t* depth; const uint8_t* img; float *vmap, *nmap; int16_t *dx, *dy; int w, h, tiles_x, first_block; float fx_inv, fy_inv, cx, cy; };
+struct FrameLevels { FrameLevel l[IFX_NUM_PYRS]; float cutoff; };
+__global__ void __launch_bounds__(256) k_frame_maps(FrameLevels a)
+{
+    int lv = 0;
+#pragma unroll
+    for (int q = 1; q < IFX_NUM_PYRS; q++) if ((int)blockIdx.x >= a.l[q].first_block) lv = q;
+    const FrameLevel L = a.l[lv];
+    const int b = blockIdx.x - L.first_block, u = (b % L.tiles_x) * 32 + (threadIdx.x & 31), v = (b / L.tiles_x) * 8 + (threadIdx.x >> 5);
+    const int w = L.w, h = L.h;
+    if (u >= w || v >= h) return;
+    {   // computeVmapKernel + computeNmapKernel (k_vmap_nmap)
+        const float qn = qnan_f();
+        v3 v00;
+        bool ok00 = vert_from_depth(L.depth, w, u, v, L.fx_inv, L.fy_inv, L.cx, L.cy, a.cutoff, v00);
+        L.vmap[v * w + u] = ok00 ? v00.x : qn;
+        L.vmap[(v + h) * w + u] = ok00 ? v00.y : qn;
+        L.vmap[(v + 2 * h) * w + u] = ok00 ? v00.z : qn;
+        v3 r = v3m(qn, qn, qn);
+        if (!(u == w - 1 || v == h - 1) && ok00) {
+            v3 v01, v10;
+            bool ok01 = vert_from_depth(L.depth, w, u + 1, v, L.fx_inv, L.fy_inv, L.cx, L.cy, a.cutoff, v01);
+            bool ok10 = vert_from_depth(L.depth, w, u, v + 1, L.fx_inv, L.fy_inv, L.cx, L.cy, a.cutoff, v10);
+            if (ok01 && ok10) r = normalized(cross(v01 - v00, v10 - v00));
+        }
+        L.nmap[v * w + u] = r.x;
+        L.nmap[(v + h) * w + u] = r.y;
+        L.nmap[(v + 2 * h) * w + u] = r.z;
+    }
+    {   // applyKernel (k_sobel)
+        const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+        const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+        float dxVal = 0, dyVal = 0;
+        int k = 8;
+        for (int j = max(v - 1, 0); j <= min(v + 1, h - 1); j++)
+            for (int i = max(u - 1, 0); i <= min(u + 1, w - 1); i++) {
+                dxVal += (float)L.img[j * w + i] * gsx[k];
+                dyVal += (float)L.img[j * w + i] * gsy[k];
+                --k;
+            }
+        L.dx[v * w + u] = (int16_t)dxVal;
+        L.dy[v * w + u] = (int16_t)dyVal;
+    }
+}
 
 // ---- model side in one launch per pyramid level.  Level 0: copyMaps + verticesToDepth + intensity (k_model_level0),
 // the global transform (k_transform_maps) and the point cloud of the photometric step (k_project_cloud) are all
@@ -1385,7 +1409,7 @@ void ifx_bind_slot(ifx* h, int s)
     h->cur_slot = s;
     h->rgb = f.rgb; h->depth_raw = f.depth_raw; h->depth_filt = f.depth_filt; h->dm = f.dm; h->dmf = f.dmf;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
-        p.depth_tmp[i] = f.depth_tmp[i]; p.vmap_curr[i] = f.vmap_curr[i]; p.nmap_curr[i] = f.nmap_curr[i];
+        p.depth_tmp[i] = (i == 0) ? f.depth_filt : f.depth_tmp[i]; p.vmap_curr[i] = f.vmap_curr[i]; p.nmap_curr[i] = f.nmap_curr[i];
         p.next_img[i] = f.next_img[i]; p.didx[i] = f.didx[i]; p.didy[i] = f.didy[i];
         p.lastnext_img[i] = h->slot[s ^ 1].next_img[i];
     }
@@ -1447,19 +1471,23 @@ static void tracker_init_model(ifx* h, const float* pv, const float* pn, const u
 static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t* rgb)
 {
     Pyr& p = h->pyr;
-    hipMemcpyAsync(p.depth_tmp[0], depth_filt, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur);
+    (void)depth_filt;   // level 0 of the depth pyramid IS the filtered depth (ifx_bind_slot aliases it; the reference copies it)
     LAUNCH(h, "intensity", dim3(cdiv(h->P, 256)), dim3(256), k_intensity, rgb, 3, h->P, p.next_img[0]);
-    for (int i = 1; i < IFX_NUM_PYRS; i++) {
-        LAUNCH(h, "pyrdown_u16", G2(p.w[i], p.h[i]), B2, k_pyrdown_u16, p.depth_tmp[i - 1], p.w[i - 1], p.h[i - 1], p.depth_tmp[i]);
-        LAUNCH(h, "pyrdown_u8", G2(p.w[i], p.h[i]), B2, k_pyrdown_gauss_u8, p.next_img[i - 1], p.w[i - 1], p.h[i - 1], p.next_img[i]);
-    }
+    for (int i = 1; i < IFX_NUM_PYRS; i++)
+        LAUNCH(h, "frame_down", G2(p.w[i], p.h[i]), B2, k_frame_down, p.depth_tmp[i - 1], p.next_img[i - 1], p.w[i - 1], p.h[i - 1], p.depth_tmp[i], p.next_img[i]);
+    FrameLevels fl;
+    int blocks = 0;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         float div = (float)(1 << i);
-        float fx = h->cfg.fx / div, fy = h->cfg.fy / div, cx = h->cfg.cx / div, cy = h->cfg.cy / div;
-        LAUNCH(h, "vmap_nmap", G2(p.w[i], p.h[i]), B2, k_vmap_nmap, p.depth_tmp[i], p.w[i], p.h[i], 1.f / fx, 1.f / fy, cx, cy, h->cfg.max_depth_processed,
-               p.vmap_curr[i], p.nmap_curr[i]);
-        LAUNCH(h, "sobel", G2(p.w[i], p.h[i]), B2, k_sobel, p.next_img[i], p.w[i], p.h[i], p.didx[i], p.didy[i]);
+        float fx = h->cfg.fx / div, fy = h->cfg.fy / div;
+        FrameLevel& L = fl.l[i];
+        L.depth = p.depth_tmp[i]; L.img = p.next_img[i]; L.vmap = p.vmap_curr[i]; L.nmap = p.nmap_curr[i]; L.dx = p.didx[i]; L.dy = p.didy[i];
+        L.w = p.w[i]; L.h = p.h[i]; L.tiles_x = cdiv(p.w[i], 32); L.first_block = blocks;
+        L.fx_inv = 1.f / fx; L.fy_inv = 1.f / fy; L.cx = h->cfg.cx / div; L.cy = h->cfg.cy / div;
+        blocks += L.tiles_x * cdiv(p.h[i], 8);
     }
+    fl.cutoff = h->cfg.max_depth_processed;
+    LAUNCH(h, "frame_maps", dim3(blocks), dim3(256), k_frame_maps, fl);
 }
 
 // getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603, enqueued without any readback

@@ -804,11 +804,21 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
                             const float4* __restrict__ index_nr, Cam c, int time, uint32_t* __restrict__ assoc, float4* __restrict__ mpc, float4* __restrict__ mnr,
                             float* __restrict__ mcol, uint32_t* __restrict__ upd_owner)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    // Only the pixels with i % 2 == j % 2 == time % 2 create measurements (data.vert:98): one thread per 2x2 block, so that
+    // every lane of a wave works; the thread also marks the three silent pixels of its block.
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+    const int par = time % 2, i = 2 * bx + par, j = 2 * by + par;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int ii = 2 * bx + a, jj = 2 * by + b;
+            if (ii < c.w && jj < c.h && !(ii == i && jj == j)) assoc[jj * c.w + ii] = ASSOC_NONE;
+        }
     if (i >= c.w || j >= c.h) return;
     int k = j * c.w + i;
     uint32_t res = ASSOC_NONE;
-    if (i % 2 == time % 2 && j % 2 == time % 2) {
+    {
         const float* pose = pose_ex ? pose_ex : st->pose;
         float weighting = pose_ex ? weighting_ex : st->weighting;
         float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
@@ -862,7 +872,7 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
                               const float* __restrict__ mcol, Cam c, int time, uint32_t* __restrict__ upd_owner, float4* __restrict__ pc, float4* __restrict__ nr,
                               float2* __restrict__ col, float2* __restrict__ tm)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int par = time % 2, i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + par, j = 2 * (blockIdx.y * blockDim.y + threadIdx.y) + par;   // the pixels that can hold an association
     if (i >= c.w || j >= c.h) return;
     int k = j * c.w + i;
     uint32_t id = assoc[k];
@@ -1094,7 +1104,7 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
 static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
 {
     Cam c = make_cam(h);
-    dim3 b(32, 8), g(cdiv(h->w, 32), cdiv(h->h, 8));
+    dim3 b(32, 8), g(cdiv(cdiv(h->w, 2), 32), cdiv(cdiv(h->h, 2), 8));   // one thread per 2x2 pixel block
     LAUNCH(h, "associate", g, b, k_associate, h->d_state, d_pose, weighting, h->dm, h->dmf, h->rgb, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_nr, c, time,
            h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner);
     LAUNCH(h, "fuse_update", g, b, k_fuse_update, h->d_state, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr, h->meas_col, c, time, h->upd_owner,

@@ -171,6 +171,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "two_streams") h->opt_two_streams = value;
     else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;
+    else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
     else { h->err = "unknown option " + s; return IFX_E_INVALID; }
     return IFX_OK;
@@ -306,6 +307,7 @@ extern "C" int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const ui
 {
     (void)timestamp;
     if (!h || !d_rgb || !d_depth) return IFX_E_INVALID;
+    ifx_housekeeping(h);   // before this frame's map passes; a tracker run that is already queued does not care about slot numbers
     return enqueue_frame(h, d_rgb, d_depth, 0, in_pose16, weight_mult);
 }
 
@@ -353,12 +355,25 @@ extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* d
     r = ifx_sync(h);
     if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
     if (r) return r;
-    // housekeeping the host decides from the frame result: compact when tombstones pile up
-    if (!h->opt_compact_every_frame && h->h_result->n_dead > 0 &&
-        (h->h_result->n_dead > h->h_result->count / 8 || h->h_result->count > h->cap - h->P)) {
-        ifx_compact_enqueue(h, 1);
-    }
+    ifx_housekeeping(h);
     return 0;
+}
+
+// Tombstones pile up: when the last frame result the host has seen says that more than 1/8 of the
+// slots are dead, or that the capacity gets tight, the map is compacted (order-preserving) and ids_after re-rendered.
+// The decision uses the pinned frame result as it is -- possibly a frame or two old on the asynchronous path: it is a
+// heuristic about WHEN, not about what; results do not depend on it (tests: test_full_size_properties, housekeeping mode
+// of test_lookahead_equivalence).
+int ifx_housekeeping(ifx* h)
+{
+    const FrameResult* r = h->h_result;
+    if (h->opt_compact_every_frame || h->tick <= 2 || r->n_dead <= 0) return IFX_OK;
+    if (r->n_dead > r->count / std::max(h->opt_compact_divisor, 1) || r->count > h->cap - h->P) {
+        if (h->last_compact_tick == h->tick) return IFX_OK;
+        h->last_compact_tick = h->tick;
+        return ifx_compact_enqueue(h, 1);
+    }
+    return IFX_OK;
 }
 
 extern "C" int ifx_set_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth)

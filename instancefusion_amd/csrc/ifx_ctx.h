@@ -110,6 +110,8 @@ struct ifx {
     int ids_pending = 0;
     // options
     int opt_compact_every_frame = 0;
+    int last_compact_tick = -1;
+    int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_blocks = 304;
@@ -218,6 +220,7 @@ int ifx_tracker_commit(ifx* h);                                // publish the po
 int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
 int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
 void ifx_bind_slot(ifx* h, int s);
+int ifx_housekeeping(ifx* h);                                  // tombstone compaction decided from the last frame result
 int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
-static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out)
+static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false)
 {
     Cam c = make_cam(h);
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
@@ -781,7 +781,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
                h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr);
     } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
     // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums
-    const int seg = (want & LIST_IDS) && ids_out == h->ids_after && d_pose_inv == nullptr;
+    const int seg = frame_sums && (want & LIST_IDS);   // only the frame's own render feeds whetherDoSegmentation (not the re-render after a compaction)
     const int ds = 10, nseg = seg ? cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256) : 0;
     LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, (want & LIST_SPLAT) ? 1 : 0, h->ids_after,
            (const float4*)h->votes, h->cap, ds);
@@ -1149,7 +1149,7 @@ int ifx_map_frame(ifx* h)
 // ElasticFusion::predict, EF/ElasticFusion.cpp:729-763, fused with renderSurfelIds(GENERAL_AFTER) of :694
 int ifx_map_predict(ifx* h)
 {
-    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u), h->ids_after);
+    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u), h->ids_after, true);
     h->ids_pending = 0;
     return IFX_OK;
 }

@@ -426,7 +426,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
 }
 
 // ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267 on the (w/20 x h/20) nearest resample
-// End of a raster pass in one launch: block 0 = the dense-enough test (k_dense) and the re-arm of the work list;
+// End of a raster pass in one launch: block 0 = the dense-enough test (EF/ElasticFusion.cpp:252-267) and the re-arm of the work list;
 // blocks 1.. = checkProjectDepthAndInstanceKernel (IF/Core/InstanceFusionCuda.cu:736-760) over the id image this pass
 // rendered, accumulated for k_frame_result, so that whetherDoSegmentation needs no launch of its own.
 __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, int w, int h, int do_dense, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap,
@@ -488,7 +488,7 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // work list (wave ballot -> one atomicAdd per wave), and (2) a dense pass over the list that reads
 // normal+radius and does the expensive part (disc rasterisation / window taps) with every lane
 // busy.  The one-kernel versions above ran at 0.6-1.1 TB/s because the heavy path diverged inside
-// waves of mostly-culled surfels (profiles/r01_a: k_raster 205 us, k_clean_old 206 us for 5.6M slots).
+// waves of mostly-culled surfels (profiles/r01_a: the one-kernel raster 205 us, the one-kernel clean 206 us for 5.6M slots).
 #define LIST_SPLAT 0x40000000u
 #define LIST_IDS 0x80000000u
 #define LIST_IDX 0x3FFFFFFFu

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) k_frame_maps(FrameLevels a)
     const int b = blockIdx.x - L.first_block, u = (b % L.tiles_x) * 32 + (threadIdx.x & 31), v = (b / L.tiles_x) * 8 + (threadIdx.x >> 5);
     const int w = L.w, h = L.h;
     if (u >= w || v >= h) return;
-    {   // computeVmapKernel + computeNmapKernel (k_vmap_nmap)
+    {   // computeVmapKernel + computeNmapKernel, EF/Cuda/cudafuncs.cu:109-133,151-188
         const float qn = qnan_f();
         v3 v00;
         bool ok00 = vert_from_depth(L.depth, w, u, v, L.fx_inv, L.fy_inv, L.cx, L.cy, a.cutoff, v00);
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_frame_maps(FrameLevels a)
         L.nmap[(v + h) * w + u] = r.y;
         L.nmap[(v + 2 * h) * w + u] = r.z;
     }
-    {   // applyKernel (k_sobel)
+    {   // applyKernel (Sobel), EF/Cuda/cudafuncs.cu:583-607
         const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
         const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
         float dxVal = 0, dyVal = 0;
@@ -210,8 +210,8 @@ __global__ void __launch_bounds__(256) k_frame_maps(FrameLevels a)
     }
 }
 
-// ---- model side in one launch per pyramid level.  Level 0: copyMaps + verticesToDepth + intensity (k_model_level0),
-// the global transform (k_transform_maps) and the point cloud of the photometric step (k_project_cloud) are all
+// ---- model side in one launch per pyramid level.  Level 0: copyMaps (EF/Cuda/cudafuncs.cu:270-310) + verticesToDepth (:526-537) + intensity,
+// the global transform (tranformMaps :206-248) and the point cloud of the photometric step (projectPoints :641-659) are all
 // per-pixel, so they chain through registers.  Level i > 0: the 2x2 resize of both maps, the two 5x5 Gaussian
 // pyr-downs (depth, intensity), then transform + cloud of the SAME output pixel.  16 launches -> 3; a dependent
 // launch costs ~4.7 us on this GPU whatever its size.

@@ -1186,7 +1186,11 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
     st->lastRGBCount = (float)rgbSize;
     if (icp) { st->lastICPError = sqrtf(oi[27]) / oi[28]; st->lastICPCount = oi[28]; }
     double result[6];
-    ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
+    // With the ICP term the system is well conditioned and the unpivoted factorisation agrees with Eigen's pivoted LDLT to
+    // ~1e-7 in the pose; the photometric term alone can be close to singular along unobservable directions, where the
+    // pivoting decides the answer: that configuration takes the pivoted path the reference takes (EF/Utils/RGBDOdometry.cpp:552).
+    if (icp) ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
+    else ldlt_solve_n<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
     // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
     double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9];
     rodrigues_d(&result[3], Rr);

@@ -650,3 +650,68 @@ def test_many_masks_overseg_filter(ifx, orc, gputest_pair):
     assert np.array_equal(inst.maskSuperPixelFilter_OverSeg(fin, masks), o.mask_superpixel_filter(fin, masks))
     assert np.array_equal(inst.maskCleanOverlap(masks), _clean(orc, masks))
     g.close(); o.close()
+
+
+# ---------------------------------------------------------------- a23: instance table eviction (96 slots full -> the 20 weakest instances are dropped)
+def test_instance_table_eviction_exact(ifx, orc, small_stream):
+    from instancefusion_amd import synth
+
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    inst = ifx.InstanceFusion(g)
+    for i in range(6):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        g.processFrame(st["rgb"][i], st["depth"][i])
+    m = o.download(); m["pc"][:, 3] = 20.0
+    o.upload(m); g.upload(m)
+    o.set_pose(po, o.tick); g.set_pose(po, o.tick)
+    g.processFrame(st["rgb"][5], st["depth"][5], inPose=po); o.process_frame(st["rgb"][5], st["depth"][5], in_pose=po)
+    assert np.array_equal(g.image("ids_after"), o.image("ids_after"))
+    masks, cls = synth.canned_masks(st["obj"][5], st["scene"])
+    nm = masks.shape[0]
+    assert nm >= 4
+    evicted = False
+    for call in range(30):
+        classes = (1 + (call * nm + np.arange(nm)) % 79).astype(np.int32)      # a new class for every mask of every call: nothing matches
+        inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], masks, classes, 100 + 3 * call)
+        o.process_segmentation(st["rgb"][5], st["depth"][5], masks, classes, 100 + 3 * call)
+        tg, to = inst.getInstanceTable(), o.instance_table()
+        assert np.array_equal(tg, to), call
+        if (to >= 0).sum() < 96 and call * nm > 96:
+            evicted = True
+        assert np.array_equal(g.download()["votes"], o.download()["votes"]), call
+        assert np.array_equal(inst.labels(), o.labels()), call
+    assert evicted
+    lc = inst.getLoopClosureInstanceTable()
+    assert lc.shape == (96, 5) and np.array_equal(lc[:, 3] >= 0, to >= 0)
+    g.close(); o.close()
+
+
+def test_knn_vote_with_tombstones(ifx, orc, small_stream):
+    """The smoothing on a map with dead slots (no compaction) equals the oracle's on the compacted map."""
+    from instancefusion_amd import synth
+
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    inst = ifx.InstanceFusion(g)
+    for i in range(6):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        g.processFrame(st["rgb"][i], st["depth"][i])
+    m = o.download()
+    o.upload(m); g.upload(m)                       # identical maps; from here on the pose is held, so both sides stay identical
+    o.set_pose(po, o.tick); g.set_pose(po, o.tick)
+    for i in (6, 7):
+        g.processFrame(st["rgb"][i], st["depth"][i], inPose=po); o.process_frame(st["rgb"][i], st["depth"][i], in_pose=po)
+    assert g.slots > g.count                       # tombstones present on the device (young unstable surfels died)
+    assert g.count == o.count
+    masks, cls = synth.canned_masks(st["obj"][7], st["scene"])
+    inst.ProcessSegmentation(st["rgb"][7], st["depth"][7], masks, cls, 50, isflann=True)
+    o.process_segmentation(st["rgb"][7], st["depth"][7], masks, cls, 50, flags=1)
+    assert np.array_equal(inst.labels(), o.labels())
+    mg, mo = g.download(), o.download()
+    assert all(np.array_equal(mg[k], mo[k]) for k in MAP_KEYS)
+    g.close(); o.close()

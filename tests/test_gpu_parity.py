@@ -715,3 +715,48 @@ def test_knn_vote_with_tombstones(ifx, orc, small_stream):
     mg, mo = g.download(), o.download()
     assert all(np.array_equal(mg[k], mo[k]) for k in MAP_KEYS)
     g.close(); o.close()
+
+
+# ---------------------------------------------------------------- 8f-1: log replay end to end (tools/run_log.py)
+def test_run_log_replay(ifx, small_stream, tmp_path):
+    import importlib.util
+    import os
+
+    from instancefusion_amd import logio, synth
+
+    st = small_stream
+    n = 8
+    klg = str(tmp_path / "s.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg", jpeg_quality=100)
+    for i in range(n + 1):                                   # the reader never delivers the last frame
+        wr.add(33333 * i, st["rgb"][min(i, n - 1)], st["depth"][min(i, n - 1)])
+    wr.close()
+    mdir = tmp_path / "masks"
+    mdir.mkdir()
+    for i in range(n):
+        mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+        np.savez(mdir / f"{i:06d}.npz", masks=mk, class_ids=cl)
+    spec = importlib.util.spec_from_file_location("run_log", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "run_log.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "Result")
+    rc = mod.main([klg, "--width", str(SMALL["w"]), "--height", str(SMALL["h"]), "--fx", str(SMALL["fx"]), "--fy", str(SMALL["fy"]), "--cx", str(SMALL["cx"]),
+                   "--cy", str(SMALL["cy"]), "--max-surfels", "400000", "--masks", str(mdir), "--out", out, "--flann-every", "2"])
+    assert rc == 0
+    traj = np.loadtxt(out + ".freiburg")
+    assert traj.shape == (n, 8) and np.allclose(traj[:, 0], 0.033333 * np.arange(n), atol=1e-6)
+    # same poses as feeding the decoded frames directly
+    rd = logio.RawLogReader(klg, SMALL["w"], SMALL["h"])
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    k = 0
+    while rd.hasMore():
+        rd.getNext()
+        p = g.processFrame(rd.rgb, rd.depth)
+        assert np.allclose(traj[k, 1:4], p[:3, 3], atol=2e-6), k
+        k += 1
+    g.close()
+    for suffix in (".ply", "_Instance.ply"):
+        raw = open(out + suffix, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        nv = int(head.split(b"element vertex ")[1].split(b"\n")[0])
+        assert len(body) == nv * 31

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--loop", type=int, default=90, help="length of the closed camera loop (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--res", default="640x480", help="WxH of the synthetic stream (other BASELINE configurations; the metric is quoted at 640x480)")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -78,8 +79,8 @@ def main():
     import instancefusion_amd as ifx
     from instancefusion_amd import synth
 
-    W, H = 640, 480
-    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    W, H = (int(v) for v in args.res.lower().split("x"))
+    K = dict(fx=528.0 * W / 640, fy=528.0 * W / 640, cx=W / 2.0, cy=H / 2.0)
     P = W * H
     L = args.loop
     t_gen = time.time()
@@ -216,7 +217,7 @@ def main():
             o.process_frame(st["rgb"][k % L], st["depth"][k % L])
         tc = time.perf_counter() - tc
         cpu = dict(value=round(args.cpu_frames / tc, 4), unit="frames/s", cores=1, kind="port",
-                   sample=f"{args.cpu_frames} frames of the same 640x480 stream into the same {n_cpu}-surfel synthetic map (no instance calls)")
+                   sample=f"{args.cpu_frames} frames of the same {W}x{H} stream into the same {n_cpu}-surfel synthetic map (no instance calls)")
         o.close()
 
     if rank == 0:
@@ -226,7 +227,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"640x480 synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}, {args.surfels}-surfel map",
+            "config": {"workload": f"{W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}, {args.surfels}-surfel map",
                        "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": f"replicas x{world}", "loop_frames": L},
             "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
             "ate_rms_m": ate, "gen_s": round(t_gen, 1),

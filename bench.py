@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--res", default="640x480", help="WxH of the synthetic stream (other BASELINE configurations; the metric is quoted at 640x480)")
+    ap.add_argument("--sharded", action="store_true", help="one stream, every rank holds the map, projection passes sliced across ranks + RCCL all-reduce(MIN) of the key images "
+                    "(instancefusion_amd/sharded.py; strong scaling; pays for tens of millions of surfels -- DESIGN.md section 7).  Default for --gpus N: one replica per rank")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -84,10 +86,11 @@ def main():
     P = W * H
     L = args.loop
     t_gen = time.time()
-    st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + rank, **K)
+    srank = 0 if args.sharded else rank          # sharded: every rank is fed the same stream and map
+    st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + srank, **K)
     masks = [synth.canned_masks(st["obj"][i], st["scene"]) for i in range(L)]
     tick0 = 1000
-    m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + rank)
+    m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + srank)
     t_gen = time.time() - t_gen
 
     cap = args.surfels + 2_500_000
@@ -109,9 +112,22 @@ def main():
     del m
 
     frame_no = [0]
+    sh = None
+    if args.sharded:
+        from instancefusion_amd import sharded as ifsh
+
+        sh = ifsh.ShardedElasticFusion(ef, rank, world, dist)
 
     def step(k):
         i = k % L
+        if sh is not None:
+            sh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+            frame_no[0] += 1
+            if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
+                mk, cl = masks[i]
+                if mk.shape[0]:
+                    inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0], superpixels=not args.no_superpixels)
+            return
         if not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame's tracking
             ef.hint_next_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
@@ -221,14 +237,14 @@ def main():
         o.close()
 
     if rank == 0:
-        fps = world * args.steps / dt
+        fps = (1 if args.sharded else world) * args.steps / dt
         out = {
             "metric": "frames/s + ms/frame (ICP|fuse|instance) at 640x480, 5M surfels, 1/2/4/8 GPU",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}, {args.surfels}-surfel map",
-                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": f"replicas x{world}", "loop_frames": L},
+                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"sharded projection x{world}" if args.sharded else f"replicas x{world}"), "loop_frames": L},
             "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
             "ate_rms_m": ate, "gen_s": round(t_gen, 1),
             "roofline": roof, "cpu_baseline": cpu,

@@ -84,6 +84,15 @@ int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_
  * call places the announced frame's image-only work itself (behind the coarse pyramid levels of its own
  * tracker, where the GPU is least busy).  Preferred over ifx_prefetch_frame_device. */
 int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next);
+/* ---- sharded projection for large maps.  Every rank (one process per GPU) holds the full map replica and is
+ * fed the same frames and masks; the passes that stream the whole surfel store with one atomic per visible surfel (index map
+ * x2, splat + id raster) only handle this rank's slice of the slots, and the ranks combine their key images between the four
+ * phases of a frame by an element-wise UNSIGNED 64-bit minimum (RCCL all-reduce over xGMI; instancefusion_amd/sharded.py does
+ * it through torch.distributed).  Exchange after phase 0 and after phase 1: key_index; after phase 2: key_splat, key_ids,
+ * key_both; phase 3 needs none.  The replicas stay bit-identical, and identical to a single-GPU run. */
+int ifx_set_shard(ifx_t* h, int rank, int nranks);
+int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);   /* pointers used by phase 0 */
+int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids, void** key_both, int64_t* n_pixels);
 int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);

@@ -66,6 +66,9 @@ _SIGS = {
     "ifx_global_error": (C.c_char_p, []),
     "ifx_process_frame": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, _P]),
     "ifx_enqueue_frame_device": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float]),
+    "ifx_set_shard": (C.c_int, [_P, C.c_int, C.c_int]),
+    "ifx_sharded_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
+    "ifx_key_images": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_sync": (C.c_int, [_P]),

@@ -303,6 +303,60 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     return IFX_OK;
 }
 
+// ---- sharded projection (ifx_map_sharded_phase): one frame in four phases, the caller exchanging the key
+// images (element-wise unsigned min across ranks) between them.  Every rank is fed the same frames and masks.
+extern "C" int ifx_set_shard(ifx_t* h, int rank, int nranks)
+{
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks) return IFX_E_INVALID;
+    h->shard_rank = rank; h->shard_n = nranks;
+    h->tracked_ahead = 0; h->hint_rgb = nullptr;
+    return IFX_OK;
+}
+
+extern "C" int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids, void** key_both, int64_t* n_pixels)
+{
+    if (!h) return IFX_E_INVALID;
+    if (key_index) *key_index = h->key_index;
+    if (key_splat) *key_splat = h->key_splat;
+    if (key_ids) *key_ids = h->key_ids;
+    if (key_both) *key_both = h->key_both;
+    if (n_pixels) *n_pixels = h->P;
+    return IFX_OK;
+}
+
+extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
+{
+    if (!h || phase < 0 || phase > 3) return IFX_E_INVALID;
+    const bool first = h->tick == 1;
+    const int s = h->tick & 1;
+    FrameSlot& f = h->slot[s];
+    if (phase == 0) {
+        if (!d_rgb || !d_depth) return IFX_E_INVALID;
+        h->tracked_ahead = 0;
+        ifx_housekeeping(h);                       // identical decision on every rank: the frame results are identical
+        const int two = h->opt_two_streams;
+        h->opt_two_streams = 0;                     // the frame side runs inline on the main stream in this mode
+        int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, 0);
+        h->opt_two_streams = two;
+        if (r) return r;
+        f.for_tick = -1;
+        ifx_bind_slot(h, s);
+        if (!first) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
+    }
+    int r = ifx_map_sharded_phase(h, phase, first);
+    if (r) return r;
+    if (phase == 3) {
+        int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
+        LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+        hipEventRecord(f.released, h->stream);
+        h->ev_result = f.released;
+        h->seg_counts_valid = 1;
+        h->n_traj++;
+        h->tick++;
+    }
+    return IFX_OK;
+}
+
 extern "C" int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth, int64_t timestamp, const float* in_pose16, float weight_mult)
 {
     (void)timestamp;

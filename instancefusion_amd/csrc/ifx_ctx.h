@@ -98,6 +98,7 @@ struct ifx {
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
     FrameSlot slot[2];
     int cur_slot = 0;
+    int shard_rank = 0, shard_n = 1;    // sharded projection: this rank's slice of the slots (ifx_set_shard)
     int opt_two_streams = 1;
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
@@ -224,6 +225,7 @@ int ifx_housekeeping(ifx* h);                                  // tombstone comp
 int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
+int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame);
 int ifx_map_predict(ifx* h);                                  // splat + fill-in + dense flag
 int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total /*device ptr or null*/);
 int ifx_alloc_tracker(ifx* h);

@@ -58,12 +58,13 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
     return normalized(cross(del_x, del_y));
 }
 
-struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; };
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; };   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode)
 static Cam make_cam(ifx* h)
 {
     Cam c;
     c.fx = h->cfg.fx; c.fy = h->cfg.fy; c.cx = h->cfg.cx; c.cy = h->cfg.cy; c.w = h->w; c.h = h->h;
     c.maxDepth = h->cfg.max_depth_processed; c.conf = h->cfg.confidence; c.timeDelta = h->cfg.time_delta;
+    c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     return c;
 }
 
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
     const int n = st->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const int lo = (int)((long long)n * c.srank / c.sn), hi = (int)((long long)n * (c.srank + 1) / c.sn);   // this rank's slice (all slots when not sharded)
+    for (int i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += blockDim.x * gridDim.x) {
         float lastT = tm[i].y;
         if ((float)time - lastT > (float)c.timeDelta) continue;   // inactive (or tombstone): 8 B, position not loaded
         float4 p4 = pc[i];
@@ -241,11 +243,12 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
 
 // for_association: the frame path, where k_associate is the only consumer (it reads ids, positions and normals): the colour /
 // time image is not produced and the winner's colour and times are not fetched
-static void index_pass(ifx* h, const float* d_pose_inv, int time, bool for_association = false)
+static void index_pass(ifx* h, const float* d_pose_inv, int time, bool for_association = false, int part = 0)
 {
     Cam c = make_cam(h);
-    LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
-    LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+    if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
+    if (part != 2) LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
+    if (part != 1) LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, for_association ? (float4*)nullptr : (float4*)h->index_ct, (float4*)h->index_nr, time,
            h->cfg.confidence, (float4*)nullptr);
 }
@@ -564,14 +567,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
     if (threadIdx.x == 0) L.n = 0;
     __syncthreads();
     const int n = st->count;
+    const int lo = (int)((long long)n * c.srank / c.sn), hi = (int)((long long)n * (c.srank + 1) / c.sn);   // this rank's slice (all slots when not sharded)
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
-    for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
+    for (int chunk = lo / CHUNK_SLOTS + blockIdx.x; chunk * CHUNK_SLOTS < hi; chunk += gridDim.x) {
         unsigned int val[CHUNK_ROUNDS], pos[CHUNK_ROUNDS];
 #pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++) {
             int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
             unsigned int flags = 0;
-            if (i < n) {
+            if (i >= lo && i < hi) {
                 float4 p4 = pc[i];
                 float lastT = tm[i].y;
                 // cheapest tests first: unstable surfels are on neither list, nor is anything behind the camera
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
     if (threadIdx.x == 0) { L2.n[0] = 0; L2.n[1] = 0; }
     __syncthreads();
     const int n = st->count;
+    const int lo = (int)((long long)n * c.srank / c.sn), hi = (int)((long long)n * (c.srank + 1) / c.sn);   // slice for the index projection only: the lists cover every slot
     for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
         unsigned int pos[CHUNK_ROUNDS];
         unsigned int cmask = 0, kmask = 0;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                         v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
                         if (p.z > 0.f) {
                             float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
-                            if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h))
+                            if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) && i >= lo && i < hi)
                                 key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, (unsigned int)i));
                             cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
                         }
@@ -767,13 +772,17 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
-static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false)
+static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0)
 {
     Cam c = make_cam(h);
-    LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
-           h->list_a);
-    LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
-           h->key_ids, h->key_both);
+    if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
+    if (part != 2) {
+        LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
+               h->list_a);
+        LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+               h->key_ids, h->key_both);
+    }
+    if (part == 1) return;
     if (want & LIST_SPLAT) {
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
@@ -1111,12 +1120,14 @@ static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
            (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm);
 }
 
-static void clean_pass(ifx* h, const float* d_pose_inv, int time)
+static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 {
     Cam c = make_cam(h);
+    if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
     // index map of the post-fuse state (EF/ElasticFusion.cpp:662) fused with the clean cull
-    LAUNCH(h, "cull_clean", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_clean, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index,
+    if (part != 2) LAUNCH(h, "cull_clean", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_clean, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index,
            h->list_b, h->list_c);
+    if (part == 1) return;
     LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
            (float4*)h->index_tap);
@@ -1151,6 +1162,35 @@ int ifx_map_predict(ifx* h)
 {
     raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u), h->ids_after, true);
     h->ids_pending = 0;
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ sharded projection
+// Every rank keeps the full map replica and runs the whole frame deterministically, so the replicas stay bit-identical;
+// only the projection passes (index map x2, splat + id raster) -- the passes that stream the whole surfel store with one
+// atomic per visible surfel / covered pixel -- are cut by slot range (Cam::srank / sn), and the ranks exchange their key
+// images by an element-wise unsigned minimum between the phases (min over disjoint slices == global min, ties included,
+// because the key carries the slot id).  The exchange itself is the caller's: a RCCL all-reduce(MIN) over xGMI through
+// torch.distributed in instancefusion_amd/sharded.py.
+//   phase 0: index projection of the slice                         | exchange key_index
+//   phase 1: resolve, association, fusion, clean cull + projection | exchange key_index
+//   phase 2: tap resolve, clean, append, raster cull + raster      | exchange key_splat, key_ids, key_both
+//   phase 3: splat / id resolve, finish
+int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame)
+{
+    if (first_frame) {   // no map yet: the first-frame initialisation is replicated; only the prediction raster is sliced
+        if (phase == 0) return ifx_map_init_first(h);
+        if (phase == 2) raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, h->ids_after, true, 1);   // as ifx_map_predict on the first frame: no id render yet
+        if (phase == 3) raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, h->ids_after, true, 2);
+        return IFX_OK;
+    }
+    switch (phase) {
+    case 0: index_pass(h, nullptr, h->tick, true, 1); break;
+    case 1: index_pass(h, nullptr, h->tick, true, 2); fuse_pass(h, nullptr, 0.f, h->tick); clean_pass(h, nullptr, h->tick, 1); break;
+    case 2: clean_pass(h, nullptr, h->tick, 2); raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | LIST_IDS, h->ids_after, true, 1); break;
+    case 3: raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | LIST_IDS, h->ids_after, true, 2); break;
+    default: return IFX_E_INVALID;
+    }
     return IFX_OK;
 }
 

@@ -1,0 +1,95 @@
+"""Sharded projection across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank holds the full surfel map and is
+fed the same frames and masks, so the replicas stay bit-identical; the passes that stream the whole store with one
+atomic per visible surfel -- the two index maps and the splat + id raster -- only handle this rank's slice of the slots
+(`ifx_set_shard`), and between the four phases of a frame (`ifx_sharded_frame_phase`) the ranks combine their 64-bit key
+images by an all-reduce(MIN).  min over disjoint slices == the global min (the key carries the slot id, so ties too),
+hence the result equals the single-GPU run bit for bit (tests/test_gpu_parity.py::test_sharded_projection_emulated).
+
+It pays for maps whose streaming passes dominate the frame (tens of millions of surfels); at the
+BASELINE size of 5 M surfels replicas (bench.py's default for --gpus N) are faster.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+_SIGN = -(1 << 63)   # x ^ SIGN maps the unsigned order of the keys onto the signed order torch / RCCL reduce in
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface, also honoured on ROCm)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 3}
+
+
+class KeyExchange:
+    """The four key images of a handle as int64 torch tensors + the reduction across ranks."""
+
+    def __init__(self, ef):
+        import torch
+
+        ptrs = [C.c_void_p() for _ in range(4)]
+        n = C.c_int64()
+        ef._chk(ef.L.ifx_key_images(ef.handle, *[C.byref(p) for p in ptrs], C.byref(n)), "ifx_key_images")
+        self.t = [torch.as_tensor(_DevArray(p.value, n.value), device=f"cuda:{ef.cfgd['device']}") for p in ptrs]   # index, splat, ids, both
+
+    def tensors(self, phase: int):
+        return [self.t[0]] if phase in (0, 1) else self.t[1:]
+
+    @staticmethod
+    def reduce_min(tensors, dist):
+        """Element-wise UNSIGNED minimum across the ranks of `dist`, in place."""
+        for t in tensors:
+            t.bitwise_xor_(_SIGN)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            t.bitwise_xor_(_SIGN)
+
+
+class ShardedElasticFusion:
+    """ElasticFusion.processFrame over `world` ranks.  `dist` is torch.distributed (initialised, backend nccl) or None for
+    a single rank; `ef` an instancefusion_amd.ElasticFusion created on this rank's device."""
+
+    def __init__(self, ef, rank: int, world: int, dist=None):
+        import torch
+
+        self.ef, self.rank, self.world, self.dist, self.torch = ef, rank, world, dist, torch
+        ef._chk(ef.L.ifx_set_shard(ef.handle, rank, world), "ifx_set_shard")
+        self.keys = KeyExchange(ef)
+
+    def process_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
+        """One frame (device pointers, same content on every rank); returns nothing -- poses via ef.trajectory() / getCurrPose."""
+        ef = self.ef
+        for phase in range(4):
+            ef._chk(ef.L.ifx_sharded_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_sharded_frame_phase")
+            if phase < 3 and self.world > 1:
+                ef.sync()                                  # the library's streams -> host
+                KeyExchange.reduce_min(self.keys.tensors(phase), self.dist)
+                self.torch.cuda.synchronize()              # torch's streams -> host, before the next phase reads the images
+
+
+def emulate_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int, exchanges=None):
+    """Test helper: `efs` are handles of ONE process (same GPU) configured as ranks 0..G-1 of G; the all-reduce is replaced by
+    an element-wise minimum over their key images.  Exercises everything of the sharded mode except RCCL itself."""
+    import torch
+
+    xs = exchanges or [KeyExchange(e) for e in efs]
+    for phase in range(4):
+        for e in efs:
+            e._chk(e.L.ifx_sharded_frame_phase(e.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_sharded_frame_phase")
+        if phase < 3:
+            for e in efs:
+                e.sync()
+            per_rank = [x.tensors(phase) for x in xs]
+            for imgs in zip(*per_rank):
+                m = imgs[0] ^ _SIGN
+                for t in imgs[1:]:
+                    m = torch.minimum(m, t ^ _SIGN)
+                m ^= _SIGN
+                for t in imgs:
+                    t.copy_(m)
+            torch.cuda.synchronize()
+    return xs

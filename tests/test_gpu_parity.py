@@ -760,3 +760,70 @@ def test_run_log_replay(ifx, small_stream, tmp_path):
         head, body = raw.split(b"end_header\n", 1)
         nv = int(head.split(b"element vertex ")[1].split(b"\n")[0])
         assert len(body) == nv * 31
+
+
+# ---------------------------------------------------------------- 8e: sharded projection, emulated on one GPU
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_projection_emulated(ifx, small_stream, world):
+    """G handles of one process act as ranks 0..G-1 (each projects only its slice of the slots); the all-reduce(MIN) of the
+    key images is replaced by an element-wise minimum.  Every replica must equal the single-handle run bit for bit."""
+    import torch
+
+    from instancefusion_amd import sharded, synth
+
+    st = small_stream
+    n = 7
+    d_rgb = torch.from_numpy(st["rgb"][:n].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:n].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    ref = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    ref.set_option("two_streams", 0)
+    rinst = ifx.InstanceFusion(ref)
+    efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000) for _ in range(world)]
+    insts = [ifx.InstanceFusion(e) for e in efs]
+    for r, e in enumerate(efs):
+        e._chk(e.L.ifx_set_shard(e.handle, r, world), "ifx_set_shard")
+    xs = None
+    for i in range(n):
+        ref.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        xs = sharded.emulate_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr(), xs)
+        seg = rinst.whetherDoSegmentation(10 + i)
+        assert all(x.whetherDoSegmentation(10 + i) == seg for x in insts), i
+        if i == 4:   # the instance layer runs replicated on identical inputs
+            mk, cl = synth.canned_masks(st["obj"][4], st["scene"])
+            for x in [rinst] + insts:
+                x.ProcessSegmentation(st["rgb"][4], st["depth"][4], mk, cl, 14, superpixels=True)
+    ref.sync()
+    t0, m0, i0, l0 = ref.trajectory(), ref.download(), ref.image("ids_after"), rinst.labels()
+    for r, (e, x) in enumerate(zip(efs, insts)):
+        e.sync()
+        assert np.array_equal(e.trajectory(), t0), r
+        assert np.array_equal(e.image("ids_after"), i0), r
+        m = e.download()
+        assert all(np.array_equal(m[k], m0[k]) for k in MAP_KEYS), r
+        assert np.array_equal(x.labels(), l0), r
+        e.close()
+    ref.close()
+
+
+def test_sharded_world_of_one(ifx, small_stream):
+    """ShardedElasticFusion with a single rank (no process group): the phase API alone equals the normal entry point."""
+    import torch
+
+    from instancefusion_amd import sharded
+
+    st = small_stream
+    d_rgb = torch.from_numpy(st["rgb"][:5].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:5].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    a = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    b = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    sb = sharded.ShardedElasticFusion(b, 0, 1, None)
+    for i in range(5):
+        a.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        sb.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+    a.sync(); b.sync()
+    assert np.array_equal(a.trajectory(), b.trajectory())
+    ma, mb = a.download(), b.download()
+    assert all(np.array_equal(ma[k], mb[k]) for k in MAP_KEYS)
+    a.close(); b.close()

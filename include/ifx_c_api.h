@@ -93,6 +93,9 @@ int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16
 int ifx_set_shard(ifx_t* h, int rank, int nranks);
 int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);   /* pointers used by phase 0 */
 int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids, void** key_both, int64_t* n_pixels);
+/* The handle's HIP streams (hipStream_t): work enqueued on the main stream between two phases (the key exchange) is
+ * ordered with the phases without any host synchronisation. */
+int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
 int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);

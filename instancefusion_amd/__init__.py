@@ -69,6 +69,7 @@ _SIGS = {
     "ifx_set_shard": (C.c_int, [_P, C.c_int, C.c_int]),
     "ifx_sharded_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
     "ifx_key_images": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ifx_stream_handles": (C.c_int, [_P, _P, _P]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_sync": (C.c_int, [_P]),

@@ -324,6 +324,16 @@ extern "C" int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void
     return IFX_OK;
 }
 
+// the handle's HIP streams (hipStream_t as void*), so that a host can order its own work -- e.g. the RCCL exchange of the
+// sharded mode -- on them instead of synchronising
+extern "C" int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream)
+{
+    if (!h) return IFX_E_INVALID;
+    if (main_stream) *main_stream = (void*)h->stream;
+    if (side_stream) *side_stream = (void*)h->stream_b;
+    return IFX_OK;
+}
+
 extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
 {
     if (!h || phase < 0 || phase > 3) return IFX_E_INVALID;

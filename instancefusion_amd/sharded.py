@@ -59,16 +59,20 @@ class ShardedElasticFusion:
         self.ef, self.rank, self.world, self.dist, self.torch = ef, rank, world, dist, torch
         ef._chk(ef.L.ifx_set_shard(ef.handle, rank, world), "ifx_set_shard")
         self.keys = KeyExchange(ef)
+        main = C.c_void_p()
+        ef._chk(ef.L.ifx_stream_handles(ef.handle, C.byref(main), None), "ifx_stream_handles")
+        # the exchange is enqueued on the handle's own main stream (torch orders its RCCL stream against the current stream
+        # with events), so a frame needs no host synchronisation between its phases
+        self.stream = torch.cuda.ExternalStream(main.value, device=f"cuda:{ef.cfgd['device']}")
 
     def process_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         """One frame (device pointers, same content on every rank); returns nothing -- poses via ef.trajectory() / getCurrPose."""
         ef = self.ef
         for phase in range(4):
             ef._chk(ef.L.ifx_sharded_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_sharded_frame_phase")
-            if phase < 3 and self.world > 1:
-                ef.sync()                                  # the library's streams -> host
-                KeyExchange.reduce_min(self.keys.tensors(phase), self.dist)
-                self.torch.cuda.synchronize()              # torch's streams -> host, before the next phase reads the images
+            if phase < 3 and self.dist is not None:
+                with self.torch.cuda.stream(self.stream):
+                    KeyExchange.reduce_min(self.keys.tensors(phase), self.dist)
 
 
 def emulate_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int, exchanges=None):

@@ -827,3 +827,38 @@ def test_sharded_world_of_one(ifx, small_stream):
     ma, mb = a.download(), b.download()
     assert all(np.array_equal(ma[k], mb[k]) for k in MAP_KEYS)
     a.close(); b.close()
+
+
+def test_sharded_rccl_world_of_one(ifx, small_stream):
+    """The real exchange path -- torch.distributed 'nccl' (RCCL) all-reduce(MIN) enqueued on the handle's own stream -- with a
+    process group of one rank: exercises the stream hand-over and the RCCL call; the result must equal the plain entry point."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from instancefusion_amd import sharded
+
+    st = small_stream
+    d_rgb = torch.from_numpy(st["rgb"][:5].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:5].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        a = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+        b = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+        sb = sharded.ShardedElasticFusion(b, 0, 1, dist)
+        for i in range(5):
+            a.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            sb.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+        a.sync(); b.sync(); torch.cuda.synchronize()
+        assert np.array_equal(a.trajectory(), b.trajectory())
+        ma, mb = a.download(), b.download()
+        assert all(np.array_equal(ma[k], mb[k]) for k in MAP_KEYS)
+        assert np.array_equal(a.image("ids_after"), b.image("ids_after"))
+        a.close(); b.close()
+    finally:
+        dist.destroy_process_group()

@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # no test may hang a GPU box: every test gets a hard limit (pytest-timeout), the RCCL one a short one
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(180 if "rccl" in it.name else 600))
+
+
 SMALL = dict(w=320, h=240, fx=264.0, fy=264.0, cx=160.0, cy=120.0)
 
 

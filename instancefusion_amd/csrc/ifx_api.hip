@@ -173,6 +173,16 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
+    // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;
+    // refused while a frame is announced ahead (its image-only work may already be on the queue with the old configuration)
+    else if (s == "pyramid" || s == "fast_odom" || s == "so3" || s == "icp_weight_x1000") {
+        if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "tracker options cannot change while a frame is announced ahead"; return IFX_E_STATE; }
+        h->tracked_ahead = 0;
+        if (s == "pyramid") h->cfg.pyramid = value ? 1 : 0;
+        else if (s == "fast_odom") h->cfg.fast_odom = value ? 1 : 0;
+        else if (s == "so3") h->cfg.so3 = value ? 1 : 0;
+        else { if (value < 0 || value > 100000) { h->err = "icp_weight_x1000 must be in [0, 100000]"; return IFX_E_INVALID; } h->cfg.icp_weight = value / 1000.f; }
+    }
     else { h->err = "unknown option " + s; return IFX_E_INVALID; }
     return IFX_OK;
 }

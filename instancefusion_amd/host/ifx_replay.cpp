@@ -1,0 +1,127 @@
+// ifx_replay -- the reference's main program (IF/main.cpp:49-330) without its GUI, on the C++ host classes of ifx_host.hpp:
+// log reader -> ElasticFusionInterface::ProcessFrame -> InstanceFusion::whetherDoSegmentation -> ProcessSegmentation (masks replayed
+// from files instead of the Mask-RCNN bridge, kNN smoothing when the last one is more than flann_skip_frames old) -> at the end
+// ResultModel.freiburg (ElasticFusion's destructor, EF/ElasticFusion.cpp:99-136), ResultModel.ply and ResultModel_Instance.ply
+// (map->SavePly(), IF/main.cpp:300-305), and optionally the per-surfel instance labels.
+//
+//   ifx_replay LOG.klg|data.txt [--width 640 --height 480 --fx 528 --fy 528 --cx 320 --cy 240] [--masks DIR] [--out PREFIX]
+//              [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--device K]
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+
+#include "ifx_host.hpp"
+
+namespace {
+const int instanceNum = 96;        // IF/main.cpp:31
+const int cnn_start_frames = 0;    // IF/main.cpp:34-36 (cnn_skip_frames is dead once whetherDoSegmentation decides)
+int flann_skip_frames = 40;       // IF/main.cpp:36; --flann-every overrides it
+
+struct Args {
+    std::string log, masks, out = "./ResultModel", labels;
+    int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
+    float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
+    bool superpixels = true, flip = false;
+};
+
+int usage(const char* argv0)
+{
+    std::fprintf(stderr,
+                 "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K]\n",
+                 argv0);
+    return 2;
+}
+}   // namespace
+
+int main(int argc, char** argv)
+{
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        const std::string s = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(2); }
+            return argv[++i];
+        };
+        if (s == "--width") a.width = std::atoi(val("--width"));
+        else if (s == "--height") a.height = std::atoi(val("--height"));
+        else if (s == "--fx") a.fx = (float)std::atof(val("--fx"));
+        else if (s == "--fy") a.fy = (float)std::atof(val("--fy"));
+        else if (s == "--cx") a.cx = (float)std::atof(val("--cx"));
+        else if (s == "--cy") a.cy = (float)std::atof(val("--cy"));
+        else if (s == "--masks") a.masks = val("--masks");
+        else if (s == "--out") a.out = val("--out");
+        else if (s == "--labels") a.labels = val("--labels");
+        else if (s == "--max-frames") a.max_frames = std::atoi(val("--max-frames"));
+        else if (s == "--max-surfels") a.max_surfels = std::atoi(val("--max-surfels"));
+        else if (s == "--flann-every") flann_skip_frames = std::atoi(val("--flann-every"));
+        else if (s == "--device") a.device = std::atoi(val("--device"));
+        else if (s == "--no-superpixels") a.superpixels = false;
+        else if (s == "--flip-colors") a.flip = true;
+        else if (s == "--help" || s == "-h") { usage(argv[0]); return 0; }
+        else if (!s.empty() && s[0] == '-') { std::fprintf(stderr, "unknown option %s\n", s.c_str()); return usage(argv[0]); }
+        else a.log = s;
+    }
+    if (a.log.empty()) return usage(argv[0]);
+
+    try {
+        Resolution::getInstance(a.width, a.height);            // IF/main.cpp:46-47
+        Intrinsics::getInstance(a.fx, a.fy, a.cx, a.cy);
+
+        std::unique_ptr<LogReader> log_reader;                 // IF/main.cpp:60-75
+        if (a.log.size() > 4 && a.log.substr(a.log.size() - 4) == ".txt") log_reader.reset(new PNGLogReader(a.log));
+        else log_reader.reset(new RawLogReader(a.log, a.flip));
+
+        std::unique_ptr<InstanceFusion> instancefusion(new InstanceFusion(instanceNum, a.width, a.height, false, 0));
+        instancefusion->setSuperpixelRefinement(a.superpixels);
+        if (!a.masks.empty()) instancefusion->setMaskSource(std::make_shared<MaskReplay>(a.masks));
+
+        std::unique_ptr<ElasticFusionInterface> map(new ElasticFusionInterface());
+        if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out)) {
+            std::cout << "ElasticFusionInterface init failure" << std::endl;
+            return 1;
+        }
+        instancefusion->bindMap(map);
+
+        int frame_Fusion = 0, lastTimeFlann = -1;
+        std::vector<int> instanceTableLoopClosure((size_t)instancefusion->getInstanceNum() * 5);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (log_reader->hasMore() && (a.max_frames <= 0 || frame_Fusion < a.max_frames)) {   // IF/main.cpp:108-307
+            log_reader->getNext();
+            instancefusion->getLoopClosureInstanceTable(instanceTableLoopClosure.data());
+            if (!map->ProcessFrame(log_reader->rgb, log_reader->depth, log_reader->timestamp, instanceTableLoopClosure.data(), NULL)) {
+                std::cout << "Elastic fusion lost!" << a.log << std::endl;
+                return 1;
+            }
+            if (frame_Fusion >= cnn_start_frames && !a.masks.empty() && instancefusion->whetherDoSegmentation(map, frame_Fusion)) {
+                bool flannFlag = false;
+                if (frame_Fusion - lastTimeFlann > flann_skip_frames) {
+                    lastTimeFlann = frame_Fusion;
+                    flannFlag = true;
+                }
+                instancefusion->ProcessSegmentation(log_reader->rgb, log_reader->depth, map, frame_Fusion, flannFlag);
+            }
+            frame_Fusion++;
+        }
+        ifx_sync(map->handle());
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+        const int n_geo = map->elasticFusion().savePly();
+        const int n_ins = map->elasticFusion().savePlyInstance();
+        if (!a.labels.empty()) {   // bestIDInEachSurfel of the live surfels, one int32 each (what evaluateAndSave consumes, IF/Core/InstanceFusion.h:79)
+            const std::vector<int32_t> l = instancefusion->getSurfelLabels(map);
+            std::ofstream f(a.labels, std::ios::binary);
+            f.write((const char*)l.data(), (std::streamsize)l.size() * 4);
+        }
+        const Matrix4f P = map->getCurrPose();
+        std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
+                    "last position %.6f %.6f %.6f\n",
+                    frame_Fusion, dt, frame_Fusion / (dt > 0 ? dt : 1), instancefusion->segmentationCalls(), map->getMapSurfelCount(), n_geo, a.out.c_str(), n_ins,
+                    P(0, 3), P(1, 3), P(2, 3));
+        map.reset();   // ~ElasticFusion writes PREFIX.freiburg
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "ifx_replay: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

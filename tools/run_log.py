@@ -55,7 +55,7 @@ def main(argv=None):
     ef = ifx.ElasticFusion(w=args.width, h=args.height, fx=args.fx, fy=args.fy, cx=args.cx, cy=args.cy, max_surfels=args.max_surfels)
     inst = ifx.InstanceFusion(ef)
     stamps, poses = [], []
-    frame, last_flann, n_seg = 0, 0, 0
+    frame, last_flann, n_seg = 0, -1, 0     # lastTimeFlann = -1, IF/main.cpp:111
     t0 = time.perf_counter()
     while reader.hasMore() and (args.max_frames <= 0 or frame < args.max_frames):
         reader.getNext()

@@ -106,6 +106,18 @@ int ifx_trajectory(ifx_t* h, float* out_poses16, int max_frames);
  * velocity weighting, fill-in flag (EF/Utils/RGBDOdometry.h:65-70). */
 int ifx_tracker_diag(ifx_t* h, float* diag8);
 
+/* ---- local loop-closure DETECTION (the closeLoops / countThresh / errThresh / covThresh constructor arguments, EF/ElasticFusion.h:48-51;
+ * EF/ElasticFusion.cpp:453-566 with no fern match).  When enabled every tracked frame also runs predict() at the new pose, the INACTIVE
+ * prediction (surfels not seen for time_delta frames), the model-to-model tracker (RGBDOdometry modelToModel: active render against
+ * inactive render, ICP weight 10, no SO(3)) and the gates covariance diagonal <= cov_thresh, lastICPCount > count_thresh, lastICPError <
+ * err_thresh.  The reference then deforms the map (deformation graph) and adopts the estimated pose; that part is NOT implemented
+ * (DESIGN.md section 0): an accepted candidate is counted and reported, the frame continues with the tracked pose.  A run whose
+ * candidate count stays 0 is therefore what the reference computes with closeLoops = true and an empty fern data base.
+ * out24: 0 model-to-model ran (0: nothing inactive in view), 1 pixels of the inactive render, 2 lastICPError, 3 lastICPCount, 4 covOk,
+ * 5 accepted, 6..21 estimated pose (row-major 4x4), 22 largest diagonal covariance entry, 23 candidates accepted so far. */
+int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, float err_thresh, float cov_thresh);
+int ifx_loop_closure_diag(ifx_t* h, float* out24);
+
 /* ---- map access (replaces getMapSurfelsGpu / getMapSurfelCount / id textures,
  * IF/map_interface/ElasticFusionInterface.h:55-120).  The store is struct-of-arrays; slots whose
  * surfel was deleted stay in place as tombstones until ifx_compact (DESIGN.md "Tombstones"). */
@@ -138,7 +150,8 @@ const int32_t* ifx_ids_after(ifx_t* h);
 /* Host copy of an internal image (synchronises).  Names: "ids_after", "ids_tmp", "index",
  * "index_vc", "index_ct", "index_nr", "pred_vertex", "pred_normal", "pred_image", "pred_inst",
  * "pred_time", "fill_vertex", "fill_normal", "fill_image", "depth_filtered", "depth_metric",
- * "depth_metric_filtered".  Returns bytes written or <0. */
+ * "depth_metric_filtered", and with loop-closure detection on "old_vertex", "old_normal", "old_image", "old_time" (the
+ * INACTIVE prediction, IndexMap::oldVertexTex() etc.).  Returns bytes written or <0. */
 int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t max_bytes);
 
 /* ---- map stage API (unit-parity surface; each replaces one GL pass of the reference) */

@@ -77,6 +77,8 @@ _SIGS = {
     "ifx_tick": (C.c_int, [_P]),
     "ifx_trajectory": (C.c_int, [_P, _P, C.c_int]),
     "ifx_tracker_diag": (C.c_int, [_P, _P]),
+    "ifx_set_loop_closure": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "ifx_loop_closure_diag": (C.c_int, [_P, _P]),
     "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
     "ifx_map_count": (C.c_int, [_P]),
     "ifx_map_slots": (C.c_int, [_P]),
@@ -148,6 +150,7 @@ _IMG_SPECS = {
     "pred_normal": (np.float32, 4), "pred_image": (np.uint8, 4), "pred_inst": (np.uint8, 4), "pred_time": (np.uint16, 1),
     "fill_vertex": (np.float32, 4), "fill_normal": (np.float32, 4), "fill_image": (np.uint8, 4),
     "depth_filtered": (np.uint16, 1), "depth_metric": (np.float32, 1), "depth_metric_filtered": (np.float32, 1),
+    "old_vertex": (np.float32, 4), "old_normal": (np.float32, 4), "old_image": (np.uint8, 4), "old_time": (np.uint16, 1),
 }
 _TRK_SPECS = {
     "vmap_curr": (np.float32, 3, True), "nmap_curr": (np.float32, 3, True), "vmap_prev": (np.float32, 3, True),
@@ -239,6 +242,16 @@ class ElasticFusion:
         out = np.zeros(8, np.float32)
         self._chk(self.L.ifx_tracker_diag(self.handle, _ptr(out)), "ifx_tracker_diag")
         return out
+
+    # -- local loop-closure detection (closeLoops, countThresh, errThresh, covThresh of the reference constructor)
+    def set_loop_closure(self, enable=True, count_thresh=35000, err_thresh=5e-5, cov_thresh=1e-5):
+        self._chk(self.L.ifx_set_loop_closure(self.handle, int(enable), int(count_thresh), err_thresh, cov_thresh), "ifx_set_loop_closure")
+
+    def loop_closure_diag(self):
+        out = np.zeros(24, np.float32)
+        self._chk(self.L.ifx_loop_closure_diag(self.handle, _ptr(out)), "ifx_loop_closure_diag")
+        return dict(ran=bool(out[0]), inactive_pixels=int(out[1]), icp_error=float(out[2]), icp_count=float(out[3]), cov_ok=bool(out[4]),
+                    accepted=bool(out[5]), est_pose=out[6:22].reshape(4, 4).copy(), cov_max=float(out[22]), candidates=int(out[23]))
 
     # -- map access (getMapSurfelCount / getMapSurfelsGpu / id textures)
     def getMapSurfelCount(self):

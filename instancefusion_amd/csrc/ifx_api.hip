@@ -161,6 +161,26 @@ extern "C" void ifx_destroy(ifx_t* h)
     delete h;
 }
 
+extern "C" int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, float err_thresh, float cov_thresh)
+{
+    if (!h) return IFX_E_INVALID;
+    if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "loop-closure detection cannot change while a frame is announced ahead"; return IFX_E_STATE; }
+    h->tracked_ahead = 0;
+    if (enable) {
+        int r = ifx_tracker_alloc_m2m(h);
+        if (r) return r;
+    }
+    h->lc_enable = enable ? 1 : 0; h->lc_count_thresh = count_thresh; h->lc_err_thresh = err_thresh; h->lc_cov_thresh = cov_thresh;
+    return IFX_OK;
+}
+extern "C" int ifx_loop_closure_diag(ifx_t* h, float* out24)
+{
+    if (!h || !out24) return IFX_E_INVALID;
+    if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
+    memcpy(out24, h->h_result->lc, sizeof(h->h_result->lc));
+    return IFX_OK;
+}
+
 extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
 {
     if (!h || !name) return IFX_E_INVALID;
@@ -193,6 +213,7 @@ __global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restric
     if (threadIdx.x != 0) return;
     out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
     st->seg_acc[0] = 0; st->seg_acc[1] = 0;
+    for (int k = 0; k < 24; k++) out->lc[k] = st->lc[k];
     for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
     out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
     out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
@@ -236,9 +257,35 @@ int ifx_enqueue_hinted_frame_side(ifx* h)
     return enqueue_frame_side(h, (h->tick + 1) & 1, h->tick + 1, r, d, 0);
 }
 
-// ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Loop
-// closure (ferns, deformation graph, model-to-model tracking) is out of scope, and so
-// is the first predict() of :453 whose only consumers are those stages.
+// Local loop-closure detection of the frame just tracked (EF/ElasticFusion.cpp:453-566 with no fern match): predict() at the new pose,
+// INACTIVE prediction, model-to-model tracking, covariance / count / error gates.  While tick - timeDelta < 1 no surfel the frames created
+// can be old enough (lastTime >= 1), so unless a map was uploaded the whole block is skipped on the host -- exactly what the gates would
+// decide on an empty render.
+__global__ void k_lc_idle(DevState* st)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 23; k++) st->lc[k] = 0.f;
+    for (int k = 0; k < 16; k++) st->lc[6 + k] = st->pose[k];
+    st->lc[23] = (float)st->lc_candidates;
+}
+static int enqueue_loop_closure_detection(ifx* h)
+{
+    if (!h->map_external && h->tick - h->cfg.time_delta < 1) {
+        LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state);
+        return IFX_OK;
+    }
+    {
+        StageTimer t(h, 1);
+        ifx_tracker_m2m_begin(h);
+        ifx_map_predict_loop_closure(h);
+    }
+    StageTimer t(h, 0);
+    return ifx_tracker_loop_closure(h);
+}
+
+// ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)
+// the local detection is implemented (ifx_set_loop_closure); ferns and the deformation graph are out of scope, and
+// without the detection the first predict() of :453, whose only consumers are those stages, is not executed.
 static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult)
 {
     const int s = h->tick & 1;
@@ -276,6 +323,10 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
             }
+        }
+        if (h->lc_enable) {
+            int r = enqueue_loop_closure_detection(h);
+            if (r) return r;
         }
         StageTimer t(h, 1);
         ifx_map_frame(h);
@@ -592,6 +643,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
     h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
+    h->map_external = 1;
     if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->pc, pc, (size_t)n * 16, hipMemcpyHostToDevice));
@@ -656,6 +708,10 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     else if (s == "pred_image") { src = h->pred_image; bytes = P * 4; }
     else if (s == "pred_inst") { src = h->pred_inst; bytes = P * 4; }
     else if (s == "pred_time") { src = h->pred_time; bytes = P * 2; }
+    else if (s == "old_vertex" && h->d_m2m) { src = h->old_vertex; bytes = P * 16; }
+    else if (s == "old_normal" && h->d_m2m) { src = h->old_normal; bytes = P * 16; }
+    else if (s == "old_image" && h->d_m2m) { src = h->old_image; bytes = P * 4; }
+    else if (s == "old_time" && h->d_m2m) { src = h->old_time; bytes = P * 2; }
     else if (s == "fill_vertex") { src = h->fill_vertex; bytes = P * 16; }
     else if (s == "fill_normal") { src = h->fill_normal; bytes = P * 16; }
     else if (s == "fill_image") { src = h->fill_image; bytes = P * 4; }

@@ -45,6 +45,11 @@ struct DevState {
     int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
     unsigned int append_ticket;  // last-block ticket of k_append_scan
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
+    // local loop-closure detection (EF/ElasticFusion.cpp:453-566).  The model-to-model tracker has a DevState of its own (ifx::d_m2m):
+    // there `count` counts the pixels of the INACTIVE render and `skip` is set when it is empty; the verdict lands in lc[] of the MAIN state.
+    int skip;             // tracker kernels return at once (model-to-model run with nothing to align)
+    float lc[24];         // ifx_loop_closure_diag layout
+    int lc_candidates;
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
@@ -53,6 +58,7 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     float diag[8];
     int count, n_dead, n_new, overflow;
     int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
+    float lc[24];        // loop-closure detection of this frame (ifx_loop_closure_diag)
 };
 
 struct Pyr {
@@ -61,7 +67,8 @@ struct Pyr {
     float *vmap_curr[IFX_NUM_PYRS], *nmap_curr[IFX_NUM_PYRS];
     float *vmap_cam[IFX_NUM_PYRS], *nmap_cam[IFX_NUM_PYRS];   // model maps in the camera frame (before the global transform)
     float *vmap_prev[IFX_NUM_PYRS], *nmap_prev[IFX_NUM_PYRS];
-    float* last_depth[IFX_NUM_PYRS];                          // == next_depth (reference quirk)
+    float* last_depth[IFX_NUM_PYRS];                          // == next_depth in the frame-to-model tracker (reference quirk)
+    float* next_depth[IFX_NUM_PYRS] = {};                     // model-to-model tracker only (nullptr: last_depth)
     uint8_t *last_img[IFX_NUM_PYRS], *next_img[IFX_NUM_PYRS], *lastnext_img[IFX_NUM_PYRS];
     int16_t *didx[IFX_NUM_PYRS], *didy[IFX_NUM_PYRS];
     float* cloud[IFX_NUM_PYRS];
@@ -116,6 +123,15 @@ struct ifx {
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_blocks = 304;
+    // local loop-closure detection (ifx_set_loop_closure): second tracker instance + the INACTIVE prediction images
+    int map_external = 0;               // a map was uploaded: surfel times are not bounded by the frames processed
+    int lc_enable = 0, lc_count_thresh = 35000;
+    float lc_err_thresh = 5e-5f, lc_cov_thresh = 1e-5f;
+    DevState* d_m2m = nullptr;
+    Pyr m2m;
+    float *old_vertex = nullptr, *old_normal = nullptr;
+    uint8_t *old_image = nullptr, *old_inst = nullptr;
+    uint16_t* old_time = nullptr;
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned
@@ -226,6 +242,10 @@ int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of 
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
 int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame);
+int ifx_map_predict_loop_closure(ifx* h);                     // predict() at the tracked pose + INACTIVE prediction (old* images)
+int ifx_tracker_alloc_m2m(ifx* h);
+int ifx_tracker_loop_closure(ifx* h);                         // model-to-model tracking + gates, after ifx_map_predict_loop_closure
+int ifx_tracker_m2m_begin(ifx* h);
 int ifx_map_predict(ifx* h);                                  // splat + fill-in + dense flag
 int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total /*device ptr or null*/);
 int ifx_alloc_tracker(ifx* h);

@@ -373,7 +373,8 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
-                                unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out)
+                                unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
+                                int* __restrict__ n_valid)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -410,6 +411,11 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
         to = (uint16_t)(unsigned int)t2.x;
     }
     pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
+    if (n_valid) {   // INACTIVE prediction of the loop-closure detection: covered pixels (one atomic per wave that has any)
+        const unsigned long long m = __ballot(vo.z != 0);
+        if (m && (__lane_id() == (unsigned)(__ffsll((long long)m) - 1))) atomicAdd(n_valid, __popcll(m));
+    }
+    if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
     // fill-in
     float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
     if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
-static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0)
+static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0)
 {
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
@@ -783,11 +789,19 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
                h->key_ids, h->key_both);
     }
     if (part == 1) return;
+    if ((want & LIST_SPLAT) && old_target) {   // INACTIVE prediction into the old* images (IndexMap::oldFrameBuffer, EF/IndexMap.cpp:480-483), no fill-in, no dense flag
+        LAUNCH(h, "splat_resolve_old", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
+               (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->old_vertex, (float4*)h->old_normal,
+               (uchar4*)h->old_image, (uchar4*)h->old_inst, h->old_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr,
+               &h->d_m2m->count);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10);
+        return;
+    }
     if (want & LIST_SPLAT) {
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
-               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr);
+               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr);
     } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
     // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums
     const int seg = frame_sums && (want & LIST_IDS);   // only the frame's own render feeds whetherDoSegmentation (not the re-render after a compaction)
@@ -1154,6 +1168,16 @@ int ifx_map_frame(ifx* h)
     clean_pass(h, nullptr, h->tick);   // includes the second predictIndices
     if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
     h->ids_pending = 1;                // rendered together with the prediction (same map state, same pose)
+    return IFX_OK;
+}
+
+// Loop-closure detection, map side (EF/ElasticFusion.cpp:453 and :519-526): predict() at the pose just tracked (pre-fusion map), then the
+// INACTIVE prediction -- surfels last seen at or before tick - timeDelta (splat.vert:60 with time = 0, maxTime = tick - timeDelta) -- into
+// the old* images; DevState(m2m)::count receives the number of covered pixels.
+int ifx_map_predict_loop_closure(ifx* h)
+{
+    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, nullptr);
+    raster_pass(h, nullptr, 0, h->tick - h->cfg.time_delta, LIST_SPLAT, nullptr, false, 0, 1);
     return IFX_OK;
 }
 

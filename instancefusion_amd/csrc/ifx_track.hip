@@ -223,14 +223,16 @@ struct ModelOut {
 };
 __device__ __forceinline__ void model_tail(const DevState* __restrict__ st, int x, int y, int w, int h, v3 vs, v3 ns, float z, const ModelOut& o)
 {
-    const float* P = st->pose;
-    const float qn = qnan_f();
-    v3 vd = v3m(qn, qn, qn);
-    if (!(vs.x != vs.x)) vd = xf_dir(P, vs) + v3m(P[3], P[7], P[11]);
-    o.vprev[y * w + x] = vd.x; o.vprev[(y + h) * w + x] = vd.y; o.vprev[(y + 2 * h) * w + x] = vd.z;
-    v3 nd = v3m(qn, qn, qn);
-    if (!(ns.x != ns.x)) nd = xf_dir(P, ns);
-    o.nprev[y * w + x] = nd.x; o.nprev[(y + h) * w + x] = nd.y; o.nprev[(y + 2 * h) * w + x] = nd.z;
+    if (o.vprev) {   // nullptr: the maps stay in the camera frame (frame side of the model-to-model tracker)
+        const float* P = st->pose;
+        const float qn = qnan_f();
+        v3 vd = v3m(qn, qn, qn);
+        if (!(vs.x != vs.x)) vd = xf_dir(P, vs) + v3m(P[3], P[7], P[11]);
+        o.vprev[y * w + x] = vd.x; o.vprev[(y + h) * w + x] = vd.y; o.vprev[(y + 2 * h) * w + x] = vd.z;
+        v3 nd = v3m(qn, qn, qn);
+        if (!(ns.x != ns.x)) nd = xf_dir(P, ns);
+        o.nprev[y * w + x] = nd.x; o.nprev[(y + h) * w + x] = nd.y; o.nprev[(y + 2 * h) * w + x] = nd.z;
+    }
     if (o.cloud) {
         o.cloud[(y * w + x) * 3 + 0] = (float)((x - o.cx) * z * o.invFx);
         o.cloud[(y * w + x) * 3 + 1] = (float)((y - o.cy) * z * o.invFy);
@@ -242,7 +244,7 @@ __global__ void k_model_l0(const DevState* __restrict__ st, const float* __restr
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
-    const bool fill = !st->dense_enough;
+    const bool fill = fv && !st->dense_enough;
     const float4 v = reinterpret_cast<const float4*>(fill ? fv : pv)[y * w + x];
     const float4 n = reinterpret_cast<const float4*>(fill ? fn : pn)[y * w + x];
     const uint8_t* s = (fill ? fi : pi) + (size_t)(y * w + x) * 4;
@@ -535,7 +537,7 @@ struct PairArgs {
     float fx, fy, cx, cy, distThres, angleThres;
     float minScale, maxDepthDelta;
     const int16_t *dIdx, *dIdy;
-    const float* lastDepth;
+    const float *lastDepth, *nextDepth;   // the same image in the frame-to-model tracker (reference quirk), two images model-to-model
     const uint8_t *lastImage, *nextImage;
     Corres8* corres;
     int w, h, nb_icp, nb_res;
@@ -545,12 +547,13 @@ struct PairArgs {
 };
 __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, PairArgs a)
 {
+    if (st->skip) return;
     if ((int)blockIdx.x < a.nb_icp) {
         IcpArgs ia;   // unused when st != nullptr
         icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_partials);
     } else {
         ResArgs ra;
-        residual_body(blockIdx.x - a.nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.lastDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, a.w,
+        residual_body(blockIdx.x - a.nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, a.w,
                       a.h, a.res_partials, a.res_total);
     }
 }
@@ -1256,6 +1259,7 @@ struct StepArgs {
 };
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
 {
+    if (st->skip) return;   // uniform over the grid: the last-block ticket stays armed
     __shared__ int s_last;
 #ifdef IFX_STAMPS
     long long t0 = clock64();
@@ -1419,6 +1423,7 @@ void ifx_bind_slot(ifx* h, int s)
     }
 }
 
+static void free_m2m(ifx* h);
 void ifx_free_tracker(ifx* h)
 {
     Pyr& p = h->pyr;
@@ -1431,6 +1436,7 @@ void ifx_free_tracker(ifx* h)
         hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
     for (int q = 0; q < 2; q++) hipFree(h->slot[q].so3);
+    free_m2m(h);
     hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
@@ -1453,11 +1459,10 @@ int ifx_tracker_init_first(ifx* h)
 }
 
 // model side: initICPModel + initRGBModel (EF/Utils/RGBDOdometry.cpp:169-206,237-241)
-static void tracker_init_model(ifx* h, const float* pv, const float* pn, const uint8_t* pi, const float* fv, const float* fn, const uint8_t* fi)
+static void tracker_init_model(ifx* h, DevState* st, Pyr& p, float icp_weight, const float* pv, const float* pn, const uint8_t* pi, const float* fv, const float* fn, const uint8_t* fi)
 {
-    Pyr& p = h->pyr;
     const ifx_config& c = h->cfg;
-    const int rgb = c.icp_weight < 100;
+    const int rgb = icp_weight < 100;
     const int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         const float div = (float)(1 << i);
@@ -1465,8 +1470,43 @@ static void tracker_init_model(ifx* h, const float* pv, const float* pn, const u
         o.vcam = p.vmap_cam[i]; o.ncam = p.nmap_cam[i]; o.depth = p.last_depth[i]; o.img = p.last_img[i];
         o.vprev = p.vmap_prev[i]; o.nprev = p.nmap_prev[i]; o.cloud = (rgb && iterations[i] > 0) ? p.cloud[i] : nullptr;
         o.invFx = 1.0f / (c.fx / div); o.invFy = 1.0f / (c.fy / div); o.cx = c.cx / div; o.cy = c.cy / div;
-        if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, h->d_state, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o);
-        else LAUNCH(h, "model_down", G2(p.w[i], p.h[i]), B2, k_model_down, h->d_state, p.vmap_cam[i - 1], p.nmap_cam[i - 1], p.last_depth[i - 1], p.last_img[i - 1], p.w[i - 1], p.h[i - 1], o);
+        if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, st, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o);
+        else LAUNCH(h, "model_down", G2(p.w[i], p.h[i]), B2, k_model_down, st, p.vmap_cam[i - 1], p.nmap_cam[i - 1], p.last_depth[i - 1], p.last_img[i - 1], p.w[i - 1], p.h[i - 1], o);
+    }
+}
+
+// frame side of the model-to-model tracker: initICP(predictedVertices, predictedNormals) + initRGB(predictedImage)
+// (EF/Utils/RGBDOdometry.cpp:144-167, 243-247) -- copyMaps, verticesToDepth, intensity at level 0, then resizeVMap / resizeNMap and the
+// two Gaussian pyr-downs per level: the model-side kernels with the camera-frame maps as their only output -- plus the Sobel
+// images of :287-293.
+__global__ void k_sobel(const uint8_t* __restrict__ img, int w, int h, int16_t* __restrict__ dx, int16_t* __restrict__ dy)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+    if (u >= w || v >= h) return;
+    // applyKernel (Sobel), EF/Cuda/cudafuncs.cu:583-607
+    const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    float dxVal = 0, dyVal = 0;
+    int k = 8;
+    for (int j = max(v - 1, 0); j <= min(v + 1, h - 1); j++)
+        for (int i = max(u - 1, 0); i <= min(u + 1, w - 1); i++) {
+            dxVal += (float)img[j * w + i] * gsx[k];
+            dyVal += (float)img[j * w + i] * gsy[k];
+            --k;
+        }
+    dx[v * w + u] = (int16_t)dxVal;
+    dy[v * w + u] = (int16_t)dyVal;
+}
+static void tracker_init_frame_maps(ifx* h, DevState* st, Pyr& p, const float* pv, const float* pn, const uint8_t* pi)
+{
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        ModelOut o;
+        o.vcam = p.vmap_curr[i]; o.ncam = p.nmap_curr[i]; o.depth = p.next_depth[i]; o.img = p.next_img[i];
+        o.vprev = nullptr; o.nprev = nullptr; o.cloud = nullptr;
+        o.invFx = 0; o.invFy = 0; o.cx = 0; o.cy = 0;
+        if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, st, pv, pn, pi, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, h->w, h->h, 6.0f, o);
+        else LAUNCH(h, "model_down", G2(p.w[i], p.h[i]), B2, k_model_down, st, p.vmap_curr[i - 1], p.nmap_curr[i - 1], p.next_depth[i - 1], p.next_img[i - 1], p.w[i - 1], p.h[i - 1], o);
+        LAUNCH(h, "sobel", G2(p.w[i], p.h[i]), B2, k_sobel, p.next_img[i], p.w[i], p.h[i], p.didx[i], p.didy[i]);
     }
 }
 
@@ -1495,24 +1535,24 @@ static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t
 }
 
 // getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603, enqueued without any readback
-static void tracker_run(ifx* h, float weight_mult, int commit = 1)
+// `st` / `p`: the state and pyramids of the tracker instance (frame-to-model: h->d_state / h->pyr; model-to-model: h->d_m2m / h->m2m)
+static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3, float weight_mult, int commit, bool frame_tracker)
 {
-    Pyr& p = h->pyr;
     const ifx_config& c = h->cfg;
-    const int icp = c.icp_weight > 0, rgb = c.icp_weight < 100, so3 = c.so3;
+    const int icp = icp_weight > 0, rgb = icp_weight < 100;
     int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
     int first = -1;
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) if (iterations[i] > 0) { first = i; break; }
     {
         const float div = (float)(1 << (first < 0 ? 0 : first));
-        LAUNCH(h, "track_gn_begin", dim3(1), dim3(64), k_track_gn_begin, h->d_state, h->slot[h->cur_slot].so3, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div);
+        LAUNCH(h, "track_gn_begin", dim3(1), dim3(64), k_track_gn_begin, st, h->slot[h->cur_slot].so3, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div);
     }
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
         // The coarse levels are on the queue: the host is now ahead of the GPU by ~20 latency-bound launches, and the
         // finest level keeps the GPU mostly idle for another ~0.3 ms -- the place to slip in the next frame's image-only work.
-        if (i == 0) ifx_enqueue_hinted_frame_side(h);
+        if (i == 0 && frame_tracker) ifx_enqueue_hinted_frame_side(h);
         float div = (float)(1 << i);
         float fx = c.fx / div, fy = c.fy / div, cx = c.cx / div, cy = c.cy / div;
         int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n);
@@ -1525,22 +1565,22 @@ static void tracker_run(ifx* h, float weight_mult, int commit = 1)
         pa.vmap_curr = p.vmap_curr[i]; pa.nmap_curr = p.nmap_curr[i]; pa.vmap_prev = p.vmap_prev[i]; pa.nmap_prev = p.nmap_prev[i];
         pa.fx = fx; pa.fy = fy; pa.cx = cx; pa.cy = cy; pa.distThres = 0.10f; pa.angleThres = sinf(20.f * 3.14159254f / 180.f);
         pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
-        pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
+        pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
         pa.icp_partials = h->icp_partials; pa.res_partials = h->res_partials; pa.res_total = (int*)(h->d_ticket + 8);
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
-            LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, h->d_state, pa);
+            LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb; sa2.nb_icp = nb; sa2.nb_res = nb;
             sa2.rgb_partials = h->rgb_partials; sa2.icp_partials = h->icp_partials; sa2.res_partials = h->res_partials;
-            sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = c.icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
+            sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
             sa2.ticket = h->d_ticket; sa2.res_total = (int*)(h->d_ticket + 8);
-            LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, h->d_state, sa2);
+            LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, rgb, 1, weight_mult, commit);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit);
 }
 
 // frame side of the tracker for the bound slot: frame pyramids, then (unless this is the first frame, which only
@@ -1572,13 +1612,122 @@ int ifx_tracker_frame_side(ifx* h, int first)
 
 int ifx_tracker_model_side(ifx* h)
 {
-    tracker_init_model(h, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
+    tracker_init_model(h, h->d_state, h->pyr, h->cfg.icp_weight, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
     return IFX_OK;
 }
 
 int ifx_tracker_run_frame(ifx* h, int commit)
 {
-    tracker_run(h, 1.0f, commit);
+    tracker_run(h, h->d_state, h->pyr, h->cfg.icp_weight, h->cfg.so3, 1.0f, commit, true);
+    return IFX_OK;
+}
+
+// ---- local loop-closure detection, tracker side (EF/ElasticFusion.cpp:528-566)
+// start of the detection of a frame: the model-to-model state takes the pose just tracked; its pixel counter is cleared
+__global__ void k_m2m_begin(const DevState* __restrict__ st, DevState* __restrict__ m)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) { m->pose[k] = st->pose[k]; m->pose_inv[k] = st->pose_inv[k]; }
+    m->dense_enough = 1; m->count = 0; m->skip = 0;
+}
+// after the INACTIVE render: nothing old in view -> every reduction would be empty (count 0 fails the gate of :566 whatever else is computed)
+__global__ void k_m2m_arm(DevState* __restrict__ m)
+{
+    if (threadIdx.x == 0) m->skip = (m->count == 0);
+}
+// getCovariance (EF/Utils/RGBDOdometry.cpp:605-608: lastA.lu().inverse(), here Gauss-Jordan with partial pivoting in f64) and the gates of
+// EF/ElasticFusion.cpp:547-566.  The verdict goes to the main state; the deformation an accepted candidate triggers in the reference is
+// not part of this path: candidates are counted and reported.
+__global__ void k_m2m_decide(DevState* __restrict__ st, const DevState* __restrict__ m, int count_thresh, float err_thresh, float cov_thresh)
+{
+    if (threadIdx.x != 0) return;
+    float* lc = st->lc;
+    for (int k = 0; k < 23; k++) lc[k] = 0.f;
+    lc[1] = (float)m->count;
+    for (int k = 0; k < 16; k++) lc[6 + k] = st->pose[k];
+    if (!m->skip) {
+        double a[6][12];
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++) { a[r][c] = m->lastA[r * 6 + c]; a[r][6 + c] = (r == c) ? 1.0 : 0.0; }
+        for (int k = 0; k < 6; k++) {
+            int piv = k;
+            for (int r = k + 1; r < 6; r++) if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
+            if (piv != k) for (int c = 0; c < 12; c++) { double tmp = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = tmp; }
+            const double d = 1.0 / a[k][k];
+            for (int c = 0; c < 12; c++) a[k][c] *= d;
+            for (int r = 0; r < 6; r++) {
+                if (r == k) continue;
+                const double f = a[r][k];
+                for (int c = 0; c < 12; c++) a[r][c] -= f * a[k][c];
+            }
+        }
+        int cov_ok = 1;
+        double cmax = 0;
+        for (int i = 0; i < 6; i++) {
+            if (a[i][6 + i] > (double)cov_thresh) cov_ok = 0;
+            if (!(a[i][6 + i] <= cmax)) cmax = a[i][6 + i];
+        }
+        const int accept = cov_ok && m->lastICPCount > (float)count_thresh && m->lastICPError < err_thresh;
+        lc[0] = 1.f; lc[2] = m->lastICPError; lc[3] = m->lastICPCount; lc[4] = (float)cov_ok; lc[5] = (float)accept;
+        for (int k = 0; k < 16; k++) lc[6 + k] = m->pose[k];
+        lc[22] = (float)cmax;
+        st->lc_candidates += accept;
+    }
+    lc[23] = (float)st->lc_candidates;
+}
+
+int ifx_tracker_alloc_m2m(ifx* h)
+{
+    if (h->d_m2m) return IFX_OK;
+    Pyr& p = h->m2m;
+    const size_t P = (size_t)h->P;
+    HIPCHK(h, hipMalloc(&h->d_m2m, sizeof(DevState)));
+    HIPCHK(h, hipMemset(h->d_m2m, 0, sizeof(DevState)));
+    HIPCHK(h, hipMalloc(&h->old_vertex, P * 16)); HIPCHK(h, hipMalloc(&h->old_normal, P * 16)); HIPCHK(h, hipMalloc(&h->old_image, P * 4));
+    HIPCHK(h, hipMalloc(&h->old_inst, P * 4)); HIPCHK(h, hipMalloc(&h->old_time, P * 2));
+    HIPCHK(h, hipMemset(h->old_vertex, 0, P * 16)); HIPCHK(h, hipMemset(h->old_normal, 0, P * 16)); HIPCHK(h, hipMemset(h->old_image, 0, P * 4));
+    HIPCHK(h, hipMemset(h->old_time, 0, P * 2));
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        p.w[i] = h->w >> i; p.h[i] = h->h >> i;
+        const size_t n = (size_t)p.w[i] * p.h[i];
+        p.depth_tmp[i] = nullptr; p.lastnext_img[i] = nullptr;
+        HIPCHK(h, hipMalloc(&p.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_curr[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.vmap_cam[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_cam[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.vmap_prev[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_prev[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.last_depth[i], n * 4)); HIPCHK(h, hipMalloc(&p.next_depth[i], n * 4));
+        HIPCHK(h, hipMalloc(&p.last_img[i], n)); HIPCHK(h, hipMalloc(&p.next_img[i], n));
+        HIPCHK(h, hipMalloc(&p.didx[i], n * 2)); HIPCHK(h, hipMalloc(&p.didy[i], n * 2));
+        HIPCHK(h, hipMalloc(&p.cloud[i], n * 12)); HIPCHK(h, hipMalloc(&p.corres[i], n * 8));
+    }
+    return IFX_OK;
+}
+static void free_m2m(ifx* h)
+{
+    if (!h->d_m2m) return;
+    Pyr& p = h->m2m;
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        hipFree(p.vmap_curr[i]); hipFree(p.nmap_curr[i]); hipFree(p.vmap_cam[i]); hipFree(p.nmap_cam[i]); hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]);
+        hipFree(p.last_depth[i]); hipFree(p.next_depth[i]); hipFree(p.last_img[i]); hipFree(p.next_img[i]); hipFree(p.didx[i]); hipFree(p.didy[i]);
+        hipFree(p.cloud[i]); hipFree(p.corres[i]);
+    }
+    hipFree(h->d_m2m); hipFree(h->old_vertex); hipFree(h->old_normal); hipFree(h->old_image); hipFree(h->old_inst); hipFree(h->old_time);
+    h->d_m2m = nullptr;
+}
+int ifx_tracker_m2m_begin(ifx* h)
+{
+    LAUNCH(h, "m2m_begin", dim3(1), dim3(64), k_m2m_begin, (const DevState*)h->d_state, h->d_m2m);
+    return IFX_OK;
+}
+// modelToModel.initICPModel / initRGBModel (old render, global frame at currPose), initICP / initRGB (active render), then
+// getIncrementalTransformation(trans, rot, false, 10, pyramid, fastOdom, false) (EF/ElasticFusion.cpp:528-545) and the gates
+int ifx_tracker_loop_closure(ifx* h)
+{
+    DevState* m = h->d_m2m;
+    LAUNCH(h, "m2m_arm", dim3(1), dim3(64), k_m2m_arm, m);
+    tracker_init_model(h, m, h->m2m, 10.0f, h->old_vertex, h->old_normal, h->old_image, nullptr, nullptr, nullptr);
+    tracker_init_frame_maps(h, m, h->m2m, h->pred_vertex, h->pred_normal, h->pred_image);
+    tracker_run(h, m, h->m2m, 10.0f, 0, 1.0f, 1, false);
+    LAUNCH(h, "m2m_decide", dim3(1), dim3(64), k_m2m_decide, h->d_state, (const DevState*)m, h->lc_count_thresh, h->lc_err_thresh, h->lc_cov_thresh);
     return IFX_OK;
 }
 
@@ -1700,9 +1849,9 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
     HIPCHK(h, hipMemcpyAsync(h->d_traj, pose16, 64, hipMemcpyHostToDevice, h->stream));   // scratch slot 0 of the log
     LAUNCH(h, "write_pose", dim3(1), dim3(64), k_write_pose, h->d_state, h->d_traj);
     LAUNCH(h, "set_dense", dim3(1), dim3(64), k_set_dense, h->d_state, 1);
-    tracker_init_model(h, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
+    tracker_init_model(h, h->d_state, h->pyr, h->cfg.icp_weight, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
     ifx_tracker_frame_side(h, 0);
-    tracker_run(h, 1.0f);
+    tracker_run(h, h->d_state, h->pyr, h->cfg.icp_weight, h->cfg.so3, 1.0f, 1, true);
     DevState hs;
     HIPCHK(h, hipMemcpyAsync(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

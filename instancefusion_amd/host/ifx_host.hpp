@@ -117,9 +117,10 @@ inline const char* const* ifx_coco_class_names()
 // ------------------------------------------------------------------------------------------------ ElasticFusion
 class ElasticFusion {
 public:
-    // EF/ElasticFusion.h:47-62, same order and defaults.  countThresh / errThresh / covThresh / photoThresh / fernThresh / closeLoops /
-    // reloc belong to the loop-closure and relocalisation logic, which is outside the path libifx.so implements:
-    // they are kept so that existing call sites compile and are readable through the getters, nothing else.
+    // EF/ElasticFusion.h:47-62, same order and defaults.  closeLoops turns the local loop-closure DETECTION on (ifx_set_loop_closure with
+    // countThresh / errThresh / covThresh: INACTIVE prediction + model-to-model tracking + gates; candidates are counted, the deformation
+    // they trigger in the reference is outside the path).  photoThresh / fernThresh / reloc belong to the fern data base
+    // and relocalisation: kept so that existing call sites compile and readable through the getters, nothing else.
     ElasticFusion(const int timeDelta = 200, const int countThresh = 35000, const float errThresh = 5e-05, const float covThresh = 1e-05,
                   const bool closeLoops = true, const bool iclnuim = false, const bool reloc = false, const float photoThresh = 115,
                   const float confidence = 10, const float depthCut = 3, const float icpThresh = 10, const bool fastOdom = false,
@@ -149,6 +150,11 @@ public:
         cfg_.n_ranks = 1;
         cfg_.rank = 0;
         if (ifx_create(&cfg_, &h_) != IFX_OK) throw std::runtime_error(std::string("ifx_create: ") + ifx_global_error());
+        if (closeLoops && ifx_set_loop_closure(h_, 1, countThresh, errThresh, covThresh) != IFX_OK) {
+            const std::string e = ifx_last_error(h_);
+            ifx_destroy(h_);
+            throw std::runtime_error("ifx_set_loop_closure: " + e);
+        }
         currPose_ = Matrix4f::Identity();
     }
     ElasticFusion(const ElasticFusion&) = delete;
@@ -178,6 +184,10 @@ public:
         const int r = ifx_process_frame(h_, rgb, depth, timestamp, inPose ? inPose->data() : nullptr, weightMultiplier, currPose_.data());
         if (r < 0) throw std::runtime_error(std::string("ifx_process_frame: ") + ifx_last_error(h_));
         lost_ = (r == 1);
+        if (closeLoops_) {   // poseMatches of the reference (EF/ElasticFusion.h:118): here only counted
+            float lc[24];
+            if (ifx_loop_closure_diag(h_, lc) == IFX_OK) loopCandidates_ = (int)lc[23];
+        }
         tick_++;
         poseGraph_.push_back(currPose_);
         poseLogTimes_.push_back(timestamp);
@@ -189,7 +199,10 @@ public:
     const int& getTimeDelta() { return cfg_.time_delta; }
     const float& getConfidenceThreshold() { return cfg_.confidence; }
     const float& getMaxDepthProcessed() { return cfg_.max_depth_processed; }
-    const int& getDeforms() { return deforms_; }                  // always 0: no loop closure on this path
+    const int& getDeforms() { return deforms_; }                  // always 0: the map is never deformed on this path
+    // frames whose local loop-closure candidate passed the reference's gates (each would have deformed the map in the reference);
+    // 0 at the end of a run = the trajectory and map are what the reference computes with closeLoops and an empty fern data base
+    const int& getLoopClosureCandidates() { return loopCandidates_; }
     const int& getFernDeforms() { return deforms_; }
     bool getCloseLoops() const { return closeLoops_; }
     int getCountThresh() const { return countThresh_; }
@@ -311,6 +324,7 @@ private:
     bool lost_ = false;
     int tick_ = 1;   // EF/ElasticFusion.cpp:48
     int deforms_ = 0;
+    int loopCandidates_ = 0;
     bool closeLoops_, iclnuim_, reloc_, frameToFrameRGB_;
     int countThresh_;
     float errThresh_, covThresh_, photoThresh_, fernThresh_;
@@ -328,12 +342,13 @@ public:
     int width() const { return width_; }
 
     // IF/map_interface/ElasticFusionInterface.cpp:27-58 (the GL context and colour look-up go away; the constants stay)
+    // closeLoops / confidence: the reference passes true / 10; exposed for replays that want the plain pipeline or a quicker map
     virtual bool Init(std::vector<ClassColour> class_colour_lookup, int maxSurfels = 6 * 1000 * 1000, int device = 0,
-                      const std::string& fileName = "./ResultModel")
+                      const std::string& fileName = "./ResultModel", bool closeLoops = true, float confidence = 10.f)
     {
         class_colour_lookup_ = std::move(class_colour_lookup);
         try {
-            elastic_fusion_.reset(new ElasticFusion(200, 35000, 5e-05, 1e-05, true, false, false, 115, 10, 12, 10, false, 0.3095, true, false, fileName,
+            elastic_fusion_.reset(new ElasticFusion(200, 35000, 5e-05, 1e-05, closeLoops, false, false, 115, confidence, 12, 10, false, 0.3095, true, false, fileName,
                                                     maxSurfels, device));
         } catch (const std::exception& e) {
             std::fprintf(stderr, "ElasticFusionInterface::Init: %s\n", e.what());

@@ -21,14 +21,15 @@ struct Args {
     std::string log, masks, out = "./ResultModel", labels;
     int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
     float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
-    bool superpixels = true, flip = false;
+    bool superpixels = true, flip = false, close_loops = true;
+    float confidence = 10.f;
 };
 
 int usage(const char* argv0)
 {
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
-                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K]\n",
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--confidence C]\n",
                  argv0);
     return 2;
 }
@@ -57,6 +58,8 @@ int main(int argc, char** argv)
         else if (s == "--flann-every") flann_skip_frames = std::atoi(val("--flann-every"));
         else if (s == "--device") a.device = std::atoi(val("--device"));
         else if (s == "--no-superpixels") a.superpixels = false;
+        else if (s == "--no-close-loops") a.close_loops = false;
+        else if (s == "--confidence") a.confidence = (float)std::atof(val("--confidence"));
         else if (s == "--flip-colors") a.flip = true;
         else if (s == "--help" || s == "-h") { usage(argv[0]); return 0; }
         else if (!s.empty() && s[0] == '-') { std::fprintf(stderr, "unknown option %s\n", s.c_str()); return usage(argv[0]); }
@@ -77,7 +80,7 @@ int main(int argc, char** argv)
         if (!a.masks.empty()) instancefusion->setMaskSource(std::make_shared<MaskReplay>(a.masks));
 
         std::unique_ptr<ElasticFusionInterface> map(new ElasticFusionInterface());
-        if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out)) {
+        if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out, a.close_loops, a.confidence)) {
             std::cout << "ElasticFusionInterface init failure" << std::endl;
             return 1;
         }
@@ -115,9 +118,9 @@ int main(int argc, char** argv)
         }
         const Matrix4f P = map->getCurrPose();
         std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
-                    "last position %.6f %.6f %.6f\n",
+                    "last position %.6f %.6f %.6f, %d local loop-closure candidates\n",
                     frame_Fusion, dt, frame_Fusion / (dt > 0 ? dt : 1), instancefusion->segmentationCalls(), map->getMapSurfelCount(), n_geo, a.out.c_str(), n_ins,
-                    P(0, 3), P(1, 3), P(2, 3));
+                    P(0, 3), P(1, 3), P(2, 3), map->elasticFusion().getLoopClosureCandidates());
         map.reset();   // ~ElasticFusion writes PREFIX.freiburg
     } catch (const std::exception& e) {
         std::fprintf(stderr, "ifx_replay: %s\n", e.what());

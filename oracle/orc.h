@@ -101,6 +101,11 @@ void orc_tracker_init_model(orc_tracker*, const float* model_v4, const float* mo
                             const uint8_t* model_rgba, const float* pose16);
 void orc_tracker_init_frame(orc_tracker*, const uint16_t* depth_filtered, const uint8_t* rgb,
                             float depth_cutoff);
+/* initICP(predictedVertices, predictedNormals) + initRGB (EF/Utils/RGBDOdometry.cpp:144-167, 243-247): the "current frame" of
+ * the model-to-model tracker is a render of the map (float4 maps in the camera frame, RGBA8 image) */
+void orc_tracker_init_frame_maps(orc_tracker*, const float* v4, const float* n4, const uint8_t* rgba);
+/* getCovariance, EF/Utils/RGBDOdometry.cpp:605-608: inverse of the last normal matrix (row-major 6x6) */
+void orc_tracker_covariance(orc_tracker*, double* cov36);
 /* pose16 in/out (row-major 4x4, camera-to-world); diag[8]: icpErr,icpCount,rgbErr,rgbCount,so3Err,so3Count,0,0 */
 void orc_tracker_run(orc_tracker*, float* pose16, float icp_weight, int pyramid, int fast_odom,
                      int so3, float* diag);
@@ -124,8 +129,18 @@ void orc_map_upload(orc_t*, int n, const float* pc, const float* nr, const float
                     const float* tm, const float* ic, const float* votes);
 void orc_set_pose(orc_t*, const float* pose16, int tick);
 /* images: name in {"ids_after","index","pred_vertex","pred_normal","pred_image","pred_time",
- * "fill_vertex","fill_normal","fill_image","depth_filtered","depth_metric","depth_metric_filtered"} */
+ * "fill_vertex","fill_normal","fill_image","depth_filtered","depth_metric","depth_metric_filtered",
+ * "old_vertex","old_normal","old_image","old_time"} */
 const void* orc_image(orc_t*, const char* name);
+
+/* ---- local loop-closure detection (EF/ElasticFusion.cpp:453-566 without ferns): predict() at the tracked pose, INACTIVE
+ * prediction (surfels not seen for time_delta frames), model-to-model tracking of the active render against the inactive one,
+ * covariance / count / error gates.  Constructor arguments countThresh, errThresh, covThresh (EF/ElasticFusion.h:48-50).
+ * The deformation that follows an accepted candidate is NOT part of the oracle. */
+void orc_set_loop_closure(orc_t*, int enable, int count_thresh, float err_thresh, float cov_thresh);
+/* out[24]: 0 model-to-model ran (0: no inactive pixel in view), 1 valid pixels of the inactive render, 2 lastICPError,
+ * 3 lastICPCount, 4 covOk, 5 accepted, 6..21 estPose (row-major), 22 largest diagonal covariance entry, 23 candidates so far */
+void orc_loop_closure_diag(orc_t*, float* out24);
 
 /* stage-level map entry points operating on the object's map with an explicit pose/time */
 void orc_predict_indices(orc_t*, const float* pose16, int time);

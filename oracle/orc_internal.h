@@ -48,6 +48,14 @@ struct orc {
     int32_t* labels;                  /* bestIDInEachSurfel, length cap */
     int last_seg_frame;
     int clean_times;
+    /* local loop-closure detection (EF/ElasticFusion.cpp:453-566) */
+    int lc_enable, lc_count_thresh, lc_candidates;
+    float lc_err_thresh, lc_cov_thresh;
+    float *old_vertex, *old_normal;
+    uint8_t *old_image, *old_inst;
+    uint16_t* old_time;
+    orc_tracker* m2m;
+    float lc[24];
 };
 
 float orc_encode_color(float r, float g, float b);

@@ -138,6 +138,8 @@ void orc_destroy(orc_t* o)
     free(o->pred_image); free(o->pred_inst); free(o->pred_time); free(o->fill_vertex); free(o->fill_normal);
     free(o->fill_image); free(o->ids_after); free(o->ids_tmp); free(o->zbuf); free(o->newbuf); free(o->updbuf);
     orc_tracker_destroy(o->trk);
+    orc_tracker_destroy(o->m2m);
+    free(o->old_vertex); free(o->old_normal); free(o->old_image); free(o->old_inst); free(o->old_time);
     orc_instance_free(o);
     free(o);
 }
@@ -191,6 +193,10 @@ const void* orc_image(orc_t* o, const char* name)
     if (!strcmp(name, "fill_vertex")) return o->fill_vertex;
     if (!strcmp(name, "fill_normal")) return o->fill_normal;
     if (!strcmp(name, "fill_image")) return o->fill_image;
+    if (!strcmp(name, "old_vertex")) return o->old_vertex;
+    if (!strcmp(name, "old_normal")) return o->old_normal;
+    if (!strcmp(name, "old_image")) return o->old_image;
+    if (!strcmp(name, "old_time")) return o->old_time;
     if (!strcmp(name, "depth_filtered")) return o->depth_filt;
     if (!strcmp(name, "depth_metric")) return o->dm;
     if (!strcmp(name, "depth_metric_filtered")) return o->dmf;
@@ -670,9 +676,60 @@ static void predict(orc_t* o)
     fill_in(o);
 }
 
-/* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Loop closure (ferns, deformation,
- * model-to-model) is out of scope; the first predict() of :453, whose only
- * consumers are those stages, is therefore not executed. */
+void orc_set_loop_closure(orc_t* o, int enable, int count_thresh, float err_thresh, float cov_thresh)
+{
+    o->lc_enable = enable; o->lc_count_thresh = count_thresh; o->lc_err_thresh = err_thresh; o->lc_cov_thresh = cov_thresh;
+    if (enable && !o->m2m) {
+        size_t P = (size_t)o->P;
+        o->old_vertex = (float*)calloc(P * 4, 4); o->old_normal = (float*)calloc(P * 4, 4);
+        o->old_image = (uint8_t*)calloc(P * 4, 1); o->old_inst = (uint8_t*)calloc(P * 4, 1); o->old_time = (uint16_t*)calloc(P, 2);
+        o->m2m = orc_tracker_create(o->w, o->h, o->cfg.fx, o->cfg.fy, o->cfg.cx, o->cfg.cy);
+    }
+}
+void orc_loop_closure_diag(orc_t* o, float* out24) { memcpy(out24, o->lc, sizeof(o->lc)); }
+
+/* EF/ElasticFusion.cpp:453-566 with ferns.lastClosest == -1 (no fern data base): predict(); INACTIVE prediction; model-to-model
+ * tracking; the three gates.  An accepted candidate is only reported (the deformation graph is not restated). */
+static void loop_closure_local(orc_t* o)
+{
+    predict(o);                                                         /* :453 */
+    float *pv = o->pred_vertex, *pn = o->pred_normal;                   /* :519-526: same shader, other framebuffer */
+    uint8_t *pi = o->pred_image, *ps = o->pred_inst;
+    uint16_t* pt = o->pred_time;
+    o->pred_vertex = o->old_vertex; o->pred_normal = o->old_normal; o->pred_image = o->old_image; o->pred_inst = o->old_inst; o->pred_time = o->old_time;
+    orc_combined_predict(o, o->pose, 0, o->tick - o->cfg.time_delta);
+    o->pred_vertex = pv; o->pred_normal = pn; o->pred_image = pi; o->pred_inst = ps; o->pred_time = pt;
+    int n_old = 0;
+    for (int k = 0; k < o->P; k++) n_old += (o->old_vertex[(size_t)k * 4 + 2] != 0);
+    const float cand = o->lc[23];
+    memset(o->lc, 0, sizeof(o->lc));
+    o->lc[1] = (float)n_old; o->lc[23] = cand;
+    memcpy(&o->lc[6], o->pose, 64);
+    if (n_old == 0) return;   /* every reduction would be empty: count 0 fails the gate whatever the rest computes */
+    orc_tracker_init_model(o->m2m, o->old_vertex, o->old_normal, o->old_image, o->pose);      /* :530-531 */
+    orc_tracker_init_frame_maps(o->m2m, o->pred_vertex, o->pred_normal, o->pred_image);        /* :533-534 */
+    float est[16], diag[8];
+    memcpy(est, o->pose, 64);
+    orc_tracker_run(o->m2m, est, 10.0f, o->cfg.pyramid, o->cfg.fast_odom, 0, diag);          /* :539-545 */
+    double cov[36];
+    orc_tracker_covariance(o->m2m, cov);
+    int cov_ok = 1;
+    double cmax = 0;
+    for (int i = 0; i < 6; i++) {
+        if (cov[i * 6 + i] > o->lc_cov_thresh) { cov_ok = 0; }
+        if (!(cov[i * 6 + i] <= cmax)) cmax = cov[i * 6 + i];
+    }
+    const int accept = cov_ok && diag[1] > (float)o->lc_count_thresh && diag[0] < o->lc_err_thresh;   /* :566 */
+    o->lc[0] = 1; o->lc[2] = diag[0]; o->lc[3] = diag[1]; o->lc[4] = (float)cov_ok; o->lc[5] = (float)accept;
+    memcpy(&o->lc[6], est, 64);
+    o->lc[22] = (float)cmax;
+    o->lc_candidates += accept;
+    o->lc[23] = (float)o->lc_candidates;
+}
+
+/* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Of the loop-closure block (:450-617) only the local detection
+ * is restated (loop_closure_local, when enabled); ferns and the deformation graph are out of scope, and without
+ * the detection the predict() of :453, whose only consumers are those stages, is not executed. */
 int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64_t ts,
                       const float* in_pose16, float weight_mult, float* out_pose16)
 {
@@ -715,6 +772,7 @@ int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64
         if (weighting > largest) weighting = largest;
         weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
         o->last_weighting = weighting;
+        if (o->lc_enable) loop_closure_local(o);
 
         orc_predict_indices(o, o->pose, o->tick);
         orc_fuse(o, o->pose, o->tick, weighting);

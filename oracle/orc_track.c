@@ -573,6 +573,42 @@ void orc_tracker_init_frame(orc_tracker* t, const uint16_t* depth_filtered, cons
     populate_rgbd(t, rgb, 3, t->next_depth, t->next_img);
 }
 
+/* initICP(predictedVertices, predictedNormals, depthCutoff) + initRGB(predictedImage), EF/Utils/RGBDOdometry.cpp:144-167, 243-247.
+ * Unlike the depth-image variant this one DOES refresh vmaps_tmp, so nextDepth is the depth of these vertices. */
+void orc_tracker_init_frame_maps(orc_tracker* t, const float* v4, const float* n4, const uint8_t* rgba)
+{
+    memcpy(t->vmaps_tmp, v4, (size_t)t->w * t->h * 16);
+    orc_copy_maps(v4, n4, t->w, t->h, t->vmap_curr[0], t->nmap_curr[0]);
+    for (int i = 1; i < ORC_NUM_PYRS; i++) {
+        orc_resize_map(t->vmap_curr[i - 1], t->lw[i - 1], t->lh[i - 1], t->vmap_curr[i], 0);
+        orc_resize_map(t->nmap_curr[i - 1], t->lw[i - 1], t->lh[i - 1], t->nmap_curr[i], 1);
+    }
+    populate_rgbd(t, rgba, 4, t->next_depth, t->next_img);
+}
+
+/* getCovariance, EF/Utils/RGBDOdometry.cpp:605-608: lastA.cast<double>().lu().inverse() -- Gauss-Jordan with partial
+ * pivoting (the same elimination order as the partial-pivot LU).  A singular matrix gives non-finite entries. */
+void orc_tracker_covariance(orc_tracker* t, double* cov)
+{
+    double a[6][12];
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) { a[r][c] = t->lastA[r * 6 + c]; a[r][6 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int k = 0; k < 6; k++) {
+        int piv = k;
+        for (int r = k + 1; r < 6; r++) if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
+        if (piv != k) for (int c = 0; c < 12; c++) { double tmp = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = tmp; }
+        double d = 1.0 / a[k][k];
+        for (int c = 0; c < 12; c++) a[k][c] *= d;
+        for (int r = 0; r < 6; r++) {
+            if (r == k) continue;
+            double f = a[r][k];
+            for (int c = 0; c < 12; c++) a[r][c] -= f * a[k][c];
+        }
+    }
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) cov[r * 6 + c] = a[r][6 + c];
+}
+
 const void* orc_tracker_buffer(orc_tracker* t, const char* name, int l)
 {
     if (!strcmp(name, "vmap_curr")) return t->vmap_curr[l];

@@ -93,6 +93,7 @@ _IMG_SPECS = {
     "index_ct": (np.float32, 4), "index_nr": (np.float32, 4), "pred_vertex": (np.float32, 4),
     "pred_normal": (np.float32, 4), "pred_image": (np.uint8, 4), "pred_inst": (np.uint8, 4), "pred_time": (np.uint16, 1),
     "fill_vertex": (np.float32, 4), "fill_normal": (np.float32, 4), "fill_image": (np.uint8, 4),
+    "old_vertex": (np.float32, 4), "old_normal": (np.float32, 4), "old_image": (np.uint8, 4), "old_time": (np.uint16, 1),
     "depth_filtered": (np.uint16, 1), "depth_metric": (np.float32, 1), "depth_metric_filtered": (np.float32, 1),
 }
 
@@ -154,6 +155,18 @@ class Oracle:
         buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p)
         a = np.frombuffer(buf, dtype=dt).copy()
         return a.reshape(self.h_, self.w_, ch) if ch > 1 else a.reshape(self.h_, self.w_)
+
+    # ---- local loop-closure detection (EF/ElasticFusion.cpp:453-566)
+    def set_loop_closure(self, enable=True, count_thresh=35000, err_thresh=5e-5, cov_thresh=1e-5):
+        self.L.orc_set_loop_closure.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        self.L.orc_set_loop_closure(self.h, int(enable), int(count_thresh), err_thresh, cov_thresh)
+
+    def loop_closure_diag(self):
+        out = np.zeros(24, np.float32)
+        self.L.orc_loop_closure_diag.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_loop_closure_diag(self.h, ptr(out))
+        return dict(ran=bool(out[0]), inactive_pixels=int(out[1]), icp_error=float(out[2]), icp_count=float(out[3]), cov_ok=bool(out[4]),
+                    accepted=bool(out[5]), est_pose=out[6:22].reshape(4, 4).copy(), cov_max=float(out[22]), candidates=int(out[23]))
 
     def predict_indices(self, pose, time):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)

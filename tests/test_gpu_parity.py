@@ -862,3 +862,88 @@ def test_sharded_rccl_world_of_one(ifx, small_stream):
         a.close(); b.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- 8f-3a: local loop-closure detection (INACTIVE prediction + model-to-model tracking + gates)
+def test_loop_closure_detection(ifx, orc, small_stream):
+    """EF/ElasticFusion.cpp:453-566 without ferns.  A 3-frame time window makes most of the map 'inactive' from the fourth
+    frame on, so the model-to-model tracker has something to align on the 10-frame stream played forth and back."""
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    thr = 35000 * (SMALL["w"] * SMALL["h"]) // (640 * 480)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+    g0 = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)          # same run without the detection
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    for e in (g, g0):
+        e.set_option("compact_every_frame", 1)
+    g.set_loop_closure(True, thr, 1e-4, 1e-5)
+    o.set_loop_closure(True, thr, 1e-4, 1e-5)
+    seq = list(range(10)) + list(range(8, 2, -1))
+    n_ran = 0
+    po = None
+    for k, i in enumerate(seq):
+        strict = k >= 10
+        if k >= 3:
+            # Both sides start every frame from the oracle's map and pose: this configuration (3-frame window) tracks against a sparse
+            # prediction and free-running trajectories drift apart by > 1e-4 within ten frames, which is not what is tested here.
+            m, tick0, po_prev = o.download(), o.tick, po
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        if k >= 3:
+            for e in (g, g0):
+                e.upload(m); e.set_pose(po_prev, tick0)
+        # frames 3..9: the GPU tracks by itself (poses agree to ~1e-6, not bit for bit); frames 10..: it is handed the oracle's pose, so that
+        # the renders the model-to-model tracker aligns are identical on both sides
+        pg = g.processFrame(st["rgb"][i], st["depth"][i], inPose=po if strict else None)
+        p0 = g0.processFrame(st["rgb"][i], st["depth"][i], inPose=po if strict else None)
+        assert np.array_equal(pg, p0), k                               # the detection has no side effect on the frame
+        assert np.abs(pg - po).max() < 1e-4, k
+        dg, do = g.loop_closure_diag(), o.loop_closure_diag()
+        assert dg["ran"] == do["ran"], (k, dg, do)
+        if k == 2:                                                     # every surfel stable from here on (only stable ones are predicted)
+            m = o.download(); m["pc"][:, 3] = 20.0; o.upload(m)
+        if k < 3:
+            assert not dg["ran"] and dg["inactive_pixels"] == 0 and not dg["accepted"]
+            assert k == 0 or np.array_equal(dg["est_pose"], pg)      # (the first frame only initialises the map)
+            continue
+        n_ran += dg["ran"]
+        assert dg["cov_ok"] == do["cov_ok"] and dg["accepted"] == do["accepted"], (k, dg, do)
+        if strict:
+            for name in ("old_vertex", "old_normal", "old_image", "old_time"):
+                assert np.array_equal(g.image(name), o.image(name)), (k, name)
+            assert dg["inactive_pixels"] == do["inactive_pixels"] > 1000 and dg["icp_count"] == do["icp_count"], (k, dg, do)
+            assert abs(dg["icp_error"] - do["icp_error"]) <= 1e-3 * do["icp_error"], (k, dg, do)
+            assert abs(dg["cov_max"] - do["cov_max"]) <= 1e-3 * abs(do["cov_max"]), (k, dg, do)
+            assert np.abs(dg["est_pose"] - do["est_pose"]).max() < 2e-5, k
+        else:
+            # a 1e-7 difference of the pose moves a few pixels of the two renders (u8 colours, z-buffer winners) and the alignment of two
+            # noisy renders answers with up to a few 1e-4: gates and sums are compared tightly, the estimate loosely
+            assert abs(dg["inactive_pixels"] - do["inactive_pixels"]) <= max(4, do["inactive_pixels"] // 1000), (k, dg, do)
+            assert abs(dg["icp_count"] - do["icp_count"]) <= max(8.0, do["icp_count"] * 0.002), (k, dg, do)
+            assert abs(dg["icp_error"] - do["icp_error"]) <= 0.01 * do["icp_error"], (k, dg, do)
+            assert abs(dg["cov_max"] - do["cov_max"]) <= 0.01 * abs(do["cov_max"]), (k, dg, do)
+            assert np.abs(dg["est_pose"] - do["est_pose"]).max() < 1e-3, k
+    assert n_ran >= 10
+    assert g.loop_closure_diag()["candidates"] == o.loop_closure_diag()["candidates"] > 0
+    assert g.count == g0.count and all(np.array_equal(a, b) for a, b in zip(g.download().values(), g0.download().values()))
+    g.close(); g0.close(); o.close()
+
+
+def test_loop_closure_detection_nothing_inactive(ifx, small_stream):
+    """Default 200-frame window: nothing can be inactive on a short stream -> the block is skipped, results and candidates untouched;
+    with an uploaded map (unknown times) the INACTIVE render runs, finds nothing and the tracker kernels return at once."""
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g0 = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_loop_closure(True)
+    for i in range(5):
+        assert np.array_equal(g.processFrame(st["rgb"][i], st["depth"][i]), g0.processFrame(st["rgb"][i], st["depth"][i]))
+        d = g.loop_closure_diag()
+        assert not d["ran"] and d["candidates"] == 0
+    m = g.download()
+    g.upload(m); g0.upload(m)
+    for i in range(5, 8):
+        assert np.array_equal(g.processFrame(st["rgb"][i], st["depth"][i]), g0.processFrame(st["rgb"][i], st["depth"][i]))
+        d = g.loop_closure_diag()
+        assert not d["ran"] and d["inactive_pixels"] == 0 and not d["accepted"]
+    assert all(np.array_equal(a, b) for a, b in zip(g.download().values(), g0.download().values()))
+    g.close(); g0.close()

@@ -156,19 +156,20 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     from instancefusion_amd import logio, synth
 
     st = small_stream
-    n = 8
+    n = 16                                                    # long enough for surfels to become stable (confidence > 10) and take labels
+    src = [i if i < 10 else 18 - i for i in range(n + 1)]     # the 10-frame stream forth and back
     klg = str(tmp_path / "s.klg")
     wr = logio.RawLogWriter(klg, depth="zlib", image="raw")
     for i in range(n + 1):
-        wr.add(33333 * i, st["rgb"][min(i, n - 1)], st["depth"][min(i, n - 1)])
+        wr.add(33333 * i, st["rgb"][src[i]], st["depth"][src[i]])
     wr.close()
     mdir = tmp_path / "masks"
     mdir.mkdir()
     for i in range(n):
-        mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+        mk, cl = synth.canned_masks(st["obj"][src[i]], st["scene"])
         (np.savez_compressed if i % 2 else np.savez)(mdir / f"{i:06d}.npz", masks=mk, class_ids=cl)
     common = ["--width", str(SMALL["w"]), "--height", str(SMALL["h"]), "--fx", str(SMALL["fx"]), "--fy", str(SMALL["fy"]), "--cx", str(SMALL["cx"]),
-              "--cy", str(SMALL["cy"]), "--max-surfels", "400000", "--masks", str(mdir), "--flann-every", "2"]
+              "--cy", str(SMALL["cy"]), "--max-surfels", "400000", "--masks", str(mdir), "--flann-every", "2", "--confidence", "2"]
     out_c = str(tmp_path / "C")
     r = subprocess.run([REPLAY, klg] + common + ["--out", out_c, "--labels", out_c + ".labels"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -177,9 +178,11 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     out_p = str(tmp_path / "P")
-    assert mod.main([klg] + common + ["--out", out_p]) == 0
+    assert mod.main([klg] + common + ["--out", out_p, "--labels", out_p + ".labels"]) == 0
     assert open(out_c + ".freiburg").read() == open(out_p + ".freiburg").read()
     for suffix in (".ply", "_Instance.ply"):
         assert open(out_c + suffix, "rb").read() == open(out_p + suffix, "rb").read(), suffix
     lab = np.fromfile(out_c + ".labels", np.int32)
-    assert lab.size > 0 and (lab >= 0).any()
+    assert lab.size > 0 and np.array_equal(lab, np.fromfile(out_p + ".labels", np.int32))
+    head = open(out_c + ".ply", "rb").read(200)
+    assert int(head.split(b"element vertex ")[1].split(b"\n")[0]) > 1000          # stable surfels were exported

@@ -330,3 +330,47 @@ def test_knn_vote_against_scipy(orc):
             cnt = np.bincount(ls, minlength=96)
             assert after[i] != 0 and (cnt.max() > 0)
     o.close()
+
+
+# ---------------------------------------------------------------- local loop-closure detection (EF/ElasticFusion.cpp:453-566)
+def test_loop_closure_detection_properties(orc, small_stream):
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    thr = 35000 * (SMALL["w"] * SMALL["h"]) // (640 * 480)
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    o0 = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    o.set_loop_closure(True, thr, 1e-4, 1e-5)
+    for k in range(7):
+        p = o.process_frame(st["rgb"][k], st["depth"][k])
+        assert np.array_equal(p, o0.process_frame(st["rgb"][k], st["depth"][k]))       # detection only: no side effect
+        d = o.loop_closure_diag()
+        if k == 2:                                                                     # every surfel stable from here on (only stable ones are predicted)
+            for e in (o, o0):
+                m = e.download(); m["pc"][:, 3] = 20.0; e.upload(m)
+        if k < 3:                                                                      # nothing can be 3 frames old yet
+            assert not d["ran"] and d["inactive_pixels"] == 0 and (k == 0 or np.array_equal(d["est_pose"], p))   # (the first frame only initialises the map)
+        else:
+            assert d["ran"] and d["inactive_pixels"] > 0.5 * SMALL["w"] * SMALL["h"]
+            assert d["icp_count"] > thr and d["cov_ok"] and 0 < d["cov_max"] < 1e-5
+            # active and inactive surfels lie on the same static surfaces: the alignment is (nearly) the identity
+            assert np.abs(d["est_pose"][:3, 3] - p[:3, 3]).max() < 0.02
+            assert d["accepted"] == (d["icp_error"] < 1e-4)
+    assert o.count == o0.count and all(np.array_equal(a, b) for a, b in zip(o.download().values(), o0.download().values()))
+    # the INACTIVE render holds only surfels at least time_delta frames old
+    m = o.download()
+    old_ids = set(np.flatnonzero(m["tm"][:, 1] <= o.tick - 1 - 3).tolist())     # lastTime <= tick - timeDelta at the time of the render
+    assert len(old_ids) > 0
+    # gates: an impossible error threshold accepts nothing
+    o.set_loop_closure(True, thr, 0.0, 1e-5)
+    o.process_frame(st["rgb"][7], st["depth"][7])
+    d = o.loop_closure_diag()
+    assert d["ran"] and not d["accepted"]
+    # a singular normal matrix gives a non-finite covariance, never a crash
+    L = orc.lib()
+    t = L.orc_tracker_create(64, 48, 50.0, 50.0, 32.0, 24.0)
+    cov = np.zeros(36, np.float64)
+    L.orc_tracker_covariance.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_tracker_covariance(t, cov.ctypes.data_as(C.c_void_p))
+    assert not np.isfinite(cov).all()
+    L.orc_tracker_destroy(t)
+    o.close(); o0.close()

@@ -41,6 +41,9 @@ def main(argv=None):
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--flann-every", type=int, default=40, help="kNN smoothing when a segmentation happens more than this many frames after the last one (IF/main.cpp:36)")
     ap.add_argument("--flip-colors", action="store_true")
+    ap.add_argument("--confidence", type=float, default=10.0, help="surfel stability threshold (the reference's constructor argument)")
+    ap.add_argument("--no-close-loops", action="store_true", help="switch the local loop-closure detection off (the reference runs with closeLoops = true)")
+    ap.add_argument("--labels", default=None, help="write bestIDInEachSurfel of the live surfels (int32, map order) to this file")
     args = ap.parse_args(argv)
 
     import torch  # noqa: F401  (binds the HIP runtime first)
@@ -52,7 +55,9 @@ def main(argv=None):
         reader = logio.PNGLogReader(args.log, args.width, args.height)
     else:
         reader = logio.RawLogReader(args.log, args.width, args.height, flipColors=args.flip_colors)
-    ef = ifx.ElasticFusion(w=args.width, h=args.height, fx=args.fx, fy=args.fy, cx=args.cx, cy=args.cy, max_surfels=args.max_surfels)
+    ef = ifx.ElasticFusion(w=args.width, h=args.height, fx=args.fx, fy=args.fy, cx=args.cx, cy=args.cy, max_surfels=args.max_surfels, confidence=args.confidence)
+    if not args.no_close_loops:
+        ef.set_loop_closure(True, 35000, 5e-5, 1e-5)       # IF/map_interface/ElasticFusionInterface.cpp:43-45
     inst = ifx.InstanceFusion(ef)
     stamps, poses = [], []
     frame, last_flann, n_seg = 0, -1, 0     # lastTimeFlann = -1, IF/main.cpp:111
@@ -75,10 +80,13 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     logio.save_freiburg(args.out + ".freiburg", stamps, poses)
     m = ef.download()
-    n_geo = logio.save_ply(args.out + ".ply", m, confidence=10.0)
-    n_ins = logio.save_ply(args.out + "_Instance.ply", m, confidence=10.0, instance=True)
+    n_geo = logio.save_ply(args.out + ".ply", m, confidence=args.confidence)
+    n_ins = logio.save_ply(args.out + "_Instance.ply", m, confidence=args.confidence, instance=True)
+    if args.labels:
+        inst.labels().astype(np.int32).tofile(args.labels)
     print(f"{frame} frames in {dt:.2f} s ({frame / max(dt, 1e-9):.1f} frames/s incl. log decoding), {n_seg} segmentation calls, {ef.count} surfels, "
-          f"{n_geo} stable surfels -> {args.out}.ply / _Instance.ply ({n_ins}), trajectory -> {args.out}.freiburg")
+          f"{n_geo} stable surfels -> {args.out}.ply / _Instance.ply ({n_ins}), trajectory -> {args.out}.freiburg, "
+          f"{ef.loop_closure_diag()['candidates'] if not args.no_close_loops else 0} local loop-closure candidates")
     ef.close()
     return 0
 

@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
+    ap.add_argument("--close-loops", action="store_true", help="also run the local loop-closure detection every frame (the reference's closeLoops = true: predict() at the "
+                    "tracked pose, INACTIVE prediction, model-to-model tracking, gates; thresholds of IF/map_interface/ElasticFusionInterface.cpp:43-45)")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     args = ap.parse_args()
 
@@ -111,6 +113,8 @@ def main():
     ef.combined_predict(st["poses"][0], tick0, tick0)
     del m
 
+    if args.close_loops:
+        ef.set_loop_closure(True, 35000, 5e-5, 1e-5)
     frame_no = [0]
     sh = None
     if args.sharded:
@@ -196,7 +200,7 @@ def main():
         # MI355X_MICROARCH.md prescribes for gfx950; collected offline on this same command, see profiles/README.md)
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")) as f:
                 pmc = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
             pass
@@ -243,10 +247,11 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}, {args.surfels}-surfel map",
+            "config": {"workload": f"{W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}, {args.surfels}-surfel map",
                        "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"sharded projection x{world}" if args.sharded else f"replicas x{world}"), "loop_frames": L},
             "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
             "ate_rms_m": ate, "gen_s": round(t_gen, 1),
+            **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

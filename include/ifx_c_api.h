@@ -117,6 +117,25 @@ int ifx_tracker_diag(ifx_t* h, float* diag8);
  * 5 accepted, 6..21 estimated pose (row-major 4x4), 22 largest diagonal covariance entry, 23 candidates accepted so far. */
 int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, float err_thresh, float cov_thresh);
 int ifx_loop_closure_diag(ifx_t* h, float* out24);
+/* ---- hooks for the deformation that follows an accepted candidate (EF/ElasticFusion.cpp:566-613).  The graph OPTIMISATION is host code
+ * of the reference (Deformation / DeformationGraph: Eigen + cholmod) and stays with the caller; the library provides what touched the GPU:
+ * ifx_set_loop_closure_callback: cb runs inside ifx_process_frame / ifx_enqueue_frame_device right after the gates of a frame whose candidate
+ *   was accepted (the frame waits for the verdict: one host synchronisation per frame while a callback is set).  From the callback:
+ * ifx_sample_graph_model: Deformation::sampleGraphModel (EF/Deformation.cpp:224-337, sample.geom): x, y, z, init time of every 5000th surfel
+ *   of the map order (the map state is the one the reference samples at the end of the previous frame); returns the number written.
+ * ifx_loop_closure_constraints: the samples of :568-598 -- ACTIVE vertex render and INACTIVE time render on a (w/20) x (h/20) grid; per valid
+ *   sample worldRawPoint = currPose * v (src3), worldModelPoint = estPose * v (dst3) and the surfel time (times); returns the count.
+ * ifx_set_deformation: the `graph` argument of GlobalModel::clean (EF/GlobalModel.cpp:700-760): n_nodes x 16 floats (position 3, rotation 9
+ *   column-major, translation 3, time), sorted by time, 4 <= n_nodes < 1024.  The NEXT clean (of this frame when called from the callback)
+ *   applies it to every surviving surfel not created in that frame (copy_unstable.vert:178-374) and, for a local loop closure
+ *   (is_fern = 0), refreshes the time stamp of moved stable surfels in front of the re-rendered INACTIVE depth (IndexMap::synthesizeDepth).
+ * ifx_adopt_estimated_pose: currPose = estPose (:606). */
+typedef int (*ifx_loop_closure_cb)(ifx_t* h, const float* lc24, void* user);
+int ifx_set_loop_closure_callback(ifx_t* h, ifx_loop_closure_cb cb, void* user);
+int ifx_sample_graph_model(ifx_t* h, float* out_xyzt, int max_n);
+int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, int32_t* times, int max_n);
+int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern);
+int ifx_adopt_estimated_pose(ifx_t* h);
 
 /* ---- map access (replaces getMapSurfelsGpu / getMapSurfelCount / id textures,
  * IF/map_interface/ElasticFusionInterface.h:55-120).  The store is struct-of-arrays; slots whose

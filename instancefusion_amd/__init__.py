@@ -79,6 +79,11 @@ _SIGS = {
     "ifx_tracker_diag": (C.c_int, [_P, _P]),
     "ifx_set_loop_closure": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "ifx_loop_closure_diag": (C.c_int, [_P, _P]),
+    "ifx_set_loop_closure_callback": (C.c_int, [_P, _P, _P]),
+    "ifx_sample_graph_model": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_loop_closure_constraints": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "ifx_set_deformation": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "ifx_adopt_estimated_pose": (C.c_int, [_P]),
     "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
     "ifx_map_count": (C.c_int, [_P]),
     "ifx_map_slots": (C.c_int, [_P]),
@@ -252,6 +257,44 @@ class ElasticFusion:
         self._chk(self.L.ifx_loop_closure_diag(self.handle, _ptr(out)), "ifx_loop_closure_diag")
         return dict(ran=bool(out[0]), inactive_pixels=int(out[1]), icp_error=float(out[2]), icp_count=float(out[3]), cov_ok=bool(out[4]),
                     accepted=bool(out[5]), est_pose=out[6:22].reshape(4, 4).copy(), cov_max=float(out[22]), candidates=int(out[23]))
+
+    # -- hooks of the deformation an accepted candidate triggers (the graph optimisation itself is the caller's)
+    def set_loop_closure_callback(self, fn):
+        """fn(ef, lc24) runs inside processFrame when the frame's candidate was accepted (None removes it)."""
+        if fn is None:
+            self._lc_cb = None
+            self._chk(self.L.ifx_set_loop_closure_callback(self.handle, None, None), "ifx_set_loop_closure_callback")
+            return
+
+        def tramp(_h, lc, _user):
+            try:
+                fn(self, np.ctypeslib.as_array(lc, shape=(24,)).copy())
+                return 0
+            except Exception:      # never unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        self._lc_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_void_p)(tramp)
+        self._chk(self.L.ifx_set_loop_closure_callback(self.handle, C.cast(self._lc_cb, C.c_void_p), None), "ifx_set_loop_closure_callback")
+
+    def sample_graph_model(self, max_n=4096):
+        out = np.zeros((max_n, 4), np.float32)
+        n = self._chk(self.L.ifx_sample_graph_model(self.handle, _ptr(out), max_n), "ifx_sample_graph_model")
+        return out[:n].copy()
+
+    def loop_closure_constraints(self, max_n=4096):
+        src, dst, tm = np.zeros((max_n, 3), np.float32), np.zeros((max_n, 3), np.float32), np.zeros(max_n, np.int32)
+        n = self._chk(self.L.ifx_loop_closure_constraints(self.handle, _ptr(src), _ptr(dst), _ptr(tm), max_n), "ifx_loop_closure_constraints")
+        return src[:n].copy(), dst[:n].copy(), tm[:n].copy()
+
+    def set_deformation(self, graph16, is_fern=False):
+        g = np.ascontiguousarray(graph16, np.float32).reshape(-1, 16)
+        self._chk(self.L.ifx_set_deformation(self.handle, _ptr(g), g.shape[0], int(is_fern)), "ifx_set_deformation")
+
+    def adopt_estimated_pose(self):
+        self._chk(self.L.ifx_adopt_estimated_pose(self.handle), "ifx_adopt_estimated_pose")
 
     # -- map access (getMapSurfelCount / getMapSurfelsGpu / id textures)
     def getMapSurfelCount(self):

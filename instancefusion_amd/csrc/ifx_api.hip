@@ -173,6 +173,12 @@ extern "C" int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, floa
     h->lc_enable = enable ? 1 : 0; h->lc_count_thresh = count_thresh; h->lc_err_thresh = err_thresh; h->lc_cov_thresh = cov_thresh;
     return IFX_OK;
 }
+extern "C" int ifx_set_loop_closure_callback(ifx_t* h, ifx_loop_closure_cb cb, void* user)
+{
+    if (!h) return IFX_E_INVALID;
+    h->lc_cb = cb; h->lc_user = user;
+    return IFX_OK;
+}
 extern "C" int ifx_loop_closure_diag(ifx_t* h, float* out24)
 {
     if (!h || !out24) return IFX_E_INVALID;
@@ -279,8 +285,22 @@ static int enqueue_loop_closure_detection(ifx* h)
         ifx_tracker_m2m_begin(h);
         ifx_map_predict_loop_closure(h);
     }
-    StageTimer t(h, 0);
-    return ifx_tracker_loop_closure(h);
+    {
+        StageTimer t(h, 0);
+        int r = ifx_tracker_loop_closure(h);
+        if (r) return r;
+    }
+    if (h->lc_cb) {   // the caller deforms the map on an accepted candidate: it needs the verdict before the map passes are enqueued
+        HIPCHK(h, hipMemcpyAsync(h->h_result->lc, h->d_state->lc, sizeof(h->h_result->lc), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->h_result->lc[5] != 0.f) {
+            float lc[24];
+            memcpy(lc, h->h_result->lc, sizeof(lc));
+            int r = h->lc_cb(h, lc, h->lc_user);
+            if (r < 0) { h->err = "loop-closure callback failed"; return r; }
+        }
+    }
+    return IFX_OK;
 }
 
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)

@@ -132,6 +132,11 @@ struct ifx {
     float *old_vertex = nullptr, *old_normal = nullptr;
     uint8_t *old_image = nullptr, *old_inst = nullptr;
     uint16_t* old_time = nullptr;
+    float* d_graph = nullptr;           // deformation graph handed in for the next clean (ifx_set_deformation): nodes x 16 floats
+    int graph_nodes = 0, graph_is_fern = 0;
+    float *d_sample = nullptr, *d_cons = nullptr;   // scratch of ifx_sample_graph_model / ifx_loop_closure_constraints
+    ifx_loop_closure_cb lc_cb = nullptr;
+    void* lc_user = nullptr;
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned
@@ -220,6 +225,14 @@ void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
         hipEvent_t ea_ = nullptr;                                                                  \
         if ((h)->opt_kernel_timing) ifx_ktime_begin((h), name, &ea_);                              \
         hipLaunchKernelGGL(kernel, grid, block, 0, (h)->cur, __VA_ARGS__);                      \
+        if ((h)->opt_kernel_timing) ifx_ktime_end((h), name, ea_);                                 \
+    } while (0)
+
+#define LAUNCH_SMEM(h, name, grid, block, smem, kernel, ...)                                      \
+    do {                                                                                           \
+        hipEvent_t ea_ = nullptr;                                                                  \
+        if ((h)->opt_kernel_timing) ifx_ktime_begin((h), name, &ea_);                              \
+        hipLaunchKernelGGL(kernel, grid, block, smem, (h)->cur, __VA_ARGS__);                   \
         if ((h)->opt_kernel_timing) ifx_ktime_end((h), name, ea_);                                 \
     } while (0)
 

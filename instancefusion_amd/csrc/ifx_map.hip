@@ -1134,10 +1134,158 @@ static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
            (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm);
 }
 
+// ------------------------------------------------------------------ loop-closure hooks on the map
+// Deformation-graph application of copy_unstable.vert:178-374 for every surviving surfel that was not created this frame: binary search of the
+// node nearest in time, the 20 nodes around it in the (time-sorted) sequence, the 4 nearest of those in space with weights (1 - d / d5)^2,
+// blended rigid motions; then (stable surfels, local loop closure) the time stamp is refreshed when the moved surfel lies in front of the
+// re-rendered INACTIVE model depth (IndexMap::synthesizeDepth).  The graph (<= 1023 nodes x 64 B) is staged in LDS.
+__global__ __launch_bounds__(256) void k_deform(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float* __restrict__ graph, int nodes, int is_fern,
+                                                 int time, Cam c, const float4* __restrict__ depth_v4, float4* __restrict__ pc, float4* __restrict__ nr, float2* __restrict__ tm)
+{
+    extern __shared__ float g[];
+    for (int k = threadIdx.x; k < nodes * 16; k += blockDim.x) g[k] = graph[k];
+    __syncthreads();
+    const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float2 t2 = tm[i];
+        if (!(t2.y > DEAD_TIME) || t2.x == (float)time) continue;   // tombstone / created this frame (fused with the updated pose already)
+        float4 p4 = pc[i], n4 = nr[i];
+        const int K = 4, LOOK = 20;
+        int nearNodes[LOOK];
+        float nearDists[LOOK];
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) { nearNodes[q] = -1; nearDists[q] = 16777216.0f; }
+        const int poseTime = (int)t2.x;
+        int foundIndex = 0, imin = 0, imax = nodes - 1, imid = (imin + imax) / 2;
+        while (imax >= imin) {
+            imid = (imin + imax) / 2;
+            const int nodeTime = (int)g[imid * 16 + 15];
+            if (nodeTime < poseTime) imin = imid + 1;
+            else if (nodeTime > poseTime) imax = imid - 1;
+            else break;
+        }
+        imin = min(imin, nodes - 1);
+        const int cmax = imax < 0 ? 0 : imax;   // see oracle/orc_deform.c: an index clamp instead of the shader's out-of-range texel
+        const int nodeMin = (int)g[imin * 16 + 15], nodeMid = (int)g[imid * 16 + 15], nodeMax = (int)g[cmax * 16 + 15];
+        if (abs(nodeMin - poseTime) <= abs(nodeMid - poseTime) && abs(nodeMin - poseTime) <= abs(nodeMax - poseTime)) foundIndex = imin;
+        else if (abs(nodeMid - poseTime) <= abs(nodeMin - poseTime) && abs(nodeMid - poseTime) <= abs(nodeMax - poseTime)) foundIndex = imid;
+        else foundIndex = cmax;
+        if (foundIndex == nodes) foundIndex = nodes - 1;
+        int nearNodeIndex = 0, distanceBack = 0;
+        const v3 p = v3m(p4.x, p4.y, p4.z);
+        for (int j = foundIndex; j >= 0; j--) {
+            const v3 d = p - v3m(g[j * 16], g[j * 16 + 1], g[j * 16 + 2]);
+            nearNodes[nearNodeIndex] = j;
+            nearDists[nearNodeIndex] = sqrtf(dot(d, d));
+            nearNodeIndex++;
+            if (++distanceBack == LOOK / 2) break;
+        }
+        for (int j = foundIndex + 1; j < nodes; j++) {
+            const v3 d = p - v3m(g[j * 16], g[j * 16 + 1], g[j * 16 + 2]);
+            nearNodes[nearNodeIndex] = j;
+            nearDists[nearNodeIndex] = sqrtf(dot(d, d));
+            nearNodeIndex++;
+            if (++distanceBack == LOOK) break;
+        }
+        for (int a = 0; a < LOOK - 1; ++a)
+            for (int b = a + 1; b < LOOK; ++b)
+                if (nearDists[b] < nearDists[a]) {
+                    const float t = nearDists[a]; nearDists[a] = nearDists[b]; nearDists[b] = t;
+                    const int u = nearNodes[a]; nearNodes[a] = nearNodes[b]; nearNodes[b] = u;
+                }
+        const float dMax = nearDists[K];
+        float wgt[K], weightSum = 0;
+        for (int j = 0; j < K; j++) {
+            const float* nd = &g[nearNodes[j] * 16];
+            const v3 d = p - v3m(nd[0], nd[1], nd[2]);
+            const float u = 1.0f - (sqrtf(dot(d, d)) / dMax);
+            wgt[j] = u * u;
+            weightSum += wgt[j];
+        }
+        for (int j = 0; j < K; j++) wgt[j] /= weightSum;
+        v3 newPos = v3m(0, 0, 0), newNorm = v3m(0, 0, 0);
+        for (int q = 0; q < K; q++) {
+            const float* nd = &g[nearNodes[q] * 16];
+            const v3 gp = v3m(nd[0], nd[1], nd[2]);
+            const float R[9] = {nd[3], nd[6], nd[9], nd[4], nd[7], nd[10], nd[5], nd[8], nd[11]};   // mat3(column0, column1, column2), row-major here
+            const v3 tr = v3m(nd[12], nd[13], nd[14]);
+            const v3 qd = p - gp;
+            const v3 rq = v3m(R[0] * qd.x + R[1] * qd.y + R[2] * qd.z, R[3] * qd.x + R[4] * qd.y + R[5] * qd.z, R[6] * qd.x + R[7] * qd.y + R[8] * qd.z);
+            newPos = newPos + ((rq + gp) + tr) * wgt[q];
+            // transpose(inverse(rotation)): general 3x3 inverse in cofactor form
+            const float c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+            const float det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+            const float id = 1.0f / det;
+            const float Ri[9] = {c00 * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id, c01 * id, (R[0] * R[8] - R[2] * R[6]) * id,
+                                 (R[2] * R[3] - R[0] * R[5]) * id, c02 * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+            const v3 nv = v3m(Ri[0] * n4.x + Ri[3] * n4.y + Ri[6] * n4.z, Ri[1] * n4.x + Ri[4] * n4.y + Ri[7] * n4.z, Ri[2] * n4.x + Ri[5] * n4.y + Ri[8] * n4.z);
+            newNorm = newNorm + nv * wgt[q];
+        }
+        const v3 nn = normalized(newNorm);
+        pc[i] = make_float4(newPos.x, newPos.y, newPos.z, p4.w);
+        nr[i] = make_float4(nn.x, nn.y, nn.z, n4.w);
+        if (p4.w > c.conf && !is_fern) {
+            const v3 lp = xf_point(T, newPos);
+            const float x = ((c.fx * lp.x) / lp.z) + c.cx, y = ((c.fy * lp.y) / lp.z) + c.cy;
+            if (lp.z > 0 && lp.z < c.maxDepth && x > 0 && y > 0 && x < (float)c.w && y < (float)c.h) {
+                const float cur = depth_v4[(int)floorf(y) * c.w + (int)floorf(x)].z;
+                if (cur > 0.0f && lp.z < cur + 0.1f) tm[i] = make_float2(t2.x, (float)time);
+            }
+        }
+    }
+}
+
+// Deformation::sampleGraphModel (sample.vert/.geom): the live surfel number 5000 k of the map order -> x, y, z, init time
+__global__ void k_sample_graph(const DevState* __restrict__ st, const int* __restrict__ flags, const int* __restrict__ rank, const float4* __restrict__ pc,
+                               const float2* __restrict__ tm, float4* __restrict__ out, int max_n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st->count || !flags[i]) return;
+    const int r = rank[i];
+    if (r % 5000 != 0 || r / 5000 >= max_n) return;
+    const float4 p = pc[i];
+    out[r / 5000] = make_float4(p.x, p.y, p.z, tm[i].x);
+}
+
+// the constraint samples of EF/ElasticFusion.cpp:568-598: ACTIVE vertex render and INACTIVE time render at the centres of a (w/20) x (h/20)
+// grid; record = valid, time, worldRawPoint (currPose * v), worldModelPoint (estPose * v)
+__global__ void k_cons_sample(const DevState* __restrict__ st, const float4* __restrict__ pred_vertex, const uint16_t* __restrict__ old_time, int w, int h, float maxDepth,
+                              float* __restrict__ out8)
+{
+    const int rw = w / 20, rh = h / 20, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rw * rh) return;
+    const int i = t / rh, j = t - i * rh;   // column by column, as the reference's loops
+    const int sx = (i * w + w / 2) / rw, sy = (j * h + h / 2) / rh, k = sy * w + sx;
+    const float4 v = pred_vertex[k];
+    const int tt = old_time[k];
+    float* o = out8 + (size_t)t * 8;
+    const bool ok = v.z > 0 && v.z < maxDepth && tt > 0;
+    o[0] = ok ? 1.f : 0.f; o[1] = (float)tt;
+    const float* P = st->pose;
+    const float* E = &st->lc[6];
+    for (int r = 0; r < 3; r++) {
+        o[2 + r] = P[r * 4] * v.x + P[r * 4 + 1] * v.y + P[r * 4 + 2] * v.z + P[r * 4 + 3] * 1.0f;
+        o[5 + r] = E[r * 4] * v.x + E[r * 4 + 1] * v.y + E[r * 4 + 2] * v.z + E[r * 4 + 3] * 1.0f;
+    }
+}
+// currPose = estPose (EF/ElasticFusion.cpp:606)
+__global__ void k_adopt_est_pose(DevState* st)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) st->pose[k] = st->lc[6 + k];
+    pose_inverse(st->pose, st->pose_inv);
+}
+
 static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 {
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
+    // A deformation graph was handed in for this clean (local loop closure): IndexMap::synthesizeDepth (EF/ElasticFusion.cpp:667-676) -- splat.vert
+    // with time = tick, maxTime = tick - timeDelta, timeDelta = 65535 culls what the INACTIVE prediction culls and depth_splat.frag writes the z of
+    // the same ray-disc intersection, so the depth image is the z channel of an INACTIVE prediction of the post-fuse map: rendered into old_vertex.
+    const bool deform = h->graph_nodes > 0 && part != 1;
+    if (deform && !h->graph_is_fern) raster_pass(h, d_pose_inv, 0, time - h->cfg.time_delta, LIST_SPLAT, nullptr, false, 0, 1);
     // index map of the post-fuse state (EF/ElasticFusion.cpp:662) fused with the clean cull
     if (part != 2) LAUNCH(h, "cull_clean", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_clean, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index,
            h->list_b, h->list_c);
@@ -1147,6 +1295,11 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
            (float4*)h->index_tap);
     LAUNCH(h, "clean_list", dim3(1024), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_b, h->list_c);
+    if (deform) {
+        LAUNCH_SMEM(h, "deform", dim3(MAP_BLOCKS), dim3(256), (size_t)h->graph_nodes * 64, k_deform, h->d_state, d_pose_inv, h->d_graph, h->graph_nodes, h->graph_is_fern, time, c,
+                    (const float4*)h->old_vertex, (float4*)h->pc, (float4*)h->nr, (float2*)h->tm);
+        h->graph_nodes = 0;   // rawGraph lives for one frame (EF/ElasticFusion.cpp:482)
+    }
     const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
     LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr,
            (const float4*)h->index_tap, h->scan_flags, h->scan_block);
@@ -1287,5 +1440,77 @@ extern "C" int ifx_render_ids(ifx_t* h, const float* pose16, int mode)
     if (r) return r;
     ids_pass(h, di, mode, h->ids_tmp);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+
+// ------------------------------------------------------------------ loop-closure hooks, C-ABI (include/ifx_c_api.h)
+extern "C" int ifx_sample_graph_model(ifx_t* h, float* out_xyzt, int max_n)
+{
+    if (!h || !out_xyzt || max_n <= 0) return IFX_E_INVALID;
+    const int cap_s = h->cap / 5000 + 2;
+    if (!h->d_sample) HIPCHK(h, hipMalloc(&h->d_sample, (size_t)cap_s * 16));
+    if (max_n > cap_s) max_n = cap_s;
+    const int n = h->cap;
+    LAUNCH(h, "alive_flags", dim3(cdiv(n, 256)), dim3(256), k_alive_flags, h->d_state, (const float2*)h->tm, h->scan_flags, n);
+    ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
+    LAUNCH(h, "sample_graph", dim3(cdiv(n, 256)), dim3(256), k_sample_graph, h->d_state, h->scan_flags, h->scan_out, (const float4*)h->pc, (const float2*)h->tm,
+           (float4*)h->d_sample, max_n);
+    int live = 0;
+    HIPCHK(h, hipMemcpyAsync(&live, &h->d_state->seg_counts[1], 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int m = (live + 4999) / 5000;
+    if (m > max_n) m = max_n;
+    if (m > 0) HIPCHK(h, hipMemcpy(out_xyzt, h->d_sample, (size_t)m * 16, hipMemcpyDeviceToHost));
+    return m;
+}
+
+extern "C" int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, int32_t* times, int max_n)
+{
+    if (!h || !src3 || !dst3 || !times) return IFX_E_INVALID;
+    if (!h->d_m2m) { h->err = "loop-closure detection is not enabled"; return IFX_E_STATE; }
+    const int rw = h->w / 20, rh = h->h / 20, ns = rw * rh;
+    if (!h->d_cons) HIPCHK(h, hipMalloc(&h->d_cons, (size_t)ns * 32));
+    LAUNCH(h, "cons_sample", dim3(cdiv(ns, 64)), dim3(64), k_cons_sample, (const DevState*)h->d_state, (const float4*)h->pred_vertex, h->old_time, h->w, h->h,
+           h->cfg.max_depth_processed, h->d_cons);
+    std::vector<float> rec((size_t)ns * 8);
+    HIPCHK(h, hipMemcpyAsync(rec.data(), h->d_cons, rec.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int m = 0;
+    for (int t = 0; t < ns && m < max_n; t++) {
+        const float* r = &rec[(size_t)t * 8];
+        if (r[0] == 0.f) continue;
+        times[m] = (int32_t)r[1];
+        for (int k = 0; k < 3; k++) { src3[m * 3 + k] = r[2 + k]; dst3[m * 3 + k] = r[5 + k]; }
+        m++;
+    }
+    return m;
+}
+
+extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern)
+{
+    if (!h || n_nodes < 0 || (n_nodes > 0 && !graph16)) return IFX_E_INVALID;
+    if (n_nodes == 0) { h->graph_nodes = 0; return IFX_OK; }
+    if (n_nodes < 4 || n_nodes >= 1024) { h->err = "a deformation graph has 4 .. 1023 nodes (GlobalModel::MAX_NODES, 4 neighbours per surfel)"; return IFX_E_INVALID; }
+    for (int i = 1; i < n_nodes; i++)
+        if (graph16[i * 16 + 15] < graph16[(i - 1) * 16 + 15]) { h->err = "deformation graph nodes must be sorted by time"; return IFX_E_INVALID; }
+    if (!is_fern) {   // the time-stamp refresh samples the re-rendered INACTIVE depth: needs the old* images
+        int r = ifx_tracker_alloc_m2m(h);
+        if (r) return r;
+    }
+    if (!h->d_graph) HIPCHK(h, hipMalloc(&h->d_graph, 1024 * 64));
+    HIPCHK(h, hipMemcpyAsync(h->d_graph, graph16, (size_t)n_nodes * 64, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // graph16 is the caller's
+    h->graph_nodes = n_nodes; h->graph_is_fern = is_fern ? 1 : 0;
+    h->tracked_ahead = 0;
+    return IFX_OK;
+}
+
+extern "C" int ifx_adopt_estimated_pose(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!h->d_m2m) { h->err = "loop-closure detection is not enabled"; return IFX_E_STATE; }
+    h->tracked_ahead = 0;
+    LAUNCH(h, "adopt_est_pose", dim3(1), dim3(64), k_adopt_est_pose, h->d_state);
     return IFX_OK;
 }

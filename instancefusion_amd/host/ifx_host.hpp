@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <memory>
 #include <sstream>
@@ -199,7 +200,7 @@ public:
     const int& getTimeDelta() { return cfg_.time_delta; }
     const float& getConfidenceThreshold() { return cfg_.confidence; }
     const float& getMaxDepthProcessed() { return cfg_.max_depth_processed; }
-    const int& getDeforms() { return deforms_; }                  // always 0: the map is never deformed on this path
+    const int& getDeforms() { return deforms_; }                  // graphs handed to setDeformation (0 unless a handler deforms the map)
     // frames whose local loop-closure candidate passed the reference's gates (each would have deformed the map in the reference);
     // 0 at the end of a run = the trajectory and map are what the reference computes with closeLoops and an empty fern data base
     const int& getLoopClosureCandidates() { return loopCandidates_; }
@@ -216,6 +217,54 @@ public:
     void setPyramid(const bool& val) { option("pyramid", val ? 1 : 0); cfg_.pyramid = val; }
     void setFastOdom(const bool& val) { option("fast_odom", val ? 1 : 0); cfg_.fast_odom = val; }
     void setSo3(const bool& val) { option("so3", val ? 1 : 0); cfg_.so3 = val; }
+
+    // ---- hooks of the deformation an accepted local loop-closure candidate triggers (EF/ElasticFusion.cpp:566-613).  The graph optimisation
+    // (Deformation::constrain -> DeformationGraph::optimiseGraphSparse, Eigen + cholmod) is host code of the reference and stays with the caller:
+    // the handler runs inside processFrame right after the gates and typically does
+    //     auto c = ef.loopClosureConstraints();  auto v = ef.sampleGraphModel();      // what resize.vertex/time and sampleGraphModel delivered
+    //     ... localDeformation.addConstraint(c.src, c.dst, tick, c.times, ...); localDeformation.constrain(..., rawGraph, ...) ...
+    //     ef.setDeformation(rawGraph, false);  ef.adoptEstimatedPose();               // GlobalModel::clean(..., rawGraph, ...), currPose = estPose
+    struct LoopClosureCandidate {
+        float icpError, icpCount, covMax;
+        Matrix4f estPose;
+    };
+    struct Constraints {
+        std::vector<float> src, dst;   // n x 3 each: worldRawPoint, worldModelPoint
+        std::vector<int32_t> times;    // n
+    };
+    void setLoopClosureHandler(std::function<void(ElasticFusion&, const LoopClosureCandidate&)> fn)
+    {
+        lcHandler_ = std::move(fn);
+        if (ifx_set_loop_closure_callback(h_, lcHandler_ ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK) throw std::runtime_error(ifx_last_error(h_));
+    }
+    std::vector<float> sampleGraphModel()   // x, y, z, init time of every 5000th surfel (Deformation::sampleGraphModel)
+    {
+        std::vector<float> v((size_t)(cfg_.max_surfels / 5000 + 2) * 4);
+        const int n = ifx_sample_graph_model(h_, v.data(), (int)(v.size() / 4));
+        if (n < 0) throw std::runtime_error(std::string("ifx_sample_graph_model: ") + ifx_last_error(h_));
+        v.resize((size_t)n * 4);
+        return v;
+    }
+    Constraints loopClosureConstraints()
+    {
+        const int cap = (cfg_.width / 20) * (cfg_.height / 20);
+        Constraints c;
+        c.src.resize((size_t)cap * 3); c.dst.resize((size_t)cap * 3); c.times.resize((size_t)cap);
+        const int n = ifx_loop_closure_constraints(h_, c.src.data(), c.dst.data(), c.times.data(), cap);
+        if (n < 0) throw std::runtime_error(std::string("ifx_loop_closure_constraints: ") + ifx_last_error(h_));
+        c.src.resize((size_t)n * 3); c.dst.resize((size_t)n * 3); c.times.resize((size_t)n);
+        return c;
+    }
+    void setDeformation(const std::vector<float>& rawGraph, bool isFern)   // 16 floats per node, as Deformation::constrain fills rawGraph
+    {
+        if (ifx_set_deformation(h_, rawGraph.data(), (int)(rawGraph.size() / 16), isFern ? 1 : 0) != IFX_OK)
+            throw std::runtime_error(std::string("ifx_set_deformation: ") + ifx_last_error(h_));
+        deforms_ += !rawGraph.empty();
+    }
+    void adoptEstimatedPose()
+    {
+        if (ifx_adopt_estimated_pose(h_) != IFX_OK) throw std::runtime_error(std::string("ifx_adopt_estimated_pose: ") + ifx_last_error(h_));
+    }
 
     int getMapSurfelCount() { return ifx_map_count(h_); }
     ifx_t* handle() { return h_; }
@@ -314,6 +363,21 @@ public:
     std::string saveFilename;
 
 private:
+    static int lcTrampoline(ifx_t*, const float* lc, void* user)
+    {
+        ElasticFusion* self = static_cast<ElasticFusion*>(user);
+        LoopClosureCandidate c;
+        c.icpError = lc[2]; c.icpCount = lc[3]; c.covMax = lc[22];
+        std::memcpy(c.estPose.data(), lc + 6, 64);
+        try {
+            if (self->lcHandler_) self->lcHandler_(*self, c);
+        } catch (const std::exception& e) {   // never unwind through the C frames of libifx.so
+            std::fprintf(stderr, "loop-closure handler: %s\n", e.what());
+            return IFX_E_STATE;
+        }
+        return IFX_OK;
+    }
+    std::function<void(ElasticFusion&, const LoopClosureCandidate&)> lcHandler_;
     void option(const char* name, int v)
     {
         if (ifx_set_option(h_, name, v) != IFX_OK) throw std::runtime_error(std::string("ifx_set_option(") + name + "): " + ifx_last_error(h_));

@@ -122,6 +122,7 @@ void orc_destroy(orc_t*);
 int orc_process_frame(orc_t*, const uint8_t* rgb, const uint16_t* depth, int64_t ts,
                       const float* in_pose16, float weight_mult, float* out_pose16);
 int orc_map_count(orc_t*);
+void orc_get_pose(orc_t*, float* out16);
 int orc_tick(orc_t*);
 /* copy out map fields; any pointer may be NULL.  pc,nr,ic: float4 per surfel; col,tm: float2; votes: 48 floats/surfel */
 void orc_map_download(orc_t*, float* pc, float* nr, float* col, float* tm, float* ic, float* votes);
@@ -141,6 +142,15 @@ void orc_set_loop_closure(orc_t*, int enable, int count_thresh, float err_thresh
 /* out[24]: 0 model-to-model ran (0: no inactive pixel in view), 1 valid pixels of the inactive render, 2 lastICPError,
  * 3 lastICPCount, 4 covOk, 5 accepted, 6..21 estPose (row-major), 22 largest diagonal covariance entry, 23 candidates so far */
 void orc_loop_closure_diag(orc_t*, float* out24);
+/* ---- device-side hooks of the deformation that follows an accepted candidate (orc_deform.c).  The callback runs inside
+ * orc_process_frame right after the gates when a candidate was accepted (the place of EF/ElasticFusion.cpp:566-613); it may call
+ * the four functions below.  The graph optimisation itself (EF/Utils/DeformationGraph.cpp) is the caller's. */
+typedef int (*orc_lc_callback)(orc_t*, const float* lc24, void* user);
+void orc_set_loop_closure_callback(orc_t*, orc_lc_callback cb, void* user);
+int orc_sample_graph_model(orc_t*, float* out_xyzt, int max_n);                                   /* Deformation::sampleGraphModel */
+int orc_loop_closure_constraints(orc_t*, float* src3, float* dst3, int32_t* times, int max_n);   /* EF/ElasticFusion.cpp:568-598 */
+void orc_set_deformation(orc_t*, const float* graph16, int n_nodes, int is_fern);                 /* `graph` of GlobalModel::clean, applied by the next clean */
+void orc_adopt_estimated_pose(orc_t*);                                                            /* currPose = estPose, :606 */
 
 /* stage-level map entry points operating on the object's map with an explicit pose/time */
 void orc_predict_indices(orc_t*, const float* pose16, int time);

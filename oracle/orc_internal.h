@@ -56,7 +56,15 @@ struct orc {
     uint16_t* old_time;
     orc_tracker* m2m;
     float lc[24];
+    /* deformation graph handed in for the next clean (GlobalModel::clean's `graph` argument), orc_deform.c */
+    float* graph;
+    int graph_nodes, graph_is_fern;
+    orc_lc_callback lc_cb;
+    void* lc_user;
 };
+
+void orc_deform_surfel(const float* g, int nodes, float* pc, float* nr, float initT, float* lastT, int time, float thr, int is_fern, const float* tinv,
+                       const float* depth, int w, int h, float cx, float cy, float fx, float fy, float maxDepth);
 
 float orc_encode_color(float r, float g, float b);
 void orc_decode_color(float c, float* out3);

@@ -139,12 +139,14 @@ void orc_destroy(orc_t* o)
     free(o->fill_image); free(o->ids_after); free(o->ids_tmp); free(o->zbuf); free(o->newbuf); free(o->updbuf);
     orc_tracker_destroy(o->trk);
     orc_tracker_destroy(o->m2m);
+    free(o->graph);
     free(o->old_vertex); free(o->old_normal); free(o->old_image); free(o->old_inst); free(o->old_time);
     orc_instance_free(o);
     free(o);
 }
 
 int orc_map_count(orc_t* o) { return o->n; }
+void orc_get_pose(orc_t* o, float* out16) { memcpy(out16, o->pose, 64); }
 int orc_tick(orc_t* o) { return o->tick; }
 
 void orc_map_download(orc_t* o, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
@@ -566,10 +568,28 @@ void orc_clean(orc_t* o, const float* pose, int time)
     float tinv[16];
     orc_pose_inverse(pose, tinv);
     int m = 0;
+    const float* depth = NULL;
+    if (o->graph_nodes > 0 && !o->graph_is_fern) {
+        /* IndexMap::synthesizeDepth (EF/ElasticFusion.cpp:667-676, EF/IndexMap.cpp:576-648): splat.vert with time = tick, maxTime = tick - timeDelta,
+         * timeDelta = 65535 culls exactly what the INACTIVE prediction culls, and depth_splat.frag writes the z of the same ray-disc intersection:
+         * the depth image is the z channel of an INACTIVE prediction of the post-fuse map at the (adopted) pose.  Rendered into the old* images. */
+        float *pv = o->pred_vertex, *pn = o->pred_normal;
+        uint8_t *pi = o->pred_image, *ps = o->pred_inst;
+        uint16_t* pt = o->pred_time;
+        o->pred_vertex = o->old_vertex; o->pred_normal = o->old_normal; o->pred_image = o->old_image; o->pred_inst = o->old_inst; o->pred_time = o->old_time;
+        orc_combined_predict(o, pose, 0, time - o->cfg.time_delta);
+        o->pred_vertex = pv; o->pred_normal = pn; o->pred_image = pi; o->pred_inst = ps; o->pred_time = pt;
+        float* d = o->zbuf;   /* free between passes */
+        for (int k = 0; k < o->P; k++) d[k] = o->old_vertex[(size_t)k * 4 + 2];
+        depth = d;
+    }
     for (int i = 0; i < o->n; i++) {
         float lastT = o->tm[i * 2 + 1];
         int keep = clean_test(o, tinv, time, &o->pc[i * 4], &o->nr[i * 4], o->tm[i * 2], &lastT);
         if (!keep) continue;
+        if (o->graph_nodes > 0 && o->tm[i * 2] != (float)time)   /* copy_unstable.vert:178-181: survivors not created this frame */
+            orc_deform_surfel(o->graph, o->graph_nodes, &o->pc[i * 4], &o->nr[i * 4], o->tm[i * 2], &lastT, time, o->cfg.confidence, o->graph_is_fern, tinv, depth,
+                              o->w, o->h, o->cfg.cx, o->cfg.cy, o->cfg.fx, o->cfg.fy, o->cfg.max_depth_processed);
         if (m != i) {
             memcpy(&o->pc[m * 4], &o->pc[i * 4], 16);
             memcpy(&o->nr[m * 4], &o->nr[i * 4], 16);
@@ -596,6 +616,7 @@ void orc_clean(orc_t* o, const float* pose, int time)
     }
     o->n = m;
     o->n_new = 0;
+    if (o->graph_nodes > 0) orc_set_deformation(o, NULL, 0, 0);   /* rawGraph lives for one frame (EF/ElasticFusion.cpp:482) */
 }
 
 /* IndexMap::renderSurfelIds, EF/IndexMap.cpp:315-465 + surfel_ids.vert/.geom/.frag and
@@ -725,7 +746,9 @@ static void loop_closure_local(orc_t* o)
     o->lc[22] = (float)cmax;
     o->lc_candidates += accept;
     o->lc[23] = (float)o->lc_candidates;
+    if (accept && o->lc_cb) o->lc_cb(o, o->lc, o->lc_user);   /* :566-613: constraints, graph optimisation (caller), rawGraph, currPose = estPose */
 }
+void orc_set_loop_closure_callback(orc_t* o, orc_lc_callback cb, void* user) { o->lc_cb = cb; o->lc_user = user; }
 
 /* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Of the loop-closure block (:450-617) only the local detection
  * is restated (loop_closure_local, when enabled); ferns and the deformation graph are out of scope, and without

@@ -54,6 +54,24 @@ int main(int argc, char** argv)
             }
             return 0;
         }
+        if (mode == "api") {   // compile-time check of the loop-closure hooks of the class surface (no GPU: construction must fail loudly)
+            Resolution::getInstance(64, 48);
+            Intrinsics::getInstance(50.f, 50.f, 32.f, 24.f);
+            try {
+                ElasticFusion ef(200, 35000, 5e-05f, 1e-05f, true);
+                ef.setLoopClosureHandler([](ElasticFusion& e, const ElasticFusion::LoopClosureCandidate&) {
+                    ElasticFusion::Constraints c = e.loopClosureConstraints();
+                    std::vector<float> nodes = e.sampleGraphModel(), rawGraph;
+                    (void)c;
+                    e.setDeformation(rawGraph, false);
+                    e.adoptEstimatedPose();
+                });
+                std::printf("created\n");
+            } catch (const std::exception& e) {
+                std::printf("refused: %s\n", e.what());
+            }
+            return 0;
+        }
         std::fprintf(stderr, "bad mode\n");
         return 2;
     } catch (const std::exception& e) {

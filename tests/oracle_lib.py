@@ -144,6 +144,12 @@ class Oracle:
         a = {k: np.ascontiguousarray(m[k], np.float32) for k in ("pc", "nr", "col", "tm", "ic", "votes")}
         self.L.orc_map_upload(self.h, n, ptr(a["pc"]), ptr(a["nr"]), ptr(a["col"]), ptr(a["tm"]), ptr(a["ic"]), ptr(a["votes"]))
 
+    def get_pose(self):
+        out = np.zeros(16, np.float32)
+        self.L.orc_get_pose.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_get_pose(self.h, ptr(out))
+        return out.reshape(4, 4)
+
     def set_pose(self, pose, tick):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)
         self.L.orc_set_pose(self.h, ptr(p), tick)
@@ -167,6 +173,44 @@ class Oracle:
         self.L.orc_loop_closure_diag(self.h, ptr(out))
         return dict(ran=bool(out[0]), inactive_pixels=int(out[1]), icp_error=float(out[2]), icp_count=float(out[3]), cov_ok=bool(out[4]),
                     accepted=bool(out[5]), est_pose=out[6:22].reshape(4, 4).copy(), cov_max=float(out[22]), candidates=int(out[23]))
+
+    # ---- deformation hooks (orc_deform.c)
+    def set_loop_closure_callback(self, fn):
+        """fn(oracle, lc_dict) is called inside process_frame when a candidate is accepted (None removes it)."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_void_p)
+        self.L.orc_set_loop_closure_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if fn is None:
+            self._cb = None
+            self.L.orc_set_loop_closure_callback(self.h, None, None)
+            return
+
+        def tramp(_h, lc, _user):
+            fn(self, np.ctypeslib.as_array(lc, shape=(24,)).copy())
+            return 0
+
+        self._cb = CB(tramp)
+        self.L.orc_set_loop_closure_callback(self.h, C.cast(self._cb, C.c_void_p), None)
+
+    def sample_graph_model(self, max_n=4096):
+        out = np.zeros((max_n, 4), np.float32)
+        self.L.orc_sample_graph_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        n = self.L.orc_sample_graph_model(self.h, ptr(out), max_n)
+        return out[:n].copy()
+
+    def loop_closure_constraints(self, max_n=4096):
+        src, dst, tm = np.zeros((max_n, 3), np.float32), np.zeros((max_n, 3), np.float32), np.zeros(max_n, np.int32)
+        self.L.orc_loop_closure_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        n = self.L.orc_loop_closure_constraints(self.h, ptr(src), ptr(dst), ptr(tm), max_n)
+        return src[:n].copy(), dst[:n].copy(), tm[:n].copy()
+
+    def set_deformation(self, graph16, is_fern=False):
+        g = np.ascontiguousarray(graph16, np.float32).reshape(-1, 16)
+        self.L.orc_set_deformation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self.L.orc_set_deformation(self.h, ptr(g), g.shape[0], int(is_fern))
+
+    def adopt_estimated_pose(self):
+        self.L.orc_adopt_estimated_pose.argtypes = [C.c_void_p]
+        self.L.orc_adopt_estimated_pose(self.h)
 
     def predict_indices(self, pose, time):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)

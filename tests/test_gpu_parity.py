@@ -947,3 +947,136 @@ def test_loop_closure_detection_nothing_inactive(ifx, small_stream):
         assert not d["ran"] and d["inactive_pixels"] == 0 and not d["accepted"]
     assert all(np.array_equal(a, b) for a, b in zip(g.download().values(), g0.download().values()))
     g.close(); g0.close()
+
+
+# ---------------------------------------------------------------- 8f-3: deformation hooks (graph application inside clean, graph sampling, constraint samples)
+def _random_graph(samples, rng, rot=0.05, trans=0.02):
+    import math
+
+    g = np.zeros((samples.shape[0], 16), np.float32)
+    g[:, :3] = samples[:, :3]; g[:, 15] = samples[:, 3]
+    for i in range(len(g)):
+        a = rng.uniform(-rot, rot, 3)
+        Rx = np.array([[1, 0, 0], [0, math.cos(a[0]), -math.sin(a[0])], [0, math.sin(a[0]), math.cos(a[0])]])
+        Ry = np.array([[math.cos(a[1]), 0, math.sin(a[1])], [0, 1, 0], [-math.sin(a[1]), 0, math.cos(a[1])]])
+        Rz = np.array([[math.cos(a[2]), -math.sin(a[2]), 0], [math.sin(a[2]), math.cos(a[2]), 0], [0, 0, 1]])
+        g[i, 3:12] = (Rz @ Ry @ Rx).T.reshape(9)
+        g[i, 12:15] = rng.uniform(-trans, trans, 3)
+    return g
+
+
+@pytest.mark.parametrize("is_fern", [True, False])
+def test_deformation_application_exact(ifx, orc, small_stream, is_fern):
+    """GlobalModel::clean with a deformation graph (copy_unstable.vert:178-374) on identical maps: positions, normals and time stamps bit for bit,
+    incl. the time-stamp refresh against the re-rendered INACTIVE depth (local loop closure, is_fern = False)."""
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+    o.set_loop_closure(True); g.set_loop_closure(True)
+    for k in range(7):
+        pose = o.process_frame(st["rgb"][k], st["depth"][k])
+        if k == 2:
+            m = o.download(); m["pc"][:, 3] = 20.0; o.upload(m)
+    # the GPU runs its own frames too (so that its store has tombstones and its own slot numbering), then takes the oracle's map
+    for k in range(4):
+        g.processFrame(st["rgb"][k], st["depth"][k])
+    m0 = o.download()
+    g.upload(m0)
+    tick = o.tick
+    g.set_pose(pose, tick)
+    so, sg = o.sample_graph_model(), g.sample_graph_model()
+    assert np.array_equal(so, sg) and so.shape[0] >= 5
+    graph = _random_graph(so, np.random.RandomState(11))
+    pose2 = pose.copy(); pose2[:3, 3] += np.array([0.004, -0.003, 0.002], np.float32)      # the adopted pose differs from the tracked one
+    for e in (o, g):
+        e.set_frame(st["rgb"][7], st["depth"][7])                      # the order of a frame: index map, fuse, index map, clean (with the graph)
+        e.predict_indices(pose2, tick)
+        e.fuse(pose2, tick, 1.0)
+        e.predict_indices(pose2, tick)
+        e.set_deformation(graph, is_fern=is_fern)
+        e.clean(pose2, tick)
+    mo, mg = o.download(), g.download()
+    assert mo["pc"].shape == mg["pc"].shape
+    for key in MAP_KEYS:
+        assert np.array_equal(mo[key], mg[key]), key
+    assert np.abs(mo["pc"][: len(m0["pc"]), :3] - m0["pc"][: len(mo["pc"]), :3]).max() > 1e-3 or len(mo["pc"]) != len(m0["pc"])      # something moved
+    if not is_fern:
+        assert (mo["tm"][:, 1] == tick).sum() > (m0["tm"][:, 1] == tick).sum()          # moved stable surfels in front of the old model were re-activated
+    # the graph is consumed by one clean
+    for e in (o, g):
+        e.predict_indices(pose2, tick); e.fuse(pose2, tick, 1.0); e.predict_indices(pose2, tick); e.clean(pose2, tick)
+    assert all(np.array_equal(o.download()[key], g.download()[key]) for key in MAP_KEYS)
+    o.close(); g.close()
+
+
+def test_sample_graph_with_tombstones(ifx, small_stream):
+    """Deformation::sampleGraphModel numbers the surfels of the compacted map; the store keeps tombstones: the sample must not depend on them."""
+    st = small_stream
+    a = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0, time_delta=3)
+    b = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0, time_delta=3)
+    b.set_option("compact_every_frame", 1)
+    for k in range(8):
+        a.processFrame(st["rgb"][k], st["depth"][k]); b.processFrame(st["rgb"][k], st["depth"][k])
+    assert a.slots > b.slots == b.count == a.count                     # a holds tombstones
+    sa, sb = a.sample_graph_model(), b.sample_graph_model()
+    assert sa.shape[0] == (a.count + 4999) // 5000 and np.array_equal(sa, sb)
+    m = b.download()
+    assert np.array_equal(sb[:, :3], m["pc"][::5000, :3]) and np.array_equal(sb[:, 3], m["tm"][::5000, 0])
+    a.close(); b.close()
+
+
+def test_loop_closure_callback_end_to_end(ifx, orc, small_stream):
+    """An accepted candidate calls back into the host (EF/ElasticFusion.cpp:566-613): constraint samples, graph sample, a deformation graph
+    (here a stand-in for the reference's optimiser: rigid nodes carrying the mean constraint offset), currPose = estPose -- same callback on both sides."""
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    thr = 35000 * (SMALL["w"] * SMALL["h"]) // (640 * 480)
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+    g.set_option("compact_every_frame", 1)
+    o.set_loop_closure(True, thr, 1e-4, 1e-5); g.set_loop_closure(True, thr, 1e-4, 1e-5)
+    log = {"o": [], "g": []}
+    tracked = [None]
+
+    def make_cb(tag):
+        def cb(e, lc):
+            if tag == "o":
+                tracked[0] = e.get_pose()       # the pose the frame was tracked to (before currPose = estPose)
+            src, dst, tm = e.loop_closure_constraints()
+            s = e.sample_graph_model()
+            log[tag].append((src, dst, tm, s, lc))
+            if len(log[tag]) > 1:          # deform on the first candidate only
+                return
+            graph = np.zeros((s.shape[0], 16), np.float32)
+            graph[:, :3] = s[:, :3]; graph[:, 3] = graph[:, 7] = graph[:, 11] = 1.0; graph[:, 15] = s[:, 3]
+            graph[:, 12:15] = (dst - src).mean(axis=0) if len(src) else 0.0
+            e.set_deformation(graph, is_fern=False)
+            e.adopt_estimated_pose()
+        return cb
+
+    o.set_loop_closure_callback(make_cb("o")); g.set_loop_closure_callback(make_cb("g"))
+    po = None
+    for k in range(9):
+        if k >= 3:
+            m, tick0, po_prev = o.download(), o.tick, po
+        tracked[0] = None
+        po = o.process_frame(st["rgb"][k], st["depth"][k])
+        if k >= 3:
+            g.upload(m); g.set_pose(po_prev, tick0)
+        # the GPU is handed the pose the oracle tracked (the renders the candidate is judged on are then identical); when the callback adopts
+        # the estimated pose the frame continues with it on both sides
+        pg = g.processFrame(st["rgb"][k], st["depth"][k], inPose=None if k < 3 else (tracked[0] if tracked[0] is not None else po))
+        if k == 2:
+            m = o.download(); m["pc"][:, 3] = 20.0; o.upload(m)
+        assert np.abs(pg - po).max() < 5e-5, k
+    assert len(log["o"]) == len(log["g"]) >= 2
+    so, sg = log["o"][0], log["g"][0]
+    assert np.array_equal(so[2], sg[2]) and len(so[2]) > 20                 # constraint times
+    assert np.array_equal(so[0], sg[0]) and np.abs(so[1] - sg[1]).max() < 5e-5   # src = currPose * v exact, dst = estPose * v to the estimate's tolerance
+    assert np.array_equal(so[3], sg[3])                                   # graph samples
+    assert g.count == o.count
+    mo, mg = o.download(), g.download()
+    assert np.abs(mo["pc"] - mg["pc"]).max() < 2e-4 and np.array_equal(mo["tm"][:, 0], mg["tm"][:, 0])
+    o.close(); g.close()
+

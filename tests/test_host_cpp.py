@@ -129,6 +129,16 @@ def test_quaternion_equals_python(checker, tmp_path):
         assert np.allclose(q[k], np.array(logio._quaternion(R.astype(np.float32)), np.float32), atol=1e-7)
 
 
+def test_class_surface_compiles_and_refuses_without_gpu(checker):
+    import torch
+
+    r = subprocess.run([checker, "api"], capture_output=True, text=True, check=True)
+    if torch.cuda.is_available():
+        assert r.stdout.startswith("created")
+    else:
+        assert r.stdout.startswith("refused") and "no CPU fallback" in r.stdout
+
+
 def test_replay_program_built_and_fails_loudly_without_gpu(tmp_path):
     import torch
 

@@ -374,3 +374,94 @@ def test_loop_closure_detection_properties(orc, small_stream):
     assert not np.isfinite(cov).all()
     L.orc_tracker_destroy(t)
     o.close(); o0.close()
+
+
+# ---------------------------------------------------------------- deformation hooks (copy_unstable.vert:178-374, sample.geom, EF/ElasticFusion.cpp:568-598)
+def _deform_numpy(g, p, n, init_t):
+    """Independent restatement of the per-surfel graph application (float32 numpy), for a handful of surfels."""
+    f = np.float32
+    times = g[:, 15].astype(np.int64)
+    pt = int(init_t)
+    imin, imax = 0, len(g) - 1
+    imid = (imin + imax) // 2
+    while imax >= imin:
+        imid = (imin + imax) // 2
+        if times[imid] < pt:
+            imin = imid + 1
+        elif times[imid] > pt:
+            imax = imid - 1
+        else:
+            break
+    imin = min(imin, len(g) - 1)
+    cmax = max(imax, 0)
+    dmin, dmid, dmax_ = abs(times[imin] - pt), abs(times[imid] - pt), abs(times[cmax] - pt)
+    found = imin if (dmin <= dmid and dmin <= dmax_) else (imid if (dmid <= dmin and dmid <= dmax_) else cmax)
+    idx = list(range(found, max(found - 10, -1), -1))
+    idx += list(range(found + 1, min(len(g), found + 1 + 20 - len(idx))))
+    d = np.array([np.sqrt(np.sum((p - g[j, :3]) ** 2, dtype=f), dtype=f) for j in idx], f)
+    order = np.argsort(d, kind="stable")
+    near, nd = [idx[k] for k in order], d[order]
+    d5 = nd[4] if len(nd) > 4 else f(16777216.0)
+    w = np.array([(f(1) - nd[k] / d5) ** 2 for k in range(4)], f)
+    w = w / w.sum(dtype=f)
+    newp, newn = np.zeros(3, f), np.zeros(3, f)
+    for k in range(4):
+        nd_ = g[near[k]]
+        R = nd_[3:12].reshape(3, 3).T.astype(f)          # stored column-major
+        newp += w[k] * (R @ (p - nd_[:3]) + nd_[:3] + nd_[12:15])
+        newn += w[k] * (np.linalg.inv(R.astype(np.float64)).T.astype(f) @ n)
+    return newp, newn / np.linalg.norm(newn)
+
+
+def test_deformation_hooks_properties(orc, small_stream):
+    st = small_stream
+    o = orc.Oracle(**SMALL, max_surfels=400000, confidence=2.0)
+    for k in range(4):
+        pose = o.process_frame(st["rgb"][k], st["depth"][k])
+    m0 = o.download()
+    n = o.count
+    # Deformation::sampleGraphModel: every 5000th surfel of the map order, times non-decreasing (the reference asserts it)
+    s = o.sample_graph_model()
+    assert s.shape[0] == (n + 4999) // 5000 >= 5
+    assert np.array_equal(s[:, :3], m0["pc"][::5000, :3]) and np.array_equal(s[:, 3], m0["tm"][::5000, 0])
+    assert (np.diff(s[:, 3]) >= 0).all()
+    # a graph that moves everything rigidly: R = I, t constant  ->  every surfel not created in this frame moves by t, normals stay
+    tvec = np.array([0.01, -0.02, 0.005], np.float32)
+    g = np.zeros((s.shape[0], 16), np.float32)
+    g[:, :3] = s[:, :3]; g[:, 3] = g[:, 7] = g[:, 11] = 1.0; g[:, 12:15] = tvec; g[:, 15] = s[:, 3]
+    tick = o.tick
+    o.predict_indices(pose, tick)
+    o.set_deformation(g, is_fern=True)
+    o.clean(pose, tick)
+    m1 = o.download()
+    o2 = orc.Oracle(**SMALL, max_surfels=400000, confidence=2.0)          # the same clean without a graph keeps the same surfels
+    o2.upload(m0); o2.set_pose(pose, tick); o2.predict_indices(pose, tick); o2.clean(pose, tick)
+    m2 = o2.download()
+    assert m1["pc"].shape == m2["pc"].shape
+    moved = m2["tm"][:, 0] != tick
+    assert moved.sum() > 0.9 * len(moved)
+    assert np.abs(m1["pc"][moved, :3] - (m2["pc"][moved, :3] + tvec)).max() < 2e-6
+    assert np.abs(m1["nr"][moved, :3] - m2["nr"][moved, :3]).max() < 2e-6
+    assert np.array_equal(m1["pc"][~moved], m2["pc"][~moved]) and np.array_equal(m1["pc"][:, 3], m2["pc"][:, 3]) and np.array_equal(m1["nr"][:, 3], m2["nr"][:, 3])
+    assert np.array_equal(m1["tm"], m2["tm"])                             # is_fern: no time-stamp refresh
+    # the graph lives for one clean
+    o.predict_indices(pose, tick); o.clean(pose, tick)
+    assert np.array_equal(o.download()["pc"], m1["pc"])
+    # a general graph (small random rotations / translations): the C restatement against an independent numpy one, surfel by surfel
+    rng = np.random.RandomState(4)
+    g2 = g.copy()
+    for i in range(len(g2)):
+        a = rng.uniform(-0.05, 0.05, 3)
+        Rx = np.array([[1, 0, 0], [0, math.cos(a[0]), -math.sin(a[0])], [0, math.sin(a[0]), math.cos(a[0])]])
+        Ry = np.array([[math.cos(a[1]), 0, math.sin(a[1])], [0, 1, 0], [-math.sin(a[1]), 0, math.cos(a[1])]])
+        Rz = np.array([[math.cos(a[2]), -math.sin(a[2]), 0], [math.sin(a[2]), math.cos(a[2]), 0], [0, 0, 1]])
+        g2[i, 3:12] = (Rz @ Ry @ Rx).T.reshape(9)                        # column-major
+        g2[i, 12:15] = rng.uniform(-0.02, 0.02, 3)
+    o2.upload(m0); o2.set_pose(pose, tick); o2.predict_indices(pose, tick); o2.set_deformation(g2, is_fern=True); o2.clean(pose, tick)
+    m3 = o2.download()
+    o2.upload(m0); o2.set_pose(pose, tick); o2.predict_indices(pose, tick); o2.clean(pose, tick)
+    m4 = o2.download()                                                     # same survivors, undeformed
+    for i in rng.choice(np.flatnonzero(m4["tm"][:, 0] != tick), 40, replace=False):
+        newp, newn = _deform_numpy(g2, m4["pc"][i, :3], m4["nr"][i, :3], m4["tm"][i, 0])
+        assert np.abs(m3["pc"][i, :3] - newp).max() < 5e-6 and np.abs(m3["nr"][i, :3] - newn).max() < 5e-6, i
+    o.close(); o2.close()

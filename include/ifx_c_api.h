@@ -170,7 +170,8 @@ const int32_t* ifx_ids_after(ifx_t* h);
  * "index_vc", "index_ct", "index_nr", "pred_vertex", "pred_normal", "pred_image", "pred_inst",
  * "pred_time", "fill_vertex", "fill_normal", "fill_image", "depth_filtered", "depth_metric",
  * "depth_metric_filtered", and with loop-closure detection on "old_vertex", "old_normal", "old_image", "old_time" (the
- * INACTIVE prediction, IndexMap::oldVertexTex() etc.).  Returns bytes written or <0. */
+ * INACTIVE prediction, IndexMap::oldVertexTex() etc.) and "act_vertex", "act_normal", "act_image" (the predict() of
+ * EF/ElasticFusion.cpp:453).  Returns bytes written or <0. */
 int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t max_bytes);
 
 /* ---- map stage API (unit-parity surface; each replaces one GL pass of the reference) */

@@ -137,11 +137,14 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
 extern "C" void ifx_destroy(ifx_t* h)
 {
     if (!h) return;
+    if (h->stream_c) hipStreamSynchronize(h->stream_c);
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
     if (h->stream) hipStreamSynchronize(h->stream);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
+    if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
+    if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
     void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
@@ -156,6 +159,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_slic_free(h);
     ifx_knn_free(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
+    if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -166,9 +170,14 @@ extern "C" int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, floa
     if (!h) return IFX_E_INVALID;
     if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "loop-closure detection cannot change while a frame is announced ahead"; return IFX_E_STATE; }
     h->tracked_ahead = 0;
+    if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     if (enable) {
         int r = ifx_tracker_alloc_m2m(h);
         if (r) return r;
+        if (!h->stream_c) {
+            if (hipStreamCreate(&h->stream_c) != hipSuccess || hipEventCreateWithFlags(&h->ev_lc_ready, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_lc_done, hipEventDisableTiming) != hipSuccess) { h->err = "stream / event creation failed"; return IFX_E_HIP; }
+        }
     }
     h->lc_enable = enable ? 1 : 0; h->lc_count_thresh = count_thresh; h->lc_err_thresh = err_thresh; h->lc_cov_thresh = cov_thresh;
     return IFX_OK;
@@ -182,8 +191,10 @@ extern "C" int ifx_set_loop_closure_callback(ifx_t* h, ifx_loop_closure_cb cb, v
 extern "C" int ifx_loop_closure_diag(ifx_t* h, float* out24)
 {
     if (!h || !out24) return IFX_E_INVALID;
+    if (!h->h_lc) { memset(out24, 0, 24 * 4); return IFX_OK; }   // detection never enabled
     if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
-    memcpy(out24, h->h_result->lc, sizeof(h->h_result->lc));
+    if (h->lc_event_valid) HIPCHK(h, hipEventSynchronize(h->ev_lc_done));   // the model-to-model tracker may outlive its frame
+    memcpy(out24, h->h_lc, 24 * 4);
     return IFX_OK;
 }
 
@@ -219,7 +230,6 @@ __global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restric
     if (threadIdx.x != 0) return;
     out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
     st->seg_acc[0] = 0; st->seg_acc[1] = 0;
-    for (int k = 0; k < 24; k++) out->lc[k] = st->lc[k];
     for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
     out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
     out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
@@ -267,40 +277,69 @@ int ifx_enqueue_hinted_frame_side(ifx* h)
 // INACTIVE prediction, model-to-model tracking, covariance / count / error gates.  While tick - timeDelta < 1 no surfel the frames created
 // can be old enough (lastTime >= 1), so unless a map was uploaded the whole block is skipped on the host -- exactly what the gates would
 // decide on an empty render.
-__global__ void k_lc_idle(DevState* st)
+__global__ void k_lc_idle(DevState* st, float* __restrict__ host_lc)
 {
     if (threadIdx.x != 0) return;
     for (int k = 0; k < 23; k++) st->lc[k] = 0.f;
     for (int k = 0; k < 16; k++) st->lc[6 + k] = st->pose[k];
     st->lc[23] = (float)st->lc_candidates;
+    for (int k = 0; k < 24; k++) host_lc[k] = st->lc[k];
 }
-static int enqueue_loop_closure_detection(ifx* h)
+// Part 1, before the map passes: the two renders.  With a callback (the caller deforms the map on an accepted candidate) the model-to-model
+// tracker follows at once on the main stream and the host waits for the verdict; otherwise the tracker is deferred to part 2.
+static int enqueue_loop_closure_renders(ifx* h)
 {
+    h->lc_deferred = 0;
     if (!h->map_external && h->tick - h->cfg.time_delta < 1) {
-        LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state);
+        LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state, h->h_lc);
         return IFX_OK;
     }
+    // the previous frame's model-to-model run may still be on its stream: it owns the act* / old* images and its state until it is done
+    if (h->lc_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_lc_done, 0)); h->lc_pending = 0; }
     {
         StageTimer t(h, 1);
         ifx_tracker_m2m_begin(h);
         ifx_map_predict_loop_closure(h);
+    }
+    if (!h->lc_cb) {
+        if (h->opt_two_streams && h->stream_c) HIPCHK(h, hipEventRecord(h->ev_lc_ready, h->stream));
+        h->lc_deferred = 1;
+        return IFX_OK;
     }
     {
         StageTimer t(h, 0);
         int r = ifx_tracker_loop_closure(h);
         if (r) return r;
     }
-    if (h->lc_cb) {   // the caller deforms the map on an accepted candidate: it needs the verdict before the map passes are enqueued
-        HIPCHK(h, hipMemcpyAsync(h->h_result->lc, h->d_state->lc, sizeof(h->h_result->lc), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->h_result->lc[5] != 0.f) {
-            float lc[24];
-            memcpy(lc, h->h_result->lc, sizeof(lc));
-            int r = h->lc_cb(h, lc, h->lc_user);
-            if (r < 0) { h->err = "loop-closure callback failed"; return r; }
-        }
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // the verdict is in pinned memory (k_m2m_decide)
+    if (h->h_lc[5] != 0.f) {
+        float lc[24];
+        memcpy(lc, h->h_lc, sizeof(lc));
+        int r = h->lc_cb(h, lc, h->lc_user);
+        if (r < 0) { h->err = "loop-closure callback failed"; return r; }
     }
     return IFX_OK;
+}
+// Part 2, after the map passes of the frame are on the main stream: the model-to-model tracker reads only the two renders (images of their
+// own) and its own state, and nothing of the frame consumes its verdict, so it goes to a stream of its own and runs under the map passes, the
+// end-of-frame predict() and the next frame's tracker (both trackers are chains of small latency-bound launches).  Enqueued AFTER the map
+// passes on the host as well: its ~50 launches would otherwise keep the main queue empty for their whole enqueue time.
+static int enqueue_loop_closure_tracker(ifx* h)
+{
+    if (!h->lc_deferred) return IFX_OK;
+    h->lc_deferred = 0;
+    const bool aside = h->opt_two_streams && h->stream_c;
+    if (aside) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream_c, h->ev_lc_ready, 0));
+        h->cur = h->stream_c;
+    }
+    int r;
+    {
+        StageTimer t(h, 0);
+        r = ifx_tracker_loop_closure(h);
+    }
+    if (aside) { hipEventRecord(h->ev_lc_done, h->stream_c); h->cur = h->stream; h->lc_pending = 1; h->lc_event_valid = 1; }
+    return r;
 }
 
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)
@@ -345,11 +384,17 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
             }
         }
         if (h->lc_enable) {
-            int r = enqueue_loop_closure_detection(h);
+            int r = enqueue_loop_closure_renders(h);
             if (r) return r;
         }
-        StageTimer t(h, 1);
-        ifx_map_frame(h);
+        {
+            StageTimer t(h, 1);
+            ifx_map_frame(h);
+        }
+        if (h->lc_enable) {
+            int r = enqueue_loop_closure_tracker(h);
+            if (r) return r;
+        }
     }
     {
         StageTimer t(h, 1);
@@ -481,6 +526,7 @@ extern "C" int ifx_sync(ifx_t* h)
     if (!h) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream_b));
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
@@ -717,6 +763,7 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     std::string s(name);
     size_t P = (size_t)h->P, bytes = 0;
     const void* src = nullptr;
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
     if (s == "ids_after") { src = h->ids_after; bytes = P * 4; }
     else if (s == "ids_tmp") { src = h->ids_tmp; bytes = P * 4; }
     else if (s == "index") { src = h->index_id; bytes = P * 4; }
@@ -732,6 +779,9 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     else if (s == "old_normal" && h->d_m2m) { src = h->old_normal; bytes = P * 16; }
     else if (s == "old_image" && h->d_m2m) { src = h->old_image; bytes = P * 4; }
     else if (s == "old_time" && h->d_m2m) { src = h->old_time; bytes = P * 2; }
+    else if (s == "act_vertex" && h->d_m2m) { src = h->act_vertex; bytes = P * 16; }
+    else if (s == "act_normal" && h->d_m2m) { src = h->act_normal; bytes = P * 16; }
+    else if (s == "act_image" && h->d_m2m) { src = h->act_image; bytes = P * 4; }
     else if (s == "fill_vertex") { src = h->fill_vertex; bytes = P * 16; }
     else if (s == "fill_normal") { src = h->fill_normal; bytes = P * 16; }
     else if (s == "fill_image") { src = h->fill_image; bytes = P * 4; }

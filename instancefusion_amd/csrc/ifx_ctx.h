@@ -58,7 +58,6 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     float diag[8];
     int count, n_dead, n_new, overflow;
     int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
-    float lc[24];        // loop-closure detection of this frame (ifx_loop_closure_diag)
 };
 
 struct Pyr {
@@ -69,6 +68,10 @@ struct Pyr {
     float *vmap_prev[IFX_NUM_PYRS], *nmap_prev[IFX_NUM_PYRS];
     float* last_depth[IFX_NUM_PYRS];                          // == next_depth in the frame-to-model tracker (reference quirk)
     float* next_depth[IFX_NUM_PYRS] = {};                     // model-to-model tracker only (nullptr: last_depth)
+    // reduction scratch of this tracker instance (the two instances can be on the GPU at the same time)
+    float *icp_partials = nullptr, *rgb_partials = nullptr;
+    int* res_partials = nullptr;
+    unsigned int* ticket = nullptr;                           // [0] last-block ticket of k_rgb_step_solve, [8..9] residual totals
     uint8_t *last_img[IFX_NUM_PYRS], *next_img[IFX_NUM_PYRS], *lastnext_img[IFX_NUM_PYRS];
     int16_t *didx[IFX_NUM_PYRS], *didy[IFX_NUM_PYRS];
     float* cloud[IFX_NUM_PYRS];
@@ -102,6 +105,9 @@ struct ifx {
     int w, h, P, cap;
     hipStream_t stream = nullptr;      // main stream: model side, tracking, map, instance layer
     hipStream_t stream_b = nullptr;    // side stream: frame side (FrameSlot)
+    hipStream_t stream_c = nullptr;    // loop-closure detection: the model-to-model tracker, under the map passes of its frame
+    hipEvent_t ev_lc_ready = nullptr, ev_lc_done = nullptr;
+    int lc_pending = 0, lc_deferred = 0;
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
     FrameSlot slot[2];
     int cur_slot = 0;
@@ -129,9 +135,14 @@ struct ifx {
     float lc_err_thresh = 5e-5f, lc_cov_thresh = 1e-5f;
     DevState* d_m2m = nullptr;
     Pyr m2m;
-    float *old_vertex = nullptr, *old_normal = nullptr;
+    float *old_vertex = nullptr, *old_normal = nullptr;        // INACTIVE prediction (IndexMap::oldVertexTex() ...)
     uint8_t *old_image = nullptr, *old_inst = nullptr;
     uint16_t* old_time = nullptr;
+    float *act_vertex = nullptr, *act_normal = nullptr;        // predict() of EF/ElasticFusion.cpp:453 (ACTIVE render at the tracked pose, pre-fusion map): kept apart from
+    uint8_t *act_image = nullptr, *act_inst = nullptr;         // pred_*, which the end-of-frame predict() rewrites while the model-to-model tracker may still be reading
+    uint16_t* act_time = nullptr;
+    float* h_lc = nullptr;                                     // pinned: verdict of the last detection (ifx_loop_closure_diag)
+    int lc_event_valid = 0;
     float* d_graph = nullptr;           // deformation graph handed in for the next clean (ifx_set_deformation): nodes x 16 floats
     int graph_nodes = 0, graph_is_fern = 0;
     float *d_sample = nullptr, *d_cons = nullptr;   // scratch of ifx_sample_graph_model / ifx_loop_closure_constraints

@@ -411,10 +411,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
         to = (uint16_t)(unsigned int)t2.x;
     }
     pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
-    if (n_valid) {   // INACTIVE prediction of the loop-closure detection: covered pixels (one atomic per wave that has any)
-        const unsigned long long m = __ballot(vo.z != 0);
-        if (m && (__lane_id() == (unsigned)(__ffsll((long long)m) - 1))) atomicAdd(n_valid, __popcll(m));
-    }
+    (void)n_valid;
     if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
     // fill-in
     float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
@@ -789,11 +786,12 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
                h->key_ids, h->key_both);
     }
     if (part == 1) return;
-    if ((want & LIST_SPLAT) && old_target) {   // INACTIVE prediction into the old* images (IndexMap::oldFrameBuffer, EF/IndexMap.cpp:480-483), no fill-in, no dense flag
-        LAUNCH(h, "splat_resolve_old", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
-               (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->old_vertex, (float4*)h->old_normal,
-               (uchar4*)h->old_image, (uchar4*)h->old_inst, h->old_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr,
-               &h->d_m2m->count);
+    if ((want & LIST_SPLAT) && old_target) {   // loop-closure renders: 1 = INACTIVE prediction into the old* images (IndexMap::oldFrameBuffer, EF/IndexMap.cpp:480-483),
+        const bool old = old_target == 1;       // 2 = the predict() of EF/ElasticFusion.cpp:453 into the act* images; no fill-in, no dense flag
+        LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat,
+               (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
+               (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
+               old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
         LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10);
         return;
     }
@@ -1326,10 +1324,10 @@ int ifx_map_frame(ifx* h)
 
 // Loop-closure detection, map side (EF/ElasticFusion.cpp:453 and :519-526): predict() at the pose just tracked (pre-fusion map), then the
 // INACTIVE prediction -- surfels last seen at or before tick - timeDelta (splat.vert:60 with time = 0, maxTime = tick - timeDelta) -- into
-// the old* images; DevState(m2m)::count receives the number of covered pixels.
+// the old* images.  The first render goes to images of its own (act*): pred_* belong to the frame-to-model tracker.
 int ifx_map_predict_loop_closure(ifx* h)
 {
-    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, nullptr);
+    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, nullptr, false, 0, 2);
     raster_pass(h, nullptr, 0, h->tick - h->cfg.time_delta, LIST_SPLAT, nullptr, false, 0, 1);
     return IFX_OK;
 }
@@ -1469,9 +1467,10 @@ extern "C" int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, 
 {
     if (!h || !src3 || !dst3 || !times) return IFX_E_INVALID;
     if (!h->d_m2m) { h->err = "loop-closure detection is not enabled"; return IFX_E_STATE; }
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
     const int rw = h->w / 20, rh = h->h / 20, ns = rw * rh;
     if (!h->d_cons) HIPCHK(h, hipMalloc(&h->d_cons, (size_t)ns * 32));
-    LAUNCH(h, "cons_sample", dim3(cdiv(ns, 64)), dim3(64), k_cons_sample, (const DevState*)h->d_state, (const float4*)h->pred_vertex, h->old_time, h->w, h->h,
+    LAUNCH(h, "cons_sample", dim3(cdiv(ns, 64)), dim3(64), k_cons_sample, (const DevState*)h->d_state, (const float4*)h->act_vertex, h->old_time, h->w, h->h,
            h->cfg.max_depth_processed, h->d_cons);
     std::vector<float> rec((size_t)ns * 8);
     HIPCHK(h, hipMemcpyAsync(rec.data(), h->d_cons, rec.size() * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1498,6 +1497,7 @@ extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, 
         int r = ifx_tracker_alloc_m2m(h);
         if (r) return r;
     }
+    if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }   // a model-to-model run still reading the old* images
     if (!h->d_graph) HIPCHK(h, hipMalloc(&h->d_graph, 1024 * 64));
     HIPCHK(h, hipMemcpyAsync(h->d_graph, graph16, (size_t)n_nodes * 64, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // graph16 is the caller's

@@ -1400,6 +1400,7 @@ int ifx_alloc_tracker(ifx* h)
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
     HIPCHK(h, hipMalloc(&h->d_ticket, 512));
     HIPCHK(h, hipMemset(h->d_ticket, 0, 512));
+    p.icp_partials = h->icp_partials; p.rgb_partials = h->rgb_partials; p.res_partials = h->res_partials; p.ticket = h->d_ticket;
     for (int q = 0; q < 2; q++) {
         HIPCHK(h, hipMalloc(&h->slot[q].so3, sizeof(DevState)));
         HIPCHK(h, hipMemset(h->slot[q].so3, 0, sizeof(DevState)));
@@ -1568,16 +1569,16 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
         pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
-        pa.icp_partials = h->icp_partials; pa.res_partials = h->res_partials; pa.res_total = (int*)(h->d_ticket + 8);
+        pa.icp_partials = p.icp_partials; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8);
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
             LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb; sa2.nb_icp = nb; sa2.nb_res = nb;
-            sa2.rgb_partials = h->rgb_partials; sa2.icp_partials = h->icp_partials; sa2.res_partials = h->res_partials;
+            sa2.rgb_partials = p.rgb_partials; sa2.icp_partials = p.icp_partials; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
-            sa2.ticket = h->d_ticket; sa2.res_total = (int*)(h->d_ticket + 8);
+            sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8);
             LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }
@@ -1631,7 +1632,18 @@ __global__ void k_m2m_begin(const DevState* __restrict__ st, DevState* __restric
     for (int k = 0; k < 16; k++) { m->pose[k] = st->pose[k]; m->pose_inv[k] = st->pose_inv[k]; }
     m->dense_enough = 1; m->count = 0; m->skip = 0;
 }
-// after the INACTIVE render: nothing old in view -> every reduction would be empty (count 0 fails the gate of :566 whatever else is computed)
+// after the INACTIVE render: its covered pixels are counted (one atomic per block); nothing old in view -> every reduction would be empty
+// (count 0 fails the gate of :566 whatever else is computed) and the tracker kernels return at once
+__global__ __launch_bounds__(256) void k_m2m_count(DevState* __restrict__ m, const float4* __restrict__ old_vertex, int P)
+{
+    __shared__ int lds[4];
+    int c = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P; k += blockDim.x * gridDim.x) c += (old_vertex[k].z != 0);
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { const int t = lds[0] + lds[1] + lds[2] + lds[3]; if (t) atomicAdd(&m->count, t); }
+}
 __global__ void k_m2m_arm(DevState* __restrict__ m)
 {
     if (threadIdx.x == 0) m->skip = (m->count == 0);
@@ -1639,7 +1651,7 @@ __global__ void k_m2m_arm(DevState* __restrict__ m)
 // getCovariance (EF/Utils/RGBDOdometry.cpp:605-608: lastA.lu().inverse(), here Gauss-Jordan with partial pivoting in f64) and the gates of
 // EF/ElasticFusion.cpp:547-566.  The verdict goes to the main state; the deformation an accepted candidate triggers in the reference is
 // not part of this path: candidates are counted and reported.
-__global__ void k_m2m_decide(DevState* __restrict__ st, const DevState* __restrict__ m, int count_thresh, float err_thresh, float cov_thresh)
+__global__ void k_m2m_decide(DevState* __restrict__ st, const DevState* __restrict__ m, int count_thresh, float err_thresh, float cov_thresh, float* __restrict__ host_lc)
 {
     if (threadIdx.x != 0) return;
     float* lc = st->lc;
@@ -1647,23 +1659,39 @@ __global__ void k_m2m_decide(DevState* __restrict__ st, const DevState* __restri
     lc[1] = (float)m->count;
     for (int k = 0; k < 16; k++) lc[6 + k] = st->pose[k];
     if (!m->skip) {
+        // every index below is a compile-time constant after unrolling (the pivot row is swapped in by predicated exchanges), so the
+        // 6 x 12 tableau lives in registers: 50 us -> a few us for this one-thread kernel on the critical path of the frame result
         double a[6][12];
+#pragma unroll
         for (int r = 0; r < 6; r++)
+#pragma unroll
             for (int c = 0; c < 6; c++) { a[r][c] = m->lastA[r * 6 + c]; a[r][6 + c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
         for (int k = 0; k < 6; k++) {
             int piv = k;
-            for (int r = k + 1; r < 6; r++) if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
-            if (piv != k) for (int c = 0; c < 12; c++) { double tmp = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = tmp; }
+            double best = fabs(a[k][k]);
+#pragma unroll
+            for (int r = k + 1; r < 6; r++) { const double v = fabs(a[r][k]); if (v > best) { best = v; piv = r; } }
+#pragma unroll
+            for (int r = k + 1; r < 6; r++)
+                if (piv == r) {
+#pragma unroll
+                    for (int c = 0; c < 12; c++) { const double tmp = a[k][c]; a[k][c] = a[r][c]; a[r][c] = tmp; }
+                }
             const double d = 1.0 / a[k][k];
+#pragma unroll
             for (int c = 0; c < 12; c++) a[k][c] *= d;
+#pragma unroll
             for (int r = 0; r < 6; r++) {
                 if (r == k) continue;
                 const double f = a[r][k];
+#pragma unroll
                 for (int c = 0; c < 12; c++) a[r][c] -= f * a[k][c];
             }
         }
         int cov_ok = 1;
         double cmax = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             if (a[i][6 + i] > (double)cov_thresh) cov_ok = 0;
             if (!(a[i][6 + i] <= cmax)) cmax = a[i][6 + i];
@@ -1675,6 +1703,7 @@ __global__ void k_m2m_decide(DevState* __restrict__ st, const DevState* __restri
         st->lc_candidates += accept;
     }
     lc[23] = (float)st->lc_candidates;
+    for (int k = 0; k < 24; k++) host_lc[k] = lc[k];
 }
 
 int ifx_tracker_alloc_m2m(ifx* h)
@@ -1688,6 +1717,15 @@ int ifx_tracker_alloc_m2m(ifx* h)
     HIPCHK(h, hipMalloc(&h->old_inst, P * 4)); HIPCHK(h, hipMalloc(&h->old_time, P * 2));
     HIPCHK(h, hipMemset(h->old_vertex, 0, P * 16)); HIPCHK(h, hipMemset(h->old_normal, 0, P * 16)); HIPCHK(h, hipMemset(h->old_image, 0, P * 4));
     HIPCHK(h, hipMemset(h->old_time, 0, P * 2));
+    HIPCHK(h, hipMalloc(&h->act_vertex, P * 16)); HIPCHK(h, hipMalloc(&h->act_normal, P * 16)); HIPCHK(h, hipMalloc(&h->act_image, P * 4));
+    HIPCHK(h, hipMalloc(&h->act_inst, P * 4)); HIPCHK(h, hipMalloc(&h->act_time, P * 2));
+    HIPCHK(h, hipMemset(h->act_vertex, 0, P * 16)); HIPCHK(h, hipMemset(h->act_normal, 0, P * 16)); HIPCHK(h, hipMemset(h->act_image, 0, P * 4));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_lc, 24 * 4, hipHostMallocDefault));
+    memset(h->h_lc, 0, 24 * 4);
+    const int maxb = 1024;
+    HIPCHK(h, hipMalloc(&p.icp_partials, maxb * 32 * 4)); HIPCHK(h, hipMalloc(&p.rgb_partials, maxb * 32 * 4)); HIPCHK(h, hipMalloc(&p.res_partials, maxb * 2 * 4));
+    HIPCHK(h, hipMalloc(&p.ticket, 512));
+    HIPCHK(h, hipMemset(p.ticket, 0, 512));
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         p.w[i] = h->w >> i; p.h[i] = h->h >> i;
         const size_t n = (size_t)p.w[i] * p.h[i];
@@ -1712,6 +1750,9 @@ static void free_m2m(ifx* h)
         hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
     hipFree(h->d_m2m); hipFree(h->old_vertex); hipFree(h->old_normal); hipFree(h->old_image); hipFree(h->old_inst); hipFree(h->old_time);
+    hipFree(h->act_vertex); hipFree(h->act_normal); hipFree(h->act_image); hipFree(h->act_inst); hipFree(h->act_time);
+    hipFree(p.icp_partials); hipFree(p.rgb_partials); hipFree(p.res_partials); hipFree(p.ticket);
+    if (h->h_lc) hipHostFree(h->h_lc);
     h->d_m2m = nullptr;
 }
 int ifx_tracker_m2m_begin(ifx* h)
@@ -1724,11 +1765,12 @@ int ifx_tracker_m2m_begin(ifx* h)
 int ifx_tracker_loop_closure(ifx* h)
 {
     DevState* m = h->d_m2m;
+    LAUNCH(h, "m2m_count", dim3(cdiv(h->P, 4096)), dim3(256), k_m2m_count, m, (const float4*)h->old_vertex, h->P);
     LAUNCH(h, "m2m_arm", dim3(1), dim3(64), k_m2m_arm, m);
     tracker_init_model(h, m, h->m2m, 10.0f, h->old_vertex, h->old_normal, h->old_image, nullptr, nullptr, nullptr);
-    tracker_init_frame_maps(h, m, h->m2m, h->pred_vertex, h->pred_normal, h->pred_image);
+    tracker_init_frame_maps(h, m, h->m2m, h->act_vertex, h->act_normal, h->act_image);
     tracker_run(h, m, h->m2m, 10.0f, 0, 1.0f, 1, false);
-    LAUNCH(h, "m2m_decide", dim3(1), dim3(64), k_m2m_decide, h->d_state, (const DevState*)m, h->lc_count_thresh, h->lc_err_thresh, h->lc_cov_thresh);
+    LAUNCH(h, "m2m_decide", dim3(1), dim3(64), k_m2m_decide, h->d_state, (const DevState*)m, h->lc_count_thresh, h->lc_err_thresh, h->lc_cov_thresh, h->h_lc);
     return IFX_OK;
 }
 

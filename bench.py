@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--surfels", type=int, default=5_000_000)
     ap.add_argument("--loop", type=int, default=90, help="length of the closed camera loop (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-oracle sample (about 12 s of one core at 5M surfels)")
     ap.add_argument("--res", default="640x480", help="WxH of the synthetic stream (other BASELINE configurations; the metric is quoted at 640x480)")
     ap.add_argument("--sharded", action="store_true", help="one stream, every rank holds the map, projection passes sliced across ranks + RCCL all-reduce(MIN) of the key images "
                     "(instancefusion_amd/sharded.py; strong scaling; pays for tens of millions of surfels -- DESIGN.md section 7).  Default for --gpus N: one replica per rank")

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "ifx_c_api.h"
+#include "ifx_jpeg.hpp"
 
 typedef unsigned char* ImagePtr;    // IF/utilities/Types.h
 typedef unsigned short* DepthPtr;
@@ -750,7 +751,7 @@ protected:
 };
 
 // IF/utilities/RawLogReader.cpp: int32 frame count; per frame int64 timestamp, int32 depthSize, int32 imageSize, depth (raw or zlib),
-// colour (raw; JPEG frames need a decoder this header does not carry and raise an error).
+// colour (raw or baseline JPEG).
 class RawLogReader : public LogReader {
 public:
     RawLogReader(std::string file, bool flipColors) : LogReader(std::move(file), flipColors)
@@ -812,9 +813,12 @@ private:
         if (is && std::fread(io_.data(), (size_t)is, 1, fp_) != 1) throw std::runtime_error(file + ": truncated colour");
         if (is == numPixels * 3)
             std::memcpy(rgbBuf_.data(), io_.data(), (size_t)numPixels * 3);
-        else if (is > 0)
-            throw std::runtime_error(file + ": JPEG colour frames are not supported by this reader (re-encode the log with raw colour, e.g. instancefusion_amd.logio.RawLogWriter)");
-        else
+        else if (is > 0) {   // RawLogReader.cpp:96-106: JPEG (cvDecodeImage in the reference; libjpeg's default decompression path restated in ifx_jpeg.hpp)
+            int jw = 0, jh = 0;
+            ifx_jpeg::decode(io_.data(), (size_t)is, jpegBuf_, jw, jh);
+            if (jw != width || jh != height) throw std::runtime_error(file + ": JPEG frame size differs from Resolution");
+            std::memcpy(rgbBuf_.data(), jpegBuf_.data(), (size_t)numPixels * 3);
+        } else
             std::memset(rgbBuf_.data(), 0, (size_t)numPixels * 3);   // RawLogReader.cpp:107-110
         if (flipColors)
             for (int i = 0; i < numPixels; i++) std::swap(rgbBuf_[(size_t)i * 3], rgbBuf_[(size_t)i * 3 + 2]);
@@ -824,7 +828,7 @@ private:
     int numFrames_ = 0;
     std::vector<long> filePointers_;
     std::vector<unsigned short> depthBuf_;
-    std::vector<unsigned char> rgbBuf_, io_;
+    std::vector<unsigned char> rgbBuf_, io_, jpegBuf_;
 };
 
 namespace ifx_detail {

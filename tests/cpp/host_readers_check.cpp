@@ -41,6 +41,17 @@ int main(int argc, char** argv)
             }
             return 0;
         }
+        if (mode == "jpg") {   // jpg FILE OUT -> int32 w, h, rgb
+            const std::vector<unsigned char> f = ifx_detail::read_file(argv[2]);
+            std::vector<uint8_t> rgb;
+            int w = 0, h = 0;
+            ifx_jpeg::decode(f.data(), f.size(), rgb, w, h);
+            std::ofstream o(argv[3], std::ios::binary);
+            const int32_t hd[2] = {w, h};
+            o.write((const char*)hd, 8);
+            o.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+            return 0;
+        }
         if (mode == "quat") {
             std::ofstream f(argv[2], std::ios::binary);
             const float R[3][9] = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, -1, 0, 1, 0, 0, 0, 0, 1}, {-1, 0, 0, 0, -0.6f, 0.8f, 0, 0.8f, 0.6f}};

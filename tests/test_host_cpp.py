@@ -56,16 +56,77 @@ def test_raw_log_reader_equals_python(checker, tmp_path, depth_mode):
     assert k == len(got) == n - 1        # the last frame is never delivered (RawLogReader.cpp:134-137)
 
 
-def test_raw_log_reader_refuses_jpeg(checker, tmp_path):
+def _test_image(w, h, seed):
+    """smooth structure + texture + hard edges + saturated colours: exercises AC runs, EOB, ZRL, chroma upsampling edges and clamping"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 120 * np.sin(x / 9.0 + seed) * np.cos(y / 13.0), 127 + 120 * np.cos(x / 5.0) * np.sin(y / 7.0 + 1), 255.0 * ((x // 16 + y // 16) % 2)], -1)
+    img += rng.normal(0, 12, img.shape)
+    img[: h // 5, : w // 4] = (255, 0, 0)
+    img[-h // 6:, -w // 3:] = (0, 0, 255)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,quality,subsampling", [(64, 48, 90, 2), (640, 480, 95, 2), (61, 43, 75, 2), (33, 17, 100, 2), (50, 30, 85, 1), (47, 29, 60, 1),
+                                                     (40, 40, 92, 0), (8, 8, 90, 2), (1, 1, 90, 2), (17, 9, 30, 2)])
+def test_jpeg_decoder_equals_libjpeg(checker, tmp_path, w, h, quality, subsampling):
+    """ifx_jpeg.hpp against libjpeg (through PIL): every pixel identical, for 4:2:0 / 4:2:2 / 4:4:4, odd sizes, low and high quality."""
+    from PIL import Image
+
+    img = _test_image(w, h, w + h + quality)
+    f = str(tmp_path / "a.jpg")
+    Image.fromarray(img).save(f, format="JPEG", quality=quality, subsampling=subsampling)
+    ref = np.asarray(Image.open(f).convert("RGB"))
+    out = str(tmp_path / "a.bin")
+    subprocess.run([checker, "jpg", f, out], check=True)
+    b = open(out, "rb").read()
+    assert tuple(np.frombuffer(b[:8], np.int32)) == (w, h)
+    got = np.frombuffer(b[8:], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(got, ref), (np.abs(got.astype(int) - ref.astype(int)).max(), (got != ref).mean())
+
+
+def test_jpeg_decoder_grey_restart_and_refusals(checker, tmp_path):
+    from PIL import Image
+
+    img = _test_image(70, 50, 3)
+    f, out = str(tmp_path / "g.jpg"), str(tmp_path / "g.bin")
+    Image.fromarray(img[..., 0]).save(f, format="JPEG", quality=88)                      # single component
+    subprocess.run([checker, "jpg", f, out], check=True)
+    got = np.frombuffer(open(out, "rb").read()[8:], np.uint8).reshape(50, 70, 3)
+    assert np.array_equal(got, np.asarray(Image.open(f).convert("RGB")))
+    for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1)):             # restart intervals (DRI / RSTn)
+        Image.fromarray(img).save(f, format="JPEG", quality=88, **kw)
+        assert b"\xff\xdd" in open(f, "rb").read()
+        subprocess.run([checker, "jpg", f, out], check=True)
+        got = np.frombuffer(open(out, "rb").read()[8:], np.uint8).reshape(50, 70, 3)
+        assert np.array_equal(got, np.asarray(Image.open(f).convert("RGB"))), kw
+    Image.fromarray(img).save(f, format="JPEG", quality=88, progressive=True)            # progressive: refused, loudly
+    r = subprocess.run([checker, "jpg", f, out], capture_output=True, text=True)
+    assert r.returncode == 1 and "progressive" in r.stderr
+    open(f, "wb").write(b"not a jpeg at all")
+    assert subprocess.run([checker, "jpg", f, out], capture_output=True).returncode == 1
+
+
+def test_raw_log_reader_decodes_jpeg_frames(checker, tmp_path):
+    """The usual .klg (zlib depth + JPEG colour, what ElasticFusion's logger writes): same frames as the Python reader, which decodes with PIL."""
     from instancefusion_amd import logio
 
+    w, h = 64, 48
     klg = str(tmp_path / "j.klg")
-    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg")
-    for k in range(2):
-        wr.add(k, np.zeros((48, 64, 3), np.uint8), np.zeros((48, 64), np.uint16))
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg", jpeg_quality=90)
+    for k in range(4):
+        wr.add(1000 * k, _test_image(w, h, k), np.full((h, w), 1000 + k, np.uint16))
     wr.close()
-    r = subprocess.run([checker, "klg", klg, "64", "48", str(tmp_path / "o")], capture_output=True, text=True)
-    assert r.returncode == 1 and "JPEG" in r.stderr
+    out = str(tmp_path / "o.bin")
+    subprocess.run([checker, "klg", klg, str(w), str(h), out], check=True)
+    got = _frames(open(out, "rb").read(), w, h)
+    rd = logio.RawLogReader(klg, w, h)
+    k = 0
+    while rd.hasMore():
+        rd.getNext()
+        assert got[k][0] == rd.timestamp and np.array_equal(got[k][1], rd.depth) and np.array_equal(got[k][2], rd.rgb), k
+        k += 1
+    assert k == 3
 
 
 def test_png_log_reader_equals_python(checker, tmp_path):
@@ -169,7 +230,7 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     n = 16                                                    # long enough for surfels to become stable (confidence > 10) and take labels
     src = [i if i < 10 else 18 - i for i in range(n + 1)]     # the 10-frame stream forth and back
     klg = str(tmp_path / "s.klg")
-    wr = logio.RawLogWriter(klg, depth="zlib", image="raw")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg", jpeg_quality=95)       # what ElasticFusion's logger writes; both readers decode identically
     for i in range(n + 1):
         wr.add(33333 * i, st["rgb"][src[i]], st["depth"][src[i]])
     wr.close()

@@ -220,6 +220,11 @@ int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth
                              int flags);
 /* bestIDInEachSurfel (IF/Core/InstanceFusionCuda.cu:1158-1200) for the live surfels, map order. */
 int ifx_labels(ifx_t* h, int32_t* out, int max_n);
+/* InstanceFusion::renderProjectMap (IF/Core/InstanceFusion.cpp:1232-1252, renderProjectFrameKernel IF/Core/InstanceFusionCuda.cu:1432-1498): the
+ * instance colour of the surfel under every pixel of the id image after fusion -- what getProjectColorMap_gpu() hands to the GUI: H x W x 4
+ * floats (r, g, b in [0,1], alpha 1; black where no stable surfel is visible).  out_rgba: host buffer or NULL; d_out_rgba: device buffer or NULL
+ * (enqueue only, no synchronisation).  The 2-D boxes the reference draws on top on the host are not drawn. */
+int ifx_render_project_map(ifx_t* h, float* out_rgba, float* d_out_rgba);
 /* class id per instance slot, -1 = unused (getInstanceTable, IF/Core/InstanceFusion.h:87) */
 int ifx_instance_table(ifx_t* h, int32_t* out96);
 /* getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121: int[96*5] = r,g,b,class,index */

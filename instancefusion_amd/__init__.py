@@ -109,6 +109,7 @@ _SIGS = {
     "ifx_should_segment": (C.c_int, [_P, C.c_int]),
     "ifx_process_segmentation": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "ifx_labels": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_render_project_map": (C.c_int, [_P, _P, _P]),
     "ifx_instance_table": (C.c_int, [_P, _P]),
     "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
     "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
@@ -424,6 +425,12 @@ class InstanceFusion:
         out = np.zeros(max(n, 1), np.int32)
         m = self.ef._chk(self.L.ifx_labels(self.ef.handle, _ptr(out), n), "ifx_labels")
         return out[:m]
+
+    def renderProjectMap(self):
+        """InstanceFusion::renderProjectMap: instance colour under every pixel (H x W x 4 float32)."""
+        out = np.zeros((self.ef.h, self.ef.w, 4), np.float32)
+        self.ef._chk(self.L.ifx_render_project_map(self.ef.handle, _ptr(out), None), "ifx_render_project_map")
+        return out
 
     def getInstanceTable(self):
         out = np.zeros(96, np.int32)

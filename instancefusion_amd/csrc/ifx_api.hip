@@ -462,6 +462,7 @@ extern "C" int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stre
 
 extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
 {
+    if (h && h->lc_enable) { h->err = "loop-closure detection is not available in the sharded frame phases"; return IFX_E_STATE; }
     if (!h || phase < 0 || phase > 3) return IFX_E_INVALID;
     const bool first = h->tick == 1;
     const int s = h->tick & 1;

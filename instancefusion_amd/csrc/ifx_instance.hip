@@ -673,6 +673,35 @@ extern "C" int ifx_labels(ifx_t* h, int32_t* out, int max_n)
     return n;
 }
 
+// renderProjectFrameKernel, IF/Core/InstanceFusionCuda.cu:1432-1498 (InstanceFusion::renderProjectMap without the boxes drawn on the host)
+__global__ void k_render_project(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float2* __restrict__ col, int P, float4* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int id = ids[k];
+    float4 c = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (id > 0 && id < st->count) {
+        const int v = (int)col[id].y;
+        c.x = (float)((v >> 16) & 0xFF) / 255.0f; c.y = (float)((v >> 8) & 0xFF) / 255.0f; c.z = (float)(v & 0xFF) / 255.0f;
+    }
+    out[k] = c;
+}
+extern "C" int ifx_render_project_map(ifx_t* h, float* out_rgba, float* d_out_rgba)
+{
+    if (!h || (!out_rgba && !d_out_rgba)) return IFX_E_INVALID;
+    float* dst = d_out_rgba;
+    if (!dst) {
+        if (!h->d_project) HIPCHK(h, hipMalloc(&h->d_project, (size_t)h->P * 16));
+        dst = h->d_project;
+    }
+    LAUNCH(h, "render_project", dim3(cdiv(h->P, 256)), dim3(256), k_render_project, (const DevState*)h->d_state, (const int32_t*)h->ids_after, (const float2*)h->col, h->P, (float4*)dst);
+    if (out_rgba) {
+        HIPCHK(h, hipMemcpyAsync(out_rgba, dst, (size_t)h->P * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return IFX_OK;
+}
+
 extern "C" int ifx_instance_table(ifx_t* h, int32_t* out96)
 {
     if (!h || !out96) return IFX_E_INVALID;

@@ -663,6 +663,15 @@ public:
         segmentations_++;
     }
 
+    // IF/Core/InstanceFusion.cpp:1232-1252 (the image the GUI shows as "segmentation"; the 2-D boxes are not drawn): H x W x 4 floats
+    const std::vector<float>& renderProjectMap(const std::unique_ptr<ElasticFusionInterface>& map, bool /*drawBBox*/ = false)
+    {
+        projectColor_.resize((size_t)width * height * 4);
+        if (ifx_render_project_map(map->handle(), projectColor_.data(), nullptr) != IFX_OK) throw std::runtime_error(std::string("ifx_render_project_map: ") + ifx_last_error(map->handle()));
+        return projectColor_;
+    }
+    const std::vector<float>& getProjectColorMap() const { return projectColor_; }
+
     // IF/Core/InstanceFusion.h:87: one entry per instance slot; name = COCO class of the slot ("" = unused slot)
     std::vector<ClassColour> getInstanceTable()
     {
@@ -719,6 +728,7 @@ private:
     ifx_t* handle_ = nullptr;
     bool superpixels_ = true;
     int segmentations_ = 0;
+    std::vector<float> projectColor_;
 };
 
 // ------------------------------------------------------------------------------------------------ log readers

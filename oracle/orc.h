@@ -166,6 +166,7 @@ int orc_process_segmentation(orc_t*, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks, const int32_t* class_ids, int n, int frame,
                              int do_knn);
 void orc_labels(orc_t*, int32_t* out);
+void orc_render_project_map(orc_t*, float* out_rgba);   /* renderProjectFrameKernel: instance colour under every pixel, H x W x 4 floats */
 void orc_instance_table(orc_t*, int32_t* class_of_instance /*96, -1 unused*/);
 
 /* superpixel refinement (a20, a21; orc_slic.c).  orc_slic_segment: gSLICrInterface, returns the number of

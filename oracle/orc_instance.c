@@ -46,6 +46,21 @@ void orc_instance_free(orc_t* o) { free(o->labels); }
 void orc_instance_table(orc_t* o, int32_t* out) { memcpy(out, o->inst_class, sizeof(o->inst_class)); }
 void orc_labels(orc_t* o, int32_t* out) { memcpy(out, o->labels, (size_t)o->n * 4); }
 
+/* InstanceFusion::renderProjectMap without the boxes: renderProjectFrameKernel, IF/Core/InstanceFusionCuda.cu:1432-1498 -- the instance colour of
+ * the surfel under every pixel of the id image after fusion, RGBA float, black where no stable surfel is visible */
+void orc_render_project_map(orc_t* o, float* out_rgba)
+{
+    for (int k = 0; k < o->P; k++) {
+        const int id = o->ids_after[k];
+        float* c = out_rgba + (size_t)k * 4;
+        if (id > 0 && id < o->n) {
+            const int v = (int)o->col[id * 2 + 1];
+            c[0] = (float)((v >> 16) & 0xFF) / 255.0f; c[1] = (float)((v >> 8) & 0xFF) / 255.0f; c[2] = (float)(v & 0xFF) / 255.0f;
+        } else c[0] = c[1] = c[2] = 0.0f;
+        c[3] = 1.0f;
+    }
+}
+
 /* maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131 */
 void orc_mask_clean_overlap(uint8_t* masks, int n, int w, int h)
 {

@@ -295,6 +295,12 @@ class Oracle:
         self.L.orc_mask_superpixel_filter(self.h, ptr(fin), ptr(masks), masks.shape[0])
         return masks
 
+    def render_project_map(self):
+        out = np.zeros((self.h_, self.w_, 4), np.float32)
+        self.L.orc_render_project_map.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_render_project_map(self.h, ptr(out))
+        return out
+
     def labels(self):
         out = np.zeros(self.count, np.int32)
         self.L.orc_labels(self.h, ptr(out))

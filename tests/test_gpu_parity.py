@@ -686,6 +686,9 @@ def test_instance_table_eviction_exact(ifx, orc, small_stream):
     assert evicted
     lc = inst.getLoopClosureInstanceTable()
     assert lc.shape == (96, 5) and np.array_equal(lc[:, 3] >= 0, to >= 0)
+    # InstanceFusion::renderProjectMap: the instance colour under every pixel
+    pm_g, pm_o = inst.renderProjectMap(), o.render_project_map()
+    assert np.array_equal(pm_g, pm_o) and (pm_o[..., :3].sum(axis=2) > 0).mean() > 0.05 and (pm_o[..., 3] == 1).all()
     g.close(); o.close()
 
 

@@ -465,3 +465,25 @@ def test_deformation_hooks_properties(orc, small_stream):
         newp, newn = _deform_numpy(g2, m4["pc"][i, :3], m4["nr"][i, :3], m4["tm"][i, 0])
         assert np.abs(m3["pc"][i, :3] - newp).max() < 5e-6 and np.abs(m3["nr"][i, :3] - newn).max() < 5e-6, i
     o.close(); o2.close()
+
+
+def test_render_project_map_properties(orc, small_stream):
+    """renderProjectFrameKernel: black where the id image is empty, the surfel's instance colour elsewhere."""
+    from instancefusion_amd import synth
+
+    st = small_stream
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    for i in range(4):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+    m = o.download(); m["pc"][:, 3] = 20.0
+    o.upload(m); o.set_pose(po, o.tick)
+    o.process_frame(st["rgb"][3], st["depth"][3], in_pose=po)
+    masks, cls = synth.canned_masks(st["obj"][3], st["scene"])
+    o.process_segmentation(st["rgb"][3], st["depth"][3], masks, cls, 3)
+    ids, pm, mm = o.image("ids_after"), o.render_project_map(), o.download()
+    assert (pm[..., 3] == 1).all() and (pm[ids <= 0][:, :3] == 0).all()
+    vis = ids > 0
+    c = mm["col"][ids[vis], 1].astype(np.int64)
+    assert np.array_equal(pm[vis][:, 0], ((c >> 16) & 255).astype(np.float32) / np.float32(255)) and np.array_equal(pm[vis][:, 2], (c & 255).astype(np.float32) / np.float32(255))
+    assert (pm[vis][:, :3].sum(axis=1) > 0).any()
+    o.close()

@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libifx.so")
+LIB_PATH = os.environ.get("IFX_LIB") or os.path.join(_HERE, "libifx.so")   # IFX_LIB: an experimental build of the same library (tools/bench_variants.sh)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ifx_c_api.h")
 
 NUM_INSTANCES = 96

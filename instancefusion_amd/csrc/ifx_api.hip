@@ -95,7 +95,11 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->pc, C * 16); ALLOC(h->nr, C * 16); ALLOC(h->col, C * 8); ALLOC(h->tm, C * 8); ALLOC(h->ic, C * 16); ALLOC(h->votes, C * 192);
     ALLOC(h->pc2, C * 16); ALLOC(h->nr2, C * 16); ALLOC(h->col2, C * 8); ALLOC(h->tm2, C * 8); ALLOC(h->ic2, C * 16); ALLOC(h->votes2, C * 192);
     ALLOC(h->upd_owner, C * 4);
-    ALLOC(h->list_a, C * 4); ALLOC(h->list_b, C * 4); ALLOC(h->list_c, C * 4);
+    // a chunk of 4096 slots (ifx_map.hip: MAP_THREADS x CHUNK_ROUNDS) appends to segment chunk % 8: a segment holds at most its share of the chunks
+    h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096);
+    ALLOC(h->list_a, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_b, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_c, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
+    ALLOC(h->d_list_ctr, 3 * IFX_LIST_SEGS * 32 * 4);
+    hipMemset(h->d_list_ctr, 0, 3 * IFX_LIST_SEGS * 32 * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
@@ -145,7 +149,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,

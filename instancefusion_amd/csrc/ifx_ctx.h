@@ -22,7 +22,7 @@ struct DevState {
     int n_dead;           // tombstones
     int n_new;            // new surfels appended by the last clean
     int overflow;         // set when an append hit the capacity
-    unsigned int list_n[4];   // lengths of the per-frame work lists (0: raster candidates, 1: clean candidates, 2: kill list)
+    unsigned int list_n[4];   // (unused: the work-list lengths live in ifx::d_list_ctr, one counter per list segment)
     unsigned int r_max_bits;  // float bits of an upper bound of every surfel radius ever stored (conservative frustum margin)
     // tracker state (RGBDOdometry::getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603)
     float Rprev[9], tprev[3], Rprev_inv[9];
@@ -97,6 +97,10 @@ struct FrameSlot {
     int for_tick = -1;                // frame the slot was prepared for
 };
 
+#ifndef IFX_LIST_SEGS
+#define IFX_LIST_SEGS 8   // segments of a work list, each with its own length counter (ifx_map.hip)
+#endif
+
 struct KernelTiming { double total_ms = 0; int launches = 0; };
 struct PendingEvent { int name_id; hipEvent_t a, b; };
 
@@ -159,7 +163,9 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
-    uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [cap] work lists (surfel index | flags << 30)
+    uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [8 segments x list_seg_cap] work lists (surfel index | flags << 30): raster candidates, clean candidates, kill list
+    unsigned int* d_list_ctr = nullptr;   // [3 lists][8 segments] lengths, 128 B apart
+    unsigned int list_seg_cap = 0;
     int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot
     int* scan_flags = nullptr;         // [max(cap,P)]
     int* scan_block = nullptr;

@@ -18,7 +18,9 @@
 #define ASSOC_NONE 0xFFFFFFFFu
 #define ASSOC_NEW 0xFFFFFFFEu
 #define MAP_THREADS 256
+#ifndef MAP_BLOCKS
 #define MAP_BLOCKS 2048
+#endif
 
 // ------------------------------------------------------------------ shared GLSL helpers
 // EF/Shaders/surfels.glsl:19-34
@@ -58,13 +60,21 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
     return normalized(cross(del_x, del_y));
 }
 
-struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; };   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode)
+// Work lists are kept in LIST_SEGS independent segments, each with its own length counter on a cache line of its own: a block appends the survivors
+// of chunk c to segment c % LIST_SEGS.  One returning atomic per chunk on a SINGLE counter costs ~8 ns each once ~1300 blocks hit it at the same
+// time (doubling the chunks per launch slowed the cull kernels from 42 to 52 us); spread over 8 addresses they no longer queue up: 42 -> 34 us.
+// A consumer block works on segment blockIdx % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk).
+#define LIST_SEGS IFX_LIST_SEGS
+#define LIST_CTR_STRIDE 32   // uints between counters: 128 B
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; };   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
+__device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
 static Cam make_cam(ifx* h)
 {
     Cam c;
     c.fx = h->cfg.fx; c.fy = h->cfg.fy; c.cx = h->cfg.cx; c.cy = h->cfg.cy; c.w = h->w; c.h = h->h;
     c.maxDepth = h->cfg.max_depth_processed; c.conf = h->cfg.confidence; c.timeDelta = h->cfg.time_delta;
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
+    c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
     return c;
 }
 
@@ -436,7 +446,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
 // blocks 1.. = checkProjectDepthAndInstanceKernel (IF/Core/InstanceFusionCuda.cu:736-760) over the id image this pass
 // rendered, accumulated for k_frame_result, so that whetherDoSegmentation needs no launch of its own.
 __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, int w, int h, int do_dense, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap,
-                                int downsample)
+                                int downsample, unsigned int* __restrict__ lctr)
 {
     if (blockIdx.x == 0) {
         if (do_dense) {
@@ -456,7 +466,7 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
                 st->dense_enough = ((float)sum / (float)(rw * rh) > 0.75f) ? 1 : 0;
             }
         }
-        if (threadIdx.x == 0) st->list_n[0] = 0;
+        if (threadIdx.x < LIST_SEGS) lctr[threadIdx.x * LIST_CTR_STRIDE] = 0;   // re-arm the raster work list (list 0)
         return;
     }
     const int gw = (w + downsample - 1) / downsample, gh = (h + downsample - 1) / downsample;
@@ -502,8 +512,11 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // Block-aggregated list append: survivors of a 4096-slot chunk are collected in LDS (wave ballot ->
 // one LDS atomic per wave) and flushed with ONE global atomicAdd per block and chunk.  (One global
 // returning atomic per wave on a single counter saturates at ~88 per microsecond -- 87k waves cost 1 ms.)
+#ifndef CHUNK_ROUNDS
 #define CHUNK_ROUNDS 16
+#endif
 #define CHUNK_SLOTS (MAP_THREADS * CHUNK_ROUNDS)
+static_assert(CHUNK_SLOTS == 4096, "ifx_create sizes the work-list segments for 4096-slot chunks (list_seg_cap)");
 // Per-chunk append without an LDS staging buffer: every round reserves wave-contiguous positions in a
 // block-local counter (one LDS atomic per wave), the block reserves its range of the global list with
 // ONE global atomic, and each thread then writes its survivors straight to list[base + position].
@@ -596,7 +609,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
             val[r] = flags ? ((unsigned int)i | flags) : 0u;
             pos[r] = bcount_reserve(L, flags != 0);
         }
-        const unsigned int base = bcount_commit(L, &st->list_n[0]);
+        const int seg = chunk % LIST_SEGS;
+        const unsigned int base = seg * c.seg_cap + bcount_commit(L, list_ctr(c, 0, seg));
 #pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++)
             if (val[r]) list[base + pos[r]] = val[r];
@@ -613,9 +627,12 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
-    const unsigned int n = st->list_n[0];
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += blockDim.x * gridDim.x) {
-        const unsigned int e = list[t];
+    // block b works on segment b % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk): one length to read, no search
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, 0, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
+        const unsigned int e = seg_list[t];
         const unsigned int i = e & LIST_IDX;
         float4 p4 = pc[i], n4 = nr[i];
         v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
@@ -722,9 +739,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
             kmask |= kill ? (1u << r) : 0u;
         }
         __syncthreads();
-        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(&st->list_n[1 + threadIdx.x], L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
+        const int seg = chunk % LIST_SEGS;
+        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(list_ctr(c, 1 + threadIdx.x, seg), L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
         __syncthreads();
-        const unsigned int bc = L2.base[0], bk = L2.base[1];
+        const unsigned int bc = seg * c.seg_cap + L2.base[0], bk = seg * c.seg_cap + L2.base[1];
 #pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++) {
             unsigned int i = (unsigned int)(chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x);
@@ -743,9 +761,11 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = Ti[k];
-    const unsigned int nc = st->list_n[1], nk = st->list_n[2];
+    const int seg = blockIdx.x % LIST_SEGS;   // as k_raster_list: one segment of both lists per block
+    const unsigned int nc = *list_ctr(c, 1, seg), nk = *list_ctr(c, 2, seg);
+    list_cand += (size_t)seg * c.seg_cap; list_kill += (size_t)seg * c.seg_cap;
     int dead = 0;
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < nc + nk; t += blockDim.x * gridDim.x) {
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < nc + nk; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
         bool del;
         unsigned int i;
         float2 tt;
@@ -792,7 +812,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
                (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
                (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
                old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
-        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
         return;
     }
     if (want & LIST_SPLAT) {
@@ -805,7 +825,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
     const int seg = frame_sums && (want & LIST_IDS);   // only the frame's own render feeds whetherDoSegmentation (not the re-render after a compaction)
     const int ds = 10, nseg = seg ? cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256) : 0;
     LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, (want & LIST_SPLAT) ? 1 : 0, h->ids_after,
-           (const float4*)h->votes, h->cap, ds);
+           (const float4*)h->votes, h->cap, ds, h->d_list_ctr);
 }
 static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime) { raster_pass(h, d_pose_inv, time, maxTime, LIST_SPLAT, nullptr); }
 
@@ -1007,8 +1027,8 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
     __syncthreads();
     if (threadIdx.x == 0) {
         block_counts[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-        if (blockIdx.x == 0) { st->list_n[1] = 0; st->list_n[2] = 0; }   // k_clean_list, the launch before this one, was their last reader
     }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * LIST_SEGS) c.lctr[(LIST_SEGS + threadIdx.x) * LIST_CTR_STRIDE] = 0;   // lists 1, 2: k_clean_list, the launch before this one, was their last reader
 }
 
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,

@@ -544,10 +544,11 @@ struct PairArgs {
     float* icp_partials;
     int* res_partials;
     int* res_total;
+    int check_skip;
 };
 __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, PairArgs a)
 {
-    if (st->skip) return;
+    if (a.check_skip && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
     if ((int)blockIdx.x < a.nb_icp) {
         IcpArgs ia;   // unused when st != nullptr
         icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_partials);
@@ -1256,10 +1257,11 @@ struct StepArgs {
     int icp, rgb;
     float icp_weight, nfx, nfy, ncx, ncy;
     unsigned int* ticket;
+    int check_skip;
 };
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
 {
-    if (st->skip) return;   // uniform over the grid: the last-block ticket stays armed
+    if (a.check_skip && st->skip) return;   // (model-to-model instance only) uniform over the grid: the last-block ticket stays armed
     __shared__ int s_last;
 #ifdef IFX_STAMPS
     long long t0 = clock64();
@@ -1569,7 +1571,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
         pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nb : 0; pa.nb_res = rgb ? nb : 0;
-        pa.icp_partials = p.icp_partials; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8);
+        pa.icp_partials = p.icp_partials; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8); pa.check_skip = frame_tracker ? 0 : 1;
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
             LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
@@ -1578,7 +1580,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb; sa2.nb_icp = nb; sa2.nb_res = nb;
             sa2.rgb_partials = p.rgb_partials; sa2.icp_partials = p.icp_partials; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
-            sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8);
+            sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8); sa2.check_skip = frame_tracker ? 0 : 1;
             LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }

@@ -11,7 +11,8 @@
  * restated here by hand, each function citing the reference file:line it follows.  The only stage
  * whose reference source builds as-is is gSLICr's shared per-pixel maths
  * (src/gSLICr/gSLICr_Lib/engines/gSLICr_seg_engine_shared.h with -DCOMPILE_WITHOUT_CUDA); it is
- * compiled into oracle/_ref/ and pins orc_slic_* (see oracle/Makefile, tests/test_oracle_slic.py).
+ * compiled into oracle/_ref/ and pins orc_slic_* (see oracle/Makefile, tests/test_oracle_slic.py).  The k-NN search of orc_knn_vote is
+ * pinned by the reference's vendored FLANN 1.8.4 (header-only C++ API, exact CPU index; oracle/ref_knn.cpp, tests/golden/knn_ref.npz).
  *
  * Citation prefixes:  EF/ = elasticfusionpublic/Core/src/   IF/ = src/   (under /root/reference)
  *

@@ -602,6 +602,27 @@ def test_knn_vote_exact(ifx, orc):
     g.close(); o.close()
 
 
+def test_knn_against_reference_flann_golden(ifx):
+    """The HIP grid search against the neighbour lists of the reference's vendored FLANN 1.8.4 (tests/golden/knn_ref.npz)."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_ref.npz"))
+    pos, ref_idx = gold["pos"], gold["idx"].astype(np.int64)
+    n = pos.shape[0]
+    g = ifx.ElasticFusion(w=320, h=240, fx=264.0, fy=264.0, cx=160.0, cy=120.0, max_surfels=n + 10)
+    m = dict(pc=np.concatenate([pos, np.full((n, 1), 20.0, np.float32)], 1), nr=np.tile(np.array([0, 0, 1, 0.01], np.float32), (n, 1)), col=np.zeros((n, 2), np.float32),
+             tm=np.ones((n, 2), np.float32), ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32))
+    g.upload(m)
+    mine = ifx.InstanceFusion(g).flannKnnVoteSurfelMap(with_neighbours=True)[:n].astype(np.int64)
+    p64 = pos.astype(np.float64)
+    dm = np.sort(((p64[mine] - p64[:, None, :]) ** 2).sum(-1), axis=1)
+    dr = np.sort(((p64[ref_idx] - p64[:, None, :]) ** 2).sum(-1), axis=1)
+    assert np.array_equal(dm, dr)                                     # same distances: equal up to the order / choice of equidistant points
+    strict = (np.diff(dr, axis=1) > 0).all(axis=1)
+    assert strict.mean() > 0.95 and np.array_equal(mine[strict], ref_idx[strict])
+    g.close()
+
+
 # ---------------------------------------------------------------- tracker configurations other than the default (BASELINE config 1: single-scale ICP)
 @pytest.mark.parametrize("name,kw", [
     ("single_scale_icp_only", dict(pyramid=0, icp_weight=100.0, so3=0)),     # RGBDOdometry iterations {10,0,0}, icp && !rgb

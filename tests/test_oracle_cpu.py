@@ -332,6 +332,54 @@ def test_knn_vote_against_scipy(orc):
     o.close()
 
 
+def _knn_lists_equivalent(pos, mine, ref_idx):
+    """Two 10-NN answers agree when every point has the same sorted distances (equidistant neighbours may be listed in another order or,
+    at the 10th place, be another point) and identical index lists wherever the distances are strictly increasing."""
+    p64 = pos.astype(np.float64)
+    dm = np.sort(((p64[mine] - p64[:, None, :]) ** 2).sum(-1), axis=1)
+    dr = np.sort(((p64[ref_idx] - p64[:, None, :]) ** 2).sum(-1), axis=1)
+    assert np.array_equal(dm, dr)
+    strict = (np.diff(dr, axis=1) > 0).all(axis=1)
+    assert strict.mean() > 0.95 and np.array_equal(mine[strict], ref_idx[strict])
+
+
+def _oracle_knn_lists(orc, pos):
+    n = pos.shape[0]
+    o = orc.Oracle(w=320, h=240, fx=264.0, fy=264.0, cx=160.0, cy=120.0, max_surfels=n + 10)
+    m = dict(pc=np.concatenate([pos, np.full((n, 1), 20.0, np.float32)], 1), nr=np.tile(np.array([0, 0, 1, 0.01], np.float32), (n, 1)), col=np.zeros((n, 2), np.float32),
+             tm=np.ones((n, 2), np.float32), ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32))
+    o.upload(m)
+    nbr = o.knn_vote(with_neighbours=True)
+    o.close()
+    return nbr
+
+
+def test_knn_against_reference_flann_golden(orc):
+    """The oracle's neighbour lists against the answer of the reference's vendored FLANN 1.8.4 (tests/golden/knn_ref.npz, tools/make_golden.py)."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_ref.npz"))
+    pos, ref_idx = gold["pos"], gold["idx"].astype(np.int64)
+    assert (ref_idx[:, 0] == np.arange(len(pos))).mean() > 0.999            # a point is its own nearest neighbour
+    _knn_lists_equivalent(pos, _oracle_knn_lists(orc, pos).astype(np.int64), ref_idx)
+
+
+def test_knn_against_reference_flann_live(orc):
+    """Same, against oracle/_ref/libref_knn.so itself on another cloud (needs /root/reference at build time)."""
+    import os
+
+    so = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libref_knn.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_knn.so not built (needs /root/reference)")
+    ref = C.CDLL(so)
+    ref.ref_knn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.RandomState(5)
+    pos = np.ascontiguousarray(np.concatenate([rng.uniform(-2, 2, (3000, 3)), rng.normal(0, 0.05, (1500, 3))]), np.float32)   # uniform + a dense cluster
+    idx, dist = np.zeros((len(pos), 10), np.int32), np.zeros((len(pos), 10), np.float32)
+    assert ref.ref_knn(pos.ctypes.data, len(pos), 10, 64, idx.ctypes.data, dist.ctypes.data) == 0
+    _knn_lists_equivalent(pos, _oracle_knn_lists(orc, pos).astype(np.int64), idx.astype(np.int64))
+
+
 # ---------------------------------------------------------------- local loop-closure detection (EF/ElasticFusion.cpp:453-566)
 def test_loop_closure_detection_properties(orc, small_stream):
     st = small_stream

@@ -68,6 +68,25 @@ def slic_fixtures(d):
         o.close()
     np.savez_compressed(os.path.join(OUT, "slic_ref.npz"), **out)
     print({k: (v.shape, v.dtype) for k, v in out.items()})
+    knn_fixture()
+
+
+def knn_fixture():
+    """4. knn_ref.npz -- the 10 nearest neighbours of every point of a seeded surfel cloud according to the REFERENCE's vendored FLANN 1.8.4
+    (oracle/_ref/libref_knn.so: KDTreeSingleIndex, exact search, leaf_max_size 64 as at IF/Core/InstanceFusion.cpp:1085-1087)."""
+    import ctypes as C
+
+    from instancefusion_amd import synth
+
+    n = 6000
+    st = synth.make_stream(1, 320, 240, 264.0, 264.0, 160.0, 120.0, noise=False)
+    pos = np.ascontiguousarray(synth.make_map(n, st["scene"], st["poses_world"][0], 10, seed=77)["pc"][:, :3], np.float32)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_knn.so"))
+    ref.ref_knn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    idx, dist = np.zeros((n, 10), np.int32), np.zeros((n, 10), np.float32)
+    assert ref.ref_knn(pos.ctypes.data, n, 10, 64, idx.ctypes.data, dist.ctypes.data) == 0
+    np.savez_compressed(os.path.join(OUT, "knn_ref.npz"), pos=pos, idx=idx.astype(np.int16), dist=dist)
+    print("knn_ref", pos.shape, idx.shape)
 
 
 if __name__ == "__main__":

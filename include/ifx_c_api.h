@@ -11,7 +11,7 @@
  * on failure; ifx_last_error() gives the message.  Nothing calls exit() (the reference's
  * cudaSafeCall / gpuErrChk do: EF/Cuda/convenience.cuh:64-71, IF/Core/InstanceFusionCuda.cu:11-20).
  *
- * Threading: one ifx_t = one host thread + one HIP stream; the handle is not thread-safe.
+ * Threading: one ifx_t = one host thread + its own HIP streams (main, frame side, loop-closure tracker); the handle is not thread-safe.
  */
 #ifndef IFX_C_API_H_
 #define IFX_C_API_H_

@@ -195,6 +195,13 @@ def main():
             table[nme] = dict(avg_ms=avg, launches=cnt, total_ms=avg * cnt)
             if cnt and algorithmic_bytes(nme, n_slots, P) > 0 and (best is None or avg * cnt > table[best]["total_ms"]):
                 best = nme
+        # the two launches of a Gauss-Newton iteration (icp_residual, rgb_step_solve) take the same time to within a per cent, so which of them
+        # is "the" dominant kernel would flip from run to run: within 5 % the one that moves more algorithmic bytes is reported
+        if best:
+            for nme in names:
+                t = table[nme]
+                if t["launches"] and nme != best and t["total_ms"] > 0.95 * table[best]["total_ms"] and algorithmic_bytes(nme, n_slots, P) > algorithmic_bytes(best, n_slots, P):
+                    best = nme
         ef.set_option("kernel_timing", 0)
         # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
         # MI355X_MICROARCH.md prescribes for gfx950; collected offline on this same command, see profiles/README.md)

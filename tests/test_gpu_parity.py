@@ -1034,6 +1034,36 @@ def test_deformation_application_exact(ifx, orc, small_stream, is_fern):
     o.close(); g.close()
 
 
+def test_deformation_large_graph(ifx, orc, small_stream):
+    """1000 nodes (the reference allows < 1024): 64 KB of graph in LDS, deep binary search, every surfel has 20 time neighbours on both sides."""
+    st = small_stream
+    o = orc.Oracle(**SMALL, max_surfels=400000, confidence=2.0)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
+    for k in range(5):
+        pose = o.process_frame(st["rgb"][k], st["depth"][k])
+    m0 = o.download()
+    g.processFrame(st["rgb"][0], st["depth"][0])
+    g.upload(m0); g.set_pose(pose, o.tick)
+    rng = np.random.RandomState(3)
+    pick = np.sort(rng.choice(len(m0["pc"]), 1000, replace=False))                 # map order = time order
+    samples = np.concatenate([m0["pc"][pick, :3], m0["tm"][pick, :1]], 1)
+    assert (np.diff(samples[:, 3]) >= 0).all()
+    graph = _random_graph(samples, rng, rot=0.02, trans=0.01)
+    for e in (o, g):
+        e.set_frame(st["rgb"][5], st["depth"][5])
+        e.predict_indices(pose, o.tick); e.fuse(pose, o.tick, 1.0); e.predict_indices(pose, o.tick)
+        e.set_deformation(graph, is_fern=True)
+        e.clean(pose, o.tick)
+    mo, mg = o.download(), g.download()
+    for key in MAP_KEYS:
+        assert np.array_equal(mo[key], mg[key]), key
+    with pytest.raises(ifx.IfxError):
+        g.set_deformation(np.zeros((1024, 16), np.float32))                        # GlobalModel::MAX_NODES
+    with pytest.raises(ifx.IfxError):
+        g.set_deformation(graph[::-1].copy())                                      # not sorted by time
+    o.close(); g.close()
+
+
 def test_sample_graph_with_tombstones(ifx, small_stream):
     """Deformation::sampleGraphModel numbers the surfels of the compacted map; the store keeps tombstones: the sample must not depend on them."""
     st = small_stream

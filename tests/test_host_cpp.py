@@ -257,3 +257,36 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     assert lab.size > 0 and np.array_equal(lab, np.fromfile(out_p + ".labels", np.int32))
     head = open(out_c + ".ply", "rb").read(200)
     assert int(head.split(b"element vertex ")[1].split(b"\n")[0]) > 1000          # stable surfels were exported
+
+
+@pytest.mark.gpu
+def test_cpp_replay_png_log_equals_klg(small_stream, tmp_path):
+    """The same frames as a data.txt image list (IF/utilities/PNGLogReader.cpp) and as a .klg: identical trajectories from ifx_replay.
+    (The PNG reader delivers every frame, the .klg reader never its last one: the .klg gets one more frame.)"""
+    from PIL import Image
+
+    from instancefusion_amd import logio
+
+    st = small_stream
+    n = 6
+    klg = str(tmp_path / "s.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="raw")
+    lines = []
+    for i in range(n + 1):
+        k = min(i, n - 1)
+        wr.add(33333 * i, st["rgb"][k], st["depth"][k])
+        if i < n:
+            Image.fromarray(st["rgb"][k]).save(tmp_path / f"{i}_color.png")
+            Image.fromarray(st["depth"][k]).save(tmp_path / f"{i}_depth.png")
+            lines.append(f"{33333 * i} {i}_depth.png {i}_color.png {i} {i}")
+    wr.close()
+    (tmp_path / "data.txt").write_text("\n".join(lines) + "\n")
+    common = ["--width", str(SMALL["w"]), "--height", str(SMALL["h"]), "--fx", str(SMALL["fx"]), "--fy", str(SMALL["fy"]), "--cx", str(SMALL["cx"]),
+              "--cy", str(SMALL["cy"]), "--max-surfels", "400000"]
+    outs = []
+    for src, tag in ((klg, "K"), (str(tmp_path / "data.txt"), "P")):
+        out = str(tmp_path / tag)
+        r = subprocess.run([REPLAY, src] + common + ["--out", out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and f"{n} frames" in r.stdout, (r.stdout, r.stderr)
+        outs.append(open(out + ".freiburg").read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == n

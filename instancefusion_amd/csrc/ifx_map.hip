@@ -508,6 +508,7 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 #define LIST_SPLAT 0x40000000u
 #define LIST_IDS 0x80000000u
 #define LIST_IDX 0x3FFFFFFFu
+#define LIST_DUAL 0x1u   // only in the `want` argument of the cull: two splat renders (active / inactive window) from one scan
 
 // Block-aggregated list append: survivors of a 4096-slot chunk are collected in LDS (wave ballot ->
 // one LDS atomic per wave) and flushed with ONE global atomicAdd per block and chunk.  (One global
@@ -599,9 +600,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
                     v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
                     if (q.z > 0.f && may_touch_image(reach, q, c)) {
                         if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) flags |= LIST_IDS;
-                        if ((want & LIST_SPLAT) && !(q.z > c.maxDepth || (float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime)) {
-                            float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;   // exact: GL clips points by their centre
-                            if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= LIST_SPLAT;
+                        if ((want & LIST_SPLAT) && !(q.z > c.maxDepth)) {
+                            // LIST_DUAL (loop-closure renders): the ACTIVE prediction (time, maxTime) and the INACTIVE one (time = 0, maxTime = time - timeDelta:
+                            // last seen at or before that) in one scan -- the second flag travels in the LIST_IDS bit, which that pass does not use otherwise
+                            const bool act = !((float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime);
+                            const bool old = (want & LIST_DUAL) && !(0.f - lastT > (float)c.timeDelta || lastT > (float)(time - c.timeDelta));
+                            if (act || old) {
+                                float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;   // exact: GL clips points by their centre
+                                if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= (act ? LIST_SPLAT : 0u) | (old ? LIST_IDS : 0u);
+                            }
                         }
                     }
                 }
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
                                                              const float4* __restrict__ nr, Cam c, const unsigned int* __restrict__ list,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
-                                                             unsigned long long* __restrict__ key_both)
+                                                             unsigned long long* __restrict__ key_both, int dual)
 {
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
@@ -652,6 +659,27 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                 sx0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, c.w - 1); sx1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, c.w - 1);
                 sy0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, c.h - 1); sy1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, c.h - 1);
             }
+        }
+        if (dual) {   // two splat renders: the LIST_IDS bit marks the INACTIVE one, same sprite region and depth rule, its own key image
+            if (!(e & LIST_SPLAT)) {   // (do_s was computed for the SPLAT bit only)
+                float s2 = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
+                if (!(s2 == s2)) continue;
+                s2 = fminf(fmaxf(s2, 1.0f), IFX_MAX_SPRITE);
+                sx0 = clampi((int)ceilf(u - s2 * 0.5f - 0.5f), 0, c.w - 1); sx1 = clampi((int)floorf(u + s2 * 0.5f - 0.5f), 0, c.w - 1);
+                sy0 = clampi((int)ceilf(v - s2 * 0.5f - 0.5f), 0, c.h - 1); sy1 = clampi((int)floorf(v + s2 * 0.5f - 0.5f), 0, c.h - 1);
+            } else if (!do_s) continue;
+            const bool to_act = (e & LIST_SPLAT) != 0, to_old = (e & LIST_IDS) != 0;
+            Disc dd;
+            dd.q = q; dd.n = nn; dd.r2 = r * r;
+            for (int py = sy0; py <= sy1; py++)
+                for (int px = sx0; px <= sx1; px++) {
+                    float z;
+                    if (!disc_hit(dd, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
+                    if (!(z >= -c.maxDepth && z <= c.maxDepth)) continue;
+                    if (to_act) key_min(&key_splat[py * c.w + px], make_key(z, i));
+                    if (to_old) key_min(&key_ids[py * c.w + px], make_key(z, i));
+                }
+            continue;
         }
         // id region: bounding box of the quad (surfel_ids.geom:49-82)
         bool do_i = (e & LIST_IDS) != 0;
@@ -803,7 +831,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
         LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
                h->list_a);
         LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
-               h->key_ids, h->key_both);
+               h->key_ids, h->key_both, 0);
     }
     if (part == 1) return;
     if ((want & LIST_SPLAT) && old_target) {   // loop-closure renders: 1 = INACTIVE prediction into the old* images (IndexMap::oldFrameBuffer, EF/IndexMap.cpp:480-483),
@@ -1347,8 +1375,20 @@ int ifx_map_frame(ifx* h)
 // the old* images.  The first render goes to images of its own (act*): pred_* belong to the frame-to-model tracker.
 int ifx_map_predict_loop_closure(ifx* h)
 {
-    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, nullptr, false, 0, 2);
-    raster_pass(h, nullptr, 0, h->tick - h->cfg.time_delta, LIST_SPLAT, nullptr, false, 0, 1);
+    // both renders see the same map at the same pose and differ only in the time window: one scan of the store, one raster launch (two key images)
+    Cam c = make_cam(h);
+    c.srank = 0; c.sn = 1;
+    LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
+           LIST_SPLAT | LIST_DUAL, h->list_a);
+    LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+           h->key_ids, h->key_both, 1);
+    for (int old = 0; old < 2; old++)
+        LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, (const float*)nullptr,
+               old ? h->key_ids : h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt,
+               (float4*)(old ? h->old_vertex : h->act_vertex), (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image),
+               (uchar4*)(old ? h->old_inst : h->act_inst), old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both,
+               (int32_t*)nullptr, (int*)nullptr);
+    LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
     return IFX_OK;
 }
 

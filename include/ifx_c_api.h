@@ -137,6 +137,19 @@ int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, int32_t* ti
 int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern);
 int ifx_adopt_estimated_pose(ifx_t* h);
 
+/* ---- the GPU contacts of the fern data base (EF/Ferns.cpp; codes, similarity search and keyframe store are host code of the reference and stay with
+ * the caller, like the graph optimiser).
+ * ifx_fern_frame: the four Resize passes of Ferns::addFrame / findFrame (:95-98, :192-195): fill-in image / vertex / normal and the instance render of the
+ *   last predict(), resampled to (w/8) x (h/8) and read back (rgb: 3 bytes, maps: float4 per sample); returns the number of samples.
+ * ifx_track_maps: the texture-initialised tracker as a stage -- initICPModel / initRGBModel(model maps, given in the frame of pose16) + initICP(vertices,
+ *   normals) / initRGB(current maps) + getIncrementalTransformation starting at pose16 (EF/Ferns.cpp:558-592, EF/ElasticFusion.cpp:528-545).  Host
+ *   float4 maps of the handle's resolution (RGBA8 images or NULL); uses the handle's configuration (icp_weight, pyramid, fast_odom; no SO(3)): for
+ *   ferns create a handle with width/8, height/8, intrinsics/8, icp_weight 100, pyramid 0.  pose16 in: model pose = initial estimate; out: estimate.
+ *   diag8: lastICPError, lastICPCount, lastRGBError, lastRGBCount, 0... */
+int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb);
+int ifx_track_maps(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba, const float* cur_v4, const float* cur_n4,
+                   const uint8_t* cur_rgba, float* pose16, float* diag8);
+
 /* ---- map access (replaces getMapSurfelsGpu / getMapSurfelCount / id textures,
  * IF/map_interface/ElasticFusionInterface.h:55-120).  The store is struct-of-arrays; slots whose
  * surfel was deleted stay in place as tombstones until ifx_compact (DESIGN.md "Tombstones"). */

@@ -84,6 +84,8 @@ _SIGS = {
     "ifx_loop_closure_constraints": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "ifx_set_deformation": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ifx_adopt_estimated_pose": (C.c_int, [_P]),
+    "ifx_fern_frame": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ifx_track_maps": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
     "ifx_map_count": (C.c_int, [_P]),
     "ifx_map_slots": (C.c_int, [_P]),
@@ -297,6 +299,23 @@ class ElasticFusion:
     def adopt_estimated_pose(self):
         self._chk(self.L.ifx_adopt_estimated_pose(self.handle), "ifx_adopt_estimated_pose")
 
+    # -- GPU contacts of the fern data base (EF/Ferns.cpp)
+    def fern_frame(self):
+        """fill-in image / vertex / normal and instance render at (w/8) x (h/8): what Ferns::addFrame / findFrame read back"""
+        rw, rh = self.w // 8, self.h // 8
+        img, inst = np.zeros((rh, rw, 3), np.uint8), np.zeros((rh, rw, 3), np.uint8)
+        v, n = np.zeros((rh, rw, 4), np.float32), np.zeros((rh, rw, 4), np.float32)
+        self._chk(self.L.ifx_fern_frame(self.handle, _ptr(img), _ptr(v), _ptr(n), _ptr(inst)), "ifx_fern_frame")
+        return img, v, n, inst
+
+    def track_maps(self, model_v4, model_n4, cur_v4, cur_n4, pose, model_rgba=None, cur_rgba=None):
+        a = [np.ascontiguousarray(x, np.float32) for x in (model_v4, model_n4, cur_v4, cur_n4)]
+        im = [None if x is None else np.ascontiguousarray(x, np.uint8) for x in (model_rgba, cur_rgba)]
+        p = np.ascontiguousarray(pose, np.float32).reshape(16).copy()
+        diag = np.zeros(8, np.float32)
+        self._chk(self.L.ifx_track_maps(self.handle, _ptr(a[0]), _ptr(a[1]), _ptr(im[0]), _ptr(a[2]), _ptr(a[3]), _ptr(im[1]), _ptr(p), _ptr(diag)), "ifx_track_maps")
+        return p.reshape(4, 4), diag
+
     # -- map access (getMapSurfelCount / getMapSurfelsGpu / id textures)
     def getMapSurfelCount(self):
         return self._chk(self.L.ifx_map_count(self.handle), "ifx_map_count")
@@ -378,7 +397,16 @@ class ElasticFusion:
         self._chk(self.L.ifx_track_pair(self.handle, *[_ptr(a) for a in args], _ptr(p), _ptr(diag)), "ifx_track_pair")
         return p.reshape(4, 4), diag
 
-    def tracker_buffer(self, name, level):
+    def tracker_buffer(self, name, level, m2m=False):
+        if m2m:
+            dt, ch, planar = _TRK_SPECS[name]
+            w, h = self.w >> level, self.h >> level
+            a = np.zeros((ch, h, w) if planar else ((h, w, ch) if ch > 1 else (h, w)), dt)
+            self._chk(self.L.ifx_tracker_buffer_download(self.handle, ("m2m:" + name).encode(), level, _ptr(a), a.nbytes), "ifx_tracker_buffer_download")
+            return a
+        return self._tracker_buffer(name, level)
+
+    def _tracker_buffer(self, name, level):
         w, h = self.w >> level, self.h >> level
         if name == "corres":
             a = np.zeros((h, w), CORRES_DTYPE)

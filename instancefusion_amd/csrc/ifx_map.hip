@@ -1546,6 +1546,41 @@ extern "C" int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, 
     return m;
 }
 
+// ---- Ferns (EF/Ferns.cpp) GPU contact no. 1: the four Resize passes of addFrame / findFrame (:95-98, :192-195) -- the fill-in image, vertex and
+// normal maps and the instance render resampled to (w/8) x (h/8) (nearest texel of the sample centre) and read back
+__global__ void k_fern_resize(const uchar4* __restrict__ img, const float4* __restrict__ vert, const float4* __restrict__ norm, const uchar4* __restrict__ inst, int w, int h,
+                              uint8_t* __restrict__ o_img, float4* __restrict__ o_vert, float4* __restrict__ o_norm, uint8_t* __restrict__ o_inst)
+{
+    const int rw = w / 8, rh = h / 8, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rw * rh) return;
+    const int j = t / rw, i = t - j * rw;
+    const int k = ((j * h + h / 2) / rh) * w + (i * w + w / 2) / rw;
+    const uchar4 c = img[k], q = inst[k];
+    o_img[t * 3] = c.x; o_img[t * 3 + 1] = c.y; o_img[t * 3 + 2] = c.z;
+    o_inst[t * 3] = q.x; o_inst[t * 3 + 1] = q.y; o_inst[t * 3 + 2] = q.z;
+    o_vert[t] = vert[k];
+    o_norm[t] = norm[k];
+}
+extern "C" int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb)
+{
+    if (!h || !img_rgb || !verts4 || !norms4 || !inst_rgb) return IFX_E_INVALID;
+    const int n = (h->w / 8) * (h->h / 8);
+    if (!h->d_fern) HIPCHK(h, hipMalloc(&h->d_fern, (size_t)n * (3 + 16 + 16 + 3) + 64));
+    uint8_t* base = (uint8_t*)h->d_fern;
+    float4* dv = (float4*)base;
+    float4* dn = dv + n;
+    uint8_t* di = (uint8_t*)(dn + n);
+    uint8_t* ds = di + (size_t)n * 3;
+    LAUNCH(h, "fern_resize", dim3(cdiv(n, 64)), dim3(64), k_fern_resize, (const uchar4*)h->fill_image, (const float4*)h->fill_vertex, (const float4*)h->fill_normal,
+           (const uchar4*)h->pred_inst, h->w, h->h, di, dv, dn, ds);
+    HIPCHK(h, hipMemcpyAsync(verts4, dv, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(norms4, dn, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(img_rgb, di, (size_t)n * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(inst_rgb, ds, (size_t)n * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return n;
+}
+
 extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern)
 {
     if (!h || n_nodes < 0 || (n_nodes > 0 && !graph16)) return IFX_E_INVALID;

@@ -1440,7 +1440,7 @@ void ifx_free_tracker(ifx* h)
     }
     for (int q = 0; q < 2; q++) hipFree(h->slot[q].so3);
     free_m2m(h);
-    hipFree(h->d_graph); hipFree(h->d_sample); hipFree(h->d_cons); hipFree(h->d_project);
+    hipFree(h->d_graph); hipFree(h->d_sample); hipFree(h->d_cons); hipFree(h->d_project); hipFree(h->d_fern);
     hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
@@ -1776,6 +1776,53 @@ int ifx_tracker_loop_closure(ifx* h)
     return IFX_OK;
 }
 
+// ---- Ferns (EF/Ferns.cpp) GPU contact no. 2: RGBDOdometry on two small renders (a stored keyframe against the current frame, Ferns.cpp:558-592),
+// and in general the texture-initialised tracker (initICPModel / initRGBModel + initICP(vertices, normals) / initRGB + getIncrementalTransformation)
+// as a stage: host float4 maps in, estimate out.  Runs on the model-to-model instance of this handle with the handle's own configuration
+// (resolution, intrinsics, icp_weight, pyramid, fast_odom; no SO(3)): for ferns the caller creates a handle at width/8 x height/8 with
+// icp_weight 100, pyramid 0 -- what Ferns::findFrame passes.
+__global__ void k_m2m_prepare(DevState* m, const float* __restrict__ pose16)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) m->pose[k] = pose16[k];
+    pose_inverse(m->pose, m->pose_inv);
+    m->dense_enough = 1; m->count = 0; m->skip = 0;
+}
+extern "C" int ifx_track_maps(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba, const float* cur_v4, const float* cur_n4,
+                              const uint8_t* cur_rgba, float* pose16, float* diag8)
+{
+    if (!h || !model_v4 || !model_n4 || !cur_v4 || !cur_n4 || !pose16) return IFX_E_INVALID;
+    int r = ifx_tracker_alloc_m2m(h);
+    if (r) return r;
+    if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
+    h->tracked_ahead = 0;
+    const size_t P = (size_t)h->P;
+    HIPCHK(h, hipMemcpyAsync(h->old_vertex, model_v4, P * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->old_normal, model_n4, P * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->act_vertex, cur_v4, P * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->act_normal, cur_n4, P * 16, hipMemcpyHostToDevice, h->stream));
+    if (model_rgba) HIPCHK(h, hipMemcpyAsync(h->old_image, model_rgba, P * 4, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(h->old_image, 0, P * 4, h->stream));
+    if (cur_rgba) HIPCHK(h, hipMemcpyAsync(h->act_image, cur_rgba, P * 4, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(h->act_image, 0, P * 4, h->stream));
+    float* slot = h->d_traj + (size_t)(h->max_traj - 6) * 16;   // scratch at the tail of the trajectory log
+    HIPCHK(h, hipMemcpyAsync(slot, pose16, 64, hipMemcpyHostToDevice, h->stream));
+    DevState* m = h->d_m2m;
+    LAUNCH(h, "m2m_prepare", dim3(1), dim3(64), k_m2m_prepare, m, (const float*)slot);
+    tracker_init_model(h, m, h->m2m, h->cfg.icp_weight, h->old_vertex, h->old_normal, h->old_image, nullptr, nullptr, nullptr);
+    tracker_init_frame_maps(h, m, h->m2m, h->act_vertex, h->act_normal, h->act_image);
+    tracker_run(h, m, h->m2m, h->cfg.icp_weight, 0, 1.0f, 1, false);
+    DevState hs;
+    HIPCHK(h, hipMemcpyAsync(&hs, m, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(pose16, hs.pose, 64);
+    if (diag8) {
+        diag8[0] = hs.lastICPError; diag8[1] = hs.lastICPCount; diag8[2] = hs.lastRGBError; diag8[3] = hs.lastRGBCount;
+        diag8[4] = 0; diag8[5] = 0; diag8[6] = 0; diag8[7] = 0;
+    }
+    return IFX_OK;
+}
+
 int ifx_tracker_commit(ifx* h)
 {
     LAUNCH(h, "commit_pose", dim3(1), dim3(64), k_commit_pose, h->d_state);
@@ -1911,16 +1958,23 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
 extern "C" int ifx_tracker_buffer_download(ifx_t* h, const char* name, int l, void* out, int64_t max_bytes)
 {
     if (!h || !name || l < 0 || l >= IFX_NUM_PYRS) return IFX_E_INVALID;
-    Pyr& p = h->pyr;
+    std::string s(name);
+    const bool second = s.rfind("m2m:", 0) == 0;   // "m2m:<name>": the model-to-model instance (loop-closure detection, ifx_track_maps)
+    if (second) {
+        if (!h->d_m2m) { h->err = "the model-to-model tracker was never used"; return IFX_E_STATE; }
+        if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+        s = s.substr(4);
+    }
+    Pyr& p = second ? h->m2m : h->pyr;
     size_t n = (size_t)p.w[l] * p.h[l];
     const void* src = nullptr;
     size_t bytes = 0;
-    std::string s(name);
     if (s == "vmap_curr") { src = p.vmap_curr[l]; bytes = n * 12; }
     else if (s == "nmap_curr") { src = p.nmap_curr[l]; bytes = n * 12; }
     else if (s == "vmap_prev") { src = p.vmap_prev[l]; bytes = n * 12; }
     else if (s == "nmap_prev") { src = p.nmap_prev[l]; bytes = n * 12; }
-    else if (s == "last_depth" || s == "next_depth") { src = p.last_depth[l]; bytes = n * 4; }
+    else if (s == "last_depth") { src = p.last_depth[l]; bytes = n * 4; }
+    else if (s == "next_depth") { src = p.next_depth[l] ? p.next_depth[l] : p.last_depth[l]; bytes = n * 4; }
     else if (s == "last_img") { src = p.last_img[l]; bytes = n; }
     else if (s == "next_img") { src = p.next_img[l]; bytes = n; }
     else if (s == "lastnext_img") { src = p.lastnext_img[l]; bytes = n; }

@@ -1134,3 +1134,70 @@ def test_loop_closure_callback_end_to_end(ifx, orc, small_stream):
     assert np.abs(mo["pc"] - mg["pc"]).max() < 2e-4 and np.array_equal(mo["tm"][:, 0], mg["tm"][:, 0])
     o.close(); g.close()
 
+
+
+# ---------------------------------------------------------------- 8f-3: the GPU contacts of the fern data base (EF/Ferns.cpp)
+def test_fern_hooks(ifx, orc, small_stream):
+    """(1) the resampled fill-in / instance images Ferns::addFrame and findFrame read back; (2) the ICP-only, single-scale tracker on two small
+    renders (keyframe against current frame, Ferns.cpp:558-592) against the oracle's tracker fed the same maps."""
+    st = small_stream
+    W, H = SMALL["w"], SMALL["h"]
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    frames = []
+    for k in range(4):
+        pose = g.processFrame(st["rgb"][k], st["depth"][k])
+        img, v, n, inst = g.fern_frame()
+        rw, rh = W // 8, H // 8
+        ys = (np.arange(rh) * H + H // 2) // rh
+        xs = (np.arange(rw) * W + W // 2) // rw
+        assert np.array_equal(img, g.image("fill_image")[ys][:, xs][..., :3]) and np.array_equal(inst, g.image("pred_inst")[ys][:, xs][..., :3])
+        assert np.array_equal(v, g.image("fill_vertex")[ys][:, xs]) and np.array_equal(n, g.image("fill_normal")[ys][:, xs])
+        assert (v[..., 2] > 0).mean() > 0.9
+        # for the tracker below: the same maps at 1/4 (80 x 60, the fern resolution of a 640 x 480 stream; 40 x 30 is not a valid pyramid size)
+        y4, x4 = (np.arange(H // 4) * H + H // 2) // (H // 4), (np.arange(W // 4) * W + W // 2) // (W // 4)
+        frames.append((pose.copy(), g.image("fill_vertex")[y4][:, x4].copy(), g.image("fill_normal")[y4][:, x4].copy(), g.image("fill_image")[y4][:, x4][..., :3].copy()))
+    # keyframe = frame 1, current = frame 3; handle configured as Ferns::findFrame drives its RGBDOdometry
+    KS = dict(w=W // 4, h=H // 4, fx=SMALL["fx"] / 4, fy=SMALL["fy"] / 4, cx=SMALL["cx"] / 4, cy=SMALL["cy"] / 4)
+    small = ifx.ElasticFusion(**KS, max_surfels=1000, icp_weight=100.0, pyramid=0, so3=0)
+    (pm, vm, nm, im), (pc_, vc, nc, ic_) = frames[1], frames[3]
+    est_g, dg = small.track_maps(vm, nm, vc, nc, pm)
+    L = orc.lib()
+    t = L.orc_tracker_create(KS["w"], KS["h"], KS["fx"], KS["fy"], KS["cx"], KS["cy"])
+    rgba0 = np.zeros((KS["h"], KS["w"], 4), np.uint8)
+    pose_o = np.ascontiguousarray(pm, np.float32).reshape(16).copy()
+    diag_o = np.zeros(8, np.float32)
+    L.orc_tracker_init_model(t, orc.ptr(np.ascontiguousarray(vm)), orc.ptr(np.ascontiguousarray(nm)), orc.ptr(rgba0), orc.ptr(pose_o))
+    L.orc_tracker_init_frame_maps.argtypes = [C.c_void_p] * 4
+    L.orc_tracker_init_frame_maps(t, orc.ptr(np.ascontiguousarray(vc)), orc.ptr(np.ascontiguousarray(nc)), orc.ptr(rgba0))
+    L.orc_tracker_run(t, orc.ptr(pose_o), 100.0, 0, 0, 0, orc.ptr(diag_o))
+    L.orc_tracker_destroy(t)
+    assert dg[1] == diag_o[1] > 300 and abs(dg[0] - diag_o[0]) <= 1e-3 * diag_o[0]
+    assert np.abs(est_g - pose_o.reshape(4, 4)).max() < 1e-5
+    assert np.abs(est_g - pm).max() > 1e-4                                  # it did move away from its start
+    # with images and the default weights (ICP + RGB, 3 levels): the model-to-model configuration on host maps, at 1/2 resolution (at 80 x 60 the coarsest
+    # level has 300 pixels and its 6x6 system is so poorly conditioned that the unpivoted device solve and the pivoted oracle solve part ways)
+    y2, x2 = (np.arange(H // 2) * H + H // 2) // (H // 2), (np.arange(W // 2) * W + W // 2) // (W // 2)
+    KH = dict(w=W // 2, h=H // 2, fx=SMALL["fx"] / 2, fy=SMALL["fy"] / 2, cx=SMALL["cx"] / 2, cy=SMALL["cy"] / 2)
+    g2 = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    half = []
+    for k in range(3):
+        pose = g2.processFrame(st["rgb"][k], st["depth"][k])
+        half.append((pose.copy(), g2.image("fill_vertex")[y2][:, x2].copy(), g2.image("fill_normal")[y2][:, x2].copy(), g2.image("fill_image")[y2][:, x2].copy()))
+    g2.close()
+    (pm, vm, nm, im), (pc_, vc, nc, ic_) = half[1], half[2]
+    full = ifx.ElasticFusion(**KH, max_surfels=1000, so3=0)
+    est2, d2 = full.track_maps(vm, nm, vc, nc, pm, model_rgba=im, cur_rgba=ic_)
+    t = L.orc_tracker_create(KH["w"], KH["h"], KH["fx"], KH["fy"], KH["cx"], KH["cy"])
+    pose_o2 = np.ascontiguousarray(pm, np.float32).reshape(16).copy()
+    L.orc_tracker_init_model(t, orc.ptr(np.ascontiguousarray(vm)), orc.ptr(np.ascontiguousarray(nm)), orc.ptr(np.ascontiguousarray(im)), orc.ptr(pose_o2))
+    L.orc_tracker_init_frame_maps(t, orc.ptr(np.ascontiguousarray(vc)), orc.ptr(np.ascontiguousarray(nc)), orc.ptr(np.ascontiguousarray(ic_)))
+    L.orc_tracker_run(t, orc.ptr(pose_o2), 10.0, 1, 0, 0, orc.ptr(diag_o))
+    for l in range(3):                                                    # the second tracker's pyramids, buffer by buffer
+        for name, dt, ch in (("vmap_curr", np.float32, 3), ("nmap_prev", np.float32, 3), ("next_depth", np.float32, 1), ("last_img", np.uint8, 1), ("didx", np.int16, 1)):
+            w_, h_ = KH["w"] >> l, KH["h"] >> l
+            n_ = w_ * h_ * ch * np.dtype(dt).itemsize
+            a = np.frombuffer((C.c_char * n_).from_address(L.orc_tracker_buffer(t, name.encode(), l)), dt).reshape((ch, h_, w_) if ch > 1 else (h_, w_))
+            assert nan_equal(a.astype(np.float64), full.tracker_buffer(name, l, m2m=True).astype(np.float64)), (l, name)
+    L.orc_tracker_destroy(t)
+    assert abs(d2[1] - diag_o[1]) <= max(2.0, 0.002 * diag_o[1]) and d2[3] == diag_o[3] and np.abs(est2 - pose_o2.reshape(4, 4)).max() < 2e-5
+    g.close(); small.close(); full.close()

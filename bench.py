@@ -188,7 +188,7 @@ def main():
             step(k)
         ef.sync()
         names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_raster", "raster_list", "cull_clean", "clean_list", "index_project", "index_resolve", "associate",
-                 "fuse_update", "bilateral_metric", "splat_resolve", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
+                 "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
         best, table = None, {}
         for nme in names:
             avg, cnt = ef.kernel_ms(nme)

@@ -98,6 +98,10 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     // a chunk of 4096 slots (ifx_map.hip: MAP_THREADS x CHUNK_ROUNDS) appends to segment chunk % 8: a segment holds at most its share of the chunks
     h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096);
     ALLOC(h->list_a, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_b, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_c, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
+    if (const char* ev = getenv("IFX_RASTER_TILES")) h->opt_raster_tiles = atoi(ev);   // A/B switch for whole test runs
+    h->tile_pair_cap = (unsigned int)std::max<size_t>(2 * C, (size_t)1 << 22);
+    ALLOC(h->tile_n, 5 * 4096 * 4 + 64); ALLOC(h->tile_box, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->tile_pairs, (size_t)h->tile_pair_cap * 4);
+    hipMemset(h->tile_n, 0, 5 * 4096 * 4 + 64);
     ALLOC(h->d_list_ctr, 3 * IFX_LIST_SEGS * 32 * 4);
     hipMemset(h->d_list_ctr, 0, 3 * IFX_LIST_SEGS * 32 * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
@@ -149,7 +153,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
@@ -214,6 +218,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
+    else if (s == "raster_tiles") h->opt_raster_tiles = value;
     // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;
     // refused while a frame is announced ahead (its image-only work may already be on the queue with the old configuration)
     else if (s == "pyramid" || s == "fast_odom" || s == "so3" || s == "icp_weight_x1000") {

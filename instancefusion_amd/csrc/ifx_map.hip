@@ -574,8 +574,10 @@ __device__ __forceinline__ bool may_touch_image(float reach, v3 q, const Cam& c)
 // phase 1 of the post-clean pass: candidates for the splat prediction and / or the id render
 __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
                                                              const float2* __restrict__ tm, Cam c, int time, int maxTime, unsigned int want,
-                                                             unsigned int* __restrict__ list)
+                                                             unsigned int* __restrict__ list, unsigned int* __restrict__ zero_buf, int zero_n)
 {
+    if (zero_buf && blockIdx.x == gridDim.x - 1)   // the tiled rasteriser's per-tile counts, for the count pass that follows (an idle block: the grid exceeds the chunks)
+        for (int k = threadIdx.x; k < zero_n; k += blockDim.x) zero_buf[k] = 0;
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
 #pragma unroll
@@ -624,12 +626,49 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
     }
 }
 
+// Screen-space geometry of one listed surfel (splat.vert:55-92): camera-frame centre and normal, the projected extent of its quad, the point-sprite box
+// of the splat render.  Shared by the global-atomic rasteriser (k_raster_list) and the tiled one (k_tile_*), so that both draw the same pixels.
+struct SurfGeo { v3 q, nn; float r, u, v, xs[2], ys[2], minz; bool do_s; int sx0, sx1, sy0, sy1; };
+__device__ __forceinline__ void surfel_geo(const float* T, float4 p4, float4 n4, unsigned int e, const Cam& c, SurfGeo& G)
+{
+    G.q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+    G.nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
+    G.r = n4.w;
+    disc_extent(G.q, G.nn, G.r, c, G.xs, G.ys, G.minz);
+    G.u = ((c.fx * G.q.x) / G.q.z) + c.cx; G.v = ((c.fy * G.q.y) / G.q.z) + c.cy;
+    // splat region: GL point sprite (splat.vert:75-92)
+    G.do_s = (e & LIST_SPLAT) != 0;
+    G.sx0 = 0; G.sx1 = -1; G.sy0 = 0; G.sy1 = -1;
+    if (G.do_s) {
+        float s = fmaxf(fabsf(G.xs[1] - G.xs[0]), fabsf(G.ys[1] - G.ys[0]));
+        if (!(s == s)) G.do_s = false;
+        else {
+            s = fminf(fmaxf(s, 1.0f), IFX_MAX_SPRITE);
+            G.sx0 = clampi((int)ceilf(G.u - s * 0.5f - 0.5f), 0, c.w - 1); G.sx1 = clampi((int)floorf(G.u + s * 0.5f - 0.5f), 0, c.w - 1);
+            G.sy0 = clampi((int)ceilf(G.v - s * 0.5f - 0.5f), 0, c.h - 1); G.sy1 = clampi((int)floorf(G.v + s * 0.5f - 0.5f), 0, c.h - 1);
+        }
+    }
+}
+// id region of the id render: bounding box of the quad (surfel_ids.geom:49-82); false = nothing to draw
+__device__ __forceinline__ bool surfel_id_box(const SurfGeo& G, unsigned int e, const Cam& c, int& ix0, int& ix1, int& iy0, int& iy1)
+{
+    ix0 = 0; ix1 = -1; iy0 = 0; iy1 = -1;
+    if (!(e & LIST_IDS)) return false;
+    if (!(G.minz > 0) || !(G.xs[0] == G.xs[0]) || !(G.ys[0] == G.ys[0]) || G.xs[1] - G.xs[0] > IFX_MAX_SPRITE || G.ys[1] - G.ys[0] > IFX_MAX_SPRITE || G.xs[1] < 0 || G.ys[1] < 0 ||
+        G.xs[0] > (float)c.w || G.ys[0] > (float)c.h)
+        return false;
+    ix0 = clampi((int)ceilf(G.xs[0] - 0.5f), 0, c.w - 1); ix1 = clampi((int)floorf(G.xs[1] - 0.5f), 0, c.w - 1);
+    iy0 = clampi((int)ceilf(G.ys[0] - 0.5f), 0, c.h - 1); iy1 = clampi((int)floorf(G.ys[1] - 0.5f), 0, c.h - 1);
+    return true;
+}
+
 // phase 2: disc rasterisation of the listed surfels into the splat and / or id key images
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
                                                              const float4* __restrict__ nr, Cam c, const unsigned int* __restrict__ list,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
-                                                             unsigned long long* __restrict__ key_both, int dual)
+                                                             unsigned long long* __restrict__ key_both, int dual, const int* __restrict__ gate)
 {
+    if (gate && !*gate) return;   // fallback launch behind the tiled rasteriser: only when its pair buffer overflowed
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
 #pragma unroll
@@ -641,25 +680,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
     for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
         const unsigned int e = seg_list[t];
         const unsigned int i = e & LIST_IDX;
-        float4 p4 = pc[i], n4 = nr[i];
-        v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
-        v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
-        float r = n4.w;
-        float xs[2], ys[2], minz;
-        disc_extent(q, nn, r, c, xs, ys, minz);
-        float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
-        // splat region: GL point sprite (splat.vert:75-92)
-        bool do_s = (e & LIST_SPLAT) != 0;
-        int sx0 = 0, sx1 = -1, sy0 = 0, sy1 = -1;
-        if (do_s) {
-            float s = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
-            if (!(s == s)) do_s = false;
-            else {
-                s = fminf(fmaxf(s, 1.0f), IFX_MAX_SPRITE);
-                sx0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, c.w - 1); sx1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, c.w - 1);
-                sy0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, c.h - 1); sy1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, c.h - 1);
-            }
-        }
+        SurfGeo G;
+        surfel_geo(T, pc[i], nr[i], e, c, G);
+        const v3 q = G.q, nn = G.nn;
+        const float r = G.r, u = G.u, v = G.v;
+        const float* xs = G.xs;
+        const float* ys = G.ys;
+        const float minz = G.minz;
+        bool do_s = G.do_s;
+        int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1;
         if (dual) {   // two splat renders: the LIST_IDS bit marks the INACTIVE one, same sprite region and depth rule, its own key image
             if (!(e & LIST_SPLAT)) {   // (do_s was computed for the SPLAT bit only)
                 float s2 = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
@@ -681,18 +710,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                 }
             continue;
         }
-        // id region: bounding box of the quad (surfel_ids.geom:49-82)
-        bool do_i = (e & LIST_IDS) != 0;
-        int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;
-        if (do_i) {
-            if (!(minz > 0) || !(xs[0] == xs[0]) || !(ys[0] == ys[0]) || xs[1] - xs[0] > IFX_MAX_SPRITE || ys[1] - ys[0] > IFX_MAX_SPRITE || xs[1] < 0 || ys[1] < 0 ||
-                xs[0] > (float)c.w || ys[0] > (float)c.h)
-                do_i = false;
-            else {
-                ix0 = clampi((int)ceilf(xs[0] - 0.5f), 0, c.w - 1); ix1 = clampi((int)floorf(xs[1] - 0.5f), 0, c.w - 1);
-                iy0 = clampi((int)ceilf(ys[0] - 0.5f), 0, c.h - 1); iy1 = clampi((int)floorf(ys[1] - 0.5f), 0, c.h - 1);
-            }
-        }
+        int ix0, ix1, iy0, iy1;
+        bool do_i = surfel_id_box(G, e, c, ix0, ix1, iy0, iy1);
         if (!do_s && !do_i) continue;
         if (!do_s) { sx0 = ix0; sx1 = ix1; sy0 = iy0; sy1 = iy1; }
         if (!do_i) { ix0 = sx0; ix1 = sx1; iy0 = sy0; iy1 = sy1; }
@@ -711,6 +730,211 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                 else if (in_s) key_min(&key_splat[py * c.w + px], make_key(z, i));
                 else if (in_i) key_min(&key_ids[py * c.w + px], make_key(z, i));
             }
+    }
+}
+
+// ------------------------------------------------------------------ tiled rasteriser
+// k_raster_list is bound by its global 64-bit atomics (one per covered pixel and render; 105 us at VGA / 5M surfels, 0.9 ms at 1280x960 / 20M).  The
+// tiled path bins the listed surfels by the 32x32-pixel tiles their discs touch and lets one workgroup per tile resolve its three key tiles
+// (splat / ids / both) in LDS -- LDS atomics instead of L2 atomics, each key written to HBM once:
+//   k_tile_count : per list entry the tile box of its disc (kept in tile_box) and a per-tile count -- block-local histogram in LDS, then one global add
+//                  per block and non-empty tile (a direct global add per (entry, tile) would queue thousands of atomics on each of a few hundred words)
+//   k_tile_scan  : exclusive scan of the tile counts (one block)
+//   k_tile_fill  : the (tile, entry) pairs, grouped by tile: block-local ranks from an LDS histogram + one returning global add per block and tile
+//   k_tile_raster: one block per tile; identical coverage / depth rules as k_raster_list (same surfel_geo), atomicMin on LDS keys, tiles stored whole
+// More pairs than the pair buffer holds (a camera inside a cloud of huge discs): the scan raises a flag, the tile kernels return and k_raster_list,
+// launched behind them with that flag as its gate, draws the frame with global atomics as before.
+#define TILE 32
+#define TILE_LOG 5
+#define TILE_MAX 4096   // tiles per image the LDS histograms are sized for (2048 x 2048 pixels)
+#define TILE_CHUNK 2048   // pairs one rasterising block draws; a tile with more pairs is shared by several blocks, which merge through atomicMin
+struct TileArgs { unsigned int *tile_n, *tile_off, *tile_fill, *blk_off, *tile_box, *pairs; int* overflow; unsigned int pair_cap; int tw, th; };
+
+__device__ __forceinline__ unsigned int tile_box_of(const float* T, const float4* __restrict__ pc, const float4* __restrict__ nr, unsigned int e, const Cam& c)
+{
+    SurfGeo G;
+    const unsigned int i = e & LIST_IDX;
+    surfel_geo(T, pc[i], nr[i], e, c, G);
+    int ix0, ix1, iy0, iy1;
+    const bool do_i = surfel_id_box(G, e, c, ix0, ix1, iy0, iy1);
+    if (!G.do_s && !do_i) return 0xFFFFFFFFu;
+    int x0 = G.do_s ? G.sx0 : ix0, x1 = G.do_s ? G.sx1 : ix1, y0 = G.do_s ? G.sy0 : iy0, y1 = G.do_s ? G.sy1 : iy1;
+    if (do_i) { x0 = min(x0, ix0); x1 = max(x1, ix1); y0 = min(y0, iy0); y1 = max(y1, iy1); }
+    if (x1 < x0 || y1 < y0) return 0xFFFFFFFFu;
+    return (unsigned int)(x0 >> TILE_LOG) | ((unsigned int)(y0 >> TILE_LOG) << 8) | ((unsigned int)(x1 >> TILE_LOG) << 16) | ((unsigned int)(y1 >> TILE_LOG) << 24);
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_tile_count(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                            const float4* __restrict__ nr, Cam c, const unsigned int* __restrict__ list, TileArgs ta)
+{
+    __shared__ unsigned int hist[TILE_MAX];
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const int ntiles = ta.tw * ta.th;
+    for (int k = threadIdx.x; k < ntiles; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, 0, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    unsigned int* __restrict__ seg_box = ta.tile_box + (size_t)seg * c.seg_cap;
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
+        const unsigned int box = tile_box_of(T, pc, nr, seg_list[t], c);
+        seg_box[t] = box;
+        if (box == 0xFFFFFFFFu) continue;
+        const int tx0 = box & 255, ty0 = (box >> 8) & 255, tx1 = (box >> 16) & 255, ty1 = box >> 24;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * ta.tw + tx], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ntiles; k += blockDim.x)
+        if (hist[k]) atomicAdd(&ta.tile_n[k], hist[k]);
+}
+
+__global__ __launch_bounds__(256) void k_tile_scan(TileArgs ta)
+{
+    __shared__ unsigned int part[256], bpart[256];
+    const int ntiles = ta.tw * ta.th, per = (ntiles + 255) / 256, lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    unsigned int sum = 0, bsum = 0;
+    for (int k = lo; k < hi; k++) { const unsigned int v = ta.tile_n[k]; sum += v; bsum += (v + TILE_CHUNK - 1) / TILE_CHUNK; }
+    part[threadIdx.x] = sum; bpart[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0, brun = 0;
+        for (int k = 0; k < 256; k++) { const unsigned int v = part[k], b = bpart[k]; part[k] = run; bpart[k] = brun; run += v; brun += b; }
+        *ta.overflow = run > ta.pair_cap ? 1 : 0;
+        ta.blk_off[ntiles] = brun;   // number of rasterising blocks with work
+    }
+    __syncthreads();
+    unsigned int run = part[threadIdx.x], brun = bpart[threadIdx.x];
+    for (int k = lo; k < hi; k++) {
+        const unsigned int v = ta.tile_n[k];
+        ta.tile_off[k] = run; run += v;
+        ta.blk_off[k] = brun; brun += (v + TILE_CHUNK - 1) / TILE_CHUNK;
+        ta.tile_fill[k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_tile_fill(Cam c, const unsigned int* __restrict__ list, TileArgs ta)
+{
+    __shared__ unsigned int hist[TILE_MAX];   // phase 1: this block's count per tile; phase 2: its base inside the tile's range; phase 3: running rank
+    __shared__ unsigned int base[TILE_MAX];
+    if (*ta.overflow) return;
+    const int ntiles = ta.tw * ta.th;
+    for (int k = threadIdx.x; k < ntiles; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, 0, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    const unsigned int* __restrict__ seg_box = ta.tile_box + (size_t)seg * c.seg_cap;
+    const unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x, stride = blockDim.x * (gridDim.x / LIST_SEGS);
+    for (unsigned int t = t0; t < n; t += stride) {
+        const unsigned int box = seg_box[t];
+        if (box == 0xFFFFFFFFu) continue;
+        const int tx0 = box & 255, ty0 = (box >> 8) & 255, tx1 = (box >> 16) & 255, ty1 = box >> 24;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * ta.tw + tx], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ntiles; k += blockDim.x) {
+        const unsigned int cnt = hist[k];
+        base[k] = ta.tile_off[k] + (cnt ? atomicAdd(&ta.tile_fill[k], cnt) : 0u);
+        hist[k] = 0;
+    }
+    __syncthreads();
+    for (unsigned int t = t0; t < n; t += stride) {
+        const unsigned int box = seg_box[t];
+        if (box == 0xFFFFFFFFu) continue;
+        const unsigned int e = seg_list[t];
+        const int tx0 = box & 255, ty0 = (box >> 8) & 255, tx1 = (box >> 16) & 255, ty1 = box >> 24;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int k = ty * ta.tw + tx;
+                ta.pairs[base[k] + atomicAdd(&hist[k], 1u)] = e;
+            }
+    }
+}
+
+#define TILE_THREADS 512
+__device__ __forceinline__ void tile_draw(const float* T, float4 p4, float4 n4, unsigned int e, const Cam& c, int bx0, int by0, int bx1, int by1,
+                                          unsigned long long* ks, unsigned long long* ki, unsigned long long* kb)
+{
+    const unsigned int i = e & LIST_IDX;
+    SurfGeo G;
+    surfel_geo(T, p4, n4, e, c, G);
+    int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
+    const bool do_s = G.do_s, do_i = surfel_id_box(G, e, c, ix0, ix1, iy0, iy1);
+    if (!do_s && !do_i) return;
+    if (!do_s) { sx0 = ix0; sx1 = ix1; sy0 = iy0; sy1 = iy1; }
+    if (!do_i) { ix0 = sx0; ix1 = sx1; iy0 = sy0; iy1 = sy1; }
+    const int x0 = max(min(sx0, ix0), bx0), x1 = min(max(sx1, ix1), bx1), y0 = max(min(sy0, iy0), by0), y1 = min(max(sy1, iy1), by1);
+    Disc d;
+    d.q = G.q; d.n = G.nn; d.r2 = G.r * G.r;
+    for (int py = y0; py <= y1; py++)
+        for (int px = x0; px <= x1; px++) {
+            float z;
+            if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
+            const bool in_s = do_s && px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
+            const bool in_i = do_i && px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
+            const int k = (py - by0) * TILE + (px - bx0);
+            if (in_s && in_i) atomicMin(&kb[k], make_key(z, i));
+            else if (in_s) atomicMin(&ks[k], make_key(z, i));
+            else if (in_i) atomicMin(&ki[k], make_key(z, i));
+        }
+}
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
+                                                               const float4* __restrict__ nr, Cam c, TileArgs ta, unsigned long long* __restrict__ key_splat,
+                                                               unsigned long long* __restrict__ key_ids, unsigned long long* __restrict__ key_both)
+{
+    __shared__ unsigned long long ks[TILE * TILE], ki[TILE * TILE], kb[TILE * TILE];
+    if (*ta.overflow) return;
+    const int ntiles = ta.tw * ta.th;
+    if (blockIdx.x >= ta.blk_off[ntiles]) return;   // the grid is sized for the worst case
+    int lo = 0, hi = ntiles - 1;                     // last tile whose first block is <= blockIdx.x (empty tiles own no block: skip over equal offsets)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ta.blk_off[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int tile = lo, tx = tile % ta.tw, ty = tile / ta.tw;
+    const unsigned int part = blockIdx.x - ta.blk_off[tile], nt = ta.tile_n[tile], nblk = (nt + TILE_CHUNK - 1) / TILE_CHUNK;
+    const unsigned int off = ta.tile_off[tile] + part * TILE_CHUNK, n = min(nt - part * TILE_CHUNK, (unsigned int)TILE_CHUNK);
+    for (int k = threadIdx.x; k < TILE * TILE; k += blockDim.x) { ks[k] = IFX_KEY_EMPTY; ki[k] = IFX_KEY_EMPTY; kb[k] = IFX_KEY_EMPTY; }
+    __syncthreads();
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
+    const int bx0 = tx * TILE, by0 = ty * TILE, bx1 = bx0 + TILE - 1, by1 = by0 + TILE - 1;
+    // four pairs per thread and round: their eight gathers are in flight together
+    for (unsigned int p = threadIdx.x; p < n; p += 4 * blockDim.x) {
+        unsigned int e[4];
+        float4 p4[4], n4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const unsigned int q = p + u * blockDim.x; e[u] = q < n ? ta.pairs[off + q] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const unsigned int i = e[u] == 0xFFFFFFFFu ? 0u : (e[u] & LIST_IDX); p4[u] = pc[i]; n4[u] = nr[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (e[u] != 0xFFFFFFFFu) tile_draw(T, p4[u], n4[u], e[u], c, bx0, by0, bx1, by1, ks, ki, kb);
+    }
+    __syncthreads();
+    // the key images are all-empty between passes (the resolve clears what it reads): only winners are written -- plainly by a tile's only block,
+    // through atomicMin when several blocks share the tile
+    for (int k = threadIdx.x; k < TILE * TILE; k += blockDim.x) {
+        const int px = bx0 + (k & (TILE - 1)), py = by0 + (k >> TILE_LOG);
+        if (px < c.w && py < c.h) {
+            const int g = py * c.w + px;
+            const unsigned long long a = ks[k], b = ki[k], d = kb[k];
+            if (nblk == 1) {
+                if (a != IFX_KEY_EMPTY) key_splat[g] = a;
+                if (b != IFX_KEY_EMPTY) key_ids[g] = b;
+                if (d != IFX_KEY_EMPTY) key_both[g] = d;
+            } else {
+                if (a != IFX_KEY_EMPTY) atomicMin(&key_splat[g], a);
+                if (b != IFX_KEY_EMPTY) atomicMin(&key_ids[g], b);
+                if (d != IFX_KEY_EMPTY) atomicMin(&key_both[g], d);
+            }
+        }
     }
 }
 
@@ -828,10 +1052,25 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
     if (part != 2) {
+        const int tw = cdiv(h->w, TILE), th = cdiv(h->h, TILE);
+        const bool want_tiles = h->opt_raster_tiles < 0 ? (h->P >= 1000000) : (h->opt_raster_tiles != 0);
+        const bool tiled = want_tiles && tw * th <= TILE_MAX && tw <= 255 && th <= 255 && h->tile_pairs;
         LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
-               h->list_a);
-        LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
-               h->key_ids, h->key_both, 0);
+               h->list_a, tiled ? h->tile_n : (unsigned int*)nullptr, tw * th);
+        if (tiled) {
+            TileArgs ta;
+            ta.tile_n = h->tile_n; ta.tile_off = h->tile_n + TILE_MAX; ta.tile_fill = h->tile_n + 2 * TILE_MAX; ta.blk_off = h->tile_n + 3 * TILE_MAX; ta.overflow = (int*)(h->tile_n + 4 * TILE_MAX + 8);
+            ta.tile_box = h->tile_box; ta.pairs = h->tile_pairs; ta.pair_cap = h->tile_pair_cap; ta.tw = tw; ta.th = th;
+            LAUNCH(h, "tile_count", dim3(1024), dim3(MAP_THREADS), k_tile_count, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, ta);
+            LAUNCH(h, "tile_scan", dim3(1), dim3(256), k_tile_scan, ta);
+            LAUNCH(h, "tile_fill", dim3(1024), dim3(MAP_THREADS), k_tile_fill, c, h->list_a, ta);
+            LAUNCH(h, "tile_raster", dim3(tw * th + h->tile_pair_cap / TILE_CHUNK), dim3(TILE_THREADS), k_tile_raster, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, ta, h->key_splat,
+                   h->key_ids, h->key_both);
+            LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+                   h->key_ids, h->key_both, 0, (const int*)ta.overflow);
+        } else
+            LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+                   h->key_ids, h->key_both, 0, (const int*)nullptr);
     }
     if (part == 1) return;
     if ((want & LIST_SPLAT) && old_target) {   // loop-closure renders: 1 = INACTIVE prediction into the old* images (IndexMap::oldFrameBuffer, EF/IndexMap.cpp:480-483),
@@ -1379,9 +1618,9 @@ int ifx_map_predict_loop_closure(ifx* h)
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
-           LIST_SPLAT | LIST_DUAL, h->list_a);
+           LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
     LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
-           h->key_ids, h->key_both, 1);
+           h->key_ids, h->key_both, 1, (const int*)nullptr);
     for (int old = 0; old < 2; old++)
         LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, (const float*)nullptr,
                old ? h->key_ids : h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt,

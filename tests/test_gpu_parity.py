@@ -973,6 +973,28 @@ def test_loop_closure_detection_nothing_inactive(ifx, small_stream):
     g.close(); g0.close()
 
 
+# ---------------------------------------------------------------- a9 / a14: the tiled rasteriser against the global-atomic one
+@pytest.mark.parametrize("res", [(320, 240), (328, 248)])
+def test_tiled_rasteriser_equals_atomic_rasteriser(ifx, small_stream, res):
+    """k_tile_* (key tiles resolved in LDS, on by default from 1 Mpixel) and k_raster_list (global atomics) must draw the same images: trajectories, maps,
+    predictions and id images bit for bit over several frames, also on an image whose size is no multiple of the tile size."""
+    from instancefusion_amd import synth
+
+    w, h = res
+    K = dict(fx=264.0, fy=264.0, cx=w / 2.0, cy=h / 2.0)
+    st = small_stream if res == (320, 240) else synth.make_stream(6, w, h, noise=True, **K)
+    a = ifx.ElasticFusion(w=w, h=h, max_surfels=400000, confidence=2.0, **K)
+    b = ifx.ElasticFusion(w=w, h=h, max_surfels=400000, confidence=2.0, **K)
+    a.set_option("raster_tiles", 0); b.set_option("raster_tiles", 1)
+    for k in range(6):
+        assert np.array_equal(a.processFrame(st["rgb"][k], st["depth"][k]), b.processFrame(st["rgb"][k], st["depth"][k])), k
+        for name in ("ids_after", "pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex"):
+            assert np.array_equal(a.image(name), b.image(name)), (k, name)
+    ma, mb = a.download(), b.download()
+    assert all(np.array_equal(ma[key], mb[key]) for key in MAP_KEYS) and (a.image("ids_after") > 0).mean() > 0.3
+    a.close(); b.close()
+
+
 # ---------------------------------------------------------------- 8f-3: deformation hooks (graph application inside clean, graph sampling, constraint samples)
 def _random_graph(samples, rng, rot=0.05, trans=0.02):
     import math

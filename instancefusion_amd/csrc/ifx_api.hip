@@ -217,7 +217,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
-    else if (s == "icp_blocks") h->opt_icp_blocks = std::max(1, std::min(1024, value));
+    else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;
     // refused while a frame is announced ahead (its image-only work may already be on the queue with the old configuration)

@@ -132,7 +132,7 @@ struct ifx {
     int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
-    int opt_icp_blocks = 304;
+    int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)
     int opt_raster_tiles = -1;       // tiled rasteriser (k_tile_*: key tiles resolved in LDS) instead of global atomics: 0 off, 1 on, -1 by image size (on from 1 Mpixel:
                                      // at 640x480 / 5M surfels the binning passes cost what the LDS tiles save, at 1280x960 / 20M the frame rate gains 12 %)
     // local loop-closure detection (ifx_set_loop_closure): second tracker instance + the INACTIVE prediction images

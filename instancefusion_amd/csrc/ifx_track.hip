@@ -1082,20 +1082,31 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
         // float4 columns; rows g, g+32, ... (<= 10 per array for <= 320 blocks) -> one memory round trip
         const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
         {   // requires blockDim.x == 256 (RED_THREADS)
-            float4 ti[10], tr[10];
+            double vi[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0};
+            // ten rows per thread and array at a time (all of them for <= 320 blocks: one memory round trip); more blocks (large images) take further rounds,
+            // accumulated in the same row order
+            const int rows = max(icp_blocks, rgb_blocks);
+            for (int u0 = 0; u0 * 32 < rows; u0 += 10) {
+                float4 ti[10], tr[10];
 #pragma unroll
-            for (int u = 0; u < 10; u++) {
-                // unconditional loads from a clamped row (no branch between the loads), masked afterwards
-                int b = g + 32 * u;
-                int bi = min(b, max(icp_blocks, 1) - 1), br = min(b, max(rgb_blocks, 1) - 1);
-                ti[u] = reinterpret_cast<const float4*>(icp_partials)[bi * 8 + c4];
-                tr[u] = reinterpret_cast<const float4*>(rgb_partials)[br * 8 + c4];
-            }
+                for (int u = 0; u < 10; u++) {
+                    // unconditional loads from a clamped row (no branch between the loads), masked afterwards
+                    int b = g + 32 * (u0 + u);
+                    int bi = min(b, max(icp_blocks, 1) - 1), br = min(b, max(rgb_blocks, 1) - 1);
+                    ti[u] = reinterpret_cast<const float4*>(icp_partials)[bi * 8 + c4];
+                    tr[u] = reinterpret_cast<const float4*>(rgb_partials)[br * 8 + c4];
+                }
 #pragma unroll
-            for (int u = 0; u < 10; u++) {
-                int b = g + 32 * u;
-                if (!(b < icp_blocks)) ti[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(b < rgb_blocks)) tr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < 10; u++) {
+                    int b = g + 32 * (u0 + u);
+                    if (!(b < icp_blocks)) ti[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(b < rgb_blocks)) tr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 10; u++) {
+                    vi[0] += (double)ti[u].x; vi[1] += (double)ti[u].y; vi[2] += (double)ti[u].z; vi[3] += (double)ti[u].w;
+                    vr[0] += (double)tr[u].x; vr[1] += (double)tr[u].y; vr[2] += (double)tr[u].z; vr[3] += (double)tr[u].w;
+                }
             }
             int c0 = 0, c1 = 0;
             if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
@@ -1106,18 +1117,12 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, const float* __rest
                     __hip_atomic_store(&res_total[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
-                int b = threadIdx.x;
-                int2 r0 = (b < res_blocks) ? reinterpret_cast<const int2*>(res_partials)[b] : make_int2(0, 0);
-                int2 r1 = (b + 256 < res_blocks) ? reinterpret_cast<const int2*>(res_partials)[b + 256] : make_int2(0, 0);
-                c0 = r0.x + r1.x; c1 = r0.y + r1.y;
+                for (int b = threadIdx.x; b < res_blocks; b += 256) {
+                    const int2 r0 = reinterpret_cast<const int2*>(res_partials)[b];
+                    c0 += r0.x; c1 += r0.y;
+                }
             }
             if (threadIdx.x < 2) s_res[threadIdx.x] = 0;
-            double vi[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int u = 0; u < 10; u++) {
-                vi[0] += (double)ti[u].x; vi[1] += (double)ti[u].y; vi[2] += (double)ti[u].z; vi[3] += (double)ti[u].w;
-                vr[0] += (double)tr[u].x; vr[1] += (double)tr[u].y; vr[2] += (double)tr[u].z; vr[3] += (double)tr[u].w;
-            }
 #pragma unroll
             for (int q = 0; q < 4; q++) { s_part[0][g][c4 * 4 + q] = vi[q]; s_part[1][g][c4 * 4 + q] = vr[q]; }
             __syncthreads();   // orders the s_res zeroing before the integer atomics below
@@ -1447,7 +1452,10 @@ void ifx_free_tracker(ifx* h)
 static inline int red_blocks(ifx* h, int n)
 {
     int b = cdiv(n, RED_THREADS * RED_IT);
-    if (b > h->opt_icp_blocks) b = h->opt_icp_blocks;
+    // cap on the blocks of a reduction launch (their partial rows are summed by the last block): 304 at 640x480 (one 1024-pixel chunk per block at
+    // level 0, flat beyond), one block per 2048 pixels on larger images (1280x960: 608 blocks, tracker 1.33 -> 1.18 ms)
+    const int cap = h->opt_icp_blocks > 0 ? h->opt_icp_blocks : std::max(304, std::min(1024, h->P / 2048));
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return b;
 }

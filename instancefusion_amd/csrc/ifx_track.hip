@@ -347,7 +347,15 @@ __device__ inline void products7(const float* row, bool found, float* acc)
 // thread has all of its memory requests in flight together.  (The first version used a rolled
 // grid-stride loop: 4-5 serial iterations of two dependent round trips each made even the 19 200-px
 // level take 11 us.)  Pixel u of a thread is base + u * blockDim.x, i.e. coalesced across lanes.
-#define RED_IT 4
+// Pixels per thread and loop round.  One for the ICP / residual passes: with four (the first tuning) a level-0 launch at 640x480 took 16.0 us, with one
+// 13.3 us -- the four-stage body already keeps a thread's requests in flight together, and the smaller register footprint lets more waves hide each
+// other's gathers (1004 -> 1057 frames/s).  The photometric step, whose 8-byte records stream, keeps four.
+#ifndef RED_IT
+#define RED_IT 1
+#endif
+#ifndef RED_IT_RGB
+#define RED_IT_RGB 4
+#endif
 #ifdef IFX_STAMPS
 __device__ long long g_dbg2[8];
 #define g_ts ts_local
@@ -570,7 +578,7 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
 #endif
     const int N = w * h;
     // stage 1 loads are issued before the sigma reduction so that both latencies overlap
-    const int base0 = bid * (blockDim.x * RED_IT) + threadIdx.x;
+    const int base0 = bid * (blockDim.x * RED_IT_RGB) + threadIdx.x;
     float sigma = sigma_explicit;
     if (res_total) {
         int cnt = res_total[0], sg = res_total[1];
@@ -602,12 +610,12 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
     float acc[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.f;
-    for (int base = base0; base < N; base += nblk * blockDim.x * RED_IT) {
-        Corres8 c[RED_IT];
-        float X[RED_IT], Y[RED_IT], Z[RED_IT];
-        short gx[RED_IT], gy[RED_IT];
+    for (int base = base0; base < N; base += nblk * blockDim.x * RED_IT_RGB) {
+        Corres8 c[RED_IT_RGB];
+        float X[RED_IT_RGB], Y[RED_IT_RGB], Z[RED_IT_RGB];
+        short gx[RED_IT_RGB], gy[RED_IT_RGB];
 #pragma unroll
-        for (int u = 0; u < RED_IT; u++) {
+        for (int u = 0; u < RED_IT_RGB; u++) {
             int k = base + u * blockDim.x;
             bool in = k < N;
             int kk = in ? k : 0;
@@ -616,12 +624,12 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
             if (!in) c[u].zx = -1;
         }
 #pragma unroll
-        for (int u = 0; u < RED_IT; u++) {
+        for (int u = 0; u < RED_IT_RGB; u++) {
             int g = (c[u].zx >= 0) ? ((int)c[u].zy * w + (int)c[u].zx) * 3 : 0;
             X[u] = cloud[g]; Y[u] = cloud[g + 1]; Z[u] = cloud[g + 2];
         }
 #pragma unroll
-        for (int u = 0; u < RED_IT; u++) {
+        for (int u = 0; u < RED_IT_RGB; u++) {
             float row[7] = {0, 0, 0, 0, 0, 0, 0};
             bool found = c[u].zx >= 0;
             if (found) {

@@ -21,6 +21,9 @@
 #ifndef MAP_BLOCKS
 #define MAP_BLOCKS 2048
 #endif
+#ifndef LIST_BLOCKS
+#define LIST_BLOCKS 1024   // grid of the work-list consumers (k_raster_list, k_clean_list, k_tile_count / fill): a multiple of the list segments
+#endif
 
 // ------------------------------------------------------------------ shared GLSL helpers
 // EF/Shaders/surfels.glsl:19-34
@@ -1061,15 +1064,15 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
             TileArgs ta;
             ta.tile_n = h->tile_n; ta.tile_off = h->tile_n + TILE_MAX; ta.tile_fill = h->tile_n + 2 * TILE_MAX; ta.blk_off = h->tile_n + 3 * TILE_MAX; ta.overflow = (int*)(h->tile_n + 4 * TILE_MAX + 8);
             ta.tile_box = h->tile_box; ta.pairs = h->tile_pairs; ta.pair_cap = h->tile_pair_cap; ta.tw = tw; ta.th = th;
-            LAUNCH(h, "tile_count", dim3(1024), dim3(MAP_THREADS), k_tile_count, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, ta);
+            LAUNCH(h, "tile_count", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_tile_count, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, ta);
             LAUNCH(h, "tile_scan", dim3(1), dim3(256), k_tile_scan, ta);
-            LAUNCH(h, "tile_fill", dim3(1024), dim3(MAP_THREADS), k_tile_fill, c, h->list_a, ta);
+            LAUNCH(h, "tile_fill", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_tile_fill, c, h->list_a, ta);
             LAUNCH(h, "tile_raster", dim3(tw * th + h->tile_pair_cap / TILE_CHUNK), dim3(TILE_THREADS), k_tile_raster, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, ta, h->key_splat,
                    h->key_ids, h->key_both);
-            LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+            LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
                    h->key_ids, h->key_both, 0, (const int*)ta.overflow);
         } else
-            LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+            LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
                    h->key_ids, h->key_both, 0, (const int*)nullptr);
     }
     if (part == 1) return;
@@ -1578,7 +1581,7 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
     LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
            (float4*)h->index_tap);
-    LAUNCH(h, "clean_list", dim3(1024), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+    LAUNCH(h, "clean_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_b, h->list_c);
     if (deform) {
         LAUNCH_SMEM(h, "deform", dim3(MAP_BLOCKS), dim3(256), (size_t)h->graph_nodes * 64, k_deform, h->d_state, d_pose_inv, h->d_graph, h->graph_nodes, h->graph_is_fern, time, c,
@@ -1619,7 +1622,7 @@ int ifx_map_predict_loop_closure(ifx* h)
     c.srank = 0; c.sn = 1;
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
            LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
-    LAUNCH(h, "raster_list", dim3(1024), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+    LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
            h->key_ids, h->key_both, 1, (const int*)nullptr);
     for (int old = 0; old < 2; old++)
         LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, (const float*)nullptr,

@@ -169,6 +169,7 @@ struct ifx {
     uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [8 segments x list_seg_cap] work lists (surfel index | flags << 30): raster candidates, clean candidates, kill list
     unsigned int *tile_n = nullptr, *tile_box = nullptr, *tile_pairs = nullptr;   // tiled rasteriser: [4 x TILE_MAX] counters / offsets / fill / flag, per-entry tile box, (tile, entry) pairs
     unsigned int tile_pair_cap = 0;
+    void* tile_recs = nullptr;          // [list size] 32-B camera-frame geometry records of the listed surfels (allocated when the tiled path is first used)
     unsigned int* d_list_ctr = nullptr;   // [3 lists][8 segments] lengths, 128 B apart
     unsigned int list_seg_cap = 0;
     int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot

@@ -632,11 +632,17 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_raster(DevState* st, const
 // Screen-space geometry of one listed surfel (splat.vert:55-92): camera-frame centre and normal, the projected extent of its quad, the point-sprite box
 // of the splat render.  Shared by the global-atomic rasteriser (k_raster_list) and the tiled one (k_tile_*), so that both draw the same pixels.
 struct SurfGeo { v3 q, nn; float r, u, v, xs[2], ys[2], minz; bool do_s; int sx0, sx1, sy0, sy1; };
+__device__ __forceinline__ void surfel_geo_cam(v3 q, v3 nn, float r, unsigned int e, const Cam& c, SurfGeo& G);
 __device__ __forceinline__ void surfel_geo(const float* T, float4 p4, float4 n4, unsigned int e, const Cam& c, SurfGeo& G)
 {
-    G.q = xf_point(T, v3m(p4.x, p4.y, p4.z));
-    G.nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
-    G.r = n4.w;
+    surfel_geo_cam(xf_point(T, v3m(p4.x, p4.y, p4.z)), normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z))), n4.w, e, c, G);
+}
+// the same from the camera-frame centre / normal (the tiled rasteriser keeps them per list entry)
+__device__ __forceinline__ void surfel_geo_cam(v3 q, v3 nn, float r, unsigned int e, const Cam& c, SurfGeo& G)
+{
+    G.q = q;
+    G.nn = nn;
+    G.r = r;
     disc_extent(G.q, G.nn, G.r, c, G.xs, G.ys, G.minz);
     G.u = ((c.fx * G.q.x) / G.q.z) + c.cx; G.v = ((c.fy * G.q.y) / G.q.z) + c.cy;
     // splat region: GL point sprite (splat.vert:75-92)
@@ -751,13 +757,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
 #define TILE_LOG 5
 #define TILE_MAX 4096   // tiles per image the LDS histograms are sized for (2048 x 2048 pixels)
 #define TILE_CHUNK 2048   // pairs one rasterising block draws; a tile with more pairs is shared by several blocks, which merge through atomicMin
-struct TileArgs { unsigned int *tile_n, *tile_off, *tile_fill, *blk_off, *tile_box, *pairs; int* overflow; unsigned int pair_cap; int tw, th; };
+struct TileRec { float qx, qy, qz, nx, ny, nz, r; unsigned int e; };   // camera-frame geometry of a list entry: the draw pass gathers one 32-B record instead of two 16-B ones and repeats no transform
+struct TileArgs { unsigned int *tile_n, *tile_off, *tile_fill, *blk_off, *tile_box, *pairs; TileRec* recs; int* overflow; unsigned int pair_cap; int tw, th; };
 
-__device__ __forceinline__ unsigned int tile_box_of(const float* T, const float4* __restrict__ pc, const float4* __restrict__ nr, unsigned int e, const Cam& c)
+__device__ __forceinline__ unsigned int tile_box_of(const float* T, const float4* __restrict__ pc, const float4* __restrict__ nr, unsigned int e, const Cam& c, TileRec& rec)
 {
     SurfGeo G;
     const unsigned int i = e & LIST_IDX;
     surfel_geo(T, pc[i], nr[i], e, c, G);
+    rec.qx = G.q.x; rec.qy = G.q.y; rec.qz = G.q.z; rec.nx = G.nn.x; rec.ny = G.nn.y; rec.nz = G.nn.z; rec.r = G.r; rec.e = e;
     int ix0, ix1, iy0, iy1;
     const bool do_i = surfel_id_box(G, e, c, ix0, ix1, iy0, iy1);
     if (!G.do_s && !do_i) return 0xFFFFFFFFu;
@@ -782,9 +790,12 @@ __global__ __launch_bounds__(MAP_THREADS) void k_tile_count(const DevState* __re
     const unsigned int n = *list_ctr(c, 0, seg);
     const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
     unsigned int* __restrict__ seg_box = ta.tile_box + (size_t)seg * c.seg_cap;
+    TileRec* __restrict__ seg_rec = ta.recs + (size_t)seg * c.seg_cap;
     for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
-        const unsigned int box = tile_box_of(T, pc, nr, seg_list[t], c);
+        TileRec rec;
+        const unsigned int box = tile_box_of(T, pc, nr, seg_list[t], c, rec);
         seg_box[t] = box;
+        if (box != 0xFFFFFFFFu) *reinterpret_cast<float4*>(&seg_rec[t]) = make_float4(rec.qx, rec.qy, rec.qz, rec.nx), *(reinterpret_cast<float4*>(&seg_rec[t]) + 1) = make_float4(rec.ny, rec.nz, rec.r, __uint_as_float(rec.e));
         if (box == 0xFFFFFFFFu) continue;
         const int tx0 = box & 255, ty0 = (box >> 8) & 255, tx1 = (box >> 16) & 255, ty1 = box >> 24;
         for (int ty = ty0; ty <= ty1; ty++)
@@ -849,23 +860,23 @@ __global__ __launch_bounds__(MAP_THREADS) void k_tile_fill(Cam c, const unsigned
     for (unsigned int t = t0; t < n; t += stride) {
         const unsigned int box = seg_box[t];
         if (box == 0xFFFFFFFFu) continue;
-        const unsigned int e = seg_list[t];
+        const unsigned int ri = (unsigned int)((size_t)seg * c.seg_cap + t);   // index of the entry's geometry record
         const int tx0 = box & 255, ty0 = (box >> 8) & 255, tx1 = (box >> 16) & 255, ty1 = box >> 24;
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int k = ty * ta.tw + tx;
-                ta.pairs[base[k] + atomicAdd(&hist[k], 1u)] = e;
+                ta.pairs[base[k] + atomicAdd(&hist[k], 1u)] = ri;
             }
     }
 }
 
 #define TILE_THREADS 512
-__device__ __forceinline__ void tile_draw(const float* T, float4 p4, float4 n4, unsigned int e, const Cam& c, int bx0, int by0, int bx1, int by1,
+__device__ __forceinline__ void tile_draw(float4 ra, float4 rb, const Cam& c, int bx0, int by0, int bx1, int by1,
                                           unsigned long long* ks, unsigned long long* ki, unsigned long long* kb)
 {
-    const unsigned int i = e & LIST_IDX;
+    const unsigned int e = __float_as_uint(rb.w), i = e & LIST_IDX;
     SurfGeo G;
-    surfel_geo(T, p4, n4, e, c, G);
+    surfel_geo_cam(v3m(ra.x, ra.y, ra.z), v3m(ra.w, rb.x, rb.y), rb.z, e, c, G);
     int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
     const bool do_s = G.do_s, do_i = surfel_id_box(G, e, c, ix0, ix1, iy0, iy1);
     if (!do_s && !do_i) return;
@@ -911,14 +922,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __
     const int bx0 = tx * TILE, by0 = ty * TILE, bx1 = bx0 + TILE - 1, by1 = by0 + TILE - 1;
     // four pairs per thread and round: their eight gathers are in flight together
     for (unsigned int p = threadIdx.x; p < n; p += 4 * blockDim.x) {
-        unsigned int e[4];
-        float4 p4[4], n4[4];
+        unsigned int ri[4];
+        float4 ra[4], rb[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const unsigned int q = p + u * blockDim.x; e[u] = q < n ? ta.pairs[off + q] : 0xFFFFFFFFu; }
+        for (int u = 0; u < 4; u++) { const unsigned int q = p + u * blockDim.x; ri[u] = q < n ? ta.pairs[off + q] : 0xFFFFFFFFu; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const unsigned int i = e[u] == 0xFFFFFFFFu ? 0u : (e[u] & LIST_IDX); p4[u] = pc[i]; n4[u] = nr[i]; }
+        for (int u = 0; u < 4; u++) {
+            const float4* r4 = reinterpret_cast<const float4*>(&ta.recs[ri[u] == 0xFFFFFFFFu ? 0u : ri[u]]);
+            ra[u] = r4[0]; rb[u] = r4[1];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (e[u] != 0xFFFFFFFFu) tile_draw(T, p4[u], n4[u], e[u], c, bx0, by0, bx1, by1, ks, ki, kb);
+        for (int u = 0; u < 4; u++) if (ri[u] != 0xFFFFFFFFu) tile_draw(ra[u], rb[u], c, bx0, by0, bx1, by1, ks, ki, kb);
     }
     __syncthreads();
     // the key images are all-empty between passes (the resolve clears what it reads): only winners are written -- plainly by a tile's only block,
@@ -1057,13 +1071,14 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
     if (part != 2) {
         const int tw = cdiv(h->w, TILE), th = cdiv(h->h, TILE);
         const bool want_tiles = h->opt_raster_tiles < 0 ? (h->P >= 1000000) : (h->opt_raster_tiles != 0);
-        const bool tiled = want_tiles && tw * th <= TILE_MAX && tw <= 255 && th <= 255 && h->tile_pairs;
+        if (want_tiles && !h->tile_recs && hipMalloc(&h->tile_recs, (size_t)h->list_seg_cap * LIST_SEGS * 32) != hipSuccess) h->tile_recs = nullptr;   // 32 B per list entry, on first use
+        const bool tiled = want_tiles && tw * th <= TILE_MAX && tw <= 255 && th <= 255 && h->tile_pairs && h->tile_recs;
         LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, maxTime, want,
                h->list_a, tiled ? h->tile_n : (unsigned int*)nullptr, tw * th);
         if (tiled) {
             TileArgs ta;
             ta.tile_n = h->tile_n; ta.tile_off = h->tile_n + TILE_MAX; ta.tile_fill = h->tile_n + 2 * TILE_MAX; ta.blk_off = h->tile_n + 3 * TILE_MAX; ta.overflow = (int*)(h->tile_n + 4 * TILE_MAX + 8);
-            ta.tile_box = h->tile_box; ta.pairs = h->tile_pairs; ta.pair_cap = h->tile_pair_cap; ta.tw = tw; ta.th = th;
+            ta.tile_box = h->tile_box; ta.pairs = h->tile_pairs; ta.recs = (TileRec*)h->tile_recs; ta.pair_cap = h->tile_pair_cap; ta.tw = tw; ta.th = th;
             LAUNCH(h, "tile_count", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_tile_count, (const DevState*)h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, ta);
             LAUNCH(h, "tile_scan", dim3(1), dim3(256), k_tile_scan, ta);
             LAUNCH(h, "tile_fill", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_tile_fill, c, h->list_a, ta);

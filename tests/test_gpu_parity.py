@@ -1223,3 +1223,55 @@ def test_fern_hooks(ifx, orc, small_stream):
     L.orc_tracker_destroy(t)
     assert abs(d2[1] - diag_o[1]) <= max(2.0, 0.002 * diag_o[1]) and d2[3] == diag_o[3] and np.abs(est2 - pose_o2.reshape(4, 4)).max() < 2e-5
     g.close(); small.close(); full.close()
+
+
+def test_loop_closure_scheduling_equivalence(ifx, small_stream):
+    """The model-to-model tracker runs on a stream of its own, under the map passes and the next frame's tracker: every scheduling variant (one
+    stream, plain, announced next frame, host-buffer entry point) must give the same verdict sequence bit for bit -- and the same frames as without
+    the detection."""
+    import torch
+
+    st = small_stream
+    seq = list(range(10)) + list(range(8, 0, -1))
+    n = len(seq)
+    d_rgb = torch.from_numpy(st["rgb"][seq].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][seq].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    kw = dict(time_delta=3, confidence=1.5)
+    thr = 35000 * (SMALL["w"] * SMALL["h"]) // (640 * 480)
+
+    def run(mode):
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+        if mode != "off":
+            g.set_loop_closure(True, thr, 1e-4, 1e-5)
+        if mode == "single":
+            g.set_option("two_streams", 0)
+        verdicts = []
+        for i in range(n):
+            if mode == "host":
+                g.processFrame(st["rgb"][seq[i]], st["depth"][seq[i]])
+            else:
+                if mode == "hint" and i + 1 < n:
+                    g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+                g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            if mode != "off" and (mode in ("host", "single") or i % 3 == 2):      # reading the verdict waits for the third stream: not after every frame
+                d = g.loop_closure_diag()
+                verdicts.append((i, d["ran"], d["inactive_pixels"], d["icp_count"], d["icp_error"], d["accepted"], d["est_pose"].tobytes()))
+        g.sync()
+        d = g.loop_closure_diag() if mode != "off" else None
+        out = (g.trajectory(), g.download(), g.image("ids_after"), verdicts, d["candidates"] if d else 0)
+        g.close()
+        return out
+
+    ref = run("single")
+    assert ref[4] >= 0 and any(v[1] for v in ref[3]) and any(v[2] > 1000 for v in ref[3])       # the tracker did run on populated renders
+    for mode in ("plain", "hint", "host", "off"):
+        t, m, ids, verdicts, cand = run(mode)
+        assert np.array_equal(t[:n], ref[0][:n]), mode
+        assert all(np.array_equal(m[k], ref[1][k]) for k in MAP_KEYS) and np.array_equal(ids, ref[2]), mode
+        if mode == "off":
+            continue
+        assert cand == ref[4], mode
+        want = {v[0]: v for v in ref[3]}
+        for v in verdicts:
+            assert v == want[v[0]], (mode, v[0])

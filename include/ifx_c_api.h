@@ -174,6 +174,15 @@ int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const floa
                    const float* tm, const float* ic, const float* votes);
 int ifx_set_pose(ifx_t* h, const float* pose16, int tick);
 int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
+/* Runtime options (name, value):
+ *   "pyramid" / "fast_odom" / "so3" (0|1), "icp_weight_x1000" -- ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176), from the
+ *                           next frame on; refused while a frame is announced ahead
+ *   "reference_passes" 1  -- also run the BEFORE / INSTANCECOMPARE id renders of EF/ElasticFusion.cpp:679-680 (nobody on this path consumes them)
+ *   "compact_every_frame" 1 -- remove tombstones after every clean (tests); "compact_divisor" d -- housekeeping compaction when tombstones > slots / d (default 8)
+ *   "two_streams" 0       -- everything on one stream; "track_ahead" 0 -- do not enqueue the announced frame's tracker behind the current frame
+ *   "stage_timing" / "kernel_timing" 1 -- HIP-event records for ifx_stage_ms / ifx_kernel_ms (cost frame rate: off by default)
+ *   "icp_blocks" n        -- cap on the blocks of a tracker reduction launch (0 = by image size)
+ *   "raster_tiles" -1|0|1 -- tiled rasteriser (key tiles in LDS): by image size (on from 1 Mpixel) | off | on; results are identical either way */
 int ifx_set_option(ifx_t* h, const char* name, int value);
 
 /* R32I surfel-id image after fusion (getSurfelIdsAfterFusionGpu, ElasticFusionInterface.h:90-102):

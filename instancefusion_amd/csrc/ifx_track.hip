@@ -1457,9 +1457,9 @@ void ifx_free_tracker(ifx* h)
     hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
-static inline int red_blocks(ifx* h, int n)
+static inline int red_blocks(ifx* h, int n, int it = RED_IT)
 {
-    int b = cdiv(n, RED_THREADS * RED_IT);
+    int b = cdiv(n, RED_THREADS * it);
     // cap on the blocks of a reduction launch (their partial rows are summed by the last block): 304 at 640x480 (one 1024-pixel chunk per block at
     // level 0, flat beyond), one block per 2048 pixels on larger images (1280x960: 608 blocks, tracker 1.33 -> 1.18 ms)
     const int cap = h->opt_icp_blocks > 0 ? h->opt_icp_blocks : std::max(304, std::min(1024, h->P / 2048));
@@ -1575,7 +1575,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         if (i == 0 && frame_tracker) ifx_enqueue_hinted_frame_side(h);
         float div = (float)(1 << i);
         float fx = c.fx / div, fy = c.fy / div, cx = c.cx / div, cy = c.cy / div;
-        int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n);
+        int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n), nb_rgb = red_blocks(h, n, RED_IT_RGB);   // the photometric step handles four pixels per thread: fewer blocks, fewer partial rows
         // intrinsics of the level the iteration after this level's last one runs at (for the warp matrices the solve emits)
         int nl = i - 1;
         while (nl >= 0 && iterations[nl] == 0) nl--;
@@ -1593,11 +1593,11 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
-            sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb; sa2.nb_icp = nb; sa2.nb_res = nb;
+            sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nb; sa2.nb_res = nb;
             sa2.rgb_partials = p.rgb_partials; sa2.icp_partials = p.icp_partials; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
             sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8); sa2.check_skip = frame_tracker ? 0 : 1;
-            LAUNCH(h, "rgb_step_solve", dim3(nb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
+            LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }
     LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit);

@@ -247,6 +247,13 @@ int ifx_labels(ifx_t* h, int32_t* out, int max_n);
  * floats (r, g, b in [0,1], alpha 1; black where no stable surfel is visible).  out_rgba: host buffer or NULL; d_out_rgba: device buffer or NULL
  * (enqueue only, no synchronisation).  The 2-D boxes the reference draws on top on the host are not drawn. */
 int ifx_render_project_map(ifx_t* h, float* out_rgba, float* d_out_rgba);
+/* ---- instance ground truth (the reference's ScanNet evaluation).
+ * ifx_set_instance_gt: the instanceGT argument of ElasticFusion::processFrame (EF/ElasticFusion.h:79, EF/ElasticFusion.cpp:285-291): H x W bytes; surfels created by the
+ *   frames that follow remember the id under the pixel that created them (vImgCorr.w, data.vert:215-228; -2 without ground truth).  NULL switches it off.
+ * ifx_precision_recall: computePrecisionAndRecallKernel (IF/Core/InstanceFusionCuda.cu:2085-2114), the device half of InstanceFusion::evaluateAndSave
+ *   (IF/Core/InstanceTable.cpp:336-370): surfels per instance (by instance colour), per ground-truth id, and per (ground-truth id, instance) pair. */
+int ifx_set_instance_gt(ifx_t* h, const uint8_t* gt_hw);
+int ifx_precision_recall(ifx_t* h, int32_t* inst_num96, int32_t* gt_num256, int32_t* inst_gt_map_256x96);
 /* class id per instance slot, -1 = unused (getInstanceTable, IF/Core/InstanceFusion.h:87) */
 int ifx_instance_table(ifx_t* h, int32_t* out96);
 /* getLoopClosureInstanceTable, IF/Core/InstanceTable.cpp:98-121: int[96*5] = r,g,b,class,index */

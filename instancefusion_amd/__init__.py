@@ -112,6 +112,8 @@ _SIGS = {
     "ifx_process_segmentation": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "ifx_labels": (C.c_int, [_P, _P, C.c_int]),
     "ifx_render_project_map": (C.c_int, [_P, _P, _P]),
+    "ifx_set_instance_gt": (C.c_int, [_P, _P]),
+    "ifx_precision_recall": (C.c_int, [_P, _P, _P, _P]),
     "ifx_instance_table": (C.c_int, [_P, _P]),
     "ifx_loop_closure_instance_table": (C.c_int, [_P, _P]),
     "ifx_mask_clean_overlap": (C.c_int, [_P, _P, C.c_int]),
@@ -205,6 +207,10 @@ class ElasticFusion:
         self._chk(self.L.ifx_set_option(self.handle, name.encode(), int(value)), "ifx_set_option")
 
     # -- frame entry (ElasticFusion::processFrame)
+    def set_instance_gt(self, gt):
+        """instanceGT of ElasticFusion::processFrame for the frames that follow (H x W uint8, None: off)."""
+        self._chk(self.L.ifx_set_instance_gt(self.handle, None if gt is None else _ptr(np.ascontiguousarray(gt, np.uint8))), "ifx_set_instance_gt")
+
     def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16)
@@ -453,6 +459,12 @@ class InstanceFusion:
         out = np.zeros(max(n, 1), np.int32)
         m = self.ef._chk(self.L.ifx_labels(self.ef.handle, _ptr(out), n), "ifx_labels")
         return out[:m]
+
+    def precision_recall(self):
+        """computePrecisionAndRecall: surfels per instance, per ground-truth id, per (gt, instance)."""
+        a, b, c = np.zeros(96, np.int32), np.zeros(256, np.int32), np.zeros((256, 96), np.int32)
+        self.ef._chk(self.L.ifx_precision_recall(self.ef.handle, _ptr(a), _ptr(b), _ptr(c)), "ifx_precision_recall")
+        return a, b, c
 
     def renderProjectMap(self):
         """InstanceFusion::renderProjectMap: instance colour under every pixel (H x W x 4 float32)."""

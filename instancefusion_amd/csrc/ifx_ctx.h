@@ -151,6 +151,8 @@ struct ifx {
     int lc_event_valid = 0;
     float* d_graph = nullptr;           // deformation graph handed in for the next clean (ifx_set_deformation): nodes x 16 floats
     int graph_nodes = 0, graph_is_fern = 0;
+    uint8_t* d_inst_gt = nullptr;       // instanceGT of processFrame (H x W bytes) for the frames to come
+    int inst_gt_on = 0;
     void* d_fern = nullptr;             // ifx_fern_frame scratch
     float* d_project = nullptr;         // ifx_render_project_map scratch (H x W float4)
     float *d_sample = nullptr, *d_cons = nullptr;   // scratch of ifx_sample_graph_model / ifx_loop_closure_constraints

@@ -673,6 +673,54 @@ extern "C" int ifx_labels(ifx_t* h, int32_t* out, int max_n)
     return n;
 }
 
+// ---- instance ground truth (ScanNet evaluation of the reference)
+// instanceGT argument of ElasticFusion::processFrame (EF/ElasticFusion.cpp:273-291): surfels created from now on remember the id under their pixel
+extern "C" int ifx_set_instance_gt(ifx_t* h, const uint8_t* gt_hw)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!gt_hw) { h->inst_gt_on = 0; return IFX_OK; }
+    if (!h->d_inst_gt) HIPCHK(h, hipMalloc(&h->d_inst_gt, (size_t)h->P));
+    HIPCHK(h, hipMemcpyAsync(h->d_inst_gt, gt_hw, (size_t)h->P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // gt_hw is the caller's
+    h->inst_gt_on = 1;
+    h->tracked_ahead = 0;
+    return IFX_OK;
+}
+// computePrecisionAndRecallKernel, IF/Core/InstanceFusionCuda.cu:2085-2114
+__global__ void k_precision_recall(const DevState* __restrict__ st, const float2* __restrict__ col, const float2* __restrict__ tm, const float4* __restrict__ ic,
+                                   const float* __restrict__ inst_color, int* __restrict__ inst_num, int* __restrict__ gt_num, int* __restrict__ inst_gt_map)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= st->count || !(tm[s].y > -1.0e8f)) return;   // tombstones are not part of the map
+    const float cc = col[s].y;
+    int inst = -1;
+    for (int i = 0; i < IFX_NUM_INSTANCES; i++) if (cc == inst_color[i]) { inst = i; break; }
+    if (inst >= 0) atomicAdd(&inst_num[inst], 1);
+    const int gt = (int)ic[s].w;
+    if (gt >= 0 && gt < 256) atomicAdd(&gt_num[gt], 1);
+    if (inst >= 0 && gt >= 0 && gt < 256) atomicAdd(&inst_gt_map[gt * IFX_NUM_INSTANCES + inst], 1);
+}
+extern "C" int ifx_precision_recall(ifx_t* h, int32_t* inst_num96, int32_t* gt_num256, int32_t* inst_gt_map)
+{
+    if (!h || !inst_num96 || !gt_num256 || !inst_gt_map) return IFX_E_INVALID;
+    const size_t n = IFX_NUM_INSTANCES + 256 + 256 * IFX_NUM_INSTANCES;
+    int* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, n * 4));
+    hipMemsetAsync(d, 0, n * 4, h->stream);
+    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->stream);
+    LAUNCH(h, "precision_recall", dim3(cdiv(h->cap, 256)), dim3(256), k_precision_recall, (const DevState*)h->d_state, (const float2*)h->col, (const float2*)h->tm,
+           (const float4*)h->ic, (const float*)h->d_inst_color, d, d + IFX_NUM_INSTANCES, d + IFX_NUM_INSTANCES + 256);
+    std::vector<int32_t> host(n);
+    hipError_t e = hipMemcpyAsync(host.data(), d, n * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
+    memcpy(inst_num96, host.data(), IFX_NUM_INSTANCES * 4);
+    memcpy(gt_num256, host.data() + IFX_NUM_INSTANCES, 256 * 4);
+    memcpy(inst_gt_map, host.data() + IFX_NUM_INSTANCES + 256, (size_t)256 * IFX_NUM_INSTANCES * 4);
+    return IFX_OK;
+}
+
 // renderProjectFrameKernel, IF/Core/InstanceFusionCuda.cu:1432-1498 (InstanceFusion::renderProjectMap without the boxes drawn on the host)
 __global__ void k_render_project(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float2* __restrict__ col, int P, float4* __restrict__ out)
 {

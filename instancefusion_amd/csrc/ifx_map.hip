@@ -1318,7 +1318,8 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
 
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
                                                      const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
-                                                     float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
+                                                     float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
+                                                     const uint8_t* __restrict__ inst_gt)
 {
     __shared__ int s_wave[4], s_base, s_last;
     const int P = c.w * c.h, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1359,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
         col[n] = make_float2(mcol[k], 0.f);
         tm[n] = make_float2((float)time, (float)time);
-        ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, -2.f);
+        ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
         for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (over) st->overflow = 1;
@@ -1607,7 +1608,8 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
     LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, d_pose_inv, c, time, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr,
            (const float4*)h->index_tap, h->scan_flags, h->scan_block);
     LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
-           (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
+           (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
 }
 

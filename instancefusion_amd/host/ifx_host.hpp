@@ -174,14 +174,17 @@ public:
         }
     }
 
-    // EF/ElasticFusion.h:75-82.  smallInstanceTable (96 x 5) and instanceGT feed the fern data base / ground-truth colouring of the
-    // reference only; both are accepted and unused.  bootstrap (inPose as an initial guess) is not part of the path.
+    // EF/ElasticFusion.h:75-82.  smallInstanceTable (96 x 5) feeds the fern data base of the reference only: accepted and unused.  instanceGT (H x W bytes,
+    // ScanNet ground truth) is stored per new surfel for InstanceFusion::evaluateAndSave.  bootstrap (inPose as an initial guess) is not part of the path.
     void processFrame(const unsigned char* rgb, const unsigned short* depth, const int64_t& timestamp, int* smallInstanceTable,
                       const unsigned char* instanceGT = NULL, const Matrix4f* inPose = 0, const float weightMultiplier = 1.f,
                       const bool bootstrap = false)
     {
         (void)smallInstanceTable;
-        (void)instanceGT;
+        if (instanceGT || hadInstanceGT_) {   // EF/ElasticFusion.cpp:285-291: the ground-truth instance image of this frame (new surfels remember the id under their pixel)
+            if (ifx_set_instance_gt(h_, instanceGT) != IFX_OK) throw std::runtime_error(std::string("ifx_set_instance_gt: ") + ifx_last_error(h_));
+            hadInstanceGT_ = instanceGT != NULL;
+        }
         if (bootstrap) throw std::runtime_error("ElasticFusion::processFrame: bootstrap is not supported");
         const int r = ifx_process_frame(h_, rgb, depth, timestamp, inPose ? inPose->data() : nullptr, weightMultiplier, currPose_.data());
         if (r < 0) throw std::runtime_error(std::string("ifx_process_frame: ") + ifx_last_error(h_));
@@ -390,6 +393,7 @@ private:
     int tick_ = 1;   // EF/ElasticFusion.cpp:48
     int deforms_ = 0;
     int loopCandidates_ = 0;
+    bool hadInstanceGT_ = false;
     bool closeLoops_, iclnuim_, reloc_, frameToFrameRGB_;
     int countThresh_;
     float errThresh_, covThresh_, photoThresh_, fernThresh_;
@@ -661,6 +665,42 @@ public:
         if (r < 0) throw std::runtime_error(std::string("ifx_process_segmentation: ") + ifx_last_error(map->handle()));
         handle_ = map->handle();
         segmentations_++;
+    }
+
+    // IF/Core/InstanceTable.cpp:336-445: precision / recall against the ground-truth ids the surfels carry (processFrame's instanceGT); appends to `path` the
+    // rows the reference appends to ./temp/Precision_Recall_RAW.txt.  inUse: instance slots in use (+ evicted ones) as the reference's summary row reports them.
+    void evaluateAndSave(const std::unique_ptr<ElasticFusionInterface>& map, const std::string& fileName, const std::string& path = "./Precision_Recall_RAW.txt")
+    {
+        std::vector<int32_t> instPointNum((size_t)instanceNum), gtPointNum(256), inst_gt_Map((size_t)256 * instanceNum);
+        if (ifx_precision_recall(map->handle(), instPointNum.data(), gtPointNum.data(), inst_gt_Map.data()) != IFX_OK)
+            throw std::runtime_error(std::string("ifx_precision_recall: ") + ifx_last_error(map->handle()));
+        bool hasFile = false;
+        {
+            std::ifstream probe(path);
+            hasFile = probe.good() && probe.peek() != std::ifstream::traits_type::eof();
+        }
+        std::ofstream ff(path, std::ios::app);
+        if (!ff) throw std::runtime_error("cannot write " + path);
+        if (!hasFile) ff << "fileName,class,gtPointNum,instPointNum,intersectionNum";
+        ff << std::endl;
+        int howManyGT = 0, inUse = 0;
+        for (int gtID = 0; gtID < 256; gtID++) howManyGT += gtPointNum[(size_t)gtID] > 6000;
+        const std::vector<ClassColour> table = getInstanceTable();
+        for (const ClassColour& c : table) inUse += !c.name.empty();
+        ff << ",,,,,,," << howManyGT << "," << inUse << std::endl;
+        for (int gtID = 0; gtID < 256; gtID++) {
+            if (gtPointNum[(size_t)gtID] <= 150) continue;
+            int maxInstanceInGTNum = 0, maxInstanceID = -1;
+            for (int i = 0; i < instanceNum; i++)
+                if (inst_gt_Map[(size_t)gtID * instanceNum + i] > maxInstanceInGTNum) { maxInstanceInGTNum = inst_gt_Map[(size_t)gtID * instanceNum + i]; maxInstanceID = i; }
+            if (maxInstanceInGTNum <= 150) continue;
+            bool flag = true;
+            for (int other = 0; other < 256; other++)
+                if (inst_gt_Map[(size_t)other * instanceNum + maxInstanceID] > inst_gt_Map[(size_t)gtID * instanceNum + maxInstanceID]) flag = false;
+            if (flag)
+                ff << fileName << "," << table[(size_t)maxInstanceID].name << "," << gtPointNum[(size_t)gtID] << "," << instPointNum[(size_t)maxInstanceID] << ","
+                   << inst_gt_Map[(size_t)gtID * instanceNum + maxInstanceID] << std::endl;
+        }
     }
 
     // IF/Core/InstanceFusion.cpp:1232-1252 (the image the GUI shows as "segmentation"; the 2-D boxes are not drawn): H x W x 4 floats

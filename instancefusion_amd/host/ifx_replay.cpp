@@ -5,7 +5,7 @@
 // (map->SavePly(), IF/main.cpp:300-305), and optionally the per-surfel instance labels.
 //
 //   ifx_replay LOG.klg|data.txt [--width 640 --height 480 --fx 528 --fy 528 --cx 320 --cy 240] [--masks DIR] [--out PREFIX]
-//              [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--device K]
+//              [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--device K] [--gt-dir DIR --eval FILE]
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -18,7 +18,7 @@ const int cnn_start_frames = 0;    // IF/main.cpp:34-36 (cnn_skip_frames is dead
 int flann_skip_frames = 40;       // IF/main.cpp:36; --flann-every overrides it
 
 struct Args {
-    std::string log, masks, out = "./ResultModel", labels;
+    std::string log, masks, out = "./ResultModel", labels, gt_dir, eval_file;
     int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
     float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
     bool superpixels = true, flip = false, close_loops = true;
@@ -53,6 +53,8 @@ int main(int argc, char** argv)
         else if (s == "--masks") a.masks = val("--masks");
         else if (s == "--out") a.out = val("--out");
         else if (s == "--labels") a.labels = val("--labels");
+        else if (s == "--gt-dir") a.gt_dir = val("--gt-dir");      // DIR/<frame, 6 digits>.png: 8-bit instance ground truth (hasInstanceGroundTruth, IF/main.cpp:73)
+        else if (s == "--eval") a.eval_file = val("--eval");
         else if (s == "--max-frames") a.max_frames = std::atoi(val("--max-frames"));
         else if (s == "--max-surfels") a.max_surfels = std::atoi(val("--max-surfels"));
         else if (s == "--flann-every") flann_skip_frames = std::atoi(val("--flann-every"));
@@ -92,7 +94,20 @@ int main(int argc, char** argv)
         while (log_reader->hasMore() && (a.max_frames <= 0 || frame_Fusion < a.max_frames)) {   // IF/main.cpp:108-307
             log_reader->getNext();
             instancefusion->getLoopClosureInstanceTable(instanceTableLoopClosure.data());
-            if (!map->ProcessFrame(log_reader->rgb, log_reader->depth, log_reader->timestamp, instanceTableLoopClosure.data(), NULL)) {
+            const unsigned char* instanceGT = NULL;
+            std::vector<unsigned char> gtBuf;
+            if (!a.gt_dir.empty()) {
+                char name[32];
+                std::snprintf(name, sizeof(name), "/%06d.png", frame_Fusion);
+                std::ifstream probe(a.gt_dir + name, std::ios::binary);
+                if (probe) {
+                    const ifx_detail::PngImage g = ifx_detail::decode_png(ifx_detail::read_file(a.gt_dir + name), a.gt_dir + name);
+                    if (g.w != a.width || g.h != a.height || g.channels != 1 || g.bits != 8) throw std::runtime_error(a.gt_dir + name + ": ground truth must be 8-bit grey of the frame size");
+                    gtBuf = g.data;
+                    instanceGT = gtBuf.data();
+                }
+            }
+            if (!map->ProcessFrame(log_reader->rgb, log_reader->depth, log_reader->timestamp, instanceTableLoopClosure.data(), instanceGT)) {
                 std::cout << "Elastic fusion lost!" << a.log << std::endl;
                 return 1;
             }
@@ -116,6 +131,7 @@ int main(int argc, char** argv)
             std::ofstream f(a.labels, std::ios::binary);
             f.write((const char*)l.data(), (std::streamsize)l.size() * 4);
         }
+        if (!a.eval_file.empty()) instancefusion->evaluateAndSave(map, a.log, a.eval_file);   // IF/main.cpp:340
         const Matrix4f P = map->getCurrPose();
         std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
                     "last position %.6f %.6f %.6f, %d local loop-closure candidates\n",

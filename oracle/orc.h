@@ -124,6 +124,7 @@ int orc_process_frame(orc_t*, const uint8_t* rgb, const uint16_t* depth, int64_t
                       const float* in_pose16, float weight_mult, float* out_pose16);
 int orc_map_count(orc_t*);
 void orc_get_pose(orc_t*, float* out16);
+void orc_set_instance_gt(orc_t*, const uint8_t* gt_hw);   /* instanceGT of processFrame: new surfels remember the id under their pixel (vImgCorr.w) */
 int orc_tick(orc_t*);
 /* copy out map fields; any pointer may be NULL.  pc,nr,ic: float4 per surfel; col,tm: float2; votes: 48 floats/surfel */
 void orc_map_download(orc_t*, float* pc, float* nr, float* col, float* tm, float* ic, float* votes);
@@ -167,6 +168,7 @@ int orc_process_segmentation(orc_t*, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks, const int32_t* class_ids, int n, int frame,
                              int do_knn);
 void orc_labels(orc_t*, int32_t* out);
+void orc_precision_recall(orc_t*, int32_t* inst_num96, int32_t* gt_num256, int32_t* inst_gt_map_256x96);   /* computePrecisionAndRecallKernel */
 void orc_render_project_map(orc_t*, float* out_rgba);   /* renderProjectFrameKernel: instance colour under every pixel, H x W x 4 floats */
 void orc_instance_table(orc_t*, int32_t* class_of_instance /*96, -1 unused*/);
 

@@ -46,6 +46,21 @@ void orc_instance_free(orc_t* o) { free(o->labels); }
 void orc_instance_table(orc_t* o, int32_t* out) { memcpy(out, o->inst_class, sizeof(o->inst_class)); }
 void orc_labels(orc_t* o, int32_t* out) { memcpy(out, o->labels, (size_t)o->n * 4); }
 
+/* computePrecisionAndRecallKernel, IF/Core/InstanceFusionCuda.cu:2085-2114 (InstanceFusion::evaluateAndSave, IF/Core/InstanceTable.cpp:336-370): per surfel the
+ * instance whose table colour equals its instance colour (first match) and the ground-truth id kept in vImgCorr.w */
+void orc_precision_recall(orc_t* o, int32_t* inst_num, int32_t* gt_num, int32_t* inst_gt_map)
+{
+    memset(inst_num, 0, ORC_NUM_INST * 4); memset(gt_num, 0, 256 * 4); memset(inst_gt_map, 0, 256 * ORC_NUM_INST * 4);
+    for (int s = 0; s < o->n; s++) {
+        int inst = -1;
+        for (int i = 0; i < ORC_NUM_INST; i++) if (o->col[s * 2 + 1] == o->inst_color[i]) { inst = i; break; }
+        if (inst >= 0) inst_num[inst]++;
+        const int gt = (int)o->ic[s * 4 + 3];
+        if (gt >= 0 && gt < 256) gt_num[gt]++;
+        if (inst >= 0 && gt >= 0 && gt < 256) inst_gt_map[gt * ORC_NUM_INST + inst]++;
+    }
+}
+
 /* InstanceFusion::renderProjectMap without the boxes: renderProjectFrameKernel, IF/Core/InstanceFusionCuda.cu:1432-1498 -- the instance colour of
  * the surfel under every pixel of the id image after fusion, RGBA float, black where no stable surfel is visible */
 void orc_render_project_map(orc_t* o, float* out_rgba)

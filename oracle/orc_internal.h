@@ -59,6 +59,7 @@ struct orc {
     /* deformation graph handed in for the next clean (GlobalModel::clean's `graph` argument), orc_deform.c */
     float* graph;
     int graph_nodes, graph_is_fern;
+    uint8_t* inst_gt;   /* instance ground truth of the frames to come (NULL: none) */
     orc_lc_callback lc_cb;
     void* lc_user;
 };

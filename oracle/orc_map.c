@@ -139,7 +139,7 @@ void orc_destroy(orc_t* o)
     free(o->fill_image); free(o->ids_after); free(o->ids_tmp); free(o->zbuf); free(o->newbuf); free(o->updbuf);
     orc_tracker_destroy(o->trk);
     orc_tracker_destroy(o->m2m);
-    free(o->graph);
+    free(o->graph); free(o->inst_gt);
     free(o->old_vertex); free(o->old_normal); free(o->old_image); free(o->old_inst); free(o->old_time);
     orc_instance_free(o);
     free(o);
@@ -147,6 +147,13 @@ void orc_destroy(orc_t* o)
 
 int orc_map_count(orc_t* o) { return o->n; }
 void orc_get_pose(orc_t* o, float* out16) { memcpy(out16, o->pose, 64); }
+/* instanceGT argument of ElasticFusion::processFrame (EF/ElasticFusion.cpp:285-286): H x W bytes, kept until replaced; NULL switches it off */
+void orc_set_instance_gt(orc_t* o, const uint8_t* gt)
+{
+    free(o->inst_gt);
+    o->inst_gt = NULL;
+    if (gt) { o->inst_gt = (uint8_t*)malloc((size_t)o->P); memcpy(o->inst_gt, gt, (size_t)o->P); }
+}
 int orc_tick(orc_t* o) { return o->tick; }
 
 void orc_map_download(orc_t* o, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
@@ -438,7 +445,8 @@ static void associate_pixel(orc_t* o, const float* pose, int time, float weighti
     const uint8_t* c = &o->rgb[(j * w + i) * 3];
     m->col0 = orc_encode_color(c[0] / 255.0f, c[1] / 255.0f, c[2] / 255.0f);
     m->nr[0] = ng.x; m->nr[1] = ng.y; m->nr[2] = ng.z; m->nr[3] = get_radius(vf.z, nl.z, ifx, ify);
-    m->ic[0] = x; m->ic[1] = y; m->ic[2] = (float)time; m->ic[3] = -2;
+    m->ic[0] = x; m->ic[1] = y; m->ic[2] = (float)time;
+    m->ic[3] = o->inst_gt ? (float)o->inst_gt[j * w + i] : -2.0f;   /* data.vert:215-228: the ground-truth instance id of the creating pixel */
 
     float xl = (x - cx) * ifx, yl = (y - cy) * ify;
     float lambda = sqrtf(xl * xl + yl * yl + 1);

@@ -295,6 +295,16 @@ class Oracle:
         self.L.orc_mask_superpixel_filter(self.h, ptr(fin), ptr(masks), masks.shape[0])
         return masks
 
+    def set_instance_gt(self, gt):
+        self.L.orc_set_instance_gt.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_set_instance_gt(self.h, None if gt is None else ptr(np.ascontiguousarray(gt, np.uint8)))
+
+    def precision_recall(self):
+        a, b, c = np.zeros(96, np.int32), np.zeros(256, np.int32), np.zeros((256, 96), np.int32)
+        self.L.orc_precision_recall.argtypes = [C.c_void_p] * 4
+        self.L.orc_precision_recall(self.h, ptr(a), ptr(b), ptr(c))
+        return a, b, c
+
     def render_project_map(self):
         out = np.zeros((self.h_, self.w_, 4), np.float32)
         self.L.orc_render_project_map.argtypes = [C.c_void_p, C.c_void_p]

@@ -1275,3 +1275,37 @@ def test_loop_closure_scheduling_equivalence(ifx, small_stream):
         want = {v[0]: v for v in ref[3]}
         for v in verdicts:
             assert v == want[v[0]], (mode, v[0])
+
+
+# ---------------------------------------------------------------- a1: the instanceGT argument of processFrame + computePrecisionAndRecall (evaluateAndSave)
+def test_instance_ground_truth_and_precision_recall(ifx, orc, small_stream):
+    from instancefusion_amd import synth
+
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000, confidence=2.0)
+    inst = ifx.InstanceFusion(g)
+    for k in range(6):
+        gt = (st["obj"][k] % 250).astype(np.uint8) if k >= 1 else None          # no ground truth for the first frames, then one per frame
+        g.set_instance_gt(gt); o.set_instance_gt(gt)
+        po = o.process_frame(st["rgb"][k], st["depth"][k])
+        g.processFrame(st["rgb"][k], st["depth"][k])
+    m = o.download(); m["pc"][:, 3] = 20.0                                       # every surfel stable, so that the segmentation below labels some
+    g.upload(m); o.upload(m); g.set_pose(po, o.tick); o.set_pose(po, o.tick)     # identical maps from here on
+    g.processFrame(st["rgb"][5], st["depth"][5], inPose=po); o.process_frame(st["rgb"][5], st["depth"][5], in_pose=po)
+    mg, mo = g.download(), o.download()
+    assert np.array_equal(mg["ic"], mo["ic"])
+    w = mo["ic"][:, 3]
+    assert (w == -1).any() and (w >= 0).sum() > 1000 and set(np.unique(w[w >= 0]).astype(int)) <= set(np.unique(st["obj"][1:6] % 250).astype(int))
+    masks, cls = synth.canned_masks(st["obj"][5], st["scene"])
+    inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], masks, cls, 5)
+    o.process_segmentation(st["rgb"][5], st["depth"][5], masks, cls, 5)
+    pg, po_ = inst.precision_recall(), o.precision_recall()
+    for a, b in zip(pg, po_):
+        assert np.array_equal(a, b)
+    assert po_[1].sum() == (w >= 0).sum() and po_[0].sum() > 0 and po_[2].sum() > 0
+    g.set_instance_gt(None); o.set_instance_gt(None)                             # switched off: new surfels carry -2 again
+    g.processFrame(st["rgb"][6], st["depth"][6], inPose=po); o.process_frame(st["rgb"][6], st["depth"][6], in_pose=po)
+    assert np.array_equal(g.download()["ic"], o.download()["ic"]) and (o.download()["ic"][:, 3] == -2).any()
+    g.close(); o.close()

@@ -29,7 +29,8 @@ int usage(const char* argv0)
 {
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
-                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--confidence C]\n",
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--confidence C]\n"
+                 "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n",
                  argv0);
     return 2;
 }

@@ -228,7 +228,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks of a multi-GPU run would wait for it)
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol

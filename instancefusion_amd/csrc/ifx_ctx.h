@@ -205,6 +205,7 @@ struct ifx {
     int* res_partials = nullptr;    // [blocks][2]
     float* so3_partials = nullptr;  // [blocks][12]
     float* d_out29 = nullptr;
+    int res_rows = 1024;                // rows of res_partials (blocks of the residual pass)
     unsigned int* d_ticket = nullptr;   // last-block ticket of k_rgb_step_solve
     // instance layer
     int32_t inst_class[IFX_NUM_INSTANCES];

@@ -207,7 +207,7 @@ def main():
         # MI355X_MICROARCH.md prescribes for gfx950; collected offline on this same command, see profiles/README.md)
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_p_pmc_traffic.json")) as f:
                 pmc = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
             pass

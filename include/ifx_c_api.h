@@ -145,7 +145,16 @@ int ifx_adopt_estimated_pose(ifx_t* h);
  *   normals) / initRGB(current maps) + getIncrementalTransformation starting at pose16 (EF/Ferns.cpp:558-592, EF/ElasticFusion.cpp:528-545).  Host
  *   float4 maps of the handle's resolution (RGBA8 images or NULL); uses the handle's configuration (icp_weight, pyramid, fast_odom; no SO(3)): for
  *   ferns create a handle with width/8, height/8, intrinsics/8, icp_weight 100, pyramid 0.  pose16 in: model pose = initial estimate; out: estimate.
- *   diag8: lastICPError, lastICPCount, lastRGBError, lastRGBCount, 0... */
+ *   diag8: lastICPError, lastICPCount, lastRGBError, lastRGBCount, 0...
+ * ifx_set_fern_callback: where the reference looks its fern data base up and deforms globally (EF/ElasticFusion.cpp:457-514): every frame after the
+ *   first, with loop closure enabled, right after predict() at the tracked pose and before the local detection.  Inside the callback ifx_fern_frame
+ *   delivers that predict() (what findFrame resamples), ifx_set_deformation(is_fern = 1) hands the optimised graph to this frame's clean and
+ *   ifx_adopt_pose sets currPose = recoveryPose (:482, :504).  Return 1 when a graph was produced (rawGraph.size() > 0: the local detection of this
+ *   frame is skipped, :516), 0 otherwise, < 0 to fail the frame.  A handle with this callback synchronises once per frame, as the reference does.
+ *   Outside the callback ifx_fern_frame delivers the end-of-frame predict() (what Ferns::addFrame stores, :713-716). */
+typedef int (*ifx_fern_cb)(ifx_t* h, void* user);
+int ifx_set_fern_callback(ifx_t* h, ifx_fern_cb cb, void* user);
+int ifx_adopt_pose(ifx_t* h, const float* pose16);
 int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb);
 int ifx_track_maps(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba, const float* cur_v4, const float* cur_n4,
                    const uint8_t* cur_rgba, float* pose16, float* diag8);

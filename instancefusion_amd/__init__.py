@@ -84,6 +84,8 @@ _SIGS = {
     "ifx_loop_closure_constraints": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "ifx_set_deformation": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ifx_adopt_estimated_pose": (C.c_int, [_P]),
+    "ifx_set_fern_callback": (C.c_int, [_P, _P, _P]),
+    "ifx_adopt_pose": (C.c_int, [_P, _P]),
     "ifx_fern_frame": (C.c_int, [_P, _P, _P, _P, _P]),
     "ifx_track_maps": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
@@ -306,6 +308,30 @@ class ElasticFusion:
         self._chk(self.L.ifx_adopt_estimated_pose(self.handle), "ifx_adopt_estimated_pose")
 
     # -- GPU contacts of the fern data base (EF/Ferns.cpp)
+    def set_fern_callback(self, fn):
+        """fn(ef) -> truthy when a graph was produced; runs inside processFrame every frame after predict() at the tracked pose
+        (Ferns::findFrame + global deformation, EF/ElasticFusion.cpp:457-514).  None removes it."""
+        if fn is None:
+            self._fern_cb = None
+            self._chk(self.L.ifx_set_fern_callback(self.handle, None, None), "ifx_set_fern_callback")
+            return
+
+        def tramp(_h, _user):
+            try:
+                return 1 if fn(self) else 0
+            except Exception:      # never unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        self._fern_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(tramp)
+        self._chk(self.L.ifx_set_fern_callback(self.handle, C.cast(self._fern_cb, C.c_void_p), None), "ifx_set_fern_callback")
+
+    def adopt_pose(self, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.ifx_adopt_pose(self.handle, _ptr(p)), "ifx_adopt_pose")
+
     def fern_frame(self):
         """fill-in image / vertex / normal and instance render at (w/8) x (h/8): what Ferns::addFrame / findFrame read back"""
         rw, rh = self.w // 8, self.h // 8

@@ -196,6 +196,13 @@ extern "C" int ifx_set_loop_closure_callback(ifx_t* h, ifx_loop_closure_cb cb, v
     h->lc_cb = cb; h->lc_user = user;
     return IFX_OK;
 }
+extern "C" int ifx_set_fern_callback(ifx_t* h, ifx_fern_cb cb, void* user)
+{
+    if (!h) return IFX_E_INVALID;
+    if (cb && !h->lc_enable) { h->err = "the fern callback runs inside the loop-closure block: enable it first (ifx_set_loop_closure)"; return IFX_E_STATE; }
+    h->fern_cb = cb; h->fern_user = user;
+    return IFX_OK;
+}
 extern "C" int ifx_loop_closure_diag(ifx_t* h, float* out24)
 {
     if (!h || !out24) return IFX_E_INVALID;
@@ -299,7 +306,7 @@ __global__ void k_lc_idle(DevState* st, float* __restrict__ host_lc)
 static int enqueue_loop_closure_renders(ifx* h)
 {
     h->lc_deferred = 0;
-    if (!h->map_external && h->tick - h->cfg.time_delta < 1) {
+    if (!h->fern_cb && !h->map_external && h->tick - h->cfg.time_delta < 1) {
         LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state, h->h_lc);
         return IFX_OK;
     }
@@ -309,6 +316,17 @@ static int enqueue_loop_closure_renders(ifx* h)
         StageTimer t(h, 1);
         ifx_tracker_m2m_begin(h);
         ifx_map_predict_loop_closure(h);
+    }
+    if (h->fern_cb) {   // Ferns::findFrame and the global deformation (EF/ElasticFusion.cpp:457-514): host code of the caller, every frame, on the finished renders
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->in_fern_cb = 1;
+        int r = h->fern_cb(h, h->fern_user);
+        h->in_fern_cb = 0;
+        if (r < 0) { h->err = "fern callback failed"; return r; }
+        if (r > 0) {    // matched to a fern and deformed (rawGraph.size() > 0): no local loop closure this frame (:516)
+            LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state, h->h_lc);
+            return IFX_OK;
+        }
     }
     if (!h->lc_cb) {
         if (h->opt_two_streams && h->stream_c) HIPCHK(h, hipEventRecord(h->ev_lc_ready, h->stream));

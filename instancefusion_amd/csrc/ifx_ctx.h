@@ -158,6 +158,9 @@ struct ifx {
     float *d_sample = nullptr, *d_cons = nullptr;   // scratch of ifx_sample_graph_model / ifx_loop_closure_constraints
     ifx_loop_closure_cb lc_cb = nullptr;
     void* lc_user = nullptr;
+    ifx_fern_cb fern_cb = nullptr;      // global loop closure (Ferns::findFrame, EF/ElasticFusion.cpp:457-514): runs every frame after predict()
+    void* fern_user = nullptr;
+    int in_fern_cb = 0;                 // inside it the "last predict()" is the one at the tracked pose (act* images)
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned

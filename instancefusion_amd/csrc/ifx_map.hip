@@ -1807,18 +1807,39 @@ extern "C" int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, 
 
 // ---- Ferns (EF/Ferns.cpp) GPU contact no. 1: the four Resize passes of addFrame / findFrame (:95-98, :192-195) -- the fill-in image, vertex and
 // normal maps and the instance render resampled to (w/8) x (h/8) (nearest texel of the sample centre) and read back
+// fill = 0: img / vert / norm are the fill-in images; fill = 1: they are a raw prediction and the fill-in (fill_rgb/vertex/normal.frag, as in
+// k_splat_resolve) is evaluated at the samples only
 __global__ void k_fern_resize(const uchar4* __restrict__ img, const float4* __restrict__ vert, const float4* __restrict__ norm, const uchar4* __restrict__ inst, int w, int h,
-                              uint8_t* __restrict__ o_img, float4* __restrict__ o_vert, float4* __restrict__ o_norm, uint8_t* __restrict__ o_inst)
+                              uint8_t* __restrict__ o_img, float4* __restrict__ o_vert, float4* __restrict__ o_norm, uint8_t* __restrict__ o_inst, int fill, Cam c,
+                              const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt)
 {
     const int rw = w / 8, rh = h / 8, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rw * rh) return;
     const int j = t / rw, i = t - j * rw;
-    const int k = ((j * h + h / 2) / rh) * w + (i * w + w / 2) / rw;
-    const uchar4 c = img[k], q = inst[k];
-    o_img[t * 3] = c.x; o_img[t * 3 + 1] = c.y; o_img[t * 3 + 2] = c.z;
+    const int y = (j * h + h / 2) / rh, x = (i * w + w / 2) / rw;
+    const int k = y * w + x;
+    uchar4 cl = img[k];
+    const uchar4 q = inst[k];
+    float4 vo = vert[k], no = norm[k];
+    if (fill) {
+        const float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+        if ((int)cl.x + (int)cl.y + (int)cl.z == 0) cl = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
+        const float zc = (float)depth_filt[k] / 1000.0f;
+        if (no.z == 0) {
+            v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
+            int xr = clampi(x + 1, 0, w - 1), yd = clampi(y + 1, 0, h - 1);
+            float zx = (float)depth_filt[y * w + xr] / 1000.0f, zy = (float)depth_filt[yd * w + x] / 1000.0f;
+            v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
+            v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
+            v3 nn = normalized(cross(vx - vp, vy - vp));
+            no = make_float4(nn.x, nn.y, nn.z, 1.f);
+        }
+        if (vo.z == 0) vo = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
+    }
+    o_img[t * 3] = cl.x; o_img[t * 3 + 1] = cl.y; o_img[t * 3 + 2] = cl.z;
     o_inst[t * 3] = q.x; o_inst[t * 3 + 1] = q.y; o_inst[t * 3 + 2] = q.z;
-    o_vert[t] = vert[k];
-    o_norm[t] = norm[k];
+    o_vert[t] = vo;
+    o_norm[t] = no;
 }
 extern "C" int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb)
 {
@@ -1830,8 +1851,13 @@ extern "C" int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* 
     float4* dn = dv + n;
     uint8_t* di = (uint8_t*)(dn + n);
     uint8_t* ds = di + (size_t)n * 3;
-    LAUNCH(h, "fern_resize", dim3(cdiv(n, 64)), dim3(64), k_fern_resize, (const uchar4*)h->fill_image, (const float4*)h->fill_vertex, (const float4*)h->fill_normal,
-           (const uchar4*)h->pred_inst, h->w, h->h, di, dv, dn, ds);
+    // the last predict(): inside the fern callback the one at the tracked pose (act* images, fill-in evaluated at the samples), else the end-of-frame one
+    if (h->in_fern_cb)
+        LAUNCH(h, "fern_resize", dim3(cdiv(n, 64)), dim3(64), k_fern_resize, (const uchar4*)h->act_image, (const float4*)h->act_vertex, (const float4*)h->act_normal,
+               (const uchar4*)h->act_inst, h->w, h->h, di, dv, dn, ds, 1, make_cam(h), (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt);
+    else
+        LAUNCH(h, "fern_resize", dim3(cdiv(n, 64)), dim3(64), k_fern_resize, (const uchar4*)h->fill_image, (const float4*)h->fill_vertex, (const float4*)h->fill_normal,
+               (const uchar4*)h->pred_inst, h->w, h->h, di, dv, dn, ds, 0, make_cam(h), (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt);
     HIPCHK(h, hipMemcpyAsync(verts4, dv, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(norms4, dn, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(img_rgb, di, (size_t)n * 3, hipMemcpyDeviceToHost, h->stream));
@@ -1857,6 +1883,24 @@ extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, 
     HIPCHK(h, hipStreamSynchronize(h->stream));   // graph16 is the caller's
     h->graph_nodes = n_nodes; h->graph_is_fern = is_fern ? 1 : 0;
     h->tracked_ahead = 0;
+    return IFX_OK;
+}
+
+struct Pose16 { float m[16]; };
+__global__ void k_adopt_pose(DevState* st, Pose16 p)
+{
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 16; k++) st->pose[k] = p.m[k];
+    pose_inverse(st->pose, st->pose_inv);
+}
+extern "C" int ifx_adopt_pose(ifx_t* h, const float* pose16)
+{
+    if (!h || !pose16) return IFX_E_INVALID;
+    if (!h->in_fern_cb) { h->err = "ifx_adopt_pose: only inside the fern callback (currPose = recoveryPose, EF/ElasticFusion.cpp:482,504)"; return IFX_E_STATE; }
+    Pose16 p;
+    memcpy(p.m, pose16, sizeof(p.m));
+    h->tracked_ahead = 0;
+    LAUNCH(h, "adopt_pose", dim3(1), dim3(64), k_adopt_pose, h->d_state, p);
     return IFX_OK;
 }
 

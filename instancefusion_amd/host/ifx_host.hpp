@@ -53,6 +53,9 @@ struct Matrix4f {   // row-major camera-to-world pose; stands in for Eigen::Matr
     float* data() { return m; }
 };
 
+#include "ifx_ferns.hpp"
+typedef FernsT<Matrix4f> Ferns;   // EF/Ferns.h
+
 // ------------------------------------------------------------------------------------------------ singletons
 class Resolution {   // EF/Utils/Resolution.h:27-68
 public:
@@ -121,8 +124,9 @@ class ElasticFusion {
 public:
     // EF/ElasticFusion.h:47-62, same order and defaults.  closeLoops turns the local loop-closure DETECTION on (ifx_set_loop_closure with
     // countThresh / errThresh / covThresh: INACTIVE prediction + model-to-model tracking + gates; candidates are counted, the deformation
-    // they trigger in the reference is outside the path).  photoThresh / fernThresh / reloc belong to the fern data base
-    // and relocalisation: kept so that existing call sites compile and readable through the getters, nothing else.
+    // they trigger in the reference is outside the path) and the fern data base (ferns(500, depthCut * 1000, photoThresh),
+    // EF/ElasticFusion.cpp:49): findFrame every frame inside the handle's fern callback, addFrame with fernThresh after every frame.  A fern match
+    // needs the reference's global graph optimiser to become a deformation: that is the caller's (setFernHandler).  reloc is kept for the getter only.
     ElasticFusion(const int timeDelta = 200, const int countThresh = 35000, const float errThresh = 5e-05, const float covThresh = 1e-05,
                   const bool closeLoops = true, const bool iclnuim = false, const bool reloc = false, const float photoThresh = 115,
                   const float confidence = 10, const float depthCut = 3, const float icpThresh = 10, const bool fastOdom = false,
@@ -157,6 +161,14 @@ public:
             ifx_destroy(h_);
             throw std::runtime_error("ifx_set_loop_closure: " + e);
         }
+        if (closeLoops) {
+            ferns_.reset(new Ferns(500, (int)(depthCut * 1000), photoThresh, cfg_.width, cfg_.height, cfg_.fx, cfg_.fy, cfg_.cx, cfg_.cy, device));
+            if (ifx_set_fern_callback(h_, &ElasticFusion::fernTrampoline, this) != IFX_OK) {
+                const std::string e = ifx_last_error(h_);
+                ifx_destroy(h_);
+                throw std::runtime_error("ifx_set_fern_callback: " + e);
+            }
+        }
         currPose_ = Matrix4f::Identity();
     }
     ElasticFusion(const ElasticFusion&) = delete;
@@ -174,13 +186,13 @@ public:
         }
     }
 
-    // EF/ElasticFusion.h:75-82.  smallInstanceTable (96 x 5) feeds the fern data base of the reference only: accepted and unused.  instanceGT (H x W bytes,
+    // EF/ElasticFusion.h:75-82.  smallInstanceTable (96 x 5) is handed to Ferns::findFrame, whose only writer of it is disabled in the reference.  instanceGT (H x W bytes,
     // ScanNet ground truth) is stored per new surfel for InstanceFusion::evaluateAndSave.  bootstrap (inPose as an initial guess) is not part of the path.
     void processFrame(const unsigned char* rgb, const unsigned short* depth, const int64_t& timestamp, int* smallInstanceTable,
                       const unsigned char* instanceGT = NULL, const Matrix4f* inPose = 0, const float weightMultiplier = 1.f,
                       const bool bootstrap = false)
     {
-        (void)smallInstanceTable;
+        smallInstanceTable_ = smallInstanceTable;
         if (instanceGT || hadInstanceGT_) {   // EF/ElasticFusion.cpp:285-291: the ground-truth instance image of this frame (new surfels remember the id under their pixel)
             if (ifx_set_instance_gt(h_, instanceGT) != IFX_OK) throw std::runtime_error(std::string("ifx_set_instance_gt: ") + ifx_last_error(h_));
             hadInstanceGT_ = instanceGT != NULL;
@@ -193,6 +205,7 @@ public:
             float lc[24];
             if (ifx_loop_closure_diag(h_, lc) == IFX_OK) loopCandidates_ = (int)lc[23];
         }
+        if (ferns_ && !lost_) ferns_->addFrame(h_, currPose_, tick_, fernThresh_);   // processFerns(), EF/ElasticFusion.cpp:713-727
         tick_++;
         poseGraph_.push_back(currPose_);
         poseLogTimes_.push_back(timestamp);
@@ -236,6 +249,25 @@ public:
         std::vector<float> src, dst;   // n x 3 each: worldRawPoint, worldModelPoint
         std::vector<int32_t> times;    // n
     };
+    // ---- global loop closure (EF/ElasticFusion.cpp:457-514).  Ferns::findFrame runs every frame; when it produced constraints (lastClosest != -1) the
+    // handler stands where the reference adds them to globalDeformation and calls constrain(ferns.frames, rawGraph, tick, true, poseGraph, true):
+    //     handler(ef, constraints, recoveryPose, fernSrcTime) -> rawGraph (empty = the optimiser refused; the local detection then runs as usual)
+    // A non-empty graph is applied by this frame's clean as a fern deformation and currPose becomes the recovery pose.
+    typedef std::function<std::vector<float>(ElasticFusion&, const std::vector<Ferns::SurfaceConstraint>&, const Matrix4f& recoveryPose, int fernSrcTime)> FernHandler;
+    void setFernHandler(FernHandler fn) { fernHandler_ = std::move(fn); }
+    Ferns* ferns() { return ferns_.get(); }
+    // the reference seeds its fern table with time(0) (EF/Ferns.cpp:52); a fixed seed makes a run repeatable.  Empties the data base.
+    void resetFerns(uint32_t seed)
+    {
+        if (!ferns_) return;
+        ferns_.reset(new Ferns(500, (int)(cfg_.depth_cut * 1000), photoThresh_, cfg_.width, cfg_.height, cfg_.fx, cfg_.fy, cfg_.cx, cfg_.cy, cfg_.device, seed));
+    }
+    int getFernMatches() const { return fernMatches_; }     // frames on which findFrame produced constraints
+    void adoptPose(const Matrix4f& pose)
+    {
+        if (ifx_adopt_pose(h_, pose.data()) != IFX_OK) throw std::runtime_error(std::string("ifx_adopt_pose: ") + ifx_last_error(h_));
+    }
+
     void setLoopClosureHandler(std::function<void(ElasticFusion&, const LoopClosureCandidate&)> fn)
     {
         lcHandler_ = std::move(fn);
@@ -382,6 +414,32 @@ private:
         return IFX_OK;
     }
     std::function<void(ElasticFusion&, const LoopClosureCandidate&)> lcHandler_;
+    // inside ifx_process_frame, after predict() at the tracked pose (ifx_set_fern_callback)
+    static int fernTrampoline(ifx_t* h, void* user)
+    {
+        ElasticFusion* self = static_cast<ElasticFusion*>(user);
+        try {
+            Matrix4f tracked;
+            if (ifx_get_pose(h, tracked.data()) < 0) return IFX_E_STATE;
+            std::vector<Ferns::SurfaceConstraint> constraints;
+            const Matrix4f recoveryPose = self->ferns_->findFrame(constraints, tracked, h, self->smallInstanceTable_, self->tick_, self->lost_);
+            if (self->ferns_->lastClosest == -1) return 0;
+            self->fernMatches_++;
+            if (!self->fernHandler_) return 0;
+            const std::vector<float> rawGraph = self->fernHandler_(*self, constraints, recoveryPose, self->ferns_->frames[self->ferns_->lastClosest]->srcTime);
+            if (rawGraph.empty()) return 0;
+            self->setDeformation(rawGraph, true);
+            self->adoptPose(recoveryPose);
+            return 1;
+        } catch (const std::exception& e) {   // never unwind through the C frames of libifx.so
+            std::fprintf(stderr, "fern data base: %s\n", e.what());
+            return IFX_E_STATE;
+        }
+    }
+    std::unique_ptr<Ferns> ferns_;
+    FernHandler fernHandler_;
+    int fernMatches_ = 0;
+    int* smallInstanceTable_ = nullptr;
     void option(const char* name, int v)
     {
         if (ifx_set_option(h_, name, v) != IFX_OK) throw std::runtime_error(std::string("ifx_set_option(") + name + "): " + ifx_last_error(h_));

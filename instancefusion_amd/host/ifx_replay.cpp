@@ -135,9 +135,10 @@ int main(int argc, char** argv)
         if (!a.eval_file.empty()) instancefusion->evaluateAndSave(map, a.log, a.eval_file);   // IF/main.cpp:340
         const Matrix4f P = map->getCurrPose();
         std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
-                    "last position %.6f %.6f %.6f, %d local loop-closure candidates\n",
+                    "last position %.6f %.6f %.6f, %d local loop-closure candidates, %d fern keyframes, %d fern matches\n",
                     frame_Fusion, dt, frame_Fusion / (dt > 0 ? dt : 1), instancefusion->segmentationCalls(), map->getMapSurfelCount(), n_geo, a.out.c_str(), n_ins,
-                    P(0, 3), P(1, 3), P(2, 3), map->elasticFusion().getLoopClosureCandidates());
+                    P(0, 3), P(1, 3), P(2, 3), map->elasticFusion().getLoopClosureCandidates(),
+                    map->elasticFusion().ferns() ? (int)map->elasticFusion().ferns()->frames.size() : 0, map->elasticFusion().getFernMatches());
         map.reset();   // ~ElasticFusion writes PREFIX.freiburg
     } catch (const std::exception& e) {
         std::fprintf(stderr, "ifx_replay: %s\n", e.what());

@@ -149,6 +149,13 @@ void orc_loop_closure_diag(orc_t*, float* out24);
  * the four functions below.  The graph optimisation itself (EF/Utils/DeformationGraph.cpp) is the caller's. */
 typedef int (*orc_lc_callback)(orc_t*, const float* lc24, void* user);
 void orc_set_loop_closure_callback(orc_t*, orc_lc_callback cb, void* user);
+/* the place of Ferns::findFrame and the global deformation (EF/ElasticFusion.cpp:457-514): every frame after predict() at the tracked pose; > 0 = a graph
+ * was produced, the local detection is skipped (:516).  orc_fern_frame: the four Resize passes of EF/Ferns.cpp:95-98 / :192-195 on the last predict()
+ * ((w/8) x (h/8) nearest samples of the fill-in image / vertex / normal and of the instance render).  orc_adopt_pose: currPose = recoveryPose (:482, :504). */
+typedef int (*orc_fern_callback)(orc_t*, void* user);
+void orc_set_fern_callback(orc_t*, orc_fern_callback cb, void* user);
+int orc_fern_frame(orc_t*, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb);
+void orc_adopt_pose(orc_t*, const float* pose16);
 int orc_sample_graph_model(orc_t*, float* out_xyzt, int max_n);                                   /* Deformation::sampleGraphModel */
 int orc_loop_closure_constraints(orc_t*, float* src3, float* dst3, int32_t* times, int max_n);   /* EF/ElasticFusion.cpp:568-598 */
 void orc_set_deformation(orc_t*, const float* graph16, int n_nodes, int is_fern);                 /* `graph` of GlobalModel::clean, applied by the next clean */

@@ -62,6 +62,8 @@ struct orc {
     uint8_t* inst_gt;   /* instance ground truth of the frames to come (NULL: none) */
     orc_lc_callback lc_cb;
     void* lc_user;
+    orc_fern_callback fern_cb;   /* Ferns::findFrame + global deformation of the caller (EF/ElasticFusion.cpp:457-514) */
+    void* fern_user;
 };
 
 void orc_deform_surfel(const float* g, int nodes, float* pc, float* nr, float initT, float* lastT, int time, float thr, int is_fern, const float* tinv,

@@ -722,6 +722,13 @@ void orc_loop_closure_diag(orc_t* o, float* out24) { memcpy(out24, o->lc, sizeof
 static void loop_closure_local(orc_t* o)
 {
     predict(o);                                                         /* :453 */
+    if (o->fern_cb && o->fern_cb(o, o->fern_user) > 0) {                /* :457-514; matched to a fern and deformed: :516 skips the rest */
+        const float cand = o->lc[23];
+        memset(o->lc, 0, sizeof(o->lc));
+        o->lc[23] = cand;
+        memcpy(&o->lc[6], o->pose, 64);
+        return;
+    }
     float *pv = o->pred_vertex, *pn = o->pred_normal;                   /* :519-526: same shader, other framebuffer */
     uint8_t *pi = o->pred_image, *ps = o->pred_inst;
     uint16_t* pt = o->pred_time;
@@ -757,6 +764,22 @@ static void loop_closure_local(orc_t* o)
     if (accept && o->lc_cb) o->lc_cb(o, o->lc, o->lc_user);   /* :566-613: constraints, graph optimisation (caller), rawGraph, currPose = estPose */
 }
 void orc_set_loop_closure_callback(orc_t* o, orc_lc_callback cb, void* user) { o->lc_cb = cb; o->lc_user = user; }
+void orc_set_fern_callback(orc_t* o, orc_fern_callback cb, void* user) { o->fern_cb = cb; o->fern_user = user; }
+void orc_adopt_pose(orc_t* o, const float* pose16) { memcpy(o->pose, pose16, 64); }
+/* Resize::image / Resize::vertex (EF/Shaders/Resize.cpp, resize.frag: nearest sample at the centre of each target texel) */
+int orc_fern_frame(orc_t* o, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb)
+{
+    const int rw = o->w / 8, rh = o->h / 8;
+    for (int j = 0; j < rh; j++)
+        for (int i = 0; i < rw; i++) {
+            const int t = j * rw + i, k = ((j * o->h + o->h / 2) / rh) * o->w + (i * o->w + o->w / 2) / rw;
+            memcpy(&img_rgb[t * 3], &o->fill_image[k * 4], 3);
+            memcpy(&inst_rgb[t * 3], &o->pred_inst[k * 4], 3);
+            memcpy(&verts4[t * 4], &o->fill_vertex[k * 4], 16);
+            memcpy(&norms4[t * 4], &o->fill_normal[k * 4], 16);
+        }
+    return rw * rh;
+}
 
 /* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Of the loop-closure block (:450-617) only the local detection
  * is restated (loop_closure_local, when enabled); ferns and the deformation graph are out of scope, and without

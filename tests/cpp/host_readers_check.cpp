@@ -52,6 +52,86 @@ int main(int argc, char** argv)
             o.write((const char*)rgb.data(), (std::streamsize)rgb.size());
             return 0;
         }
+        if (mode == "ferns") {   // ferns IN OUT: the host maths of the fern data base (ifx_ferns.hpp) on given read-back images, with a stand-in tracker
+            // IN: int32 fullW, fullH, nFerns, maxDepth, seed, minGap, nOps; f32 fx, fy, cx, cy, photoThresh; per op: int32 kind (0 add, 1 find), time; f32 threshold;
+            //     pose16; img np*3; inst np*3; verts np*4; norms np*4; (find) tracker answer: f32 dpose3 (added to the keyframe's translation), diag8
+            std::ifstream in(argv[2], std::ios::binary);
+            std::ofstream f(argv[3], std::ios::binary);
+            int32_t hd[7];
+            float fl[5];
+            in.read((char*)hd, sizeof(hd));
+            in.read((char*)fl, sizeof(fl));
+            Ferns ferns(hd[2], hd[3], fl[4], hd[0], hd[1], fl[0], fl[1], fl[2], fl[3], 0, (uint32_t)hd[4]);
+            ferns.minTimeGap = hd[5];
+            for (auto& fe : ferns.conservatory) {
+                const int32_t row[6] = {fe.pos[0], fe.pos[1], fe.rgbd[0], fe.rgbd[1], fe.rgbd[2], fe.rgbd[3]};
+                f.write((const char*)row, sizeof(row));
+            }
+            const size_t np = (size_t)ferns.width * ferns.height;
+            std::vector<unsigned char> img(np * 3), inst(np * 3);
+            std::vector<float> verts(np * 4), norms(np * 4);
+            for (int op = 0; op < hd[6]; op++) {
+                int32_t kt[2];
+                float thr;
+                Matrix4f pose;
+                in.read((char*)kt, 8); in.read((char*)&thr, 4); in.read((char*)pose.data(), 64);
+                in.read((char*)img.data(), (std::streamsize)np * 3); in.read((char*)inst.data(), (std::streamsize)np * 3);
+                in.read((char*)verts.data(), (std::streamsize)np * 16); in.read((char*)norms.data(), (std::streamsize)np * 16);
+                if (kt[0] == 0) {
+                    const int32_t ok = ferns.addFrameMaps(img.data(), verts.data(), norms.data(), inst.data(), pose, kt[1], thr) ? 1 : 0;
+                    const int32_t nf = (int32_t)ferns.frames.size();
+                    f.write((const char*)&ok, 4); f.write((const char*)&nf, 4);
+                } else {
+                    float ans[11];
+                    in.read((char*)ans, sizeof(ans));
+                    ferns.setTracker([&](const float*, const float*, const float*, const float*, float* p16, float* d8) {
+                        p16[3] += ans[0]; p16[7] += ans[1]; p16[11] += ans[2];
+                        std::memcpy(d8, ans + 3, 32);
+                    });
+                    std::vector<Ferns::SurfaceConstraint> cons;
+                    const Matrix4f est = ferns.findFrameMaps(cons, pose, img.data(), verts.data(), norms.data(), kt[1], false);
+                    const int32_t r[3] = {ferns.lastCandidate, ferns.lastClosest, (int32_t)cons.size()};
+                    const float d[2] = {ferns.lastDissimilarity, ferns.lastPhotoError};
+                    f.write((const char*)r, 12); f.write((const char*)d, 8); f.write((const char*)est.data(), 64);
+                    for (auto& c : cons) { f.write((const char*)c.sourcePoint, 16); f.write((const char*)c.targetPoint, 16); }
+                }
+            }
+            return 0;
+        }
+        if (mode == "fernrun") {   // fernrun KLG W H FX FY CX CY GAP CONFIDENCE (GPU): the data base inside real frames, with a rigid stand-in for the graph optimiser
+            Resolution::getInstance(std::atoi(argv[3]), std::atoi(argv[4]));
+            Intrinsics::getInstance((float)std::atof(argv[5]), (float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8]));
+            RawLogReader log(argv[2], false);
+            ElasticFusion ef(200, 35000, 5e-05, 1e-05, true, false, false, 115, (float)std::atof(argv[10]), 12, 10, false, 0.3095, true, false, "", 2000000, 0);
+            ef.resetFerns(12345u);
+            ef.ferns()->minTimeGap = std::atoi(argv[9]);
+            float lastShift = 0;
+            ef.setFernHandler([&](ElasticFusion& e, const std::vector<Ferns::SurfaceConstraint>& cons, const Matrix4f& recovery, int srcTime) {
+                (void)recovery; (void)srcTime;
+                std::vector<float> nodes = e.sampleGraphModel(), g;
+                float mean[3] = {0, 0, 0};
+                for (auto& c : cons)
+                    for (int k = 0; k < 3; k++) mean[k] += (c.targetPoint[k] - c.sourcePoint[k]) / (float)cons.size();
+                lastShift = std::sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+                if (nodes.size() / 4 < 4 || cons.empty()) return g;
+                for (size_t i = 0; i < nodes.size() / 4; i++) {
+                    const float n[16] = {nodes[i * 4], nodes[i * 4 + 1], nodes[i * 4 + 2], 1, 0, 0, 0, 1, 0, 0, 0, 1, mean[0], mean[1], mean[2], nodes[i * 4 + 3]};
+                    g.insert(g.end(), n, n + 16);
+                }
+                return g;
+            });
+            int table[96 * 5] = {0};
+            while (log.hasMore()) {
+                log.getNext();
+                ef.processFrame(log.rgb, log.depth, log.timestamp, table);
+                const Ferns& f = *ef.ferns();
+                const Matrix4f& P = ef.getCurrPose();
+                std::printf("tick %d keyframes %d candidate %d closest %d icpErr %g icpCount %g photo %g matches %d deforms %d shift %g pos %.6f %.6f %.6f surfels %d\n",
+                            ef.getTick() - 1, (int)f.frames.size(), f.lastCandidate, f.lastClosest, f.lastICPError, f.lastICPCount, f.lastPhotoError, ef.getFernMatches(),
+                            ef.getFernDeforms(), lastShift, P(0, 3), P(1, 3), P(2, 3), ef.getMapSurfelCount());
+            }
+            return 0;
+        }
         if (mode == "quat") {
             std::ofstream f(argv[2], std::ios::binary);
             const float R[3][9] = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, -1, 0, 1, 0, 0, 0, 0, 1}, {-1, 0, 0, 0, -0.6f, 0.8f, 0, 0.8f, 0.6f}};

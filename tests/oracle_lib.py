@@ -208,6 +208,29 @@ class Oracle:
         self.L.orc_set_deformation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         self.L.orc_set_deformation(self.h, ptr(g), g.shape[0], int(is_fern))
 
+    def set_fern_callback(self, fn):
+        """fn(oracle) -> truthy when a graph was produced (EF/ElasticFusion.cpp:457-514)"""
+        self.L.orc_set_fern_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if fn is None:
+            self._fcb = None
+            self.L.orc_set_fern_callback(self.h, None, None)
+            return
+        self._fcb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(lambda _h, _u: 1 if fn(self) else 0)
+        self.L.orc_set_fern_callback(self.h, C.cast(self._fcb, C.c_void_p), None)
+
+    def fern_frame(self):
+        rw, rh = self.w_ // 8, self.h_ // 8
+        img, inst = np.zeros((rh, rw, 3), np.uint8), np.zeros((rh, rw, 3), np.uint8)
+        v, n = np.zeros((rh, rw, 4), np.float32), np.zeros((rh, rw, 4), np.float32)
+        self.L.orc_fern_frame.argtypes = [C.c_void_p] * 5
+        self.L.orc_fern_frame(self.h, ptr(img), ptr(v), ptr(n), ptr(inst))
+        return img, v, n, inst
+
+    def adopt_pose(self, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.L.orc_adopt_pose.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_adopt_pose(self.h, ptr(p))
+
     def adopt_estimated_pose(self):
         self.L.orc_adopt_estimated_pose.argtypes = [C.c_void_p]
         self.L.orc_adopt_estimated_pose(self.h)

@@ -1159,6 +1159,66 @@ def test_loop_closure_callback_end_to_end(ifx, orc, small_stream):
 
 
 # ---------------------------------------------------------------- 8f-3: the GPU contacts of the fern data base (EF/Ferns.cpp)
+def test_fern_callback_global_deformation(ifx, orc, small_stream):
+    """The place of Ferns::findFrame and the global deformation inside a frame (EF/ElasticFusion.cpp:457-514): the callback runs every frame on the
+    predict() at the tracked pose (its resampled fill-in images are what findFrame reads), a produced graph is applied by this frame's clean as a
+    fern deformation, currPose = recoveryPose, and the local detection of that frame is skipped (:516).  Same callback on both sides, exact."""
+    st = small_stream
+    kw = dict(time_delta=3, confidence=2.0)
+    o = orc.Oracle(**SMALL, max_surfels=400000, **kw)
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000, **kw)
+    g.set_option("compact_every_frame", 1)
+    o.set_loop_closure(True); g.set_loop_closure(True)
+    log = {"o": [], "g": []}
+    tracked = [None]
+    DEFORM_AT = 4   # callback number (= frame index 5)
+
+    def make_cb(tag):
+        def cb(e):
+            if tag == "o":
+                tracked[0] = e.get_pose()
+            log[tag].append(e.fern_frame())
+            if len(log[tag]) != DEFORM_AT:
+                return False
+            s = e.sample_graph_model()
+            e.set_deformation(_random_graph(s, np.random.RandomState(5)), is_fern=True)
+            p2 = tracked[0].copy(); p2[:3, 3] += np.array([0.003, -0.002, 0.004], np.float32)
+            e.adopt_pose(p2)
+            return True
+        return cb
+
+    with pytest.raises(RuntimeError):
+        g.adopt_pose(np.eye(4, dtype=np.float32))                      # only inside the callback
+    o.set_fern_callback(make_cb("o")); g.set_fern_callback(make_cb("g"))
+    po = None
+    for k in range(8):
+        if k >= 1:
+            m, tick0, po_prev = o.download(), o.tick, po
+        po = o.process_frame(st["rgb"][k], st["depth"][k])
+        if k >= 1:
+            g.upload(m); g.set_pose(po_prev, tick0)
+        pg = g.processFrame(st["rgb"][k], st["depth"][k], inPose=None if k < 1 else tracked[0])
+        assert len(log["o"]) == len(log["g"]) == k, k                  # every frame after the first
+        if k >= 1:
+            assert np.array_equal(pg, po), k
+            for a, b in zip(log["o"][-1], log["g"][-1]):                # findFrame's four images
+                assert np.array_equal(a, b), k
+            assert (log["g"][-1][1][..., 2] > 0).mean() > 0.9
+            do, dg = o.loop_closure_diag(), g.loop_closure_diag()
+            assert do["ran"] == dg["ran"] == (len(log["g"]) != DEFORM_AT and do["inactive_pixels"] > 0), k
+            if len(log["g"]) == DEFORM_AT:
+                assert np.abs(pg[:3, 3] - tracked[0][:3, 3]).max() > 1e-3      # the adopted pose
+            mo, mg = o.download(), g.download()
+            for key in MAP_KEYS:
+                assert np.array_equal(mo[key], mg[key]), (k, key)
+        for a, b in zip(o.fern_frame(), g.fern_frame()):                # addFrame's four images (end-of-frame predict)
+            assert np.array_equal(a, b), k
+        if k == 2:                                                      # everything stable from here on: an old model comes into being
+            m2 = o.download(); m2["pc"][:, 3] = 20.0; o.upload(m2)
+    assert len(log["g"]) > DEFORM_AT
+    o.close(); g.close()
+
+
 def test_fern_hooks(ifx, orc, small_stream):
     """(1) the resampled fill-in / instance images Ferns::addFrame and findFrame read back; (2) the ICP-only, single-scale tracker on two small
     renders (keyframe against current frame, Ferns.cpp:558-592) against the oracle's tracker fed the same maps."""

@@ -245,6 +245,9 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     r = subprocess.run([REPLAY, klg] + common + ["--out", out_c, "--labels", out_c + ".labels"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert f"{n} frames" in r.stdout and " 0 segmentation calls" not in r.stdout
+    # the fern data base ran inside every frame (findFrame in the callback, addFrame after it): keyframes were admitted, nothing is old enough to match,
+    # and the frames are what the Python loop (no data base) computes
+    assert int(r.stdout.split(" fern keyframes")[0].split()[-1]) >= 1 and " 0 fern matches" in r.stdout
     spec = importlib.util.spec_from_file_location("run_log", os.path.join(ROOT, "tools", "run_log.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -290,3 +293,130 @@ def test_cpp_replay_png_log_equals_klg(small_stream, tmp_path):
         assert r.returncode == 0 and f"{n} frames" in r.stdout, (r.stdout, r.stderr)
         outs.append(open(out + ".freiburg").read())
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == n
+
+
+# ---------------------------------------------------------------- the fern data base (ifx_ferns.hpp) against oracle/orc_ferns.py, no GPU
+def _fern_scene(rng, w, h, fx, fy, cx, cy, holes):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = rng.uniform(0.6, 2.4)
+    z = (base + 0.3 * np.sin(xx / rng.uniform(2, 5) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(2, 5))).astype(np.float32)
+    z[rng.random((h, w)) < holes] = 0
+    verts = np.stack([(xx - cx) * z / fx, (yy - cy) * z / fy, z, np.ones_like(z)], axis=-1).astype(np.float32)
+    verts[z == 0] = 0
+    norms = np.zeros((h, w, 4), np.float32); norms[..., 2] = -1; norms[..., 3] = 1
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    img = ((img.astype(np.int32) + np.roll(img, 1, axis=1) + np.roll(img, 1, axis=0)) // 3).astype(np.uint8)
+    return img, verts, norms
+
+
+def test_fern_database_equals_restatement(checker, tmp_path):
+    """Ferns::addFrame / findFrame (EF/Ferns.cpp): fern codes, co-occurrence search, keyframe admission, blockHDAware, photometric check, the gates of
+    :644 and the constraints, C++ class against the Python restatement on the same read-back images, the same fern table and the same tracker answers."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc_ferns
+
+    FW, FH, NF, MAXD, SEED, GAP = 160, 120, 200, 3000, 77, 2
+    fx, fy, cx, cy, photo = 130.0, 130.0, 80.0, 60.0, 115.0
+    w, h = FW // 8, FH // 8
+    rng = np.random.default_rng(3)
+    scenes = [_fern_scene(rng, w, h, fx / 8, fy / 8, cx / 8, cy / 8, holes) for holes in (0.05, 0.1, 0.3, 0.05)]
+    ops = []
+    t = 1
+    for rep in range(3):
+        for si, (img, verts, norms) in enumerate(scenes):
+            im = np.clip(img.astype(np.int32) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8) if rep else img
+            pose = np.eye(4, dtype=np.float32); pose[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+            if rep:   # a lookup first (as inside a frame), then the admission test
+                dp = rng.uniform(-0.01, 0.01, 3).astype(np.float32)
+                diag = np.zeros(8, np.float32)
+                diag[0] = [1e-4, 1e-4, 5e-4, 1e-4][si] if rep == 1 else 1e-4       # lastICPError: one failing the gate
+                diag[1] = [3000, 2000, 3000, 3000][si] if rep == 1 else 3000        # lastICPCount: one failing the gate
+                ops.append(dict(kind=1, time=t, thr=0.0, pose=pose, img=im, verts=verts, norms=norms, dp=dp, diag=diag))
+            ops.append(dict(kind=0, time=t, thr=0.3095 if rep < 2 else 0.0, pose=pose, img=im, verts=verts, norms=norms))
+            t += 1
+    blank = np.zeros_like(scenes[0][1])
+    ops.append(dict(kind=0, time=t, thr=0.3, pose=np.eye(4, dtype=np.float32), img=scenes[0][0], verts=blank, norms=blank))     # no valid sample: never admitted
+    ops.append(dict(kind=1, time=t, thr=0.0, pose=np.eye(4, dtype=np.float32), img=scenes[0][0], verts=blank, norms=blank, dp=np.zeros(3, np.float32),
+                    diag=np.zeros(8, np.float32)))
+    inp, outp = str(tmp_path / "ferns.in"), str(tmp_path / "ferns.out")
+    with open(inp, "wb") as f:
+        f.write(np.array([FW, FH, NF, MAXD, SEED, GAP, len(ops)], np.int32).tobytes())
+        f.write(np.array([fx, fy, cx, cy, photo], np.float32).tobytes())
+        for o in ops:
+            f.write(np.array([o["kind"], o["time"]], np.int32).tobytes()); f.write(np.float32(o["thr"]).tobytes()); f.write(o["pose"].tobytes())
+            f.write(o["img"].tobytes()); f.write(np.zeros_like(o["img"]).tobytes()); f.write(o["verts"].tobytes()); f.write(o["norms"].tobytes())
+            if o["kind"] == 1:
+                f.write(o["dp"].tobytes()); f.write(o["diag"].tobytes())
+    subprocess.run([checker, "ferns", inp, outp], check=True)
+    blob = open(outp, "rb").read()
+    table = np.frombuffer(blob[:NF * 24], np.int32).reshape(NF, 6)
+    assert table[:, 0].min() >= 0 and table[:, 0].max() < w and table[:, 1].max() < h and table[:, 5].min() >= 400 and table[:, 5].max() <= MAXD
+    assert len(np.unique(table[:, 0])) > w // 2                     # drawn, not constant
+    ref = orc_ferns.Ferns(table, w, h, MAXD, photo, fx / 8, fy / 8, cx / 8, cy / 8, min_gap=GAP)
+    off = NF * 24
+    n_match = n_cand = n_admit = n_reject = 0
+    for o in ops:
+        if o["kind"] == 0:
+            ok, nf = np.frombuffer(blob[off:off + 8], np.int32); off += 8
+            exp = ref.add_frame(o["img"], o["verts"], o["norms"], o["pose"], o["time"], o["thr"])
+            assert bool(ok) == exp and nf == len(ref.frames)
+            n_admit += exp; n_reject += not exp
+        else:
+            cand, closest, nc = np.frombuffer(blob[off:off + 12], np.int32); off += 12
+            dissim, photo_err = np.frombuffer(blob[off:off + 8], np.float32); off += 8
+            est = np.frombuffer(blob[off:off + 64], np.float32).reshape(4, 4); off += 64
+            cons = np.frombuffer(blob[off:off + nc * 32], np.float32).reshape(nc, 2, 4); off += nc * 32
+
+            def tracker(mv, mn, cv, cn, p, o=o):
+                p[:3, 3] += o["dp"]
+                return p, o["diag"][0], o["diag"][1]
+
+            r = ref.find_frame(o["pose"], o["img"], o["verts"], o["norms"], o["time"], False, tracker)
+            assert (cand, closest, nc) == (r["candidate"], r["closest"], len(r["constraints"]))
+            assert dissim == r["dissim"] and np.array_equal(est, r["est"])
+            assert photo_err == r["photo"] or (np.isnan(photo_err) and np.isnan(r["photo"]))
+            for a, (src, dst) in zip(cons, r["constraints"]):
+                assert np.array_equal(a[0], src) and np.array_equal(a[1], dst)
+            n_cand += cand != -1; n_match += closest != -1
+    assert off == len(blob)
+    assert n_admit >= 4 and n_reject >= 3 and n_cand >= 6 and 2 <= n_match < n_cand      # every branch was taken
+
+
+@pytest.mark.gpu
+def test_fern_database_inside_frames(checker, tmp_path):
+    """The C++ data base driven by real frames (640 x 480, fern resolution 80 x 60): the camera goes forth and back, a keyframe of the way out is found on
+    the way back (findFrame inside the frame: read-back of the tracked-pose prediction, ifx_track_maps on a handle of fern resolution, photometric check,
+    gates), the handler's graph is applied as a fern deformation and the recovery pose is adopted.  The time gap of EF/Ferns.cpp:238 is shortened."""
+    from instancefusion_amd import logio, synth
+
+    W, H, K = 640, 480, dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    # no depth noise: the first keyframe is taken before anything is stable, i.e. from the fill-in of the raw frame, whose normals are forward differences
+    st = synth.make_stream(7, W, H, K["fx"], K["fy"], K["cx"], K["cy"], noise=False)
+    src = [0, 1, 2, 3, 4, 5, 6, 5, 4, 3, 2, 1, 0, 1, 2]
+    klg = str(tmp_path / "v.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="raw")
+    for i, s in enumerate(src + [0]):
+        wr.add(33333 * i, st["rgb"][s], st["depth"][s])
+    wr.close()
+    r = subprocess.run([checker, "fernrun", klg, str(W), str(H), str(K["fx"]), str(K["fy"]), str(K["cx"]), str(K["cy"]), "5", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = []
+    for l in r.stdout.splitlines():
+        if l.startswith("tick"):
+            t = l.split()
+            i = t.index("pos")
+            d = dict(zip(t[0:i:2], t[1:i:2]))
+            d["pos"] = np.array([float(v) for v in t[i + 1:i + 4]]); d["surfels"] = int(t[i + 5])
+            rows.append(d)
+    assert len(rows) == len(src)
+    assert int(rows[0]["keyframes"]) == 1 and int(rows[5]["candidate"]) == -1          # the first frame is always a keyframe; nothing is old enough yet
+    hit = [q for q in rows if int(q["closest"]) != -1]
+    assert hit, r.stdout
+    q = hit[0]
+    assert float(q["icpErr"]) < 3e-4 and float(q["icpCount"]) > 2400 and float(q["photo"]) < 115      # the gates of :644
+    assert float(q["shift"]) < 0.03                                                                    # estPose * v against currPose * v: the same place
+    assert int(rows[-1]["matches"]) >= 1 and int(rows[-1]["deforms"]) >= 1
+    # the trajectory stays the trajectory (ground truth: forth and back to the start)
+    assert np.abs(rows[12]["pos"] - rows[0]["pos"]).max() < 0.03 and rows[-1]["surfels"] > 100000

@@ -137,8 +137,8 @@ int ifx_loop_closure_constraints(ifx_t* h, float* src3, float* dst3, int32_t* ti
 int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern);
 int ifx_adopt_estimated_pose(ifx_t* h);
 
-/* ---- the GPU contacts of the fern data base (EF/Ferns.cpp; codes, similarity search and keyframe store are host code of the reference and stay with
- * the caller, like the graph optimiser).
+/* ---- the GPU contacts of the fern data base (EF/Ferns.cpp; codes, similarity search and keyframe store are host code in the reference and here:
+ * instancefusion_amd/host/ifx_ferns.hpp is that class over the entry points below).
  * ifx_fern_frame: the four Resize passes of Ferns::addFrame / findFrame (:95-98, :192-195): fill-in image / vertex / normal and the instance render of the
  *   last predict(), resampled to (w/8) x (h/8) and read back (rgb: 3 bytes, maps: float4 per sample); returns the number of samples.
  * ifx_track_maps: the texture-initialised tracker as a stage -- initICPModel / initRGBModel(model maps, given in the frame of pose16) + initICP(vertices,

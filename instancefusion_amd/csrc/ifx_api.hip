@@ -370,8 +370,8 @@ static int enqueue_loop_closure_tracker(ifx* h)
 }
 
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)
-// the local detection is implemented (ifx_set_loop_closure); ferns and the deformation graph are out of scope, and
-// without the detection the first predict() of :453, whose only consumers are those stages, is not executed.
+// the local detection is implemented (ifx_set_loop_closure), the fern lookup and both deformations run in the caller's callbacks (the graph
+// optimiser is host code of the reference); without the detection the first predict() of :453, whose only consumers are those stages, is not executed.
 static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult)
 {
     const int s = h->tick & 1;

@@ -781,9 +781,10 @@ int orc_fern_frame(orc_t* o, uint8_t* img_rgb, float* verts4, float* norms4, uin
     return rw * rh;
 }
 
-/* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Of the loop-closure block (:450-617) only the local detection
- * is restated (loop_closure_local, when enabled); ferns and the deformation graph are out of scope, and without
- * the detection the predict() of :453, whose only consumers are those stages, is not executed. */
+/* ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720.  Of the loop-closure block (:450-617) the local detection is
+ * restated (loop_closure_local, when enabled) with the two places where the caller's host code runs (fern lookup, deformation:
+ * orc_set_fern_callback / orc_set_loop_closure_callback; the fern data base itself is restated in orc_ferns.py); without the
+ * detection the predict() of :453, whose only consumers are those stages, is not executed. */
 int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64_t ts,
                       const float* in_pose16, float weight_mult, float* out_pose16)
 {

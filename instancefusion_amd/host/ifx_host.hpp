@@ -53,6 +53,7 @@ struct Matrix4f {   // row-major camera-to-world pose; stands in for Eigen::Matr
     float* data() { return m; }
 };
 
+#include "ifx_deformation.hpp"
 #include "ifx_ferns.hpp"
 typedef FernsT<Matrix4f> Ferns;   // EF/Ferns.h
 
@@ -162,6 +163,11 @@ public:
             throw std::runtime_error("ifx_set_loop_closure: " + e);
         }
         if (closeLoops) {
+            if (ifx_set_loop_closure_callback(h_, &ElasticFusion::lcTrampoline, this) != IFX_OK) {
+                const std::string e = ifx_last_error(h_);
+                ifx_destroy(h_);
+                throw std::runtime_error("ifx_set_loop_closure_callback: " + e);
+            }
             ferns_.reset(new Ferns(500, (int)(depthCut * 1000), photoThresh, cfg_.width, cfg_.height, cfg_.fx, cfg_.fy, cfg_.cx, cfg_.cy, device));
             if (ifx_set_fern_callback(h_, &ElasticFusion::fernTrampoline, this) != IFX_OK) {
                 const std::string e = ifx_last_error(h_);
@@ -217,11 +223,16 @@ public:
     const int& getTimeDelta() { return cfg_.time_delta; }
     const float& getConfidenceThreshold() { return cfg_.confidence; }
     const float& getMaxDepthProcessed() { return cfg_.max_depth_processed; }
-    const int& getDeforms() { return deforms_; }                  // graphs handed to setDeformation (0 unless a handler deforms the map)
+    const int& getDeforms() { return deforms_; }                  // local deformations applied (EF/ElasticFusion.h:99)
     // frames whose local loop-closure candidate passed the reference's gates (each would have deformed the map in the reference);
     // 0 at the end of a run = the trajectory and map are what the reference computes with closeLoops and an empty fern data base
     const int& getLoopClosureCandidates() { return loopCandidates_; }
-    const int& getFernDeforms() { return deforms_; }
+    const int& getFernDeforms() { return fernDeforms_; }          // global (fern) deformations applied
+    // closeLoops deforms the map on an accepted loop closure, as the reference does (localDeformation / globalDeformation, ifx_deformation.hpp); switched
+    // off, loop closures are only detected and counted, and every frame is tracked and fused as if none had fired
+    void setDeformOnLoopClosure(bool on) { deformOnLoopClosure_ = on; }
+    Deformation& getLocalDeformation() { return localDeformation_; }
+    Deformation& getGlobalDeformation() { return globalDeformation_; }
     bool getCloseLoops() const { return closeLoops_; }
     int getCountThresh() const { return countThresh_; }
     float getErrThresh() const { return errThresh_; }
@@ -270,8 +281,8 @@ public:
 
     void setLoopClosureHandler(std::function<void(ElasticFusion&, const LoopClosureCandidate&)> fn)
     {
-        lcHandler_ = std::move(fn);
-        if (ifx_set_loop_closure_callback(h_, lcHandler_ ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK) throw std::runtime_error(ifx_last_error(h_));
+        lcHandler_ = std::move(fn);   // replaces the built-in handler (defaultLoopClosure); an empty function restores it
+        if (ifx_set_loop_closure_callback(h_, (lcHandler_ || closeLoops_) ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK) throw std::runtime_error(ifx_last_error(h_));
     }
     std::vector<float> sampleGraphModel()   // x, y, z, init time of every 5000th surfel (Deformation::sampleGraphModel)
     {
@@ -295,7 +306,7 @@ public:
     {
         if (ifx_set_deformation(h_, rawGraph.data(), (int)(rawGraph.size() / 16), isFern ? 1 : 0) != IFX_OK)
             throw std::runtime_error(std::string("ifx_set_deformation: ") + ifx_last_error(h_));
-        deforms_ += !rawGraph.empty();
+        (isFern ? fernDeforms_ : deforms_) += !rawGraph.empty();
     }
     void adoptEstimatedPose()
     {
@@ -407,6 +418,7 @@ private:
         std::memcpy(c.estPose.data(), lc + 6, 64);
         try {
             if (self->lcHandler_) self->lcHandler_(*self, c);
+            else if (self->deformOnLoopClosure_) self->defaultLoopClosure();
         } catch (const std::exception& e) {   // never unwind through the C frames of libifx.so
             std::fprintf(stderr, "loop-closure handler: %s\n", e.what());
             return IFX_E_STATE;
@@ -425,8 +437,10 @@ private:
             const Matrix4f recoveryPose = self->ferns_->findFrame(constraints, tracked, h, self->smallInstanceTable_, self->tick_, self->lost_);
             if (self->ferns_->lastClosest == -1) return 0;
             self->fernMatches_++;
-            if (!self->fernHandler_) return 0;
-            const std::vector<float> rawGraph = self->fernHandler_(*self, constraints, recoveryPose, self->ferns_->frames[self->ferns_->lastClosest]->srcTime);
+            const int fernSrcTime = self->ferns_->frames[self->ferns_->lastClosest]->srcTime;
+            if (!self->fernHandler_ && !self->deformOnLoopClosure_) return 0;
+            const std::vector<float> rawGraph = self->fernHandler_ ? self->fernHandler_(*self, constraints, recoveryPose, fernSrcTime)
+                                                                   : self->defaultFernClosure(constraints, fernSrcTime);
             if (rawGraph.empty()) return 0;
             self->setDeformation(rawGraph, true);
             self->adoptPose(recoveryPose);
@@ -436,6 +450,51 @@ private:
             return IFX_E_STATE;
         }
     }
+    // ---- what the reference does on an accepted loop closure, with its own optimiser (ifx_deformation.hpp)
+    std::vector<Deformation::TimedPose> fernPoses()
+    {
+        std::vector<Deformation::TimedPose> v;
+        if (ferns_)
+            for (auto& f : ferns_->frames) v.push_back({(uint64_t)f->srcTime, f->pose.data()});
+        return v;
+    }
+    void sampleGraphs()   // EF/ElasticFusion.cpp:704-708 at the end of the previous frame = the map as this frame found it
+    {
+        localDeformation_.sampleGraphModel(sampleGraphModel());
+        globalDeformation_.sampleGraphFrom(localDeformation_);
+    }
+    // local loop closure, EF/ElasticFusion.cpp:566-613
+    void defaultLoopClosure()
+    {
+        const Constraints c = loopClosureConstraints();
+        sampleGraphs();
+        for (size_t i = 0; i < c.times.size(); i++) localDeformation_.addConstraint(&c.src[i * 3], &c.dst[i * 3], (uint64_t)tick_, (uint64_t)c.times[i], deforms_ == 0);
+        std::vector<Deformation::TimedPose> fp = fernPoses(), none;
+        std::vector<float> rawGraph;
+        std::vector<Deformation::Constraint> newRelativeCons;
+        if (localDeformation_.constrain(fp, rawGraph, tick_, false, none, false, &newRelativeCons)) {
+            if (!rawGraph.empty()) setDeformation(rawGraph, false);
+            adoptEstimatedPose();
+            const size_t step = std::max<size_t>(newRelativeCons.size() / 3, 1);
+            for (size_t i = 0; i < newRelativeCons.size(); i += step) relativeCons_.push_back(newRelativeCons[i]);
+        }
+    }
+    // global loop closure, EF/ElasticFusion.cpp:486-512; an empty graph = refused
+    std::vector<float> defaultFernClosure(const std::vector<Ferns::SurfaceConstraint>& constraints, int fernSrcTime)
+    {
+        sampleGraphs();
+        for (const auto& c : constraints) globalDeformation_.addConstraint(c.sourcePoint, c.targetPoint, (uint64_t)tick_, (uint64_t)fernSrcTime, true);
+        for (const auto& rc : relativeCons_) globalDeformation_.addConstraint(rc);
+        std::vector<Deformation::TimedPose> fp = fernPoses(), pg;
+        for (size_t i = 0; i < poseGraph_.size(); i++) pg.push_back({(uint64_t)(i + 1), poseGraph_[i].data()});
+        std::vector<float> rawGraph;
+        if (!globalDeformation_.constrain(fp, rawGraph, tick_, true, pg, true)) rawGraph.clear();
+        return rawGraph;
+    }
+    Deformation localDeformation_, globalDeformation_;
+    std::vector<Deformation::Constraint> relativeCons_;
+    bool deformOnLoopClosure_ = true;
+    int fernDeforms_ = 0;
     std::unique_ptr<Ferns> ferns_;
     FernHandler fernHandler_;
     int fernMatches_ = 0;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "ifx_host.hpp"
+#include "ifx_deformation.hpp"
 
 int main(int argc, char** argv)
 {
@@ -98,15 +99,15 @@ int main(int argc, char** argv)
             }
             return 0;
         }
-        if (mode == "fernrun") {   // fernrun KLG W H FX FY CX CY GAP CONFIDENCE (GPU): the data base inside real frames, with a rigid stand-in for the graph optimiser
+        if (mode == "fernrun") {   // fernrun KLG W H FX FY CX CY GAP CONFIDENCE rigid|builtin TIMEDELTA (GPU): the data base inside real frames, with a rigid stand-in for the graph optimiser
             Resolution::getInstance(std::atoi(argv[3]), std::atoi(argv[4]));
             Intrinsics::getInstance((float)std::atof(argv[5]), (float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8]));
             RawLogReader log(argv[2], false);
-            ElasticFusion ef(200, 35000, 5e-05, 1e-05, true, false, false, 115, (float)std::atof(argv[10]), 12, 10, false, 0.3095, true, false, "", 2000000, 0);
+            ElasticFusion ef(std::atoi(argv[12]), 35000, 5e-05, 1e-05, true, false, false, 115, (float)std::atof(argv[10]), 12, 10, false, 0.3095, true, false, "", 2000000, 0);
             ef.resetFerns(12345u);
             ef.ferns()->minTimeGap = std::atoi(argv[9]);
             float lastShift = 0;
-            ef.setFernHandler([&](ElasticFusion& e, const std::vector<Ferns::SurfaceConstraint>& cons, const Matrix4f& recovery, int srcTime) {
+            if (std::string(argv[11]) == "rigid") ef.setFernHandler([&](ElasticFusion& e, const std::vector<Ferns::SurfaceConstraint>& cons, const Matrix4f& recovery, int srcTime) {
                 (void)recovery; (void)srcTime;
                 std::vector<float> nodes = e.sampleGraphModel(), g;
                 float mean[3] = {0, 0, 0};
@@ -126,10 +127,53 @@ int main(int argc, char** argv)
                 ef.processFrame(log.rgb, log.depth, log.timestamp, table);
                 const Ferns& f = *ef.ferns();
                 const Matrix4f& P = ef.getCurrPose();
-                std::printf("tick %d keyframes %d candidate %d closest %d icpErr %g icpCount %g photo %g matches %d deforms %d shift %g pos %.6f %.6f %.6f surfels %d\n",
+                std::printf("tick %d keyframes %d candidate %d closest %d icpErr %g icpCount %g photo %g matches %d deforms %d shift %g local %d lccand %d consErr %g pos %.6f %.6f %.6f surfels %d\n",
                             ef.getTick() - 1, (int)f.frames.size(), f.lastCandidate, f.lastClosest, f.lastICPError, f.lastICPCount, f.lastPhotoError, ef.getFernMatches(),
-                            ef.getFernDeforms(), lastShift, P(0, 3), P(1, 3), P(2, 3), ef.getMapSurfelCount());
+                            ef.getFernDeforms(), lastShift, ef.getDeforms(), ef.getLoopClosureCandidates(), ef.getLocalDeformation().lastMeanConsError, P(0, 3), P(1, 3), P(2, 3),
+                            ef.getMapSurfelCount());
             }
+            return 0;
+        }
+        if (mode == "deform") {   // deform IN OUT: Deformation::constrain on given nodes, constraints and poses (no GPU)
+            std::ifstream in(argv[2], std::ios::binary);
+            std::ofstream f(argv[3], std::ios::binary);
+            int32_t hd[7];   // nodes, constraints, poses, fernMatch, relaxGraph, lastDeformTime, time
+            in.read((char*)hd, sizeof(hd));
+            std::vector<float> xyzt((size_t)hd[0] * 4);
+            in.read((char*)xyzt.data(), (std::streamsize)xyzt.size() * 4);
+            Deformation d;
+            d.sampleGraphModel(xyzt);
+            d.lastDeformTime = (uint64_t)hd[5];
+            for (int i = 0; i < hd[1]; i++) {
+                float st[6];
+                int32_t q[4];
+                in.read((char*)st, 24); in.read((char*)q, 16);
+                if (q[2]) {
+                    Deformation::Constraint c;
+                    std::memcpy(c.src, st, 12); std::memcpy(c.target, st + 3, 12);
+                    c.srcTime = (uint64_t)q[0]; c.targetTime = (uint64_t)q[1]; c.relative = true; c.pin = false; c.srcPointPoolId = c.tarPointPoolId = -1;
+                    d.addConstraint(c);
+                } else d.addConstraint(st, st + 3, (uint64_t)q[0], (uint64_t)q[1], q[3] != 0);
+            }
+            std::vector<Matrix4f> poses((size_t)hd[2]);
+            std::vector<Deformation::TimedPose> tp, none;
+            for (int i = 0; i < hd[2]; i++) {
+                int32_t t;
+                in.read((char*)&t, 4); in.read((char*)poses[i].data(), 64);
+                tp.push_back({(uint64_t)t, poses[i].data()});
+            }
+            std::vector<float> rawGraph;
+            std::vector<Deformation::Constraint> rel;
+            const int32_t ok = d.constrain(tp, rawGraph, hd[6], hd[3] != 0, none, hd[4] != 0, &rel) ? 1 : 0;
+            const float e[2] = {d.lastError, d.lastMeanConsError};
+            const int32_t ng = (int32_t)rawGraph.size(), nr = (int32_t)rel.size();
+            f.write((const char*)&ok, 4); f.write((const char*)e, 8); f.write((const char*)&ng, 4);
+            f.write((const char*)rawGraph.data(), (std::streamsize)ng * 4);
+            for (auto& P : poses) f.write((const char*)P.data(), 64);
+            f.write((const char*)&nr, 4);
+            for (auto& c : rel) { f.write((const char*)c.src, 12); f.write((const char*)c.target, 12); }
+            const int32_t ldt = (int32_t)d.lastDeformTime;
+            f.write((const char*)&ldt, 4);
             return 0;
         }
         if (mode == "quat") {

@@ -400,16 +400,21 @@ def test_fern_database_inside_frames(checker, tmp_path):
     for i, s in enumerate(src + [0]):
         wr.add(33333 * i, st["rgb"][s], st["depth"][s])
     wr.close()
-    r = subprocess.run([checker, "fernrun", klg, str(W), str(H), str(K["fx"]), str(K["fy"]), str(K["cx"]), str(K["cy"]), "5", "2"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    rows = []
-    for l in r.stdout.splitlines():
-        if l.startswith("tick"):
-            t = l.split()
-            i = t.index("pos")
-            d = dict(zip(t[0:i:2], t[1:i:2]))
-            d["pos"] = np.array([float(v) for v in t[i + 1:i + 4]]); d["surfels"] = int(t[i + 5])
-            rows.append(d)
+    def run(handler, time_delta):
+        r = subprocess.run([checker, "fernrun", klg, str(W), str(H), str(K["fx"]), str(K["fy"]), str(K["cx"]), str(K["cy"]), "5", "2", handler, str(time_delta)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        rows = []
+        for l in r.stdout.splitlines():
+            if l.startswith("tick"):
+                t = l.split()
+                i = t.index("pos")
+                d = dict(zip(t[0:i:2], t[1:i:2]))
+                d["pos"] = np.array([float(v) for v in t[i + 1:i + 4]]); d["surfels"] = int(t[i + 5])
+                rows.append(d)
+        return r, rows
+
+    r, rows = run("rigid", 200)
     assert len(rows) == len(src)
     assert int(rows[0]["keyframes"]) == 1 and int(rows[5]["candidate"]) == -1          # the first frame is always a keyframe; nothing is old enough yet
     hit = [q for q in rows if int(q["closest"]) != -1]
@@ -420,3 +425,111 @@ def test_fern_database_inside_frames(checker, tmp_path):
     assert int(rows[-1]["matches"]) >= 1 and int(rows[-1]["deforms"]) >= 1
     # the trajectory stays the trajectory (ground truth: forth and back to the start)
     assert np.abs(rows[12]["pos"] - rows[0]["pos"]).max() < 0.03 and rows[-1]["surfels"] > 100000
+    # the reference's own optimiser (ifx_deformation.hpp) in the same place: the keyframe is found again, but the map already agrees with it (mean constraint
+    # error < 6 cm), so the global deformation is refused (DeformationGraph.cpp:469) and the frames are those of a run without loop closures
+    r2, rows2 = run("builtin", 200)
+    assert int(rows2[-1]["matches"]) >= 1 and int(rows2[-1]["deforms"]) == 0 and int(rows2[-1]["local"]) == 0
+    # ... and with a short time window (surfels count as old after 3 frames) local loop closures fire and are optimised and applied inside the frames
+    r3, rows3 = run("builtin", 3)
+    assert int(rows3[-1]["lccand"]) >= 1 and int(rows3[-1]["local"]) >= 1, r3.stdout
+    assert float([q for q in rows3 if int(q["local"]) >= 1][0]["consErr"]) < 0.01
+    assert np.abs(rows3[12]["pos"] - rows3[0]["pos"]).max() < 0.03 and rows3[-1]["surfels"] > 100000
+
+
+# ---------------------------------------------------------------- the deformation-graph optimiser (ifx_deformation.hpp) against oracle/orc_deformation.py, no GPU
+def _deform_case(seed, n_nodes, fern_match, with_relative, last_deform_time, shift, noise=0.002):
+    rng = np.random.default_rng(seed)
+    # nodes: a walk through space, one node every few "frames" (times sorted, as the map order guarantees)
+    steps = rng.normal(0, 0.12, (n_nodes, 3)).cumsum(axis=0)
+    times = np.sort(rng.integers(1, 600, n_nodes))
+    xyzt = np.concatenate([steps, times[:, None]], axis=1).astype(np.float32)
+    cons = []
+    late = np.nonzero(times > times[-1] - 80)[0]
+    for _ in range(20):                                        # the recent part of the map is pulled onto where the old model says it should be
+        j = rng.choice(late)
+        src = xyzt[j, :3] + rng.normal(0, 0.05, 3).astype(np.float32)
+        tgt = (src + np.asarray(shift, np.float32) + rng.normal(0, 1.0, 3) * noise).astype(np.float32)
+        cons.append(dict(src=src, target=tgt, src_time=int(times[j]), target_time=int(times[rng.integers(0, 5)]), relative=False, pin=fern_match))
+    if with_relative:                                          # constraints of an earlier closure: two parts of the map stay together
+        for _ in range(6):
+            a, b = rng.integers(0, n_nodes // 3), rng.integers(n_nodes // 2, n_nodes)
+            p = xyzt[a, :3] + rng.normal(0, 0.03, 3).astype(np.float32)
+            cons.append(dict(src=p.astype(np.float32), target=(p + rng.normal(0, 0.004, 3)).astype(np.float32), src_time=int(times[a]), target_time=int(times[b]),
+                             relative=True, pin=False))
+    poses = []
+    for j in rng.choice(n_nodes, 6, replace=False):
+        P = np.eye(4, dtype=np.float32)
+        a = rng.normal(0, 0.3, 3)
+        Rz = np.array([[np.cos(a[0]), -np.sin(a[0]), 0], [np.sin(a[0]), np.cos(a[0]), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        P[:3, :3] = (Rz @ Ry).astype(np.float32); P[:3, 3] = xyzt[j, :3] + rng.normal(0, 0.05, 3).astype(np.float32)
+        poses.append((int(times[j]), P))
+    return xyzt, cons, poses
+
+
+@pytest.mark.parametrize("case", [dict(seed=1, n=40, fern=False, rel=False, ldt=0, shift=(0.05, -0.03, 0.02)),
+                                  dict(seed=2, n=120, fern=False, rel=True, ldt=0, shift=(0.08, 0.02, -0.04)),
+                                  dict(seed=3, n=60, fern=False, rel=False, ldt=300, shift=(0.04, 0.04, 0.0)),      # nodes before the last deformation stay fixed
+                                  dict(seed=4, n=80, fern=True, rel=False, ldt=300, shift=(0.12, -0.07, 0.04), noise=0.0),   # a fern match re-opens the whole graph
+                                  dict(seed=4, n=80, fern=True, rel=True, ldt=300, shift=(0.12, -0.07, 0.04), noise=0.0),    # optimised, then refused by the gates of :166
+                                  dict(seed=5, n=30, fern=True, rel=False, ldt=0, shift=(0.01, 0.0, 0.0))])         # mean constraint error < 0.06: refused before optimising
+def test_deformation_optimiser_equals_dense_restatement(checker, tmp_path, case):
+    """Deformation::constrain (EF/Deformation.cpp:89-220): vertex weights, Gauss-Newton on the embedded deformation graph with the reference's energy,
+    stopping rules and acceptance gates, the graph applied to poses and constraint points -- C++ (skyline Cholesky, f32 state as in the reference) against
+    a dense f64 numpy restatement."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc_deformation
+
+    xyzt, cons, poses = _deform_case(case["seed"], case["n"], case["fern"], case["rel"], case["ldt"], case["shift"], case.get("noise", 0.002))
+    # (constraint order of Deformation::addConstraint: a pinned constraint is followed by its pin target -> target)
+    flat = []
+    for c in cons:
+        flat.append(c)
+        if c["pin"] and not c["relative"]:
+            flat.append(dict(src=c["target"], target=c["target"], src_time=c["target_time"], target_time=c["target_time"], relative=False, pin=True))
+            flat[-2] = dict(c, pin=False)
+    inp, outp = str(tmp_path / "d.in"), str(tmp_path / "d.out")
+    with open(inp, "wb") as f:
+        f.write(np.array([len(xyzt), len(cons), len(poses), int(case["fern"]), 0, case["ldt"], 700], np.int32).tobytes())
+        f.write(xyzt.tobytes())
+        for c in cons:
+            f.write(np.asarray(c["src"], np.float32).tobytes()); f.write(np.asarray(c["target"], np.float32).tobytes())
+            f.write(np.array([c["src_time"], c["target_time"], int(c["relative"]), int(c["pin"])], np.int32).tobytes())
+        for t, P in poses:
+            f.write(np.int32(t).tobytes()); f.write(P.tobytes())
+    subprocess.run([checker, "deform", inp, outp], check=True)
+    b = open(outp, "rb").read()
+    ok = int(np.frombuffer(b[:4], np.int32)[0]); err, mc = np.frombuffer(b[4:12], np.float32); ng = int(np.frombuffer(b[12:16], np.int32)[0])
+    off = 16
+    raw = np.frombuffer(b[off:off + ng * 4], np.float32).reshape(-1, 16); off += ng * 4
+    P_out = np.frombuffer(b[off:off + len(poses) * 64], np.float32).reshape(-1, 4, 4); off += len(poses) * 64
+    nr = int(np.frombuffer(b[off:off + 4], np.int32)[0]); off += 4
+    rel = np.frombuffer(b[off:off + nr * 24], np.float32).reshape(nr, 2, 3); off += nr * 24
+    ldt_out = int(np.frombuffer(b[off:off + 4], np.int32)[0])
+    ref = orc_deformation.constrain(xyzt, flat, [P.copy() for _, P in poses], [t for t, _ in poses], case["fern"], False, case["ldt"])
+    assert bool(ok) == ref["ok"]
+    assert abs(mc - ref["mean_cons"]) < 2e-5
+    assert abs(err - ref["error"]) < 1e-4 * max(1.0, ref["error"])
+    assert ref["ok"] == (not case["fern"] or (not case["rel"] and case["seed"] == 4))              # the case exercises the branch it was built for
+    if not ref["ok"]:
+        assert ng == 0 and nr == 0 and np.array_equal(P_out, np.array([P for _, P in poses]))      # refused: nothing moves
+        assert (ref["error"] > 0) == (case["seed"] == 4)
+        return
+    assert raw.shape == ref["raw_graph"].shape and np.abs(raw - ref["raw_graph"]).max() < 2e-4
+    assert np.abs(P_out - np.array(ref["poses"])).max() < 2e-4
+    for P in P_out:
+        assert np.abs(P[:3, :3] @ P[:3, :3].T - np.eye(3)).max() < 1e-5                        # re-orthonormalised
+    assert np.abs(raw[:, 12:15]).max() > 0.02                                                   # the graph did move
+    if case["ldt"] and not case["fern"]:
+        old = xyzt[:, 3] <= case["ldt"]
+        assert old.any() and np.array_equal(raw[old, 3:12], np.tile(np.eye(3, dtype=np.float32).reshape(9), (old.sum(), 1))) and not raw[old, 12:15].any()
+    if not case["fern"]:
+        assert nr == len(ref["new_rel"]) == 20 and ldt_out == 700
+        for a, (s_, t_, _, _) in zip(rel, ref["new_rel"]):
+            assert np.abs(a[0] - s_).max() < 2e-4 and np.abs(a[1] - t_).max() < 1e-6
+        moved_err = np.linalg.norm(rel[:, 0] - rel[:, 1], axis=1).mean()
+        assert moved_err < 0.01                                                                  # the constraint points arrived (they started ~6-9 cm away)
+    else:
+        assert nr == 0 and ldt_out == case["ldt"]

@@ -21,7 +21,7 @@ struct Args {
     std::string log, masks, out = "./ResultModel", labels, gt_dir, eval_file;
     int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
     float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
-    bool superpixels = true, flip = false, close_loops = true;
+    bool superpixels = true, flip = false, close_loops = true, deform = true;
     float confidence = 10.f;
 };
 
@@ -29,7 +29,7 @@ int usage(const char* argv0)
 {
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
-                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--confidence C]\n"
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--confidence C]\n"
                  "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n",
                  argv0);
     return 2;
@@ -62,6 +62,7 @@ int main(int argc, char** argv)
         else if (s == "--device") a.device = std::atoi(val("--device"));
         else if (s == "--no-superpixels") a.superpixels = false;
         else if (s == "--no-close-loops") a.close_loops = false;
+        else if (s == "--detect-only") a.deform = false;   // loop closures are found and counted, the map is never deformed
         else if (s == "--confidence") a.confidence = (float)std::atof(val("--confidence"));
         else if (s == "--flip-colors") a.flip = true;
         else if (s == "--help" || s == "-h") { usage(argv[0]); return 0; }
@@ -88,6 +89,7 @@ int main(int argc, char** argv)
             return 1;
         }
         instancefusion->bindMap(map);
+        if (!a.deform) map->elasticFusion().setDeformOnLoopClosure(false);
 
         int frame_Fusion = 0, lastTimeFlann = -1;
         std::vector<int> instanceTableLoopClosure((size_t)instancefusion->getInstanceNum() * 5);
@@ -135,10 +137,11 @@ int main(int argc, char** argv)
         if (!a.eval_file.empty()) instancefusion->evaluateAndSave(map, a.log, a.eval_file);   // IF/main.cpp:340
         const Matrix4f P = map->getCurrPose();
         std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
-                    "last position %.6f %.6f %.6f, %d local loop-closure candidates, %d fern keyframes, %d fern matches\n",
+                    "last position %.6f %.6f %.6f, %d local loop-closure candidates, %d fern keyframes, %d fern matches, %d local / %d global deformations\n",
                     frame_Fusion, dt, frame_Fusion / (dt > 0 ? dt : 1), instancefusion->segmentationCalls(), map->getMapSurfelCount(), n_geo, a.out.c_str(), n_ins,
                     P(0, 3), P(1, 3), P(2, 3), map->elasticFusion().getLoopClosureCandidates(),
-                    map->elasticFusion().ferns() ? (int)map->elasticFusion().ferns()->frames.size() : 0, map->elasticFusion().getFernMatches());
+                    map->elasticFusion().ferns() ? (int)map->elasticFusion().ferns()->frames.size() : 0, map->elasticFusion().getFernMatches(),
+                    map->elasticFusion().getDeforms(), map->elasticFusion().getFernDeforms());
         map.reset();   // ~ElasticFusion writes PREFIX.freiburg
     } catch (const std::exception& e) {
         std::fprintf(stderr, "ifx_replay: %s\n", e.what());

@@ -26,10 +26,13 @@
 #include <fstream>
 #include <functional>
 #include <iomanip>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ifx_c_api.h"
@@ -928,32 +931,76 @@ public:
         int32_t n = 0;
         if (std::fread(&n, 4, 1, fp_) != 1) throw std::runtime_error(this->file + ": empty log");
         numFrames_ = n;
-        depthBuf_.resize((size_t)numPixels);
-        rgbBuf_.resize((size_t)numPixels * 3);
-        depth = depthBuf_.data();
-        rgb = rgbBuf_.data();
+        cur_.depth.resize((size_t)numPixels);
+        cur_.rgb.resize((size_t)numPixels * 3);
+        depth = cur_.depth.data();
+        rgb = cur_.rgb.data();
     }
     ~RawLogReader() override
     {
+        stopReadAhead();
         if (fp_) std::fclose(fp_);
     }
     int getNumFrames() override { return numFrames_; }
     bool hasMore() override { return currentFrame + 1 < numFrames_; }   // RawLogReader.cpp:134-137: the last frame is never delivered
     bool rewound() override { return false; }
+
+    // Decoding ahead: the records of the next `frames` frames are read and inflated / JPEG-decoded by `threads` workers while the caller processes the
+    // current one (a 640 x 480 zlib + JPEG record takes ~5 ms on one core, a frame on the GPU ~1 ms).  Same frames in the same order; getBack and
+    // fastForward fall back to the synchronous path.
+    void setReadAhead(int frames, int threads)
+    {
+        stopReadAhead();
+        if (frames <= 0 || threads <= 0) return;
+        ring_.resize((size_t)frames);
+        for (Frame& f : ring_) { f.depth.resize((size_t)numPixels); f.rgb.resize((size_t)numPixels * 3); f.state = 0; }
+        head_ = tail_ = 0;
+        nextToRead_ = currentFrame + 1;   // the value currentFrame takes when that frame is delivered
+        quit_ = false;
+        for (int i = 0; i < threads; i++) workers_.emplace_back([this] { work(); });
+    }
     void getNext() override
     {
-        filePointers_.push_back(std::ftell(fp_));
-        getCore();
+        if (workers_.empty()) {
+            filePointers_.push_back(std::ftell(fp_));
+            readRecord(cur_);
+            decode(cur_);
+            publish();
+            return;
+        }
+        fill();
+        Frame* f;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            f = &ring_[head_ % ring_.size()];
+            done_.wait(lk, [&] { return f->state >= 2; });
+        }
+        if (f->state == 3) throw std::runtime_error(f->error);
+        filePointers_.push_back(f->filePos);
+        std::swap(cur_.depth, f->depth);
+        std::swap(cur_.rgb, f->rgb);
+        cur_.timestamp = f->timestamp;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            f->state = 0;
+            head_++;
+        }
+        publish();
+        fill();   // keep the workers busy while the caller processes this frame
     }
     void getBack() override
     {
         if (filePointers_.empty()) throw std::runtime_error("RawLogReader::getBack: at the start");
+        stopReadAhead();
         std::fseek(fp_, filePointers_.back(), SEEK_SET);
         filePointers_.pop_back();
-        getCore();
+        readRecord(cur_);
+        decode(cur_);
+        publish();
     }
     void fastForward(int frame) override
     {
+        stopReadAhead();
         while (currentFrame < frame && hasMore()) {
             filePointers_.push_back(std::ftell(fp_));
             int64_t ts;
@@ -965,37 +1012,126 @@ public:
     }
 
 private:
-    void getCore()
+    struct Frame {
+        long filePos = 0;
+        int64_t timestamp = 0;
+        std::vector<unsigned char> dz, iz, jpeg;   // the record as stored; scratch of the JPEG decoder
+        std::vector<unsigned short> depth;
+        std::vector<unsigned char> rgb;
+        int state = 0;   // 0 free, 1 queued, 2 decoded, 3 failed
+        std::string error;
+    };
+    void publish()
+    {
+        depth = cur_.depth.data();
+        rgb = cur_.rgb.data();
+        timestamp = cur_.timestamp;
+        currentFrame++;
+    }
+    void readRecord(Frame& f)
     {
         int32_t ds = 0, is = 0;
-        if (std::fread(&timestamp, 8, 1, fp_) != 1 || std::fread(&ds, 4, 1, fp_) != 1 || std::fread(&is, 4, 1, fp_) != 1) throw std::runtime_error(file + ": truncated frame header");
-        io_.resize((size_t)std::max(ds, is));
-        if (ds && std::fread(io_.data(), (size_t)ds, 1, fp_) != 1) throw std::runtime_error(file + ": truncated depth");
-        if (ds == numPixels * 2)
-            std::memcpy(depthBuf_.data(), io_.data(), (size_t)numPixels * 2);
+        f.filePos = std::ftell(fp_);
+        if (std::fread(&f.timestamp, 8, 1, fp_) != 1 || std::fread(&ds, 4, 1, fp_) != 1) throw std::runtime_error(file + ": truncated frame header");
+        // (the record is: timestamp, depth size, image size, depth bytes, image bytes)
+        if (std::fread(&is, 4, 1, fp_) != 1 || ds < 0 || is < 0) throw std::runtime_error(file + ": truncated frame header");
+        f.dz.resize((size_t)ds);
+        f.iz.resize((size_t)is);
+        if (ds && std::fread(f.dz.data(), (size_t)ds, 1, fp_) != 1) throw std::runtime_error(file + ": truncated depth");
+        if (is && std::fread(f.iz.data(), (size_t)is, 1, fp_) != 1) throw std::runtime_error(file + ": truncated colour");
+    }
+    void decode(Frame& f) const
+    {
+        if ((int64_t)f.dz.size() == (int64_t)numPixels * 2)
+            std::memcpy(f.depth.data(), f.dz.data(), (size_t)numPixels * 2);
         else {
             uLongf len = (uLongf)numPixels * 2;
-            if (uncompress((Bytef*)depthBuf_.data(), &len, io_.data(), (uLong)ds) != Z_OK || len != (uLongf)numPixels * 2) throw std::runtime_error(file + ": depth does not inflate to the frame size");
+            if (uncompress((Bytef*)f.depth.data(), &len, f.dz.data(), (uLong)f.dz.size()) != Z_OK || len != (uLongf)numPixels * 2)
+                throw std::runtime_error(file + ": depth does not inflate to the frame size");
         }
-        if (is && std::fread(io_.data(), (size_t)is, 1, fp_) != 1) throw std::runtime_error(file + ": truncated colour");
-        if (is == numPixels * 3)
-            std::memcpy(rgbBuf_.data(), io_.data(), (size_t)numPixels * 3);
-        else if (is > 0) {   // RawLogReader.cpp:96-106: JPEG (cvDecodeImage in the reference; libjpeg's default decompression path restated in ifx_jpeg.hpp)
+        if ((int64_t)f.iz.size() == (int64_t)numPixels * 3)
+            std::memcpy(f.rgb.data(), f.iz.data(), (size_t)numPixels * 3);
+        else if (!f.iz.empty()) {   // RawLogReader.cpp:96-106: JPEG (cvDecodeImage in the reference; libjpeg's default decompression path restated in ifx_jpeg.hpp)
             int jw = 0, jh = 0;
-            ifx_jpeg::decode(io_.data(), (size_t)is, jpegBuf_, jw, jh);
+            ifx_jpeg::decode(f.iz.data(), f.iz.size(), f.jpeg, jw, jh);
             if (jw != width || jh != height) throw std::runtime_error(file + ": JPEG frame size differs from Resolution");
-            std::memcpy(rgbBuf_.data(), jpegBuf_.data(), (size_t)numPixels * 3);
+            std::memcpy(f.rgb.data(), f.jpeg.data(), (size_t)numPixels * 3);
         } else
-            std::memset(rgbBuf_.data(), 0, (size_t)numPixels * 3);   // RawLogReader.cpp:107-110
+            std::memset(f.rgb.data(), 0, (size_t)numPixels * 3);   // RawLogReader.cpp:107-110
         if (flipColors)
-            for (int i = 0; i < numPixels; i++) std::swap(rgbBuf_[(size_t)i * 3], rgbBuf_[(size_t)i * 3 + 2]);
-        currentFrame++;
+            for (int i = 0; i < numPixels; i++) std::swap(f.rgb[(size_t)i * 3], f.rgb[(size_t)i * 3 + 2]);
+    }
+    // reads the records of the frames to come into free ring slots (the consumer thread does the file I/O, the workers the decoding)
+    void fill()
+    {
+        while (nextToRead_ < numFrames_) {   // frames 1 .. numFrames - 1 are delivered (hasMore)
+            Frame* f;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (tail_ - head_ >= ring_.size()) return;
+                f = &ring_[tail_ % ring_.size()];
+            }
+            readRecord(*f);
+            nextToRead_++;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                f->state = 1;
+                tail_++;
+            }
+            work_.notify_one();
+        }
+    }
+    void work()
+    {
+        for (;;) {
+            Frame* f = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                work_.wait(lk, [&] { return quit_ || next_ < tail_; });
+                if (quit_) return;
+                f = &ring_[next_ % ring_.size()];
+                next_++;
+            }
+            int st = 2;
+            try {
+                decode(*f);
+            } catch (const std::exception& e) {
+                f->error = e.what();
+                st = 3;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                f->state = st;
+            }
+            done_.notify_all();
+        }
+    }
+    // ends the read-ahead and puts the file position behind the last frame the caller has seen
+    void stopReadAhead()
+    {
+        if (workers_.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        work_.notify_all();
+        for (std::thread& t : workers_) t.join();
+        workers_.clear();
+        if (tail_ > head_) std::fseek(fp_, ring_[head_ % ring_.size()].filePos, SEEK_SET);
+        ring_.clear();
+        head_ = tail_ = next_ = 0;
     }
     std::FILE* fp_ = nullptr;
     int numFrames_ = 0;
     std::vector<long> filePointers_;
-    std::vector<unsigned short> depthBuf_;
-    std::vector<unsigned char> rgbBuf_, io_, jpegBuf_;
+    Frame cur_;
+    std::vector<Frame> ring_;
+    size_t head_ = 0, tail_ = 0, next_ = 0;   // consumed / read / handed to a worker
+    int nextToRead_ = 0;
+    bool quit_ = false;
+    std::mutex mu_;
+    std::condition_variable work_, done_;
+    std::vector<std::thread> workers_;
 };
 
 namespace ifx_detail {

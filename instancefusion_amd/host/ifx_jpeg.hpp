@@ -360,20 +360,26 @@ inline void decode(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, 
             throw std::runtime_error("JPEG: 1x2 chroma sampling is not supported");
     }
     // ---- YCbCr -> RGB (jdcolor.c build_ycc_rgb_table / ycc_rgb_convert)
-    static int cr_r[256], cb_b[256];
-    static long cr_g[256], cb_g[256];
-    static bool tables = false;
-    if (!tables) {
-        const long ONE_HALF = 1L << 15;
-        for (int i = 0; i < 256; i++) {
-            const long x = i - 128;
-            cr_r[i] = (int)((91881L * x + ONE_HALF) >> 16);      // FIX(1.40200)
-            cb_b[i] = (int)((116130L * x + ONE_HALF) >> 16);     // FIX(1.77200)
-            cr_g[i] = -46802L * x;                               // FIX(0.71414)
-            cb_g[i] = -22554L * x + ONE_HALF;                    // FIX(0.34414)
+    struct YccTables {   // built once; a function-local static object is initialised thread-safely (the log reader decodes on several threads)
+        int cr_r[256], cb_b[256];
+        long cr_g[256], cb_g[256];
+        YccTables()
+        {
+            const long ONE_HALF = 1L << 15;
+            for (int i = 0; i < 256; i++) {
+                const long x = i - 128;
+                cr_r[i] = (int)((91881L * x + ONE_HALF) >> 16);      // FIX(1.40200)
+                cb_b[i] = (int)((116130L * x + ONE_HALF) >> 16);     // FIX(1.77200)
+                cr_g[i] = -46802L * x;                               // FIX(0.71414)
+                cb_g[i] = -22554L * x + ONE_HALF;                    // FIX(0.34414)
+            }
         }
-        tables = true;
-    }
+    };
+    static const YccTables T;
+    const int* cr_r = T.cr_r;
+    const int* cb_b = T.cb_b;
+    const long* cr_g = T.cr_g;
+    const long* cb_g = T.cb_g;
     const int ow = comp[1].w * hmax;
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {

@@ -22,6 +22,7 @@ struct Args {
     int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
     float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
     bool superpixels = true, flip = false, close_loops = true, deform = true;
+    int decode_threads = 4;
     float confidence = 10.f;
 };
 
@@ -29,7 +30,7 @@ int usage(const char* argv0)
 {
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
-                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--confidence C]\n"
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--decode-threads N] [--confidence C]\n"
                  "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n",
                  argv0);
     return 2;
@@ -62,6 +63,7 @@ int main(int argc, char** argv)
         else if (s == "--device") a.device = std::atoi(val("--device"));
         else if (s == "--no-superpixels") a.superpixels = false;
         else if (s == "--no-close-loops") a.close_loops = false;
+        else if (s == "--decode-threads") a.decode_threads = std::atoi(val("--decode-threads"));   // 0: records are decoded when asked for, as in the reference
         else if (s == "--detect-only") a.deform = false;   // loop closures are found and counted, the map is never deformed
         else if (s == "--confidence") a.confidence = (float)std::atof(val("--confidence"));
         else if (s == "--flip-colors") a.flip = true;
@@ -77,7 +79,11 @@ int main(int argc, char** argv)
 
         std::unique_ptr<LogReader> log_reader;                 // IF/main.cpp:60-75
         if (a.log.size() > 4 && a.log.substr(a.log.size() - 4) == ".txt") log_reader.reset(new PNGLogReader(a.log));
-        else log_reader.reset(new RawLogReader(a.log, a.flip));
+        else {
+            RawLogReader* raw = new RawLogReader(a.log, a.flip);
+            log_reader.reset(raw);
+            raw->setReadAhead(2 * a.decode_threads, a.decode_threads);   // records are inflated / JPEG-decoded ahead of the frame loop
+        }
 
         std::unique_ptr<InstanceFusion> instancefusion(new InstanceFusion(instanceNum, a.width, a.height, false, 0));
         instancefusion->setSuperpixelRefinement(a.superpixels);

@@ -16,7 +16,11 @@ int main(int argc, char** argv)
         if (mode == "klg" || mode == "png") {
             Resolution::getInstance(std::atoi(argv[3]), std::atoi(argv[4]));
             std::unique_ptr<LogReader> r;
-            if (mode == "klg") r.reset(new RawLogReader(argv[2], false));
+            if (mode == "klg") {
+                RawLogReader* raw = new RawLogReader(argv[2], false);
+                r.reset(raw);
+                if (argc > 6) raw->setReadAhead(std::atoi(argv[6]), std::atoi(argv[7]));   // klg FILE W H OUT [AHEAD THREADS]
+            }
             else r.reset(new PNGLogReader(argv[2]));
             std::ofstream f(argv[5], std::ios::binary);
             const size_t P = (size_t)Resolution::getInstance().numPixels();

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(ROOT, "instancefusion_amd")
 @pytest.fixture(scope="module")
 def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("hostcpp") / "host_readers_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", HOST,
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", HOST,
                     os.path.join(ROOT, "tests", "cpp", "host_readers_check.cpp"), "-L", LIBDIR, "-lifx", "-lz", f"-Wl,-rpath,{LIBDIR}", "-o", exe], check=True)
     return exe
 
@@ -32,19 +32,21 @@ def _frames(blob, w, h):
     return out
 
 
-@pytest.mark.parametrize("depth_mode", ["raw", "zlib"])
+@pytest.mark.parametrize("depth_mode", ["raw", "zlib", "zlib-ahead"])
 def test_raw_log_reader_equals_python(checker, tmp_path, depth_mode):
     from instancefusion_amd import logio
 
-    w, h, n = 64, 48, 5
+    ahead = depth_mode.endswith("-ahead")          # records decoded ahead by worker threads: same frames, same order
+    depth_mode = depth_mode.split("-")[0]
+    w, h, n = 64, 48, 23 if ahead else 5
     rng = np.random.default_rng(5)
     klg = str(tmp_path / "a.klg")
-    wr = logio.RawLogWriter(klg, depth=depth_mode, image="raw")
+    wr = logio.RawLogWriter(klg, depth=depth_mode, image="jpeg" if ahead else "raw")
     for k in range(n):
         wr.add(1000 * k + 7, rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 8000, (h, w), dtype=np.uint16))
     wr.close()
     out = str(tmp_path / "dump.bin")
-    r = subprocess.run([checker, "klg", klg, str(w), str(h), out], capture_output=True, text=True, check=True)
+    r = subprocess.run([checker, "klg", klg, str(w), str(h), out] + (["6", "3"] if ahead else []), capture_output=True, text=True, check=True)
     assert int(r.stdout) == n
     got = _frames(open(out, "rb").read(), w, h)
     rd = logio.RawLogReader(klg, w, h)

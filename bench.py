@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--close-loops", action="store_true", help="also run the local loop-closure detection every frame (the reference's closeLoops = true: predict() at the "
                     "tracked pose, INACTIVE prediction, model-to-model tracking, gates; thresholds of IF/map_interface/ElasticFusionInterface.cpp:43-45)")
     ap.add_argument("--fern-hook", action="store_true", help="with --close-loops: also the two read-backs per frame of the fern data base (findFrame inside the frame "
-                    "through the fern callback, addFrame after it); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
+                    "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     args = ap.parse_args()
 
@@ -117,8 +117,15 @@ def main():
 
     if args.close_loops:
         ef.set_loop_closure(True, 35000, 5e-5, 1e-5)
+        fern_pending = [False]
         if args.fern_hook:
-            ef.set_fern_callback(lambda e: bool(e.fern_frame() and False))
+            def fern_cb(e):
+                if fern_pending[0]:                 # Ferns::addFrame of the previous frame: enqueued behind it, complete by now
+                    e.fern_frame_fetch()
+                    fern_pending[0] = False
+                e.fern_frame()                      # Ferns::findFrame's read-back of the prediction at the tracked pose
+                return False
+            ef.set_fern_callback(fern_cb)
     frame_no = [0]
     sh = None
     if args.sharded:
@@ -140,7 +147,10 @@ def main():
             ef.hint_next_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
         if args.fern_hook and args.close_loops:
-            ef.fern_frame()                                # Ferns::addFrame's read-back of the end-of-frame prediction
+            if fern_pending[0]:
+                ef.fern_frame_fetch()
+            ef.fern_frame_async()                          # Ferns::addFrame's read-back of the end-of-frame prediction, fetched in the next callback
+            fern_pending[0] = True
         frame_no[0] += 1
         if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
             mk, cl = masks[i]

@@ -156,6 +156,10 @@ typedef int (*ifx_fern_cb)(ifx_t* h, void* user);
 int ifx_set_fern_callback(ifx_t* h, ifx_fern_cb cb, void* user);
 int ifx_adopt_pose(ifx_t* h, const float* pose16);
 int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb);
+/* the end-of-frame read-back (Ferns::addFrame) without a host stall: _async enqueues it behind the frame just processed, _fetch waits for it and hands
+ * the four images over -- typically at the start of the next frame's fern callback, where the host has to wait for the stream anyway */
+int ifx_fern_frame_async(ifx_t* h);
+int ifx_fern_frame_fetch(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb);
 int ifx_track_maps(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba, const float* cur_v4, const float* cur_n4,
                    const uint8_t* cur_rgba, float* pose16, float* diag8);
 

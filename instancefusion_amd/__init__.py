@@ -87,6 +87,8 @@ _SIGS = {
     "ifx_set_fern_callback": (C.c_int, [_P, _P, _P]),
     "ifx_adopt_pose": (C.c_int, [_P, _P]),
     "ifx_fern_frame": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ifx_fern_frame_async": (C.c_int, [_P]),
+    "ifx_fern_frame_fetch": (C.c_int, [_P, _P, _P, _P, _P]),
     "ifx_track_maps": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ifx_map_view": (C.c_int, [_P, C.POINTER(SoaView)]),
     "ifx_map_count": (C.c_int, [_P]),
@@ -338,6 +340,16 @@ class ElasticFusion:
         img, inst = np.zeros((rh, rw, 3), np.uint8), np.zeros((rh, rw, 3), np.uint8)
         v, n = np.zeros((rh, rw, 4), np.float32), np.zeros((rh, rw, 4), np.float32)
         self._chk(self.L.ifx_fern_frame(self.handle, _ptr(img), _ptr(v), _ptr(n), _ptr(inst)), "ifx_fern_frame")
+        return img, v, n, inst
+
+    def fern_frame_async(self):
+        self._chk(self.L.ifx_fern_frame_async(self.handle), "ifx_fern_frame_async")
+
+    def fern_frame_fetch(self):
+        rw, rh = self.w // 8, self.h // 8
+        img, inst = np.zeros((rh, rw, 3), np.uint8), np.zeros((rh, rw, 3), np.uint8)
+        v, n = np.zeros((rh, rw, 4), np.float32), np.zeros((rh, rw, 4), np.float32)
+        self._chk(self.L.ifx_fern_frame_fetch(self.handle, _ptr(img), _ptr(v), _ptr(n), _ptr(inst)), "ifx_fern_frame_fetch")
         return img, v, n, inst
 
     def track_maps(self, model_v4, model_n4, cur_v4, cur_n4, pose, model_rgba=None, cur_rgba=None):

@@ -160,6 +160,9 @@ struct ifx {
     void* lc_user = nullptr;
     ifx_fern_cb fern_cb = nullptr;      // global loop closure (Ferns::findFrame, EF/ElasticFusion.cpp:457-514): runs every frame after predict()
     void* fern_user = nullptr;
+    uint8_t* h_fern = nullptr;          // pinned: ifx_fern_frame_async -> ifx_fern_frame_fetch
+    hipEvent_t ev_fern = nullptr;
+    int fern_pending = 0;
     int in_fern_cb = 0;                 // inside it the "last predict()" is the one at the tracked pose (act* images)
     // device state
     DevState* d_state = nullptr;

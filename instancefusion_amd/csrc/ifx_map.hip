@@ -1866,6 +1866,43 @@ extern "C" int ifx_fern_frame(ifx_t* h, uint8_t* img_rgb, float* verts4, float* 
     return n;
 }
 
+// The same read-back without stalling the caller: enqueued behind the frame, fetched when the host next has to wait for the stream anyway (the
+// fern callback of the following frame) -- Ferns::addFrame only has to be done before the next findFrame.
+extern "C" int ifx_fern_frame_async(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    if (h->in_fern_cb) { h->err = "ifx_fern_frame_async reads the end-of-frame prediction: not inside the fern callback"; return IFX_E_STATE; }
+    const int n = (h->w / 8) * (h->h / 8);
+    const size_t bytes = (size_t)n * (3 + 16 + 16 + 3);
+    if (!h->d_fern) HIPCHK(h, hipMalloc(&h->d_fern, bytes + 64));
+    if (!h->h_fern) { HIPCHK(h, hipHostMalloc((void**)&h->h_fern, bytes + 64)); HIPCHK(h, hipEventCreateWithFlags(&h->ev_fern, hipEventDisableTiming)); }
+    uint8_t* base = (uint8_t*)h->d_fern;
+    float4* dv = (float4*)base;
+    float4* dn = dv + n;
+    uint8_t* di = (uint8_t*)(dn + n);
+    uint8_t* ds = di + (size_t)n * 3;
+    LAUNCH(h, "fern_resize", dim3(cdiv(n, 64)), dim3(64), k_fern_resize, (const uchar4*)h->fill_image, (const float4*)h->fill_vertex, (const float4*)h->fill_normal,
+           (const uchar4*)h->pred_inst, h->w, h->h, di, dv, dn, ds, 0, make_cam(h), (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt);
+    HIPCHK(h, hipMemcpyAsync(h->h_fern, h->d_fern, bytes, hipMemcpyDeviceToHost, h->stream));   // one copy: the staging buffer has the layout of the pinned one
+    HIPCHK(h, hipEventRecord(h->ev_fern, h->stream));
+    h->fern_pending = 1;
+    return n;
+}
+extern "C" int ifx_fern_frame_fetch(ifx_t* h, uint8_t* img_rgb, float* verts4, float* norms4, uint8_t* inst_rgb)
+{
+    if (!h || !img_rgb || !verts4 || !norms4 || !inst_rgb) return IFX_E_INVALID;
+    if (!h->fern_pending) { h->err = "ifx_fern_frame_fetch: nothing was requested (ifx_fern_frame_async)"; return IFX_E_STATE; }
+    HIPCHK(h, hipEventSynchronize(h->ev_fern));
+    h->fern_pending = 0;
+    const int n = (h->w / 8) * (h->h / 8);
+    const uint8_t* p = h->h_fern;
+    memcpy(verts4, p, (size_t)n * 16); p += (size_t)n * 16;
+    memcpy(norms4, p, (size_t)n * 16); p += (size_t)n * 16;
+    memcpy(img_rgb, p, (size_t)n * 3); p += (size_t)n * 3;
+    memcpy(inst_rgb, p, (size_t)n * 3);
+    return n;
+}
+
 extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, int is_fern)
 {
     if (!h || n_nodes < 0 || (n_nodes > 0 && !graph16)) return IFX_E_INVALID;

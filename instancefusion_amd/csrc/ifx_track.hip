@@ -1455,6 +1455,8 @@ void ifx_free_tracker(ifx* h)
     for (int q = 0; q < 2; q++) hipFree(h->slot[q].so3);
     free_m2m(h);
     hipFree(h->d_graph); hipFree(h->d_sample); hipFree(h->d_cons); hipFree(h->d_project); hipFree(h->d_fern); hipFree(h->d_inst_gt);
+    if (h->h_fern) hipHostFree(h->h_fern);
+    if (h->ev_fern) hipEventDestroy(h->ev_fern);
     hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 

@@ -214,7 +214,11 @@ public:
             float lc[24];
             if (ifx_loop_closure_diag(h_, lc) == IFX_OK) loopCandidates_ = (int)lc[23];
         }
-        if (ferns_ && !lost_) ferns_->addFrame(h_, currPose_, tick_, fernThresh_);   // processFerns(), EF/ElasticFusion.cpp:713-727
+        if (ferns_ && !lost_) {   // processFerns(), EF/ElasticFusion.cpp:713-727: the read-back is enqueued behind the frame, the data base takes it in
+            flushPendingFernFrame();   // before the next lookup (flushPendingFernFrame), so the host does not wait for the frame here
+            if (ifx_fern_frame_async(h_) < 0) throw std::runtime_error(std::string("ifx_fern_frame_async: ") + ifx_last_error(h_));
+            fernPending_ = true; fernPendingPose_ = currPose_; fernPendingTick_ = tick_;
+        }
         tick_++;
         poseGraph_.push_back(currPose_);
         poseLogTimes_.push_back(timestamp);
@@ -269,11 +273,27 @@ public:
     // A non-empty graph is applied by this frame's clean as a fern deformation and currPose becomes the recovery pose.
     typedef std::function<std::vector<float>(ElasticFusion&, const std::vector<Ferns::SurfaceConstraint>&, const Matrix4f& recoveryPose, int fernSrcTime)> FernHandler;
     void setFernHandler(FernHandler fn) { fernHandler_ = std::move(fn); }
-    Ferns* ferns() { return ferns_.get(); }
+    Ferns* ferns()
+    {
+        flushPendingFernFrame();
+        return ferns_.get();
+    }
+    // Ferns::addFrame of the last processed frame, if it is still outstanding
+    void flushPendingFernFrame()
+    {
+        if (!fernPending_) return;
+        fernPending_ = false;
+        const size_t np = (size_t)ferns_->width * ferns_->height;
+        fernImg_.resize(np * 3); fernInst_.resize(np * 3); fernVerts_.resize(np * 4); fernNorms_.resize(np * 4);
+        if (ifx_fern_frame_fetch(h_, fernImg_.data(), fernVerts_.data(), fernNorms_.data(), fernInst_.data()) < 0)
+            throw std::runtime_error(std::string("ifx_fern_frame_fetch: ") + ifx_last_error(h_));
+        ferns_->addFrameMaps(fernImg_.data(), fernVerts_.data(), fernNorms_.data(), fernInst_.data(), fernPendingPose_, fernPendingTick_, fernThresh_);
+    }
     // the reference seeds its fern table with time(0) (EF/Ferns.cpp:52); a fixed seed makes a run repeatable.  Empties the data base.
     void resetFerns(uint32_t seed)
     {
         if (!ferns_) return;
+        fernPending_ = false;
         ferns_.reset(new Ferns(500, (int)(cfg_.depth_cut * 1000), photoThresh_, cfg_.width, cfg_.height, cfg_.fx, cfg_.fy, cfg_.cx, cfg_.cy, cfg_.device, seed));
     }
     int getFernMatches() const { return fernMatches_; }     // frames on which findFrame produced constraints
@@ -434,6 +454,7 @@ private:
     {
         ElasticFusion* self = static_cast<ElasticFusion*>(user);
         try {
+            self->flushPendingFernFrame();
             Matrix4f tracked;
             if (ifx_get_pose(h, tracked.data()) < 0) return IFX_E_STATE;
             std::vector<Ferns::SurfaceConstraint> constraints;
@@ -499,6 +520,11 @@ private:
     bool deformOnLoopClosure_ = true;
     int fernDeforms_ = 0;
     std::unique_ptr<Ferns> ferns_;
+    bool fernPending_ = false;
+    Matrix4f fernPendingPose_;
+    int fernPendingTick_ = 0;
+    std::vector<unsigned char> fernImg_, fernInst_;
+    std::vector<float> fernVerts_, fernNorms_;
     FernHandler fernHandler_;
     int fernMatches_ = 0;
     int* smallInstanceTable_ = nullptr;

@@ -1211,7 +1211,10 @@ def test_fern_callback_global_deformation(ifx, orc, small_stream):
             mo, mg = o.download(), g.download()
             for key in MAP_KEYS:
                 assert np.array_equal(mo[key], mg[key]), (k, key)
+        g.fern_frame_async()                                            # the same read-back enqueued behind the frame and fetched later
         for a, b in zip(o.fern_frame(), g.fern_frame()):                # addFrame's four images (end-of-frame predict)
+            assert np.array_equal(a, b), k
+        for a, b in zip(o.fern_frame(), g.fern_frame_fetch()):
             assert np.array_equal(a, b), k
         if k == 2:                                                      # everything stable from here on: an old model comes into being
             m2 = o.download(); m2["pc"][:, 3] = 20.0; o.upload(m2)

@@ -237,7 +237,12 @@ public:
     const int& getFernDeforms() { return fernDeforms_; }          // global (fern) deformations applied
     // closeLoops deforms the map on an accepted loop closure, as the reference does (localDeformation / globalDeformation, ifx_deformation.hpp); switched
     // off, loop closures are only detected and counted, and every frame is tracked and fused as if none had fired
-    void setDeformOnLoopClosure(bool on) { deformOnLoopClosure_ = on; }
+    void setDeformOnLoopClosure(bool on)
+    {
+        deformOnLoopClosure_ = on;   // without a consumer of the verdict inside the frame the model-to-model tracker runs on its own stream under the map passes
+        const bool need = lcHandler_ || (closeLoops_ && on);
+        if (ifx_set_loop_closure_callback(h_, need ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK) throw std::runtime_error(ifx_last_error(h_));
+    }
     Deformation& getLocalDeformation() { return localDeformation_; }
     Deformation& getGlobalDeformation() { return globalDeformation_; }
     bool getCloseLoops() const { return closeLoops_; }
@@ -305,7 +310,8 @@ public:
     void setLoopClosureHandler(std::function<void(ElasticFusion&, const LoopClosureCandidate&)> fn)
     {
         lcHandler_ = std::move(fn);   // replaces the built-in handler (defaultLoopClosure); an empty function restores it
-        if (ifx_set_loop_closure_callback(h_, (lcHandler_ || closeLoops_) ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK) throw std::runtime_error(ifx_last_error(h_));
+        if (ifx_set_loop_closure_callback(h_, (lcHandler_ || (closeLoops_ && deformOnLoopClosure_)) ? &ElasticFusion::lcTrampoline : nullptr, this) != IFX_OK)
+            throw std::runtime_error(ifx_last_error(h_));
     }
     std::vector<float> sampleGraphModel()   // x, y, z, init time of every 5000th surfel (Deformation::sampleGraphModel)
     {

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <ctime>
 #include <functional>
@@ -297,13 +298,19 @@ private:
     void track(const float* mv, const float* mn, const float* cv, const float* cn, float* pose16, float* diag8)
     {
         if (tracker_) { tracker_(mv, mn, cv, cn, pose16, diag8); return; }
+        if (trackerUnavailable_) return;   // diag stays zero: lastICPCount = 0 fails the gate, no match
         if (!tracker_handle_) {
             ifx_config c;
             std::memset(&c, 0, sizeof(c));
             c.width = width; c.height = height; c.fx = fx_; c.fy = fy_; c.cx = cx_; c.cy = cy_;
             c.time_delta = 200; c.confidence = 10.f; c.depth_cut = (float)maxDepth / 1000.0f; c.max_depth_processed = 20.f;
             c.icp_weight = 100.f; c.pyramid = 0; c.fast_odom = 0; c.so3 = 0; c.max_surfels = 1024; c.device = device_; c.n_ranks = 1; c.rank = 0;
-            if (ifx_create(&c, &tracker_handle_) != IFX_OK) { tracker_handle_ = nullptr; throw std::runtime_error(std::string("Ferns: tracker handle: ") + ifx_global_error()); }
+            if (ifx_create(&c, &tracker_handle_) != IFX_OK) {   // e.g. a 320 x 240 stream: 40 x 30 is not a size the tracker's pyramids take
+                tracker_handle_ = nullptr;
+                trackerUnavailable_ = true;
+                std::fprintf(stderr, "Ferns: no tracker at %d x %d (%s): keyframes are kept, matches cannot be verified\n", width, height, ifx_global_error());
+                return;
+            }
         }
         if (ifx_track_maps(tracker_handle_, mv, mn, nullptr, cv, cn, nullptr, pose16, diag8) != IFX_OK)
             throw std::runtime_error(std::string("ifx_track_maps: ") + ifx_last_error(tracker_handle_));
@@ -313,6 +320,7 @@ private:
     const int device_;
     Tracker tracker_;
     ifx_t* tracker_handle_ = nullptr;
+    bool trackerUnavailable_ = false;
     std::vector<unsigned char> img_, inst_;
     std::vector<float> verts_, norms_;
 };

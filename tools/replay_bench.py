@@ -16,11 +16,13 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--unique", type=int, default=40)
     ap.add_argument("--out", default="/tmp/replay_bench")
+    ap.add_argument("--res", default="640x480")
     a = ap.parse_args()
     from instancefusion_amd import logio, synth
 
     os.makedirs(a.out, exist_ok=True)
-    W, H, K = 640, 480, (528.0, 528.0, 320.0, 240.0)
+    W, H = (int(v) for v in a.res.split("x"))
+    K = (528.0 * W / 640, 528.0 * H / 480, W / 2.0, H / 2.0)
     t0 = time.time()
     st = synth.make_stream(a.unique, W, H, *K, noise=True)
     klg = os.path.join(a.out, "s.klg")

@@ -205,6 +205,14 @@ int main(int argc, char** argv)
                     e.setDeformation(rawGraph, false);
                     e.adoptEstimatedPose();
                 });
+                ef.setFernHandler([](ElasticFusion& e, const std::vector<Ferns::SurfaceConstraint>& cons, const Matrix4f& recoveryPose, int fernSrcTime) {
+                    for (const auto& c : cons) e.getGlobalDeformation().addConstraint(c.sourcePoint, c.targetPoint, (uint64_t)e.getTick(), (uint64_t)fernSrcTime, true);
+                    (void)recoveryPose;
+                    return std::vector<float>();
+                });
+                ef.resetFerns(1u);
+                ef.setDeformOnLoopClosure(false);
+                (void)ef.getFernMatches(); (void)ef.getFernDeforms(); (void)ef.getLocalDeformation().lastDeformTime; (void)ef.ferns()->frames.size();
                 std::printf("created\n");
             } catch (const std::exception& e) {
                 std::printf("refused: %s\n", e.what());

@@ -25,8 +25,12 @@ int main(int argc, char** argv)
             std::ofstream f(argv[5], std::ios::binary);
             const size_t P = (size_t)Resolution::getInstance().numPixels();
             std::printf("%d\n", r->getNumFrames());
+            int delivered = 0;
+            const int back_at = argc > 8 ? std::atoi(argv[8]) : -1;   // ... [AHEAD THREADS BACK_AT]: getBack() after that many frames, then carry on
             while (r->hasMore()) {
-                r->getNext();
+                if (delivered == back_at) r->getBack();
+                else r->getNext();
+                delivered++;
                 f.write((const char*)&r->timestamp, 8);
                 f.write((const char*)r->depth, (std::streamsize)P * 2);
                 f.write((const char*)r->rgb, (std::streamsize)P * 3);

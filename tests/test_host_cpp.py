@@ -58,6 +58,28 @@ def test_raw_log_reader_equals_python(checker, tmp_path, depth_mode):
     assert k == len(got) == n - 1        # the last frame is never delivered (RawLogReader.cpp:134-137)
 
 
+def test_raw_log_reader_get_back_under_read_ahead(checker, tmp_path):
+    """getBack() while records are being decoded ahead: the read-ahead is dropped, the file position is put back behind the last delivered frame, and the
+    sequence of frames is the one the synchronous reader delivers for the same calls."""
+    from instancefusion_amd import logio
+
+    w, h, n = 64, 48, 17
+    rng = np.random.default_rng(9)
+    klg = str(tmp_path / "b.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg")
+    for k in range(n):
+        wr.add(100 * k, rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 8000, (h, w), dtype=np.uint16))
+    wr.close()
+    outs = []
+    for ahead in (["0", "0", "5"], ["6", "3", "5"]):
+        out = str(tmp_path / f"dump{ahead[0]}.bin")
+        subprocess.run([checker, "klg", klg, str(w), str(h), out] + ahead, check=True, capture_output=True, timeout=60)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 0
+    ts = [f[0] for f in _frames(outs[0], w, h)]
+    assert ts[4] == ts[5]                      # getBack re-delivers the frame it was called on
+
+
 def _test_image(w, h, seed):
     """smooth structure + texture + hard edges + saturated colours: exercises AC runs, EOB, ZRL, chroma upsampling edges and clamping"""
     rng = np.random.default_rng(seed)

@@ -72,13 +72,29 @@ def main():
     ap.add_argument("--fern-hook", action="store_true", help="with --close-loops: also the two read-backs per frame of the fern data base (findFrame inside the frame "
                     "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
+    ap.add_argument("--extras-frames", type=int, default=60, help="frames of each extra leg at N = 1 (host entry point, closeLoops = true); 0 skips them")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one worker per GPU from this parent, which has not
+        # touched HIP (a process that has initialised the GPU must never exec / re-launch), and relay rank 0's line
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
 
     from instancefusion_amd import dist as ifd
 
     rank, local_rank, world, dist = ifd.init("nccl")
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
 
@@ -126,24 +142,48 @@ def main():
                 e.fern_frame()                      # Ferns::findFrame's read-back of the prediction at the tracked pose
                 return False
             ef.set_fern_callback(fern_cb)
-    frame_no = [0]
+    # ---- the instance layer inside the loop: whetherDoSegmentation every frame, a segmentation call when it fires (IF/main.cpp:108-307)
+    seg = dict(frame=0, shift=0, last_true=None, calls=0, fast=0)
+
+    def instance_step(i, allow=True):
+        seg["frame"] += 1
+        f = 100 + seg["frame"] + seg["shift"]
+        if args.no_instance or not allow:
+            return
+        if inst.whetherDoSegmentation(f):
+            if seg["last_true"] is not None and f - seg["last_true"] <= 45:
+                seg["fast"] += 1                    # the fast cadence (every 3rd frame) was chosen at least once
+            seg["last_true"] = f
+            mk, cl = masks[i]
+            if mk.shape[0]:
+                seg["calls"] += 1
+                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
+
+    def place_call_in_window(n_frames):
+        """The adaptive cadence (every 46th frame once the map carries votes, IF/Core/InstanceFusion.cpp:192-238) would leave a short
+        timed window without any instance work.  The frame numbers handed to whetherDoSegmentation are shifted so that a call falls
+        due in the MIDDLE of a window shorter than the cadence: such a window then holds one call (more instance work per frame than
+        the steady state, never less); longer windows keep the natural phase."""
+        if args.no_instance or seg["last_true"] is None:
+            return
+        nxt = 100 + seg["frame"] + seg["shift"] + 1          # frame number the next step will present
+        due = seg["last_true"] + 46
+        if due > nxt + n_frames - 1 or due < nxt:
+            seg["shift"] += due - (nxt + n_frames // 2)
+
     sh = None
     if args.sharded:
         from instancefusion_amd import sharded as ifsh
 
         sh = ifsh.ShardedElasticFusion(ef, rank, world, dist)
 
-    def step(k):
+    def step(k, hint=True):
         i = k % L
         if sh is not None:
             sh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
-            frame_no[0] += 1
-            if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
-                mk, cl = masks[i]
-                if mk.shape[0]:
-                    inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0], superpixels=not args.no_superpixels)
+            instance_step(i)
             return
-        if not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame's tracking
+        if hint and not args.no_prefetch:   # log replay: the next frame is known, its image-only work overlaps this frame's tracking
             ef.hint_next_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
         ef.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), k)
         if args.fern_hook and args.close_loops:
@@ -151,11 +191,7 @@ def main():
                 ef.fern_frame_fetch()
             ef.fern_frame_async()                          # Ferns::addFrame's read-back of the end-of-frame prediction, fetched in the next callback
             fern_pending[0] = True
-        frame_no[0] += 1
-        if not args.no_instance and inst.whetherDoSegmentation(100 + frame_no[0]):
-            mk, cl = masks[i]
-            if mk.shape[0]:
-                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, frame_no[0], superpixels=not args.no_superpixels)
+        instance_step(i)
 
     def barrier():
         if dist is not None:
@@ -163,16 +199,25 @@ def main():
         torch.cuda.synchronize()
         ef.sync()
 
-    k0 = 1
-    for k in range(k0, k0 + args.warmup):
-        step(k)
+    def timed(k_first, n, fn):
+        """n frames through fn(k), bracketed by barrier + synchronize; returns seconds (this rank)."""
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(k_first, k_first + n):
+            fn(k)
+        barrier()
+        return time.perf_counter() - t0
+
+    k = 1
+    for _ in range(args.warmup):
+        step(k); k += 1
     barrier()
     ef.stage_ms(reset=True)
-    t0 = time.perf_counter()
-    for k in range(k0 + args.warmup, k0 + args.warmup + args.steps):
-        step(k)
-    barrier()
-    dt = time.perf_counter() - t0
+    place_call_in_window(args.steps)
+    seg["calls"] = 0
+    k_timed = k
+    dt = timed(k, args.steps, step); k += args.steps
+    calls_in_window = seg["calls"]
     inst_ms = ef.stage_ms(reset=True)["instance"]          # the instance stage is always timed (two events per segmentation call)
     traj = ef.trajectory()                                  # poses up to the end of the timed region
     dt = ifd.max_over_ranks(dt, dist, device=f"cuda:{dev}")
@@ -180,9 +225,8 @@ def main():
     # (eight marker packets per frame: they would cost ~4 % of the frame rate inside the timed region)
     n_split = 40
     ef.set_option("stage_timing", 1)
-    kk = k0 + args.warmup + args.steps
-    for k in range(kk, kk + n_split):
-        step(k)
+    for _ in range(n_split):
+        step(k); k += 1
     ef.sync()
     stage = ef.stage_ms(reset=True)
     ef.set_option("stage_timing", 0)
@@ -190,7 +234,7 @@ def main():
     stage["instance"] = inst_ms
     n_live, n_slots = ef.count, ef.slots
     # trajectory error vs the synthetic ground truth over the timed frames (diagnostic)
-    gt = np.stack([st["poses"][(k0 + args.warmup + j) % L] for j in range(args.steps)])
+    gt = np.stack([st["poses"][(k_timed + j) % L] for j in range(args.steps)])
     est = traj[-args.steps:]
     ate = float(np.sqrt(np.mean(np.sum((est[:, :3, 3] - gt[:, :3, 3]) ** 2, axis=1)))) if len(est) == args.steps else float("nan")
 
@@ -199,11 +243,13 @@ def main():
     if rank == 0:
         ef.set_option("kernel_timing", 1)
         ef.kernel_ms("__reset__")
-        kk = k0 + args.warmup + args.steps + n_split
-        for k in range(kk, kk + 20):
-            step(k)
+        seg["calls"] = 0
+        n_kt = 20
+        place_call_in_window(n_kt)
+        for _ in range(n_kt):
+            step(k); k += 1
         ef.sync()
-        names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_raster", "raster_list", "cull_clean", "clean_list", "index_project", "index_resolve", "associate",
+        names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "index_list", "index_project", "index_resolve", "associate",
                  "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
         best, table = None, {}
         for nme in names:
@@ -219,12 +265,23 @@ def main():
                 if t["launches"] and nme != best and t["total_ms"] > 0.95 * table[best]["total_ms"] and algorithmic_bytes(nme, n_slots, P) > algorithmic_bytes(best, n_slots, P):
                     best = nme
         ef.set_option("kernel_timing", 0)
-        # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
-        # MI355X_MICROARCH.md prescribes for gfx950; collected offline on this same command, see profiles/README.md)
-        pmc = {}
+        # HBM traffic per launch: PMC counters cannot be read from inside the process.  They are collected by tools/pmc_collect.sh (rocprofv3
+        # --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS command, corrected as MI355X_MICROARCH.md prescribes) into
+        # profiles/<round>_pmc_traffic.json together with the slot count and the kernel list of that run.  A file is used only when it
+        # describes this workload (same resolution, slot count within 2 %) and this kernel set; otherwise `traffic` is null -- never a stale constant.
+        pmc, pmc_src = {}, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_p_pmc_traffic.json")) as f:
-                pmc = json.load(f)["kernels"]
+            cands = sorted(f_ for f_ in os.listdir(os.path.join(ROOT, "profiles")) if f_.endswith("_pmc_traffic.json"))
+            for f_ in reversed(cands):
+                with open(os.path.join(ROOT, "profiles", f_)) as f:
+                    j = json.load(f)
+                meta = j.get("workload")
+                if not meta or meta.get("res") != f"{W}x{H}" or abs(meta.get("surfel_slots", 0) - n_slots) > 0.02 * n_slots:
+                    continue
+                if not all(("k_" + n_) in j["kernels"] for n_ in names if table[n_]["launches"] and algorithmic_bytes(n_, n_slots, P) > 0):
+                    continue
+                pmc, pmc_src = j["kernels"], "profiles/" + f_
+                break
         except (OSError, ValueError, KeyError):
             pass
 
@@ -233,35 +290,90 @@ def main():
             ach = b / (table[nme]["avg_ms"] * 1e-3) / 1e9 if table[nme]["avg_ms"] > 0 else 0.0
             t = pmc.get("k_" + nme)
             return dict(bound="hbm", kernel=nme, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=(t["bytes_read"] + t["bytes_written"]) if t else None, avg_launch_ms=round(table[nme]["avg_ms"], 5), bytes_per_launch=b)
+                        traffic=(t["bytes_read"] + t["bytes_written"]) if t else None, traffic_source=pmc_src if t else None,
+                        avg_launch_ms=round(table[nme]["avg_ms"], 5), bytes_per_launch=b)
 
         if best:
             roof = entry(best)
-            roof["kernels"] = {k: dict(avg_ms=round(v["avg_ms"], 5), launches=v["launches"]) for k, v in table.items()}
-            # the dominant kernel by time is a latency-bound reduction; the three streaming passes over the
-            # whole surfel store are reported next to it so that the bandwidth-bound part of the path has its roofline numbers too
-            roof["streaming_passes"] = [entry(n_) for n_ in ("cull_raster", "cull_clean", "index_project") if table.get(n_, {}).get("launches")]
+            roof["kernels"] = {k_: dict(avg_ms=round(v["avg_ms"], 5), launches=v["launches"]) for k_, v in table.items() if v["launches"]}
+            # the dominant kernel by time is a latency-bound reduction; the passes that stream the whole surfel
+            # store are reported next to it so that the bandwidth-bound part of the path has its roofline numbers too
+            roof["streaming_passes"] = [entry(n_) for n_ in ("cull_frame", "cull_raster", "cull_clean", "index_project", "count_colour") if table.get(n_, {}).get("launches")]
 
-    # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload
+    # ---- extra legs (N = 1 only, bounded): the same workload through the reference-shaped host entry point, and with closeLoops = true
+    extras = {}
+    if rank == 0 and world == 1 and sh is None and args.extras_frames > 0 and not args.close_loops:
+        ne = args.extras_frames
+        step(k, hint=False); k += 1                           # drains the one-frame look-ahead: the next leg hands over host buffers
+        ef.sync()
+
+        def host_step(kk):
+            i = kk % L
+            ef.processFrame(st["rgb"][i], st["depth"][i])     # ifx_process_frame: caller's host buffers, 1.54 MB H2D per frame, synchronous
+            instance_step(i)
+
+        for _ in range(5):
+            host_step(k); k += 1
+        place_call_in_window(ne)
+        seg["calls"] = 0
+        t_host = timed(k, ne, host_step); k += ne
+        extras["value_host_entry"] = dict(value=round(ne / t_host, 2), unit="frames/s", frames=ne, segmentation_calls=seg["calls"],
+                                          what="ifx_process_frame (ElasticFusion::processFrame's signature): host rgb/depth pointers, H2D inside the call, one host synchronisation per frame")
+        # the reference's own configuration: closeLoops = true (IF/map_interface/ElasticFusionInterface.cpp:43): predict() at the tracked pose,
+        # INACTIVE prediction, model-to-model tracker and the gates on every frame; resident frames + look-ahead as in `value`
+        ef.set_loop_closure(True, 35000, 5e-5, 1e-5)
+        for _ in range(8):
+            step(k); k += 1
+        place_call_in_window(ne)
+        seg["calls"] = 0
+        t_lc = timed(k, ne, step); k += ne
+        lcd = ef.loop_closure_diag()
+        extras["value_close_loops"] = dict(value=round(ne / t_lc, 2), unit="frames/s", frames=ne, segmentation_calls=seg["calls"], candidates=int(lcd["candidates"]),
+                                           what="as `value`, with the local loop-closure detection of closeLoops = true on every frame (no fern data base, no deformation applied)")
+        step(k, hint=False); k += 1
+        ef.sync()
+        ef.set_loop_closure(False, 35000, 5e-5, 1e-5)
+
+    # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload, one core and all cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks of a multi-GPU run would wait for it)
-        os.environ.setdefault("OMP_NUM_THREADS", "1")
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
 
         n_cpu = min(args.surfels, 5_000_000)
-        o = ol.Oracle(w=W, h=H, max_surfels=n_cpu + 1_000_000, **K)
-        o.process_frame(st["rgb"][0], st["depth"][0])
-        o.upload(synth.make_map(n_cpu, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7))
-        o.set_pose(st["poses"][0], tick0)
-        o.combined_predict(st["poses"][0], tick0, tick0)
-        tc = time.perf_counter()
-        for k in range(1, 1 + args.cpu_frames):
-            o.process_frame(st["rgb"][k % L], st["depth"][k % L])
-        tc = time.perf_counter() - tc
-        cpu = dict(value=round(args.cpu_frames / tc, 4), unit="frames/s", cores=1, kind="port",
-                   sample=f"{args.cpu_frames} frames of the same {W}x{H} stream into the same {n_cpu}-surfel synthetic map (no instance calls)")
-        o.close()
+        ncores = os.cpu_count() or 1
+        cpu_map = synth.make_map(n_cpu, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7)
+
+        def cpu_leg(threads, frames):
+            ol.set_threads(threads)
+            o = ol.Oracle(w=W, h=H, max_surfels=n_cpu + 1_000_000, **K)
+            o.process_frame(st["rgb"][0], st["depth"][0])
+            o.upload(cpu_map)
+            o.set_pose(st["poses"][0], tick0)
+            o.combined_predict(st["poses"][0], tick0, tick0)
+            o.stage_ms(reset=True)
+            tc = time.perf_counter()
+            for kk in range(1, 1 + frames):
+                o.process_frame(st["rgb"][kk % L], st["depth"][kk % L])
+            t_frames = time.perf_counter() - tc
+            ms = o.stage_ms(reset=True)
+            mk, cl = masks[frames % L]
+            t_seg = 0.0
+            if mk.shape[0] and not args.no_instance:          # one segmentation call (masks, superpixels, flood fill, votes, label scan)
+                tc = time.perf_counter()
+                o.process_segmentation(st["rgb"][frames % L], st["depth"][frames % L], mk, cl, 200, flags=0 if args.no_superpixels else 2)
+                t_seg = time.perf_counter() - tc
+            o.close()
+            return dict(value=round(frames / t_frames, 4), unit="frames/s", cores=threads, frames=frames,
+                        ms_per_frame={"track": round(ms["track"] / frames, 2), "fuse": round(ms["fuse"] / frames, 2)}, instance_ms_per_call=round(t_seg * 1e3, 1))
+
+        one = cpu_leg(1, max(2, args.cpu_frames // 2))
+        allc = cpu_leg(ncores, args.cpu_frames) if ncores > 1 else one
+        cpu = dict(value=allc["value"], unit="frames/s", cores=allc["cores"], kind="port",
+                   sample=f"{allc['frames']} frames of the same {W}x{H} stream into the same {n_cpu}-surfel synthetic map + one segmentation call (timed apart), OpenMP over rows / surfels on all {allc['cores']} host cores; "
+                          f"`one_core`: {one['frames']} frames on one core",
+                   ms_per_frame=allc["ms_per_frame"], instance_ms_per_call=allc["instance_ms_per_call"], one_core=one)
+        del cpu_map
 
     if rank == 0:
         fps = (1 if args.sharded else world) * args.steps / dt
@@ -270,9 +382,13 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}, {args.surfels}-surfel map",
+            "config": {"workload": f"{args.surfels}-surfel map, {W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}",
                        "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"sharded projection x{world}" if args.sharded else f"replicas x{world}"), "loop_frames": L},
-            "ms_per_frame_gpu": {k: round(v / args.steps, 4) for k, v in stage.items()},
+            "ms_per_frame_gpu": {k_: round(v / args.steps, 4) for k_, v in stage.items()},
+            "instance": {"calls_in_window": calls_in_window, "ms_per_call": round(inst_ms / calls_in_window, 4) if calls_in_window else None,
+                         "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,
+                         "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call"},
+            **extras,
             "ate_rms_m": ate, "gen_s": round(t_gen, 1),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu,

@@ -69,6 +69,15 @@ const char* ifx_global_error(void);
  * currPose.  Returns 0 ok, 1 lost (never in this configuration: reloc=false), <0 error. */
 int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
                       const float* in_pose16, float weight_mult, float* out_pose16);
+/* The complete argument list of ElasticFusion::processFrame (EF/ElasticFusion.h:75-82).
+ * inst_table: `smallInstanceTable` (96 x 5 ints, may be NULL).  Its only consumer in the reference is Ferns::findFrame
+ *   (EF/ElasticFusion.cpp:468), host code that lives above this boundary (instancefusion_amd/host/ifx_ferns.hpp), so the
+ *   library accepts it and does not read it -- which is why ifx_process_frame omits it.
+ * bootstrap != 0: in_pose16 (required) is a GUESS, not a replacement: the model maps are placed with the current pose, then
+ *   currPose = currPose * inPose is the tracker's initial estimate, and the velocity weighting compares the tracked pose with
+ *   the pose before the guess (EF/ElasticFusion.cpp:330-356, :433). */
+int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const int32_t* inst_table,
+                         const float* in_pose16, float weight_mult, int bootstrap, float* out_pose16);
 /* Same, with the frame already resident in HBM and no host synchronisation: the call only
  * enqueues work on the handle's stream.  Poses are appended to the device-side trajectory log. */
 int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth,
@@ -100,7 +109,8 @@ int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);
 int ifx_tick(ifx_t* h);
-/* Trajectory log: one pose per processed frame (ResultModel.freiburg, EF/ElasticFusion.cpp:99-136). */
+/* Trajectory log: one pose per processed frame (ResultModel.freiburg, EF/ElasticFusion.cpp:99-136), kept on the device as a ring of
+ * 65536 frames: returns the LAST min(frames processed, 65536, max_frames) poses, oldest first. */
 int ifx_trajectory(ifx_t* h, float* out_poses16, int max_frames);
 /* diag[8]: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count,
  * velocity weighting, fill-in flag (EF/Utils/RGBDOdometry.h:65-70). */
@@ -110,9 +120,10 @@ int ifx_tracker_diag(ifx_t* h, float* diag8);
  * EF/ElasticFusion.cpp:453-566 with no fern match).  When enabled every tracked frame also runs predict() at the new pose, the INACTIVE
  * prediction (surfels not seen for time_delta frames), the model-to-model tracker (RGBDOdometry modelToModel: active render against
  * inactive render, ICP weight 10, no SO(3)) and the gates covariance diagonal <= cov_thresh, lastICPCount > count_thresh, lastICPError <
- * err_thresh.  The reference then deforms the map (deformation graph) and adopts the estimated pose; that part is NOT implemented
- * (DESIGN.md section 0): an accepted candidate is counted and reported, the frame continues with the tracked pose.  A run whose
- * candidate count stays 0 is therefore what the reference computes with closeLoops = true and an empty fern data base.
+ * err_thresh.  The reference then deforms the map (deformation graph) and adopts the estimated pose: the GPU half of that is provided by
+ * the hooks below (ifx_set_loop_closure_callback ... ifx_adopt_estimated_pose), the graph optimiser is host code above this boundary
+ * (instancefusion_amd/host/ifx_deformation.hpp).  Without a callback an accepted candidate is counted and reported and the frame
+ * continues with the tracked pose; a run whose candidate count stays 0 is what the reference computes with closeLoops = true.
  * out24: 0 model-to-model ran (0: nothing inactive in view), 1 pixels of the inactive render, 2 lastICPError, 3 lastICPCount, 4 covOk,
  * 5 accepted, 6..21 estimated pose (row-major 4x4), 22 largest diagonal covariance entry, 23 candidates accepted so far. */
 int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, float err_thresh, float cov_thresh);

@@ -65,6 +65,7 @@ _SIGS = {
     "ifx_last_error": (C.c_char_p, [_P]),
     "ifx_global_error": (C.c_char_p, []),
     "ifx_process_frame": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float, _P]),
+    "ifx_process_frame_ex": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "ifx_enqueue_frame_device": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_float]),
     "ifx_set_shard": (C.c_int, [_P, C.c_int, C.c_int]),
     "ifx_sharded_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
@@ -215,14 +216,18 @@ class ElasticFusion:
         """instanceGT of ElasticFusion::processFrame for the frames that follow (H x W uint8, None: off)."""
         self._chk(self.L.ifx_set_instance_gt(self.handle, None if gt is None else _ptr(np.ascontiguousarray(gt, np.uint8))), "ifx_set_instance_gt")
 
-    def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0):
+    def processFrame(self, rgb, depth, timestamp=0, smallInstanceTable=None, instanceGT=None, inPose=None, weightMultiplier=1.0, bootstrap=False):
+        """ElasticFusion::processFrame (EF/ElasticFusion.h:75-82), same argument order and meaning."""
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16)
         assert rgb.size == self.w * self.h * 3 and depth.size == self.w * self.h
+        if instanceGT is not None:
+            self.set_instance_gt(instanceGT)
         out = np.zeros(16, np.float32)
         ip = None if inPose is None else np.ascontiguousarray(inPose, np.float32).reshape(16)
-        self._chk(self.L.ifx_process_frame(self.handle, _ptr(rgb), _ptr(depth), int(timestamp), _ptr(ip), float(weightMultiplier), _ptr(out)),
-                  "ifx_process_frame")
+        tab = None if smallInstanceTable is None else np.ascontiguousarray(smallInstanceTable, np.int32)
+        self._chk(self.L.ifx_process_frame_ex(self.handle, _ptr(rgb), _ptr(depth), int(timestamp), _ptr(tab), _ptr(ip), float(weightMultiplier), int(bool(bootstrap)), _ptr(out)),
+                  "ifx_process_frame_ex")
         return out.reshape(4, 4)
 
     process_frame = processFrame

@@ -92,6 +92,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
     memset(h->h_result, 0, sizeof(FrameResult));
     ALLOC(h->d_traj, (size_t)h->max_traj * 64);
+    ALLOC(h->d_scratch, 8 * 64);
     ALLOC(h->pc, C * 16); ALLOC(h->nr, C * 16); ALLOC(h->col, C * 8); ALLOC(h->tm, C * 8); ALLOC(h->ic, C * 16); ALLOC(h->votes, C * 192);
     ALLOC(h->pc2, C * 16); ALLOC(h->nr2, C * 16); ALLOC(h->col2, C * 8); ALLOC(h->tm2, C * 8); ALLOC(h->ic2, C * 16); ALLOC(h->votes2, C * 192);
     ALLOC(h->upd_owner, C * 4);
@@ -153,7 +154,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
@@ -372,8 +373,10 @@ static int enqueue_loop_closure_tracker(ifx* h)
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)
 // the local detection is implemented (ifx_set_loop_closure), the fern lookup and both deformations run in the caller's callbacks (the graph
 // optimiser is host code of the reference); without the detection the first predict() of :453, whose only consumers are those stages, is not executed.
-static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult)
+int ifx_tracker_bootstrap_pose(ifx* h, const float* d_in_pose16);
+static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult, int bootstrap = 0)
 {
+    if (bootstrap && !in_pose16) { h->err = "bootstrap needs inPose (EF/ElasticFusion.cpp:352-356)"; return IFX_E_INVALID; }
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
     const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0;
@@ -398,14 +401,19 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
                 int r = ifx_enqueue_hinted_frame_side(h);   // no tracker enqueue to hide it in: it runs under this frame's map passes
                 if (r) return r;
-            } else if (!in_pose16) {
+            } else if (!in_pose16 || bootstrap) {
                 ifx_tracker_model_side(h);                       // model pyramid: independent of the frame side
                 HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
-                ifx_tracker_run_frame(h);
+                if (bootstrap) {   // inPose is a guess, not a replacement: currPose = currPose * inPose AFTER the model maps were placed with the old pose (:334-356)
+                    float* slot = h->d_scratch + 2 * 16;
+                    HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
+                    ifx_tracker_bootstrap_pose(h, slot);
+                }
+                ifx_tracker_run_frame(h, 1, bootstrap);
                 if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
             } else {
                 HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
-                float* slot = h->d_traj + (size_t)(h->max_traj - 4) * 16;
+                float* slot = h->d_scratch + 2 * 16;
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
             }
@@ -427,7 +435,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
         StageTimer t(h, 1);
         ifx_map_predict(h);
     }
-    int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
+    const int slot = h->n_traj % h->max_traj;
     LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
     hipEventRecord(f.released, h->stream);   // one marker: the side stream waits for it before it reuses the slot,
     h->ev_result = f.released;               // the host before it reads the frame result
@@ -497,7 +505,10 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
     if (phase == 0) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
         h->tracked_ahead = 0;
-        ifx_housekeeping(h);                       // identical decision on every rank: the frame results are identical
+        // The compaction decision must be the SAME on every rank (slot numbers travel inside the exchanged keys): it is taken from the
+        // result of the previous frame, which is identical on all ranks -- once the host has actually waited for it.
+        if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
+        ifx_housekeeping(h);
         const int two = h->opt_two_streams;
         h->opt_two_streams = 0;                     // the frame side runs inline on the main stream in this mode
         int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, 0);
@@ -510,7 +521,7 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
     int r = ifx_map_sharded_phase(h, phase, first);
     if (r) return r;
     if (phase == 3) {
-        int slot = h->n_traj < h->max_traj - 8 ? h->n_traj : h->max_traj - 8;
+        const int slot = h->n_traj % h->max_traj;
         LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
         hipEventRecord(f.released, h->stream);
         h->ev_result = f.released;
@@ -563,13 +574,21 @@ extern "C" int ifx_sync(ifx_t* h)
 
 extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const float* in_pose16, float weight_mult, float* out_pose16)
 {
-    (void)timestamp;
+    return ifx_process_frame_ex(h, rgb, depth, timestamp, nullptr, in_pose16, weight_mult, 0, out_pose16);
+}
+
+// The full argument list of ElasticFusion::processFrame (EF/ElasticFusion.h:75-82).  inst_table (smallInstanceTable, 96 x 5) has one consumer in
+// the reference, Ferns::findFrame (EF/ElasticFusion.cpp:468), i.e. host code above this boundary (host/ifx_ferns.hpp): accepted, not read.
+extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const int32_t* inst_table, const float* in_pose16,
+                                    float weight_mult, int bootstrap, float* out_pose16)
+{
+    (void)timestamp; (void)inst_table;
     if (!h || !rgb || !depth) return IFX_E_INVALID;
     // caller buffers are borrowed for the call only (EF/ElasticFusion.cpp:280-281 copies them too)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
     memcpy(h->depth_stage, depth, (size_t)h->P * 2);
-    int r = enqueue_frame(h, h->rgb_stage, h->depth_stage, 1, in_pose16, weight_mult);
+    int r = enqueue_frame(h, h->rgb_stage, h->depth_stage, 1, in_pose16, weight_mult, bootstrap);
     if (r) return r;
     r = ifx_sync(h);
     if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
@@ -620,9 +639,12 @@ extern "C" int ifx_tick(ifx_t* h) { return h ? h->tick : IFX_E_INVALID; }
 extern "C" int ifx_trajectory(ifx_t* h, float* out, int max_frames)
 {
     if (!h || !out) return IFX_E_INVALID;
-    int n = std::min(std::min(h->n_traj, max_frames), h->max_traj - 8);
+    // the log is a ring of max_traj frames: the LAST min(frames processed, max_traj, max_frames) poses, oldest first
+    const int n = std::min(std::min(h->n_traj, max_frames), h->max_traj);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->d_traj, (size_t)n * 64, hipMemcpyDeviceToHost));
+    const int first = (h->n_traj - n) % h->max_traj, head = std::min(n, h->max_traj - first);
+    if (head > 0) HIPCHK(h, hipMemcpy(out, h->d_traj + (size_t)first * 16, (size_t)head * 64, hipMemcpyDeviceToHost));
+    if (n > head) HIPCHK(h, hipMemcpy(out + (size_t)head * 16, h->d_traj, (size_t)(n - head) * 64, hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -678,6 +700,9 @@ extern "C" int ifx_map_view(ifx_t* h, ifx_soa_view* out)
 }
 static int read_state(ifx* h, DevState* hs)
 {
+    // every stream that writes the state: the model-to-model tracker (stream_c) leaves its verdict in lc[] / lc_candidates of the main state
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+    if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(hs, h->d_state, sizeof(*hs), hipMemcpyDeviceToHost));
     return IFX_OK;
@@ -739,6 +764,8 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     h->seg_counts_valid = 0;
     h->map_external = 1;
     if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
+    if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
+    if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->pc, pc, (size_t)n * 16, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->nr, nr, (size_t)n * 16, hipMemcpyHostToDevice));

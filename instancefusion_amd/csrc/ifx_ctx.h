@@ -167,8 +167,9 @@ struct ifx {
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned
-    float* d_traj = nullptr;           // [max_traj][16]
+    float* d_traj = nullptr;           // [max_traj][16] ring: frame f's pose lives in slot f % max_traj (ifx_trajectory returns the last max_traj frames)
     int max_traj = 1 << 16;
+    float* d_scratch = nullptr;        // [8][16] poses uploaded by the stage API / inPose / ifx_track_maps (0-1 stage pose + inverse, 2 inPose, 4 track_maps, 6 track_pair)
     int n_traj = 0;
     // map (SoA)
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
@@ -278,7 +279,7 @@ int ifx_knn_vote(ifx* h, int32_t* d_nbr_out);
 int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric
 int ifx_tracker_init_first(ifx* h);
-int ifx_tracker_run_frame(ifx* h, int commit = 1);                            // model pyramid + GN loops (all on device); the frame side is in the slot
+int ifx_tracker_run_frame(ifx* h, int commit = 1, int keep_last = 0);                            // model pyramid + GN loops (all on device); the frame side is in the slot
 int ifx_tracker_commit(ifx* h);                                // publish the pose of a tracker run that was enqueued ahead
 int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
 int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot

@@ -1694,7 +1694,7 @@ static int upload_pose(ifx* h, const float* pose16, float** d_pose, float** d_in
     float buf[32];
     memcpy(buf, pose16, 64);
     pose_inverse(pose16, buf + 16);
-    float* slot = h->d_traj + (size_t)(h->max_traj - 2) * 16;   // scratch at the tail of the log
+    float* slot = h->d_scratch;   // pose + inverse
     HIPCHK(h, hipMemcpyAsync(slot, buf, 128, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *d_pose = slot;

@@ -958,10 +958,10 @@ __device__ void set_so3_matrices(DevState* st, float fx, float fy, float cx, flo
 
 // start of a tracker run (model side): Rprev/tprev from the current pose (:278-311, :388-403), then the seed of the
 // Gauss-Newton loop from the SO(3) result held in the slot's shadow state (:392-403)
-__global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy)
+__global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last)
 {
     if (threadIdx.x != 0) return;
-    for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];
+    if (!keep_last) for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];   // bootstrap: lastPose is the pose before the guess was applied (k_bootstrap_pose)
     for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++) st->Rprev[r * 3 + c] = st->Rcurr[r * 3 + c] = st->pose[r * 4 + c];
         st->tprev[r] = st->tcurr[r] = st->pose[r * 4 + 3];
@@ -1559,7 +1559,7 @@ static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t
 
 // getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603, enqueued without any readback
 // `st` / `p`: the state and pyramids of the tracker instance (frame-to-model: h->d_state / h->pyr; model-to-model: h->d_m2m / h->m2m)
-static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3, float weight_mult, int commit, bool frame_tracker)
+static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3, float weight_mult, int commit, bool frame_tracker, int keep_last = 0)
 {
     const ifx_config& c = h->cfg;
     const int icp = icp_weight > 0, rgb = icp_weight < 100;
@@ -1568,7 +1568,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) if (iterations[i] > 0) { first = i; break; }
     {
         const float div = (float)(1 << (first < 0 ? 0 : first));
-        LAUNCH(h, "track_gn_begin", dim3(1), dim3(64), k_track_gn_begin, st, h->slot[h->cur_slot].so3, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div);
+        LAUNCH(h, "track_gn_begin", dim3(1), dim3(64), k_track_gn_begin, st, h->slot[h->cur_slot].so3, so3, c.fx / div, c.fy / div, c.cx / div, c.cy / div, keep_last);
     }
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
@@ -1642,9 +1642,29 @@ int ifx_tracker_model_side(ifx* h)
     return IFX_OK;
 }
 
-int ifx_tracker_run_frame(ifx* h, int commit)
+int ifx_tracker_run_frame(ifx* h, int commit, int keep_last)
 {
-    tracker_run(h, h->d_state, h->pyr, h->cfg.icp_weight, h->cfg.so3, 1.0f, commit, true);
+    tracker_run(h, h->d_state, h->pyr, h->cfg.icp_weight, h->cfg.so3, 1.0f, commit, true, keep_last);
+    return IFX_OK;
+}
+
+// bootstrap (EF/ElasticFusion.cpp:352-356): currPose = currPose * inPose as the tracker's initial guess; lastPose keeps the pose before it
+__global__ void k_bootstrap_pose(DevState* st, const float* __restrict__ in16)
+{
+    if (threadIdx.x != 0) return;
+    float o[16];
+    for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            float s = 0;
+            for (int k = 0; k < 4; k++) s += st->pose[r * 4 + k] * in16[k * 4 + c];
+            o[r * 4 + c] = s;
+        }
+    for (int k = 0; k < 16; k++) st->pose[k] = o[k];
+}
+int ifx_tracker_bootstrap_pose(ifx* h, const float* d_in_pose16)
+{
+    LAUNCH(h, "bootstrap_pose", dim3(1), dim3(64), k_bootstrap_pose, h->d_state, d_in_pose16);
     return IFX_OK;
 }
 
@@ -1827,7 +1847,7 @@ extern "C" int ifx_track_maps(ifx_t* h, const float* model_v4, const float* mode
     else HIPCHK(h, hipMemsetAsync(h->old_image, 0, P * 4, h->stream));
     if (cur_rgba) HIPCHK(h, hipMemcpyAsync(h->act_image, cur_rgba, P * 4, hipMemcpyHostToDevice, h->stream));
     else HIPCHK(h, hipMemsetAsync(h->act_image, 0, P * 4, h->stream));
-    float* slot = h->d_traj + (size_t)(h->max_traj - 6) * 16;   // scratch at the tail of the trajectory log
+    float* slot = h->d_scratch + 4 * 16;
     HIPCHK(h, hipMemcpyAsync(slot, pose16, 64, hipMemcpyHostToDevice, h->stream));
     DevState* m = h->d_m2m;
     LAUNCH(h, "m2m_prepare", dim3(1), dim3(64), k_m2m_prepare, m, (const float*)slot);
@@ -1960,8 +1980,8 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
     }
     HIPCHK(h, hipMemcpyAsync(h->rgb, rgb, P * 3, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->depth_filt, depth_filtered, P * 2, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_traj, pose16, 64, hipMemcpyHostToDevice, h->stream));   // scratch slot 0 of the log
-    LAUNCH(h, "write_pose", dim3(1), dim3(64), k_write_pose, h->d_state, h->d_traj);
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch + 6 * 16, pose16, 64, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "write_pose", dim3(1), dim3(64), k_write_pose, h->d_state, h->d_scratch + 6 * 16);
     LAUNCH(h, "set_dense", dim3(1), dim3(64), k_set_dense, h->d_state, 1);
     tracker_init_model(h, h->d_state, h->pyr, h->cfg.icp_weight, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image);
     ifx_tracker_frame_side(h, 0);

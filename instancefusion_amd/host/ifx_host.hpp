@@ -196,7 +196,7 @@ public:
     }
 
     // EF/ElasticFusion.h:75-82.  smallInstanceTable (96 x 5) is handed to Ferns::findFrame, whose only writer of it is disabled in the reference.  instanceGT (H x W bytes,
-    // ScanNet ground truth) is stored per new surfel for InstanceFusion::evaluateAndSave.  bootstrap (inPose as an initial guess) is not part of the path.
+    // ScanNet ground truth) is stored per new surfel for InstanceFusion::evaluateAndSave.  bootstrap: inPose is the tracker's initial guess (currPose * inPose), not a replacement.
     void processFrame(const unsigned char* rgb, const unsigned short* depth, const int64_t& timestamp, int* smallInstanceTable,
                       const unsigned char* instanceGT = NULL, const Matrix4f* inPose = 0, const float weightMultiplier = 1.f,
                       const bool bootstrap = false)
@@ -206,9 +206,9 @@ public:
             if (ifx_set_instance_gt(h_, instanceGT) != IFX_OK) throw std::runtime_error(std::string("ifx_set_instance_gt: ") + ifx_last_error(h_));
             hadInstanceGT_ = instanceGT != NULL;
         }
-        if (bootstrap) throw std::runtime_error("ElasticFusion::processFrame: bootstrap is not supported");
-        const int r = ifx_process_frame(h_, rgb, depth, timestamp, inPose ? inPose->data() : nullptr, weightMultiplier, currPose_.data());
-        if (r < 0) throw std::runtime_error(std::string("ifx_process_frame: ") + ifx_last_error(h_));
+        if (bootstrap && !inPose) throw std::runtime_error("ElasticFusion::processFrame: bootstrap needs inPose");   // assert(inPose), EF/ElasticFusion.cpp:354
+        const int r = ifx_process_frame_ex(h_, rgb, depth, timestamp, smallInstanceTable, inPose ? inPose->data() : nullptr, weightMultiplier, bootstrap ? 1 : 0, currPose_.data());
+        if (r < 0) throw std::runtime_error(std::string("ifx_process_frame_ex: ") + ifx_last_error(h_));
         lost_ = (r == 1);
         if (closeLoops_) {   // poseMatches of the reference (EF/ElasticFusion.h:118): here only counted
             float lc[24];

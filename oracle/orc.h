@@ -126,6 +126,9 @@ int orc_map_count(orc_t*);
 void orc_get_pose(orc_t*, float* out16);
 void orc_set_instance_gt(orc_t*, const uint8_t* gt_hw);   /* instanceGT of processFrame: new surfels remember the id under their pixel (vImgCorr.w) */
 int orc_tick(orc_t*);
+void orc_set_bootstrap(orc_t*, int on);
+/* wall-clock per stage since the last reset (ms): track incl. preprocessing | map passes | instance layer */
+void orc_stage_ms(orc_t*, double* out3, int reset);
 /* copy out map fields; any pointer may be NULL.  pc,nr,ic: float4 per surfel; col,tm: float2; votes: 48 floats/surfel */
 void orc_map_download(orc_t*, float* pc, float* nr, float* col, float* tm, float* ic, float* votes);
 void orc_map_upload(orc_t*, int n, const float* pc, const float* nr, const float* col,

@@ -262,6 +262,7 @@ int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth
 {
     int w = o->w, h = o->h, P = w * h, n = o->n;
     if (nm == 0 || n == 0) return 0;
+    const double t_begin = orc_now_ms();
     uint8_t* masks = (uint8_t*)malloc((size_t)nm * P);
     uint8_t* ori = (uint8_t*)malloc((size_t)nm * P);
     memcpy(masks, masks_in, (size_t)nm * P);
@@ -364,6 +365,7 @@ int orc_process_segmentation(orc_t* o, const uint8_t* rgb, const uint16_t* depth
     }
     free(masks); free(ori); free(unavailable); free(maskBBox); free(cmp); free(pdm);
     if (flags & 1) orc_knn_vote(o, NULL); /* isflann, :1051 */
+    o->stage_ms[2] += orc_now_ms() - t_begin;
     return 0;
 }
 

@@ -62,6 +62,8 @@ struct orc {
     uint8_t* inst_gt;   /* instance ground truth of the frames to come (NULL: none) */
     orc_lc_callback lc_cb;
     void* lc_user;
+    int bootstrap_next;          /* processFrame's `bootstrap` for the next frame (EF/ElasticFusion.cpp:334-356) */
+    double stage_ms[3];          /* wall-clock of the stages (track incl. preprocessing | map passes | instance layer): the bench's CPU baseline reads them */
     orc_fern_callback fern_cb;   /* Ferns::findFrame + global deformation of the caller (EF/ElasticFusion.cpp:457-514) */
     void* fern_user;
 };
@@ -74,5 +76,6 @@ void orc_decode_color(float c, float* out3);
 void orc_pose_inverse(const float* p, float* o);
 void orc_instance_init(orc_t* o);
 void orc_instance_free(orc_t* o);
+double orc_now_ms(void);
 
 #endif

@@ -12,6 +12,8 @@
  *     floor(coordinate) clamped to the image (the exact-arithmetic reading of
  *     EF/Shaders/data.vert:137-153 and copy_unstable.vert:110-151 with IndexMap::FACTOR = 1).
  */
+#define _POSIX_C_SOURCE 199309L
+#include <time.h>
 #include "orc.h"
 #include "orc_math.h"
 #include "orc_internal.h"
@@ -155,6 +157,19 @@ void orc_set_instance_gt(orc_t* o, const uint8_t* gt)
     if (gt) { o->inst_gt = (uint8_t*)malloc((size_t)o->P); memcpy(o->inst_gt, gt, (size_t)o->P); }
 }
 int orc_tick(orc_t* o) { return o->tick; }
+/* the `bootstrap` argument of processFrame for the NEXT orc_process_frame call (needs in_pose16) */
+void orc_set_bootstrap(orc_t* o, int on) { o->bootstrap_next = on; }
+double orc_now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+/* wall-clock per stage since the last reset: track (preprocessing + tracker) | map passes | instance layer */
+void orc_stage_ms(orc_t* o, double* out3, int reset)
+{
+    for (int k = 0; k < 3; k++) { out3[k] = o->stage_ms[k]; if (reset) o->stage_ms[k] = 0; }
+}
 
 void orc_map_download(orc_t* o, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
 {
@@ -790,6 +805,8 @@ int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64
 {
     (void)ts;
     int P = o->P;
+    const double t_begin = orc_now_ms();
+    double t_tracked = t_begin;
     memcpy(o->rgb, rgb, (size_t)P * 3);
     memcpy(o->depth_raw, depth, (size_t)P * 2);
     orc_bilateral(o->depth_raw, o->depth_filt, o->w, o->h, o->cfg.depth_cut);
@@ -801,11 +818,23 @@ int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64
     } else {
         float lastPose[16];
         memcpy(lastPose, o->pose, 64);
-        if (!in_pose16) {
+        const int boot = o->bootstrap_next && in_pose16;
+        o->bootstrap_next = 0;
+        if (!in_pose16 || boot) {
             int fill = !dense_enough(o);
             orc_tracker_init_model(o->trk, fill ? o->fill_vertex : o->pred_vertex, fill ? o->fill_normal : o->pred_normal,
                                    fill ? o->fill_image : o->pred_image, o->pose);
             orc_tracker_init_frame(o->trk, o->depth_filt, rgb, o->cfg.max_depth_processed);
+            if (boot) {   /* EF/ElasticFusion.cpp:352-356: currPose = currPose * inPose after the model maps were placed */
+                float g[16];
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) {
+                        float s = 0;
+                        for (int k = 0; k < 4; k++) s += o->pose[r * 4 + k] * in_pose16[k * 4 + c];
+                        g[r * 4 + c] = s;
+                    }
+                memcpy(o->pose, g, 64);
+            }
             orc_tracker_run(o->trk, o->pose, o->cfg.icp_weight, o->cfg.pyramid, o->cfg.fast_odom, o->cfg.so3, o->diag);
         } else memcpy(o->pose, in_pose16, 64);
         /* velocity weighting :433-449 */
@@ -827,6 +856,7 @@ int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64
         if (weighting > largest) weighting = largest;
         weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
         o->last_weighting = weighting;
+        t_tracked = orc_now_ms();
         if (o->lc_enable) loop_closure_local(o);
 
         orc_predict_indices(o, o->pose, o->tick);
@@ -837,6 +867,11 @@ int orc_process_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth, int64
         memcpy(o->ids_after, o->ids_tmp, (size_t)P * 4);
     }
     predict(o);
+    {
+        const double t_end = orc_now_ms();
+        o->stage_ms[0] += t_tracked - t_begin;
+        o->stage_ms[1] += t_end - t_tracked;
+    }
     if (out_pose16) memcpy(out_pose16, o->pose, 64);
     o->tick++;
     return 0;

@@ -22,3 +22,7 @@ void orc_set_frame(orc_t* o, const uint8_t* rgb, const uint16_t* depth)
 
 /* copies an id image into ids_after (lets tests drive the instance layer from a chosen id render) */
 void orc_set_ids_after(orc_t* o, const int32_t* ids) { memcpy(o->ids_after, ids, (size_t)o->P * 4); }
+
+/* number of OpenMP threads for the oracle's parallel loops (bench.py's cpu_baseline: one core / all cores) */
+#include <omp.h>
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }

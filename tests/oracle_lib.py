@@ -81,6 +81,12 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads the oracle's parallel loops use from now on (results do not depend on it)."""
+    lib().orc_set_threads.argtypes = [C.c_int]
+    lib().orc_set_threads(int(n))
+
+
 def ptr(a):
     if a is None:
         return None
@@ -116,7 +122,10 @@ class Oracle:
     def __del__(self):
         self.close()
 
-    def process_frame(self, rgb, depth, ts=0, in_pose=None, weight_mult=1.0):
+    def process_frame(self, rgb, depth, ts=0, in_pose=None, weight_mult=1.0, bootstrap=False):
+        if bootstrap:
+            self.L.orc_set_bootstrap.argtypes = [C.c_void_p, C.c_int]
+            self.L.orc_set_bootstrap(self.h, 1)
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16)
         out = np.zeros(16, np.float32)
@@ -143,6 +152,13 @@ class Oracle:
         n = m["pc"].shape[0]
         a = {k: np.ascontiguousarray(m[k], np.float32) for k in ("pc", "nr", "col", "tm", "ic", "votes")}
         self.L.orc_map_upload(self.h, n, ptr(a["pc"]), ptr(a["nr"]), ptr(a["col"]), ptr(a["tm"]), ptr(a["ic"]), ptr(a["votes"]))
+
+    def stage_ms(self, reset=False):
+        """wall-clock per stage since the last reset: track (preprocessing + tracker) | fuse (map passes) | instance"""
+        out = (C.c_double * 3)()
+        self.L.orc_stage_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L.orc_stage_ms(self.h, out, int(reset))
+        return dict(track=out[0], fuse=out[1], instance=out[2])
 
     def get_pose(self):
         out = np.zeros(16, np.float32)

@@ -258,7 +258,9 @@ def test_end_to_end_sequence(ifx, orc, small_stream):
     assert np.array_equal(ids_o, ids_g)
     # run one more frame with the pose held fixed so that both refresh ids_after from the same state
     pg = g.processFrame(st["rgb"][9], st["depth"][9], inPose=pose); po2 = o.process_frame(st["rgb"][9], st["depth"][9], in_pose=pose)
-    assert np.array_equal(g.image("ids_after"), o.image("ids_after")) or (g.image("ids_after") != o.image("ids_after")).mean() < 0.002
+    # identical map, identical pose, identical frame: the precondition of the exact label comparison below is asserted, not assumed
+    assert g.count == o.count
+    assert np.array_equal(g.image("ids_after"), o.image("ids_after"))
     masks, cls = synth.canned_masks(st["obj"][9], st["scene"])
     assert inst.whetherDoSegmentation(100) == o.should_segment(100)
     for frame in (100, 103):
@@ -266,13 +268,36 @@ def test_end_to_end_sequence(ifx, orc, small_stream):
         o.process_segmentation(st["rgb"][9], st["depth"][9], masks, cls, frame)
         assert np.array_equal(inst.getInstanceTable(), o.instance_table())
         lg, lo = inst.labels(), o.labels()
-        if g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after")):
-            assert np.array_equal(lg, lo)                      # exact integer match of the instance IDs
-            assert np.array_equal(g.download()["votes"], o.download()["votes"])
-        else:
-            assert abs(len(lg) - len(lo)) <= 4
+        assert np.array_equal(lg, lo)                      # exact integer match of the instance IDs
+        assert np.array_equal(g.download()["votes"], o.download()["votes"])
     assert (lo >= 0).sum() > 100
     assert np.array_equal(inst.maskCleanOverlap(masks), _clean(orc, masks))
+    g.close(); o.close()
+
+
+def test_bootstrap_pose_guess(ifx, orc, small_stream):
+    """processFrame(..., inPose, bootstrap=true), EF/ElasticFusion.cpp:334-356: inPose is the tracker's initial guess
+    (currPose * inPose), the model maps keep the old pose, the velocity weighting compares with the pose before the guess."""
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    for i in range(4):
+        pg = g.processFrame(st["rgb"][i], st["depth"][i]); po = o.process_frame(st["rgb"][i], st["depth"][i])
+    # the true relative motion of the next frame as the guess, slightly off
+    rel = (np.linalg.inv(st["poses"][3].astype(np.float64)) @ st["poses"][4].astype(np.float64)).astype(np.float32)
+    rel[:3, 3] += np.float32([0.002, -0.001, 0.0015])
+    pg = g.processFrame(st["rgb"][4], st["depth"][4], inPose=rel, bootstrap=True)
+    po = o.process_frame(st["rgb"][4], st["depth"][4], in_pose=rel, bootstrap=True)
+    assert np.abs(pg - po).max() < 1e-4
+    assert np.abs(pg - st["poses"][4]).max() < 0.02                      # it tracked (a replaced pose would equal pose3 * rel exactly)
+    assert np.abs(pg - (st["poses"][3] @ rel)).max() > 1e-6
+    # the frames that follow are unaffected by the mode
+    pg = g.processFrame(st["rgb"][5], st["depth"][5]); po = o.process_frame(st["rgb"][5], st["depth"][5])
+    assert np.abs(pg - po).max() < 1e-4
+    assert abs(g.count - o.count) <= max(4, o.count // 2000)
+    with pytest.raises(ifx.IfxError):
+        g.processFrame(st["rgb"][6], st["depth"][6], bootstrap=True)     # assert(inPose) in the reference
     g.close(); o.close()
 
 

@@ -44,6 +44,7 @@ void orc_bilateral(const uint16_t* in, uint16_t* out, int w, int h, float maxD)
 void orc_metric(const uint16_t* in, float* out, int w, int h, float maxD)
 {
     const uint32_t maxv = (uint32_t)(maxD * 1000.0f);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < w * h; i++) {
         uint32_t v = in[i];
         out[i] = (v > maxv || v < 300u) ? 0.0f : (float)v / 1000.0f;
@@ -59,6 +60,7 @@ void orc_pyrdown_u16(const uint16_t* src, int sw, int sh, uint16_t* dst)
     const float sigma_color = 30;
     const float weights[3] = {0.375f, 0.25f, 0.0625f};
     int dw = sw / 2, dh = sh / 2;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             int center = src[(2 * y) * sw + 2 * x];
@@ -82,6 +84,7 @@ void orc_vmap(const uint16_t* depth, int w, int h, float fx, float fy, float cx,
               float cutoff, float* vmap)
 {
     float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
+#pragma omp parallel for schedule(static)
     for (int v = 0; v < h; v++)
         for (int u = 0; u < w; u++) {
             float z = depth[v * w + u] / 1000.f;
@@ -102,6 +105,7 @@ void orc_vmap(const uint16_t* depth, int w, int h, float fx, float fy, float cx,
 /* computeNmapKernel, EF/Cuda/cudafuncs.cu:151-188 */
 void orc_nmap(const float* vmap, int w, int h, float* nmap)
 {
+#pragma omp parallel for schedule(static)
     for (int v = 0; v < h; v++)
         for (int u = 0; u < w; u++) {
             float* nx = &nmap[v * w + u];
@@ -129,6 +133,7 @@ void orc_nmap(const float* vmap, int w, int h, float* nmap)
 /* copyMapsKernel, EF/Cuda/cudafuncs.cu:270-310 */
 void orc_copy_maps(const float* v4, const float* n4, int w, int h, float* vmap, float* nmap)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const float* vs = &v4[(y * w + x) * 4];
@@ -145,6 +150,7 @@ void orc_copy_maps(const float* v4, const float* n4, int w, int h, float* vmap, 
 void orc_resize_map(const float* in, int sw, int sh, float* out, int normalize)
 {
     int dw = sw / 2, dh = sh / 2;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             int xs = x * 2, ys = y * 2;
@@ -172,6 +178,7 @@ void orc_resize_map(const float* in, int sw, int sh, float* out, int normalize)
 /* tranformMapsKernel (in place), EF/Cuda/cudafuncs.cu:206-248 */
 void orc_transform_maps(float* vmap, float* nmap, int w, int h, const float* R, const float* t)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float* px[3] = {&vmap[y * w + x], &vmap[(y + h) * w + x], &vmap[(y + 2 * h) * w + x]};
@@ -190,6 +197,7 @@ void orc_transform_maps(float* vmap, float* nmap, int w, int h, const float* R, 
 /* verticesToDepthKernel, EF/Cuda/cudafuncs.cu:526-537 */
 void orc_vertices_to_depth(const float* v4, int w, int h, float cutoff, float* d)
 {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < w * h; i++) {
         float z = v4[i * 4 + 2];
         d[i] = (z > cutoff || z <= 0) ? orc_qnan() : z;
@@ -203,6 +211,7 @@ void orc_pyrdown_gauss_f(const float* src, int sw, int sh, float* dst)
 {
     const int D = 5;
     int dw = sw / 2, dh = sh / 2;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             int tx = imin(2 * x - D / 2 + D, sw - 1), ty = imin(2 * y - D / 2 + D, sh - 1);
@@ -226,6 +235,7 @@ void orc_pyrdown_gauss_u8(const uint8_t* src, int sw, int sh, uint8_t* dst)
 {
     const int D = 5;
     int dw = sw / 2, dh = sh / 2;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             int tx = imin(2 * x - D / 2 + D, sw - 1), ty = imin(2 * y - D / 2 + D, sh - 1);
@@ -248,6 +258,7 @@ void orc_pyrdown_gauss_u8(const uint8_t* src, int sw, int sh, uint8_t* dst)
  * .x=R .y=G .z=B and the "BGR" weights are applied to RGB order, as in the reference. */
 void orc_rgb_to_intensity(const uint8_t* rgb, int stride, int n, uint8_t* dst)
 {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) {
         const uint8_t* s = rgb + (size_t)i * stride;
         int value = (int)((float)s[0] * 0.114f + (float)s[1] * 0.299f + (float)s[2] * 0.587f);
@@ -260,6 +271,7 @@ void orc_sobel(const uint8_t* img, int w, int h, int16_t* dx, int16_t* dy)
 {
     static const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
     static const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float dxVal = 0, dyVal = 0;
@@ -280,6 +292,7 @@ void orc_project_cloud(const float* depth, int w, int h, float fx, float fy, flo
                        float* cloud3)
 {
     float invFx = 1.0f / fx, invFy = 1.0f / fy;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float z = depth[y * w + x];
@@ -310,11 +323,13 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
                   float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
                   float dist_thres, float angle_thres, int w, int h, float* out29)
 {
-    double acc[29];
-    for (int i = 0; i < 29; i++) acc[i] = 0;
+    /* one f64 partial sum per image row, rows added in order: the same result for any number of OpenMP threads */
+    double (*racc)[29] = (double (*)[29])calloc((size_t)h, sizeof(double[29]));
     v3 tc = v3m(tcurr[0], tcurr[1], tcurr[2]), tp = v3m(tprev[0], tprev[1], tprev[2]);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
+            double* acc = racc[y];
             float row[7] = {0, 0, 0, 0, 0, 0, 0};
             int found = 0;
             v3 vcurr = v3m(vmap_curr[y * w + x], vmap_curr[(y + h) * w + x], vmap_curr[(y + 2 * h) * w + x]);
@@ -344,7 +359,12 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
             }
             accum_products7(row, found, acc);
         }
-    for (int i = 0; i < 29; i++) out29[i] = (float)acc[i];
+    double tot[29];
+    for (int i = 0; i < 29; i++) tot[i] = 0;
+    for (int y = 0; y < h; y++)
+        for (int i = 0; i < 29; i++) tot[i] += racc[y][i];
+    for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
+    free(racc);
 }
 
 /* RGBResidual::getProducts, EF/Cuda/reduce.cu:768-842 */
@@ -355,6 +375,7 @@ void orc_rgb_residual(float min_scale, const int16_t* didx, const int16_t* didy,
 {
     const int border = 16;
     int cnt = 0, sig = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cnt, sig)
     for (int i = 0; i < h; i++)
         for (int j0 = 0; j0 < w; j0++) {
             orc_dataterm c;
@@ -400,9 +421,10 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
                   const int16_t* didx, const int16_t* didy, float sobel_scale, int w, int h,
                   float* out29)
 {
-    double acc[29];
-    for (int i = 0; i < 29; i++) acc[i] = 0;
+    double (*racc)[29] = (double (*)[29])calloc((size_t)h, sizeof(double[29]));   /* per-row partial sums, as orc_icp_step */
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < w * h; k++) {
+        double* acc = racc[k / w];
         const orc_dataterm* c = &corres[k];
         float row[7] = {0, 0, 0, 0, 0, 0, 0};
         if (c->valid) {
@@ -424,17 +446,23 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
         }
         accum_products7(row, c->valid, acc);
     }
-    for (int i = 0; i < 29; i++) out29[i] = (float)acc[i];
+    double tot[29];
+    for (int i = 0; i < 29; i++) tot[i] = 0;
+    for (int y = 0; y < h; y++)
+        for (int i = 0; i < 29; i++) tot[i] += racc[y][i];
+    for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
+    free(racc);
 }
 
 /* SO3Reduction::getProducts, EF/Cuda/reduce.cu:954-1055 */
 void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float* ib,
                   const float* kinv, const float* krlr, int w, int h, float* out11)
 {
-    double acc[11];
-    for (int i = 0; i < 11; i++) acc[i] = 0;
+    double (*racc)[11] = (double (*)[11])calloc((size_t)h, sizeof(double[11]));   /* per-row partial sums, as orc_icp_step */
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
+            double* acc = racc[y];
             v3 up = v3m((float)x, (float)y, 1.0f);
             v3 wp = m33mul(ib, up);
             int wx = orc_f2i_rn(wp.x / wp.z), wy = orc_f2i_rn(wp.y / wp.z);
@@ -461,7 +489,12 @@ void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float*
             acc[9] += (double)(row[3] * row[3]);
             acc[10] += found ? 1.0 : 0.0;
         }
-    for (int i = 0; i < 11; i++) out11[i] = (float)acc[i];
+    double tot[11];
+    for (int i = 0; i < 11; i++) tot[i] = 0;
+    for (int y = 0; y < h; y++)
+        for (int i = 0; i < 11; i++) tot[i] += racc[y][i];
+    for (int i = 0; i < 11; i++) out11[i] = (float)tot[i];
+    free(racc);
 }
 
 /* ======================================================================= tracker object (a3,a8) */

@@ -423,8 +423,9 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
 {
     double (*racc)[29] = (double (*)[29])calloc((size_t)h, sizeof(double[29]));   /* per-row partial sums, as orc_icp_step */
 #pragma omp parallel for schedule(static)
-    for (int k = 0; k < w * h; k++) {
-        double* acc = racc[k / w];
+    for (int y = 0; y < h; y++)
+    for (int k = y * w; k < (y + 1) * w; k++) {   /* a row belongs to one thread: its partial sum is built in pixel order */
+        double* acc = racc[y];
         const orc_dataterm* c = &corres[k];
         float row[7] = {0, 0, 0, 0, 0, 0, 0};
         if (c->valid) {

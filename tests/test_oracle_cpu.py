@@ -535,3 +535,20 @@ def test_render_project_map_properties(orc, small_stream):
     assert np.array_equal(pm[vis][:, 0], ((c >> 16) & 255).astype(np.float32) / np.float32(255)) and np.array_equal(pm[vis][:, 2], (c & 255).astype(np.float32) / np.float32(255))
     assert (pm[vis][:, :3].sum(axis=1) > 0).any()
     o.close()
+
+
+def test_oracle_does_not_depend_on_thread_count(orc, small_stream):
+    """The oracle's OpenMP loops keep a fixed summation layout (one f64 partial per image row, rows added in order): poses and maps
+    are bit-identical for any number of threads, also oversubscribed ones whose chunk borders fall inside rows."""
+    st = small_stream
+    out = {}
+    for th in (1, 3, 32):
+        orc.set_threads(th)
+        o = orc.Oracle(**SMALL, max_surfels=400000)
+        poses = np.stack([o.process_frame(st["rgb"][i], st["depth"][i]).copy() for i in range(4)])
+        out[th] = (poses, o.download())
+        o.close()
+    orc.set_threads(1)
+    for th in (3, 32):
+        assert np.array_equal(out[th][0], out[1][0]), th
+        assert all(np.array_equal(out[th][1][k], out[1][1][k]) for k in out[1][1]), th

@@ -341,7 +341,7 @@ def main():
         import oracle_lib as ol
 
         n_cpu = min(args.surfels, 5_000_000)
-        ncores = os.cpu_count() or 1
+        ncores = ol.usable_cores()                           # affinity capped by the cgroup quota (the GPU box shows 256 CPUs and grants 16)
         cpu_map = synth.make_map(n_cpu, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7)
 
         def cpu_leg(threads, frames):

@@ -69,7 +69,7 @@ struct Pyr {
     float* last_depth[IFX_NUM_PYRS];                          // == next_depth in the frame-to-model tracker (reference quirk)
     float* next_depth[IFX_NUM_PYRS] = {};                     // model-to-model tracker only (nullptr: last_depth)
     // reduction scratch of this tracker instance (the two instances can be on the GPU at the same time)
-    float *icp_partials = nullptr, *rgb_partials = nullptr;
+    double* acc = nullptr;                                    // exact accumulator rows of this tracker instance: [3 quantities: icp, rgb, so3][IFX_ACC_REPL replicas][IFX_ACC_STRIDE] f64, all zero between launches
     int* res_partials = nullptr;
     unsigned int* ticket = nullptr;                           // [0] last-block ticket of k_rgb_step_solve, [8..9] residual totals
     uint8_t *last_img[IFX_NUM_PYRS], *next_img[IFX_NUM_PYRS], *lastnext_img[IFX_NUM_PYRS];
@@ -207,10 +207,7 @@ struct ifx {
     float *meas_pc = nullptr, *meas_nr = nullptr, *meas_col = nullptr;
     // tracker
     Pyr pyr;
-    float* icp_partials = nullptr;  // [blocks][32]
-    float* rgb_partials = nullptr;
     int* res_partials = nullptr;    // [blocks][2]
-    float* so3_partials = nullptr;  // [blocks][12]
     float* d_out29 = nullptr;
     int res_rows = 1024;                // rows of res_partials (blocks of the residual pass)
     unsigned int* d_ticket = nullptr;   // last-block ticket of k_rgb_step_solve

@@ -157,6 +157,36 @@ __device__ inline int wave_sum_i(int v)
     return v;
 }
 
+// ---- exact, order-independent sums of the tracker's normal equations (DESIGN.md "Arithmetic contract").
+// Every f32 product that enters one of the 29 (11) sums is first rounded to a fixed grid 2^g (g per entry class, chosen so
+// that a term spans at most 32 bits above the grid for the magnitudes the tracker sees) and the sums run in f64: all partial
+// sums are integers in units of the grid and stay below 2^53 of them, so every addition is exact and the total does not
+// depend on the order -- thread, wave, block, atomic arrival or OpenMP chunk.  oracle/orc_math.h holds the same tables; the
+// HIP path and the CPU oracle therefore produce bit-identical sums (the reference's own f32 tree depends on a per-GPU launch
+// configuration, EF/Utils/GPUConfig.h:53-137, so there is no single reference order to reproduce).
+__host__ __device__ constexpr double ifx_pow2(int e)
+{
+    double r = 1.0;
+    for (int i = 0; i < (e < 0 ? -e : e); i++) r = e < 0 ? r * 0.5 : r * 2.0;
+    return r;
+}
+// (t + M) - M rounds t to a multiple of 2^g (round to nearest even) while |t| < 2^(51 + g)
+__host__ __device__ constexpr double ifx_magic(int g) { return 1.5 * ifx_pow2(52 + g); }
+__host__ __device__ inline double ifx_quant(float p, double M)
+{
+    double t = (double)p;
+    t = t + M;
+    return t - M;
+}
+#define IFX_EXACT_TERM_BITS 32
+// binary exponents of the row entries' working range: ICP row = (n', s' x n', r), RGB row = (v0, v1, v2, rotational part, r), SO(3) row = (jr, r)
+#define IFX_E_ICP {0, 0, 0, 4, 4, 4, -3}
+#define IFX_E_RGB {11, 11, 11, 13, 13, 13, 3}
+#define IFX_E_SO3 {16, 16, 16, 8}
+#define IFX_SO3_TERM_BITS 38
+#define IFX_ACC_REPL 4       // replicas of a global accumulator row (same-address atomics queue up at the memory side)
+#define IFX_ACC_STRIDE 32    // doubles per replica row (256 B: a row per cache line pair)
+
 // order-preserving map float -> uint for atomicMin depth keys (depths are >= 0 here but be general)
 __device__ inline unsigned int depth_bits(float z)
 {

@@ -307,39 +307,74 @@ __global__ void k_model_down(const DevState* __restrict__ st, const float* __res
 #define RED_THREADS 256
 #define RED_WAVES (RED_THREADS / 64)
 
-// Block reduction of NV floats per thread: wave64 shuffle tree, one LDS row per wave, the first
-// NV threads add the rows in wave order and store the block partial.
-template <int NV, bool WRITE_THROUGH = false>
-__device__ inline void block_reduce_store(float* acc, float* __restrict__ out /* [NV] for this block */)
+// Exact block sum of NV doubles per thread (grid-valued terms, see ifx_dev.h): quads by DPP, 64 quad sums per value through
+// LDS, eight partial sums per value, then ONE f64 atomic add per value and block into replica `rep` of the global accumulator
+// row.  Every addition is exact, so neither the tree shape nor the arrival order of the atomics matters.
+__device__ __forceinline__ double dpp_quad_sum_d(double v)
 {
-    __shared__ float lds[RED_WAVES][NV];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    {   // quad_perm [1,0,3,2]
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+        v += __hiloint2double(hi, lo);
+    }
+    {   // quad_perm [2,3,0,1]
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, true);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void block_sum_exact(const double* acc, double* __restrict__ gacc, int rep)
+{
+    __shared__ double lds[NV][RED_THREADS / 4 + 2];
+    __shared__ double part[NV][8];
+    const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        float v = wave_sum_last(acc[k]);
-        if (lane == 63) lds[wid][k] = v;
+        const double q = dpp_quad_sum_d(acc[k]);
+        if ((t & 3) == 0) lds[k][t >> 2] = q;
     }
     __syncthreads();
-    if (threadIdx.x < NV) {
-        float s = 0;
+    if (t < NV * 8) {
+        const int k = t >> 3, p = t & 7;
+        double s = 0;
 #pragma unroll
-        for (int wv = 0; wv < RED_WAVES; wv++) s += lds[wv][threadIdx.x];
-        // WRITE_THROUGH: sc1 store for rows another block of the SAME launch reads (no release fence needed,
-        // cdna_hip_programming.md section 5 "In-launch split-K reduction", sc1 variant)
-        if (WRITE_THROUGH) __hip_atomic_store(&out[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[threadIdx.x] = s;
+        for (int j = 0; j < 8; j++) s += lds[k][p * 8 + ((j + p) & 7)];
+        part[k][p] = s;
+    }
+    __syncthreads();
+    if (t < NV) {
+        double s = 0;
+#pragma unroll
+        for (int p = 0; p < 8; p++) s += part[t][p];
+        if (s != 0.0) unsafeAtomicAdd(&gacc[rep * IFX_ACC_STRIDE + t], s);   // global_atomic_add_f64, no return
     }
 }
-
-__device__ inline void products7(const float* row, bool found, float* acc)
+// the accumulator rows of one quantity, read by the block that finishes last (agent-scope loads: the adds were performed at the memory side)
+__device__ __forceinline__ double acc_total(const double* gacc, int k)
 {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < IFX_ACC_REPL; r++) s += __hip_atomic_load(&gacc[r * IFX_ACC_STRIDE + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
+}
+__device__ __forceinline__ void acc_clear(double* gacc, int k)
+{
+#pragma unroll
+    for (int r = 0; r < IFX_ACC_REPL; r++) __hip_atomic_store(&gacc[r * IFX_ACC_STRIDE + k], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// KIND 0: ICP row, 1: photometric row
+template <int KIND>
+__device__ __forceinline__ void products7(const float* row, bool found, double* acc)
+{
+    constexpr int E[2][7] = {IFX_E_ICP, IFX_E_RGB};
     int s = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 7; j++) acc[s++] += row[i] * row[j];
-    acc[27] += row[6] * row[6];
-    acc[28] += found ? 1.0f : 0.0f;
+        for (int j = i; j < 7; j++) acc[s++] += ifx_quant(row[i] * row[j], ifx_magic(E[KIND][i] + E[KIND][j] - IFX_EXACT_TERM_BITS));
+    acc[27] += ifx_quant(row[6] * row[6], ifx_magic(2 * E[KIND][6] - IFX_EXACT_TERM_BITS));
+    acc[28] += found ? 1.0 : 0.0;
 }
 
 // Every reduction body handles IT pixels per thread in four straight-line stages -- coalesced
@@ -368,7 +403,7 @@ struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
 template <bool WT = false>
 __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __restrict__ st, const IcpArgs& ex, const float* __restrict__ vmap_curr,
                                          const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx,
-                                         float fy, float cx, float cy, float distThres, float angleThres, int w, int h, float* __restrict__ partials)
+                                         float fy, float cx, float cy, float distThres, float angleThres, int w, int h, double* __restrict__ gacc)
 {
     const float* Rc = st ? st->Rcurr : ex.Rcurr;
     const float* tcp = st ? st->tcurr : ex.tcurr;
@@ -378,9 +413,9 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
 #pragma unroll
     for (int k = 0; k < 9; k++) { Rcurr[k] = Rc[k]; Rprev_inv[k] = Rpi[k]; }
     const v3 tc = v3m(tcp[0], tcp[1], tcp[2]), tp = v3m(tpp[0], tpp[1], tpp[2]);
-    float acc[29];
+    double acc[29];
 #pragma unroll
-    for (int k = 0; k < 29; k++) acc[k] = 0.f;
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
     const int N = w * h;
     for (int base = bid * (blockDim.x * RED_IT) + threadIdx.x; base < N; base += nblk * blockDim.x * RED_IT) {
         v3 vcurr[RED_IT], ncurr[RED_IT], vprev[RED_IT], nprev[RED_IT], vcurr_g[RED_IT];
@@ -428,17 +463,17 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
                     row[6] = dot(n_cp, s_cp - d_cp);
                 }
             }
-            products7(row, found, acc);
+            products7<0>(row, found, acc);
         }
     }
-    block_reduce_store<29, WT>(acc, partials + (size_t)bid * 32);
+    block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
                                                      const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
                                                      const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy, float distThres,
-                                                     float angleThres, int w, int h, float* __restrict__ partials)
+                                                     float angleThres, int w, int h, double* __restrict__ gacc)
 {
-    icp_body(blockIdx.x, gridDim.x, st, ex, vmap_curr, nmap_curr, vmap_prev, nmap_prev, fx, fy, cx, cy, distThres, angleThres, w, h, partials);
+    icp_body(blockIdx.x, gridDim.x, st, ex, vmap_curr, nmap_curr, vmap_prev, nmap_prev, fx, fy, cx, cy, distThres, angleThres, w, h, gacc);
 }
 
 // 8-byte correspondence record (the reference's DataTerm is 16 B, EF/Cuda/types.cuh:75-81: `one`
@@ -549,7 +584,7 @@ struct PairArgs {
     const uint8_t *lastImage, *nextImage;
     Corres8* corres;
     int w, h, nb_icp, nb_res;
-    float* icp_partials;
+    double* icp_acc;
     int* res_partials;
     int* res_total;
     int check_skip;
@@ -559,7 +594,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
     if (a.check_skip && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
     if ((int)blockIdx.x < a.nb_icp) {
         IcpArgs ia;   // unused when st != nullptr
-        icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_partials);
+        icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_acc);
     } else {
         ResArgs ra;
         residual_body(blockIdx.x - a.nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, a.w,
@@ -571,7 +606,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
 // residual pass's block partials with the reference's precedence quirk (EF/Utils/RGBDOdometry.cpp:461).
 __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
                                               int res_blocks, const float* __restrict__ cloud, float fx, float fy, const int16_t* __restrict__ dIdx,
-                                              const int16_t* __restrict__ dIdy, float sobelScale, int w, int h, float* __restrict__ partials, const int* __restrict__ res_total = nullptr)
+                                              const int16_t* __restrict__ dIdy, float sobelScale, int w, int h, double* __restrict__ gacc, const int* __restrict__ res_total = nullptr)
 {
 #ifdef IFX_STAMPS
     long long ts_local[3]; long long ts_start = clock64();
@@ -607,9 +642,9 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
 #ifdef IFX_STAMPS
     g_ts[0] = clock64();
 #endif
-    float acc[29];
+    double acc[29];
 #pragma unroll
-    for (int k = 0; k < 29; k++) acc[k] = 0.f;
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
     for (int base = base0; base < N; base += nblk * blockDim.x * RED_IT_RGB) {
         Corres8 c[RED_IT_RGB];
         float X[RED_IT_RGB], Y[RED_IT_RGB], Z[RED_IT_RGB];
@@ -648,13 +683,13 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
                 row[4] = Z[u] * v0 - X[u] * v2;
                 row[5] = -Y[u] * v0 + X[u] * v1;
             }
-            products7(row, found, acc);
+            products7<1>(row, found, acc);
         }
     }
 #ifdef IFX_STAMPS
     g_ts[1] = clock64();
 #endif
-    block_reduce_store<29, true>(acc, partials + (size_t)bid * 32);
+    block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
 #ifdef IFX_STAMPS
     g_ts[2] = clock64();
     if (threadIdx.x == 0) { s_dbg_blk[0] = ts_local[0] - ts_start; s_dbg_blk[1] = ts_local[1] - ts_local[0]; s_dbg_blk[2] = ts_local[2] - ts_local[1]; }
@@ -663,9 +698,9 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step(const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
                                                           int res_blocks, const float* __restrict__ cloud, float fx, float fy,
                                                           const int16_t* __restrict__ dIdx, const int16_t* __restrict__ dIdy, float sobelScale, int w, int h,
-                                                          float* __restrict__ partials)
+                                                          double* __restrict__ gacc)
 {
-    rgb_step_body(blockIdx.x, gridDim.x, corres, sigma_explicit, res_partials, res_blocks, cloud, fx, fy, dIdx, dIdy, sobelScale, w, h, partials);
+    rgb_step_body(blockIdx.x, gridDim.x, corres, sigma_explicit, res_partials, res_blocks, cloud, fx, fy, dIdx, dIdy, sobelScale, w, h, gacc);
 }
 
 // SO3Reduction, EF/Cuda/reduce.cu:938-1076
@@ -679,7 +714,7 @@ __device__ inline float grady(const uint8_t* img, int w, int px, int py)
     return (((float)img[(py - 1) * w + px] + (float)img[py * w + px]) / 2.0f) - (((float)img[(py + 1) * w + px] + (float)img[py * w + px]) / 2.0f);
 }
 __device__ __forceinline__ void so3_body(int bid, int nblk, const DevState* __restrict__ st, const So3Args& ex, const uint8_t* __restrict__ lastImage,
-                                         const uint8_t* __restrict__ nextImage, int w, int h, float* __restrict__ partials)
+                                         const uint8_t* __restrict__ nextImage, int w, int h, double* __restrict__ gacc)
 {
     const float* ibp = st ? st->imageBasis : ex.ib;
     const float* kip = st ? st->kinv : ex.kinv;
@@ -687,9 +722,10 @@ __device__ __forceinline__ void so3_body(int bid, int nblk, const DevState* __re
     float ib[9], kinv[9], krlr[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) { ib[k] = ibp[k]; kinv[k] = kip[k]; krlr[k] = krp[k]; }
-    float acc[11];
+    double acc[11];
 #pragma unroll
-    for (int k = 0; k < 11; k++) acc[k] = 0.f;
+    for (int k = 0; k < 11; k++) acc[k] = 0.0;
+    constexpr int E[4] = IFX_E_SO3;
     const int N = w * h;
     for (int k = bid * blockDim.x + threadIdx.x; k < N; k += blockDim.x * nblk) {
         int y = k / w, x = k - y * w;
@@ -715,17 +751,17 @@ __device__ __forceinline__ void so3_body(int bid, int nblk, const DevState* __re
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = i; j < 4; j++) acc[s++] += row[i] * row[j];
-        acc[9] += row[3] * row[3];
-        acc[10] += found ? 1.0f : 0.0f;
+            for (int j = i; j < 4; j++) acc[s++] += ifx_quant(row[i] * row[j], ifx_magic(E[i] + E[j] - IFX_SO3_TERM_BITS));
+        acc[9] += ifx_quant(row[3] * row[3], ifx_magic(2 * E[3] - IFX_SO3_TERM_BITS));
+        acc[10] += found ? 1.0 : 0.0;
     }
-    block_reduce_store<11, true>(acc, partials + (size_t)bid * 12);
+    block_sum_exact<11>(acc, gacc, bid % IFX_ACC_REPL);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict__ st, So3Args ex, const uint8_t* __restrict__ lastImage,
-                                                     const uint8_t* __restrict__ nextImage, int w, int h, float* __restrict__ partials)
+                                                     const uint8_t* __restrict__ nextImage, int w, int h, double* __restrict__ gacc)
 {
     if (st && st->so3_done) return;   // block-uniform early exit once the host-free loop has converged
-    so3_body(blockIdx.x, gridDim.x, st, ex, lastImage, nextImage, w, h, partials);
+    so3_body(blockIdx.x, gridDim.x, st, ex, lastImage, nextImage, w, h, gacc);
 }
 
 // ======================================================================= device-side solve (a8)
@@ -997,19 +1033,16 @@ __global__ void k_so3_begin(DevState* st, float fx2, float fy2, float cx2, float
 }
 
 __device__ __forceinline__ void so3_update_scalar(DevState* st, const float* o, float fx2, float fy2, float cx2, float cy2);
-// one SO(3) iteration's host logic, EF/Utils/RGBDOdometry.cpp:348-380, executed by one wave
-// (fixed-order f64 sums of the block partials by shuffle; lane 0 then runs the scalar logic)
-__device__ __forceinline__ void so3_update_wave(DevState* st, const float* __restrict__ partials, int blocks, float fx2, float fy2, float cx2, float cy2)
+// one SO(3) iteration's host logic, EF/Utils/RGBDOdometry.cpp:348-380: the 11 exact totals are read from the accumulator rows
+// (and the rows cleared for the next launch), lane 0 then runs the scalar logic
+__device__ __forceinline__ void so3_update_wave(DevState* st, double* __restrict__ gacc, float fx2, float fy2, float cx2, float cy2)
 {
     const int lane = threadIdx.x & 63;
+    double v = 0;
+    if (lane < 11) { v = acc_total(gacc, lane); acc_clear(gacc, lane); }
     float o[11];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        double v = 0;
-        for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 12 + k];
-        v = wave_sum_d(v);
-        o[k] = (float)v;
-    }
+    for (int k = 0; k < 11; k++) o[k] = (float)__shfl(v, k, 64);
     if (lane != 0) return;
     so3_update_scalar(st, o, fx2, fy2, cx2, cy2);
 }
@@ -1048,15 +1081,15 @@ __device__ __forceinline__ void so3_update_scalar(DevState* st, const float* o, 
 
 // SO(3) reduction + (last block) update in one launch; same hand-off as k_rgb_step_solve.
 __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int w, int h,
-                                                           float* __restrict__ partials, int nb, unsigned int* ticket, float fx2, float fy2, float cx2, float cy2)
+                                                           double* __restrict__ gacc, int nb, unsigned int* ticket, float fx2, float fy2, float cx2, float cy2)
 {
     __shared__ int s_last;
     if (st->so3_done) return;
     So3Args ex;
-    so3_body(blockIdx.x, nb, st, ex, lastImage, nextImage, w, h, partials);
+    so3_body(blockIdx.x, nb, st, ex, lastImage, nextImage, w, h, gacc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {   // partial rows were stored sc1 and every wave drained vmcnt before the barrier
+    if (threadIdx.x == 0) {   // this block's atomic adds were performed at the memory side: every wave drained vmcnt before the barrier
         unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (unsigned int)(nb - 1));
     }
@@ -1068,91 +1101,49 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const u
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (threadIdx.x < 64) so3_update_wave(st, partials, nb, fx2, fy2, cx2, cy2);
+    if (threadIdx.x < 64) so3_update_wave(st, gacc, fx2, fy2, cx2, cy2);
 }
 
 // one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583 (icp && rgb branch
 // selected by the flags), on one block: fixed-order double sums of the block partials, 6x6 pivoted
 // LDLT in double, SE(3) update, next warp matrices.
-__device__ __forceinline__ void gn_solve_block(DevState* st, const float* __restrict__ icp_partials, int icp_blocks, const float* __restrict__ rgb_partials, int rgb_blocks,
+__device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict__ icp_acc, double* __restrict__ rgb_acc,
                            const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy,
                            int* __restrict__ res_total = nullptr)
 {
-    // fixed-order f64 sums of the block partials: thread t owns column k = t % 32 of block rows
-    // g, g+8, g+16, ... (g = t / 32), all loads independent and coalesced; the 8 row groups are then
-    // added in order through LDS.  (The first version walked the columns one after the other with a
-    // shuffle tree each: 15 dependent global round trips per wave, ~20 us.)
-    __shared__ double s_part[2][32][32];
+    // the 2 x 29 exact totals: one thread per value reads the replicas of its accumulator row entry and clears them for the
+    // next iteration (the first version summed up to 500 partial rows of 128 B here: 4.6k cycles of the last block)
     __shared__ double s_icp[29], s_rgb[29];
     __shared__ int s_res[2];
-    {
-        // every load of the hand-off is issued before any is used: 256 threads = 32 row groups x 8
-        // float4 columns; rows g, g+32, ... (<= 10 per array for <= 320 blocks) -> one memory round trip
-        const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
-        {   // requires blockDim.x == 256 (RED_THREADS)
-            double vi[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0};
-            // ten rows per thread and array at a time (all of them for <= 320 blocks: one memory round trip); more blocks (large images) take further rounds,
-            // accumulated in the same row order
-            const int rows = max(icp_blocks, rgb_blocks);
-            for (int u0 = 0; u0 * 32 < rows; u0 += 10) {
-                float4 ti[10], tr[10];
-#pragma unroll
-                for (int u = 0; u < 10; u++) {
-                    // unconditional loads from a clamped row (no branch between the loads), masked afterwards
-                    int b = g + 32 * (u0 + u);
-                    int bi = min(b, max(icp_blocks, 1) - 1), br = min(b, max(rgb_blocks, 1) - 1);
-                    ti[u] = reinterpret_cast<const float4*>(icp_partials)[bi * 8 + c4];
-                    tr[u] = reinterpret_cast<const float4*>(rgb_partials)[br * 8 + c4];
-                }
-#pragma unroll
-                for (int u = 0; u < 10; u++) {
-                    int b = g + 32 * (u0 + u);
-                    if (!(b < icp_blocks)) ti[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!(b < rgb_blocks)) tr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 10; u++) {
-                    vi[0] += (double)ti[u].x; vi[1] += (double)ti[u].y; vi[2] += (double)ti[u].z; vi[3] += (double)ti[u].w;
-                    vr[0] += (double)tr[u].x; vr[1] += (double)tr[u].y; vr[2] += (double)tr[u].z; vr[3] += (double)tr[u].w;
-                }
-            }
-            int c0 = 0, c1 = 0;
-            if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
-                if (threadIdx.x == 0) {
-                    c0 = __hip_atomic_load(&res_total[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    c1 = __hip_atomic_load(&res_total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&res_total[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&res_total[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                for (int b = threadIdx.x; b < res_blocks; b += 256) {
-                    const int2 r0 = reinterpret_cast<const int2*>(res_partials)[b];
-                    c0 += r0.x; c1 += r0.y;
-                }
-            }
-            if (threadIdx.x < 2) s_res[threadIdx.x] = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { s_part[0][g][c4 * 4 + q] = vi[q]; s_part[1][g][c4 * 4 + q] = vr[q]; }
-            __syncthreads();   // orders the s_res zeroing before the integer atomics below
-            c0 = wave_sum_i(c0);
-            c1 = wave_sum_i(c1);
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&s_res[0], c0); atomicAdd(&s_res[1], c1); }
-        }
-    }
-#ifdef IFX_STAMPS
-    long long ts_a = clock64();
-#endif
-    __syncthreads();
-#ifdef IFX_STAMPS
-    long long ts_b = clock64();
-#endif
     if (threadIdx.x < 58) {
         const int which = threadIdx.x >= 29, k = threadIdx.x - 29 * which;
-        double v = 0;
-#pragma unroll
-        for (int g = 0; g < 32; g++) v += s_part[which][g][k];
+        double* g = which ? rgb_acc : icp_acc;
+        const double v = acc_total(g, k);
+        acc_clear(g, k);
         if (which) s_rgb[k] = v; else s_icp[k] = v;
     }
+    if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
+        if (threadIdx.x == 64) {
+            s_res[0] = __hip_atomic_load(&res_total[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_res[1] = __hip_atomic_load(&res_total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&res_total[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&res_total[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (threadIdx.x < 2) s_res[threadIdx.x] = 0;
+        __syncthreads();
+        int c0 = 0, c1 = 0;
+        for (int b = threadIdx.x; b < res_blocks; b += 256) {
+            const int2 r0 = reinterpret_cast<const int2*>(res_partials)[b];
+            c0 += r0.x; c1 += r0.y;
+        }
+        c0 = wave_sum_i(c0);
+        c1 = wave_sum_i(c1);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&s_res[0], c0); atomicAdd(&s_res[1], c1); }
+    }
+#ifdef IFX_STAMPS
+    long long ts_a = clock64(), ts_b = ts_a;
+#endif
     __syncthreads();
 #ifdef IFX_STAMPS
     long long ts_c = clock64();
@@ -1263,8 +1254,8 @@ struct StepArgs {
     float fx, fy, sobelScale;
     const int16_t *dIdx, *dIdy;
     int w, h, nb, nb_icp, nb_res;
-    float* rgb_partials;
-    const float* icp_partials;
+    double* rgb_acc;
+    double* icp_acc;
     const int* res_partials;
     int* res_total;
     int icp, rgb;
@@ -1279,13 +1270,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
 #ifdef IFX_STAMPS
     long long t0 = clock64();
 #endif
-    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_partials, a.res_total);
+    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_acc, a.res_total);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef IFX_STAMPS
     long long t1 = clock64();
 #endif
-    if (threadIdx.x == 0) {   // partial rows were stored sc1 and every wave drained vmcnt before the barrier
+    if (threadIdx.x == 0) {   // this block's atomic adds were performed at the memory side: every wave drained vmcnt before the barrier
         unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (unsigned int)(a.nb - 1));
     }
@@ -1300,7 +1291,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, a.icp_partials, a.nb_icp, a.rgb_partials, a.nb, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total);
+    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
@@ -1408,15 +1399,14 @@ int ifx_alloc_tracker(ifx* h)
         HIPCHK(h, hipMalloc(&p.corres[i], n * 8));
     }
     const int maxb = 1024;
-    HIPCHK(h, hipMalloc(&h->icp_partials, maxb * 32 * 4));
-    HIPCHK(h, hipMalloc(&h->rgb_partials, maxb * 32 * 4));
+    HIPCHK(h, hipMalloc(&p.acc, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
+    HIPCHK(h, hipMemset(p.acc, 0, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
     h->res_rows = std::max(maxb, cdiv(h->P, RED_THREADS) + 1);   // the residual pass runs one block per 256 pixels
     HIPCHK(h, hipMalloc(&h->res_partials, (size_t)h->res_rows * 2 * 4));
-    HIPCHK(h, hipMalloc(&h->so3_partials, maxb * 12 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
     HIPCHK(h, hipMalloc(&h->d_ticket, 512));
     HIPCHK(h, hipMemset(h->d_ticket, 0, 512));
-    p.icp_partials = h->icp_partials; p.rgb_partials = h->rgb_partials; p.res_partials = h->res_partials; p.ticket = h->d_ticket;
+    p.res_partials = h->res_partials; p.ticket = h->d_ticket;
     for (int q = 0; q < 2; q++) {
         HIPCHK(h, hipMalloc(&h->slot[q].so3, sizeof(DevState)));
         HIPCHK(h, hipMemset(h->slot[q].so3, 0, sizeof(DevState)));
@@ -1457,7 +1447,7 @@ void ifx_free_tracker(ifx* h)
     hipFree(h->d_graph); hipFree(h->d_sample); hipFree(h->d_cons); hipFree(h->d_project); hipFree(h->d_fern); hipFree(h->d_inst_gt);
     if (h->h_fern) hipHostFree(h->h_fern);
     if (h->ev_fern) hipEventDestroy(h->ev_fern);
-    hipFree(h->icp_partials); hipFree(h->rgb_partials); hipFree(h->res_partials); hipFree(h->so3_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
+    hipFree(h->pyr.acc); hipFree(h->res_partials); hipFree(h->d_out29); hipFree(h->d_ticket);
 }
 
 static inline int red_blocks(ifx* h, int n, int it = RED_IT)
@@ -1593,14 +1583,14 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         // last block to sum): one pixel per thread, no loop -- 152 blocks 17.5 us, 304 blocks 13.3 us, 1200 blocks 11.3 us per launch at 640x480 (1053 -> 1102 frames/s).
         const int nbi = nb, nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
-        pa.icp_partials = p.icp_partials; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8); pa.check_skip = frame_tracker ? 0 : 1;
+        pa.icp_acc = p.acc; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8); pa.check_skip = frame_tracker ? 0 : 1;
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
             LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nbi; sa2.nb_res = nbr;
-            sa2.rgb_partials = p.rgb_partials; sa2.icp_partials = p.icp_partials; sa2.res_partials = p.res_partials;
+            sa2.rgb_acc = p.acc + IFX_ACC_REPL * IFX_ACC_STRIDE; sa2.icp_acc = p.acc; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
             sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8); sa2.check_skip = frame_tracker ? 0 : 1;
             LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
@@ -1630,7 +1620,7 @@ int ifx_tracker_frame_side(ifx* h, int first)
         DevState* ss = h->slot[h->cur_slot].so3;
         LAUNCH(h, "so3_begin", dim3(1), dim3(64), k_so3_begin, ss, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
         for (int it = 0; it < 10; it++)
-            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, ss, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], h->so3_partials, nb, h->d_ticket + 4, c.fx / d2, c.fy / d2,
+            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, ss, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], p.acc + 2 * IFX_ACC_REPL * IFX_ACC_STRIDE, nb, h->d_ticket + 4, c.fx / d2, c.fy / d2,
                    c.cx / d2, c.cy / d2);
     }
     return IFX_OK;
@@ -1767,7 +1757,7 @@ int ifx_tracker_alloc_m2m(ifx* h)
     HIPCHK(h, hipHostMalloc((void**)&h->h_lc, 24 * 4, hipHostMallocDefault));
     memset(h->h_lc, 0, 24 * 4);
     const int maxb = 1024;
-    HIPCHK(h, hipMalloc(&p.icp_partials, maxb * 32 * 4)); HIPCHK(h, hipMalloc(&p.rgb_partials, maxb * 32 * 4)); HIPCHK(h, hipMalloc(&p.res_partials, (size_t)h->res_rows * 2 * 4));
+    HIPCHK(h, hipMalloc(&p.acc, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)))); HIPCHK(h, hipMemset(p.acc, 0, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)))); HIPCHK(h, hipMalloc(&p.res_partials, (size_t)h->res_rows * 2 * 4));
     HIPCHK(h, hipMalloc(&p.ticket, 512));
     HIPCHK(h, hipMemset(p.ticket, 0, 512));
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
@@ -1795,7 +1785,7 @@ static void free_m2m(ifx* h)
     }
     hipFree(h->d_m2m); hipFree(h->old_vertex); hipFree(h->old_normal); hipFree(h->old_image); hipFree(h->old_inst); hipFree(h->old_time);
     hipFree(h->act_vertex); hipFree(h->act_normal); hipFree(h->act_image); hipFree(h->act_inst); hipFree(h->act_time);
-    hipFree(p.icp_partials); hipFree(p.rgb_partials); hipFree(p.res_partials); hipFree(p.ticket);
+    hipFree(p.acc); hipFree(p.res_partials); hipFree(p.ticket);
     if (h->h_lc) hipHostFree(h->h_lc);
     h->d_m2m = nullptr;
 }
@@ -1893,14 +1883,17 @@ int ifx_tracker_set_weight(ifx* h, float weight_mult)
 
 // ======================================================================= stage API (unit parity)
 
-static int final_sum(ifx* h, const float* d_partials, int stride, int nv, int nb, float* out_host)
+// stage API: the exact totals of one quantity (0 icp, 1 rgb, 2 so3) from the accumulator rows, which are cleared again
+static double* stage_acc(ifx* h, int which) { return h->pyr.acc + (size_t)which * IFX_ACC_REPL * IFX_ACC_STRIDE; }
+static int final_sum(ifx* h, int which, int nv, float* out_host)
 {
-    std::vector<float> hp((size_t)nb * stride);
-    HIPCHK(h, hipMemcpyAsync(hp.data(), d_partials, hp.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    double hp[IFX_ACC_REPL * IFX_ACC_STRIDE];
+    HIPCHK(h, hipMemcpyAsync(hp, stage_acc(h, which), sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemsetAsync(stage_acc(h, which), 0, sizeof(hp), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int k = 0; k < nv; k++) {
         double s = 0;
-        for (int b = 0; b < nb; b++) s += (double)hp[(size_t)b * stride + k];
+        for (int r = 0; r < IFX_ACC_REPL; r++) s += hp[r * IFX_ACC_STRIDE + k];
         out_host[k] = (float)s;
     }
     return IFX_OK;
@@ -1915,8 +1908,8 @@ extern "C" int ifx_icp_step(ifx_t* h, const float* Rcurr9, const float* tcurr3, 
     memcpy(ia.Rcurr, Rcurr9, 36); memcpy(ia.tcurr, tcurr3, 12); memcpy(ia.Rprev_inv, Rprev_inv9, 36); memcpy(ia.tprev, tprev3, 12);
     int nb = red_blocks(h, w * hgt);
     LAUNCH(h, "icp", dim3(nb), dim3(RED_THREADS), k_icp, (const DevState*)nullptr, ia, d_vmap_curr, d_nmap_curr, d_vmap_g_prev, d_nmap_g_prev, fx, fy, cx, cy, dist_thres,
-           angle_thres, w, hgt, h->icp_partials);
-    return final_sum(h, h->icp_partials, 32, 29, nb, out29_host);
+           angle_thres, w, hgt, stage_acc(h, 0));
+    return final_sum(h, 0, 29, out29_host);
 }
 
 extern "C" int ifx_rgb_residual(ifx_t* h, float min_scale, const int16_t* d_didx, const int16_t* d_didy, const float* d_last_depth, const float* d_next_depth,
@@ -1945,8 +1938,8 @@ extern "C" int ifx_rgb_step(ifx_t* h, const void* d_corres8, float sigma, const 
     if (!h || !out29_host) return IFX_E_INVALID;
     int nb = red_blocks(h, w * hgt);
     LAUNCH(h, "rgb_step", dim3(nb), dim3(RED_THREADS), k_rgb_step, (const Corres8*)d_corres8, sigma, (const int*)nullptr, 0, d_cloud3, fx, fy, d_didx, d_didy, sobel_scale, w,
-           hgt, h->rgb_partials);
-    return final_sum(h, h->rgb_partials, 32, 29, nb, out29_host);
+           hgt, stage_acc(h, 1));
+    return final_sum(h, 1, 29, out29_host);
 }
 
 extern "C" int ifx_so3_step(ifx_t* h, const uint8_t* d_last_img, const uint8_t* d_next_img, const float* image_basis9, const float* kinv9, const float* krlr9, int w,
@@ -1956,8 +1949,8 @@ extern "C" int ifx_so3_step(ifx_t* h, const uint8_t* d_last_img, const uint8_t* 
     So3Args sa;
     memcpy(sa.ib, image_basis9, 36); memcpy(sa.kinv, kinv9, 36); memcpy(sa.krlr, krlr9, 36);
     int nb = red_blocks(h, w * hgt);
-    LAUNCH(h, "so3", dim3(nb), dim3(RED_THREADS), k_so3, (const DevState*)nullptr, sa, d_last_img, d_next_img, w, hgt, h->so3_partials);
-    return final_sum(h, h->so3_partials, 12, 11, nb, out11_host);
+    LAUNCH(h, "so3", dim3(nb), dim3(RED_THREADS), k_so3, (const DevState*)nullptr, sa, d_last_img, d_next_img, w, hgt, stage_acc(h, 2));
+    return final_sum(h, 2, 11, out11_host);
 }
 
 __global__ void k_write_pose(DevState* st, const float* p)

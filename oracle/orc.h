@@ -126,6 +126,7 @@ int orc_map_count(orc_t*);
 void orc_get_pose(orc_t*, float* out16);
 void orc_set_instance_gt(orc_t*, const uint8_t* gt_hw);   /* instanceGT of processFrame: new surfels remember the id under their pixel (vImgCorr.w) */
 int orc_tick(orc_t*);
+void orc_tracker_diag(orc_t*, float* out8);
 void orc_set_bootstrap(orc_t*, int on);
 /* wall-clock per stage since the last reset (ms): track incl. preprocessing | map passes | instance layer */
 void orc_stage_ms(orc_t*, double* out3, int reset);
@@ -167,6 +168,7 @@ void orc_adopt_estimated_pose(orc_t*);                                          
 /* stage-level map entry points operating on the object's map with an explicit pose/time */
 void orc_predict_indices(orc_t*, const float* pose16, int time);
 void orc_combined_predict(orc_t*, const float* pose16, int time, int max_time);
+void orc_stage_predict(orc_t*, const float* pose16, int time, int max_time);   /* + fill-in, as ifx_combined_predict */
 void orc_fuse(orc_t*, const float* pose16, int time, float weighting);
 void orc_clean(orc_t*, const float* pose16, int time);
 void orc_render_ids(orc_t*, const float* pose16, int mode /*0 general, 1 instance-compare*/);

@@ -157,6 +157,8 @@ void orc_set_instance_gt(orc_t* o, const uint8_t* gt)
     if (gt) { o->inst_gt = (uint8_t*)malloc((size_t)o->P); memcpy(o->inst_gt, gt, (size_t)o->P); }
 }
 int orc_tick(orc_t* o) { return o->tick; }
+/* lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count of the last tracked frame */
+void orc_tracker_diag(orc_t* o, float* out8) { memcpy(out8, o->diag, 32); }
 /* the `bootstrap` argument of processFrame for the NEXT orc_process_frame call (needs in_pose16) */
 void orc_set_bootstrap(orc_t* o, int on) { o->bootstrap_next = on; }
 double orc_now_ms(void)
@@ -711,6 +713,17 @@ static void rodrigues2(const float* R, float* out3)
         rx *= vth; ry *= vth; rz *= vth;
     }
     out3[0] = (float)rx; out3[1] = (float)ry; out3[2] = (float)rz;
+}
+
+/* Stage entry used by the tests and the bench after a map upload: the combined prediction at an explicit pose FOLLOWED by the fill-in
+ * (EF/ElasticFusion.cpp:729-763 does both: the tracker takes the fill-in images whenever the prediction is not dense enough).  The HIP
+ * library's ifx_combined_predict resolves the fill-in in the same kernel; without it here the two trackers would start from
+ * different models on sparse maps. */
+static void fill_in(orc_t* o);
+void orc_stage_predict(orc_t* o, const float* pose, int time, int max_time)
+{
+    orc_combined_predict(o, pose, time, max_time);
+    fill_in(o);
 }
 
 /* ElasticFusion::predict, EF/ElasticFusion.cpp:729-763 */

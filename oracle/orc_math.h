@@ -10,6 +10,25 @@
 
 typedef struct { float x, y, z; } v3;
 
+/* ---- exact, order-independent sums of the tracker's normal equations (the arithmetic contract shared with the HIP path,
+ * instancefusion_amd/csrc/ifx_dev.h): every f32 product that enters one of the 29 (11) sums is rounded to a fixed grid 2^g
+ * (g = e_i + e_j - 32 for a product of row entries i and j; e = binary exponent of the entry's working range) and the sums run
+ * in f64, where every partial sum is an integer number of grid units below 2^53: each addition is exact, so the total is the
+ * same for any order (rows, OpenMP chunks; on the GPU threads, waves, blocks, atomics).  The reference's own sums are an f32
+ * tree whose shape depends on a per-GPU launch table (EF/Utils/GPUConfig.h:53-137): there is no single reference order. */
+static const int ORC_E_ICP[7] = {0, 0, 0, 4, 4, 4, -3};
+static const int ORC_E_RGB[7] = {11, 11, 11, 13, 13, 13, 3};   /* measured RMS on the reference's RGB-D pair: v 6..33, r 0.14 */
+static const int ORC_E_SO3[4] = {16, 16, 16, 8};             /* measured RMS: jr 650..1750, r 36 */
+#define ORC_EXACT_TERM_BITS 32
+#define ORC_SO3_TERM_BITS 38
+/* (t + M) - M with M = 1.5 * 2^(52 + g) rounds t to a multiple of 2^g (nearest even) */
+static inline double orc_quant(float p, int g) {
+    const double M = ldexp(1.5, 52 + g);
+    double t = (double)p;
+    t = t + M;
+    return t - M;
+}
+
 static inline v3 v3m(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 v3sub(v3 a, v3 b) { return v3m(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 v3add(v3 a, v3 b) { return v3m(a.x + b.x, a.y + b.y, a.z + b.z); }

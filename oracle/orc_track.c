@@ -7,6 +7,11 @@
 #include <stdlib.h>
 #include <stdio.h>
 
+/* test hook (orc_set_sum_order): 0 = rows added top to bottom, 1 = bottom to top, 2 = every row partial rounded to f32 first (the precision
+ * of the HIP path's per-block partial rows).  Same arithmetic, another summation order / rounding: used to
+ * measure how far two equally valid executions of the algorithm drift apart (tests/test_oracle_cpu.py). */
+int orc_sum_reverse = 0;
+void orc_set_sum_order(int reverse) { orc_sum_reverse = reverse; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 
@@ -304,16 +309,16 @@ void orc_project_cloud(const float* depth, int w, int h, float fx, float fy, flo
 
 /* ======================================================================= reductions (a4-a7) */
 
-static void accum_products7(const float* row, int found, double* acc29)
+static void accum_products7(const float* row, int found, double* acc29, const int* e)
 {
     int s = 0;
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < 6; i++)
         for (int j = i; j < 7; j++) {
-            if (i == 6 && j == 6) break;
-            acc29[s++] += (double)(row[i] * row[j]);
+            /* JtJJtrSE3: the f32 product of the reference (EF/Cuda/types.cuh:101-152), rounded to the entry's grid, summed exactly */
+            acc29[s++] += orc_quant(row[i] * row[j], e[i] + e[j] - ORC_EXACT_TERM_BITS);
         }
     /* order: aa..ag, bb..bg, cc..cg, dd..dg, ee,ef,eg, ff,fg  = 27 ; then residual, inliers */
-    acc29[27] += (double)(row[6] * row[6]);
+    acc29[27] += orc_quant(row[6] * row[6], 2 * e[6] - ORC_EXACT_TERM_BITS);
     acc29[28] += found ? 1.0 : 0.0;
 }
 
@@ -357,12 +362,14 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
                     }
                 }
             }
-            accum_products7(row, found, acc);
+            accum_products7(row, found, acc, ORC_E_ICP);
         }
     double tot[29];
     for (int i = 0; i < 29; i++) tot[i] = 0;
-    for (int y = 0; y < h; y++)
-        for (int i = 0; i < 29; i++) tot[i] += racc[y][i];
+    for (int yy = 0; yy < h; yy++) {
+        const int y = orc_sum_reverse == 1 ? h - 1 - yy : yy;
+        for (int i = 0; i < 29; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
+    }
     for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
     free(racc);
 }
@@ -445,12 +452,14 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
             row[4] = cp[2] * v0 - cp[0] * v2;
             row[5] = -cp[1] * v0 + cp[0] * v1;
         }
-        accum_products7(row, c->valid, acc);
+        accum_products7(row, c->valid, acc, ORC_E_RGB);
     }
     double tot[29];
     for (int i = 0; i < 29; i++) tot[i] = 0;
-    for (int y = 0; y < h; y++)
-        for (int i = 0; i < 29; i++) tot[i] += racc[y][i];
+    for (int yy = 0; yy < h; yy++) {
+        const int y = orc_sum_reverse == 1 ? h - 1 - yy : yy;
+        for (int i = 0; i < 29; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
+    }
     for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
     free(racc);
 }
@@ -486,14 +495,16 @@ void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float*
             }
             int s = 0;
             for (int i = 0; i < 3; i++)
-                for (int j = i; j < 4; j++) acc[s++] += (double)(row[i] * row[j]);
-            acc[9] += (double)(row[3] * row[3]);
+                for (int j = i; j < 4; j++) acc[s++] += orc_quant(row[i] * row[j], ORC_E_SO3[i] + ORC_E_SO3[j] - ORC_SO3_TERM_BITS);
+            acc[9] += orc_quant(row[3] * row[3], 2 * ORC_E_SO3[3] - ORC_SO3_TERM_BITS);
             acc[10] += found ? 1.0 : 0.0;
         }
     double tot[11];
     for (int i = 0; i < 11; i++) tot[i] = 0;
-    for (int y = 0; y < h; y++)
-        for (int i = 0; i < 11; i++) tot[i] += racc[y][i];
+    for (int yy = 0; yy < h; yy++) {
+        const int y = orc_sum_reverse == 1 ? h - 1 - yy : yy;
+        for (int i = 0; i < 11; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
+    }
     for (int i = 0; i < 11; i++) out11[i] = (float)tot[i];
     free(racc);
 }

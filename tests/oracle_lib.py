@@ -81,6 +81,19 @@ def lib():
     return _lib
 
 
+def usable_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup's CPU quota (a GPU box shows 256 logical
+    CPUs and grants 16: 256 OpenMP threads on 16 CPUs run 30x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def set_threads(n):
     """OpenMP threads the oracle's parallel loops use from now on (results do not depend on it)."""
     lib().orc_set_threads.argtypes = [C.c_int]
@@ -152,6 +165,12 @@ class Oracle:
         n = m["pc"].shape[0]
         a = {k: np.ascontiguousarray(m[k], np.float32) for k in ("pc", "nr", "col", "tm", "ic", "votes")}
         self.L.orc_map_upload(self.h, n, ptr(a["pc"]), ptr(a["nr"]), ptr(a["col"]), ptr(a["tm"]), ptr(a["ic"]), ptr(a["votes"]))
+
+    def tracker_diag(self):
+        out = np.zeros(8, np.float32)
+        self.L.orc_tracker_diag.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_tracker_diag(self.h, ptr(out))
+        return out
 
     def stage_ms(self, reset=False):
         """wall-clock per stage since the last reset: track (preprocessing + tracker) | fuse (map passes) | instance"""
@@ -257,7 +276,8 @@ class Oracle:
 
     def combined_predict(self, pose, time, max_time):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)
-        self.L.orc_combined_predict(self.h, ptr(p), time, max_time)
+        self.L.orc_stage_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self.L.orc_stage_predict(self.h, ptr(p), time, max_time)   # combinedPredict + FillIn, what ifx_combined_predict resolves in one kernel
 
     def fuse(self, pose, time, weighting):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)

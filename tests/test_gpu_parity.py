@@ -58,10 +58,10 @@ def test_tracker_gputest_pair(ifx, orc, gputest_pair, oracle_pins):
     V, N, rgba, prev, depth_mm, rgb = protocol_inputs(*gputest_pair)
     g = ifx.ElasticFusion(w=w, h=h, max_surfels=1000, **HALF_K)
     pose, diag = g.track_pair(V, N, rgba, prev, depth_mm, rgb, np.eye(4))
-    # real sensor data: reduction-order differences (f32 wave trees vs sequential f64) move a few
-    # threshold decisions; tolerance = the north star's 1e-4 (measured 2.5e-5)
-    assert np.abs(pose - oracle_pins["pose_pyr"]).max() < 1e-4
-    assert np.allclose(diag[:6], oracle_pins["diag_pyr"][:6], rtol=5e-3)
+    # real sensor data.  The sums of the normal equations are exact on both sides (bit-identical); what is left between the two is the
+    # f64 rounding of the 6x6 solve (unpivoted on the device, pivoted in the oracle), which almost never survives the cast to f32
+    assert np.abs(pose - oracle_pins["pose_pyr"]).max() < 1e-6
+    assert np.allclose(diag[:6], oracle_pins["diag_pyr"][:6], rtol=1e-6)
     # pyramid buffers against a live oracle tracker
     t = L.orc_tracker_create(w, h, HALF_K["fx"], HALF_K["fy"], HALF_K["cx"], HALF_K["cy"])
     L.orc_tracker_init_first_rgb(t, orc.ptr(prev))
@@ -123,7 +123,7 @@ def test_reduction_stage_api(ifx, orc, gputest_pair):
         r = G.ifx_icp_step(g.handle, orc.ptr(Rc.reshape(9).copy()), orc.ptr(tc), d["vmap_curr"].data_ptr(), d["nmap_curr"].data_ptr(), orc.ptr(I3.reshape(9).copy()), orc.ptr(z3),
                            fx, fy, cx, cy, d["vmap_prev"].data_ptr(), d["nmap_prev"].data_ptr(), 0.10, sn, lw, lh, orc.ptr(got))
         assert r == 0 and got[28] == ref[28] and ref[28] > 100
-        assert np.allclose(got, ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max())
+        assert np.array_equal(got, ref)            # exact: grid-valued terms summed in f64, the same total in any order (ifx_dev.h / orc_math.h)
         # --- rgb residual + rgb step
         didx = np.zeros((lh, lw), np.int16); didy = np.zeros((lh, lw), np.int16)
         L.orc_sobel(orc.ptr(b["next_img"]), lw, lh, orc.ptr(didx), orc.ptr(didy))
@@ -156,7 +156,7 @@ def test_reduction_stage_api(ifx, orc, gputest_pair):
             L.orc_rgb_step(orc.ptr(dt_ref), sigma, orc.ptr(cloud), fx, fy, orc.ptr(didx), orc.ptr(didy), 0.125, lw, lh, orc.ptr(ref))
             r = G.ifx_rgb_step(g.handle, d_cor.data_ptr(), sigma, d_cloud.data_ptr(), fx, fy, d_didx.data_ptr(), d_didy.data_ptr(), 0.125, lw, lh, orc.ptr(got))
             assert r == 0 and got[28] == ref[28]
-            assert np.allclose(got, ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max())
+            assert np.array_equal(got, ref)
         # --- so3
         Kinv = np.linalg.inv(K)
         Rs = np.array([[1, 0, 0.004], [0, 1, -0.003], [-0.004, 0.003, 1]], np.float64)
@@ -166,7 +166,7 @@ def test_reduction_stage_api(ifx, orc, gputest_pair):
         L.orc_so3_step(orc.ptr(b["lastnext_img"]), orc.ptr(b["next_img"]), orc.ptr(ib), orc.ptr(kinv), orc.ptr(krlr), lw, lh, orc.ptr(r11))
         r = G.ifx_so3_step(g.handle, d["lastnext_img"].data_ptr(), d["next_img"].data_ptr(), orc.ptr(ib), orc.ptr(kinv), orc.ptr(krlr), lw, lh, orc.ptr(g11))
         assert r == 0 and g11[10] == r11[10]
-        assert np.allclose(g11, r11, rtol=2e-4, atol=1e-6 * np.abs(r11).max())
+        assert np.array_equal(g11, r11)
     L.orc_tracker_destroy(t)
     g.close()
 
@@ -256,7 +256,9 @@ def test_end_to_end_sequence(ifx, orc, small_stream):
     pose = po
     ids_o = o.render_ids(pose, 0); ids_g = g.render_ids(pose, 0)
     assert np.array_equal(ids_o, ids_g)
-    # run one more frame with the pose held fixed so that both refresh ids_after from the same state
+    # run one more frame with the pose held fixed so that both refresh ids_after from the same state (the pose BEFORE it identical too:
+    # the velocity weighting of the fused measurements compares the two)
+    g.set_pose(pose, o.tick); o.set_pose(pose, o.tick)
     pg = g.processFrame(st["rgb"][9], st["depth"][9], inPose=pose); po2 = o.process_frame(st["rgb"][9], st["depth"][9], in_pose=pose)
     # identical map, identical pose, identical frame: the precondition of the exact label comparison below is asserted, not assumed
     assert g.count == o.count
@@ -374,8 +376,9 @@ def test_full_loop_640x480_trajectory_and_labels(ifx, orc):
     W, H, NF = 640, 480, 90
     K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
     st = synth.make_stream(NF, W, H, noise=True, loop_len=NF, **K)
-    orc.set_threads(os.cpu_count() or 1)
-    g = ifx.ElasticFusion(w=W, h=H, max_surfels=3_000_000, **K)          # housekeeping compaction as in production (not every frame)
+    orc.set_threads(orc.usable_cores())
+    g = ifx.ElasticFusion(w=W, h=H, max_surfels=3_000_000, **K)
+    g.set_option("compact_every_frame", 1)                                # slot numbers = the oracle's indices, so that the id images can be compared (lazy compaction: test_full_size_properties)
     o = orc.Oracle(w=W, h=H, max_surfels=3_000_000, **K)
     inst = ifx.InstanceFusion(g)
     err, rot = [], []
@@ -440,7 +443,7 @@ def test_config3_5m_map_full_instance_path(ifx, orc):
     N = 5_000_000
     st = synth.make_stream(4, W, H, noise=True, loop_len=90, **K)
     big = synth.make_map(N, st["scene"], st["poses_world"][0], 1000)
-    orc.set_threads(os.cpu_count() or 1)
+    orc.set_threads(orc.usable_cores())
     g = ifx.ElasticFusion(w=W, h=H, max_surfels=N + 600_000, **K)
     g.set_option("compact_every_frame", 1)
     o = orc.Oracle(w=W, h=H, max_surfels=N + 600_000, **K)

@@ -37,6 +37,7 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
     only streams every launch must touch are counted (e.g. the normal/radius reads of listed surfels are not)."""
     table = {
         # map: streaming culls over all slots
+        "cull_frame": n_slots * 24.0,                       # the one scan of the store (view list): times 8 B + position/confidence 16 B of every slot
         "cull_raster": n_slots * 24.0,                      # pos+conf 16 B + times 8 B per slot
         "cull_clean": n_slots * (8.0 + 16.0 * active_fraction),   # times for every slot, position only inside the time window
         "index_project": n_slots * (8.0 + 16.0 * active_fraction),
@@ -249,7 +250,7 @@ def main():
         for _ in range(n_kt):
             step(k); k += 1
         ef.sync()
-        names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "index_list", "index_project", "index_resolve", "associate",
+        names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "associate",
                  "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
         best, table = None, {}
         for nme in names:

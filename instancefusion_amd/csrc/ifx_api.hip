@@ -8,6 +8,7 @@ int ifx_tracker_external_pose(ifx* h, const float* d_pose16, float weight_mult);
 int ifx_tracker_set_weight(ifx* h, float weight_mult);
 int ifx_compact_enqueue(ifx* h, int refresh_ids);
 
+void hs_invalidate_view(ifx* h);
 static std::string g_err;
 extern "C" const char* ifx_global_error(void) { return g_err.c_str(); }
 extern "C" const char* ifx_last_error(ifx_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
@@ -97,14 +98,16 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->pc2, C * 16); ALLOC(h->nr2, C * 16); ALLOC(h->col2, C * 8); ALLOC(h->tm2, C * 8); ALLOC(h->ic2, C * 16); ALLOC(h->votes2, C * 192);
     ALLOC(h->upd_owner, C * 4);
     // a chunk of 4096 slots (ifx_map.hip: MAP_THREADS x CHUNK_ROUNDS) appends to segment chunk % 8: a segment holds at most its share of the chunks
-    h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096);
+    // (+ P: a segment of the cached view list also takes its share of the surfels appended while the list lives, at most P / 4 per frame over 32 frames and 8 segments)
+    h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096 + P);
     ALLOC(h->list_a, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_b, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_c, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     if (const char* ev = getenv("IFX_RASTER_TILES")) h->opt_raster_tiles = atoi(ev);   // A/B switch for whole test runs
     h->tile_pair_cap = (unsigned int)std::max<size_t>(2 * C, (size_t)1 << 22);
     ALLOC(h->tile_n, 5 * 4096 * 4 + 64); ALLOC(h->tile_box, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->tile_pairs, (size_t)h->tile_pair_cap * 4);
     hipMemset(h->tile_n, 0, 5 * 4096 * 4 + 64);
-    ALLOC(h->d_list_ctr, 3 * IFX_LIST_SEGS * 32 * 4);
-    hipMemset(h->d_list_ctr, 0, 3 * IFX_LIST_SEGS * 32 * 4);
+    ALLOC(h->d_list_ctr, 4 * IFX_LIST_SEGS * 32 * 4);
+    hipMemset(h->d_list_ctr, 0, 4 * IFX_LIST_SEGS * 32 * 4);
+    ALLOC(h->list_v, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
@@ -154,7 +157,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
@@ -227,6 +230,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
+    else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "raster_earlyz") h->opt_raster_earlyz = value;
     // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;
     // refused while a frame is announced ahead (its image-only work may already be on the queue with the old configuration)
     else if (s == "pyramid" || s == "fast_odom" || s == "so3" || s == "icp_weight_x1000") {
@@ -469,6 +474,8 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
 extern "C" int ifx_set_shard(ifx_t* h, int rank, int nranks)
 {
     if (!h || nranks < 1 || rank < 0 || rank >= nranks) return IFX_E_INVALID;
+    ifx_vlist_reap(h);
+    hs_invalidate_view(h);
     h->shard_rank = rank; h->shard_n = nranks;
     h->tracked_ahead = 0; h->hint_rgb = nullptr;
     return IFX_OK;
@@ -700,6 +707,7 @@ extern "C" int ifx_map_view(ifx_t* h, ifx_soa_view* out)
 }
 static int read_state(ifx* h, DevState* hs)
 {
+    ifx_vlist_reap(h);   // counts are read: nothing outside the view list may outlive the age rule
     // every stream that writes the state: the model-to-model tracker (stream_c) leaves its verdict in lc[] / lc_candidates of the main state
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
     if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
@@ -782,7 +790,8 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     }
     DevState hs;
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
-    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0;
+    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0; hs.vl_valid = 0;
+    h->view_dirty = 0;
     {
         float rmax = 0.f;
         for (int i = 0; i < n; i++) { float r = nr[(size_t)i * 4 + 3]; if (r == r && r > rmax && r < 1e30f) rmax = r; }

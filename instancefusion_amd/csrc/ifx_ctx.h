@@ -50,6 +50,12 @@ struct DevState {
     int skip;             // tracker kernels return at once (model-to-model run with nothing to align)
     float lc[24];         // ifx_loop_closure_diag layout
     int lc_candidates;
+    // cached view list (ifx_map.hip, "View list"): slots that can touch the image from any pose near vl_pose
+    float vl_pose[16];    // camera-to-world pose the list was built for
+    int vl_valid;         // the list describes the store (cleared by compaction, upload, deformation, first frame)
+    int vl_scan;          // decision for the frame being enqueued: 1 = k_cull_frame rebuilds the list, 0 = it returns at once
+    int vl_age;           // frames since the last scan
+    int vl_scans;         // scans so far (diagnostics)
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
@@ -100,6 +106,35 @@ struct FrameSlot {
 #ifndef IFX_LIST_SEGS
 #define IFX_LIST_SEGS 8   // segments of a work list, each with its own length counter (ifx_map.hip)
 #endif
+
+// ---- cached view list (ifx_map.hip "View list"): margins and the per-frame decision, shared by the kernels that commit a pose
+#define VL_ROT 0.0523599f      // 3 degrees
+#define VL_TRANS 0.06f         // metres
+#define VL_MAX_AGE 32
+#define LIST_V 3
+#define IFX_LIST_CTR_STRIDE 32
+
+// decision for the frame whose pose was just committed; one thread (k_track_end / k_commit_pose / pose adoption)
+__device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lctr)
+{
+    bool ok = st->vl_valid && st->vl_age < VL_MAX_AGE;
+    if (ok) {
+        const float* A = st->vl_pose;
+        const float* B = st->pose;
+        const float dx = B[3] - A[3], dy = B[7] - A[7], dz = B[11] - A[11];
+        float tr = 0.f;   // trace(Ra^T Rb) = sum of the element-wise products
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) tr += A[r * 4 + c] * B[r * 4 + c];
+        // 10 % slack on both margins for the rounding of this test itself
+        ok = (dx * dx + dy * dy + dz * dz <= 0.81f * VL_TRANS * VL_TRANS) && ((tr - 1.0f) * 0.5f >= cosf(0.9f * VL_ROT)) && tr == tr;
+    }
+    if (ok) { st->vl_scan = 0; st->vl_age++; return; }
+    st->vl_scan = 1; st->vl_age = 0; st->vl_valid = 1; st->vl_scans++;
+    for (int k = 0; k < 16; k++) st->vl_pose[k] = st->pose[k];
+    for (int k = 0; k < IFX_LIST_SEGS; k++) lctr[(LIST_V * IFX_LIST_SEGS + k) * IFX_LIST_CTR_STRIDE] = 0;
+}
 
 struct KernelTiming { double total_ms = 0; int launches = 0; };
 struct PendingEvent { int name_id; hipEvent_t a, b; };
@@ -175,11 +210,18 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
+    uint32_t* list_v = nullptr;         // [8 segments x list_seg_cap] the cached view list (list 3 of d_list_ctr)
+    int view_frame = 0;                 // the frame being enqueued went through the view list (its end-of-frame raster may too)
+    int view_block = 0;                 // the pose was replaced after the view-list decision of this frame (pose adoption): the frame takes the per-pass culls
+    int last_clean_time = 0;            // time of the last clean pass (the age rule a forced scan applies to the slots outside the list)
+    int view_dirty = 0;                 // frames ran through the view list since the last forced scan: slots outside it may have outlived the age rule
+    int opt_vlist = 1;                  // frame path through the cached view list (0: one cull per pass over all slots, the round-1 path)
+    int opt_raster_earlyz = 1;          // view-list rasteriser: skip the atomic when a plain read of the key image already shows a nearer surfel
     uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [8 segments x list_seg_cap] work lists (surfel index | flags << 30): raster candidates, clean candidates, kill list
     unsigned int *tile_n = nullptr, *tile_box = nullptr, *tile_pairs = nullptr;   // tiled rasteriser: [4 x TILE_MAX] counters / offsets / fill / flag, per-entry tile box, (tile, entry) pairs
     unsigned int tile_pair_cap = 0;
     void* tile_recs = nullptr;          // [list size] 32-B camera-frame geometry records of the listed surfels (allocated when the tiled path is first used)
-    unsigned int* d_list_ctr = nullptr;   // [3 lists][8 segments] lengths, 128 B apart
+    unsigned int* d_list_ctr = nullptr;   // [4 lists][8 segments] lengths, 128 B apart (raster, clean candidates, kill, view list)
     unsigned int list_seg_cap = 0;
     int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot
     int* scan_flags = nullptr;         // [max(cap,P)]
@@ -285,6 +327,7 @@ int ifx_housekeeping(ifx* h);                                  // tombstone comp
 int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
+int ifx_vlist_reap(ifx* h);                                   // forced view-list scan: applies the age rule to the slots outside the list (before any whole-map consumer)
 int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame);
 int ifx_map_predict_loop_closure(ifx* h);                     // predict() at the tracked pose + INACTIVE prediction (old* images)
 int ifx_tracker_alloc_m2m(ifx* h);

@@ -558,6 +558,7 @@ static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
 
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
+    if (h) ifx_vlist_reap(h);   // whole-map consumer: nothing outside the cached view list may outlive the age rule (ifx_map.hip "View list")
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
     h->seg_counts_valid = 0;
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
@@ -660,6 +661,7 @@ __global__ void k_alive_flags2(const DevState* __restrict__ st, const float2* __
 
 extern "C" int ifx_labels(ifx_t* h, int32_t* out, int max_n)
 {
+    if (h) ifx_vlist_reap(h);   // whole-map consumer: nothing outside the cached view list may outlive the age rule (ifx_map.hip "View list")
     if (!h || !out) return IFX_E_INVALID;
     // labels of the live surfels in map order: rank = exclusive scan of the alive flags
     LAUNCH(h, "alive_flags", dim3(cdiv(h->cap, 256)), dim3(256), k_alive_flags2, h->d_state, (const float2*)h->tm, h->scan_flags, h->cap);
@@ -702,6 +704,7 @@ __global__ void k_precision_recall(const DevState* __restrict__ st, const float2
 }
 extern "C" int ifx_precision_recall(ifx_t* h, int32_t* inst_num96, int32_t* gt_num256, int32_t* inst_gt_map)
 {
+    if (h) ifx_vlist_reap(h);   // whole-map consumer: nothing outside the cached view list may outlive the age rule (ifx_map.hip "View list")
     if (!h || !inst_num96 || !gt_num256 || !inst_gt_map) return IFX_E_INVALID;
     const size_t n = IFX_NUM_INSTANCES + 256 + 256 * IFX_NUM_INSTANCES;
     int* d = nullptr;

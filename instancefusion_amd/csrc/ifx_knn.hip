@@ -215,6 +215,7 @@ int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
 // `max_n` slots (host, [max_n][10], -1 = none / dead slot)
 extern "C" int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n)
 {
+    if (h) ifx_vlist_reap(h);   // whole-map consumer: nothing outside the cached view list may outlive the age rule (ifx_map.hip "View list")
     if (!h || max_n < 0) return IFX_E_INVALID;
     int32_t* d_nbr = nullptr;
     if (nbr_out && max_n > 0) {

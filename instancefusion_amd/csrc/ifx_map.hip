@@ -68,7 +68,7 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
 // time (doubling the chunks per launch slowed the cull kernels from 42 to 52 us); spread over 8 addresses they no longer queue up: 42 -> 34 us.
 // A consumer block works on segment blockIdx % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk).
 #define LIST_SEGS IFX_LIST_SEGS
-#define LIST_CTR_STRIDE 32   // uints between counters: 128 B
+#define LIST_CTR_STRIDE IFX_LIST_CTR_STRIDE   // uints between counters: 128 B
 struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; };   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
 __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
 static Cam make_cam(ifx* h)
@@ -178,7 +178,7 @@ __global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const
 }
 __global__ void k_init_count(DevState* st, const int* total, int cap)
 {
-    if (threadIdx.x == 0) { int t = *total; st->count = t < cap ? t : cap; st->n_dead = 0; st->n_new = st->count; }
+    if (threadIdx.x == 0) { int t = *total; st->count = t < cap ? t : cap; st->n_dead = 0; st->n_new = st->count; st->vl_valid = 0; }
 }
 
 int ifx_map_init_first(ifx* h)
@@ -1063,6 +1063,346 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 }
 
 
+// ------------------------------------------------------------------ view list (frame path)
+// The three culls of a frame (index map before the fusion, index map + clean after it, raster after the clean) all
+// look at the map from the frame's pose, and consecutive frames look from almost the same pose.  k_cull_frame therefore
+// streams the store ONCE (24 B per slot: times, position + confidence -- the id render has no time window, so every
+// live position is needed) and keeps every slot whose disc can touch the image from ANY pose within VL_ROT of rotation and
+// VL_TRANS of translation of the scan pose: the view list (list 3).  The passes of the following frames walk that list
+// instead of the store -- new surfels are appended to it as they are created (k_append_scan) -- until the tracked pose
+// leaves the margin, the list is VL_MAX_AGE frames old or the store was renumbered / moved (compaction, upload,
+// deformation): the decision is taken on the device when the frame's pose is committed (vlist_decide), and a scan kernel that
+// has nothing to do returns at its first instruction.  Results are those of the per-pass culls bit for bit: the list is a
+// superset, every pass re-tests its entries exactly.
+// Slots outside the list cannot be seen, matched or updated while it is valid; the one thing the clean pass would still do
+// to them is the age rule (copy_unstable.vert:166: unstable and not seen for 20 frames -> removed), which the scan applies
+// to the slots it leaves out.  Between two scans such a slot may outlive its deadline by a few frames, invisible to every
+// pass; ifx_vlist_reap forces a scan before anything that looks at the whole store (count, download, compaction, labels,
+// kNN, segmentation statistics).
+__global__ void k_vlist_decide(DevState* st, unsigned int* lctr, int force)
+{
+    if (threadIdx.x != 0) return;
+    if (force) st->vl_valid = 0;
+    vlist_decide(st, lctr);
+}
+
+// can the disc of a surfel at camera-frame position q (scan pose) touch the image from a pose within the margins?
+// Every point of the disc lies within `reach` of q; a point of the moved frustum lies within VL_TRANS + VL_ROT * |x| of the
+// scan frustum; so q is within D = reach + VL_TRANS + VL_ROT * (|q| + reach + VL_TRANS) of the scan frustum, hence within D of
+// each of its bounding half-spaces (conservative; 1 % + 1 cm slack for the arithmetic).
+struct VlPlanes { float lx, lz, rx, rz, ty, tz, by, bz; };   // unit outward normals of the four side planes: (lx, 0, lz), (rx, 0, rz), (0, ty, tz), (0, by, bz)
+__device__ __forceinline__ bool near_frustum(v3 q, float reach, const VlPlanes& P, float maxDepth)
+{
+    const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    const float D = (reach + VL_TRANS + VL_ROT * (len + reach + VL_TRANS)) * 1.01f + 0.01f;
+    if (!(len == len)) return true;
+    return !(P.lx * q.x + P.lz * q.z > D || P.rx * q.x + P.rz * q.z > D || P.ty * q.y + P.tz * q.z > D || P.by * q.y + P.bz * q.z > D || -q.z > D || q.z - maxDepth > D);
+}
+static VlPlanes make_planes(const Cam& c)
+{
+    VlPlanes P;
+    // u >= 0  <=>  fx x + cx z >= 0 ; u <= w  <=>  fx x + (cx - w) z <= 0 ; same in v
+    float n = sqrtf(c.fx * c.fx + c.cx * c.cx);
+    P.lx = -c.fx / n; P.lz = -c.cx / n;
+    n = sqrtf(c.fx * c.fx + (c.cx - c.w) * (c.cx - c.w));
+    P.rx = c.fx / n; P.rz = (c.cx - c.w) / n;
+    n = sqrtf(c.fy * c.fy + c.cy * c.cy);
+    P.ty = -c.fy / n; P.tz = -c.cy / n;
+    n = sqrtf(c.fy * c.fy + (c.cy - c.h) * (c.cy - c.h));
+    P.by = c.fy / n; P.bz = (c.cy - c.h) / n;
+    return P;
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const float4* __restrict__ pc_in, float4* __restrict__ pc_rw, float2* __restrict__ tm, Cam c, VlPlanes P,
+                                                            int time, unsigned int* __restrict__ list)
+{
+    if (!st->vl_scan) return;
+    float Tm[16], T[12];
+#pragma unroll
+    for (int k = 0; k < 16; k++) Tm[k] = st->vl_pose[k];
+    {   // rigid inverse of the scan pose
+        float inv[16];
+        pose_inverse(Tm, inv);
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = inv[k];
+    }
+    __shared__ BlockCount L;
+    if (threadIdx.x == 0) L.n = 0;
+    __syncthreads();
+    const int n = st->count;
+    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
+    int dead = 0;
+    for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
+        unsigned int pos[CHUNK_ROUNDS];
+        unsigned int keep = 0;
+#pragma unroll
+        for (int r = 0; r < CHUNK_ROUNDS; r++) {
+            const int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
+            bool in = false;
+            if (i < n) {
+                const float4 p4 = pc_in[i];
+                const float2 t = tm[i];
+                const float wv = t.y;
+                if (wv > DEAD_TIME) {
+                    in = near_frustum(xf_point(T, v3m(p4.x, p4.y, p4.z)), reach, P, c.maxDepth);
+                    if (!in) {   // never seen while the list is valid: only the age rule of the clean pass applies to it (copy_unstable.vert:160-172)
+                        int test = 1;
+                        if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
+                        if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
+                        if (!test) {
+                            float4 q4 = p4;
+                            q4.w = -1.0f;
+                            pc_rw[i] = q4;
+                            tm[i] = make_float2(t.x, DEAD_TIME);
+                            dead++;
+                        }
+                    }
+                }
+            }
+            pos[r] = bcount_reserve(L, in);
+            keep |= in ? (1u << r) : 0u;
+        }
+        const int seg = chunk % LIST_SEGS;
+        const unsigned int base = seg * c.seg_cap + bcount_commit(L, list_ctr(c, LIST_V, seg));
+#pragma unroll
+        for (int r = 0; r < CHUNK_ROUNDS; r++)
+            if (keep & (1u << r)) list[base + pos[r]] = (unsigned int)(chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x);
+    }
+    dead = wave_sum_i(dead);
+    if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
+}
+
+// index-map projection (index_map.vert:40-66) of the view-list entries: the work of k_index_project on the slots that can be seen at all
+__global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, Cam c, int time,
+                                                            const unsigned int* __restrict__ list, unsigned long long* __restrict__ keys)
+{
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, LIST_V, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
+        const unsigned int i = seg_list[t];
+        const float lastT = tm[i].y;
+        if ((float)time - lastT > (float)c.timeDelta) continue;   // inactive or tombstone
+        const float4 p4 = pc[i];
+        const v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+        if (p.z > c.maxDepth || p.z < 0) continue;
+        const float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+        if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
+        key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, i));
+    }
+}
+
+// clean (copy_unstable.vert:103-174) over the view list, after the post-fuse index map is resolved: the decisions of
+// k_cull_clean + k_clean_list for the listed slots.  A block classifies 256 entries at a time; the ones that need the
+// 16-tap window test are gathered in LDS and tested with every lane busy.
+__global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c, int time, float4* __restrict__ pc, const float4* __restrict__ nr, float2* __restrict__ tm,
+                                                            const float4* __restrict__ tap, const unsigned int* __restrict__ list)
+{
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
+    __shared__ unsigned int s_cand[2 * MAP_THREADS];
+    __shared__ unsigned int s_n;
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, LIST_V, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    const unsigned int stride = blockDim.x * (gridDim.x / LIST_SEGS);
+    int dead = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x; t0 < n; t0 += stride) {
+        const unsigned int t = t0 + threadIdx.x;
+        bool cand = false;
+        unsigned int i = 0;
+        if (t < n) {
+            i = seg_list[t];
+            const float2 tt = tm[i];
+            const float wv = tt.y;
+            if (wv > DEAD_TIME && !(wv > 0.f && (float)time - wv > (float)c.timeDelta)) {   // live and not exempt by the time window
+                const float4 p4 = pc[i];
+                if (!((float)time - wv > (float)c.timeDelta)) {
+                    const v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                    if (p.z > 0.f) {
+                        const float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+                        cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
+                    }
+                }
+                if (!cand) {   // count = zCount = 0: only the stability / age rules apply
+                    int test = 1;
+                    if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
+                    if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
+                    if (!test) {
+                        float4 q4 = p4;
+                        q4.w = -1.0f;
+                        pc[i] = q4;
+                        tm[i] = make_float2(tt.x, DEAD_TIME);
+                        dead++;
+                    }
+                }
+            }
+        }
+        {   // gather the candidates of this round
+            const unsigned long long m = __ballot(cand);
+            unsigned int base = 0;
+            const int lane = threadIdx.x & 63;
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) base = atomicAdd(&s_n, (unsigned int)__popcll(m));
+                base = __shfl(base, leader, 64);
+            }
+            if (cand) s_cand[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+        __syncthreads();
+        // drain in full rounds of 256; the remainder waits for the next round (or the end)
+        const bool last_round = t0 + stride >= n;
+        unsigned int have = s_n;
+        unsigned int done = 0;
+        while (have - done >= blockDim.x || (last_round && have > done)) {
+            const unsigned int k = done + threadIdx.x;
+            if (k < have) {
+                const unsigned int j = s_cand[k];
+                const float2 tt = tm[j];
+                const float4 p4 = pc[j];
+                float lastT = tt.y;
+                if (!clean_test(T, c, time, p4, nr[j], tt.x, lastT, tap)) {
+                    float4 q4 = p4;
+                    q4.w = -1.0f;
+                    pc[j] = q4;
+                    tm[j] = make_float2(tt.x, DEAD_TIME);
+                    dead++;
+                }
+            }
+            done += blockDim.x;
+            if (done > have) done = have;
+        }
+        __syncthreads();
+        if (done > 0 && done < have) {   // move the remainder to the front
+            const unsigned int rest = have - done;
+            unsigned int v = 0;
+            if (threadIdx.x < rest) v = s_cand[done + threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < rest) s_cand[threadIdx.x] = v;
+        }
+        if (threadIdx.x == 0) s_n = have - done;
+        __syncthreads();
+    }
+    dead = wave_sum_i(dead);
+    if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
+}
+
+// Splat prediction + id render over the view list: the culls of k_cull_raster and the coverage / depth rules of
+// k_raster_list (same surfel_geo, same disc_hit: the images are bit-identical), with the pixel work of a wave FLATTENED:
+// every lane first prepares one listed surfel (cull, camera-frame geometry, pixel box), the boxes' areas are prefix-summed
+// across the wave, and the wave then walks the concatenation of all candidate pixels 64 at a time -- lane l of step s
+// tests pixel 64 s + l of that sequence, whichever surfel it belongs to.  In k_raster_list a lane walks its own box, so a
+// wave runs as long as its largest box and its 64 atomics of a step go to 64 unrelated places; here every lane has work
+// in every step and neighbouring lanes hit neighbouring pixels of the same few surfels.
+// earlyz: a plain (agent-scope) read of the key before the atomic; a key that is not below what the image already held
+// at ANY earlier time cannot win (keys only decrease during the pass), so the atomic is dropped -- with ~17 discs over
+// every pixel of the benchmark map most of them lose.
+struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; int x0, y0, bw, excl; int s01, s23, i01, i23; };
+__global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
+                                                             int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list,
+                                                             unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
+                                                             unsigned long long* __restrict__ key_both, int earlyz)
+{
+    __shared__ RvRec recs[MAP_THREADS / 64][64];
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = *list_ctr(c, LIST_V, seg);
+    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
+    const unsigned int stride = blockDim.x * (gridDim.x / LIST_SEGS);
+    for (unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
+        const unsigned int t = t0 + lane;
+        int area = 0;
+        RvRec R;
+        R.bw = 1;
+        if (t < n) {
+            const unsigned int i = seg_list[t];
+            const float4 p4 = pc[i];
+            unsigned int flags = 0;
+            if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
+                const float lastT = tm[i].y;
+                const v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                if (q.z > 0.f && may_touch_image(reach, q, c)) {
+                    if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) flags |= LIST_IDS;
+                    if ((want & LIST_SPLAT) && !(q.z > c.maxDepth) && !((float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime)) {
+                        const float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;   // exact: GL clips points by their centre
+                        if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= LIST_SPLAT;
+                    }
+                }
+            }
+            if (flags) {
+                SurfGeo G;
+                surfel_geo(T, p4, nr[i], i | flags, c, G);
+                int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
+                const bool do_s = G.do_s, do_i = surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
+                if (do_s || do_i) {
+                    // a render that does not draw this surfel gets an empty box (x1 < x0): no pixel passes its range test
+                    if (!do_s) { sx0 = 1; sx1 = 0; sy0 = 1; sy1 = 0; }
+                    if (!do_i) { ix0 = 1; ix1 = 0; iy0 = 1; iy1 = 0; }
+                    const int x0 = do_s && do_i ? min(sx0, ix0) : (do_s ? sx0 : ix0), x1 = do_s && do_i ? max(sx1, ix1) : (do_s ? sx1 : ix1);
+                    const int y0 = do_s && do_i ? min(sy0, iy0) : (do_s ? sy0 : iy0), y1 = do_s && do_i ? max(sy1, iy1) : (do_s ? sy1 : iy1);
+                    if (x1 >= x0 && y1 >= y0) {
+                        area = (x1 - x0 + 1) * (y1 - y0 + 1);
+                        R.qx = G.q.x; R.qy = G.q.y; R.qz = G.q.z; R.nx = G.nn.x; R.ny = G.nn.y; R.nz = G.nn.z; R.r2 = G.r * G.r; R.id = i;
+                        R.x0 = x0; R.y0 = y0; R.bw = x1 - x0 + 1;
+                        R.s01 = (sx0 & 0xFFFF) | (sx1 << 16); R.s23 = (sy0 & 0xFFFF) | (sy1 << 16);
+                        R.i01 = (ix0 & 0xFFFF) | (ix1 << 16); R.i23 = (iy0 & 0xFFFF) | (iy1 << 16);
+                    }
+                }
+            }
+        }
+        int incl = area;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        const int excl = incl - area, total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        R.excl = excl;
+        if (area) recs[wid][lane] = R;
+        // (single wave: LDS writes are ordered before the reads below by the wave's own program order + s_waitcnt)
+        int jlo = 0;
+        for (int g0 = 0; g0 < total; g0 += 64) {
+            while (jlo < 63 && __builtin_amdgcn_readlane(incl, __builtin_amdgcn_readfirstlane(jlo)) <= g0) jlo++;
+            const int g = g0 + lane;
+            int mine = jlo;
+            for (int j = jlo + 1; j < 64; j++) {
+                const int ej = __builtin_amdgcn_readlane(excl, __builtin_amdgcn_readfirstlane(j));
+                if (ej >= g0 + 64) break;
+                if (g >= ej) mine = j;
+            }
+            if (g >= total) continue;
+            const RvRec* rp = &recs[wid][mine];
+            const float4 a = *reinterpret_cast<const float4*>(&rp->qx), b = *reinterpret_cast<const float4*>(&rp->ny);
+            const int4 bx = *reinterpret_cast<const int4*>(&rp->x0), rg = *reinterpret_cast<const int4*>(&rp->s01);
+            const int k = g - bx.w;
+            const int row = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z)), col = k - row * bx.z;   // exact for boxes up to 512 x 512 (IFX_MAX_SPRITE)
+            const int px = bx.x + col, py = bx.y + row;
+            Disc d;
+            d.q = v3m(a.x, a.y, a.z); d.n = v3m(a.w, b.x, b.y); d.r2 = b.z;
+            const unsigned int id = __float_as_uint(b.w);
+            float z;
+            if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
+            const int sx0 = (short)(rg.x & 0xFFFF), sx1 = rg.x >> 16, sy0 = (short)(rg.y & 0xFFFF), sy1 = rg.y >> 16;
+            const int ix0 = (short)(rg.z & 0xFFFF), ix1 = rg.z >> 16, iy0 = (short)(rg.w & 0xFFFF), iy1 = rg.w >> 16;
+            const bool in_s = px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
+            const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
+            if (!in_s && !in_i) continue;
+            unsigned long long* addr = (in_s && in_i ? key_both : (in_s ? key_splat : key_ids)) + (py * c.w + px);
+            const unsigned long long key = make_key(z, id);
+            if (earlyz && !(key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) continue;
+            key_min(addr, key);
+        }
+    }
+}
+
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
 static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0)
 {
@@ -1319,9 +1659,10 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
                                                      const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
                                                      float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
-                                                     const uint8_t* __restrict__ inst_gt)
+                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels)
 {
     __shared__ int s_wave[4], s_base, s_last;
+    __shared__ unsigned int s_vbase;
     const int P = c.w * c.h, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int count0 = st->count;
     // counts of the blocks before this one
@@ -1348,13 +1689,21 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     int wave_off = 0;
     for (int q = 0; q < wid; q++) wave_off += s_wave[q];
     int rank = s_base + wave_off + incl - mine;
+    // the new surfels join the cached view list (they were created from this frame's pixels, so they are in view): one reservation per block
+    const int vseg = blockIdx.x % LIST_SEGS, blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const bool to_view = list_v && st->vl_valid;
+    if (tid == 0) s_vbase = (to_view && blk_total) ? atomicAdd(list_ctr(c, LIST_V, vseg), (unsigned int)blk_total) : 0u;
+    __syncthreads();
+    unsigned int vpos = s_vbase + (unsigned int)(wave_off + incl - mine);
     bool over = false;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (!f[u]) continue;
         const int ord = ord0 + u, i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
         const int n = count0 + rank++;
+        const unsigned int vp = vpos++;
         if (n >= cap) { over = true; continue; }
+        if (to_view && vp < c.seg_cap) list_v[(size_t)vseg * c.seg_cap + vp] = (unsigned int)n;
         pc[n] = mpc[k];
         nr[n] = mnr[k];
         { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
@@ -1362,6 +1711,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         tm[n] = make_float2((float)time, (float)time);
         ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
         for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        labels[n] = -1;   // no label until the next label scan (the slot may hold one from before a compaction)
     }
     if (over) st->overflow = 1;
     // every block has read st->count before it draws its ticket; the last one publishes the new count
@@ -1408,12 +1758,13 @@ __global__ void k_compact_scatter(const int* __restrict__ flags, const int* __re
 }
 __global__ void k_compact_count(DevState* st, const int* total)
 {
-    if (threadIdx.x == 0) { st->count = *total; st->n_dead = 0; }
+    if (threadIdx.x == 0) { st->count = *total; st->n_dead = 0; st->vl_valid = 0; }   // slots renumbered: the view list is void
 }
 
 static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out);
 int ifx_compact_enqueue(ifx* h, int refresh_ids)
 {
+    ifx_vlist_reap(h);   // slots the view list left out may have outlived the age rule: tombstone them before the live ranks are taken
     // alive flags over the host-known upper bound of slots; scan; scatter into the second buffer set; swap
     int n = h->cap;
     LAUNCH(h, "alive_flags", dim3(cdiv(n, 256)), dim3(256), k_alive_flags, h->d_state, (const float2*)h->tm, h->scan_flags, n);
@@ -1449,6 +1800,7 @@ __global__ __launch_bounds__(256) void k_deform(const DevState* __restrict__ st,
     extern __shared__ float g[];
     for (int k = threadIdx.x; k < nodes * 16; k += blockDim.x) g[k] = graph[k];
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevState*>(st)->vl_valid = 0;   // positions move: the cached view list is void
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
@@ -1579,10 +1931,12 @@ __global__ void k_adopt_est_pose(DevState* st)
     if (threadIdx.x != 0) return;
     for (int k = 0; k < 16; k++) st->pose[k] = st->lc[6 + k];
     pose_inverse(st->pose, st->pose_inv);
+    st->vl_valid = 0;   // another pose, and a deformation follows (positions move): the frame takes the per-pass culls, the list is rebuilt next frame
 }
 
 static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 {
+    h->last_clean_time = time;
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
     // A deformation graph was handed in for this clean (local loop closure): IndexMap::synthesizeDepth (EF/ElasticFusion.cpp:667-676) -- splat.vert
@@ -1609,13 +1963,68 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
            (const float4*)h->index_tap, h->scan_flags, h->scan_block);
     LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr);
+           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
+}
+
+// ---- frame path through the cached view list
+__global__ void k_vlist_invalidate(DevState* st) { if (threadIdx.x == 0) st->vl_valid = 0; }
+void hs_invalidate_view(ifx* h) { LAUNCH(h, "vlist_invalidate", dim3(1), dim3(64), k_vlist_invalidate, h->d_state); }
+static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
+static void view_scan(ifx* h, int time)
+{
+    Cam c = make_cam(h);
+    c.srank = 0; c.sn = 1;
+    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_v);
+}
+// A forced scan at the current pose with the time of the last processed frame: every slot the list leaves out gets the age rule
+// it may have outlived (see "View list"); cheap no-op when the view-list path never ran since the last scan of this kind.
+int ifx_vlist_reap(ifx* h)
+{
+    if (!h->view_dirty) return IFX_OK;
+    h->view_dirty = 0;
+    LAUNCH(h, "vlist_decide", dim3(1), dim3(64), k_vlist_decide, h->d_state, h->d_list_ctr, 1);
+    view_scan(h, h->last_clean_time);
+    return IFX_OK;
+}
+static void index_list_pass(ifx* h, int time, bool taps)
+{
+    Cam c = make_cam(h);
+    c.srank = 0; c.sn = 1;
+    LAUNCH(h, "index_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
+    if (!taps)
+        LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr);
+    else
+        LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap);
 }
 
 // EF/ElasticFusion.cpp:620-694 without the loop-closure branches
 int ifx_map_frame(ifx* h)
 {
+    h->view_frame = 0;
+    if (use_view_list(h)) {
+        Cam c = make_cam(h);
+        c.srank = 0; c.sn = 1;
+        const int time = h->tick;
+        view_scan(h, time);                     // rebuilds the list when vlist_decide asked for it, returns at once otherwise
+        index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
+        fuse_pass(h, nullptr, 0.f, time);
+        index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
+        LAUNCH(h, "clean_view", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+               (const float4*)h->index_tap, h->list_v);
+        const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+        LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
+               (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
+        LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
+               (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels);
+        h->view_frame = 1; h->view_dirty = 1; h->last_clean_time = time;
+        if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);   // (reaps first; the raster below then takes the per-pass cull: the list is void after a compaction)
+        h->ids_pending = 1;
+        return IFX_OK;
+    }
     index_pass(h, nullptr, h->tick, true);
     fuse_pass(h, nullptr, 0.f, h->tick);
     if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680); they need the post-fuse index map too
@@ -1624,6 +2033,7 @@ int ifx_map_frame(ifx* h)
         ids_pass(h, nullptr, 0, h->ids_tmp);
     }
     clean_pass(h, nullptr, h->tick);   // includes the second predictIndices
+    h->view_block = 0;
     if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
     h->ids_pending = 1;                // rendered together with the prediction (same map state, same pose)
     return IFX_OK;
@@ -1654,7 +2064,17 @@ int ifx_map_predict_loop_closure(ifx* h)
 // ElasticFusion::predict, EF/ElasticFusion.cpp:729-763, fused with renderSurfelIds(GENERAL_AFTER) of :694
 int ifx_map_predict(ifx* h)
 {
-    raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u), h->ids_after, true);
+    const unsigned int want = LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u);
+    const bool tiles = h->opt_raster_tiles < 0 ? (h->P >= 1000000) : (h->opt_raster_tiles != 0);
+    if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since
+        Cam c = make_cam(h);
+        c.srank = 0; c.sn = 1;
+        LAUNCH(h, "raster_view", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+               want, h->list_v, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
+    } else
+        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
+    h->view_frame = 0;
     h->ids_pending = 0;
     return IFX_OK;
 }
@@ -1765,6 +2185,7 @@ extern "C" int ifx_render_ids(ifx_t* h, const float* pose16, int mode)
 extern "C" int ifx_sample_graph_model(ifx_t* h, float* out_xyzt, int max_n)
 {
     if (!h || !out_xyzt || max_n <= 0) return IFX_E_INVALID;
+    ifx_vlist_reap(h);
     const int cap_s = h->cap / 5000 + 2;
     if (!h->d_sample) HIPCHK(h, hipMalloc(&h->d_sample, (size_t)cap_s * 16));
     if (max_n > cap_s) max_n = cap_s;
@@ -1929,6 +2350,7 @@ __global__ void k_adopt_pose(DevState* st, Pose16 p)
     if (threadIdx.x != 0) return;
     for (int k = 0; k < 16; k++) st->pose[k] = p.m[k];
     pose_inverse(st->pose, st->pose_inv);
+    st->vl_valid = 0;
 }
 extern "C" int ifx_adopt_pose(ifx_t* h, const float* pose16)
 {
@@ -1937,6 +2359,7 @@ extern "C" int ifx_adopt_pose(ifx_t* h, const float* pose16)
     Pose16 p;
     memcpy(p.m, pose16, sizeof(p.m));
     h->tracked_ahead = 0;
+    h->view_block = 1;
     LAUNCH(h, "adopt_pose", dim3(1), dim3(64), k_adopt_pose, h->d_state, p);
     return IFX_OK;
 }
@@ -1946,6 +2369,7 @@ extern "C" int ifx_adopt_estimated_pose(ifx_t* h)
     if (!h) return IFX_E_INVALID;
     if (!h->d_m2m) { h->err = "loop-closure detection is not enabled"; return IFX_E_STATE; }
     h->tracked_ahead = 0;
+    h->view_block = 1;
     LAUNCH(h, "adopt_est_pose", dim3(1), dim3(64), k_adopt_est_pose, h->d_state);
     return IFX_OK;
 }

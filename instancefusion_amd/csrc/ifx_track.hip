@@ -1325,7 +1325,7 @@ __device__ void rodrigues2(const float* R, float* out3)
 }
 
 // end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449)
-__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit)
+__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
 {
     if (threadIdx.x != 0) return;
     float* pose = commit ? st->pose : st->spec_pose;
@@ -1363,13 +1363,15 @@ __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mul
     if (weighting > largest) weighting = largest;
     const float wgt = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
     if (commit) st->weighting = wgt; else st->spec_weighting = wgt;
+    if (commit && lctr) vlist_decide(st, lctr);   // the frame's pose is final: does the cached view list still cover it?
 }
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
-__global__ void k_commit_pose(DevState* st)
+__global__ void k_commit_pose(DevState* st, unsigned int* lctr)
 {
     if (threadIdx.x != 0) return;
     for (int k = 0; k < 16; k++) { st->pose[k] = st->spec_pose[k]; st->pose_inv[k] = st->spec_pose_inv[k]; }
     st->weighting = st->spec_weighting;
+    vlist_decide(st, lctr);
 }
 
 
@@ -1596,7 +1598,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit, frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr);
 }
 
 // frame side of the tracker for the bound slot: frame pyramids, then (unless this is the first frame, which only
@@ -1857,7 +1859,7 @@ extern "C" int ifx_track_maps(ifx_t* h, const float* model_v4, const float* mode
 
 int ifx_tracker_commit(ifx* h)
 {
-    LAUNCH(h, "commit_pose", dim3(1), dim3(64), k_commit_pose, h->d_state);
+    LAUNCH(h, "commit_pose", dim3(1), dim3(64), k_commit_pose, h->d_state, h->d_list_ctr);
     return IFX_OK;
 }
 
@@ -1871,13 +1873,13 @@ __global__ void k_set_pose(DevState* st, const float* pose16)
 int ifx_tracker_external_pose(ifx* h, const float* d_pose16, float weight_mult)
 {
     LAUNCH(h, "set_pose", dim3(1), dim3(64), k_set_pose, h->d_state, d_pose16);
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1, h->d_list_ctr);
     return IFX_OK;
 }
 int ifx_tracker_set_weight(ifx* h, float weight_mult)
 {
     // re-evaluates the velocity weighting with the caller's multiplier (weightMultiplier argument)
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1);
+    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, h->d_state, 0, 0, weight_mult, 1, (unsigned int*)nullptr);
     return IFX_OK;
 }
 

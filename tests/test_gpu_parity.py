@@ -497,6 +497,49 @@ def test_config3_5m_map_full_instance_path(ifx, orc):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("earlyz", [1, 0])
+def test_view_list_path_equals_per_pass_culls(ifx, earlyz):
+    """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,
+    flattened rasteriser, early-z) against the round-1 path (three culls over all slots per frame): poses, maps, id images and
+    labels bit for bit, over enough frames for several list rebuilds, appended surfels, deletions and a lazy compaction."""
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    NF = 26
+    st = synth.make_stream(NF, W, H, noise=True, loop_len=90, **K)
+    big = synth.make_map(400_000, st["scene"], st["poses_world"][0], 1000)
+
+    def run(view):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_600_000, **K)
+        g.set_option("view_list", view)
+        g.set_option("raster_earlyz", earlyz)
+        g.set_option("compact_divisor", 64)            # a lazy compaction inside the run
+        g.processFrame(st["rgb"][0], st["depth"][0])
+        g.upload(big); g.set_pose(st["poses"][0], 1000); g.combined_predict(st["poses"][0], 1000, 1000)
+        inst = ifx.InstanceFusion(g)
+        poses, ids = [], []
+        for i in range(1, NF):
+            poses.append(g.processFrame(st["rgb"][i], st["depth"][i]))
+            if i % 6 == 0:
+                ids.append(g.image("ids_after").copy())
+            if i == 12:
+                masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, 200, superpixels=True)
+        slots, live = g.slots, g.count
+        lab = inst.labels()
+        m = g.download()
+        g.close()
+        return np.stack(poses), ids, lab, m, slots, live
+
+    a, b = run(1), run(0)
+    assert np.array_equal(a[0], b[0])
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert np.array_equal(a[2], b[2]) and a[5] == b[5]
+    assert all(np.array_equal(a[3][k], b[3][k]) for k in MAP_KEYS)
+    assert a[3]["pc"].shape[0] > 400_000 and (a[2] >= 0).sum() > 100
+
+
 # ---------------------------------------------------------------- a20, a21: superpixel refinement
 def _slic_cases(gputest_pair):
     from instancefusion_amd import synth

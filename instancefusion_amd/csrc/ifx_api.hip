@@ -105,9 +105,9 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     h->tile_pair_cap = (unsigned int)std::max<size_t>(2 * C, (size_t)1 << 22);
     ALLOC(h->tile_n, 5 * 4096 * 4 + 64); ALLOC(h->tile_box, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->tile_pairs, (size_t)h->tile_pair_cap * 4);
     hipMemset(h->tile_n, 0, 5 * 4096 * 4 + 64);
-    ALLOC(h->d_list_ctr, 4 * IFX_LIST_SEGS * 32 * 4);
-    hipMemset(h->d_list_ctr, 0, 4 * IFX_LIST_SEGS * 32 * 4);
-    ALLOC(h->list_v, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
+    ALLOC(h->d_list_ctr, 5 * IFX_LIST_SEGS * 32 * 4);
+    hipMemset(h->d_list_ctr, 0, 5 * IFX_LIST_SEGS * 32 * 4);
+    ALLOC(h->list_v, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_vi, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
@@ -157,7 +157,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,

@@ -112,6 +112,7 @@ struct FrameSlot {
 #define VL_TRANS 0.06f         // metres
 #define VL_MAX_AGE 32
 #define LIST_V 3
+#define LIST_VI 4
 #define IFX_LIST_CTR_STRIDE 32
 
 // decision for the frame whose pose was just committed; one thread (k_track_end / k_commit_pose / pose adoption)
@@ -133,7 +134,7 @@ __device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lct
     if (ok) { st->vl_scan = 0; st->vl_age++; return; }
     st->vl_scan = 1; st->vl_age = 0; st->vl_valid = 1; st->vl_scans++;
     for (int k = 0; k < 16; k++) st->vl_pose[k] = st->pose[k];
-    for (int k = 0; k < IFX_LIST_SEGS; k++) lctr[(LIST_V * IFX_LIST_SEGS + k) * IFX_LIST_CTR_STRIDE] = 0;
+    for (int k = 0; k < 2 * IFX_LIST_SEGS; k++) lctr[(LIST_V * IFX_LIST_SEGS + k) * IFX_LIST_CTR_STRIDE] = 0;   // lists 3 and 4
 }
 
 struct KernelTiming { double total_ms = 0; int launches = 0; };
@@ -210,13 +211,13 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
-    uint32_t* list_v = nullptr;         // [8 segments x list_seg_cap] the cached view list (list 3 of d_list_ctr)
+    uint32_t *list_v = nullptr, *list_vi = nullptr;   // [8 segments x list_seg_cap] the cached view lists (lists 3, 4 of d_list_ctr): inside / outside the time window
     int view_frame = 0;                 // the frame being enqueued went through the view list (its end-of-frame raster may too)
     int view_block = 0;                 // the pose was replaced after the view-list decision of this frame (pose adoption): the frame takes the per-pass culls
     int last_clean_time = 0;            // time of the last clean pass (the age rule a forced scan applies to the slots outside the list)
     int view_dirty = 0;                 // frames ran through the view list since the last forced scan: slots outside it may have outlived the age rule
     int opt_vlist = 1;                  // frame path through the cached view list (0: one cull per pass over all slots, the round-1 path)
-    int opt_raster_earlyz = 1;          // view-list rasteriser: skip the atomic when a plain read of the key image already shows a nearer surfel
+    int opt_raster_earlyz = 0;          // view-list rasteriser: skip the atomic when a plain read of the key image already shows a nearer surfel (measured: 136 against 113 us -- the reads cost more than the dropped atomics save)
     uint32_t *list_a = nullptr, *list_b = nullptr, *list_c = nullptr;   // [8 segments x list_seg_cap] work lists (surfel index | flags << 30): raster candidates, clean candidates, kill list
     unsigned int *tile_n = nullptr, *tile_box = nullptr, *tile_pairs = nullptr;   // tiled rasteriser: [4 x TILE_MAX] counters / offsets / fill / flag, per-entry tile box, (tile, entry) pairs
     unsigned int tile_pair_cap = 0;

@@ -1113,8 +1113,12 @@ static VlPlanes make_planes(const Cam& c)
     return P;
 }
 
+// Two lists: LIST_V, the slots inside the time window at the scan (everything the index maps, the clean pass and the splat render can
+// ever touch while the list lives: a slot outside the window stays outside -- only a deformation re-activates surfels, and that voids
+// the list), and LIST_VI, the stable slots outside it, which only the id render draws (it has no time window).  Unstable slots outside
+// the window are frozen (nothing updates them) and invisible to every render: they are on neither list.
 __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const float4* __restrict__ pc_in, float4* __restrict__ pc_rw, float2* __restrict__ tm, Cam c, VlPlanes P,
-                                                            int time, unsigned int* __restrict__ list)
+                                                            int time, unsigned int* __restrict__ list, unsigned int* __restrict__ list_i)
 {
     if (!st->vl_scan) return;
     float Tm[16], T[12];
@@ -1126,26 +1130,29 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
 #pragma unroll
         for (int k = 0; k < 12; k++) T[k] = inv[k];
     }
-    __shared__ BlockCount L;
-    if (threadIdx.x == 0) L.n = 0;
+    __shared__ BlockCount2 L2;
+    if (threadIdx.x == 0) { L2.n[0] = 0; L2.n[1] = 0; }
     __syncthreads();
     const int n = st->count;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
     int dead = 0;
     for (int chunk = blockIdx.x; chunk * CHUNK_SLOTS < n; chunk += gridDim.x) {
         unsigned int pos[CHUNK_ROUNDS];
-        unsigned int keep = 0;
+        unsigned int keep = 0, keep_i = 0;
 #pragma unroll
         for (int r = 0; r < CHUNK_ROUNDS; r++) {
             const int i = chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x;
-            bool in = false;
+            bool in = false, in_i = false;
             if (i < n) {
                 const float4 p4 = pc_in[i];
                 const float2 t = tm[i];
                 const float wv = t.y;
                 if (wv > DEAD_TIME) {
                     in = near_frustum(xf_point(T, v3m(p4.x, p4.y, p4.z)), reach, P, c.maxDepth);
-                    if (!in) {   // never seen while the list is valid: only the age rule of the clean pass applies to it (copy_unstable.vert:160-172)
+                    if (in && wv > 0.f && (float)time - wv > (float)c.timeDelta) {   // outside the time window for good
+                        in = false;
+                        in_i = p4.w > c.conf;
+                    } else if (!in) {   // never seen while the list is valid: only the age rule of the clean pass applies to it (copy_unstable.vert:160-172)
                         int test = 1;
                         if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
                         if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
@@ -1159,14 +1166,21 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                     }
                 }
             }
-            pos[r] = bcount_reserve(L, in);
+            pos[r] = bcount2_reserve(L2, in, in_i);
             keep |= in ? (1u << r) : 0u;
+            keep_i |= in_i ? (1u << r) : 0u;
         }
+        __syncthreads();
         const int seg = chunk % LIST_SEGS;
-        const unsigned int base = seg * c.seg_cap + bcount_commit(L, list_ctr(c, LIST_V, seg));
+        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(list_ctr(c, threadIdx.x ? LIST_VI : LIST_V, seg), L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
+        __syncthreads();
+        const unsigned int ba = seg * c.seg_cap + L2.base[0], bi = seg * c.seg_cap + L2.base[1];
 #pragma unroll
-        for (int r = 0; r < CHUNK_ROUNDS; r++)
-            if (keep & (1u << r)) list[base + pos[r]] = (unsigned int)(chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x);
+        for (int r = 0; r < CHUNK_ROUNDS; r++) {
+            const unsigned int i = (unsigned int)(chunk * CHUNK_SLOTS + r * MAP_THREADS + threadIdx.x);
+            if (keep & (1u << r)) list[ba + pos[r]] = i;
+            if (keep_i & (1u << r)) list_i[bi + pos[r]] = i;
+        }
     }
     dead = wave_sum_i(dead);
     if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
@@ -1305,7 +1319,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
 // every pixel of the benchmark map most of them lose.
 struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; int x0, y0, bw, excl; int s01, s23, i01, i23; };
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
-                                                             int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list,
+                                                             int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
                                                              unsigned long long* __restrict__ key_both, int earlyz)
 {
@@ -1315,8 +1329,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int seg = blockIdx.x % LIST_SEGS;
-    const unsigned int n = *list_ctr(c, LIST_V, seg);
-    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
+    // the two view lists of the segment, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
+    const unsigned int na = *list_ctr(c, LIST_V, seg), n = na + ((want & LIST_IDS) ? *list_ctr(c, LIST_VI, seg) : 0u);
+    const unsigned int* __restrict__ seg_a = list_a + (size_t)seg * c.seg_cap;
+    const unsigned int* __restrict__ seg_i = list_i + (size_t)seg * c.seg_cap;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
     const unsigned int stride = blockDim.x * (gridDim.x / LIST_SEGS);
     for (unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
@@ -1325,7 +1341,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         RvRec R;
         R.bw = 1;
         if (t < n) {
-            const unsigned int i = seg_list[t];
+            const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
             const float4 p4 = pc[i];
             unsigned int flags = 0;
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
@@ -1975,7 +1991,7 @@ static void view_scan(ifx* h, int time)
 {
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
-    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_v);
+    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_v, h->list_vi);
 }
 // A forced scan at the current pose with the time of the last processed frame: every slot the list leaves out gets the age rule
 // it may have outlived (see "View list"); cheap no-op when the view-list path never ran since the last scan of this kind.
@@ -2070,7 +2086,7 @@ int ifx_map_predict(ifx* h)
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
         LAUNCH(h, "raster_view", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-               want, h->list_v, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+               want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
     } else
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);

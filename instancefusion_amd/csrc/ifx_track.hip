@@ -954,7 +954,9 @@ __device__ void k_matrix_d(float fx, float fy, float cx, float cy, double* K, do
 // krkinv / kt of the next residual pass from resultRt (EF/Utils/RGBDOdometry.cpp:424-434), all in registers
 __device__ __forceinline__ void warp_from(const double* M, float fx, float fy, float cx, float cy, float* krk, float* kt)
 {
-    // K = [fx 0 cx; 0 fy cy; 0 0 1], Kinv = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1]
+    // K = [fx 0 cx; 0 fy cy; 0 0 1], Kinv = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1].  The products below are K R Kinv and K t with the
+    // terms that multiply K's / Kinv's zeros left out, in the order a dense 3x3 product adds the others: the same values (x + 0 = x)
+    // in half the f64 instructions of this lone-lane path.
     const double K0 = fx, K2 = cx, K4 = fy, K5 = cy;
     const double I0 = 1.0 / K0, I4 = 1.0 / K4, I2 = -K2 / K0, I5 = -K5 / K4;
     double R3[9], tt[3];
@@ -964,14 +966,22 @@ __device__ __forceinline__ void warp_from(const double* M, float fx, float fy, f
         for (int j = 0; j < 3; j++) R3[i * 3 + j] = M[j * 4 + i];
 #pragma unroll
     for (int i = 0; i < 3; i++) tt[i] = -(R3[i * 3 + 0] * M[3] + R3[i * 3 + 1] * M[7] + R3[i * 3 + 2] * M[11]);
-    const double K[9] = {K0, 0, K2, 0, K4, K5, 0, 0, 1}, Kinv[9] = {I0, 0, I2, 0, I4, I5, 0, 0, 1};
-    double KR[9], KRK[9];
-    matmul_d(3, K, R3, KR);
-    matmul_d(3, KR, Kinv, KRK);
+    double KR[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) krk[k] = (float)KRK[k];
+    for (int j = 0; j < 3; j++) {
+        KR[j] = K0 * R3[j] + K2 * R3[6 + j];
+        KR[3 + j] = K4 * R3[3 + j] + K5 * R3[6 + j];
+        KR[6 + j] = R3[6 + j];
+    }
 #pragma unroll
-    for (int r = 0; r < 3; r++) kt[r] = (float)(K[r * 3] * tt[0] + K[r * 3 + 1] * tt[1] + K[r * 3 + 2] * tt[2]);
+    for (int i = 0; i < 3; i++) {
+        krk[i * 3 + 0] = (float)(KR[i * 3] * I0);
+        krk[i * 3 + 1] = (float)(KR[i * 3 + 1] * I4);
+        krk[i * 3 + 2] = (float)((KR[i * 3] * I2 + KR[i * 3 + 1] * I5) + KR[i * 3 + 2]);
+    }
+    kt[0] = (float)(K0 * tt[0] + K2 * tt[2]);
+    kt[1] = (float)(K4 * tt[1] + K5 * tt[2]);
+    kt[2] = (float)tt[2];
 }
 __device__ void set_warp_matrices(DevState* st, float fx, float fy, float cx, float cy)
 {
@@ -1095,11 +1105,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const u
     }
     __syncthreads();
     if (!s_last) return;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the totals are read by agent-scope loads: no acquire needed)
     __syncthreads();
     if (threadIdx.x < 64) so3_update_wave(st, gacc, fx2, fy2, cx2, cy2);
 }
@@ -1109,7 +1115,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const u
 // LDLT in double, SE(3) update, next warp matrices.
 __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict__ icp_acc, double* __restrict__ rgb_acc,
                            const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy,
-                           int* __restrict__ res_total = nullptr)
+                           int* __restrict__ res_total = nullptr, int final_iter = 1)
 {
     // the 2 x 29 exact totals: one thread per value reads the replicas of its accumulator row entry and clears them for the
     // next iteration (the first version summed up to 500 partial rows of 128 B here: 4.6k cycles of the last block)
@@ -1183,12 +1189,14 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     }
     // diagnostics first: nothing below needs the 58 sums or a second copy of the system any more
     // (keeping them live across the solve cost ~130 registers)
+    if (final_iter) {   // lastA / lastb / the 2 x 29 sums describe the run's LAST iteration (getCovariance, diagnostics): 130 scalar stores the others skip
 #pragma unroll
-    for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
+        for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
 #pragma unroll
-    for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
+        for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
+        for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
+    }
     st->rgb_count = rgbSize; st->rgb_sigma = sigma;
     st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
     st->lastRGBCount = (float)rgbSize;
@@ -1207,7 +1215,17 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; c++) upd[r * 4 + c] = Rr[r * 3 + c];
     upd[3] = result[0]; upd[7] = result[1]; upd[11] = result[2];
-    matmul_d(4, upd, RRt, RRt);
+    {   // upd * RRt for two rigid transforms (last rows 0 0 0 1): the terms a dense 4x4 product would multiply by those zeros are left out
+        double N[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) N[r * 4 + c] = (upd[r * 4] * RRt[c] + upd[r * 4 + 1] * RRt[4 + c]) + upd[r * 4 + 2] * RRt[8 + c];
+            N[r * 4 + 3] = ((upd[r * 4] * RRt[3] + upd[r * 4 + 1] * RRt[7]) + upd[r * 4 + 2] * RRt[11]) + upd[r * 4 + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) RRt[k] = N[k];
+    }
     float oR[9], ot[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -1262,6 +1280,7 @@ struct StepArgs {
     float icp_weight, nfx, nfy, ncx, ncy;
     unsigned int* ticket;
     int check_skip;
+    int final_iter;   // last Gauss-Newton iteration of the run: leaves lastA / lastb / the sums in DevState
 };
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
 {
@@ -1283,15 +1302,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Everything the other blocks of this launch produced reaches this block through agent-scope atomics and agent-scope
+        // (sc1) loads -- the accumulator rows, the residual totals, the ticket -- which are performed at / served from the
+        // memory side: no acquire (buffer_inv, ~1.7 us) is needed.  Only the stage-API variant reads plain partial rows.
+        if (!a.res_total) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch (stream order)
     }
     __syncthreads();
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total);
+    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total, a.final_iter);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
@@ -1595,6 +1616,11 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             sa2.rgb_acc = p.acc + IFX_ACC_REPL * IFX_ACC_STRIDE; sa2.icp_acc = p.acc; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
             sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8); sa2.check_skip = frame_tracker ? 0 : 1;
+            {   // is this the run's last iteration?  (no level below this one iterates)
+                bool later = false;
+                for (int q = i - 1; q >= 0; q--) later = later || iterations[q] > 0;
+                sa2.final_iter = (j == iterations[i] - 1 && !later) ? 1 : 0;
+            }
             LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }

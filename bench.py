@@ -390,7 +390,7 @@ def main():
                          "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,
                          "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call"},
             **extras,
-            "ate_rms_m": ate, "gen_s": round(t_gen, 1),
+            "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": ef.view_list_stats(),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu,
         }

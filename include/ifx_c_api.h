@@ -105,6 +105,9 @@ int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids,
 /* The handle's HIP streams (hipStream_t): work enqueued on the main stream between two phases (the key exchange) is
  * ordered with the phases without any host synchronisation. */
 int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
+/* Diagnostics of the cached view list ("View list"): out4 = entries inside the time window, stable entries
+ * outside it, scans of the store so far, frames since the last scan. */
+int ifx_view_list_stats(ifx_t* h, int32_t* out4);
 int ifx_sync(ifx_t* h);
 /* getCurrPose(), EF/ElasticFusion.cpp:1346 / ElasticFusionInterface.h:112-115 (synchronises) */
 int ifx_get_pose(ifx_t* h, float* out_pose16);

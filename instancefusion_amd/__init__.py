@@ -73,6 +73,7 @@ _SIGS = {
     "ifx_stream_handles": (C.c_int, [_P, _P, _P]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
+    "ifx_view_list_stats": (C.c_int, [_P, _P]),
     "ifx_sync": (C.c_int, [_P]),
     "ifx_get_pose": (C.c_int, [_P, _P]),
     "ifx_tick": (C.c_int, [_P]),
@@ -243,6 +244,11 @@ class ElasticFusion:
     def hint_next_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         """Announce the frame after the one about to be enqueued (see ifx_hint_next_frame_device)."""
         self._chk(self.L.ifx_hint_next_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_hint_next_frame_device")
+
+    def view_list_stats(self):
+        out = np.zeros(4, np.int32)
+        self._chk(self.L.ifx_view_list_stats(self.handle, _ptr(out)), "ifx_view_list_stats")
+        return dict(window=int(out[0]), outside=int(out[1]), scans=int(out[2]), age=int(out[3]))
 
     def sync(self):
         self._chk(self.L.ifx_sync(self.handle), "ifx_sync")

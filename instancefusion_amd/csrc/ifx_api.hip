@@ -229,6 +229,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(1024, value));
+    else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
     else if (s == "raster_earlyz") h->opt_raster_earlyz = value;
@@ -564,6 +565,16 @@ extern "C" int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, c
 {
     if (!h || !d_rgb_next || !d_depth_next) return IFX_E_INVALID;
     h->hint_rgb = d_rgb_next; h->hint_depth = d_depth_next;
+    return IFX_OK;
+}
+
+extern "C" int ifx_view_list_stats(ifx_t* h, int32_t* out4)
+{
+    if (!h || !out4) return IFX_E_INVALID;
+    DevState hs;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    out4[0] = (int32_t)hs.vl_n[0]; out4[1] = (int32_t)hs.vl_n[1]; out4[2] = hs.vl_scans; out4[3] = hs.vl_age;
     return IFX_OK;
 }
 

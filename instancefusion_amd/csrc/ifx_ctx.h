@@ -8,6 +8,10 @@
 #include "../../include/ifx_c_api.h"
 #include "ifx_dev.h"
 
+#ifndef IFX_LIST_SEGS
+#define IFX_LIST_SEGS 8   // segments of a work list, each with its own length counter (ifx_map.hip)
+#endif
+
 // ---- device-resident per-frame state: everything the kernels of one frame hand to each other
 // without a host round trip (the reference reads back 60-125 times per frame).
 struct DevState {
@@ -56,6 +60,8 @@ struct DevState {
     int vl_scan;          // decision for the frame being enqueued: 1 = k_cull_frame rebuilds the list, 0 = it returns at once
     int vl_age;           // frames since the last scan
     int vl_scans;         // scans so far (diagnostics)
+    unsigned int vl_n[2]; // lengths of the two flat view lists: [0] inside the time window (grows with the appended surfels), [1] stable slots outside it
+    unsigned int vl_seg_n[2 * IFX_LIST_SEGS], vl_seg_off[2 * IFX_LIST_SEGS];   // segment lengths / offsets of the scan's raw output (k_vlist_offsets, which re-arms the live counters)
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
 };
 
@@ -103,9 +109,6 @@ struct FrameSlot {
     int for_tick = -1;                // frame the slot was prepared for
 };
 
-#ifndef IFX_LIST_SEGS
-#define IFX_LIST_SEGS 8   // segments of a work list, each with its own length counter (ifx_map.hip)
-#endif
 
 // ---- cached view list (ifx_map.hip "View list"): margins and the per-frame decision, shared by the kernels that commit a pose
 #define VL_ROT 0.0523599f      // 3 degrees
@@ -134,7 +137,8 @@ __device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lct
     if (ok) { st->vl_scan = 0; st->vl_age++; return; }
     st->vl_scan = 1; st->vl_age = 0; st->vl_valid = 1; st->vl_scans++;
     for (int k = 0; k < 16; k++) st->vl_pose[k] = st->pose[k];
-    for (int k = 0; k < 2 * IFX_LIST_SEGS; k++) lctr[(LIST_V * IFX_LIST_SEGS + k) * IFX_LIST_CTR_STRIDE] = 0;   // lists 3 and 4
+    st->vl_n[0] = 0; st->vl_n[1] = 0;
+    (void)lctr;
 }
 
 struct KernelTiming { double total_ms = 0; int launches = 0; };
@@ -168,6 +172,7 @@ struct ifx {
     int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
+    int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
     int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)
     int opt_raster_tiles = -1;       // tiled rasteriser (k_tile_*: key tiles resolved in LDS) instead of global atomics: 0 off, 1 on, -1 by image size (on from 1 Mpixel:
                                      // at 640x480 / 5M surfels the binning passes cost what the LDS tiles save, at 1280x960 / 20M the frame rate gains 12 %)
@@ -211,7 +216,7 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
-    uint32_t *list_v = nullptr, *list_vi = nullptr;   // [8 segments x list_seg_cap] the cached view lists (lists 3, 4 of d_list_ctr): inside / outside the time window
+    uint32_t *list_v = nullptr, *list_vi = nullptr;   // [8 x list_seg_cap] the cached view lists, flat (lengths: DevState::vl_n): inside / outside the time window
     int view_frame = 0;                 // the frame being enqueued went through the view list (its end-of-frame raster may too)
     int view_block = 0;                 // the pose was replaced after the view-list decision of this frame (pose adoption): the frame takes the per-pass culls
     int last_clean_time = 0;            // time of the last clean pass (the age rule a forced scan applies to the slots outside the list)

@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
         }
         __syncthreads();
         const int seg = chunk % LIST_SEGS;
-        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(list_ctr(c, threadIdx.x ? LIST_VI : LIST_V, seg), L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
+        if (threadIdx.x < 2) { L2.base[threadIdx.x] = L2.n[threadIdx.x] ? atomicAdd(list_ctr(c, 1 + threadIdx.x, seg), L2.n[threadIdx.x]) : 0u; L2.n[threadIdx.x] = 0; }
         __syncthreads();
         const unsigned int ba = seg * c.seg_cap + L2.base[0], bi = seg * c.seg_cap + L2.base[1];
 #pragma unroll
@@ -1186,6 +1186,38 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
     if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&st->n_dead, dead);
 }
 
+// ---- the scan's raw output (8 segments per list, each with its own counter so that ~2000 appending blocks do not queue on one word) is
+// concatenated into two flat lists, to which k_append_scan adds the new surfels.  (Sorting the lists by screen tile of the scan pose
+// was tried -- a wave then works inside one 32x32-pixel neighbourhood -- and changed nothing: raster 79 -> 84 us, clean 64 -> 67 us,
+// index 28 -> 29 us.  The list passes are bound by their GATHERS FROM THE STORE, one 64-B line per field and entry whatever the order of
+// the list: 476 k window entries + 640 k outside ones out of 5.4 M slots; profiles/r02_l_kernel_stats.csv.)
+__global__ void k_vlist_offsets(DevState* st, Cam c)
+{
+    if (!st->vl_scan || threadIdx.x != 0) return;
+    for (int which = 0; which < 2; which++) {
+        unsigned int run = 0;
+        for (int seg = 0; seg < LIST_SEGS; seg++) {
+            unsigned int* ctr = list_ctr(c, 1 + which, seg);
+            const unsigned int n = *ctr;
+            *ctr = 0;                                            // re-armed for the clean pass / the next scan
+            st->vl_seg_n[which * LIST_SEGS + seg] = n;
+            st->vl_seg_off[which * LIST_SEGS + seg] = run;
+            run += n;
+        }
+        st->vl_n[which] = run;
+    }
+}
+__global__ __launch_bounds__(MAP_THREADS) void k_vlist_concat(const DevState* __restrict__ st, Cam c, const unsigned int* __restrict__ raw_a, const unsigned int* __restrict__ raw_i,
+                                                              unsigned int* __restrict__ flat_a, unsigned int* __restrict__ flat_i)
+{
+    if (!st->vl_scan) return;
+    const int which = blockIdx.y, seg = blockIdx.x % LIST_SEGS;
+    const unsigned int n = st->vl_seg_n[which * LIST_SEGS + seg], off = st->vl_seg_off[which * LIST_SEGS + seg];
+    const unsigned int* __restrict__ raw = (which ? raw_i : raw_a) + (size_t)seg * c.seg_cap;
+    unsigned int* __restrict__ flat = (which ? flat_i : flat_a) + off;
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) flat[t] = raw[t];
+}
+
 // index-map projection (index_map.vert:40-66) of the view-list entries: the work of k_index_project on the slots that can be seen at all
 __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, Cam c, int time,
                                                             const unsigned int* __restrict__ list, unsigned long long* __restrict__ keys)
@@ -1193,11 +1225,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
-    const int seg = blockIdx.x % LIST_SEGS;
-    const unsigned int n = *list_ctr(c, LIST_V, seg);
-    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
-    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
-        const unsigned int i = seg_list[t];
+    const unsigned int n = st->vl_n[0];
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += blockDim.x * gridDim.x) {
+        const unsigned int i = list[t];
         const float lastT = tm[i].y;
         if ((float)time - lastT > (float)c.timeDelta) continue;   // inactive or tombstone
         const float4 p4 = pc[i];
@@ -1220,14 +1250,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     __shared__ unsigned int s_cand[2 * MAP_THREADS];
     __shared__ unsigned int s_n;
-    const int seg = blockIdx.x % LIST_SEGS;
-    const unsigned int n = *list_ctr(c, LIST_V, seg);
-    const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
-    const unsigned int stride = blockDim.x * (gridDim.x / LIST_SEGS);
+    const unsigned int n = st->vl_n[0];
+    const unsigned int* __restrict__ seg_list = list;
+    const unsigned int stride = blockDim.x * gridDim.x;
     int dead = 0;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x; t0 < n; t0 += stride) {
+    for (unsigned int t0 = blockIdx.x * blockDim.x; t0 < n; t0 += stride) {
         const unsigned int t = t0 + threadIdx.x;
         bool cand = false;
         unsigned int i = 0;
@@ -1328,14 +1357,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int seg = blockIdx.x % LIST_SEGS;
-    // the two view lists of the segment, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
-    const unsigned int na = *list_ctr(c, LIST_V, seg), n = na + ((want & LIST_IDS) ? *list_ctr(c, LIST_VI, seg) : 0u);
-    const unsigned int* __restrict__ seg_a = list_a + (size_t)seg * c.seg_cap;
-    const unsigned int* __restrict__ seg_i = list_i + (size_t)seg * c.seg_cap;
+    // the two view lists, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
+    const unsigned int na = st->vl_n[0], n = na + ((want & LIST_IDS) ? st->vl_n[1] : 0u);
+    const unsigned int* __restrict__ seg_a = list_a;
+    const unsigned int* __restrict__ seg_i = list_i;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
-    const unsigned int stride = blockDim.x * (gridDim.x / LIST_SEGS);
-    for (unsigned int t0 = (blockIdx.x / LIST_SEGS) * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
+    const unsigned int stride = blockDim.x * gridDim.x;
+    for (unsigned int t0 = blockIdx.x * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
         const unsigned int t = t0 + lane;
         int area = 0;
         RvRec R;
@@ -1706,9 +1734,9 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     for (int q = 0; q < wid; q++) wave_off += s_wave[q];
     int rank = s_base + wave_off + incl - mine;
     // the new surfels join the cached view list (they were created from this frame's pixels, so they are in view): one reservation per block
-    const int vseg = blockIdx.x % LIST_SEGS, blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const int blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     const bool to_view = list_v && st->vl_valid;
-    if (tid == 0) s_vbase = (to_view && blk_total) ? atomicAdd(list_ctr(c, LIST_V, vseg), (unsigned int)blk_total) : 0u;
+    if (tid == 0) s_vbase = (to_view && blk_total) ? atomicAdd(&st->vl_n[0], (unsigned int)blk_total) : 0u;
     __syncthreads();
     unsigned int vpos = s_vbase + (unsigned int)(wave_off + incl - mine);
     bool over = false;
@@ -1719,7 +1747,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         const int n = count0 + rank++;
         const unsigned int vp = vpos++;
         if (n >= cap) { over = true; continue; }
-        if (to_view && vp < c.seg_cap) list_v[(size_t)vseg * c.seg_cap + vp] = (unsigned int)n;
+        if (to_view && vp < c.seg_cap * LIST_SEGS) list_v[vp] = (unsigned int)n;
         pc[n] = mpc[k];
         nr[n] = mnr[k];
         { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
@@ -1991,7 +2019,10 @@ static void view_scan(ifx* h, int time)
 {
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
-    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_v, h->list_vi);
+    // raw output in the clean pass's lists 1, 2 (free at this point of a frame and between frames), then concatenated into list_v / list_vi
+    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c);
+    LAUNCH(h, "vlist_offsets", dim3(1), dim3(64), k_vlist_offsets, h->d_state, c);
+    LAUNCH(h, "vlist_concat", dim3(256, 2), dim3(MAP_THREADS), k_vlist_concat, (const DevState*)h->d_state, c, h->list_b, h->list_c, h->list_v, h->list_vi);
 }
 // A forced scan at the current pose with the time of the last processed frame: every slot the list leaves out gets the age rule
 // it may have outlived (see "View list"); cheap no-op when the view-list path never ran since the last scan of this kind.

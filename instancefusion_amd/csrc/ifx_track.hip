@@ -1591,7 +1591,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         if (i == 0 && frame_tracker) ifx_enqueue_hinted_frame_side(h);
         float div = (float)(1 << i);
         float fx = c.fx / div, fy = c.fy / div, cx = c.cx / div, cy = c.cy / div;
-        int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n), nb_rgb = std::min(red_blocks(h, n, RED_IT_RGB), 192);   // the photometric step's launch is dominated by the last block's hand-off and solve: fewer blocks, fewer partial rows (64: 16.9, 192: 15.3, 304: 16.1, 608: 18.5 us per launch)
+        int lw = p.w[i], lh = p.h[i], n = lw * lh, nb = red_blocks(h, n), nb_rgb = std::min(red_blocks(h, n, RED_IT_RGB), h->opt_rgb_blocks > 0 ? h->opt_rgb_blocks : 192);   // the photometric step's launch is dominated by the last block's hand-off and solve: fewer blocks, fewer partial rows (64: 16.9, 192: 15.3, 304: 16.1, 608: 18.5 us per launch)
         // intrinsics of the level the iteration after this level's last one runs at (for the warp matrices the solve emits)
         int nl = i - 1;
         while (nl >= 0 && iterations[nl] == 0) nl--;

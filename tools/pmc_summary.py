@@ -40,9 +40,19 @@ def pmc_table(path, counter):
     return {k: (n, s / n) for k, (n, s) in acc.items()}
 
 
-def pmc(fetch_csv, write_csv, dst, about):
+def pmc(fetch_csv, write_csv, dst, about, bench_json=None):
     fe, wr = pmc_table(fetch_csv, "FETCH_SIZE"), pmc_table(write_csv, "WRITE_SIZE")
-    out = {"_about": about, "kernels": {}}
+    out = {"_about": about + ".  Values are KB per launch (averages).  bytes_read = FETCH_SIZE * 1024 * 2 (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE "
+                     "reports half of the bytes of wide coalesced streaming reads; the factor is calibrated for 16-B-per-lane streams only -- tools/micro/stream_ceiling "
+                     "under the same counters gives the factor for this store's 8-B + 16-B pattern), bytes_written = WRITE_SIZE * 1024.", "kernels": {}}
+    if bench_json:   # the workload the counters were collected on: bench.py uses the file only for a matching run
+        try:
+            with open(bench_json) as f:
+                b = json.loads(f.read().strip().splitlines()[-1])
+            res = b["config"]["workload"].split("surfel map, ")[1].split(" ")[0]
+            out["workload"] = {"res": res, "surfel_slots": b["config"]["surfel_slots"], "surfels_live": b["config"]["surfels_live"], "value_under_profiler": b["value"]}
+        except (OSError, ValueError, KeyError, IndexError) as e:
+            out["workload_error"] = str(e)
     for k in sorted(fe, key=lambda k_: -fe[k_][0] * fe[k_][1]):
         if not k.startswith("k_"):
             continue
@@ -57,6 +67,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "", sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         sys.exit(__doc__)

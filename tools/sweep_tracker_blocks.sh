@@ -1,0 +1,6 @@
+for o in "" "--opt icp_blocks=600" "--opt icp_blocks=1000" "--opt rgb_blocks=96" "--opt rgb_blocks=304" "--opt icp_blocks=600 --opt rgb_blocks=304"; do
+  python bench.py --gpus 1 --steps 150 --warmup 30 --no-cpu-baseline --extras-frames 0 $o 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']
+print('$o', d['value'], d['ms_per_frame_gpu']['track'], 'icp', k['icp_residual']['avg_ms'], 'rgb', k['rgb_step_solve']['avg_ms'])"
+done

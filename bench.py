@@ -63,8 +63,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-oracle sample (about 12 s of one core at 5M surfels)")
     ap.add_argument("--res", default="640x480", help="WxH of the synthetic stream (other BASELINE configurations; the metric is quoted at 640x480)")
-    ap.add_argument("--sharded", action="store_true", help="one stream, every rank holds the map, projection passes sliced across ranks + RCCL all-reduce(MIN) of the key images "
-                    "(instancefusion_amd/sharded.py; strong scaling; pays for tens of millions of surfels -- DESIGN.md section 7).  Default for --gpus N: one replica per rank")
+    ap.add_argument("--sharded", action="store_true", help="one stream into ONE map spatially sharded across the ranks (owner = spatial hash of a surfel's position: every rank stores 1 / N of the "
+                    "map; RCCL all-reduces of the key images and of the winners' attributes between the phases of a frame -- instancefusion_amd/sharded.py, DESIGN.md section 7; strong scaling, "
+                    "geometry only: the instance layer is not sharded yet).  Default for --gpus N: one replica per rank")
+    ap.add_argument("--sharded-projection", action="store_true", help="round 1's variant: every rank holds the whole map, the projection passes are sliced by slot range")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -107,7 +109,10 @@ def main():
     P = W * H
     L = args.loop
     t_gen = time.time()
-    srank = 0 if args.sharded else rank          # sharded: every rank is fed the same stream and map
+    one_map = args.sharded or args.sharded_projection
+    if args.sharded:
+        args.no_instance = True
+    srank = 0 if one_map else rank          # sharded: every rank is fed the same stream and map
     st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + srank, **K)
     masks = [synth.canned_masks(st["obj"][i], st["scene"]) for i in range(L)]
     tick0 = 1000
@@ -115,7 +120,8 @@ def main():
     t_gen = time.time() - t_gen
 
     cap = args.surfels + 2_500_000
-    ef = ifx.ElasticFusion(w=W, h=H, max_surfels=cap, device=dev, **K)
+    owner = args.sharded and world > 1
+    ef = ifx.ElasticFusion(w=W, h=H, max_surfels=(cap // world + P + 500_000) if owner else cap, device=dev, **K, **(dict(n_ranks=world, rank=rank) if owner else {}))
     inst = ifx.InstanceFusion(ef)
     for kv in args.opt:
         k_, v_ = kv.split("=")
@@ -126,10 +132,20 @@ def main():
 
     # frame 0 initialises the tracker's previous-image pyramid; then the synthetic map replaces the
     # first-frame map and the model prediction is re-rendered from it
-    ef.processFrame(st["rgb"][0], st["depth"][0])
-    ef.upload(m)
-    ef.set_pose(st["poses"][0], tick0)
-    ef.combined_predict(st["poses"][0], tick0, tick0)
+    osh = None
+    if owner:
+        from instancefusion_amd import sharded as ifsh
+
+        osh = ifsh.OwnerShardedElasticFusion(ef, dist)
+        osh.process_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+        ef.upload(m)                                   # every rank is handed all rows and keeps the ones it owns
+        ef.set_pose(st["poses"][0], tick0)
+        osh.predict()
+    else:
+        ef.processFrame(st["rgb"][0], st["depth"][0])
+        ef.upload(m)
+        ef.set_pose(st["poses"][0], tick0)
+        ef.combined_predict(st["poses"][0], tick0, tick0)
     del m
 
     if args.close_loops:
@@ -172,8 +188,8 @@ def main():
         if due > nxt + n_frames - 1 or due < nxt:
             seg["shift"] += due - (nxt + n_frames // 2)
 
-    sh = None
-    if args.sharded:
+    sh = osh
+    if args.sharded_projection:
         from instancefusion_amd import sharded as ifsh
 
         sh = ifsh.ShardedElasticFusion(ef, rank, world, dist)
@@ -269,7 +285,7 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside the process.  They are collected by tools/pmc_collect.sh (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS command, corrected as MI355X_MICROARCH.md prescribes) into
         # profiles/<round>_pmc_traffic.json together with the slot count and the kernel list of that run.  A file is used only when it
-        # describes this workload (same resolution, slot count within 2 %) and this kernel set; otherwise `traffic` is null -- never a stale constant.
+        # describes this workload (same resolution, slot count within 10 %: tombstones come and go) and this kernel set; otherwise `traffic` is null -- never a stale constant.
         pmc, pmc_src = {}, None
         try:
             cands = sorted(f_ for f_ in os.listdir(os.path.join(ROOT, "profiles")) if f_.endswith("_pmc_traffic.json"))
@@ -277,7 +293,7 @@ def main():
                 with open(os.path.join(ROOT, "profiles", f_)) as f:
                     j = json.load(f)
                 meta = j.get("workload")
-                if not meta or meta.get("res") != f"{W}x{H}" or abs(meta.get("surfel_slots", 0) - n_slots) > 0.02 * n_slots:
+                if not meta or meta.get("res") != f"{W}x{H}" or abs(meta.get("surfel_slots", 0) - n_slots) > 0.10 * n_slots:
                     continue
                 if not all(("k_" + n_) in j["kernels"] for n_ in names if table[n_]["launches"] and algorithmic_bytes(n_, n_slots, P) > 0):
                     continue
@@ -377,14 +393,14 @@ def main():
         del cpu_map
 
     if rank == 0:
-        fps = (1 if args.sharded else world) * args.steps / dt
+        fps = (1 if one_map else world) * args.steps / dt
         out = {
             "metric": "frames/s + ms/frame (ICP|fuse|instance) at 640x480, 5M surfels, 1/2/4/8 GPU",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None,
+            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if one_map else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.surfels}-surfel map, {W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}",
-                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"sharded projection x{world}" if args.sharded else f"replicas x{world}"), "loop_frames": L},
+                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"spatially sharded map x{world}" if args.sharded else (f"sharded projection x{world}" if args.sharded_projection else f"replicas x{world}")), "loop_frames": L},
             "ms_per_frame_gpu": {k_: round(v / args.steps, 4) for k_, v in stage.items()},
             "instance": {"calls_in_window": calls_in_window, "ms_per_call": round(inst_ms / calls_in_window, 4) if calls_in_window else None,
                          "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,

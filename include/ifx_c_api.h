@@ -49,7 +49,7 @@ typedef struct ifx_config {
     int32_t so3;                 /* 1 */
     int32_t max_surfels;         /* capacity of the surfel store (reference: 1536^2, EF/GlobalModel.cpp:22-23) */
     int32_t device;              /* HIP device ordinal */
-    int32_t n_ranks, rank;       /* spatial-hash map sharding: this handle owns shard `rank` of `n_ranks` */
+    int32_t n_ranks, rank;       /* spatially sharded map: this handle stores shard `rank` of `n_ranks` (0 or 1: the whole map); see ifx_owner_frame_phase */
 } ifx_config;
 
 typedef struct ifx ifx_t;
@@ -105,6 +105,23 @@ int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids,
 /* The handle's HIP streams (hipStream_t): work enqueued on the main stream between two phases (the key exchange) is
  * ordered with the phases without any host synchronisation. */
 int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
+/* ---- spatially sharded map (BASELINE configurations 4 and 5): a handle created with ifx_config::n_ranks = G > 1 STORES only
+ * the surfels it owns -- owner = Morton code of the 8 cm voxel of the position a surfel was created (or uploaded) at, mod G (ifx_owner_of) --
+ * i.e. 1 / G of the map.  One process per GPU, every rank fed the same frame.  A frame is seven calls of ifx_owner_frame_phase (phase 0..6,
+ * the image pointers are used by phase 0); after phase p the caller reduces, across the ranks, the device buffers ifx_owner_exchange(p)
+ * lists: ops 0 = element-wise MINIMUM of unsigned 64-bit words (key images: depth | creation number), ops 1 = SUM of 32-bit words
+ * (attribute images with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  instancefusion_amd/sharded.py does
+ * it with RCCL all-reduces on the handle's stream.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
+ * bit.  Per-surfel work (projections, fusion update, clean) is sharded, per-pixel work (tracking, association) replicated; the instance
+ * layer and the loop-closure detection are not available in this mode yet. */
+int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);
+int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n);
+/* ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose): step 0, exchange as after phase 4,
+ * step 1, exchange as after phase 5, step 2. */
+int ifx_owner_predict_phase(ifx_t* h, int step);
+int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out);
+/* creation numbers (uint32) of the live surfels in the order of ifx_map_download; returns the count */
+int ifx_map_seq(ifx_t* h, uint32_t* out, int max_n);
 /* Diagnostics of the cached view list ("View list"): out4 = entries inside the time window, stable entries
  * outside it, scans of the store so far, frames since the last scan. */
 int ifx_view_list_stats(ifx_t* h, int32_t* out4);

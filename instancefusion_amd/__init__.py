@@ -71,6 +71,11 @@ _SIGS = {
     "ifx_sharded_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
     "ifx_key_images": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ifx_stream_handles": (C.c_int, [_P, _P, _P]),
+    "ifx_owner_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
+    "ifx_owner_exchange": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
+    "ifx_owner_of": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),
+    "ifx_map_seq": (C.c_int, [_P, _P, C.c_int]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_view_list_stats": (C.c_int, [_P, _P]),
@@ -404,6 +409,13 @@ class ElasticFusion:
     def set_pose(self, pose, tick):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)
         self._chk(self.L.ifx_set_pose(self.handle, _ptr(p), int(tick)), "ifx_set_pose")
+
+    def seq(self):
+        """creation numbers of the live surfels in download() order (a sharded map's shards merge by them into the unsharded map)"""
+        n = self.count
+        out = np.zeros(max(n, 1), np.uint32)
+        m = self._chk(self.L.ifx_map_seq(self.handle, _ptr(out), n), "ifx_map_seq")
+        return out[:m]
 
     def compact(self):
         self._chk(self.L.ifx_compact(self.handle), "ifx_compact")

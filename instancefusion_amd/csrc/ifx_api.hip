@@ -78,6 +78,10 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         g_err = "width/height must be positive multiples of 4 (three pyramid levels) and max_surfels > 0";
         return IFX_E_INVALID;
     }
+    if (cfg->n_ranks < 0 || cfg->n_ranks > 64 || (cfg->n_ranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->n_ranks)) || (cfg->n_ranks <= 1 && cfg->rank != 0)) {
+        g_err = "n_ranks / rank: a spatially sharded map has 2..64 ranks and 0 <= rank < n_ranks (n_ranks 0 or 1: unsharded, rank 0)";
+        return IFX_E_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device available: libifx.so has no CPU fallback"; return IFX_E_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_err = "device ordinal out of range"; return IFX_E_INVALID; }
@@ -102,6 +106,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096 + P);
     ALLOC(h->list_a, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_b, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_c, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     if (const char* ev = getenv("IFX_RASTER_TILES")) h->opt_raster_tiles = atoi(ev);   // A/B switch for whole test runs
+    if (cfg->n_ranks > 1) h->opt_raster_tiles = 0;   // (the tiled rasteriser's pair records carry slots, the sharded map's keys creation numbers)
     h->tile_pair_cap = (unsigned int)std::max<size_t>(2 * C, (size_t)1 << 22);
     ALLOC(h->tile_n, 5 * 4096 * 4 + 64); ALLOC(h->tile_box, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->tile_pairs, (size_t)h->tile_pair_cap * 4);
     hipMemset(h->tile_n, 0, 5 * 4096 * 4 + 64);
@@ -110,6 +115,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->list_v, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_vi, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
+    ALLOC(h->seq, C * 4); ALLOC(h->seq2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
     ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (std::max(SN, (size_t)1 << 24) / 1024 + 8) * 4);   // also serves the 256^3-cell scan of the kNN grid
@@ -157,7 +163,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels,
+    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
@@ -382,6 +388,7 @@ static int enqueue_loop_closure_tracker(ifx* h)
 int ifx_tracker_bootstrap_pose(ifx* h, const float* d_in_pose16);
 static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult, int bootstrap = 0)
 {
+    if (h->cfg.n_ranks > 1) { h->err = "a sharded map (n_ranks > 1) is driven through ifx_owner_frame_phase / ifx_owner_exchange"; return IFX_E_STATE; }
     if (bootstrap && !in_pose16) { h->err = "bootstrap needs inPose (EF/ElasticFusion.cpp:352-356)"; return IFX_E_INVALID; }
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
@@ -538,6 +545,92 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
         h->tick++;
     }
     return IFX_OK;
+}
+
+// ---- spatially sharded map (ifx_config::n_ranks > 1): one frame in seven phases; after phase p the caller reduces the buffers
+// ifx_owner_exchange(p) lists across the ranks (instancefusion_amd/sharded.py: RCCL all-reduce; tests: the same reduction by hand)
+int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
+extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
+{
+    if (!h || phase < 0 || phase > 6) return IFX_E_INVALID;
+    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (h->lc_enable) { h->err = "loop-closure detection is not available on a sharded map"; return IFX_E_STATE; }
+    const bool first = h->tick == 1 && h->n_traj == 0;
+    const int s = h->tick & 1;
+    FrameSlot& f = h->slot[s];
+    if (phase == 0) {
+        if (!d_rgb || !d_depth) return IFX_E_INVALID;
+        h->tracked_ahead = 0;
+        ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
+        const int two = h->opt_two_streams;
+        h->opt_two_streams = 0;
+        int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, 0);
+        h->opt_two_streams = two;
+        if (r) return r;
+        f.for_tick = -1;
+        ifx_bind_slot(h, s);
+        if (!first) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }   // replicated: every rank holds the exchanged prediction (DESIGN.md section 7 on the alternative)
+    }
+    int r = ifx_map_owner_phase(h, phase, first);
+    if (r) return r;
+    if (phase == 6) {
+        const int slot = h->n_traj % h->max_traj;
+        LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+        hipEventRecord(f.released, h->stream);
+        h->ev_result = f.released;
+        h->seg_counts_valid = 0;
+        h->n_traj++;
+        h->tick++;
+    }
+    return IFX_OK;
+}
+// ElasticFusion::predict on a sharded map outside a frame (after an upload / set_pose): step 0 = local raster (then exchange as after
+// phase 4), step 1 = owned winners (then exchange as after phase 5), step 2 = fill-in
+extern "C" int ifx_owner_predict_phase(ifx_t* h, int step)
+{
+    if (!h || step < 0 || step > 2) return IFX_E_INVALID;
+    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_predict_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    h->tracked_ahead = 0;
+    return ifx_map_owner_phase(h, step == 0 ? 104 : 4 + step, false);
+}
+// what to reduce after phase `phase`: ptrs[k] (device), bytes[k], ops[k] (0: element-wise minimum of unsigned 64-bit words, 1: sum of
+// 32-bit words -- the supports are disjoint, so the sum is a bitwise merge); returns the number of buffers (0: nothing to exchange)
+extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n)
+{
+    if (!h || !ptrs || !bytes || !ops) return IFX_E_INVALID;
+    const bool first = h->tick == 1 && h->n_traj == 0;   // first frame in flight (phase 6 has not run yet); an uploaded map makes every frame a regular one
+    const size_t P = (size_t)h->P;
+    int n = 0;
+    auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
+    switch (phase) {
+    case 0: if (!first) add(h->key_index, P * 8, 0); break;
+    case 1: if (!first) { add(h->index_vc, P * 16, 1); add(h->index_nr, P * 16, 1); } break;
+    case 2: if (!first) add(h->key_index, P * 8, 0); break;
+    case 3: if (!first) add(h->index_tap, P * 16, 1); break;
+    case 4: add(h->key_splat, P * 8, 0); add(h->key_ids, P * 8, 0); add(h->key_both, P * 8, 0); break;
+    case 5: add(h->pred_vertex, P * 16, 1); add(h->pred_normal, P * 16, 1); add(h->pred_image, P * 4, 1); add(h->pred_inst, P * 4, 1); add(h->pred_time, P * 2, 1); break;
+    default: break;
+    }
+    return n;
+}
+extern "C" int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out)
+{
+    if (!xyz || !out || n < 0) return IFX_E_INVALID;
+    for (int i = 0; i < n; i++) out[i] = ifx_owner_of_point(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], n_ranks);
+    return IFX_OK;
+}
+// creation numbers of the live surfels, in the order of ifx_map_download (which compacts): merging the shards of a sharded map by them
+// gives the unsharded map
+extern "C" int ifx_map_seq(ifx_t* h, uint32_t* out, int max_n)
+{
+    if (!h || !out) return IFX_E_INVALID;
+    int r = ifx_compact(h);
+    if (r) return r;
+    DevState hs;
+    HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+    const int n = std::min(hs.count, max_n);
+    HIPCHK(h, hipMemcpy(out, h->seq, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return n;
 }
 
 extern "C" int ifx_enqueue_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth, int64_t timestamp, const float* in_pose16, float weight_mult)
@@ -782,6 +875,24 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     h->tracked_ahead = 0;
     h->seg_counts_valid = 0;
     h->map_external = 1;
+    // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
+    const int n_all = n;
+    std::vector<uint32_t> keep;
+    std::vector<float> f_pc, f_nr, f_col, f_tm, f_ic, f_votes;
+    keep.reserve(h->cfg.n_ranks > 1 ? (size_t)n / h->cfg.n_ranks + 1024 : (size_t)n);
+    for (int i = 0; i < n; i++)
+        if (h->cfg.n_ranks <= 1 || ifx_owner_of_point(pc[(size_t)i * 4], pc[(size_t)i * 4 + 1], pc[(size_t)i * 4 + 2], h->cfg.n_ranks) == h->cfg.rank) keep.push_back((uint32_t)i);
+    if (h->cfg.n_ranks > 1) {
+        const size_t m = keep.size();
+        auto gather = [&](const float* src, int width, std::vector<float>& dst) {
+            if (!src) return (const float*)nullptr;
+            dst.resize(m * width);
+            for (size_t k = 0; k < m; k++) memcpy(&dst[k * width], &src[(size_t)keep[k] * width], (size_t)width * 4);
+            return (const float*)dst.data();
+        };
+        pc = gather(pc, 4, f_pc); nr = gather(nr, 4, f_nr); col = gather(col, 2, f_col); tm = gather(tm, 2, f_tm); ic = gather(ic, 4, f_ic); votes = gather(votes, 48, f_votes);
+        n = (int)m;
+    }
     if (n > h->cap) { h->err = "upload exceeds capacity"; return IFX_E_CAPACITY; }
     if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
@@ -801,7 +912,8 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     }
     DevState hs;
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
-    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0; hs.vl_valid = 0;
+    HIPCHK(h, hipMemcpy(h->seq, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0; hs.vl_valid = 0; hs.next_seq = (unsigned int)n_all;
     h->view_dirty = 0;
     {
         float rmax = 0.f;

@@ -48,6 +48,7 @@ struct DevState {
     int seg_counts[2];
     int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
     unsigned int append_ticket;  // last-block ticket of k_append_scan
+    unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
     // local loop-closure detection (EF/ElasticFusion.cpp:453-566).  The model-to-model tracker has a DevState of its own (ifx::d_m2m):
     // there `count` counts the pixels of the INACTIVE render and `skip` is set when it is empty; the verdict lands in lc[] of the MAIN state.
@@ -230,6 +231,7 @@ struct ifx {
     unsigned int* d_list_ctr = nullptr;   // [4 lists][8 segments] lengths, 128 B apart (raster, clean candidates, kill, view list)
     unsigned int list_seg_cap = 0;
     int32_t *labels = nullptr, *labels2 = nullptr;   // [cap] bestIDInEachSurfel per slot
+    uint32_t *seq = nullptr, *seq2 = nullptr;        // [cap] creation number per slot (ascending; = the slot index of an unsharded, compacted map)
     int* scan_flags = nullptr;         // [max(cap,P)]
     int* scan_block = nullptr;
     int* scan_out = nullptr;

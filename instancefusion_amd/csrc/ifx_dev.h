@@ -187,6 +187,26 @@ __host__ __device__ inline double ifx_quant(float p, double M)
 #define IFX_ACC_REPL 4       // replicas of a global accumulator row (same-address atomics queue up at the memory side)
 #define IFX_ACC_STRIDE 32    // doubles per replica row (256 B: a row per cache line pair)
 
+// ---- owner of a surfel in the spatially sharded map: a pure function of the position it was created at (or uploaded
+// with): 8 cm voxel -> 30-bit Morton code -> mod n_ranks, so that neighbouring voxels land on different GPUs (load balance) and
+// every rank can tell who owns a new surfel without asking.  instancefusion_amd/dist.py owner_of is the same function.
+__host__ __device__ inline unsigned int ifx_part1by2_10(unsigned int v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__host__ __device__ inline int ifx_owner_of_point(float x, float y, float z, int n_ranks)
+{
+    if (n_ranks <= 1) return 0;
+    const int vx = (int)floorf(x / 0.08f) + 512, vy = (int)floorf(y / 0.08f) + 512, vz = (int)floorf(z / 0.08f) + 512;
+    const unsigned int code = ifx_part1by2_10((unsigned int)vx) | (ifx_part1by2_10((unsigned int)vy) << 1) | (ifx_part1by2_10((unsigned int)vz) << 2);
+    return (int)(code % (unsigned int)n_ranks);
+}
+
 // order-preserving map float -> uint for atomicMin depth keys (depths are >= 0 here but be general)
 __device__ inline unsigned int depth_bits(float z)
 {

@@ -69,8 +69,23 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
 // A consumer block works on segment blockIdx % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk).
 #define LIST_SEGS IFX_LIST_SEGS
 #define LIST_CTR_STRIDE IFX_LIST_CTR_STRIDE   // uints between counters: 128 B
-struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; };   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; };   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
 __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
+// Spatially sharded map: the id a surfel carries in keys / id images is its creation number (the same on every rank; ascending in slot order,
+// so "lowest id wins" is the single-GPU tie-break), and a rank finds the slot of an id it owns by binary search -- -1: another rank's surfel.
+__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 1 ? c.seq[i] : i; }
+__device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id)
+{
+    if (c.own_n <= 1) return (int)id;
+    int lo = 0, hi = count - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned int v = c.seq[mid];
+        if (v == id) return mid;
+        if (v < id) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
 static Cam make_cam(ifx* h)
 {
     Cam c;
@@ -78,6 +93,7 @@ static Cam make_cam(ifx* h)
     c.maxDepth = h->cfg.max_depth_processed; c.conf = h->cfg.confidence; c.timeDelta = h->cfg.time_delta;
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
+    c.seq = h->seq; c.own_n = h->cfg.n_ranks > 1 ? h->cfg.n_ranks : 1; c.own_rank = h->cfg.n_ranks > 1 ? h->cfg.rank : 0;
     return c;
 }
 
@@ -154,7 +170,7 @@ __global__ void k_init_flags(const float* __restrict__ dm, const float* __restri
 }
 __global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const float* __restrict__ dmf, const uint8_t* __restrict__ rgb, Cam c, int tick,
                                const int* __restrict__ flags, const int* __restrict__ rank, int cap, float4* __restrict__ pc, float4* __restrict__ nr,
-                               float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes)
+                               float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes, uint32_t* __restrict__ seq)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.w * c.h || !flags[k]) return;
@@ -175,10 +191,11 @@ __global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const
     if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad));
     ic[n] = make_float4(-1.f, -1.f, -1.f, -1.f);
     for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(-1.f, -1.f, -1.f, -1.f);
+    seq[n] = (uint32_t)n;
 }
 __global__ void k_init_count(DevState* st, const int* total, int cap)
 {
-    if (threadIdx.x == 0) { int t = *total; st->count = t < cap ? t : cap; st->n_dead = 0; st->n_new = st->count; st->vl_valid = 0; }
+    if (threadIdx.x == 0) { int t = *total; st->count = t < cap ? t : cap; st->n_dead = 0; st->n_new = st->count; st->vl_valid = 0; st->next_seq = (unsigned int)st->count; }
 }
 
 int ifx_map_init_first(ifx* h)
@@ -187,7 +204,7 @@ int ifx_map_init_first(ifx* h)
     LAUNCH(h, "init_flags", dim3(cdiv(h->P, 256)), dim3(256), k_init_flags, h->dm, h->dmf, c, h->scan_flags);
     ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
     LAUNCH(h, "init_scatter", dim3(cdiv(h->P, 256)), dim3(256), k_init_scatter, h->d_state, h->dm, h->dmf, h->rgb, c, h->tick, h->scan_flags, h->scan_out, h->cap,
-           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes);
+           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes, h->seq);
     LAUNCH(h, "init_count", dim3(1), dim3(64), k_init_count, h->d_state, &h->d_state->seg_counts[0], h->cap);
     return IFX_OK;
 }
@@ -216,13 +233,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
         float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
         if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
         int px = (int)floorf(u), py = (int)floorf(v);
-        key_min(&keys[py * c.w + px], make_key(p.z, (unsigned int)i));
+        key_min(&keys[py * c.w + px], make_key(p.z, key_id(c, (unsigned int)i)));
     }
 }
 // index_map.frag:33-40: gathers the winner's attributes; also re-arms the key image for the next pass
 __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, int P, uint32_t* __restrict__ index_id,
-                                float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm, int time, float conf_thr, float4* __restrict__ tap)
+                                float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm, int time, float conf_thr, float4* __restrict__ tap, Cam c)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -237,16 +254,22 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     }
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
-    float4 p4 = pc[id];
+    const int li = local_slot(c, st->count, id);
+    if (li < 0) {   // sharded map: another rank's surfel won this pixel -- that rank writes its attributes, this one zeros (the images are summed bitwise across ranks)
+        if (index_id) { index_id[k] = id; vc[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); if (ct) ct[k] = make_float4(0, 0, 0, 0); }
+        if (tap) tap[k] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    float4 p4 = pc[li];
     float2 t2 = make_float2(0.f, 0.f);
-    if (ct || tap) t2 = tm[id];
+    if (ct || tap) t2 = tm[li];
     v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
     if (index_id) {
-        float4 n4 = nr[id];
+        float4 n4 = nr[li];
         v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
         index_id[k] = id;
         vc[k] = make_float4(p.x, p.y, p.z, p4.w);
-        if (ct) { float2 c2 = col[id]; ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y); }
+        if (ct) { float2 c2 = col[li]; ct[k] = make_float4(c2.x, c2.y, t2.x, t2.y); }
         nrm[k] = make_float4(nn.x, nn.y, nn.z, n4.w);
     }
     // 16-B record for the clean window taps: (x, y, z, initTime) with two flags in the (otherwise positive)
@@ -263,7 +286,7 @@ static void index_pass(ifx* h, const float* d_pose_inv, int time, bool for_assoc
     if (part != 2) LAUNCH(h, "index_project", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_index_project, h->d_state, d_pose_inv, (const float4*)h->pc, (const float2*)h->tm, c, time, h->key_index);
     if (part != 1) LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, for_association ? (float4*)nullptr : (float4*)h->index_ct, (float4*)h->index_nr, time,
-           h->cfg.confidence, (float4*)nullptr);
+           h->cfg.confidence, (float4*)nullptr, c);
 }
 
 // ------------------------------------------------------------------ disc rasteriser (a9, a14)
@@ -408,7 +431,12 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     uint16_t to = 0;
     if (key != IFX_KEY_EMPTY) {
         const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
-        unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
+        const int li = local_slot(c, st->count, (unsigned int)(key & 0xFFFFFFFFull));
+        if (li < 0) key = IFX_KEY_EMPTY;   // sharded map: the winner's rank writes this pixel, the others leave zeros (summed bitwise across ranks)
+    }
+    if (key != IFX_KEY_EMPTY) {
+        const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+        unsigned int id = (unsigned int)local_slot(c, st->count, (unsigned int)(key & 0xFFFFFFFFull));
         float z = key_depth(key);
         float4 p4 = pc[id], n4 = nr[id];
         float2 c2 = col[id], t2 = tm[id];
@@ -688,7 +716,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
     const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
     for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
         const unsigned int e = seg_list[t];
-        const unsigned int i = e & LIST_IDX;
+        const unsigned int i = e & LIST_IDX, kid = key_id(c, i);
         SurfGeo G;
         surfel_geo(T, pc[i], nr[i], e, c, G);
         const v3 q = G.q, nn = G.nn;
@@ -714,8 +742,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                     float z;
                     if (!disc_hit(dd, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
                     if (!(z >= -c.maxDepth && z <= c.maxDepth)) continue;
-                    if (to_act) key_min(&key_splat[py * c.w + px], make_key(z, i));
-                    if (to_old) key_min(&key_ids[py * c.w + px], make_key(z, i));
+                    if (to_act) key_min(&key_splat[py * c.w + px], make_key(z, kid));
+                    if (to_old) key_min(&key_ids[py * c.w + px], make_key(z, kid));
                 }
             continue;
         }
@@ -735,9 +763,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                 // 127 -> 56 us), so a pixel covered in both goes to a third image once; the resolve takes min(own, both).
                 const bool in_s = do_s && px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
                 const bool in_i = do_i && px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
-                if (in_s && in_i) key_min(&key_both[py * c.w + px], make_key(z, i));
-                else if (in_s) key_min(&key_splat[py * c.w + px], make_key(z, i));
-                else if (in_i) key_min(&key_ids[py * c.w + px], make_key(z, i));
+                if (in_s && in_i) key_min(&key_both[py * c.w + px], make_key(z, kid));
+                else if (in_s) key_min(&key_splat[py * c.w + px], make_key(z, kid));
+                else if (in_i) key_min(&key_ids[py * c.w + px], make_key(z, kid));
             }
     }
 }
@@ -990,7 +1018,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                         if (p.z > 0.f) {
                             float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
                             if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) && i >= lo && i < hi)
-                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, (unsigned int)i));
+                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, key_id(c, (unsigned int)i)));
                             cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
                         }
                     }
@@ -1570,7 +1598,8 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
                 }
             if (counter > 0) {
                 res = best;
-                atomicMin(&upd_owner[best], (uint32_t)(i * c.h + j));   // first pixel in column-major order owns the surfel
+                const int lb = local_slot(c, st->count, best);
+                if (lb >= 0) atomicMin(&upd_owner[lb], (uint32_t)(i * c.h + j));   // first pixel in column-major order owns the surfel (sharded map: only the surfel's rank keeps the score)
             } else res = ASSOC_NEW;
         }
     }
@@ -1585,9 +1614,11 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     const int par = time % 2, i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + par, j = 2 * (blockIdx.y * blockDim.y + threadIdx.y) + par;   // the pixels that can hold an association
     if (i >= c.w || j >= c.h) return;
     int k = j * c.w + i;
-    uint32_t id = assoc[k];
-    if (id >= ASSOC_NEW) return;
-    if ((int)id >= st->count) return;
+    const uint32_t gid = assoc[k];
+    if (gid >= ASSOC_NEW) return;
+    const int li = local_slot(c, st->count, gid);   // sharded map: -1 = another rank's surfel (that rank applies the update)
+    if (li < 0 || li >= st->count) return;
+    const uint32_t id = (uint32_t)li;
     if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
     upd_owner[id] = 0xFFFFFFFFu;
     float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
@@ -1667,14 +1698,16 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // before it (<= 300 integers), scans its own flags and scatters; the block that finishes last publishes the
 // new surfel count.
 #define NEW_PER_BLOCK 1024
+// flags: bit 0 = the new surfel survives its first clean test, bit 1 = ... and this rank owns it (spatially sharded map; always set otherwise).
+// block_counts: [block][2] = survivors, owned survivors.
 __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
                                                          const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags,
                                                          int* __restrict__ block_counts)
 {
-    __shared__ int lds[4];
+    __shared__ int lds[4][2];
     const int P = c.w * c.h, ord0 = blockIdx.x * NEW_PER_BLOCK + threadIdx.x * 4;
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
-    int keep[4], cnt = 0;
+    int keep[4], cnt = 0, own = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int ord = ord0 + u;
@@ -1683,68 +1716,78 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
             const int i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
             if (assoc[k] == ASSOC_NEW) {
                 float lastT = -2.f;
-                keep[u] = clean_test(T, c, time, mpc[k], mnr[k], (float)time, lastT, tap);
+                const float4 m4 = mpc[k];
+                if (clean_test(T, c, time, m4, mnr[k], (float)time, lastT, tap)) keep[u] = 1 | ((c.own_n <= 1 || ifx_owner_of_point(m4.x, m4.y, m4.z, c.own_n) == c.own_rank) ? 2 : 0);
             }
         }
-        cnt += keep[u];
+        cnt += keep[u] & 1;
+        own += keep[u] >> 1;
     }
     if (ord0 + 3 < P) *reinterpret_cast<int4*>(flags + ord0) = make_int4(keep[0], keep[1], keep[2], keep[3]);
     else
         for (int u = 0; u < 4; u++) if (ord0 + u < P) flags[ord0 + u] = keep[u];
     cnt = wave_sum_i(cnt);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+    own = wave_sum_i(own);
+    if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6][0] = cnt; lds[threadIdx.x >> 6][1] = own; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        block_counts[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-    }
+    if (threadIdx.x < 2) block_counts[blockIdx.x * 2 + threadIdx.x] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x < 2 * LIST_SEGS) c.lctr[(LIST_SEGS + threadIdx.x) * LIST_CTR_STRIDE] = 0;   // lists 1, 2: k_clean_list, the launch before this one, was their last reader
 }
 
+// Two ranks per surviving new surfel: its place in the frame's append order (-> creation number, the same on every rank) and its place among
+// the ones this rank stores (-> slot).  Without sharding the two coincide.
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
                                                      const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
                                                      float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
-                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels)
+                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq)
 {
-    __shared__ int s_wave[4], s_base, s_last;
+    __shared__ int s_wave[4][2], s_base[2], s_last;
     __shared__ unsigned int s_vbase;
     const int P = c.w * c.h, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int count0 = st->count;
+    const unsigned int seq0 = st->next_seq;
     // counts of the blocks before this one
-    int before = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += 256) before += block_counts[b];
-    before = wave_sum_i(before);
-    if (lane == 0) s_wave[wid] = before;
+    int beforeG = 0, beforeO = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) { beforeG += block_counts[2 * b]; beforeO += block_counts[2 * b + 1]; }
+    beforeG = wave_sum_i(beforeG);
+    beforeO = wave_sum_i(beforeO);
+    if (lane == 0) { s_wave[wid][0] = beforeG; s_wave[wid][1] = beforeO; }
     __syncthreads();
-    if (tid == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (tid < 2) s_base[tid] = s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
     __syncthreads();
-    // exclusive scan of this block's flags: 4 per thread, wave scan by shuffles, wave totals through LDS
+    // exclusive scans of this block's flags: 4 per thread, wave scan by shuffles, wave totals through LDS
     const int ord0 = blockIdx.x * NEW_PER_BLOCK + tid * 4;
     int f[4] = {0, 0, 0, 0};
     if (ord0 + 3 < P) { int4 v = *reinterpret_cast<const int4*>(flags + ord0); f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
     else
         for (int u = 0; u < 4; u++) if (ord0 + u < P) f[u] = flags[ord0 + u];
-    const int mine = f[0] + f[1] + f[2] + f[3];
-    int incl = mine;
+    const int mineG = (f[0] & 1) + (f[1] & 1) + (f[2] & 1) + (f[3] & 1), mineO = (f[0] >> 1) + (f[1] >> 1) + (f[2] >> 1) + (f[3] >> 1);
+    int inclG = mineG, inclO = mineO;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int tg = __shfl_up(inclG, o), to = __shfl_up(inclO, o);
+        if (lane >= o) { inclG += tg; inclO += to; }
+    }
     __syncthreads();
-    if (lane == 63) s_wave[wid] = incl;
+    if (lane == 63) { s_wave[wid][0] = inclG; s_wave[wid][1] = inclO; }
     __syncthreads();
-    int wave_off = 0;
-    for (int q = 0; q < wid; q++) wave_off += s_wave[q];
-    int rank = s_base + wave_off + incl - mine;
+    int wave_offG = 0, wave_offO = 0;
+    for (int q = 0; q < wid; q++) { wave_offG += s_wave[q][0]; wave_offO += s_wave[q][1]; }
+    int rankG = s_base[0] + wave_offG + inclG - mineG, rankO = s_base[1] + wave_offO + inclO - mineO;
     // the new surfels join the cached view list (they were created from this frame's pixels, so they are in view): one reservation per block
-    const int blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const int blk_total = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
     const bool to_view = list_v && st->vl_valid;
     if (tid == 0) s_vbase = (to_view && blk_total) ? atomicAdd(&st->vl_n[0], (unsigned int)blk_total) : 0u;
     __syncthreads();
-    unsigned int vpos = s_vbase + (unsigned int)(wave_off + incl - mine);
+    unsigned int vpos = s_vbase + (unsigned int)(wave_offO + inclO - mineO);
     bool over = false;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        if (!f[u]) continue;
+        if (!(f[u] & 1)) continue;
+        const unsigned int sq = seq0 + (unsigned int)rankG++;
+        if (!(f[u] & 2)) continue;   // another rank stores it
         const int ord = ord0 + u, i = ord / c.h, j = ord - i * c.h, k = j * c.w + i;
-        const int n = count0 + rank++;
+        const int n = count0 + rankO++;
         const unsigned int vp = vpos++;
         if (n >= cap) { over = true; continue; }
         if (to_view && vp < c.seg_cap * LIST_SEGS) list_v[vp] = (unsigned int)n;
@@ -1756,9 +1799,10 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
         for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
         labels[n] = -1;   // no label until the next label scan (the slot may hold one from before a compaction)
+        seq[n] = sq;
     }
     if (over) st->overflow = 1;
-    // every block has read st->count before it draws its ticket; the last one publishes the new count
+    // every block has read st->count / st->next_seq before it draws its ticket; the last one publishes the new values
     __syncthreads();
     if (tid == 0) {
         unsigned int t = __hip_atomic_fetch_add(&st->append_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1766,17 +1810,20 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     }
     __syncthreads();
     if (!s_last) return;
-    int total = 0;
-    for (int b = tid; b < nblocks; b += 256) total += block_counts[b];
-    total = wave_sum_i(total);
+    int totalG = 0, totalO = 0;
+    for (int b = tid; b < nblocks; b += 256) { totalG += block_counts[2 * b]; totalO += block_counts[2 * b + 1]; }
+    totalG = wave_sum_i(totalG);
+    totalO = wave_sum_i(totalO);
     __syncthreads();
-    if (lane == 0) s_wave[wid] = total;
+    if (lane == 0) { s_wave[wid][0] = totalG; s_wave[wid][1] = totalO; }
     __syncthreads();
     if (tid == 0) {
-        int t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3], nc = count0 + t;
+        const int tg = s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0], to = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+        int nc = count0 + to;
         if (nc > cap) { nc = cap; st->overflow = 1; }
         st->n_new = nc - count0;
         st->count = nc;
+        st->next_seq = seq0 + (unsigned int)tg;
         __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1791,13 +1838,15 @@ __global__ void k_alive_flags(const DevState* __restrict__ st, const float2* __r
 __global__ void k_compact_scatter(const int* __restrict__ flags, const int* __restrict__ rank, int cap, const float4* __restrict__ pc, const float4* __restrict__ nr,
                                   const float2* __restrict__ col, const float2* __restrict__ tm, const float4* __restrict__ ic, const float4* __restrict__ votes,
                                   const int32_t* __restrict__ labels, float4* __restrict__ pc2, float4* __restrict__ nr2, float2* __restrict__ col2,
-                                  float2* __restrict__ tm2, float4* __restrict__ ic2, float4* __restrict__ votes2, int32_t* __restrict__ labels2)
+                                  float2* __restrict__ tm2, float4* __restrict__ ic2, float4* __restrict__ votes2, int32_t* __restrict__ labels2,
+                                  const uint32_t* __restrict__ seq, uint32_t* __restrict__ seq2)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap || !flags[i]) return;
     int d = rank[i];
     pc2[d] = pc[i]; nr2[d] = nr[i]; col2[d] = col[i]; tm2[d] = tm[i]; ic2[d] = ic[i];
     if (labels2) labels2[d] = labels[i];
+    seq2[d] = seq[i];
     for (int q = 0; q < 12; q++) votes2[(size_t)q * cap + d] = votes[(size_t)q * cap + i];
 }
 __global__ void k_compact_count(DevState* st, const int* total)
@@ -1815,10 +1864,10 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
     ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
     LAUNCH(h, "compact_scatter", dim3(cdiv(n, 256)), dim3(256), k_compact_scatter, h->scan_flags, h->scan_out, n, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, (const float4*)h->ic, (const float4*)h->votes, (const int32_t*)h->labels, (float4*)h->pc2, (float4*)h->nr2,
-           (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2);
+           (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2, (const uint32_t*)h->seq, h->seq2);
     LAUNCH(h, "compact_count", dim3(1), dim3(64), k_compact_count, h->d_state, &h->d_state->seg_counts[1]);
-    std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2);
-    if (refresh_ids) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image
+    std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2); std::swap(h->seq, h->seq2);
+    if (refresh_ids && h->cfg.n_ranks <= 1) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image (a sharded map's id image holds creation numbers: nothing changed)
     return IFX_OK;
 }
 
@@ -1994,7 +2043,7 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
     if (part == 1) return;
     LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, d_pose_inv, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
-           (float4*)h->index_tap);
+           (float4*)h->index_tap, c);
     LAUNCH(h, "clean_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_list, h->d_state, d_pose_inv, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_b, h->list_c);
     if (deform) {
@@ -2007,14 +2056,14 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
            (const float4*)h->index_tap, h->scan_flags, h->scan_block);
     LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels);
+           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->cfg.n_ranks > 1 ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
 }
 
 // ---- frame path through the cached view list
 __global__ void k_vlist_invalidate(DevState* st) { if (threadIdx.x == 0) st->vl_valid = 0; }
 void hs_invalidate_view(ifx* h) { LAUNCH(h, "vlist_invalidate", dim3(1), dim3(64), k_vlist_invalidate, h->d_state); }
-static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
+static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && h->cfg.n_ranks <= 1 && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
 static void view_scan(ifx* h, int time)
 {
     Cam c = make_cam(h);
@@ -2041,10 +2090,10 @@ static void index_list_pass(ifx* h, int time, bool taps)
     LAUNCH(h, "index_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
     if (!taps)
         LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr);
+               (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr, c);
     else
         LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap);
+               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap, c);
 }
 
 // EF/ElasticFusion.cpp:620-694 without the loop-closure branches
@@ -2066,7 +2115,7 @@ int ifx_map_frame(ifx* h)
                (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
         LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
                (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels);
+               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->cfg.n_ranks > 1 ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
         h->view_frame = 1; h->view_dirty = 1; h->last_clean_time = time;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);   // (reaps first; the raster below then takes the per-pass cull: the list is void after a compaction)
         h->ids_pending = 1;
@@ -2150,6 +2199,135 @@ int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame)
     case 1: index_pass(h, nullptr, h->tick, true, 2); fuse_pass(h, nullptr, 0.f, h->tick); clean_pass(h, nullptr, h->tick, 1); break;
     case 2: clean_pass(h, nullptr, h->tick, 2); raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | LIST_IDS, h->ids_after, true, 1); break;
     case 3: raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT | LIST_IDS, h->ids_after, true, 2); break;
+    default: return IFX_E_INVALID;
+    }
+    return IFX_OK;
+}
+
+// ------------------------------------------------------------------ spatially sharded map (ifx_config::n_ranks > 1)
+// One process per GPU; this handle STORES only the surfels it owns (owner = Morton(8 cm voxel of the creation position) mod n_ranks,
+// ifx_owner_of_point), i.e. 1 / n_ranks of the map.  Every rank is fed the same frame.  Per-surfel work -- the three projections,
+// the fusion update, the clean pass -- runs on the local shard; per-pixel work -- tracking, association, the stability test of new
+// surfels -- is replicated (P pixels against N / G surfels: cheaper than routing it).  Between the phases of a frame the ranks combine
+//   * their key images by an element-wise unsigned 64-bit MIN: keys carry the CREATION NUMBER of a surfel instead of its slot, the same
+//     number on every rank and ascending in map order, so the nearest surfel and the tie-break are those of one GPU;
+//   * the attribute images of the winners (index map, clean taps, prediction) by a bitwise SUM over int32: a pixel is written by the one
+//     rank that owns its winner (binary search of the creation number in the local store), all others contribute zeros -- the
+//     cross-shard reprojection exchange of the north star, as an all-reduce over disjoint supports.
+// New surfels need no routing: every rank computes the same append list and keeps the ones it owns, numbering all of them alike.
+// Compaction is local and independent (ids are creation numbers, not slots).  The result is bit-identical to one GPU:
+// tests/test_gpu_parity.py::test_owner_sharded_map_emulated.  Exchange volume per frame at W x H pixels: keys 5 x 8 B, attributes
+// 32 + 16 + 42 B per pixel = 130 B/pixel (40 MB at 640x480) whatever the map size; DESIGN.md section 7 has the cost model.
+__global__ void k_owner_flags(const DevState* __restrict__ st, const float4* __restrict__ pc, int n_ranks, int rank, int* __restrict__ flags, int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    int f = 0;
+    if (i < st->count) { const float4 p = pc[i]; f = ifx_owner_of_point(p.x, p.y, p.z, n_ranks) == rank; }
+    flags[i] = f;
+}
+__global__ void k_owner_count(DevState* st, const int* total)
+{
+    if (threadIdx.x == 0) { st->next_seq = (unsigned int)st->count; st->count = *total; st->n_dead = 0; }
+}
+// fill_rgb / fill_vertex / fill_normal.frag on the exchanged prediction (EF/Shaders/FillIn.cpp:65-195): the second half of k_splat_resolve
+__global__ void k_fill_in(Cam c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt, const float4* __restrict__ pv, const float4* __restrict__ pn,
+                          const uchar4* __restrict__ pimg, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= c.w || y >= c.h) return;
+    const int k = y * c.w + x;
+    const float4 vo = pv[k], no = pn[k];
+    const uchar4 io = pimg[k];
+    float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
+    else fimg[k] = io;
+    float zc = (float)depth_filt[k] / 1000.0f;
+    if (vo.z == 0) fv[k] = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
+    else fv[k] = vo;
+    if (no.z == 0) {
+        v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
+        int xr = clampi(x + 1, 0, c.w - 1), yd = clampi(y + 1, 0, c.h - 1);
+        float zx = (float)depth_filt[y * c.w + xr] / 1000.0f, zy = (float)depth_filt[yd * c.w + x] / 1000.0f;
+        v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
+        v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
+        v3 nn = normalized(cross(vx - vp, vy - vp));
+        fn[k] = make_float4(nn.x, nn.y, nn.z, 1.f);
+    } else fn[k] = no;
+}
+
+// first frame: the dense initialisation is computed by every rank, which then keeps its own surfels (creation numbers = the unsharded slots)
+static void owner_filter(ifx* h)
+{
+    const int n = h->cap;
+    LAUNCH(h, "owner_flags", dim3(cdiv(n, 256)), dim3(256), k_owner_flags, (const DevState*)h->d_state, (const float4*)h->pc, h->cfg.n_ranks, h->cfg.rank, h->scan_flags, n);
+    ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
+    LAUNCH(h, "compact_scatter", dim3(cdiv(n, 256)), dim3(256), k_compact_scatter, h->scan_flags, h->scan_out, n, (const float4*)h->pc, (const float4*)h->nr,
+           (const float2*)h->col, (const float2*)h->tm, (const float4*)h->ic, (const float4*)h->votes, (const int32_t*)h->labels, (float4*)h->pc2, (float4*)h->nr2,
+           (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2, (const uint32_t*)h->seq, h->seq2);
+    LAUNCH(h, "owner_count", dim3(1), dim3(64), k_owner_count, h->d_state, &h->d_state->seg_counts[1]);
+    std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2); std::swap(h->seq, h->seq2);
+}
+
+// phase p of a frame of the sharded map; the caller reduces the buffers ifx_owner_exchange(p) lists across the ranks before phase p + 1
+int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
+{
+    Cam c = make_cam(h);
+    c.srank = 0; c.sn = 1;
+    const int time = h->tick;
+    const dim3 b2(32, 8), g2(cdiv(h->w, 32), cdiv(h->h, 8));
+    if (first_frame) {
+        switch (phase) {
+        case 0: ifx_map_init_first(h); owner_filter(h); break;
+        case 4: raster_pass(h, nullptr, time, time, LIST_SPLAT, h->ids_after, false, 1); break;
+        case 5:
+            LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
+                   (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
+                   (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
+            break;
+        case 6:
+            LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
+                   (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+            LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+            break;
+        default: break;
+        }
+        return IFX_OK;
+    }
+    switch (phase) {
+    case 0: index_pass(h, nullptr, time, true, 1); break;                                                   // local projection | keys: MIN
+    case 1: index_pass(h, nullptr, time, true, 2); break;                                                   // winners this rank owns | index_vc, index_nr: SUM
+    case 2: fuse_pass(h, nullptr, 0.f, time); clean_pass(h, nullptr, time, 1); break;                       // association (replicated), update (owned), post-fuse projection | keys: MIN
+    case 3:                                                                                                 // owned tap records | index_tap: SUM
+        LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
+               (float4*)h->index_tap, c);
+        break;
+    case 4: {                                                                                               // clean (local), append (replicated list, owned kept), local raster | keys: MIN
+        LAUNCH(h, "clean_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_list, h->d_state, (const float*)nullptr, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+               (const float4*)h->index_tap, h->list_b, h->list_c);
+        const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+        LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
+               (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
+        LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
+               (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, (unsigned int*)nullptr, h->labels, h->seq);
+        h->last_clean_time = time;
+        if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
+        raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
+        break;
+    }
+    case 104: raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1); break;   // ifx_owner_predict_phase: the local raster alone
+    case 5:                                                                                                 // owned winners of the prediction | pred_*: SUM ; ids_after = creation numbers, from the keys
+        LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
+               (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
+               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr);
+        break;
+    case 6:                                                                                                 // fill-in and dense flag on the exchanged prediction (replicated)
+        LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
+               (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+        break;
     default: return IFX_E_INVALID;
     }
     return IFX_OK;

@@ -3,9 +3,12 @@
 What is sharded (DESIGN.md "Multi-GPU"):
 * round 1: `bench.py --gpus N` runs N replicas (one stream + one map per rank), no data-path
   collective; only the timing barrier / max-over-ranks go through torch.distributed.
-* the surfel-map owner function below (spatial hash: 8 cm voxels -> Morton code -> mod n_ranks,
-  SURVEY.md 8e) and the one-shot all-reduce of the 2 x 29-float normal equations are the two
-  primitives of the sharded-map mode; they are exercised on CPU with gloo in tests/test_dist_cpu.py.
+* `owner_of` is the owner function of the spatially sharded map (8 cm voxel -> Morton code -> mod n_ranks), the
+  Python twin of ifx_owner_of_point: `ifx_map_upload` and the append kernel of a handle created with n_ranks > 1 keep the surfels it
+  selects (instancefusion_amd/sharded.py: OwnerShardedElasticFusion).
+* `allreduce_normal_equations`: the one collective a row-tiled tracker would need (2 x 29 sums).  The sums are exact integers
+  in f64 (DESIGN.md "Arithmetic contract"), so an all-reduce(SUM) of them is exact and order-independent; the product keeps the
+  tracker replicated (DESIGN.md section 7 has the numbers), this helper and its gloo test document the exchange.
 """
 from __future__ import annotations
 
@@ -55,22 +58,25 @@ def whole_job_rate(units_per_rank: int, world: int, seconds_max: float) -> float
     return world * units_per_rank / seconds_max
 
 
-def _part1by2(v: np.ndarray) -> np.ndarray:
-    v = v.astype(np.uint64) & np.uint64(0x1FFFFF)
-    v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
-    v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
-    v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
-    v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
-    v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+def _part1by2_10(v: np.ndarray) -> np.ndarray:
+    v = v.astype(np.uint32) & np.uint32(0x3FF)
+    v = (v | (v << np.uint32(16))) & np.uint32(0x030000FF)
+    v = (v | (v << np.uint32(8))) & np.uint32(0x0300F00F)
+    v = (v | (v << np.uint32(4))) & np.uint32(0x030C30C3)
+    v = (v | (v << np.uint32(2))) & np.uint32(0x09249249)
     return v
 
 
 def owner_of(pos: np.ndarray, n_ranks: int) -> np.ndarray:
-    """Owner rank of each surfel: a pure function of its position (so that a surfel's owner can be
-    found by any rank): 8 cm voxel -> 63-bit Morton code -> mod n_ranks."""
-    v = np.floor(np.asarray(pos, np.float64)[..., :3] / VOXEL_M).astype(np.int64) + (1 << 20)
-    code = _part1by2(v[..., 0]) | (_part1by2(v[..., 1]) << np.uint64(1)) | (_part1by2(v[..., 2]) << np.uint64(2))
-    return (code % np.uint64(max(n_ranks, 1))).astype(np.int32)
+    """Owner rank of each surfel of the spatially sharded map: a pure function of the position it was created at (so that every
+    rank can tell who owns a new surfel without asking): 8 cm voxel (f32 arithmetic) -> 30-bit Morton code -> mod n_ranks.  The same
+    function as ifx_owner_of_point (instancefusion_amd/csrc/ifx_dev.h), which the kernels and ifx_map_upload use."""
+    if n_ranks <= 1:
+        return np.zeros(np.asarray(pos).shape[:-1], np.int32)
+    p = np.asarray(pos, np.float32)[..., :3]
+    v = np.floor(p / np.float32(VOXEL_M)).astype(np.int64) + 512
+    code = _part1by2_10(v[..., 0]) | (_part1by2_10(v[..., 1]) << np.uint32(1)) | (_part1by2_10(v[..., 2]) << np.uint32(2))
+    return (code % np.uint32(n_ranks)).astype(np.int32)
 
 
 def allreduce_normal_equations(icp29: np.ndarray, rgb29: np.ndarray, dist):

@@ -97,3 +97,106 @@ def emulate_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int, exchanges=None):
                     t.copy_(m)
             torch.cuda.synchronize()
     return xs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Spatially sharded map (ifx_config.n_ranks > 1): every rank STORES 1 / G of the surfels (owner = spatial hash of the creation position).
+
+
+def _exchange_spec(ef, phase):
+    ptrs = (C.c_void_p * 8)()
+    nbytes = (C.c_int64 * 8)()
+    ops = (C.c_int32 * 8)()
+    n = ef._chk(ef.L.ifx_owner_exchange(ef.handle, phase, ptrs, nbytes, ops, 8), "ifx_owner_exchange")
+    return [(ptrs[k], nbytes[k], ops[k]) for k in range(n)]
+
+
+class _DevWords:
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3}
+
+
+class OwnerShardedElasticFusion:
+    """ElasticFusion.processFrame over a spatially sharded map: `ef` was created with n_ranks = world, rank = this rank, on this rank's
+    GPU; `dist` is torch.distributed (backend nccl = RCCL over xGMI).  Per frame: seven phases, between them all-reduces of the key images
+    (unsigned MIN) and of the winners' attribute images (int32 SUM over disjoint supports), enqueued on the handle's own stream."""
+
+    def __init__(self, ef, dist):
+        import torch
+
+        self.ef, self.dist, self.torch = ef, dist, torch
+        main = C.c_void_p()
+        ef._chk(ef.L.ifx_stream_handles(ef.handle, C.byref(main), None), "ifx_stream_handles")
+        self.dev = f"cuda:{ef.cfgd['device']}"
+        self.stream = torch.cuda.ExternalStream(main.value, device=self.dev)
+
+    def _tensor(self, ptr, nbytes, op):
+        return self.torch.as_tensor(_DevWords(ptr, nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=self.dev)
+
+    def _exchange(self, phase):
+        spec = _exchange_spec(self.ef, phase)
+        if spec and self.dist is not None:
+            with self.torch.cuda.stream(self.stream):
+                for ptr, nbytes, op in spec:
+                    t = self._tensor(ptr, nbytes, op)
+                    if op == 0:
+                        KeyExchange.reduce_min([t], self.dist)
+                    else:
+                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def process_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
+        ef = self.ef
+        for phase in range(7):
+            ef._chk(ef.L.ifx_owner_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
+            self._exchange(phase)
+
+    def predict(self):
+        """ElasticFusion::predict outside a frame (after upload / set_pose)."""
+        ef = self.ef
+        for step in range(3):
+            ef._chk(ef.L.ifx_owner_predict_phase(ef.handle, step), "ifx_owner_predict_phase")
+            if step < 2:
+                self._exchange(4 + step)
+
+
+def _reduce_by_hand(efs, specs):
+    import torch
+
+    dev = f"cuda:{efs[0].cfgd['device']}"
+    for e in efs:
+        e.sync()
+    for k in range(len(specs[0])):
+        op, nbytes = specs[0][k][2], specs[0][k][1]
+        ts = [torch.as_tensor(_DevWords(sp[k][0], nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=dev) for sp in specs]
+        if op == 0:
+            m = ts[0] ^ _SIGN
+            for t in ts[1:]:
+                m = torch.minimum(m, t ^ _SIGN)
+            m ^= _SIGN
+        else:
+            m = ts[0].clone()
+            for t in ts[1:]:
+                m += t
+        for t in ts:
+            t.copy_(m)
+    torch.cuda.synchronize()
+
+
+def emulate_owner_predict(efs):
+    """ElasticFusion::predict of a sharded map outside a frame (after upload / set_pose), the exchanges done by hand."""
+    for step in range(3):
+        for e in efs:
+            e._chk(e.L.ifx_owner_predict_phase(e.handle, step), "ifx_owner_predict_phase")
+        if step < 2:
+            _reduce_by_hand(efs, [_exchange_spec(e, 4 + step) for e in efs])
+
+
+def emulate_owner_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int):
+    """Test helper: `efs` = handles of ONE process created with n_ranks = len(efs), rank = 0..G-1; the all-reduces are done by hand
+    (element-wise unsigned minimum / int32 sum over the handles' buffers).  Everything of the sharded map except RCCL itself."""
+    for phase in range(7):
+        for e in efs:
+            e._chk(e.L.ifx_owner_frame_phase(e.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
+        specs = [_exchange_spec(e, phase) for e in efs]
+        if specs[0]:
+            _reduce_by_hand(efs, specs)

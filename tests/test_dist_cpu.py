@@ -66,6 +66,63 @@ def test_owner_function_partitions_space():
     assert ifd.env() == (0, 0, 1)
 
 
+def test_owner_function_equals_the_library():
+    """dist.owner_of is the Python twin of ifx_owner_of_point, the function the kernels and ifx_map_upload use (host entry: no GPU needed)."""
+    import ctypes as C
+
+    import instancefusion_amd as ifx
+
+    L = ifx.lib()
+    rng = np.random.RandomState(3)
+    pos = np.concatenate([rng.uniform(-8, 8, (50000, 3)), rng.uniform(-0.2, 0.2, (5000, 3)), np.floor(rng.uniform(-50, 50, (5000, 3))) * 0.08]).astype(np.float32)
+    for g in (1, 2, 3, 4, 8):
+        out = np.zeros(len(pos), np.int32)
+        assert L.ifx_owner_of(pos.ctypes.data_as(C.c_void_p), len(pos), g, out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out, ifd.owner_of(pos, g)), g
+
+
+def _sumworker(rank, world, port, q):
+    import torch
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w, d = ifd.init("gloo")
+    rng = np.random.RandomState(5)
+    # the attribute exchange of the sharded map: every pixel is written by ONE rank (the owner of its winner), zeros elsewhere; the
+    # all-reduce is a SUM over int32 words, i.e. a bitwise merge -- also for -0.0, NaN payloads and denormals
+    full = rng.standard_normal((4000, 4)).astype(np.float32)
+    full[::97] = np.float32(-0.0); full[5::131] = np.nan; full[7::173] = np.float32(1e-42)
+    owner = rng.randint(0, world, 4000)
+    mine = np.where((owner == rank)[:, None], full, np.float32(0)).astype(np.float32)
+    t = torch.from_numpy(mine.view(np.int32).copy())
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    # the tracker's collective: exact (integer-valued) f64 sums -> the all-reduce is exact whatever the association order
+    part = np.floor(rng.standard_normal((480, 29)) * 2.0 ** 20)[rank::world].sum(0)
+    tot = np.floor(np.random.RandomState(5).standard_normal((4000, 4)) * 0 + 0)  # (keeps the stream of `rng` aligned across ranks)
+    icp, _ = ifd.allreduce_normal_equations(part, part, d)
+    q.put((rank, full.view(np.int32).copy(), t.numpy().copy(), icp))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_attribute_sum_exchange_and_exact_normal_equations_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sumworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert np.array_equal(r[2], res[0][1])                       # bit patterns of the merged image == the unsharded image, on both ranks
+    rng = np.random.RandomState(5)
+    rng.standard_normal((4000, 4)); rng.randint(0, 2, 4000)
+    rows = np.floor(rng.standard_normal((480, 29)) * 2.0 ** 20)
+    assert np.array_equal(res[0][3], rows.sum(0)) and np.array_equal(res[1][3], rows.sum(0))   # exact, not allclose
+
+
 def _minworker(rank, world, port, q):
     import torch
 

@@ -497,6 +497,63 @@ def test_config3_5m_map_full_instance_path(ifx, orc):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_sharded_map_emulated(ifx, small_stream, world):
+    """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images
+    MIN-reduced, winners' attributes SUM-merged between the seven phases of a frame) against one GPU: G handles in one process, the
+    all-reduces done by hand.  Poses, prediction / index / id images and -- merged by creation number -- the whole map, bit for bit,
+    over first-frame initialisation, an uploaded map, appended surfels, deletions and independent local compactions."""
+    import torch
+
+    from instancefusion_amd import dist as ifd
+    from instancefusion_amd import sharded, synth
+
+    st = small_stream
+    NF = 8
+    d_rgb = torch.from_numpy(st["rgb"][:NF]).cuda()
+    d_dep = torch.from_numpy(st["depth"][:NF].view(np.int16)).cuda()
+    one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
+    for e in efs:
+        e.set_option("compact_divisor", 16 if e.cfgd["rank"] else 64)     # the ranks compact at different times: ids are creation numbers, nothing to agree on
+    poses = []
+    for i in range(NF):
+        if i == 4:   # an uploaded map in the middle: every rank is handed all rows and keeps its own
+            m = one.download()
+            m["pc"][::2, 3] = 15.0
+            one.upload(m); one.set_pose(poses[-1], one.tick); one.combined_predict(poses[-1], one.tick, one.tick)
+            for e in efs:
+                e.upload(m)
+                e.set_pose(poses[-1], one.tick)
+            own = ifd.owner_of(m["pc"][:, :3], world)
+            assert [e.count for e in efs] == [int((own == r).sum()) for r in range(world)]
+            sharded.emulate_owner_predict(efs)          # ElasticFusion::predict on the sharded map: local raster, exchange, owned winners, exchange, fill-in
+        one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+        poses.append(one.getCurrPose())
+        for e in efs:
+            assert np.array_equal(e.getCurrPose(), poses[-1]), (i, e.cfgd["rank"])
+        for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
+            a = one.image(name)
+            for e in efs:
+                assert np.array_equal(e.image(name), a), (i, name, e.cfgd["rank"])
+    # the maps: shards merged by creation number == the unsharded map (whose creation numbers are 0..n-1 after the compaction of download())
+    ref = one.download()
+    parts = [(e.seq(), e.download()) for e in efs]
+    seq = np.concatenate([p[0] for p in parts])
+    order = np.argsort(seq, kind="stable")
+    assert len(np.unique(seq)) == len(seq)
+    assert sum(len(p[0]) for p in parts) == ref["pc"].shape[0]
+    for k in MAP_KEYS:
+        merged = np.concatenate([p[1][k] for p in parts])[order]
+        assert np.array_equal(merged, ref[k]), k
+    assert min(len(p[0]) for p in parts) > 0.5 * len(seq) / world          # every rank holds about 1 / G of the map
+    # ownership is what the hash says, for created and uploaded surfels alike (by their current position for the ones that never moved)
+    for e in efs:
+        e.close()
+    one.close()
+
+
 @pytest.mark.parametrize("earlyz", [1, 0])
 def test_view_list_path_equals_per_pass_culls(ifx, earlyz):
     """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,

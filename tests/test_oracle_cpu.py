@@ -552,3 +552,30 @@ def test_oracle_does_not_depend_on_thread_count(orc, small_stream):
     for th in (3, 32):
         assert np.array_equal(out[th][0], out[1][0]), th
         assert all(np.array_equal(out[th][1][k], out[1][1][k]) for k in out[1][1]), th
+
+
+def test_rounding_level_perturbation_grows(orc):
+    """Why the tracker's sums are exact: the oracle against ITSELF with every per-row partial sum rounded to f32
+    once (6e-8 relative, what separates two f32 summation orders) -- identical for a few frames, then the trajectories part by more
+    than the north star's 1e-4 m within ~15 frames of the 640x480 benchmark stream.  Two implementations that do not share their sums
+    bit for bit cannot stay within 1e-4 m of each other over a sequence; with the exact sums the HIP path and the oracle do
+    (tests/test_gpu_parity.py::test_full_loop_640x480_trajectory_and_labels)."""
+    from instancefusion_amd import synth
+
+    W, H, NF = 640, 480, 24
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(NF, W, H, noise=True, loop_len=90, **K)
+    orc.set_threads(orc.usable_cores())
+    L = orc.lib()
+    runs = []
+    for mode in (0, 2, 1):
+        L.orc_set_sum_order(mode)
+        o = orc.Oracle(w=W, h=H, max_surfels=2_000_000, **K)
+        runs.append(np.stack([o.process_frame(st["rgb"][i], st["depth"][i]).copy() for i in range(NF)]))
+        o.close()
+    L.orc_set_sum_order(0)
+    orc.set_threads(1)
+    gap = np.linalg.norm(runs[0][:, :3, 3] - runs[1][:, :3, 3], axis=1)
+    assert gap[:3].max() < 1e-7                      # the perturbation itself is tiny ...
+    assert gap.max() > 1e-4                          # ... and grows past the parity tolerance within the run
+    assert np.array_equal(runs[0], runs[2])          # a different ORDER of the exact sums (rows bottom-up) changes nothing at all

@@ -32,6 +32,9 @@ struct Huff {
         for (int len = 1; len <= 16; len++) {
             valptr[len] = k;
             mincode[len] = code;
+            // the lengths must form a prefix code: after the codes of this length at most 2^len values are used (otherwise `first` below
+            // would index past fast[] and the decoder could be steered out of vals[])
+            if (code + counts[len - 1] > (1 << len)) throw std::runtime_error("JPEG: Huffman code lengths do not form a prefix code");
             for (int i = 0; i < counts[len - 1]; i++, k++, code++) {
                 if (len <= 9) {
                     const int first = code << (9 - len);
@@ -73,6 +76,7 @@ struct BitReader {
     int get(int n)
     {
         if (n == 0) return 0;
+        if (n < 0 || n > 16) throw std::runtime_error("JPEG: bad magnitude category");   // a corrupted table can name any symbol value
         const int v = peek(n);
         skip(n);
         return v;
@@ -189,8 +193,9 @@ inline void decode(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, 
         if (m == 0xDB) {   // DQT
             while (s < se) {
                 const int pq = s[0] >> 4, tq = s[0] & 15;
-                if (tq > 3) throw std::runtime_error("JPEG: bad quantisation table id");
+                if (tq > 3 || pq > 1) throw std::runtime_error("JPEG: bad quantisation table id / precision");
                 s++;
+                if (s + (pq ? 128 : 64) > se) throw std::runtime_error("JPEG: truncated quantisation table");
                 for (int k = 0; k < 64; k++) {
                     quant[tq][zigzag[k]] = pq ? ((s[0] << 8) | s[1]) : s[0];
                     s += pq ? 2 : 1;
@@ -199,6 +204,7 @@ inline void decode(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, 
             }
         } else if (m == 0xC4) {   // DHT
             while (s < se) {
+                if (s + 17 > se) throw std::runtime_error("JPEG: truncated Huffman table");
                 const int tc = s[0] >> 4, th = s[0] & 15;
                 if (th > 3 || tc > 1) throw std::runtime_error("JPEG: bad Huffman table id");
                 int n = 0;
@@ -208,16 +214,22 @@ inline void decode(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, 
                 s += 17 + n;
             }
         } else if (m == 0xC0 || m == 0xC1) {   // SOF0 / SOF1
+            if (s + 6 > se) throw std::runtime_error("JPEG: truncated frame header");
             if (s[0] != 8) throw std::runtime_error("JPEG: only 8-bit samples are supported");
             height = (s[1] << 8) | s[2];
             width = (s[3] << 8) | s[4];
             ncomp = s[5];
             if (ncomp != 1 && ncomp != 3) throw std::runtime_error("JPEG: only grey and YCbCr images are supported");
+            if (s + 6 + 3 * ncomp > se) throw std::runtime_error("JPEG: truncated frame header");
+            if (width <= 0 || height <= 0 || (size_t)width * height > ((size_t)1 << 28)) throw std::runtime_error("JPEG: bad image size");
+            hmax = vmax = 1;
             for (int c = 0; c < ncomp; c++) {
                 comp[c].id = s[6 + c * 3];
                 comp[c].h = s[7 + c * 3] >> 4;
                 comp[c].v = s[7 + c * 3] & 15;
                 comp[c].tq = s[8 + c * 3];
+                if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2) throw std::runtime_error("JPEG: sampling factors other than 1 and 2 are not supported");
+                if (comp[c].tq > 3) throw std::runtime_error("JPEG: bad quantisation table id");
                 if (comp[c].h > hmax) hmax = comp[c].h;
                 if (comp[c].v > vmax) vmax = comp[c].v;
             }
@@ -225,15 +237,21 @@ inline void decode(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, 
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             throw std::runtime_error("JPEG: progressive / lossless / arithmetic-coded files are not supported");
         } else if (m == 0xDD) {
+            if (s + 2 > se) throw std::runtime_error("JPEG: truncated restart interval");
             restart = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {   // SOS: the entropy-coded data follows
             if (!width || !height) throw std::runtime_error("JPEG: SOS before SOF");
+            if (s + 1 > se) throw std::runtime_error("JPEG: truncated scan header");
             const int ns = s[0];
             if (ns != ncomp) throw std::runtime_error("JPEG: non-interleaved multi-scan files are not supported");
+            if (s + 1 + 2 * ns > se) throw std::runtime_error("JPEG: truncated scan header");
+            for (int c = 0; c < ncomp; c++) { comp[c].td = -1; comp[c].ta = -1; }
             for (int k = 0; k < ns; k++) {
                 for (int c = 0; c < ncomp; c++)
                     if (comp[c].id == s[1 + k * 2]) { comp[c].td = s[2 + k * 2] >> 4; comp[c].ta = s[2 + k * 2] & 15; }
             }
+            for (int c = 0; c < ncomp; c++)
+                if (comp[c].td < 0 || comp[c].td > 3 || comp[c].ta < 0 || comp[c].ta > 3) throw std::runtime_error("JPEG: bad entropy table selector");
             if (hmax > 2 || vmax > 2) throw std::runtime_error("JPEG: sampling factors above 2 are not supported");
             for (int c = 1; c < ncomp; c++)
                 if (comp[c].h != 1 || comp[c].v != 1) throw std::runtime_error("JPEG: subsampled luma / oversampled chroma is not supported");

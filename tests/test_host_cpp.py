@@ -131,6 +131,24 @@ def test_jpeg_decoder_grey_restart_and_refusals(checker, tmp_path):
     assert subprocess.run([checker, "jpg", f, out], capture_output=True).returncode == 1
 
 
+def test_jpeg_decoder_survives_malformed_input(tmp_path):
+    """Memory safety of the hand-written decoder on hostile input (the .klg reader feeds it whatever the file holds): crafted headers --
+    code lengths that are no prefix code, table selectors and sampling factors out of range, segments shorter than their fields, absurd
+    sizes -- truncations and 3000 seeded random corruptions, under AddressSanitizer + UBSan on the CPU: every variant either decodes or
+    is refused with an exception."""
+    from PIL import Image
+
+    exe = str(tmp_path / "jpeg_fuzz")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", HOST,
+                    os.path.join(ROOT, "tests", "cpp", "jpeg_fuzz.cpp"), "-o", exe], check=True)
+    for sub, q in ((2, 90), (1, 70), (0, 95)):
+        f = str(tmp_path / f"v{sub}.jpg")
+        Image.fromarray(_test_image(72, 56, 11 + sub)).save(f, format="JPEG", quality=q, subsampling=sub, restart_marker_blocks=4 if sub == 1 else 0)
+        r = subprocess.run([exe, f, "1000"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-400:], r.stderr[-2000:])
+        assert "refused" in r.stdout
+
+
 def test_raw_log_reader_decodes_jpeg_frames(checker, tmp_path):
     """The usual .klg (zlib depth + JPEG colour, what ElasticFusion's logger writes): same frames as the Python reader, which decodes with PIL."""
     from instancefusion_amd import logio

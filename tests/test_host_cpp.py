@@ -305,6 +305,47 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_replay_baseline_size_reference_defaults(tmp_path):
+    """ElasticFusionInterface::ProcessFrame at the BASELINE size with the reference's own configuration -- 640x480, Init() defaults, i.e.
+    closeLoops = true with the fern data base inside every frame (IF/map_interface/ElasticFusionInterface.cpp:43-45) -- through the C++
+    classes of ifx_host.hpp (ifx_replay) against the Python main loop over the same .klg (zlib depth, JPEG colour) and masks: identical
+    trajectory file, models and labels."""
+    import importlib.util
+
+    from instancefusion_amd import logio, synth
+
+    W, H, n = 640, 480, 20
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(n + 1, W, H, noise=True, loop_len=90, **K)
+    klg = str(tmp_path / "b.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg", jpeg_quality=95)
+    for i in range(n + 1):
+        wr.add(33333 * i, st["rgb"][i], st["depth"][i])
+    wr.close()
+    mdir = tmp_path / "masks"
+    mdir.mkdir()
+    for i in range(n):
+        mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+        np.savez_compressed(mdir / f"{i:06d}.npz", masks=mk, class_ids=cl)
+    common = ["--max-surfels", "2000000", "--masks", str(mdir), "--confidence", "2"]       # intrinsics, resolution, closeLoops: the defaults
+    out_c = str(tmp_path / "C")
+    r = subprocess.run([REPLAY, klg] + common + ["--out", out_c, "--labels", out_c + ".labels"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert f"{n} frames" in r.stdout and " 0 segmentation calls" not in r.stdout and "fern keyframes" in r.stdout
+    spec = importlib.util.spec_from_file_location("run_log", os.path.join(ROOT, "tools", "run_log.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out_p = str(tmp_path / "P")
+    assert mod.main([klg] + common + ["--out", out_p, "--labels", out_p + ".labels"]) == 0
+    assert open(out_c + ".freiburg").read() == open(out_p + ".freiburg").read()
+    assert len(open(out_c + ".freiburg").read().splitlines()) == n
+    for suffix in (".ply", "_Instance.ply"):
+        assert open(out_c + suffix, "rb").read() == open(out_p + suffix, "rb").read(), suffix
+    lab = np.fromfile(out_c + ".labels", np.int32)
+    assert lab.size > 100000 and np.array_equal(lab, np.fromfile(out_p + ".labels", np.int32)) and (lab >= 0).sum() > 100
+
+
+@pytest.mark.gpu
 def test_cpp_replay_png_log_equals_klg(small_stream, tmp_path):
     """The same frames as a data.txt image list (IF/utilities/PNGLogReader.cpp) and as a .klg: identical trajectories from ifx_replay.
     (The PNG reader delivers every frame, the .klg reader never its last one: the .klg gets one more frame.)"""

@@ -1218,7 +1218,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
 // concatenated into two flat lists, to which k_append_scan adds the new surfels.  (Sorting the lists by screen tile of the scan pose
 // was tried -- a wave then works inside one 32x32-pixel neighbourhood -- and changed nothing: raster 79 -> 84 us, clean 64 -> 67 us,
 // index 28 -> 29 us.  The list passes are bound by their GATHERS FROM THE STORE, one 64-B line per field and entry whatever the order of
-// the list: 476 k window entries + 640 k outside ones out of 5.4 M slots; profiles/r02_l_kernel_stats.csv.)
+// the list: 476 k window entries + 640 k outside ones out of 5.4 M slots; profiles/r02_l_kernel_stats_tile_sorted_lists.csv.  Compact copies of
+// the hot fields in list order, kept coherent through the fusion update / clean / append, were tried next: raster 79 -> 74 us, clean 64 -> 54,
+// index 28 -> 23, but the fusion update 13 -> 23 and 11 us per frame for the copies: no net gain, removed; profiles/r02_p_kernel_stats_compact_view_cache.csv.
+// What is left in these passes is their atomics and the clean pass's taps.)
 __global__ void k_vlist_offsets(DevState* st, Cam c)
 {
     if (!st->vl_scan || threadIdx.x != 0) return;

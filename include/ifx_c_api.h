@@ -122,6 +122,19 @@ int ifx_owner_predict_phase(ifx_t* h, int step);
 int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out);
 /* creation numbers (uint32) of the live surfels in the order of ifx_map_download; returns the count */
 int ifx_map_seq(ifx_t* h, uint32_t* out, int max_n);
+/* ---- display / export branch of the instance layer.
+ * ifx_map_bounding_boxes: InstanceFusion::computeMapBoundingBox (IF/Core/InstanceFusion.cpp:1261-1457; kernels testAllSurfelNormalVote,
+ *   setGroundandInstanceCoordinate, testAllSurfelFindBBox, IF/Core/InstanceFusionCuda.cu:1555-1917): normal votes on an 18 x 36 sphere grid,
+ *   ground normal = the cell with most votes, ground frame and one frame per instance (heading from the instance's own votes), boxes as
+ *   min / max of the coordinates scaled by `ratio` (reference: 1e6) and truncated, in the ground frame (bbox_type 1) or the instance's
+ *   (0); boxes96x6 = {minX, maxX, minY, maxY, minZ, maxZ} per instance, +-999999999 / ratio for an instance without surfels.  The optional
+ *   outputs: ground normal (3), ground frame (16, row-major), instance frames (96 x 16), the 648 vote counts of the whole map.
+ * ifx_instance_point_cloud: InstanceFusion::getInstancePointCloud (:1459-1590; mapCountInstanceByInstColor, getSurfelToInstanceBuffer,
+ *   IF/Core/InstanceFusionCuda.cu:1920-2066): surfels per instance (counts96) and, for inst >= 0, its records {slot, x, y, z and normal in
+ *   the box frame, r, g, b} (10 floats) in slot order; returns the number of records written. */
+int ifx_map_bounding_boxes(ifx_t* h, int bbox_type, float ratio, float* boxes96x6, float* ground_normal3, float* gc_matrix16, float* inst_matrix96x16,
+                           int32_t* ground_votes648);
+int ifx_instance_point_cloud(ifx_t* h, int bbox_type, int32_t* counts96, int inst, float* out10, int max_records);
 /* Diagnostics of the cached view list ("View list"): out4 = entries inside the time window, stable entries
  * outside it, scans of the store so far, frames since the last scan. */
 int ifx_view_list_stats(ifx_t* h, int32_t* out4);

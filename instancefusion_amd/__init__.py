@@ -79,6 +79,8 @@ _SIGS = {
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_view_list_stats": (C.c_int, [_P, _P]),
+    "ifx_map_bounding_boxes": (C.c_int, [_P, C.c_int, C.c_float, _P, _P, _P, _P, _P]),
+    "ifx_instance_point_cloud": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "ifx_sync": (C.c_int, [_P]),
     "ifx_get_pose": (C.c_int, [_P, _P]),
     "ifx_tick": (C.c_int, [_P]),
@@ -571,6 +573,19 @@ class InstanceFusion:
         un = np.zeros(masks.shape[0], np.uint8) if unavailable is None else np.ascontiguousarray(unavailable, np.uint8).copy()
         self.ef._chk(self.L.ifx_mask_geometric_filter(self.ef.handle, _ptr(depth), _ptr(masks), _ptr(ori), int(masks.shape[0]), _ptr(un)), "ifx_mask_geometric_filter")
         return masks, un
+
+    def computeMapBoundingBox(self, bboxType=True, ratio=1000000.0):
+        """InstanceFusion::computeMapBoundingBox: (boxes 96x6, ground normal, ground frame, instance frames, 648 ground votes)"""
+        boxes, gn, gc, im, gv = np.zeros((96, 6), np.float32), np.zeros(3, np.float32), np.zeros((4, 4), np.float32), np.zeros((96, 4, 4), np.float32), np.zeros(648, np.int32)
+        self.ef._chk(self.L.ifx_map_bounding_boxes(self.ef.handle, int(bool(bboxType)), float(ratio), _ptr(boxes), _ptr(gn), _ptr(gc), _ptr(im), _ptr(gv)), "ifx_map_bounding_boxes")
+        return boxes, gn, gc, im, gv
+
+    def getInstancePointCloud(self, inst=-1, bboxType=True, max_records=1 << 20):
+        """InstanceFusion::getInstancePointCloud: (surfels per instance, records of `inst` {slot, xyz, normal, rgb})"""
+        counts = np.zeros(96, np.int32)
+        out = np.zeros((max_records if inst >= 0 else 1, 10), np.float32)
+        n = self.ef._chk(self.L.ifx_instance_point_cloud(self.ef.handle, int(bool(bboxType)), _ptr(counts), int(inst), _ptr(out), max_records if inst >= 0 else 0), "ifx_instance_point_cloud")
+        return counts, out[:n]
 
     def flannKnnVoteSurfelMap(self, with_neighbours=False):
         n = self.ef.slots

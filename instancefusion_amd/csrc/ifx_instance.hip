@@ -772,3 +772,306 @@ extern "C" int ifx_loop_closure_instance_table(ifx_t* h, int32_t* out)
     }
     return IFX_OK;
 }
+
+// =========================================================================== f-4: 3-D boxes and per-instance point clouds
+// InstanceFusion::computeMapBoundingBox / getInstancePointCloud (IF/Core/InstanceFusion.cpp:1261-1590) with their kernels
+// (IF/Core/InstanceFusionCuda.cu:1555-2083): the reference's display / export branch.  A surfel belongs to the instance whose table colour
+// its instance colour equals (first match); its normal votes for the cells of an 18 x 36 longitude-latitude grid of the unit sphere whose
+// centre lies within the cell's vertex-to-centre distance; the cell with most votes over the whole map gives the ground normal, every
+// instance's own votes its heading around that normal; boxes are min / max of the integer-scaled coordinates in the ground (bbox_type 1)
+// or instance (0) frame.  The reference evaluates the 648 cell centres with cos / sin inside the kernel for every surfel; here the table
+// is built once on the host (the same libm the oracle uses, so the votes are comparable count for count) and staged in LDS.
+#define BB_SEG 18
+#define BB_CELLS (BB_SEG * BB_SEG * 2)
+struct BBCell { float x, y, z, R; };
+
+static void bb_cell_table(BBCell* t)
+{
+    const float pi = 3.1415926f;
+    int p = 0;
+    for (int i = -BB_SEG / 2; i < BB_SEG / 2; i++) {
+        const float theta_v = i * pi / BB_SEG, d_v = cosf(theta_v), y_v = sinf(theta_v);
+        const float theta_m = (i + 0.5f) * pi / BB_SEG, d_m = cosf(theta_m), y_m = sinf(theta_m);
+        for (int j = 0; j < 2 * BB_SEG; j++) {
+            const float alpha_v = j * pi / BB_SEG, x_v = d_v * cosf(alpha_v), z_v = d_v * sinf(alpha_v);
+            const float alpha_m = (j + 0.5f) * pi / BB_SEG, x_m = d_m * cosf(alpha_m), z_m = d_m * sinf(alpha_m);
+            const float dx = x_v - x_m, dy = y_v - y_m, dz = z_v - z_m;
+            t[p].x = x_m; t[p].y = y_m; t[p].z = z_m; t[p].R = sqrtf(dx * dx + dy * dy + dz * dz);
+            p++;
+        }
+    }
+}
+__device__ __forceinline__ int instance_of_colour(float cc, const float* __restrict__ inst_color)
+{
+    for (int i = 0; i < IFX_NUM_INSTANCES; i++) if (cc == inst_color[i]) return i;
+    return -1;
+}
+// testAllSurfelNormalVoteKernel, IF/Core/InstanceFusionCuda.cu:1555-1637
+__global__ __launch_bounds__(256) void k_normal_vote(const DevState* __restrict__ st, const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm,
+                                                     const float* __restrict__ inst_color, const BBCell* __restrict__ cells, int* __restrict__ ground_vote, int* __restrict__ inst_vote)
+{
+    __shared__ BBCell s_cell[BB_CELLS];
+    __shared__ int s_vote[BB_CELLS];
+    __shared__ float s_col[IFX_NUM_INSTANCES];
+    for (int k = threadIdx.x; k < BB_CELLS; k += blockDim.x) { s_cell[k] = cells[k]; s_vote[k] = 0; }
+    for (int k = threadIdx.x; k < IFX_NUM_INSTANCES; k += blockDim.x) s_col[k] = inst_color[k];
+    __syncthreads();
+    const int n = st->count;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += blockDim.x * gridDim.x) {
+        if (!(tm[id].y > DEAD_TIME)) continue;
+        const int inst = instance_of_colour(col[id].y, s_col);
+        const float4 n4 = nr[id];
+        float nx = n4.x, ny = -n4.y, nz = -n4.z;   // "surfels normal in (Map) is inconsistent with (World)", :1574
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        nx = nx / len; ny = ny / len; nz = nz / len;
+        for (int p = 0; p < BB_CELLS; p++) {
+            const float dx = nx - s_cell[p].x, dy = ny - s_cell[p].y, dz = nz - s_cell[p].z;
+            if (sqrtf(dx * dx + dy * dy + dz * dz) < s_cell[p].R) {
+                atomicAdd(&s_vote[p], 1);
+                if (inst != -1) atomicAdd(&inst_vote[BB_CELLS * inst + p], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < BB_CELLS; k += blockDim.x) if (s_vote[k]) atomicAdd(&ground_vote[k], s_vote[k]);
+}
+// testAllSurfelFindBBoxKernel, IF/Core/InstanceFusionCuda.cu:1831-1901 (including its comparison of the frame coordinates with the WORLD ones)
+__global__ __launch_bounds__(256) void k_find_bbox(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ col, const float2* __restrict__ tm,
+                                                   const float* __restrict__ inst_color, float ratio, const float* __restrict__ gc_inv, const float* __restrict__ inst_inv,
+                                                   int bbox_type, int* __restrict__ box)
+{
+    __shared__ float s_col[IFX_NUM_INSTANCES];
+    for (int k = threadIdx.x; k < IFX_NUM_INSTANCES; k += blockDim.x) s_col[k] = inst_color[k];
+    __syncthreads();
+    const int n = st->count;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += blockDim.x * gridDim.x) {
+        if (!(tm[id].y > DEAD_TIME)) continue;
+        const int inst = instance_of_colour(col[id].y, s_col);
+        if (inst == -1) continue;
+        const float4 p = pc[id];
+        const float* M = bbox_type ? gc_inv : inst_inv + 16 * inst;
+        const float gx = M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3] * 1.0f;
+        const float gy = M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7] * 1.0f;
+        const float gz = M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11] * 1.0f;
+        const int vx = f2i_rz(gx * ratio), vy = f2i_rz(gy * ratio), vz = f2i_rz(gz * ratio);
+        int minX = vx, minY = vy, minZ = vz, maxX = vx, maxY = vy, maxZ = vz;
+        if (minX > p.x * ratio) minX--;
+        if (minY > p.y * ratio) minY--;
+        if (minZ > p.z * ratio) minZ--;
+        if (maxX < p.x * ratio) maxX++;
+        if (maxY < p.y * ratio) maxY++;
+        if (maxZ < p.z * ratio) maxZ++;
+        atomicMin(&box[6 * inst + 0], minX); atomicMin(&box[6 * inst + 2], minY); atomicMin(&box[6 * inst + 4], minZ);
+        atomicMax(&box[6 * inst + 1], maxX); atomicMax(&box[6 * inst + 3], maxY); atomicMax(&box[6 * inst + 5], maxZ);
+    }
+}
+
+// ---- the small per-instance part (setGroundandInstanceCoordinateKernel, :1675-1813: 97 threads in the reference) on the host
+static void bb_normalize(float* v) { const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; }
+static void bb_cross(const float* a, const float* b, float* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+static void bb_rodrigues(float angle, const float* v, const float* k, float* r)
+{
+    const float c = cosf(angle), s = sinf(angle), kv = v[0] * k[0] + v[1] * k[1] + v[2] * k[2];
+    const float cr[3] = {v[1] * k[2] - v[2] * k[1], v[2] * k[0] - v[0] * k[2], v[0] * k[1] - v[1] * k[0]};
+    for (int q = 0; q < 3; q++) r[q] = c * v[q] + (1 - c) * kv * k[q] + s * cr[q];
+}
+static void bb_matrix(const float* bx, const float* by, const float* bz, float* m)
+{
+    m[0] = bx[0]; m[1] = by[0]; m[2] = bz[0]; m[3] = 0;
+    m[4] = bx[1]; m[5] = by[1]; m[6] = bz[1]; m[7] = 0;
+    m[8] = bx[2]; m[9] = by[2]; m[10] = bz[2]; m[11] = 0;
+    m[12] = 0; m[13] = 0; m[14] = 0; m[15] = 1;
+}
+static void bb_frames(const float* ground_normal, const int* inst_vote, float* gc, float* instm)
+{
+    const float pi = 3.1415926f;
+    float by[3] = {ground_normal[0], ground_normal[1], ground_normal[2]}, bx[3], bz[3];
+    bb_normalize(by);
+    {
+        const float setZ[3] = {0, 0, 1};
+        bb_cross(setZ, by, bx); bb_normalize(bx);
+        bb_cross(by, bx, bz); bb_normalize(bz);
+        bb_matrix(bx, by, bz, gc);
+    }
+    const float step = pi / BB_SEG;
+    for (int id = 0; id < IFX_NUM_INSTANCES; id++) {
+        const int* nv = inst_vote + id * BB_CELLS;
+        int cross_vote[2 * BB_SEG] = {0};
+        const float oriZ[3] = {0, 0, -1};
+        float oriX[3];
+        bb_cross(by, oriZ, oriX); bb_normalize(oriX);
+        for (int i = 0; i < BB_CELLS; i++) {
+            if (nv[i] == 0) continue;
+            const int a = i / (2 * BB_SEG) - BB_SEG / 2, b = i % (2 * BB_SEG) - 1;
+            const float theta = (a + 0.5f) * pi / BB_SEG, alpha = (b + 0.5f) * pi / BB_SEG, d = cosf(theta);
+            float tz[3] = {d * cosf(alpha), sinf(theta), d * sinf(alpha)};
+            bb_normalize(tz);
+            const float cs = by[0] * tz[0] + by[1] * tz[1] + by[2] * tz[2];
+            if (cs > 0.525f || -cs > 0.525f) continue;
+            float best = 999999.9f;
+            int best_j = -1;
+            for (int j = 0; j < 2 * BB_SEG; j++) {
+                float rv[3];
+                bb_rodrigues(j * step, oriX, by, rv); bb_normalize(rv);
+                const float dx = rv[0] - tz[0], dy = rv[1] - tz[1], dz = rv[2] - tz[2], dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (dist < best) { best_j = j; best = dist; }
+            }
+            cross_vote[best_j] += nv[i];
+        }
+        int vmax = 0, vid = 0;
+        for (int i = 0; i < 2 * BB_SEG; i++) if (cross_vote[i] > vmax) { vmax = cross_vote[i]; vid = i; }
+        float rv[3];
+        bb_rodrigues(vid * step, oriX, by, rv); bb_normalize(rv);
+        bb_cross(rv, by, bx); bb_normalize(bx);
+        bb_cross(by, bx, bz); bb_normalize(bz);
+        bb_matrix(bx, by, bz, instm + 16 * id);
+    }
+}
+// inverse of [B 0; 0 1] with B orthonormal up to rounding: general 3x3 inverse in f64 (Eigen's Matrix4f::inverse in the reference)
+static void bb_inverse(const float* m, float* o)
+{
+    const double a[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+    const double inv[9] = {c00 * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id, c01 * id, (a[0] * a[8] - a[2] * a[6]) * id,
+                           (a[2] * a[3] - a[0] * a[5]) * id, c02 * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id};
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o[r * 4 + c] = (float)inv[r * 3 + c]; o[r * 4 + 3] = 0; }
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
+}
+
+struct BBState { std::vector<float> gc_inv, inst_inv; };
+static int bb_compute(ifx* h, float* ground_normal3, float* gc16, float* inst16, int32_t* ground_votes, float* d_inv /* [16 + 96*16] device, out */)
+{
+    BBCell cells[BB_CELLS];
+    bb_cell_table(cells);
+    const size_t nv = (size_t)BB_CELLS * (1 + IFX_NUM_INSTANCES);
+    int* d_vote = nullptr;
+    BBCell* d_cells = nullptr;
+    HIPCHK(h, hipMalloc(&d_vote, nv * 4));
+    if (hipMalloc(&d_cells, sizeof(cells)) != hipSuccess) { hipFree(d_vote); h->err = "hipMalloc failed"; return IFX_E_HIP; }
+    hipMemsetAsync(d_vote, 0, nv * 4, h->stream);
+    hipMemcpyAsync(d_cells, cells, sizeof(cells), hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->stream);
+    LAUNCH(h, "normal_vote", dim3(2048), dim3(256), k_normal_vote, (const DevState*)h->d_state, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm,
+           (const float*)h->d_inst_color, (const BBCell*)d_cells, d_vote, d_vote + BB_CELLS);
+    std::vector<int> votes(nv);
+    hipError_t e = hipMemcpyAsync(votes.data(), d_vote, nv * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_vote); hipFree(d_cells);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
+    // ground normal: the cell with most votes (IF/Core/InstanceFusion.cpp:1289-1328, including its `- 1` on the longitude index)
+    float gn[3] = {0, -1, 0};
+    int vmax = -1, vid = -1;
+    for (int i = 0; i < BB_CELLS; i++) if (votes[i] > vmax) { vmax = votes[i]; vid = i; }
+    if (vid != -1) {
+        const float pi = 3.1415926f;
+        const int i = vid / (2 * BB_SEG) - BB_SEG / 2, j = vid % (2 * BB_SEG) - 1;
+        const float theta = (i + 0.5f) * pi / BB_SEG, alpha = (j + 0.5f) * pi / BB_SEG, d = cosf(theta);
+        gn[0] = d * cosf(alpha); gn[1] = sinf(theta); gn[2] = d * sinf(alpha);
+        bb_normalize(gn);
+    }
+    float gc[16], instm[16 * IFX_NUM_INSTANCES], inv[16 + 16 * IFX_NUM_INSTANCES];
+    bb_frames(gn, votes.data() + BB_CELLS, gc, instm);
+    bb_inverse(gc, inv);
+    for (int i = 0; i < IFX_NUM_INSTANCES; i++) bb_inverse(instm + 16 * i, inv + 16 + 16 * i);
+    if (ground_normal3) memcpy(ground_normal3, gn, 12);
+    if (gc16) memcpy(gc16, gc, 64);
+    if (inst16) memcpy(inst16, instm, sizeof(instm));
+    if (ground_votes) memcpy(ground_votes, votes.data(), BB_CELLS * 4);
+    HIPCHK(h, hipMemcpyAsync(d_inv, inv, sizeof(inv), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+extern "C" int ifx_map_bounding_boxes(ifx_t* h, int bbox_type, float ratio, float* boxes96x6, float* ground_normal3, float* gc_matrix16, float* inst_matrix96x16, int32_t* ground_votes648)
+{
+    if (!h || !boxes96x6) return IFX_E_INVALID;
+    ifx_vlist_reap(h);
+    float* d_inv = nullptr;
+    int* d_box = nullptr;
+    HIPCHK(h, hipMalloc(&d_inv, (16 + 16 * IFX_NUM_INSTANCES) * 4));
+    int r = bb_compute(h, ground_normal3, gc_matrix16, inst_matrix96x16, ground_votes648, d_inv);
+    if (r) { hipFree(d_inv); return r; }
+    if (hipMalloc(&d_box, IFX_NUM_INSTANCES * 6 * 4) != hipSuccess) { hipFree(d_inv); h->err = "hipMalloc failed"; return IFX_E_HIP; }
+    int init[IFX_NUM_INSTANCES * 6];
+    for (int i = 0; i < IFX_NUM_INSTANCES; i++) { init[i * 6] = init[i * 6 + 2] = init[i * 6 + 4] = 999999999; init[i * 6 + 1] = init[i * 6 + 3] = init[i * 6 + 5] = -999999999; }
+    hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, h->stream);
+    LAUNCH(h, "find_bbox", dim3(2048), dim3(256), k_find_bbox, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->col, (const float2*)h->tm,
+           (const float*)h->d_inst_color, ratio, (const float*)d_inv, (const float*)(d_inv + 16), bbox_type ? 1 : 0, d_box);
+    hipError_t e = hipMemcpyAsync(init, d_box, sizeof(init), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_box); hipFree(d_inv);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
+    for (int k = 0; k < IFX_NUM_INSTANCES * 6; k++) boxes96x6[k] = init[k] / ratio;   // :1424-1430
+    return IFX_OK;
+}
+
+// mapCountInstanceByInstColorKernel + getSurfelToInstanceBufferKernel, IF/Core/InstanceFusionCuda.cu:1920-2066: the surfels of one instance
+// as records {slot, position in the box frame, normal in the box frame (incl. the reference's homogeneous 1 on the direction), r, g, b}.
+// The reference fills its buffers in the order the atomics land; here in slot order (flags, scan, scatter).
+__global__ void k_inst_flags(const DevState* __restrict__ st, const float2* __restrict__ col, const float2* __restrict__ tm, const float* __restrict__ inst_color, int want, int cap,
+                             int* __restrict__ flags, int* __restrict__ counts)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= cap) return;
+    int f = 0;
+    if (id < st->count && tm[id].y > DEAD_TIME) {
+        const int inst = instance_of_colour(col[id].y, inst_color);
+        if (inst != -1) atomicAdd(&counts[inst], 1);
+        f = inst == want;
+    }
+    flags[id] = f;
+}
+__global__ void k_inst_records(const int* __restrict__ flags, const int* __restrict__ rank, int cap, int max_rec, const float4* __restrict__ pc, const float4* __restrict__ nr,
+                               const float2* __restrict__ col, const float* __restrict__ M, float* __restrict__ out)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= cap || !flags[id]) return;
+    const int k = rank[id];
+    if (k >= max_rec) return;
+    const float4 p = pc[id], n4 = nr[id];
+    float nx = n4.x, ny = -n4.y, nz = -n4.z;
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    float* o = out + (size_t)k * 10;
+    o[0] = (float)id;
+    o[1] = M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3] * 1.0f;
+    o[2] = M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7] * 1.0f;
+    o[3] = M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11] * 1.0f;
+    o[4] = M[0] * nx + M[1] * ny + M[2] * nz + M[3] * 1.0f;
+    o[5] = M[4] * nx + M[5] * ny + M[6] * nz + M[7] * 1.0f;
+    o[6] = M[8] * nx + M[9] * ny + M[10] * nz + M[11] * 1.0f;
+    const int c = f2i_rz(col[id].x);
+    o[7] = (float)(c >> 16 & 0xFF) / 255.0f; o[8] = (float)(c >> 8 & 0xFF) / 255.0f; o[9] = (float)(c & 0xFF) / 255.0f;
+}
+extern "C" int ifx_instance_point_cloud(ifx_t* h, int bbox_type, int32_t* counts96, int inst, float* out10, int max_records)
+{
+    if (!h || !counts96 || inst < -1 || inst >= IFX_NUM_INSTANCES || (inst >= 0 && (!out10 || max_records <= 0))) return IFX_E_INVALID;
+    ifx_vlist_reap(h);
+    float* d_inv = nullptr;
+    HIPCHK(h, hipMalloc(&d_inv, (16 + 16 * IFX_NUM_INSTANCES) * 4));
+    int r = bb_compute(h, nullptr, nullptr, nullptr, nullptr, d_inv);
+    if (r) { hipFree(d_inv); return r; }
+    int* d_cnt = h->d_inst_stats;
+    hipMemsetAsync(d_cnt, 0, IFX_NUM_INSTANCES * 4, h->stream);
+    const int n = h->cap;
+    LAUNCH(h, "inst_flags", dim3(cdiv(n, 256)), dim3(256), k_inst_flags, (const DevState*)h->d_state, (const float2*)h->col, (const float2*)h->tm, (const float*)h->d_inst_color, inst, n,
+           h->scan_flags, d_cnt);
+    int written = 0;
+    float* d_out = nullptr;
+    if (inst >= 0) {
+        ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
+        if (hipMalloc(&d_out, (size_t)max_records * 40) != hipSuccess) { hipFree(d_inv); h->err = "hipMalloc failed"; return IFX_E_HIP; }
+        LAUNCH(h, "inst_records", dim3(cdiv(n, 256)), dim3(256), k_inst_records, (const int*)h->scan_flags, (const int*)h->scan_out, n, max_records, (const float4*)h->pc,
+               (const float4*)h->nr, (const float2*)h->col, (const float*)(bbox_type ? d_inv : d_inv + 16 + 16 * inst), d_out);
+    }
+    hipError_t e = hipMemcpyAsync(counts96, d_cnt, IFX_NUM_INSTANCES * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && inst >= 0) {
+        written = std::min(counts96[inst], max_records);
+        if (written > 0) e = hipMemcpy(out10, d_out, (size_t)written * 40, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_out); hipFree(d_inv);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
+    return written;
+}

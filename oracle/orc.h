@@ -126,6 +126,9 @@ int orc_map_count(orc_t*);
 void orc_get_pose(orc_t*, float* out16);
 void orc_set_instance_gt(orc_t*, const uint8_t* gt_hw);   /* instanceGT of processFrame: new surfels remember the id under their pixel (vImgCorr.w) */
 int orc_tick(orc_t*);
+/* f-4: computeMapBoundingBox / getInstancePointCloud (IF/Core/InstanceFusion.cpp:1261-1590) */
+void orc_map_bounding_boxes(orc_t*, int bbox_type, float ratio, float* boxes96x6, float* ground_normal3, float* gc16, float* inst16, int32_t* ground_votes648);
+int orc_instance_point_cloud(orc_t*, int bbox_type, int32_t* counts96, int inst, float* out10, int max_records);
 void orc_tracker_diag(orc_t*, float* out8);
 void orc_set_bootstrap(orc_t*, int on);
 /* wall-clock per stage since the last reset (ms): track incl. preprocessing | map passes | instance layer */

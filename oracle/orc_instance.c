@@ -413,3 +413,176 @@ void orc_test_mask_geometric_filter(orc_t* o, const uint16_t* depth, uint8_t* ma
 {
     mask_geometric_filter(o, depth, masks, ori, nm, unavailable);
 }
+
+/* =========================================================================== f-4: 3-D boxes and per-instance point clouds
+ * InstanceFusion::computeMapBoundingBox / getInstancePointCloud (IF/Core/InstanceFusion.cpp:1261-1590) and their kernels
+ * (IF/Core/InstanceFusionCuda.cu:1555-2083), restated sequentially: the cell loop of testAllSurfelNormalVoteKernel is evaluated as
+ * written (cos / sin of every cell for every surfel would be the same values every time: they are computed once). */
+#define BB_SEG 18
+#define BB_CELLS (BB_SEG * BB_SEG * 2)
+static int bb_instance_of(const orc_t* o, int s)
+{
+    for (int i = 0; i < ORC_NUM_INST; i++) if (o->col[s * 2 + 1] == o->inst_color[i]) return i;
+    return -1;
+}
+static void bb_norm3(float* v) { const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; }
+static void bb_cross3(const float* a, const float* b, float* r) { r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0]; }
+/* rodriguesRotation, IF/Core/InstanceFusionCuda.cu:94-115 */
+static void bb_rot(float angle, const float* v, const float* k, float* r)
+{
+    const float c = cosf(angle), s = sinf(angle), kv = v[0] * k[0] + v[1] * k[1] + v[2] * k[2];
+    const float cr[3] = {v[1] * k[2] - v[2] * k[1], v[2] * k[0] - v[0] * k[2], v[0] * k[1] - v[1] * k[0]};
+    for (int q = 0; q < 3; q++) r[q] = c * v[q] + (1 - c) * kv * k[q] + s * cr[q];
+}
+static void bb_set(const float* bx, const float* by, const float* bz, float* m)   /* matrixSetCoordinate, shift == 0 */
+{
+    m[0] = bx[0]; m[1] = by[0]; m[2] = bz[0]; m[3] = 0; m[4] = bx[1]; m[5] = by[1]; m[6] = bz[1]; m[7] = 0;
+    m[8] = bx[2]; m[9] = by[2]; m[10] = bz[2]; m[11] = 0; m[12] = 0; m[13] = 0; m[14] = 0; m[15] = 1;
+}
+static void bb_inv(const float* m, float* o)
+{
+    const double a[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+    const double inv[9] = {c00 * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id, c01 * id, (a[0] * a[8] - a[2] * a[6]) * id,
+                           (a[2] * a[3] - a[0] * a[5]) * id, c02 * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id};
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o[r * 4 + c] = (float)inv[r * 3 + c]; o[r * 4 + 3] = 0; }
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
+}
+/* votes, ground normal, frames, their inverses: everything up to testAllSurfelFindBBox */
+static void bb_prepare(orc_t* o, int* gvote, float* gn, float* gc, float* instm, float* gc_inv, float* inst_inv)
+{
+    const float pi = 3.1415926f;
+    float cx[BB_CELLS], cy[BB_CELLS], cz[BB_CELLS], cR[BB_CELLS];
+    int p = 0;
+    for (int i = -BB_SEG / 2; i < BB_SEG / 2; i++) {
+        const float tv = i * pi / BB_SEG, dv = cosf(tv), yv = sinf(tv), tmid = (i + 0.5f) * pi / BB_SEG, dm = cosf(tmid), ym = sinf(tmid);
+        for (int j = 0; j < 2 * BB_SEG; j++) {
+            const float av = j * pi / BB_SEG, xv = dv * cosf(av), zv = dv * sinf(av), am = (j + 0.5f) * pi / BB_SEG, xm = dm * cosf(am), zm = dm * sinf(am);
+            const float dx = xv - xm, dy = yv - ym, dz = zv - zm;
+            cx[p] = xm; cy[p] = ym; cz[p] = zm; cR[p] = sqrtf(dx * dx + dy * dy + dz * dz);
+            p++;
+        }
+    }
+    int* ivote = (int*)calloc((size_t)ORC_NUM_INST * BB_CELLS, sizeof(int));
+    memset(gvote, 0, BB_CELLS * sizeof(int));
+    for (int s = 0; s < o->n; s++) {
+        const int inst = bb_instance_of(o, s);
+        float nx = o->nr[s * 4], ny = -o->nr[s * 4 + 1], nz = -o->nr[s * 4 + 2];
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        nx = nx / len; ny = ny / len; nz = nz / len;
+        for (int q = 0; q < BB_CELLS; q++) {
+            const float dx = nx - cx[q], dy = ny - cy[q], dz = nz - cz[q];
+            if (sqrtf(dx * dx + dy * dy + dz * dz) < cR[q]) { gvote[q]++; if (inst != -1) ivote[inst * BB_CELLS + q]++; }
+        }
+    }
+    gn[0] = 0; gn[1] = -1; gn[2] = 0;
+    int vmax = -1, vid = -1;
+    for (int i = 0; i < BB_CELLS; i++) if (gvote[i] > vmax) { vmax = gvote[i]; vid = i; }
+    if (vid != -1) {
+        const int i = vid / (2 * BB_SEG) - BB_SEG / 2, j = vid % (2 * BB_SEG) - 1;
+        const float theta = (i + 0.5f) * pi / BB_SEG, alpha = (j + 0.5f) * pi / BB_SEG, d = cosf(theta);
+        gn[0] = d * cosf(alpha); gn[1] = sinf(theta); gn[2] = d * sinf(alpha);
+        bb_norm3(gn);
+    }
+    float by[3] = {gn[0], gn[1], gn[2]}, bx[3], bz[3];
+    bb_norm3(by);
+    const float setZ[3] = {0, 0, 1};
+    bb_cross3(setZ, by, bx); bb_norm3(bx);
+    bb_cross3(by, bx, bz); bb_norm3(bz);
+    bb_set(bx, by, bz, gc);
+    const float step = pi / BB_SEG;
+    for (int id = 0; id < ORC_NUM_INST; id++) {
+        int crossv[2 * BB_SEG];
+        memset(crossv, 0, sizeof(crossv));
+        const float oriZ[3] = {0, 0, -1};
+        float oriX[3];
+        bb_cross3(by, oriZ, oriX); bb_norm3(oriX);
+        for (int i = 0; i < BB_CELLS; i++) {
+            const int v = ivote[id * BB_CELLS + i];
+            if (v == 0) continue;
+            const int a = i / (2 * BB_SEG) - BB_SEG / 2, b = i % (2 * BB_SEG) - 1;
+            const float theta = (a + 0.5f) * pi / BB_SEG, alpha = (b + 0.5f) * pi / BB_SEG, d = cosf(theta);
+            float tz[3] = {d * cosf(alpha), sinf(theta), d * sinf(alpha)};
+            bb_norm3(tz);
+            const float cs = by[0] * tz[0] + by[1] * tz[1] + by[2] * tz[2];
+            if (cs > 0.525f || -cs > 0.525f) continue;
+            float best = 999999.9f;
+            int bj = -1;
+            for (int j = 0; j < 2 * BB_SEG; j++) {
+                float rv[3];
+                bb_rot(j * step, oriX, by, rv); bb_norm3(rv);
+                const float dx = rv[0] - tz[0], dy = rv[1] - tz[1], dz = rv[2] - tz[2], dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (dist < best) { bj = j; best = dist; }
+            }
+            crossv[bj] += v;
+        }
+        int m = 0, mid = 0;
+        for (int i = 0; i < 2 * BB_SEG; i++) if (crossv[i] > m) { m = crossv[i]; mid = i; }
+        float rv[3];
+        bb_rot(mid * step, oriX, by, rv); bb_norm3(rv);
+        bb_cross3(rv, by, bx); bb_norm3(bx);
+        bb_cross3(by, bx, bz); bb_norm3(bz);
+        bb_set(bx, by, bz, instm + 16 * id);
+    }
+    bb_inv(gc, gc_inv);
+    for (int i = 0; i < ORC_NUM_INST; i++) bb_inv(instm + 16 * i, inst_inv + 16 * i);
+    free(ivote);
+}
+void orc_map_bounding_boxes(orc_t* o, int bbox_type, float ratio, float* boxes, float* ground_normal3, float* gc16, float* inst16, int32_t* ground_votes)
+{
+    int gvote[BB_CELLS];
+    float gn[3], gc[16], instm[16 * ORC_NUM_INST], gci[16], insti[16 * ORC_NUM_INST];
+    bb_prepare(o, gvote, gn, gc, instm, gci, insti);
+    int box[ORC_NUM_INST * 6];
+    for (int i = 0; i < ORC_NUM_INST; i++) { box[i * 6] = box[i * 6 + 2] = box[i * 6 + 4] = 999999999; box[i * 6 + 1] = box[i * 6 + 3] = box[i * 6 + 5] = -999999999; }
+    for (int s = 0; s < o->n; s++) {   /* testAllSurfelFindBBoxKernel :1831-1901 */
+        const int inst = bb_instance_of(o, s);
+        if (inst == -1) continue;
+        const float* P = &o->pc[s * 4];
+        const float* M = bbox_type ? gci : insti + 16 * inst;
+        const float g[3] = {M[0] * P[0] + M[1] * P[1] + M[2] * P[2] + M[3] * 1.0f, M[4] * P[0] + M[5] * P[1] + M[6] * P[2] + M[7] * 1.0f,
+                            M[8] * P[0] + M[9] * P[1] + M[10] * P[2] + M[11] * 1.0f};
+        for (int a = 0; a < 3; a++) {
+            const int v = orc_f2i_rz(g[a] * ratio);
+            int mn = v, mx = v;
+            if (mn > P[a] * ratio) mn--;   /* compares with the WORLD coordinate, as the reference does */
+            if (mx < P[a] * ratio) mx++;
+            if (mn < box[inst * 6 + 2 * a]) box[inst * 6 + 2 * a] = mn;
+            if (mx > box[inst * 6 + 2 * a + 1]) box[inst * 6 + 2 * a + 1] = mx;
+        }
+    }
+    for (int k = 0; k < ORC_NUM_INST * 6; k++) boxes[k] = box[k] / ratio;
+    if (ground_normal3) memcpy(ground_normal3, gn, 12);
+    if (gc16) memcpy(gc16, gc, 64);
+    if (inst16) memcpy(inst16, instm, sizeof(instm));
+    if (ground_votes) memcpy(ground_votes, gvote, sizeof(gvote));
+}
+/* mapCountInstanceByInstColor + getSurfelToInstanceBuffer (:1920-2066), records of one instance in map order */
+int orc_instance_point_cloud(orc_t* o, int bbox_type, int32_t* counts, int inst, float* out10, int max_records)
+{
+    int gvote[BB_CELLS];
+    float gn[3], gc[16], instm[16 * ORC_NUM_INST], gci[16], insti[16 * ORC_NUM_INST];
+    bb_prepare(o, gvote, gn, gc, instm, gci, insti);
+    memset(counts, 0, ORC_NUM_INST * sizeof(int32_t));
+    int w = 0;
+    for (int s = 0; s < o->n; s++) {
+        const int q = bb_instance_of(o, s);
+        if (q == -1) continue;
+        counts[q]++;
+        if (q != inst || w >= max_records) continue;
+        const float* P = &o->pc[s * 4];
+        const float* M = bbox_type ? gci : insti + 16 * inst;
+        float nx = o->nr[s * 4], ny = -o->nr[s * 4 + 1], nz = -o->nr[s * 4 + 2];
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        nx = nx / len; ny = ny / len; nz = nz / len;
+        float* r = out10 + (size_t)w * 10;
+        r[0] = (float)s;
+        r[1] = M[0] * P[0] + M[1] * P[1] + M[2] * P[2] + M[3] * 1.0f; r[2] = M[4] * P[0] + M[5] * P[1] + M[6] * P[2] + M[7] * 1.0f; r[3] = M[8] * P[0] + M[9] * P[1] + M[10] * P[2] + M[11] * 1.0f;
+        r[4] = M[0] * nx + M[1] * ny + M[2] * nz + M[3] * 1.0f; r[5] = M[4] * nx + M[5] * ny + M[6] * nz + M[7] * 1.0f; r[6] = M[8] * nx + M[9] * ny + M[10] * nz + M[11] * 1.0f;
+        const int c = orc_f2i_rz(o->col[s * 2]);
+        r[7] = (float)(c >> 16 & 0xFF) / 255.0f; r[8] = (float)(c >> 8 & 0xFF) / 255.0f; r[9] = (float)(c & 0xFF) / 255.0f;
+        w++;
+    }
+    return w;
+}

@@ -370,6 +370,19 @@ class Oracle:
         self.L.orc_render_project_map(self.h, ptr(out))
         return out
 
+    def map_bounding_boxes(self, bbox_type=True, ratio=1000000.0):
+        boxes, gn, gc, im, gv = np.zeros((96, 6), np.float32), np.zeros(3, np.float32), np.zeros((4, 4), np.float32), np.zeros((96, 4, 4), np.float32), np.zeros(648, np.int32)
+        self.L.orc_map_bounding_boxes.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5
+        self.L.orc_map_bounding_boxes(self.h, int(bool(bbox_type)), ratio, ptr(boxes), ptr(gn), ptr(gc), ptr(im), ptr(gv))
+        return boxes, gn, gc, im, gv
+
+    def instance_point_cloud(self, inst=-1, bbox_type=True, max_records=1 << 20):
+        counts = np.zeros(96, np.int32)
+        out = np.zeros((max(max_records, 1), 10), np.float32)
+        self.L.orc_instance_point_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        n = self.L.orc_instance_point_cloud(self.h, int(bool(bbox_type)), ptr(counts), int(inst), ptr(out), max_records)
+        return counts, out[:n]
+
     def labels(self):
         out = np.zeros(self.count, np.int32)
         self.L.orc_labels(self.h, ptr(out))

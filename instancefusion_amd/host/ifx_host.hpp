@@ -901,18 +901,18 @@ public:
     // IF/Core/InstanceFusion.cpp:1261-1457: 3-D boxes of the instances (map3DBBox: 6 floats per instance, ground frame when bboxType) + the frames
     void computeMapBoundingBox(const std::unique_ptr<ElasticFusionInterface>& map, bool bboxType)
     {
-        map3DBBox.assign((size_t)instanceNum_ * 6, 0.f);
-        instcMatrix.assign((size_t)instanceNum_ * 16, 0.f);
+        map3DBBox.assign((size_t)instanceNum * 6, 0.f);
+        instcMatrix.assign((size_t)instanceNum * 16, 0.f);
         if (ifx_map_bounding_boxes(map->handle(), bboxType ? 1 : 0, ratio3DBBox, map3DBBox.data(), groundNormal, gcMatrix, instcMatrix.data(), nullptr) < 0)
             throw std::runtime_error(std::string("ifx_map_bounding_boxes: ") + ifx_last_error(map->handle()));
     }
     // IF/Core/InstanceFusion.cpp:1459-1590: the surfels of every instance as {slot, position and normal in the box frame, r, g, b} records
     void getInstancePointCloud(const std::unique_ptr<ElasticFusionInterface>& map, bool bboxType)
     {
-        std::vector<int32_t> counts((size_t)instanceNum_, 0);
+        std::vector<int32_t> counts((size_t)instanceNum, 0);
         if (ifx_instance_point_cloud(map->handle(), bboxType ? 1 : 0, counts.data(), -1, nullptr, 0) < 0) throw std::runtime_error(std::string("ifx_instance_point_cloud: ") + ifx_last_error(map->handle()));
-        instSurfels.assign((size_t)instanceNum_, std::vector<float>());
-        for (int q = 0; q < instanceNum_; q++) {
+        instSurfels.assign((size_t)instanceNum, std::vector<float>());
+        for (int q = 0; q < instanceNum; q++) {
             if (counts[q] <= 0) continue;
             instSurfels[q].resize((size_t)counts[q] * 10);
             const int n = ifx_instance_point_cloud(map->handle(), bboxType ? 1 : 0, counts.data(), q, instSurfels[q].data(), counts[q]);

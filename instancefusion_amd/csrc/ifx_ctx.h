@@ -173,6 +173,7 @@ struct ifx {
     int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
+    int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
     int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)
     int opt_raster_tiles = -1;       // tiled rasteriser (k_tile_*: key tiles resolved in LDS) instead of global atomics: 0 off, 1 on, -1 by image size (on from 1 Mpixel:

@@ -468,6 +468,78 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
     }
     block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
 }
+// The north star's "LDS-staged depth / normal tiles for the ICP reduction", as an option (ifx_set_option("icp_lds", 1); level 0 only):
+// a block owns a 64 x 16 pixel tile, stages the model's vertex and normal maps of the tile plus an 8-pixel halo in LDS (80 x 32 x 24 B =
+// 60 KB, coalesced row loads) and takes a correspondence from LDS when it falls inside, from global memory otherwise.  Same values, same
+// exact sums: bit-identical results.  MEASURED: slower than the plain gathers -- a frame's motion is a few pixels, so
+// neighbouring pixels already gather neighbouring model texels through L1 / L2, and the staging reads 2.5x the bytes the gathers touch.
+#define LT_W 64
+#define LT_H 16
+#define LT_HALO 8
+#define LT_SW (LT_W + 2 * LT_HALO)
+#define LT_SH (LT_H + 2 * LT_HALO)
+__device__ __forceinline__ void icp_body_lds(int bid, const DevState* __restrict__ st, const float* __restrict__ vmap_curr, const float* __restrict__ nmap_curr,
+                                             const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy,
+                                             float distThres, float angleThres, int w, int h, double* __restrict__ gacc)
+{
+    __shared__ float s_m[6][LT_SH][LT_SW];
+    float Rcurr[9], Rprev_inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rcurr[k] = st->Rcurr[k]; Rprev_inv[k] = st->Rprev_inv[k]; }
+    const v3 tc = v3m(st->tcurr[0], st->tcurr[1], st->tcurr[2]), tp = v3m(st->tprev[0], st->tprev[1], st->tprev[2]);
+    const int N = w * h, tiles_x = (w + LT_W - 1) / LT_W;
+    const int x0 = (bid % tiles_x) * LT_W, y0 = (bid / tiles_x) * LT_H;
+    for (int idx = threadIdx.x; idx < LT_SW * LT_SH; idx += blockDim.x) {
+        const int ly = idx / LT_SW, lx = idx - ly * LT_SW, gx = x0 - LT_HALO + lx, gy = y0 - LT_HALO + ly;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+            const int g = gy * w + gx;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { s_m[q][ly][lx] = vmap_prev[g + q * N]; s_m[3 + q][ly][lx] = nmap_prev[g + q * N]; }
+        }
+    }
+    __syncthreads();
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
+    const int tx = threadIdx.x & (LT_W - 1), ty0 = threadIdx.x >> 6;   // 256 threads = 64 columns x 4 rows, 4 rounds of rows
+#pragma unroll
+    for (int u = 0; u < LT_H / 4; u++) {
+        const int px = x0 + tx, py = y0 + ty0 + 4 * u;
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool found = false;
+        if (px < w && py < h) {
+            const int i = py * w + px;
+            const v3 vcurr = v3m(vmap_curr[i], vmap_curr[i + N], vmap_curr[i + 2 * N]), ncurr = v3m(nmap_curr[i], nmap_curr[i + N], nmap_curr[i + 2 * N]);
+            const v3 vcurr_g = mulp(Rcurr, vcurr) + tc;
+            const v3 vcurr_cp = mulp(Rprev_inv, vcurr_g - tp);
+            const int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx), uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
+            const bool inb = !(vcurr.x != vcurr.x) && !(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0);
+            if (inb) {
+                v3 vprev, nprev;
+                const int lx = ux - x0 + LT_HALO, ly = uy - y0 + LT_HALO;
+                if (lx >= 0 && lx < LT_SW && ly >= 0 && ly < LT_SH) {
+                    vprev = v3m(s_m[0][ly][lx], s_m[1][ly][lx], s_m[2][ly][lx]);
+                    nprev = v3m(s_m[3][ly][lx], s_m[4][ly][lx], s_m[5][ly][lx]);
+                } else {
+                    const int j = uy * w + ux;
+                    vprev = v3m(vmap_prev[j], vmap_prev[j + N], vmap_prev[j + 2 * N]);
+                    nprev = v3m(nmap_prev[j], nmap_prev[j + N], nmap_prev[j + 2 * N]);
+                }
+                const v3 ncurr_g = mulp(Rcurr, ncurr);
+                const float dist = norm(vprev - vcurr_g), sine = norm(cross(ncurr_g, nprev));
+                found = (sine < angleThres && dist <= distThres && !(ncurr.x != ncurr.x) && !(nprev.x != nprev.x));
+                if (found) {
+                    const v3 s_cp = mulp(Rprev_inv, vcurr_g - tp), d_cp = mulp(Rprev_inv, vprev - tp), n_cp = mulp(Rprev_inv, nprev), c = cross(s_cp, n_cp);
+                    row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = c.x; row[4] = c.y; row[5] = c.z;
+                    row[6] = dot(n_cp, s_cp - d_cp);
+                }
+            }
+        }
+        products7<0>(row, found, acc);
+    }
+    block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
+}
+
 __global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
                                                      const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
                                                      const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy, float distThres,
@@ -588,11 +660,14 @@ struct PairArgs {
     int* res_partials;
     int* res_total;
     int check_skip;
+    int lds_tiles;   // ICP half on 64 x 16 tiles with the model maps staged in LDS (option icp_lds, level 0)
 };
+template <bool LDS_TILES>
 __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, PairArgs a)
 {
     if (a.check_skip && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
     if ((int)blockIdx.x < a.nb_icp) {
+        if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_acc); return; }
         IcpArgs ia;   // unused when st != nullptr
         icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_acc);
     } else {
@@ -1604,12 +1679,15 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         // The residual half of the launch is the slower one and scales with its blocks (its totals go through integer atomics, it has no partial rows for the
         // last block to sum): one pixel per thread, no loop -- 152 blocks 17.5 us, 304 blocks 13.3 us, 1200 blocks 11.3 us per launch at 640x480 (1053 -> 1102 frames/s).
-        const int nbi = nb, nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
+        const bool lds_tiles = h->opt_icp_lds && i == 0;
+        const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
+        pa.lds_tiles = lds_tiles ? 1 : 0;
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
         pa.icp_acc = p.acc; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8); pa.check_skip = frame_tracker ? 0 : 1;
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
-            LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual, st, pa);
+            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual<true>, st, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual<false>, st, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nbi; sa2.nb_res = nbr;

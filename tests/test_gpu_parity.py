@@ -541,6 +541,24 @@ def test_config3_5m_map_full_instance_path(ifx, orc):
     g.close(); o.close()
 
 
+def test_lds_staged_icp_tiles_are_bit_identical(ifx):
+    """The north star's LDS-staged model tiles for the level-0 ICP reduction (option icp_lds): same correspondences, same exact sums --
+    trajectories and maps bit-identical to the plain gathers (it is slower, DESIGN.md section 6, hence an option)."""
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(6, W, H, noise=True, loop_len=90, **K)
+    out = []
+    for lds in (0, 1):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
+        g.set_option("icp_lds", lds)
+        out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(6)]), g.download()))
+        g.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in MAP_KEYS)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_owner_sharded_map_emulated(ifx, small_stream, world):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images

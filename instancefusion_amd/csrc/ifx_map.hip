@@ -508,13 +508,16 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
         if (x < w && y < h) {
             const int id = ids[y * w + x];
             if (id > 0 && id < st->count) {
+                float4 v[12];   // all twelve planes in flight together (one after the other they were twelve HBM round trips: 13 us for this little kernel)
+#pragma unroll
+                for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + id];
+#pragma unroll
                 for (int q = 0; q < 12; q++) {
-                    float4 v = votes[(size_t)q * cap + id];
                     int a, b;
-                    vote_decode(v.x, a, b); mass += a + b;
-                    vote_decode(v.y, a, b); mass += a + b;
-                    vote_decode(v.z, a, b); mass += a + b;
-                    vote_decode(v.w, a, b); mass += a + b;
+                    vote_decode(v[q].x, a, b); mass += a + b;
+                    vote_decode(v[q].y, a, b); mass += a + b;
+                    vote_decode(v[q].z, a, b); mass += a + b;
+                    vote_decode(v[q].w, a, b); mass += a + b;
                 }
             } else empty = 1;
         }
@@ -1625,16 +1628,18 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
     upd_owner[id] = 0xFFFFFFFFu;
     float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
+    const float2 cl0 = col[id], t0_ = tm[id];   // issued with the other loads (they used to follow them: two more dependent round trips)
+    const float mc = mcol[k];
     float c_k = p.w, a = mp.w;
     if (mn.w < (1.0f + 0.5f) * n.w) {
         p.x = ((c_k * p.x) + (a * mp.x)) / (c_k + a);
         p.y = ((c_k * p.y) + (a * mp.y)) / (c_k + a);
         p.z = ((c_k * p.z) + (a * mp.z)) / (c_k + a);
         p.w = c_k + a;
-        float2 cl = col[id];
+        float2 cl = cl0;
         float oc[3], nc[3];
         decode_color(cl.x, oc);
-        decode_color(mcol[k], nc);
+        decode_color(mc, nc);
         cl.x = encode_color(((c_k * oc[0]) + (a * nc[0])) / (c_k + a), ((c_k * oc[1]) + (a * nc[1])) / (c_k + a), ((c_k * oc[2]) + (a * nc[2])) / (c_k + a));
         col[id] = cl;
         float t0 = ((c_k * n.x) + (a * mn.x)) / (c_k + a), t1 = ((c_k * n.y) + (a * mn.y)) / (c_k + a), t2 = ((c_k * n.z) + (a * mn.z)) / (c_k + a);
@@ -1647,7 +1652,7 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
         p.w = c_k + a;
         pc[id] = p;
     }
-    float2 t = tm[id];
+    float2 t = t0_;
     t.y = (float)time;
     tm[id] = t;
 }

@@ -1185,12 +1185,85 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3_fused(DevState* st, const u
     if (threadIdx.x < 64) so3_update_wave(st, gacc, fx2, fy2, cx2, cy2);
 }
 
+// rodrigues2, EF/ElasticFusion.cpp:1183-1228 (without the SVD re-orthonormalisation)
+__device__ void rodrigues2(const float* R, float* out3)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = ((double)(R[0] + R[4] + R[8]) - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        double t;
+        if (c > 0) rx = ry = rz = 0;
+        else {
+            t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0.0);
+            t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+            t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    out3[0] = (float)rx; out3[1] = (float)ry; out3[2] = (float)rz;
+}
+
+// end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449)
+__device__ void track_end_dev(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
+{
+    float* pose = commit ? st->pose : st->spec_pose;
+    float* pose_inv = commit ? st->pose_inv : st->spec_pose_inv;
+    if (!commit && !tracked) for (int k = 0; k < 16; k++) pose[k] = st->pose[k];
+    if (tracked) {
+        if (rgb) {
+            v3 d = v3m(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
+            if (norm(d) > 0.3f) {
+                for (int k = 0; k < 9; k++) st->Rcurr[k] = st->Rprev[k];
+                for (int k = 0; k < 3; k++) st->tcurr[k] = st->tprev[k];
+            }
+        }
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) pose[r * 4 + c] = st->Rcurr[r * 3 + c];
+            pose[r * 4 + 3] = st->tcurr[r];
+        }
+        pose[12] = pose[13] = pose[14] = 0.f; pose[15] = 1.f;
+    }
+    pose_inverse(pose, pose_inv);
+    float diff[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            float s = 0;
+            for (int k = 0; k < 4; k++) s += pose_inv[r * 4 + k] * st->last_pose[k * 4 + c];
+            diff[r * 4 + c] = s;
+        }
+    float R3[9] = {diff[0], diff[1], diff[2], diff[4], diff[5], diff[6], diff[8], diff[9], diff[10]};
+    float rv[3];
+    rodrigues2(R3, rv);
+    float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
+    float rn = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    float weighting = fmaxf(tn, rn);
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    const float wgt = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
+    if (commit) st->weighting = wgt; else st->spec_weighting = wgt;
+    if (commit && lctr) vlist_decide(st, lctr);   // the frame's pose is final: does the cached view list still cover it?
+}
+__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
+{
+    if (threadIdx.x != 0) return;
+    track_end_dev(st, rgb, tracked, weight_mult, commit, lctr);
+}
+
 // one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583 (icp && rgb branch
 // selected by the flags), on one block: fixed-order double sums of the block partials, 6x6 pivoted
 // LDLT in double, SE(3) update, next warp matrices.
 __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict__ icp_acc, double* __restrict__ rgb_acc,
                            const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy,
-                           int* __restrict__ res_total = nullptr, int final_iter = 1)
+                           int* __restrict__ res_total = nullptr, int final_iter = 1, int end_run = 0, float weight_mult = 1.f, int commit = 1, unsigned int* lctr = nullptr)
 {
     // the 2 x 29 exact totals: one thread per value reads the replicas of its accumulator row entry and clears them for the
     // next iteration (the first version summed up to 500 partial rows of 128 B here: 4.6k cycles of the last block)
@@ -1330,6 +1403,8 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krk[k]; }
 #pragma unroll
     for (int k = 0; k < 3; k++) { st->tcurr[k] = tc[k]; st->kt[k] = kt[k]; }
+    // the run's last iteration also ends the run (:587-603, pose write-back, velocity weighting, view-list decision): the same lane, one launch less per frame
+    if (end_run) track_end_dev(st, rgb, 1, weight_mult, commit, lctr);
 #ifdef IFX_STAMPS
     { long long ts_d = clock64(); st->dbg[4] += ts_d - ts_c; st->dbg[6] += ts_b - ts_a; st->dbg[7] += ts_c - ts_b; st->dbg[3] += ts_a; }
 #endif
@@ -1356,6 +1431,9 @@ struct StepArgs {
     unsigned int* ticket;
     int check_skip;
     int final_iter;   // last Gauss-Newton iteration of the run: leaves lastA / lastb / the sums in DevState
+    int end_run, commit;   // ... and ends the run in the same lane (track_end_dev)
+    float weight_mult;
+    unsigned int* lctr;
 };
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
 {
@@ -1387,80 +1465,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total, a.final_iter);
+    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
 }
 
-// rodrigues2, EF/ElasticFusion.cpp:1183-1228 (without the SVD re-orthonormalisation)
-__device__ void rodrigues2(const float* R, float* out3)
-{
-    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-    double c = ((double)(R[0] + R[4] + R[8]) - 1) * 0.5;
-    c = c > 1. ? 1. : c < -1. ? -1. : c;
-    double theta = acos(c);
-    if (s < 1e-5) {
-        double t;
-        if (c > 0) rx = ry = rz = 0;
-        else {
-            t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0.0);
-            t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
-            t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
-            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
-            theta /= sqrt(rx * rx + ry * ry + rz * rz);
-            rx *= theta; ry *= theta; rz *= theta;
-        }
-    } else {
-        double vth = 1 / (2 * s);
-        vth *= theta;
-        rx *= vth; ry *= vth; rz *= vth;
-    }
-    out3[0] = (float)rx; out3[1] = (float)ry; out3[2] = (float)rz;
-}
-
-// end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449)
-__global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
-{
-    if (threadIdx.x != 0) return;
-    float* pose = commit ? st->pose : st->spec_pose;
-    float* pose_inv = commit ? st->pose_inv : st->spec_pose_inv;
-    if (!commit && !tracked) for (int k = 0; k < 16; k++) pose[k] = st->pose[k];
-    if (tracked) {
-        if (rgb) {
-            v3 d = v3m(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
-            if (norm(d) > 0.3f) {
-                for (int k = 0; k < 9; k++) st->Rcurr[k] = st->Rprev[k];
-                for (int k = 0; k < 3; k++) st->tcurr[k] = st->tprev[k];
-            }
-        }
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) pose[r * 4 + c] = st->Rcurr[r * 3 + c];
-            pose[r * 4 + 3] = st->tcurr[r];
-        }
-        pose[12] = pose[13] = pose[14] = 0.f; pose[15] = 1.f;
-    }
-    pose_inverse(pose, pose_inv);
-    float diff[16];
-    for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) {
-            float s = 0;
-            for (int k = 0; k < 4; k++) s += pose_inv[r * 4 + k] * st->last_pose[k * 4 + c];
-            diff[r * 4 + c] = s;
-        }
-    float R3[9] = {diff[0], diff[1], diff[2], diff[4], diff[5], diff[6], diff[8], diff[9], diff[10]};
-    float rv[3];
-    rodrigues2(R3, rv);
-    float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
-    float rn = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-    float weighting = fmaxf(tn, rn);
-    const float largest = 0.01f, minWeight = 0.5f;
-    if (weighting > largest) weighting = largest;
-    const float wgt = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
-    if (commit) st->weighting = wgt; else st->spec_weighting = wgt;
-    if (commit && lctr) vlist_decide(st, lctr);   // the frame's pose is final: does the cached view list still cover it?
-}
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
 __global__ void k_commit_pose(DevState* st, unsigned int* lctr)
 {
@@ -1660,6 +1670,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     }
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
+    bool ended = false;
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
         // The coarse levels are on the queue: the host is now ahead of the GPU by ~20 latency-bound launches, and the
         // finest level keeps the GPU mostly idle for another ~0.3 ms -- the place to slip in the next frame's image-only work.
@@ -1699,10 +1710,13 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 for (int q = i - 1; q >= 0; q--) later = later || iterations[q] > 0;
                 sa2.final_iter = (j == iterations[i] - 1 && !later) ? 1 : 0;
             }
+            sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
+            ended = ended || sa2.end_run;
             LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
         }
     }
-    LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit, frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr);
+    if (!ended)   // (no iteration ran at all: every level has zero iterations)
+        LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit, frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr);
 }
 
 // frame side of the tracker for the bound slot: frame pyramids, then (unless this is the first frame, which only

@@ -64,6 +64,12 @@ struct DevState {
     unsigned int vl_n[2]; // lengths of the two flat view lists: [0] inside the time window (grows with the appended surfels), [1] stable slots outside it
     unsigned int vl_seg_n[2 * IFX_LIST_SEGS], vl_seg_off[2 * IFX_LIST_SEGS];   // segment lengths / offsets of the scan's raw output (k_vlist_offsets, which re-arms the live counters)
     long long dbg[8];     // in-kernel cycle stamps (IFX_STAMPS builds only)
+    // Gauss-Newton hand-off words of THIS tracker instance.  They live in the state so that a kernel reaches them through the state pointer, which
+    // arrives preloaded with the wave (kernarg preload): no kernarg round trip in front of the first dependent load.  A line of their own: they are
+    // the target of atomics while other fields are read through the scalar cache.
+    alignas(64) int gn_res[2];   // residual totals (count, sigma) of the iteration in flight: written by k_icp_residual, consumed and re-armed by k_rgb_step_solve
+    unsigned int gn_ticket;      // last-block ticket of k_rgb_step_solve
+    int gn_pad[13];
 };
 
 struct FrameResult {   // copied to pinned host memory at the end of every frame

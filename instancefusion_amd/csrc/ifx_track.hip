@@ -400,15 +400,16 @@ __shared__ long long s_dbg_blk[4];
 struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
 // ICPReduction, EF/Cuda/reduce.cu:257-411.  Rcurr/tcurr/Rprev_inv/tprev come from DevState (or from
 // explicit arguments for the stage API when st == nullptr).
-template <bool WT = false>
+template <bool WT = false, bool FROM_STATE = false>
 __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __restrict__ st, const IcpArgs& ex, const float* __restrict__ vmap_curr,
                                          const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx,
                                          float fy, float cx, float cy, float distThres, float angleThres, int w, int h, double* __restrict__ gacc)
 {
-    const float* Rc = st ? st->Rcurr : ex.Rcurr;
-    const float* tcp = st ? st->tcurr : ex.tcurr;
-    const float* Rpi = st ? st->Rprev_inv : ex.Rprev_inv;
-    const float* tpp = st ? st->tprev : ex.tprev;
+    const bool from_state = FROM_STATE || st != nullptr;   // (FROM_STATE: known at compile time -- no per-element select, the loads leave in one batch)
+    const float* Rc = from_state ? st->Rcurr : ex.Rcurr;
+    const float* tcp = from_state ? st->tcurr : ex.tcurr;
+    const float* Rpi = from_state ? st->Rprev_inv : ex.Rprev_inv;
+    const float* tpp = from_state ? st->tprev : ex.tprev;
     float Rcurr[9], Rprev_inv[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) { Rcurr[k] = Rc[k]; Rprev_inv[k] = Rpi[k]; }
@@ -417,13 +418,13 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.0;
     const int N = w * h;
-    for (int base = bid * (blockDim.x * RED_IT) + threadIdx.x; base < N; base += nblk * blockDim.x * RED_IT) {
+    for (int base = bid * (RED_THREADS * RED_IT) + threadIdx.x; base < N; base += nblk * RED_THREADS * RED_IT) {
         v3 vcurr[RED_IT], ncurr[RED_IT], vprev[RED_IT], nprev[RED_IT], vcurr_g[RED_IT];
         int j[RED_IT];
         bool inb[RED_IT];
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 1: coalesced loads
-            int i = base + u * blockDim.x;
+            int i = base + u * RED_THREADS;
             bool in = i < N;
             int ii = in ? i : 0;
             vcurr[u] = v3m(vmap_curr[ii], vmap_curr[ii + N], vmap_curr[ii + 2 * N]);
@@ -489,7 +490,7 @@ __device__ __forceinline__ void icp_body_lds(int bid, const DevState* __restrict
     const v3 tc = v3m(st->tcurr[0], st->tcurr[1], st->tcurr[2]), tp = v3m(st->tprev[0], st->tprev[1], st->tprev[2]);
     const int N = w * h, tiles_x = (w + LT_W - 1) / LT_W;
     const int x0 = (bid % tiles_x) * LT_W, y0 = (bid / tiles_x) * LT_H;
-    for (int idx = threadIdx.x; idx < LT_SW * LT_SH; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < LT_SW * LT_SH; idx += RED_THREADS) {
         const int ly = idx / LT_SW, lx = idx - ly * LT_SW, gx = x0 - LT_HALO + lx, gy = y0 - LT_HALO + ly;
         if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
             const int g = gy * w + gx;
@@ -554,13 +555,15 @@ struct Corres8 { short zx, zy; float diff; };
 
 // RGBResidual, EF/Cuda/reduce.cu:739-863
 struct ResArgs { float krkinv[9], kt[3]; };
+template <bool FROM_STATE = false>
 __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState* __restrict__ st, const ResArgs& ex, float minScale, const int16_t* __restrict__ dIdx,
                                               const int16_t* __restrict__ dIdy, const float* __restrict__ lastDepth, const float* __restrict__ nextDepth,
                                               const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, Corres8* __restrict__ corres,
                                               float maxDepthDelta, int w, int h, int* __restrict__ partials, int* __restrict__ res_total = nullptr)
 {
-    const float* kk = st ? st->krkinv : ex.krkinv;
-    const float* ktp = st ? st->kt : ex.kt;
+    const bool from_state = FROM_STATE || st != nullptr;
+    const float* kk = from_state ? st->krkinv : ex.krkinv;
+    const float* ktp = from_state ? st->kt : ex.kt;
     float krk[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) krk[k] = kk[k];
@@ -568,14 +571,14 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
     const int border = 16;
     const int N = w * h;
     int cnt = 0, sig = 0;
-    for (int base = bid * (blockDim.x * RED_IT) + threadIdx.x; base < N; base += nblk * blockDim.x * RED_IT) {
+    for (int base = bid * (RED_THREADS * RED_IT) + threadIdx.x; base < N; base += nblk * RED_THREADS * RED_IT) {
         bool cand[RED_IT];
         int kidx[RED_IT], gj[RED_IT];
         float d1[RED_IT], td1[RED_IT];
         uint8_t ni[RED_IT];
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 1: own-pixel tests (4x4 non-zero block, gradient gate) and depth
-            int k = base + u * blockDim.x;
+            int k = base + u * RED_THREADS;
             kidx[u] = k;
             bool in = k < N;
             int kk2 = in ? k : 0;
@@ -583,16 +586,20 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
             bool ok = in && i >= border && i < h - border && j0 >= border && j0 < w - border && j0 < w - 5 && i < h - 1;
             // inside the 16-px border the 4x4 block [i-2,i+2) x [j0-2,j0+2) is always in the image
             int ci = ok ? i : 16, cj = ok ? j0 : 16;
+            // "all 16 pixels non-zero": four unaligned 4-byte loads issued together and a has-zero-byte test per row (the byte-by-byte
+            // form compiled to 16 dependent loads, each behind the previous one's branch: ~2 us of every residual launch)
             bool valid = true;
 #pragma unroll
-            for (int a = -2; a < 2; a++)
-#pragma unroll
-                for (int b = -2; b < 2; b++) valid = valid && (nextImage[(ci + a) * w + cj + b] > 0);
+            for (int a = -2; a < 2; a++) {
+                uint32_t r4;
+                __builtin_memcpy(&r4, nextImage + (ci + a) * w + cj - 2, 4);
+                valid = valid & (((r4 - 0x01010101u) & ~r4 & 0x80808080u) == 0u);
+            }
             short valx = dIdx[kk2], valy = dIdy[kk2];
             float mTwo = (float)((valx * valx) + (valy * valy));
             d1[u] = nextDepth[kk2];
             ni[u] = nextImage[kk2];
-            cand[u] = ok && valid && (mTwo >= minScale) && !(d1[u] != d1[u]);
+            cand[u] = ok & valid & (mTwo >= minScale) & !(d1[u] != d1[u]);   // (bitwise: no load of this stage may hide behind a branch)
         }
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 2: warp into the last image
@@ -601,7 +608,7 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
             td1[u] = (float)(d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
             int u0 = f2i_rn((d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
             int v0 = f2i_rn((d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
-            cand[u] = cand[u] && (u0 >= 0 && v0 >= 0 && u0 < w && v0 < h);
+            cand[u] = cand[u] & ((u0 >= 0) & (v0 >= 0) & (u0 < w) & (v0 < h));
             gj[u] = cand[u] ? v0 * w + u0 : 0;
         }
         float d0[RED_IT];
@@ -611,14 +618,13 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 4
             Corres8 c;
-            c.zx = -1; c.zy = -1; c.diff = 0.f;
-            if (cand[u] && d0[u] > 0 && fabsf(td1[u] - d0[u]) <= maxDepthDelta && li[u] != 0) {
-                int v0 = gj[u] / w, u0 = gj[u] - v0 * w;
-                c.zx = (short)u0; c.zy = (short)v0;
-                c.diff = (float)ni[u] - (float)li[u];
-                cnt += 1;
-                sig += (int)(c.diff * c.diff);
-            }
+            const bool hit = cand[u] & (d0[u] > 0) & (fabsf(td1[u] - d0[u]) <= maxDepthDelta) & (li[u] != 0);
+            const int v0 = gj[u] / w, u0 = gj[u] - v0 * w;
+            const float diff = (float)ni[u] - (float)li[u];
+            c.zx = hit ? (short)u0 : (short)-1; c.zy = hit ? (short)v0 : (short)-1;
+            c.diff = hit ? diff : 0.f;
+            cnt += hit ? 1 : 0;
+            sig += hit ? (int)(diff * diff) : 0;
             if (kidx[u] < N) corres[kidx[u]] = c;
         }
     }
@@ -662,18 +668,25 @@ struct PairArgs {
     int check_skip;
     int lds_tiles;   // ICP half on 64 x 16 tiles with the model maps staged in LDS (option icp_lds, level 0)
 };
-template <bool LDS_TILES>
-__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, PairArgs a)
+// All kernel-argument words a launch needs are pulled into SGPRs in the entry block (one scalar round trip).  Left to itself the compiler sinks
+// each group of s_loads into the branch that uses it: four to five dependent scalar round trips in front of the first vector load of a
+// latency-bound launch.
+#define IFX_PIN_S(x) asm volatile("" ::"s"(x))
+template <bool LDS_TILES, bool CHECK_SKIP>
+__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, int nb_icp, int w, int h, PairArgs a)
 {
-    if (a.check_skip && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
-    if ((int)blockIdx.x < a.nb_icp) {
-        if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_acc); return; }
+    // `st`, `nb_icp`, `w` and `h` arrive preloaded: the branch below is decided without a load, and each half then fetches its argument words and its
+    // state fields in ONE scalar round trip (they used to be four to five dependent ones in front of the first vector load)
+    __builtin_assume(st != nullptr);
+    if (CHECK_SKIP && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
+    if ((int)blockIdx.x < nb_icp) {
+        if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, a.icp_acc); return; }
         IcpArgs ia;   // unused when st != nullptr
-        icp_body(blockIdx.x, a.nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, a.icp_acc);
+        icp_body<false, true>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, a.icp_acc);
     } else {
         ResArgs ra;
-        residual_body(blockIdx.x - a.nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, a.w,
-                      a.h, a.res_partials, a.res_total);
+        residual_body<true>(blockIdx.x - nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, w,
+                      h, a.res_partials, a.res_total);
     }
 }
 
@@ -688,7 +701,7 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
 #endif
     const int N = w * h;
     // stage 1 loads are issued before the sigma reduction so that both latencies overlap
-    const int base0 = bid * (blockDim.x * RED_IT_RGB) + threadIdx.x;
+    const int base0 = bid * (RED_THREADS * RED_IT_RGB) + threadIdx.x;
     float sigma = sigma_explicit;
     if (res_total) {
         int cnt = res_total[0], sg = res_total[1];
@@ -720,13 +733,13 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
     double acc[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.0;
-    for (int base = base0; base < N; base += nblk * blockDim.x * RED_IT_RGB) {
+    for (int base = base0; base < N; base += nblk * RED_THREADS * RED_IT_RGB) {
         Corres8 c[RED_IT_RGB];
         float X[RED_IT_RGB], Y[RED_IT_RGB], Z[RED_IT_RGB];
         short gx[RED_IT_RGB], gy[RED_IT_RGB];
 #pragma unroll
         for (int u = 0; u < RED_IT_RGB; u++) {
-            int k = base + u * blockDim.x;
+            int k = base + u * RED_THREADS;
             bool in = k < N;
             int kk = in ? k : 0;
             c[u] = corres[kk];
@@ -802,7 +815,7 @@ __device__ __forceinline__ void so3_body(int bid, int nblk, const DevState* __re
     for (int k = 0; k < 11; k++) acc[k] = 0.0;
     constexpr int E[4] = IFX_E_SO3;
     const int N = w * h;
-    for (int k = bid * blockDim.x + threadIdx.x; k < N; k += blockDim.x * nblk) {
+    for (int k = bid * RED_THREADS + threadIdx.x; k < N; k += RED_THREADS * nblk) {
         int y = k / w, x = k - y * w;
         v3 up = v3m((float)x, (float)y, 1.0f);
         v3 wp = mulp(ib, up);
@@ -1269,6 +1282,16 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     // next iteration (the first version summed up to 500 partial rows of 128 B here: 4.6k cycles of the last block)
     __shared__ double s_icp[29], s_rgb[29];
     __shared__ int s_res[2];
+    // the pose state the serial part starts from: written by the previous launch, so it can be fetched together with the totals
+    // (one memory round trip instead of two on the critical path of every iteration)
+    double RRt[16];
+    float Rp[9], tp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) RRt[k] = st->resultRt[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tp[k] = st->tprev[k];
     if (threadIdx.x < 58) {
         const int which = threadIdx.x >= 29, k = threadIdx.x - 29 * which;
         double* g = which ? rgb_acc : icp_acc;
@@ -1306,14 +1329,6 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     // ---- serial part on one lane.  Every input is read once into registers and every output is
     // stored once at the end: a store to DevState followed by a load of the same field costs a full
     // memory round trip on a lone lane (the first version did that five times per solve).
-    double RRt[16];
-    float Rp[9], tp[3];
-#pragma unroll
-    for (int k = 0; k < 16; k++) RRt[k] = st->resultRt[k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) tp[k] = st->tprev[k];
     float oi[29], orr[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) { oi[k] = icp ? (float)s_icp[k] : 0.f; orr[k] = rgb ? (float)s_rgb[k] : 0.f; }
@@ -1435,37 +1450,40 @@ struct StepArgs {
     float weight_mult;
     unsigned int* lctr;
 };
+template <bool CHECK_SKIP>
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
 {
-    if (a.check_skip && st->skip) return;   // (model-to-model instance only) uniform over the grid: the last-block ticket stays armed
+    __builtin_assume(st != nullptr);
+    // the words the reduction body needs, and the residual totals behind the (preloaded) state pointer, in one scalar round trip
+    asm volatile("" ::"s"(a.corres), "s"(a.cloud), "s"(a.dIdx), "s"(a.dIdy), "s"(a.rgb_acc), "s"(a.icp_acc), "s"(a.fx), "s"(a.fy), "s"(a.sobelScale), "s"(a.w), "s"(a.h),
+                 "s"(a.nb), "s"(a.rgb), "s"(a.icp));
+    if (CHECK_SKIP && st->skip) return;   // (model-to-model instance only) uniform over the grid: the last-block ticket stays armed
+    int* const res_total = st->gn_res;
+    unsigned int* const ticket = &st->gn_ticket;
     __shared__ int s_last;
 #ifdef IFX_STAMPS
     long long t0 = clock64();
 #endif
-    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_acc, a.res_total);
+    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_acc, res_total);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef IFX_STAMPS
     long long t1 = clock64();
 #endif
     if (threadIdx.x == 0) {   // this block's atomic adds were performed at the memory side: every wave drained vmcnt before the barrier
-        unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (unsigned int)(a.nb - 1));
     }
     __syncthreads();
     if (!s_last) return;
-    if (threadIdx.x == 0) {
-        // Everything the other blocks of this launch produced reaches this block through agent-scope atomics and agent-scope
-        // (sc1) loads -- the accumulator rows, the residual totals, the ticket -- which are performed at / served from the
-        // memory side: no acquire (buffer_inv, ~1.7 us) is needed.  Only the stage-API variant reads plain partial rows.
-        if (!a.res_total) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch (stream order)
-    }
-    __syncthreads();
+    // Everything the other blocks of this launch produced reaches this block through agent-scope atomics and agent-scope
+    // (sc1) loads -- the accumulator rows, the residual totals, the ticket -- which are performed at / served from the
+    // memory side: no acquire (buffer_inv, ~1.7 us) is needed.
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch (stream order)
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
+    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
@@ -1690,21 +1708,22 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         // The residual half of the launch is the slower one and scales with its blocks (its totals go through integer atomics, it has no partial rows for the
         // last block to sum): one pixel per thread, no loop -- 152 blocks 17.5 us, 304 blocks 13.3 us, 1200 blocks 11.3 us per launch at 640x480 (1053 -> 1102 frames/s).
-        const bool lds_tiles = h->opt_icp_lds && i == 0;
+        const bool lds_tiles = h->opt_icp_lds && i == 0 && frame_tracker;
         const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
         pa.lds_tiles = lds_tiles ? 1 : 0;
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
-        pa.icp_acc = p.acc; pa.res_partials = p.res_partials; pa.res_total = (int*)(p.ticket + 8); pa.check_skip = frame_tracker ? 0 : 1;
+        pa.icp_acc = p.acc; pa.res_partials = p.res_partials; pa.res_total = (int*)((char*)st + offsetof(DevState, gn_res)); pa.check_skip = frame_tracker ? 0 : 1;
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
-            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual<true>, st, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
-            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), k_icp_residual<false>, st, pa);
+            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            else if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, pa);
+            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nbi; sa2.nb_res = nbr;
             sa2.rgb_acc = p.acc + IFX_ACC_REPL * IFX_ACC_STRIDE; sa2.icp_acc = p.acc; sa2.res_partials = p.res_partials;
             sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
-            sa2.ticket = p.ticket; sa2.res_total = (int*)(p.ticket + 8); sa2.check_skip = frame_tracker ? 0 : 1;
+            sa2.ticket = nullptr; sa2.res_total = nullptr; sa2.check_skip = frame_tracker ? 0 : 1;   // (hand-off words: DevState::gn_ticket / gn_res)
             {   // is this the run's last iteration?  (no level below this one iterates)
                 bool later = false;
                 for (int q = i - 1; q >= 0; q--) later = later || iterations[q] > 0;
@@ -1712,7 +1731,8 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             }
             sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
             ended = ended || sa2.end_run;
-            LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve, st, sa2);
+            if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2);
+            else LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2);
         }
     }
     if (!ended)   // (no iteration ran at all: every level has zero iterations)

@@ -234,7 +234,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
-    else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(1024, value));
+    else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
+    else if (s == "res_blocks") h->opt_res_blocks = std::max(0, std::min(4096, value));
     else if (s == "icp_lds") h->opt_icp_lds = value;
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;

@@ -70,6 +70,7 @@ struct DevState {
     alignas(64) int gn_res[2];   // residual totals (count, sigma) of the iteration in flight: written by k_icp_residual, consumed and re-armed by k_rgb_step_solve
     unsigned int gn_ticket;      // last-block ticket of k_rgb_step_solve
     int gn_pad[13];
+    double gn_acc[2 * IFX_ACC_REPL * IFX_ACC_STRIDE];   // exact accumulator rows of the iteration in flight: [0] ICP, [1] photometric (layout of block_sum_exact)
 };
 
 struct FrameResult {   // copied to pinned host memory at the end of every frame
@@ -181,6 +182,7 @@ struct ifx {
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
+    int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)
     int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)
     int opt_raster_tiles = -1;       // tiled rasteriser (k_tile_*: key tiles resolved in LDS) instead of global atomics: 0 off, 1 on, -1 by image size (on from 1 Mpixel:
                                      // at 640x480 / 5M surfels the binning passes cost what the LDS tiles save, at 1280x960 / 20M the frame rate gains 12 %)

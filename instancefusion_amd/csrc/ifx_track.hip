@@ -418,54 +418,53 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.0;
     const int N = w * h;
-    for (int base = bid * (RED_THREADS * RED_IT) + threadIdx.x; base < N; base += nblk * RED_THREADS * RED_IT) {
-        v3 vcurr[RED_IT], ncurr[RED_IT], vprev[RED_IT], nprev[RED_IT], vcurr_g[RED_IT];
-        int j[RED_IT];
-        bool inb[RED_IT];
-#pragma unroll
-        for (int u = 0; u < RED_IT; u++) {   // stage 1: coalesced loads
-            int i = base + u * RED_THREADS;
-            bool in = i < N;
-            int ii = in ? i : 0;
-            vcurr[u] = v3m(vmap_curr[ii], vmap_curr[ii + N], vmap_curr[ii + 2 * N]);
-            ncurr[u] = v3m(nmap_curr[ii], nmap_curr[ii + N], nmap_curr[ii + 2 * N]);
-            if (!in) vcurr[u].x = qnan_f();
-        }
-#pragma unroll
-        for (int u = 0; u < RED_IT; u++) {   // stage 2: projection into the model frame
-            vcurr_g[u] = mulp(Rcurr, vcurr[u]) + tc;
-            v3 vcurr_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
-            int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
-            int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
-            inb[u] = !(vcurr[u].x != vcurr[u].x) && !(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0);
-            j[u] = inb[u] ? uy * w + ux : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < RED_IT; u++) {   // stage 3: gathers
-            vprev[u] = v3m(vmap_prev[j[u]], vmap_prev[j[u] + N], vmap_prev[j[u] + 2 * N]);
-            nprev[u] = v3m(nmap_prev[j[u]], nmap_prev[j[u] + N], nmap_prev[j[u] + 2 * N]);
-        }
-#pragma unroll
-        for (int u = 0; u < RED_IT; u++) {   // stage 4: row of the normal equations
-            float row[7] = {0, 0, 0, 0, 0, 0, 0};
-            bool found = false;
-            if (inb[u]) {
-                v3 ncurr_g = mulp(Rcurr, ncurr[u]);
-                float dist = norm(vprev[u] - vcurr_g[u]);
-                float sine = norm(cross(ncurr_g, nprev[u]));
-                found = (sine < angleThres && dist <= distThres && !(ncurr[u].x != ncurr[u].x) && !(nprev[u].x != nprev[u].x));
-                if (found) {
-                    v3 s_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
-                    v3 d_cp = mulp(Rprev_inv, vprev[u] - tp);
-                    v3 n_cp = mulp(Rprev_inv, nprev[u]);
-                    v3 c = cross(s_cp, n_cp);
-                    row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
-                    row[3] = c.x; row[4] = c.y; row[5] = c.z;
-                    row[6] = dot(n_cp, s_cp - d_cp);
-                }
+    // One pixel per thread and round, software-pipelined: the coalesced loads of the NEXT round are issued right behind this round's gathers, so a
+    // round costs one memory round trip instead of two (a level-0 block runs four rounds).  Issue order matters: vector loads return in order,
+    // so the gathers go first and the prefetch rides behind them.
+    const int stride = nblk * RED_THREADS;
+    int i = bid * RED_THREADS + threadIdx.x;
+    v3 vcurr, ncurr;
+    {
+        const int ii = i < N ? i : 0;
+        vcurr = v3m(vmap_curr[ii], vmap_curr[ii + N], vmap_curr[ii + 2 * N]);
+        ncurr = v3m(nmap_curr[ii], nmap_curr[ii + N], nmap_curr[ii + 2 * N]);
+    }
+    while (i < N) {
+        // stage 2: projection into the model frame
+        const v3 vcurr_g = mulp(Rcurr, vcurr) + tc;
+        const v3 vcurr_cp = mulp(Rprev_inv, vcurr_g - tp);
+        const int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
+        const int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
+        const bool inb = !(vcurr.x != vcurr.x) && !(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0);
+        const int j = inb ? uy * w + ux : 0;
+        // stage 3: gathers
+        const v3 vprev = v3m(vmap_prev[j], vmap_prev[j + N], vmap_prev[j + 2 * N]);
+        const v3 nprev = v3m(nmap_prev[j], nmap_prev[j + N], nmap_prev[j + 2 * N]);
+        // next round's coalesced loads (a thread in its last round re-reads its own pixel: no branch around the loads)
+        const int inext = i + stride;
+        const int ip = inext < N ? inext : i;
+        const v3 vnext = v3m(vmap_curr[ip], vmap_curr[ip + N], vmap_curr[ip + 2 * N]);
+        const v3 nnext = v3m(nmap_curr[ip], nmap_curr[ip + N], nmap_curr[ip + 2 * N]);
+        // stage 4: row of the normal equations
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool found = false;
+        if (inb) {
+            v3 ncurr_g = mulp(Rcurr, ncurr);
+            float dist = norm(vprev - vcurr_g);
+            float sine = norm(cross(ncurr_g, nprev));
+            found = (sine < angleThres && dist <= distThres && !(ncurr.x != ncurr.x) && !(nprev.x != nprev.x));
+            if (found) {
+                v3 s_cp = mulp(Rprev_inv, vcurr_g - tp);
+                v3 d_cp = mulp(Rprev_inv, vprev - tp);
+                v3 n_cp = mulp(Rprev_inv, nprev);
+                v3 c = cross(s_cp, n_cp);
+                row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+                row[3] = c.x; row[4] = c.y; row[5] = c.z;
+                row[6] = dot(n_cp, s_cp - d_cp);
             }
-            products7<0>(row, found, acc);
         }
+        products7<0>(row, found, acc);
+        vcurr = vnext; ncurr = nnext; i = inext;
     }
     block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
 }
@@ -637,7 +636,7 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
     if (threadIdx.x < 2) {
         int s = 0;
         for (int wv = 0; wv < RED_WAVES; wv++) s += lds[wv][threadIdx.x];
-        partials[bid * 2 + threadIdx.x] = s;
+        if (!FROM_STATE) partials[bid * 2 + threadIdx.x] = s;
         // grand totals by integer atomics (exact in any order): the next launch reads two ints instead of reducing rows
         if (res_total && s) atomicAdd(&res_total[threadIdx.x], s);
     }
@@ -662,9 +661,6 @@ struct PairArgs {
     const uint8_t *lastImage, *nextImage;
     Corres8* corres;
     int w, h, nb_icp, nb_res;
-    double* icp_acc;
-    int* res_partials;
-    int* res_total;
     int check_skip;
     int lds_tiles;   // ICP half on 64 x 16 tiles with the model maps staged in LDS (option icp_lds, level 0)
 };
@@ -673,20 +669,21 @@ struct PairArgs {
 // latency-bound launch.
 #define IFX_PIN_S(x) asm volatile("" ::"s"(x))
 template <bool LDS_TILES, bool CHECK_SKIP>
-__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, int nb_icp, int w, int h, PairArgs a)
+__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, int nb_icp, int w, int h, double* __restrict__ gacc, int* __restrict__ gres, PairArgs a)
 {
-    // `st`, `nb_icp`, `w` and `h` arrive preloaded: the branch below is decided without a load, and each half then fetches its argument words and its
+    // `st`, `nb_icp`, `w`, `h` and the two hand-off pointers (DevState::gn_acc / gn_res of `st`: separate arguments, so that the state itself stays
+    // read-only here and its fields come through the scalar cache) arrive preloaded: the branch below is decided without a load, and each half then fetches its argument words and its
     // state fields in ONE scalar round trip (they used to be four to five dependent ones in front of the first vector load)
     __builtin_assume(st != nullptr);
     if (CHECK_SKIP && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
     if ((int)blockIdx.x < nb_icp) {
-        if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, a.icp_acc); return; }
+        if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc); return; }
         IcpArgs ia;   // unused when st != nullptr
-        icp_body<false, true>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, a.icp_acc);
+        icp_body<false, true>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc);
     } else {
         ResArgs ra;
         residual_body<true>(blockIdx.x - nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, w,
-                      h, a.res_partials, a.res_total);
+                      h, nullptr, gres);
     }
 }
 
@@ -1271,16 +1268,57 @@ __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mul
     track_end_dev(st, rgb, tracked, weight_mult, commit, lctr);
 }
 
-// one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583 (icp && rgb branch
-// selected by the flags), on one block: fixed-order double sums of the block partials, 6x6 pivoted
-// LDLT in double, SE(3) update, next warp matrices.
+// K^-1 entries of the level the next iteration runs at, as the lone lane would compute them (1/fx, 1/fy, -cx/fx, -cy/fy in f64): computed on the host
+// -- the same IEEE divisions -- so that four f64 divisions leave the serial part of every iteration
+struct KInv { double i0, i4, i2, i5; };
+static inline KInv kinv_of(float fx, float fy, float cx, float cy)
+{
+    const double K0 = fx, K2 = cx, K4 = fy, K5 = cy;
+    KInv k;
+    k.i0 = 1.0 / K0; k.i4 = 1.0 / K4; k.i2 = -K2 / K0; k.i5 = -K5 / K4;
+    return k;
+}
+__device__ __forceinline__ void warp_from_k(const double* M, float fx, float fy, float cx, float cy, const KInv& ki, float* krk, float* kt)
+{
+    const double K0 = fx, K2 = cx, K4 = fy, K5 = cy;
+    const double I0 = ki.i0, I4 = ki.i4, I2 = ki.i2, I5 = ki.i5;
+    double R3[9], tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R3[i * 3 + j] = M[j * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) tt[i] = -(R3[i * 3 + 0] * M[3] + R3[i * 3 + 1] * M[7] + R3[i * 3 + 2] * M[11]);
+    double KR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        KR[j] = K0 * R3[j] + K2 * R3[6 + j];
+        KR[3 + j] = K4 * R3[3 + j] + K5 * R3[6 + j];
+        KR[6 + j] = R3[6 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        krk[i * 3 + 0] = (float)(KR[i * 3] * I0);
+        krk[i * 3 + 1] = (float)(KR[i * 3 + 1] * I4);
+        krk[i * 3 + 2] = (float)((KR[i * 3] * I2 + KR[i * 3 + 1] * I5) + KR[i * 3 + 2]);
+    }
+    kt[0] = (float)(K0 * tt[0] + K2 * tt[2]);
+    kt[1] = (float)(K4 * tt[1] + K5 * tt[2]);
+    kt[2] = (float)tt[2];
+}
+
+// one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583, run by the block that finishes last.
+// What is serial -- the 6x6 factorisation, the pose update, the next warp matrices -- runs on lane 0; everything that is not sits on other lanes:
+//   threads 0..28   fetch (and clear) the ICP and photometric total of "their" element, round both to f32 as the reference's reductions deliver
+//                   them, and assemble the element of the combined system lastA / lastb (:547-565) -- lane 0 then reads 27 finished doubles;
+//   wave 1          the diagnostics (error norms, counts; on the run's last iteration also lastA / lastb / the 2 x 29 sums: 130 stores).
+// In-kernel stamps of the previous form (everything on lane 0): 8.6k cycles serial; see DESIGN.md section 6.
 __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict__ icp_acc, double* __restrict__ rgb_acc,
-                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy,
+                           const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy, const KInv& ki,
                            int* __restrict__ res_total = nullptr, int final_iter = 1, int end_run = 0, float weight_mult = 1.f, int commit = 1, unsigned int* lctr = nullptr)
 {
-    // the 2 x 29 exact totals: one thread per value reads the replicas of its accumulator row entry and clears them for the
-    // next iteration (the first version summed up to 500 partial rows of 128 B here: 4.6k cycles of the last block)
-    __shared__ double s_icp[29], s_rgb[29];
+    __shared__ double s_sys[27];      // combined system: index = position in the reference's 29-vector (upper triangle of A row by row, b in column 6)
+    __shared__ float s_oi[29], s_or[29];
     __shared__ int s_res[2];
     // the pose state the serial part starts from: written by the previous launch, so it can be fetched together with the totals
     // (one memory round trip instead of two on the critical path of every iteration)
@@ -1292,12 +1330,21 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) tp[k] = st->tprev[k];
-    if (threadIdx.x < 58) {
-        const int which = threadIdx.x >= 29, k = threadIdx.x - 29 * which;
-        double* g = which ? rgb_acc : icp_acc;
-        const double v = acc_total(g, k);
-        acc_clear(g, k);
-        if (which) s_rgb[k] = v; else s_icp[k] = v;
+    if (threadIdx.x < 29) {
+        const int k = threadIdx.x;
+        const double ti = acc_total(icp_acc, k), tr = acc_total(rgb_acc, k);
+        acc_clear(icp_acc, k);
+        acc_clear(rgb_acc, k);
+        const float oi = icp ? (float)ti : 0.f, orr = rgb ? (float)tr : 0.f;
+        s_oi[k] = oi; s_or[k] = orr;
+        if (k < 27) {
+            // lastA = A_rgb + w*w*A_icp, lastb = b_rgb + w*b_icp (EF/Utils/RGBDOdometry.cpp:547-565); column 6 of a row is its b entry
+            const double wgt = icp_weight;
+            const double wa = wgt * wgt, wb = wgt;
+            const bool is_b = (k == 6) | (k == 12) | (k == 17) | (k == 21) | (k == 24) | (k == 26);
+            const double vi = (double)oi, vr = (double)orr;
+            s_sys[k] = (icp && rgb) ? vr + (is_b ? wb : wa) * vi : (icp ? vi : vr);
+        }
     }
     if (res_total) {   // totals accumulated by the residual pass; re-armed (zeroed) for the next iteration
         if (threadIdx.x == 64) {
@@ -1325,45 +1372,39 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
 #ifdef IFX_STAMPS
     long long ts_c = clock64();
 #endif
+    if (threadIdx.x >= 64 && threadIdx.x < 128) {   // ---- wave 1: diagnostics, off the serial lane
+        const int t = threadIdx.x - 64;
+        if (t == 0) {
+            const int rgbSize = rgb ? s_res[0] : 0, sigma = rgb ? s_res[1] : 0;
+            st->rgb_count = rgbSize; st->rgb_sigma = sigma;
+            st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
+            st->lastRGBCount = (float)rgbSize;
+            if (icp) { st->lastICPError = sqrtf(s_oi[27]) / s_oi[28]; st->lastICPCount = s_oi[28]; }
+        }
+        if (final_iter) {   // lastA / lastb / the 2 x 29 sums describe the run's LAST iteration (getCovariance, diagnostics)
+            if (t < 29) { st->icp29[t] = s_oi[t]; st->rgb29[t] = s_or[t]; }
+            if (t < 36) {
+                const int i = t / 6, j = t - 6 * i, lo = i < j ? i : j, hi = i < j ? j : i;
+                st->lastA[t] = s_sys[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)];
+            }
+            if (t < 6) st->lastb[t] = s_sys[t * 7 - (t * (t - 1)) / 2 + (6 - t)];
+        }
+        return;
+    }
     if (threadIdx.x != 0) return;
-    // ---- serial part on one lane.  Every input is read once into registers and every output is
-    // stored once at the end: a store to DevState followed by a load of the same field costs a full
-    // memory round trip on a lone lane (the first version did that five times per solve).
-    float oi[29], orr[29];
-#pragma unroll
-    for (int k = 0; k < 29; k++) { oi[k] = icp ? (float)s_icp[k] : 0.f; orr[k] = rgb ? (float)s_rgb[k] : 0.f; }
-    const int rgbSize = rgb ? s_res[0] : 0, sigma = rgb ? s_res[1] : 0;
+    // ---- serial part on one lane.  Every input is in registers or LDS and every output is stored once at the end.
     double lA[36], lb[6];
     {
-        const double wgt = icp_weight;
-        const double wa = (icp && rgb) ? wgt * wgt : (icp ? 1.0 : 0.0), wb = (icp && rgb) ? wgt : (icp ? 1.0 : 0.0), wr = rgb ? 1.0 : 0.0;
         int shift = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = i; j < 7; ++j) {
-                // lastA = A_rgb + w*w*A_icp, lastb = b_rgb + w*b_icp (EF/Utils/RGBDOdometry.cpp:547-565)
-                const double vi = (double)oi[shift], vr = (double)orr[shift];
-                shift++;
-                if (j == 6) lb[i] = (icp && rgb) ? vr + wb * vi : (icp ? vi : vr);
-                else { const double v = (icp && rgb) ? vr + wa * vi : (icp ? vi : vr); lA[j * 6 + i] = v; lA[i * 6 + j] = v; }
+                const double v = s_sys[shift++];
+                if (j == 6) lb[i] = v;
+                else { lA[j * 6 + i] = v; lA[i * 6 + j] = v; }
             }
-        (void)wr;
     }
-    // diagnostics first: nothing below needs the 58 sums or a second copy of the system any more
-    // (keeping them live across the solve cost ~130 registers)
-    if (final_iter) {   // lastA / lastb / the 2 x 29 sums describe the run's LAST iteration (getCovariance, diagnostics): 130 scalar stores the others skip
-#pragma unroll
-        for (int k = 0; k < 29; k++) { st->icp29[k] = oi[k]; st->rgb29[k] = orr[k]; }
-#pragma unroll
-        for (int k = 0; k < 36; k++) st->lastA[k] = lA[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) st->lastb[k] = lb[k];
-    }
-    st->rgb_count = rgbSize; st->rgb_sigma = sigma;
-    st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
-    st->lastRGBCount = (float)rgbSize;
-    if (icp) { st->lastICPError = sqrtf(oi[27]) / oi[28]; st->lastICPCount = oi[28]; }
     double result[6];
     // With the ICP term the system is well conditioned and the unpivoted factorisation agrees with Eigen's pivoted LDLT to
     // ~1e-7 in the pose; the photometric term alone can be close to singular along unobservable directions, where the
@@ -1410,7 +1451,7 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
         tc[r] = Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2] + tp[r];
     }
     float krk[9], kt[3];
-    warp_from(RRt, nfx, nfy, ncx, ncy, krk, kt);   // intrinsics of the level the NEXT iteration runs at
+    warp_from_k(RRt, nfx, nfy, ncx, ncy, ki, krk, kt);   // intrinsics of the level the NEXT iteration runs at
     // ---- stores
 #pragma unroll
     for (int k = 0; k < 16; k++) st->resultRt[k] = RRt[k];
@@ -1437,13 +1478,9 @@ struct StepArgs {
     float fx, fy, sobelScale;
     const int16_t *dIdx, *dIdy;
     int w, h, nb, nb_icp, nb_res;
-    double* rgb_acc;
-    double* icp_acc;
-    const int* res_partials;
-    int* res_total;
     int icp, rgb;
     float icp_weight, nfx, nfy, ncx, ncy;
-    unsigned int* ticket;
+    KInv ki;   // K^-1 of (nfx, nfy, ncx, ncy)
     int check_skip;
     int final_iter;   // last Gauss-Newton iteration of the run: leaves lastA / lastb / the sums in DevState
     int end_run, commit;   // ... and ends the run in the same lane (track_end_dev)
@@ -1451,20 +1488,18 @@ struct StepArgs {
     unsigned int* lctr;
 };
 template <bool CHECK_SKIP>
-__global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, StepArgs a)
+__global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, int nb, int rgb, int w, int h, StepArgs a)
 {
     __builtin_assume(st != nullptr);
-    // the words the reduction body needs, and the residual totals behind the (preloaded) state pointer, in one scalar round trip
-    asm volatile("" ::"s"(a.corres), "s"(a.cloud), "s"(a.dIdx), "s"(a.dIdy), "s"(a.rgb_acc), "s"(a.icp_acc), "s"(a.fx), "s"(a.fy), "s"(a.sobelScale), "s"(a.w), "s"(a.h),
-                 "s"(a.nb), "s"(a.rgb), "s"(a.icp));
     if (CHECK_SKIP && st->skip) return;   // (model-to-model instance only) uniform over the grid: the last-block ticket stays armed
-    int* const res_total = st->gn_res;
+    int* const res_total = st->gn_res;   // hand-off words and accumulator rows: behind the state pointer, which arrives preloaded
     unsigned int* const ticket = &st->gn_ticket;
+    double* const icp_acc = st->gn_acc, * const rgb_acc = st->gn_acc + IFX_ACC_REPL * IFX_ACC_STRIDE;
     __shared__ int s_last;
 #ifdef IFX_STAMPS
     long long t0 = clock64();
 #endif
-    if (a.rgb) rgb_step_body(blockIdx.x, a.nb, a.corres, 0.f, a.res_partials, a.nb_res, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, a.rgb_acc, res_total);
+    if (rgb) rgb_step_body(blockIdx.x, nb, a.corres, 0.f, nullptr, 0, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, w, h, rgb_acc, res_total);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef IFX_STAMPS
@@ -1472,7 +1507,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
 #endif
     if (threadIdx.x == 0) {   // this block's atomic adds were performed at the memory side: every wave drained vmcnt before the barrier
         unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned int)(a.nb - 1));
+        s_last = (t == (unsigned int)(nb - 1));
     }
     __syncthreads();
     if (!s_last) return;
@@ -1483,7 +1518,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, St
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, a.icp_acc, a.rgb_acc, a.res_partials, a.nb_res, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
+    gn_solve_block(st, icp_acc, rgb_acc, nullptr, 0, a.icp, rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.ki, res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
@@ -1581,7 +1616,7 @@ static inline int red_blocks(ifx* h, int n, int it = RED_IT)
     int b = cdiv(n, RED_THREADS * it);
     // cap on the blocks of a reduction launch (their partial rows are summed by the last block): 304 at 640x480 (one 1024-pixel chunk per block at
     // level 0, flat beyond), one block per 2048 pixels on larger images (1280x960: 608 blocks, tracker 1.33 -> 1.18 ms)
-    const int cap = h->opt_icp_blocks > 0 ? h->opt_icp_blocks : std::max(304, std::min(1024, h->P / 2048));
+    const int cap = h->opt_icp_blocks > 0 ? h->opt_icp_blocks : std::max(456, std::min(1024, h->P / 2048));
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return b;
@@ -1709,21 +1744,22 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         // The residual half of the launch is the slower one and scales with its blocks (its totals go through integer atomics, it has no partial rows for the
         // last block to sum): one pixel per thread, no loop -- 152 blocks 17.5 us, 304 blocks 13.3 us, 1200 blocks 11.3 us per launch at 640x480 (1053 -> 1102 frames/s).
         const bool lds_tiles = h->opt_icp_lds && i == 0 && frame_tracker;
-        const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
+        const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : (1 << 30));
         pa.lds_tiles = lds_tiles ? 1 : 0;
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
-        pa.icp_acc = p.acc; pa.res_partials = p.res_partials; pa.res_total = (int*)((char*)st + offsetof(DevState, gn_res)); pa.check_skip = frame_tracker ? 0 : 1;
+        double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
+        int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
+        pa.check_skip = frame_tracker ? 0 : 1;   // (accumulator rows, residual totals, ticket: DevState::gn_acc / gn_res / gn_ticket of `st`)
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
-            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
-            else if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, pa);
-            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, pa);
+            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            else if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
+            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nbi; sa2.nb_res = nbr;
-            sa2.rgb_acc = p.acc + IFX_ACC_REPL * IFX_ACC_STRIDE; sa2.icp_acc = p.acc; sa2.res_partials = p.res_partials;
-            sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd;
-            sa2.ticket = nullptr; sa2.res_total = nullptr; sa2.check_skip = frame_tracker ? 0 : 1;   // (hand-off words: DevState::gn_ticket / gn_res)
+            sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd; sa2.ki = kinv_of(sa2.nfx, sa2.nfy, sa2.ncx, sa2.ncy);
+            sa2.check_skip = frame_tracker ? 0 : 1;
             {   // is this the run's last iteration?  (no level below this one iterates)
                 bool later = false;
                 for (int q = i - 1; q >= 0; q--) later = later || iterations[q] > 0;
@@ -1731,8 +1767,8 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             }
             sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
             ended = ended || sa2.end_run;
-            if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2);
-            else LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2);
+            if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
+            else LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
         }
     }
     if (!ended)   // (no iteration ran at all: every level has zero iterations)

@@ -235,6 +235,9 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
+    else if (s == "view_blocks") h->opt_view_blocks = std::max(0, std::min(65536, value));
+    else if (s == "clean_blocks") h->opt_clean_blocks = std::max(0, std::min(65536, value));
+    else if (s == "index_blocks") h->opt_index_blocks = std::max(0, std::min(8192, value));
     else if (s == "res_blocks") h->opt_res_blocks = std::max(0, std::min(4096, value));
     else if (s == "icp_lds") h->opt_icp_lds = value;
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));

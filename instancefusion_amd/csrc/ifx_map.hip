@@ -1260,16 +1260,34 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     const unsigned int n = st->vl_n[0];
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += blockDim.x * gridDim.x) {
-        const unsigned int i = list[t];
-        const float lastT = tm[i].y;
-        if ((float)time - lastT > (float)c.timeDelta) continue;   // inactive or tombstone
-        const float4 p4 = pc[i];
-        const v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
-        if (p.z > c.maxDepth || p.z < 0) continue;
-        const float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
-        if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
-        key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, i));
+    // Two entries per thread and round, every load of a stage issued before the first use: list entries, then times AND positions (a position is
+    // fetched even when the time test will reject the entry -- in the time-window list that is the rare case), then the atomics.  One entry at a
+    // time with the early exits in front of each load was three dependent round trips per entry and two rounds per thread.
+#ifndef INDEX_U
+#define INDEX_U 1
+#endif
+    constexpr int U = INDEX_U;
+    const unsigned int stride = blockDim.x * gridDim.x;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += U * stride) {
+        unsigned int i[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const unsigned int tt = t + u * stride; in[u] = tt < n; i[u] = list[in[u] ? tt : t]; }
+        float lastT[U];
+        float4 p4[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { lastT[u] = tm[i[u]].y; p4[u] = pc[i[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" ::"v"(lastT[u]), "v"(p4[u].x), "v"(p4[u].y), "v"(p4[u].z));   // (keeps the compiler from sinking a load behind the previous entry's branches)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!in[u] || (float)time - lastT[u] > (float)c.timeDelta) continue;   // inactive or tombstone
+            const v3 p = xf_point(T, v3m(p4[u].x, p4[u].y, p4[u].z));
+            if (p.z > c.maxDepth || p.z < 0) continue;
+            const float uu = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+            if (!(uu >= 0 && uu < (float)c.w && v >= 0 && v < (float)c.h)) continue;
+            key_min(&keys[(int)floorf(v) * c.w + (int)floorf(uu)], make_key(p.z, i[u]));
+        }
     }
 }
 
@@ -1297,9 +1315,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
         if (t < n) {
             i = seg_list[t];
             const float2 tt = tm[i];
+            const float4 p4 = pc[i];   // (fetched with the times: in the time-window list nearly every entry needs it, and behind the test it was a third dependent round trip)
+            asm volatile("" ::"v"(tt.y), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             const float wv = tt.y;
             if (wv > DEAD_TIME && !(wv > 0.f && (float)time - wv > (float)c.timeDelta)) {   // live and not exempt by the time window
-                const float4 p4 = pc[i];
                 if (!((float)time - wv > (float)c.timeDelta)) {
                     const v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
                     if (p.z > 0.f) {
@@ -1405,9 +1424,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         if (t < n) {
             const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
             const float4 p4 = pc[i];
+            const float lastT = tm[i].y;   // (with the position: one round trip for both)
+            asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             unsigned int flags = 0;
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
-                const float lastT = tm[i].y;
                 const v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
                 if (q.z > 0.f && may_touch_image(reach, q, c)) {
                     if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) flags |= LIST_IDS;
@@ -2095,7 +2115,7 @@ static void index_list_pass(ifx* h, int time, bool taps)
 {
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
-    LAUNCH(h, "index_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
+    LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
     if (!taps)
         LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
                (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr, c);
@@ -2116,7 +2136,7 @@ int ifx_map_frame(ifx* h)
         index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
         fuse_pass(h, nullptr, 0.f, time);
         index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
-        LAUNCH(h, "clean_view", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+        LAUNCH(h, "clean_view", dim3(h->opt_clean_blocks > 0 ? h->opt_clean_blocks : 2 * LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
                (const float4*)h->index_tap, h->list_v);
         const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
         LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
@@ -2174,7 +2194,7 @@ int ifx_map_predict(ifx* h)
     if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
-        LAUNCH(h, "raster_view", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+        LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
                want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
     } else

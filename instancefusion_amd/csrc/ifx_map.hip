@@ -1587,16 +1587,51 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
         float weighting = pose_ex ? weighting_ex : st->weighting;
         float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
         float x = (float)i + 0.5f, y = (float)j + 0.5f;
-        v3 vl = get_vertex_f(dm, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
-        bool nb = !(tex_f(dm, c.w, c.h, i - 1, j) == 0 || tex_f(dm, c.w, c.h, i, j - 1) == 0 || tex_f(dm, c.w, c.h, i + 1, j) == 0 || tex_f(dm, c.w, c.h, i, j + 1) == 0);
+        // Every load of the pixel is issued up front -- the raw and filtered depth crosses, the colour, the index-map window -- and the reference's
+        // tests then run on registers in the reference's order.  (Written test by test, each load sat behind the previous test's branch: up to
+        // ~30 dependent round trips for a launch of only 300 blocks, 24 us.)
+        // The window: offsets {-1, -0.5, 0, 0.5} around a pixel centre floor to {i-1, i, i, i+1}: 3 x 3 distinct texels, visited 16 times.  A repeated
+        // visit never changes the running best (dist < bestDist is strict), so the nine first visits in the original (a, b) order decide.
+        const int xs[3] = {clampi((int)floorf(x - 1.0f), 0, c.w - 1), clampi((int)floorf(x - 0.5f), 0, c.w - 1), clampi((int)floorf(x + 0.5f), 0, c.w - 1)};
+        const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};
+        uint32_t cur[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) cur[a * 3 + b] = index_id[ys[b] * c.w + xs[a]];
+        const float d_c = tex_f(dm, c.w, c.h, i, j), d_l = tex_f(dm, c.w, c.h, i - 1, j), d_u = tex_f(dm, c.w, c.h, i, j - 1), d_r = tex_f(dm, c.w, c.h, i + 1, j),
+                    d_d = tex_f(dm, c.w, c.h, i, j + 1);
+        const float f_c = tex_f(dmf, c.w, c.h, i, j), f_l = tex_f(dmf, c.w, c.h, i - 1, j), f_u = tex_f(dmf, c.w, c.h, i, j - 1), f_r = tex_f(dmf, c.w, c.h, i + 1, j),
+                    f_d = tex_f(dmf, c.w, c.h, i, j + 1);
+        const uint8_t* cc = &rgb[k * 3];
+        const uint8_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
+        float4 vcs[9], nrs[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {   // the records of all nine texels, occupied or not (an empty texel's record is never looked at): no branch around a load
+            const int a = q / 3, b = q - 3 * a;
+            const int kk = ys[b] * c.w + xs[a];
+            vcs[q] = index_vc[kk];
+            nrs[q] = index_nr[kk];
+        }
+        asm volatile("" ::"v"(d_c), "v"(d_l), "v"(d_u), "v"(d_r), "v"(d_d), "v"(f_c), "v"(f_l), "v"(f_u), "v"(f_r), "v"(f_d), "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(cur[4]),
+                     "v"(cur[5]), "v"(cur[6]), "v"(cur[7]), "v"(cur[8]));
+        asm volatile("" ::"v"(vcs[0].x), "v"(vcs[1].x), "v"(vcs[2].x), "v"(vcs[3].x), "v"(vcs[4].x), "v"(vcs[5].x), "v"(vcs[6].x), "v"(vcs[7].x), "v"(vcs[8].x), "v"(nrs[0].x),
+                     "v"(nrs[1].x), "v"(nrs[2].x), "v"(nrs[3].x), "v"(nrs[4].x), "v"(nrs[5].x), "v"(nrs[6].x), "v"(nrs[7].x), "v"(nrs[8].x));   // (all 18 in flight before the first test)
+        v3 vl = v3m((x - c.cx) * d_c * ifx_, (y - c.cy) * d_c * ify_, d_c);
+        bool nb = !(d_l == 0 || d_u == 0 || d_r == 0 || d_d == 0);
         if (nb && vl.z > 0 && vl.z <= c.maxDepth) {
             v3 vg = xf_point(pose, vl);
-            v3 vf = get_vertex_f(dmf, c.w, c.h, i, j, x, y, c.cx, c.cy, ifx_, ify_);
-            v3 nl = get_normal_f(dmf, c.w, c.h, i, j, x, y, vf, c.cx, c.cy, ifx_, ify_);
+            v3 vf = v3m((x - c.cx) * f_c * ifx_, (y - c.cy) * f_c * ify_, f_c);
+            v3 nl;
+            {   // get_normal_f on the taps already in registers
+                const v3 xf = v3m((x + 1 - c.cx) * f_r * ifx_, (y - c.cy) * f_r * ify_, f_r), xb = v3m((x - 1 - c.cx) * f_l * ifx_, (y - c.cy) * f_l * ify_, f_l);
+                const v3 yf = v3m((x - c.cx) * f_d * ifx_, (y + 1 - c.cy) * f_d * ify_, f_d), yb = v3m((x - c.cx) * f_u * ifx_, (y - 1 - c.cy) * f_u * ify_, f_u);
+                const v3 del_x = ((xb + vf) * 0.5f) - ((xf + vf) * 0.5f), del_y = ((yb + vf) * 0.5f) - ((yf + vf) * 0.5f);
+                nl = normalized(cross(del_x, del_y));
+            }
             v3 ng = xf_dir(pose, nl);
             mpc[k] = make_float4(vg.x, vg.y, vg.z, confidence_fn(x, y, c.cx, c.cy, weighting));
-            const uint8_t* cc = &rgb[k * 3];
-            mcol[k] = encode_color(cc[0] / 255.0f, cc[1] / 255.0f, cc[2] / 255.0f);
+            mcol[k] = encode_color(c0 / 255.0f, c1 / 255.0f, c2 / 255.0f);
             mnr[k] = make_float4(ng.x, ng.y, ng.z, get_radius(vf.z, nl.z, ifx_, ify_));
             float xl = (x - c.cx) * ifx_, yl = (y - c.cy) * ify_;
             float lambda = sqrtf(xl * xl + yl * yl + 1);
@@ -1605,23 +1640,19 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
             float bestDist = 1000;
             uint32_t best = 0;
             int counter = 0;
-            const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
-            for (int a = 0; a < 4; a++)
-                for (int b = 0; b < 4; b++) {
-                    int tx = clampi((int)floorf(x + offs[a]), 0, c.w - 1), ty = clampi((int)floorf(y + offs[b]), 0, c.h - 1);
-                    int kk = ty * c.w + tx;
-                    uint32_t cur = index_id[kk];
-                    if (cur > 0u) {
-                        float4 vc = index_vc[kk];
-                        if (fabsf((vc.z * lambda) - (vl.z * lambda)) < 0.05f) {
-                            float dist = norm(cross(ray, v3m(vc.x, vc.y, vc.z))) / rayLen;
-                            float4 nrm = index_nr[kk];
-                            v3 nn = v3m(nrm.x, nrm.y, nrm.z);
-                            float cang = dot(nn, nl) / (norm(nn) * norm(nl));
-                            if (dist < bestDist && (fabsf(nrm.z) < 0.75f || cang > 0.87758256189f)) { counter++; bestDist = dist; best = cur; }
-                        }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                if (cur[q] > 0u) {
+                    const float4 vc = vcs[q];
+                    if (fabsf((vc.z * lambda) - (vl.z * lambda)) < 0.05f) {
+                        float dist = norm(cross(ray, v3m(vc.x, vc.y, vc.z))) / rayLen;
+                        const float4 nrm = nrs[q];
+                        v3 nn = v3m(nrm.x, nrm.y, nrm.z);
+                        float cang = dot(nn, nl) / (norm(nn) * norm(nl));
+                        if (dist < bestDist && (fabsf(nrm.z) < 0.75f || cang > 0.87758256189f)) { counter++; bestDist = dist; best = cur[q]; }
                     }
                 }
+            }
             if (counter > 0) {
                 res = best;
                 const int lb = local_slot(c, st->count, best);
@@ -1645,11 +1676,15 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     const int li = local_slot(c, st->count, gid);   // sharded map: -1 = another rank's surfel (that rank applies the update)
     if (li < 0 || li >= st->count) return;
     const uint32_t id = (uint32_t)li;
-    if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
-    upd_owner[id] = 0xFFFFFFFFu;
+    // the surfel's record and the measurement are fetched together with the ownership word (a pixel that turns out not to own the surfel -- the rare
+    // case -- has read 80 bytes in vain; behind the test the records were one more dependent round trip for every pixel)
+    const uint32_t owner = upd_owner[id];
     float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
-    const float2 cl0 = col[id], t0_ = tm[id];   // issued with the other loads (they used to follow them: two more dependent round trips)
+    const float2 cl0 = col[id], t0_ = tm[id];
     const float mc = mcol[k];
+    asm volatile("" ::"v"(owner), "v"(p.x), "v"(n.x), "v"(mp.x), "v"(mn.x), "v"(cl0.x), "v"(t0_.x), "v"(mc));
+    if (owner != (uint32_t)(i * c.h + j)) return;
+    upd_owner[id] = 0xFFFFFFFFu;
     float c_k = p.w, a = mp.w;
     if (mn.w < (1.0f + 0.5f) * n.w) {
         p.x = ((c_k * p.x) + (a * mp.x)) / (c_k + a);

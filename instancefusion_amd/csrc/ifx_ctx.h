@@ -182,6 +182,7 @@ struct ifx {
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
+    int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
     int opt_view_blocks = 0, opt_clean_blocks = 0, opt_index_blocks = 0;   // grids of the view-list kernels (0: LIST_BLOCKS)
     int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)
     int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)

@@ -1400,16 +1400,29 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
 // at ANY earlier time cannot win (keys only decrease during the pass), so the atomic is dropped -- with ~17 discs over
 // every pixel of the benchmark map most of them lose.
 struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; int x0, y0, bw, excl; int s01, s23, i01, i23; };
+// LDSMIN: the depth test of a wave's 64 surfels is first played out in LDS.  The entries of a wave are neighbours in creation order, i.e. (mostly)
+// neighbouring pixels of the frame that created them, so their discs overlap each other: ~3 candidates per touched pixel inside one wave.  A
+// wave-private direct-mapped table (16 x 16 pixel window x 2 targets, tag = pixel and target image) takes the minimum per pixel with LDS atomics;
+// a candidate whose slot holds another pixel goes to global memory as before; after the walk the occupied slots are flushed with one global
+// atomic each.  min is order-independent: the images are bit-identical.
+#define RV_SLOTS 512
+template <bool LDSMIN>
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
                                                              int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
                                                              unsigned long long* __restrict__ key_both, int earlyz)
 {
     __shared__ RvRec recs[MAP_THREADS / 64][64];
+    __shared__ unsigned int s_tag[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
+    __shared__ unsigned long long s_key[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (LDSMIN) {
+#pragma unroll
+        for (int q = 0; q < RV_SLOTS / 64; q++) { s_tag[wid][q * 64 + lane] = 0u; s_key[wid][q * 64 + lane] = ~0ull; }
+    }
     // the two view lists, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
     const unsigned int na = st->vl_n[0], n = na + ((want & LIST_IDS) ? st->vl_n[1] : 0u);
     const unsigned int* __restrict__ seg_a = list_a;
@@ -1493,10 +1506,30 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             const bool in_s = px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
             const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
             if (!in_s && !in_i) continue;
-            unsigned long long* addr = (in_s && in_i ? key_both : (in_s ? key_splat : key_ids)) + (py * c.w + px);
+            const int tsel = in_s && in_i ? 0 : (in_s ? 1 : 2);
+            unsigned long long* addr = (tsel == 0 ? key_both : (tsel == 1 ? key_splat : key_ids)) + (py * c.w + px);
             const unsigned long long key = make_key(z, id);
+            if (LDSMIN) {
+                const unsigned int tag = ((unsigned int)(py * c.w + px) << 2 | (unsigned int)tsel) + 1u;
+                const int slot = ((py & 15) << 5) | ((px & 15) << 1) | (tsel != 0);
+                const unsigned int old = atomicCAS(&s_tag[wid][slot], 0u, tag);
+                if (old == 0u || old == tag) { atomicMin(&s_key[wid][slot], key); continue; }
+            }
             if (earlyz && !(key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) continue;
             key_min(addr, key);
+        }
+        if (LDSMIN) {   // flush: one global atomic per touched (pixel, target); the table is left empty for the next round
+#pragma unroll
+            for (int q = 0; q < RV_SLOTS / 64; q++) {
+                const int sl = q * 64 + lane;
+                const unsigned int tag = s_tag[wid][sl];
+                if (tag) {
+                    const unsigned long long key = s_key[wid][sl];
+                    const unsigned int pt = tag - 1u, tsel = pt & 3u, pix = pt >> 2;
+                    key_min((tsel == 0 ? key_both : (tsel == 1 ? key_splat : key_ids)) + pix, key);
+                    s_tag[wid][sl] = 0u; s_key[wid][sl] = ~0ull;
+                }
+            }
         }
     }
 }
@@ -2229,8 +2262,12 @@ int ifx_map_predict(ifx* h)
     if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
-        LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-               want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+        if (h->opt_raster_lds)
+            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<true>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+        else
+            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
     } else
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);

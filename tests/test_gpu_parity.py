@@ -616,8 +616,8 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world):
     one.close()
 
 
-@pytest.mark.parametrize("earlyz", [1, 0])
-def test_view_list_path_equals_per_pass_culls(ifx, earlyz):
+@pytest.mark.parametrize("earlyz,lds", [(1, 0), (0, 0), (0, 1)])
+def test_view_list_path_equals_per_pass_culls(ifx, earlyz, lds):
     """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,
     flattened rasteriser, early-z) against the round-1 path (three culls over all slots per frame): poses, maps, id images and
     labels bit for bit, over enough frames for several list rebuilds, appended surfels, deletions and a lazy compaction."""
@@ -633,6 +633,7 @@ def test_view_list_path_equals_per_pass_culls(ifx, earlyz):
         g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_600_000, **K)
         g.set_option("view_list", view)
         g.set_option("raster_earlyz", earlyz)
+        g.set_option("raster_lds", lds)                # per-wave depth test in LDS in front of the global atomics
         g.set_option("compact_divisor", 64)            # a lazy compaction inside the run
         g.processFrame(st["rgb"][0], st["depth"][0])
         g.upload(big); g.set_pose(st["poses"][0], 1000); g.combined_predict(st["poses"][0], 1000, 1000)

@@ -699,6 +699,18 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
     const int N = w * h;
     // stage 1 loads are issued before the sigma reduction so that both latencies overlap
     const int base0 = bid * (RED_THREADS * RED_IT_RGB) + threadIdx.x;
+    // first round's records and gradients: requested before sigma is worked out, so that both latencies overlap
+    Corres8 c[RED_IT_RGB];
+    short gx[RED_IT_RGB], gy[RED_IT_RGB];
+#pragma unroll
+    for (int u = 0; u < RED_IT_RGB; u++) {
+        const int k = base0 + u * RED_THREADS;
+        const bool in = k < N;
+        const int kk = in ? k : 0;
+        c[u] = corres[kk];
+        gx[u] = dIdx[kk]; gy[u] = dIdy[kk];
+        if (!in) c[u].zx = -1;
+    }
     float sigma = sigma_explicit;
     if (res_total) {
         int cnt = res_total[0], sg = res_total[1];
@@ -730,23 +742,25 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
     double acc[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) acc[k] = 0.0;
-    for (int base = base0; base < N; base += nblk * RED_THREADS * RED_IT_RGB) {
-        Corres8 c[RED_IT_RGB];
+    // software-pipelined like the ICP rounds: the records and gradients of the NEXT round are requested right behind this round's cloud gathers
+    const int stride = nblk * RED_THREADS * RED_IT_RGB;
+    for (int base = base0; base < N; base += stride) {
         float X[RED_IT_RGB], Y[RED_IT_RGB], Z[RED_IT_RGB];
-        short gx[RED_IT_RGB], gy[RED_IT_RGB];
-#pragma unroll
-        for (int u = 0; u < RED_IT_RGB; u++) {
-            int k = base + u * RED_THREADS;
-            bool in = k < N;
-            int kk = in ? k : 0;
-            c[u] = corres[kk];
-            gx[u] = dIdx[kk]; gy[u] = dIdy[kk];
-            if (!in) c[u].zx = -1;
-        }
 #pragma unroll
         for (int u = 0; u < RED_IT_RGB; u++) {
             int g = (c[u].zx >= 0) ? ((int)c[u].zy * w + (int)c[u].zx) * 3 : 0;
             X[u] = cloud[g]; Y[u] = cloud[g + 1]; Z[u] = cloud[g + 2];
+        }
+        Corres8 cn[RED_IT_RGB];
+        short gxn[RED_IT_RGB], gyn[RED_IT_RGB];
+#pragma unroll
+        for (int u = 0; u < RED_IT_RGB; u++) {   // (a thread past its last round reads record 0 and drops it: no branch around the loads)
+            const int k = base + stride + u * RED_THREADS;
+            const bool in = k < N;
+            const int kk = in ? k : 0;
+            cn[u] = corres[kk];
+            gxn[u] = dIdx[kk]; gyn[u] = dIdy[kk];
+            if (!in) cn[u].zx = -1;
         }
 #pragma unroll
         for (int u = 0; u < RED_IT_RGB; u++) {
@@ -770,6 +784,8 @@ __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* 
             }
             products7<1>(row, found, acc);
         }
+#pragma unroll
+        for (int u = 0; u < RED_IT_RGB; u++) { c[u] = cn[u]; gx[u] = gxn[u]; gy[u] = gyn[u]; }
     }
 #ifdef IFX_STAMPS
     g_ts[1] = clock64();

@@ -43,6 +43,9 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
         "index_project": n_slots * (8.0 + 16.0 * active_fraction),
         "count_colour": n_slots * (192.0 + 8 + 8 + 4),
         # tracker: per-pixel passes, averaged over the pyramid levels a launch can run at
+        # persistent level kernel, averaged over the three levels: per pixel 39 B of frame-side constants once (vertex + normal 24, depth 4, intensity 1 + 4x4 window ~4 after
+        # reuse, gradients 4) + per iteration 41 B of gathers (model vertex + normal 24, depth 4, intensity 1, cloud point 12); iterations 10 / 5 / 4 on P, P/4, P/16
+        "gn_level": P * ((1 + 0.25 + 0.0625) * 39.0 + (10 + 5 * 0.25 + 4 * 0.0625) * 41.0) / 3.0,
         "icp_residual": P * LEVEL_AVG * (48.0 + 22.0),     # ICP 24 B coalesced + 24 B gathered; residual 14 B read + 8 B written
         "rgb_step_solve": P * LEVEL_AVG * 24.0,            # 8-B record + 4 B gradients + 12 B gathered cloud point
         "bilateral_metric": P * (2.0 + 2 + 4 + 4),
@@ -268,7 +271,7 @@ def main():
         for _ in range(n_kt):
             step(k); k += 1
         ef.sync()
-        names = ["icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "associate",
+        names = ["gn_level", "icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "associate",
                  "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
         # k_cull_frame is launched every frame and decides ON THE DEVICE whether the cached view list is still valid; a launch that finds it
         # valid returns at once.  Its algorithmic bytes are therefore the scan's bytes x (scans / launches) of this window.

@@ -71,6 +71,11 @@ struct DevState {
     unsigned int gn_ticket;      // last-block ticket of k_rgb_step_solve
     int gn_pad[13];
     double gn_acc[2 * IFX_ACC_REPL * IFX_ACC_STRIDE];   // exact accumulator rows of the iteration in flight: [0] ICP, [1] photometric (layout of block_sum_exact)
+    // persistent level kernel (k_gn_level): accumulator rows and residual totals double-buffered by iteration parity, one grid-barrier word per pyramid level
+    double gn_acc2[2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE];   // [parity][ICP | photometric]
+    alignas(64) int gn_res2[2 * 16];                          // [parity] (count, sigma), a line each
+    alignas(64) unsigned int gn_bar[4 * 32 * 16];             // [level][32 sub-counters] arrivals, a line each (gn_grid_barrier)
+    int gn_timeout;                                           // a grid barrier gave up (never in a healthy run; tests assert 0)
 };
 
 struct FrameResult {   // copied to pinned host memory at the end of every frame
@@ -180,6 +185,8 @@ struct ifx {
     int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
+    int opt_gn_persist = 0;          // all Gauss-Newton iterations of a pyramid level in one persistent launch (k_gn_level) when its grid fits the GPU; measured slower: off
+    int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)

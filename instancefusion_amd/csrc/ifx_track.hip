@@ -1107,6 +1107,10 @@ __device__ void set_so3_matrices(DevState* st, float fx, float fy, float cx, flo
 // Gauss-Newton loop from the SO(3) result held in the slot's shadow state (:392-403)
 __global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last)
 {
+    // hand-off words of the persistent level kernels: both parities of the accumulator rows and residual totals, the barrier words
+    for (int k = threadIdx.x; k < 2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE; k += blockDim.x) st->gn_acc2[k] = 0.0;
+    if (threadIdx.x < 32) st->gn_res2[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < 4 * 32 * 16; k += blockDim.x) st->gn_bar[k] = 0u;
     if (threadIdx.x != 0) return;
     if (!keep_last) for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];   // bootstrap: lastPose is the pose before the guess was applied (k_bootstrap_pose)
     for (int r = 0; r < 3; r++) {
@@ -1323,6 +1327,72 @@ __device__ __forceinline__ void warp_from_k(const double* M, float fx, float fy,
     kt[2] = (float)tt[2];
 }
 
+// The serial lane of one Gauss-Newton iteration: the combined 6x6 system (27 doubles in LDS, layout of the reference's 29-vector) -> LDLT -> SE(3)
+// update of resultRt (RRt, in/out) -> current pose (Rc, tc) and the warp matrices of the next residual pass (krk, kt).
+// EF/Utils/RGBDOdometry.cpp:552-583, OdometryProvider.h:73-93.  Shared by the two-launch form (gn_solve_block) and the persistent level kernel.
+__device__ __forceinline__ void gn_serial_lane(const double* s_sys, int icp, double* RRt, const float* Rp, const float* tp, float nfx, float nfy, float ncx, float ncy, const KInv& ki,
+                                               float* Rc, float* tc, float* krk, float* kt)
+{
+    double lA[36], lb[6];
+    {
+        int shift = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) {
+                const double v = s_sys[shift++];
+                if (j == 6) lb[i] = v;
+                else { lA[j * 6 + i] = v; lA[i * 6 + j] = v; }
+            }
+    }
+    double result[6];
+    // With the ICP term the system is well conditioned and the unpivoted factorisation agrees with Eigen's pivoted LDLT to
+    // ~1e-7 in the pose; the photometric term alone can be close to singular along unobservable directions, where the
+    // pivoting decides the answer: that configuration takes the pivoted path the reference takes (EF/Utils/RGBDOdometry.cpp:552).
+    if (icp) ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
+    else ldlt_solve_n<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
+    // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
+    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9];
+    rodrigues_d(&result[3], Rr);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) upd[r * 4 + c] = Rr[r * 3 + c];
+    upd[3] = result[0]; upd[7] = result[1]; upd[11] = result[2];
+    {   // upd * RRt for two rigid transforms (last rows 0 0 0 1): the terms a dense 4x4 product would multiply by those zeros are left out
+        double N[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) N[r * 4 + c] = (upd[r * 4] * RRt[c] + upd[r * 4 + 1] * RRt[4 + c]) + upd[r * 4 + 2] * RRt[8 + c];
+            N[r * 4 + 3] = ((upd[r * 4] * RRt[3] + upd[r * 4 + 1] * RRt[7]) + upd[r * 4 + 2] * RRt[11]) + upd[r * 4 + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) RRt[k] = N[k];
+    }
+    float oR[9], ot[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) oR[r * 3 + c] = (float)RRt[r * 4 + c];
+        ot[r] = (float)RRt[r * 4 + 3];
+    }
+    float iR[9], it[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) iR[r * 3 + c] = oR[c * 3 + r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) Rc[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
+        tc[r] = Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2] + tp[r];
+    }
+    warp_from_k(RRt, nfx, nfy, ncx, ncy, ki, krk, kt);   // intrinsics of the level the NEXT iteration runs at
+}
+
 // one Gauss-Newton iteration's host logic, EF/Utils/RGBDOdometry.cpp:461-583, run by the block that finishes last.
 // What is serial -- the 6x6 factorisation, the pose update, the next warp matrices -- runs on lane 0; everything that is not sits on other lanes:
 //   threads 0..28   fetch (and clear) the ICP and photometric total of "their" element, round both to f32 as the reference's reductions deliver
@@ -1409,65 +1479,8 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     }
     if (threadIdx.x != 0) return;
     // ---- serial part on one lane.  Every input is in registers or LDS and every output is stored once at the end.
-    double lA[36], lb[6];
-    {
-        int shift = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 7; ++j) {
-                const double v = s_sys[shift++];
-                if (j == 6) lb[i] = v;
-                else { lA[j * 6 + i] = v; lA[i * 6 + j] = v; }
-            }
-    }
-    double result[6];
-    // With the ICP term the system is well conditioned and the unpivoted factorisation agrees with Eigen's pivoted LDLT to
-    // ~1e-7 in the pose; the photometric term alone can be close to singular along unobservable directions, where the
-    // pivoting decides the answer: that configuration takes the pivoted path the reference takes (EF/Utils/RGBDOdometry.cpp:552).
-    if (icp) ldlt_nopivot<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
-    else ldlt_solve_n<double, 6>(lA, lb, result, 1.0 / DBL_MAX);
-    // computeUpdateSE3, EF/Utils/OdometryProvider.h:73-93
-    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9];
-    rodrigues_d(&result[3], Rr);
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) upd[r * 4 + c] = Rr[r * 3 + c];
-    upd[3] = result[0]; upd[7] = result[1]; upd[11] = result[2];
-    {   // upd * RRt for two rigid transforms (last rows 0 0 0 1): the terms a dense 4x4 product would multiply by those zeros are left out
-        double N[12];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) N[r * 4 + c] = (upd[r * 4] * RRt[c] + upd[r * 4 + 1] * RRt[4 + c]) + upd[r * 4 + 2] * RRt[8 + c];
-            N[r * 4 + 3] = ((upd[r * 4] * RRt[3] + upd[r * 4 + 1] * RRt[7]) + upd[r * 4 + 2] * RRt[11]) + upd[r * 4 + 3];
-        }
-#pragma unroll
-        for (int k = 0; k < 12; k++) RRt[k] = N[k];
-    }
-    float oR[9], ot[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) oR[r * 3 + c] = (float)RRt[r * 4 + c];
-        ot[r] = (float)RRt[r * 4 + 3];
-    }
-    float iR[9], it[3], Rc[9], tc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) iR[r * 3 + c] = oR[c * 3 + r];
-#pragma unroll
-    for (int r = 0; r < 3; r++) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) Rc[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
-        tc[r] = Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2] + tp[r];
-    }
-    float krk[9], kt[3];
-    warp_from_k(RRt, nfx, nfy, ncx, ncy, ki, krk, kt);   // intrinsics of the level the NEXT iteration runs at
+    float Rc[9], tc[3], krk[9], kt[3];
+    gn_serial_lane(s_sys, icp, RRt, Rp, tp, nfx, nfy, ncx, ncy, ki, Rc, tc, krk, kt);
     // ---- stores
 #pragma unroll
     for (int k = 0; k < 16; k++) st->resultRt[k] = RRt[k];
@@ -1540,6 +1553,304 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
 #endif
 }
 
+
+// ======================================================================= persistent Gauss-Newton level
+// ALL iterations of one pyramid level in ONE launch.  The two-launch form above pays per iteration two launch boundaries, two argument / state
+// prologues, a round trip of the correspondence records through memory and the last block's ticket: ~14 us even at 160 x 120, where the
+// arithmetic is nothing.  Here a thread keeps "its" pixels for the whole level:
+//   * everything that depends only on the frame -- vertex, normal, depth, intensity, gradients, the 4x4 validity test -- is fetched ONCE into
+//     registers; an iteration only gathers from the model maps (one memory round trip: ICP correspondence, residual taps and the point-cloud
+//     entry of the photometric step are all requested together);
+//   * the correspondence record never leaves the thread (the residual pass and the step work on the same pixel);
+//   * the blocks meet at two grid barriers per iteration (after the ICP sums + residual totals, after the photometric sums): one agent-scope
+//     atomic per block and a polling load -- no data crosses blocks except through the exact accumulator rows (memory-side atomics, read back
+//     with agent-scope loads), so no cache write-back / invalidate is needed anywhere;
+//   * every block then solves the 6x6 system itself (the same totals give the same bits): no broadcast of the pose, no third meeting.
+// Accumulator rows and residual totals are double-buffered by iteration parity; block 0 clears a buffer one barrier after its last reader.
+// The grid is sized to be co-resident (ifx_tracker_init queries the occupancy); a barrier that would spin for seconds gives up and raises
+// DevState::gn_timeout instead of hanging the GPU.
+// Same per-pixel arithmetic and the same exact sums as k_icp_residual / k_rgb_step_solve: bit-identical poses (tests/test_gpu_parity.py).
+struct LevelArgs {
+    const float *vmap_curr, *nmap_curr, *vmap_prev, *nmap_prev;
+    const int16_t *dIdx, *dIdy;
+    const float *lastDepth, *nextDepth;
+    const uint8_t *lastImage, *nextImage;
+    const float* cloud;
+    float fx, fy, cx, cy, distThres, angleThres, minScale, maxDepthDelta, sobelScale;
+    int w, h, iters, icp, rgb;
+    float icp_weight;
+    float nfx, nfy, ncx, ncy;     // intrinsics of the level the iteration AFTER this level's last one runs at
+    KInv ki_same, ki_next;
+    int acc_base;                 // iterations of the run before this level (parity of the double buffers continues across levels)
+    int level;                    // barrier word
+    int final_level;              // the run's last level: its last iteration leaves the diagnostics and ends the run
+    int commit;
+    float weight_mult;
+    unsigned int* lctr;
+};
+
+// Grid barrier.  Memory-side atomics on ONE line serialise at ~8 ns each, and so do the polling loads: 400 blocks arriving at and polling one word
+// cost ~12 us per meeting.  Here a block arrives (fire and forget) at one of GN_BAR_SUB counters, each on a line of its own, and wave 0 polls
+// all of them with one vector load (lane s reads counter s): a meeting is one atomic + one or two polling round trips.
+#define GN_BAR_SUB 32
+__device__ __forceinline__ void gn_grid_barrier(unsigned int* bar, int k, int nb, int* timeout)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's accumulator atomics have been performed at the memory side
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(&bar[((int)blockIdx.x % GN_BAR_SUB) * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // sub-counter s is fed by the blocks with bid % GN_BAR_SUB == s
+        const unsigned int mine = lane < GN_BAR_SUB ? (unsigned int)((nb - lane + GN_BAR_SUB - 1) / GN_BAR_SUB) : 0u;
+        const unsigned int target = (unsigned int)k * mine;
+        int spin = 0;
+        for (;;) {
+            const unsigned int v = lane < GN_BAR_SUB ? __hip_atomic_load(&bar[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__all(v >= target)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spin > (1 << 21)) { if (lane == 0) *timeout = 1; break; }
+        }
+    }
+    __syncthreads();
+}
+
+template <int PX>
+__global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArgs a)
+{
+    // (ICP + photometric term, the reference's default: any other weighting takes the two-launch form, which also carries the pivoted solve)
+    constexpr int ICP = 1, RGB = 1;
+    const int N = a.w * a.h, nb = gridDim.x, bid = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_pose[24];      // Rcurr 9, tcurr 3, krkinv 9, kt 3 of the iteration about to run
+    __shared__ double s_RRt[16];
+    __shared__ double s_sys[27];
+    __shared__ float s_oi[29], s_or[29];
+    __shared__ int s_res[2];
+    __shared__ int s_cs[RED_WAVES][2];
+    // ---- state of the run (constant over the level) and the pose the level starts from
+    float Rprev_inv[9], Rp[9], tpv[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rprev_inv[k] = st->Rprev_inv[k]; Rp[k] = st->Rprev[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) tpv[k] = st->tprev[k];
+    const v3 tp = v3m(tpv[0], tpv[1], tpv[2]);
+    if (tid < 9) { s_pose[tid] = st->Rcurr[tid]; s_pose[12 + tid] = st->krkinv[tid]; }
+    if (tid < 3) { s_pose[9 + tid] = st->tcurr[tid]; s_pose[21 + tid] = st->kt[tid]; }
+    if (tid < 16) s_RRt[tid] = st->resultRt[tid];
+    // ---- per-pixel constants: pixel u of a thread is (u * nb + bid) * 256 + tid (coalesced across lanes)
+    v3 vcurr[PX], ncurr[PX];
+    float d1[PX], nif[PX];
+    short gx[PX], gy[PX];
+    bool cand0[PX];
+    int xy[PX];
+    const int border = 16;
+#pragma unroll
+    for (int u = 0; u < PX; u++) {
+        const int p = (u * nb + bid) * RED_THREADS + tid;
+        const bool in = p < N;
+        const int pp = in ? p : 0;
+        const int i = pp / a.w, j0 = pp - i * a.w;
+        xy[u] = (i << 16) | j0;
+        vcurr[u] = v3m(a.vmap_curr[pp], a.vmap_curr[pp + N], a.vmap_curr[pp + 2 * N]);
+        ncurr[u] = v3m(a.nmap_curr[pp], a.nmap_curr[pp + N], a.nmap_curr[pp + 2 * N]);
+        if (!in) vcurr[u].x = qnan_f();
+        // RGBResidual's own-pixel tests (EF/Cuda/reduce.cu:739-790): 16-px border, 4x4 non-zero block, gradient gate, valid depth
+        const bool ok = in && i >= border && i < a.h - border && j0 >= border && j0 < a.w - border && j0 < a.w - 5 && i < a.h - 1;
+        const int ci = ok ? i : 16, cj = ok ? j0 : 16;
+        bool valid = true;
+#pragma unroll
+        for (int q = -2; q < 2; q++) {
+            uint32_t r4;
+            __builtin_memcpy(&r4, a.nextImage + (ci + q) * a.w + cj - 2, 4);
+            valid = valid & (((r4 - 0x01010101u) & ~r4 & 0x80808080u) == 0u);
+        }
+        gx[u] = a.dIdx[pp]; gy[u] = a.dIdy[pp];
+        const float mTwo = (float)((gx[u] * gx[u]) + (gy[u] * gy[u]));
+        d1[u] = a.nextDepth[pp];
+        nif[u] = (float)a.nextImage[pp];
+        cand0[u] = ok & valid & (mTwo >= a.minScale) & !(d1[u] != d1[u]);
+    }
+    __syncthreads();
+    unsigned int* bar = &st->gn_bar[a.level * GN_BAR_SUB * 16];
+    for (int it = 0; it < a.iters; it++) {
+        const int par = (a.acc_base + it) & 1;
+        double* const icp_acc = st->gn_acc2 + (size_t)(par * 2 + 0) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+        double* const rgb_acc = st->gn_acc2 + (size_t)(par * 2 + 1) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+        int* const gres = st->gn_res2 + par * 16;
+        float Rcurr[9], krk[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { Rcurr[k] = s_pose[k]; krk[k] = s_pose[12 + k]; }
+        const v3 tc = v3m(s_pose[9], s_pose[10], s_pose[11]);
+        const float kt0 = s_pose[21], kt1 = s_pose[22], kt2 = s_pose[23];
+        // ---- phase A: projections, then every gather of the iteration in one batch
+        v3 vcurr_g[PX], vprev[PX], nprev[PX];
+        bool inb[PX], cand[PX];
+        int gj[PX];
+        float td1[PX], d0[PX], lif[PX], X[PX], Y[PX], Z[PX];
+#pragma unroll
+        for (int u = 0; u < PX; u++) {
+            // ICPReduction::search, EF/Cuda/reduce.cu:257-300
+            vcurr_g[u] = mulp(Rcurr, vcurr[u]) + tc;
+            const v3 vcurr_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
+            const int ux = f2i_rn(vcurr_cp.x * a.fx / vcurr_cp.z + a.cx);
+            const int uy = f2i_rn(vcurr_cp.y * a.fy / vcurr_cp.z + a.cy);
+            inb[u] = !(vcurr[u].x != vcurr[u].x) && !(ux < 0 || uy < 0 || ux >= a.w || uy >= a.h || vcurr_cp.z < 0);
+            const int j = inb[u] ? uy * a.w + ux : 0;
+            // RGBResidual warp, EF/Cuda/reduce.cu:791-810
+            const int y = xy[u] >> 16, x = xy[u] & 0xFFFF;
+            td1[u] = (float)(d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
+            const int u0 = f2i_rn((d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
+            const int v0 = f2i_rn((d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
+            cand[u] = cand0[u] & ((u0 >= 0) & (v0 >= 0) & (u0 < a.w) & (v0 < a.h));
+            gj[u] = cand[u] ? v0 * a.w + u0 : 0;
+            vprev[u] = v3m(a.vmap_prev[j], a.vmap_prev[j + N], a.vmap_prev[j + 2 * N]);
+            nprev[u] = v3m(a.nmap_prev[j], a.nmap_prev[j + N], a.nmap_prev[j + 2 * N]);
+            d0[u] = a.lastDepth[gj[u]];
+            lif[u] = (float)a.lastImage[gj[u]];
+            const int g3 = gj[u] * 3;   // the step's point-cloud entry lives at the correspondence: known before the taps come back
+            X[u] = a.cloud[g3]; Y[u] = a.cloud[g3 + 1]; Z[u] = a.cloud[g3 + 2];
+        }
+        double acc[29];
+#pragma unroll
+        for (int k = 0; k < 29; k++) acc[k] = 0.0;
+        int cnt = 0, sig = 0;
+        bool hit[PX];
+        float diff[PX];
+#pragma unroll
+        for (int u = 0; u < PX; u++) {
+            float row[7] = {0, 0, 0, 0, 0, 0, 0};
+            bool found = false;
+            if (ICP && inb[u]) {   // EF/Cuda/reduce.cu:302-387
+                const v3 ncurr_g = mulp(Rcurr, ncurr[u]);
+                const float dist = norm(vprev[u] - vcurr_g[u]);
+                const float sine = norm(cross(ncurr_g, nprev[u]));
+                found = (sine < a.angleThres && dist <= a.distThres && !(ncurr[u].x != ncurr[u].x) && !(nprev[u].x != nprev[u].x));
+                if (found) {
+                    const v3 s_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
+                    const v3 d_cp = mulp(Rprev_inv, vprev[u] - tp);
+                    const v3 n_cp = mulp(Rprev_inv, nprev[u]);
+                    const v3 c = cross(s_cp, n_cp);
+                    row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+                    row[3] = c.x; row[4] = c.y; row[5] = c.z;
+                    row[6] = dot(n_cp, s_cp - d_cp);
+                }
+            }
+            if (ICP) products7<0>(row, found, acc);
+            // EF/Cuda/reduce.cu:811-842
+            hit[u] = RGB && (cand[u] & (d0[u] > 0) & (fabsf(td1[u] - d0[u]) <= a.maxDepthDelta) & (lif[u] != 0.f));
+            diff[u] = nif[u] - lif[u];
+            cnt += hit[u] ? 1 : 0;
+            sig += hit[u] ? (int)(diff[u] * diff[u]) : 0;
+        }
+        if (ICP) block_sum_exact<29>(acc, icp_acc, bid % IFX_ACC_REPL);
+        {
+            const int lane = tid & 63, wid = tid >> 6;
+            cnt = wave_sum_i(cnt);
+            sig = wave_sum_i(sig);
+            if (lane == 0) { s_cs[wid][0] = cnt; s_cs[wid][1] = sig; }
+            __syncthreads();
+            if (tid < 2) {
+                int s2 = 0;
+                for (int wv = 0; wv < RED_WAVES; wv++) s2 += s_cs[wv][tid];
+                if (s2) atomicAdd(&gres[tid], s2);
+            }
+        }
+        gn_grid_barrier(bar, 2 * it + 1, nb, &st->gn_timeout);
+        if (bid == 0) {   // the other parity's buffers were last read in the solve of the previous iteration: every block is past it now
+            double* const other = st->gn_acc2 + (size_t)((1 - par) * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+            __hip_atomic_store(&other[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 x REPL x STRIDE = 256 doubles
+            if (tid < 2) __hip_atomic_store(&st->gn_res2[(1 - par) * 16 + tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- phase B: the photometric rows (RGBReduction, EF/Cuda/reduce.cu:494-619) from registers
+        const int rcnt = __hip_atomic_load(&gres[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), rsig = __hip_atomic_load(&gres[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RGB) {
+            const float q = (float)rsig / (float)rcnt;
+            const float sigma = (float)sqrt((double)((q == 0) ? 1 : rcnt));   // the reference's precedence quirk (EF/Utils/RGBDOdometry.cpp:461)
+#pragma unroll
+            for (int k = 0; k < 29; k++) acc[k] = 0.0;
+#pragma unroll
+            for (int u = 0; u < PX; u++) {
+                float row[7] = {0, 0, 0, 0, 0, 0, 0};
+                const bool found = hit[u];
+                if (found) {
+                    float wgt = sigma + fabsf(diff[u]);
+                    wgt = wgt > 1.19209290E-07F ? 1.0f / wgt : 1.0f;
+                    if (sigma == -1) wgt = 1;
+                    row[6] = -wgt * diff[u];
+                    const float invz = (float)(1.0 / Z[u]);
+                    const float dI_dx = wgt * a.sobelScale * gx[u];
+                    const float dI_dy = wgt * a.sobelScale * gy[u];
+                    const float v0 = dI_dx * a.fx * invz;
+                    const float v1 = dI_dy * a.fy * invz;
+                    const float v2 = -(v0 * X[u] + v1 * Y[u]) * invz;
+                    row[0] = v0; row[1] = v1; row[2] = v2;
+                    row[3] = -Z[u] * v1 + Y[u] * v2;
+                    row[4] = Z[u] * v0 - X[u] * v2;
+                    row[5] = -Y[u] * v0 + X[u] * v1;
+                }
+                products7<1>(row, found, acc);
+            }
+            block_sum_exact<29>(acc, rgb_acc, bid % IFX_ACC_REPL);
+        }
+        gn_grid_barrier(bar, 2 * it + 2, nb, &st->gn_timeout);
+        // ---- every block: totals -> combined system -> solve -> the next iteration's pose in LDS
+        const bool last_it = it == a.iters - 1;
+        if (tid < 29) {
+            const double ti = acc_total(icp_acc, tid), tr = acc_total(rgb_acc, tid);
+            const float oi = ICP ? (float)ti : 0.f, orr = RGB ? (float)tr : 0.f;
+            s_oi[tid] = oi; s_or[tid] = orr;
+            if (tid < 27) {
+                const double wgt = a.icp_weight;
+                const double wa = wgt * wgt, wb = wgt;
+                const bool is_b = (tid == 6) | (tid == 12) | (tid == 17) | (tid == 21) | (tid == 24) | (tid == 26);
+                const double vi = (double)oi, vr = (double)orr;
+                s_sys[tid] = (ICP && RGB) ? vr + (is_b ? wb : wa) * vi : (ICP ? vi : vr);
+            }
+        }
+        if (tid == 64) { s_res[0] = rcnt; s_res[1] = rsig; }
+        __syncthreads();
+        if (bid == 0 && last_it && a.final_level && tid >= 64 && tid < 128) {   // diagnostics of the run's last iteration (block 0, off the serial lane)
+            const int t = tid - 64;
+            if (t == 0) {
+                const int rgbSize = RGB ? s_res[0] : 0, sigma = RGB ? s_res[1] : 0;
+                st->rgb_count = rgbSize; st->rgb_sigma = sigma;
+                st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
+                st->lastRGBCount = (float)rgbSize;
+                if (ICP) { st->lastICPError = sqrtf(s_oi[27]) / s_oi[28]; st->lastICPCount = s_oi[28]; }
+            }
+            if (t < 29) { st->icp29[t] = s_oi[t]; st->rgb29[t] = s_or[t]; }
+            if (t < 36) {
+                const int i = t / 6, j = t - 6 * i, lo = i < j ? i : j, hi = i < j ? j : i;
+                st->lastA[t] = s_sys[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)];
+            }
+            if (t < 6) st->lastb[t] = s_sys[t * 7 - (t * (t - 1)) / 2 + (6 - t)];
+        }
+        if (tid == 0 && !(last_it && bid != 0)) {   // (the level's last solve is only block 0's to publish)
+            double RRt[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) RRt[k] = s_RRt[k];
+            float Rc[9], tcn[3], krkn[9], ktn[3];
+            if (last_it) gn_serial_lane(s_sys, ICP, RRt, Rp, tpv, a.nfx, a.nfy, a.ncx, a.ncy, a.ki_next, Rc, tcn, krkn, ktn);
+            else gn_serial_lane(s_sys, ICP, RRt, Rp, tpv, a.fx, a.fy, a.cx, a.cy, a.ki_same, Rc, tcn, krkn, ktn);
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_RRt[k] = RRt[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { s_pose[k] = Rc[k]; s_pose[12 + k] = krkn[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_pose[9 + k] = tcn[k]; s_pose[21 + k] = ktn[k]; }
+            if (bid == 0 && last_it) {   // the level's result for whatever runs next (the next level's launch, the end of the run, diagnostics)
+#pragma unroll
+                for (int k = 0; k < 16; k++) st->resultRt[k] = RRt[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krkn[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { st->tcurr[k] = tcn[k]; st->kt[k] = ktn[k]; }
+                if (a.final_level) track_end_dev(st, RGB, 1, a.weight_mult, a.commit, a.lctr);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
 __global__ void k_commit_pose(DevState* st, unsigned int* lctr)
 {
@@ -1578,6 +1889,17 @@ int ifx_alloc_tracker(ifx* h)
     const int maxb = 1024;
     HIPCHK(h, hipMalloc(&p.acc, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
     HIPCHK(h, hipMemset(p.acc, 0, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
+    {   // grids of the persistent level kernel must be co-resident: blocks per CU from the runtime's occupancy calculator x the CU count
+        int cus = 0, dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int occ[4] = {0, 0, 0, 0};
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], k_gn_level<1>, RED_THREADS, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], k_gn_level<2>, RED_THREADS, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], k_gn_level<3>, RED_THREADS, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], k_gn_level<4>, RED_THREADS, 0);
+        for (int q = 0; q < 4; q++) h->gn_max_blocks[q] = std::max(0, occ[q]) * std::max(0, cus);
+    }
     h->res_rows = std::max(maxb, cdiv(h->P, RED_THREADS) + 1);   // the residual pass runs one block per 256 pixels
     HIPCHK(h, hipMalloc(&h->res_partials, (size_t)h->res_rows * 2 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
@@ -1740,6 +2062,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
     bool ended = false;
+    int iters_done = 0;
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
         // The coarse levels are on the queue: the host is now ahead of the GPU by ~20 latency-bound launches, and the
         // finest level keeps the GPU mostly idle for another ~0.3 ms -- the place to slip in the next frame's image-only work.
@@ -1766,6 +2089,37 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
         int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
         pa.check_skip = frame_tracker ? 0 : 1;   // (accumulator rows, residual totals, ticket: DevState::gn_acc / gn_res / gn_ticket of `st`)
+        if (frame_tracker && h->opt_gn_persist && iterations[i] > 0 && !lds_tiles && icp && rgb) {   // all iterations of the level in one persistent launch
+            static const int pxs[4] = {1, 2, 3, 4};
+            int q = -1, nbp = 0;
+            for (int t = 0; t < 4 && q < 0; t++) {
+                const int need = cdiv(n, RED_THREADS * pxs[t]);
+                if (need <= h->gn_max_blocks[t] * 7 / 8) { q = t; nbp = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
+            }
+            if (q >= 0) {
+                LevelArgs la;
+                la.vmap_curr = pa.vmap_curr; la.nmap_curr = pa.nmap_curr; la.vmap_prev = pa.vmap_prev; la.nmap_prev = pa.nmap_prev;
+                la.dIdx = pa.dIdx; la.dIdy = pa.dIdy; la.lastDepth = pa.lastDepth; la.nextDepth = pa.nextDepth; la.lastImage = pa.lastImage; la.nextImage = pa.nextImage;
+                la.cloud = p.cloud[i];
+                la.fx = fx; la.fy = fy; la.cx = cx; la.cy = cy; la.distThres = pa.distThres; la.angleThres = pa.angleThres; la.minScale = pa.minScale; la.maxDepthDelta = pa.maxDepthDelta;
+                la.sobelScale = (float)sobelScale;
+                la.w = lw; la.h = lh; la.iters = iterations[i]; la.icp = icp; la.rgb = rgb; la.icp_weight = icp_weight;
+                la.nfx = c.fx / ld; la.nfy = c.fy / ld; la.ncx = c.cx / ld; la.ncy = c.cy / ld;
+                la.ki_same = kinv_of(fx, fy, cx, cy); la.ki_next = kinv_of(la.nfx, la.nfy, la.ncx, la.ncy);
+                la.acc_base = iters_done; la.level = i;
+                bool later = false;
+                for (int q2 = i - 1; q2 >= 0; q2--) later = later || iterations[q2] > 0;
+                la.final_level = later ? 0 : 1; la.commit = commit; la.weight_mult = weight_mult; la.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
+                if (q == 0) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<1>, st, la);
+                else if (q == 1) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<2>, st, la);
+                else if (q == 2) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<3>, st, la);
+                else LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<4>, st, la);
+                iters_done += iterations[i];
+                ended = ended || la.final_level;
+                continue;
+            }
+        }
+        iters_done += iterations[i];
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
             if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)

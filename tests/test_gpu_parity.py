@@ -559,6 +559,25 @@ def test_lds_staged_icp_tiles_are_bit_identical(ifx):
     assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in MAP_KEYS)
 
 
+def test_persistent_level_kernel_is_bit_identical(ifx):
+    """All Gauss-Newton iterations of a pyramid level in one persistent launch with grid barriers (option gn_persist; k_gn_level): the same
+    rows and the same exact sums as the two launches per iteration -- trajectories and maps bit-identical (the in-kernel meetings cost more
+    than launch boundaries on this GPU, DESIGN.md section 6, hence an option).  A barrier that timed out would show up as a different pose."""
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(8, W, H, noise=True, loop_len=90, **K)
+    out = []
+    for persist in (0, 1):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
+        g.set_option("gn_persist", persist)
+        out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(8)]), g.download()))
+        g.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in MAP_KEYS)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_owner_sharded_map_emulated(ifx, small_stream, world):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images

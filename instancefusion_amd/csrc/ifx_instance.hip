@@ -400,6 +400,7 @@ struct FFArgs {
     const uint16_t* depth; uint8_t* masks; const uint8_t* ori; const uint8_t* skip;   // skip[m] != 0: mask left alone
     int* label; int* cnt; int* meta;   // meta[m*32 + 0] oriPoints, [1] kept count, [2] finalPoints, [4..24) kept region ids
     int* changed;                      // [0] set when a launch lowered a label
+    uint8_t* tile_active;              // [nm][tiles]: the tile holds a labelled pixel (a tile without one has nothing to relax, whatever its halo says: labels only ever move between mask pixels)
     int nm, w, h;
 };
 
@@ -414,6 +415,7 @@ __global__ void k_ff_init(FFArgs a)
         bool v = interior && a.masks[(size_t)m * P + k] && a.depth[k];
         a.label[(size_t)m * P + k] = v ? k : -1;
         a.cnt[(size_t)m * P + k] = 0;
+        if (v) a.tile_active[(size_t)m * ((a.w + FF_T - 1) / FF_T) * ((a.h + FF_T - 1) / FF_T) + (y / FF_T) * ((a.w + FF_T - 1) / FF_T) + x / FF_T] = 1;   // (same value from every writer)
     }
     unsigned long long b = __ballot(o);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&a.meta[m * 32], __popcll(b));
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a)
     __shared__ int s_lab[FF_T + 2][FF_T + 2];
     __shared__ unsigned short s_d[FF_T + 2][FF_T + 2];
     const int P = a.w * a.h, m = blockIdx.z;
-    if (a.skip[m]) return;
+    if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
     const int x0 = blockIdx.x * FF_T - 1, y0 = blockIdx.y * FF_T - 1, tid = threadIdx.x;
     for (int t = tid; t < (FF_T + 2) * (FF_T + 2); t += 256) {
@@ -537,7 +539,7 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     if (need > h->ff_cap) {
         if (h->d_ff_label) hipFree(h->d_ff_label);
         h->d_ff_label = nullptr; h->ff_cap = 0;
-        HIPCHK(h, hipMalloc(&h->d_ff_label, need * 2 * 4 + (size_t)256 * 32 * 4 + 64 + 256));
+        HIPCHK(h, hipMalloc(&h->d_ff_label, need * 2 * 4 + (size_t)256 * 32 * 4 + 64 + 256 + (size_t)256 * cdiv(h->w, FF_T) * cdiv(h->h, FF_T)));
         h->ff_cap = need;
     }
     FFArgs a;
@@ -545,6 +547,8 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     a.label = h->d_ff_label; a.cnt = h->d_ff_label + h->ff_cap; a.meta = a.cnt + h->ff_cap; a.changed = a.meta + 256 * 32;
     uint8_t* d_skip = (uint8_t*)(a.changed + 16);
     a.skip = d_skip;
+    a.tile_active = d_skip + 256;
+    HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->stream));
     HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->stream));   // the verdict must not change who is skipped mid-way
     HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->stream));
     dim3 per_px(cdiv(P, 256), nm);

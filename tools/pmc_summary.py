@@ -14,8 +14,12 @@ import sys
 from collections import defaultdict
 
 
-def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+def short(name, keep_template=False):
+    """k_name (template arguments dropped: the variants of a kernel are one entry; `keep_template` keeps them, without commas, for the stats table)."""
+    n = name.split("(")[0].replace("void ", "").strip()
+    if "<" in n:
+        n = n.replace(", ", " ") if keep_template else n.split("<")[0]
+    return n
 
 
 def stats(src, dst):
@@ -24,7 +28,7 @@ def stats(src, dst):
         head = next(r)
         g.write(",".join(head) + "\n")
         for row in r:
-            row[0] = short(row[0])
+            row[0] = short(row[0], keep_template=True)
             g.write(",".join(row) + "\n")
 
 

@@ -107,19 +107,28 @@ int ifx_key_images(ifx_t* h, void** key_index, void** key_splat, void** key_ids,
 int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
 /* ---- spatially sharded map (BASELINE configurations 4 and 5): a handle created with ifx_config::n_ranks = G > 1 STORES only
  * the surfels it owns -- owner = Morton code of the 8 cm voxel of the position a surfel was created (or uploaded) at, mod G (ifx_owner_of) --
- * i.e. 1 / G of the map.  One process per GPU, every rank fed the same frame.  A frame is seven calls of ifx_owner_frame_phase (phase 0..6,
- * the image pointers are used by phase 0); after phase p the caller reduces, across the ranks, the device buffers ifx_owner_exchange(p)
+ * i.e. 1 / G of the map.  One process per GPU, every rank fed the same frame.  A frame is eight calls of ifx_owner_frame_phase (phase 0..7,
+ * the image pointers are used by phase 0); after phase p (0..6) the caller reduces, across the ranks, the device buffers ifx_owner_exchange(p)
  * lists: ops 0 = element-wise MINIMUM of unsigned 64-bit words (key images: depth | creation number), ops 1 = SUM of 32-bit words
  * (attribute images with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  instancefusion_amd/sharded.py does
  * it with RCCL all-reduces on the handle's stream.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
- * bit.  Per-surfel work (projections, fusion update, clean) is sharded, per-pixel work (tracking, association) replicated; the instance
- * layer and the loop-closure detection are not available in this mode yet. */
+ * bit.  Per-surfel work (projections, fusion update, clean, votes, label scan) is sharded, per-pixel work (tracking, association, the mask
+ * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume; the kNN smoothing and the loop-closure
+ * detection are not available in this mode yet. */
 int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);
 int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n);
 /* ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose): step 0, exchange as after phase 4,
  * step 1, exchange as after phase 5, step 2. */
 int ifx_owner_predict_phase(ifx_t* h, int step);
 int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out);
+/* InstanceFusion::processInstance (src/Core/InstanceFusion.cpp:655-1067) on a sharded map.  Every rank passes the same masks; what depends on a surfel's
+ * votes or position is computed by its owner and merged at exchange points: _begin / _resume return 1 while one is pending -- reduce the buffers
+ * ifx_owner_exchange(h, 200, ...) names (ops: 1 sum of 32-bit words, 2 minimum of signed 32-bit words, 3 maximum of signed 32-bit words), then call
+ * _resume -- and 0 when the call is complete (labels of the owned surfels: ifx_labels).  flags: bit 1 superpixel refinement; the kNN smoothing (bit 0)
+ * is not offered on a sharded map.  The whetherDoSegmentation sums of a frame are complete after ifx_owner_frame_phase(h, 7, ...) (phase 6 leaves
+ * the vote mass of the owned surfels in the buffer ifx_owner_exchange(h, 6, ...) names; phase 7 publishes the frame result). */
+int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks, const int32_t* class_ids, int nm, int frame, int flags);
+int ifx_owner_segmentation_resume(ifx_t* h);
 /* creation numbers (uint32) of the live surfels in the order of ifx_map_download; returns the count */
 int ifx_map_seq(ifx_t* h, uint32_t* out, int max_n);
 /* ---- display / export branch of the instance layer.

@@ -74,6 +74,8 @@ _SIGS = {
     "ifx_owner_frame_phase": (C.c_int, [_P, C.c_int, _P, _P]),
     "ifx_owner_exchange": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "ifx_owner_of": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "ifx_owner_segmentation_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "ifx_owner_segmentation_resume": (C.c_int, [_P]),
     "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),
     "ifx_map_seq": (C.c_int, [_P, _P, C.c_int]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),

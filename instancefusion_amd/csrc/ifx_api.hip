@@ -559,7 +559,7 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
 extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
 {
-    if (!h || phase < 0 || phase > 6) return IFX_E_INVALID;
+    if (!h || phase < 0 || phase > 7) return IFX_E_INVALID;
     if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     if (h->lc_enable) { h->err = "loop-closure detection is not available on a sharded map"; return IFX_E_STATE; }
     const bool first = h->tick == 1 && h->n_traj == 0;
@@ -580,12 +580,12 @@ extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, 
     }
     int r = ifx_map_owner_phase(h, phase, first);
     if (r) return r;
-    if (phase == 6) {
+    if (phase == 7) {   // after the vote mass of phase 6 was summed across the ranks: the frame result every rank reads its whetherDoSegmentation decision from
         const int slot = h->n_traj % h->max_traj;
         LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
         hipEventRecord(f.released, h->stream);
         h->ev_result = f.released;
-        h->seg_counts_valid = 0;
+        h->seg_counts_valid = first ? 0 : 1;
         h->n_traj++;
         h->tick++;
     }
@@ -616,6 +616,15 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4: add(h->key_splat, P * 8, 0); add(h->key_ids, P * 8, 0); add(h->key_both, P * 8, 0); break;
     case 5: add(h->pred_vertex, P * 16, 1); add(h->pred_normal, P * 16, 1); add(h->pred_image, P * 4, 1); add(h->pred_inst, P * 4, 1); add(h->pred_time, P * 2, 1); break;
+    case 6: if (!first) add(&h->d_state->seg_acc[0], 4, 1); break;   // vote mass under the id image: every rank adds the surfels it owns
+    case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume)
+        switch (h->oseg_pending) {
+        case 1: add(h->d_bbox, (size_t)(96 + h->oseg_nm) * 4 * 4, 2); break;                       // boxes, maxima negated: MIN of 32-bit words
+        case 2: add(h->d_pdm, P * 2, 1); break;                                                     // model depth under the camera: disjoint supports
+        case 3: add(h->d_inst_stats, 96 * 4, 3); add(h->d_inst_stats + 96, 96 * 4, 1); break;      // per-instance maximum (MAX) and sum (SUM) of the vote counters
+        default: break;
+        }
+        break;
     default: break;
     }
     return n;

@@ -78,6 +78,23 @@ struct DevState {
     int gn_timeout;                                           // a grid barrier gave up (never in a healthy run; tests assert 0)
 };
 
+// Ids in the id images are slot indices on an unsharded map and creation numbers on a spatially sharded one (ifx_map.hip, key_id / local_slot):
+// the instance layer, which goes from a pixel's id to the votes / position of that surfel, maps them through this.  -1: no surfel of THIS rank.
+struct IdMap { const uint32_t* seq; int own_n; };
+__device__ __forceinline__ int idmap_slot(const IdMap& m, int count, int id)
+{
+    if (id <= 0) return -1;
+    if (m.own_n <= 1) return id < count ? id : -1;
+    int lo = 0, hi = count - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned int v = m.seq[mid];
+        if (v == (unsigned int)id) return mid;
+        if (v < (unsigned int)id) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
 struct FrameResult {   // copied to pinned host memory at the end of every frame
     float pose[16];
     float diag[8];
@@ -189,6 +206,11 @@ struct ifx {
     int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
+    // spatially sharded map: ifx_owner_segmentation_begin / _resume carry one segmentation call across its exchange points
+    int oseg_state = 0, oseg_nm = 0, oseg_m = 0, oseg_flags = 0, oseg_pending = 0;
+    std::vector<uint8_t> oseg_unavail;
+    std::vector<int> oseg_cmp, oseg_bbox, oseg_class;
+    hipEvent_t oseg_ev = nullptr;
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
     int opt_view_blocks = 0, opt_clean_blocks = 0, opt_index_blocks = 0;   // grids of the view-list kernels (0: LIST_BLOCKS)
     int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)
@@ -304,6 +326,7 @@ struct ifx {
     std::vector<PendingEvent> kpending;
     std::vector<hipEvent_t> event_pool;
 };
+static inline IdMap ifx_idmap(const ifx* h) { IdMap m; m.seq = h->seq; m.own_n = h->cfg.n_ranks > 1 ? h->cfg.n_ranks : 1; return m; }
 
 #define HIPCHK(h, call)                                                                            \
     do {                                                                                           \

@@ -98,14 +98,15 @@ __device__ __forceinline__ void bbox_extend_wave(int* b, bool mine, int x, int y
     }
 }
 __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
-                               int nm, int w, int h, int* __restrict__ bbox)
+                               int nm, int w, int h, int* __restrict__ bbox, IdMap im)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & 63;
     const bool inside = x < w && y < h;
     const int P = w * h, k = inside ? y * w + x : 0;
-    const int id = inside ? ids[k] : 0;
-    bool has = inside && id > 0 && id < st->count;
+    const int gid = inside ? ids[k] : 0;
+    const int id = idmap_slot(im, st->count, gid);   // (sharded map: the pixels whose surfel another rank owns extend that rank's partial boxes)
+    bool has = inside && id >= 0;
     int maxNum = 0, maxID = -1, first = 0;
     if (has) {
         float4 v[12];
@@ -150,13 +151,13 @@ __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* _
 }
 
 // getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996
-__global__ void k_project_depth(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ pc, int P, int ratio, uint16_t* __restrict__ pdm)
+__global__ void k_project_depth(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ pc, int P, int ratio, uint16_t* __restrict__ pdm, IdMap im)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
-    int id = ids[k];
+    const int id = idmap_slot(im, st->count, ids[k]);
     uint16_t o = 0;
-    if (id > 0 && id < st->count) {
+    if (id >= 0) {
         float4 p = pc[id];
         float dx = st->pose[3] - p.x, dy = st->pose[7] - p.y, dz = st->pose[11] - p.z;
         o = (uint16_t)(sqrtf(dx * dx + dy * dy + dz * dz) * ratio);
@@ -169,13 +170,13 @@ __global__ void k_project_depth(const DevState* __restrict__ st, const int32_t* 
 // an atomicCAS loop makes the result independent of scheduling (every pixel's increment lands), which
 // is also what the sequential oracle computes.
 __global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ mask, int P, int cap, int instanceID, int inc,
-                              float* __restrict__ votes)
+                              float* __restrict__ votes, IdMap im)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
     if (!(mask[k] > 0)) return;
-    int id = ids[k];
-    if (!(id > 0 && id < st->count)) return;
+    const int id = idmap_slot(im, st->count, ids[k]);
+    if (id < 0) return;
     int fi = instanceID / 2, p = instanceID % 2;
     // planar float4 store: float fi of surfel id lives in plane fi/4, component fi%4
     unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
@@ -604,11 +605,165 @@ static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
 {
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
     LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
-           h->d_bbox);
+           h->d_bbox, ifx_idmap(h));
     bbox.resize((size_t)(NI + nm) * 4);
     HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return IFX_OK;
+}
+
+// ------------------------------------------------------------------ a segmentation call on a spatially sharded map
+// Every rank runs the call on the same masks and the same (replicated) id image; what depends on a surfel's votes or position is computed by the
+// rank that owns the surfel and merged at three kinds of exchange points (ifx_owner_exchange(h, 200, ...) names the buffers and the operation):
+//   1  the projected boxes           partial min / max per instance (maxima negated: one MIN over 32-bit words)
+//   2  the model depth under the camera (flood fill input)   disjoint supports: SUM
+//   3  per-instance max / sum of the vote counters, when the instance table is full and its twenty weakest entries are evicted
+//      (followed by another exchange of kind 1: the boxes after the eviction)
+// The mask pipeline (overlap cleaning, superpixels, flood fill), the compare map and the instance table are image-space / host work and run
+// replicated; vote updates and the label scan touch owned surfels only.  ifx_owner_segmentation_begin returns 1 while an exchange is pending
+// (then: exchange, ifx_owner_segmentation_resume), 0 when the call is complete.  The kNN smoothing (flags & 1) needs every rank's positions and
+// is not offered here.
+__global__ void k_bbox_flip(int* __restrict__ bbox, int nboxes)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nboxes * 4 && (k & 1)) bbox[k] = -bbox[k];   // {minX, maxX, minY, maxY}: entries 1 and 3 are maxima
+}
+static int oseg_launch_bboxes(ifx* h)
+{
+    const int nm = h->oseg_nm;
+    LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+           h->d_bbox, ifx_idmap(h));
+    LAUNCH(h, "bbox_flip", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_bbox_flip, h->d_bbox, NI + nm);
+    h->oseg_pending = 1;
+    return 1;
+}
+static int oseg_read_bboxes(ifx* h)
+{
+    const int nm = h->oseg_nm;
+    LAUNCH(h, "bbox_flip", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_bbox_flip, h->d_bbox, NI + nm);
+    h->oseg_bbox.resize((size_t)(NI + nm) * 4);
+    HIPCHK(h, hipMemcpyAsync(h->oseg_bbox.data(), h->d_bbox, h->oseg_bbox.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::fill(h->oseg_cmp.begin(), h->oseg_cmp.end(), 0);
+    compare_map(h, &h->oseg_bbox[NI * 4], &h->oseg_bbox[0], h->oseg_class.data(), nm, h->oseg_unavail, h->oseg_cmp);
+    return IFX_OK;
+}
+// the loop over the masks (step 3) from mask oseg_m on; stops (returns 1) when the table is full and the eviction statistics must be merged
+static int oseg_mask_loop(ifx* h, bool after_eviction)
+{
+    const int nm = h->oseg_nm, P = h->P;
+    std::vector<int>& cmp = h->oseg_cmp;
+    for (int m = h->oseg_m; m < nm; m++) {
+        const bool resumed = after_eviction && m == h->oseg_m;   // this mask asked for room before the eviction: it goes on where the unsharded loop does (no second look at `exist`)
+        bool need = resumed;
+        if (!resumed) {
+            bool exist = false;
+            for (int q = 0; q < NI; q++) if (cmp[q + m * NI] == 1) { exist = true; break; }
+            need = !exist && !h->oseg_unavail[m];
+        }
+        if (need) {
+            int empty = first_not_used(h);
+            if (empty == -1 && !resumed) {
+                h->clean_times++;
+                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->stream));
+                LAUNCH(h, "max_count", dim3(1024), dim3(256), k_max_count, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, h->d_inst_stats, h->d_inst_stats + NI);
+                h->oseg_m = m; h->oseg_state = 3; h->oseg_pending = 3;
+                return 1;
+            }
+            if (empty >= 0) { h->inst_class[empty] = h->oseg_class[m]; cmp[empty + m * NI] = 1; }
+        }
+        for (int q = 0; q < NI; q++)
+            if (cmp[q + m * NI] == 1)
+                LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes, ifx_idmap(h));
+    }
+    // step 4: labels of the owned surfels
+    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+    hipEvent_t eb = ifx_event_get(h);
+    hipEventRecord(eb, h->stream);
+    h->stage_pending.push_back({2, {h->oseg_ev, eb}});
+    h->oseg_ev = nullptr;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->oseg_state = 0; h->oseg_pending = 0;
+    return 0;
+}
+extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+{
+    if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
+    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_segmentation_begin: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (flags & 1) { h->err = "kNN smoothing is not offered on a sharded map (it needs every rank's positions)"; return IFX_E_INVALID; }
+    if (h->oseg_state) { h->err = "a segmentation call is already in flight"; return IFX_E_STATE; }
+    if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
+    ifx_vlist_reap(h);
+    h->seg_counts_valid = 0;
+    h->oseg_ev = ifx_event_get(h);
+    hipEventRecord(h->oseg_ev, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (nm == 0) { h->event_pool.push_back(h->oseg_ev); h->oseg_ev = nullptr; return 0; }   // (an empty shard still takes part: the other ranks wait for its boxes)
+    const int P = h->P;
+    const size_t mbytes = (size_t)nm * P;
+    int r = ifx_ensure_masks(h, mbytes);
+    if (r) return r;
+    h->oseg_nm = nm; h->oseg_m = 0; h->oseg_flags = flags;
+    h->oseg_unavail.assign(nm, 0);
+    h->oseg_cmp.assign((size_t)nm * NI, 0);
+    h->oseg_class.assign(class_ids, class_ids + nm);
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
+    if (flags & 2) {
+        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
+        if (r) return r;
+    }
+    h->oseg_state = 1;
+    return oseg_launch_bboxes(h);
+}
+extern "C" int ifx_owner_segmentation_resume(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!h->oseg_state) { h->err = "no segmentation call in flight"; return IFX_E_STATE; }
+    const int nm = h->oseg_nm, P = h->P;
+    int r;
+    switch (h->oseg_state) {
+    case 1:   // boxes merged -> compare map; model depth of the owned surfels
+        if ((r = oseg_read_bboxes(h))) return r;
+        LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
+        h->oseg_state = 2; h->oseg_pending = 2;
+        return 1;
+    case 2:   // model depth merged -> flood fill (replicated), then the masks
+        HIPCHK(h, hipMemcpyAsync(h->d_unavail, h->oseg_unavail.data(), nm, hipMemcpyHostToDevice, h->stream));
+        if ((r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail))) return r;
+        HIPCHK(h, hipMemcpyAsync(h->oseg_unavail.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->oseg_state = 5;
+        return oseg_mask_loop(h, false);
+    case 3: {   // eviction statistics merged -> getInstanceTableCleanList (IF/Core/InstanceTable.cpp:185-224), clean, the boxes again
+        int stats[NI * 2];
+        HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        int* maxv = stats; int* sumv = stats + NI;
+        int order[NI], cl[NI];
+        for (int i = 0; i < NI; i++) order[i] = i;
+        for (int i = 0; i < NI; i++)
+            for (int j = i + 1; j < NI; j++)
+                if ((float)sumv[j] < (float)sumv[i]) { std::swap(maxv[i], maxv[j]); std::swap(order[i], order[j]); std::swap(sumv[i], sumv[j]); }
+        for (int i = 0; i < NI; i++) cl[i] = 0;
+        for (int i = 0; i < 20; i++) cl[order[i]] = 1;
+        for (int q = 0; q < NI; q++) if (cl[q] == 1) h->inst_class[q] = -1;
+        HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->stream));
+        LAUNCH(h, "clean_table", dim3(1024), dim3(256), k_clean_table, h->d_state, h->votes, h->cap, h->d_clean_list);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->oseg_state = 4;
+        return oseg_launch_bboxes(h);
+    }
+    case 4:   // boxes after the eviction merged -> compare map again, the mask that asked for room goes on
+        if ((r = oseg_read_bboxes(h))) return r;
+        h->oseg_state = 5;
+        return oseg_mask_loop(h, true);
+    default: break;
+    }
+    h->err = "ifx_owner_segmentation_resume: bad state";
+    return IFX_E_STATE;
 }
 
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
@@ -645,7 +800,7 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     std::vector<int> cmp((size_t)nm * NI, 0);
     compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
     // step 3_0: model depth under the camera, then the flood fill of every usable mask (device)
-    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm);
+    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
     HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->stream));
     r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail);
     if (r) return r;
@@ -687,7 +842,7 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
         }
         for (int q = 0; q < NI; q++)
             if (cmp[q + m * NI] == 1)
-                LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes);
+                LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes, ifx_idmap(h));
     }
     // step 4
     LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);

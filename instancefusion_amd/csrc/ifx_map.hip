@@ -477,7 +477,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
 // blocks 1.. = checkProjectDepthAndInstanceKernel (IF/Core/InstanceFusionCuda.cu:736-760) over the id image this pass
 // rendered, accumulated for k_frame_result, so that whetherDoSegmentation needs no launch of its own.
 __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, int w, int h, int do_dense, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap,
-                                int downsample, unsigned int* __restrict__ lctr)
+                                int downsample, unsigned int* __restrict__ lctr, IdMap im)
 {
     if (blockIdx.x == 0) {
         if (do_dense) {
@@ -506,8 +506,10 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
     if (t < gw * gh) {
         const int gy = t / gw, gx = t - gy * gw, x = gx * downsample, y = gy * downsample;
         if (x < w && y < h) {
-            const int id = ids[y * w + x];
-            if (id > 0 && id < st->count) {
+            const int gid = ids[y * w + x];
+            const int id = idmap_slot(im, st->count, gid);   // sharded map: the vote mass of a pixel is counted by the rank that owns its surfel (summed across ranks afterwards)
+            if (im.own_n > 1 ? gid > 0 : id >= 0) {
+              if (id >= 0) {
                 float4 v[12];   // all twelve planes in flight together (one after the other they were twelve HBM round trips: 13 us for this little kernel)
 #pragma unroll
                 for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + id];
@@ -519,6 +521,7 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
                     vote_decode(v[q].z, a, b); mass += a + b;
                     vote_decode(v[q].w, a, b); mass += a + b;
                 }
+              }
             } else empty = 1;
         }
     }
@@ -1583,7 +1586,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
                (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
                (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
                old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
-        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
         return;
     }
     if (want & LIST_SPLAT) {
@@ -1596,7 +1599,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
     const int seg = frame_sums && (want & LIST_IDS);   // only the frame's own render feeds whetherDoSegmentation (not the re-render after a compaction)
     const int ds = 10, nseg = seg ? cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256) : 0;
     LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, (want & LIST_SPLAT) ? 1 : 0, h->ids_after,
-           (const float4*)h->votes, h->cap, ds, h->d_list_ctr);
+           (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h));
 }
 static void splat_pass(ifx* h, const float* d_pose_inv, int time, int maxTime) { raster_pass(h, d_pose_inv, time, maxTime, LIST_SPLAT, nullptr); }
 
@@ -2264,7 +2267,7 @@ int ifx_map_predict_loop_closure(ifx* h)
                (float4*)(old ? h->old_vertex : h->act_vertex), (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image),
                (uchar4*)(old ? h->old_inst : h->act_inst), old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both,
                (int32_t*)nullptr, (int*)nullptr);
-    LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+    LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
     return IFX_OK;
 }
 
@@ -2404,9 +2407,9 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         case 6:
             LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
                    (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-            LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+            LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
             break;
-        default: break;
+        default: break;   // (incl. 7)
         }
         return IFX_OK;
     }
@@ -2439,11 +2442,14 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
                (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
                (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr);
         break;
-    case 6:                                                                                                 // fill-in and dense flag on the exchanged prediction (replicated)
+    case 6: {                                                                                               // fill-in and dense flag on the exchanged prediction (replicated); whetherDoSegmentation sums: empty pixels replicated, vote mass of the owned surfels | seg_acc[0]: SUM
         LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
                (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr);
+        const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);
+        LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h));
         break;
+    }
+    case 7: break;                                                                                          // (the frame result is published by ifx_owner_frame_phase)
     default: return IFX_E_INVALID;
     }
     return IFX_OK;

@@ -142,11 +142,11 @@ class OwnerShardedElasticFusion:
                     if op == 0:
                         KeyExchange.reduce_min([t], self.dist)
                     else:
-                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                        self.dist.all_reduce(t, op={1: self.dist.ReduceOp.SUM, 2: self.dist.ReduceOp.MIN, 3: self.dist.ReduceOp.MAX}[op])
 
     def process_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         ef = self.ef
-        for phase in range(7):
+        for phase in range(8):   # 0..6 with their exchanges (after 6: the vote mass of the whetherDoSegmentation sums), 7 publishes the frame result
             ef._chk(ef.L.ifx_owner_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
             self._exchange(phase)
 
@@ -157,6 +157,23 @@ class OwnerShardedElasticFusion:
             ef._chk(ef.L.ifx_owner_predict_phase(ef.handle, step), "ifx_owner_predict_phase")
             if step < 2:
                 self._exchange(4 + step)
+
+    def process_segmentation(self, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True):
+        """InstanceFusion::processInstance on the sharded map (same masks on every rank): the owners' partial boxes, model depth and -- when the
+        instance table overflows -- eviction statistics are merged at the call's exchange points; labels of the owned surfels: ef.labels()."""
+        r = _seg_begin(self.ef, rgb, depth, masks, class_ids, frame, superpixels)
+        while r == 1:
+            self._exchange(200)
+            r = self.ef._chk(self.ef.L.ifx_owner_segmentation_resume(self.ef.handle), "ifx_owner_segmentation_resume")
+
+
+def _seg_begin(ef, rgb, depth, masks, class_ids, frame, superpixels):
+    masks = np.ascontiguousarray(masks, np.uint8)
+    cls = np.ascontiguousarray(class_ids, np.int32)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    depth = np.ascontiguousarray(depth, np.uint16)
+    return ef._chk(ef.L.ifx_owner_segmentation_begin(ef.handle, rgb.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p), masks.ctypes.data_as(C.c_void_p),
+                                                     cls.ctypes.data_as(C.c_void_p), int(masks.shape[0]), int(frame), 2 if superpixels else 0), "ifx_owner_segmentation_begin")
 
 
 def _reduce_by_hand(efs, specs):
@@ -173,10 +190,14 @@ def _reduce_by_hand(efs, specs):
             for t in ts[1:]:
                 m = torch.minimum(m, t ^ _SIGN)
             m ^= _SIGN
-        else:
+        elif op == 1:
             m = ts[0].clone()
             for t in ts[1:]:
                 m += t
+        else:
+            m = ts[0].clone()
+            for t in ts[1:]:
+                m = torch.minimum(m, t) if op == 2 else torch.maximum(m, t)
         for t in ts:
             t.copy_(m)
     torch.cuda.synchronize()
@@ -194,9 +215,19 @@ def emulate_owner_predict(efs):
 def emulate_owner_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int):
     """Test helper: `efs` = handles of ONE process created with n_ranks = len(efs), rank = 0..G-1; the all-reduces are done by hand
     (element-wise unsigned minimum / int32 sum over the handles' buffers).  Everything of the sharded map except RCCL itself."""
-    for phase in range(7):
+    for phase in range(8):
         for e in efs:
             e._chk(e.L.ifx_owner_frame_phase(e.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
         specs = [_exchange_spec(e, phase) for e in efs]
         if specs[0]:
             _reduce_by_hand(efs, specs)
+
+
+def emulate_owner_segmentation(efs, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True):
+    """A segmentation call on the handles of emulate_owner_ranks, in lock step, the exchanges done by hand."""
+    rs = [_seg_begin(e, rgb, depth, masks, class_ids, frame, superpixels) for e in efs]
+    while rs[0] == 1:
+        assert all(r == 1 for r in rs), "the ranks disagree about the call's exchange points"
+        _reduce_by_hand(efs, [_exchange_spec(e, 200) for e in efs])
+        rs = [e._chk(e.L.ifx_owner_segmentation_resume(e.handle), "ifx_owner_segmentation_resume") for e in efs]
+    assert all(r == 0 for r in rs)

@@ -635,6 +635,78 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world):
     one.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_sharded_instance_emulated(ifx, small_stream, world):
+    """The instance layer on the spatially sharded map: whetherDoSegmentation sums (vote mass of the owned surfels summed
+    across the ranks), segmentation calls with superpixels (partial boxes MIN / MAX-merged, model depth SUM-merged, votes and label scan on the
+    owned surfels) and the eviction of a full instance table (per-instance max / sum of the vote counters merged) against one GPU: decisions,
+    instance tables and -- merged by creation number -- votes and labels, bit for bit."""
+    import torch
+
+    from instancefusion_amd import sharded, synth
+
+    st = small_stream
+    NF = 10
+    d_rgb = torch.from_numpy(st["rgb"][:NF]).cuda()
+    d_dep = torch.from_numpy(st["depth"][:NF].view(np.int16)).cuda()
+    one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
+    inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
+
+    def merged(name_of):
+        parts = [(e.seq(), name_of(e, x)) for e, x in zip(efs, insts)]
+        seq = np.concatenate([p[0] for p in parts])
+        return np.concatenate([p[1] for p in parts])[np.argsort(seq, kind="stable")]
+
+    def check(tag):
+        assert all(np.array_equal(x.getInstanceTable(), inst_one.getInstanceTable()) for x in insts), tag
+        assert np.array_equal(merged(lambda e, x: e.download()["votes"]), one.download()["votes"]), tag
+        assert np.array_equal(merged(lambda e, x: x.labels()), inst_one.labels()), tag
+
+    calls = 0
+    for i in range(NF):
+        if i == 4:   # make the map stable (confidence 20): from here on the id image is populated and the masks find surfels to vote for
+            m = one.download()
+            m["pc"][:, 3] = 20.0
+            pose = one.getCurrPose()
+            one.upload(m); one.set_pose(pose, one.tick); one.combined_predict(pose, one.tick, one.tick)
+            for e in efs:
+                e.upload(m)
+                e.set_pose(pose, one.tick)
+            sharded.emulate_owner_predict(efs)
+        one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+        want = inst_one.whetherDoSegmentation(i)
+        assert [x.whetherDoSegmentation(i) for x in insts] == [want] * world, i
+        if i >= 2 and (want or i % 3 == 0):
+            masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+            if masks.shape[0]:
+                inst_one.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, i, superpixels=True)
+                sharded.emulate_owner_segmentation(efs, st["rgb"][i], st["depth"][i], masks, cls, i, superpixels=True)
+                calls += 1
+                check(("call", i))
+    assert calls >= 2 and (inst_one.labels() >= 0).sum() > 100
+    # a full table: new classes for every mask of every call until the twenty weakest instances are evicted (exchange points 3 and 1 again)
+    i = NF - 1
+    masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+    nm = masks.shape[0]
+    evicted = False
+    for call in range(40):
+        classes = (1 + (call * nm + np.arange(nm)) % 79).astype(np.int32)
+        before = (inst_one.getInstanceTable() >= 0).sum()
+        inst_one.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, classes, 200 + 3 * call)
+        sharded.emulate_owner_segmentation(efs, st["rgb"][i], st["depth"][i], masks, classes, 200 + 3 * call, superpixels=False)
+        evicted = evicted or (inst_one.getInstanceTable() >= 0).sum() < before
+        if call % 8 == 7 or evicted:
+            check(("eviction", call))
+        if evicted:
+            break
+    assert evicted
+    for e in efs:
+        e.close()
+    one.close()
+
+
 @pytest.mark.parametrize("earlyz,lds", [(1, 0), (0, 0), (0, 1)])
 def test_view_list_path_equals_per_pass_culls(ifx, earlyz, lds):
     """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,

@@ -67,8 +67,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-oracle sample (about 12 s of one core at 5M surfels)")
     ap.add_argument("--res", default="640x480", help="WxH of the synthetic stream (other BASELINE configurations; the metric is quoted at 640x480)")
     ap.add_argument("--sharded", action="store_true", help="one stream into ONE map spatially sharded across the ranks (owner = spatial hash of a surfel's position: every rank stores 1 / N of the "
-                    "map; RCCL all-reduces of the key images and of the winners' attributes between the phases of a frame -- instancefusion_amd/sharded.py, DESIGN.md section 7; strong scaling, "
-                    "geometry only: the instance layer is not sharded yet).  Default for --gpus N: one replica per rank")
+                    "map; RCCL all-reduces of the key images and of the winners' attributes between the phases of a frame -- instancefusion_amd/sharded.py, DESIGN.md section 7; strong scaling; "
+                    "segmentation calls through ifx_owner_segmentation_begin / _resume).  Default for --gpus N: one replica per rank")
     ap.add_argument("--sharded-projection", action="store_true", help="round 1's variant: every rank holds the whole map, the projection passes are sliced by slot range")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
@@ -113,8 +113,6 @@ def main():
     L = args.loop
     t_gen = time.time()
     one_map = args.sharded or args.sharded_projection
-    if args.sharded:
-        args.no_instance = True
     srank = 0 if one_map else rank          # sharded: every rank is fed the same stream and map
     st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + srank, **K)
     masks = [synth.canned_masks(st["obj"][i], st["scene"]) for i in range(L)]
@@ -177,7 +175,10 @@ def main():
             mk, cl = masks[i]
             if mk.shape[0]:
                 seg["calls"] += 1
-                inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
+                if osh is not None:   # sharded map: the owners' boxes / model depth / table statistics are merged at the call's exchange points
+                    osh.process_segmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
+                else:
+                    inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
 
     def place_call_in_window(n_frames):
         """The adaptive cadence (every 46th frame once the map carries votes, IF/Core/InstanceFusion.cpp:192-238) would leave a short

@@ -1727,15 +1727,11 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     const int li = local_slot(c, st->count, gid);   // sharded map: -1 = another rank's surfel (that rank applies the update)
     if (li < 0 || li >= st->count) return;
     const uint32_t id = (uint32_t)li;
-    // the surfel's record and the measurement are fetched together with the ownership word (a pixel that turns out not to own the surfel -- the rare
-    // case -- has read 80 bytes in vain; behind the test the records were one more dependent round trip for every pixel)
-    const uint32_t owner = upd_owner[id];
-    float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
-    const float2 cl0 = col[id], t0_ = tm[id];
-    const float mc = mcol[k];
-    asm volatile("" ::"v"(owner), "v"(p.x), "v"(n.x), "v"(mp.x), "v"(mn.x), "v"(cl0.x), "v"(t0_.x), "v"(mc));
-    if (owner != (uint32_t)(i * c.h + j)) return;
+    if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
     upd_owner[id] = 0xFFFFFFFFu;
+    float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
+    const float2 cl0 = col[id], t0_ = tm[id];   // issued with the other loads (they used to follow them: two more dependent round trips).  Fetching all of it
+    const float mc = mcol[k];                   // together with the ownership word was tried too: 13.9 -> 15.6 us (the losers' 80 bytes cost more than the round trip)
     float c_k = p.w, a = mp.w;
     if (mn.w < (1.0f + 0.5f) * n.w) {
         p.x = ((c_k * p.x) + (a * mp.x)) / (c_k + a);

@@ -113,8 +113,8 @@ int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
  * (attribute images with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  instancefusion_amd/sharded.py does
  * it with RCCL all-reduces on the handle's stream.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
  * bit.  Per-surfel work (projections, fusion update, clean, votes, label scan) is sharded, per-pixel work (tracking, association, the mask
- * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume; the kNN smoothing and the loop-closure
- * detection are not available in this mode yet. */
+ * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume, the kNN smoothing through ifx_owner_knn_export /
+ * _vote; the loop-closure detection is not available in this mode yet. */
 int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);
 int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n);
 /* ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose): step 0, exchange as after phase 4,
@@ -125,10 +125,17 @@ int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out);
  * votes or position is computed by its owner and merged at exchange points: _begin / _resume return 1 while one is pending -- reduce the buffers
  * ifx_owner_exchange(h, 200, ...) names (ops: 1 sum of 32-bit words, 2 minimum of signed 32-bit words, 3 maximum of signed 32-bit words), then call
  * _resume -- and 0 when the call is complete (labels of the owned surfels: ifx_labels).  flags: bit 1 superpixel refinement; the kNN smoothing (bit 0)
- * is not offered on a sharded map.  The whetherDoSegmentation sums of a frame are complete after ifx_owner_frame_phase(h, 7, ...) (phase 6 leaves
+ * is a separate call on a sharded map (ifx_owner_knn_export / _vote).  The whetherDoSegmentation sums of a frame are complete after ifx_owner_frame_phase(h, 7, ...) (phase 6 leaves
  * the vote mass of the owned surfels in the buffer ifx_owner_exchange(h, 6, ...) names; phase 7 publishes the frame result). */
 int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks, const int32_t* class_ids, int nm, int frame, int flags);
 int ifx_owner_segmentation_resume(ifx_t* h);
+/* InstanceFusion::flannKnnVoteSurfelMap (src/Core/InstanceFusion.cpp:1070-1163) on a sharded map: exact 10-NN over ALL surfels needs every rank's
+ * positions.  ifx_owner_knn_export hands out this rank's slots as device arrays -- points[n] float4 (x, y, z, creation number; x = NaN: dead slot),
+ * labels[n] int32 (bestIDInEachSurfel) --, the caller all-gathers both in rank order (16 + 4 bytes per slot, once per smoothing, i.e. every > 40
+ * frames), and ifx_owner_knn_vote searches the gathered set for the surfels of this rank (own_offset = where this rank's export starts in it)
+ * and recolours them.  Ties in distance go to the lower creation number: the neighbour sets of the unsharded map. */
+int ifx_owner_knn_export(ifx_t* h, void** d_points, void** d_labels, int* n);
+int ifx_owner_knn_vote(ifx_t* h, const void* d_all_points, const void* d_all_labels, int n_all, int own_offset);
 /* creation numbers (uint32) of the live surfels in the order of ifx_map_download; returns the count */
 int ifx_map_seq(ifx_t* h, uint32_t* out, int max_n);
 /* ---- display / export branch of the instance layer.

@@ -76,6 +76,8 @@ _SIGS = {
     "ifx_owner_of": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ifx_owner_segmentation_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "ifx_owner_segmentation_resume": (C.c_int, [_P]),
+    "ifx_owner_knn_export": (C.c_int, [_P, _P, _P, _P]),
+    "ifx_owner_knn_vote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),
     "ifx_map_seq": (C.c_int, [_P, _P, C.c_int]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),

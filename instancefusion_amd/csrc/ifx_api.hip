@@ -175,7 +175,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_free_tracker(h);
     ifx_free_instance(h);
     ifx_slic_free(h);
-    ifx_knn_free(h);
+    ifx_knn_free_all(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
     if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);

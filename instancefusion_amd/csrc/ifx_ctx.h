@@ -211,6 +211,7 @@ struct ifx {
     std::vector<uint8_t> oseg_unavail;
     std::vector<int> oseg_cmp, oseg_bbox, oseg_class;
     hipEvent_t oseg_ev = nullptr;
+    void* d_kexp = nullptr;            // ifx_owner_knn_export: [cap] float4 (x, y, z, creation number) + [cap] int32 labels
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
     int opt_view_blocks = 0, opt_clean_blocks = 0, opt_index_blocks = 0;   // grids of the view-list kernels (0: LIST_BLOCKS)
     int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)
@@ -363,6 +364,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // stage entry points implemented across the .hip files
 void ifx_slic_free(ifx* h);
 void ifx_knn_free(ifx* h);
+void ifx_knn_free_all(ifx* h);
 int ifx_knn_vote(ifx* h, int32_t* d_nbr_out);
 int ifx_ensure_masks(ifx* h, size_t bytes);
 int ifx_preprocess(ifx* h);                                   // bilateral + metric

@@ -171,12 +171,137 @@ __global__ void __launch_bounds__(128) k_knn_vote(const DevState* __restrict__ s
     if (bestCount > 0) col[i].y = inst_color[best];
 }
 
+// ---- the same search over an EXPLICIT point set: the smoothing on a spatially sharded map (the ranks' exports, all-gathered).
+// pts[i] = (x, y, z, creation number); x = NaN marks a dead slot.  Ties in distance go to the lower creation number -- the order of the
+// unsharded map's indices (compaction preserves it), so the neighbour sets are the ones ifx_knn_vote finds on the unsharded map.
+__global__ void k_knnx_export(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, const uint32_t* __restrict__ seq,
+                              const int32_t* __restrict__ labels, float4* __restrict__ pts, int32_t* __restrict__ lab)
+{
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        float4 p = pc[i];
+        p.w = __uint_as_float(seq[i]);
+        if (!(tm[i].y > DEAD_TIME)) p.x = __int_as_float(0x7FC00000);
+        pts[i] = p;
+        lab[i] = labels[i];
+    }
+}
+__global__ void k_knnx_bounds(const float4* __restrict__ pts, int n, KnnGrid* g)
+{
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        const float4 p = pts[i];
+        if (p.x != p.x) continue;
+        int v[3] = {ord(p.x), ord(p.y), ord(p.z)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], v[k]); hi[k] = max(hi[k], v[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], o)); hi[k] = max(hi[k], __shfl_xor(hi[k], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&g->lo_bits[k], lo[k]); atomicMax(&g->hi_bits[k], hi[k]); }
+    }
+}
+__global__ void k_knnx_count(const float4* __restrict__ pts, int n, const KnnGrid* __restrict__ g, int* __restrict__ cell_id, int* __restrict__ counts)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        int id = -1;
+        const float4 p = pts[i];
+        if (!(p.x != p.x)) {
+            int c[3];
+            cell_of(g, p, c);
+            id = (c[2] * g->dim[1] + c[1]) * g->dim[0] + c[0];
+            atomicAdd(&counts[id], 1);
+        }
+        cell_id[i] = id;
+    }
+}
+__global__ void k_knnx_scatter(const float4* __restrict__ pts, const int32_t* __restrict__ lab, int n, const int* __restrict__ cell_id, const int* __restrict__ start,
+                               int* __restrict__ fill, float4* __restrict__ sorted, int2* __restrict__ aux)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        const int id = cell_id[i];
+        if (id < 0) continue;
+        const int at = start[id] + atomicAdd(&fill[id], 1);
+        sorted[at] = pts[i];
+        aux[at] = make_int2(i, lab[i]);   // index in the gathered set, bestIDInEachSurfel
+    }
+}
+__global__ void __launch_bounds__(128) k_knnx_vote(const KnnGrid* __restrict__ g, const int* __restrict__ start, const int* __restrict__ counts, const float4* __restrict__ sorted,
+                                                   const int2* __restrict__ aux, const int* __restrict__ total, int own_lo, int own_n, const float* __restrict__ inst_color,
+                                                   float2* __restrict__ col)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // queries in cell order; only the points this rank exported are queries
+    if (t >= *total) return;
+    const int gi = aux[t].x;
+    if (gi < own_lo || gi >= own_lo + own_n) return;
+    const float4 q = sorted[t];
+    int c[3];
+    cell_of(g, q, c);
+    const int dx = g->dim[0], dy = g->dim[1], dz = g->dim[2];
+    float bd[KNN];
+    unsigned int bs[KNN];   // creation number (tie-break)
+    int bl[KNN];            // label
+#pragma unroll
+    for (int k = 0; k < KNN; k++) { bd[k] = INFINITY; bs[k] = 0xFFFFFFFFu; bl[k] = -1; }
+    const int rmax = max(max(dx, dy), dz);
+    for (int r = 0; r <= rmax; r++) {
+        for (int z = max(c[2] - r, 0); z <= min(c[2] + r, dz - 1); z++)
+            for (int y = max(c[1] - r, 0); y <= min(c[1] + r, dy - 1); y++) {
+                const bool face = abs(z - c[2]) == r || abs(y - c[1]) == r;
+                for (int x = max(c[0] - r, 0); x <= min(c[0] + r, dx - 1); x++) {
+                    if (!face && abs(x - c[0]) != r) continue;
+                    const int id = (z * dy + y) * dx + x, s0 = start[id], s1 = s0 + counts[id];
+                    for (int s = s0; s < s1; s++) {
+                        const float4 p = sorted[s];
+                        const unsigned int j = __float_as_uint(p.w);
+                        const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+                        float d = (ex * ex + ey * ey) + ez * ez;
+                        if (!(d < bd[KNN - 1] || (d == bd[KNN - 1] && j < bs[KNN - 1]))) continue;
+                        unsigned int jj = j;
+                        int ll = aux[s].y;
+#pragma unroll
+                        for (int k = 0; k < KNN; k++) {
+                            const bool before = d < bd[k] || (d == bd[k] && jj < bs[k]);
+                            const float td = before ? bd[k] : d;
+                            const unsigned int ts = before ? bs[k] : jj;
+                            const int tl = before ? bl[k] : ll;
+                            bd[k] = before ? d : bd[k];
+                            bs[k] = before ? jj : bs[k];
+                            bl[k] = before ? ll : bl[k];
+                            d = td; jj = ts; ll = tl;
+                        }
+                    }
+                }
+            }
+        const float safe = (float)r * g->cell * 0.99f;
+        if (bs[KNN - 1] != 0xFFFFFFFFu && bd[KNN - 1] <= safe * safe) break;
+    }
+    int best = -1, bestCount = 0;
+#pragma unroll
+    for (int k = 0; k < KNN; k++) {
+        if (bs[k] == 0xFFFFFFFFu || bl[k] < 0) continue;
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < KNN; m++) cnt += (bs[m] != 0xFFFFFFFFu && bl[m] == bl[k]);
+        if (cnt > bestCount || (cnt == bestCount && bl[k] < best)) { bestCount = cnt; best = bl[k]; }
+    }
+    if (bestCount > 0) col[gi - own_lo].y = inst_color[best];   // (the export is in slot order: export index = slot)
+}
+
 }  // namespace
 
 void ifx_knn_free(ifx* h)
 {
     if (h->d_knn) hipFree(h->d_knn);
     h->d_knn = nullptr; h->knn_cap = 0;
+}
+void ifx_knn_free_all(ifx* h)
+{
+    ifx_knn_free(h);
+    if (h->d_kexp) hipFree(h->d_kexp);
+    h->d_kexp = nullptr;
 }
 
 int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total);
@@ -227,4 +352,60 @@ extern "C" int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n)
     hipStreamSynchronize(h->stream);
     if (d_nbr) hipFree(d_nbr);
     return r;
+}
+
+// ---- flannKnnVoteSurfelMap on a spatially sharded map: export, all-gather by the caller, vote
+extern "C" int ifx_owner_knn_export(ifx_t* h, void** d_points, void** d_labels, int* n)
+{
+    if (!h || !d_points || !d_labels || !n) return IFX_E_INVALID;
+    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_knn_export: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    ifx_vlist_reap(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int cnt = 0;
+    HIPCHK(h, hipMemcpy(&cnt, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
+    if (!h->d_kexp) HIPCHK(h, hipMalloc(&h->d_kexp, (size_t)h->cap * 20));
+    float4* pts = (float4*)h->d_kexp;
+    int32_t* lab = (int32_t*)(pts + h->cap);
+    if (cnt > 0) LAUNCH(h, "knnx_export", dim3(1024), dim3(256), k_knnx_export, h->d_state, (const float4*)h->pc, (const float2*)h->tm, (const uint32_t*)h->seq, h->labels, pts, lab);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *d_points = pts; *d_labels = lab; *n = cnt;
+    return IFX_OK;
+}
+extern "C" int ifx_owner_knn_vote(ifx_t* h, const void* d_all_points, const void* d_all_labels, int n_all, int own_offset)
+{
+    if (!h || !d_all_points || !d_all_labels || n_all < 0 || own_offset < 0) return IFX_E_INVALID;
+    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_knn_vote: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    int own_n = 0;
+    HIPCHK(h, hipMemcpy(&own_n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
+    if (own_offset + own_n > n_all) { h->err = "ifx_owner_knn_vote: this rank's export does not fit the gathered set"; return IFX_E_INVALID; }
+    if (n_all == 0) return IFX_OK;
+    const size_t cells = (size_t)GRID_MAX * GRID_MAX * GRID_MAX, capx = ((size_t)n_all + 3) & ~(size_t)3;
+    const size_t need = 64 + cells * 3 + capx * 7 + 16;   // grid header, counts / starts / fill, cell ids, positions (float4) and (index, label) pairs in cell order
+    if (need > h->knn_cap) {
+        ifx_knn_free(h);
+        HIPCHK(h, hipMalloc(&h->d_knn, need * 4));
+        h->knn_cap = need;
+    }
+    KnnGrid* g = (KnnGrid*)h->d_knn;
+    int* counts = h->d_knn + 64;
+    int* starts = counts + cells;
+    int* fill = starts + cells;
+    int* cell_id = fill + cells;
+    float4* sorted = (float4*)(cell_id + capx);
+    int2* aux = (int2*)(sorted + capx);
+    int* total = (int*)(aux + capx);
+    const float4* pts = (const float4*)d_all_points;
+    const int32_t* lab = (const int32_t*)d_all_labels;
+    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->stream));
+    LAUNCH(h, "knn_bounds_init", dim3(1), dim3(64), k_knn_bounds_init, g);
+    LAUNCH(h, "knnx_bounds", dim3(1024), dim3(256), k_knnx_bounds, pts, n_all, g);
+    LAUNCH(h, "knn_grid", dim3(1), dim3(64), k_knn_grid, g);
+    LAUNCH(h, "knnx_count", dim3(2048), dim3(256), k_knnx_count, pts, n_all, g, cell_id, counts);
+    int r = ifx_scan_exclusive(h, counts, (int)cells, starts, total);
+    if (r) return r;
+    LAUNCH(h, "knnx_scatter", dim3(2048), dim3(256), k_knnx_scatter, pts, lab, n_all, cell_id, starts, fill, sorted, aux);
+    LAUNCH(h, "knnx_vote", dim3(cdiv(n_all, 128)), dim3(128), k_knnx_vote, g, starts, counts, sorted, aux, total, own_offset, own_n, h->d_inst_color, (float2*)h->col);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
 }

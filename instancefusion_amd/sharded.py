@@ -158,6 +158,29 @@ class OwnerShardedElasticFusion:
             if step < 2:
                 self._exchange(4 + step)
 
+    def knn_vote_colour(self):
+        """InstanceFusion::flannKnnVoteSurfelMap on the sharded map: all-gather of every rank's slots (20 B each), exact 10-NN of the owned surfels."""
+        torch, dist = self.torch, self.dist
+        pts, lab = _knn_export(self.ef, torch, self.dev)
+        if dist is None:
+            allp, alll, off = pts, lab, 0
+        else:
+            world, rank = dist.get_world_size(), dist.get_rank()
+            n = torch.tensor([pts.shape[0]], dtype=torch.int64, device=self.dev)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n)
+            ns = [int(x.item()) for x in ns]
+            nmax = max(ns)
+            padp = torch.full((nmax, 4), float("nan"), dtype=torch.float32, device=self.dev); padp[:pts.shape[0]] = pts
+            padl = torch.full((nmax,), -1, dtype=torch.int32, device=self.dev); padl[:lab.shape[0]] = lab
+            gp = [torch.empty_like(padp) for _ in range(world)]; gl = [torch.empty_like(padl) for _ in range(world)]
+            dist.all_gather(gp, padp); dist.all_gather(gl, padl)
+            allp = torch.cat([gp[r][:ns[r]] for r in range(world)]).contiguous()
+            alll = torch.cat([gl[r][:ns[r]] for r in range(world)]).contiguous()
+            off = sum(ns[:rank])
+        torch.cuda.synchronize()
+        self.ef._chk(self.ef.L.ifx_owner_knn_vote(self.ef.handle, C.c_void_p(allp.data_ptr()), C.c_void_p(alll.data_ptr()), int(allp.shape[0]), int(off)), "ifx_owner_knn_vote")
+
     def process_segmentation(self, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True):
         """InstanceFusion::processInstance on the sharded map (same masks on every rank): the owners' partial boxes, model depth and -- when the
         instance table overflows -- eviction statistics are merged at the call's exchange points; labels of the owned surfels: ef.labels()."""
@@ -165,6 +188,16 @@ class OwnerShardedElasticFusion:
         while r == 1:
             self._exchange(200)
             r = self.ef._chk(self.ef.L.ifx_owner_segmentation_resume(self.ef.handle), "ifx_owner_segmentation_resume")
+
+
+def _knn_export(ef, torch, dev):
+    pp, pl, n = C.c_void_p(), C.c_void_p(), C.c_int()
+    ef._chk(ef.L.ifx_owner_knn_export(ef.handle, C.byref(pp), C.byref(pl), C.byref(n)), "ifx_owner_knn_export")
+    if n.value == 0:
+        return torch.zeros((0, 4), dtype=torch.float32, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+    pts = torch.as_tensor(_DevWords(pp.value, n.value * 4, "<f4"), device=dev).view(-1, 4)
+    lab = torch.as_tensor(_DevWords(pl.value, n.value, "<i4"), device=dev)
+    return pts, lab
 
 
 def _seg_begin(ef, rgb, depth, masks, class_ids, frame, superpixels):
@@ -231,3 +264,18 @@ def emulate_owner_segmentation(efs, rgb, depth, masks, class_ids, frame: int, su
         _reduce_by_hand(efs, [_exchange_spec(e, 200) for e in efs])
         rs = [e._chk(e.L.ifx_owner_segmentation_resume(e.handle), "ifx_owner_segmentation_resume") for e in efs]
     assert all(r == 0 for r in rs)
+
+
+def emulate_owner_knn(efs):
+    """The kNN smoothing on the handles of emulate_owner_ranks: the all-gather is a concatenation of the exports in rank order."""
+    import torch
+
+    dev = f"cuda:{efs[0].cfgd['device']}"
+    ex = [_knn_export(e, torch, dev) for e in efs]
+    allp = torch.cat([p for p, _ in ex]).contiguous()
+    alll = torch.cat([l for _, l in ex]).contiguous()
+    torch.cuda.synchronize()
+    off = 0
+    for e, (p, _) in zip(efs, ex):
+        e._chk(e.L.ifx_owner_knn_vote(e.handle, C.c_void_p(allp.data_ptr()), C.c_void_p(alll.data_ptr()), int(allp.shape[0]), int(off)), "ifx_owner_knn_vote")
+        off += int(p.shape[0])

@@ -686,6 +686,11 @@ def test_owner_sharded_instance_emulated(ifx, small_stream, world):
                 calls += 1
                 check(("call", i))
     assert calls >= 2 and (inst_one.labels() >= 0).sum() > 100
+    # flannKnnVoteSurfelMap: exact 10-NN over every rank's surfels (exports all-gathered), the owned surfels recoloured
+    inst_one.flannKnnVoteSurfelMap()
+    sharded.emulate_owner_knn(efs)
+    assert np.array_equal(merged(lambda e, x: e.download()["col"]), one.download()["col"])
+    assert len(np.unique(one.download()["col"][:, 1])) > 2
     # a full table: new classes for every mask of every call until the twenty weakest instances are evicted (exchange points 3 and 1 again)
     i = NF - 1
     masks, cls = synth.canned_masks(st["obj"][i], st["scene"])

@@ -158,3 +158,73 @@ def test_key_image_min_allreduce_gloo():
     want = np.minimum(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], want) and np.array_equal(res[1][2], want)
     assert (want == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() > 0
+
+
+def _segworker(rank, world, port, q):
+    import torch
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w, d = ifd.init("gloo")
+    rng = np.random.RandomState(7)                       # the same "unsharded" data on every rank ...
+    W, H, NB = 320, 240, 40
+    px = rng.randint(0, W * H, 6000)
+    box_of = rng.randint(0, NB, 6000)
+    owner = (px * 7 + px // 13) % world                   # ... of which this rank sees the pixels whose surfel it owns (one owner per pixel)
+    depth = rng.randint(1, 60000, W * H).astype(np.uint16)
+    stat_max, stat_sum = rng.randint(0, 200, (6000,)), rng.randint(0, 50, (6000,))
+
+    def boxes(sel):
+        b = np.tile(np.array([W, 0, H, 0], np.int32), (NB, 1))       # {minX, maxX, minY, maxY} as k_init_bbox leaves them
+        for p, k in zip(px[sel], box_of[sel]):
+            x, y = p % W, p // W
+            b[k] = (min(b[k, 0], x), max(b[k, 1], x), min(b[k, 2], y), max(b[k, 3], y))
+        return b
+
+    mine = owner == rank
+    # exchange point 1: maxima negated (k_bbox_flip), ONE int32 MIN, negated back
+    b = boxes(mine)
+    b[:, 1::2] *= -1
+    t = torch.from_numpy(b.reshape(-1).copy())
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    merged = t.numpy().reshape(NB, 4).copy()
+    merged[:, 1::2] *= -1
+    # exchange point 2: the uint16 model depth, disjoint supports, summed as int32 words
+    part = np.zeros(W * H, np.uint16)
+    sel = np.zeros(W * H, bool); sel[px[mine]] = True
+    part[sel] = depth[sel]
+    t2 = torch.from_numpy(part.view(np.int32).copy())
+    d.all_reduce(t2, op=d.ReduceOp.SUM)
+    # exchange point 3: per-instance maximum (MAX) and sum (SUM) of the vote counters
+    mx, sm = np.zeros(NB, np.int32), np.zeros(NB, np.int32)
+    np.maximum.at(mx, box_of[mine], stat_max[mine].astype(np.int32))
+    np.add.at(sm, box_of[mine], stat_sum[mine].astype(np.int32))
+    t3, t4 = torch.from_numpy(mx), torch.from_numpy(sm)
+    d.all_reduce(t3, op=d.ReduceOp.MAX)
+    d.all_reduce(t4, op=d.ReduceOp.SUM)
+    seen = np.zeros(W * H, bool); seen[px] = True
+    want_depth = np.where(seen, depth, 0).astype(np.uint16)
+    wmx, wsm = np.zeros(NB, np.int32), np.zeros(NB, np.int32)
+    np.maximum.at(wmx, box_of, stat_max.astype(np.int32))
+    np.add.at(wsm, box_of, stat_sum.astype(np.int32))
+    ok = (np.array_equal(merged, boxes(np.ones(6000, bool))) and np.array_equal(t2.numpy().view(np.uint16), want_depth)
+          and np.array_equal(t3.numpy(), wmx) and np.array_equal(t4.numpy(), wsm))
+    q.put((rank, bool(ok)))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_segmentation_exchange_points_gloo():
+    """The three exchange points of a segmentation call on the sharded map (ifx_owner_exchange(h, 200, ...)), with the encodings the
+    library uses -- boxes with negated maxima under one int32 MIN, uint16 depth with disjoint supports summed as int32 words,
+    per-instance MAX / SUM -- over gloo with two ranks: every rank ends with the unsharded values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_segworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

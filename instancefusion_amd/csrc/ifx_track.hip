@@ -302,6 +302,156 @@ __global__ void k_model_down(const DevState* __restrict__ st, const float* __res
     model_tail(st, x, y, dw, dh, res[0], res[1], z, o);
 }
 
+// ---- the model side of the frame tracker in ONE launch: levels 0, 1 and 2 of k_model_l0 / k_model_down for an image whose width is a multiple
+// of 32 and height a multiple of 16.  A block owns an 8 x 4 tile of level 2, i.e. 16 x 8 of level 1 and 32 x 16 of level 0; what the two 5 x 5
+// Gaussian pyr-downs read beyond the tile (level-1 region 19 x 11, level-0 region 41 x 25: depth and intensity only) is recomputed into LDS
+// from the prediction images, the 2 x 2 map resizes chain through LDS.  Same per-pixel arithmetic, same
+// clipped windows: the pyramids are bit-identical to the three launches (tests/test_gpu_parity.py::test_tracker_gputest_pair compares every
+// buffer with the oracle).  Three dependent launches (6.7 + 9.8 + 9.8 us) become one.
+#define MP_R0W 41
+#define MP_R0H 25
+#define MP_R1W 19
+#define MP_R1H 11
+template <typename FD, typename FI>
+__device__ __forceinline__ void pyr_gauss5(int x, int y, int sw, int sh, FD depth_at, FI img_at, float& z, uint8_t& lum)
+{
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+    float sumf = 0, sumi = 0;
+    int cntf = 0, cnti = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+            const float sf = depth_at(cx, cy);      // pyrDownKernelGaussF :332-363
+            if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
+            const int si = img_at(cx, cy);          // pyrDownKernelIntensityGauss :470-500
+            if (si > 0) { sumi += si * g; cnti += (int)g; }
+        }
+    z = (float)(sumf / (float)cntf);
+    lum = cnti ? (uint8_t)f2i_rz(sumi / (float)cnti) : (uint8_t)0;
+}
+__device__ __forceinline__ v3 resize4(float a00, float a01, float a10, float a11, float b00, float b01, float b10, float b11, float c00, float c01, float c10, float c11, bool norm_it)
+{
+    const float qn = qnan_f();
+    v3 n = v3m(qn, qn, qn);
+    if (!((a00 != a00) || (a01 != a01) || (a10 != a10) || (a11 != a11))) {   // resizeMapKernel<normalize>, EF/Cuda/cudafuncs.cu:365-416 (the test looks at the x plane only)
+        n.x = (a00 + a01 + a10 + a11) / 4;
+        n.y = (b00 + b01 + b10 + b11) / 4;
+        n.z = (c00 + c01 + c10 + c11) / 4;
+        if (norm_it) n = normalized(n);
+    }
+    return n;
+}
+struct ModelOut3 { ModelOut l[3]; };
+__global__ __launch_bounds__(256) void k_model_pyr3(const DevState* __restrict__ st, const float* __restrict__ pv, const float* __restrict__ pn, const uint8_t* __restrict__ pi,
+                                                    const float* __restrict__ fv, const float* __restrict__ fn, const uint8_t* __restrict__ fi, int w, int h, float cutoff, ModelOut3 o)
+{
+    __shared__ float s_d0[MP_R0H][MP_R0W];
+    __shared__ uint8_t s_i0[MP_R0H][MP_R0W];
+    __shared__ float s_d1[MP_R1H][MP_R1W];
+    __shared__ uint8_t s_i1[MP_R1H][MP_R1W];
+    __shared__ float s_v0[6][16][33];  // level-0 vertex (0..2) and normal (3..5) of the tile (padded rows)
+    __shared__ float s_v1[6][8][16];   // level-1 vertex (0..2) and normal (3..5) of the tile
+    const int tid = threadIdx.x;
+    const int w1 = w / 2, h1 = h / 2, w2 = w / 4, h2 = h / 4;
+    const int x2_0 = blockIdx.x * 8, y2_0 = blockIdx.y * 4, x1_0 = 2 * x2_0, y1_0 = 2 * y2_0, x0_0 = 2 * x1_0, y0_0 = 2 * y1_0;
+    const int r1x = x1_0 - 2, r1y = y1_0 - 2;   // origin of the level-1 region
+    const int r0x = x0_0 - 6, r0y = y0_0 - 6;   // origin of the level-0 region
+    const bool fill = fv && !st->dense_enough;
+    const float* sv = fill ? fv : pv;
+    const float* sn = fill ? fn : pn;
+    const uint8_t* si = fill ? fi : pi;
+    const float qn = qnan_f();
+    // ---- level 0, depth and intensity of the region (k_model_l0's z and luminance)
+    for (int t = tid; t < MP_R0W * MP_R0H; t += 256) {
+        const int ly = t / MP_R0W, lx = t - ly * MP_R0W, x = r0x + lx, y = r0y + ly;
+        float z = qn;
+        uint8_t lum = 0;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            const float vz = sv[(size_t)(y * w + x) * 4 + 2];
+            const uint8_t* s = si + (size_t)(y * w + x) * 4;
+            z = (vz > cutoff || vz <= 0) ? qn : vz;
+            lum = (uint8_t)(int)((float)s[0] * 0.114f + (float)s[1] * 0.299f + (float)s[2] * 0.587f);
+        }
+        s_d0[ly][lx] = z;
+        s_i0[ly][lx] = lum;
+    }
+    __syncthreads();
+    // ---- level 0 of the tile: two pixels per thread, row-major (coalesced loads and stores); vertex and normal also go to LDS for the 2 x 2 resize
+    auto d0_at = [&](int cx, int cy) { return s_d0[cy - r0y][cx - r0x]; };
+    auto i0_at = [&](int cx, int cy) { return (int)s_i0[cy - r0y][cx - r0x]; };
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = tid + u * 256, lx = t & 31, ly = t >> 5, x = x0_0 + lx, y = y0_0 + ly;
+        const float4 v = reinterpret_cast<const float4*>(sv)[y * w + x];
+        const float4 n = reinterpret_cast<const float4*>(sn)[y * w + x];
+        const bool ok = !(v.z == 0);
+        const v3 vs = v3m(ok ? v.x : qn, ok ? v.y : qn, ok ? v.z : qn), ns = v3m(ok ? n.x : qn, ok ? n.y : qn, ok ? n.z : qn);
+        const ModelOut& o0 = o.l[0];
+        o0.vcam[y * w + x] = vs.x; o0.vcam[(y + h) * w + x] = vs.y; o0.vcam[(y + 2 * h) * w + x] = vs.z;
+        o0.ncam[y * w + x] = ns.x; o0.ncam[(y + h) * w + x] = ns.y; o0.ncam[(y + 2 * h) * w + x] = ns.z;
+        const float z = s_d0[y - r0y][x - r0x];
+        o0.depth[y * w + x] = z;
+        o0.img[y * w + x] = s_i0[y - r0y][x - r0x];
+        model_tail(st, x, y, w, h, vs, ns, z, o0);
+        s_v0[0][ly][lx] = vs.x; s_v0[1][ly][lx] = vs.y; s_v0[2][ly][lx] = vs.z;
+        s_v0[3][ly][lx] = ns.x; s_v0[4][ly][lx] = ns.y; s_v0[5][ly][lx] = ns.z;
+    }
+    __syncthreads();
+    // ---- threads 0..127: level-1 pixel (lx1, ly1) of the tile; 128..255: level-1 depth / intensity of the halo
+    if (tid < 128) {
+        const int lx1 = tid & 15, ly1 = tid >> 4, x1 = x1_0 + lx1, y1 = y1_0 + ly1;
+        const int ax = 2 * lx1, ay = 2 * ly1;
+        const v3 v1 = resize4(s_v0[0][ay][ax], s_v0[0][ay][ax + 1], s_v0[0][ay + 1][ax], s_v0[0][ay + 1][ax + 1], s_v0[1][ay][ax], s_v0[1][ay][ax + 1], s_v0[1][ay + 1][ax], s_v0[1][ay + 1][ax + 1],
+                              s_v0[2][ay][ax], s_v0[2][ay][ax + 1], s_v0[2][ay + 1][ax], s_v0[2][ay + 1][ax + 1], false);
+        const v3 n1 = resize4(s_v0[3][ay][ax], s_v0[3][ay][ax + 1], s_v0[3][ay + 1][ax], s_v0[3][ay + 1][ax + 1], s_v0[4][ay][ax], s_v0[4][ay][ax + 1], s_v0[4][ay + 1][ax], s_v0[4][ay + 1][ax + 1],
+                              s_v0[5][ay][ax], s_v0[5][ay][ax + 1], s_v0[5][ay + 1][ax], s_v0[5][ay + 1][ax + 1], true);
+        float z1;
+        uint8_t l1;
+        pyr_gauss5(x1, y1, w, h, d0_at, i0_at, z1, l1);
+        const ModelOut& o1 = o.l[1];
+        o1.vcam[y1 * w1 + x1] = v1.x; o1.vcam[(y1 + h1) * w1 + x1] = v1.y; o1.vcam[(y1 + 2 * h1) * w1 + x1] = v1.z;
+        o1.ncam[y1 * w1 + x1] = n1.x; o1.ncam[(y1 + h1) * w1 + x1] = n1.y; o1.ncam[(y1 + 2 * h1) * w1 + x1] = n1.z;
+        o1.depth[y1 * w1 + x1] = z1;
+        o1.img[y1 * w1 + x1] = l1;
+        model_tail(st, x1, y1, w1, h1, v1, n1, z1, o1);
+        s_d1[y1 - r1y][x1 - r1x] = z1;
+        s_i1[y1 - r1y][x1 - r1x] = l1;
+        s_v1[0][ly1][lx1] = v1.x; s_v1[1][ly1][lx1] = v1.y; s_v1[2][ly1][lx1] = v1.z;
+        s_v1[3][ly1][lx1] = n1.x; s_v1[4][ly1][lx1] = n1.y; s_v1[5][ly1][lx1] = n1.z;
+    } else {
+        // the 19 x 11 level-1 region minus the 16 x 8 tile: 81 pixels
+        for (int t = tid - 128; t < MP_R1W * MP_R1H; t += 128) {
+            const int ly = t / MP_R1W, lx = t - ly * MP_R1W, x1 = r1x + lx, y1 = r1y + ly;
+            if (lx >= 2 && lx < 18 && ly >= 2 && ly < 10) continue;   // the tile itself (threads 0..127)
+            float z1 = qn;
+            uint8_t l1 = 0;
+            if (x1 >= 0 && x1 < w1 && y1 >= 0 && y1 < h1) pyr_gauss5(x1, y1, w, h, d0_at, i0_at, z1, l1);
+            s_d1[ly][lx] = z1;
+            s_i1[ly][lx] = l1;
+        }
+    }
+    __syncthreads();
+    // ---- level 2: 32 pixels
+    if (tid < 32) {
+        const int lx2 = tid & 7, ly2 = tid >> 3, x2 = x2_0 + lx2, y2 = y2_0 + ly2;
+        const int ax = 2 * lx2, ay = 2 * ly2;
+        const v3 v2 = resize4(s_v1[0][ay][ax], s_v1[0][ay][ax + 1], s_v1[0][ay + 1][ax], s_v1[0][ay + 1][ax + 1], s_v1[1][ay][ax], s_v1[1][ay][ax + 1], s_v1[1][ay + 1][ax], s_v1[1][ay + 1][ax + 1],
+                              s_v1[2][ay][ax], s_v1[2][ay][ax + 1], s_v1[2][ay + 1][ax], s_v1[2][ay + 1][ax + 1], false);
+        const v3 n2 = resize4(s_v1[3][ay][ax], s_v1[3][ay][ax + 1], s_v1[3][ay + 1][ax], s_v1[3][ay + 1][ax + 1], s_v1[4][ay][ax], s_v1[4][ay][ax + 1], s_v1[4][ay + 1][ax], s_v1[4][ay + 1][ax + 1],
+                              s_v1[5][ay][ax], s_v1[5][ay][ax + 1], s_v1[5][ay + 1][ax], s_v1[5][ay + 1][ax + 1], true);
+        float z2;
+        uint8_t l2;
+        pyr_gauss5(x2, y2, w1, h1, [&](int cx, int cy) { return s_d1[cy - r1y][cx - r1x]; }, [&](int cx, int cy) { return (int)s_i1[cy - r1y][cx - r1x]; }, z2, l2);
+        const ModelOut& o2 = o.l[2];
+        o2.vcam[y2 * w2 + x2] = v2.x; o2.vcam[(y2 + h2) * w2 + x2] = v2.y; o2.vcam[(y2 + 2 * h2) * w2 + x2] = v2.z;
+        o2.ncam[y2 * w2 + x2] = n2.x; o2.ncam[(y2 + h2) * w2 + x2] = n2.y; o2.ncam[(y2 + 2 * h2) * w2 + x2] = n2.z;
+        o2.depth[y2 * w2 + x2] = z2;
+        o2.img[y2 * w2 + x2] = l2;
+        model_tail(st, x2, y2, w2, h2, v2, n2, z2, o2);
+    }
+}
+
 // ======================================================================= reductions (a4-a7)
 
 #define RED_THREADS 256
@@ -1976,12 +2126,20 @@ static void tracker_init_model(ifx* h, DevState* st, Pyr& p, float icp_weight, c
     const ifx_config& c = h->cfg;
     const int rgb = icp_weight < 100;
     const int iterations[3] = {c.fast_odom ? 3 : 10, c.pyramid ? 5 : 0, c.pyramid ? 4 : 0};
+    ModelOut3 o3;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         const float div = (float)(1 << i);
-        ModelOut o;
+        ModelOut& o = o3.l[i];
         o.vcam = p.vmap_cam[i]; o.ncam = p.nmap_cam[i]; o.depth = p.last_depth[i]; o.img = p.last_img[i];
         o.vprev = p.vmap_prev[i]; o.nprev = p.nmap_prev[i]; o.cloud = (rgb && iterations[i] > 0) ? p.cloud[i] : nullptr;
         o.invFx = 1.0f / (c.fx / div); o.invFy = 1.0f / (c.fy / div); o.cx = c.cx / div; o.cy = c.cy / div;
+    }
+    if (h->opt_model_fused && IFX_NUM_PYRS == 3 && h->w % 32 == 0 && h->h % 16 == 0 && fv) {   // the three levels in one launch
+        LAUNCH(h, "model_pyr3", dim3(h->w / 32, h->h / 16), dim3(256), k_model_pyr3, st, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o3);
+        return;
+    }
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        const ModelOut& o = o3.l[i];
         if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, st, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o);
         else LAUNCH(h, "model_down", G2(p.w[i], p.h[i]), B2, k_model_down, st, p.vmap_cam[i - 1], p.nmap_cam[i - 1], p.last_depth[i - 1], p.last_img[i - 1], p.w[i - 1], p.h[i - 1], o);
     }

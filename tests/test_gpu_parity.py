@@ -569,13 +569,15 @@ def test_persistent_level_kernel_is_bit_identical(ifx):
     K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
     st = synth.make_stream(8, W, H, noise=True, loop_len=90, **K)
     out = []
-    for persist in (0, 1):
+    for persist, fused in ((0, 0), (1, 0), (0, 1)):   # (0, 1): the three levels of the model pyramid in one launch (option model_fused; k_model_pyr3) -- same pyramids
         g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
         g.set_option("gn_persist", persist)
+        g.set_option("model_fused", fused)
         out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(8)]), g.download()))
         g.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in MAP_KEYS)
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0])
+        assert all(np.array_equal(out[0][1][k], other[1][k]) for k in MAP_KEYS)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -716,12 +716,24 @@ extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const 
         if (r) return r;
     }
     h->oseg_state = 1;
-    return oseg_launch_bboxes(h);
+    r = oseg_launch_bboxes(h);
+    if (r < 0) { h->oseg_state = 0; h->oseg_pending = 0; }
+    return r;
 }
+static int oseg_resume(ifx* h);
 extern "C" int ifx_owner_segmentation_resume(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
     if (!h->oseg_state) { h->err = "no segmentation call in flight"; return IFX_E_STATE; }
+    const int r = oseg_resume(h);
+    if (r < 0) {   // a failed call is over: the next _begin starts from scratch
+        h->oseg_state = 0; h->oseg_pending = 0;
+        if (h->oseg_ev) { h->event_pool.push_back(h->oseg_ev); h->oseg_ev = nullptr; }
+    }
+    return r;
+}
+static int oseg_resume(ifx* h)
+{
     const int nm = h->oseg_nm, P = h->P;
     int r;
     switch (h->oseg_state) {

@@ -243,6 +243,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "icp_px") h->opt_icp_px = value;
     else if (s == "model_fused") h->opt_model_fused = value;
     else if (s == "gn_persist") h->opt_gn_persist = value;
     else if (s == "raster_lds") h->opt_raster_lds = value;

@@ -202,6 +202,7 @@ struct ifx {
     int opt_compact_divisor = 8;        // housekeeping: compact when tombstones exceed count / divisor (or capacity gets tight)
     int opt_kernel_timing = 0;
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
+    int opt_icp_px = 0;              // ICP and residual reductions on the same pixels of one thread, all loads in two batches (k_icp_residual_px; bits: 1 level 0, 2 levels 1-2, 4 one pixel per thread); measured slower: off
     int opt_model_fused = 0;         // model pyramid of the frame tracker in one launch (k_model_pyr3) when the image size allows; measured equal to the three launches (28 vs 27 us): off
     int opt_gn_persist = 0;          // all Gauss-Newton iterations of a pyramid level in one persistent launch (k_gn_level) when its grid fits the GPU; measured slower: off
     int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>

@@ -837,6 +837,125 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
     }
 }
 
+// The two reductions of k_icp_residual on the SAME pixels of one thread: PX pixels per thread, no loop.  Every coalesced load of the thread -- the ICP's
+// vertex / normal and the residual pass's window, gradients, depth, intensity -- leaves in one batch, every gather (model vertex / normal, warped depth
+// and intensity) in a second one: two memory round trips for the whole launch, whatever the level, where the split form runs an ICP block through three
+// pipelined rounds at level 0 and needs 1 656 blocks (more than fit the GPU at once).  Same rows, same exact sums.
+template <int PX, bool CHECK_SKIP>
+__global__ __launch_bounds__(RED_THREADS) void k_icp_residual_px(const DevState* __restrict__ st, int nb, int w, int h, double* __restrict__ gacc, int* __restrict__ gres, PairArgs a)
+{
+    __builtin_assume(st != nullptr);
+    if (CHECK_SKIP && st->skip) return;
+    const int N = w * h, bid = blockIdx.x, tid = threadIdx.x;
+    float Rcurr[9], Rprev_inv[9], krk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rcurr[k] = st->Rcurr[k]; Rprev_inv[k] = st->Rprev_inv[k]; krk[k] = st->krkinv[k]; }
+    const v3 tc = v3m(st->tcurr[0], st->tcurr[1], st->tcurr[2]), tp = v3m(st->tprev[0], st->tprev[1], st->tprev[2]);
+    const float kt0 = st->kt[0], kt1 = st->kt[1], kt2 = st->kt[2];
+    const int border = 16;
+    // ---- batch 1: everything that is addressed by the pixel itself
+    v3 vcurr[PX], ncurr[PX];
+    float d1[PX], nif[PX];
+    short gx[PX], gy[PX];
+    uint32_t r4[PX][4];
+    bool okb[PX], inp[PX];
+    int xy[PX], pix[PX];
+#pragma unroll
+    for (int u = 0; u < PX; u++) {
+        const int p = (u * nb + bid) * RED_THREADS + tid;
+        inp[u] = p < N;
+        const int pp = inp[u] ? p : 0;
+        pix[u] = p;
+        const int i = pp / w, j0 = pp - i * w;
+        xy[u] = (i << 16) | j0;
+        vcurr[u] = v3m(a.vmap_curr[pp], a.vmap_curr[pp + N], a.vmap_curr[pp + 2 * N]);
+        ncurr[u] = v3m(a.nmap_curr[pp], a.nmap_curr[pp + N], a.nmap_curr[pp + 2 * N]);
+        okb[u] = inp[u] && i >= border && i < h - border && j0 >= border && j0 < w - border && j0 < w - 5 && i < h - 1;
+        const int ci = okb[u] ? i : 16, cj = okb[u] ? j0 : 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&r4[u][q], a.nextImage + (ci + q - 2) * w + cj - 2, 4);
+        gx[u] = a.dIdx[pp]; gy[u] = a.dIdy[pp];
+        d1[u] = a.nextDepth[pp];
+        nif[u] = (float)a.nextImage[pp];
+    }
+    // ---- projections, then batch 2: every gather
+    v3 vcurr_g[PX], vprev[PX], nprev[PX];
+    bool inb[PX], cand[PX];
+    int gj[PX];
+    float td1[PX], d0[PX], lif[PX];
+#pragma unroll
+    for (int u = 0; u < PX; u++) {
+        if (!inp[u]) vcurr[u].x = qnan_f();
+        vcurr_g[u] = mulp(Rcurr, vcurr[u]) + tc;
+        const v3 vcurr_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
+        const int ux = f2i_rn(vcurr_cp.x * a.fx / vcurr_cp.z + a.cx);
+        const int uy = f2i_rn(vcurr_cp.y * a.fy / vcurr_cp.z + a.cy);
+        inb[u] = !(vcurr[u].x != vcurr[u].x) && !(ux < 0 || uy < 0 || ux >= w || uy >= h || vcurr_cp.z < 0);
+        const int j = inb[u] ? uy * w + ux : 0;
+        bool valid = true;
+#pragma unroll
+        for (int q = 0; q < 4; q++) valid = valid & (((r4[u][q] - 0x01010101u) & ~r4[u][q] & 0x80808080u) == 0u);
+        const float mTwo = (float)((gx[u] * gx[u]) + (gy[u] * gy[u]));
+        const bool c0 = okb[u] & valid & (mTwo >= a.minScale) & !(d1[u] != d1[u]);
+        const int y = xy[u] >> 16, x = xy[u] & 0xFFFF;
+        td1[u] = (float)(d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
+        const int u0 = f2i_rn((d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
+        const int v0 = f2i_rn((d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
+        cand[u] = c0 & ((u0 >= 0) & (v0 >= 0) & (u0 < w) & (v0 < h));
+        gj[u] = cand[u] ? v0 * w + u0 : 0;
+        vprev[u] = v3m(a.vmap_prev[j], a.vmap_prev[j + N], a.vmap_prev[j + 2 * N]);
+        nprev[u] = v3m(a.nmap_prev[j], a.nmap_prev[j + N], a.nmap_prev[j + 2 * N]);
+        d0[u] = a.lastDepth[gj[u]];
+        lif[u] = (float)a.lastImage[gj[u]];
+    }
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
+    int cnt = 0, sig = 0;
+#pragma unroll
+    for (int u = 0; u < PX; u++) {
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool found = false;
+        if (inb[u]) {
+            const v3 ncurr_g = mulp(Rcurr, ncurr[u]);
+            const float dist = norm(vprev[u] - vcurr_g[u]);
+            const float sine = norm(cross(ncurr_g, nprev[u]));
+            found = (sine < a.angleThres && dist <= a.distThres && !(ncurr[u].x != ncurr[u].x) && !(nprev[u].x != nprev[u].x));
+            if (found) {
+                const v3 s_cp = mulp(Rprev_inv, vcurr_g[u] - tp);
+                const v3 d_cp = mulp(Rprev_inv, vprev[u] - tp);
+                const v3 n_cp = mulp(Rprev_inv, nprev[u]);
+                const v3 c = cross(s_cp, n_cp);
+                row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+                row[3] = c.x; row[4] = c.y; row[5] = c.z;
+                row[6] = dot(n_cp, s_cp - d_cp);
+            }
+        }
+        products7<0>(row, found, acc);
+        const bool hit = cand[u] & (d0[u] > 0) & (fabsf(td1[u] - d0[u]) <= a.maxDepthDelta) & (lif[u] != 0.f);
+        const int v0 = gj[u] / w, u0 = gj[u] - v0 * w;
+        const float diff = nif[u] - lif[u];
+        Corres8 c8;
+        c8.zx = hit ? (short)u0 : (short)-1; c8.zy = hit ? (short)v0 : (short)-1;
+        c8.diff = hit ? diff : 0.f;
+        cnt += hit ? 1 : 0;
+        sig += hit ? (int)(diff * diff) : 0;
+        if (inp[u]) a.corres[pix[u]] = c8;
+    }
+    block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
+    __shared__ int lds2[RED_WAVES][2];
+    const int lane = tid & 63, wid = tid >> 6;
+    cnt = wave_sum_i(cnt);
+    sig = wave_sum_i(sig);
+    if (lane == 0) { lds2[wid][0] = cnt; lds2[wid][1] = sig; }
+    __syncthreads();
+    if (tid < 2) {
+        int s2 = 0;
+        for (int wv = 0; wv < RED_WAVES; wv++) s2 += lds2[wv][tid];
+        if (s2) atomicAdd(&gres[tid], s2);
+    }
+}
+
 // RGBReduction, EF/Cuda/reduce.cu:494-619.  sigma is either explicit (stage API) or derived from the
 // residual pass's block partials with the reference's precedence quirk (EF/Utils/RGBDOdometry.cpp:461).
 __device__ __forceinline__ void rgb_step_body(int bid, int nblk, const Corres8* __restrict__ corres, float sigma_explicit, const int* __restrict__ res_partials,
@@ -2278,9 +2397,14 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             }
         }
         iters_done += iterations[i];
+        // both reductions on the same pixels of one thread (k_icp_residual_px); option bits: 1 = at level 0, 2 = at levels 1 and 2, 4 = one pixel per thread at level 0 too
+        const bool px_form = frame_tracker && icp && rgb && !lds_tiles && (i == 0 ? (h->opt_icp_px & 1) : (h->opt_icp_px & 2));
+        const bool px_two = !(h->opt_icp_px & 4);
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
-            if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            if (px_form && px_two && n > 150000) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS * 2)), dim3(RED_THREADS), (k_icp_residual_px<2, false>), st, cdiv(n, RED_THREADS * 2), pa.w, pa.h, gacc, gres, pa);
+            else if (px_form) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS)), dim3(RED_THREADS), (k_icp_residual_px<1, false>), st, cdiv(n, RED_THREADS), pa.w, pa.h, gacc, gres, pa);
+            else if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
             else if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
             else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
             StepArgs sa2;

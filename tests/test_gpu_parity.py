@@ -569,10 +569,13 @@ def test_persistent_level_kernel_is_bit_identical(ifx):
     K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
     st = synth.make_stream(8, W, H, noise=True, loop_len=90, **K)
     out = []
-    for persist, fused in ((0, 0), (1, 0), (0, 1)):   # (0, 1): the three levels of the model pyramid in one launch (option model_fused; k_model_pyr3) -- same pyramids
+    # (0, 1, 0): the three levels of the model pyramid in one launch (option model_fused; k_model_pyr3); (0, 0, 3): the ICP and residual reductions on the
+    # same pixels of one thread (option icp_px; k_icp_residual_px) -- the same pyramids / rows / sums
+    for persist, fused, px in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 3)):
         g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
         g.set_option("gn_persist", persist)
         g.set_option("model_fused", fused)
+        g.set_option("icp_px", px)
         out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(8)]), g.download()))
         g.close()
     for other in out[1:]:

@@ -263,9 +263,10 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     float4 p4 = pc[li];
     float2 t2 = make_float2(0.f, 0.f);
     if (ct || tap) t2 = tm[li];
+    float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (index_id) n4 = nr[li];   // (with the position and the times: one round trip for the winner's record)
     v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
     if (index_id) {
-        float4 n4 = nr[li];
         v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
         index_id[k] = id;
         vc[k] = make_float4(p.x, p.y, p.z, p4.w);
@@ -415,12 +416,24 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
     int k = y * c.w + x;
+    // everything addressed by the pixel itself leaves in one batch: the three keys and, for the fill-in, the frame's colour and filtered depth
+    // (one after the other, each behind the previous test, they were five dependent round trips)
     unsigned long long key = keys[k];
+    const unsigned long long bk0 = ids_out ? both_keys[k] : IFX_KEY_EMPTY, ik0 = ids_out ? id_keys[k] : IFX_KEY_EMPTY;
+    uint8_t f_r = 0, f_g = 0, f_b = 0;
+    uint16_t f_d = 0, f_dx = 0, f_dy = 0;
+    if (fv) {
+        f_r = rgb[k * 3]; f_g = rgb[k * 3 + 1]; f_b = rgb[k * 3 + 2];
+        f_d = depth_filt[k];
+        f_dx = depth_filt[y * c.w + clampi(x + 1, 0, c.w - 1)];
+        f_dy = depth_filt[clampi(y + 1, 0, c.h - 1) * c.w + x];
+    }
+    asm volatile("" ::"v"((unsigned int)key), "v"((unsigned int)bk0), "v"((unsigned int)ik0), "v"((unsigned int)f_r), "v"((unsigned int)f_d), "v"((unsigned int)f_dx), "v"((unsigned int)f_dy));
     keys[k] = IFX_KEY_EMPTY;
     if (ids_out) {   // k_ids_resolve of the id render that shared the raster pass; `both` holds the pixels common to the two renders
-        const unsigned long long bk = both_keys[k];
+        const unsigned long long bk = bk0;
         both_keys[k] = IFX_KEY_EMPTY;
-        unsigned long long ik = id_keys[k];
+        unsigned long long ik = ik0;
         id_keys[k] = IFX_KEY_EMPTY;
         ik = ik < bk ? ik : bk;
         key = key < bk ? key : bk;
@@ -456,15 +469,14 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
     // fill-in
     float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
-    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
+    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(f_r, f_g, f_b, 255);
     else fimg[k] = io;
-    float zc = (float)depth_filt[k] / 1000.0f;
+    float zc = (float)f_d / 1000.0f;
     if (vo.z == 0) fv[k] = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
     else fv[k] = vo;
     if (no.z == 0) {
         v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
-        int xr = clampi(x + 1, 0, c.w - 1), yd = clampi(y + 1, 0, c.h - 1);
-        float zx = (float)depth_filt[y * c.w + xr] / 1000.0f, zy = (float)depth_filt[yd * c.w + x] / 1000.0f;
+        float zx = (float)f_dx / 1000.0f, zy = (float)f_dy / 1000.0f;
         v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
         v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
         v3 nn = normalized(cross(vx - vp, vy - vp));

@@ -141,8 +141,12 @@ struct FrameSlot {
 
 
 // ---- cached view list (ifx_map.hip "View list"): margins and the per-frame decision, shared by the kernels that commit a pose
+#ifndef VL_ROT
 #define VL_ROT 0.0523599f      // 3 degrees
+#endif
+#ifndef VL_TRANS
 #define VL_TRANS 0.06f         // metres
+#endif
 #define VL_MAX_AGE 32
 #define LIST_V 3
 #define LIST_VI 4

@@ -3,11 +3,11 @@
 # rebuilds $SRC.o (default ifx_track) with the extra flags into a scratch object, relinks the library, runs the bench, restores the regular library
 cd "$(dirname "$0")/.."
 X="$1"; shift
-SRC=${SRC:-ifx_track}
-OBJS=""; for o in ifx_api ifx_track ifx_map ifx_instance ifx_slic ifx_knn; do if [ $o = $SRC ]; then OBJS="$OBJS /tmp/t_v.o"; else OBJS="$OBJS $o.o"; fi; done
+SRC=${SRC:-ifx_track}     # one file, or several: SRC="ifx_track ifx_map ifx_api"
+OBJS=""; for o in ifx_api ifx_track ifx_map ifx_instance ifx_slic ifx_knn; do if [[ " $SRC " == *" $o "* ]]; then OBJS="$OBJS /tmp/v_$o.o"; else OBJS="$OBJS $o.o"; fi; done
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-value -Wno-unused-result"
 cp instancefusion_amd/libifx.so /tmp/libifx.keep
-( cd instancefusion_amd/csrc && /opt/rocm/bin/hipcc $F $X -c $SRC.hip -o /tmp/t_v.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libifx.so $OBJS ) || { cp /tmp/libifx.keep instancefusion_amd/libifx.so; exit 1; }
+( cd instancefusion_amd/csrc && for f in $SRC; do /opt/rocm/bin/hipcc $F $X -c $f.hip -o /tmp/v_$f.o || exit 1; done && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libifx.so $OBJS ) || { cp /tmp/libifx.keep instancefusion_amd/libifx.so; exit 1; }
 python bench.py --gpus 1 --steps 200 --warmup 30 --no-cpu-baseline --extras-frames 0 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']

@@ -6,9 +6,8 @@ What is sharded (DESIGN.md "Multi-GPU"):
 * `owner_of` is the owner function of the spatially sharded map (8 cm voxel -> Morton code -> mod n_ranks), the
   Python twin of ifx_owner_of_point: `ifx_map_upload` and the append kernel of a handle created with n_ranks > 1 keep the surfels it
   selects (instancefusion_amd/sharded.py: OwnerShardedElasticFusion).
-* `allreduce_normal_equations`: the one collective a row-tiled tracker would need (2 x 29 sums).  The sums are exact integers
-  in f64 (DESIGN.md "Arithmetic contract"), so an all-reduce(SUM) of them is exact and order-independent; the product keeps the
-  tracker replicated (DESIGN.md section 7 has the numbers), this helper and its gloo test document the exchange.
+* The tracker stays replicated (DESIGN.md section 7 has the numbers); the collective a row-tiled tracker would need -- an all-reduce of the
+  2 x 29 exact sums -- is exercised in tests/test_dist_cpu.py only.
 """
 from __future__ import annotations
 
@@ -77,17 +76,3 @@ def owner_of(pos: np.ndarray, n_ranks: int) -> np.ndarray:
     v = np.floor(p / np.float32(VOXEL_M)).astype(np.int64) + 512
     code = _part1by2_10(v[..., 0]) | (_part1by2_10(v[..., 1]) << np.uint32(1)) | (_part1by2_10(v[..., 2]) << np.uint32(2))
     return (code % np.uint32(n_ranks)).astype(np.int32)
-
-
-def allreduce_normal_equations(icp29: np.ndarray, rgb29: np.ndarray, dist):
-    """The only collective of the tracking stage when image tiles are sharded: 2 x 29 floats summed
-    over ranks in one message (latency-bound)."""
-    buf = np.concatenate([np.asarray(icp29, np.float64), np.asarray(rgb29, np.float64)])
-    if dist is None:
-        return buf[:29].copy(), buf[29:].copy()
-    import torch
-
-    t = torch.from_numpy(buf)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    out = t.numpy()
-    return out[:29].copy(), out[29:].copy()

@@ -9,6 +9,18 @@ import torch.multiprocessing as mp
 from instancefusion_amd import dist as ifd
 
 
+def _allreduce_normal_equations(icp29, rgb29, dist):
+    """The one collective a row-tiled tracker would need: 2 x 29 sums in one message.  The sums are exact integers in f64 (DESIGN.md
+    "Arithmetic contract"), so an all-reduce(SUM) of them is exact and order-independent.  (The product keeps the tracker replicated.)"""
+    import torch
+
+    buf = np.concatenate([np.asarray(icp29, np.float64), np.asarray(rgb29, np.float64)])
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    out = t.numpy()
+    return out[:29].copy(), out[29:].copy()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -28,7 +40,7 @@ def _worker(rank, world, port, q):
     rng = np.random.RandomState(7)
     rows = rng.standard_normal((480, 29))
     part = rows[rank::world].sum(0)
-    icp, rgb = ifd.allreduce_normal_equations(part, 2 * part, d)
+    icp, rgb = _allreduce_normal_equations(part, 2 * part, d)
     ok = np.allclose(icp, rows.sum(0)) and np.allclose(rgb, 2 * rows.sum(0))
     q.put((rank, dt, rate, bool(ok)))
     d.barrier()
@@ -98,7 +110,7 @@ def _sumworker(rank, world, port, q):
     # the tracker's collective: exact (integer-valued) f64 sums -> the all-reduce is exact whatever the association order
     part = np.floor(rng.standard_normal((480, 29)) * 2.0 ** 20)[rank::world].sum(0)
     tot = np.floor(np.random.RandomState(5).standard_normal((4000, 4)) * 0 + 0)  # (keeps the stream of `rng` aligned across ranks)
-    icp, _ = ifd.allreduce_normal_equations(part, part, d)
+    icp, _ = _allreduce_normal_equations(part, part, d)
     q.put((rank, full.view(np.int32).copy(), t.numpy().copy(), icp))
     d.barrier()
     d.destroy_process_group()

@@ -243,6 +243,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "labels_incremental") { h->opt_labels_incremental = value; h->labels_stale_all = 1; }
     else if (s == "icp_px") h->opt_icp_px = value;
     else if (s == "model_fused") h->opt_model_fused = value;
     else if (s == "gn_persist") h->opt_gn_persist = value;
@@ -942,6 +943,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     HIPCHK(h, hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(h->upd_owner, 0xFF, (size_t)h->cap * 4));
     HIPCHK(h, hipMemset(h->labels, 0xFF, (size_t)h->cap * 4));
+    h->labels_stale_all = 1;   // uploaded votes: the next segmentation call scans the labels of the whole map
     return IFX_OK;
 }
 

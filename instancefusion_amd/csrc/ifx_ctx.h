@@ -218,6 +218,8 @@ struct ifx {
     std::vector<int> oseg_cmp, oseg_bbox, oseg_class;
     hipEvent_t oseg_ev = nullptr;
     void* d_kexp = nullptr;            // ifx_owner_knn_export: [cap] float4 (x, y, z, creation number) + [cap] int32 labels
+    int labels_stale_all = 1;        // the next segmentation call re-scans the labels of ALL surfels (after create / upload / table eviction); otherwise only what the call can have changed
+    int opt_labels_incremental = 1;
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
     int opt_view_blocks = 0, opt_clean_blocks = 0, opt_index_blocks = 0;   // grids of the view-list kernels (0: LIST_BLOCKS)
     int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)

@@ -194,6 +194,52 @@ __global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __
 
 // countAndColourSurfelMapKernel, IF/Core/InstanceFusionCuda.cu:1158-1200: the label scan.  Per surfel
 // 192 B of votes read as 12 coalesced float4 plane loads + 8 B colour RMW + 4 B label.
+// countAndColourSurfelMapKernel restricted to what a segmentation call can have changed.  A call changes votes only of the surfels under the
+// id image (k_vote_update), so labels and colours of all other surfels are what the previous scan left -- except the surfels created since then,
+// which the full scan would move from "no colour" (0) to the default colour: pass A does that from 16 bytes per slot, pass B redoes the arg-max
+// for the surfel under every pixel (192 bytes each, <= P of them) exactly as the full scan would.  5 M surfels: 83 MB + <= 59 MB instead of
+// 1.1 GB.  Anything that rewrites votes wholesale (upload, table eviction) sets ifx::labels_stale_all and the next call scans everything.
+__global__ __launch_bounds__(256) void k_colour_default(const DevState* __restrict__ st, const float2* __restrict__ tm, float2* __restrict__ col)
+{
+    const float defaultColor = 7434609;
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        const float2 c = col[i];
+        if (c.y == 0 && tm[i].y > DEAD_TIME) col[i] = make_float2(c.x, defaultColor);   // (votes untouched since creation: no label, the default colour)
+    }
+}
+__global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restrict__ st, const int32_t* __restrict__ ids, int P, const float4* __restrict__ votes, int cap,
+                                                         const float2* __restrict__ tm, float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels,
+                                                         IdMap im)
+{
+    const float defaultColor = 7434609;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int i = idmap_slot(im, st->count, ids[k]);
+    if (i < 0) return;
+    float4 v[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + i];
+    int best = -1, bestCount = 0;
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        float f[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int a, b;
+            vote_decode(f[t], a, b);
+            if (bestCount < a) { bestCount = a; best = (q * 4 + t) * 2; }
+            if (bestCount < b) { bestCount = b; best = (q * 4 + t) * 2 + 1; }
+        }
+    }
+    if (tm[i].y <= DEAD_TIME) { labels[i] = -1; return; }
+    labels[i] = best;          // (several pixels can show the same surfel: they all write the same values)
+    float2 c = col[i];
+    if (c.y == 0 || c.y == defaultColor) {
+        c.y = (best != -1) ? inst_color[best] : defaultColor;
+        col[i] = c;
+    }
+}
 __global__ __launch_bounds__(256) void k_count_colour(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
                                                       float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels)
 {
@@ -843,6 +889,7 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
                 for (int q = 0; q < NI; q++) if (cl[q] == 1) h->inst_class[q] = -1;
                 HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->stream));
                 LAUNCH(h, "clean_table", dim3(1024), dim3(256), k_clean_table, h->d_state, h->votes, h->cap, h->d_clean_list);
+                h->labels_stale_all = 1;   // votes of every surfel that carried an evicted instance changed
                 HIPCHK(h, hipStreamSynchronize(h->stream));
                 r = run_bboxes(h, nm, bbox);
                 if (r) return r;
@@ -857,7 +904,14 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
                 LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes, ifx_idmap(h));
     }
     // step 4
-    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+    if (h->opt_labels_incremental && !h->labels_stale_all) {
+        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col);
+        LAUNCH(h, "count_colour_px", dim3(cdiv(P, 256)), dim3(256), k_count_colour_px, h->d_state, h->ids_after, P, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col,
+               h->d_inst_color, h->labels, ifx_idmap(h));
+    } else {
+        LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+        h->labels_stale_all = 0;
+    }
     // flannKnnVoteSurfelMap (isflann, :1051)
     if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
     hipEvent_t eb = ifx_event_get(h);

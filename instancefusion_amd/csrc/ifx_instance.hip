@@ -826,7 +826,9 @@ static int oseg_resume(ifx* h)
 
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
-    if (h) ifx_vlist_reap(h);   // whole-map consumer: nothing outside the cached view list may outlive the age rule (ifx_map.hip "View list")
+    // Only the kNN smoothing looks at surfels the id image does not show: a slot outside the cached view list that has outlived the age rule
+    // (ifx_map.hip "View list") is unstable, so it was never in an id image, carries no votes and takes part in nothing else of this call.
+    if (h && (flags & 1)) ifx_vlist_reap(h);
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
     h->seg_counts_valid = 0;
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }

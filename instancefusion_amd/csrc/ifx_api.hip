@@ -557,7 +557,7 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
     return IFX_OK;
 }
 
-// ---- spatially sharded map (ifx_config::n_ranks > 1): one frame in seven phases; after phase p the caller reduces the buffers
+// ---- spatially sharded map (ifx_config::n_ranks > 1): one frame in eight phases; after phase p (0..6) the caller reduces the buffers
 // ifx_owner_exchange(p) lists across the ranks (instancefusion_amd/sharded.py: RCCL all-reduce; tests: the same reduction by hand)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
 extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)

@@ -118,7 +118,7 @@ class _DevWords:
 
 class OwnerShardedElasticFusion:
     """ElasticFusion.processFrame over a spatially sharded map: `ef` was created with n_ranks = world, rank = this rank, on this rank's
-    GPU; `dist` is torch.distributed (backend nccl = RCCL over xGMI).  Per frame: seven phases, between them all-reduces of the key images
+    GPU; `dist` is torch.distributed (backend nccl = RCCL over xGMI).  Per frame: eight phases (the last one publishes the frame result), between them all-reduces of the key images
     (unsigned MIN) and of the winners' attribute images (int32 SUM over disjoint supports), enqueued on the handle's own stream."""
 
     def __init__(self, ef, dist):

@@ -586,7 +586,7 @@ def test_persistent_level_kernel_is_bit_identical(ifx):
 @pytest.mark.parametrize("world", [2, 3])
 def test_owner_sharded_map_emulated(ifx, small_stream, world):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images
-    MIN-reduced, winners' attributes SUM-merged between the seven phases of a frame) against one GPU: G handles in one process, the
+    MIN-reduced, winners' attributes SUM-merged between the eight phases of a frame) against one GPU: G handles in one process, the
     all-reduces done by hand.  Poses, prediction / index / id images and -- merged by creation number -- the whole map, bit for bit,
     over first-frame initialisation, an uploaded map, appended surfels, deletions and independent local compactions."""
     import torch

@@ -478,7 +478,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
         HIPCHK(h, hipStreamWaitEvent(h->stream, nf.ready, 0));
         {
             StageTimer t(h, 0);
-            ifx_tracker_model_side(h);
+            ifx_tracker_model_side(h, 1);
             ifx_tracker_run_frame(h, 0);
         }
         ifx_bind_slot(h, s);

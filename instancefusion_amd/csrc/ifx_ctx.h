@@ -218,6 +218,7 @@ struct ifx {
     std::vector<int> oseg_cmp, oseg_bbox, oseg_class;
     hipEvent_t oseg_ev = nullptr;
     void* d_kexp = nullptr;            // ifx_owner_knn_export: [cap] float4 (x, y, z, creation number) + [cap] int32 labels
+    int gn_begin_folded = 0;         // the start of the next frame-tracker run was done by the model side's last launch
     int labels_stale_all = 1;        // the next segmentation call re-scans the labels of ALL surfels (after create / upload / table eviction); otherwise only what the call can have changed
     int opt_labels_incremental = 1;
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
@@ -379,7 +380,7 @@ int ifx_preprocess(ifx* h);                                   // bilateral + met
 int ifx_tracker_init_first(ifx* h);
 int ifx_tracker_run_frame(ifx* h, int commit = 1, int keep_last = 0);                            // model pyramid + GN loops (all on device); the frame side is in the slot
 int ifx_tracker_commit(ifx* h);                                // publish the pose of a tracker run that was enqueued ahead
-int ifx_tracker_model_side(ifx* h);                           // model pyramid from the prediction of the previous frame
+int ifx_tracker_model_side(ifx* h, int fold_begin = 0);                           // model pyramid from the prediction of the previous frame
 int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
 void ifx_bind_slot(ifx* h, int s);
 int ifx_housekeeping(ifx* h);                                  // tombstone compaction decided from the last frame result

@@ -90,7 +90,15 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     h->cfg = *cfg;
     h->w = cfg->width; h->h = cfg->height; h->P = h->w * h->h; h->cap = cfg->max_surfels;
     size_t P = (size_t)h->P, C = (size_t)h->cap;
-    if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream_b) != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+    {   // the main stream carries the latency-bound chain of the frame (tracker, map passes): highest priority; the side stream's image-only work
+        // (bilateral filter, frame pyramids, SO(3)) fills in around it: lowest (IFX_STREAM_PRIORITIES=0 in the environment: both default)
+        int lo = 0, hi = 0;
+        const char* e = getenv("IFX_STREAM_PRIORITIES");
+        const bool prio = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
+        hipError_t r1 = prio ? hipStreamCreateWithPriority(&h->stream, hipStreamDefault, hi) : hipStreamCreate(&h->stream);
+        hipError_t r2 = prio ? hipStreamCreateWithPriority(&h->stream_b, hipStreamDefault, lo) : hipStreamCreate(&h->stream_b);
+        if (r1 != hipSuccess || r2 != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+    }
     h->cur = h->stream;
     ALLOC(h->d_state, sizeof(DevState));
     hipMemset(h->d_state, 0, sizeof(DevState));

@@ -237,7 +237,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     std::string s(name);
     if (s == "compact_every_frame") h->opt_compact_every_frame = value;
     else if (s == "kernel_timing") { hipStreamSynchronize(h->stream); ktime_flush(h); h->opt_kernel_timing = value; }
-    else if (s == "reference_passes") h->opt_reference_passes = value;
+    else if (s == "reference_passes") { h->opt_reference_passes = value; ifx_vlist_reap(h); hs_invalidate_view(h); }   // the view-list path is off while it is set: no device-side "valid" may outlive the switch
     else if (s == "two_streams") h->opt_two_streams = value;
     else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;

@@ -80,11 +80,13 @@ struct DevState {
 
 // Ids in the id images are slot indices on an unsharded map and creation numbers on a spatially sharded one (ifx_map.hip, key_id / local_slot):
 // the instance layer, which goes from a pixel's id to the votes / position of that surfel, maps them through this.  -1: no surfel of THIS rank.
+// On a sharded map the id is a creation number: an UNSIGNED 32-bit value carried in the int32 id image (0 = no surfel), so numbers from 2^31 on
+// stay reachable; k_append_scan raises DevState::overflow before the numbering could wrap (include/ifx_c_api.h, "creation numbers").
 struct IdMap { const uint32_t* seq; int own_n; };
 __device__ __forceinline__ int idmap_slot(const IdMap& m, int count, int id)
 {
-    if (id <= 0) return -1;
-    if (m.own_n <= 1) return id < count ? id : -1;
+    if (m.own_n <= 1) return (id > 0 && id < count) ? id : -1;
+    if (id == 0) return -1;
     int lo = 0, hi = count - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;

@@ -199,13 +199,15 @@ __global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __
 // which the full scan would move from "no colour" (0) to the default colour: pass A does that from 16 bytes per slot, pass B redoes the arg-max
 // for the surfel under every pixel (192 bytes each, <= P of them) exactly as the full scan would.  5 M surfels: 83 MB + <= 59 MB instead of
 // 1.1 GB.  Anything that rewrites votes wholesale (upload, table eviction) sets ifx::labels_stale_all and the next call scans everything.
-__global__ __launch_bounds__(256) void k_colour_default(const DevState* __restrict__ st, const float2* __restrict__ tm, float2* __restrict__ col)
+__global__ __launch_bounds__(256) void k_colour_default(const DevState* __restrict__ st, const float2* __restrict__ tm, float2* __restrict__ col, int32_t* __restrict__ labels)
 {
     const float defaultColor = 7434609;
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
         const float2 c = col[i];
-        if (c.y == 0 && tm[i].y > DEAD_TIME) col[i] = make_float2(c.x, defaultColor);   // (votes untouched since creation: no label, the default colour)
+        const bool live = tm[i].y > DEAD_TIME;
+        if (c.y == 0 && live) col[i] = make_float2(c.x, defaultColor);   // (votes untouched since creation: no label, the default colour)
+        if (!live && labels[i] != -1) labels[i] = -1;                    // a tombstone carries no label, as in the full scan (visible through ifx_owner_knn_export until a compaction)
     }
 }
 __global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restrict__ st, const int32_t* __restrict__ ids, int P, const float4* __restrict__ votes, int cap,
@@ -824,7 +826,16 @@ static int oseg_resume(ifx* h)
     return IFX_E_STATE;
 }
 
+static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags);
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+{
+    const int r = process_segmentation(h, rgb, depth, masks_in, class_ids, nm, frame, flags);
+    // a call that failed part-way may have updated votes without the label scan that follows them: the incremental scan of the next call assumes
+    // that votes outside its own id image are unchanged since the last scan, so the next call scans everything
+    if (r != IFX_OK && h) h->labels_stale_all = 1;
+    return r;
+}
+static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
     // Only the kNN smoothing looks at surfels the id image does not show: a slot outside the cached view list that has outlived the age rule
     // (ifx_map.hip "View list") is unstable, so it was never in an id image, carries no votes and takes part in nothing else of this call.
@@ -907,7 +918,7 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     }
     // step 4
     if (h->opt_labels_incremental && !h->labels_stale_all) {
-        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col);
+        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels);
         LAUNCH(h, "count_colour_px", dim3(cdiv(P, 256)), dim3(256), k_count_colour_px, h->d_state, h->ids_after, P, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col,
                h->d_inst_color, h->labels, ifx_idmap(h));
     } else {

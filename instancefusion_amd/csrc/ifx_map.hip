@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
-    const unsigned int n = st->vl_n[0];
+    const unsigned int n = min(st->vl_n[0], c.seg_cap * LIST_SEGS);
     // Two entries per thread and round, every load of a stage issued before the first use: list entries, then times AND positions (a position is
     // fetched even when the time test will reject the entry -- in the time-window list that is the rare case), then the atomics.  One entry at a
     // time with the early exits in front of each load was three dependent round trips per entry and two rounds per thread.
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
     __shared__ unsigned int s_cand[2 * MAP_THREADS];
     __shared__ unsigned int s_n;
-    const unsigned int n = st->vl_n[0];
+    const unsigned int n = min(st->vl_n[0], c.seg_cap * LIST_SEGS);
     const unsigned int* __restrict__ seg_list = list;
     const unsigned int stride = blockDim.x * gridDim.x;
     int dead = 0;
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         for (int q = 0; q < RV_SLOTS / 64; q++) { s_tag[wid][q * 64 + lane] = 0u; s_key[wid][q * 64 + lane] = ~0ull; }
     }
     // the two view lists, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
-    const unsigned int na = st->vl_n[0], n = na + ((want & LIST_IDS) ? st->vl_n[1] : 0u);
+    const unsigned int na = min(st->vl_n[0], c.seg_cap * LIST_SEGS), n = na + ((want & LIST_IDS) ? min(st->vl_n[1], c.seg_cap * LIST_SEGS) : 0u);
     const unsigned int* __restrict__ seg_a = list_a;
     const unsigned int* __restrict__ seg_i = list_i;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
@@ -1897,9 +1897,16 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     for (int q = 0; q < wid; q++) { wave_offG += s_wave[q][0]; wave_offO += s_wave[q][1]; }
     int rankG = s_base[0] + wave_offG + inclG - mineG, rankO = s_base[1] + wave_offO + inclO - mineO;
     // the new surfels join the cached view list (they were created from this frame's pixels, so they are in view): one reservation per block
+    // Only surfels that are actually STORED get a list position: slots ascend with the owned rank, so the ones of this block that fit below
+    // `cap` are its first `fit` -- a full map must not leave reserved-but-unwritten entries for the list walkers to dereference.
     const int blk_total = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+    const int room = cap - (count0 + s_base[1]), fit = room <= 0 ? 0 : (room < blk_total ? room : blk_total);
     const bool to_view = list_v && st->vl_valid;
-    if (tid == 0) s_vbase = (to_view && blk_total) ? atomicAdd(&st->vl_n[0], (unsigned int)blk_total) : 0u;
+    if (tid == 0) {
+        unsigned int vb = (to_view && fit) ? atomicAdd(&st->vl_n[0], (unsigned int)fit) : 0u;
+        if (to_view && fit && vb + (unsigned int)fit > c.seg_cap * LIST_SEGS) { st->vl_valid = 0; vb = c.seg_cap * LIST_SEGS; }   // list full: void it (rebuilt by the next frame's scan)
+        s_vbase = vb;
+    }
     __syncthreads();
     unsigned int vpos = s_vbase + (unsigned int)(wave_offO + inclO - mineO);
     bool over = false;
@@ -1923,7 +1930,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         labels[n] = -1;   // no label until the next label scan (the slot may hold one from before a compaction)
         seq[n] = sq;
     }
-    if (over) st->overflow = 1;
+    if (over) { st->overflow = 1; st->vl_valid = 0; }
     // every block has read st->count / st->next_seq before it draws its ticket; the last one publishes the new values
     __syncthreads();
     if (tid == 0) {
@@ -1946,6 +1953,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         st->n_new = nc - count0;
         st->count = nc;
         st->next_seq = seq0 + (unsigned int)tg;
+        if (seq0 + (unsigned int)tg < seq0 || seq0 + (unsigned int)tg > 0xFFF00000u) st->overflow = 1;   // creation numbers are never renumbered: 2^32 of them is the life of a sharded map (reported as a full store)
         __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -2243,6 +2251,7 @@ int ifx_map_frame(ifx* h)
         h->ids_pending = 1;
         return IFX_OK;
     }
+    if (h->opt_vlist && h->cfg.n_ranks <= 1 && h->shard_n <= 1) hs_invalidate_view(h);   // this frame runs no scan: a device-side "valid" must never describe a list the host did not build
     index_pass(h, nullptr, h->tick, true);
     fuse_pass(h, nullptr, 0.f, h->tick);
     if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680); they need the post-fuse index map too

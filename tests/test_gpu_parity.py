@@ -1,14 +1,15 @@
 """GPU parity tests: the HIP path (libifx.so through its C-ABI) against the CPU oracle on identical
 seeded inputs.  Integer / index / byte outputs must match exactly; float outputs computed by the
 same per-element formula must match exactly too (both sides are built without FMA contraction and
-share the deterministic expf); reductions (29-float normal equations) match to rel 1e-4 and poses
-to 1e-5 (north star: trajectory within 1e-4 m RMS)."""
+share the deterministic expf); the tracker's reductions are exact, order-independent sums on both sides, so the
+29 / 11 floats of the normal equations, the poses (conftest.assert_pose_equal: bit-equal, at most one f32 ulp where the
+6x6 solve's pivoting differs), the map sizes, the id images and the labels are compared for EQUALITY over whole runs."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from conftest import SMALL
+from conftest import SMALL, assert_pose_equal
 from gputest_protocol import HALF_K, protocol_inputs
 
 pytestmark = pytest.mark.gpu
@@ -244,11 +245,9 @@ def test_end_to_end_sequence(ifx, orc, small_stream):
     for i in range(10):
         pg = g.processFrame(st["rgb"][i], st["depth"][i])
         po = o.process_frame(st["rgb"][i], st["depth"][i])
-        err.append(np.linalg.norm(pg[:3, 3] - po[:3, 3]))
-        assert np.abs(pg - po).max() < 1e-4
-    assert np.sqrt(np.mean(np.square(err))) < 1e-5     # trajectory RMS vs the oracle (north star: 1e-4 m)
-    assert abs(g.count - o.count) <= max(4, o.count // 2000)
-    assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.005
+        assert_pose_equal(pg, po, f"frame {i}")
+        assert g.count == o.count, i
+        assert np.array_equal(g.image("ids_after"), o.image("ids_after")), i
     assert np.allclose(g.trajectory()[-1], pg)
     # instance layer on identical map states: upload the oracle's map into the GPU object
     m = o.download(); m["pc"][:, 3] = np.maximum(m["pc"][:, 3], 12.0)
@@ -291,13 +290,13 @@ def test_bootstrap_pose_guess(ifx, orc, small_stream):
     rel[:3, 3] += np.float32([0.002, -0.001, 0.0015])
     pg = g.processFrame(st["rgb"][4], st["depth"][4], inPose=rel, bootstrap=True)
     po = o.process_frame(st["rgb"][4], st["depth"][4], in_pose=rel, bootstrap=True)
-    assert np.abs(pg - po).max() < 1e-4
+    assert_pose_equal(pg, po, "bootstrap frame")
     assert np.abs(pg - st["poses"][4]).max() < 0.02                      # it tracked (a replaced pose would equal pose3 * rel exactly)
     assert np.abs(pg - (st["poses"][3] @ rel)).max() > 1e-6
     # the frames that follow are unaffected by the mode
     pg = g.processFrame(st["rgb"][5], st["depth"][5]); po = o.process_frame(st["rgb"][5], st["depth"][5])
-    assert np.abs(pg - po).max() < 1e-4
-    assert abs(g.count - o.count) <= max(4, o.count // 2000)
+    assert_pose_equal(pg, po, "frame after the bootstrap frame")
+    assert g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after"))
     with pytest.raises(ifx.IfxError):
         g.processFrame(st["rgb"][6], st["depth"][6], bootstrap=True)     # assert(inPose) in the reference
     g.close(); o.close()
@@ -410,9 +409,9 @@ def _label_image(ids, labels):
 def test_full_loop_640x480_trajectory_and_labels(ifx, orc):
     """The whole 90-frame camera loop of the benchmark stream at 640x480, HIP against the oracle frame by frame (BASELINE
     configuration 2 without the pre-populated map, so that the oracle finishes in a minute): per-frame pose, RMS over the
-    whole trajectory <= 1e-4 m (north star), bounded map / id-image divergence, and the instance layer with superpixel
-    refinement at four segmentation calls -- instance tables exact, labels under the pixels compared; then exact integer
-    label equality on identical map states."""
+    whole trajectory bit-equal (<= 1 ulp; the north star asks 1e-4 m RMS), map sizes / id images / the whole map equal, and the
+    instance layer with superpixel refinement at four segmentation calls -- instance tables, labels and the label under every
+    pixel equal; a fifth call after re-uploading the map (exercises upload + held pose at this size)."""
     import os
 
     from instancefusion_amd import synth
@@ -432,11 +431,10 @@ def test_full_loop_640x480_trajectory_and_labels(ifx, orc):
         pg = g.processFrame(st["rgb"][i], st["depth"][i]); po = o.process_frame(st["rgb"][i], st["depth"][i])
         err.append(float(np.linalg.norm(pg[:3, 3] - po[:3, 3])))
         rot.append(float(np.abs(pg[:3, :3] - po[:3, :3]).max()))
-        assert err[-1] < 1e-4 and rot[-1] < 1e-4, (i, err[-1], rot[-1])     # every single frame, not only the RMS
+        assert_pose_equal(pg, po, f"frame {i}")                              # every single frame: bit-equal (<= 1 ulp, counted)
         if i % 15 == 14 or i in seg_frames:
-            cg, co = g.count, o.count
-            assert abs(cg - co) <= max(8, co // 1000), (i, cg, co)           # map sizes: within 0.1 %
-            assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.01, i
+            assert g.count == o.count, (i, g.count, o.count)                 # map sizes equal
+            assert np.array_equal(g.image("ids_after"), o.image("ids_after")), i
         if i in seg_frames:
             masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
             assert masks.shape[0] > 0
@@ -446,10 +444,14 @@ def test_full_loop_640x480_trajectory_and_labels(ifx, orc):
             lg, lo = inst.labels(), o.labels()
             li_g, li_o = _label_image(g.image("ids_after"), lg), _label_image(o.image("ids_after"), lo)
             lab_mismatch.append(float((li_g != li_o).mean()))
-            assert lab_mismatch[-1] < 0.01, (i, lab_mismatch)                 # label under the pixels (the maps differ by a few surfels by now)
-            assert abs(int((lg >= 0).sum()) - int((lo >= 0).sum())) <= max(20, int((lo >= 0).sum()) // 100)
+            assert np.array_equal(lg, lo), i                                  # every label of the map, every call
+            assert np.array_equal(li_g, li_o), (i, lab_mismatch)
     rms = float(np.sqrt(np.mean(np.square(err))))
-    assert rms <= 1e-4, rms                                                  # north star: trajectory within 1e-4 m RMS
+    assert rms <= 1e-7, rms                                                  # (north star: 1e-4 m RMS; asserted: <= 1 ulp per pose entry above)
+    mg_, mo_ = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg_[k], mo_[k]), k                             # the whole map after 90 free-running frames, bit for bit
+    del mg_, mo_
     gt = st["poses"][:NF]
     traj = g.trajectory()
     assert traj.shape[0] == NF
@@ -500,12 +502,7 @@ def test_config3_5m_map_full_instance_path(ifx, orc):
     inst = ifx.InstanceFusion(g)
     for i in (1, 2):
         pg = g.processFrame(st["rgb"][i], st["depth"][i]); po = o.process_frame(st["rgb"][i], st["depth"][i])
-        assert np.abs(pg - po).max() < 1e-4, i
-    same = g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after"))
-    if not same:   # a threshold decision flipped somewhere in 5M surfels: continue from one map so that the label comparison below is exact
-        m = o.download(); g.upload(m); o.upload(m)
-        g.set_pose(po, o.tick); o.set_pose(po, o.tick)
-        g.processFrame(st["rgb"][2], st["depth"][2], inPose=po); o.process_frame(st["rgb"][2], st["depth"][2], in_pose=po)
+        assert_pose_equal(pg, po, f"frame {i}")
     assert g.count == o.count and np.array_equal(g.image("ids_after"), o.image("ids_after"))
     masks, cls = synth.canned_masks(st["obj"][2], st["scene"])
     inst.ProcessSegmentation(st["rgb"][2], st["depth"][2], masks, cls, 300, superpixels=True)
@@ -761,6 +758,55 @@ def test_view_list_path_equals_per_pass_culls(ifx, earlyz, lds):
     assert a[3]["pc"].shape[0] > 400_000 and (a[2] >= 0).sum() > 100
 
 
+def test_view_list_survives_a_full_map(ifx, small_stream):
+    """A store that fills up while the cached view list is on: new surfels that do not fit get NO list position (an advisor finding of
+    round 2: reserved-but-unwritten entries were dereferenced by the list walkers), the frames report IFX_E_CAPACITY, and the handle
+    keeps working -- ids and list lengths stay inside the store, the map downloads finite, a compaction + more frames run."""
+    st = small_stream
+    cap = 30_000
+    g = ifx.ElasticFusion(**SMALL, max_surfels=cap)
+    full = 0
+    for rep in range(3):
+        for i in range(10):
+            try:
+                g.processFrame(st["rgb"][i], st["depth"][i], inPose=st["poses"][i] if rep else None)
+            except ifx.IfxError as e:
+                assert "capacity" in str(e)
+                full += 1
+            vs = g.view_list_stats()
+            assert 0 <= vs["window"] <= cap and 0 <= vs["outside"] <= cap, vs
+            ids = g.image("ids_after")
+            assert ids.min() >= 0 and ids.max() < cap
+    assert full > 0 and g.slots == cap
+    m = g.download()
+    assert m["pc"].shape[0] <= cap and np.isfinite(m["pc"]).all() and np.isfinite(m["nr"]).all()
+    g.compact()
+    assert g.count == m["pc"].shape[0]
+    g.close()
+
+
+def test_reference_passes_toggle_keeps_the_view_list_honest(ifx, orc, small_stream):
+    """Switching `reference_passes` on takes the frames off the view-list path; switching it back must not let a device-side "valid"
+    describe a list the host never built (advisor finding of round 2: the passes then walked an almost empty list).  Against the
+    oracle frame by frame across both switches: poses, map sizes and id images equal."""
+    st = small_stream
+    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("compact_every_frame", 0)
+    o = orc.Oracle(**SMALL, max_surfels=400000)
+    for i in range(10):
+        if i == 3:
+            g.set_option("reference_passes", 1)
+        if i == 6:
+            g.set_option("reference_passes", 0)
+        pg = g.processFrame(st["rgb"][i], st["depth"][i]); po = o.process_frame(st["rgb"][i], st["depth"][i])
+        assert_pose_equal(pg, po, f"frame {i}")
+        assert g.count == o.count, i
+    mg, mo = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg[k], mo[k]), k
+    g.close(); o.close()
+
+
 # ---------------------------------------------------------------- a20, a21: superpixel refinement
 def _slic_cases(gputest_pair):
     from instancefusion_amd import synth
@@ -956,11 +1002,11 @@ def test_other_resolutions_against_oracle(ifx, orc, w, h, frames):
     for i in range(frames):
         pg = g.processFrame(st["rgb"][i], st["depth"][i])
         po = o.process_frame(st["rgb"][i], st["depth"][i])
-        assert np.abs(pg - po).max() < 1e-4, i
+        assert_pose_equal(pg, po, f"frame {i}")
         for name in ("depth_filtered", "depth_metric", "depth_metric_filtered"):
             assert np.array_equal(g.image(name), o.image(name)), (i, name)
-    assert abs(g.count - o.count) <= max(4, o.count // 2000)
-    assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.005
+    assert g.count == o.count
+    assert np.array_equal(g.image("ids_after"), o.image("ids_after"))
     # identical map state -> identical integer outputs of the map stages at this size
     m = o.download()
     g.upload(m); o.upload(m)
@@ -1072,14 +1118,16 @@ def test_tracker_and_map_configurations(ifx, orc, small_stream, name, kw):
     # The photometric term alone (about 1 500 correspondences on this stream) leaves directions of the 6x6 system almost
     # unobservable: the 2e-4 relative difference between f32 tree sums and sequential f64 sums is amplified to millimetres
     # (frame 1 agrees to 1e-6, later frames drift apart), on the reference's own CUDA reductions as much as here.
-    tol = 2e-2 if name == "rgb_only" else 1e-4
     for i in range(6):
         pg = g.processFrame(st["rgb"][i], st["depth"][i])
         po = o.process_frame(st["rgb"][i], st["depth"][i])
-        assert np.abs(pg - po).max() < tol, (name, i)
+        if name == "rgb_only":
+            assert np.abs(pg - po).max() < 2e-2, (name, i)
+        else:
+            assert_pose_equal(pg, po, f"{name} frame {i}")
     if name != "rgb_only":
-        assert abs(g.count - o.count) <= max(4, o.count // 1000), name
-        assert (g.image("ids_after") != o.image("ids_after")).mean() < 0.01, name
+        assert g.count == o.count, name
+        assert np.array_equal(g.image("ids_after"), o.image("ids_after")), name
     g.close(); o.close()
 
 

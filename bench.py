@@ -9,9 +9,10 @@ update and the label scan when it fires), into a pre-populated synthetic N-surfe
 Frames are resident in HBM before the timed region starts.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run
-(one rank per GPU, RCCL): every rank runs the same workload on its own stream + map replica
-("replicas only" -- DESIGN.md section Multi-GPU), barrier + synchronize on both sides of the timed
-region, max over ranks, rank 0 prints one JSON line.
+(one rank per GPU, RCCL).  Default: every rank runs the same workload on its own stream + map replica (weak scaling, no
+data-path collective); `--sharded`: ONE stream into ONE map spatially sharded across the ranks, the exchanges of a frame
+enqueued by libifx.so itself on the communicator it is handed.  Barrier + synchronize on both sides
+of the timed region, max over ranks, rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
@@ -32,9 +33,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 LEVEL_AVG = (10 + 5 / 4.0 + 4 / 16.0) / 19.0   # pixel count of the average Gauss-Newton launch / P (10, 5, 4 iterations on levels 0, 1, 2)
 
 
-def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float = 0.3) -> float:
+def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float = 0.3, vl=None) -> float:
     """Algorithmic HBM bytes of ONE launch of `kernel`.  Deliberately conservative:
-    only streams every launch must touch are counted (e.g. the normal/radius reads of listed surfels are not)."""
+    only streams every launch must touch are counted (e.g. the key-image atomics of the rasteriser and the clean pass's window taps are not).
+    vl = (entries of the time-window view list, stable entries outside it) of the run, from ifx_view_list_stats."""
+    nw, no = (vl if vl else (0, 0))
     table = {
         # map: streaming culls over all slots
         "cull_frame": n_slots * 24.0,                       # the one scan of the store (view list): times 8 B + position/confidence 16 B of every slot
@@ -42,6 +45,13 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
         "cull_clean": n_slots * (8.0 + 16.0 * active_fraction),   # times for every slot, position only inside the time window
         "index_project": n_slots * (8.0 + 16.0 * active_fraction),
         "count_colour": n_slots * (192.0 + 8 + 8 + 4),
+        # map: list-driven passes (the frame path): per list entry the 4-B entry + the fields the pass reads of that slot
+        "index_list": nw * (4.0 + 8 + 16),                  # entry, times, position + confidence
+        "clean_view": nw * (4.0 + 8 + 16 + 16),             # + normal / radius of the candidates (window taps: L2-resident image, not counted)
+        "raster_view": (nw + no) * (4.0 + 8 + 16 + 16),     # both lists: entry, times, position, normal / radius (key-image atomics not counted)
+        "fuse_update": (P / 4.0) * (4.0 + 96),              # upper bound: every active pixel matched (association word + 48 B read + 48 B written in place)
+        "project_bbox": P * (4.0 + 192),                    # id image + the 12 vote planes of the surfel under every pixel
+        "count_colour_px": P * (4.0 + 192 + 8),
         # tracker: per-pixel passes, averaged over the pyramid levels a launch can run at
         # persistent level kernel, averaged over the three levels: per pixel 39 B of frame-side constants once (vertex + normal 24, depth 4, intensity 1 + 4x4 window ~4 after
         # reuse, gradients 4) + per iteration 41 B of gathers (model vertex + normal 24, depth 4, intensity 1, cloud point 12); iterations 10 / 5 / 4 on P, P/4, P/16
@@ -54,6 +64,13 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
         "associate": P * (4.0 * 4 + 3 + 40),
     }
     return table.get(kernel, 0.0)
+
+
+# which ms/frame column of the metric a kernel is billed to (roofline.stages)
+STAGE_OF = {"track": ("icp_residual", "rgb_step_solve", "gn_level", "model_l0", "model_down"),
+            "fuse": ("cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "index_resolve_taps",
+                     "associate", "fuse_update", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "new_flags_count", "append_scan"),
+            "instance": ("count_colour", "count_colour_px", "project_bbox")}
 
 
 def main():
@@ -121,8 +138,8 @@ def main():
     t_gen = time.time() - t_gen
 
     cap = args.surfels + 2_500_000
-    owner = args.sharded and world > 1
-    ef = ifx.ElasticFusion(w=W, h=H, max_surfels=(cap // world + P + 500_000) if owner else cap, device=dev, **K, **(dict(n_ranks=world, rank=rank) if owner else {}))
+    owner = args.sharded        # at world == 1 too: a world of one on the sharded path (n_ranks = -1), every exchange point a one-rank RCCL collective
+    ef = ifx.ElasticFusion(w=W, h=H, max_surfels=(cap // world + P + 500_000) if owner else cap, device=dev, **K, **(dict(n_ranks=(world if world > 1 else -1), rank=rank) if owner else {}))
     inst = ifx.InstanceFusion(ef)
     for kv in args.opt:
         k_, v_ = kv.split("=")
@@ -137,7 +154,7 @@ def main():
     if owner:
         from instancefusion_amd import sharded as ifsh
 
-        osh = ifsh.OwnerShardedElasticFusion(ef, dist)
+        osh = ifsh.OwnerShardedElasticFusion(ef, dist)   # hands libifx.so a RCCL communicator; from here on a frame is one library call
         osh.process_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
         ef.upload(m)                                   # every rank is handed all rows and keeps the ones it owns
         ef.set_pose(st["poses"][0], tick0)
@@ -237,7 +254,10 @@ def main():
     place_call_in_window(args.steps)
     seg["calls"] = 0
     k_timed = k
+    if osh is not None:
+        osh.exchange_stats(reset=True)
     dt = timed(k, args.steps, step); k += args.steps
+    xstats = osh.exchange_stats() if osh is not None else None
     calls_in_window = seg["calls"]
     inst_ms = ef.stage_ms(reset=True)["instance"]          # the instance stage is always timed (two events per segmentation call)
     traj = ef.trajectory()                                  # poses up to the end of the timed region
@@ -272,27 +292,31 @@ def main():
         for _ in range(n_kt):
             step(k); k += 1
         ef.sync()
-        names = ["gn_level", "icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "associate",
-                 "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count", "append_scan", "count_colour"]
+        names = ["gn_level", "icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve",
+                 "index_resolve_taps", "associate", "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count",
+                 "append_scan", "count_colour", "count_colour_px", "project_bbox"]
         # k_cull_frame is launched every frame and decides ON THE DEVICE whether the cached view list is still valid; a launch that finds it
         # valid returns at once.  Its algorithmic bytes are therefore the scan's bytes x (scans / launches) of this window.
-        scans_kt = (ef.view_list_stats().get("scans", 0) - scans0) if sh is None else 0
+        vls = ef.view_list_stats() if sh is None else {}
+        scans_kt = (vls.get("scans", 0) - scans0) if sh is None else 0
+        vl = (vls.get("window", 0), vls.get("outside", 0))
+        alg = lambda n_: algorithmic_bytes(n_, n_slots, P, vl=vl)
         best, table = None, {}
         for nme in names:
             avg, cnt = ef.kernel_ms(nme)
             table[nme] = dict(avg_ms=avg, launches=cnt, total_ms=avg * cnt)
-            if cnt and algorithmic_bytes(nme, n_slots, P) > 0 and (best is None or avg * cnt > table[best]["total_ms"]):
+            if cnt and alg(nme) > 0 and (best is None or avg * cnt > table[best]["total_ms"]):
                 best = nme
         # the two launches of a Gauss-Newton iteration (icp_residual, rgb_step_solve) take the same time to within a per cent, so which of them
         # is "the" dominant kernel would flip from run to run: within 5 % the one that moves more algorithmic bytes is reported
         if best:
             for nme in names:
                 t = table[nme]
-                if t["launches"] and nme != best and t["total_ms"] > 0.95 * table[best]["total_ms"] and algorithmic_bytes(nme, n_slots, P) > algorithmic_bytes(best, n_slots, P):
+                if t["launches"] and nme != best and t["total_ms"] > 0.95 * table[best]["total_ms"] and alg(nme) > alg(best):
                     best = nme
         ef.set_option("kernel_timing", 0)
         # HBM traffic per launch: PMC counters cannot be read from inside the process.  They are collected by tools/pmc_collect.sh (rocprofv3
-        # --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS command, corrected as MI355X_MICROARCH.md prescribes) into
+        # --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS command, corrected as MI355X_MICROARCH.md prescribes, per access pattern: tools/pmc_summary.py) into
         # profiles/<round>_pmc_traffic.json together with the slot count and the kernel list of that run.  A file is used only when it
         # describes this workload (same resolution, slot count within 10 %: tombstones come and go) and this kernel set; otherwise `traffic` is null -- never a stale constant.
         pmc, pmc_src = {}, None
@@ -304,7 +328,7 @@ def main():
                 meta = j.get("workload")
                 if not meta or meta.get("res") != f"{W}x{H}" or abs(meta.get("surfel_slots", 0) - n_slots) > 0.10 * n_slots:
                     continue
-                if not all(("k_" + n_) in j["kernels"] for n_ in names if table[n_]["launches"] and algorithmic_bytes(n_, n_slots, P) > 0):
+                if not all(("k_" + n_) in j["kernels"] for n_ in names if table[n_]["launches"] and alg(n_) > 0 and n_ != "index_resolve_taps"):
                     continue
                 pmc, pmc_src = j["kernels"], "profiles/" + f_
                 break
@@ -312,14 +336,15 @@ def main():
             pass
 
         def entry(nme):
-            b = algorithmic_bytes(nme, n_slots, P)
+            b = alg(nme)
             if nme == "cull_frame" and table[nme]["launches"]:
                 b *= min(1.0, scans_kt / table[nme]["launches"])
             ach = b / (table[nme]["avg_ms"] * 1e-3) / 1e9 if table[nme]["avg_ms"] > 0 else 0.0
             t = pmc.get("k_" + nme)
+            traffic = (t["bytes_read"] + t["bytes_written"]) if t else None
             return dict(bound="hbm", kernel=nme, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=(t["bytes_read"] + t["bytes_written"]) if t else None, traffic_source=pmc_src if t else None,
-                        avg_launch_ms=round(table[nme]["avg_ms"], 5), bytes_per_launch=b,
+                        traffic=traffic, traffic_source=pmc_src if t else None, traffic_over_algorithmic=(round(traffic / b, 2) if (traffic and b > 0) else None),
+                        fetch_factor=(t.get("fetch_factor") if t else None), avg_launch_ms=round(table[nme]["avg_ms"], 5), bytes_per_launch=b,
                         **({"scans": scans_kt, "launches": table[nme]["launches"]} if nme == "cull_frame" else {}))
 
         if best:
@@ -328,6 +353,27 @@ def main():
             # the dominant kernel by time is a latency-bound reduction; the passes that stream the whole surfel
             # store are reported next to it so that the bandwidth-bound part of the path has its roofline numbers too
             roof["streaming_passes"] = [entry(n_) for n_ in ("cull_frame", "cull_raster", "cull_clean", "index_project", "count_colour") if table.get(n_, {}).get("launches")]
+            # the list-driven passes that ARE the map stage on the frame path, and the per-call kernels of the instance layer: achieved fraction and waste ratio of each
+            roof["map_passes"] = [entry(n_) for n_ in ("raster_view", "clean_view", "index_list", "fuse_update", "associate", "index_resolve", "splat_resolve", "project_bbox", "count_colour_px")
+                                  if table.get(n_, {}).get("launches")]
+            # blended per stage: algorithmic bytes of the stage's launches per frame over the stage's measured ms per frame (the columns of the metric)
+            stages = {}
+            for sname, members in STAGE_OF.items():
+                b_frame = 0.0
+                for n_ in members:
+                    if table.get(n_, {}).get("launches"):
+                        b_l = alg("index_resolve" if n_ == "index_resolve_taps" else n_)
+                        if n_ == "cull_frame":
+                            b_l *= min(1.0, scans_kt / table[n_]["launches"])
+                        b_frame += b_l * table[n_]["launches"] / n_kt
+                ms = stage.get(sname, 0.0) / args.steps
+                if sname == "instance":   # per segmentation call, not per frame
+                    ms = (inst_ms / calls_in_window) if calls_in_window else 0.0
+                    b_frame = b_frame * n_kt / max(1, seg["calls"])
+                stages[sname] = dict(algorithmic_bytes=round(b_frame), ms=round(ms, 4), achieved=round(b_frame / (ms * 1e-3) / 1e9, 1) if ms > 0 else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                                     frac=round(b_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None, per="segmentation call" if sname == "instance" else "frame")
+            roof["stages"] = stages
+            roof["view_list_entries"] = dict(window=vl[0], outside=vl[1])
 
     # ---- extra legs (N = 1 only, bounded): the same workload through the reference-shaped host entry point, and with closeLoops = true
     extras = {}
@@ -419,6 +465,8 @@ def main():
                          "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call"},
             **extras,
             "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": ef.view_list_stats(),
+            **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
+                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1)}} if xstats else {}),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu,
         }

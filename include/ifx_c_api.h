@@ -49,7 +49,7 @@ typedef struct ifx_config {
     int32_t so3;                 /* 1 */
     int32_t max_surfels;         /* capacity of the surfel store (reference: 1536^2, EF/GlobalModel.cpp:22-23) */
     int32_t device;              /* HIP device ordinal */
-    int32_t n_ranks, rank;       /* spatially sharded map: this handle stores shard `rank` of `n_ranks` (0 or 1: the whole map); see ifx_owner_frame_phase */
+    int32_t n_ranks, rank;       /* spatially sharded map: this handle stores shard `rank` of `n_ranks` (0 or 1: the whole map; -1: the sharded path with one rank); see ifx_owner_frame_phase */
 } ifx_config;
 
 typedef struct ifx ifx_t;
@@ -110,12 +110,39 @@ int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
  * i.e. 1 / G of the map.  One process per GPU, every rank fed the same frame.  A frame is eight calls of ifx_owner_frame_phase (phase 0..7,
  * the image pointers are used by phase 0); after phase p (0..6) the caller reduces, across the ranks, the device buffers ifx_owner_exchange(p)
  * lists: ops 0 = element-wise MINIMUM of unsigned 64-bit words (key images: depth | creation number), ops 1 = SUM of 32-bit words
- * (attribute images with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  instancefusion_amd/sharded.py does
- * it with RCCL all-reduces on the handle's stream.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
+ * (attribute blocks with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  The library does it itself once it holds a
+ * communicator (ifx_owner_process_frame_device below); the phase / exchange pair stays for hosts with their own transport and for the emulation tests.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
  * bit.  Per-surfel work (projections, fusion update, clean, votes, label scan) is sharded, per-pixel work (tracking, association, the mask
  * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume, the kNN smoothing through ifx_owner_knn_export /
  * _vote; the loop-closure detection is not available in this mode yet. */
 int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);
+/* ---- the same frame as ONE call, the collectives enqueued by the library itself (instancefusion_amd/csrc/ifx_comm.hip).  The reference has no
+ * counterpart (one GPU, IF/main.cpp:75); BASELINE.json's north star asks for "RCCL all-reduce over xGMI ... all-to-all for cross-shard surfel
+ * reprojection" with the host in C++.  The library holds a RCCL communicator (librccl.so.1 loaded with dlopen on first use: a single-GPU process
+ * never maps it) and issues the exchange of every phase on the handle's main stream, between the kernels of two phases: no host round trip inside a
+ * frame, six collectives per frame (u64 MIN of key images, int32 SUM of the winners' attribute blocks), 122 bytes per pixel.
+ *   ifx_comm_unique_id(out128)       ncclGetUniqueId on one rank; the host hands the 128 bytes to the other ranks (MPI, a file, a socket, torch.distributed)
+ *   ifx_owner_init_comm(h, id128)    ncclCommInitRank(n_ranks, id, rank) on the handle's device -- collective: every rank calls it
+ *   ifx_owner_set_comm(h, comm)      adopt a ncclComm_t the host already owns (size / rank must match the handle's); NULL: back to caller-driven exchanges
+ *   ifx_owner_process_frame_device   phases 0..7 + exchanges, device pointers, no synchronisation (poses: ifx_trajectory / ifx_get_pose)
+ *   ifx_owner_process_frame          ElasticFusion::processFrame's shape (EF/ElasticFusion.h:75-82): host pointers, one synchronisation, currPose back
+ *   ifx_owner_predict                ElasticFusion::predict outside a frame (after ifx_map_upload / ifx_set_pose)
+ *   ifx_owner_process_segmentation   InstanceFusion::processInstance (IF/Core/InstanceFusion.cpp:655-1067): begin / resume with the exchanges inside; flags bit 0 also runs
+ *   ifx_owner_knn_vote_colour        flannKnnVoteSurfelMap (:1070-1163): all-gather of every rank's slots (20 B each), exact 10-NN of the owned surfels
+ *   ifx_owner_exchange_stats         out2 = collectives enqueued, bytes handed to them since the last reset
+ * ifx_config::n_ranks = -1 creates a WORLD OF ONE on this path (creation-number ids, owner filter, every exchange point as a one-rank collective): what
+ * `bench.py --sharded --gpus 1` and the single-GPU RCCL test run.
+ * Creation numbers (the ids of a sharded map) are unsigned 32-bit and never renumbered: a handle reports IFX_E_CAPACITY once 2^32 - 2^20 of them have been
+ * handed out (at most P / 4 per frame: > 50 000 frames at 640 x 480 in the worst case, millions in practice). */
+int ifx_comm_unique_id(uint8_t* out128);
+int ifx_owner_init_comm(ifx_t* h, const uint8_t* unique_id128);
+int ifx_owner_set_comm(ifx_t* h, void* nccl_comm);
+int ifx_owner_process_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth, int64_t timestamp);
+int ifx_owner_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float* out_pose16);
+int ifx_owner_predict(ifx_t* h);
+int ifx_owner_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks, const int32_t* class_ids, int nm, int frame, int flags);
+int ifx_owner_knn_vote_colour(ifx_t* h);
+int ifx_owner_exchange_stats(ifx_t* h, int64_t* out2, int reset);
 int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n);
 /* ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose): step 0, exchange as after phase 4,
  * step 1, exchange as after phase 5, step 2. */

@@ -79,6 +79,15 @@ _SIGS = {
     "ifx_owner_knn_export": (C.c_int, [_P, _P, _P, _P]),
     "ifx_owner_knn_vote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),
+    "ifx_comm_unique_id": (C.c_int, [_P]),
+    "ifx_owner_init_comm": (C.c_int, [_P, _P]),
+    "ifx_owner_set_comm": (C.c_int, [_P, _P]),
+    "ifx_owner_process_frame_device": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "ifx_owner_process_frame": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ifx_owner_predict": (C.c_int, [_P]),
+    "ifx_owner_process_segmentation": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "ifx_owner_knn_vote_colour": (C.c_int, [_P]),
+    "ifx_owner_exchange_stats": (C.c_int, [_P, _P, C.c_int]),
     "ifx_map_seq": (C.c_int, [_P, _P, C.c_int]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),

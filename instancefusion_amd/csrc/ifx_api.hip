@@ -78,8 +78,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         g_err = "width/height must be positive multiples of 4 (three pyramid levels) and max_surfels > 0";
         return IFX_E_INVALID;
     }
-    if (cfg->n_ranks < 0 || cfg->n_ranks > 64 || (cfg->n_ranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->n_ranks)) || (cfg->n_ranks <= 1 && cfg->rank != 0)) {
-        g_err = "n_ranks / rank: a spatially sharded map has 2..64 ranks and 0 <= rank < n_ranks (n_ranks 0 or 1: unsharded, rank 0)";
+    if (cfg->n_ranks < -1 || cfg->n_ranks > 64 || (cfg->n_ranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->n_ranks)) || (cfg->n_ranks <= 1 && cfg->rank != 0)) {
+        g_err = "n_ranks / rank: a spatially sharded map has 2..64 ranks and 0 <= rank < n_ranks (n_ranks 0 or 1: unsharded, rank 0; -1: the sharded path with a single rank)";
         return IFX_E_INVALID;
     }
     int ndev = 0;
@@ -89,6 +89,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ifx* h = new ifx();
     h->cfg = *cfg;
     h->w = cfg->width; h->h = cfg->height; h->P = h->w * h->h; h->cap = cfg->max_surfels;
+    h->own = cfg->n_ranks > 1 || cfg->n_ranks == -1;   // -1: a world of one on the sharded path (creation-number ids, owner filter, exchange points) -- RCCL tests and `bench.py --sharded --gpus 1`
+    h->own_g = cfg->n_ranks > 1 ? cfg->n_ranks : 1;
     size_t P = (size_t)h->P, C = (size_t)h->cap;
     {   // the main stream carries the latency-bound chain of the frame (tracker, map passes): highest priority; the side stream's image-only work
         // (bilateral filter, frame pyramids, SO(3)) fills in around it: lowest (IFX_STREAM_PRIORITIES=0 in the environment: both default)
@@ -114,7 +116,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     h->list_seg_cap = (unsigned int)(((C + 4095) / 4096 / IFX_LIST_SEGS + 1) * 4096 + P);
     ALLOC(h->list_a, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_b, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_c, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     if (const char* ev = getenv("IFX_RASTER_TILES")) h->opt_raster_tiles = atoi(ev);   // A/B switch for whole test runs
-    if (cfg->n_ranks > 1) h->opt_raster_tiles = 0;   // (the tiled rasteriser's pair records carry slots, the sharded map's keys creation numbers)
+    if (h->own) h->opt_raster_tiles = 0;   // (the tiled rasteriser's pair records carry slots, the sharded map's keys creation numbers)
     h->tile_pair_cap = (unsigned int)std::max<size_t>(2 * C, (size_t)1 << 22);
     ALLOC(h->tile_n, 5 * 4096 * 4 + 64); ALLOC(h->tile_box, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->tile_pairs, (size_t)h->tile_pair_cap * 4);
     hipMemset(h->tile_n, 0, 5 * 4096 * 4 + 64);
@@ -136,10 +138,15 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     }
     hipHostMalloc((void**)&h->rgb_stage, P * 3);
     hipHostMalloc((void**)&h->depth_stage, P * 2);
-    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8); ALLOC(h->key_ids, P * 8); ALLOC(h->key_both, P * 8);
-    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8); hipMemset(h->key_ids, 0xFF, P * 8); hipMemset(h->key_both, 0xFF, P * 8);
-    ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16); ALLOC(h->index_ct, P * 16); ALLOC(h->index_nr, P * 16); ALLOC(h->index_tap, P * 16);
-    ALLOC(h->pred_vertex, P * 16); ALLOC(h->pred_normal, P * 16); ALLOC(h->pred_image, P * 4); ALLOC(h->pred_inst, P * 4); ALLOC(h->pred_time, P * 2);
+    // Buffers that travel together between the ranks of a sharded map are ONE allocation each, so that an exchange point is one collective
+    // (ifx_owner_exchange): [key_splat | key_ids | key_both], [index_vc | index_nr], [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail].
+    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8 * 3); h->key_ids = h->key_splat + P; h->key_both = h->key_splat + 2 * P;
+    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8 * 3);
+    ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16 * 2); h->index_nr = h->index_vc + 4 * P; ALLOC(h->index_ct, P * 16); ALLOC(h->index_tap, P * 16);
+    h->pred_bytes = ((P * 42 + 15) / 16) * 16 + 16;   // + the tail: [0] vote mass of the owned surfels under the id image (whetherDoSegmentation), summed with the prediction
+    ALLOC(h->pred_vertex, h->pred_bytes); h->pred_normal = h->pred_vertex + 4 * P; h->pred_image = (uint8_t*)(h->pred_normal + 4 * P); h->pred_inst = h->pred_image + 4 * P;
+    h->pred_time = (uint16_t*)(h->pred_inst + 4 * P); h->pred_tail = (int*)((uint8_t*)h->pred_vertex + h->pred_bytes - 16);
+    hipMemset(h->pred_vertex, 0, h->pred_bytes);
     ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
     ALLOC(h->ids_after, P * 4); ALLOC(h->ids_tmp, P * 4);
     hipMemset(h->ids_after, 0, P * 4); hipMemset(h->ids_tmp, 0, P * 4);
@@ -166,6 +173,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->stream_c) hipStreamSynchronize(h->stream_c);
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
     if (h->stream) hipStreamSynchronize(h->stream);
+    ifx_comm_free(h);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
@@ -173,8 +181,8 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
     void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
-                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat, h->key_ids, h->key_both,
-                    h->index_id, h->index_vc, h->index_ct, h->index_nr, h->index_tap, h->pred_vertex, h->pred_normal, h->pred_image, h->pred_inst, h->pred_time, h->fill_vertex,
+                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat,
+                    h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->h_result) hipHostFree(h->h_result);
@@ -406,7 +414,7 @@ static int enqueue_loop_closure_tracker(ifx* h)
 int ifx_tracker_bootstrap_pose(ifx* h, const float* d_in_pose16);
 static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind, const float* in_pose16, float weight_mult, int bootstrap = 0)
 {
-    if (h->cfg.n_ranks > 1) { h->err = "a sharded map (n_ranks > 1) is driven through ifx_owner_frame_phase / ifx_owner_exchange"; return IFX_E_STATE; }
+    if (h->own) { h->err = "a sharded map (n_ranks > 1) is driven through ifx_owner_frame_phase / ifx_owner_exchange"; return IFX_E_STATE; }
     if (bootstrap && !in_pose16) { h->err = "bootstrap needs inPose (EF/ElasticFusion.cpp:352-356)"; return IFX_E_INVALID; }
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
@@ -568,10 +576,56 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
 // ---- spatially sharded map (ifx_config::n_ranks > 1): one frame in eight phases; after phase p (0..6) the caller reduces the buffers
 // ifx_owner_exchange(p) lists across the ranks (instancefusion_amd/sharded.py: RCCL all-reduce; tests: the same reduction by hand)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
-extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth)
+static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind);
+extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth) { return h ? owner_frame_phase(h, phase, d_rgb, d_depth, 0) : IFX_E_INVALID; }
+// One call = one frame of the sharded map: the eight phases with their exchanges enqueued by the library on the handle's main stream (ifx_comm.hip), no
+// host synchronisation (the frame result lands in pinned memory behind the last kernel, as on the unsharded path).
+static int owner_process_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind)
+{
+    if (!ifx_comm_ready(h)) { h->err = "no communicator: ifx_owner_init_comm / ifx_owner_set_comm first"; return IFX_E_STATE; }
+    for (int phase = 0; phase < 8; phase++) {
+        int r = owner_frame_phase(h, phase, rgb, depth, src_kind);
+        if (r) return r;
+        if (phase < 6) { r = ifx_comm_exchange(h, phase); if (r) return r; }
+    }
+    return IFX_OK;
+}
+extern "C" int ifx_owner_process_frame_device(ifx_t* h, const uint8_t* d_rgb, const uint16_t* d_depth, int64_t timestamp)
+{
+    (void)timestamp;
+    if (!h || !d_rgb || !d_depth) return IFX_E_INVALID;
+    return owner_process_frame(h, d_rgb, d_depth, 0);
+}
+// ElasticFusion::processFrame's signature on the sharded map: host pointers, H2D inside the call, one host synchronisation, the pose back
+extern "C" int ifx_owner_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float* out_pose16)
+{
+    (void)timestamp;
+    if (!h || !rgb || !depth) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
+    memcpy(h->depth_stage, depth, (size_t)h->P * 2);
+    int r = owner_process_frame(h, h->rgb_stage, h->depth_stage, 1);
+    if (r) return r;
+    r = ifx_sync(h);
+    if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
+    return r;
+}
+// ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose), exchanges included
+extern "C" int ifx_owner_predict(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!ifx_comm_ready(h)) { h->err = "no communicator: ifx_owner_init_comm / ifx_owner_set_comm first"; return IFX_E_STATE; }
+    for (int step = 0; step < 3; step++) {
+        int r = ifx_owner_predict_phase(h, step);
+        if (r) return r;
+        if (step < 2) { r = ifx_comm_exchange(h, 4 + step); if (r) return r; }
+    }
+    return IFX_OK;
+}
+static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind)
 {
     if (!h || phase < 0 || phase > 7) return IFX_E_INVALID;
-    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (!h->own) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     if (h->lc_enable) { h->err = "loop-closure detection is not available on a sharded map"; return IFX_E_STATE; }
     const bool first = h->tick == 1 && h->n_traj == 0;
     const int s = h->tick & 1;
@@ -582,7 +636,7 @@ extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, 
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
         const int two = h->opt_two_streams;
         h->opt_two_streams = 0;
-        int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, 0);
+        int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, src_kind);
         h->opt_two_streams = two;
         if (r) return r;
         f.for_tick = -1;
@@ -607,9 +661,9 @@ extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, 
 extern "C" int ifx_owner_predict_phase(ifx_t* h, int step)
 {
     if (!h || step < 0 || step > 2) return IFX_E_INVALID;
-    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_predict_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (!h->own) { h->err = "ifx_owner_predict_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     h->tracked_ahead = 0;
-    return ifx_map_owner_phase(h, step == 0 ? 104 : 4 + step, false);
+    return ifx_map_owner_phase(h, 104 + step, false);
 }
 // what to reduce after phase `phase`: ptrs[k] (device), bytes[k], ops[k] (0: element-wise minimum of unsigned 64-bit words, 1: sum of
 // 32-bit words -- the supports are disjoint, so the sum is a bitwise merge); returns the number of buffers (0: nothing to exchange)
@@ -622,12 +676,12 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
     switch (phase) {
     case 0: if (!first) add(h->key_index, P * 8, 0); break;
-    case 1: if (!first) { add(h->index_vc, P * 16, 1); add(h->index_nr, P * 16, 1); } break;
+    case 1: if (!first) add(h->index_vc, P * 32, 1); break;                                   // [index_vc | index_nr], one allocation
     case 2: if (!first) add(h->key_index, P * 8, 0); break;
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
-    case 4: add(h->key_splat, P * 8, 0); add(h->key_ids, P * 8, 0); add(h->key_both, P * 8, 0); break;
-    case 5: add(h->pred_vertex, P * 16, 1); add(h->pred_normal, P * 16, 1); add(h->pred_image, P * 4, 1); add(h->pred_inst, P * 4, 1); add(h->pred_time, P * 2, 1); break;
-    case 6: if (!first) add(&h->d_state->seg_acc[0], 4, 1); break;   // vote mass under the id image: every rank adds the surfels it owns
+    case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
+    case 5: add(h->pred_vertex, h->pred_bytes, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
+    case 6: break;
     case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume)
         switch (h->oseg_pending) {
         case 1: add(h->d_bbox, (size_t)(96 + h->oseg_nm) * 4 * 4, 2); break;                       // boxes, maxima negated: MIN of 32-bit words
@@ -906,10 +960,10 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     const int n_all = n;
     std::vector<uint32_t> keep;
     std::vector<float> f_pc, f_nr, f_col, f_tm, f_ic, f_votes;
-    keep.reserve(h->cfg.n_ranks > 1 ? (size_t)n / h->cfg.n_ranks + 1024 : (size_t)n);
+    keep.reserve(h->own ? (size_t)n / h->own_g + 1024 : (size_t)n);
     for (int i = 0; i < n; i++)
-        if (h->cfg.n_ranks <= 1 || ifx_owner_of_point(pc[(size_t)i * 4], pc[(size_t)i * 4 + 1], pc[(size_t)i * 4 + 2], h->cfg.n_ranks) == h->cfg.rank) keep.push_back((uint32_t)i);
-    if (h->cfg.n_ranks > 1) {
+        if (!h->own || ifx_owner_of_point(pc[(size_t)i * 4], pc[(size_t)i * 4 + 1], pc[(size_t)i * 4 + 2], h->own_g) == h->cfg.rank) keep.push_back((uint32_t)i);
+    if (h->own) {
         const size_t m = keep.size();
         auto gather = [&](const float* src, int width, std::vector<float>& dst) {
             if (!src) return (const float*)nullptr;

@@ -85,7 +85,7 @@ struct DevState {
 struct IdMap { const uint32_t* seq; int own_n; };
 __device__ __forceinline__ int idmap_slot(const IdMap& m, int count, int id)
 {
-    if (m.own_n <= 1) return (id > 0 && id < count) ? id : -1;
+    if (m.own_n <= 0) return (id > 0 && id < count) ? id : -1;
     if (id == 0) return -1;
     int lo = 0, hi = count - 1;
     while (lo <= hi) {
@@ -191,6 +191,9 @@ struct ifx {
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
     FrameSlot slot[2];
     int cur_slot = 0;
+    int own = 0, own_g = 1;             // spatially sharded map (ifx_config::n_ranks > 1, or -1: a world of one): this handle stores the surfels it owns; own_g = number of ranks
+    size_t pred_bytes = 0; int* pred_tail = nullptr;   // the prediction images are one allocation of pred_bytes (+ a 16-byte tail that travels with them on a sharded map)
+    void* comm = nullptr;               // ifx_comm.hip: the RCCL communicator + exchange scratch of a sharded map (ifx_owner_init_comm / ifx_owner_set_comm)
     int shard_rank = 0, shard_n = 1;    // sharded projection: this rank's slice of the slots (ifx_set_shard)
     int opt_two_streams = 1;
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
@@ -338,7 +341,7 @@ struct ifx {
     std::vector<PendingEvent> kpending;
     std::vector<hipEvent_t> event_pool;
 };
-static inline IdMap ifx_idmap(const ifx* h) { IdMap m; m.seq = h->seq; m.own_n = h->cfg.n_ranks > 1 ? h->cfg.n_ranks : 1; return m; }
+static inline IdMap ifx_idmap(const ifx* h) { IdMap m; m.seq = h->seq; m.own_n = h->own ? h->own_g : 0; return m; }
 
 #define HIPCHK(h, call)                                                                            \
     do {                                                                                           \
@@ -400,4 +403,8 @@ int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_tot
 int ifx_alloc_tracker(ifx* h);
 void ifx_free_tracker(ifx* h);
 int ifx_alloc_instance(ifx* h);
+// ifx_comm.hip: the collectives of a sharded map inside the library
+int ifx_comm_exchange(ifx* h, int phase);
+int ifx_comm_ready(ifx* h);
+void ifx_comm_free(ifx* h);
 void ifx_free_instance(ifx* h);

@@ -738,7 +738,7 @@ static int oseg_mask_loop(ifx* h, bool after_eviction)
 extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
-    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_segmentation_begin: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (!h->own) { h->err = "ifx_owner_segmentation_begin: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     if (flags & 1) { h->err = "kNN smoothing is not offered on a sharded map (it needs every rank's positions)"; return IFX_E_INVALID; }
     if (h->oseg_state) { h->err = "a segmentation call is already in flight"; return IFX_E_STATE; }
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }

@@ -358,7 +358,7 @@ extern "C" int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n)
 extern "C" int ifx_owner_knn_export(ifx_t* h, void** d_points, void** d_labels, int* n)
 {
     if (!h || !d_points || !d_labels || !n) return IFX_E_INVALID;
-    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_knn_export: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (!h->own) { h->err = "ifx_owner_knn_export: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     ifx_vlist_reap(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int cnt = 0;
@@ -374,7 +374,7 @@ extern "C" int ifx_owner_knn_export(ifx_t* h, void** d_points, void** d_labels, 
 extern "C" int ifx_owner_knn_vote(ifx_t* h, const void* d_all_points, const void* d_all_labels, int n_all, int own_offset)
 {
     if (!h || !d_all_points || !d_all_labels || n_all < 0 || own_offset < 0) return IFX_E_INVALID;
-    if (h->cfg.n_ranks <= 1) { h->err = "ifx_owner_knn_vote: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
+    if (!h->own) { h->err = "ifx_owner_knn_vote: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     int own_n = 0;
     HIPCHK(h, hipMemcpy(&own_n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
     if (own_offset + own_n > n_all) { h->err = "ifx_owner_knn_vote: this rank's export does not fit the gathered set"; return IFX_E_INVALID; }

@@ -73,10 +73,10 @@ struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta
 __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
 // Spatially sharded map: the id a surfel carries in keys / id images is its creation number (the same on every rank; ascending in slot order,
 // so "lowest id wins" is the single-GPU tie-break), and a rank finds the slot of an id it owns by binary search -- -1: another rank's surfel.
-__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 1 ? c.seq[i] : i; }
+__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 0 ? c.seq[i] : i; }
 __device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id)
 {
-    if (c.own_n <= 1) return (int)id;
+    if (c.own_n <= 0) return (int)id;
     int lo = 0, hi = count - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -93,7 +93,7 @@ static Cam make_cam(ifx* h)
     c.maxDepth = h->cfg.max_depth_processed; c.conf = h->cfg.confidence; c.timeDelta = h->cfg.time_delta;
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
-    c.seq = h->seq; c.own_n = h->cfg.n_ranks > 1 ? h->cfg.n_ranks : 1; c.own_rank = h->cfg.n_ranks > 1 ? h->cfg.rank : 0;
+    c.seq = h->seq; c.own_n = h->own ? h->own_g : 0; c.own_rank = h->own ? h->cfg.rank : 0;
     return c;
 }
 
@@ -488,10 +488,13 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
 // End of a raster pass in one launch: block 0 = the dense-enough test (EF/ElasticFusion.cpp:252-267) and the re-arm of the work list;
 // blocks 1.. = checkProjectDepthAndInstanceKernel (IF/Core/InstanceFusionCuda.cu:736-760) over the id image this pass
 // rendered, accumulated for k_frame_result, so that whetherDoSegmentation needs no launch of its own.
+// Sharded map: the vote mass goes to `mass_out` (the tail of the prediction block, summed across the ranks with it) and the launch of the next
+// phase takes the total back through `mass_in`.
 __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, int w, int h, int do_dense, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap,
-                                int downsample, unsigned int* __restrict__ lctr, IdMap im)
+                                int downsample, unsigned int* __restrict__ lctr, IdMap im, int* __restrict__ mass_out = nullptr, int* __restrict__ mass_in = nullptr)
 {
     if (blockIdx.x == 0) {
+        if (mass_in && threadIdx.x == 0) { st->seg_acc[0] = mass_in[0]; mass_in[0] = 0; }
         if (do_dense) {
             __shared__ int lds[4];
             int rw = w / 20, rh = h / 20, cnt = 0;
@@ -520,7 +523,7 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
         if (x < w && y < h) {
             const int gid = ids[y * w + x];
             const int id = idmap_slot(im, st->count, gid);   // sharded map: the vote mass of a pixel is counted by the rank that owns its surfel (summed across ranks afterwards)
-            if (im.own_n > 1 ? gid > 0 : id >= 0) {
+            if (im.own_n > 0 ? gid > 0 : id >= 0) {
               if (id >= 0) {
                 float4 v[12];   // all twelve planes in flight together (one after the other they were twelve HBM round trips: 13 us for this little kernel)
 #pragma unroll
@@ -540,7 +543,7 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
     mass = wave_sum_i(mass);
     empty = wave_sum_i(empty);
     if ((threadIdx.x & 63) == 0) {
-        if (mass) atomicAdd(&st->seg_acc[0], mass);
+        if (mass) atomicAdd(mass_out ? mass_out : &st->seg_acc[0], mass);
         if (empty) atomicAdd(&st->seg_acc[1], empty);
     }
 }
@@ -1839,7 +1842,7 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
             if (assoc[k] == ASSOC_NEW) {
                 float lastT = -2.f;
                 const float4 m4 = mpc[k];
-                if (clean_test(T, c, time, m4, mnr[k], (float)time, lastT, tap)) keep[u] = 1 | ((c.own_n <= 1 || ifx_owner_of_point(m4.x, m4.y, m4.z, c.own_n) == c.own_rank) ? 2 : 0);
+                if (clean_test(T, c, time, m4, mnr[k], (float)time, lastT, tap)) keep[u] = 1 | ((c.own_n <= 0 || ifx_owner_of_point(m4.x, m4.y, m4.z, c.own_n) == c.own_rank) ? 2 : 0);
             }
         }
         cnt += keep[u] & 1;
@@ -1997,7 +2000,7 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
            (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2, (const uint32_t*)h->seq, h->seq2);
     LAUNCH(h, "compact_count", dim3(1), dim3(64), k_compact_count, h->d_state, &h->d_state->seg_counts[1]);
     std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2); std::swap(h->seq, h->seq2);
-    if (refresh_ids && h->cfg.n_ranks <= 1) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image (a sharded map's id image holds creation numbers: nothing changed)
+    if (refresh_ids && !h->own) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image (a sharded map's id image holds creation numbers: nothing changed)
     return IFX_OK;
 }
 
@@ -2186,14 +2189,14 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
            (const float4*)h->index_tap, h->scan_flags, h->scan_block);
     LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
            (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->cfg.n_ranks > 1 ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
+           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->own ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
     // the new surfels were never associated: clear the arbitration words nobody reset (losing pixels)
 }
 
 // ---- frame path through the cached view list
 __global__ void k_vlist_invalidate(DevState* st) { if (threadIdx.x == 0) st->vl_valid = 0; }
 void hs_invalidate_view(ifx* h) { LAUNCH(h, "vlist_invalidate", dim3(1), dim3(64), k_vlist_invalidate, h->d_state); }
-static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && h->cfg.n_ranks <= 1 && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
+static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && !h->own && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
 static void view_scan(ifx* h, int time)
 {
     Cam c = make_cam(h);
@@ -2245,13 +2248,13 @@ int ifx_map_frame(ifx* h)
                (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
         LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
                (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->cfg.n_ranks > 1 ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
+               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->own ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
         h->view_frame = 1; h->view_dirty = 1; h->last_clean_time = time;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);   // (reaps first; the raster below then takes the per-pass cull: the list is void after a compaction)
         h->ids_pending = 1;
         return IFX_OK;
     }
-    if (h->opt_vlist && h->cfg.n_ranks <= 1 && h->shard_n <= 1) hs_invalidate_view(h);   // this frame runs no scan: a device-side "valid" must never describe a list the host did not build
+    if (h->opt_vlist && !h->own && h->shard_n <= 1) hs_invalidate_view(h);   // this frame runs no scan: a device-side "valid" must never describe a list the host did not build
     index_pass(h, nullptr, h->tick, true);
     fuse_pass(h, nullptr, 0.f, h->tick);
     if (h->opt_reference_passes) {   // renders nobody on the path consumes (EF/ElasticFusion.cpp:679-680); they need the post-fuse index map too
@@ -2396,7 +2399,7 @@ __global__ void k_fill_in(Cam c, const uint8_t* __restrict__ rgb, const uint16_t
 static void owner_filter(ifx* h)
 {
     const int n = h->cap;
-    LAUNCH(h, "owner_flags", dim3(cdiv(n, 256)), dim3(256), k_owner_flags, (const DevState*)h->d_state, (const float4*)h->pc, h->cfg.n_ranks, h->cfg.rank, h->scan_flags, n);
+    LAUNCH(h, "owner_flags", dim3(cdiv(n, 256)), dim3(256), k_owner_flags, (const DevState*)h->d_state, (const float4*)h->pc, h->own_g, h->cfg.rank, h->scan_flags, n);
     ifx_scan_exclusive(h, h->scan_flags, n, h->scan_out, &h->d_state->seg_counts[1]);
     LAUNCH(h, "compact_scatter", dim3(cdiv(n, 256)), dim3(256), k_compact_scatter, h->scan_flags, h->scan_out, n, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->col, (const float2*)h->tm, (const float4*)h->ic, (const float4*)h->votes, (const int32_t*)h->labels, (float4*)h->pc2, (float4*)h->nr2,
@@ -2405,13 +2408,31 @@ static void owner_filter(ifx* h)
     std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2); std::swap(h->seq, h->seq2);
 }
 
-// phase p of a frame of the sharded map; the caller reduces the buffers ifx_owner_exchange(p) lists across the ranks before phase p + 1
+// The pixels a surfel covers in BOTH renders of a raster pass went to key_both (one atomic instead of two); before the keys travel they are folded back
+// into the two renders' own images, so that an exchange point moves two key images instead of three (the resolve's min with key_both then finds it empty).
+__global__ void k_merge_both(unsigned long long* __restrict__ ks, unsigned long long* __restrict__ ki, unsigned long long* __restrict__ kb, int P)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const unsigned long long b = kb[k];
+    if (b == IFX_KEY_EMPTY) return;
+    const unsigned long long a = ks[k], c = ki[k];
+    ks[k] = a < b ? a : b;
+    ki[k] = c < b ? c : b;
+    kb[k] = IFX_KEY_EMPTY;
+}
+
+// phase p of a frame of the sharded map; the buffers ifx_owner_exchange(p) lists are reduced across the ranks before phase p + 1 -- by the library itself
+// on its communicator (ifx_comm.hip: ifx_owner_process_frame_device), or by the caller (the emulation tests).  phase 104..106: ElasticFusion::predict
+// outside a frame (ifx_owner_predict_phase): phases 4..6 without the clean / append and without the whetherDoSegmentation sums.
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
 {
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
     const int time = h->tick;
     const dim3 b2(32, 8), g2(cdiv(h->w, 32), cdiv(h->h, 8));
+    const bool in_frame = phase < 100;
+    if (phase >= 105) phase -= 100;
     if (first_frame) {
         switch (phase) {
         case 0: ifx_map_init_first(h); owner_filter(h); break;
@@ -2424,7 +2445,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         case 6:
             LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
                    (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-            LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
+            LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
+                   (int*)nullptr, h->pred_tail);
             break;
         default: break;   // (incl. 7)
         }
@@ -2432,14 +2454,14 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
     }
     switch (phase) {
     case 0: index_pass(h, nullptr, time, true, 1); break;                                                   // local projection | keys: MIN
-    case 1: index_pass(h, nullptr, time, true, 2); break;                                                   // winners this rank owns | index_vc, index_nr: SUM
+    case 1: index_pass(h, nullptr, time, true, 2); break;                                                   // winners this rank owns | [index_vc | index_nr]: SUM
     case 2: fuse_pass(h, nullptr, 0.f, time); clean_pass(h, nullptr, time, 1); break;                       // association (replicated), update (owned), post-fuse projection | keys: MIN
     case 3:                                                                                                 // owned tap records | index_tap: SUM
         LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
                (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,
                (float4*)h->index_tap, c);
         break;
-    case 4: {                                                                                               // clean (local), append (replicated list, owned kept), local raster | keys: MIN
+    case 4: {                                                                                               // clean (local), append (replicated list, owned kept), local raster | [key_splat | key_ids]: MIN
         LAUNCH(h, "clean_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_list, h->d_state, (const float*)nullptr, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
                (const float4*)h->index_tap, h->list_b, h->list_c);
         const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
@@ -2451,21 +2473,30 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         h->last_clean_time = time;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
         raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
+        LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
         break;
     }
-    case 104: raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1); break;   // ifx_owner_predict_phase: the local raster alone
-    case 5:                                                                                                 // owned winners of the prediction | pred_*: SUM ; ids_after = creation numbers, from the keys
+    case 104:                                                                                               // ifx_owner_predict_phase: the local raster alone
+        raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
+        LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
+        break;
+    case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
                (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr);
-        break;
-    case 6: {                                                                                               // fill-in and dense flag on the exchanged prediction (replicated); whetherDoSegmentation sums: empty pixels replicated, vote mass of the owned surfels | seg_acc[0]: SUM
-        LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
-               (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
-        const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);
-        LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h));
+        if (in_frame) {   // whetherDoSegmentation sums: empty pixels replicated, vote mass by the owners -> the tail of the prediction block
+            const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);
+            LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h),
+                   h->pred_tail, (int*)nullptr);
+        }
         break;
     }
+    case 6:                                                                                                 // fill-in and dense flag on the exchanged prediction (replicated); takes the summed vote mass
+        LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
+               (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
+               (int*)nullptr, in_frame ? h->pred_tail : (int*)nullptr);
+        break;
     case 7: break;                                                                                          // (the frame result is published by ifx_owner_frame_phase)
     default: return IFX_E_INVALID;
     }

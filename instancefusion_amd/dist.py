@@ -1,8 +1,10 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm).
 
 What is sharded (DESIGN.md "Multi-GPU"):
-* round 1: `bench.py --gpus N` runs N replicas (one stream + one map per rank), no data-path
+* default of `bench.py --gpus N`: N replicas (one stream + one map per rank), no data-path
   collective; only the timing barrier / max-over-ranks go through torch.distributed.
+* `bench.py --sharded`: one stream into ONE spatially sharded map; the exchanges of a frame are enqueued by libifx.so itself on a RCCL
+  communicator (csrc/ifx_comm.hip), torch.distributed only carries the ncclUniqueId to the ranks.
 * `owner_of` is the owner function of the spatially sharded map (8 cm voxel -> Morton code -> mod n_ranks), the
   Python twin of ifx_owner_of_point: `ifx_map_upload` and the append kernel of a handle created with n_ranks > 1 keep the surfels it
   selects (instancefusion_amd/sharded.py: OwnerShardedElasticFusion).

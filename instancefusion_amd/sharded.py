@@ -1,4 +1,7 @@
-"""Sharded projection across the GPUs of one node.
+"""Multi-GPU drivers over libifx.so: the spatially sharded map (OwnerShardedElasticFusion: the collectives
+are enqueued by the library itself, csrc/ifx_comm.hip) and, first in this file, round 1's sharded PROJECTION over full replicas.
+
+Sharded projection:
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank holds the full surfel map and is
 fed the same frames and masks, so the replicas stay bit-identical; the passes that stream the whole store with one
@@ -117,19 +120,35 @@ class _DevWords:
 
 
 class OwnerShardedElasticFusion:
-    """ElasticFusion.processFrame over a spatially sharded map: `ef` was created with n_ranks = world, rank = this rank, on this rank's
-    GPU; `dist` is torch.distributed (backend nccl = RCCL over xGMI).  Per frame: eight phases (the last one publishes the frame result), between them all-reduces of the key images
-    (unsigned MIN) and of the winners' attribute images (int32 SUM over disjoint supports), enqueued on the handle's own stream."""
+    """ElasticFusion.processFrame over a spatially sharded map: `ef` was created with n_ranks = world, rank = this rank, on this rank's GPU
+    (world of one: n_ranks = -1).  The collectives live INSIDE libifx.so (csrc/ifx_comm.hip): this class only hands the library a communicator --
+    rank 0 draws a ncclUniqueId (ifx_comm_unique_id), `dist` (torch.distributed, any backend; None for a world of one) carries its 128 bytes to the
+    other ranks, every rank calls ifx_owner_init_comm -- and a frame / predict / segmentation call / kNN smoothing is ONE library call each,
+    with no return to Python between the phases.  `transport="torch"` keeps round 2's caller-driven exchanges (torch.distributed all-reduces on the
+    handle's stream between ifx_owner_frame_phase calls) for hosts that bring their own transport."""
 
-    def __init__(self, ef, dist):
+    def __init__(self, ef, dist=None, transport: str = "library"):
         import torch
 
-        self.ef, self.dist, self.torch = ef, dist, torch
-        main = C.c_void_p()
-        ef._chk(ef.L.ifx_stream_handles(ef.handle, C.byref(main), None), "ifx_stream_handles")
+        self.ef, self.dist, self.torch, self.transport = ef, dist, torch, transport
         self.dev = f"cuda:{ef.cfgd['device']}"
-        self.stream = torch.cuda.ExternalStream(main.value, device=self.dev)
+        if transport == "library":
+            uid = np.zeros(128, np.uint8)
+            multi = dist is not None and dist.get_world_size() > 1
+            if not multi or dist.get_rank() == 0:
+                ef._chk(ef.L.ifx_comm_unique_id(uid.ctypes.data_as(C.c_void_p)), "ifx_comm_unique_id")
+            if multi:
+                on_gpu = dist.get_backend() == "nccl"
+                t = torch.from_numpy(uid).to(self.dev) if on_gpu else torch.from_numpy(uid)
+                dist.broadcast(t, src=0)
+                uid = t.cpu().numpy().copy()
+            ef._chk(ef.L.ifx_owner_init_comm(ef.handle, uid.ctypes.data_as(C.c_void_p)), "ifx_owner_init_comm")
+        else:
+            main = C.c_void_p()
+            ef._chk(ef.L.ifx_stream_handles(ef.handle, C.byref(main), None), "ifx_stream_handles")
+            self.stream = torch.cuda.ExternalStream(main.value, device=self.dev)
 
+    # ---- caller-driven exchanges (transport="torch")
     def _tensor(self, ptr, nbytes, op):
         return self.torch.as_tensor(_DevWords(ptr, nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=self.dev)
 
@@ -144,22 +163,45 @@ class OwnerShardedElasticFusion:
                     else:
                         self.dist.all_reduce(t, op={1: self.dist.ReduceOp.SUM, 2: self.dist.ReduceOp.MIN, 3: self.dist.ReduceOp.MAX}[op])
 
+    # ---- the frame
     def process_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         ef = self.ef
-        for phase in range(8):   # 0..6 with their exchanges (after 6: the vote mass of the whetherDoSegmentation sums), 7 publishes the frame result
+        if self.transport == "library":
+            ef._chk(ef.L.ifx_owner_process_frame_device(ef.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr), 0), "ifx_owner_process_frame_device")
+            return
+        for phase in range(8):   # 0..5 with their exchanges, 6 fill-in / dense flag, 7 publishes the frame result
             ef._chk(ef.L.ifx_owner_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
             self._exchange(phase)
+
+    def process_frame(self, rgb, depth):
+        """ElasticFusion::processFrame's shape: host images in, currPose out (one synchronisation)."""
+        ef = self.ef
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        pose = np.zeros(16, np.float32)
+        ef._chk(ef.L.ifx_owner_process_frame(ef.handle, rgb.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p), 0, pose.ctypes.data_as(C.c_void_p)), "ifx_owner_process_frame")
+        return pose.reshape(4, 4)
 
     def predict(self):
         """ElasticFusion::predict outside a frame (after upload / set_pose)."""
         ef = self.ef
+        if self.transport == "library":
+            ef._chk(ef.L.ifx_owner_predict(ef.handle), "ifx_owner_predict")
+            return
         for step in range(3):
             ef._chk(ef.L.ifx_owner_predict_phase(ef.handle, step), "ifx_owner_predict_phase")
             if step < 2:
                 self._exchange(4 + step)
 
+    def exchange_stats(self, reset=False):
+        out = np.zeros(2, np.int64)
+        self.ef._chk(self.ef.L.ifx_owner_exchange_stats(self.ef.handle, out.ctypes.data_as(C.c_void_p), int(reset)), "ifx_owner_exchange_stats")
+        return dict(collectives=int(out[0]), bytes=int(out[1]))
+
     def knn_vote_colour(self):
         """InstanceFusion::flannKnnVoteSurfelMap on the sharded map: all-gather of every rank's slots (20 B each), exact 10-NN of the owned surfels."""
+        if self.transport == "library":
+            self.ef._chk(self.ef.L.ifx_owner_knn_vote_colour(self.ef.handle), "ifx_owner_knn_vote_colour")
+            return
         torch, dist = self.torch, self.dist
         pts, lab = _knn_export(self.ef, torch, self.dev)
         if dist is None:
@@ -181,13 +223,23 @@ class OwnerShardedElasticFusion:
         torch.cuda.synchronize()
         self.ef._chk(self.ef.L.ifx_owner_knn_vote(self.ef.handle, C.c_void_p(allp.data_ptr()), C.c_void_p(alll.data_ptr()), int(allp.shape[0]), int(off)), "ifx_owner_knn_vote")
 
-    def process_segmentation(self, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True):
+    def process_segmentation(self, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True, knn: bool = False):
         """InstanceFusion::processInstance on the sharded map (same masks on every rank): the owners' partial boxes, model depth and -- when the
         instance table overflows -- eviction statistics are merged at the call's exchange points; labels of the owned surfels: ef.labels()."""
+        if self.transport == "library":
+            ef = self.ef
+            masks = np.ascontiguousarray(masks, np.uint8); cls = np.ascontiguousarray(class_ids, np.int32)
+            rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+            ef._chk(ef.L.ifx_owner_process_segmentation(ef.handle, rgb.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p), masks.ctypes.data_as(C.c_void_p),
+                                                        cls.ctypes.data_as(C.c_void_p), int(masks.shape[0]), int(frame), (2 if superpixels else 0) | (1 if knn else 0)),
+                    "ifx_owner_process_segmentation")
+            return
         r = _seg_begin(self.ef, rgb, depth, masks, class_ids, frame, superpixels)
         while r == 1:
             self._exchange(200)
             r = self.ef._chk(self.ef.L.ifx_owner_segmentation_resume(self.ef.handle), "ifx_owner_segmentation_resume")
+        if knn:
+            self.knn_vote_colour()
 
 
 def _knn_export(ef, torch, dev):

@@ -777,11 +777,17 @@ def test_view_list_survives_a_full_map(ifx, small_stream):
             assert 0 <= vs["window"] <= cap and 0 <= vs["outside"] <= cap, vs
             ids = g.image("ids_after")
             assert ids.min() >= 0 and ids.max() < cap
-    assert full > 0 and g.slots == cap
+    assert full > 0
+    with pytest.raises(ifx.IfxError, match="capacity"):    # the flag is sticky until a map is uploaded: whole-map consumers refuse too
+        g.download()
+    # an uploaded map clears it; the handle tracks and fuses again
+    from instancefusion_amd import synth
+    small = synth.make_map(5_000, st["scene"], st["poses_world"][0], 1000)
+    g.upload(small); g.set_pose(st["poses"][0], 1000)
+    for i in range(1, 4):
+        g.processFrame(st["rgb"][i], st["depth"][i], inPose=st["poses"][i])
     m = g.download()
-    assert m["pc"].shape[0] <= cap and np.isfinite(m["pc"]).all() and np.isfinite(m["nr"]).all()
-    g.compact()
-    assert g.count == m["pc"].shape[0]
+    assert 5_000 < m["pc"].shape[0] <= cap and np.isfinite(m["pc"]).all() and np.isfinite(m["nr"]).all()
     g.close()
 
 
@@ -1367,6 +1373,72 @@ def test_sharded_rccl_world_of_one(ifx, small_stream):
         a.close(); b.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
+    """The spatially sharded map with the collectives INSIDE libifx.so (csrc/ifx_comm.hip), on real RCCL: a world of one (ifx_config.n_ranks = -1:
+    creation-number ids, owner filter, every exchange point of a frame / predict / segmentation call / kNN smoothing issued as a one-rank
+    ncclAllReduce / ncclAllGather on the handle's stream by the library itself).  One library call per frame; against the unsharded handle:
+    poses, prediction / fill-in / id images, instance table, and -- by creation number -- the whole map, votes, labels and colours, bit for bit.
+    Also the host-pointer entry (ifx_owner_process_frame) and the exchange statistics: six collectives and 122 bytes per pixel per frame."""
+    import torch
+
+    from instancefusion_amd import sharded, synth
+
+    st = small_stream
+    NF = 9
+    d_rgb = torch.from_numpy(st["rgb"][:NF].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:NF].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    ef = ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=-1, rank=0)
+    osh = sharded.OwnerShardedElasticFusion(ef, None)            # ifx_comm_unique_id + ifx_owner_init_comm: ncclCommInitRank(1, id, 0)
+    inst_one, inst = ifx.InstanceFusion(one), ifx.InstanceFusion(ef)
+    P = SMALL["w"] * SMALL["h"]
+
+    def by_seq(x):
+        return x[np.argsort(ef.seq(), kind="stable")]
+
+    for i in range(NF):
+        if i == 4:   # an uploaded, stable map: upload keeps the owned rows (all of them here), predict runs with its two exchanges inside the library
+            m = one.download(); m["pc"][:, 3] = 20.0
+            pose = one.getCurrPose()
+            one.upload(m); one.set_pose(pose, one.tick); one.combined_predict(pose, one.tick, one.tick)
+            ef.upload(m); ef.set_pose(pose, one.tick)
+            osh.predict()
+        if i == 6:   # the reference-shaped entry: host pointers, one synchronisation, currPose back
+            one.processFrame(st["rgb"][i], st["depth"][i])
+            pg = osh.process_frame(st["rgb"][i], st["depth"][i])
+            assert np.array_equal(pg, one.getCurrPose())
+        else:
+            if i == 7:
+                osh.exchange_stats(reset=True)
+            one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+            if i == 7:
+                xs = osh.exchange_stats()
+                assert xs["collectives"] == 6 and xs["bytes"] == 122 * P + 16, xs     # keys 8 + 8 + 16, attribute blocks 32 + 16 + 42 bytes per pixel, + the 16-byte tail
+        assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
+        for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
+            assert np.array_equal(ef.image(name), one.image(name)), (i, name)
+        want = inst_one.whetherDoSegmentation(i)
+        assert inst.whetherDoSegmentation(i) == want, i
+        if i >= 5:
+            masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+            inst_one.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, i, superpixels=True)
+            osh.process_segmentation(st["rgb"][i], st["depth"][i], masks, cls, i, superpixels=True)
+            assert np.array_equal(inst.getInstanceTable(), inst_one.getInstanceTable()), i
+            assert np.array_equal(by_seq(inst.labels()), inst_one.labels()), i
+    assert (inst_one.labels() >= 0).sum() > 100
+    inst_one.flannKnnVoteSurfelMap()
+    osh.knn_vote_colour()                                       # the all-gather of the slots inside the library
+    ref, got = one.download(), ef.download()
+    order = np.argsort(ef.seq(), kind="stable")
+    assert len(order) == ref["pc"].shape[0]
+    for k in MAP_KEYS:
+        assert np.array_equal(got[k][order], ref[k]), k
+    assert len(np.unique(ref["col"][:, 1])) > 2
+    ef.close(); one.close()
 
 
 # ---------------------------------------------------------------- 8f-3a: local loop-closure detection (INACTIVE prediction + model-to-model tracking + gates)

@@ -11,7 +11,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_$TAG -o w -- python3 bench.py $ARGS > /dev/null 2> gpurun_out/${TAG}_pmc_w.err
 F=$(find gpurun_out/pmc_fetch_$TAG -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/pmc_write_$TAG -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py pmc "$F" "$W" gpurun_out/${TAG}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on python3 bench.py $ARGS" gpurun_out/${TAG}_pmc_bench.json
+python3 tools/pmc_summary.py pmc "$F" "$W" gpurun_out/${TAG}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on python3 bench.py $ARGS" gpurun_out/${TAG}_pmc_bench.json "$(ls gpurun_out/*_pmc_calibration.json profiles/*_pmc_calibration.json 2>/dev/null | tail -1)"
 rm -rf gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG
 python3 - <<PY
 import json

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -123,6 +124,39 @@ inline const char* const* ifx_coco_class_names()
     return names;
 }
 
+// ------------------------------------------------------------------------------------------------ spatially sharded map (one process per GPU)
+// How this process takes part in a spatially sharded map (BASELINE configurations 4 / 5): `ranks` processes, this one is `rank`, each
+// on its own GPU, every one fed the same frames.  The collectives of a frame are enqueued by libifx.so itself on a RCCL communicator
+// (ifx_owner_init_comm); what the host has to do is carry rank 0's 128-byte ncclUniqueId to the other ranks.  `idFile` is the transport for hosts without
+// MPI: rank 0 writes the id there (atomically: temporary name + rename), the others wait for the file.  ranks = -1: a world of one on the sharded path.
+struct Sharding {
+    int ranks = 1, rank = 0;
+    std::string idFile;
+    bool on() const { return ranks > 1 || ranks == -1; }
+    // the id: drawn by rank 0 (or a world of one), read from idFile by the others (waits up to timeoutSeconds for it)
+    std::vector<uint8_t> uniqueId(int timeoutSeconds = 120) const
+    {
+        std::vector<uint8_t> id(128, 0);
+        if (ranks == -1 || rank == 0) {
+            if (ifx_comm_unique_id(id.data()) != IFX_OK) throw std::runtime_error("ifx_comm_unique_id failed (RCCL not loadable?)");
+            if (ranks > 1) {
+                if (idFile.empty()) throw std::runtime_error("Sharding: idFile is needed to hand the ncclUniqueId to the other ranks");
+                const std::string tmp = idFile + ".tmp";
+                { std::ofstream f(tmp, std::ios::binary); f.write((const char*)id.data(), 128); if (!f) throw std::runtime_error("cannot write " + tmp); }
+                if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+            }
+            return id;
+        }
+        if (idFile.empty()) throw std::runtime_error("Sharding: idFile is needed to receive the ncclUniqueId of rank 0");
+        for (int waited = 0; waited < timeoutSeconds * 20; waited++) {
+            std::ifstream f(idFile, std::ios::binary);
+            if (f && f.read((char*)id.data(), 128) && f.gcount() == 128) return id;
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+        throw std::runtime_error("Sharding: no ncclUniqueId in " + idFile + " after waiting");
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ ElasticFusion
 class ElasticFusion {
 public:
@@ -135,11 +169,12 @@ public:
                   const bool closeLoops = true, const bool iclnuim = false, const bool reloc = false, const float photoThresh = 115,
                   const float confidence = 10, const float depthCut = 3, const float icpThresh = 10, const bool fastOdom = false,
                   const float fernThresh = 0.3095, const bool so3 = true, const bool frameToFrameRGB = false, const std::string fileName = "",
-                  const int maxSurfels = 6 * 1000 * 1000, const int device = 0)
+                  const int maxSurfels = 6 * 1000 * 1000, const int device = 0, const Sharding& sharding = Sharding())
         : saveFilename(fileName), closeLoops_(closeLoops), iclnuim_(iclnuim), reloc_(reloc), frameToFrameRGB_(frameToFrameRGB),
-          countThresh_(countThresh), errThresh_(errThresh), covThresh_(covThresh), photoThresh_(photoThresh), fernThresh_(fernThresh)
+          countThresh_(countThresh), errThresh_(errThresh), covThresh_(covThresh), photoThresh_(photoThresh), fernThresh_(fernThresh), sharding_(sharding)
     {
         if (frameToFrameRGB) throw std::runtime_error("ElasticFusion: frameToFrameRGB is not part of the MI355X path");
+        if (sharding.on() && closeLoops) throw std::runtime_error("ElasticFusion: loop closure is not available on a spatially sharded map (pass closeLoops = false)");
         std::memset(&cfg_, 0, sizeof(cfg_));
         cfg_.width = Resolution::getInstance().width();
         cfg_.height = Resolution::getInstance().height();
@@ -157,9 +192,17 @@ public:
         cfg_.so3 = so3 ? 1 : 0;
         cfg_.max_surfels = maxSurfels;
         cfg_.device = device;
-        cfg_.n_ranks = 1;
-        cfg_.rank = 0;
+        cfg_.n_ranks = sharding.on() ? sharding.ranks : 1;
+        cfg_.rank = sharding.on() ? sharding.rank : 0;
         if (ifx_create(&cfg_, &h_) != IFX_OK) throw std::runtime_error(std::string("ifx_create: ") + ifx_global_error());
+        if (sharding.on()) {   // the library gets its communicator here; from now on a frame is one call, its exchanges enqueued by libifx.so (csrc/ifx_comm.hip)
+            const std::vector<uint8_t> id = sharding.uniqueId();
+            if (ifx_owner_init_comm(h_, id.data()) != IFX_OK) {
+                const std::string e = ifx_last_error(h_);
+                ifx_destroy(h_);
+                throw std::runtime_error("ifx_owner_init_comm: " + e);
+            }
+        }
         if (closeLoops && ifx_set_loop_closure(h_, 1, countThresh, errThresh, covThresh) != IFX_OK) {
             const std::string e = ifx_last_error(h_);
             ifx_destroy(h_);
@@ -207,8 +250,15 @@ public:
             hadInstanceGT_ = instanceGT != NULL;
         }
         if (bootstrap && !inPose) throw std::runtime_error("ElasticFusion::processFrame: bootstrap needs inPose");   // assert(inPose), EF/ElasticFusion.cpp:354
-        const int r = ifx_process_frame_ex(h_, rgb, depth, timestamp, smallInstanceTable, inPose ? inPose->data() : nullptr, weightMultiplier, bootstrap ? 1 : 0, currPose_.data());
-        if (r < 0) throw std::runtime_error(std::string("ifx_process_frame_ex: ") + ifx_last_error(h_));
+        int r;
+        if (sharding_.on()) {   // every rank is fed the same frame; poses, images and -- merged by creation number -- the map equal the unsharded run
+            if (inPose || bootstrap || weightMultiplier != 1.f) throw std::runtime_error("ElasticFusion::processFrame: inPose / bootstrap / weightMultiplier are not offered on a sharded map");
+            r = ifx_owner_process_frame(h_, rgb, depth, timestamp, currPose_.data());
+            if (r < 0) throw std::runtime_error(std::string("ifx_owner_process_frame: ") + ifx_last_error(h_));
+        } else {
+            r = ifx_process_frame_ex(h_, rgb, depth, timestamp, smallInstanceTable, inPose ? inPose->data() : nullptr, weightMultiplier, bootstrap ? 1 : 0, currPose_.data());
+            if (r < 0) throw std::runtime_error(std::string("ifx_process_frame_ex: ") + ifx_last_error(h_));
+        }
         lost_ = (r == 1);
         if (closeLoops_) {   // poseMatches of the reference (EF/ElasticFusion.h:118): here only counted
             float lc[24];
@@ -540,6 +590,10 @@ private:
     }
     ifx_config cfg_;
     ifx_t* h_ = nullptr;
+    Sharding sharding_;
+public:
+    const Sharding& sharding() const { return sharding_; }
+private:
     Matrix4f currPose_;
     bool lost_ = false;
     int tick_ = 1;   // EF/ElasticFusion.cpp:48
@@ -565,12 +619,12 @@ public:
     // IF/map_interface/ElasticFusionInterface.cpp:27-58 (the GL context and colour look-up go away; the constants stay)
     // closeLoops / confidence: the reference passes true / 10; exposed for replays that want the plain pipeline or a quicker map
     virtual bool Init(std::vector<ClassColour> class_colour_lookup, int maxSurfels = 6 * 1000 * 1000, int device = 0,
-                      const std::string& fileName = "./ResultModel", bool closeLoops = true, float confidence = 10.f)
+                      const std::string& fileName = "./ResultModel", bool closeLoops = true, float confidence = 10.f, const Sharding& sharding = Sharding())
     {
         class_colour_lookup_ = std::move(class_colour_lookup);
         try {
             elastic_fusion_.reset(new ElasticFusion(200, 35000, 5e-05, 1e-05, closeLoops, false, false, 115, confidence, 12, 10, false, 0.3095, true, false, fileName,
-                                                    maxSurfels, device));
+                                                    maxSurfels, device, sharding));
         } catch (const std::exception& e) {
             std::fprintf(stderr, "ElasticFusionInterface::Init: %s\n", e.what());
             return false;
@@ -813,8 +867,10 @@ public:
         MaskResult res;
         if (!source_->detect(frame_num, rgb, width, height, &res)) return;
         const int flags = (isflann ? 1 : 0) | (superpixels_ ? 2 : 0);
-        const int r = ifx_process_segmentation(map->handle(), rgb, depth, res.masks.data(), res.class_ids.data(), res.n, frame_num, flags);
-        if (r < 0) throw std::runtime_error(std::string("ifx_process_segmentation: ") + ifx_last_error(map->handle()));
+        const bool sharded = map->elasticFusion().sharding().on();   // the owners' boxes / model depth / eviction statistics are merged inside the library
+        const int r = sharded ? ifx_owner_process_segmentation(map->handle(), rgb, depth, res.masks.data(), res.class_ids.data(), res.n, frame_num, flags)
+                              : ifx_process_segmentation(map->handle(), rgb, depth, res.masks.data(), res.class_ids.data(), res.n, frame_num, flags);
+        if (r < 0) throw std::runtime_error(std::string(sharded ? "ifx_owner_process_segmentation: " : "ifx_process_segmentation: ") + ifx_last_error(map->handle()));
         handle_ = map->handle();
         segmentations_++;
     }

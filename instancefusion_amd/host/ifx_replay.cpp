@@ -24,6 +24,7 @@ struct Args {
     bool superpixels = true, flip = false, close_loops = true, deform = true;
     int decode_threads = 4;
     float confidence = 10.f;
+    Sharding shard;   // --shard-ranks G --shard-rank r --shard-id FILE: this process is rank r of G over one spatially sharded map (one process per GPU)
 };
 
 int usage(const char* argv0)
@@ -31,7 +32,8 @@ int usage(const char* argv0)
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
                  "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--decode-threads N] [--confidence C]\n"
-                 "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n",
+                 "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n"
+                 "       [--shard-ranks G --shard-rank r --shard-id FILE (one process per GPU over one spatially sharded map; every rank replays the same log; -1: a world of one)]\n",
                  argv0);
     return 2;
 }
@@ -67,6 +69,9 @@ int main(int argc, char** argv)
         else if (s == "--detect-only") a.deform = false;   // loop closures are found and counted, the map is never deformed
         else if (s == "--confidence") a.confidence = (float)std::atof(val("--confidence"));
         else if (s == "--flip-colors") a.flip = true;
+        else if (s == "--shard-ranks") a.shard.ranks = std::atoi(val("--shard-ranks"));   // -1: a world of one on the sharded path
+        else if (s == "--shard-rank") a.shard.rank = std::atoi(val("--shard-rank"));
+        else if (s == "--shard-id") a.shard.idFile = val("--shard-id");                   // where rank 0 leaves the ncclUniqueId for the others
         else if (s == "--help" || s == "-h") { usage(argv[0]); return 0; }
         else if (!s.empty() && s[0] == '-') { std::fprintf(stderr, "unknown option %s\n", s.c_str()); return usage(argv[0]); }
         else a.log = s;
@@ -90,7 +95,8 @@ int main(int argc, char** argv)
         if (!a.masks.empty()) instancefusion->setMaskSource(std::make_shared<MaskReplay>(a.masks));
 
         std::unique_ptr<ElasticFusionInterface> map(new ElasticFusionInterface());
-        if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out, a.close_loops, a.confidence)) {
+        if (a.shard.on()) a.close_loops = false;   // (not available on a sharded map)
+        if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out, a.close_loops, a.confidence, a.shard)) {
             std::cout << "ElasticFusionInterface init failure" << std::endl;
             return 1;
         }

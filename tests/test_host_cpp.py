@@ -305,6 +305,42 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_replay_sharded_world_of_one_equals_unsharded(small_stream, tmp_path):
+    """The C++ host on the spatially sharded map: `ifx_replay --shard-ranks -1` (ElasticFusion constructed with a Sharding spec: ifx_comm_unique_id +
+    ifx_owner_init_comm, then ifx_owner_process_frame / ifx_owner_process_segmentation -- every exchange a RCCL collective enqueued by libifx.so)
+    against the unsharded replay without loop closing: identical trajectory file, PLY models and labels."""
+    from instancefusion_amd import logio, synth
+
+    st = small_stream
+    n = 14
+    src = [i if i < 10 else 18 - i for i in range(n + 1)]
+    klg = str(tmp_path / "s.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="raw")
+    for i in range(n + 1):
+        wr.add(33333 * i, st["rgb"][src[i]], st["depth"][src[i]])
+    wr.close()
+    mdir = tmp_path / "masks"
+    mdir.mkdir()
+    for i in range(n):
+        mk, cl = synth.canned_masks(st["obj"][src[i]], st["scene"])
+        np.savez(mdir / f"{i:06d}.npz", masks=mk, class_ids=cl)
+    common = ["--width", str(SMALL["w"]), "--height", str(SMALL["h"]), "--fx", str(SMALL["fx"]), "--fy", str(SMALL["fy"]), "--cx", str(SMALL["cx"]),
+              "--cy", str(SMALL["cy"]), "--max-surfels", "400000", "--masks", str(mdir), "--flann-every", "2", "--confidence", "2", "--no-close-loops"]
+    outs = {}
+    for tag, extra in (("one", []), ("shard", ["--shard-ranks", "-1"])):
+        out = str(tmp_path / tag)
+        r = subprocess.run([REPLAY, klg] + common + extra + ["--out", out, "--labels", out + ".labels"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert f"{n} frames" in r.stdout and " 0 segmentation calls" not in r.stdout
+        outs[tag] = out
+    assert open(outs["one"] + ".freiburg").read() == open(outs["shard"] + ".freiburg").read()
+    for suffix in (".ply", "_Instance.ply"):
+        assert open(outs["one"] + suffix, "rb").read() == open(outs["shard"] + suffix, "rb").read(), suffix
+    lab = np.fromfile(outs["one"] + ".labels", np.int32)
+    assert lab.size > 0 and (lab >= 0).sum() > 0 and np.array_equal(lab, np.fromfile(outs["shard"] + ".labels", np.int32))
+
+
+@pytest.mark.gpu
 def test_cpp_replay_baseline_size_reference_defaults(tmp_path):
     """ElasticFusionInterface::ProcessFrame at the BASELINE size with the reference's own configuration -- 640x480, Init() defaults, i.e.
     closeLoops = true with the fern data base inside every frame (IF/map_interface/ElasticFusionInterface.cpp:43-45) -- through the C++

@@ -8,7 +8,7 @@
 #include <stdio.h>
 
 /* test hook (orc_set_sum_order): 0 = rows added top to bottom, 1 = bottom to top, 2 = every row partial rounded to f32 first (the precision
- * of the HIP path's per-block partial rows).  Same arithmetic, another summation order / rounding: used to
+ * of the HIP path's per-block partial rows), 3 = the reference's own f32 tree with its GTX 1080 launch table (ref_tree_sum below).  Same arithmetic, another summation order / rounding: used to
  * measure how far two equally valid executions of the algorithm drift apart (tests/test_oracle_cpu.py). */
 int orc_sum_reverse = 0;
 void orc_set_sum_order(int reverse) { orc_sum_reverse = reverse; }
@@ -322,6 +322,70 @@ static void accum_products7(const float* row, int found, double* acc29, const in
     acc29[28] += found ? 1.0 : 0.0;
 }
 
+/* ---- mode 3 of orc_set_sum_order: the sums as THE REFERENCE builds them -- f32 products, f32 additions, in the tree of its kernels with the launch
+ * table's GTX 1080 row (EF/Utils/GPUConfig.h:123-126: icpStep 128 x 160, rgbStep 160 x 80, so3Step 160 x 80).  Thread (b, t) of a <<<B, T>>> launch adds
+ * the products of the pixels b T + t, + B T, ... one after the other (EF/Cuda/reduce.cu:397-402); blockReduceSum (:133-165) folds a warp by shuffles
+ * (offsets 16, 8, 4, 2, 1), parks one partial per warp in shared memory and folds those in warp 0; reduceSum<<<1, 512>>> (:167-185) does the same over the
+ * block partials.  Not what parity is asserted against (the reference's tree depends on the GPU model it runs on): it exists to MEASURE
+ * how far the reference's arithmetic is from the exact sums over a trajectory (tests/test_oracle_cpu.py::test_reference_shaped_f32_tree_gap). */
+static void ref_warp_fold(float v[32][29], int K)
+{
+    for (int off = 16; off >= 1; off >>= 1) {
+        float nv[32][29];
+        for (int l = 0; l < 32; l++)
+            for (int k = 0; k < K; k++) nv[l][k] = v[l][k] + v[l + off < 32 ? l + off : l][k];   /* __shfl_down: a lane past the end reads itself */
+        memcpy(v, nv, sizeof(nv));
+    }
+}
+static void ref_block_reduce(const float* thread_vals /* [T][K] */, int T, int K, float* out /* [K] */)
+{
+    float shared[32][29];
+    memset(shared, 0, sizeof(shared));
+    const int nw = T / 32;
+    for (int wp = 0; wp < nw; wp++) {
+        float v[32][29];
+        for (int l = 0; l < 32; l++)
+            for (int k = 0; k < K; k++) v[l][k] = thread_vals[(size_t)(wp * 32 + l) * K + k];
+        ref_warp_fold(v, K);
+        for (int k = 0; k < K; k++) shared[wp][k] = v[0][k];
+    }
+    float v[32][29];
+    for (int l = 0; l < 32; l++)
+        for (int k = 0; k < K; k++) v[l][k] = l < nw ? shared[l][k] : 0.0f;
+    ref_warp_fold(v, K);
+    for (int k = 0; k < K; k++) out[k] = v[0][k];
+}
+/* prods: [N][K] f32 products of every pixel in the kernel's linear order */
+static void ref_tree_sum(const float* prods, int N, int K, int T, int B, float* out)
+{
+    float* part = (float*)calloc((size_t)B * K, sizeof(float));
+    float* tv = (float*)malloc((size_t)T * K * sizeof(float));
+    for (int b = 0; b < B; b++) {
+        for (int t = 0; t < T; t++) {
+            float* sum = &tv[(size_t)t * K];
+            for (int k = 0; k < K; k++) sum[k] = 0.0f;
+            for (long i = (long)b * T + t; i < N; i += (long)B * T)
+                for (int k = 0; k < K; k++) sum[k] += prods[(size_t)i * K + k];
+        }
+        ref_block_reduce(tv, T, K, &part[(size_t)b * K]);
+    }
+    free(tv);
+    float* tv2 = (float*)calloc((size_t)512 * K, sizeof(float));      /* reduceSum<<<1, MAX_THREADS = 512>>>(sum, out, blocks) */
+    for (int t = 0; t < 512; t++)
+        for (int i = t; i < B; i += 512)
+            for (int k = 0; k < K; k++) tv2[(size_t)t * K + k] += part[(size_t)i * K + k];
+    ref_block_reduce(tv2, 512, K, out);
+    free(tv2); free(part);
+}
+static void ref_products7(const float* row, int found, float* p29)
+{
+    int s = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 7; j++) p29[s++] = row[i] * row[j];
+    p29[27] = row[6] * row[6];
+    p29[28] = found ? 1.0f : 0.0f;
+}
+
 /* ICPReduction::search/getProducts, EF/Cuda/reduce.cu:282-387; sums of :397-402 (+ reduceSum) */
 void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr,
                   const float* nmap_curr, const float* Rprev_inv, const float* tprev, float fx,
@@ -330,6 +394,7 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
 {
     /* one f64 partial sum per image row, rows added in order: the same result for any number of OpenMP threads */
     double (*racc)[29] = (double (*)[29])calloc((size_t)h, sizeof(double[29]));
+    float* prods = orc_sum_reverse == 3 ? (float*)malloc((size_t)w * h * 29 * sizeof(float)) : NULL;
     v3 tc = v3m(tcurr[0], tcurr[1], tcurr[2]), tp = v3m(tprev[0], tprev[1], tprev[2]);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
@@ -363,6 +428,7 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
                 }
             }
             accum_products7(row, found, acc, ORC_E_ICP);
+            if (prods) ref_products7(row, found, &prods[(size_t)(y * w + x) * 29]);
         }
     double tot[29];
     for (int i = 0; i < 29; i++) tot[i] = 0;
@@ -371,6 +437,7 @@ void orc_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
         for (int i = 0; i < 29; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
     }
     for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
+    if (prods) { ref_tree_sum(prods, w * h, 29, 128, 160, out29); free(prods); }   /* icpStepMap["GeForce GTX 1080"] */
     free(racc);
 }
 
@@ -429,6 +496,7 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
                   float* out29)
 {
     double (*racc)[29] = (double (*)[29])calloc((size_t)h, sizeof(double[29]));   /* per-row partial sums, as orc_icp_step */
+    float* prods = orc_sum_reverse == 3 ? (float*)malloc((size_t)w * h * 29 * sizeof(float)) : NULL;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
     for (int k = y * w; k < (y + 1) * w; k++) {   /* a row belongs to one thread: its partial sum is built in pixel order */
@@ -453,6 +521,7 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
             row[5] = -cp[1] * v0 + cp[0] * v1;
         }
         accum_products7(row, c->valid, acc, ORC_E_RGB);
+        if (prods) ref_products7(row, c->valid, &prods[(size_t)k * 29]);
     }
     double tot[29];
     for (int i = 0; i < 29; i++) tot[i] = 0;
@@ -461,6 +530,7 @@ void orc_rgb_step(const orc_dataterm* corres, float sigma, const float* cloud3, 
         for (int i = 0; i < 29; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
     }
     for (int i = 0; i < 29; i++) out29[i] = (float)tot[i];
+    if (prods) { ref_tree_sum(prods, w * h, 29, 160, 80, out29); free(prods); }   /* rgbStepMap["GeForce GTX 1080"] */
     free(racc);
 }
 
@@ -469,6 +539,7 @@ void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float*
                   const float* kinv, const float* krlr, int w, int h, float* out11)
 {
     double (*racc)[11] = (double (*)[11])calloc((size_t)h, sizeof(double[11]));   /* per-row partial sums, as orc_icp_step */
+    float* prods = orc_sum_reverse == 3 ? (float*)malloc((size_t)w * h * 11 * sizeof(float)) : NULL;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -498,6 +569,14 @@ void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float*
                 for (int j = i; j < 4; j++) acc[s++] += orc_quant(row[i] * row[j], ORC_E_SO3[i] + ORC_E_SO3[j] - ORC_SO3_TERM_BITS);
             acc[9] += orc_quant(row[3] * row[3], 2 * ORC_E_SO3[3] - ORC_SO3_TERM_BITS);
             acc[10] += found ? 1.0 : 0.0;
+            if (prods) {   /* JtJJtrSO3, EF/Cuda/types.cuh:154-181 */
+                float* pp = &prods[(size_t)(y * w + x) * 11];
+                int q = 0;
+                for (int i = 0; i < 3; i++)
+                    for (int j = i; j < 4; j++) pp[q++] = row[i] * row[j];
+                pp[9] = row[3] * row[3];
+                pp[10] = found ? 1.0f : 0.0f;
+            }
         }
     double tot[11];
     for (int i = 0; i < 11; i++) tot[i] = 0;
@@ -506,6 +585,7 @@ void orc_so3_step(const uint8_t* last_img, const uint8_t* next_img, const float*
         for (int i = 0; i < 11; i++) tot[i] += orc_sum_reverse == 2 ? (double)(float)racc[y][i] : racc[y][i];
     }
     for (int i = 0; i < 11; i++) out11[i] = (float)tot[i];
+    if (prods) { ref_tree_sum(prods, w * h, 11, 160, 80, out11); free(prods); }   /* so3StepMap["GeForce GTX 1080"] */
     free(racc);
 }
 

@@ -714,6 +714,85 @@ def test_owner_sharded_instance_emulated(ifx, small_stream, world):
     one.close()
 
 
+@pytest.mark.timeout(1500)
+def test_config4_1280x960_20m_map_sharded_x4(ifx):
+    """BASELINE configuration 4 at its size: a 1280x960 stream into a 20M-surfel map spatially sharded over FOUR ranks (5M surfels each; the four
+    handles live in one process on this GPU, the exchanges of a frame reduced by hand exactly as the collectives would) against ONE handle holding all
+    20M surfels.  Over five frames with a segmentation call (superpixels) in between: poses, prediction / fill-in / id images bit for bit every frame,
+    whetherDoSegmentation decisions, instance table, and at the end -- merged by creation number -- the whole 20M-surfel map, votes and labels."""
+    import torch
+
+    from instancefusion_amd import dist as ifd
+    from instancefusion_amd import sharded, synth
+
+    W, H, G, N, NF = 1280, 960, 4, 20_000_000, 5
+    K = dict(fx=1056.0, fy=1056.0, cx=640.0, cy=480.0)
+    st = synth.make_stream(NF + 1, W, H, noise=True, loop_len=90, **K)
+    big = synth.make_map(N, st["scene"], st["poses_world"][0], 1000, fx=K["fx"], fy=K["fy"])
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    one = ifx.ElasticFusion(w=W, h=H, max_surfels=N + 3_000_000, **K)
+    efs = [ifx.ElasticFusion(w=W, h=H, max_surfels=N // G + 2_500_000, n_ranks=G, rank=r, **K) for r in range(G)]
+    inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
+    # frame 0 initialises the tracker's previous image; then the 20M map replaces the first-frame map on both sides
+    one.enqueue_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr(), 0)
+    sharded.emulate_owner_ranks(efs, d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+    one.upload(big); one.set_pose(st["poses"][0], 1000); one.combined_predict(st["poses"][0], 1000, 1000)
+    own = ifd.owner_of(big["pc"][:, :3], G)
+    for e in efs:
+        e.upload(big); e.set_pose(st["poses"][0], 1000)
+    assert [e.count for e in efs] == [int((own == r).sum()) for r in range(G)]
+    assert min(e.count for e in efs) > 0.9 * N / G                         # the spatial hash balances: every rank holds about 5M surfels
+    del big, own
+    sharded.emulate_owner_predict(efs)
+    for name in ("pred_vertex", "pred_normal", "pred_image"):
+        a = one.image(name)
+        assert all(np.array_equal(e.image(name), a) for e in efs), name     # the prediction of the 20M map itself
+    seg_at = 3
+    for i in range(1, NF + 1):
+        one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+        pose = one.getCurrPose()
+        for e in efs:
+            assert np.array_equal(e.getCurrPose(), pose), (i, e.cfgd["rank"])
+        for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
+            a = one.image(name)
+            for e in efs:
+                assert np.array_equal(e.image(name), a), (i, name, e.cfgd["rank"])
+        want = inst_one.whetherDoSegmentation(100 + i)
+        assert [x.whetherDoSegmentation(100 + i) for x in insts] == [want] * G, i
+        if i == seg_at:
+            masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+            assert masks.shape[0] > 0
+            inst_one.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, 100 + i, superpixels=True)
+            sharded.emulate_owner_segmentation(efs, st["rgb"][i], st["depth"][i], masks, cls, 100 + i, superpixels=True)
+            assert all(np.array_equal(x.getInstanceTable(), inst_one.getInstanceTable()) for x in insts)
+    assert np.abs(one.getCurrPose() - st["poses"][NF]).max() < 0.05          # it tracked
+    # labels, then the map: shards merged by creation number == the unsharded map
+    lab_one = inst_one.labels()
+    labs = [x.labels() for x in insts]
+    seqs = [e.seq() for e in efs]
+    seq = np.concatenate(seqs)
+    order = np.argsort(seq, kind="stable")
+    assert len(np.unique(seq)) == len(seq) == lab_one.shape[0]
+    assert np.array_equal(np.concatenate(labs)[order], lab_one) and (lab_one >= 0).sum() > 1000
+    del labs, lab_one
+    ref = one.download()
+    one.close()
+    for k in MAP_KEYS:                                                       # one field at a time: 20M x 48 vote floats are 3.8 GB
+        parts = []
+        for e in efs:
+            m = e.download()
+            parts.append(m[k])
+            del m
+        merged = np.concatenate(parts)[order]
+        del parts
+        assert np.array_equal(merged, ref.pop(k)), k
+        del merged
+    for e in efs:
+        e.close()
+
+
 @pytest.mark.parametrize("earlyz,lds", [(1, 0), (0, 0), (0, 1)])
 def test_view_list_path_equals_per_pass_culls(ifx, earlyz, lds):
     """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,

@@ -579,3 +579,61 @@ def test_rounding_level_perturbation_grows(orc):
     assert gap[:3].max() < 1e-7                      # the perturbation itself is tiny ...
     assert gap.max() > 1e-4                          # ... and grows past the parity tolerance within the run
     assert np.array_equal(runs[0], runs[2])          # a different ORDER of the exact sums (rows bottom-up) changes nothing at all
+
+
+def test_reference_shaped_f32_tree_gap(orc, gputest_pair):
+    """How far is the REFERENCE's arithmetic from the exact sums every parity claim rests on?  `orc_set_sum_order(3)` makes the oracle sum the 29 / 11
+    products of the normal equations as the reference's kernels do -- f32 products, f32 additions, thread-strided partial sums, shuffle tree, one
+    partial per warp, second launch over the block partials, with the launch table's GTX 1080 row (EF/Cuda/reduce.cu:133-185, :397-402;
+    EF/Utils/GPUConfig.h:123-126).  Asserted here: (1) stage level, on the reference's own RGB-D pair: the f32-tree sums agree with the exact sums to
+    1e-5 of their scale ("29-float sums rel. err <= 1e-5"), so mode 3 is the same quantity; (2) trajectory level, 24 frames of the 640x480
+    benchmark stream: identical at first, apart by more than the north star's 1e-4 m within the run, and bounded (< 5 mm).  The committed 90-frame
+    record (tools/reference_tree_gap.py -> profiles/r03_reference_tree_gap.json): 1.4 mm RMS, 3.5 mm max, first frame over 1e-4 m: frame 9, while both
+    runs are equally far from the ground truth (35.6 vs 35.5 mm) -- "within 1e-4 m RMS of the reference" is not a property any second implementation of
+    this algorithm can have over a sequence, the reference on another GPU model included; what CAN be asserted is bit-identity with a fixed arithmetic,
+    which is what tests/test_gpu_parity.py does."""
+    import json
+    import os
+
+    from gputest_protocol import HALF_K, protocol_inputs
+    from instancefusion_amd import synth
+
+    L = orc.lib()
+    # (1) stage level
+    h, w = gputest_pair[1].shape
+    V, N, rgba, prev, depth_mm, rgb = protocol_inputs(*gputest_pair)
+    sums = {}
+    for mode in (0, 3):
+        L.orc_set_sum_order(mode)
+        t = L.orc_tracker_create(w, h, HALF_K["fx"], HALF_K["fy"], HALF_K["cx"], HALF_K["cy"])
+        L.orc_tracker_init_first_rgb(t, orc.ptr(prev))
+        p0 = np.eye(4, dtype=np.float32).reshape(16).copy()
+        L.orc_tracker_init_model(t, orc.ptr(V), orc.ptr(N), orc.ptr(rgba), orc.ptr(p0))
+        L.orc_tracker_init_frame(t, orc.ptr(depth_mm), orc.ptr(rgb), 20.0)
+        pose = p0.copy()
+        L.orc_tracker_run(t, orc.ptr(pose), 10.0, 1, 0, 1, None)
+        sums[mode] = pose.reshape(4, 4).copy()
+        L.orc_tracker_destroy(t)
+    L.orc_set_sum_order(0)
+    pair_gap = float(np.linalg.norm(sums[0][:3, 3] - sums[3][:3, 3]))
+    assert pair_gap < 2e-4, pair_gap                 # one frame of real sensor data: the two arithmetics agree to a fraction of a millimetre
+    # (2) trajectory level
+    W, H, NF = 640, 480, 24
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(NF, W, H, noise=True, loop_len=90, **K)
+    orc.set_threads(orc.usable_cores())
+    runs = {}
+    for mode in (0, 3):
+        L.orc_set_sum_order(mode)
+        o = orc.Oracle(w=W, h=H, max_surfels=2_000_000, **K)
+        runs[mode] = np.stack([o.process_frame(st["rgb"][i], st["depth"][i]).copy() for i in range(NF)])
+        o.close()
+    L.orc_set_sum_order(0)
+    orc.set_threads(1)
+    gap = np.linalg.norm(runs[0][:, :3, 3] - runs[3][:, :3, 3], axis=1)
+    assert gap[:4].max() < 1e-5                      # the same algorithm: the first frames agree to micrometres
+    assert gap.max() > 1e-4                          # ... and part by more than the north star's tolerance within 24 frames
+    assert gap.max() < 5e-3                          # bounded: both stay on the trajectory (the gap is tracking noise, not divergence)
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_reference_tree_gap.json")))
+    assert np.allclose(gap, rec["gap_m"][:NF], rtol=0, atol=1e-12) or abs(np.sqrt(np.mean(gap ** 2)) - np.sqrt(np.mean(np.square(rec["gap_m"][:NF])))) < 1e-4   # the committed record is this computation
+    print(f"reference-shaped f32 tree vs exact sums: pair {pair_gap:.2e} m; 24 frames: max {gap.max():.2e} m, rms {np.sqrt(np.mean(gap ** 2)):.2e} m; committed 90-frame record rms {rec['gap_rms_m']:.2e} max {rec['gap_max_m']:.2e}")

@@ -114,7 +114,10 @@ int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
  * communicator (ifx_owner_process_frame_device below); the phase / exchange pair stays for hosts with their own transport and for the emulation tests.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
  * bit.  Per-surfel work (projections, fusion update, clean, votes, label scan) is sharded, per-pixel work (tracking, association, the mask
  * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume, the kNN smoothing through ifx_owner_knn_export /
- * _vote; the loop-closure detection is not available in this mode yet. */
+ * _vote.  With the local loop-closure detection enabled (ifx_set_loop_closure; the deformation callbacks are not offered in this mode) a frame has two
+ * more phases IN FRONT of phase 0 -- 300: frame side, tracker and the local ACTIVE + INACTIVE renders at the tracked pose; 301: the owners' winners of both --
+ * each followed by the exchange ifx_owner_exchange(300 | 301) lists; phase 0 then runs the model-to-model tracker and the gates on the exchanged renders,
+ * replicated (the same verdict on every rank, ifx_loop_closure_diag).  Both are no-ops while the detection is off or nothing can be inactive yet. */
 int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth);
 /* ---- the same frame as ONE call, the collectives enqueued by the library itself (instancefusion_amd/csrc/ifx_comm.hip).  The reference has no
  * counterpart (one GPU, IF/main.cpp:75); BASELINE.json's north star asks for "RCCL all-reduce over xGMI ... all-to-all for cross-shard surfel

@@ -187,6 +187,7 @@ _IMG_SPECS = {
     "fill_vertex": (np.float32, 4), "fill_normal": (np.float32, 4), "fill_image": (np.uint8, 4),
     "depth_filtered": (np.uint16, 1), "depth_metric": (np.float32, 1), "depth_metric_filtered": (np.float32, 1),
     "old_vertex": (np.float32, 4), "old_normal": (np.float32, 4), "old_image": (np.uint8, 4), "old_time": (np.uint16, 1),
+    "act_vertex": (np.float32, 4), "act_normal": (np.float32, 4), "act_image": (np.uint8, 4),
 }
 _TRK_SPECS = {
     "vmap_curr": (np.float32, 3, True), "nmap_curr": (np.float32, 3, True), "vmap_prev": (np.float32, 3, True),

@@ -577,12 +577,19 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
 // ifx_owner_exchange(p) lists across the ranks (instancefusion_amd/sharded.py: RCCL all-reduce; tests: the same reduction by hand)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
 static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind);
+static bool owner_lc_due(ifx* h);
 extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth) { return h ? owner_frame_phase(h, phase, d_rgb, d_depth, 0) : IFX_E_INVALID; }
 // One call = one frame of the sharded map: the eight phases with their exchanges enqueued by the library on the handle's main stream (ifx_comm.hip), no
 // host synchronisation (the frame result lands in pinned memory behind the last kernel, as on the unsharded path).
 static int owner_process_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind)
 {
     if (!ifx_comm_ready(h)) { h->err = "no communicator: ifx_owner_init_comm / ifx_owner_set_comm first"; return IFX_E_STATE; }
+    if (owner_lc_due(h))   // the local loop-closure detection: two more phases in front of the frame, two more collectives (16 + 84 bytes per pixel)
+        for (int phase = 300; phase < 302; phase++) {
+            int r = owner_frame_phase(h, phase, rgb, depth, src_kind);
+            if (r) return r;
+            if ((r = ifx_comm_exchange(h, phase))) return r;
+        }
     for (int phase = 0; phase < 8; phase++) {
         int r = owner_frame_phase(h, phase, rgb, depth, src_kind);
         if (r) return r;
@@ -622,15 +629,22 @@ extern "C" int ifx_owner_predict(ifx_t* h)
     }
     return IFX_OK;
 }
+// is the local loop-closure detection of this frame due?  (the host-side skip of enqueue_loop_closure_renders: while tick - timeDelta < 1 nothing the frames created can be old enough)
+static bool owner_lc_due(ifx* h) { return h->lc_enable && !(h->tick == 1 && h->n_traj == 0) && (h->map_external || h->tick - h->cfg.time_delta >= 1); }
 static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind)
 {
-    if (!h || phase < 0 || phase > 7) return IFX_E_INVALID;
+    if (!h || ((phase < 0 || phase > 7) && phase != 300 && phase != 301)) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
-    if (h->lc_enable) { h->err = "loop-closure detection is not available on a sharded map"; return IFX_E_STATE; }
+    if (h->lc_enable && (h->lc_cb || h->fern_cb)) { h->err = "on a sharded map the loop-closure DETECTION is available; the deformation callbacks are not"; return IFX_E_STATE; }
     const bool first = h->tick == 1 && h->n_traj == 0;
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
-    if (phase == 0) {
+    // With the detection on, a frame starts with two extra phases (300, 301: the two renders of EF/ElasticFusion.cpp:453 / :519-526 at the tracked pose, pre-fusion map);
+    // phase 300 then carries the frame side and the tracker, and phase 0 runs the model-to-model tracker on the exchanged renders before its index projection.
+    const bool lc_due = owner_lc_due(h);
+    if (phase >= 300 && !lc_due) return IFX_OK;   // (nothing to render: the caller's exchange list for it is empty too)
+    const bool starts_frame = phase == 300 || (phase == 0 && h->own_tracked_tick != h->tick);
+    if (starts_frame) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
         h->tracked_ahead = 0;
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
@@ -642,6 +656,15 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         f.for_tick = -1;
         ifx_bind_slot(h, s);
         if (!first) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }   // replicated: every rank holds the exchanged prediction (DESIGN.md section 7 on the alternative)
+        h->own_tracked_tick = h->tick;
+        if (phase == 300) {
+            if (h->lc_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_lc_done, 0)); h->lc_pending = 0; }
+            ifx_tracker_m2m_begin(h);
+        }
+    }
+    if (phase == 0 && h->lc_enable && !first) {
+        if (lc_due) { int r = ifx_tracker_loop_closure(h); if (r) return r; h->lc_event_valid = 0; }   // replicated on the exchanged act_* / old_* images: the same verdict on every rank
+        else LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state, h->h_lc);
     }
     int r = ifx_map_owner_phase(h, phase, first);
     if (r) return r;
@@ -682,6 +705,8 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
     case 5: add(h->pred_vertex, h->pred_bytes, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
     case 6: break;
+    case 300: if (owner_lc_due(h)) add(h->key_splat, P * 16, 0); break;                       // the detection's two renders: [key_splat (ACTIVE) | key_ids (INACTIVE)]
+    case 301: if (owner_lc_due(h)) add(h->act_vertex, 2 * h->lc_half, 1); break;            // [act_* | old_*]: the owners' winners of both
     case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume)
         switch (h->oseg_pending) {
         case 1: add(h->d_bbox, (size_t)(96 + h->oseg_nm) * 4 * 4, 2); break;                       // boxes, maxima negated: MIN of 32-bit words

@@ -244,6 +244,8 @@ struct ifx {
     float *act_vertex = nullptr, *act_normal = nullptr;        // predict() of EF/ElasticFusion.cpp:453 (ACTIVE render at the tracked pose, pre-fusion map): kept apart from
     uint8_t *act_image = nullptr, *act_inst = nullptr;         // pred_*, which the end-of-frame predict() rewrites while the model-to-model tracker may still be reading
     uint16_t* act_time = nullptr;
+    size_t lc_half = 0;                                        // bytes of one of the two render blocks (act_* / old_* are one allocation of 2 * lc_half)
+    int own_tracked_tick = 0;                                  // sharded map with the detection on: the frame side + tracker of this tick ran in phase 300 already
     float* h_lc = nullptr;                                     // pinned: verdict of the last detection (ifx_loop_closure_diag)
     int lc_event_valid = 0;
     float* d_graph = nullptr;           // deformation graph handed in for the next clean (ifx_set_deformation): nodes x 16 floats

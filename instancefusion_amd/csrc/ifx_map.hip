@@ -2431,8 +2431,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
     c.srank = 0; c.sn = 1;
     const int time = h->tick;
     const dim3 b2(32, 8), g2(cdiv(h->w, 32), cdiv(h->h, 8));
-    const bool in_frame = phase < 100;
-    if (phase >= 105) phase -= 100;
+    const bool in_frame = phase < 100 || phase >= 300;
+    if (phase >= 105 && phase < 300) phase -= 100;
     if (first_frame) {
         switch (phase) {
         case 0: ifx_map_init_first(h); owner_filter(h); break;
@@ -2453,6 +2453,24 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         return IFX_OK;
     }
     switch (phase) {
+    // ---- local loop-closure detection on the sharded map (EF/ElasticFusion.cpp:453-566), before the frame's map passes: predict() at the tracked pose and the
+    // INACTIVE prediction from one scan of the local shard (as ifx_map_predict_loop_closure), the owners' winners of both renders, then the model-to-model
+    // tracker replicated on the exchanged images (ifx_api.hip: owner_frame_phase)
+    case 300:                                                                                               // local dual raster | [key_splat (ACTIVE) | key_ids (INACTIVE)]: MIN
+        LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, time, time,
+               LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
+        LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
+               h->key_ids, h->key_both, 1, (const int*)nullptr);
+        break;
+    case 301:                                                                                               // owned winners of both renders | [act_* | old_*]: SUM
+        for (int old = 0; old < 2; old++)
+            LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, old ? h->key_ids : h->key_splat, (const float4*)h->pc,
+                   (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
+                   (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
+                   old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
+               (int*)nullptr, (int*)nullptr);
+        break;
     case 0: index_pass(h, nullptr, time, true, 1); break;                                                   // local projection | keys: MIN
     case 1: index_pass(h, nullptr, time, true, 2); break;                                                   // winners this rank owns | [index_vc | index_nr]: SUM
     case 2: fuse_pass(h, nullptr, 0.f, time); clean_pass(h, nullptr, time, 1); break;                       // association (replicated), update (owned), post-fuse projection | keys: MIN

@@ -2601,13 +2601,14 @@ int ifx_tracker_alloc_m2m(ifx* h)
     const size_t P = (size_t)h->P;
     HIPCHK(h, hipMalloc(&h->d_m2m, sizeof(DevState)));
     HIPCHK(h, hipMemset(h->d_m2m, 0, sizeof(DevState)));
-    HIPCHK(h, hipMalloc(&h->old_vertex, P * 16)); HIPCHK(h, hipMalloc(&h->old_normal, P * 16)); HIPCHK(h, hipMalloc(&h->old_image, P * 4));
-    HIPCHK(h, hipMalloc(&h->old_inst, P * 4)); HIPCHK(h, hipMalloc(&h->old_time, P * 2));
-    HIPCHK(h, hipMemset(h->old_vertex, 0, P * 16)); HIPCHK(h, hipMemset(h->old_normal, 0, P * 16)); HIPCHK(h, hipMemset(h->old_image, 0, P * 4));
-    HIPCHK(h, hipMemset(h->old_time, 0, P * 2));
-    HIPCHK(h, hipMalloc(&h->act_vertex, P * 16)); HIPCHK(h, hipMalloc(&h->act_normal, P * 16)); HIPCHK(h, hipMalloc(&h->act_image, P * 4));
-    HIPCHK(h, hipMalloc(&h->act_inst, P * 4)); HIPCHK(h, hipMalloc(&h->act_time, P * 2));
-    HIPCHK(h, hipMemset(h->act_vertex, 0, P * 16)); HIPCHK(h, hipMemset(h->act_normal, 0, P * 16)); HIPCHK(h, hipMemset(h->act_image, 0, P * 4));
+    // the two renders of the detection are ONE allocation, [act_vertex | act_normal | act_image | act_inst | act_time | pad][old_* likewise]: on a spatially
+    // sharded map the owners' winners of both travel in one collective (ifx_owner_exchange(h, 301, ...))
+    h->lc_half = ((P * 42 + 15) / 16) * 16;
+    HIPCHK(h, hipMalloc(&h->act_vertex, 2 * h->lc_half));
+    HIPCHK(h, hipMemset(h->act_vertex, 0, 2 * h->lc_half));
+    h->act_normal = h->act_vertex + 4 * P; h->act_image = (uint8_t*)(h->act_normal + 4 * P); h->act_inst = h->act_image + 4 * P; h->act_time = (uint16_t*)(h->act_inst + 4 * P);
+    h->old_vertex = (float*)((uint8_t*)h->act_vertex + h->lc_half);
+    h->old_normal = h->old_vertex + 4 * P; h->old_image = (uint8_t*)(h->old_normal + 4 * P); h->old_inst = h->old_image + 4 * P; h->old_time = (uint16_t*)(h->old_inst + 4 * P);
     HIPCHK(h, hipHostMalloc((void**)&h->h_lc, 24 * 4, hipHostMallocDefault));
     memset(h->h_lc, 0, 24 * 4);
     const int maxb = 1024;
@@ -2637,8 +2638,7 @@ static void free_m2m(ifx* h)
         hipFree(p.last_depth[i]); hipFree(p.next_depth[i]); hipFree(p.last_img[i]); hipFree(p.next_img[i]); hipFree(p.didx[i]); hipFree(p.didy[i]);
         hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
-    hipFree(h->d_m2m); hipFree(h->old_vertex); hipFree(h->old_normal); hipFree(h->old_image); hipFree(h->old_inst); hipFree(h->old_time);
-    hipFree(h->act_vertex); hipFree(h->act_normal); hipFree(h->act_image); hipFree(h->act_inst); hipFree(h->act_time);
+    hipFree(h->d_m2m); hipFree(h->act_vertex);   // (act_* and old_* are one allocation)
     hipFree(p.acc); hipFree(p.res_partials); hipFree(p.ticket);
     if (h->h_lc) hipHostFree(h->h_lc);
     h->d_m2m = nullptr;

@@ -87,6 +87,8 @@ def main():
                     "map; RCCL all-reduces of the key images and of the winners' attributes between the phases of a frame -- instancefusion_amd/sharded.py, DESIGN.md section 7; strong scaling; "
                     "segmentation calls through ifx_owner_segmentation_begin / _resume).  Default for --gpus N: one replica per rank")
     ap.add_argument("--sharded-projection", action="store_true", help="round 1's variant: every rank holds the whole map, the projection passes are sliced by slot range")
+    ap.add_argument("--map-order", default="random", choices=["random", "morton"], help="order of the pre-populated synthetic map: `random` (default: surfels sampled uniformly, neighbours in the map are "
+                    "unrelated in space -- the worst case for the passes that gather the visible part of the store) or `morton` (spatially coherent, as a map built frame by frame is)")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -140,7 +142,7 @@ def main():
     st = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED + srank, **K)
     masks = [synth.canned_masks(st["obj"][i], st["scene"]) for i in range(L)]
     tick0 = 1000
-    m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + srank)
+    m = synth.make_map(args.surfels, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7 + srank, order=args.map_order)
     t_gen = time.time() - t_gen
 
     cap = args.surfels + 2_500_000
@@ -464,7 +466,7 @@ def main():
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if one_map else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.surfels}-surfel map, {W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}",
-                       "surfels_live": n_live, "surfel_slots": n_slots, "parallelism": (f"spatially sharded map x{world}" if args.sharded else (f"sharded projection x{world}" if args.sharded_projection else f"replicas x{world}")), "loop_frames": L},
+                       "surfels_live": n_live, "surfel_slots": n_slots, "map_order": args.map_order, "parallelism": (f"spatially sharded map x{world}" if args.sharded else (f"sharded projection x{world}" if args.sharded_projection else f"replicas x{world}")), "loop_frames": L},
             "ms_per_frame_gpu": {k_: round(v / args.steps, 4) for k_, v in stage.items()},
             "instance": {"calls_in_window": calls_in_window, "ms_per_call": round(inst_ms / calls_in_window, 4) if calls_in_window else None,
                          "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,

@@ -137,6 +137,21 @@ int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint1
  * `bench.py --sharded --gpus 1` and the single-GPU RCCL test run.
  * Creation numbers (the ids of a sharded map) are unsigned 32-bit and never renumbered: a handle reports IFX_E_CAPACITY once 2^32 - 2^20 of them have been
  * handed out (at most P / 4 per frame: > 50 000 frames at 640 x 480 in the worst case, millions in practice). */
+/* ---- K streams into ONE map (BASELINE configuration 5; the reference has one stream, IF/main.cpp:75).  Semantics of a FRAME SET (one frame per camera): the K frames
+ * are processed one after the other, in camera order, on the one map; a camera tracks against the prediction rendered at the end of ITS last frame.
+ *   ifx_camera_count(h, K)        K camera contexts on this handle (pose block, prediction + fill-in, the last frame's intensity pyramid, id image)
+ *   ifx_camera_select(h, c)       park the current camera's context, bring camera c's in (enqueue-only, between frames); a camera selected for the first time
+ *                                 starts as a copy of the current one: give it its pose (ifx_set_pose) or an external pose for its first frame
+ * On a spatially sharded map (every rank holds the K contexts and is fed all K streams):
+ *   ifx_owner_set_frame_pose      the next frame takes this pose instead of tracking (the in_pose of the unsharded entry points)
+ *   ifx_owner_set_tracking_rank   only this rank tracks the frames to come -- stream k on GPU k, no tracker collective; the others run the frame side,
+ *                                 and the tracked pose block reaches them by a broadcast (phase 310 + ifx_owner_exchange(h, 310): op 4 | root << 8), which
+ *                                 ifx_owner_process_frame_device issues itself.  -1: every rank tracks (replicated).
+ * tests/test_gpu_parity.py::test_config5_two_streams_one_sharded_map: K = 2 cameras, G = 2 ranks, bit-identical to one GPU. */
+int ifx_camera_count(ifx_t* h, int n_cameras);
+int ifx_camera_select(ifx_t* h, int cam);
+int ifx_owner_set_frame_pose(ifx_t* h, const float* pose16);
+int ifx_owner_set_tracking_rank(ifx_t* h, int rank);
 int ifx_comm_unique_id(uint8_t* out128);
 int ifx_owner_init_comm(ifx_t* h, const uint8_t* unique_id128);
 int ifx_owner_set_comm(ifx_t* h, void* nccl_comm);

@@ -79,6 +79,10 @@ _SIGS = {
     "ifx_owner_knn_export": (C.c_int, [_P, _P, _P, _P]),
     "ifx_owner_knn_vote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),
+    "ifx_camera_count": (C.c_int, [_P, C.c_int]),
+    "ifx_camera_select": (C.c_int, [_P, C.c_int]),
+    "ifx_owner_set_frame_pose": (C.c_int, [_P, _P]),
+    "ifx_owner_set_tracking_rank": (C.c_int, [_P, C.c_int]),
     "ifx_comm_unique_id": (C.c_int, [_P]),
     "ifx_owner_init_comm": (C.c_int, [_P, _P]),
     "ifx_owner_set_comm": (C.c_int, [_P, _P]),
@@ -265,6 +269,19 @@ class ElasticFusion:
     def hint_next_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int):
         """Announce the frame after the one about to be enqueued (see ifx_hint_next_frame_device)."""
         self._chk(self.L.ifx_hint_next_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_hint_next_frame_device")
+
+    def camera_count(self, k):
+        self._chk(self.L.ifx_camera_count(self.handle, int(k)), "ifx_camera_count")
+
+    def camera_select(self, c):
+        self._chk(self.L.ifx_camera_select(self.handle, int(c)), "ifx_camera_select")
+
+    def owner_set_frame_pose(self, pose):
+        p = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.ifx_owner_set_frame_pose(self.handle, _ptr(p)), "ifx_owner_set_frame_pose")
+
+    def owner_set_tracking_rank(self, r):
+        self._chk(self.L.ifx_owner_set_tracking_rank(self.handle, int(r)), "ifx_owner_set_tracking_rank")
 
     def view_list_stats(self):
         out = np.zeros(4, np.int32)

@@ -167,6 +167,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     return IFX_OK;
 }
 
+static void camera_free(ifx* h);
 extern "C" void ifx_destroy(ifx_t* h)
 {
     if (!h) return;
@@ -174,6 +175,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
     if (h->stream) hipStreamSynchronize(h->stream);
     ifx_comm_free(h);
+    camera_free(h);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
@@ -503,6 +505,84 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     return IFX_OK;
 }
 
+// ---- camera contexts: K streams into one map (BASELINE configuration 5).  The single-GPU semantics of a FRAME SET -- one frame per camera -- is: the K frames
+// processed one after the other, in camera order, on the one map; every camera tracks against the prediction rendered at the end of ITS last frame.
+static_assert(offsetof(DevState, count) == IFX_CAM_STATE_BYTES, "the pose block of DevState (pose, pose_inv, last_pose, weighting, dense_enough) is what a camera context parks");
+static void camera_free(ifx* h)
+{
+    for (CamCtx& c : h->cams) {
+        hipFree(c.state); hipFree(c.pred); hipFree(c.fill_v); hipFree(c.fill_n); hipFree(c.fill_i); hipFree(c.ids);
+        for (int l = 0; l < IFX_NUM_PYRS; l++) hipFree(c.img[l]);
+    }
+    h->cams.clear();
+}
+extern "C" int ifx_camera_count(ifx_t* h, int n_cameras)
+{
+    if (!h || n_cameras < 1 || n_cameras > 64) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    camera_free(h);
+    h->cur_cam = 0;
+    if (n_cameras == 1) return IFX_OK;
+    const size_t P = (size_t)h->P;
+    h->cams.resize((size_t)n_cameras);
+    for (CamCtx& c : h->cams) {
+        HIPCHK(h, hipMalloc(&c.state, IFX_CAM_STATE_BYTES)); HIPCHK(h, hipMalloc(&c.pred, h->pred_bytes));
+        HIPCHK(h, hipMalloc(&c.fill_v, P * 16)); HIPCHK(h, hipMalloc(&c.fill_n, P * 16)); HIPCHK(h, hipMalloc(&c.fill_i, P * 4)); HIPCHK(h, hipMalloc(&c.ids, P * 4));
+        for (int l = 0; l < IFX_NUM_PYRS; l++) HIPCHK(h, hipMalloc(&c.img[l], (size_t)(h->w >> l) * (h->h >> l)));
+    }
+    return IFX_OK;
+}
+// camera `cam` takes over the handle: the current camera's set is parked, cam's is brought in (a camera selected for the first time starts as a copy of the
+// current one: give it its pose with ifx_set_pose / an external pose for its first frame).  Enqueue-only; between frames.
+extern "C" int ifx_camera_select(ifx_t* h, int cam)
+{
+    if (!h || cam < 0 || (cam > 0 && (size_t)cam >= h->cams.size())) return IFX_E_INVALID;
+    if (h->cams.empty() || cam == h->cur_cam) return IFX_OK;
+    if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "ifx_camera_select: a frame is announced ahead"; return IFX_E_STATE; }
+    h->tracked_ahead = 0;
+    if (h->lc_pending && h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
+    if (!h->own) { ifx_vlist_reap(h); hs_invalidate_view(h); }   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
+    const size_t P = (size_t)h->P;
+    FrameSlot& prev = h->slot[(h->tick & 1) ^ 1];   // the slot of the frame just processed = the "previous image" of the next one
+    auto move = [&](CamCtx& c, bool save) -> int {
+        const hipMemcpyKind k = hipMemcpyDeviceToDevice;
+#define CAMCP(ctx_ptr, live_ptr, bytes) HIPCHK(h, save ? hipMemcpyAsync((ctx_ptr), (live_ptr), (bytes), k, h->stream) : hipMemcpyAsync((live_ptr), (ctx_ptr), (bytes), k, h->stream))
+        CAMCP(c.state, (void*)h->d_state, IFX_CAM_STATE_BYTES);
+        CAMCP(c.pred, (void*)h->pred_vertex, h->pred_bytes);
+        CAMCP(c.fill_v, (void*)h->fill_vertex, P * 16); CAMCP(c.fill_n, (void*)h->fill_normal, P * 16); CAMCP(c.fill_i, (void*)h->fill_image, P * 4);
+        CAMCP(c.ids, (void*)h->ids_after, P * 4);
+        for (int l = 0; l < IFX_NUM_PYRS; l++) CAMCP(c.img[l], (void*)prev.next_img[l], (size_t)(h->w >> l) * (h->h >> l));
+#undef CAMCP
+        return IFX_OK;
+    };
+    int r = move(h->cams[(size_t)h->cur_cam], true);
+    if (r) return r;
+    h->cams[(size_t)h->cur_cam].valid = 1;
+    if (h->cams[(size_t)cam].valid) { r = move(h->cams[(size_t)cam], false); if (r) return r; }
+    h->cur_cam = cam;
+    h->seg_counts_valid = 0;
+    return IFX_OK;
+}
+// sharded map: the next frame takes `pose16` instead of tracking (the in_pose argument of the unsharded entry points); NULL clears it
+extern "C" int ifx_owner_set_frame_pose(ifx_t* h, const float* pose16)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!h->own) { h->err = "ifx_owner_set_frame_pose: the handle was not created for a sharded map"; return IFX_E_STATE; }
+    h->own_frame_pose_set = pose16 ? 1 : 0;
+    if (pose16) memcpy(h->own_frame_pose, pose16, 64);
+    return IFX_OK;
+}
+// sharded map, K streams: only `rank` tracks the frames to come (stream k tracked on GPU k: no tracker collective); a frame then starts with
+// phase 310 (frame side everywhere, tracker on `rank`) and the exchange ifx_owner_exchange(h, 310, ...) -- the pose block, broadcast from `rank` (op 4 | rank << 8).
+// -1: every rank tracks (replicated; the default).
+extern "C" int ifx_owner_set_tracking_rank(ifx_t* h, int rank)
+{
+    if (!h || rank < -1 || rank >= (h ? h->own_g : 1)) return IFX_E_INVALID;
+    if (!h->own) { h->err = "ifx_owner_set_tracking_rank: the handle was not created for a sharded map"; return IFX_E_STATE; }
+    h->own_track_rank = rank;
+    return IFX_OK;
+}
+
 // ---- sharded projection (ifx_map_sharded_phase): one frame in four phases, the caller exchanging the key
 // images (element-wise unsigned min across ranks) between them.  Every rank is fed the same frames and masks.
 extern "C" int ifx_set_shard(ifx_t* h, int rank, int nranks)
@@ -584,6 +664,11 @@ extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, 
 static int owner_process_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int src_kind)
 {
     if (!ifx_comm_ready(h)) { h->err = "no communicator: ifx_owner_init_comm / ifx_owner_set_comm first"; return IFX_E_STATE; }
+    if (h->own_track_rank >= 0) {   // K streams: this frame is tracked by one rank, the pose block broadcast to the others
+        int r = owner_frame_phase(h, 310, rgb, depth, src_kind);
+        if (r) return r;
+        if ((r = ifx_comm_exchange(h, 310))) return r;
+    }
     if (owner_lc_due(h))   // the local loop-closure detection: two more phases in front of the frame, two more collectives (16 + 84 bytes per pixel)
         for (int phase = 300; phase < 302; phase++) {
             int r = owner_frame_phase(h, phase, rgb, depth, src_kind);
@@ -633,7 +718,7 @@ extern "C" int ifx_owner_predict(ifx_t* h)
 static bool owner_lc_due(ifx* h) { return h->lc_enable && !(h->tick == 1 && h->n_traj == 0) && (h->map_external || h->tick - h->cfg.time_delta >= 1); }
 static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind)
 {
-    if (!h || ((phase < 0 || phase > 7) && phase != 300 && phase != 301)) return IFX_E_INVALID;
+    if (!h || ((phase < 0 || phase > 7) && phase != 300 && phase != 301 && phase != 310)) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     if (h->lc_enable && (h->lc_cb || h->fern_cb)) { h->err = "on a sharded map the loop-closure DETECTION is available; the deformation callbacks are not"; return IFX_E_STATE; }
     const bool first = h->tick == 1 && h->n_traj == 0;
@@ -642,8 +727,9 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
     // With the detection on, a frame starts with two extra phases (300, 301: the two renders of EF/ElasticFusion.cpp:453 / :519-526 at the tracked pose, pre-fusion map);
     // phase 300 then carries the frame side and the tracker, and phase 0 runs the model-to-model tracker on the exchanged renders before its index projection.
     const bool lc_due = owner_lc_due(h);
-    if (phase >= 300 && !lc_due) return IFX_OK;   // (nothing to render: the caller's exchange list for it is empty too)
-    const bool starts_frame = phase == 300 || (phase == 0 && h->own_tracked_tick != h->tick);
+    if ((phase == 300 || phase == 301) && !lc_due) return IFX_OK;   // (nothing to render: the caller's exchange list for it is empty too)
+    if (phase == 310 && h->own_track_rank < 0) return IFX_OK;   // every rank tracks: nothing to hand over
+    const bool starts_frame = phase == 310 || ((phase == 300 || phase == 0) && h->own_tracked_tick != h->tick);
     if (starts_frame) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
         h->tracked_ahead = 0;
@@ -655,9 +741,18 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         if (r) return r;
         f.for_tick = -1;
         ifx_bind_slot(h, s);
-        if (!first) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }   // replicated: every rank holds the exchanged prediction (DESIGN.md section 7 on the alternative)
+        const bool tracks = h->own_track_rank < 0 || h->own_track_rank == h->cfg.rank;
+        if (!first && h->own_frame_pose_set) {   // an external pose replaces tracking (EF/ElasticFusion.cpp:357-360), on every rank alike
+            float* slot = h->d_scratch + 2 * 16;
+            HIPCHK(h, hipMemcpyAsync(slot, h->own_frame_pose, 64, hipMemcpyHostToDevice, h->stream));
+            ifx_tracker_external_pose(h, slot, 1.0f);
+        } else if (!first && tracks) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
+        h->own_frame_pose_set = 0;
         h->own_tracked_tick = h->tick;
-        if (phase == 300) {
+        if (phase == 310) return IFX_OK;   // the pose block travels from the tracking rank next (exchange 310)
+    }
+    if (phase == 300 && h->own_tracked_tick == h->tick) {
+        {
             if (h->lc_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_lc_done, 0)); h->lc_pending = 0; }
             ifx_tracker_m2m_begin(h);
         }
@@ -705,6 +800,7 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
     case 5: add(h->pred_vertex, h->pred_bytes, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
     case 6: break;
+    case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank
     case 300: if (owner_lc_due(h)) add(h->key_splat, P * 16, 0); break;                       // the detection's two renders: [key_splat (ACTIVE) | key_ids (INACTIVE)]
     case 301: if (owner_lc_due(h)) add(h->act_vertex, 2 * h->lc_half, 1); break;            // [act_* | old_*]: the owners' winners of both
     case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume)

@@ -36,6 +36,7 @@ struct Rccl {
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -51,7 +52,7 @@ bool rccl_load(std::string& err)
     if (!lib) { g_rccl.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); err = g_rccl.err; return false; }
 #define SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name); if (!g_rccl.field) { g_rccl.err = std::string("RCCL symbol missing: ") + name; err = g_rccl.err; dlclose(lib); return false; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
-    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     g_rccl.lib = lib;
     return true;
@@ -151,6 +152,11 @@ int ifx_comm_exchange(ifx* h, int phase)
     if (n < 0) return n;
     for (int k = 0; k < n && k < 8; k++) {
         // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX
+        if ((ops[k] & 0xFF) == 4) {   // broadcast from rank ops >> 8 (the pose block of a frame tracked by one rank)
+            NCCLCHK(h, g_rccl.Broadcast(ptrs[k], ptrs[k], (size_t)bytes[k], ncclInt8, ops[k] >> 8, c->comm, h->stream));
+            c->n_coll++; c->bytes += bytes[k];
+            continue;
+        }
         const bool u64 = ops[k] == 0;
         const ncclRedOp_t op = ops[k] == 0 ? ncclMin : (ops[k] == 1 ? ncclSum : (ops[k] == 2 ? ncclMin : ncclMax));
         NCCLCHK(h, g_rccl.AllReduce(ptrs[k], ptrs[k], (size_t)bytes[k] / (u64 ? 8 : 4), u64 ? ncclUint64 : ncclInt32, op, c->comm, h->stream));

@@ -177,6 +177,20 @@ __device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lct
     (void)lctr;
 }
 
+// ---- camera contexts (BASELINE configuration 5: K streams into ONE map).  What a camera carries from its last frame to its next: the pose block of the
+// state (pose, inverse, last pose, velocity weighting, dense flag), the model prediction it tracks against (+ fill-in), the intensity pyramid of its last
+// frame (the "previous image" of the SO(3) pre-alignment) and the id image.  ifx_camera_select parks the current camera's set and brings another one in.
+struct CamCtx {
+    float* state = nullptr;            // IFX_CAM_STATE_BYTES of DevState from offset 0
+    uint8_t* pred = nullptr;           // the prediction block (ifx::pred_bytes)
+    float *fill_v = nullptr, *fill_n = nullptr;
+    uint8_t* fill_i = nullptr;
+    uint8_t* img[IFX_NUM_PYRS] = {};
+    int32_t* ids = nullptr;
+    int valid = 0;
+};
+#define IFX_CAM_STATE_BYTES 200        // pose[16], pose_inv[16], last_pose[16], weighting, dense_enough
+
 struct KernelTiming { double total_ms = 0; int launches = 0; };
 struct PendingEvent { int name_id; hipEvent_t a, b; };
 
@@ -191,6 +205,10 @@ struct ifx {
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
     FrameSlot slot[2];
     int cur_slot = 0;
+    std::vector<CamCtx> cams;           // camera contexts (ifx_camera_count); empty: the handle is its one camera
+    int cur_cam = 0;
+    int own_track_rank = -1;            // sharded map: the one rank that tracks the frames to come (-1: every rank tracks, replicated); the others receive the pose block (exchange 310)
+    float own_frame_pose[16]; int own_frame_pose_set = 0;   // sharded map: the next frame takes this pose instead of tracking (ifx_owner_set_frame_pose)
     int own = 0, own_g = 1;             // spatially sharded map (ifx_config::n_ranks > 1, or -1: a world of one): this handle stores the surfels it owns; own_g = number of ranks
     size_t pred_bytes = 0; int* pred_tail = nullptr;   // the prediction images are one allocation of pred_bytes (+ a 16-byte tail that travels with them on a sharded map)
     void* comm = nullptr;               // ifx_comm.hip: the RCCL communicator + exchange scratch of a sharded map (ifx_owner_init_comm / ifx_owner_set_comm)

@@ -70,6 +70,16 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
 #define LIST_SEGS IFX_LIST_SEGS
 #define LIST_CTR_STRIDE IFX_LIST_CTR_STRIDE   // uints between counters: 128 B
 struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; };   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
+// Loads of the surfel store by the passes that touch a surfel ONCE per frame (the scan, the list walkers' gathers): with IFX_NT they carry the non-temporal hint, so that the
+// ~100-450 MB of lines they pull through per frame do not evict the tracker's working set (pyramids, prediction: tens of MB) from L2 / the Infinity Cache.
+#ifdef IFX_NT
+typedef float ifx_f4v __attribute__((ext_vector_type(4)));
+typedef float ifx_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_once(const float4* p) { const ifx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ifx_f4v*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float2 ld_once(const float2* p) { const ifx_f2v v = __builtin_nontemporal_load(reinterpret_cast<const ifx_f2v*>(p)); return make_float2(v.x, v.y); }
+#else
+template <typename T> __device__ __forceinline__ T ld_once(const T* p) { return *p; }
+#endif
 __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
 // Spatially sharded map: the id a surfel carries in keys / id images is its creation number (the same on every rank; ascending in slot order,
 // so "lowest id wins" is the single-GPU tie-break), and a rank finds the slot of an id it owns by binary search -- -1: another rank's surfel.
@@ -1198,8 +1208,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
         for (int r = 0; r < CF_ROUNDS; r++) {
             const int i = chunk * CF_SLOTS + r * MAP_THREADS + threadIdx.x;
             const int ii = i < n ? i : n - 1;
-            p4s[r] = pc_in[ii];
-            ts[r] = tm[ii];
+            p4s[r] = ld_once(&pc_in[ii]);
+            ts[r] = ld_once(&tm[ii]);
         }
         asm volatile("" ::"v"(p4s[0].x), "v"(p4s[1].x), "v"(p4s[2].x), "v"(p4s[3].x), "v"(p4s[4].x), "v"(p4s[5].x), "v"(p4s[6].x), "v"(p4s[7].x), "v"(ts[0].x), "v"(ts[1].x), "v"(ts[2].x),
                      "v"(ts[3].x), "v"(ts[4].x), "v"(ts[5].x), "v"(ts[6].x), "v"(ts[7].x));
@@ -1309,7 +1319,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
         float lastT[U];
         float4 p4[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { lastT[u] = tm[i[u]].y; p4[u] = pc[i[u]]; }
+        for (int u = 0; u < U; u++) { lastT[u] = ld_once(&tm[i[u]]).y; p4[u] = ld_once(&pc[i[u]]); }
 #pragma unroll
         for (int u = 0; u < U; u++) asm volatile("" ::"v"(lastT[u]), "v"(p4[u].x), "v"(p4[u].y), "v"(p4[u].z));   // (keeps the compiler from sinking a load behind the previous entry's branches)
 #pragma unroll
@@ -1347,8 +1357,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_view(DevState* st, Cam c,
         unsigned int i = 0;
         if (t < n) {
             i = seg_list[t];
-            const float2 tt = tm[i];
-            const float4 p4 = pc[i];   // (fetched with the times: in the time-window list nearly every entry needs it, and behind the test it was a third dependent round trip)
+            const float2 tt = ld_once(&tm[i]);
+            const float4 p4 = ld_once(&pc[i]);   // (fetched with the times: in the time-window list nearly every entry needs it, and behind the test it was a third dependent round trip)
             asm volatile("" ::"v"(tt.y), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             const float wv = tt.y;
             if (wv > DEAD_TIME && !(wv > 0.f && (float)time - wv > (float)c.timeDelta)) {   // live and not exempt by the time window
@@ -1469,8 +1479,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         R.bw = 1;
         if (t < n) {
             const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
-            const float4 p4 = pc[i];
-            const float lastT = tm[i].y;   // (with the position: one round trip for both)
+            const float4 p4 = ld_once(&pc[i]);
+            const float lastT = ld_once(&tm[i]).y;   // (with the position: one round trip for both)
             asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             unsigned int flags = 0;
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
@@ -1485,7 +1495,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             }
             if (flags) {
                 SurfGeo G;
-                surfel_geo(T, p4, nr[i], i | flags, c, G);
+                surfel_geo(T, p4, ld_once(&nr[i]), i | flags, c, G);
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
                 const bool do_s = G.do_s, do_i = surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
                 if (do_s || do_i) {

@@ -169,7 +169,7 @@ class OwnerShardedElasticFusion:
         if self.transport == "library":
             ef._chk(ef.L.ifx_owner_process_frame_device(ef.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr), 0), "ifx_owner_process_frame_device")
             return
-        for phase in (300, 301) + tuple(range(8)):   # (300, 301: loop-closure renders when enabled;) 0..5 with their exchanges, 6 fill-in / dense flag, 7 publishes the frame result
+        for phase in (310, 300, 301) + tuple(range(8)):   # (310: pose hand-over when one rank tracks; 300, 301: loop-closure renders when enabled;) 0..5 with their exchanges, 6 fill-in / dense flag, 7 publishes the frame result
             ef._chk(ef.L.ifx_owner_frame_phase(ef.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
             self._exchange(phase)
 
@@ -270,7 +270,9 @@ def _reduce_by_hand(efs, specs):
     for k in range(len(specs[0])):
         op, nbytes = specs[0][k][2], specs[0][k][1]
         ts = [torch.as_tensor(_DevWords(sp[k][0], nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=dev) for sp in specs]
-        if op == 0:
+        if (op & 0xFF) == 4:                       # broadcast from rank op >> 8
+            m = ts[op >> 8].clone()
+        elif op == 0:
             m = ts[0] ^ _SIGN
             for t in ts[1:]:
                 m = torch.minimum(m, t ^ _SIGN)
@@ -300,7 +302,7 @@ def emulate_owner_predict(efs):
 def emulate_owner_ranks(efs, d_rgb_ptr: int, d_depth_ptr: int):
     """Test helper: `efs` = handles of ONE process created with n_ranks = len(efs), rank = 0..G-1; the all-reduces are done by hand
     (element-wise unsigned minimum / int32 sum over the handles' buffers).  Everything of the sharded map except RCCL itself."""
-    for phase in (300, 301) + tuple(range(8)):   # 300, 301: the two renders of the loop-closure detection (no-ops unless it is enabled and due)
+    for phase in (310, 300, 301) + tuple(range(8)):   # 310: hand-over of the pose when one rank tracks; 300, 301: the renders of the loop-closure detection (no-ops unless enabled and due)
         for e in efs:
             e._chk(e.L.ifx_owner_frame_phase(e.handle, phase, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
         specs = [_exchange_spec(e, phase) for e in efs]

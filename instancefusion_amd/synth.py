@@ -178,7 +178,7 @@ def encode_votes(counts: np.ndarray) -> np.ndarray:
 
 
 def make_map(n: int, scene: Scene, world_from_first: np.ndarray, tick: int, fx: float = 528.0, fy: float = 528.0,
-             active_fraction: float | None = None, seed: int = SEED + 7, time_delta: int = 200):
+             active_fraction: float | None = None, seed: int = SEED + 7, time_delta: int = 200, order: str = "random"):
     """N surfels sampled on the scene surfaces, expressed in the tracker's world frame (= first
     camera frame).  Returns dict of float32 arrays pc(n,4) nr(n,4) col(n,2) tm(n,2) ic(n,4) votes(n,48)."""
     rng = np.random.RandomState(seed)
@@ -265,4 +265,13 @@ def make_map(n: int, scene: Scene, world_from_first: np.ndarray, tick: int, fx: 
         ic=np.zeros((n, 4), np.float32),
         votes=votes,
     )
+    if order == "morton":
+        # The same surfels in a spatially coherent map order (Morton code of the 8 cm voxel): what a map BUILT by the pipeline looks like -- surfels are appended frame by
+        # frame in pixel order, so neighbours in the map are neighbours in space -- whereas "random" (the default, SURVEY.md 8d: "sampled uniformly") is the worst case for
+        # every pass that gathers the visible part of the store.
+        from .dist import _part1by2_10
+        v = np.floor(out["pc"][:, :3] / np.float32(0.08)).astype(np.int64) + 512
+        code = _part1by2_10(v[:, 0]).astype(np.int64) | (_part1by2_10(v[:, 1]).astype(np.int64) << 1) | (_part1by2_10(v[:, 2]).astype(np.int64) << 2)
+        perm = np.argsort(code, kind="stable")
+        out = {k: np.ascontiguousarray(a[perm]) for k, a in out.items()}
     return out

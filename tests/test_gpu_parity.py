@@ -793,6 +793,62 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx):
         e.close()
 
 
+def test_config5_two_streams_one_sharded_map(ifx):
+    """BASELINE configuration 5 in small: K = 2 cameras (two stretches of the benchmark trajectory through the same scene) feed ONE map that is spatially
+    sharded over G = 2 ranks.  Semantics of a frame set: the K frames are processed in camera order on the one map; every camera tracks against the
+    prediction rendered at the end of its own last frame (camera contexts: ifx_camera_count / ifx_camera_select).  On the sharded side camera c is tracked by
+    rank c ONLY (ifx_owner_set_tracking_rank: stream k on GPU k, no tracker collective), the pose block is handed to the other rank (exchange 310), and every
+    rank runs the frame's map phases on its shard; camera 1 enters with an external pose (its extrinsic calibration: ifx_owner_set_frame_pose).  Against ONE
+    handle that time-slices the two cameras over the whole map: every pose, the prediction after every frame and -- merged by creation number -- the map, bit for bit."""
+    import torch
+
+    from instancefusion_amd import sharded, synth
+
+    K, G, NS = 2, 2, 7
+    W, H = SMALL["w"], SMALL["h"]
+    st = synth.make_stream(30, W, H, SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], noise=True, loop_len=90)
+    first = (0, 20)                                            # camera c sees frames first[c], first[c] + 1, ... of the loop
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    one = ifx.ElasticFusion(**SMALL, max_surfels=600000)
+    efs = [ifx.ElasticFusion(**SMALL, max_surfels=600000, n_ranks=G, rank=r) for r in range(G)]
+    for e in [one] + efs:
+        e.camera_count(K)
+    pose_b0 = st["poses"][first[1]].astype(np.float32)         # camera 1's pose in the map frame (= camera 0's first frame): given, not tracked
+    for s_ in range(NS):
+        for c in range(K):
+            i = first[c] + s_
+            ext = pose_b0 if (c == 1 and s_ == 0) else None
+            one.camera_select(c)
+            p1 = one.processFrame(st["rgb"][i], st["depth"][i], inPose=ext)
+            for e in efs:
+                e.camera_select(c)
+                e.owner_set_tracking_rank(c)                    # stream c is tracked on rank c only
+                if ext is not None:
+                    e.owner_set_frame_pose(ext)
+            sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+            for e in efs:
+                assert np.array_equal(e.getCurrPose(), p1), (s_, c, e.cfgd["rank"])
+            for name in ("pred_vertex", "pred_normal", "pred_image", "fill_vertex"):
+                a = one.image(name)
+                for e in efs:
+                    assert np.array_equal(e.image(name), a), (s_, c, name, e.cfgd["rank"])
+    # both cameras tracked: their trajectories follow the ground truth of their stretch
+    assert np.abs(p1 - st["poses"][first[1] + NS - 1]).max() < 0.03
+    ref = one.download()
+    parts = [(e.seq(), e.download()) for e in efs]
+    seq = np.concatenate([p[0] for p in parts])
+    order = np.argsort(seq, kind="stable")
+    assert len(np.unique(seq)) == len(seq) == ref["pc"].shape[0]
+    for k in MAP_KEYS:
+        assert np.array_equal(np.concatenate([p[1][k] for p in parts])[order], ref[k]), k
+    assert min(len(p[0]) for p in parts) > 0.3 * len(seq) / G
+    for e in efs:
+        e.close()
+    one.close()
+
+
 @pytest.mark.parametrize("earlyz,lds", [(1, 0), (0, 0), (0, 1)])
 def test_view_list_path_equals_per_pass_culls(ifx, earlyz, lds):
     """The frame path through the cached view list (one scan of the store per ~6 frames, list-driven index / clean / raster passes,

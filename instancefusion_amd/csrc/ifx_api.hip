@@ -261,6 +261,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "seg_device") h->opt_seg_device = value;
+    else if (s == "ff_rounds") h->opt_ff_rounds = value;
     else if (s == "labels_incremental") { h->opt_labels_incremental = value; h->labels_stale_all = 1; }
     else if (s == "icp_px") h->opt_icp_px = value;
     else if (s == "model_fused") h->opt_model_fused = value;

@@ -346,6 +346,10 @@ struct ifx {
     int* d_bbox = nullptr;             // [96*4 + maxmasks*4]
     int* d_inst_stats = nullptr;       // [96*2]
     int* d_clean_list = nullptr;
+    void* d_segctl = nullptr; void* h_segctl = nullptr;          // SegCtl of the device-side segmentation call + its pinned mirror (+ 256 verdict bytes)
+    uint8_t* h_masks_stage = nullptr; size_t h_masks_cap = 0;    // pinned staging of the caller's masks
+    int opt_seg_device = 1;            // segmentation call without the host in the middle (0: the host-driven schedule of round 2)
+    int opt_ff_rounds = 0;             // relaxation launches of the flood fill's fixed schedule (0: 24)
     int last_seg_frame = -1;
     int seg_counts_valid = 0;          // h_result->seg_counts describe the current ids_after / votes
     int clean_times = 0;

@@ -344,6 +344,9 @@ int ifx_alloc_instance(ifx* h)
 void ifx_free_instance(ifx* h)
 {
     hipFree(h->d_inst_color); hipFree(h->d_masks); hipFree(h->d_masks_ori); hipFree(h->d_unavail); hipFree(h->d_ff_label); hipFree(h->d_pdm); hipFree(h->d_bbox); hipFree(h->d_inst_stats); hipFree(h->d_clean_list);
+    hipFree(h->d_segctl);
+    if (h->h_segctl) hipHostFree(h->h_segctl);
+    if (h->h_masks_stage) hipHostFree(h->h_masks_stage);
 }
 
 int ifx_ensure_masks(ifx* h, size_t bytes)
@@ -374,7 +377,7 @@ extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
 }
 
 // whetherDoSegmentation, IF/Core/InstanceFusion.cpp:192-238
-static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail);
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds = 0, bool resume = false);
 // maskGeometricFilter as a stage (host buffers): depth = model depth under the camera (u16, 1186 units per metre as
 // getProjectDepthMap produces it), masks in/out, ori = masks before clean-overlap, unavailable in/out
 extern "C" int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int n, uint8_t* unavailable)
@@ -448,7 +451,8 @@ __device__ __forceinline__ float depth_threshold_dev(int depth)
 struct FFArgs {
     const uint16_t* depth; uint8_t* masks; const uint8_t* ori; const uint8_t* skip;   // skip[m] != 0: mask left alone
     int* label; int* cnt; int* meta;   // meta[m*32 + 0] oriPoints, [1] kept count, [2] finalPoints, [4..24) kept region ids
-    int* changed;                      // [0] set when a launch lowered a label
+    int* changed;                      // [it] set when relaxation launch `it` lowered a label (host-driven rounds use slot 0 only)
+    const int* gate;                   // fixed schedule: the tail kernels run only when *gate == 0 (the last scheduled relaxation changed nothing: fixpoint); nullptr: always
     uint8_t* tile_active;              // [nm][tiles]: the tile holds a labelled pixel (a tile without one has nothing to relax, whatever its halo says: labels only ever move between mask pixels)
     int nm, w, h;
 };
@@ -470,10 +474,13 @@ __global__ void k_ff_init(FFArgs a)
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&a.meta[m * 32], __popcll(b));
 }
 
-__global__ void __launch_bounds__(256) k_ff_relax(FFArgs a)
+// `it`: index of this launch in a fixed schedule.  A launch whose predecessor changed nothing has nothing to do either (that predecessor re-checked every edge:
+// the fixpoint) and returns at its first instruction, leaving its own flag clear -- so the host can enqueue the whole schedule without looking.
+__global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 {
     __shared__ int s_lab[FF_T + 2][FF_T + 2];
     __shared__ unsigned short s_d[FF_T + 2][FF_T + 2];
+    if (it > 0 && a.changed[it - 1] == 0) return;
     const int P = a.w * a.h, m = blockIdx.z;
     if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
@@ -530,12 +537,13 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a)
         const int x = x0 + lx1, y = y0 + (tid >> 5) * 4 + u + 1;
         if (x < a.w && y < a.h && mine[u] != orig[u]) { lab[y * a.w + x] = mine[u]; dirty = 1; }
     }
-    if (__syncthreads_or(dirty) && tid == 0) *a.changed = 1;
+    if (__syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
 }
 
 // region sizes: one counter per root pixel; lanes of a wave grouped by label (regions are large)
 __global__ void k_ff_count(FFArgs a)
 {
+    if (a.gate && *a.gate) return;
     const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     int l = (k < P && !a.skip[m]) ? a.label[(size_t)m * P + k] : -1;
     const int lane = threadIdx.x & 63;
@@ -551,6 +559,7 @@ __global__ void k_ff_count(FFArgs a)
 // regions holding more than a quarter of the original mask are kept (IF/Core/InstanceFusion.cpp:560)
 __global__ void k_ff_select(FFArgs a)
 {
+    if (a.gate && *a.gate) return;
     const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (k >= P || a.skip[m] || a.label[(size_t)m * P + k] != k) return;
     float points = (float)a.cnt[(size_t)m * P + k], oriPoints = (float)a.meta[m * 32];
@@ -561,6 +570,7 @@ __global__ void k_ff_select(FFArgs a)
 }
 __global__ void k_ff_apply(FFArgs a)
 {
+    if (a.gate && *a.gate) return;
     const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     bool keep = false;
     if (k < P && !a.skip[m]) {
@@ -574,6 +584,7 @@ __global__ void k_ff_apply(FFArgs a)
 // a mask that lost more than 35 % of its pixels is unusable (:590)
 __global__ void k_ff_verdict(FFArgs a, uint8_t* unavailable)
 {
+    if (a.gate && *a.gate) return;
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= a.nm || a.skip[m]) return;
     float finalPoints = (float)a.meta[m * 32 + 2], oriPoints = (float)a.meta[m * 32];
@@ -581,38 +592,58 @@ __global__ void k_ff_verdict(FFArgs a, uint8_t* unavailable)
 }
 
 // d_unavail: [nm] bytes in/out (set entries are skipped, as `continue` at :520); masks / ori: device, [nm][P]
-static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail)
+// fixed_rounds == 0: relaxations until a launch changes nothing, the host looking every 7 launches (stage API, sharded calls, slow path).
+// fixed_rounds  > 0: exactly that many relaxation launches are enqueued -- the ones behind the fixpoint return at once -- and the tail (region sizes, selection,
+//   verdict) only runs when the last one found nothing to change; otherwise *ff_gate() stays set and the caller finishes with resume = true.  No host look at all.
+#define FF_SLOTS 64
+static FFArgs ff_args(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm)
+{
+    FFArgs a;
+    a.depth = d_depth; a.masks = d_masks; a.ori = d_ori; a.nm = nm; a.w = h->w; a.h = h->h;
+    a.label = h->d_ff_label; a.cnt = h->d_ff_label + h->ff_cap; a.meta = a.cnt + h->ff_cap; a.changed = a.meta + 256 * 32;
+    uint8_t* d_skip = (uint8_t*)(a.changed + FF_SLOTS);
+    a.skip = d_skip;
+    a.tile_active = d_skip + 256;
+    a.gate = nullptr;
+    return a;
+}
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds, bool resume)
 {
     const int P = h->P;
     size_t need = (size_t)nm * P;
     if (need > h->ff_cap) {
         if (h->d_ff_label) hipFree(h->d_ff_label);
         h->d_ff_label = nullptr; h->ff_cap = 0;
-        HIPCHK(h, hipMalloc(&h->d_ff_label, need * 2 * 4 + (size_t)256 * 32 * 4 + 64 + 256 + (size_t)256 * cdiv(h->w, FF_T) * cdiv(h->h, FF_T)));
+        HIPCHK(h, hipMalloc(&h->d_ff_label, need * 2 * 4 + (size_t)256 * 32 * 4 + FF_SLOTS * 4 + 256 + (size_t)256 * cdiv(h->w, FF_T) * cdiv(h->h, FF_T)));
         h->ff_cap = need;
     }
-    FFArgs a;
-    a.depth = d_depth; a.masks = d_masks; a.ori = d_ori; a.nm = nm; a.w = h->w; a.h = h->h;
-    a.label = h->d_ff_label; a.cnt = h->d_ff_label + h->ff_cap; a.meta = a.cnt + h->ff_cap; a.changed = a.meta + 256 * 32;
-    uint8_t* d_skip = (uint8_t*)(a.changed + 16);
-    a.skip = d_skip;
-    a.tile_active = d_skip + 256;
-    HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->stream));   // the verdict must not change who is skipped mid-way
-    HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->stream));
+    FFArgs a = ff_args(h, d_depth, d_masks, d_ori, nm);
+    uint8_t* d_skip = (uint8_t*)a.skip;
     dim3 per_px(cdiv(P, 256), nm);
-    LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
     dim3 tiles(cdiv(h->w, FF_T), cdiv(h->h, FF_T), nm);
-    for (int round = 0; round < 64; round++) {
-        HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-        for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a);
-        // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
-        HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-        LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a);
-        int changed = 0;
-        HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (!changed) break;
+    if (!resume) {
+        HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->stream));   // the verdict must not change who is skipped mid-way
+        HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(a.changed, 0, FF_SLOTS * 4, h->stream));
+        LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
+    }
+    if (fixed_rounds > 0 && !resume) {
+        if (fixed_rounds > FF_SLOTS) fixed_rounds = FF_SLOTS;
+        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, it);
+        a.gate = a.changed + (fixed_rounds - 1);
+    } else {
+        for (int round = 0; round < 64; round++) {
+            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
+            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
+            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
+            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            int changed = 0;
+            HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (!changed) break;
+        }
     }
     LAUNCH(h, "ff_count", per_px, dim3(256), k_ff_count, a);
     LAUNCH(h, "ff_select", per_px, dim3(256), k_ff_select, a);
@@ -826,59 +857,27 @@ static int oseg_resume(ifx* h)
     return IFX_E_STATE;
 }
 
-static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags);
+static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags);
+static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags);
 extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
-    const int r = process_segmentation(h, rgb, depth, masks_in, class_ids, nm, frame, flags);
+    if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
+    if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
+    const int r = h->opt_seg_device ? process_segmentation_device(h, rgb, depth, masks_in, class_ids, nm, frame, flags)
+                                    : process_segmentation_host(h, rgb, depth, masks_in, class_ids, nm, frame, flags);
     // a call that failed part-way may have updated votes without the label scan that follows them: the incremental scan of the next call assumes
     // that votes outside its own id image are unchanged since the last scan, so the next call scans everything
-    if (r != IFX_OK && h) h->labels_stale_all = 1;
+    if (r != IFX_OK) h->labels_stale_all = 1;
     return r;
 }
-static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+
+// step 3 of processInstance (IF/Core/InstanceFusion.cpp:955-1040) from mask m_start on, driven by the host: registration, the eviction of a full table
+// (computeMaxCountInMap, getInstanceTableCleanList, cleanInstanceTableMap, boxes and compare map again), one vote launch per (mask, instance)
+static int seg_host_mask_loop(ifx* h, int nm, const int32_t* class_ids, int m_start, std::vector<int>& cmp, std::vector<uint8_t>& unavailable, std::vector<int>& bbox)
 {
-    // Only the kNN smoothing looks at surfels the id image does not show: a slot outside the cached view list that has outlived the age rule
-    // (ifx_map.hip "View list") is unstable, so it was never in an id image, carries no votes and takes part in nothing else of this call.
-    if (h && (flags & 1)) ifx_vlist_reap(h);
-    if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
-    h->seg_counts_valid = 0;
-    if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
-    hipEvent_t ea = ifx_event_get(h);
-    hipEventRecord(ea, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    int n = 0;
-    HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
-    if (nm == 0 || n == 0) { h->event_pool.push_back(ea); return IFX_OK; }
     const int P = h->P;
-    size_t mbytes = (size_t)nm * P;
-    std::vector<uint8_t> unavailable(nm, 0);
-    int r = ifx_ensure_masks(h, mbytes);
-    if (r) return r;
-    // the masks stay on the device from here on: d_masks_ori = "BAK ORI MASK" (:705-706), d_masks = working copy
-    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
-    // step 0_1
-    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
-    // steps -1_1 .. -1_3 (superpixel refinement)
-    if (flags & 2) {
-        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
-        if (r) return r;
-    }
-    // steps 1, 2
-    std::vector<int> bbox;
-    r = run_bboxes(h, nm, bbox);
-    if (r) return r;
-    std::vector<int> cmp((size_t)nm * NI, 0);
-    compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
-    // step 3_0: model depth under the camera, then the flood fill of every usable mask (device)
-    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
-    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->stream));
-    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail);
-    if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(unavailable.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    // step 3
-    for (int m = 0; m < nm; m++) {
+    int r;
+    for (int m = m_start; m < nm; m++) {
         bool exist = false;
         for (int q = 0; q < NI; q++) if (cmp[q + m * NI] == 1) { exist = true; break; }
         if (!exist && !unavailable[m]) {
@@ -916,7 +915,12 @@ static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* de
             if (cmp[q + m * NI] == 1)
                 LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes, ifx_idmap(h));
     }
-    // step 4
+    return IFX_OK;
+}
+// step 4: the label scan (countAndColourSurfelMap) -- restricted to what a call can have changed unless the votes were rewritten wholesale
+static void seg_label_scan(ifx* h)
+{
+    const int P = h->P;
     if (h->opt_labels_incremental && !h->labels_stale_all) {
         LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels);
         LAUNCH(h, "count_colour_px", dim3(cdiv(P, 256)), dim3(256), k_count_colour_px, h->d_state, h->ids_after, P, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col,
@@ -925,7 +929,225 @@ static int process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* de
         LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
         h->labels_stale_all = 0;
     }
+}
+
+static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+{
+    // Only the kNN smoothing looks at surfels the id image does not show: a slot outside the cached view list that has outlived the age rule
+    // (ifx_map.hip "View list") is unstable, so it was never in an id image, carries no votes and takes part in nothing else of this call.
+    if (flags & 1) ifx_vlist_reap(h);
+    h->seg_counts_valid = 0;
+    hipEvent_t ea = ifx_event_get(h);
+    hipEventRecord(ea, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int n = 0;
+    HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
+    if (nm == 0 || n == 0) { h->event_pool.push_back(ea); return IFX_OK; }
+    const int P = h->P;
+    size_t mbytes = (size_t)nm * P;
+    std::vector<uint8_t> unavailable(nm, 0);
+    int r = ifx_ensure_masks(h, mbytes);
+    if (r) return r;
+    // the masks stay on the device from here on: d_masks_ori = "BAK ORI MASK" (:705-706), d_masks = working copy
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
+    // step 0_1
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
+    // steps -1_1 .. -1_3 (superpixel refinement)
+    if (flags & 2) {
+        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
+        if (r) return r;
+    }
+    // steps 1, 2
+    std::vector<int> bbox;
+    r = run_bboxes(h, nm, bbox);
+    if (r) return r;
+    std::vector<int> cmp((size_t)nm * NI, 0);
+    compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
+    // step 3_0: model depth under the camera, then the flood fill of every usable mask (device)
+    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
+    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->stream));
+    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(unavailable.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // step 3
+    r = seg_host_mask_loop(h, nm, class_ids, 0, cmp, unavailable, bbox);
+    if (r) return r;
+    // step 4
+    seg_label_scan(h);
     // flannKnnVoteSurfelMap (isflann, :1051)
+    if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
+    hipEvent_t eb = ifx_event_get(h);
+    hipEventRecord(eb, h->stream);
+    h->stage_pending.push_back({2, {ea, eb}});
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
+// ---- the same call without the host in the middle of it (default; ifx_set_option("seg_device", 0) restores the host-driven schedule above).
+// Round 2's call cost 1.4-1.8 ms -- two frames -- of which the kernels were ~0.8: the host waited for the stream at entry (behind the NEXT frame's tracker, enqueued
+// ahead), copied the masks from pageable memory, read the superpixel table back for connectSuperPixel, read the boxes back for computeCompareMap, looked at the
+// flood fill every 7 relaxations, read the verdicts back, and decided registration mask by mask.  Here: pinned staging, connectSuperPixel on the device
+// (ifx_slic.hip: k_sp_connect), compare map and registration in two tiny kernels on a device copy of the instance table, a FIXED schedule of flood-fill
+// relaxations (the ones behind the fixpoint return at once), one vote launch per mask that looks its target up on the device -- and ONE synchronisation at the end,
+// which brings back the table, the verdicts and two flags: "the fill did not converge inside its schedule" and "the table was full at mask m".  Both are rare and
+// are finished the old way from exactly that point (results identical either way: tests/test_gpu_parity.py::test_segmentation_device_schedule_equals_host_schedule).
+struct SegCtl { int ff_incomplete, evict_at, nm, pad; int inst_class[NI]; int cls[256]; int best[256]; int target[256]; };
+// computeCompareMap (IF/Core/InstanceFusion.cpp:595-651): one thread per mask; the LAST instance over the threshold wins, instance 0 never matches
+__global__ void k_seg_compare(SegCtl* __restrict__ s, const int* __restrict__ bbox, uint8_t* __restrict__ unavailable)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= s->nm) return;
+    const int* mb = bbox + (NI + m) * 4;
+    const int minX_m = mb[0], maxX_m = mb[1], minY_m = mb[2], maxY_m = mb[3];
+    s->target[m] = -1;
+    if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) { unavailable[m] = 1; s->best[m] = -1; return; }
+    int best = -1;
+    for (int q = 0; q < NI; q++) {
+        if (s->inst_class[q] == -1 || s->cls[m] != s->inst_class[q]) continue;
+        const int minX_i = bbox[q * 4], maxX_i = bbox[q * 4 + 1], minY_i = bbox[q * 4 + 2], maxY_i = bbox[q * 4 + 3];
+        if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
+        const float IW = (float)(min(maxX_i, maxX_m) - max(minX_i, minX_m));
+        const float IH = (float)(min(maxY_i, maxY_m) - max(minY_i, minY_m));
+        if (IW <= 0 || IH <= 0) continue;
+        const float I = IW * IH;
+        const float U = (float)(((maxX_i - minX_i) * (maxY_i - minY_i)) + ((maxX_m - minX_m) * (maxY_m - minY_m))) - I;
+        if (I / U > 0.5f) best = q;
+    }
+    s->best[m] = best > 0 ? best : -1;
+}
+// the registration decisions of the mask loop (:955-1010), sequential as in the reference: a mask without a match that is still usable takes the first free
+// slot of the table; when there is none the loop stops there (evict_at) and the host evicts (rare: 96 slots)
+__global__ void k_seg_register(SegCtl* __restrict__ s, const uint8_t* __restrict__ unavailable, const int* __restrict__ ff_gate)
+{
+    if (threadIdx.x != 0) return;
+    s->evict_at = -1;
+    if (ff_gate && *ff_gate) { s->ff_incomplete = 1; return; }
+    s->ff_incomplete = 0;
+    for (int m = 0; m < s->nm; m++) {
+        int t = s->best[m];
+        if (t < 0 && !unavailable[m]) {
+            int empty = -1;
+            for (int i = 0; i < NI; i++) if (s->inst_class[i] == -1) { empty = i; break; }
+            if (empty == -1) { s->evict_at = m; return; }
+            s->inst_class[empty] = s->cls[m];
+            t = empty;
+        }
+        s->target[m] = t;
+    }
+}
+// updateSurfelMapInstance for mask m with the instance the device chose for it; a launch for a mask without one (or behind the point where the host takes over)
+// returns at its first instruction
+__global__ void k_vote_update_m(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ masks, int P, int cap, const SegCtl* __restrict__ s, int m,
+                                float* __restrict__ votes, IdMap im)
+{
+    if (s->ff_incomplete || (s->evict_at >= 0 && m >= s->evict_at)) return;
+    const int instanceID = s->target[m];
+    if (instanceID < 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    if (!(masks[(size_t)m * P + k] > 0)) return;
+    const int id = idmap_slot(im, st->count, ids[k]);
+    if (id < 0) return;
+    const int fi = instanceID / 2, p = instanceID % 2, inc = m + 1;
+    unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
+    unsigned int old = *addr, assumed;
+    do {
+        assumed = old;
+        int a, b;
+        vote_decode(__uint_as_float(assumed), a, b);
+        if (p == 0) a += inc; else b += inc;
+        if (a >= 65535) a = 65535;
+        if (b >= 65535) b = 65535;
+        old = atomicCAS(addr, assumed, __float_as_uint(vote_encode(a, b)));
+    } while (old != assumed);
+}
+
+static int seg_ensure_ctl(ifx* h, size_t mask_bytes)
+{
+    if (!h->d_segctl) {
+        HIPCHK(h, hipMalloc(&h->d_segctl, sizeof(SegCtl)));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_segctl, sizeof(SegCtl) + 256, hipHostMallocDefault));
+    }
+    if (mask_bytes > h->h_masks_cap) {
+        if (h->h_masks_stage) hipHostFree(h->h_masks_stage);
+        h->h_masks_stage = nullptr; h->h_masks_cap = 0;
+        HIPCHK(h, hipHostMalloc((void**)&h->h_masks_stage, mask_bytes, hipHostMallocDefault));
+        h->h_masks_cap = mask_bytes;
+    }
+    return IFX_OK;
+}
+
+static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
+{
+    if (flags & 1) ifx_vlist_reap(h);
+    // the frame's result, not the stream: the next frame's tracker may already be queued behind it, and nothing here has to wait for that
+    int n = 0;
+    if (h->seg_counts_valid && h->ev_result) { HIPCHK(h, hipEventSynchronize(h->ev_result)); n = h->h_result->count; }
+    else { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost)); }
+    h->seg_counts_valid = 0;
+    if (nm == 0 || n == 0) return IFX_OK;
+    const int P = h->P;
+    const size_t mbytes = (size_t)nm * P;
+    int r = ifx_ensure_masks(h, mbytes);
+    if (r) return r;
+    if ((r = seg_ensure_ctl(h, mbytes))) return r;
+    SegCtl* hc = (SegCtl*)h->h_segctl;
+    memcpy(h->h_masks_stage, masks_in, mbytes);
+    hc->ff_incomplete = 0; hc->evict_at = -1; hc->nm = nm; hc->pad = 0;
+    for (int i = 0; i < NI; i++) hc->inst_class[i] = h->inst_class[i];
+    for (int m = 0; m < 256; m++) { hc->cls[m] = m < nm ? class_ids[m] : -1; hc->best[m] = -1; hc->target[m] = -1; }
+    hipEvent_t ea = ifx_event_get(h);
+    hipEventRecord(ea, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, h->h_masks_stage, mbytes, hipMemcpyHostToDevice, h->stream));   // pinned: a true asynchronous copy
+    HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_unavail, 0, nm, h->stream));
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
+    if (flags & 2) {
+        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
+        if (r) return r;
+    }
+    SegCtl* dc = (SegCtl*)h->d_segctl;
+    LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+           h->d_bbox, ifx_idmap(h));
+    LAUNCH(h, "seg_compare", dim3(1), dim3(256), k_seg_compare, dc, (const int*)h->d_bbox, h->d_unavail);
+    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
+    const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : 24;
+    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, rounds);
+    if (r) return r;
+    const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);
+    const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
+    LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, gate);
+    for (int m = 0; m < nm; m++)
+        LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_m, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, m, h->votes, ifx_idmap(h));
+    seg_label_scan(h);
+    uint8_t* h_un = (uint8_t*)h->h_segctl + sizeof(SegCtl);
+    HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (hc->ff_incomplete) {   // the fill needs more relaxations than the schedule holds: finish it with the host looking, then the tail again (nothing was voted yet)
+        r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
+        if (r) return r;
+        LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, (const int*)nullptr);
+        for (int m = 0; m < nm; m++)
+            LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_m, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, m, h->votes, ifx_idmap(h));
+        seg_label_scan(h);
+        HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    for (int i = 0; i < NI; i++) h->inst_class[i] = hc->inst_class[i];
+    if (hc->evict_at >= 0) {   // the table is full at this mask: the reference evicts its twenty weakest instances and goes on -- from here the host-driven loop
+        std::vector<uint8_t> unavailable(h_un, h_un + nm);
+        std::vector<int> cmp((size_t)nm * NI, 0), bbox;
+        for (int m = 0; m < nm; m++) if (hc->best[m] > 0) cmp[hc->best[m] + m * NI] = 1;
+        r = seg_host_mask_loop(h, nm, class_ids, hc->evict_at, cmp, unavailable, bbox);
+        if (r) return r;
+        seg_label_scan(h);
+    }
     if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
     hipEvent_t eb = ifx_event_get(h);
     hipEventRecord(eb, h->stream);

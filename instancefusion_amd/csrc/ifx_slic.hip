@@ -489,57 +489,97 @@ __global__ void k_sp_filter(const int* __restrict__ fin, uint8_t* __restrict__ m
 // connectSuperPixel (IF/Core/InstanceFusion_superpixel.cpp:227-400), host: ~1200 nodes with <= 11 edges each.
 // First pass drops the edges whose plane-distance + normal term exceeds either end's threshold, second
 // pass labels the connected components by their lowest member.
-void connect_superpixels(int spn, float* info, std::vector<int>& final_of)
+//
+// On the device in ONE block (the reference does both passes on the host, and so did round 2: a read-back, ~13 k sequential edge tests and an upload in the
+// middle of every segmentation call).  The reference's two sequential passes have order-free equivalents:
+//  * pass 1 visits a = 0, 1, ... and, when the directed test of (a -> b) fails, deletes b from a's list AND a from b's list.  An entry (a -> b) therefore
+//    survives iff test(a -> b) passes and (a is not in b's list or test(b -> a) passes): every thread evaluates its own node's directed tests, a barrier, then
+//    the symmetric look-up -- on the ORIGINAL lists, which is what the sequential pass reads too (a deleted entry is never re-tested).
+//  * pass 2 labels, for a = 0, 1, ..., everything reachable from a through still unlabelled nodes with a.  By induction on a this is
+//    label(t) = min { a : t reachable from a along surviving DIRECTED entries } (a node on a path from the minimal such a to t cannot have been labelled
+//    earlier, or t would be reachable from something smaller): min-propagation along the entries with pointer jumping, to the fixpoint.
+__device__ __forceinline__ bool sp_edge_fails(const float* __restrict__ A, const float* __restrict__ B)
 {
-    for (int a = 0; a < spn; a++) {
-        float* A = info + (size_t)a * SPI_SIZE;
-        A[SPI_FINAL] = -1.f;
+    const float nx = A[SPI_NOR_A], ny = A[SPI_NOR_A + 1], nz = A[SPI_NOR_A + 2];
+    const float ex = A[SPI_POS_A] - B[SPI_POS_A], ey = A[SPI_POS_A + 1] - B[SPI_POS_A + 1], ez = A[SPI_POS_A + 2] - B[SPI_POS_A + 2];
+    const float ln = sqrtf(nx * nx + ny * ny + nz * nz), le = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float dot = nx * ex + ny * ey + nz * ez;
+    const float dist_term = (float)((double)fabsf(dot / ln) + 1.0 * (double)le);
+    const float thrA = (float)(1 * ((0.026 * (double)A[SPI_DEPTH_AVG] - (double)4.0f) / (double)1186.0f));
+    const float thrB = (float)(1 * ((0.026 * (double)B[SPI_DEPTH_AVG] - (double)4.0f) / (double)1186.0f));
+    const float devA = 2 * A[SPI_DIST_DEV], devB = 2 * B[SPI_DIST_DEV];
+    const float q1 = fabsf(nx - B[SPI_NOR_A]), q2 = fabsf(ny - B[SPI_NOR_A + 1]), q3 = fabsf(nz - B[SPI_NOR_A + 2]);
+    const float nor_term = (float)(0.1 * (double)sqrtf(q1 * q1 + q2 * q2 + q3 * q3));
+    const float zA = 0 * A[SPI_NOR_DEV], zB = 0 * B[SPI_NOR_DEV];
+    const float test = dist_term + nor_term, limA = thrA + devA + zA, limB = thrB + devB + zB;
+    return test > limA || test > limB;
+}
+__global__ __launch_bounds__(1024) void k_sp_connect(int spn, float* __restrict__ info, int* __restrict__ final_of)
+{
+    extern __shared__ int sm[];
+    int* label = sm;                                   // [spn]
+    unsigned int* pass = (unsigned int*)(sm + spn);    // [spn] bit j: the directed test of entry j passed
+    unsigned int* alive = pass + spn;                  // [spn] bit j: entry j survives pass 1
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int a = tid; a < spn; a += nt) {
+        const float* A = info + (size_t)a * SPI_SIZE;
         const int na = (int)A[SPI_CONNECT_N];
+        unsigned int m = 0;
         for (int j = 0; j < na; j++) {
             const int b = (int)A[SPI_NP_FIRST + j];
             if (b == -1) continue;
-            float* B = info + (size_t)b * SPI_SIZE;
-            const float nx = A[SPI_NOR_A], ny = A[SPI_NOR_A + 1], nz = A[SPI_NOR_A + 2];
-            const float ex = A[SPI_POS_A] - B[SPI_POS_A], ey = A[SPI_POS_A + 1] - B[SPI_POS_A + 1], ez = A[SPI_POS_A + 2] - B[SPI_POS_A + 2];
-            const float ln = std::sqrt(nx * nx + ny * ny + nz * nz), le = std::sqrt(ex * ex + ey * ey + ez * ez);
-            const float dot = nx * ex + ny * ey + nz * ez;
-            const float dist_term = (float)((double)std::fabs(dot / ln) + 1.0 * (double)le);
-            const float thrA = (float)(1 * ((0.026 * (double)A[SPI_DEPTH_AVG] - (double)4.0f) / (double)1186.0f));
-            const float thrB = (float)(1 * ((0.026 * (double)B[SPI_DEPTH_AVG] - (double)4.0f) / (double)1186.0f));
-            const float devA = 2 * A[SPI_DIST_DEV], devB = 2 * B[SPI_DIST_DEV];
-            const float q1 = std::fabs(nx - B[SPI_NOR_A]), q2 = std::fabs(ny - B[SPI_NOR_A + 1]), q3 = std::fabs(nz - B[SPI_NOR_A + 2]);
-            const float nor_term = (float)(0.1 * (double)std::sqrt(q1 * q1 + q2 * q2 + q3 * q3));
-            const float zA = 0 * A[SPI_NOR_DEV], zB = 0 * B[SPI_NOR_DEV];
-            const float test = dist_term + nor_term, limA = thrA + devA + zA, limB = thrB + devB + zB;
-            if (test > limA || test > limB) {
-                A[SPI_NP_FIRST + j] = -1.f;
-                const int nb = (int)B[SPI_CONNECT_N];
-                for (int k = 0; k < nb; k++)
-                    if (B[SPI_NP_FIRST + k] == (float)a) { B[SPI_NP_FIRST + k] = -1.f; break; }
+            if (!sp_edge_fails(A, info + (size_t)b * SPI_SIZE)) m |= 1u << j;
+        }
+        pass[a] = m;
+        label[a] = a;
+    }
+    __syncthreads();
+    for (int a = tid; a < spn; a += nt) {
+        const float* A = info + (size_t)a * SPI_SIZE;
+        const int na = (int)A[SPI_CONNECT_N];
+        unsigned int m = pass[a];
+        for (int j = 0; j < na; j++) {
+            if (!(m & (1u << j))) continue;
+            const int b = (int)A[SPI_NP_FIRST + j];
+            const float* B = info + (size_t)b * SPI_SIZE;
+            const int nb = (int)B[SPI_CONNECT_N];
+            for (int k = 0; k < nb; k++)
+                if (B[SPI_NP_FIRST + k] == (float)a) { if (!(pass[b] & (1u << k))) m &= ~(1u << j); break; }   // (the first entry equal to a, as the sequential deletion)
+        }
+        alive[a] = m;
+    }
+    __syncthreads();   // every original list has been read: the deletions may be written now
+    for (int a = tid; a < spn; a += nt) {
+        float* A = info + (size_t)a * SPI_SIZE;
+        const int na = (int)A[SPI_CONNECT_N];
+        const unsigned int m = alive[a];
+        for (int j = 0; j < na; j++)
+            if (!(m & (1u << j)) && A[SPI_NP_FIRST + j] != -1.f) A[SPI_NP_FIRST + j] = -1.f;
+    }
+    __syncthreads();
+    for (int round = 0; round < 4 * 1024; round++) {   // (the fixpoint arrives within ~log(diameter) rounds; the bound only guards against a corrupt table)
+        int any = 0;
+        for (int a = tid; a < spn; a += nt) {
+            const float* A = info + (size_t)a * SPI_SIZE;
+            const int na = (int)A[SPI_CONNECT_N], la = label[a];
+            const unsigned int m = alive[a];
+            for (int j = 0; j < na; j++) {
+                if (!(m & (1u << j))) continue;
+                const int b = (int)A[SPI_NP_FIRST + j];
+                if (atomicMin(&label[b], la) > la) any = 1;
             }
         }
-    }
-    std::vector<int> stack;
-    stack.reserve((size_t)spn * (NB_MAX + 1));
-    for (int a = 0; a < spn; a++) {
-        const int root = info[(size_t)a * SPI_SIZE + SPI_FINAL] == -1.f ? a : (int)info[(size_t)a * SPI_SIZE + SPI_FINAL];
-        stack.push_back(a);
-        while (!stack.empty()) {
-            const int t = stack.back();
-            stack.pop_back();
-            float* T = info + (size_t)t * SPI_SIZE;
-            if (T[SPI_FINAL] != -1.f) continue;
-            T[SPI_FINAL] = (float)root;
-            const int nt = (int)T[SPI_CONNECT_N];
-            for (int j = 0; j < nt; j++) {
-                const int q = (int)T[SPI_NP_FIRST + j];
-                if (q == -1 || info[(size_t)q * SPI_SIZE + SPI_FINAL] != -1.f) continue;
-                stack.push_back(q);
-            }
+        __syncthreads();
+        for (int a = tid; a < spn; a += nt) {           // pointer jump: my label's label reaches me too
+            const int l = label[a], g = label[l];
+            if (g < l) { atomicMin(&label[a], g); any = 1; }
         }
+        if (!__syncthreads_or(any)) break;
     }
-    final_of.resize(spn);
-    for (int a = 0; a < spn; a++) final_of[a] = (int)info[(size_t)a * SPI_SIZE + SPI_FINAL];
+    for (int a = tid; a < spn; a += nt) {
+        info[(size_t)a * SPI_SIZE + SPI_FINAL] = (float)label[a];
+        final_of[a] = label[a];
+    }
 }
 
 template <typename T>
@@ -606,10 +646,7 @@ int merge_run(ifx* h, SlicBuf* b)
     LAUNCH(h, "sp_first_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_first_avg, b->sum1, b->adj, b->adj_words, S, b->info);
     LAUNCH(h, "sp_recluster", dim3(cdiv(w, 16), cdiv(hh, 16)), dim3(16, 16), k_sp_recluster, b->seg, b->dg, b->pos, b->nor, w, hh, b->info, b->sum2);
     LAUNCH(h, "sp_second_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_second_avg, b->sum2, S, b->info);
-    HIPCHK(h, hipMemcpyAsync(b->h_info.data(), b->info, (size_t)S * SPI_SIZE * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    connect_superpixels(S, b->h_info.data(), b->h_final);
-    HIPCHK(h, hipMemcpyAsync(b->final_of, b->h_final.data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+    LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * 12, k_sp_connect, S, b->info, b->final_of);   // connectSuperPixel on the device: no read-back inside a call
     LAUNCH(h, "sp_final", dim3(cdiv(P, 256)), dim3(256), k_sp_final, b->seg, b->final_of, b->fin, P);
     return IFX_OK;
 }
@@ -665,8 +702,12 @@ int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int
     int r = slic_buffers(h, &b);
     if (r) return r;
     const size_t P = b->P;
-    HIPCHK(h, hipMemcpyAsync(b->rgb, rgb, P * 3, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(b->depth, depth, P * 2, hipMemcpyHostToDevice, h->stream));
+    // through the handle's pinned staging (free here: ifx_process_frame, its other user, synchronises before it returns): a copy from the caller's pageable
+    // memory would make the call wait for everything queued in front of it
+    std::memcpy(h->rgb_stage, rgb, P * 3);
+    std::memcpy(h->depth_stage, depth, P * 2);
+    HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->stream));
     if ((r = slic_run(h, b))) return r;
     if ((r = merge_run(h, b))) return r;
     return filter_run(h, b, h->d_masks, nm, true);
@@ -698,6 +739,7 @@ extern "C" int ifx_merge_superpixels(ifx_t* h, const uint16_t* depth, int32_t* s
     if ((r = merge_run(h, b))) return r;
     HIPCHK(h, hipMemcpyAsync(seg_inout, b->seg, P * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(final_out, b->fin, P * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->h_info.data(), b->info, (size_t)b->spn * SPI_SIZE * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (info_out) std::memcpy(info_out, b->h_info.data(), (size_t)b->spn * SPI_SIZE * 4);
     return b->spn;

@@ -346,6 +346,57 @@ def test_bounding_boxes_and_instance_point_clouds(ifx, orc, small_stream):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("ff_rounds", [0, 2])
+def test_segmentation_device_schedule_equals_host_schedule(ifx, small_stream, ff_rounds):
+    """The segmentation call without the host in the middle of it (default since round 3: compare map, registration and the flood fill's termination on the
+    device, one synchronisation at the end) against round 2's host-driven schedule (`seg_device` 0): instance tables, votes, labels and colours bit for bit
+    over calls with superpixels, calls that match registered instances, and the eviction of a full table (the device stops at the mask that finds no free
+    slot, the host evicts and goes on from there).  ff_rounds = 2 makes the fixed relaxation schedule too short on purpose: the fill is then finished the
+    host-driven way and the tail re-issued -- same results."""
+    from instancefusion_amd import synth
+
+    st = small_stream
+    a = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    b = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    b.set_option("seg_device", 0)
+    a.set_option("ff_rounds", ff_rounds)
+    ia, ib = ifx.InstanceFusion(a), ifx.InstanceFusion(b)
+    for i in range(8):
+        pa = a.processFrame(st["rgb"][i], st["depth"][i]); pb = b.processFrame(st["rgb"][i], st["depth"][i])
+        assert np.array_equal(pa, pb)
+        if i == 3:
+            m = a.download(); m["pc"][:, 3] = 20.0
+            for e in (a, b):
+                e.upload(m); e.set_pose(pa, a.tick)
+        if i >= 4:
+            masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+            ia.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, 100 + 3 * i, superpixels=True)
+            ib.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, 100 + 3 * i, superpixels=True)
+            assert np.array_equal(ia.getInstanceTable(), ib.getInstanceTable()), i
+            assert np.array_equal(ia.labels(), ib.labels()), i
+    assert (ia.labels() >= 0).sum() > 100
+    # fill the table: new classes for every mask until the twenty weakest instances are evicted
+    i = 7
+    masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+    nm = masks.shape[0]
+    evicted = False
+    for call in range(40):
+        classes = (1 + (call * nm + np.arange(nm)) % 79).astype(np.int32)
+        before = (ib.getInstanceTable() >= 0).sum()
+        ia.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, classes, 300 + 3 * call)
+        ib.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, classes, 300 + 3 * call)
+        assert np.array_equal(ia.getInstanceTable(), ib.getInstanceTable()), call
+        evicted = evicted or (ib.getInstanceTable() >= 0).sum() < before
+        if evicted:
+            break
+    assert evicted
+    ma, mb = a.download(), b.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(ma[k], mb[k]), k
+    assert np.array_equal(ia.labels(), ib.labels())
+    a.close(); b.close()
+
+
 def _clean(orc, masks):
     m = masks.copy()
     L = orc.lib()

@@ -453,7 +453,7 @@ def main():
         one = cpu_leg(1, max(2, args.cpu_frames // 2))
         allc = cpu_leg(ncores, args.cpu_frames) if ncores > 1 else one
         cpu = dict(value=allc["value"], unit="frames/s", cores=allc["cores"], kind="port",
-                   sample=f"{allc['frames']} frames of the same {W}x{H} stream into the same {n_cpu}-surfel synthetic map + one segmentation call (timed apart), the tracker with OpenMP over image rows on all {allc['cores']} usable host cores, the map passes sequential (their z-buffers keep the draw order of the map); "
+                   sample=f"{allc['frames']} frames of the same {W}x{H} stream into the same {n_cpu}-surfel synthetic map + one segmentation call (timed apart), OpenMP on all {allc['cores']} usable host cores: the tracker over image rows, the map renders over surfel ranges into per-thread z-buffers merged in draw order, association / stability tests over pixels / surfels (compaction and the append scan sequential); "
                           f"`one_core`: {one['frames']} frames on one core",
                    ms_per_frame=allc["ms_per_frame"], instance_ms_per_call=allc["instance_ms_per_call"], one_core=one)
         del cpu_map

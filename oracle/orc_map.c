@@ -19,6 +19,7 @@
 #include "orc_internal.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <omp.h>
 
 /* ------------------------------------------------------------------ shared GLSL helpers */
 
@@ -263,6 +264,35 @@ static void init_first_frame(orc_t* o)
     o->n = n;
 }
 
+/* ------------------------------------------------------------------ parallel z-buffers that keep the draw order
+ * Every render of the map is "nearest z wins, on equal z the surfel drawn first (lowest index)" (GL_LESS + draw order).  The sequential loops
+ * of round 2 got that from `z < zbuf` over i = 0, 1, ...; here thread t draws the contiguous index range [t n / T, (t + 1) n / T) into a z-buffer of its own
+ * (depth + index per pixel), and the buffers are merged per pixel in thread order with the same strict `<` -- lower threads hold lower indices, so the winner is
+ * the one the sequential loop picks, for any number of threads.  The winner's outputs are then written by a per-pixel resolve. */
+typedef struct { int T; size_t P; float* z; int* id; } zbufs_t;
+static zbufs_t zb_open(size_t P)
+{
+    zbufs_t b;
+    b.T = omp_get_max_threads(); b.P = P;
+    b.z = (float*)malloc((size_t)b.T * P * sizeof(float));
+    b.id = (int*)malloc((size_t)b.T * P * sizeof(int));
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < (long)((size_t)b.T * P); k++) { b.z[k] = INFINITY; b.id[k] = -1; }
+    return b;
+}
+/* merged winner per pixel -> z_out / id_out (-1: nothing drawn) */
+static void zb_merge(zbufs_t* b, float* z_out, int* id_out)
+{
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < (long)b->P; k++) {
+        float z = INFINITY; int id = -1;
+        for (int t = 0; t < b->T; t++) { const float zt = b->z[(size_t)t * b->P + k]; if (zt < z) { z = zt; id = b->id[(size_t)t * b->P + k]; } }
+        z_out[k] = z; id_out[k] = id;
+    }
+    free(b->z); free(b->id);
+}
+static inline void zb_range(long n, int T, int t, long* lo, long* hi) { *lo = n * t / T; *hi = n * (t + 1) / T; }
+
 /* ------------------------------------------------------------------ index map (a10)
  * index_map.vert:40-66 / index_map.frag:33-40 under GL_LESS. */
 void orc_predict_indices(orc_t* o, const float* pose, int time)
@@ -272,30 +302,37 @@ void orc_predict_indices(orc_t* o, const float* pose, int time)
     orc_pose_inverse(pose, tinv);
     float cx = o->cfg.cx, cy = o->cfg.cy, fx = o->cfg.fx, fy = o->cfg.fy;
     float maxDepth = o->cfg.max_depth_processed;
-    memset(o->index_id, 0, (size_t)o->P * 4);
-    memset(o->index_vc, 0, (size_t)o->P * 16);
-    memset(o->index_ct, 0, (size_t)o->P * 16);
-    memset(o->index_nr, 0, (size_t)o->P * 16);
-    for (int i = 0; i < o->P; i++) o->index_z[i] = INFINITY;
-    for (int i = 0; i < o->n; i++) {
-        v3 p = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
-        if (p.z > maxDepth || p.z < 0 || (float)time - o->tm[i * 2 + 1] > (float)o->cfg.time_delta) continue;
-        float u = ((fx * p.x) / p.z) + cx, v = ((fy * p.y) / p.z) + cy;
-        if (!(u >= 0 && u < (float)w && v >= 0 && v < (float)h)) continue;
-        int px = (int)floorf(u), py = (int)floorf(v);
-        int k = py * w + px;
-        if (p.z < o->index_z[k]) {
-            o->index_z[k] = p.z;
-            o->index_id[k] = (uint32_t)i;
-            float* vc = &o->index_vc[k * 4];
-            vc[0] = p.x; vc[1] = p.y; vc[2] = p.z; vc[3] = o->pc[i * 4 + 3];
-            float* ct = &o->index_ct[k * 4];
-            ct[0] = o->col[i * 2]; ct[1] = o->col[i * 2 + 1]; ct[2] = o->tm[i * 2]; ct[3] = o->tm[i * 2 + 1];
-            v3 nn = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
-            float* nr = &o->index_nr[k * 4];
-            nr[0] = nn.x; nr[1] = nn.y; nr[2] = nn.z; nr[3] = o->nr[i * 4 + 3];
+    zbufs_t zb = zb_open((size_t)o->P);
+#pragma omp parallel num_threads(zb.T)
+    {
+        const int t = omp_get_thread_num();
+        long lo, hi;
+        zb_range(o->n, zb.T, t, &lo, &hi);
+        float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
+        for (long i = lo; i < hi; i++) {
+            v3 p = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
+            if (p.z > maxDepth || p.z < 0 || (float)time - o->tm[i * 2 + 1] > (float)o->cfg.time_delta) continue;
+            float u = ((fx * p.x) / p.z) + cx, v = ((fy * p.y) / p.z) + cy;
+            if (!(u >= 0 && u < (float)w && v >= 0 && v < (float)h)) continue;
+            int k = (int)floorf(v) * w + (int)floorf(u);
+            if (p.z < tz[k]) { tz[k] = p.z; ti[k] = (int)i; }
         }
     }
+    int* win = (int*)malloc((size_t)o->P * sizeof(int));
+    zb_merge(&zb, o->index_z, win);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < o->P; k++) {
+        float* vc = &o->index_vc[k * 4]; float* ct = &o->index_ct[k * 4]; float* nr = &o->index_nr[k * 4];
+        const int i = win[k];
+        if (i < 0) { o->index_id[k] = 0; for (int c = 0; c < 4; c++) { vc[c] = 0; ct[c] = 0; nr[c] = 0; } continue; }
+        v3 p = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
+        o->index_id[k] = (uint32_t)i;
+        vc[0] = p.x; vc[1] = p.y; vc[2] = p.z; vc[3] = o->pc[i * 4 + 3];
+        ct[0] = o->col[i * 2]; ct[1] = o->col[i * 2 + 1]; ct[2] = o->tm[i * 2]; ct[3] = o->tm[i * 2 + 1];
+        v3 nn = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
+        nr[0] = nn.x; nr[1] = nn.y; nr[2] = nn.z; nr[3] = o->nr[i * 4 + 3];
+    }
+    free(win);
 }
 
 /* ------------------------------------------------------------------ disc rasteriser
@@ -341,52 +378,65 @@ void orc_combined_predict(orc_t* o, const float* pose, int time, int max_time)
     orc_pose_inverse(pose, tinv);
     float cx = o->cfg.cx, cy = o->cfg.cy, fx = o->cfg.fx, fy = o->cfg.fy;
     float maxDepth = o->cfg.max_depth_processed, thr = o->cfg.confidence;
-    memset(o->pred_vertex, 0, (size_t)o->P * 16);
-    memset(o->pred_normal, 0, (size_t)o->P * 16);
-    memset(o->pred_image, 0, (size_t)o->P * 4);
-    memset(o->pred_inst, 0, (size_t)o->P * 4);
-    memset(o->pred_time, 0, (size_t)o->P * 2);
-    for (int i = 0; i < o->P; i++) o->zbuf[i] = INFINITY;
-    for (int i = 0; i < o->n; i++) {
-        v3 q = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
-        float conf = o->pc[i * 4 + 3], lastT = o->tm[i * 2 + 1];
-        if (q.z > maxDepth || q.z < 0 || conf < thr || (float)time - lastT > (float)o->cfg.time_delta || lastT > (float)max_time) continue;
-        float u = ((fx * q.x) / q.z) + cx, v = ((fy * q.y) / q.z) + cy;
-        if (!(u >= 0 && u <= (float)w && v >= 0 && v <= (float)h)) continue; /* GL clips points by centre */
-        v3 n = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
-        float r = o->nr[i * 4 + 3];
-        float xs[2], ys[2], minz;
-        disc_extent(q, n, r, cx, cy, fx, fy, xs, ys, &minz);
-        float s = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
-        if (!(s == s)) continue;
-        s = fminf(fmaxf(s, 1.0f), ORC_MAX_SPRITE);
-        int x0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, w - 1), x1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, w - 1);
-        int y0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, h - 1), y1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, h - 1);
-        disc_t d = {q, n, r * r};
-        for (int py = y0; py <= y1; py++)
-            for (int px = x0; px <= x1; px++) {
-                float z;
-                float fpx = (float)px + 0.5f, fpy = (float)py + 0.5f;
-                if (!disc_hit(&d, fpx, fpy, cx, cy, fx, fy, &z)) continue;
-                if (!(z >= -maxDepth && z <= maxDepth)) continue; /* gl_FragDepth in [0,1] */
-                int k = py * w + px;
-                if (z < o->zbuf[k]) {
-                    o->zbuf[k] = z;
-                    float* vo = &o->pred_vertex[k * 4];
-                    vo[0] = (fpx - cx) * z * (1.f / fx); vo[1] = (fpy - cy) * z * (1.f / fy); vo[2] = z; vo[3] = conf;
-                    float* no = &o->pred_normal[k * 4];
-                    no[0] = n.x; no[1] = n.y; no[2] = n.z; no[3] = r;
-                    float c3[3];
-                    orc_decode_color(o->col[i * 2], c3);
-                    for (int c = 0; c < 3; c++) o->pred_image[k * 4 + c] = (uint8_t)(int)roundf(c3[c] * 255.0f);
-                    o->pred_image[k * 4 + 3] = 255;
-                    orc_decode_color(o->col[i * 2 + 1], c3);
-                    for (int c = 0; c < 3; c++) o->pred_inst[k * 4 + c] = (uint8_t)(int)roundf(c3[c] * 255.0f);
-                    o->pred_inst[k * 4 + 3] = 255;
-                    o->pred_time[k] = (uint16_t)(uint32_t)o->tm[i * 2];
+    zbufs_t zb = zb_open((size_t)o->P);
+#pragma omp parallel num_threads(zb.T)
+    {
+        const int t = omp_get_thread_num();
+        long lo, hi;
+        zb_range(o->n, zb.T, t, &lo, &hi);
+        float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
+        for (long i = lo; i < hi; i++) {
+            v3 q = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
+            float conf = o->pc[i * 4 + 3], lastT = o->tm[i * 2 + 1];
+            if (q.z > maxDepth || q.z < 0 || conf < thr || (float)time - lastT > (float)o->cfg.time_delta || lastT > (float)max_time) continue;
+            float u = ((fx * q.x) / q.z) + cx, v = ((fy * q.y) / q.z) + cy;
+            if (!(u >= 0 && u <= (float)w && v >= 0 && v <= (float)h)) continue; /* GL clips points by centre */
+            v3 n = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
+            float r = o->nr[i * 4 + 3];
+            float xs[2], ys[2], minz;
+            disc_extent(q, n, r, cx, cy, fx, fy, xs, ys, &minz);
+            float s = fmaxf(fabsf(xs[1] - xs[0]), fabsf(ys[1] - ys[0]));
+            if (!(s == s)) continue;
+            s = fminf(fmaxf(s, 1.0f), ORC_MAX_SPRITE);
+            int x0 = clampi((int)ceilf(u - s * 0.5f - 0.5f), 0, w - 1), x1 = clampi((int)floorf(u + s * 0.5f - 0.5f), 0, w - 1);
+            int y0 = clampi((int)ceilf(v - s * 0.5f - 0.5f), 0, h - 1), y1 = clampi((int)floorf(v + s * 0.5f - 0.5f), 0, h - 1);
+            disc_t d = {q, n, r * r};
+            for (int py = y0; py <= y1; py++)
+                for (int px = x0; px <= x1; px++) {
+                    float z;
+                    if (!disc_hit(&d, (float)px + 0.5f, (float)py + 0.5f, cx, cy, fx, fy, &z)) continue;
+                    if (!(z >= -maxDepth && z <= maxDepth)) continue; /* gl_FragDepth in [0,1] */
+                    int k = py * w + px;
+                    if (z < tz[k]) { tz[k] = z; ti[k] = (int)i; }
                 }
-            }
+        }
     }
+    int* win = (int*)malloc((size_t)o->P * sizeof(int));
+    zb_merge(&zb, o->zbuf, win);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < o->P; k++) {
+        float* vo = &o->pred_vertex[k * 4]; float* no = &o->pred_normal[k * 4];
+        const int i = win[k];
+        if (i < 0) {
+            for (int c = 0; c < 4; c++) { vo[c] = 0; no[c] = 0; o->pred_image[k * 4 + c] = 0; o->pred_inst[k * 4 + c] = 0; }
+            o->pred_time[k] = 0;
+            continue;
+        }
+        const int px = k % w, py = k / w;
+        const float z = o->zbuf[k], fpx = (float)px + 0.5f, fpy = (float)py + 0.5f;
+        v3 n = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
+        vo[0] = (fpx - cx) * z * (1.f / fx); vo[1] = (fpy - cy) * z * (1.f / fy); vo[2] = z; vo[3] = o->pc[i * 4 + 3];
+        no[0] = n.x; no[1] = n.y; no[2] = n.z; no[3] = o->nr[i * 4 + 3];
+        float c3[3];
+        orc_decode_color(o->col[i * 2], c3);
+        for (int c = 0; c < 3; c++) o->pred_image[k * 4 + c] = (uint8_t)(int)roundf(c3[c] * 255.0f);
+        o->pred_image[k * 4 + 3] = 255;
+        orc_decode_color(o->col[i * 2 + 1], c3);
+        for (int c = 0; c < 3; c++) o->pred_inst[k * 4 + c] = (uint8_t)(int)roundf(c3[c] * 255.0f);
+        o->pred_inst[k * 4 + 3] = 255;
+        o->pred_time[k] = (uint16_t)(uint32_t)o->tm[i * 2];
+    }
+    free(win);
 }
 
 /* ------------------------------------------------------------------ fill-in
@@ -567,20 +617,28 @@ void orc_fuse(orc_t* o, const float* pose, int time, float weighting)
     o->n_new = 0;
     o->n_upd = 0;
     uint8_t* touched = (uint8_t*)calloc((size_t)o->n + 1, 1);
-    for (int i = 0; i < w; i++)
-        for (int j = 0; j < h; j++) {
-            meas_t m;
-            associate_pixel(o, pose, time, weighting, i, j, &m);
-            if (m.kind == 1) {
+    /* the association of a pixel reads the frame and the index map only: all pixels in parallel (the active ones: one in four), then the scan in column-major
+     * order that decides who owns an update texel and in which order the new surfels are appended */
+    const int par = time % 2, aw = (w - par + 1) / 2, ah = (h - par + 1) / 2;
+    meas_t* all = (meas_t*)malloc((size_t)aw * ah * sizeof(meas_t));
+#pragma omp parallel for schedule(static)
+    for (int ai = 0; ai < aw; ai++)
+        for (int aj = 0; aj < ah; aj++) associate_pixel(o, pose, time, weighting, 2 * ai + par, 2 * aj + par, &all[(size_t)ai * ah + aj]);
+    for (int ai = 0; ai < aw; ai++)
+        for (int aj = 0; aj < ah; aj++) {
+            const meas_t* m = &all[(size_t)ai * ah + aj];
+            if (m->kind == 1) {
                 /* every update point is drawn at z = 0 under GL_LESS: the first
                  * pixel in column-major order that targets a surfel owns its update texel */
-                if (m.target < (uint32_t)o->n && !touched[m.target]) {
-                    touched[m.target] = 1;
-                    o->updbuf[o->n_upd++] = m;
+                if (m->target < (uint32_t)o->n && !touched[m->target]) {
+                    touched[m->target] = 1;
+                    o->updbuf[o->n_upd++] = *m;
                 }
-            } else if (m.kind == 2) o->newbuf[o->n_new++] = m;
+            } else if (m->kind == 2) o->newbuf[o->n_new++] = *m;
         }
-    /* each update reads only its own surfel, so applying after the scan equals update.vert */
+    free(all);
+    /* each update reads and writes only its own surfel (one update per surfel), so applying after the scan, in any order, equals update.vert */
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < o->n_upd; k++) apply_update(o, o->updbuf[k].target, &o->updbuf[k], time);
     free(touched);
 }
@@ -608,10 +666,18 @@ void orc_clean(orc_t* o, const float* pose, int time)
         for (int k = 0; k < o->P; k++) d[k] = o->old_vertex[(size_t)k * 4 + 2];
         depth = d;
     }
+    /* the stability test of a surfel reads its own record and the index map only: all surfels in parallel, then the order-preserving compaction */
+    uint8_t* keepf = (uint8_t*)malloc((size_t)o->n + 1);
+    float* lastTs = (float*)malloc(((size_t)o->n + 1) * sizeof(float));
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < o->n; i++) {
-        float lastT = o->tm[i * 2 + 1];
-        int keep = clean_test(o, tinv, time, &o->pc[i * 4], &o->nr[i * 4], o->tm[i * 2], &lastT);
-        if (!keep) continue;
+        float lt = o->tm[i * 2 + 1];
+        keepf[i] = (uint8_t)clean_test(o, tinv, time, &o->pc[i * 4], &o->nr[i * 4], o->tm[i * 2], &lt);
+        lastTs[i] = lt;
+    }
+    for (int i = 0; i < o->n; i++) {
+        float lastT = lastTs[i];
+        if (!keepf[i]) continue;
         if (o->graph_nodes > 0 && o->tm[i * 2] != (float)time)   /* copy_unstable.vert:178-181: survivors not created this frame */
             orc_deform_surfel(o->graph, o->graph_nodes, &o->pc[i * 4], &o->nr[i * 4], o->tm[i * 2], &lastT, time, o->cfg.confidence, o->graph_is_fern, tinv, depth,
                               o->w, o->h, o->cfg.cx, o->cfg.cy, o->cfg.fx, o->cfg.fy, o->cfg.max_depth_processed);
@@ -626,6 +692,7 @@ void orc_clean(orc_t* o, const float* pose, int time)
         o->tm[m * 2 + 1] = lastT;
         m++;
     }
+    free(keepf); free(lastTs);
     for (int k = 0; k < o->n_new && m < o->cap; k++) {
         const orc_meas* s = &o->newbuf[k];
         float lastT = -2;
@@ -654,37 +721,47 @@ void orc_render_ids(orc_t* o, const float* pose, int mode)
     orc_pose_inverse(pose, tinv);
     float cx = o->cfg.cx, cy = o->cfg.cy, fx = o->cfg.fx, fy = o->cfg.fy;
     float maxDepth = o->cfg.max_depth_processed, thr = o->cfg.confidence;
-    memset(o->ids_tmp, 0, (size_t)o->P * 4);
-    for (int i = 0; i < o->P; i++) o->zbuf[i] = INFINITY;
-    for (int i = 0; i < o->n; i++) {
-        if (!(o->pc[i * 4 + 3] > thr)) continue;
-        if (mode == 1) {
-            const float* v = &o->votes[(size_t)i * ORC_VOTE_FLOATS];
-            int alleq = 1;
-            for (int k = 4; k < ORC_VOTE_FLOATS; k++) if (v[k] != v[k & 3]) { alleq = 0; break; }
-            if (alleq) continue;
-        }
-        v3 q = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
-        if (!(q.z / maxDepth > 0.01f)) continue;
-        v3 n = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
-        float r = o->nr[i * 4 + 3];
-        float xs[2], ys[2], minz;
-        disc_extent(q, n, r, cx, cy, fx, fy, xs, ys, &minz);
-        if (!(minz > 0) || !(xs[0] == xs[0]) || !(ys[0] == ys[0])) continue;
-        if (xs[1] - xs[0] > ORC_MAX_SPRITE || ys[1] - ys[0] > ORC_MAX_SPRITE) continue;
-        if (xs[1] < 0 || ys[1] < 0 || xs[0] > (float)w || ys[0] > (float)h) continue;
-        int x0 = clampi((int)ceilf(xs[0] - 0.5f), 0, w - 1), x1 = clampi((int)floorf(xs[1] - 0.5f), 0, w - 1);
-        int y0 = clampi((int)ceilf(ys[0] - 0.5f), 0, h - 1), y1 = clampi((int)floorf(ys[1] - 0.5f), 0, h - 1);
-        disc_t d = {q, n, r * r};
-        for (int py = y0; py <= y1; py++)
-            for (int px = x0; px <= x1; px++) {
-                float z;
-                if (!disc_hit(&d, (float)px + 0.5f, (float)py + 0.5f, cx, cy, fx, fy, &z)) continue;
-                if (!(z > 0 && z <= maxDepth)) continue;
-                int k = py * w + px;
-                if (z < o->zbuf[k]) { o->zbuf[k] = z; o->ids_tmp[k] = i; }
+    zbufs_t zb = zb_open((size_t)o->P);
+#pragma omp parallel num_threads(zb.T)
+    {
+        const int t = omp_get_thread_num();
+        long lo, hi;
+        zb_range(o->n, zb.T, t, &lo, &hi);
+        float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
+        for (long i = lo; i < hi; i++) {
+            if (!(o->pc[i * 4 + 3] > thr)) continue;
+            if (mode == 1) {
+                const float* v = &o->votes[(size_t)i * ORC_VOTE_FLOATS];
+                int alleq = 1;
+                for (int k = 4; k < ORC_VOTE_FLOATS; k++) if (v[k] != v[k & 3]) { alleq = 0; break; }
+                if (alleq) continue;
             }
+            v3 q = xf_point(tinv, v3m(o->pc[i * 4], o->pc[i * 4 + 1], o->pc[i * 4 + 2]));
+            if (!(q.z / maxDepth > 0.01f)) continue;
+            v3 n = v3normalized(xf_dir(tinv, v3m(o->nr[i * 4], o->nr[i * 4 + 1], o->nr[i * 4 + 2])));
+            float r = o->nr[i * 4 + 3];
+            float xs[2], ys[2], minz;
+            disc_extent(q, n, r, cx, cy, fx, fy, xs, ys, &minz);
+            if (!(minz > 0) || !(xs[0] == xs[0]) || !(ys[0] == ys[0])) continue;
+            if (xs[1] - xs[0] > ORC_MAX_SPRITE || ys[1] - ys[0] > ORC_MAX_SPRITE) continue;
+            if (xs[1] < 0 || ys[1] < 0 || xs[0] > (float)w || ys[0] > (float)h) continue;
+            int x0 = clampi((int)ceilf(xs[0] - 0.5f), 0, w - 1), x1 = clampi((int)floorf(xs[1] - 0.5f), 0, w - 1);
+            int y0 = clampi((int)ceilf(ys[0] - 0.5f), 0, h - 1), y1 = clampi((int)floorf(ys[1] - 0.5f), 0, h - 1);
+            disc_t d = {q, n, r * r};
+            for (int py = y0; py <= y1; py++)
+                for (int px = x0; px <= x1; px++) {
+                    float z;
+                    if (!disc_hit(&d, (float)px + 0.5f, (float)py + 0.5f, cx, cy, fx, fy, &z)) continue;
+                    if (!(z > 0 && z <= maxDepth)) continue;
+                    int k = py * w + px;
+                    if (z < tz[k]) { tz[k] = z; ti[k] = (int)i; }
+                }
+        }
     }
+    int* win = (int*)malloc((size_t)o->P * sizeof(int));
+    zb_merge(&zb, o->zbuf, win);
+    for (int k = 0; k < o->P; k++) o->ids_tmp[k] = win[k] < 0 ? 0 : win[k];
+    free(win);
 }
 
 /* rodrigues2, EF/ElasticFusion.cpp:1183-1228.  The SVD re-orthonormalisation of the (already

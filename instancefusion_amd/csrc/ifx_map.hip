@@ -2304,7 +2304,8 @@ int ifx_map_predict_loop_closure(ifx* h)
 // ElasticFusion::predict, EF/ElasticFusion.cpp:729-763, fused with renderSurfelIds(GENERAL_AFTER) of :694
 int ifx_map_predict(ifx* h)
 {
-    const unsigned int want = LIST_SPLAT | (h->ids_pending ? LIST_IDS : 0u);
+    static const bool no_ids = getenv("IFX_EXPERIMENT_NO_IDS") != nullptr;   // measurement only: what the per-frame id render costs (the id image is then stale)
+    const unsigned int want = LIST_SPLAT | ((h->ids_pending && !no_ids) ? LIST_IDS : 0u);
     // the tiled rasteriser only on request: at 1280x960 / 20 M surfels the view-list rasteriser takes 455 us where cull + bin + tile raster take 744 (profiles/r02_o_1280_20m.txt)
     const bool tiles = h->opt_raster_tiles > 0;
     if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since

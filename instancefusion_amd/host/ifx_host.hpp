@@ -590,7 +590,6 @@ private:
     }
     ifx_config cfg_;
     ifx_t* h_ = nullptr;
-    Sharding sharding_;
 public:
     const Sharding& sharding() const { return sharding_; }
 private:
@@ -603,6 +602,7 @@ private:
     bool closeLoops_, iclnuim_, reloc_, frameToFrameRGB_;
     int countThresh_;
     float errThresh_, covThresh_, photoThresh_, fernThresh_;
+    Sharding sharding_;
     std::vector<Matrix4f> poseGraph_;
     std::vector<int64_t> poseLogTimes_;
 };

@@ -380,8 +380,8 @@ def test_segmentation_device_schedule_equals_host_schedule(ifx, small_stream, ff
     masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
     nm = masks.shape[0]
     evicted = False
-    for call in range(40):
-        classes = (1 + (call * nm + np.arange(nm)) % 79).astype(np.int32)
+    for call in range(60):
+        classes = (1000 + call * nm + np.arange(nm)).astype(np.int32)     # never seen before: every usable mask takes a new slot until the table is full
         before = (ib.getInstanceTable() >= 0).sum()
         ia.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, classes, 300 + 3 * call)
         ib.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, classes, 300 + 3 * call)

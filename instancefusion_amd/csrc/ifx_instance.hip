@@ -476,66 +476,82 @@ __global__ void k_ff_init(FFArgs a)
 
 // `it`: index of this launch in a fixed schedule.  A launch whose predecessor changed nothing has nothing to do either (that predecessor re-checked every edge:
 // the fixpoint) and returns at its first instruction, leaving its own flag clear -- so the host can enqueue the whole schedule without looking.
-__global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
+//
+// Inside a tile the relaxation runs as SWEEPS (round 3): a thread owns a row (then a column) of the 34 x 34 window and carries the minimum along it in one
+// sequential pass -- left to right, right to left, top to bottom, bottom to top, halo cells as sources -- so a label crosses the whole tile in one pass instead of
+// one pixel per barrier-separated iteration (the first version: up to 128 iterations of a 256-thread block, 140 us for the first launch of a call; now a handful of
+// rounds of four passes on one wave).  Same fixpoint: min-propagation along the same directed edges (the threshold is the SOURCE pixel's), in another order.
+__device__ __forceinline__ bool ff_pull(int& l, int dp_unused, int ql, int dq, int dp)
 {
-    __shared__ int s_lab[FF_T + 2][FF_T + 2];
-    __shared__ unsigned short s_d[FF_T + 2][FF_T + 2];
+    (void)dp_unused;
+    if (ql < 0 || ql >= l) return false;
+    if ((float)abs(dq - dp) < depth_threshold_dev(dq)) { l = ql; return true; }   // edge q -> p, threshold of the source q
+    return false;
+}
+__global__ void __launch_bounds__(64) k_ff_relax(FFArgs a, int it)
+{
+    __shared__ int s_lab[FF_T + 2][FF_T + 3];          // (+1 column: rows and columns land on different banks)
+    __shared__ unsigned short s_d[FF_T + 2][FF_T + 4];
     if (it > 0 && a.changed[it - 1] == 0) return;
     const int P = a.w * a.h, m = blockIdx.z;
     if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
     const int x0 = blockIdx.x * FF_T - 1, y0 = blockIdx.y * FF_T - 1, tid = threadIdx.x;
-    for (int t = tid; t < (FF_T + 2) * (FF_T + 2); t += 256) {
-        int ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2), x = x0 + lx, y = y0 + ly;
-        bool in = x >= 0 && x < a.w && y >= 0 && y < a.h;
-        s_lab[ly][lx] = in ? lab[y * a.w + x] : -1;
+    for (int t = tid; t < (FF_T + 2) * (FF_T + 2); t += 64) {
+        const int ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2), x = x0 + lx, y = y0 + ly;
+        const bool in = x >= 0 && x < a.w && y >= 0 && y < a.h;
+        int l = in ? lab[y * a.w + x] : -1;
+        const bool interior = lx >= 1 && lx <= FF_T && ly >= 1 && ly <= FF_T;
+        if (interior && l >= 0) { const int g = lab[l]; if (g >= 0 && g < l) l = g; }   // one pointer jump for the pixels of this tile: my label reaches me, so does ITS label
+        s_lab[ly][lx] = l;
         s_d[ly][lx] = in ? a.depth[y * a.w + x] : 0;
     }
     __syncthreads();
-    // one pointer jump for the pixels of this tile: the label is a pixel that reaches me, so does ITS label
-    int mine[4], orig[4];
-    const int lx1 = (tid & 31) + 1;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int ly1 = (tid >> 5) * 4 + u + 1;
-        int l = s_lab[ly1][lx1];
-        orig[u] = l;
-        if (l >= 0) { int g = lab[l]; if (g >= 0 && g < l) l = g; }
-        mine[u] = l;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) s_lab[(tid >> 5) * 4 + u + 1][lx1] = mine[u];
-    __syncthreads();
-    for (int it = 0; it < 4 * FF_T; it++) {
+    const int line = (tid & 31) + 1;   // the row / column of this thread: 1 .. FF_T (lanes 32..63 idle in the sweeps; they help with the loads and stores)
+    for (int round = 0; round < 4 * FF_T; round++) {
         int any = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int ly1 = (tid >> 5) * 4 + u + 1;
-            int l = s_lab[ly1][lx1];
-            if (l < 0) continue;
-            const int dp = s_d[ly1][lx1];
-            int best = l;
-            const int nx[4] = {lx1, lx1, lx1 + 1, lx1 - 1}, ny[4] = {ly1 + 1, ly1 - 1, ly1, ly1};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int ql = s_lab[ny[e]][nx[e]];
-                if (ql < 0 || ql >= best) continue;
-                const int dq = s_d[ny[e]][nx[e]];
-                if ((float)abs(dq - dp) < depth_threshold_dev(dq)) best = ql;   // edge q -> p, threshold of the source q
+        if (tid < 32) {   // rows, left to right then right to left
+            int pl = s_lab[line][0], pd = s_d[line][0];
+            for (int x = 1; x <= FF_T; x++) {
+                int l = s_lab[line][x];
+                const int dp = s_d[line][x];
+                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[line][x] = l; any = 1; }
+                pl = l; pd = dp;
             }
-            if (best < l) { mine[u] = best; any = 1; }
+            pl = s_lab[line][FF_T + 1]; pd = s_d[line][FF_T + 1];
+            for (int x = FF_T; x >= 1; x--) {
+                int l = s_lab[line][x];
+                const int dp = s_d[line][x];
+                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[line][x] = l; any = 1; }
+                pl = l; pd = dp;
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; u++) s_lab[(tid >> 5) * 4 + u + 1][lx1] = mine[u];
+        if (tid < 32) {   // columns, top to bottom then bottom to top
+            int pl = s_lab[0][line], pd = s_d[0][line];
+            for (int y = 1; y <= FF_T; y++) {
+                int l = s_lab[y][line];
+                const int dp = s_d[y][line];
+                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[y][line] = l; any = 1; }
+                pl = l; pd = dp;
+            }
+            pl = s_lab[FF_T + 1][line]; pd = s_d[FF_T + 1][line];
+            for (int y = FF_T; y >= 1; y--) {
+                int l = s_lab[y][line];
+                const int dp = s_d[y][line];
+                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[y][line] = l; any = 1; }
+                pl = l; pd = dp;
+            }
+        }
         if (!__syncthreads_or(any)) break;
     }
     int dirty = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int x = x0 + lx1, y = y0 + (tid >> 5) * 4 + u + 1;
-        if (x < a.w && y < a.h && mine[u] != orig[u]) { lab[y * a.w + x] = mine[u]; dirty = 1; }
+    for (int t = tid; t < FF_T * FF_T; t += 64) {
+        const int ly = t / FF_T + 1, lx = t - (ly - 1) * FF_T + 1, x = x0 + lx, y = y0 + ly;
+        if (x < a.w && y < a.h) {
+            const int l = s_lab[ly][lx];
+            if (l >= 0 && l != lab[y * a.w + x]) { lab[y * a.w + x] = l; dirty = 1; }
+        }
     }
     if (__syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
 }
@@ -630,15 +646,15 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     }
     if (fixed_rounds > 0 && !resume) {
         if (fixed_rounds > FF_SLOTS) fixed_rounds = FF_SLOTS;
-        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, it);
+        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, it);
         a.gate = a.changed + (fixed_rounds - 1);
     } else {
         for (int round = 0; round < 64; round++) {
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, 0);
             // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, 0);
             int changed = 0;
             HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));

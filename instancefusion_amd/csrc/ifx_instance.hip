@@ -488,7 +488,7 @@ __device__ __forceinline__ bool ff_pull(int& l, int dp_unused, int ql, int dq, i
     if ((float)abs(dq - dp) < depth_threshold_dev(dq)) { l = ql; return true; }   // edge q -> p, threshold of the source q
     return false;
 }
-__global__ void __launch_bounds__(64) k_ff_relax(FFArgs a, int it)
+__global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 {
     __shared__ int s_lab[FF_T + 2][FF_T + 3];          // (+1 column: rows and columns land on different banks)
     __shared__ unsigned short s_d[FF_T + 2][FF_T + 4];
@@ -497,56 +497,60 @@ __global__ void __launch_bounds__(64) k_ff_relax(FFArgs a, int it)
     if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
     const int x0 = blockIdx.x * FF_T - 1, y0 = blockIdx.y * FF_T - 1, tid = threadIdx.x;
-    for (int t = tid; t < (FF_T + 2) * (FF_T + 2); t += 64) {
-        const int ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2), x = x0 + lx, y = y0 + ly;
-        const bool in = x >= 0 && x < a.w && y >= 0 && y < a.h;
-        int l = in ? lab[y * a.w + x] : -1;
-        const bool interior = lx >= 1 && lx <= FF_T && ly >= 1 && ly <= FF_T;
-        if (interior && l >= 0) { const int g = lab[l]; if (g >= 0 && g < l) l = g; }   // one pointer jump for the pixels of this tile: my label reaches me, so does ITS label
-        s_lab[ly][lx] = l;
-        s_d[ly][lx] = in ? a.depth[y * a.w + x] : 0;
+    {   // the window: all loads of a thread in one batch, then the pointer jumps of the tile's own pixels in a second one (two round trips, not ten)
+        constexpr int NL = ((FF_T + 2) * (FF_T + 2) + 255) / 256;
+        int l[NL], d[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int t = tid + q * 256, ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2), x = x0 + lx, y = y0 + ly;
+            const bool in = t < (FF_T + 2) * (FF_T + 2) && x >= 0 && x < a.w && y >= 0 && y < a.h;
+            l[q] = in ? lab[y * a.w + x] : -1;
+            d[q] = in ? a.depth[y * a.w + x] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int t = tid + q * 256, ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2);
+            const bool interior = lx >= 1 && lx <= FF_T && ly >= 1 && ly <= FF_T;
+            const int g = (interior && l[q] >= 0) ? lab[l[q]] : -1;   // one pointer jump: my label reaches me, so does ITS label
+            if (g >= 0 && g < l[q]) l[q] = g;
+        }
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int t = tid + q * 256, ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2);
+            if (t < (FF_T + 2) * (FF_T + 2)) { s_lab[ly][lx] = l[q]; s_d[ly][lx] = (unsigned short)d[q]; }
+        }
     }
     __syncthreads();
-    const int line = (tid & 31) + 1;   // the row / column of this thread: 1 .. FF_T (lanes 32..63 idle in the sweeps; they help with the loads and stores)
+    // A thread pulls its line into registers, sweeps it forth and back there (no LDS latency inside the dependent chain) and writes back what changed.
+    const int line = (tid & 31) + 1;   // the row / column of this thread: 1 .. FF_T (one half-wave sweeps; the whole block of 256 loads and stores)
     for (int round = 0; round < 4 * FF_T; round++) {
         int any = 0;
-        if (tid < 32) {   // rows, left to right then right to left
-            int pl = s_lab[line][0], pd = s_d[line][0];
-            for (int x = 1; x <= FF_T; x++) {
-                int l = s_lab[line][x];
-                const int dp = s_d[line][x];
-                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[line][x] = l; any = 1; }
-                pl = l; pd = dp;
+#pragma unroll 1
+        for (int dir = 0; dir < 2; dir++) {   // 0: rows, 1: columns
+            if (tid < 32) {
+                int l[FF_T + 2], d[FF_T + 2];
+#pragma unroll
+                for (int x = 0; x < FF_T + 2; x++) { l[x] = dir ? s_lab[x][line] : s_lab[line][x]; d[x] = dir ? s_d[x][line] : s_d[line][x]; }
+                unsigned int ch = 0;
+#pragma unroll
+                for (int x = 1; x <= FF_T; x++)
+                    if (l[x] >= 0 && l[x - 1] >= 0 && l[x - 1] < l[x] && (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x - 1])) { l[x] = l[x - 1]; ch |= 1u << (x - 1); }
+#pragma unroll
+                for (int x = FF_T; x >= 1; x--)
+                    if (l[x] >= 0 && l[x + 1] >= 0 && l[x + 1] < l[x] && (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x + 1])) { l[x] = l[x + 1]; ch |= 1u << (x - 1); }
+                if (ch) {
+                    any = 1;
+#pragma unroll
+                    for (int x = 1; x <= FF_T; x++)
+                        if (ch & (1u << (x - 1))) { if (dir) s_lab[x][line] = l[x]; else s_lab[line][x] = l[x]; }
+                }
             }
-            pl = s_lab[line][FF_T + 1]; pd = s_d[line][FF_T + 1];
-            for (int x = FF_T; x >= 1; x--) {
-                int l = s_lab[line][x];
-                const int dp = s_d[line][x];
-                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[line][x] = l; any = 1; }
-                pl = l; pd = dp;
-            }
-        }
-        __syncthreads();
-        if (tid < 32) {   // columns, top to bottom then bottom to top
-            int pl = s_lab[0][line], pd = s_d[0][line];
-            for (int y = 1; y <= FF_T; y++) {
-                int l = s_lab[y][line];
-                const int dp = s_d[y][line];
-                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[y][line] = l; any = 1; }
-                pl = l; pd = dp;
-            }
-            pl = s_lab[FF_T + 1][line]; pd = s_d[FF_T + 1][line];
-            for (int y = FF_T; y >= 1; y--) {
-                int l = s_lab[y][line];
-                const int dp = s_d[y][line];
-                if (l >= 0 && ff_pull(l, 0, pl, pd, dp)) { s_lab[y][line] = l; any = 1; }
-                pl = l; pd = dp;
-            }
+            __syncthreads();
         }
         if (!__syncthreads_or(any)) break;
     }
     int dirty = 0;
-    for (int t = tid; t < FF_T * FF_T; t += 64) {
+    for (int t = tid; t < FF_T * FF_T; t += 256) {
         const int ly = t / FF_T + 1, lx = t - (ly - 1) * FF_T + 1, x = x0 + lx, y = y0 + ly;
         if (x < a.w && y < a.h) {
             const int l = s_lab[ly][lx];
@@ -646,15 +650,15 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     }
     if (fixed_rounds > 0 && !resume) {
         if (fixed_rounds > FF_SLOTS) fixed_rounds = FF_SLOTS;
-        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, it);
+        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, it);
         a.gate = a.changed + (fixed_rounds - 1);
     } else {
         for (int round = 0; round < 64; round++) {
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, 0);
+            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
             // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            LAUNCH(h, "ff_relax", tiles, dim3(64), k_ff_relax, a, 0);
+            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
             int changed = 0;
             HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1013,16 +1017,21 @@ struct SegCtl { int ff_incomplete, evict_at, nm, pad; int inst_class[NI]; int cl
 // computeCompareMap (IF/Core/InstanceFusion.cpp:595-651): one thread per mask; the LAST instance over the threshold wins, instance 0 never matches
 __global__ void k_seg_compare(SegCtl* __restrict__ s, const int* __restrict__ bbox, uint8_t* __restrict__ unavailable)
 {
+    __shared__ int s_cls[NI], s_box[NI * 4];
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) s_cls[t] = s->inst_class[t];
+    for (int t = threadIdx.x; t < NI * 4; t += blockDim.x) s_box[t] = bbox[t];
+    __syncthreads();
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= s->nm) return;
     const int* mb = bbox + (NI + m) * 4;
     const int minX_m = mb[0], maxX_m = mb[1], minY_m = mb[2], maxY_m = mb[3];
     s->target[m] = -1;
     if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) { unavailable[m] = 1; s->best[m] = -1; return; }
+    const int cls = s->cls[m];
     int best = -1;
     for (int q = 0; q < NI; q++) {
-        if (s->inst_class[q] == -1 || s->cls[m] != s->inst_class[q]) continue;
-        const int minX_i = bbox[q * 4], maxX_i = bbox[q * 4 + 1], minY_i = bbox[q * 4 + 2], maxY_i = bbox[q * 4 + 3];
+        if (s_cls[q] == -1 || cls != s_cls[q]) continue;
+        const int minX_i = s_box[q * 4], maxX_i = s_box[q * 4 + 1], minY_i = s_box[q * 4 + 2], maxY_i = s_box[q * 4 + 3];
         if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
         const float IW = (float)(min(maxX_i, maxX_m) - max(minX_i, minX_m));
         const float IH = (float)(min(maxY_i, maxY_m) - max(minY_i, minY_m));
@@ -1034,24 +1043,40 @@ __global__ void k_seg_compare(SegCtl* __restrict__ s, const int* __restrict__ bb
     s->best[m] = best > 0 ? best : -1;
 }
 // the registration decisions of the mask loop (:955-1010), sequential as in the reference: a mask without a match that is still usable takes the first free
-// slot of the table; when there is none the loop stops there (evict_at) and the host evicts (rare: 96 slots)
+// slot of the table; when there is none the loop stops there (evict_at) and the host evicts (rare: 96 slots).  The table and the per-mask inputs are staged in LDS
+// by the whole block; one lane then walks the masks.
 __global__ void k_seg_register(SegCtl* __restrict__ s, const uint8_t* __restrict__ unavailable, const int* __restrict__ ff_gate)
 {
-    if (threadIdx.x != 0) return;
-    s->evict_at = -1;
-    if (ff_gate && *ff_gate) { s->ff_incomplete = 1; return; }
-    s->ff_incomplete = 0;
-    for (int m = 0; m < s->nm; m++) {
-        int t = s->best[m];
-        if (t < 0 && !unavailable[m]) {
-            int empty = -1;
-            for (int i = 0; i < NI; i++) if (s->inst_class[i] == -1) { empty = i; break; }
-            if (empty == -1) { s->evict_at = m; return; }
-            s->inst_class[empty] = s->cls[m];
-            t = empty;
+    __shared__ int s_cls[NI], s_best[256], s_mcls[256], s_tgt[256];
+    __shared__ unsigned char s_un[256];
+    const int nm = s->nm;
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) s_cls[t] = s->inst_class[t];
+    for (int t = threadIdx.x; t < nm; t += blockDim.x) { s_best[t] = s->best[t]; s_mcls[t] = s->cls[t]; s_un[t] = unavailable[t]; s_tgt[t] = -1; }
+    const int gate = ff_gate ? *ff_gate : 0;
+    __syncthreads();
+    __shared__ int s_evict;
+    if (threadIdx.x == 0) {
+        s_evict = -1;
+        if (!gate) {
+            int next_free = 0;
+            for (int m = 0; m < nm; m++) {
+                int t = s_best[m];
+                if (t < 0 && !s_un[m]) {
+                    while (next_free < NI && s_cls[next_free] != -1) next_free++;   // the first free slot: slots only fill up during the loop, so the scan never goes back
+                    if (next_free >= NI) { s_evict = m; break; }
+                    s_cls[next_free] = s_mcls[m];
+                    t = next_free;
+                }
+                s_tgt[m] = t;
+            }
         }
-        s->target[m] = t;
+        s->evict_at = s_evict;
+        s->ff_incomplete = gate ? 1 : 0;
     }
+    __syncthreads();
+    if (gate) return;
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) s->inst_class[t] = s_cls[t];
+    for (int t = threadIdx.x; t < nm; t += blockDim.x) s->target[t] = s_tgt[t];
 }
 // updateSurfelMapInstance for mask m with the instance the device chose for it; a launch for a mask without one (or behind the point where the host takes over)
 // returns at its first instruction

@@ -514,7 +514,76 @@ __device__ __forceinline__ bool sp_edge_fails(const float* __restrict__ A, const
     const float test = dist_term + nor_term, limA = thrA + devA + zA, limB = thrB + devB + zB;
     return test > limA || test > limB;
 }
+// (first version: every round of the propagation re-read the lists from the table in global memory, 30-float records, one dependent load after the other:
+// 150 us for 1200 nodes.  The lists now live in LDS as ints for the whole kernel.)
 __global__ __launch_bounds__(1024) void k_sp_connect(int spn, float* __restrict__ info, int* __restrict__ final_of)
+{
+    extern __shared__ int sm[];
+    int* label = sm;                                   // [spn]
+    unsigned int* pass = (unsigned int*)(sm + spn);    // [spn] bit j: the directed test of entry j passed
+    int* nbr = sm + 2 * spn;                           // [spn][NB_MAX] the lists (-1: no entry / deleted)
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int t = tid; t < spn * NB_MAX; t += nt) {
+        const int a = t / NB_MAX, j = t - a * NB_MAX;
+        const float* A = info + (size_t)a * SPI_SIZE;
+        nbr[t] = j < (int)A[SPI_CONNECT_N] ? (int)A[SPI_NP_FIRST + j] : -1;
+    }
+    __syncthreads();
+    for (int a = tid; a < spn; a += nt) {
+        const float* A = info + (size_t)a * SPI_SIZE;
+        unsigned int m = 0;
+        for (int j = 0; j < NB_MAX; j++) {
+            const int b = nbr[a * NB_MAX + j];
+            if (b == -1) continue;
+            if (!sp_edge_fails(A, info + (size_t)b * SPI_SIZE)) m |= 1u << j;
+        }
+        pass[a] = m;
+        label[a] = a;
+    }
+    __syncthreads();
+    unsigned int my_alive[2] = {0u, 0u};               // spn <= 2 * 1024 (ifx_slic.hip sizes the grid of superpixels from the image; checked by the launcher)
+    for (int a = tid, q = 0; a < spn; a += nt, q++) {
+        unsigned int m = pass[a];
+        for (int j = 0; j < NB_MAX; j++) {
+            if (!(m & (1u << j))) continue;
+            const int b = nbr[a * NB_MAX + j];
+            for (int k = 0; k < NB_MAX; k++)
+                if (nbr[b * NB_MAX + k] == a) { if (!(pass[b] & (1u << k))) m &= ~(1u << j); break; }   // (the first entry equal to a, as the sequential deletion)
+        }
+        my_alive[q] = m;
+    }
+    __syncthreads();   // every original list has been read: the deletions may be written now
+    for (int a = tid, q = 0; a < spn; a += nt, q++) {
+        float* A = info + (size_t)a * SPI_SIZE;
+        const unsigned int m = my_alive[q];
+        for (int j = 0; j < NB_MAX; j++)
+            if (!(m & (1u << j)) && nbr[a * NB_MAX + j] != -1) { nbr[a * NB_MAX + j] = -1; A[SPI_NP_FIRST + j] = -1.f; }
+    }
+    __syncthreads();
+    for (int round = 0; round < 4 * 1024; round++) {   // (the fixpoint arrives within ~log(diameter) rounds; the bound only guards against a corrupt table)
+        int any = 0;
+        for (int a = tid; a < spn; a += nt) {
+            const int la = label[a];
+            for (int j = 0; j < NB_MAX; j++) {
+                const int b = nbr[a * NB_MAX + j];
+                if (b >= 0 && atomicMin(&label[b], la) > la) any = 1;
+            }
+        }
+        __syncthreads();
+        for (int a = tid; a < spn; a += nt) {           // pointer jump: my label's label reaches me too
+            const int l = label[a], g = label[l];
+            if (g < l) { atomicMin(&label[a], g); any = 1; }
+        }
+        if (!__syncthreads_or(any)) break;
+    }
+    for (int a = tid; a < spn; a += nt) {
+        info[(size_t)a * SPI_SIZE + SPI_FINAL] = (float)label[a];
+        final_of[a] = label[a];
+    }
+}
+
+// the same pass for images with more superpixels than the lists-in-LDS version holds (1280 x 960: 4800): labels and flags in LDS, the lists read from the table
+__global__ __launch_bounds__(1024) void k_sp_connect_big(int spn, float* __restrict__ info, int* __restrict__ final_of)
 {
     extern __shared__ int sm[];
     int* label = sm;                                   // [spn]
@@ -646,7 +715,10 @@ int merge_run(ifx* h, SlicBuf* b)
     LAUNCH(h, "sp_first_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_first_avg, b->sum1, b->adj, b->adj_words, S, b->info);
     LAUNCH(h, "sp_recluster", dim3(cdiv(w, 16), cdiv(hh, 16)), dim3(16, 16), k_sp_recluster, b->seg, b->dg, b->pos, b->nor, w, hh, b->info, b->sum2);
     LAUNCH(h, "sp_second_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_second_avg, b->sum2, S, b->info);
-    LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * 12, k_sp_connect, S, b->info, b->final_of);   // connectSuperPixel on the device: no read-back inside a call
+    // connectSuperPixel on the device: no read-back inside a call
+    if (S <= 1200) LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * (2 + NB_MAX) * 4, k_sp_connect, S, b->info, b->final_of);
+    else if (S <= 5000) LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * 12, k_sp_connect_big, S, b->info, b->final_of);
+    else { h->err = "too many superpixels for the one-block connect pass"; return IFX_E_INVALID; }
     LAUNCH(h, "sp_final", dim3(cdiv(P, 256)), dim3(256), k_sp_final, b->seg, b->final_of, b->fin, P);
     return IFX_OK;
 }

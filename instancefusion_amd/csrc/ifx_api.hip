@@ -261,6 +261,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "lazy_ids") { ifx_ids_ensure(h); h->opt_lazy_ids = value; }
     else if (s == "seg_device") h->opt_seg_device = value;
     else if (s == "ff_rounds") h->opt_ff_rounds = value;
     else if (s == "labels_incremental") { h->opt_labels_incremental = value; h->labels_stale_all = 1; }
@@ -557,10 +558,14 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
 #undef CAMCP
         return IFX_OK;
     };
+    ifx_ids_ensure(h);   // a parked id image is a whole one (the map moves on under the other cameras)
     int r = move(h->cams[(size_t)h->cur_cam], true);
     if (r) return r;
     h->cams[(size_t)h->cur_cam].valid = 1;
-    if (h->cams[(size_t)cam].valid) { r = move(h->cams[(size_t)cam], false); if (r) return r; }
+    if (h->cams[(size_t)cam].valid) {
+        r = move(h->cams[(size_t)cam], false);
+        if (r) return r;
+    }
     h->cur_cam = cam;
     h->seg_counts_valid = 0;
     return IFX_OK;
@@ -1147,7 +1152,12 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
     return IFX_OK;
 }
 
-extern "C" const int32_t* ifx_ids_after(ifx_t* h) { return h ? h->ids_after : nullptr; }
+extern "C" const int32_t* ifx_ids_after(ifx_t* h)
+{
+    if (!h) return nullptr;
+    ifx_ids_ensure(h);   // (enqueued on the handle's main stream, like the frame that precedes it)
+    return h->ids_after;
+}
 
 extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t max_bytes)
 {
@@ -1156,7 +1166,7 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     size_t P = (size_t)h->P, bytes = 0;
     const void* src = nullptr;
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
-    if (s == "ids_after") { src = h->ids_after; bytes = P * 4; }
+    if (s == "ids_after") { ifx_ids_ensure(h); src = h->ids_after; bytes = P * 4; }
     else if (s == "ids_tmp") { src = h->ids_tmp; bytes = P * 4; }
     else if (s == "index") { src = h->index_id; bytes = P * 4; }
     else if (s == "index_vc") { src = h->index_vc; bytes = P * 16; }

@@ -223,6 +223,8 @@ struct ifx {
     std::string err;
     int tick = 1;
     int ids_pending = 0;
+    int opt_lazy_ids = 1;               // the frame renders the id image on the lattice whetherDoSegmentation samples; the whole image on demand (ifx_ids_ensure)
+    int ids_full_valid = 1, ids_sparse_frame = 0;
     // options
     int opt_compact_every_frame = 0;
     int last_compact_tick = -1;
@@ -416,6 +418,7 @@ int ifx_housekeeping(ifx* h);                                  // tombstone comp
 int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
+int ifx_ids_ensure(ifx* h);                                   // the whole id image, if the last frame rendered only the sampled lattice
 int ifx_vlist_reap(ifx* h);                                   // forced view-list scan: applies the age rule to the slots outside the list (before any whole-map consumer)
 int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame);
 int ifx_map_predict_loop_closure(ifx* h);                     // predict() at the tracked pose + INACTIVE prediction (old* images)

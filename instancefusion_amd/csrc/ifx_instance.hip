@@ -953,6 +953,7 @@ static void seg_label_scan(ifx* h)
 
 static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
+    ifx_ids_ensure(h);   // the call reads the id image under every mask pixel
     // Only the kNN smoothing looks at surfels the id image does not show: a slot outside the cached view list that has outlived the age rule
     // (ifx_map.hip "View list") is unstable, so it was never in an id image, carries no votes and takes part in nothing else of this call.
     if (flags & 1) ifx_vlist_reap(h);
@@ -1129,6 +1130,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     else { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost)); }
     h->seg_counts_valid = 0;
     if (nm == 0 || n == 0) return IFX_OK;
+    ifx_ids_ensure(h);   // the call reads the id image under every mask pixel: the whole image, if the frame rendered only the sampled lattice
     const int P = h->P;
     const size_t mbytes = (size_t)nm * P;
     int r = ifx_ensure_masks(h, mbytes);
@@ -1292,6 +1294,7 @@ __global__ void k_render_project(const DevState* __restrict__ st, const int32_t*
 extern "C" int ifx_render_project_map(ifx_t* h, float* out_rgba, float* d_out_rgba)
 {
     if (!h || (!out_rgba && !d_out_rgba)) return IFX_E_INVALID;
+    ifx_ids_ensure(h);
     float* dst = d_out_rgba;
     if (!dst) {
         if (!h->d_project) HIPCHK(h, hipMalloc(&h->d_project, (size_t)h->P * 16));

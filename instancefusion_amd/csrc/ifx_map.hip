@@ -1453,7 +1453,7 @@ template <bool LDSMIN>
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
                                                              int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
-                                                             unsigned long long* __restrict__ key_both, int earlyz)
+                                                             unsigned long long* __restrict__ key_both, int earlyz, int ids_step)
 {
     __shared__ RvRec recs[MAP_THREADS / 64][64];
     __shared__ unsigned int s_tag[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
@@ -1497,7 +1497,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
                 SurfGeo G;
                 surfel_geo(T, p4, ld_once(&nr[i]), i | flags, c, G);
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
-                const bool do_s = G.do_s, do_i = surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
+                bool do_i = surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
+                const bool do_s = G.do_s;
+                int lattice = 0;
+                if (do_i && ids_step > 1) {   // sparse id render: only the pixels of the ids_step lattice (what whetherDoSegmentation samples); the full image is rendered on demand
+                    const int lx0 = ((ix0 + ids_step - 1) / ids_step) * ids_step, lx1 = (ix1 / ids_step) * ids_step;
+                    const int ly0 = ((iy0 + ids_step - 1) / ids_step) * ids_step, ly1 = (iy1 / ids_step) * ids_step;
+                    if (lx0 > lx1 || ly0 > ly1) do_i = false;
+                    else { ix0 = lx0; ix1 = lx1; iy0 = ly0; iy1 = ly1; lattice = !do_s; }   // an id-only entry walks the lattice points of its box, nothing else
+                }
                 if (do_s || do_i) {
                     // a render that does not draw this surfel gets an empty box (x1 < x0): no pixel passes its range test
                     if (!do_s) { sx0 = 1; sx1 = 0; sy0 = 1; sy1 = 0; }
@@ -1505,9 +1513,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
                     const int x0 = do_s && do_i ? min(sx0, ix0) : (do_s ? sx0 : ix0), x1 = do_s && do_i ? max(sx1, ix1) : (do_s ? sx1 : ix1);
                     const int y0 = do_s && do_i ? min(sy0, iy0) : (do_s ? sy0 : iy0), y1 = do_s && do_i ? max(sy1, iy1) : (do_s ? sy1 : iy1);
                     if (x1 >= x0 && y1 >= y0) {
-                        area = (x1 - x0 + 1) * (y1 - y0 + 1);
+                        const int nx_ = lattice ? (x1 - x0) / ids_step + 1 : x1 - x0 + 1, ny_ = lattice ? (y1 - y0) / ids_step + 1 : y1 - y0 + 1;
+                        area = nx_ * ny_;
                         R.qx = G.q.x; R.qy = G.q.y; R.qz = G.q.z; R.nx = G.nn.x; R.ny = G.nn.y; R.nz = G.nn.z; R.r2 = G.r * G.r; R.id = i;
-                        R.x0 = x0; R.y0 = y0; R.bw = x1 - x0 + 1;
+                        R.x0 = x0; R.y0 = y0; R.bw = nx_ | (lattice << 16);
                         R.s01 = (sx0 & 0xFFFF) | (sx1 << 16); R.s23 = (sy0 & 0xFFFF) | (sy1 << 16);
                         R.i01 = (ix0 & 0xFFFF) | (ix1 << 16); R.i23 = (iy0 & 0xFFFF) | (iy1 << 16);
                     }
@@ -1537,8 +1546,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             const float4 a = *reinterpret_cast<const float4*>(&rp->qx), b = *reinterpret_cast<const float4*>(&rp->ny);
             const int4 bx = *reinterpret_cast<const int4*>(&rp->x0), rg = *reinterpret_cast<const int4*>(&rp->s01);
             const int k = g - bx.w;
-            const int row = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z)), col = k - row * bx.z;   // exact for boxes up to 512 x 512 (IFX_MAX_SPRITE)
-            const int px = bx.x + col, py = bx.y + row;
+            const int bwv = bx.z & 0xFFFF, stp = (bx.z >> 16) ? ids_step : 1;
+            const int row = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)bwv)), col = k - row * bwv;   // exact for boxes up to 512 x 512 (IFX_MAX_SPRITE)
+            const int px = bx.x + col * stp, py = bx.y + row * stp;
             Disc d;
             d.q = v3m(a.x, a.y, a.z); d.n = v3m(a.w, b.x, b.y); d.r2 = b.z;
             const unsigned int id = __float_as_uint(b.w);
@@ -1547,7 +1557,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             const int sx0 = (short)(rg.x & 0xFFFF), sx1 = rg.x >> 16, sy0 = (short)(rg.y & 0xFFFF), sy1 = rg.y >> 16;
             const int ix0 = (short)(rg.z & 0xFFFF), ix1 = rg.z >> 16, iy0 = (short)(rg.w & 0xFFFF), iy1 = rg.w >> 16;
             const bool in_s = px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
-            const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
+            const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth) && (ids_step <= 1 || (px % ids_step == 0 && py % ids_step == 0));
             if (!in_s && !in_i) continue;
             const int tsel = in_s && in_i ? 0 : (in_s ? 1 : 2);
             unsigned long long* addr = (tsel == 0 ? key_both : (tsel == 1 ? key_splat : key_ids)) + (py * c.w + px);
@@ -1635,6 +1645,17 @@ static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out)
     LAUNCH(h, "ids_raster_inst", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_raster<2>, h->d_state, d_pose_inv, (const float4*)h->pc, (const float4*)h->nr,
            (const float2*)h->tm, (const float4*)h->votes, h->cap, c, 0, 0, h->key_ids);
     LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, out);
+}
+
+// The frame path renders the id image on the sampled lattice only (ifx_map_predict); whoever needs the whole image -- a segmentation call, ifx_ids_after,
+// a download, the display -- gets it here: the id render of the current map at the current pose, exactly what the frame would have drawn (the map and the pose
+// do not change between the end of a frame and the start of the next).
+int ifx_ids_ensure(ifx* h)
+{
+    if (h->ids_full_valid || !h->ids_sparse_frame) return IFX_OK;
+    ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
+    h->ids_full_valid = 1;
+    return IFX_OK;
 }
 
 // ------------------------------------------------------------------ association + fusion (a11, a12)
@@ -2010,7 +2031,7 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
            (float2*)h->col2, (float2*)h->tm2, (float4*)h->ic2, (float4*)h->votes2, h->labels2, (const uint32_t*)h->seq, h->seq2);
     LAUNCH(h, "compact_count", dim3(1), dim3(64), k_compact_count, h->d_state, &h->d_state->seg_counts[1]);
     std::swap(h->pc, h->pc2); std::swap(h->nr, h->nr2); std::swap(h->col, h->col2); std::swap(h->tm, h->tm2); std::swap(h->ic, h->ic2); std::swap(h->votes, h->votes2); std::swap(h->labels, h->labels2); std::swap(h->seq, h->seq2);
-    if (refresh_ids && !h->own) ids_pass(h, nullptr, 0, h->ids_after);   // slot numbers changed: re-render the id image (a sharded map's id image holds creation numbers: nothing changed)
+    if (refresh_ids && !h->own) { ids_pass(h, nullptr, 0, h->ids_after); h->ids_full_valid = 1; }   // slot numbers changed: re-render the id image (a sharded map's id image holds creation numbers: nothing changed)
     return IFX_OK;
 }
 
@@ -2311,15 +2332,22 @@ int ifx_map_predict(ifx* h)
     if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
+        // The id image has one consumer per frame -- whetherDoSegmentation's sums over every 10th pixel -- and a full-image consumer only when a segmentation call, a
+        // download or the display asks for it: the frame renders the sampled lattice only (the id half of this pass: 71 -> 40 us), ifx_ids_ensure the rest on demand.
+        const int ids_step = (h->opt_lazy_ids && (want & LIST_IDS)) ? 10 : 1;
+        h->ids_full_valid = ids_step == 1;
+        h->ids_sparse_frame = ids_step > 1;
         if (h->opt_raster_lds)
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<true>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
         else
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz);
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
-    } else
+    } else {
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
+        if (want & LIST_IDS) { h->ids_full_valid = 1; h->ids_sparse_frame = 0; }
+    }
     h->view_frame = 0;
     h->ids_pending = 0;
     return IFX_OK;

@@ -257,7 +257,13 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "clean_blocks") h->opt_clean_blocks = std::max(0, std::min(65536, value));
     else if (s == "index_blocks") h->opt_index_blocks = std::max(0, std::min(8192, value));
     else if (s == "res_blocks") h->opt_res_blocks = std::max(0, std::min(4096, value));
-    else if (s == "icp_lds") h->opt_icp_lds = value;
+    else if (s == "icp_lds") {
+#ifdef IFX_EXPERIMENTS
+        h->opt_icp_lds = value;
+#else
+        if (value) { h->err = "icp_lds: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
+#endif
+    }
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
@@ -265,9 +271,27 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "seg_device") h->opt_seg_device = value;
     else if (s == "ff_rounds") h->opt_ff_rounds = value;
     else if (s == "labels_incremental") { h->opt_labels_incremental = value; h->labels_stale_all = 1; }
-    else if (s == "icp_px") h->opt_icp_px = value;
-    else if (s == "model_fused") h->opt_model_fused = value;
-    else if (s == "gn_persist") h->opt_gn_persist = value;
+    else if (s == "icp_px") {
+#ifdef IFX_EXPERIMENTS
+        h->opt_icp_px = value;
+#else
+        if (value) { h->err = "icp_px: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
+#endif
+    }
+    else if (s == "model_fused") {
+#ifdef IFX_EXPERIMENTS
+        h->opt_model_fused = value;
+#else
+        if (value) { h->err = "model_fused: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
+#endif
+    }
+    else if (s == "gn_persist") {
+#ifdef IFX_EXPERIMENTS
+        h->opt_gn_persist = value;
+#else
+        if (value) { h->err = "gn_persist: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
+#endif
+    }
     else if (s == "raster_lds") h->opt_raster_lds = value;
     else if (s == "raster_earlyz") h->opt_raster_earlyz = value;
     // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;

@@ -349,6 +349,7 @@ __device__ __forceinline__ v3 resize4(float a00, float a01, float a10, float a11
     return n;
 }
 struct ModelOut3 { ModelOut l[3]; };
+#ifdef IFX_EXPERIMENTS
 __global__ __launch_bounds__(256) void k_model_pyr3(const DevState* __restrict__ st, const float* __restrict__ pv, const float* __restrict__ pn, const uint8_t* __restrict__ pi,
                                                     const float* __restrict__ fv, const float* __restrict__ fn, const uint8_t* __restrict__ fi, int w, int h, float cutoff, ModelOut3 o)
 {
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(256) void k_model_pyr3(const DevState* __restrict__
         model_tail(st, x2, y2, w2, h2, v2, n2, z2, o2);
     }
 }
+#endif   // IFX_EXPERIMENTS
 
 // ======================================================================= reductions (a4-a7)
 
@@ -634,6 +636,7 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
 #define LT_HALO 8
 #define LT_SW (LT_W + 2 * LT_HALO)
 #define LT_SH (LT_H + 2 * LT_HALO)
+#ifdef IFX_EXPERIMENTS
 __device__ __forceinline__ void icp_body_lds(int bid, const DevState* __restrict__ st, const float* __restrict__ vmap_curr, const float* __restrict__ nmap_curr,
                                              const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx, float fy, float cx, float cy,
                                              float distThres, float angleThres, int w, int h, double* __restrict__ gacc)
@@ -695,6 +698,7 @@ __device__ __forceinline__ void icp_body_lds(int bid, const DevState* __restrict
     }
     block_sum_exact<29>(acc, gacc, bid % IFX_ACC_REPL);
 }
+#endif   // IFX_EXPERIMENTS
 
 __global__ __launch_bounds__(RED_THREADS) void k_icp(const DevState* __restrict__ st, IcpArgs ex, const float* __restrict__ vmap_curr,
                                                      const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev,
@@ -833,7 +837,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
     __builtin_assume(st != nullptr);
     if (CHECK_SKIP && st->skip) return;   // model-to-model instance only: the frame-to-model tracker pays no dependent load for it
     if ((int)blockIdx.x < nb_icp) {
+#ifdef IFX_EXPERIMENTS
         if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc); return; }
+#endif
         IcpArgs ia;   // unused when st != nullptr
         icp_body<false, true>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc);
     } else {
@@ -843,6 +849,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
     }
 }
 
+#ifdef IFX_EXPERIMENTS
 // The two reductions of k_icp_residual on the SAME pixels of one thread: PX pixels per thread, no loop.  Every coalesced load of the thread -- the ICP's
 // vertex / normal and the residual pass's window, gradients, depth, intensity -- leaves in one batch, every gather (model vertex / normal, warped depth
 // and intensity) in a second one: two memory round trips for the whole launch, whatever the level, where the split form runs an ICP block through three
@@ -961,6 +968,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual_px(const DevState*
         if (s2) atomicAdd(&gres[tid], s2);
     }
 }
+#endif   // IFX_EXPERIMENTS
 
 // RGBReduction, EF/Cuda/reduce.cu:494-619.  sigma is either explicit (stage API) or derived from the
 // residual pass's block partials with the reference's precedence quirk (EF/Utils/RGBDOdometry.cpp:461).
@@ -1835,6 +1843,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
 }
 
 
+#ifdef IFX_EXPERIMENTS   // measured alternatives that lost: compiled only on request (make FLAGS+=-DIFX_EXPERIMENTS), with their bit-identity tests
 // ======================================================================= persistent Gauss-Newton level
 // ALL iterations of one pyramid level in ONE launch.  The two-launch form above pays per iteration two launch boundaries, two argument / state
 // prologues, a round trip of the correspondence records through memory and the last block's ticket: ~14 us even at 160 x 120, where the
@@ -2131,6 +2140,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
         __syncthreads();
     }
 }
+#endif   // IFX_EXPERIMENTS
 
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
 __global__ void k_commit_pose(DevState* st, unsigned int* lctr)
@@ -2170,6 +2180,7 @@ int ifx_alloc_tracker(ifx* h)
     const int maxb = 1024;
     HIPCHK(h, hipMalloc(&p.acc, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
     HIPCHK(h, hipMemset(p.acc, 0, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
+#ifdef IFX_EXPERIMENTS
     {   // grids of the persistent level kernel must be co-resident: blocks per CU from the runtime's occupancy calculator x the CU count
         int cus = 0, dev = 0;
         hipGetDevice(&dev);
@@ -2181,6 +2192,7 @@ int ifx_alloc_tracker(ifx* h)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], k_gn_level<4>, RED_THREADS, 0);
         for (int q = 0; q < 4; q++) h->gn_max_blocks[q] = std::max(0, occ[q]) * std::max(0, cus);
     }
+#endif
     h->res_rows = std::max(maxb, cdiv(h->P, RED_THREADS) + 1);   // the residual pass runs one block per 256 pixels
     HIPCHK(h, hipMalloc(&h->res_partials, (size_t)h->res_rows * 2 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
@@ -2267,10 +2279,12 @@ static void tracker_init_model(ifx* h, DevState* st, Pyr& p, float icp_weight, c
         o.vprev = p.vmap_prev[i]; o.nprev = p.nmap_prev[i]; o.cloud = (rgb && iterations[i] > 0) ? p.cloud[i] : nullptr;
         o.invFx = 1.0f / (c.fx / div); o.invFy = 1.0f / (c.fy / div); o.cx = c.cx / div; o.cy = c.cy / div;
     }
+#ifdef IFX_EXPERIMENTS
     if (h->opt_model_fused && IFX_NUM_PYRS == 3 && h->w % 32 == 0 && h->h % 16 == 0 && fv) {   // the three levels in one launch
         LAUNCH(h, "model_pyr3", dim3(h->w / 32, h->h / 16), dim3(256), k_model_pyr3, st, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o3);
         return;
     }
+#endif
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         const ModelOut& o = o3.l[i];
         if (i == 0) LAUNCH(h, "model_l0", G2(h->w, h->h), B2, k_model_l0, st, pv, pn, pi, fv, fn, fi, h->w, h->h, 6.0f, o);
@@ -2374,13 +2388,18 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
         // The residual half of the launch is the slower one and scales with its blocks (its totals go through integer atomics, it has no partial rows for the
         // last block to sum): one pixel per thread, no loop -- 152 blocks 17.5 us, 304 blocks 13.3 us, 1200 blocks 11.3 us per launch at 640x480 (1053 -> 1102 frames/s).
+#ifdef IFX_EXPERIMENTS
         const bool lds_tiles = h->opt_icp_lds && i == 0 && frame_tracker;
+#else
+        const bool lds_tiles = false;
+#endif
         const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : (1 << 30));
         pa.lds_tiles = lds_tiles ? 1 : 0;
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
         double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
         int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
         pa.check_skip = frame_tracker ? 0 : 1;   // (accumulator rows, residual totals, ticket: DevState::gn_acc / gn_res / gn_ticket of `st`)
+#ifdef IFX_EXPERIMENTS
         if (frame_tracker && h->opt_gn_persist && iterations[i] > 0 && !lds_tiles && icp && rgb) {   // all iterations of the level in one persistent launch
             static const int pxs[4] = {1, 2, 3, 4};
             int q = -1, nbp = 0;
@@ -2411,16 +2430,22 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 continue;
             }
         }
+#endif
         iters_done += iterations[i];
         // both reductions on the same pixels of one thread (k_icp_residual_px); option bits: 1 = at level 0, 2 = at levels 1 and 2, 4 = one pixel per thread at level 0 too
+#ifdef IFX_EXPERIMENTS
         const bool px_form = frame_tracker && icp && rgb && !lds_tiles && (i == 0 ? (h->opt_icp_px & 1) : (h->opt_icp_px & 2));
         const bool px_two = !(h->opt_icp_px & 4);
+#endif
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
+#ifdef IFX_EXPERIMENTS
             if (px_form && px_two && n > 150000) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS * 2)), dim3(RED_THREADS), (k_icp_residual_px<2, false>), st, cdiv(n, RED_THREADS * 2), pa.w, pa.h, gacc, gres, pa);
             else if (px_form) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS)), dim3(RED_THREADS), (k_icp_residual_px<1, false>), st, cdiv(n, RED_THREADS), pa.w, pa.h, gacc, gres, pa);
             else if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
-            else if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
+            else
+#endif
+            if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
             else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;

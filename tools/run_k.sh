@@ -1,12 +1,15 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q > gpurun_out/r03_p_tests.log 2>&1; tail -6 gpurun_out/r03_p_tests.log
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r03_p_bench_driver.json 2>/dev/null
-python bench.py --steps 200 --warmup 30 --no-cpu-baseline --extras-frames 0 > gpurun_out/r03_p_bench.json 2>/dev/null
-python bench.py --steps 200 --warmup 30 --no-cpu-baseline --extras-frames 0 --opt lazy_ids=0 > gpurun_out/r03_p_bench_eager.json 2>/dev/null
+tools/pmc_collect.sh r03_q > gpurun_out/r03_q_pmc.log 2>&1
+tools/pmc_collect.sh r03_q_morton --map-order morton > gpurun_out/r03_q_morton_pmc.log 2>&1
+tools/prof_run.sh r03_q > gpurun_out/r03_q_prof.log 2>&1
+python bench.py --steps 200 --warmup 30 --extras-frames 0 --no-cpu-baseline --map-order morton > gpurun_out/r03_q_bench_morton.json 2>/dev/null
+python bench.py --steps 200 --warmup 30 > gpurun_out/r03_q_bench.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03_q_bench_driver.json 2>/dev/null
+tail -3 gpurun_out/r03_q_pmc.log
 python - <<PY
 import json
-for n in ("_driver","","_eager"):
-    f="gpurun_out/r03_p_bench%s.json" % n
-    d=json.loads(open(f).read().strip().splitlines()[-1]); k=d["roofline"]["kernels"]
-    print(n or "200", d["value"], d["ms_per_frame_gpu"], d["instance"]["ms_per_call"], {x:k[x]["avg_ms"] for x in ("raster_view","splat_resolve","raster_finish") if x in k}, d.get("value_host_entry",{}).get("value"), d.get("value_close_loops",{}).get("value"))
+for n in ("","_morton","_driver"):
+    d=json.loads(open("gpurun_out/r03_q_bench%s.json" % n).read().strip().splitlines()[-1])
+    r=d["roofline"]
+    print(n or "200", d["value"], d["ms_per_frame_gpu"], d["instance"]["ms_per_call"], r["kernel"], r["frac"], r["traffic"], [(e["kernel"], e["frac"], e["traffic_over_algorithmic"]) for e in r["map_passes"][:3]], r["stages"])
 PY

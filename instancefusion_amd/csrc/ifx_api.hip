@@ -100,6 +100,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         hipError_t r1 = prio ? hipStreamCreateWithPriority(&h->stream, hipStreamDefault, hi) : hipStreamCreate(&h->stream);
         hipError_t r2 = prio ? hipStreamCreateWithPriority(&h->stream_b, hipStreamDefault, lo) : hipStreamCreate(&h->stream_b);
         if (r1 != hipSuccess || r2 != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+        hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_t, hipStreamDefault, hi) : hipStreamCreate(&h->stream_t);
+        if (r3 != hipSuccess || hipEventCreateWithFlags(&h->ev_track_done, hipEventDisableTiming) != hipSuccess) { g_err = "hipStreamCreate failed"; ifx_destroy(h); return IFX_E_HIP; }
     }
     h->cur = h->stream;
     ALLOC(h->d_state, sizeof(DevState));
@@ -195,6 +197,8 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_slic_free(h);
     ifx_knn_free_all(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
+    if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
+    if (h->ev_track_done) hipEventDestroy(h->ev_track_done);
     if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -205,7 +209,7 @@ extern "C" int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, floa
 {
     if (!h) return IFX_E_INVALID;
     if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "loop-closure detection cannot change while a frame is announced ahead"; return IFX_E_STATE; }
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     if (enable) {
         int r = ifx_tracker_alloc_m2m(h);
@@ -267,6 +271,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
+    else if (s == "track_aside") { ifx_drop_tracked(h); h->opt_track_aside = value; }
+    else if (s == "fold_finish") h->opt_fold_finish = value;
     else if (s == "lazy_ids") { ifx_ids_ensure(h); h->opt_lazy_ids = value; }
     else if (s == "seg_device") h->opt_seg_device = value;
     else if (s == "ff_rounds") h->opt_ff_rounds = value;
@@ -298,7 +304,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     // refused while a frame is announced ahead (its image-only work may already be on the queue with the old configuration)
     else if (s == "pyramid" || s == "fast_odom" || s == "so3" || s == "icp_weight_x1000") {
         if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "tracker options cannot change while a frame is announced ahead"; return IFX_E_STATE; }
-        h->tracked_ahead = 0;
+        ifx_drop_tracked(h);
         if (s == "pyramid") h->cfg.pyramid = value ? 1 : 0;
         else if (s == "fast_odom") h->cfg.fast_odom = value ? 1 : 0;
         else if (s == "so3") h->cfg.so3 = value ? 1 : 0;
@@ -311,7 +317,20 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
 // ------------------------------------------------------------------ frame orchestration
 __global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restrict__ out, float* __restrict__ traj_slot)
 {
+    // view-list frames: the resolve of the prediction accumulated the end-of-pass sums (k_splat_resolve, FinishFold) in sixteen partials
+    const int fold = st->fold_total;
+    int f_mass = 0, f_empty = 0, f_lit = 0;
+    if (fold && threadIdx.x < 16) {
+        f_mass = st->fold_acc[threadIdx.x][0]; f_empty = st->fold_acc[threadIdx.x][1]; f_lit = st->fold_acc[threadIdx.x][2];
+        st->fold_acc[threadIdx.x][0] = 0; st->fold_acc[threadIdx.x][1] = 0; st->fold_acc[threadIdx.x][2] = 0;
+    }
+    f_mass = wave_sum_i(f_mass); f_empty = wave_sum_i(f_empty); f_lit = wave_sum_i(f_lit);
     if (threadIdx.x != 0) return;
+    if (fold) {
+        st->seg_acc[0] += f_mass; st->seg_acc[1] += f_empty;
+        st->dense_enough = ((float)f_lit / (float)fold > 0.75f) ? 1 : 0;   // EF/ElasticFusion.cpp:252-267
+        st->fold_total = 0;
+    }
     out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
     st->seg_acc[0] = 0; st->seg_acc[1] = 0;
     for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
@@ -450,7 +469,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0;
     // a tracker run enqueued behind the previous frame counts only for exactly this frame, tracked, with the default weight
     const bool tracked = prepared && h->tracked_ahead == h->tick && !in_pose16;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     if (!prepared) {
         int r = enqueue_frame_side(h, s, h->tick, rgb, depth, src_kind);
         if (r) return r;
@@ -520,12 +539,18 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     FrameSlot& nf = h->slot[h->tick & 1];
     if (h->opt_track_ahead && h->opt_two_streams && nf.for_tick == h->tick && h->tick > 1) {
         ifx_bind_slot(h, h->tick & 1);
-        HIPCHK(h, hipStreamWaitEvent(h->stream, nf.ready, 0));
+        const bool aside = h->opt_track_aside && h->stream_t;
+        if (aside) {   // behind this frame's result, beside whatever the caller enqueues before the next frame
+            HIPCHK(h, hipStreamWaitEvent(h->stream_t, f.released, 0));
+            h->cur = h->stream_t;
+        }
+        HIPCHK(h, hipStreamWaitEvent(h->cur, nf.ready, 0));
         {
             StageTimer t(h, 0);
             ifx_tracker_model_side(h, 1);
             ifx_tracker_run_frame(h, 0);
         }
+        if (aside) { hipEventRecord(h->ev_track_done, h->stream_t); h->cur = h->stream; h->track_aside = 1; }
         ifx_bind_slot(h, s);
         h->tracked_ahead = h->tick;
     }
@@ -566,7 +591,7 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
     if (!h || cam < 0 || (cam > 0 && (size_t)cam >= h->cams.size())) return IFX_E_INVALID;
     if (h->cams.empty() || cam == h->cur_cam) return IFX_OK;
     if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "ifx_camera_select: a frame is announced ahead"; return IFX_E_STATE; }
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     if (h->lc_pending && h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     if (!h->own) { ifx_vlist_reap(h); hs_invalidate_view(h); }   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
     const size_t P = (size_t)h->P;
@@ -622,7 +647,7 @@ extern "C" int ifx_set_shard(ifx_t* h, int rank, int nranks)
     ifx_vlist_reap(h);
     hs_invalidate_view(h);
     h->shard_rank = rank; h->shard_n = nranks;
-    h->tracked_ahead = 0; h->hint_rgb = nullptr;
+    ifx_drop_tracked(h); h->hint_rgb = nullptr;
     return IFX_OK;
 }
 
@@ -656,7 +681,7 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
     FrameSlot& f = h->slot[s];
     if (phase == 0) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
-        h->tracked_ahead = 0;
+        ifx_drop_tracked(h);
         // The compaction decision must be the SAME on every rank (slot numbers travel inside the exchanged keys): it is taken from the
         // result of the previous frame, which is identical on all ranks -- once the host has actually waited for it.
         if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
@@ -763,7 +788,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
     const bool starts_frame = phase == 310 || ((phase == 300 || phase == 0) && h->own_tracked_tick != h->tick);
     if (starts_frame) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
-        h->tracked_ahead = 0;
+        ifx_drop_tracked(h);
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
         const int two = h->opt_two_streams;
         h->opt_two_streams = 0;
@@ -811,7 +836,7 @@ extern "C" int ifx_owner_predict_phase(ifx_t* h, int step)
 {
     if (!h || step < 0 || step > 2) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_predict_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     return ifx_map_owner_phase(h, 104 + step, false);
 }
 // what to reduce after phase `phase`: ptrs[k] (device), bytes[k], ops[k] (0: element-wise minimum of unsigned 64-bit words, 1: sum of
@@ -910,6 +935,7 @@ extern "C" int ifx_sync(ifx_t* h)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream_b));
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
@@ -961,7 +987,7 @@ int ifx_housekeeping(ifx* h)
 extern "C" int ifx_set_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth)
 {
     if (!h || !rgb || !depth) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     HIPCHK(h, hipMemcpyAsync(h->rgb, rgb, (size_t)h->P * 3, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->depth_raw, depth, (size_t)h->P * 2, hipMemcpyHostToDevice, h->stream));
     ifx_preprocess(h);
@@ -1004,6 +1030,7 @@ extern "C" int ifx_stage_ms(ifx_t* h, float* ms4, int reset)
 {
     if (!h || !ms4) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));   // (a tracker run enqueued ahead has its stage markers there)
     stage_flush(h);
     for (int k = 0; k < 4; k++) ms4[k] = (float)h->stage_ms[k];
     if (reset) for (int k = 0; k < 4; k++) h->stage_ms[k] = 0;
@@ -1014,6 +1041,7 @@ extern "C" int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* l
 {
     if (!h || !kernel) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     ktime_flush(h);
     std::string s(kernel);
     if (s == "__reset__") { for (auto& k : h->ktimes) k = KernelTiming(); return IFX_OK; }
@@ -1069,7 +1097,7 @@ extern "C" int ifx_map_count(ifx_t* h)
 extern "C" int ifx_compact(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->seg_counts_valid = 0;
     ifx_compact_enqueue(h, 1);
     return ifx_sync(h);
@@ -1078,7 +1106,7 @@ extern "C" int ifx_compact(ifx_t* h)
 extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float* col, float* tm, float* ic, float* votes)
 {
     if (!h) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->seg_counts_valid = 0;
     int r = ifx_compact(h);   // live surfels in map order
     if (r) return r;
@@ -1105,7 +1133,7 @@ extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float
 extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr, const float* col, const float* tm, const float* ic, const float* votes)
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->seg_counts_valid = 0;
     h->map_external = 1;
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
@@ -1164,7 +1192,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
 extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 {
     if (!h || !pose16) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     DevState hs;
     int r = read_state(h, &hs);
     if (r) return r;

@@ -47,6 +47,8 @@ struct DevState {
     // instance
     int seg_counts[2];
     int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
+    int fold_total;              // != 0: this frame's k_splat_resolve accumulated fold_acc itself (= the number of dense-test samples); k_frame_result folds and clears
+    int fold_acc[16][4];         // partial sums by blockIdx.x & 15: vote mass, empty lattice pixels, lit dense-test samples, -
     unsigned int append_ticket;  // last-block ticket of k_append_scan
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
@@ -217,12 +219,17 @@ struct ifx {
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
+    hipStream_t stream_t = nullptr;     // the tracker run enqueued ahead of its frame goes here: whatever the caller enqueues between the two frames (a segmentation
+    hipEvent_t ev_track_done = nullptr; // call: 60 short launches) then runs beside its 170 launches instead of behind them; the main stream joins at the next frame (ifx_drop_tracked)
+    int track_aside = 0;                // a run on stream_t the main stream has not joined yet
+    int opt_track_aside = 1;
     hipEvent_t ev_result = nullptr;     // the `released` event of the slot of the last frame (recorded after k_frame_result)
     const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
     const uint16_t* hint_depth = nullptr;
     std::string err;
     int tick = 1;
     int ids_pending = 0;
+    int opt_fold_finish = 1;            // view-list frames: the end-of-pass sums (dense test, whetherDoSegmentation) ride in k_splat_resolve instead of a launch of their own
     int opt_lazy_ids = 1;               // the frame renders the id image on the lattice whetherDoSegmentation samples; the whole image on demand (ifx_ids_ensure)
     int ids_full_valid = 1, ids_sparse_frame = 0;
     // options
@@ -382,6 +389,13 @@ static inline IdMap ifx_idmap(const ifx* h) { IdMap m; m.seq = h->seq; m.own_n =
 hipEvent_t ifx_event_get(ifx* h);
 void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a);
 void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
+
+// Forget a tracker run enqueued ahead (the caller is about to change something it read, or to consume it): whatever follows on the main stream is ordered behind it.
+static inline void ifx_drop_tracked(ifx* h)
+{
+    if (h->track_aside) { hipStreamWaitEvent(h->stream, h->ev_track_done, 0); h->track_aside = 0; }
+    h->tracked_ahead = 0;
+}
 
 #define LAUNCH(h, name, grid, block, kernel, ...)                                                  \
     do {                                                                                           \

@@ -1239,7 +1239,7 @@ extern "C" int ifx_set_instance_gt(ifx_t* h, const uint8_t* gt_hw)
     HIPCHK(h, hipMemcpyAsync(h->d_inst_gt, gt_hw, (size_t)h->P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // gt_hw is the caller's
     h->inst_gt_on = 1;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     return IFX_OK;
 }
 // computePrecisionAndRecallKernel, IF/Core/InstanceFusionCuda.cu:2085-2114

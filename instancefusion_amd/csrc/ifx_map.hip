@@ -414,6 +414,16 @@ __global__ void k_ids_resolve(unsigned long long* __restrict__ keys, int P, int3
     ids[k] = (key == IFX_KEY_EMPTY) ? 0 : (int32_t)(key & 0xFFFFFFFFull);
 }
 
+// End-of-pass sums folded into the resolve (view-list frames of the unsharded map; k_raster_finish's job everywhere else): the thread of a dense-test sample
+// or of a lattice pixel of whetherDoSegmentation already holds the colour / the id the sums ask about, and the twelve vote gathers of the 1 % lattice threads
+// hide under the kernel instead of being a 12 us launch of their own.  Block totals go to sixteen partials (DevState::fold_acc), k_frame_result folds them.
+struct FinishFold {
+    int* acc;             // null: off
+    int* total;
+    const float4* votes;
+    int cap, ds, rw, rh;
+};
+
 // combo_splat.frag:54-66 outputs for the winner of each pixel, fused with FillIn
 // (fill_rgb/vertex/normal.frag, EF/Shaders/FillIn.cpp:65-195, passthrough = 0).
 __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
@@ -421,7 +431,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid)
+                                int* __restrict__ n_valid, FinishFold fold)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -440,6 +450,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     }
     asm volatile("" ::"v"((unsigned int)key), "v"((unsigned int)bk0), "v"((unsigned int)ik0), "v"((unsigned int)f_r), "v"((unsigned int)f_d), "v"((unsigned int)f_dx), "v"((unsigned int)f_dy));
     keys[k] = IFX_KEY_EMPTY;
+    int fold_id = 0;
     if (ids_out) {   // k_ids_resolve of the id render that shared the raster pass; `both` holds the pixels common to the two renders
         const unsigned long long bk = bk0;
         both_keys[k] = IFX_KEY_EMPTY;
@@ -447,7 +458,8 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
         id_keys[k] = IFX_KEY_EMPTY;
         ik = ik < bk ? ik : bk;
         key = key < bk ? key : bk;
-        ids_out[k] = (ik == IFX_KEY_EMPTY) ? 0 : (int32_t)(ik & 0xFFFFFFFFull);
+        fold_id = (ik == IFX_KEY_EMPTY) ? 0 : (int32_t)(ik & 0xFFFFFFFFull);
+        ids_out[k] = fold_id;
     }
     float4 vo = make_float4(0, 0, 0, 0), no = make_float4(0, 0, 0, 0);
     uchar4 io = make_uchar4(0, 0, 0, 0), so = make_uchar4(0, 0, 0, 0);
@@ -476,6 +488,37 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     }
     pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
     (void)n_valid;
+    if (fold.acc) {   // (uniform)
+        __shared__ int s_f[3];
+        const int lt = threadIdx.y * blockDim.x + threadIdx.x;
+        if (lt < 3) s_f[lt] = 0;
+        __syncthreads();
+        {   // ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267: the samples of the (w/20 x h/20) nearest resample
+            const int i = x * fold.rw / c.w, j = y * fold.rh / c.h;
+            if ((i * c.w + c.w / 2) / fold.rw == x && (j * c.h + c.h / 2) / fold.rh == y && io.x > 0 && io.y > 0 && io.z > 0) atomicAdd(&s_f[2], 1);
+        }
+        if (ids_out && x % fold.ds == 0 && y % fold.ds == 0) {   // checkProjectDepthAndInstanceKernel, IF/Core/InstanceFusionCuda.cu:736-760
+            const int gid = fold_id;
+            if (gid > 0 && gid < st->count) {
+                float4 v[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) v[q] = fold.votes[(size_t)q * fold.cap + gid];
+                int mass = 0;
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    int a, b;
+                    vote_decode(v[q].x, a, b); mass += a + b;
+                    vote_decode(v[q].y, a, b); mass += a + b;
+                    vote_decode(v[q].z, a, b); mass += a + b;
+                    vote_decode(v[q].w, a, b); mass += a + b;
+                }
+                if (mass) atomicAdd(&s_f[0], mass);
+            } else atomicAdd(&s_f[1], 1);
+        }
+        __syncthreads();
+        if (lt < 3 && s_f[lt]) atomicAdd(fold.acc + (blockIdx.x & 15) * 4 + lt, s_f[lt]);
+        if (lt == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fold.total = fold.rw * fold.rh;
+    }
     if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
     // fill-in
     float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
@@ -1588,7 +1631,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
 }
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
-static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0)
+static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0,
+                        bool fold_finish = false)
 {
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
@@ -1620,15 +1664,21 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
         LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat,
                (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
                (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
-               old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
+               old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr, FinishFold());
         LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
         return;
     }
     if (want & LIST_SPLAT) {
+        FinishFold ff = FinishFold();
+        if (fold_finish && frame_sums && !h->own && h->w >= 20 && h->h >= 20) {
+            ff.acc = &h->d_state->fold_acc[0][0]; ff.total = &h->d_state->fold_total;
+            ff.votes = (const float4*)h->votes; ff.cap = h->cap; ff.ds = 10; ff.rw = h->w / 20; ff.rh = h->h / 20;
+        }
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
-               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr);
+               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff);
+        if (ff.acc) return;   // (the view-list pass leaves list 0 alone: nothing to re-arm)
     } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
     // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums
     const int seg = frame_sums && (want & LIST_IDS);   // only the frame's own render feeds whetherDoSegmentation (not the re-render after a compaction)
@@ -2317,7 +2367,7 @@ int ifx_map_predict_loop_closure(ifx* h)
                old ? h->key_ids : h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt,
                (float4*)(old ? h->old_vertex : h->act_vertex), (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image),
                (uchar4*)(old ? h->old_inst : h->act_inst), old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both,
-               (int32_t*)nullptr, (int*)nullptr);
+               (int32_t*)nullptr, (int*)nullptr, FinishFold());
     LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
     return IFX_OK;
 }
@@ -2343,7 +2393,7 @@ int ifx_map_predict(ifx* h)
         else
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
                    want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
-        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2);   // resolve + finish of the same pass
+        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0);   // resolve + the end-of-pass sums in the same launch
     } else {
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
         if (want & LIST_IDS) { h->ids_full_valid = 1; h->ids_sparse_frame = 0; }
@@ -2479,7 +2529,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         case 5:
             LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                    (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
-                   (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
+                   (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr, FinishFold());
             break;
         case 6:
             LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
@@ -2506,7 +2556,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, old ? h->key_ids : h->key_splat, (const float4*)h->pc,
                    (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)(old ? h->old_vertex : h->act_vertex),
                    (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image), (uchar4*)(old ? h->old_inst : h->act_inst),
-                   old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr);
+                   old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr, FinishFold());
         LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
                (int*)nullptr, (int*)nullptr);
         break;
@@ -2540,7 +2590,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
     case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
-               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr);
+               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr, FinishFold());
         if (in_frame) {   // whetherDoSegmentation sums: empty pixels replicated, vote mass by the owners -> the tail of the prediction block
             const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);
             LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h),
@@ -2577,7 +2627,7 @@ static int upload_pose(ifx* h, const float* pose16, float** d_pose, float** d_in
 extern "C" int ifx_predict_indices(ifx_t* h, const float* pose16, int time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;
@@ -2588,7 +2638,7 @@ extern "C" int ifx_predict_indices(ifx_t* h, const float* pose16, int time)
 extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int max_time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
     if (r) return r;
@@ -2599,7 +2649,7 @@ extern "C" int ifx_combined_predict(ifx_t* h, const float* pose16, int time, int
 extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting)
 {
     if (!h || !pose16) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
@@ -2611,7 +2661,7 @@ extern "C" int ifx_fuse(ifx_t* h, const float* pose16, int time, float weighting
 extern "C" int ifx_clean(ifx_t* h, const float* pose16, int time)
 {
     if (!h || !pose16) return IFX_E_INVALID;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->seg_counts_valid = 0;
     float *dp, *di;
     int r = upload_pose(h, pose16, &dp, &di);
@@ -2792,7 +2842,7 @@ extern "C" int ifx_set_deformation(ifx_t* h, const float* graph16, int n_nodes, 
     HIPCHK(h, hipMemcpyAsync(h->d_graph, graph16, (size_t)n_nodes * 64, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // graph16 is the caller's
     h->graph_nodes = n_nodes; h->graph_is_fern = is_fern ? 1 : 0;
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     return IFX_OK;
 }
 
@@ -2810,7 +2860,7 @@ extern "C" int ifx_adopt_pose(ifx_t* h, const float* pose16)
     if (!h->in_fern_cb) { h->err = "ifx_adopt_pose: only inside the fern callback (currPose = recoveryPose, EF/ElasticFusion.cpp:482,504)"; return IFX_E_STATE; }
     Pose16 p;
     memcpy(p.m, pose16, sizeof(p.m));
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->view_block = 1;
     LAUNCH(h, "adopt_pose", dim3(1), dim3(64), k_adopt_pose, h->d_state, p);
     return IFX_OK;
@@ -2820,7 +2870,7 @@ extern "C" int ifx_adopt_estimated_pose(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;
     if (!h->d_m2m) { h->err = "loop-closure detection is not enabled"; return IFX_E_STATE; }
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     h->view_block = 1;
     LAUNCH(h, "adopt_est_pose", dim3(1), dim3(64), k_adopt_est_pose, h->d_state);
     return IFX_OK;

@@ -2706,7 +2706,7 @@ extern "C" int ifx_track_maps(ifx_t* h, const float* model_v4, const float* mode
     int r = ifx_tracker_alloc_m2m(h);
     if (r) return r;
     if (h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
-    h->tracked_ahead = 0;
+    ifx_drop_tracked(h);
     const size_t P = (size_t)h->P;
     HIPCHK(h, hipMemcpyAsync(h->old_vertex, model_v4, P * 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->old_normal, model_n4, P * 16, hipMemcpyHostToDevice, h->stream));
@@ -2783,6 +2783,7 @@ extern "C" int ifx_icp_step(ifx_t* h, const float* Rcurr9, const float* tcurr3, 
                             float angle_thres, int w, int hgt, float* out29_host)
 {
     if (!h || !out29_host) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
     IcpArgs ia;
     memcpy(ia.Rcurr, Rcurr9, 36); memcpy(ia.tcurr, tcurr3, 12); memcpy(ia.Rprev_inv, Rprev_inv9, 36); memcpy(ia.tprev, tprev3, 12);
     int nb = red_blocks(h, w * hgt);
@@ -2796,6 +2797,7 @@ extern "C" int ifx_rgb_residual(ifx_t* h, float min_scale, const int16_t* d_didx
                                 int w, int hgt, int* count_host, int* sigma_host)
 {
     if (!h) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
     ResArgs ra;
     memcpy(ra.krkinv, krkinv9, 36); memcpy(ra.kt, kt3, 12);
     int nb = red_blocks(h, w * hgt);
@@ -2815,6 +2817,7 @@ extern "C" int ifx_rgb_step(ifx_t* h, const void* d_corres8, float sigma, const 
                             float sobel_scale, int w, int hgt, float* out29_host)
 {
     if (!h || !out29_host) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
     int nb = red_blocks(h, w * hgt);
     LAUNCH(h, "rgb_step", dim3(nb), dim3(RED_THREADS), k_rgb_step, (const Corres8*)d_corres8, sigma, (const int*)nullptr, 0, d_cloud3, fx, fy, d_didx, d_didy, sobel_scale, w,
            hgt, stage_acc(h, 1));
@@ -2825,6 +2828,7 @@ extern "C" int ifx_so3_step(ifx_t* h, const uint8_t* d_last_img, const uint8_t* 
                             int hgt, float* out11_host)
 {
     if (!h || !out11_host) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
     So3Args sa;
     memcpy(sa.ib, image_basis9, 36); memcpy(sa.kinv, kinv9, 36); memcpy(sa.krlr, krlr9, 36);
     int nb = red_blocks(h, w * hgt);
@@ -2842,6 +2846,7 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
                               const uint8_t* rgb, float* pose16, float* diag8)
 {
     if (!h || !pose16) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
     size_t P = (size_t)h->P;
     HIPCHK(h, hipMemcpyAsync(h->pred_vertex, model_v4, P * 16, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pred_normal, model_n4, P * 16, hipMemcpyHostToDevice, h->stream));

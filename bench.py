@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--sharded-projection", action="store_true", help="round 1's variant: every rank holds the whole map, the projection passes are sliced by slot range")
     ap.add_argument("--map-order", default="random", choices=["random", "morton"], help="order of the pre-populated synthetic map: `random` (default: surfels sampled uniformly, neighbours in the map are "
                     "unrelated in space -- the worst case for the passes that gather the visible part of the store) or `morton` (spatially coherent, as a map built frame by frame is)")
+    ap.add_argument("--trace-steps", action="store_true", help="print the host time of every timed step to stderr (diagnostic)")
     ap.add_argument("--no-instance", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -249,10 +250,17 @@ def main():
         """n frames through fn(k), bracketed by barrier + synchronize; returns seconds (this rank)."""
         barrier()
         t0 = time.perf_counter()
+        marks = []
         for k in range(k_first, k_first + n):
             fn(k)
+            if args.trace_steps:
+                marks.append(time.perf_counter())
         barrier()
-        return time.perf_counter() - t0
+        t1 = time.perf_counter()
+        if args.trace_steps and rank == 0:   # host times of the steps (the host waits for every frame's result: they follow the device closely)
+            prev = t0
+            print("step trace (ms): " + " ".join(f"{(m - p_) * 1e3:.3f}" for m, p_ in zip(marks, [t0] + marks[:-1])) + f" | drain {(t1 - marks[-1]) * 1e3:.3f}", file=sys.stderr)
+        return t1 - t0
 
     k = 1
     for _ in range(args.warmup):

@@ -100,8 +100,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         hipError_t r1 = prio ? hipStreamCreateWithPriority(&h->stream, hipStreamDefault, hi) : hipStreamCreate(&h->stream);
         hipError_t r2 = prio ? hipStreamCreateWithPriority(&h->stream_b, hipStreamDefault, lo) : hipStreamCreate(&h->stream_b);
         if (r1 != hipSuccess || r2 != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
-        hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_t, hipStreamDefault, hi) : hipStreamCreate(&h->stream_t);
-        if (r3 != hipSuccess || hipEventCreateWithFlags(&h->ev_track_done, hipEventDisableTiming) != hipSuccess) { g_err = "hipStreamCreate failed"; ifx_destroy(h); return IFX_E_HIP; }
+        hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_s, hipStreamDefault, hi) : hipStreamCreate(&h->stream_s);
+        if (r3 != hipSuccess) { g_err = "hipStreamCreate failed"; ifx_destroy(h); return IFX_E_HIP; }
     }
     h->cur = h->stream;
     ALLOC(h->d_state, sizeof(DevState));
@@ -197,8 +197,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_slic_free(h);
     ifx_knn_free_all(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
-    if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
-    if (h->ev_track_done) hipEventDestroy(h->ev_track_done);
+    if (h->stream_s) hipStreamDestroy(h->stream_s);
     if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -271,7 +270,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "rgb_blocks") h->opt_rgb_blocks = std::max(0, std::min(1024, value));
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
-    else if (s == "track_aside") { ifx_drop_tracked(h); h->opt_track_aside = value; }
+    else if (s == "seg_aside") h->opt_seg_aside = value;
+    else if (s == "ff_union") h->opt_ff_union = value;
     else if (s == "fold_finish") h->opt_fold_finish = value;
     else if (s == "lazy_ids") { ifx_ids_ensure(h); h->opt_lazy_ids = value; }
     else if (s == "seg_device") h->opt_seg_device = value;
@@ -539,18 +539,12 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     FrameSlot& nf = h->slot[h->tick & 1];
     if (h->opt_track_ahead && h->opt_two_streams && nf.for_tick == h->tick && h->tick > 1) {
         ifx_bind_slot(h, h->tick & 1);
-        const bool aside = h->opt_track_aside && h->stream_t;
-        if (aside) {   // behind this frame's result, beside whatever the caller enqueues before the next frame
-            HIPCHK(h, hipStreamWaitEvent(h->stream_t, f.released, 0));
-            h->cur = h->stream_t;
-        }
-        HIPCHK(h, hipStreamWaitEvent(h->cur, nf.ready, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, nf.ready, 0));
         {
             StageTimer t(h, 0);
             ifx_tracker_model_side(h, 1);
             ifx_tracker_run_frame(h, 0);
         }
-        if (aside) { hipEventRecord(h->ev_track_done, h->stream_t); h->cur = h->stream; h->track_aside = 1; }
         ifx_bind_slot(h, s);
         h->tracked_ahead = h->tick;
     }
@@ -935,7 +929,6 @@ extern "C" int ifx_sync(ifx_t* h)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream_b));
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
-    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
@@ -1030,7 +1023,6 @@ extern "C" int ifx_stage_ms(ifx_t* h, float* ms4, int reset)
 {
     if (!h || !ms4) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));   // (a tracker run enqueued ahead has its stage markers there)
     stage_flush(h);
     for (int k = 0; k < 4; k++) ms4[k] = (float)h->stage_ms[k];
     if (reset) for (int k = 0; k < 4; k++) h->stage_ms[k] = 0;
@@ -1041,7 +1033,6 @@ extern "C" int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* l
 {
     if (!h || !kernel) return IFX_E_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->stream_t) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     ktime_flush(h);
     std::string s(kernel);
     if (s == "__reset__") { for (auto& k : h->ktimes) k = KernelTiming(); return IFX_OK; }

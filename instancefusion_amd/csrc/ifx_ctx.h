@@ -219,10 +219,9 @@ struct ifx {
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
-    hipStream_t stream_t = nullptr;     // the tracker run enqueued ahead of its frame goes here: whatever the caller enqueues between the two frames (a segmentation
-    hipEvent_t ev_track_done = nullptr; // call: 60 short launches) then runs beside its 170 launches instead of behind them; the main stream joins at the next frame (ifx_drop_tracked)
-    int track_aside = 0;                // a run on stream_t the main stream has not joined yet
-    int opt_track_aside = 1;
+    hipStream_t stream_s = nullptr;     // a segmentation call that finds the next frame's tracker already queued on the main stream runs here, beside it (the call
+    int opt_ff_union = 1;               // flood fill of the masks: two-way edges merged by union-find before the directed relaxation (k_ff_merge)
+    int opt_seg_aside = 1;              // is synchronous for the host, so nothing has to join afterwards); ifx_instance / ifx_slic / ifx_knn enqueue on h->cur throughout
     hipEvent_t ev_result = nullptr;     // the `released` event of the slot of the last frame (recorded after k_frame_result)
     const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
     const uint16_t* hint_depth = nullptr;
@@ -390,12 +389,8 @@ hipEvent_t ifx_event_get(ifx* h);
 void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a);
 void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
 
-// Forget a tracker run enqueued ahead (the caller is about to change something it read, or to consume it): whatever follows on the main stream is ordered behind it.
-static inline void ifx_drop_tracked(ifx* h)
-{
-    if (h->track_aside) { hipStreamWaitEvent(h->stream, h->ev_track_done, 0); h->track_aside = 0; }
-    h->tracked_ahead = 0;
-}
+// Forget a tracker run enqueued ahead (the caller is about to change something it read).
+static inline void ifx_drop_tracked(ifx* h) { h->tracked_ahead = 0; }
 
 #define LAUNCH(h, name, grid, block, kernel, ...)                                                  \
     do {                                                                                           \

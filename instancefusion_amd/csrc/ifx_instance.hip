@@ -6,6 +6,7 @@
 // first), model depth image, the vote update and the per-surfel arg-max scan over the planar vote
 // store (12 fully coalesced 16-B loads per lane).  The two CPU passes of the reference (box IoU
 // matching, depth flood fill) stay on the host, as in the reference.
+#include <chrono>
 #include "ifx_ctx.h"
 #include <string.h>
 #include <vector>
@@ -369,10 +370,10 @@ extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
     size_t bytes = (size_t)n * h->P;
     int r = ifx_ensure_masks(h, bytes);
     if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->cur));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(h->P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, n, h->P);
-    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -387,14 +388,14 @@ extern "C" int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_
     const size_t P = h->P, bytes = (size_t)n * P;
     int r = ifx_ensure_masks(h, bytes);
     if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(h->d_pdm, depth, P * 2, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, ori, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable, n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_pdm, depth, P * 2, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, bytes, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, ori, bytes, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable, n, hipMemcpyHostToDevice, h->cur));
     if ((r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, n, h->d_unavail))) return r;
-    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(unavailable, h->d_unavail, n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, bytes, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipMemcpyAsync(unavailable, h->d_unavail, n, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -411,11 +412,11 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
         count[0] = h->h_result->seg_counts[0]; count[1] = h->h_result->seg_counts[1];
     } else {
         int* cnt = h->d_inst_stats;
-        HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->cur));
         int gw = cdiv(h->w, downsample), gh = cdiv(h->h, downsample);
         LAUNCH(h, "check_project", dim3(cdiv(gw, 16), cdiv(gh, 16)), dim3(16, 16), k_check_project, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->w, h->h, downsample, cnt);
-        HIPCHK(h, hipMemcpyAsync(count, cnt, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(count, cnt, 8, hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
     }
     int w = h->w, hh = h->h;
     bool test1 = count[0] > (w / downsample * hh / downsample * 0.48 * 30);
@@ -488,11 +489,13 @@ __device__ __forceinline__ bool ff_pull(int& l, int dp_unused, int ql, int dq, i
     if ((float)abs(dq - dp) < depth_threshold_dev(dq)) { l = ql; return true; }   // edge q -> p, threshold of the source q
     return false;
 }
+// SYM: only the edges that exist in BOTH directions, no pointer jump, no `changed` flag -- the tile-local half of the union-find start (see k_ff_merge).
+template <bool SYM>
 __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 {
     __shared__ int s_lab[FF_T + 2][FF_T + 3];          // (+1 column: rows and columns land on different banks)
     __shared__ unsigned short s_d[FF_T + 2][FF_T + 4];
-    if (it > 0 && a.changed[it - 1] == 0) return;
+    if (!SYM && it > 0 && a.changed[it - 1] == 0) return;
     const int P = a.w * a.h, m = blockIdx.z;
     if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
         for (int q = 0; q < NL; q++) {
             const int t = tid + q * 256, ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2);
             const bool interior = lx >= 1 && lx <= FF_T && ly >= 1 && ly <= FF_T;
-            const int g = (interior && l[q] >= 0) ? lab[l[q]] : -1;   // one pointer jump: my label reaches me, so does ITS label
+            const int g = (!SYM && interior && l[q] >= 0) ? lab[l[q]] : -1;   // one pointer jump: my label reaches me, so does ITS label
             if (g >= 0 && g < l[q]) l[q] = g;
         }
 #pragma unroll
@@ -534,10 +537,12 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
                 unsigned int ch = 0;
 #pragma unroll
                 for (int x = 1; x <= FF_T; x++)
-                    if (l[x] >= 0 && l[x - 1] >= 0 && l[x - 1] < l[x] && (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x - 1])) { l[x] = l[x - 1]; ch |= 1u << (x - 1); }
+                    if (l[x] >= 0 && l[x - 1] >= 0 && l[x - 1] < l[x] && (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x - 1]) &&
+                        (!SYM || (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x]))) { l[x] = l[x - 1]; ch |= 1u << (x - 1); }
 #pragma unroll
                 for (int x = FF_T; x >= 1; x--)
-                    if (l[x] >= 0 && l[x + 1] >= 0 && l[x + 1] < l[x] && (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x + 1])) { l[x] = l[x + 1]; ch |= 1u << (x - 1); }
+                    if (l[x] >= 0 && l[x + 1] >= 0 && l[x + 1] < l[x] && (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x + 1]) &&
+                        (!SYM || (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x]))) { l[x] = l[x + 1]; ch |= 1u << (x - 1); }
                 if (ch) {
                     any = 1;
 #pragma unroll
@@ -557,7 +562,55 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
             if (l >= 0 && l != lab[y * a.w + x]) { lab[y * a.w + x] = l; dirty = 1; }
         }
     }
-    if (__syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
+    if (!SYM && __syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
+}
+
+// Union-find start of the fill (round 3).  Pixels joined by edges that exist in BOTH directions reach each other, so they end with the same label, whatever else
+// happens: their components can be merged with the lock-free union-find of connected-component labelling instead of walking labels across the image one tile
+// border per launch.  k_ff_relax<true> leaves every pixel pointing at the smallest pixel of its component INSIDE its tile (a forest of depth one, roots point at
+// themselves); k_ff_merge unites the trees across every tile border edge (the larger root is hung under the smaller: atomicMin, retried until it sticks);
+// k_ff_flatten points every pixel at its root = the smallest pixel of the whole component.  Every label is still "a pixel that reaches me", so the directed
+// relaxation that follows starts from a valid state and -- where every edge is two-way (model depth under 4 m: one threshold) -- finds nothing left to do.
+__device__ __forceinline__ int ff_find(const int* lab, int x)
+{
+    int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) { x = p; p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return x;
+}
+__global__ void k_ff_merge(FFArgs a)
+{
+    const int m = blockIdx.y;
+    if (a.skip[m]) return;
+    const int nbx = (a.w - 1) / FF_T, nby = (a.h - 1) / FF_T;   // vertical / horizontal tile borders inside the image
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nv = nbx * a.h, nh = nby * a.w;
+    if (t >= nv + nh) return;
+    int p, q;
+    if (t < nv) { const int b = t / a.h, y = t - b * a.h, x = (b + 1) * FF_T; p = y * a.w + x - 1; q = p + 1; }
+    else { const int u = t - nv, b = u / a.w, x = u - b * a.w, y = (b + 1) * FF_T; p = (y - 1) * a.w + x; q = p + a.w; }
+    int* lab = a.label + (size_t)m * a.w * a.h;
+    if (lab[p] < 0 || lab[q] < 0) return;
+    const int dp = a.depth[p], dq = a.depth[q];
+    const float dd = (float)abs(dp - dq);
+    if (!(dd < depth_threshold_dev(dp) && dd < depth_threshold_dev(dq))) return;
+    int ra = p, rb = q;
+    for (;;) {
+        ra = ff_find(lab, ra); rb = ff_find(lab, rb);
+        if (ra == rb) break;
+        if (ra > rb) { const int s_ = ra; ra = rb; rb = s_; }
+        const int old = atomicMin(lab + rb, ra);
+        if (old == rb) break;   // rb was a root and now hangs under ra
+        rb = old;               // somebody hung it elsewhere first: unite with that tree
+    }
+}
+__global__ void k_ff_flatten(FFArgs a)
+{
+    const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (k >= P || a.skip[m]) return;
+    int* lab = a.label + (size_t)m * P;
+    const int l = lab[k];
+    if (l < 0) return;
+    const int r = ff_find(lab, l);
+    if (r != l) __hip_atomic_store(lab + k, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // region sizes: one counter per root pixel; lanes of a wave grouped by label (regions are large)
@@ -642,26 +695,32 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     dim3 per_px(cdiv(P, 256), nm);
     dim3 tiles(cdiv(h->w, FF_T), cdiv(h->h, FF_T), nm);
     if (!resume) {
-        HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->stream));   // the verdict must not change who is skipped mid-way
-        HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->stream));
-        HIPCHK(h, hipMemsetAsync(a.changed, 0, FF_SLOTS * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->cur));
+        HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->cur));   // the verdict must not change who is skipped mid-way
+        HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->cur));
+        HIPCHK(h, hipMemsetAsync(a.changed, 0, FF_SLOTS * 4, h->cur));
         LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
+        if (h->opt_ff_union) {   // the two-way edges by union-find: three launches for what took the relaxation a launch per tile border crossed
+            const int pairs = ((h->w - 1) / FF_T) * h->h + ((h->h - 1) / FF_T) * h->w;
+            LAUNCH(h, "ff_local", tiles, dim3(256), k_ff_relax<true>, a, 0);
+            if (pairs > 0) LAUNCH(h, "ff_merge", dim3(cdiv(pairs, 256), nm), dim3(256), k_ff_merge, a);
+            LAUNCH(h, "ff_flatten", per_px, dim3(256), k_ff_flatten, a);
+        }
     }
     if (fixed_rounds > 0 && !resume) {
         if (fixed_rounds > FF_SLOTS) fixed_rounds = FF_SLOTS;
-        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, it);
+        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, it);
         a.gate = a.changed + (fixed_rounds - 1);
     } else {
         for (int round = 0; round < 64; round++) {
-            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->cur));
+            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, 0);
             // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
-            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->stream));
-            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
+            HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->cur));
+            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, 0);
             int changed = 0;
-            HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->cur));
+            HIPCHK(h, hipStreamSynchronize(h->cur));
             if (!changed) break;
         }
     }
@@ -706,8 +765,8 @@ static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
     LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     bbox.resize((size_t)(NI + nm) * 4);
-    HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -742,8 +801,8 @@ static int oseg_read_bboxes(ifx* h)
     const int nm = h->oseg_nm;
     LAUNCH(h, "bbox_flip", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_bbox_flip, h->d_bbox, NI + nm);
     h->oseg_bbox.resize((size_t)(NI + nm) * 4);
-    HIPCHK(h, hipMemcpyAsync(h->oseg_bbox.data(), h->d_bbox, h->oseg_bbox.size() * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->oseg_bbox.data(), h->d_bbox, h->oseg_bbox.size() * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     std::fill(h->oseg_cmp.begin(), h->oseg_cmp.end(), 0);
     compare_map(h, &h->oseg_bbox[NI * 4], &h->oseg_bbox[0], h->oseg_class.data(), nm, h->oseg_unavail, h->oseg_cmp);
     return IFX_OK;
@@ -765,7 +824,7 @@ static int oseg_mask_loop(ifx* h, bool after_eviction)
             int empty = first_not_used(h);
             if (empty == -1 && !resumed) {
                 h->clean_times++;
-                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->stream));
+                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->cur));
                 LAUNCH(h, "max_count", dim3(1024), dim3(256), k_max_count, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, h->d_inst_stats, h->d_inst_stats + NI);
                 h->oseg_m = m; h->oseg_state = 3; h->oseg_pending = 3;
                 return 1;
@@ -779,10 +838,10 @@ static int oseg_mask_loop(ifx* h, bool after_eviction)
     // step 4: labels of the owned surfels
     LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
     hipEvent_t eb = ifx_event_get(h);
-    hipEventRecord(eb, h->stream);
+    hipEventRecord(eb, h->cur);
     h->stage_pending.push_back({2, {h->oseg_ev, eb}});
     h->oseg_ev = nullptr;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     h->oseg_state = 0; h->oseg_pending = 0;
     return 0;
 }
@@ -796,8 +855,8 @@ extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const 
     ifx_vlist_reap(h);
     h->seg_counts_valid = 0;
     h->oseg_ev = ifx_event_get(h);
-    hipEventRecord(h->oseg_ev, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipEventRecord(h->oseg_ev, h->cur);
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     if (nm == 0) { h->event_pool.push_back(h->oseg_ev); h->oseg_ev = nullptr; return 0; }   // (an empty shard still takes part: the other ranks wait for its boxes)
     const int P = h->P;
     const size_t mbytes = (size_t)nm * P;
@@ -807,8 +866,8 @@ extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const 
     h->oseg_unavail.assign(nm, 0);
     h->oseg_cmp.assign((size_t)nm * NI, 0);
     h->oseg_class.assign(class_ids, class_ids + nm);
-    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->cur));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
     if (flags & 2) {
         r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
@@ -842,16 +901,16 @@ static int oseg_resume(ifx* h)
         h->oseg_state = 2; h->oseg_pending = 2;
         return 1;
     case 2:   // model depth merged -> flood fill (replicated), then the masks
-        HIPCHK(h, hipMemcpyAsync(h->d_unavail, h->oseg_unavail.data(), nm, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_unavail, h->oseg_unavail.data(), nm, hipMemcpyHostToDevice, h->cur));
         if ((r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail))) return r;
-        HIPCHK(h, hipMemcpyAsync(h->oseg_unavail.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->oseg_unavail.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
         h->oseg_state = 5;
         return oseg_mask_loop(h, false);
     case 3: {   // eviction statistics merged -> getInstanceTableCleanList (IF/Core/InstanceTable.cpp:185-224), clean, the boxes again
         int stats[NI * 2];
-        HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
         int* maxv = stats; int* sumv = stats + NI;
         int order[NI], cl[NI];
         for (int i = 0; i < NI; i++) order[i] = i;
@@ -861,9 +920,9 @@ static int oseg_resume(ifx* h)
         for (int i = 0; i < NI; i++) cl[i] = 0;
         for (int i = 0; i < 20; i++) cl[order[i]] = 1;
         for (int q = 0; q < NI; q++) if (cl[q] == 1) h->inst_class[q] = -1;
-        HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->cur));
         LAUNCH(h, "clean_table", dim3(1024), dim3(256), k_clean_table, h->d_state, h->votes, h->cap, h->d_clean_list);
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
         h->oseg_state = 4;
         return oseg_launch_bboxes(h);
     }
@@ -883,8 +942,17 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
 {
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
+    // The next frame's tracker is already queued on the main stream (enqueue_frame, "tracked ahead") and touches nothing this call does: the call's ~60 short
+    // launches then go to a stream of their own and run beside the tracker's 170 instead of behind them.  The call ends with the host waiting for its stream,
+    // so whatever the caller enqueues next is ordered behind it as before.
+    const bool aside = h->opt_seg_aside && h->stream_s && h->opt_seg_device && !h->own && h->tracked_ahead == h->tick && h->cur == h->stream;
+    if (aside) {
+        if (h->ev_result) HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_result, 0));   // behind the frame the call belongs to
+        h->cur = h->stream_s;
+    }
     const int r = h->opt_seg_device ? process_segmentation_device(h, rgb, depth, masks_in, class_ids, nm, frame, flags)
                                     : process_segmentation_host(h, rgb, depth, masks_in, class_ids, nm, frame, flags);
+    if (aside) { hipStreamSynchronize(h->stream_s); h->cur = h->stream; }
     // a call that failed part-way may have updated votes without the label scan that follows them: the incremental scan of the next call assumes
     // that votes outside its own id image are unchanged since the last scan, so the next call scans everything
     if (r != IFX_OK) h->labels_stale_all = 1;
@@ -904,11 +972,11 @@ static int seg_host_mask_loop(ifx* h, int nm, const int32_t* class_ids, int m_st
             int empty = first_not_used(h);
             if (empty == -1) {
                 h->clean_times++;
-                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->stream));
+                HIPCHK(h, hipMemsetAsync(h->d_inst_stats, 0, NI * 2 * 4, h->cur));
                 LAUNCH(h, "max_count", dim3(1024), dim3(256), k_max_count, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, h->d_inst_stats, h->d_inst_stats + NI);
                 int stats[NI * 2];
-                HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(h, hipStreamSynchronize(h->stream));
+                HIPCHK(h, hipMemcpyAsync(stats, h->d_inst_stats, sizeof(stats), hipMemcpyDeviceToHost, h->cur));
+                HIPCHK(h, hipStreamSynchronize(h->cur));
                 // getInstanceTableCleanList, IF/Core/InstanceTable.cpp:185-224
                 int* maxv = stats; int* sumv = stats + NI;
                 int order[NI], cl[NI];
@@ -919,10 +987,10 @@ static int seg_host_mask_loop(ifx* h, int nm, const int32_t* class_ids, int m_st
                 for (int i = 0; i < NI; i++) cl[i] = 0;
                 for (int i = 0; i < 20; i++) cl[order[i]] = 1;
                 for (int q = 0; q < NI; q++) if (cl[q] == 1) h->inst_class[q] = -1;
-                HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipMemcpyAsync(h->d_clean_list, cl, sizeof(cl), hipMemcpyHostToDevice, h->cur));
                 LAUNCH(h, "clean_table", dim3(1024), dim3(256), k_clean_table, h->d_state, h->votes, h->cap, h->d_clean_list);
                 h->labels_stale_all = 1;   // votes of every surfel that carried an evicted instance changed
-                HIPCHK(h, hipStreamSynchronize(h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->cur));
                 r = run_bboxes(h, nm, bbox);
                 if (r) return r;
                 std::fill(cmp.begin(), cmp.end(), 0);
@@ -959,8 +1027,8 @@ static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_
     if (flags & 1) ifx_vlist_reap(h);
     h->seg_counts_valid = 0;
     hipEvent_t ea = ifx_event_get(h);
-    hipEventRecord(ea, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipEventRecord(ea, h->cur);
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     int n = 0;
     HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
     if (nm == 0 || n == 0) { h->event_pool.push_back(ea); return IFX_OK; }
@@ -970,8 +1038,8 @@ static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_
     int r = ifx_ensure_masks(h, mbytes);
     if (r) return r;
     // the masks stay on the device from here on: d_masks_ori = "BAK ORI MASK" (:705-706), d_masks = working copy
-    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, masks_in, mbytes, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->cur));
     // step 0_1
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
     // steps -1_1 .. -1_3 (superpixel refinement)
@@ -987,11 +1055,11 @@ static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_
     compare_map(h, &bbox[NI * 4], &bbox[0], class_ids, nm, unavailable, cmp);
     // step 3_0: model depth under the camera, then the flood fill of every usable mask (device)
     LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
-    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_unavail, unavailable.data(), nm, hipMemcpyHostToDevice, h->cur));
     r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail);
     if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(unavailable.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(unavailable.data(), h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     // step 3
     r = seg_host_mask_loop(h, nm, class_ids, 0, cmp, unavailable, bbox);
     if (r) return r;
@@ -1000,9 +1068,9 @@ static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_
     // flannKnnVoteSurfelMap (isflann, :1051)
     if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
     hipEvent_t eb = ifx_event_get(h);
-    hipEventRecord(eb, h->stream);
+    hipEventRecord(eb, h->cur);
     h->stage_pending.push_back({2, {ea, eb}});
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -1079,31 +1147,43 @@ __global__ void k_seg_register(SegCtl* __restrict__ s, const uint8_t* __restrict
     for (int t = threadIdx.x; t < NI; t += blockDim.x) s->inst_class[t] = s_cls[t];
     for (int t = threadIdx.x; t < nm; t += blockDim.x) s->target[t] = s_tgt[t];
 }
-// updateSurfelMapInstance for mask m with the instance the device chose for it; a launch for a mask without one (or behind the point where the host takes over)
-// returns at its first instruction
-__global__ void k_vote_update_m(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ masks, int P, int cap, const SegCtl* __restrict__ s, int m,
-                                float* __restrict__ votes, IdMap im)
+// updateSurfelMapInstance (IF/Core/InstanceFusionCuda.cu:1100-1150) for every mask with the instance the device chose for it; masks without one (or behind the
+// point where the host takes over) are passed over.  All masks in one launch: the update is a saturating add of a positive increment, so the masks' updates of a surfel commute (any order ends at
+// min(65535, count + sum of increments)) and a pixel can serve every mask it lies in at once
+__global__ void k_vote_update_all(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ masks, int P, int cap, const SegCtl* __restrict__ s, int nm,
+                                  float* __restrict__ votes, IdMap im)
 {
-    if (s->ff_incomplete || (s->evict_at >= 0 && m >= s->evict_at)) return;
-    const int instanceID = s->target[m];
-    if (instanceID < 0) return;
+    if (s->ff_incomplete) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
-    if (!(masks[(size_t)m * P + k] > 0)) return;
-    const int id = idmap_slot(im, st->count, ids[k]);
-    if (id < 0) return;
-    const int fi = instanceID / 2, p = instanceID % 2, inc = m + 1;
-    unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
-    unsigned int old = *addr, assumed;
-    do {
-        assumed = old;
-        int a, b;
-        vote_decode(__uint_as_float(assumed), a, b);
-        if (p == 0) a += inc; else b += inc;
-        if (a >= 65535) a = 65535;
-        if (b >= 65535) b = 65535;
-        old = atomicCAS(addr, assumed, __float_as_uint(vote_encode(a, b)));
-    } while (old != assumed);
+    const int last = s->evict_at >= 0 ? min(nm, s->evict_at) : nm;
+    unsigned int in = 0;   // (nm <= 256: eight words would cover it; the masks of a call are few -- handled 32 at a time)
+    int id = -2;
+    for (int m0 = 0; m0 < last; m0 += 32) {
+        in = 0;
+        const int mc = min(32, last - m0);
+        for (int j = 0; j < mc; j++) in |= (masks[(size_t)(m0 + j) * P + k] > 0 ? 1u : 0u) << j;
+        while (in) {
+            const int j = __ffs(in) - 1;
+            in &= in - 1;
+            const int m = m0 + j, instanceID = s->target[m];
+            if (instanceID < 0) continue;
+            if (id == -2) id = idmap_slot(im, st->count, ids[k]);
+            if (id < 0) return;
+            const int fi = instanceID / 2, p = instanceID % 2, inc = m + 1;
+            unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
+            unsigned int old = *addr, assumed;
+            do {
+                assumed = old;
+                int a, b;
+                vote_decode(__uint_as_float(assumed), a, b);
+                if (p == 0) a += inc; else b += inc;
+                if (a >= 65535) a = 65535;
+                if (b >= 65535) b = 65535;
+                old = atomicCAS(addr, assumed, __float_as_uint(vote_encode(a, b)));
+            } while (old != assumed);
+        }
+    }
 }
 
 static int seg_ensure_ctl(ifx* h, size_t mask_bytes)
@@ -1123,14 +1203,20 @@ static int seg_ensure_ctl(ifx* h, size_t mask_bytes)
 
 static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
 {
+    static const bool trace = getenv("IFX_SEG_TRACE") != nullptr;   // diagnostic: where the host is inside a call (us since entry, to stderr)
+    const auto t_in = std::chrono::steady_clock::now();
+    auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count(); };
+    double t_res = 0, t_ids = 0, t_stage = 0, t_enq = 0, t_sync = 0;
     if (flags & 1) ifx_vlist_reap(h);
     // the frame's result, not the stream: the next frame's tracker may already be queued behind it, and nothing here has to wait for that
     int n = 0;
     if (h->seg_counts_valid && h->ev_result) { HIPCHK(h, hipEventSynchronize(h->ev_result)); n = h->h_result->count; }
-    else { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost)); }
+    else { HIPCHK(h, hipStreamSynchronize(h->cur)); HIPCHK(h, hipMemcpy(&n, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost)); }
     h->seg_counts_valid = 0;
     if (nm == 0 || n == 0) return IFX_OK;
+    t_res = us();
     ifx_ids_ensure(h);   // the call reads the id image under every mask pixel: the whole image, if the frame rendered only the sampled lattice
+    t_ids = us();
     const int P = h->P;
     const size_t mbytes = (size_t)nm * P;
     int r = ifx_ensure_masks(h, mbytes);
@@ -1141,12 +1227,13 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     hc->ff_incomplete = 0; hc->evict_at = -1; hc->nm = nm; hc->pad = 0;
     for (int i = 0; i < NI; i++) hc->inst_class[i] = h->inst_class[i];
     for (int m = 0; m < 256; m++) { hc->cls[m] = m < nm ? class_ids[m] : -1; hc->best[m] = -1; hc->target[m] = -1; }
+    t_stage = us();
     hipEvent_t ea = ifx_event_get(h);
-    hipEventRecord(ea, h->stream);
-    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, h->h_masks_stage, mbytes, hipMemcpyHostToDevice, h->stream));   // pinned: a true asynchronous copy
-    HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_unavail, 0, nm, h->stream));
+    hipEventRecord(ea, h->cur);
+    HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, h->h_masks_stage, mbytes, hipMemcpyHostToDevice, h->cur));   // pinned: a true asynchronous copy
+    HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->cur));
+    HIPCHK(h, hipMemsetAsync(h->d_unavail, 0, nm, h->cur));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
     if (flags & 2) {
         r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
@@ -1158,29 +1245,30 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "seg_compare", dim3(1), dim3(256), k_seg_compare, dc, (const int*)h->d_bbox, h->d_unavail);
     LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
-    const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : 24;
+    const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : (h->opt_ff_union ? 6 : 24);   // (after the union-find start the first relaxation normally finds the fixpoint: the rest are spares for one-way edges)
     r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, rounds);
     if (r) return r;
     const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);
     const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
     LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, gate);
-    for (int m = 0; m < nm; m++)
-        LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_m, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, m, h->votes, ifx_idmap(h));
+    LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
     seg_label_scan(h);
     uint8_t* h_un = (uint8_t*)h->h_segctl + sizeof(SegCtl);
-    HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
+    t_enq = us();
+    HIPCHK(h, hipStreamSynchronize(h->cur));
+    t_sync = us();
+    if (trace) fprintf(stderr, "seg call: result %.0f  ids %.0f  staged %.0f  enqueued %.0f  synced %.0f us (nm %d)\n", t_res, t_ids, t_stage, t_enq, t_sync, nm);
     if (hc->ff_incomplete) {   // the fill needs more relaxations than the schedule holds: finish it with the host looking, then the tail again (nothing was voted yet)
         r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
         if (r) return r;
         LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, (const int*)nullptr);
-        for (int m = 0; m < nm; m++)
-            LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_m, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, m, h->votes, ifx_idmap(h));
+        LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
         seg_label_scan(h);
-        HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
     }
     for (int i = 0; i < NI; i++) h->inst_class[i] = hc->inst_class[i];
     if (hc->evict_at >= 0) {   // the table is full at this mask: the reference evicts its twenty weakest instances and goes on -- from here the host-driven loop
@@ -1193,9 +1281,9 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     }
     if (flags & 1) { r = ifx_knn_vote(h, nullptr); if (r) return r; }
     hipEvent_t eb = ifx_event_get(h);
-    hipEventRecord(eb, h->stream);
+    hipEventRecord(eb, h->cur);
     h->stage_pending.push_back({2, {ea, eb}});
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -1222,7 +1310,7 @@ extern "C" int ifx_labels(ifx_t* h, int32_t* out, int max_n)
     ifx_scan_exclusive(h, h->scan_flags, h->cap, h->scan_out, &h->d_state->seg_counts[1]);
     LAUNCH(h, "gather_labels", dim3(cdiv(h->cap, 256)), dim3(256), k_gather_labels, h->d_state, (const float2*)h->tm, h->labels, h->scan_out, h->cap, h->labels2);
     DevState hs;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
     int n = std::min(hs.seg_counts[1], max_n);
     HIPCHK(h, hipMemcpy(out, h->labels2, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -1236,8 +1324,8 @@ extern "C" int ifx_set_instance_gt(ifx_t* h, const uint8_t* gt_hw)
     if (!h) return IFX_E_INVALID;
     if (!gt_hw) { h->inst_gt_on = 0; return IFX_OK; }
     if (!h->d_inst_gt) HIPCHK(h, hipMalloc(&h->d_inst_gt, (size_t)h->P));
-    HIPCHK(h, hipMemcpyAsync(h->d_inst_gt, gt_hw, (size_t)h->P, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // gt_hw is the caller's
+    HIPCHK(h, hipMemcpyAsync(h->d_inst_gt, gt_hw, (size_t)h->P, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));   // gt_hw is the caller's
     h->inst_gt_on = 1;
     ifx_drop_tracked(h);
     return IFX_OK;
@@ -1263,13 +1351,13 @@ extern "C" int ifx_precision_recall(ifx_t* h, int32_t* inst_num96, int32_t* gt_n
     const size_t n = IFX_NUM_INSTANCES + 256 + 256 * IFX_NUM_INSTANCES;
     int* d = nullptr;
     HIPCHK(h, hipMalloc(&d, n * 4));
-    hipMemsetAsync(d, 0, n * 4, h->stream);
-    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->stream);
+    hipMemsetAsync(d, 0, n * 4, h->cur);
+    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->cur);
     LAUNCH(h, "precision_recall", dim3(cdiv(h->cap, 256)), dim3(256), k_precision_recall, (const DevState*)h->d_state, (const float2*)h->col, (const float2*)h->tm,
            (const float4*)h->ic, (const float*)h->d_inst_color, d, d + IFX_NUM_INSTANCES, d + IFX_NUM_INSTANCES + 256);
     std::vector<int32_t> host(n);
-    hipError_t e = hipMemcpyAsync(host.data(), d, n * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipMemcpyAsync(host.data(), d, n * 4, hipMemcpyDeviceToHost, h->cur);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
     hipFree(d);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
     memcpy(inst_num96, host.data(), IFX_NUM_INSTANCES * 4);
@@ -1302,8 +1390,8 @@ extern "C" int ifx_render_project_map(ifx_t* h, float* out_rgba, float* d_out_rg
     }
     LAUNCH(h, "render_project", dim3(cdiv(h->P, 256)), dim3(256), k_render_project, (const DevState*)h->d_state, (const int32_t*)h->ids_after, (const float2*)h->col, h->P, (float4*)dst);
     if (out_rgba) {
-        HIPCHK(h, hipMemcpyAsync(out_rgba, dst, (size_t)h->P * 16, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(out_rgba, dst, (size_t)h->P * 16, hipMemcpyDeviceToHost, h->cur));
+        HIPCHK(h, hipStreamSynchronize(h->cur));
     }
     return IFX_OK;
 }
@@ -1504,14 +1592,14 @@ static int bb_compute(ifx* h, float* ground_normal3, float* gc16, float* inst16,
     BBCell* d_cells = nullptr;
     HIPCHK(h, hipMalloc(&d_vote, nv * 4));
     if (hipMalloc(&d_cells, sizeof(cells)) != hipSuccess) { hipFree(d_vote); h->err = "hipMalloc failed"; return IFX_E_HIP; }
-    hipMemsetAsync(d_vote, 0, nv * 4, h->stream);
-    hipMemcpyAsync(d_cells, cells, sizeof(cells), hipMemcpyHostToDevice, h->stream);
-    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->stream);
+    hipMemsetAsync(d_vote, 0, nv * 4, h->cur);
+    hipMemcpyAsync(d_cells, cells, sizeof(cells), hipMemcpyHostToDevice, h->cur);
+    hipMemcpyAsync(h->d_inst_color, h->inst_color, sizeof(h->inst_color), hipMemcpyHostToDevice, h->cur);
     LAUNCH(h, "normal_vote", dim3(2048), dim3(256), k_normal_vote, (const DevState*)h->d_state, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm,
            (const float*)h->d_inst_color, (const BBCell*)d_cells, d_vote, d_vote + BB_CELLS);
     std::vector<int> votes(nv);
-    hipError_t e = hipMemcpyAsync(votes.data(), d_vote, nv * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipMemcpyAsync(votes.data(), d_vote, nv * 4, hipMemcpyDeviceToHost, h->cur);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
     hipFree(d_vote); hipFree(d_cells);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
     // ground normal: the cell with most votes (IF/Core/InstanceFusion.cpp:1289-1328, including its `- 1` on the longitude index)
@@ -1533,8 +1621,8 @@ static int bb_compute(ifx* h, float* ground_normal3, float* gc16, float* inst16,
     if (gc16) memcpy(gc16, gc, 64);
     if (inst16) memcpy(inst16, instm, sizeof(instm));
     if (ground_votes) memcpy(ground_votes, votes.data(), BB_CELLS * 4);
-    HIPCHK(h, hipMemcpyAsync(d_inv, inv, sizeof(inv), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_inv, inv, sizeof(inv), hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }
 
@@ -1550,11 +1638,11 @@ extern "C" int ifx_map_bounding_boxes(ifx_t* h, int bbox_type, float ratio, floa
     if (hipMalloc(&d_box, IFX_NUM_INSTANCES * 6 * 4) != hipSuccess) { hipFree(d_inv); h->err = "hipMalloc failed"; return IFX_E_HIP; }
     int init[IFX_NUM_INSTANCES * 6];
     for (int i = 0; i < IFX_NUM_INSTANCES; i++) { init[i * 6] = init[i * 6 + 2] = init[i * 6 + 4] = 999999999; init[i * 6 + 1] = init[i * 6 + 3] = init[i * 6 + 5] = -999999999; }
-    hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, h->cur);
     LAUNCH(h, "find_bbox", dim3(2048), dim3(256), k_find_bbox, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->col, (const float2*)h->tm,
            (const float*)h->d_inst_color, ratio, (const float*)d_inv, (const float*)(d_inv + 16), bbox_type ? 1 : 0, d_box);
-    hipError_t e = hipMemcpyAsync(init, d_box, sizeof(init), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipMemcpyAsync(init, d_box, sizeof(init), hipMemcpyDeviceToHost, h->cur);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
     hipFree(d_box); hipFree(d_inv);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return IFX_E_HIP; }
     for (int k = 0; k < IFX_NUM_INSTANCES * 6; k++) boxes96x6[k] = init[k] / ratio;   // :1424-1430
@@ -1608,7 +1696,7 @@ extern "C" int ifx_instance_point_cloud(ifx_t* h, int bbox_type, int32_t* counts
     int r = bb_compute(h, nullptr, nullptr, nullptr, nullptr, d_inv);
     if (r) { hipFree(d_inv); return r; }
     int* d_cnt = h->d_inst_stats;
-    hipMemsetAsync(d_cnt, 0, IFX_NUM_INSTANCES * 4, h->stream);
+    hipMemsetAsync(d_cnt, 0, IFX_NUM_INSTANCES * 4, h->cur);
     const int n = h->cap;
     LAUNCH(h, "inst_flags", dim3(cdiv(n, 256)), dim3(256), k_inst_flags, (const DevState*)h->d_state, (const float2*)h->col, (const float2*)h->tm, (const float*)h->d_inst_color, inst, n,
            h->scan_flags, d_cnt);
@@ -1620,8 +1708,8 @@ extern "C" int ifx_instance_point_cloud(ifx_t* h, int bbox_type, int32_t* counts
         LAUNCH(h, "inst_records", dim3(cdiv(n, 256)), dim3(256), k_inst_records, (const int*)h->scan_flags, (const int*)h->scan_out, n, max_records, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float*)(bbox_type ? d_inv : d_inv + 16 + 16 * inst), d_out);
     }
-    hipError_t e = hipMemcpyAsync(counts96, d_cnt, IFX_NUM_INSTANCES * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipMemcpyAsync(counts96, d_cnt, IFX_NUM_INSTANCES * 4, hipMemcpyDeviceToHost, h->cur);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
     if (e == hipSuccess && inst >= 0) {
         written = std::min(counts96[inst], max_records);
         if (written > 0) e = hipMemcpy(out10, d_out, (size_t)written * 40, hipMemcpyDeviceToHost);

@@ -323,8 +323,8 @@ int ifx_knn_vote(ifx* h, int32_t* d_nbr_out)
     int* cell_id = fill + cells;
     float4* sorted = (float4*)(cell_id + cap);   // 16-B aligned: header 64 ints, cells and cap are multiples of 4 after rounding below
     int* total = (int*)(sorted + cap);
-    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->cur));
+    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->cur));
     LAUNCH(h, "knn_bounds_init", dim3(1), dim3(64), k_knn_bounds_init, g);
     LAUNCH(h, "knn_bounds", dim3(1024), dim3(256), k_knn_bounds, h->d_state, (const float4*)h->pc, (const float2*)h->tm, g);
     LAUNCH(h, "knn_grid", dim3(1), dim3(64), k_knn_grid, g);
@@ -345,11 +345,11 @@ extern "C" int ifx_knn_vote_colour(ifx_t* h, int32_t* nbr_out, int max_n)
     int32_t* d_nbr = nullptr;
     if (nbr_out && max_n > 0) {
         HIPCHK(h, hipMalloc(&d_nbr, (size_t)h->cap * KNN * 4));
-        HIPCHK(h, hipMemsetAsync(d_nbr, 0xFF, (size_t)h->cap * KNN * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(d_nbr, 0xFF, (size_t)h->cap * KNN * 4, h->cur));
     }
     int r = ifx_knn_vote(h, d_nbr);
-    if (!r && d_nbr) r = hipMemcpyAsync(nbr_out, d_nbr, (size_t)std::min(max_n, h->cap) * KNN * 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess ? IFX_OK : IFX_E_HIP;
-    hipStreamSynchronize(h->stream);
+    if (!r && d_nbr) r = hipMemcpyAsync(nbr_out, d_nbr, (size_t)std::min(max_n, h->cap) * KNN * 4, hipMemcpyDeviceToHost, h->cur) == hipSuccess ? IFX_OK : IFX_E_HIP;
+    hipStreamSynchronize(h->cur);
     if (d_nbr) hipFree(d_nbr);
     return r;
 }
@@ -360,14 +360,14 @@ extern "C" int ifx_owner_knn_export(ifx_t* h, void** d_points, void** d_labels, 
     if (!h || !d_points || !d_labels || !n) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_knn_export: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     ifx_vlist_reap(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     int cnt = 0;
     HIPCHK(h, hipMemcpy(&cnt, &h->d_state->count, sizeof(int), hipMemcpyDeviceToHost));
     if (!h->d_kexp) HIPCHK(h, hipMalloc(&h->d_kexp, (size_t)h->cap * 20));
     float4* pts = (float4*)h->d_kexp;
     int32_t* lab = (int32_t*)(pts + h->cap);
     if (cnt > 0) LAUNCH(h, "knnx_export", dim3(1024), dim3(256), k_knnx_export, h->d_state, (const float4*)h->pc, (const float2*)h->tm, (const uint32_t*)h->seq, h->labels, pts, lab);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     *d_points = pts; *d_labels = lab; *n = cnt;
     return IFX_OK;
 }
@@ -396,8 +396,8 @@ extern "C" int ifx_owner_knn_vote(ifx_t* h, const void* d_all_points, const void
     int* total = (int*)(aux + capx);
     const float4* pts = (const float4*)d_all_points;
     const int32_t* lab = (const int32_t*)d_all_labels;
-    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(counts, 0, cells * 4, h->cur));
+    HIPCHK(h, hipMemsetAsync(fill, 0, cells * 4, h->cur));
     LAUNCH(h, "knn_bounds_init", dim3(1), dim3(64), k_knn_bounds_init, g);
     LAUNCH(h, "knnx_bounds", dim3(1024), dim3(256), k_knnx_bounds, pts, n_all, g);
     LAUNCH(h, "knn_grid", dim3(1), dim3(64), k_knn_grid, g);
@@ -406,6 +406,6 @@ extern "C" int ifx_owner_knn_vote(ifx_t* h, const void* d_all_points, const void
     if (r) return r;
     LAUNCH(h, "knnx_scatter", dim3(2048), dim3(256), k_knnx_scatter, pts, lab, n_all, cell_id, starts, fill, sorted, aux);
     LAUNCH(h, "knnx_vote", dim3(cdiv(n_all, 128)), dim3(128), k_knnx_vote, g, starts, counts, sorted, aux, total, own_offset, own_n, h->d_inst_color, (float2*)h->col);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }

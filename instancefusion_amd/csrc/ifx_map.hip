@@ -159,7 +159,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_scan_final(const int* __restric
 }
 int ifx_scan_exclusive(ifx* h, const int* d_flags, int n, int* d_out, int* d_total)
 {
-    if (n <= 0) { if (d_total) hipMemsetAsync(d_total, 0, 4, h->stream); return IFX_OK; }
+    if (n <= 0) { if (d_total) hipMemsetAsync(d_total, 0, 4, h->cur); return IFX_OK; }
     int nb = cdiv(n, SCAN_TILE);
     LAUNCH(h, "scan_reduce", dim3(nb), dim3(MAP_THREADS), k_scan_reduce, d_flags, n, h->scan_block);
     LAUNCH(h, "scan_sums", dim3(1), dim3(1024), k_scan_sums, h->scan_block, nb, d_total);

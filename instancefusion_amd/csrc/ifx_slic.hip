@@ -689,7 +689,7 @@ int slic_run(ifx* h, SlicBuf* b)
     float nxy = 1.0f / (1.4242f * SPX), ncol = 5.0f / 1.7321f;   // seg_engine_GPU ctor :40-56 (XYZ)
     ncol *= ncol; nxy *= nxy;
     dim3 cells(cdiv(w, 16), cdiv(hh, 16)), tile(16, 16);
-    HIPCHK(h, hipMemsetAsync(b->seg, 0, (size_t)P * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(b->seg, 0, (size_t)P * 4, h->cur));
     LAUNCH(h, "slic_cvt", dim3(cdiv(P, 256)), dim3(256), k_slic_cvt, b->rgb, b->xyz, P);
     LAUNCH(h, "slic_init", dim3(cdiv(S, 256)), dim3(256), k_slic_init, b->xyz, b->ccol, b->cxy, b->mw, b->mh, w, hh);
     LAUNCH(h, "slic_assoc", cells, tile, k_slic_assoc, b->xyz, b->ccol, b->cxy, b->seg, b->mw, b->mh, w, hh, 0.6f, nxy, ncol);
@@ -707,8 +707,8 @@ int merge_run(ifx* h, SlicBuf* b)
     const int w = h->w, hh = h->h, P = b->P, S = b->spn;
     float4 cam = make_float4(h->cfg.cx, h->cfg.cy, (float)(1.0 / (double)h->cfg.fx), (float)(1.0 / (double)h->cfg.fy));
     dim3 cells(cdiv(w, 64), cdiv(hh, 4)), tile(64, 4);
-    HIPCHK(h, hipMemsetAsync(b->sum1, 0, (size_t)S * NSUM * 2 * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(b->adj, 0, (size_t)S * b->adj_words * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(b->sum1, 0, (size_t)S * NSUM * 2 * 8, h->cur));
+    HIPCHK(h, hipMemsetAsync(b->adj, 0, (size_t)S * b->adj_words * 4, h->cur));
     LAUNCH(h, "sp_gauss", cells, tile, k_sp_gauss, b->depth, b->dg, w, hh);
     LAUNCH(h, "sp_posnor", cells, tile, k_sp_posnor, b->dg, cam, w, hh, S, b->pos, b->nor, b->seg);
     LAUNCH(h, "sp_sums", dim3(cdiv(w, 16), cdiv(hh, 16)), dim3(16, 16), k_sp_sums, b->seg, b->dg, b->pos, b->nor, w, hh, b->sum1, b->adj, b->adj_words);
@@ -738,14 +738,14 @@ int filter_run(ifx* h, SlicBuf* b, uint8_t* d_masks, int nm, bool by_superpixel)
     int* num_key = b->num + need;
     dim3 cells(cdiv(h->w, 16), cdiv(h->h, 16)), tile(16, 16);
     if (by_superpixel) {
-        HIPCHK(h, hipMemsetAsync(num_key, 0, need * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(num_key, 0, need * 4, h->cur));
         LAUNCH(h, "sp_count", cells, tile, k_sp_count, b->seg, d_masks, nm, h->w, h->h, S, num_key);
         hipEvent_t ea_ = nullptr;
         if (h->opt_kernel_timing) ifx_ktime_begin(h, "sp_count_regions", &ea_);
-        hipLaunchKernelGGL(k_sp_count_regions, dim3(nm + 1), dim3(256), (size_t)S * 4, h->stream, num_key, b->final_of, S, b->num);
+        hipLaunchKernelGGL(k_sp_count_regions, dim3(nm + 1), dim3(256), (size_t)S * 4, h->cur, num_key, b->final_of, S, b->num);
         if (h->opt_kernel_timing) ifx_ktime_end(h, "sp_count_regions", ea_);
     } else {
-        HIPCHK(h, hipMemsetAsync(b->num, 0, need * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(b->num, 0, need * 4, h->cur));
         LAUNCH(h, "sp_count", cells, tile, k_sp_count, b->fin, d_masks, nm, h->w, h->h, S, b->num);
     }
     LAUNCH(h, "sp_filter", dim3(cdiv(P, 256)), dim3(256), k_sp_filter, b->fin, d_masks, nm, P, S, b->num);
@@ -778,8 +778,8 @@ int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int
     // memory would make the call wait for everything queued in front of it
     std::memcpy(h->rgb_stage, rgb, P * 3);
     std::memcpy(h->depth_stage, depth, P * 2);
-    HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->cur));
     if ((r = slic_run(h, b))) return r;
     if ((r = merge_run(h, b))) return r;
     return filter_run(h, b, h->d_masks, nm, true);
@@ -792,10 +792,10 @@ extern "C" int ifx_slic_segment(ifx_t* h, const uint8_t* rgb, int32_t* seg_out)
     SlicBuf* b;
     int r = slic_buffers(h, &b);
     if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(b->rgb, rgb, (size_t)b->P * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->rgb, rgb, (size_t)b->P * 3, hipMemcpyHostToDevice, h->cur));
     if ((r = slic_run(h, b))) return r;
-    HIPCHK(h, hipMemcpyAsync(seg_out, b->seg, (size_t)b->P * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(seg_out, b->seg, (size_t)b->P * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return b->mw * b->mh;
 }
 
@@ -806,13 +806,13 @@ extern "C" int ifx_merge_superpixels(ifx_t* h, const uint16_t* depth, int32_t* s
     int r = slic_buffers(h, &b);
     if (r) return r;
     const size_t P = b->P;
-    HIPCHK(h, hipMemcpyAsync(b->depth, depth, P * 2, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(b->seg, seg_inout, P * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->depth, depth, P * 2, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(b->seg, seg_inout, P * 4, hipMemcpyHostToDevice, h->cur));
     if ((r = merge_run(h, b))) return r;
-    HIPCHK(h, hipMemcpyAsync(seg_inout, b->seg, P * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(final_out, b->fin, P * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(b->h_info.data(), b->info, (size_t)b->spn * SPI_SIZE * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(seg_inout, b->seg, P * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipMemcpyAsync(final_out, b->fin, P * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipMemcpyAsync(b->h_info.data(), b->info, (size_t)b->spn * SPI_SIZE * 4, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     if (info_out) std::memcpy(info_out, b->h_info.data(), (size_t)b->spn * SPI_SIZE * 4);
     return b->spn;
 }
@@ -826,10 +826,10 @@ extern "C" int ifx_mask_superpixel_filter(ifx_t* h, const int32_t* final_ids, ui
     if (r) return r;
     const size_t P = b->P;
     if ((r = ifx_ensure_masks(h, (size_t)nm * P))) return r;
-    HIPCHK(h, hipMemcpyAsync(b->fin, final_ids, P * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, (size_t)nm * P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->fin, final_ids, P * 4, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->d_masks, masks, (size_t)nm * P, hipMemcpyHostToDevice, h->cur));
     if ((r = filter_run(h, b, h->d_masks, nm, false))) return r;
-    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, (size_t)nm * P, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(masks, h->d_masks, (size_t)nm * P, hipMemcpyDeviceToHost, h->cur));
+    HIPCHK(h, hipStreamSynchronize(h->cur));
     return IFX_OK;
 }

@@ -229,6 +229,7 @@ struct ifx {
     int tick = 1;
     int ids_pending = 0;
     int opt_fold_finish = 1;            // view-list frames: the end-of-pass sums (dense test, whetherDoSegmentation) ride in k_splat_resolve instead of a launch of their own
+    int ids_view_ok = 0;                // the cached view list still describes store and pose of the frame that drew the sparse id image (ifx_ids_ensure may walk it)
     int opt_lazy_ids = 1;               // the frame renders the id image on the lattice whetherDoSegmentation samples; the whole image on demand (ifx_ids_ensure)
     int ids_full_valid = 1, ids_sparse_frame = 0;
     // options
@@ -390,7 +391,7 @@ void ifx_ktime_begin(ifx* h, const char* name, hipEvent_t* a);
 void ifx_ktime_end(ifx* h, const char* name, hipEvent_t a);
 
 // Forget a tracker run enqueued ahead (the caller is about to change something it read).
-static inline void ifx_drop_tracked(ifx* h) { h->tracked_ahead = 0; }
+static inline void ifx_drop_tracked(ifx* h) { h->tracked_ahead = 0; h->ids_view_ok = 0; }
 
 #define LAUNCH(h, name, grid, block, kernel, ...)                                                  \
     do {                                                                                           \

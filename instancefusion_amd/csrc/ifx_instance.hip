@@ -17,6 +17,8 @@
 #define NI IFX_NUM_INSTANCES
 
 int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame);
+int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth);
+int ifx_superpixel_filter(ifx* h, int nm);
 
 // maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131
 __global__ void k_mask_clean_overlap(uint8_t* __restrict__ masks, int nm, int P)
@@ -1223,20 +1225,23 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     if (r) return r;
     if ((r = seg_ensure_ctl(h, mbytes))) return r;
     SegCtl* hc = (SegCtl*)h->h_segctl;
+    hipEvent_t ea = ifx_event_get(h);
+    hipEventRecord(ea, h->cur);
+    if (flags & 2) {   // superpixels and their merge: on the queue before the masks are even copied (they need the frame only)
+        if ((r = ifx_superpixel_begin(h, rgb, depth))) { h->event_pool.push_back(ea); return r; }
+    }
     memcpy(h->h_masks_stage, masks_in, mbytes);
     hc->ff_incomplete = 0; hc->evict_at = -1; hc->nm = nm; hc->pad = 0;
     for (int i = 0; i < NI; i++) hc->inst_class[i] = h->inst_class[i];
     for (int m = 0; m < 256; m++) { hc->cls[m] = m < nm ? class_ids[m] : -1; hc->best[m] = -1; hc->target[m] = -1; }
     t_stage = us();
-    hipEvent_t ea = ifx_event_get(h);
-    hipEventRecord(ea, h->cur);
     HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, h->h_masks_stage, mbytes, hipMemcpyHostToDevice, h->cur));   // pinned: a true asynchronous copy
     HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->cur));
     HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->cur));
     HIPCHK(h, hipMemsetAsync(h->d_unavail, 0, nm, h->cur));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
     if (flags & 2) {
-        r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
+        r = ifx_superpixel_filter(h, nm);
         if (r) return r;
     }
     SegCtl* dc = (SegCtl*)h->d_segctl;

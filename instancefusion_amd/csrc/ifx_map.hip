@@ -1703,7 +1703,14 @@ static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out)
 int ifx_ids_ensure(ifx* h)
 {
     if (h->ids_full_valid || !h->ids_sparse_frame) return IFX_OK;
-    ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
+    if (h->ids_view_ok && !h->own) {   // nothing touched the store, the pose or the cached view list since the frame drew its lattice from it: the rest of the image from the same list
+        Cam c = make_cam(h);
+        c.srank = 0; c.sn = 1;
+        LAUNCH(h, "raster_view_ids", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1);
+        LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, h->ids_after);
+    } else
+        ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
     h->ids_full_valid = 1;
     return IFX_OK;
 }
@@ -2071,6 +2078,7 @@ __global__ void k_compact_count(DevState* st, const int* total)
 static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out);
 int ifx_compact_enqueue(ifx* h, int refresh_ids)
 {
+    h->ids_view_ok = 0;
     ifx_vlist_reap(h);   // slots the view list left out may have outlived the age rule: tombstone them before the live ranks are taken
     // alive flags over the host-known upper bound of slots; scan; scatter into the second buffer set; swap
     int n = h->cap;
@@ -2276,7 +2284,7 @@ static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 
 // ---- frame path through the cached view list
 __global__ void k_vlist_invalidate(DevState* st) { if (threadIdx.x == 0) st->vl_valid = 0; }
-void hs_invalidate_view(ifx* h) { LAUNCH(h, "vlist_invalidate", dim3(1), dim3(64), k_vlist_invalidate, h->d_state); }
+void hs_invalidate_view(ifx* h) { h->ids_view_ok = 0; LAUNCH(h, "vlist_invalidate", dim3(1), dim3(64), k_vlist_invalidate, h->d_state); }
 static bool use_view_list(ifx* h) { return h->opt_vlist && h->shard_n <= 1 && !h->own && !h->opt_reference_passes && h->graph_nodes == 0 && !h->view_block && h->tick > 1; }
 static void view_scan(ifx* h, int time)
 {
@@ -2293,6 +2301,7 @@ int ifx_vlist_reap(ifx* h)
 {
     if (!h->view_dirty) return IFX_OK;
     h->view_dirty = 0;
+    h->ids_view_ok = 0;
     LAUNCH(h, "vlist_decide", dim3(1), dim3(64), k_vlist_decide, h->d_state, h->d_list_ctr, 1);
     view_scan(h, h->last_clean_time);
     return IFX_OK;
@@ -2314,6 +2323,7 @@ static void index_list_pass(ifx* h, int time, bool taps)
 int ifx_map_frame(ifx* h)
 {
     h->view_frame = 0;
+    h->ids_view_ok = 0;
     if (use_view_list(h)) {
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
@@ -2387,6 +2397,7 @@ int ifx_map_predict(ifx* h)
         const int ids_step = (h->opt_lazy_ids && (want & LIST_IDS)) ? 10 : 1;
         h->ids_full_valid = ids_step == 1;
         h->ids_sparse_frame = ids_step > 1;
+        h->ids_view_ok = ids_step > 1;
         if (h->opt_raster_lds)
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<true>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
                    want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
@@ -2397,6 +2408,7 @@ int ifx_map_predict(ifx* h)
     } else {
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
         if (want & LIST_IDS) { h->ids_full_valid = 1; h->ids_sparse_frame = 0; }
+        h->ids_view_ok = 0;
     }
     h->view_frame = 0;
     h->ids_pending = 0;

@@ -766,6 +766,30 @@ void ifx_slic_free(ifx* h)
 
 // steps -1_1 .. -1_3 of processInstance (IF/Core/InstanceFusion.cpp:722-738): the masks in h->d_masks ([nm][P], already
 // through clean-overlap) are refined in place on the device
+// In two halves for the device-scheduled call: the superpixels and their merge need the frame only, so they are on the queue before the host starts copying the
+// masks into pinned memory (2.4 MB for eight masks: 0.1 ms during which the device used to wait); the region filter follows the masks.
+int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth)
+{
+    if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame"; return IFX_E_INVALID; }
+    SlicBuf* b;
+    int r = slic_buffers(h, &b);
+    if (r) return r;
+    const size_t P = b->P;
+    std::memcpy(h->rgb_stage, rgb, P * 3);
+    std::memcpy(h->depth_stage, depth, P * 2);
+    HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->cur));
+    if ((r = slic_run(h, b))) return r;
+    return merge_run(h, b);
+}
+int ifx_superpixel_filter(ifx* h, int nm)
+{
+    SlicBuf* b;
+    int r = slic_buffers(h, &b);
+    if (r) return r;
+    return filter_run(h, b, h->d_masks, nm, true);
+}
+
 int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame)
 {
     (void)frame;

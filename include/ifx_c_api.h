@@ -279,7 +279,7 @@ typedef struct ifx_soa_view {
     float* d_color;         /* [capacity] float2: packed rgb, packed inst.   (vColor.xy)   */
     float* d_times;         /* [capacity] float2: init time, last time       (vColor.zw)   */
     float* d_img_corr;      /* [capacity] float4                             (vImgCorr)    */
-    float* d_votes;         /* [12][capacity] float4: vInstInfoA..L, planar                */
+    float* d_votes;         /* [capacity][48]: vInstInfoA..L, one 192-byte record per slot */
 } ifx_soa_view;
 int ifx_map_view(ifx_t* h, ifx_soa_view* out);
 int ifx_map_count(ifx_t* h);      /* live surfels (synchronises) */

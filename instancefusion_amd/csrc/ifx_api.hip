@@ -1110,14 +1110,7 @@ extern "C" int ifx_map_download(ifx_t* h, int max_n, float* pc, float* nr, float
     if (col) HIPCHK(h, hipMemcpy(col, h->col, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (tm) HIPCHK(h, hipMemcpy(tm, h->tm, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (ic) HIPCHK(h, hipMemcpy(ic, h->ic, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (votes) {
-        std::vector<float> plane((size_t)n * 4);
-        for (int q = 0; q < 12; q++) {
-            HIPCHK(h, hipMemcpy(plane.data(), h->votes + ((size_t)q * h->cap) * 4, (size_t)n * 16, hipMemcpyDeviceToHost));
-            for (int i = 0; i < n; i++)
-                for (int k = 0; k < 4; k++) votes[(size_t)i * 48 + q * 4 + k] = plane[(size_t)i * 4 + k];
-        }
-    }
+    if (votes) HIPCHK(h, hipMemcpy(votes, h->votes, (size_t)n * IFX_VF * 4, hipMemcpyDeviceToHost));   // (the device layout is the API's: one 48-float record per surfel)
     return n;
 }
 
@@ -1155,13 +1148,8 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     HIPCHK(h, hipMemcpy(h->tm, tm, (size_t)n * 8, hipMemcpyHostToDevice));
     if (ic) HIPCHK(h, hipMemcpy(h->ic, ic, (size_t)n * 16, hipMemcpyHostToDevice));
     else HIPCHK(h, hipMemset(h->ic, 0, (size_t)n * 16));
-    std::vector<float> plane((size_t)n * 4, 0.f);
-    for (int q = 0; q < 12; q++) {
-        if (votes)
-            for (int i = 0; i < n; i++)
-                for (int k = 0; k < 4; k++) plane[(size_t)i * 4 + k] = votes[(size_t)i * 48 + q * 4 + k];
-        HIPCHK(h, hipMemcpy(h->votes + ((size_t)q * h->cap) * 4, plane.data(), (size_t)n * 16, hipMemcpyHostToDevice));
-    }
+    if (votes) HIPCHK(h, hipMemcpy(h->votes, votes, (size_t)n * IFX_VF * 4, hipMemcpyHostToDevice));
+    else HIPCHK(h, hipMemset(h->votes, 0, (size_t)n * IFX_VF * 4));
     DevState hs;
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(h->seq, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));

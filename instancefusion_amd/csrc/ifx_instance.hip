@@ -45,7 +45,7 @@ __global__ void k_check_project(const DevState* __restrict__ st, const int32_t* 
     if (id > 0 && id < st->count) {
         int s = 0;
         for (int q = 0; q < 12; q++) {
-            float4 v = votes[(size_t)q * cap + id];
+            float4 v = VOTE4(votes, id, q);
             int a, b;
             vote_decode(v.x, a, b); s += a + b;
             vote_decode(v.y, a, b); s += a + b;
@@ -74,37 +74,38 @@ __device__ __forceinline__ void bbox_extend(int* b, int x, int y)
     if (y < __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[2], y);
     if (y > __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[3], y);
 }
-// min / max over the lanes of a wave (every lane gets the result)
-__device__ __forceinline__ int wave_min_i(int v)
+// The pixels of a wave (2 rows x 32 columns of the 32 x 8 block) that extend the same box are reduced in the wave first: their ballot IS the reduction -- lowest /
+// highest set bit of each row's half give min / max x, which halves are non-empty min / max y -- so a box costs a few scalar operations, one look and at most four
+// atomics per wave (first four memory-side looks per pixel and box, then four shuffle reductions of six steps per box; the twelve vote floats4 and the mask bytes of a
+// pixel are fetched in one batch each).  min / max commute: same boxes.
+__device__ __forceinline__ void bbox_extend_ballot_lds(int* b, unsigned long long bal, int xb, int yb)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    const unsigned int lo = (unsigned int)bal, hi = (unsigned int)(bal >> 32);
+    const int x0 = xb + min(lo ? __ffs(lo) - 1 : 32, hi ? __ffs(hi) - 1 : 32), x1 = xb + max(lo ? 31 - __clz(lo) : -1, hi ? 31 - __clz(hi) : -1);
+    const int y0 = yb + (lo ? 0 : 1), y1 = yb + (hi ? 1 : 0);
+    atomicMin(&b[0], x0); atomicMax(&b[1], x1); atomicMin(&b[2], y0); atomicMax(&b[3], y1);
 }
-__device__ __forceinline__ int wave_max_i(int v)
+// a block's box into the global one: almost every box lies inside it already, so look (L2) before the atomic; a stale look can only cause a redundant atomic
+__device__ __forceinline__ void bbox_extend_box(int* b, const int* sb)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    if (sb[0] < __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[0], sb[0]);
+    if (sb[1] > __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[1], sb[1]);
+    if (sb[2] < __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[2], sb[2]);
+    if (sb[3] > __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[3], sb[3]);
 }
-// The pixels of a wave (2 rows x 32 columns) that extend the same box are reduced in the wave first: one look + at most four atomics per box
-// and wave instead of four memory-side looks per pixel and box; the twelve vote planes and the mask bytes of a pixel are fetched in one batch
-// each (one after the other they were ~50 dependent round trips per wave: 300 us per segmentation call).  min / max commute: same boxes.
-__device__ __forceinline__ void bbox_extend_wave(int* b, bool mine, int x, int y, bool leader)
-{
-    const int x0 = wave_min_i(mine ? x : 0x7fffffff), x1 = wave_max_i(mine ? x : (int)0x80000000), y0 = wave_min_i(mine ? y : 0x7fffffff), y1 = wave_max_i(mine ? y : (int)0x80000000);
-    if (leader) {
-        if (x0 < __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[0], x0);
-        if (x1 > __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[1], x1);
-        if (y0 < __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&b[2], y0);
-        if (y1 > __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[3], y1);
-    }
-}
-__global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
+#define PB_ROWS 32   // k_project_bbox: blocks of 32 x PB_ROWS pixels
+__global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
                                int nm, int w, int h, int* __restrict__ bbox, IdMap im)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & 63;
+    const int xb = blockIdx.x * 32, yb = blockIdx.y * blockDim.y + (threadIdx.y & ~1);   // origin of this wave's 32 x 2 pixels (blocks of 32 x PB_ROWS)
+    // Boxes of the block first, in LDS: a wave that went to the global box itself made every box a hot spot of one L2 channel (4800 waves x a handful of boxes x four
+    // looks at the same few lines: most of the kernel's 85 us); now a block of 16 waves settles in LDS and sends one look per box it touched.
+    __shared__ int s_box[NI + 8][4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+    for (int t = tid; t < (NI + 8) * 4; t += nthreads) s_box[t >> 2][t & 3] = (t & 1) ? (int)0x80000000 : 0x7fffffff;
+    __syncthreads();
     const bool inside = x < w && y < h;
     const int P = w * h, k = inside ? y * w + x : 0;
     const int gid = inside ? ids[k] : 0;
@@ -114,7 +115,7 @@ __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* _
     if (has) {
         float4 v[12];
 #pragma unroll
-        for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + id];
+        for (int q = 0; q < 12; q++) v[q] = VOTE4(votes, id, q);
 #pragma unroll
         for (int q = 0; q < 12; q++) {
             const float f[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
@@ -135,9 +136,9 @@ __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* _
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int pick = __shfl(key, leader, 64);
-        const bool mine = key == pick;
-        bbox_extend_wave(&bbox[pick * 4], mine, x, y, lane == leader);
-        todo &= ~__ballot(mine);
+        const unsigned long long grp = __ballot(key == pick);
+        if (lane == leader) bbox_extend_ballot_lds(s_box[pick], grp, xb, yb);
+        todo &= ~grp;
     }
     // boxes of the masks
     for (int m0 = 0; m0 < nm; m0 += 8) {
@@ -146,11 +147,19 @@ __global__ void k_project_bbox(const DevState* __restrict__ st, const int32_t* _
         for (int u = 0; u < 8; u++) mb[u] = (has && m0 + u < nm) ? masks[(size_t)(m0 + u) * P + k] : (uint8_t)0;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const bool mine = mb[u] > 0;
-            const unsigned long long bal = __ballot(mine);
-            if (bal) bbox_extend_wave(&bbox[(NI + m0 + u) * 4], mine, x, y, lane == __ffsll((long long)bal) - 1);
+            const unsigned long long bal = __ballot(mb[u] > 0);
+            if (bal && lane == u) bbox_extend_ballot_lds(s_box[NI + u], bal, xb, yb);
+        }
+        __syncthreads();
+        if (tid < 8 && s_box[NI + tid][1] >= s_box[NI + tid][0]) bbox_extend_box(&bbox[(NI + m0 + tid) * 4], s_box[NI + tid]);
+        if (m0 + 8 < nm) {   // (uniform) another chunk of masks follows: re-arm their eight boxes
+            __syncthreads();
+            if (tid < 32) s_box[NI + (tid >> 2)][tid & 3] = (tid & 1) ? (int)0x80000000 : 0x7fffffff;
+            __syncthreads();
         }
     }
+    __syncthreads();
+    if (tid < NI && s_box[tid][1] >= s_box[tid][0]) bbox_extend_box(&bbox[tid * 4], s_box[tid]);
 }
 
 // getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996
@@ -182,7 +191,7 @@ __global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __
     if (id < 0) return;
     int fi = instanceID / 2, p = instanceID % 2;
     // planar float4 store: float fi of surfel id lives in plane fi/4, component fi%4
-    unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
+    unsigned int* addr = (unsigned int*)&VOTEF(votes, id, fi);
     unsigned int old = *addr, assumed;
     do {
         assumed = old;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restr
     if (i < 0) return;
     float4 v[12];
 #pragma unroll
-    for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + i];
+    for (int q = 0; q < 12; q++) v[q] = VOTE4(votes, i, q);
     int best = -1, bestCount = 0;
 #pragma unroll
     for (int q = 0; q < 12; q++) {
@@ -248,24 +257,38 @@ __global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restr
 __global__ __launch_bounds__(256) void k_count_colour(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
                                                       float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels)
 {
+    // the whole map: four lanes per surfel, each instruction of a wave reads 16 x 64 contiguous bytes of the 192-byte records; the arg-max of the four quarters is
+    // merged "larger count, then smaller index" = the sequential first-maximum rule
+    (void)cap;
     const float defaultColor = 7434609;
-    const int n = st->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
-        float4 v[12];
-#pragma unroll
-        for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + i];
+    const int n = st->count, r = threadIdx.x & 3;
+    const int per = blockDim.x >> 2;
+    for (int i0 = blockIdx.x * per; i0 < n; i0 += per * gridDim.x) {   // (uniform trip count per block: the shuffles below see whole groups)
+        const int i = i0 + (threadIdx.x >> 2);
         int best = -1, bestCount = 0;
+        if (i < n) {
+            float4 v[3];
 #pragma unroll
-        for (int q = 0; q < 12; q++) {
-            float f[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            for (int j = 0; j < 3; j++) v[j] = VOTE4(votes, i, j * 4 + r);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                int a, b;
-                vote_decode(f[t], a, b);
-                if (bestCount < a) { bestCount = a; best = (q * 4 + t) * 2; }
-                if (bestCount < b) { bestCount = b; best = (q * 4 + t) * 2 + 1; }
+            for (int j = 0; j < 3; j++) {
+                const int q = j * 4 + r;
+                float f[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    int a, b;
+                    vote_decode(f[t], a, b);
+                    if (bestCount < a) { bestCount = a; best = (q * 4 + t) * 2; }
+                    if (bestCount < b) { bestCount = b; best = (q * 4 + t) * 2 + 1; }
+                }
             }
         }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            const int oc = __shfl_xor(bestCount, o, 64), ob = __shfl_xor(best, o, 64);
+            if (oc > bestCount || (oc == bestCount && oc > 0 && ob < best)) { bestCount = oc; best = ob; }
+        }
+        if (i >= n || r != 0) continue;
         if (tm[i].y <= DEAD_TIME) { labels[i] = -1; continue; }
         labels[i] = best;
         float2 c = col[i];
@@ -281,23 +304,25 @@ __global__ __launch_bounds__(256) void k_count_colour(const DevState* __restrict
 __global__ __launch_bounds__(256) void k_max_count(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
                                                    int* __restrict__ maxv, int* __restrict__ sumv)
 {
+    (void)cap;
     __shared__ int smax[NI], ssum[NI];
     for (int t = threadIdx.x; t < NI; t += blockDim.x) { smax[t] = 0; ssum[t] = 0; }
     __syncthreads();
-    const int n = st->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const size_t n4 = (size_t)st->count * 12;   // one thread per float4 of the records: consecutive threads, consecutive bytes
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (size_t)blockDim.x * gridDim.x) {
+        const int i = (int)(g / 12), q = (int)(g - (size_t)i * 12);
         if (tm[i].y <= DEAD_TIME) continue;
-        for (int q = 0; q < 12; q++) {
-            float4 v = votes[(size_t)q * cap + i];
-            float f[4] = {v.x, v.y, v.z, v.w};
-            for (int t = 0; t < 4; t++) {
-                int a, b, k = (q * 4 + t) * 2;
-                vote_decode(f[t], a, b);
-                if (a > 0) atomicMax(&smax[k], a);
-                if (b > 0) atomicMax(&smax[k + 1], b);
-                if (a) atomicAdd(&ssum[k], a);
-                if (b) atomicAdd(&ssum[k + 1], b);
-            }
+        const float4 v = votes[g];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int a, b;
+            const int k = (q * 4 + t) * 2;
+            vote_decode(f[t], a, b);
+            if (a > 0) atomicMax(&smax[k], a);
+            if (b > 0) atomicMax(&smax[k + 1], b);
+            if (a) atomicAdd(&ssum[k], a);
+            if (b) atomicAdd(&ssum[k + 1], b);
         }
     }
     __syncthreads();
@@ -310,18 +335,18 @@ __global__ __launch_bounds__(256) void k_max_count(const DevState* __restrict__ 
 // cleanInstanceTableMapKernel, IF/Core/InstanceFusionCuda.cu:1057-1084
 __global__ void k_clean_table(const DevState* __restrict__ st, float* __restrict__ votes, int cap, const int* __restrict__ clean_list)
 {
-    const int n = st->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x)
-        for (int fi = 0; fi < IFX_VF; fi++) {
-            int c1 = clean_list[2 * fi], c2 = clean_list[2 * fi + 1];
-            if (!c1 && !c2) continue;
-            float* f = &votes[((size_t)(fi >> 2) * cap + i) * 4 + (fi & 3)];
-            int a, b;
-            vote_decode(*f, a, b);
-            if (c1) a = 0;
-            if (c2) b = 0;
-            *f = vote_encode(a, b);
-        }
+    (void)cap;
+    const size_t nf = (size_t)st->count * IFX_VF;   // one thread per float of the records
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nf; g += (size_t)blockDim.x * gridDim.x) {
+        const int fi = (int)(g % IFX_VF);
+        const int c1 = clean_list[2 * fi], c2 = clean_list[2 * fi + 1];
+        if (!c1 && !c2) continue;
+        int a, b;
+        vote_decode(votes[g], a, b);
+        if (c1) a = 0;
+        if (c2) b = 0;
+        votes[g] = vote_encode(a, b);
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -764,7 +789,7 @@ static int first_not_used(ifx* h)
 static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
 {
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     bbox.resize((size_t)(NI + nm) * 4);
     HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->cur));
@@ -792,7 +817,7 @@ static int oseg_launch_bboxes(ifx* h)
 {
     const int nm = h->oseg_nm;
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "bbox_flip", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_bbox_flip, h->d_bbox, NI + nm);
     h->oseg_pending = 1;
@@ -1173,7 +1198,7 @@ __global__ void k_vote_update_all(const DevState* __restrict__ st, const int32_t
             if (id == -2) id = idmap_slot(im, st->count, ids[k]);
             if (id < 0) return;
             const int fi = instanceID / 2, p = instanceID % 2, inc = m + 1;
-            unsigned int* addr = (unsigned int*)&votes[((size_t)(fi >> 2) * cap + id) * 4 + (fi & 3)];
+            unsigned int* addr = (unsigned int*)&VOTEF(votes, id, fi);
             unsigned int old = *addr, assumed;
             do {
                 assumed = old;
@@ -1246,7 +1271,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     }
     SegCtl* dc = (SegCtl*)h->d_segctl;
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "seg_compare", dim3(1), dim3(256), k_seg_compare, dc, (const int*)h->d_bbox, h->d_unavail);
     LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));

@@ -200,7 +200,7 @@ __global__ void k_init_scatter(DevState* st, const float* __restrict__ dm, const
     nr[n] = make_float4(nl.x, nl.y, nl.z, rad);
     if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad));
     ic[n] = make_float4(-1.f, -1.f, -1.f, -1.f);
-    for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(-1.f, -1.f, -1.f, -1.f);
+    for (int q = 0; q < 12; q++) VOTE4(votes, n, q) = make_float4(-1.f, -1.f, -1.f, -1.f);
     seq[n] = (uint32_t)n;
 }
 __global__ void k_init_count(DevState* st, const int* total, int cap)
@@ -358,10 +358,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster(const DevState* __restri
         if (MODE == 0) { if (!(u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h)) continue; }
         if (MODE == 2) {
             // every vote vec4 compared with the first one (vInstInfoB..L == vInstInfoA)
-            float4 a = votes[i];
+            float4 a = VOTE4(votes, i, 0);
             bool alleq = true;
             for (int k = 1; k < 12 && alleq; k++) {
-                float4 b = votes[(size_t)k * cap + i];
+                float4 b = VOTE4(votes, i, k);
                 alleq = (b.x == a.x) && (b.y == a.y) && (b.z == a.z) && (b.w == a.w);
             }
             if (alleq) continue;
@@ -502,7 +502,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
             if (gid > 0 && gid < st->count) {
                 float4 v[12];
 #pragma unroll
-                for (int q = 0; q < 12; q++) v[q] = fold.votes[(size_t)q * fold.cap + gid];
+                for (int q = 0; q < 12; q++) v[q] = VOTE4(fold.votes, gid, q);
                 int mass = 0;
 #pragma unroll
                 for (int q = 0; q < 12; q++) {
@@ -580,7 +580,7 @@ __global__ void k_raster_finish(DevState* st, const uchar4* __restrict__ pimg, i
               if (id >= 0) {
                 float4 v[12];   // all twelve planes in flight together (one after the other they were twelve HBM round trips: 13 us for this little kernel)
 #pragma unroll
-                for (int q = 0; q < 12; q++) v[q] = votes[(size_t)q * cap + id];
+                for (int q = 0; q < 12; q++) v[q] = VOTE4(votes, id, q);
 #pragma unroll
                 for (int q = 0; q < 12; q++) {
                     int a, b;
@@ -2017,7 +2017,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         col[n] = make_float2(mcol[k], 0.f);
         tm[n] = make_float2((float)time, (float)time);
         ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
-        for (int q = 0; q < 12; q++) votes[(size_t)q * cap + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 12; q++) VOTE4(votes, n, q) = make_float4(0.f, 0.f, 0.f, 0.f);
         labels[n] = -1;   // no label until the next label scan (the slot may hold one from before a compaction)
         seq[n] = sq;
     }
@@ -2068,7 +2068,7 @@ __global__ void k_compact_scatter(const int* __restrict__ flags, const int* __re
     pc2[d] = pc[i]; nr2[d] = nr[i]; col2[d] = col[i]; tm2[d] = tm[i]; ic2[d] = ic[i];
     if (labels2) labels2[d] = labels[i];
     seq2[d] = seq[i];
-    for (int q = 0; q < 12; q++) votes2[(size_t)q * cap + d] = votes[(size_t)q * cap + i];
+    for (int q = 0; q < 12; q++) VOTE4(votes2, d, q) = VOTE4(votes, i, q);
 }
 __global__ void k_compact_count(DevState* st, const int* total)
 {

@@ -594,10 +594,68 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 
 // Union-find start of the fill (round 3).  Pixels joined by edges that exist in BOTH directions reach each other, so they end with the same label, whatever else
 // happens: their components can be merged with the lock-free union-find of connected-component labelling instead of walking labels across the image one tile
-// border per launch.  k_ff_relax<true> leaves every pixel pointing at the smallest pixel of its component INSIDE its tile (a forest of depth one, roots point at
+// border per launch.  k_ff_tile_uf leaves every pixel pointing at the smallest pixel of its component INSIDE its tile (a forest of depth one, roots point at
 // themselves); k_ff_merge unites the trees across every tile border edge (the larger root is hung under the smaller: atomicMin, retried until it sticks);
 // k_ff_flatten points every pixel at its root = the smallest pixel of the whole component.  Every label is still "a pixel that reaches me", so the directed
 // relaxation that follows starts from a valid state and -- where every edge is two-way (model depth under 4 m: one threshold) -- finds nothing left to do.
+// Tile-local half: union-find in LDS over the two-way edges INSIDE a 32 x 32 tile (right and lower neighbour of every pixel: each edge once), then every pixel
+// points at the smallest pixel of its component within the tile (row-major order inside a tile is the global order restricted to it).  No rounds, no halo: the
+// edges across tile borders are k_ff_merge's.  (First version: k_ff_relax<true>, sweeps to the local fixpoint, 64 us a call; this one ~10.)
+__device__ __forceinline__ int ff_find_lds(const volatile int* par, int x)
+{
+    int p = par[x];
+    while (p != x) { x = p; p = par[x]; }
+    return x;
+}
+__global__ void __launch_bounds__(256) k_ff_tile_uf(FFArgs a)
+{
+    __shared__ int par[FF_T * FF_T];
+    __shared__ unsigned short dep[FF_T * FF_T];
+    const int P = a.w * a.h, m = blockIdx.z;
+    if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
+    int* lab = a.label + (size_t)m * P;
+    const int x0 = blockIdx.x * FF_T, y0 = blockIdx.y * FF_T, tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < FF_T * FF_T / 256; q++) {
+        const int t = tid + q * 256, ly = t / FF_T, lx = t - ly * FF_T, x = x0 + lx, y = y0 + ly;
+        const bool in = x < a.w && y < a.h;
+        par[t] = (in && lab[y * a.w + x] >= 0) ? t : -1;
+        dep[t] = in ? a.depth[y * a.w + x] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FF_T * FF_T / 256; q++) {
+        const int t = tid + q * 256, ly = t / FF_T, lx = t - ly * FF_T;
+        if (par[t] < 0) continue;
+        const int dp = dep[t];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (e == 0 ? lx + 1 >= FF_T : ly + 1 >= FF_T) continue;
+            const int u = e == 0 ? t + 1 : t + FF_T;
+            if (par[u] < 0) continue;
+            const int dq = dep[u];
+            const float dd = (float)abs(dp - dq);
+            if (!(dd < depth_threshold_dev(dp) && dd < depth_threshold_dev(dq))) continue;
+            int ra = t, rb = u;
+            for (;;) {
+                ra = ff_find_lds(par, ra); rb = ff_find_lds(par, rb);
+                if (ra == rb) break;
+                if (ra > rb) { const int s_ = ra; ra = rb; rb = s_; }
+                const int old = atomicMin(&par[rb], ra);
+                if (old == rb) break;
+                rb = old;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FF_T * FF_T / 256; q++) {
+        const int t = tid + q * 256, ly = t / FF_T, lx = t - ly * FF_T;
+        if (par[t] < 0) continue;
+        const int r = ff_find_lds(par, t), ry = r / FF_T, rx = r - ry * FF_T;
+        if (r != t) lab[(y0 + ly) * a.w + x0 + lx] = (y0 + ry) * a.w + x0 + rx;
+    }
+}
 __device__ __forceinline__ int ff_find(const int* lab, int x)
 {
     int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -729,7 +787,7 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
         LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
         if (h->opt_ff_union) {   // the two-way edges by union-find: three launches for what took the relaxation a launch per tile border crossed
             const int pairs = ((h->w - 1) / FF_T) * h->h + ((h->h - 1) / FF_T) * h->w;
-            LAUNCH(h, "ff_local", tiles, dim3(256), k_ff_relax<true>, a, 0);
+            LAUNCH(h, "ff_local", tiles, dim3(256), k_ff_tile_uf, a);
             if (pairs > 0) LAUNCH(h, "ff_merge", dim3(cdiv(pairs, 256), nm), dim3(256), k_ff_merge, a);
             LAUNCH(h, "ff_flatten", per_px, dim3(256), k_ff_flatten, a);
         }
@@ -1275,7 +1333,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "seg_compare", dim3(1), dim3(256), k_seg_compare, dc, (const int*)h->d_bbox, h->d_unavail);
     LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
-    const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : (h->opt_ff_union ? 6 : 24);   // (after the union-find start the first relaxation normally finds the fixpoint: the rest are spares for one-way edges)
+    const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : (h->opt_ff_union ? 4 : 24);   // (after the union-find start the first relaxation normally finds the fixpoint: the rest are spares for one-way edges)
     r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, rounds);
     if (r) return r;
     const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);

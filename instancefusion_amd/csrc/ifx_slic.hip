@@ -514,28 +514,40 @@ __device__ __forceinline__ bool sp_edge_fails(const float* __restrict__ A, const
     const float test = dist_term + nor_term, limA = thrA + devA + zA, limB = thrB + devB + zB;
     return test > limA || test > limB;
 }
+// The directed tests of all entries, one thread per (node, list position), over the whole chip: ~13 k tests of twenty table floats and double arithmetic each were
+// the long part of the one-block pass (78 us).  etab[a * NB_MAX + j] = neighbour | 0x40000000 when the test a -> neighbour passes; -1: no entry.
+__global__ void k_sp_edges(int spn, const float* __restrict__ info, int* __restrict__ etab)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= spn * NB_MAX) return;
+    const int a = t / NB_MAX, j = t - a * NB_MAX;
+    const float* A = info + (size_t)a * SPI_SIZE;
+    int e = -1;
+    if (j < (int)A[SPI_CONNECT_N]) {
+        const int b = (int)A[SPI_NP_FIRST + j];
+        e = b;
+        if (b != -1 && !sp_edge_fails(A, info + (size_t)b * SPI_SIZE)) e |= 0x40000000;
+    }
+    etab[t] = e;
+}
 // (first version: every round of the propagation re-read the lists from the table in global memory, 30-float records, one dependent load after the other:
-// 150 us for 1200 nodes.  The lists now live in LDS as ints for the whole kernel.)
-__global__ __launch_bounds__(1024) void k_sp_connect(int spn, float* __restrict__ info, int* __restrict__ final_of)
+// 150 us for 1200 nodes.  The lists now live in LDS as ints for the whole kernel, filled from k_sp_edges' table.)
+__global__ __launch_bounds__(1024) void k_sp_connect(int spn, float* __restrict__ info, int* __restrict__ final_of, const int* __restrict__ etab)
 {
     extern __shared__ int sm[];
     int* label = sm;                                   // [spn]
     unsigned int* pass = (unsigned int*)(sm + spn);    // [spn] bit j: the directed test of entry j passed
     int* nbr = sm + 2 * spn;                           // [spn][NB_MAX] the lists (-1: no entry / deleted)
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int t = tid; t < spn * NB_MAX; t += nt) {
-        const int a = t / NB_MAX, j = t - a * NB_MAX;
-        const float* A = info + (size_t)a * SPI_SIZE;
-        nbr[t] = j < (int)A[SPI_CONNECT_N] ? (int)A[SPI_NP_FIRST + j] : -1;
-    }
+    for (int t = tid; t < spn * NB_MAX; t += nt) nbr[t] = etab[t];   // (entry | pass flag; split below)
     __syncthreads();
     for (int a = tid; a < spn; a += nt) {
-        const float* A = info + (size_t)a * SPI_SIZE;
         unsigned int m = 0;
         for (int j = 0; j < NB_MAX; j++) {
-            const int b = nbr[a * NB_MAX + j];
-            if (b == -1) continue;
-            if (!sp_edge_fails(A, info + (size_t)b * SPI_SIZE)) m |= 1u << j;
+            const int e = nbr[a * NB_MAX + j];
+            if (e < 0) continue;   // (-1: no entry; a stored -1.f entry comes through as -1 too)
+            if (e & 0x40000000) m |= 1u << j;
+            nbr[a * NB_MAX + j] = e & 0x3FFFFFFF;
         }
         pass[a] = m;
         label[a] = a;
@@ -675,7 +687,7 @@ int slic_buffers(ifx* h, SlicBuf** out)
     r |= dev_alloc(h, &b->seg, P); r |= dev_alloc(h, &b->tmp, P); r |= dev_alloc(h, &b->fin, P);
     r |= dev_alloc(h, &b->sum1, S * NSUM * 2); b->sum2 = b->sum1 + S * NSUM;
     r |= dev_alloc(h, &b->adj, S * b->adj_words);
-    r |= dev_alloc(h, &b->info, S * SPI_SIZE); r |= dev_alloc(h, &b->final_of, S);
+    r |= dev_alloc(h, &b->info, S * SPI_SIZE); r |= dev_alloc(h, &b->final_of, S * (1 + NB_MAX));   // [spn] + k_sp_edges' table [spn][NB_MAX]
     if (r) return IFX_E_HIP;
     b->h_info.resize(S * SPI_SIZE);
     *out = b;
@@ -716,7 +728,10 @@ int merge_run(ifx* h, SlicBuf* b)
     LAUNCH(h, "sp_recluster", dim3(cdiv(w, 16), cdiv(hh, 16)), dim3(16, 16), k_sp_recluster, b->seg, b->dg, b->pos, b->nor, w, hh, b->info, b->sum2);
     LAUNCH(h, "sp_second_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_second_avg, b->sum2, S, b->info);
     // connectSuperPixel on the device: no read-back inside a call
-    if (S <= 1200) LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * (2 + NB_MAX) * 4, k_sp_connect, S, b->info, b->final_of);
+    if (S <= 1200) {
+        LAUNCH(h, "sp_edges", dim3(cdiv(S * NB_MAX, 256)), dim3(256), k_sp_edges, S, (const float*)b->info, b->final_of + S);
+        LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * (2 + NB_MAX) * 4, k_sp_connect, S, b->info, b->final_of, (const int*)(b->final_of + S));
+    }
     else if (S <= 5000) LAUNCH_SMEM(h, "sp_connect", dim3(1), dim3(1024), (size_t)S * 12, k_sp_connect_big, S, b->info, b->final_of);
     else { h->err = "too many superpixels for the one-block connect pass"; return IFX_E_INVALID; }
     LAUNCH(h, "sp_final", dim3(cdiv(P, 256)), dim3(256), k_sp_final, b->seg, b->final_of, b->fin, P);

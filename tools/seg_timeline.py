@@ -26,6 +26,13 @@ def main():
     i0 = starts[want]
     end_names = ("k_count_colour_px", "k_count_colour")
     i1 = next((i for i in range(i0, len(rows)) if rows[i][2] in end_names), len(rows) - 1)
+    # the call's own stream only (it runs beside the next frame's tracker), and from its first dispatch: the superpixels are enqueued before the masks are staged
+    stream = rows[i0][3]
+    rows = [r for r in rows[:i1 + 1] if r[3] == stream]
+    i1 = len(rows) - 1
+    i0 = max(i for i, r in enumerate(rows) if r[2] == "k_mask_clean_overlap")
+    while i0 > 0 and rows[i0][0] - rows[i0 - 1][1] < 300_000:
+        i0 -= 1
     t0 = rows[i0][0]
     print(f"segmentation call {want} of {len(starts)}: {i1 - i0 + 1} dispatches, {1e-3 * (rows[i1][1] - t0):.1f} us from the first kernel's start to the label scan's end")
     print(f"{'offset us':>10} {'dur us':>8} {'gap us':>8}  kernel (stream)")

@@ -91,6 +91,7 @@ def main():
                     "unrelated in space -- the worst case for the passes that gather the visible part of the store) or `morton` (spatially coherent, as a map built frame by frame is)")
     ap.add_argument("--trace-steps", action="store_true", help="print the host time of every timed step to stderr (diagnostic)")
     ap.add_argument("--no-instance", action="store_true")
+    ap.add_argument("--pace", action="store_true", help="with --no-instance: wait for every frame's result before the next is enqueued (diagnostic)")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
     ap.add_argument("--close-loops", action="store_true", help="also run the local loop-closure detection every frame (the reference's closeLoops = true: predict() at the "
@@ -193,6 +194,8 @@ def main():
         seg["frame"] += 1
         f = 100 + seg["frame"] + seg["shift"]
         if args.no_instance or not allow:
+            if args.pace:
+                ef.L.ifx_should_segment(ef.handle, -(1 << 30))   # (diagnostic) waits for the frame's result as the instance layer's decision does; never fires
             return
         if inst.whetherDoSegmentation(f):
             if seg["last_true"] is not None and f - seg["last_true"] <= 45:

@@ -100,6 +100,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         hipError_t r1 = prio ? hipStreamCreateWithPriority(&h->stream, hipStreamDefault, hi) : hipStreamCreate(&h->stream);
         hipError_t r2 = prio ? hipStreamCreateWithPriority(&h->stream_b, hipStreamDefault, lo) : hipStreamCreate(&h->stream_b);
         if (r1 != hipSuccess || r2 != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
+        hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming);
         hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_s, hipStreamDefault, hi) : hipStreamCreate(&h->stream_s);
         if (r3 != hipSuccess) { g_err = "hipStreamCreate failed"; ifx_destroy(h); return IFX_E_HIP; }
     }
@@ -198,6 +199,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_knn_free_all(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
     if (h->stream_s) hipStreamDestroy(h->stream_s);
+    if (h->ev_gate) hipEventDestroy(h->ev_gate);
     if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -271,6 +273,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "raster_tiles") h->opt_raster_tiles = value;
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
     else if (s == "seg_aside") h->opt_seg_aside = value;
+    else if (s == "pace") h->opt_pace = value;
+    else if (s == "side_gate") h->opt_side_gate = value;
     else if (s == "ff_union") h->opt_ff_union = value;
     else if (s == "fold_finish") h->opt_fold_finish = value;
     else if (s == "lazy_ids") { ifx_ids_ensure(h); h->opt_lazy_ids = value; }
@@ -291,12 +295,10 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
         if (value) { h->err = "model_fused: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
 #endif
     }
-    else if (s == "gn_persist") {
-#ifdef IFX_EXPERIMENTS
+    else if (s == "gn_persist") {   // a bit per pyramid level: that level's Gauss-Newton iterations in one persistent launch (k_gn_level); default 4 = the coarsest level only
+        if (value < 0 || value > 7) { h->err = "gn_persist is a mask of pyramid levels (0..7)"; return IFX_E_INVALID; }
+        ifx_drop_tracked(h);
         h->opt_gn_persist = value;
-#else
-        if (value) { h->err = "gn_persist: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
-#endif
     }
     else if (s == "raster_lds") h->opt_raster_lds = value;
     else if (s == "raster_earlyz") h->opt_raster_earlyz = value;
@@ -337,6 +339,7 @@ __global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restric
     out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
     out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
     out->count = st->count; out->n_dead = st->n_dead; out->n_new = st->n_new; out->overflow = st->overflow;
+    out->gn_timeout = st->gn_timeout;
 }
 
 // Frame side of frame `tick` into slot s (copy-in, bilateral + metric depth, frame pyramids, SO(3) pre-alignment).
@@ -464,6 +467,11 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
 {
     if (h->own) { h->err = "a sharded map (n_ranks > 1) is driven through ifx_owner_frame_phase / ifx_owner_exchange"; return IFX_E_STATE; }
     if (bootstrap && !in_pose16) { h->err = "bootstrap needs inPose (EF/ElasticFusion.cpp:352-356)"; return IFX_E_INVALID; }
+    // Bounded run-ahead: the previous frame's RESULT (its map passes; the tracker enqueued ahead of this frame is still behind it on the queue, so the device never
+    // idles) before this frame goes onto the queues.  A host that enqueues without ever looking back piles frame sides, event waits and barrier packets several
+    // frames deep, and the same workload runs a quarter slower (bench.py --no-instance: 1100 against 1460 frames/s; a host that asks ifx_should_segment every
+    // frame waits exactly here anyway).  Option "pace" = 0 restores the unbounded enqueue.
+    if (h->opt_pace && h->ev_result && h->tick > 1) HIPCHK(h, hipEventSynchronize(h->ev_result));
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
     const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0;
@@ -486,8 +494,11 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
             if (tracked) {
                 ifx_tracker_commit(h);
                 if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
-                int r = ifx_enqueue_hinted_frame_side(h);   // no tracker enqueue to hide it in: it runs under this frame's map passes
-                if (r) return r;
+                if (h->opt_side_gate == 1 && h->ev_gate) { hipEventRecord(h->ev_gate, h->stream); hipStreamWaitEvent(h->stream_b, h->ev_gate, 0); }   // (experiment) not under the tracker's tail
+                if (h->opt_side_gate != 2) {
+                    int r = ifx_enqueue_hinted_frame_side(h);   // no tracker enqueue to hide it in: it runs under this frame's map passes
+                    if (r) return r;
+                }
             } else if (!in_pose16 || bootstrap) {
                 ifx_tracker_model_side(h);                       // model pyramid: independent of the frame side
                 HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
@@ -527,6 +538,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     hipEventRecord(f.released, h->stream);   // one marker: the side stream waits for it before it reuses the slot,
     h->ev_result = f.released;               // the host before it reads the frame result
     {
+        if (h->opt_side_gate == 2 && h->hint_rgb && h->opt_two_streams) hipStreamWaitEvent(h->stream_b, f.released, 0);   // (experiment) under the next tracker only
         int r = ifx_enqueue_hinted_frame_side(h);   // not consumed by the tracker (first frame, external pose)
         if (r) return r;
     }
@@ -932,6 +944,7 @@ extern "C" int ifx_sync(ifx_t* h)
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
+    if (h->h_result->gn_timeout) { h->err = "the tracker's persistent level kernel gave up at a grid barrier (its blocks were not co-resident): set option gn_persist to 0"; return IFX_E_HIP; }
     return IFX_OK;
 }
 

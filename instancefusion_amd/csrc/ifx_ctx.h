@@ -103,6 +103,7 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     float pose[16];
     float diag[8];
     int count, n_dead, n_new, overflow;
+    int gn_timeout;      // DevState::gn_timeout: sticky, reported by ifx_sync
     int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
 };
 
@@ -220,6 +221,8 @@ struct ifx {
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     hipStream_t stream_s = nullptr;     // a segmentation call that finds the next frame's tracker already queued on the main stream runs here, beside it (the call
+    int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
+    int opt_pace = 1;                   // ifx_enqueue_frame_device waits for the previous frame's result before it enqueues (bounded run-ahead)
     int opt_ff_union = 1;               // flood fill of the masks: two-way edges merged by union-find before the directed relaxation (k_ff_merge)
     int opt_seg_aside = 1;              // is synchronous for the host, so nothing has to join afterwards); ifx_instance / ifx_slic / ifx_knn enqueue on h->cur throughout
     hipEvent_t ev_result = nullptr;     // the `released` event of the slot of the last frame (recorded after k_frame_result)
@@ -240,7 +243,7 @@ struct ifx {
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_px = 0;              // ICP and residual reductions on the same pixels of one thread, all loads in two batches (k_icp_residual_px; bits: 1 level 0, 2 levels 1-2, 4 one pixel per thread); measured slower: off
     int opt_model_fused = 0;         // model pyramid of the frame tracker in one launch (k_model_pyr3) when the image size allows; measured equal to the three launches (28 vs 27 us): off
-    int opt_gn_persist = 0;          // all Gauss-Newton iterations of a pyramid level in one persistent launch (k_gn_level) when its grid fits the GPU; measured slower: off
+    int opt_gn_persist = 4;          // bit i: all Gauss-Newton iterations of pyramid level i in one persistent launch (k_gn_level) when its grid fits the GPU; faster at the coarsest level only
     int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)

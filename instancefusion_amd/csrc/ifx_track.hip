@@ -1843,7 +1843,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
 }
 
 
-#ifdef IFX_EXPERIMENTS   // measured alternatives that lost: compiled only on request (make FLAGS+=-DIFX_EXPERIMENTS), with their bit-identity tests
+// (Round 2 measured it slower than the two-launch form at levels 0 and 1 -- the meetings of 300-1200 blocks cost more than launch boundaries -- and FASTER at the
+// coarsest level, 75 blocks: 12.5 against 13.9 us per iteration.  Round 3 uses it there: option gn_persist is a bit per pyramid level, default 4.)
 // ======================================================================= persistent Gauss-Newton level
 // ALL iterations of one pyramid level in ONE launch.  The two-launch form above pays per iteration two launch boundaries, two argument / state
 // prologues, a round trip of the correspondence records through memory and the last block's ticket: ~14 us even at 160 x 120, where the
@@ -2140,7 +2141,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
         __syncthreads();
     }
 }
-#endif   // IFX_EXPERIMENTS
+
 
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
 __global__ void k_commit_pose(DevState* st, unsigned int* lctr)
@@ -2180,7 +2181,6 @@ int ifx_alloc_tracker(ifx* h)
     const int maxb = 1024;
     HIPCHK(h, hipMalloc(&p.acc, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
     HIPCHK(h, hipMemset(p.acc, 0, (3 * IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double))));
-#ifdef IFX_EXPERIMENTS
     {   // grids of the persistent level kernel must be co-resident: blocks per CU from the runtime's occupancy calculator x the CU count
         int cus = 0, dev = 0;
         hipGetDevice(&dev);
@@ -2192,7 +2192,6 @@ int ifx_alloc_tracker(ifx* h)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], k_gn_level<4>, RED_THREADS, 0);
         for (int q = 0; q < 4; q++) h->gn_max_blocks[q] = std::max(0, occ[q]) * std::max(0, cus);
     }
-#endif
     h->res_rows = std::max(maxb, cdiv(h->P, RED_THREADS) + 1);   // the residual pass runs one block per 256 pixels
     HIPCHK(h, hipMalloc(&h->res_partials, (size_t)h->res_rows * 2 * 4));
     HIPCHK(h, hipMalloc(&h->d_out29, 64 * 4));
@@ -2399,8 +2398,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
         int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
         pa.check_skip = frame_tracker ? 0 : 1;   // (accumulator rows, residual totals, ticket: DevState::gn_acc / gn_res / gn_ticket of `st`)
-#ifdef IFX_EXPERIMENTS
-        if (frame_tracker && h->opt_gn_persist && iterations[i] > 0 && !lds_tiles && icp && rgb) {   // all iterations of the level in one persistent launch
+        if (frame_tracker && (h->opt_gn_persist & (1 << i)) && iterations[i] > 0 && !lds_tiles && icp && rgb) {   // all iterations of the level in one persistent launch
             static const int pxs[4] = {1, 2, 3, 4};
             int q = -1, nbp = 0;
             for (int t = 0; t < 4 && q < 0; t++) {
@@ -2430,7 +2428,6 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 continue;
             }
         }
-#endif
         iters_done += iterations[i];
         // both reductions on the same pixels of one thread (k_icp_residual_px); option bits: 1 = at level 0, 2 = at levels 1 and 2, 4 = one pixel per thread at level 0 too
 #ifdef IFX_EXPERIMENTS

@@ -594,7 +594,7 @@ def _experiments_or_skip(ifx):
     then IFX_LIB=build/variants/libifx_experiments.so): the product library refuses their options."""
     g = ifx.ElasticFusion(w=64, h=48, fx=50.0, fy=50.0, cx=32.0, cy=24.0, max_surfels=1000)
     try:
-        g.set_option("gn_persist", 1)
+        g.set_option("model_fused", 1)
     except ifx.IfxError as e:
         assert "IFX_EXPERIMENTS" in str(e)
         pytest.skip("libifx.so was built without -DIFX_EXPERIMENTS (the default): run with IFX_LIB=build/variants/libifx_experiments.so")
@@ -621,29 +621,37 @@ def test_lds_staged_icp_tiles_are_bit_identical(ifx):
     assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in MAP_KEYS)
 
 
-def test_persistent_level_kernel_is_bit_identical(ifx):
-    """All Gauss-Newton iterations of a pyramid level in one persistent launch with grid barriers (option gn_persist; k_gn_level): the same
-    rows and the same exact sums as the two launches per iteration -- trajectories and maps bit-identical (the in-kernel meetings cost more
-    than launch boundaries on this GPU, DESIGN.md section 6, hence an option).  A barrier that timed out would show up as a different pose."""
+def _tracker_variants_equal(ifx, variants):
     from instancefusion_amd import synth
 
-    _experiments_or_skip(ifx)
     W, H = 640, 480
     K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
     st = synth.make_stream(8, W, H, noise=True, loop_len=90, **K)
     out = []
-    # (0, 1, 0): the three levels of the model pyramid in one launch (option model_fused; k_model_pyr3); (0, 0, 3): the ICP and residual reductions on the
-    # same pixels of one thread (option icp_px; k_icp_residual_px) -- the same pyramids / rows / sums
-    for persist, fused, px in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 3)):
+    for opts in variants:
         g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
-        g.set_option("gn_persist", persist)
-        g.set_option("model_fused", fused)
-        g.set_option("icp_px", px)
+        for k, v in opts.items():
+            g.set_option(k, v)
         out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(8)]), g.download()))
         g.close()
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0])
         assert all(np.array_equal(out[0][1][k], other[1][k]) for k in MAP_KEYS)
+
+
+def test_persistent_level_kernel_is_bit_identical(ifx):
+    """All Gauss-Newton iterations of a pyramid level in one persistent launch with grid barriers (option gn_persist, a bit per level; k_gn_level): the same
+    rows and the same exact sums as the two launches per iteration -- trajectories and maps bit-identical whichever levels use it (the default is the coarsest
+    level only, where the meetings of 75 blocks cost less than launch boundaries).  A barrier that timed out would show up as a different
+    pose, and as an error of ifx_sync."""
+    _tracker_variants_equal(ifx, [dict(gn_persist=0), dict(gn_persist=7), dict(gn_persist=4), dict(gn_persist=6)])
+
+
+def test_lost_tracker_experiments_are_bit_identical(ifx):
+    """(experiments build only) the three levels of the model pyramid in one launch (model_fused; k_model_pyr3) and the ICP and residual reductions on the same
+    pixels of one thread (icp_px; k_icp_residual_px): the same pyramids / rows / sums."""
+    _experiments_or_skip(ifx)
+    _tracker_variants_equal(ifx, [dict(), dict(model_fused=1), dict(icp_px=3)])
 
 
 @pytest.mark.parametrize("world", [2, 3])

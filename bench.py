@@ -30,7 +30,24 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-LEVEL_AVG = (10 + 5 / 4.0 + 4 / 16.0) / 19.0   # pixel count of the average Gauss-Newton launch / P (10, 5, 4 iterations on levels 0, 1, 2)
+GN_ITERS = (10, 5, 4)     # Gauss-Newton iterations on pyramid levels 0, 1, 2
+GN_PERSIST = 4            # ifx option gn_persist (a bit per level): levels whose iterations run in ONE persistent launch (k_gn_level); default: the coarsest
+
+
+def level_avg(persist=None):
+    """pixel count of the average two-launch Gauss-Newton iteration / P: the levels that do not use the persistent kernel"""
+    persist = GN_PERSIST if persist is None else persist
+    px = sum(GN_ITERS[l] / 4.0 ** l for l in range(3) if not persist & (1 << l))
+    n = sum(GN_ITERS[l] for l in range(3) if not persist & (1 << l))
+    return px / n if n else 0.0
+
+
+def gn_level_bytes(P, persist=None):
+    """average k_gn_level launch: per pixel 39 B of frame-side constants once (vertex + normal 24, depth 4, intensity 1 + 4x4 window ~4 after reuse, gradients 4) + per
+    iteration 41 B of gathers (model vertex + normal 24, depth 4, intensity 1, cloud point 12), over the levels that use it"""
+    persist = GN_PERSIST if persist is None else persist
+    lv = [l for l in range(3) if persist & (1 << l)]
+    return sum(P / 4.0 ** l * (39.0 + GN_ITERS[l] * 41.0) for l in lv) / len(lv) if lv else 0.0
 
 
 def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float = 0.3, vl=None) -> float:
@@ -53,11 +70,9 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
         "project_bbox": P * (4.0 + 192),                    # id image + the 12 vote planes of the surfel under every pixel
         "count_colour_px": P * (4.0 + 192 + 8),
         # tracker: per-pixel passes, averaged over the pyramid levels a launch can run at
-        # persistent level kernel, averaged over the three levels: per pixel 39 B of frame-side constants once (vertex + normal 24, depth 4, intensity 1 + 4x4 window ~4 after
-        # reuse, gradients 4) + per iteration 41 B of gathers (model vertex + normal 24, depth 4, intensity 1, cloud point 12); iterations 10 / 5 / 4 on P, P/4, P/16
-        "gn_level": P * ((1 + 0.25 + 0.0625) * 39.0 + (10 + 5 * 0.25 + 4 * 0.0625) * 41.0) / 3.0,
-        "icp_residual": P * LEVEL_AVG * (48.0 + 22.0),     # ICP 24 B coalesced + 24 B gathered; residual 14 B read + 8 B written
-        "rgb_step_solve": P * LEVEL_AVG * 24.0,            # 8-B record + 4 B gradients + 12 B gathered cloud point
+        "gn_level": gn_level_bytes(P),
+        "icp_residual": P * level_avg() * (48.0 + 22.0),     # ICP 24 B coalesced + 24 B gathered; residual 14 B read + 8 B written
+        "rgb_step_solve": P * level_avg() * 24.0,            # 8-B record + 4 B gradients + 12 B gathered cloud point
         "bilateral_metric": P * (2.0 + 2 + 4 + 4),
         "splat_resolve": P * (8.0 + 16 + 16 + 4 + 4 + 2 + 16 + 16 + 4),
         "index_resolve": P * (8.0 + 4 + 48 + 16),
@@ -91,6 +106,7 @@ def main():
                     "unrelated in space -- the worst case for the passes that gather the visible part of the store) or `morton` (spatially coherent, as a map built frame by frame is)")
     ap.add_argument("--trace-steps", action="store_true", help="print the host time of every timed step to stderr (diagnostic)")
     ap.add_argument("--no-instance", action="store_true")
+    ap.add_argument("--seg-host-frame", action="store_true", help="segmentation calls take the frame's RGB / depth from host memory (the reference's signature) instead of the resident frame")
     ap.add_argument("--pace", action="store_true", help="with --no-instance: wait for every frame's result before the next is enqueued (diagnostic)")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -154,6 +170,9 @@ def main():
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ef.set_option(k_, int(v_))
+        if k_ == "gn_persist":
+            global GN_PERSIST
+            GN_PERSIST = int(v_)
     d_rgb = torch.from_numpy(st["rgb"]).cuda(dev)
     d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda(dev)
     torch.cuda.synchronize()
@@ -207,7 +226,12 @@ def main():
                 if osh is not None:   # sharded map: the owners' boxes / model depth / table statistics are merged at the call's exchange points
                     osh.process_segmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
                 else:
-                    inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
+                    # the call belongs to the frame just processed, whose images are resident on the device (ifx_process_segmentation with rgb = depth = NULL);
+                    # --seg-host-frame hands the host copies over instead, as InstanceFusion::ProcessSegmentation's signature has them (1.5 MB staged + uploaded)
+                    if args.seg_host_frame:
+                        inst.ProcessSegmentation(st["rgb"][i], st["depth"][i], mk, cl, seg["frame"], superpixels=not args.no_superpixels)
+                    else:
+                        inst.ProcessSegmentation(None, None, mk, cl, seg["frame"], superpixels=not args.no_superpixels)
 
     def place_call_in_window(n_frames):
         """The adaptive cadence (every 46th frame once the map carries votes, IF/Core/InstanceFusion.cpp:192-238) would leave a short

@@ -300,7 +300,13 @@ int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
  *   "two_streams" 0       -- everything on one stream; "track_ahead" 0 -- do not enqueue the announced frame's tracker behind the current frame
  *   "stage_timing" / "kernel_timing" 1 -- HIP-event records for ifx_stage_ms / ifx_kernel_ms (cost frame rate: off by default)
  *   "icp_blocks" n        -- cap on the blocks of a tracker reduction launch (0 = by image size)
- *   "raster_tiles" -1|0|1 -- tiled rasteriser (key tiles in LDS): by image size (on from 1 Mpixel) | off | on; results are identical either way */
+ *   "raster_tiles" -1|0|1 -- tiled rasteriser (key tiles in LDS): by image size (on from 1 Mpixel) | off | on; results are identical either way
+ *   "pace" 0              -- ifx_enqueue_frame_device normally waits for the PREVIOUS frame's result before it enqueues (the tracker announced ahead keeps the
+ *                           device busy meanwhile); 0 = enqueue without looking back (a host that runs frames ahead measured 25 % slower)
+ *   "gn_persist" mask     -- bit i: the Gauss-Newton iterations of pyramid level i in one persistent launch with grid barriers (default 4 = the coarsest level)
+ *   "lazy_ids" 0          -- render the whole id image every frame (default: the lattice whetherDoSegmentation samples; the rest on demand)
+ *   "fold_finish" 0, "seg_device" 0, "seg_aside" 0, "ff_union" 0, "ff_rounds" n -- the earlier forms of the end-of-frame sums and of the segmentation call's
+ *                           schedule (host-driven / on the main stream / relaxation-only flood fill / length of the fixed relaxation schedule); identical results */
 int ifx_set_option(ifx_t* h, const char* name, int value);
 
 /* R32I surfel-id image after fusion (getSurfelIdsAfterFusionGpu, ElasticFusionInterface.h:90-102):
@@ -354,7 +360,9 @@ int ifx_tracker_buffer_download(ifx_t* h, const char* name, int level, void* out
 int ifx_should_segment(ifx_t* h, int frame);
 /* masks: n x H x W u8 (0/255), sorted by area descending (the contract of the Mask-RCNN bridge,
  * build/mask_ori.py:117); class_ids: n COCO indices.  flags bit0: kNN smoothing of the instance colours
- * (isflann: flannKnnVoteSurfelMap, IF/Core/InstanceFusion.cpp:1070-1163), bit1: superpixel refinement (needs rgb and depth of the frame, host pointers). */
+ * (isflann: flannKnnVoteSurfelMap, IF/Core/InstanceFusion.cpp:1070-1163), bit1: superpixel refinement (needs rgb and depth of the frame: host pointers, as
+ * InstanceFusion::ProcessSegmentation takes them -- or BOTH NULL = the frame most recently processed, whose raw images are still resident in their frame slot:
+ * no staging copy, no upload). */
 int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth,
                              const uint8_t* masks, const int32_t* class_ids, int n, int frame,
                              int flags);

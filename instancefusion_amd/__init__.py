@@ -540,8 +540,9 @@ class InstanceFusion:
         return bool(self.ef._chk(self.L.ifx_should_segment(self.ef.handle, int(frame)), "ifx_should_segment"))
 
     def ProcessSegmentation(self, rgb, depth, masks, class_ids, frame, isflann=False, superpixels=False):
-        rgb = np.ascontiguousarray(rgb, np.uint8)
-        depth = np.ascontiguousarray(depth, np.uint16)
+        """InstanceFusion::ProcessSegmentation.  rgb = depth = None: the frame most recently processed (still resident on the device) instead of host copies."""
+        rgb = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
+        depth = None if depth is None else np.ascontiguousarray(depth, np.uint16)
         masks = np.ascontiguousarray(masks, np.uint8)
         cls = np.ascontiguousarray(class_ids, np.int32)
         flags = (1 if isflann else 0) | (2 if superpixels else 0)

@@ -572,7 +572,37 @@ __global__ __launch_bounds__(1024) void k_sp_connect(int spn, float* __restrict_
             if (!(m & (1u << j)) && nbr[a * NB_MAX + j] != -1) { nbr[a * NB_MAX + j] = -1; A[SPI_NP_FIRST + j] = -1.f; }
     }
     __syncthreads();
-    for (int round = 0; round < 4 * 1024; round++) {   // (the fixpoint arrives within ~log(diameter) rounds; the bound only guards against a corrupt table)
+    // Nodes joined by entries in BOTH directions reach each other, so they end with one label: those classes first, by union-find on the label array (the larger
+    // root is hung under the smaller, atomicMin, retried until it sticks), then every node points at its class's smallest member.  The directed propagation below
+    // starts from that valid state ("my label is a node that reaches me") and has only the one-way entries left to honour: 2-3 rounds where the plain propagation
+    // needed one per step of the longest chain (65 -> ~25 us for 1200 nodes).
+    for (int a = tid; a < spn; a += nt) {
+        for (int j = 0; j < NB_MAX; j++) {
+            const int b = nbr[a * NB_MAX + j];
+            if (b < 0 || b < a) continue;                       // (each mutual pair once, from its smaller end)
+            bool back = false;
+            for (int k = 0; k < NB_MAX; k++) back = back || nbr[b * NB_MAX + k] == a;
+            if (!back) continue;
+            int ra = a, rb = b;
+            for (;;) {
+                { int p_ = ((volatile int*)label)[ra]; while (p_ != ra) { ra = p_; p_ = ((volatile int*)label)[ra]; } }
+                { int p_ = ((volatile int*)label)[rb]; while (p_ != rb) { rb = p_; p_ = ((volatile int*)label)[rb]; } }
+                if (ra == rb) break;
+                if (ra > rb) { const int s_ = ra; ra = rb; rb = s_; }
+                const int old = atomicMin(&label[rb], ra);
+                if (old == rb) break;
+                rb = old;
+            }
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < spn; a += nt) {
+        int r = a, p_ = ((volatile int*)label)[r];
+        while (p_ != r) { r = p_; p_ = ((volatile int*)label)[r]; }
+        if (r != a) label[a] = r;   // (a concurrent reader walking through a sees either pointer: both lead to r)
+    }
+    __syncthreads();
+    for (int round = 0; round < 4 * 1024; round++) {   // (the bound only guards against a corrupt table)
         int any = 0;
         for (int a = tid; a < spn; a += nt) {
             const int la = label[a];
@@ -781,19 +811,36 @@ void ifx_slic_free(ifx* h)
 
 // steps -1_1 .. -1_3 of processInstance (IF/Core/InstanceFusion.cpp:722-738): the masks in h->d_masks ([nm][P], already
 // through clean-overlap) are refined in place on the device
-// In two halves for the device-scheduled call: the superpixels and their merge need the frame only, so they are on the queue before the host starts copying the
-// masks into pinned memory (2.4 MB for eight masks: 0.1 ms during which the device used to wait); the region filter follows the masks.
-int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth)
+// The frame of a segmentation call into the superpixel buffers.  rgb == depth == NULL: the frame most recently processed -- the call belongs to it, and its
+// raw images are still in their frame slot (the slot is reused two frames later) -- is copied on the device; otherwise the caller's images go through the
+// handle's pinned staging (free here: ifx_process_frame, its other user, synchronises before it returns; a copy from pageable memory would make the call
+// wait for everything queued in front of it).
+static int slic_load_frame(ifx* h, SlicBuf* b, const uint8_t* rgb, const uint16_t* depth)
 {
-    if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame"; return IFX_E_INVALID; }
-    SlicBuf* b;
-    int r = slic_buffers(h, &b);
-    if (r) return r;
     const size_t P = b->P;
+    if (!rgb && !depth) {
+        if (h->tick < 2) { h->err = "superpixel refinement of the resident frame: no frame has been processed yet"; return IFX_E_STATE; }
+        const FrameSlot& f = h->slot[(h->tick - 1) & 1];
+        HIPCHK(h, hipMemcpyAsync(b->rgb, f.rgb, P * 3, hipMemcpyDeviceToDevice, h->cur));
+        HIPCHK(h, hipMemcpyAsync(b->depth, f.depth_raw, P * 2, hipMemcpyDeviceToDevice, h->cur));
+        return IFX_OK;
+    }
+    if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame (or neither: the resident frame)"; return IFX_E_INVALID; }
     std::memcpy(h->rgb_stage, rgb, P * 3);
     std::memcpy(h->depth_stage, depth, P * 2);
     HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->cur));
     HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->cur));
+    return IFX_OK;
+}
+
+// In two halves for the device-scheduled call: the superpixels and their merge need the frame only, so they are on the queue before the host starts copying the
+// masks into pinned memory (2.4 MB for eight masks: 0.1 ms during which the device used to wait); the region filter follows the masks.
+int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth)
+{
+    SlicBuf* b;
+    int r = slic_buffers(h, &b);
+    if (r) return r;
+    if ((r = slic_load_frame(h, b, rgb, depth))) return r;
     if ((r = slic_run(h, b))) return r;
     return merge_run(h, b);
 }
@@ -808,17 +855,10 @@ int ifx_superpixel_filter(ifx* h, int nm)
 int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame)
 {
     (void)frame;
-    if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame"; return IFX_E_INVALID; }
     SlicBuf* b;
     int r = slic_buffers(h, &b);
     if (r) return r;
-    const size_t P = b->P;
-    // through the handle's pinned staging (free here: ifx_process_frame, its other user, synchronises before it returns): a copy from the caller's pageable
-    // memory would make the call wait for everything queued in front of it
-    std::memcpy(h->rgb_stage, rgb, P * 3);
-    std::memcpy(h->depth_stage, depth, P * 2);
-    HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->cur));
-    HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->cur));
+    if ((r = slic_load_frame(h, b, rgb, depth))) return r;
     if ((r = slic_run(h, b))) return r;
     if ((r = merge_run(h, b))) return r;
     return filter_run(h, b, h->d_masks, nm, true);

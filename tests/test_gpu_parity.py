@@ -1157,6 +1157,30 @@ def test_lookahead_equivalence(ifx, small_stream):
     assert np.array_equal(poses, ref[0][:n])
 
 
+def test_segmentation_call_on_the_resident_frame(ifx):
+    """ifx_process_segmentation with rgb = depth = NULL refines the masks on the frame most recently processed, still resident in its frame slot: the same
+    tables, votes, labels and colours as with the host copies of that frame handed over (the reference's signature)."""
+    from instancefusion_amd import synth
+
+    W, H = 320, 240
+    K = dict(fx=264.0, fy=264.0, cx=160.0, cy=120.0)
+    st = synth.make_stream(16, W, H, noise=True, loop_len=90, **K)
+    outs = []
+    for resident in (False, True):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=400_000, confidence=2.0, **K)
+        inst = ifx.InstanceFusion(g)
+        for i in range(16):
+            g.processFrame(st["rgb"][i], st["depth"][i])
+            if i in (7, 11, 15):
+                mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+                inst.ProcessSegmentation(None if resident else st["rgb"][i], None if resident else st["depth"][i], mk, cl, i + 1, superpixels=True)
+        outs.append((g.download(), inst.labels(), inst.getInstanceTable()))
+        g.close()
+    assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in MAP_KEYS)
+    assert np.array_equal(outs[0][1], outs[1][1]) and (outs[0][1] >= 0).any()
+    assert np.array_equal(np.asarray(outs[0][2]), np.asarray(outs[1][2]))
+
+
 # ---------------------------------------------------------------- a19: flood fill of the masks on the device
 def test_flood_fill_exact(ifx, orc):
     """The device label propagation (label = earliest pixel that reaches me) against the oracle's sequential

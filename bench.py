@@ -89,6 +89,7 @@ STAGE_OF = {"track": ("icp_residual", "rgb_step_solve", "gn_level", "model_l0", 
 
 
 def main():
+    global GN_PERSIST
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -171,7 +172,6 @@ def main():
         k_, v_ = kv.split("=")
         ef.set_option(k_, int(v_))
         if k_ == "gn_persist":
-            global GN_PERSIST
             GN_PERSIST = int(v_)
     d_rgb = torch.from_numpy(st["rgb"]).cuda(dev)
     d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda(dev)
@@ -281,12 +281,14 @@ def main():
         for k in range(k_first, k_first + n):
             fn(k)
             if args.trace_steps:
-                marks.append(time.perf_counter())
+                marks.append((time.perf_counter(), ef.view_list_stats().get("scans", 0) if sh is None else 0))
         barrier()
         t1 = time.perf_counter()
         if args.trace_steps and rank == 0:   # host times of the steps (the host waits for every frame's result: they follow the device closely)
-            prev = t0
-            print("step trace (ms): " + " ".join(f"{(m - p_) * 1e3:.3f}" for m, p_ in zip(marks, [t0] + marks[:-1])) + f" | drain {(t1 - marks[-1]) * 1e3:.3f}", file=sys.stderr)
+            ts = [m[0] for m in marks]
+            sc = [m[1] for m in marks]
+            print("step trace (ms; * = the step enqueued a view-list scan): " + " ".join(f"{(m - p_) * 1e3:.3f}{'*' if k_ and sc[k_] != sc[k_ - 1] else ''}" for k_, (m, p_) in enumerate(zip(ts, [t0] + ts[:-1])))
+                  + f" | drain {(t1 - ts[-1]) * 1e3:.3f}", file=sys.stderr)
         return t1 - t0
 
     k = 1
@@ -345,6 +347,8 @@ def main():
         vl = (vls.get("window", 0), vls.get("outside", 0))
         alg = lambda n_: algorithmic_bytes(n_, n_slots, P, vl=vl)
         best, table = None, {}
+        if ef.kernel_ms("gn_level")[1] == 0:   # (no level small enough for the persistent kernel at this resolution: every iteration is the two-launch form)
+            GN_PERSIST = 0
         for nme in names:
             avg, cnt = ef.kernel_ms(nme)
             table[nme] = dict(avg_ms=avg, launches=cnt, total_ms=avg * cnt)

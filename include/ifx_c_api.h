@@ -304,6 +304,7 @@ int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
  *   "pace" 0              -- ifx_enqueue_frame_device normally waits for the PREVIOUS frame's result before it enqueues (the tracker announced ahead keeps the
  *                           device busy meanwhile); 0 = enqueue without looking back (a host that runs frames ahead measured 25 % slower)
  *   "gn_persist" mask     -- bit i: the Gauss-Newton iterations of pyramid level i in one persistent launch with grid barriers (default 4 = the coarsest level)
+ *                           while that level's grid has at most "gn_persist_blocks" blocks (default 128: 160x120 pixels -- 75 blocks -- wins, 320x240 loses)
  *   "lazy_ids" 0          -- render the whole id image every frame (default: the lattice whetherDoSegmentation samples; the rest on demand)
  *   "fold_finish" 0, "seg_device" 0, "seg_aside" 0, "ff_union" 0, "ff_rounds" n -- the earlier forms of the end-of-frame sums and of the segmentation call's
  *                           schedule (host-driven / on the main stream / relaxation-only flood fill / length of the fixed relaxation schedule); identical results */

@@ -295,6 +295,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
         if (value) { h->err = "model_fused: a measured alternative that lost (DESIGN.md section 6); this library was built without -DIFX_EXPERIMENTS"; return IFX_E_STATE; }
 #endif
     }
+    else if (s == "gn_persist_blocks") { if (value < 1) return IFX_E_INVALID; ifx_drop_tracked(h); h->opt_gn_persist_blocks = value; }
     else if (s == "gn_persist") {   // a bit per pyramid level: that level's Gauss-Newton iterations in one persistent launch (k_gn_level); default 4 = the coarsest level only
         if (value < 0 || value > 7) { h->err = "gn_persist is a mask of pyramid levels (0..7)"; return IFX_E_INVALID; }
         ifx_drop_tracked(h);

@@ -243,6 +243,7 @@ struct ifx {
     int opt_reference_passes = 0;   // also run the id renders nobody consumes (EF/ElasticFusion.cpp:679-680)
     int opt_icp_px = 0;              // ICP and residual reductions on the same pixels of one thread, all loads in two batches (k_icp_residual_px; bits: 1 level 0, 2 levels 1-2, 4 one pixel per thread); measured slower: off
     int opt_model_fused = 0;         // model pyramid of the frame tracker in one launch (k_model_pyr3) when the image size allows; measured equal to the three launches (28 vs 27 us): off
+    int opt_gn_persist_blocks = 128;  // ... and only while its grid has at most this many blocks: the meetings cost grows with the blocks (75 at 160 x 120: faster; 300: slower)
     int opt_gn_persist = 4;          // bit i: all Gauss-Newton iterations of pyramid level i in one persistent launch (k_gn_level) when its grid fits the GPU; faster at the coarsest level only
     int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)

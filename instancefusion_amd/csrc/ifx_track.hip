@@ -2403,7 +2403,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             int q = -1, nbp = 0;
             for (int t = 0; t < 4 && q < 0; t++) {   // (fewer, fatter blocks at the finer levels -- 4 pixels per thread -- were tried for cheaper meetings: slower)
                 const int need = cdiv(n, RED_THREADS * pxs[t]);
-                if (need <= h->gn_max_blocks[t] * 7 / 8) { q = t; nbp = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
+                if (need <= h->gn_max_blocks[t] * 7 / 8 && need <= h->opt_gn_persist_blocks) { q = t; nbp = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
             }
             if (q >= 0) {
                 LevelArgs la;

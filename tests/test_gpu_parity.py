@@ -644,7 +644,8 @@ def test_persistent_level_kernel_is_bit_identical(ifx):
     rows and the same exact sums as the two launches per iteration -- trajectories and maps bit-identical whichever levels use it (the default is the coarsest
     level only, where the meetings of 75 blocks cost less than launch boundaries).  A barrier that timed out would show up as a different
     pose, and as an error of ifx_sync."""
-    _tracker_variants_equal(ifx, [dict(gn_persist=0), dict(gn_persist=7), dict(gn_persist=4), dict(gn_persist=6)])
+    big = 1 << 20   # (by default a level uses the kernel only while its grid has at most 128 blocks: lifted here so that every level really runs it)
+    _tracker_variants_equal(ifx, [dict(gn_persist=0), dict(gn_persist=7, gn_persist_blocks=big), dict(gn_persist=4), dict(gn_persist=6, gn_persist_blocks=big)])
 
 
 def test_lost_tracker_experiments_are_bit_identical(ifx):

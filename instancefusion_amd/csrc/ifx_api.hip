@@ -101,7 +101,10 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
         hipError_t r2 = prio ? hipStreamCreateWithPriority(&h->stream_b, hipStreamDefault, lo) : hipStreamCreate(&h->stream_b);
         if (r1 != hipSuccess || r2 != hipSuccess) { g_err = "hipStreamCreate failed"; delete h; return IFX_E_HIP; }
         hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming);
-        hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_s, hipStreamDefault, hi) : hipStreamCreate(&h->stream_s);
+        // ONE more stream for everything that runs beside the main stream now and then (the model-to-model tracker of the loop-closure detection, a segmentation call):
+        // the runtime multiplexes streams onto four hardware queues, the process's default stream has one, and a fifth stream shares a queue with another -- whose
+        // barrier packets then hold it up (a stream of its own for the segmentation call cost closeLoops = true two thirds of its frame rate: 1031 -> 348 frames/s)
+        hipError_t r3 = prio ? hipStreamCreateWithPriority(&h->stream_c, hipStreamDefault, hi) : hipStreamCreate(&h->stream_c);
         if (r3 != hipSuccess) { g_err = "hipStreamCreate failed"; ifx_destroy(h); return IFX_E_HIP; }
     }
     h->cur = h->stream;
@@ -198,7 +201,6 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_slic_free(h);
     ifx_knn_free_all(h);
     for (int q = 0; q < 2; q++) { if (h->slot[q].ready) hipEventDestroy(h->slot[q].ready); if (h->slot[q].released) hipEventDestroy(h->slot[q].released); }
-    if (h->stream_s) hipStreamDestroy(h->stream_s);
     if (h->ev_gate) hipEventDestroy(h->ev_gate);
     if (h->stream_c) hipStreamDestroy(h->stream_c);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
@@ -215,9 +217,10 @@ extern "C" int ifx_set_loop_closure(ifx_t* h, int enable, int count_thresh, floa
     if (enable) {
         int r = ifx_tracker_alloc_m2m(h);
         if (r) return r;
-        if (!h->stream_c) {
-            if (hipStreamCreate(&h->stream_c) != hipSuccess || hipEventCreateWithFlags(&h->ev_lc_ready, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_lc_done, hipEventDisableTiming) != hipSuccess) { h->err = "stream / event creation failed"; return IFX_E_HIP; }
+        if (!h->stream_c && hipStreamCreate(&h->stream_c) != hipSuccess) { h->err = "stream creation failed"; return IFX_E_HIP; }   // (one-stream handles)
+        if (!h->ev_lc_ready) {
+            if (hipEventCreateWithFlags(&h->ev_lc_ready, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_lc_done, hipEventDisableTiming) != hipSuccess) { h->err = "event creation failed"; return IFX_E_HIP; }
         }
     }
     h->lc_enable = enable ? 1 : 0; h->lc_count_thresh = count_thresh; h->lc_err_thresh = err_thresh; h->lc_cov_thresh = cov_thresh;

@@ -220,11 +220,11 @@ struct ifx {
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
-    hipStream_t stream_s = nullptr;     // a segmentation call that finds the next frame's tracker already queued on the main stream runs here, beside it (the call
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
     int opt_pace = 1;                   // ifx_enqueue_frame_device waits for the previous frame's result before it enqueues (bounded run-ahead)
     int opt_ff_union = 1;               // flood fill of the masks: two-way edges merged by union-find before the directed relaxation (k_ff_merge)
-    int opt_seg_aside = 1;              // is synchronous for the host, so nothing has to join afterwards); ifx_instance / ifx_slic / ifx_knn enqueue on h->cur throughout
+    int opt_seg_aside = 1;              // a segmentation call that finds the next frame's tracker already queued on the main stream runs beside it on stream_c (the call is
+                                        // synchronous for the host, so nothing has to join afterwards); ifx_instance / ifx_slic / ifx_knn enqueue on h->cur throughout
     hipEvent_t ev_result = nullptr;     // the `released` event of the slot of the last frame (recorded after k_frame_result)
     const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
     const uint16_t* hint_depth = nullptr;

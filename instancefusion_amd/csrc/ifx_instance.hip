@@ -1028,16 +1028,16 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     if (!h || nm < 0 || (nm > 0 && (!masks_in || !class_ids))) return IFX_E_INVALID;
     if (nm > 256) { h->err = "too many masks"; return IFX_E_INVALID; }
     // The next frame's tracker is already queued on the main stream (enqueue_frame, "tracked ahead") and touches nothing this call does: the call's ~60 short
-    // launches then go to a stream of their own and run beside the tracker's 170 instead of behind them.  The call ends with the host waiting for its stream,
+    // launches then go to the handle's third stream (the loop-closure tracker's: four streams is what the runtime's hardware queues hold) and run beside the tracker's 170 instead of behind them.  The call ends with the host waiting for its stream,
     // so whatever the caller enqueues next is ordered behind it as before.
-    const bool aside = h->opt_seg_aside && h->stream_s && h->opt_seg_device && !h->own && h->tracked_ahead == h->tick && h->cur == h->stream;
+    const bool aside = h->opt_seg_aside && h->stream_c && h->opt_two_streams && h->opt_seg_device && !h->own && h->tracked_ahead == h->tick && h->cur == h->stream;
     if (aside) {
-        if (h->ev_result) HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_result, 0));   // behind the frame the call belongs to
-        h->cur = h->stream_s;
+        if (h->ev_result) HIPCHK(h, hipStreamWaitEvent(h->stream_c, h->ev_result, 0));   // behind the frame the call belongs to
+        h->cur = h->stream_c;
     }
     const int r = h->opt_seg_device ? process_segmentation_device(h, rgb, depth, masks_in, class_ids, nm, frame, flags)
                                     : process_segmentation_host(h, rgb, depth, masks_in, class_ids, nm, frame, flags);
-    if (aside) { hipStreamSynchronize(h->stream_s); h->cur = h->stream; }
+    if (aside) { hipStreamSynchronize(h->stream_c); h->cur = h->stream; }
     // a call that failed part-way may have updated votes without the label scan that follows them: the incremental scan of the next call assumes
     // that votes outside its own id image are unchanged since the last scan, so the next call scans everything
     if (r != IFX_OK) h->labels_stale_all = 1;

@@ -149,8 +149,13 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8 * 3); h->key_ids = h->key_splat + P; h->key_both = h->key_splat + 2 * P;
     hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8 * 3);
     ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16 * 2); h->index_nr = h->index_vc + 4 * P; ALLOC(h->index_ct, P * 16); ALLOC(h->index_tap, P * 16);
-    h->pred_bytes = ((P * 42 + 15) / 16) * 16 + 16;   // + the tail: [0] vote mass of the owned surfels under the id image (whetherDoSegmentation), summed with the prediction
-    ALLOC(h->pred_vertex, h->pred_bytes); h->pred_normal = h->pred_vertex + 4 * P; h->pred_image = (uint8_t*)(h->pred_normal + 4 * P); h->pred_inst = h->pred_image + 4 * P;
+    // [pred_vertex | pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail]: everything behind pred_vertex travels (sharded map).  The vertex itself does not: it is
+    // a function of the pixel and of the winning key's depth, which every rank holds after the key exchange -- only its fourth component, the winner's confidence, is the
+    // owner's to tell (pred_conf, 4 B per pixel instead of 16).  Tail: [0] vote mass of the owned surfels under the id image (whetherDoSegmentation), summed with the prediction.
+    const size_t conf_bytes = ((P * 4 + 15) / 16) * 16;
+    h->pred_bytes = P * 16 + conf_bytes + ((P * 26 + 15) / 16) * 16 + 16;
+    ALLOC(h->pred_vertex, h->pred_bytes); h->pred_conf = (float*)((uint8_t*)h->pred_vertex + P * 16); h->pred_normal = (float*)((uint8_t*)h->pred_conf + conf_bytes);
+    h->pred_image = (uint8_t*)(h->pred_normal + 4 * P); h->pred_inst = h->pred_image + 4 * P;
     h->pred_time = (uint16_t*)(h->pred_inst + 4 * P); h->pred_tail = (int*)((uint8_t*)h->pred_vertex + h->pred_bytes - 16);
     hipMemset(h->pred_vertex, 0, h->pred_bytes);
     ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
@@ -864,7 +869,7 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 2: if (!first) add(h->key_index, P * 8, 0); break;
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
-    case 5: add(h->pred_vertex, h->pred_bytes, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
+    case 5: add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
     case 6: break;
     case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank
     case 300: if (owner_lc_due(h)) add(h->key_splat, P * 16, 0); break;                       // the detection's two renders: [key_splat (ACTIVE) | key_ids (INACTIVE)]

@@ -334,7 +334,7 @@ struct ifx {
     uint32_t* index_id = nullptr;
     float *index_vc = nullptr, *index_ct = nullptr, *index_nr = nullptr, *index_tap = nullptr;
     // predictions
-    float *pred_vertex = nullptr, *pred_normal = nullptr;
+    float *pred_vertex = nullptr, *pred_normal = nullptr, *pred_conf = nullptr;
     uint8_t *pred_image = nullptr, *pred_inst = nullptr;
     uint16_t* pred_time = nullptr;
     float *fill_vertex = nullptr, *fill_normal = nullptr;

@@ -431,7 +431,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -465,9 +465,14 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
     uchar4 io = make_uchar4(0, 0, 0, 0), so = make_uchar4(0, 0, 0, 0);
     uint16_t to = 0;
     if (key != IFX_KEY_EMPTY) {
-        const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
         const int li = local_slot(c, st->count, (unsigned int)(key & 0xFFFFFFFFull));
-        if (li < 0) key = IFX_KEY_EMPTY;   // sharded map: the winner's rank writes this pixel, the others leave zeros (summed bitwise across ranks)
+        if (li < 0) {   // sharded map: the winner's rank writes this pixel, the others leave zeros (summed bitwise across ranks) ...
+            if (pconf) {   // ... except the vertex of the frame's prediction, which every rank rebuilds from the key it holds (the confidence comes from the owner through pconf)
+                const float z = key_depth(key);
+                vo = make_float4(((float)x + 0.5f - c.cx) * z * (1.f / c.fx), ((float)y + 0.5f - c.cy) * z * (1.f / c.fy), z, 0.f);
+            }
+            key = IFX_KEY_EMPTY;
+        }
     }
     if (key != IFX_KEY_EMPTY) {
         const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
@@ -486,6 +491,7 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
         so = make_uchar4((uint8_t)(int)roundf(c3[0] * 255.0f), (uint8_t)(int)roundf(c3[1] * 255.0f), (uint8_t)(int)roundf(c3[2] * 255.0f), 255);
         to = (uint16_t)(unsigned int)t2.x;
     }
+    if (pconf) { pconf[k] = vo.w; vo.w = 0.f; }   // (owner: the confidence travels apart; fill_in puts it back after the exchange)
     pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
     (void)n_valid;
     if (fold.acc) {   // (uniform)
@@ -2471,13 +2477,15 @@ __global__ void k_owner_count(DevState* st, const int* total)
     if (threadIdx.x == 0) { st->next_seq = (unsigned int)st->count; st->count = *total; st->n_dead = 0; }
 }
 // fill_rgb / fill_vertex / fill_normal.frag on the exchanged prediction (EF/Shaders/FillIn.cpp:65-195): the second half of k_splat_resolve
-__global__ void k_fill_in(Cam c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt, const float4* __restrict__ pv, const float4* __restrict__ pn,
-                          const uchar4* __restrict__ pimg, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg)
+__global__ void k_fill_in(Cam c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, const float4* __restrict__ pn,
+                          const uchar4* __restrict__ pimg, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg, const float* __restrict__ pconf)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
     const int k = y * c.w + x;
-    const float4 vo = pv[k], no = pn[k];
+    float4 vo = pv[k];
+    const float4 no = pn[k];
+    if (pconf) { vo.w = pconf[k]; pv[k] = vo; }   // the winner's confidence, summed across the ranks apart from the vertex every rank rebuilt itself
     const uchar4 io = pimg[k];
     float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
     if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2], 255);
@@ -2541,11 +2549,11 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         case 5:
             LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                    (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
-                   (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr, FinishFold());
+                   (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, (int32_t*)nullptr, (int*)nullptr, FinishFold(), h->pred_conf);
             break;
         case 6:
-            LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
-                   (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+            LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (float4*)h->pred_vertex, (const float4*)h->pred_normal,
+                   (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, (const float*)h->pred_conf);
             LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
                    (int*)nullptr, h->pred_tail);
             break;
@@ -2602,7 +2610,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
     case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
-               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr, FinishFold());
+               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr, FinishFold(), h->pred_conf);
         if (in_frame) {   // whetherDoSegmentation sums: empty pixels replicated, vote mass by the owners -> the tail of the prediction block
             const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);
             LAUNCH(h, "raster_finish", dim3(1 + nseg), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, ds, h->d_list_ctr, ifx_idmap(h),
@@ -2611,8 +2619,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         break;
     }
     case 6:                                                                                                 // fill-in and dense flag on the exchanged prediction (replicated); takes the summed vote mass
-        LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (const float4*)h->pred_vertex, (const float4*)h->pred_normal,
-               (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image);
+        LAUNCH(h, "fill_in", g2, b2, k_fill_in, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, (float4*)h->pred_vertex, (const float4*)h->pred_normal,
+               (const uchar4*)h->pred_image, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, (const float*)h->pred_conf);
         LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 1, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h),
                (int*)nullptr, in_frame ? h->pred_tail : (int*)nullptr);
         break;

@@ -123,7 +123,7 @@ int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint1
  * counterpart (one GPU, IF/main.cpp:75); BASELINE.json's north star asks for "RCCL all-reduce over xGMI ... all-to-all for cross-shard surfel
  * reprojection" with the host in C++.  The library holds a RCCL communicator (librccl.so.1 loaded with dlopen on first use: a single-GPU process
  * never maps it) and issues the exchange of every phase on the handle's main stream, between the kernels of two phases: no host round trip inside a
- * frame, six collectives per frame (u64 MIN of key images, int32 SUM of the winners' attribute blocks), 122 bytes per pixel.
+ * frame, six collectives per frame (u64 MIN of key images and of the association verdicts, int32 SUM of the winners' attribute blocks), 80 bytes per pixel.
  *   ifx_comm_unique_id(out128)       ncclGetUniqueId on one rank; the host hands the 128 bytes to the other ranks (MPI, a file, a socket, torch.distributed)
  *   ifx_owner_init_comm(h, id128)    ncclCommInitRank(n_ranks, id, rank) on the handle's device -- collective: every rank calls it
  *   ifx_owner_set_comm(h, comm)      adopt a ncclComm_t the host already owns (size / rank must match the handle's); NULL: back to caller-driven exchanges

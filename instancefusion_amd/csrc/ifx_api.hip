@@ -163,6 +163,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->ids_after, 0, P * 4); hipMemset(h->ids_tmp, 0, P * 4);
     hipMemset(h->pred_vertex, 0, P * 16); hipMemset(h->pred_normal, 0, P * 16); hipMemset(h->pred_image, 0, P * 4);
     hipMemset(h->index_id, 0, P * 4);
+    { const size_t nm_ = (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2); ALLOC(h->assoc_key, nm_ * 8); hipMemset(h->assoc_key, 0xFF, nm_ * 8); }
     ALLOC(h->assoc_target, P * 4); ALLOC(h->meas_pc, P * 16); ALLOC(h->meas_nr, P * 16); ALLOC(h->meas_col, P * 4);
     if (ifx_alloc_tracker(h) != IFX_OK) { g_err = h->err; ifx_destroy(h); return IFX_E_HIP; }
     if (ifx_alloc_instance(h) != IFX_OK) { g_err = h->err; ifx_destroy(h); return IFX_E_HIP; }
@@ -196,7 +197,7 @@ extern "C" void ifx_destroy(ifx_t* h)
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat,
                     h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,
-                    h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
+                    h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_key, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->h_result) hipHostFree(h->h_result);
     if (h->rgb_stage) hipHostFree(h->rgb_stage);
@@ -865,7 +866,7 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
     switch (phase) {
     case 0: if (!first) add(h->key_index, P * 8, 0); break;
-    case 1: if (!first) add(h->index_vc, P * 32, 1); break;                                   // [index_vc | index_nr], one allocation
+    case 1: if (!first) add(h->assoc_key, (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2) * 8, 0); break;   // the best owned candidate of every measurement pixel (distance | window position)
     case 2: if (!first) add(h->key_index, P * 8, 0); break;
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)

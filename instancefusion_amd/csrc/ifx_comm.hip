@@ -13,12 +13,12 @@
 //
 // Exchange points of a frame (ifx_owner_exchange; all buffers that travel together are one allocation, so each is ONE collective):
 //   after phase 0  key_index                               u64 MIN     8 B / pixel
-//   after phase 1  [index_vc | index_nr]                   i32 SUM    32 B / pixel   (disjoint supports: the winner's owner writes, the others hold zeros)
+//   after phase 1  assoc_key (per measurement pixel)       u64 MIN     2 B / pixel    (association by the owner of each candidate: distance bits | window position)
 //   after phase 2  key_index                               u64 MIN     8
-//   after phase 3  index_tap                               i32 SUM    16
+//   after phase 3  index_tap                               i32 SUM    16             (disjoint supports: the winner's owner writes, the others hold zeros)
 //   after phase 4  [key_splat | key_ids]                   u64 MIN    16             (key_both folded in by k_merge_both)
-//   after phase 5  [pred_* | tail: vote mass]              i32 SUM    42 (+ 16 B)
-// six collectives, 122 B / pixel (round 2: fourteen collectives, 130 B / pixel).
+//   after phase 5  [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass]   i32 SUM    30 (+ 16 B)   (the vertex is rebuilt from the key's depth)
+// six collectives, 80 B / pixel (round 2: fourteen collectives, 130 B / pixel; start of round 3: six, 122 B).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>

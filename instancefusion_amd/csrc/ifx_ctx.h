@@ -342,6 +342,7 @@ struct ifx {
     int32_t *ids_after = nullptr, *ids_tmp = nullptr;
     // association scratch (per pixel)
     uint32_t* assoc_target = nullptr;  // 0xFFFFFFFF none, 0xFFFFFFFE new, else surfel id
+    unsigned long long* assoc_key = nullptr;   // [ceil(w/2) * ceil(h/2)] sharded map: best owned candidate per measurement pixel (k_associate -> exchange MIN -> k_assoc_decode)
     float *meas_pc = nullptr, *meas_nr = nullptr, *meas_col = nullptr;
     // tracker
     Pyr pyr;

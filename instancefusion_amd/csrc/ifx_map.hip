@@ -1723,10 +1723,13 @@ int ifx_ids_ensure(ifx* h)
 
 // ------------------------------------------------------------------ association + fusion (a11, a12)
 // data.vert:94-241 for every pixel; the measurement is kept per pixel for the update / append passes
+// akey != nullptr (spatially sharded map): the rank tests only the candidates it OWNS (it holds the frame and their attributes) and leaves, per measurement pixel,
+// (distance bits << 32 | window position) of its best one; the element-wise minimum across the ranks is the winner of the replicated scan -- strict-less on the
+// distance, the earlier window position on a tie -- and k_assoc_decode turns it back into the surfel: 2 B per pixel travel instead of the 32-byte attribute images.
 __global__ void k_associate(const DevState* __restrict__ st, const float* __restrict__ pose_ex, float weighting_ex, const float* __restrict__ dm, const float* __restrict__ dmf,
                             const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ index_id, const float4* __restrict__ index_vc,
                             const float4* __restrict__ index_nr, Cam c, int time, uint32_t* __restrict__ assoc, float4* __restrict__ mpc, float4* __restrict__ mnr,
-                            float* __restrict__ mcol, uint32_t* __restrict__ upd_owner)
+                            float* __restrict__ mcol, uint32_t* __restrict__ upd_owner, unsigned long long* __restrict__ akey = nullptr)
 {
     // Only the pixels with i % 2 == j % 2 == time % 2 create measurements (data.vert:98): one thread per 2x2 block, so that
     // every lane of a wave works; the thread also marks the three silent pixels of its block.
@@ -1739,6 +1742,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
             const int ii = 2 * bx + a, jj = 2 * by + b;
             if (ii < c.w && jj < c.h && !(ii == i && jj == j)) assoc[jj * c.w + ii] = ASSOC_NONE;
         }
+    if (akey && bx < (c.w + 1) / 2 && by < (c.h + 1) / 2) akey[by * ((c.w + 1) / 2) + bx] = IFX_KEY_EMPTY;
     if (i >= c.w || j >= c.h) return;
     int k = j * c.w + i;
     uint32_t res = ASSOC_NONE;
@@ -1799,21 +1803,24 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
             float rayLen = norm(ray);
             float bestDist = 1000;
             uint32_t best = 0;
-            int counter = 0;
+            int counter = 0, best_q = 0;
 #pragma unroll
             for (int q = 0; q < 9; q++) {
-                if (cur[q] > 0u) {
+                if (cur[q] > 0u && (!akey || local_slot(c, st->count, cur[q]) >= 0)) {
                     const float4 vc = vcs[q];
                     if (fabsf((vc.z * lambda) - (vl.z * lambda)) < 0.05f) {
                         float dist = norm(cross(ray, v3m(vc.x, vc.y, vc.z))) / rayLen;
                         const float4 nrm = nrs[q];
                         v3 nn = v3m(nrm.x, nrm.y, nrm.z);
                         float cang = dot(nn, nl) / (norm(nn) * norm(nl));
-                        if (dist < bestDist && (fabsf(nrm.z) < 0.75f || cang > 0.87758256189f)) { counter++; bestDist = dist; best = cur[q]; }
+                        if (dist < bestDist && (fabsf(nrm.z) < 0.75f || cang > 0.87758256189f)) { counter++; bestDist = dist; best = cur[q]; best_q = q; }
                     }
                 }
             }
-            if (counter > 0) {
+            if (akey) {   // the verdict waits for the other ranks' candidates (k_assoc_decode): "new" unless somebody has one
+                if (counter > 0) akey[by * ((c.w + 1) / 2) + bx] = ((unsigned long long)__float_as_uint(bestDist) << 32) | (unsigned int)best_q;   // (bestDist >= 0: its bits order like its value)
+                res = ASSOC_NEW;
+            } else if (counter > 0) {
                 res = best;
                 const int lb = local_slot(c, st->count, best);
                 if (lb >= 0) atomicMin(&upd_owner[lb], (uint32_t)(i * c.h + j));   // first pixel in column-major order owns the surfel (sharded map: only the surfel's rank keeps the score)
@@ -1821,6 +1828,25 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
         }
     }
     assoc[k] = res;
+}
+
+// the exchanged minimum back into the association: window position -> texel -> surfel; the surfel's rank enters the first-pixel-wins arbitration
+__global__ void k_assoc_decode(const DevState* __restrict__ st, const unsigned long long* __restrict__ akey, const uint32_t* __restrict__ index_id, Cam c, int time,
+                               uint32_t* __restrict__ assoc, uint32_t* __restrict__ upd_owner)
+{
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+    const int par = time % 2, i = 2 * bx + par, j = 2 * by + par;
+    if (i >= c.w || j >= c.h) return;
+    const unsigned long long key = akey[by * ((c.w + 1) / 2) + bx];
+    if (key == IFX_KEY_EMPTY) return;
+    const int q = (int)(key & 0xFu), a = q / 3, b = q - 3 * a;
+    const float x = (float)i + 0.5f, y = (float)j + 0.5f;
+    const int xs[3] = {clampi((int)floorf(x - 1.0f), 0, c.w - 1), clampi((int)floorf(x - 0.5f), 0, c.w - 1), clampi((int)floorf(x + 0.5f), 0, c.w - 1)};
+    const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};
+    const uint32_t best = index_id[ys[b] * c.w + xs[a]];
+    assoc[j * c.w + i] = best;
+    const int lb = local_slot(c, st->count, best);
+    if (lb >= 0) atomicMin(&upd_owner[lb], (uint32_t)(i * c.h + j));
 }
 
 // update.vert:55-141 in place, by the owning pixel only
@@ -2100,12 +2126,17 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
 }
 
 // ------------------------------------------------------------------ per-frame orchestration of the map stages
-static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time)
+// part 0: the whole pass; spatially sharded map: 1 = the association among the candidates this rank owns (leaves h->assoc_key for the exchange),
+// 2 = the exchanged verdicts decoded + the update of the owned surfels
+static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time, int part = 0)
 {
     Cam c = make_cam(h);
     dim3 b(32, 8), g(cdiv(cdiv(h->w, 2), 32), cdiv(cdiv(h->h, 2), 8));   // one thread per 2x2 pixel block
-    LAUNCH(h, "associate", g, b, k_associate, h->d_state, d_pose, weighting, h->dm, h->dmf, h->rgb, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_nr, c, time,
-           h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner);
+    if (part != 2)
+        LAUNCH(h, "associate", g, b, k_associate, h->d_state, d_pose, weighting, h->dm, h->dmf, h->rgb, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_nr, c, time,
+               h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner, part == 1 ? h->assoc_key : (unsigned long long*)nullptr);
+    if (part == 1) return;
+    if (part == 2) LAUNCH(h, "assoc_decode", g, b, k_assoc_decode, h->d_state, (const unsigned long long*)h->assoc_key, h->index_id, c, time, h->assoc_target, h->upd_owner);
     LAUNCH(h, "fuse_update", g, b, k_fuse_update, h->d_state, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr, h->meas_col, c, time, h->upd_owner,
            (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm);
 }
@@ -2581,8 +2612,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
                (int*)nullptr, (int*)nullptr);
         break;
     case 0: index_pass(h, nullptr, time, true, 1); break;                                                   // local projection | keys: MIN
-    case 1: index_pass(h, nullptr, time, true, 2); break;                                                   // winners this rank owns | [index_vc | index_nr]: SUM
-    case 2: fuse_pass(h, nullptr, 0.f, time); clean_pass(h, nullptr, time, 1); break;                       // association (replicated), update (owned), post-fuse projection | keys: MIN
+    case 1: index_pass(h, nullptr, time, true, 2); fuse_pass(h, nullptr, 0.f, time, 1); break;             // attributes of the winners this rank owns, association among them | assoc_key: MIN
+    case 2: fuse_pass(h, nullptr, 0.f, time, 2); clean_pass(h, nullptr, time, 1); break;                    // verdicts decoded, update (owned), post-fuse projection | keys: MIN
     case 3:                                                                                                 // owned tap records | index_tap: SUM
         LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
                (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence,

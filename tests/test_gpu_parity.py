@@ -1614,7 +1614,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
     creation-number ids, owner filter, every exchange point of a frame / predict / segmentation call / kNN smoothing issued as a one-rank
     ncclAllReduce / ncclAllGather on the handle's stream by the library itself).  One library call per frame; against the unsharded handle:
     poses, prediction / fill-in / id images, instance table, and -- by creation number -- the whole map, votes, labels and colours, bit for bit.
-    Also the host-pointer entry (ifx_owner_process_frame) and the exchange statistics: six collectives and 110 bytes per pixel per frame."""
+    Also the host-pointer entry (ifx_owner_process_frame) and the exchange statistics: six collectives and 80 bytes per pixel per frame."""
     import torch
 
     from instancefusion_amd import sharded, synth
@@ -1651,7 +1651,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()
-                assert xs["collectives"] == 6 and xs["bytes"] == 110 * P + 16, xs     # keys 8 + 8 + 16, attribute blocks 32 + 16 + 30 bytes per pixel (the prediction's vertex is rebuilt from the key), + the 16-byte tail
+                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

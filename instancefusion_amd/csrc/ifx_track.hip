@@ -260,13 +260,23 @@ __global__ void k_model_l0(const DevState* __restrict__ st, const float* __restr
 }
 // The start of the tracker run (gn_begin_dev: one thread's worth of work that only needs the pose and the SO(3) result) can ride on the last launch
 // of the model side instead of being a launch of its own (k_track_gn_begin, 4.8 us): `gb.enabled` on the frame tracker's tracked-ahead path.
-struct GnBegin { DevState* st; const DevState* ss; int so3; float fx, fy, cx, cy; int keep_last, enabled; };
+struct GnBegin { DevState* st; const DevState* ss; int so3; float fx, fy, cx, cy; int keep_last, enabled, persist; };
 __device__ void gn_begin_dev(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last);
+// hand-off words of the persistent level kernel (option gn_persist): both parities of the accumulator rows and residual totals, the barrier words
+__device__ __forceinline__ void gn_persist_reset(DevState* st, int lt, int nt)
+{
+    for (int k = lt; k < 2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE; k += nt) st->gn_acc2[k] = 0.0;
+    if (lt < 32) st->gn_res2[lt] = 0;
+    for (int k = lt; k < 4 * 32 * 16; k += nt) st->gn_bar[k] = 0u;
+}
 __global__ void k_model_down(const DevState* __restrict__ st, const float* __restrict__ vin, const float* __restrict__ nin, const float* __restrict__ din, const uint8_t* __restrict__ iin,
                              int sw, int sh, ModelOut o, GnBegin gb)
 {
-    if (gb.enabled && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0)   // (writes tracker state only; this launch reads the pose and the dense flag)
-        gn_begin_dev(gb.st, gb.ss, gb.so3, gb.fx, gb.fy, gb.cx, gb.cy, gb.keep_last);
+    if (gb.enabled && blockIdx.x == 0 && blockIdx.y == 0) {   // (writes tracker state only; this launch reads the pose and the dense flag)
+        const int lt = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+        if (gb.persist) gn_persist_reset(gb.st, lt, nt);
+        if (lt == 0) gn_begin_dev(gb.st, gb.ss, gb.so3, gb.fx, gb.fy, gb.cx, gb.cy, gb.keep_last);
+    }
     const int dw = sw / 2, dh = sh / 2;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= dw || y >= dh) return;
@@ -1390,11 +1400,7 @@ __device__ void set_so3_matrices(DevState* st, float fx, float fy, float cx, flo
 // Gauss-Newton loop from the SO(3) result held in the slot's shadow state (:392-403)
 __global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last, int persist)
 {
-    if (persist) {   // hand-off words of the persistent level kernels (option gn_persist): both parities of the accumulator rows and residual totals, the barrier words
-        for (int k = threadIdx.x; k < 2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE; k += blockDim.x) st->gn_acc2[k] = 0.0;
-        if (threadIdx.x < 32) st->gn_res2[threadIdx.x] = 0;
-        for (int k = threadIdx.x; k < 4 * 32 * 16; k += blockDim.x) st->gn_bar[k] = 0u;
-    }
+    if (persist) gn_persist_reset(st, threadIdx.x, blockDim.x);
     if (threadIdx.x != 0) return;
     gn_begin_dev(st, ss, so3, fx, fy, cx, cy, keep_last);
 }
@@ -2263,7 +2269,7 @@ int ifx_tracker_init_first(ifx* h)
 }
 
 // model side: initICPModel + initRGBModel (EF/Utils/RGBDOdometry.cpp:169-206,237-241)
-static inline GnBegin gb_none() { GnBegin g; g.st = nullptr; g.ss = nullptr; g.so3 = 0; g.fx = g.fy = g.cx = g.cy = 0.f; g.keep_last = 0; g.enabled = 0; return g; }
+static inline GnBegin gb_none() { GnBegin g; g.st = nullptr; g.ss = nullptr; g.so3 = 0; g.fx = g.fy = g.cx = g.cy = 0.f; g.keep_last = 0; g.enabled = 0; g.persist = 0; return g; }
 static void tracker_init_model(ifx* h, DevState* st, Pyr& p, float icp_weight, const float* pv, const float* pn, const uint8_t* pi, const float* fv, const float* fn, const uint8_t* fi, const GnBegin* gbp = nullptr)
 {
     const GnBegin gb_off = gb_none();
@@ -2496,12 +2502,12 @@ int ifx_tracker_model_side(ifx* h, int fold_begin)
     // fold_begin: the caller runs the frame tracker right behind this (nothing in between touches the pose, and the frame side of the slot is
     // ready): the start of the run rides on the model side's last launch
     const ifx_config& c = h->cfg;
-    const bool fold = fold_begin && !h->opt_gn_persist && !h->opt_model_fused && c.pyramid && IFX_NUM_PYRS == 3;
+    const bool fold = fold_begin && !h->opt_model_fused && c.pyramid && IFX_NUM_PYRS == 3;
     GnBegin gb = gb_none();
     if (fold) {
         const float div = (float)(1 << (IFX_NUM_PYRS - 1));   // the run starts at the coarsest level (pyramid on: every level iterates)
         gb.st = h->d_state; gb.ss = h->slot[h->cur_slot].so3; gb.so3 = c.so3; gb.fx = c.fx / div; gb.fy = c.fy / div; gb.cx = c.cx / div; gb.cy = c.cy / div;
-        gb.keep_last = 0; gb.enabled = 1;
+        gb.keep_last = 0; gb.enabled = 1; gb.persist = h->opt_gn_persist ? 1 : 0;
     }
     tracker_init_model(h, h->d_state, h->pyr, h->cfg.icp_weight, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image, fold ? &gb : nullptr);
     h->gn_begin_folded = fold ? 1 : 0;

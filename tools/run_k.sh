@@ -1,13 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q > gpurun_out/r03_final_tests.log 2>&1; grep -n "passed\|failed\|Error" gpurun_out/r03_final_tests.log | head -5
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash tools/prof_run.sh r03_final > /dev/null 2>&1
-python bench.py > gpurun_out/r03_final_bench.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 > gpurun_out/r03_final_bench_driver.json 2>/dev/null
-python - <<PY
-import json
-for f in ("r03_final_bench.json","r03_final_bench_driver.json"):
-    d=json.loads(open("gpurun_out/"+f).read().strip().splitlines()[-1]); r=d["roofline"]
-    print(f, d["value"], d["ms_per_frame_gpu"], d["instance"]["ms_per_call"], r["kernel"], r["frac"], r.get("traffic"), d["value_host_entry"]["value"], d["value_close_loops"]["value"], d["cpu_baseline"]["value"])
-PY
-head -12 gpurun_out/r03_final_seg_call_timeline.txt | cut -c1-100; tail -3 gpurun_out/r03_final_seg_call_timeline.txt
+python bench.py --steps 3000 --warmup 30 --no-cpu-baseline --extras-frames 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('3000 frames', d['value'], d['ms_per_frame_gpu'], d['instance'], d['view_list'], d['ate_rms_m'], d['config'].get('surfels_live'), d['config'].get('surfel_slots'))"
+python bench.py --steps 600 --warmup 30 --no-cpu-baseline --extras-frames 0 --close-loops 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('600 frames closeLoops', d['value'], d['ms_per_frame_gpu'], d['ate_rms_m'])"

@@ -1103,11 +1103,17 @@ def test_segmentation_with_superpixels_exact(ifx, orc, small_stream):
 
 
 # ---------------------------------------------------------------- frame look-ahead (side stream) must not change results
-def test_lookahead_equivalence(ifx, small_stream):
+@pytest.mark.parametrize("flann", [False, True])
+def test_lookahead_equivalence(ifx, small_stream, flann):
+    """Every way of feeding the frames -- one stream, two streams, the next frame announced (its tracker enqueued ahead, a segmentation call then runs BESIDE it on the third
+    stream), prefetched, announced wrongly, with a compaction before every frame -- gives the same trajectory, map, id image and decisions; segmentation calls with
+    superpixels (and, flann: the kNN smoothing, whose forced view-list scan then runs beside the tracker too) at frames where the map has stable surfels."""
     import torch
 
-    st = small_stream
-    n = 8
+    from instancefusion_amd import synth
+
+    n = 14
+    st = synth.make_stream(n, SMALL["w"], SMALL["h"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], noise=True)
     d_rgb = torch.from_numpy(st["rgb"][:n].copy()).cuda()
     d_dep = torch.from_numpy(st["depth"][:n].view(np.int16).copy()).cuda()
     torch.cuda.synchronize()
@@ -1116,7 +1122,7 @@ def test_lookahead_equivalence(ifx, small_stream):
 
     def run(mode):
         seg = []
-        g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
         inst = ifx.InstanceFusion(g)
         if mode == "single":
             g.set_option("two_streams", 0)
@@ -1133,17 +1139,20 @@ def test_lookahead_equivalence(ifx, small_stream):
             if mode == "wrong_hint" and i + 1 < n:   # a look-ahead that does not come true is recomputed
                 g.prefetch_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
             seg.append(inst.whetherDoSegmentation(10 + i))   # host decision between frames, as in the reference's main loop
-            if i == 5:   # and a segmentation call while the next frame's tracker may already be queued
-                mk, cl = synth.canned_masks(st["obj"][5], st["scene"])
-                inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], mk, cl, 15, superpixels=True)
+            if i in (5, 9, 12):   # and segmentation calls while the next frame's tracker may already be queued
+                mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+                res = mode == "hint_resident"   # (the frame's images from their frame slot instead of host copies)
+                inst.ProcessSegmentation(None if res else st["rgb"][i], None if res else st["depth"][i], mk, cl, 10 + i, superpixels=True, isflann=flann)
         g.sync()
-        traj, m, ids = g.trajectory(), g.download(), g.image("ids_after")
+        traj, m, ids, lab = g.trajectory(), g.download(), g.image("ids_after"), inst.labels()
         g.close()
-        return traj, m, ids, seg
+        return traj, m, ids, seg, lab
 
     ref = run("single")
-    for mode in ("plain", "hint", "hint_no_track_ahead", "prefetch", "wrong_hint", "hint_housekeeping"):
-        t, m, ids, seg = run(mode)
+    assert (ref[4] >= 0).sum() > 100   # the calls labelled something
+    for mode in ("plain", "hint", "hint_resident", "hint_no_track_ahead", "prefetch", "wrong_hint", "hint_housekeeping"):
+        t, m, ids, seg, lab = run(mode)
+        assert np.array_equal(lab, ref[4]), mode
         assert seg == ref[3], mode
         assert np.array_equal(t, ref[0]), mode
         assert all(np.array_equal(m[k], ref[1][k]) for k in MAP_KEYS), mode
@@ -1152,10 +1161,11 @@ def test_lookahead_equivalence(ifx, small_stream):
         else:
             assert np.array_equal(ids > 0, ref[2] > 0)
     # and the host-buffer entry point gives the same trajectory
-    g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
-    poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(n)])
-    g.close()
-    assert np.array_equal(poses, ref[0][:n])
+    if not flann:
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
+        poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(n)])
+        g.close()
+        assert np.array_equal(poses, ref[0][:n])
 
 
 def test_segmentation_call_on_the_resident_frame(ifx):

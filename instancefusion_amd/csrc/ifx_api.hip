@@ -283,6 +283,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "view_list") { h->opt_vlist = value; ifx_vlist_reap(h); hs_invalidate_view(h); }
     else if (s == "seg_aside") h->opt_seg_aside = value;
     else if (s == "pace") h->opt_pace = value;
+    else if (s == "lc_view") h->opt_lc_view = value;
     else if (s == "side_gate") h->opt_side_gate = value;
     else if (s == "ff_union") h->opt_ff_union = value;
     else if (s == "fold_finish") h->opt_fold_finish = value;

@@ -233,6 +233,8 @@ struct ifx {
     int ids_pending = 0;
     int opt_fold_finish = 1;            // view-list frames: the end-of-pass sums (dense test, whetherDoSegmentation) ride in k_splat_resolve instead of a launch of their own
     int ids_view_ok = 0;                // the cached view list still describes store and pose of the frame that drew the sparse id image (ifx_ids_ensure may walk it)
+    int view_scan_tick = -1;            // frame whose view-list scan is already on the queue (the loop-closure renders come before the map passes)
+    int opt_lc_view = 1;                // loop-closure detection: its two renders from the view lists (one k_raster_view in dual mode) instead of a scan of the store + k_raster_list
     int opt_lazy_ids = 1;               // the frame renders the id image on the lattice whetherDoSegmentation samples; the whole image on demand (ifx_ids_ensure)
     int ids_full_valid = 1, ids_sparse_frame = 0;
     // options

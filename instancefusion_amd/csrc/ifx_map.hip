@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                     in = near_frustum(xf_point(T, v3m(p4.x, p4.y, p4.z)), reach, P, c.maxDepth);
                     if (in && wv > 0.f && (float)time - wv > (float)c.timeDelta) {   // outside the time window for good
                         in = false;
-                        in_i = p4.w > c.conf;
+                        in_i = !(p4.w < c.conf);   // (>=: the INACTIVE splat of the loop-closure detection draws a surfel exactly AT the threshold, the id render tests > per entry)
                     } else if (!in) {   // never seen while the list is valid: only the age rule of the clean pass applies to it (copy_unstable.vert:160-172)
                         int test = 1;
                         if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
@@ -1516,7 +1516,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         for (int q = 0; q < RV_SLOTS / 64; q++) { s_tag[wid][q * 64 + lane] = 0u; s_key[wid][q * 64 + lane] = ~0ull; }
     }
     // the two view lists, one after the other: [0, na) the time-window list, [na, na + ni) the stable slots outside the window (id render only)
-    const unsigned int na = min(st->vl_n[0], c.seg_cap * LIST_SEGS), n = na + ((want & LIST_IDS) ? min(st->vl_n[1], c.seg_cap * LIST_SEGS) : 0u);
+    // want & LIST_DUAL (the loop-closure detection's two splat renders, as k_cull_raster / k_raster_list's dual mode): the ACTIVE prediction goes to key_splat, the INACTIVE
+    // one -- last seen at or before time - timeDelta -- to key_ids with the SPLAT geometry and depth rule; every entry of both lists is classified by its own time stamp
+    const bool dual = (want & LIST_DUAL) != 0;
+    const unsigned int na = min(st->vl_n[0], c.seg_cap * LIST_SEGS), n = na + (((want & LIST_IDS) || dual) ? min(st->vl_n[1], c.seg_cap * LIST_SEGS) : 0u);
     const unsigned int* __restrict__ seg_a = list_a;
     const unsigned int* __restrict__ seg_i = list_i;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
@@ -1535,19 +1538,31 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
                 const v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
                 if (q.z > 0.f && may_touch_image(reach, q, c)) {
+                    if (dual) {
+                        if (!(q.z > c.maxDepth)) {
+                            const bool act = !((float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime);
+                            const bool old = !(0.f - lastT > (float)c.timeDelta || lastT > (float)(time - c.timeDelta));
+                            if (act || old) {
+                                const float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
+                                if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= (act ? LIST_SPLAT : 0u) | (old ? LIST_IDS : 0u);
+                            }
+                        }
+                    } else {
                     if ((want & LIST_IDS) && (p4.w > c.conf) && (q.z / c.maxDepth > 0.01f)) flags |= LIST_IDS;
                     if ((want & LIST_SPLAT) && !(q.z > c.maxDepth) && !((float)time - lastT > (float)c.timeDelta || lastT > (float)maxTime)) {
                         const float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;   // exact: GL clips points by their centre
                         if (u >= 0 && u <= (float)c.w && v >= 0 && v <= (float)c.h) flags |= LIST_SPLAT;
                     }
+                    }
                 }
             }
             if (flags) {
                 SurfGeo G;
-                surfel_geo(T, p4, ld_once(&nr[i]), i | flags, c, G);
+                surfel_geo(T, p4, ld_once(&nr[i]), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
-                bool do_i = surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
-                const bool do_s = G.do_s;
+                bool do_i = dual ? (G.do_s && (flags & LIST_IDS)) : surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
+                const bool do_s = dual ? (G.do_s && (flags & LIST_SPLAT)) : G.do_s;
+                if (dual) { ix0 = sx0; ix1 = sx1; iy0 = sy0; iy1 = sy1; }
                 int lattice = 0;
                 if (do_i && ids_step > 1) {   // sparse id render: only the pixels of the ids_step lattice (what whetherDoSegmentation samples); the full image is rendered on demand
                     const int lx0 = ((ix0 + ids_step - 1) / ids_step) * ids_step, lx1 = (ix1 / ids_step) * ids_step;
@@ -1606,8 +1621,14 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             const int sx0 = (short)(rg.x & 0xFFFF), sx1 = rg.x >> 16, sy0 = (short)(rg.y & 0xFFFF), sy1 = rg.y >> 16;
             const int ix0 = (short)(rg.z & 0xFFFF), ix1 = rg.z >> 16, iy0 = (short)(rg.w & 0xFFFF), iy1 = rg.w >> 16;
             const bool in_s = px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
-            const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth) && (ids_step <= 1 || (px % ids_step == 0 && py % ids_step == 0));
+            const bool in_i = px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (dual ? (z >= -c.maxDepth && z <= c.maxDepth) : (z > 0 && z <= c.maxDepth)) &&
+                              (ids_step <= 1 || (px % ids_step == 0 && py % ids_step == 0));
             if (!in_s && !in_i) continue;
+            if (dual && in_s && in_i) {   // (last seen exactly timeDelta frames ago: in both renders; their resolves do not read key_both)
+                key_min(key_splat + (py * c.w + px), make_key(z, id));
+                key_min(key_ids + (py * c.w + px), make_key(z, id));
+                continue;
+            }
             const int tsel = in_s && in_i ? 0 : (in_s ? 1 : 2);
             unsigned long long* addr = (tsel == 0 ? key_both : (tsel == 1 ? key_splat : key_ids)) + (py * c.w + px);
             const unsigned long long key = make_key(z, id);
@@ -2365,7 +2386,7 @@ int ifx_map_frame(ifx* h)
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
         const int time = h->tick;
-        view_scan(h, time);                     // rebuilds the list when vlist_decide asked for it, returns at once otherwise
+        if (h->view_scan_tick != time) view_scan(h, time);   // rebuilds the list when vlist_decide asked for it, returns at once otherwise (the loop-closure renders may have taken it already)
         index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
         fuse_pass(h, nullptr, 0.f, time);
         index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
@@ -2405,10 +2426,17 @@ int ifx_map_predict_loop_closure(ifx* h)
     // both renders see the same map at the same pose and differ only in the time window: one scan of the store, one raster launch (two key images)
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
+    if (use_view_list(h) && h->opt_lc_view) {   // the frame's view lists hold every stable surfel in view, inside the time window or not: the scan this frame needs anyway, taken first
+        view_scan(h, h->tick);
+        h->view_scan_tick = h->tick;
+        LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1);
+    } else {
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
            LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
     LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
            h->key_ids, h->key_both, 1, (const int*)nullptr);
+    }
     for (int old = 0; old < 2; old++)
         LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, (const float*)nullptr,
                old ? h->key_ids : h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt,

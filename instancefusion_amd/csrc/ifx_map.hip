@@ -426,12 +426,12 @@ struct FinishFold {
 
 // combo_splat.frag:54-66 outputs for the winner of each pixel, fused with FillIn
 // (fill_rgb/vertex/normal.frag, EF/Shaders/FillIn.cpp:65-195, passthrough = 0).
-__global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
+__device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -541,6 +541,25 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
         v3 nn = normalized(cross(vx - vp, vy - vp));
         fn[k] = make_float4(nn.x, nn.y, nn.z, 1.f);
     } else fn[k] = no;
+}
+
+__global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
+                                const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
+                                const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
+                                uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
+                                unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr)
+{
+    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf);
+}
+// the two renders of the loop-closure detection (ACTIVE into the act* images, INACTIVE into the old* images) resolved by one launch: blockIdx.z picks the render
+struct ResolveTarget { unsigned long long* keys; float4 *pv, *pn; uchar4 *pimg, *pinst; uint16_t* ptime; };
+__global__ void k_splat_resolve_pair(const DevState* __restrict__ st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm,
+                                     Cam c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt, ResolveTarget t0, ResolveTarget t1)
+{
+    const ResolveTarget t = blockIdx.z ? t1 : t0;
+    splat_resolve_body(st, nullptr, t.keys, pc, nr, col, tm, c, rgb, depth_filt, t.pv, t.pn, t.pimg, t.pinst, t.ptime, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, FinishFold(),
+                       nullptr);
 }
 
 // ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267 on the (w/20 x h/20) nearest resample
@@ -2426,7 +2445,8 @@ int ifx_map_predict_loop_closure(ifx* h)
     // both renders see the same map at the same pose and differ only in the time window: one scan of the store, one raster launch (two key images)
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
-    if (use_view_list(h) && h->opt_lc_view) {   // the frame's view lists hold every stable surfel in view, inside the time window or not: the scan this frame needs anyway, taken first
+    const bool by_view = use_view_list(h) && h->opt_lc_view;
+    if (by_view) {   // the frame's view lists hold every stable surfel in view, inside the time window or not: the scan this frame needs anyway, taken first
         view_scan(h, h->tick);
         h->view_scan_tick = h->tick;
         LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr,
@@ -2437,13 +2457,15 @@ int ifx_map_predict_loop_closure(ifx* h)
     LAUNCH(h, "raster_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_raster_list, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float4*)h->nr, c, h->list_a, h->key_splat,
            h->key_ids, h->key_both, 1, (const int*)nullptr);
     }
-    for (int old = 0; old < 2; old++)
-        LAUNCH(h, old ? "splat_resolve_old" : "splat_resolve_act", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, (const float*)nullptr,
-               old ? h->key_ids : h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt,
-               (float4*)(old ? h->old_vertex : h->act_vertex), (float4*)(old ? h->old_normal : h->act_normal), (uchar4*)(old ? h->old_image : h->act_image),
-               (uchar4*)(old ? h->old_inst : h->act_inst), old ? h->old_time : h->act_time, (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both,
-               (int32_t*)nullptr, (int*)nullptr, FinishFold());
-    LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
+    {
+        ResolveTarget ta, to;
+        ta.keys = h->key_splat; ta.pv = (float4*)h->act_vertex; ta.pn = (float4*)h->act_normal; ta.pimg = (uchar4*)h->act_image; ta.pinst = (uchar4*)h->act_inst; ta.ptime = h->act_time;
+        to.keys = h->key_ids; to.pv = (float4*)h->old_vertex; to.pn = (float4*)h->old_normal; to.pimg = (uchar4*)h->old_image; to.pinst = (uchar4*)h->old_inst; to.ptime = h->old_time;
+        LAUNCH(h, "splat_resolve_lc", dim3(cdiv(h->w, 32), cdiv(h->h, 8), 2), dim3(32, 8), k_splat_resolve_pair, (const DevState*)h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->col, (const float2*)h->tm, c, (const uint8_t*)h->rgb, (const uint16_t*)h->depth_filt, ta, to);
+    }
+    if (!by_view)   // (re-arms work list 0, which the view-list path does not touch)
+        LAUNCH(h, "raster_finish", dim3(1), dim3(256), k_raster_finish, h->d_state, (const uchar4*)h->pred_image, h->w, h->h, 0, h->ids_after, (const float4*)h->votes, h->cap, 10, h->d_list_ctr, ifx_idmap(h));
     return IFX_OK;
 }
 

@@ -1030,7 +1030,8 @@ extern "C" int ifx_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint
     // The next frame's tracker is already queued on the main stream (enqueue_frame, "tracked ahead") and touches nothing this call does: the call's ~60 short
     // launches then go to the handle's third stream (the loop-closure tracker's: four streams is what the runtime's hardware queues hold) and run beside the tracker's 170 instead of behind them.  The call ends with the host waiting for its stream,
     // so whatever the caller enqueues next is ordered behind it as before.
-    const bool aside = h->opt_seg_aside && h->stream_c && h->opt_two_streams && h->opt_seg_device && !h->own && h->tracked_ahead == h->tick && h->cur == h->stream;
+    const bool aside = h->opt_seg_aside && h->stream_c && h->opt_two_streams && h->opt_seg_device && !h->own && h->tracked_ahead == h->tick && h->cur == h->stream &&
+                       !h->lc_pending;   // (the third stream is busy with a loop-closure tracker: behind the frame tracker on the main stream is the shorter wait)
     if (aside) {
         if (h->ev_result) HIPCHK(h, hipStreamWaitEvent(h->stream_c, h->ev_result, 0));   // behind the frame the call belongs to
         h->cur = h->stream_c;

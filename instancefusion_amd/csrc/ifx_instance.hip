@@ -516,13 +516,11 @@ __device__ __forceinline__ bool ff_pull(int& l, int dp_unused, int ql, int dq, i
     if ((float)abs(dq - dp) < depth_threshold_dev(dq)) { l = ql; return true; }   // edge q -> p, threshold of the source q
     return false;
 }
-// SYM: only the edges that exist in BOTH directions, no pointer jump, no `changed` flag -- the tile-local half of the union-find start (see k_ff_merge).
-template <bool SYM>
 __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 {
     __shared__ int s_lab[FF_T + 2][FF_T + 3];          // (+1 column: rows and columns land on different banks)
     __shared__ unsigned short s_d[FF_T + 2][FF_T + 4];
-    if (!SYM && it > 0 && a.changed[it - 1] == 0) return;
+    if (it > 0 && a.changed[it - 1] == 0) return;
     const int P = a.w * a.h, m = blockIdx.z;
     if (a.skip[m] || !a.tile_active[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;   // (most (mask, tile) pairs: the masks cover a fraction of the image)
     int* lab = a.label + (size_t)m * P;
@@ -541,7 +539,7 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
         for (int q = 0; q < NL; q++) {
             const int t = tid + q * 256, ly = t / (FF_T + 2), lx = t - ly * (FF_T + 2);
             const bool interior = lx >= 1 && lx <= FF_T && ly >= 1 && ly <= FF_T;
-            const int g = (!SYM && interior && l[q] >= 0) ? lab[l[q]] : -1;   // one pointer jump: my label reaches me, so does ITS label
+            const int g = (interior && l[q] >= 0) ? lab[l[q]] : -1;   // one pointer jump: my label reaches me, so does ITS label
             if (g >= 0 && g < l[q]) l[q] = g;
         }
 #pragma unroll
@@ -564,12 +562,10 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
                 unsigned int ch = 0;
 #pragma unroll
                 for (int x = 1; x <= FF_T; x++)
-                    if (l[x] >= 0 && l[x - 1] >= 0 && l[x - 1] < l[x] && (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x - 1]) &&
-                        (!SYM || (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x]))) { l[x] = l[x - 1]; ch |= 1u << (x - 1); }
+                    if (l[x] >= 0 && l[x - 1] >= 0 && l[x - 1] < l[x] && (float)abs(d[x - 1] - d[x]) < depth_threshold_dev(d[x - 1])) { l[x] = l[x - 1]; ch |= 1u << (x - 1); }
 #pragma unroll
                 for (int x = FF_T; x >= 1; x--)
-                    if (l[x] >= 0 && l[x + 1] >= 0 && l[x + 1] < l[x] && (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x + 1]) &&
-                        (!SYM || (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x]))) { l[x] = l[x + 1]; ch |= 1u << (x - 1); }
+                    if (l[x] >= 0 && l[x + 1] >= 0 && l[x + 1] < l[x] && (float)abs(d[x + 1] - d[x]) < depth_threshold_dev(d[x + 1])) { l[x] = l[x + 1]; ch |= 1u << (x - 1); }
                 if (ch) {
                     any = 1;
 #pragma unroll
@@ -589,7 +585,7 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
             if (l >= 0 && l != lab[y * a.w + x]) { lab[y * a.w + x] = l; dirty = 1; }
         }
     }
-    if (!SYM && __syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
+    if (__syncthreads_or(dirty) && tid == 0) a.changed[it] = 1;
 }
 
 // Union-find start of the fill (round 3).  Pixels joined by edges that exist in BOTH directions reach each other, so they end with the same label, whatever else
@@ -600,7 +596,7 @@ __global__ void __launch_bounds__(256) k_ff_relax(FFArgs a, int it)
 // relaxation that follows starts from a valid state and -- where every edge is two-way (model depth under 4 m: one threshold) -- finds nothing left to do.
 // Tile-local half: union-find in LDS over the two-way edges INSIDE a 32 x 32 tile (right and lower neighbour of every pixel: each edge once), then every pixel
 // points at the smallest pixel of its component within the tile (row-major order inside a tile is the global order restricted to it).  No rounds, no halo: the
-// edges across tile borders are k_ff_merge's.  (First version: k_ff_relax<true>, sweeps to the local fixpoint, 64 us a call; this one ~10.)
+// edges across tile borders are k_ff_merge's.  (First version: the relaxation kernel restricted to two-way edges, sweeps to the local fixpoint, 64 us a call; this one 32.)
 __device__ __forceinline__ int ff_find_lds(const volatile int* par, int x)
 {
     int p = par[x];
@@ -794,15 +790,15 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     }
     if (fixed_rounds > 0 && !resume) {
         if (fixed_rounds > FF_SLOTS) fixed_rounds = FF_SLOTS;
-        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, it);
+        for (int it = 0; it < fixed_rounds; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, it);
         a.gate = a.changed + (fixed_rounds - 1);
     } else {
         for (int round = 0; round < 64; round++) {
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->cur));
-            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, 0);
+            for (int it = 0; it < 6; it++) LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
             // the last launch of the batch decides: it re-checks every edge, so "no change" there is the fixpoint
             HIPCHK(h, hipMemsetAsync(a.changed, 0, 4, h->cur));
-            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax<false>, a, 0);
+            LAUNCH(h, "ff_relax", tiles, dim3(256), k_ff_relax, a, 0);
             int changed = 0;
             HIPCHK(h, hipMemcpyAsync(&changed, a.changed, 4, hipMemcpyDeviceToHost, h->cur));
             HIPCHK(h, hipStreamSynchronize(h->cur));

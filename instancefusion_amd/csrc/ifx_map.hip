@@ -431,7 +431,7 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf, int ids_step = 1)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -439,6 +439,9 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
     // everything addressed by the pixel itself leaves in one batch: the three keys and, for the fill-in, the frame's colour and filtered depth
     // (one after the other, each behind the previous test, they were five dependent round trips)
     unsigned long long key = keys[k];
+    // (sparse id render: only the lattice pixels were drawn, the other pixels' id keys are empty and stay so, and their entries of the id image are not looked at
+    // before ifx_ids_ensure redraws the whole image)
+    if (ids_step > 1 && (x % ids_step != 0 || y % ids_step != 0)) ids_out = nullptr;
     const unsigned long long bk0 = ids_out ? both_keys[k] : IFX_KEY_EMPTY, ik0 = ids_out ? id_keys[k] : IFX_KEY_EMPTY;
     uint8_t f_r = 0, f_g = 0, f_b = 0;
     uint16_t f_d = 0, f_dx = 0, f_dy = 0;
@@ -548,9 +551,9 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr, int ids_step = 1)
 {
-    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf);
+    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step);
 }
 // the two renders of the loop-closure detection (ACTIVE into the act* images, INACTIVE into the old* images) resolved by one launch: blockIdx.z picks the render
 struct ResolveTarget { unsigned long long* keys; float4 *pv, *pn; uchar4 *pimg, *pinst; uint16_t* ptime; };
@@ -1551,7 +1554,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
         if (t < n) {
             const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
             const float4 p4 = ld_once(&pc[i]);
-            const float lastT = ld_once(&tm[i]).y;   // (with the position: one round trip for both)
+            const float lastT = (t < na || dual) ? ld_once(&tm[i]).y : 0.f;   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
             asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             unsigned int flags = 0;
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
@@ -1678,7 +1681,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
 static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0,
-                        bool fold_finish = false)
+                        bool fold_finish = false, int resolve_ids_step = 1)
 {
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
@@ -1723,7 +1726,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
-               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff);
+               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step);
         if (ff.acc) return;   // (the view-list pass leaves list 0 alone: nothing to re-arm)
     } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
     // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums
@@ -2491,7 +2494,7 @@ int ifx_map_predict(ifx* h)
         else
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
                    want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
-        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0);   // resolve + the end-of-pass sums in the same launch
+        raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step);   // resolve + the end-of-pass sums in the same launch
     } else {
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
         if (want & LIST_IDS) { h->ids_full_valid = 1; h->ids_sparse_frame = 0; }

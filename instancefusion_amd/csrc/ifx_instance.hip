@@ -211,8 +211,14 @@ __global__ void k_vote_update(const DevState* __restrict__ st, const int32_t* __
 // which the full scan would move from "no colour" (0) to the default colour: pass A does that from 16 bytes per slot, pass B redoes the arg-max
 // for the surfel under every pixel (192 bytes each, <= P of them) exactly as the full scan would.  5 M surfels: 83 MB + <= 59 MB instead of
 // 1.1 GB.  Anything that rewrites votes wholesale (upload, table eviction) sets ifx::labels_stale_all and the next call scans everything.
-__global__ __launch_bounds__(256) void k_colour_default(const DevState* __restrict__ st, const float2* __restrict__ tm, float2* __restrict__ col, int32_t* __restrict__ labels)
+// `gate` (all three scan kernels): the first two words of the device-side call's control block (SegCtl: ff_incomplete, evict_at).  A call that cannot finish on the
+// device -- the flood fill needs more relaxations, the table is full at some mask -- must not colour anything yet: colours are assigned ONCE (c.y == 0 or the
+// default), and an instance registered before an eviction may be gone after it.  The scan then runs once, behind the host-driven tail, as in the reference.
+#define SCAN_GATED(gate) ((gate) && ((gate)[0] != 0 || (gate)[1] >= 0))
+__global__ __launch_bounds__(256) void k_colour_default(const DevState* __restrict__ st, const float2* __restrict__ tm, float2* __restrict__ col, int32_t* __restrict__ labels,
+                                                        const int* __restrict__ gate)
 {
+    if (SCAN_GATED(gate)) return;
     const float defaultColor = 7434609;
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
@@ -224,8 +230,9 @@ __global__ __launch_bounds__(256) void k_colour_default(const DevState* __restri
 }
 __global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restrict__ st, const int32_t* __restrict__ ids, int P, const float4* __restrict__ votes, int cap,
                                                          const float2* __restrict__ tm, float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels,
-                                                         IdMap im)
+                                                         IdMap im, const int* __restrict__ gate)
 {
+    if (SCAN_GATED(gate)) return;
     const float defaultColor = 7434609;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -255,8 +262,9 @@ __global__ __launch_bounds__(256) void k_count_colour_px(const DevState* __restr
     }
 }
 __global__ __launch_bounds__(256) void k_count_colour(const DevState* __restrict__ st, const float4* __restrict__ votes, int cap, const float2* __restrict__ tm,
-                                                      float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels)
+                                                      float2* __restrict__ col, const float* __restrict__ inst_color, int32_t* __restrict__ labels, const int* __restrict__ gate)
 {
+    if (SCAN_GATED(gate)) return;
     // the whole map: four lanes per surfel, each instruction of a wave reads 16 x 64 contiguous bytes of the 192-byte records; the arg-max of the four quarters is
     // merged "larger count, then smaller index" = the sequential first-maximum rule
     (void)cap;
@@ -920,7 +928,7 @@ static int oseg_mask_loop(ifx* h, bool after_eviction)
                 LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update, h->d_state, h->ids_after, h->d_masks + (size_t)m * P, P, h->cap, q, m + 1, h->votes, ifx_idmap(h));
     }
     // step 4: labels of the owned surfels
-    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
+    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels, (const int*)nullptr);
     hipEvent_t eb = ifx_event_get(h);
     hipEventRecord(eb, h->cur);
     h->stage_pending.push_back({2, {h->oseg_ev, eb}});
@@ -1091,17 +1099,19 @@ static int seg_host_mask_loop(ifx* h, int nm, const int32_t* class_ids, int m_st
     return IFX_OK;
 }
 // step 4: the label scan (countAndColourSurfelMap) -- restricted to what a call can have changed unless the votes were rewritten wholesale
-static void seg_label_scan(ifx* h)
+// `gate`: device pointer to (ff_incomplete, evict_at) of the device-side call, or null.  Returns 1 when the scan enqueued was the full one.
+static int seg_label_scan(ifx* h, const int* gate = nullptr)
 {
     const int P = h->P;
     if (h->opt_labels_incremental && !h->labels_stale_all) {
-        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels);
+        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels, gate);
         LAUNCH(h, "count_colour_px", dim3(cdiv(P, 256)), dim3(256), k_count_colour_px, h->d_state, h->ids_after, P, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col,
-               h->d_inst_color, h->labels, ifx_idmap(h));
-    } else {
-        LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels);
-        h->labels_stale_all = 0;
+               h->d_inst_color, h->labels, ifx_idmap(h), gate);
+        return 0;
     }
+    LAUNCH(h, "count_colour", dim3(2048), dim3(256), k_count_colour, h->d_state, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col, h->d_inst_color, h->labels, gate);
+    h->labels_stale_all = 0;
+    return 1;
 }
 
 static int process_segmentation_host(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks_in, const int32_t* class_ids, int nm, int frame, int flags)
@@ -1340,7 +1350,9 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
     LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, gate);
     LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
-    seg_label_scan(h);
+    // the scan kernels look at the control block themselves: when the call has to be finished by the host (fill incomplete / table full) they return at once and
+    // the ONE scan of the call runs behind the host-driven tail, after every mask and the eviction -- colours are assigned once, so an early scan would be visible
+    const int full_scan = seg_label_scan(h, (const int*)dc);
     uint8_t* h_un = (uint8_t*)h->h_segctl + sizeof(SegCtl);
     HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
     HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
@@ -1348,15 +1360,17 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     HIPCHK(h, hipStreamSynchronize(h->cur));
     t_sync = us();
     if (trace) fprintf(stderr, "seg call: result %.0f  ids %.0f  staged %.0f  enqueued %.0f  synced %.0f us (nm %d)\n", t_res, t_ids, t_stage, t_enq, t_sync, nm);
+    if ((hc->ff_incomplete || hc->evict_at >= 0) && full_scan) h->labels_stale_all = 1;   // the gated scan did not run: whatever made it a full one still holds
     if (hc->ff_incomplete) {   // the fill needs more relaxations than the schedule holds: finish it with the host looking, then the tail again (nothing was voted yet)
         r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
         if (r) return r;
         LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, (const int*)nullptr);
         LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
-        seg_label_scan(h);
+        const int full2 = seg_label_scan(h, (const int*)dc);   // (gated again: the table may turn out full at some mask)
         HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
         HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
         HIPCHK(h, hipStreamSynchronize(h->cur));
+        if (hc->evict_at >= 0 && full2) h->labels_stale_all = 1;
     }
     for (int i = 0; i < NI; i++) h->inst_class[i] = hc->inst_class[i];
     if (hc->evict_at >= 0) {   // the table is full at this mask: the reference evicts its twenty weakest instances and goes on -- from here the host-driven loop

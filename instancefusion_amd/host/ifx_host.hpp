@@ -16,6 +16,7 @@
 #define IFX_HOST_HPP_
 
 #include <zlib.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cassert>
@@ -24,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <functional>
 #include <iomanip>
@@ -134,26 +136,39 @@ struct Sharding {
     std::string idFile;
     bool on() const { return ranks > 1 || ranks == -1; }
     // the id: drawn by rank 0 (or a world of one), read from idFile by the others (waits up to timeoutSeconds for it)
+    // idFile must be a path of THIS run (a file a previous run left behind would hand the other ranks a dead id, and ncclCommInitRank would wait for ever): the file is
+    // 128 id bytes + an 8-byte nonce; `nonce` is a number the launcher gives every rank of one run (ifx_replay --shard-nonce; 0: none).  Rank 0 removes a stale file before
+    // anything else; the other ranks accept a file only if its nonce is theirs and -- without a nonce -- only if it was written after they started.
+    uint64_t nonce = 0;
     std::vector<uint8_t> uniqueId(int timeoutSeconds = 120) const
     {
         std::vector<uint8_t> id(128, 0);
         if (ranks == -1 || rank == 0) {
-            if (ifx_comm_unique_id(id.data()) != IFX_OK) throw std::runtime_error("ifx_comm_unique_id failed (RCCL not loadable?)");
             if (ranks > 1) {
                 if (idFile.empty()) throw std::runtime_error("Sharding: idFile is needed to hand the ncclUniqueId to the other ranks");
+                std::remove(idFile.c_str());   // whatever a previous run left
+            }
+            if (ifx_comm_unique_id(id.data()) != IFX_OK) throw std::runtime_error("ifx_comm_unique_id failed (RCCL not loadable?)");
+            if (ranks > 1) {
                 const std::string tmp = idFile + ".tmp";
-                { std::ofstream f(tmp, std::ios::binary); f.write((const char*)id.data(), 128); if (!f) throw std::runtime_error("cannot write " + tmp); }
+                { std::ofstream f(tmp, std::ios::binary); f.write((const char*)id.data(), 128); f.write((const char*)&nonce, 8); if (!f) throw std::runtime_error("cannot write " + tmp); }
                 if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
             }
             return id;
         }
         if (idFile.empty()) throw std::runtime_error("Sharding: idFile is needed to receive the ncclUniqueId of rank 0");
+        const std::time_t started = std::time(nullptr);
         for (int waited = 0; waited < timeoutSeconds * 20; waited++) {
             std::ifstream f(idFile, std::ios::binary);
-            if (f && f.read((char*)id.data(), 128) && f.gcount() == 128) return id;
+            uint64_t got = 0;
+            if (f && f.read((char*)id.data(), 128) && f.gcount() == 128 && f.read((char*)&got, 8) && f.gcount() == 8 && got == nonce) {
+                struct stat sb;
+                // without a nonce the only defence is the clock: a file older than this process (2 s of slack for coarse time stamps) is a previous run's
+                if (nonce != 0 || (::stat(idFile.c_str(), &sb) == 0 && sb.st_mtime + 2 >= started)) return id;
+            }
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }
-        throw std::runtime_error("Sharding: no ncclUniqueId in " + idFile + " after waiting");
+        throw std::runtime_error("Sharding: no ncclUniqueId of this run in " + idFile + " after waiting (stale file? give every rank the same --shard-nonce)");
     }
 };
 

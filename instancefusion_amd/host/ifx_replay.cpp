@@ -33,7 +33,7 @@ int usage(const char* argv0)
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
                  "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--decode-threads N] [--confidence C]\n"
                  "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n"
-                 "       [--shard-ranks G --shard-rank r --shard-id FILE (one process per GPU over one spatially sharded map; every rank replays the same log; -1: a world of one)]\n",
+                 "       [--shard-ranks G --shard-rank r --shard-id FILE [--shard-nonce N] (one process per GPU over one spatially sharded map; every rank replays the same log; -1: a world of one)]\n",
                  argv0);
     return 2;
 }
@@ -71,6 +71,7 @@ int main(int argc, char** argv)
         else if (s == "--flip-colors") a.flip = true;
         else if (s == "--shard-ranks") a.shard.ranks = std::atoi(val("--shard-ranks"));   // -1: a world of one on the sharded path
         else if (s == "--shard-rank") a.shard.rank = std::atoi(val("--shard-rank"));
+        else if (s == "--shard-nonce") a.shard.nonce = std::strtoull(val("--shard-nonce"), nullptr, 10);   // the same number for every rank of one run: a stale id file is never accepted
         else if (s == "--shard-id") a.shard.idFile = val("--shard-id");                   // where rank 0 leaves the ncclUniqueId for the others
         else if (s == "--help" || s == "-h") { usage(argv[0]); return 0; }
         else if (!s.empty() && s[0] == '-') { std::fprintf(stderr, "unknown option %s\n", s.c_str()); return usage(argv[0]); }

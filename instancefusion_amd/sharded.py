@@ -157,6 +157,9 @@ class OwnerShardedElasticFusion:
         if spec and self.dist is not None:
             with self.torch.cuda.stream(self.stream):
                 for ptr, nbytes, op in spec:
+                    if (op & 0xFF) == 4:   # the pose block of the tracking rank (ifx_owner_set_tracking_rank): a broadcast from rank op >> 8, like ifx_comm_exchange's
+                        self.dist.broadcast(self._tensor(ptr, nbytes, 1), src=op >> 8)
+                        continue
                     t = self._tensor(ptr, nbytes, op)
                     if op == 0:
                         KeyExchange.reduce_min([t], self.dist)

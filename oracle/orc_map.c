@@ -270,14 +270,22 @@ static void init_first_frame(orc_t* o)
  * (depth + index per pixel), and the buffers are merged per pixel in thread order with the same strict `<` -- lower threads hold lower indices, so the winner is
  * the one the sequential loop picks, for any number of threads.  The winner's outputs are then written by a per-pixel resolve. */
 typedef struct { int T; size_t P; float* z; int* id; } zbufs_t;
+/* the buffers are kept between renders (one set per process, grown on demand: a render of 640x480 on 64 threads would otherwise allocate, fill and free
+ * 157 MB several times per frame, which is the cpu_baseline's time, not the algorithm's); the oracle renders one image at a time */
+static float* zb_keep_z = NULL; static int* zb_keep_id = NULL; static size_t zb_keep_n = 0;
 static zbufs_t zb_open(size_t P)
 {
     zbufs_t b;
     b.T = omp_get_max_threads(); b.P = P;
-    b.z = (float*)malloc((size_t)b.T * P * sizeof(float));
-    b.id = (int*)malloc((size_t)b.T * P * sizeof(int));
+    if (b.T > 64) b.T = 64;
+    const size_t need = (size_t)b.T * P;
+    if (need > zb_keep_n) {
+        free(zb_keep_z); free(zb_keep_id);
+        zb_keep_z = (float*)malloc(need * sizeof(float)); zb_keep_id = (int*)malloc(need * sizeof(int)); zb_keep_n = need;
+    }
+    b.z = zb_keep_z; b.id = zb_keep_id;
 #pragma omp parallel for schedule(static)
-    for (long k = 0; k < (long)((size_t)b.T * P); k++) { b.z[k] = INFINITY; b.id[k] = -1; }
+    for (long k = 0; k < (long)need; k++) { b.z[k] = INFINITY; b.id[k] = -1; }
     return b;
 }
 /* merged winner per pixel -> z_out / id_out (-1: nothing drawn) */
@@ -289,8 +297,10 @@ static void zb_merge(zbufs_t* b, float* z_out, int* id_out)
         for (int t = 0; t < b->T; t++) { const float zt = b->z[(size_t)t * b->P + k]; if (zt < z) { z = zt; id = b->id[(size_t)t * b->P + k]; } }
         z_out[k] = z; id_out[k] = id;
     }
-    free(b->z); free(b->id);
 }
+/* range t of T is drawn by ONE thread of the team, whatever size the team came out (OMP_DYNAMIC, thread limits, nested regions may deliver fewer than T
+ * threads): ZB_FOR_RANGES walks t = thread, thread + team size, ... so that no range is ever left undrawn */
+#define ZB_FOR_RANGES(t, T) for (int t = omp_get_thread_num(), zb_step_ = omp_get_num_threads(); t < (T); t += zb_step_)
 static inline void zb_range(long n, int T, int t, long* lo, long* hi) { *lo = n * t / T; *hi = n * (t + 1) / T; }
 
 /* ------------------------------------------------------------------ index map (a10)
@@ -305,7 +315,7 @@ void orc_predict_indices(orc_t* o, const float* pose, int time)
     zbufs_t zb = zb_open((size_t)o->P);
 #pragma omp parallel num_threads(zb.T)
     {
-        const int t = omp_get_thread_num();
+        ZB_FOR_RANGES(t, zb.T) {
         long lo, hi;
         zb_range(o->n, zb.T, t, &lo, &hi);
         float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
@@ -316,6 +326,7 @@ void orc_predict_indices(orc_t* o, const float* pose, int time)
             if (!(u >= 0 && u < (float)w && v >= 0 && v < (float)h)) continue;
             int k = (int)floorf(v) * w + (int)floorf(u);
             if (p.z < tz[k]) { tz[k] = p.z; ti[k] = (int)i; }
+        }
         }
     }
     int* win = (int*)malloc((size_t)o->P * sizeof(int));
@@ -381,7 +392,7 @@ void orc_combined_predict(orc_t* o, const float* pose, int time, int max_time)
     zbufs_t zb = zb_open((size_t)o->P);
 #pragma omp parallel num_threads(zb.T)
     {
-        const int t = omp_get_thread_num();
+        ZB_FOR_RANGES(t, zb.T) {
         long lo, hi;
         zb_range(o->n, zb.T, t, &lo, &hi);
         float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
@@ -409,6 +420,7 @@ void orc_combined_predict(orc_t* o, const float* pose, int time, int max_time)
                     int k = py * w + px;
                     if (z < tz[k]) { tz[k] = z; ti[k] = (int)i; }
                 }
+        }
         }
     }
     int* win = (int*)malloc((size_t)o->P * sizeof(int));
@@ -724,7 +736,7 @@ void orc_render_ids(orc_t* o, const float* pose, int mode)
     zbufs_t zb = zb_open((size_t)o->P);
 #pragma omp parallel num_threads(zb.T)
     {
-        const int t = omp_get_thread_num();
+        ZB_FOR_RANGES(t, zb.T) {
         long lo, hi;
         zb_range(o->n, zb.T, t, &lo, &hi);
         float* tz = zb.z + (size_t)t * zb.P; int* ti = zb.id + (size_t)t * zb.P;
@@ -756,6 +768,7 @@ void orc_render_ids(orc_t* o, const float* pose, int mode)
                     int k = py * w + px;
                     if (z < tz[k]) { tz[k] = z; ti[k] = (int)i; }
                 }
+        }
         }
     }
     int* win = (int*)malloc((size_t)o->P * sizeof(int));

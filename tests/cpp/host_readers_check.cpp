@@ -184,6 +184,12 @@ int main(int argc, char** argv)
             f.write((const char*)&ldt, 4);
             return 0;
         }
+        if (mode == "shardid") {   // shardid FILE NONCE TIMEOUT: the reading side of Sharding::uniqueId (rank 1 of 2; no GPU) -- prints "id <first byte>" or "refused"
+            Sharding sh; sh.ranks = 2; sh.rank = 1; sh.idFile = argv[2]; sh.nonce = std::strtoull(argv[3], nullptr, 10);
+            try { const std::vector<uint8_t> id = sh.uniqueId(std::atoi(argv[4])); std::printf("id %d\n", (int)id[0]); }
+            catch (const std::exception& e) { std::printf("refused: %s\n", e.what()); }
+            return 0;
+        }
         if (mode == "quat") {
             std::ofstream f(argv[2], std::ios::binary);
             const float R[3][9] = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, -1, 0, 1, 0, 0, 0, 0, 1}, {-1, 0, 0, 0, -0.6f, 0.8f, 0, 0.8f, 0.6f}};

@@ -1427,13 +1427,22 @@ def test_instance_table_eviction_exact(ifx, orc, small_stream):
     evicted = False
     for call in range(30):
         classes = (1 + (call * nm + np.arange(nm)) % 79).astype(np.int32)      # a new class for every mask of every call: nothing matches
+        if (call + 2) * nm > 96 and not evicted:
+            # the calls around the eviction see surfels WITHOUT a colour yet (col.y = 0, as new frames leave them): colours are assigned once, so a label scan that ran
+            # before the eviction (the device-side schedule enqueues its tail before the host knows the table is full) would leave colours of evicted instances behind
+            m = o.download(); m["col"][:, 1] = 0.0
+            o.upload(m); g.upload(m)
+            o.set_pose(po, o.tick); g.set_pose(po, o.tick)
+            g.processFrame(st["rgb"][5], st["depth"][5], inPose=po); o.process_frame(st["rgb"][5], st["depth"][5], in_pose=po)
         inst.ProcessSegmentation(st["rgb"][5], st["depth"][5], masks, classes, 100 + 3 * call)
         o.process_segmentation(st["rgb"][5], st["depth"][5], masks, classes, 100 + 3 * call)
         tg, to = inst.getInstanceTable(), o.instance_table()
         assert np.array_equal(tg, to), call
         if (to >= 0).sum() < 96 and call * nm > 96:
             evicted = True
-        assert np.array_equal(g.download()["votes"], o.download()["votes"]), call
+        mg_, mo_ = g.download(), o.download()
+        assert np.array_equal(mg_["votes"], mo_["votes"]), call
+        assert np.array_equal(mg_["col"], mo_["col"]), call                    # instance colours too (ifx_map_bounding_boxes keys membership on them)
         assert np.array_equal(inst.labels(), o.labels()), call
     assert evicted
     lc = inst.getLoopClosureInstanceTable()

@@ -232,6 +232,32 @@ def test_quaternion_equals_python(checker, tmp_path):
         assert np.allclose(q[k], np.array(logio._quaternion(R.astype(np.float32)), np.float32), atol=1e-7)
 
 
+def test_sharding_unique_id_refuses_a_stale_file(checker, tmp_path):
+    """Sharding::uniqueId on a rank other than 0: a file a previous run left behind -- older than the process, or carrying another run's nonce -- is never taken for
+    this run's ncclUniqueId (ncclCommInitRank would hang on it); a file of this run is."""
+    import struct
+    import time
+
+    f = str(tmp_path / "id.bin")
+    open(f, "wb").write(bytes([7] * 128) + struct.pack("<Q", 0))
+    os.utime(f, (time.time() - 600, time.time() - 600))                       # ten minutes old, no nonce: a previous run's
+    r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
+    assert r.stdout.startswith("refused"), r.stdout
+    open(f, "wb").write(bytes([7] * 128) + struct.pack("<Q", 41))             # fresh, but another run's nonce
+    r = subprocess.run([checker, "shardid", f, "42", "1"], capture_output=True, text=True, check=True)
+    assert r.stdout.startswith("refused"), r.stdout
+    open(f, "wb").write(bytes([9] * 128) + struct.pack("<Q", 42))
+    os.utime(f, (time.time() - 600, time.time() - 600))                       # this run's nonce: the clock does not matter
+    r = subprocess.run([checker, "shardid", f, "42", "1"], capture_output=True, text=True, check=True)
+    assert r.stdout.strip() == "id 9", r.stdout
+    open(f, "wb").write(bytes([5] * 128) + struct.pack("<Q", 0))              # fresh, no nonce in use
+    r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
+    assert r.stdout.strip() == "id 5", r.stdout
+    open(f, "wb").write(bytes([5] * 100))                                     # truncated
+    r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
+    assert r.stdout.startswith("refused"), r.stdout
+
+
 def test_class_surface_compiles_and_refuses_without_gpu(checker):
     import torch
 

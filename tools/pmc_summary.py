@@ -4,6 +4,7 @@
     python tools/pmc_summary.py stats  RUN_kernel_stats.csv            OUT.csv     # kernel names shortened (no argument lists)
     python tools/pmc_summary.py pmc    FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json "about text" [bench.json [calibration.json]]
     python tools/pmc_summary.py calib  FETCH_counter_collection.csv expected.json OUT.json                        # tools/pmc_calib.sh
+    python tools/pmc_summary.py counters OUT.json PASS1_counter_collection.csv [PASS2 ...]                        # tools/pmc_bound.sh: per-kernel averages of any counters
 
 PMC: FETCH_SIZE and WRITE_SIZE are collected in separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace ...`); values are KB per
 launch.  bytes_read = FETCH_SIZE * 1024 * factor, bytes_written = WRITE_SIZE * 1024.  The factor: MI355X_MICROARCH.md (HBM section)
@@ -138,8 +139,33 @@ def pmc(fetch_csv, write_csv, dst, about, bench_json=None, calibration_json=None
         json.dump(out, g, indent=1)
 
 
+def counters(dst, paths):
+    """per kernel: launches and the average per launch of every counter found in the given passes (each pass is its own run of the same command)"""
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for path in paths:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if not k.startswith("k_"):
+                    continue
+                c = acc[k][row["Counter_Name"]]
+                c[0] += 1
+                c[1] += float(row["Counter_Value"])
+    out = {"_about": "rocprofv3 --pmc (one pass per counter group, --kernel-trace only) over python3 bench.py; values are averages PER LAUNCH, summed over all shader engines / channels "
+                     "by the *_sum forms.  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md).", "kernels": {}}
+    for k in sorted(acc, key=lambda k_: -sum(v[1] for v in acc[k_].values())):
+        e = {"launches": max(v[0] for v in acc[k].values())}
+        for c, (n, s_) in sorted(acc[k].items()):
+            e[c] = round(s_ / n, 1)
+        out["kernels"][k] = e
+    with open(dst, "w") as g:
+        json.dump(out, g, indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "", sys.argv[6] if len(sys.argv) > 6 else None, sys.argv[7] if len(sys.argv) > 7 else None)

@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 
 
 GN_ITERS = (10, 5, 4)     # Gauss-Newton iterations on pyramid levels 0, 1, 2
-GN_PERSIST = 4            # ifx option gn_persist (a bit per level): levels whose iterations run in ONE persistent launch (k_gn_level); default: the coarsest
+GN_PERSIST = 0            # ifx option gn_persist (a bit per level): levels whose iterations run in ONE persistent launch (k_gn_level); default since round 4: none
 
 
 def level_avg(persist=None):

@@ -209,6 +209,11 @@ int ifx_trajectory(ifx_t* h, float* out_poses16, int max_frames);
 /* diag[8]: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count,
  * velocity weighting, fill-in flag (EF/Utils/RGBDOdometry.h:65-70). */
 int ifx_tracker_diag(ifx_t* h, float* diag8);
+/* Pyramid levels that the persistent Gauss-Newton kernel (option gn_persist) could not finish because a meeting of its workgroups did not happen (the grid was
+ * not co-resident: other work held the GPU) and that one workgroup re-ran alone inside the same frame -- same sums, same solve, same pose, only slower.  A count since
+ * ifx_create, >= 0; negative: error.  Replaces nothing of the reference (its tracker reads every reduction back, EF/Utils/RGBDOdometry.cpp:461-583): a diagnostic
+ * of this implementation's schedule.  Waits for the frames in flight. */
+int ifx_tracker_fallbacks(ifx_t* h);
 
 /* ---- local loop-closure DETECTION (the closeLoops / countThresh / errThresh / covThresh constructor arguments, EF/ElasticFusion.h:48-51;
  * EF/ElasticFusion.cpp:453-566 with no fern match).  When enabled every tracked frame also runs predict() at the new pose, the INACTIVE

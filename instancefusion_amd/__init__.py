@@ -103,6 +103,7 @@ _SIGS = {
     "ifx_tick": (C.c_int, [_P]),
     "ifx_trajectory": (C.c_int, [_P, _P, C.c_int]),
     "ifx_tracker_diag": (C.c_int, [_P, _P]),
+    "ifx_tracker_fallbacks": (C.c_int, [_P]),
     "ifx_set_loop_closure": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "ifx_loop_closure_diag": (C.c_int, [_P, _P]),
     "ifx_set_loop_closure_callback": (C.c_int, [_P, _P, _P]),
@@ -309,6 +310,10 @@ class ElasticFusion:
         out = np.zeros(8, np.float32)
         self._chk(self.L.ifx_tracker_diag(self.handle, _ptr(out)), "ifx_tracker_diag")
         return out
+
+    def tracker_fallbacks(self):
+        """pyramid levels the persistent Gauss-Newton kernel handed to its one-workgroup fallback so far (0 in a healthy run)"""
+        return self._chk(self.L.ifx_tracker_fallbacks(self.handle), "ifx_tracker_fallbacks")
 
     # -- local loop-closure detection (closeLoops, countThresh, errThresh, covThresh of the reference constructor)
     def set_loop_closure(self, enable=True, count_thresh=35000, err_thresh=5e-5, cov_thresh=1e-5):

@@ -311,6 +311,13 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
         ifx_drop_tracked(h);
         h->opt_gn_persist = value;
     }
+    else if (s == "gn_spin_limit" || s == "gn_fault") {   // test hooks of the persistent level kernel's fallback: polls before a meeting gives up (0: 2^21) / block 1 never arrives at meeting number `value`
+        if (value < 0) return IFX_E_INVALID;
+        ifx_drop_tracked(h);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy((char*)h->d_state + (s == "gn_fault" ? offsetof(DevState, gn_fault) : offsetof(DevState, gn_spin_limit)), &value, sizeof(int), hipMemcpyHostToDevice));
+    }
+    else if (s == "gn_prologue") { ifx_drop_tracked(h); h->opt_gn_prologue = value ? 1 : 0; }
     else if (s == "raster_lds") h->opt_raster_lds = value;
     else if (s == "raster_earlyz") h->opt_raster_earlyz = value;
     // ElasticFusion::setPyramid / setFastOdom / setSo3 / setIcpWeight (EF/ElasticFusion.h:153-176): tracker configuration from the next frame on;
@@ -955,8 +962,16 @@ extern "C" int ifx_sync(ifx_t* h)
     ktime_flush(h);
     stage_flush(h);
     if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
-    if (h->h_result->gn_timeout) { h->err = "the tracker's persistent level kernel gave up at a grid barrier (its blocks were not co-resident): set option gn_persist to 0"; return IFX_E_HIP; }
     return IFX_OK;
+}
+// Levels of the tracker's pyramid that the persistent kernel (option gn_persist) could not finish -- a meeting of its blocks did not happen: the grid was not co-resident --
+// and that its block 0 re-ran alone inside the same frame, with the same result (k_gn_level / gn_level_solo).  A count since the handle was created, not an error:
+// results are unaffected, such a frame is just slower; a host that sees it grow should set gn_persist to 0.  (No counterpart in the reference: diagnostics.)
+extern "C" int ifx_tracker_fallbacks(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    int r = ifx_sync(h);
+    return r ? r : h->h_result->gn_timeout;
 }
 
 extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const float* in_pose16, float weight_mult, float* out_pose16)

@@ -77,7 +77,16 @@ struct DevState {
     double gn_acc2[2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE];   // [parity][ICP | photometric]
     alignas(64) int gn_res2[2 * 16];                          // [parity] (count, sigma), a line each
     alignas(64) unsigned int gn_bar[4 * 32 * 16];             // [level][32 sub-counters] arrivals, a line each (gn_grid_barrier)
-    int gn_timeout;                                           // a grid barrier gave up (never in a healthy run; tests assert 0)
+    int gn_timeout;                                           // levels the persistent kernel could not finish and block 0 re-ran alone (never in a healthy run; a count, not an error: ifx_tracker_fallbacks)
+    int gn_abort;                                             // this run's persistent kernel gave up at a barrier: its blocks leave, k_gn_level_solo re-runs the level on one workgroup (reset at the start of every run)
+    int gn_done_seq;                                          // level + 1 of the last persistent launch whose result was published (k_gn_level's block 0 / k_gn_level_solo)
+    int gn_spin_limit, gn_fault;                              // test hooks (options gn_spin_limit / gn_fault): polls before a barrier gives up (0: 2^21); != 0: block 1 never arrives at barrier number gn_fault
+    // "solve in the next launch's prologue" (option gn_prologue, ifx_track.hip): iteration j of a run's two-launch tail keeps its sums in parity j & 1 -- every block of
+    // the NEXT launch reads the 2 x 29 totals, rebuilds the 6x6 system and solves it itself (no last-block ticket, no pose store / pose load between the two launches);
+    // the running increment after iteration j lives in gnp_RRt[j & 1] (block 0 of the launch that solved it writes it; its readers are the launch after that)
+    alignas(64) double gnp_acc[2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE];   // [parity][ICP | photometric]
+    alignas(64) int gnp_res[2 * 16];                                     // [parity] (count, sigma), a line each
+    alignas(64) double gnp_RRt[2][16];
 };
 
 // Ids in the id images are slot indices on an unsharded map and creation numbers on a spatially sharded one (ifx_map.hip, key_id / local_slot):
@@ -103,7 +112,7 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     float pose[16];
     float diag[8];
     int count, n_dead, n_new, overflow;
-    int gn_timeout;      // DevState::gn_timeout: sticky, reported by ifx_sync
+    int gn_timeout;      // DevState::gn_timeout: levels re-run by the persistent kernel's fallback so far (ifx_tracker_fallbacks)
     int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
 };
 
@@ -246,10 +255,14 @@ struct ifx {
     int opt_icp_px = 0;              // ICP and residual reductions on the same pixels of one thread, all loads in two batches (k_icp_residual_px; bits: 1 level 0, 2 levels 1-2, 4 one pixel per thread); measured slower: off
     int opt_model_fused = 0;         // model pyramid of the frame tracker in one launch (k_model_pyr3) when the image size allows; measured equal to the three launches (28 vs 27 us): off
     int opt_gn_persist_blocks = 128;  // ... and only while its grid has at most this many blocks: the meetings cost grows with the blocks (75 at 160 x 120: faster; 300: slower)
-    int opt_gn_persist = 4;          // bit i: all Gauss-Newton iterations of pyramid level i in one persistent launch (k_gn_level) when its grid fits the GPU; faster at the coarsest level only
+    int opt_gn_persist = 0;          // bit i: all Gauss-Newton iterations of pyramid level i in one persistent launch (k_gn_level) when its grid fits the GPU.  Round 3's default was 4 (the coarsest level,
+                                     // +1.4 %); with the solve in the next launch's prologue the two-launch form is within 0.7 % of it (profiles/r04_b_ab_gn_prologue*.txt), and a spinning grid barrier does
+                                     // not belong on the default frame path for that: off.  As an option it is safe: a meeting that does not happen costs time, never the pose (k_gn_level_solo)
     int gn_max_blocks[4] = {0, 0, 0, 0};   // co-resident blocks of k_gn_level<1 | 2 | 3 | 4>
     int opt_icp_lds = 0;             // level-0 ICP reduction on 64 x 16 tiles with the model maps staged in LDS (measured slower: DESIGN.md section 6)
     int opt_rgb_blocks = 0;          // cap on the blocks of the photometric step (0: 192)
+    int opt_gn_prologue = 1;         // two-launch Gauss-Newton iterations: the 6x6 solve of iteration j runs in the prologue of EVERY block of iteration j + 1's first launch (no last-block
+                                     // hand-off inside the photometric step's launch); 0: round 3's form, the last block of the photometric step solves and stores the pose
     // spatially sharded map: ifx_owner_segmentation_begin / _resume carry one segmentation call across its exchange points
     int oseg_state = 0, oseg_nm = 0, oseg_m = 0, oseg_flags = 0, oseg_pending = 0;
     std::vector<uint8_t> oseg_unavail;

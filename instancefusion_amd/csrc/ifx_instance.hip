@@ -445,7 +445,6 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
         // already be queued behind it)
         HIPCHK(h, hipEventSynchronize(h->ev_result));
         // (the one place an asynchronous host looks at every frame's result: the sticky failures are reported here too, not only by ifx_sync)
-        if (h->h_result->gn_timeout) { h->err = "the tracker's persistent level kernel gave up at a grid barrier (its blocks were not co-resident): set option gn_persist to 0"; return IFX_E_HIP; }
         if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
         count[0] = h->h_result->seg_counts[0]; count[1] = h->h_result->seg_counts[1];
     } else {

@@ -268,6 +268,7 @@ __device__ __forceinline__ void gn_persist_reset(DevState* st, int lt, int nt)
     for (int k = lt; k < 2 * 2 * IFX_ACC_REPL * IFX_ACC_STRIDE; k += nt) st->gn_acc2[k] = 0.0;
     if (lt < 32) st->gn_res2[lt] = 0;
     for (int k = lt; k < 4 * 32 * 16; k += nt) st->gn_bar[k] = 0u;
+    if (lt == 0) { st->gn_abort = 0; st->gn_done_seq = 0; }
 }
 __global__ void k_model_down(const DevState* __restrict__ st, const float* __restrict__ vin, const float* __restrict__ nin, const float* __restrict__ din, const uint8_t* __restrict__ iin,
                              int sw, int sh, ModelOut o, GnBegin gb)
@@ -565,26 +566,80 @@ __device__ long long g_dbg2[8];
 __shared__ long long s_dbg_blk[4];
 #endif
 
+// ======================================================================= Gauss-Newton: the solve in the NEXT launch's prologue (option gn_prologue, default)
+// Round 3's iteration was: launch A (ICP sums + residual pass) -> launch B (photometric sums; the block that draws the last ticket reads the 2 x 29 totals, solves the
+// 6x6 system, stores the pose) -> launch A' (loads the pose) ...  The serial tail of B -- drain, ticket round trip, totals round trip, solve, stores -- and the pose loads of
+// A' were all on the critical path of every iteration.  Here B just sums; EVERY block of A' fetches the totals of the previous iteration itself (the same 58 agent-scope
+// loads the last block did), rebuilds the combined system and solves it on its lane 0 -- the same totals give the same bits in every block -- while the loads of its
+// first pixels, which do not depend on the pose, are already in flight.  No ticket, no last block, no pose round trip through memory; the run's LAST iteration keeps the
+// last-block form (it also ends the run: pose write-back, velocity weighting, view-list decision).  Sums, residual totals and the running increment are double-buffered
+// by iteration parity (DevState::gnp_*): iteration j writes parity j & 1, launch B of iteration j + 1 clears it after every block of launch A of j + 1 has read it.
+struct KInv { double i0, i4, i2, i5; };
+struct GnPro {
+    int k;                        // position of this launch's iteration in the run's two-launch tail; k >= 1: iteration k - 1 is solved in the prologue
+    int icp, rgb;
+    float icp_weight;
+    float nfx, nfy, ncx, ncy;     // intrinsics of the level THIS launch runs at: the warp matrices the solve emits are for this launch's own residual pass
+    KInv ki;
+};
+__device__ __forceinline__ void gn_serial_lane(const double* s_sys, int icp, double* RRt, const float* Rp, const float* tp, float nfx, float nfy, float ncx, float ncy, const KInv& ki,
+                                               float* Rc, float* tc, float* krk, float* kt);
+// returns the pose of the iteration about to run, in LDS: Rcurr 9, tcurr 3, krkinv 9, kt 3.  Call it with the block's first pose-independent loads already issued.
+__device__ __forceinline__ const float* gn_prologue(const DevState* __restrict__ st, const GnPro& g, double* __restrict__ rrt_out)
+{
+    __shared__ double s_psys[27];
+    __shared__ float s_ppose[24];
+    const int prev = (g.k - 1) & 1;
+    const double* const icp_acc = st->gnp_acc + (size_t)(prev * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+    const double* const rgb_acc = icp_acc + IFX_ACC_REPL * IFX_ACC_STRIDE;
+    if (threadIdx.x < 27) {
+        const int k = threadIdx.x;
+        const double ti = acc_total(icp_acc, k), tr = acc_total(rgb_acc, k);
+        const float oi = g.icp ? (float)ti : 0.f, orr = g.rgb ? (float)tr : 0.f;   // rounded to f32 as the reference's reductions deliver them
+        // lastA = A_rgb + w*w*A_icp, lastb = b_rgb + w*b_icp (EF/Utils/RGBDOdometry.cpp:547-565); column 6 of a row is its b entry
+        const double wgt = g.icp_weight;
+        const double wa = wgt * wgt, wb = wgt;
+        const bool is_b = (k == 6) | (k == 12) | (k == 17) | (k == 21) | (k == 24) | (k == 26);
+        const double vi = (double)oi, vr = (double)orr;
+        s_psys[k] = (g.icp && g.rgb) ? vr + (is_b ? wb : wa) * vi : (g.icp ? vi : vr);
+    }
+    // the increment after iteration k - 2 (the run's start value for k == 1) and the run's constants: uniform addresses, fetched beside the totals
+    const double* const rsrc = g.k == 1 ? st->resultRt : st->gnp_RRt[g.k & 1];
+    double RRt[16];
+    float Rp[9], tp[3];
+#pragma unroll
+    for (int k = 0; k < 12; k++) RRt[k] = rsrc[k];
+    RRt[12] = 0.0; RRt[13] = 0.0; RRt[14] = 0.0; RRt[15] = 1.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tp[k] = st->tprev[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float Rc[9], tc[3], krk[9], kt[3];
+        gn_serial_lane(s_psys, g.icp, RRt, Rp, tp, g.nfx, g.nfy, g.ncx, g.ncy, g.ki, Rc, tc, krk, kt);
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s_ppose[k] = Rc[k]; s_ppose[12 + k] = krk[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_ppose[9 + k] = tc[k]; s_ppose[21 + k] = kt[k]; }
+        if (rrt_out) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) rrt_out[k] = RRt[k];
+        }
+    }
+    __syncthreads();
+    return s_ppose;
+}
+
 struct IcpArgs { float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3]; };
 // ICPReduction, EF/Cuda/reduce.cu:257-411.  Rcurr/tcurr/Rprev_inv/tprev come from DevState (or from
 // explicit arguments for the stage API when st == nullptr).
-template <bool WT = false, bool FROM_STATE = false>
+template <bool WT = false, bool FROM_STATE = false, bool PRO = false>
 __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __restrict__ st, const IcpArgs& ex, const float* __restrict__ vmap_curr,
                                          const float* __restrict__ nmap_curr, const float* __restrict__ vmap_prev, const float* __restrict__ nmap_prev, float fx,
-                                         float fy, float cx, float cy, float distThres, float angleThres, int w, int h, double* __restrict__ gacc)
+                                         float fy, float cx, float cy, float distThres, float angleThres, int w, int h, double* __restrict__ gacc,
+                                         const GnPro* pro = nullptr, double* __restrict__ rrt_out = nullptr)
 {
-    const bool from_state = FROM_STATE || st != nullptr;   // (FROM_STATE: known at compile time -- no per-element select, the loads leave in one batch)
-    const float* Rc = from_state ? st->Rcurr : ex.Rcurr;
-    const float* tcp = from_state ? st->tcurr : ex.tcurr;
-    const float* Rpi = from_state ? st->Rprev_inv : ex.Rprev_inv;
-    const float* tpp = from_state ? st->tprev : ex.tprev;
-    float Rcurr[9], Rprev_inv[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) { Rcurr[k] = Rc[k]; Rprev_inv[k] = Rpi[k]; }
-    const v3 tc = v3m(tcp[0], tcp[1], tcp[2]), tp = v3m(tpp[0], tpp[1], tpp[2]);
-    double acc[29];
-#pragma unroll
-    for (int k = 0; k < 29; k++) acc[k] = 0.0;
     const int N = w * h;
     // One pixel per thread and round, software-pipelined: the coalesced loads of the NEXT round are issued right behind this round's gathers, so a
     // round costs one memory round trip instead of two (a level-0 block runs four rounds).  Issue order matters: vector loads return in order,
@@ -592,11 +647,24 @@ __device__ __forceinline__ void icp_body(int bid, int nblk, const DevState* __re
     const int stride = nblk * RED_THREADS;
     int i = bid * RED_THREADS + threadIdx.x;
     v3 vcurr, ncurr;
-    {
+    {   // the first round's own-pixel loads do not depend on the pose: in flight before the pose is even known (PRO: under the prologue's solve)
         const int ii = i < N ? i : 0;
         vcurr = v3m(vmap_curr[ii], vmap_curr[ii + N], vmap_curr[ii + 2 * N]);
         ncurr = v3m(nmap_curr[ii], nmap_curr[ii + N], nmap_curr[ii + 2 * N]);
     }
+    const bool from_state = FROM_STATE || st != nullptr;   // (FROM_STATE: known at compile time -- no per-element select, the loads leave in one batch)
+    const float* Rc = from_state ? st->Rcurr : ex.Rcurr;
+    const float* tcp = from_state ? st->tcurr : ex.tcurr;
+    const float* Rpi = from_state ? st->Rprev_inv : ex.Rprev_inv;
+    const float* tpp = from_state ? st->tprev : ex.tprev;
+    if (PRO) { const float* sp = gn_prologue(st, *pro, rrt_out); Rc = sp; tcp = sp + 9; }   // the pose this iteration runs at: solved here, by every block alike
+    float Rcurr[9], Rprev_inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rcurr[k] = Rc[k]; Rprev_inv[k] = Rpi[k]; }
+    const v3 tc = v3m(tcp[0], tcp[1], tcp[2]), tp = v3m(tpp[0], tpp[1], tpp[2]);
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
     while (i < N) {
         // stage 2: projection into the model frame
         const v3 vcurr_g = mulp(Rcurr, vcurr) + tc;
@@ -724,31 +792,22 @@ struct Corres8 { short zx, zy; float diff; };
 
 // RGBResidual, EF/Cuda/reduce.cu:739-863
 struct ResArgs { float krkinv[9], kt[3]; };
-template <bool FROM_STATE = false>
+template <bool FROM_STATE = false, bool PRO = false>
 __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState* __restrict__ st, const ResArgs& ex, float minScale, const int16_t* __restrict__ dIdx,
                                               const int16_t* __restrict__ dIdy, const float* __restrict__ lastDepth, const float* __restrict__ nextDepth,
                                               const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, Corres8* __restrict__ corres,
-                                              float maxDepthDelta, int w, int h, int* __restrict__ partials, int* __restrict__ res_total = nullptr)
+                                              float maxDepthDelta, int w, int h, int* __restrict__ partials, int* __restrict__ res_total = nullptr,
+                                              const GnPro* pro = nullptr, double* __restrict__ rrt_out = nullptr)
 {
-    const bool from_state = FROM_STATE || st != nullptr;
-    const float* kk = from_state ? st->krkinv : ex.krkinv;
-    const float* ktp = from_state ? st->kt : ex.kt;
-    float krk[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) krk[k] = kk[k];
-    const float kt0 = ktp[0], kt1 = ktp[1], kt2 = ktp[2];
     const int border = 16;
     const int N = w * h;
-    int cnt = 0, sig = 0;
-    for (int base = bid * (RED_THREADS * RED_IT) + threadIdx.x; base < N; base += nblk * RED_THREADS * RED_IT) {
-        bool cand[RED_IT];
-        int kidx[RED_IT], gj[RED_IT];
-        float d1[RED_IT], td1[RED_IT];
-        uint8_t ni[RED_IT];
+    // stage 1 of a round: own-pixel tests (4x4 non-zero block, gradient gate) and depth -- nothing of it depends on the pose
+    struct Own { bool cand[RED_IT]; int kidx[RED_IT]; float d1[RED_IT]; uint8_t ni[RED_IT]; };
+    auto own_pixels = [&](int base, Own& o) {
 #pragma unroll
-        for (int u = 0; u < RED_IT; u++) {   // stage 1: own-pixel tests (4x4 non-zero block, gradient gate) and depth
+        for (int u = 0; u < RED_IT; u++) {
             int k = base + u * RED_THREADS;
-            kidx[u] = k;
+            o.kidx[u] = k;
             bool in = k < N;
             int kk2 = in ? k : 0;
             int i = kk2 / w, j0 = kk2 - i * w;
@@ -766,19 +825,36 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
             }
             short valx = dIdx[kk2], valy = dIdy[kk2];
             float mTwo = (float)((valx * valx) + (valy * valy));
-            d1[u] = nextDepth[kk2];
-            ni[u] = nextImage[kk2];
-            cand[u] = ok & valid & (mTwo >= minScale) & !(d1[u] != d1[u]);   // (bitwise: no load of this stage may hide behind a branch)
+            o.d1[u] = nextDepth[kk2];
+            o.ni[u] = nextImage[kk2];
+            o.cand[u] = ok & valid & (mTwo >= minScale) & !(o.d1[u] != o.d1[u]);   // (bitwise: no load of this stage may hide behind a branch)
         }
+    };
+    const int base0 = bid * (RED_THREADS * RED_IT) + threadIdx.x, stride = nblk * RED_THREADS * RED_IT;
+    Own own;
+    own_pixels(base0, own);   // in flight before the warp matrices are known (PRO: under the prologue's solve)
+    const bool from_state = FROM_STATE || st != nullptr;
+    const float* kk = from_state ? st->krkinv : ex.krkinv;
+    const float* ktp = from_state ? st->kt : ex.kt;
+    if (PRO) { const float* sp = gn_prologue(st, *pro, rrt_out); kk = sp + 12; ktp = sp + 21; }
+    float krk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) krk[k] = kk[k];
+    const float kt0 = ktp[0], kt1 = ktp[1], kt2 = ktp[2];
+    int cnt = 0, sig = 0;
+    for (int base = base0; base < N; base += stride) {
+        if (base != base0) own_pixels(base, own);
+        int gj[RED_IT];
+        float td1[RED_IT];
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 2: warp into the last image
-            int i = kidx[u] / w, j0 = kidx[u] - i * w;
+            int i = own.kidx[u] / w, j0 = own.kidx[u] - i * w;
             int y = i, x = j0;
-            td1[u] = (float)(d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
-            int u0 = f2i_rn((d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
-            int v0 = f2i_rn((d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
-            cand[u] = cand[u] & ((u0 >= 0) & (v0 >= 0) & (u0 < w) & (v0 < h));
-            gj[u] = cand[u] ? v0 * w + u0 : 0;
+            td1[u] = (float)(own.d1[u] * (krk[6] * x + krk[7] * y + krk[8]) + kt2);
+            int u0 = f2i_rn((own.d1[u] * (krk[0] * x + krk[1] * y + krk[2]) + kt0) / td1[u]);
+            int v0 = f2i_rn((own.d1[u] * (krk[3] * x + krk[4] * y + krk[5]) + kt1) / td1[u]);
+            own.cand[u] = own.cand[u] & ((u0 >= 0) & (v0 >= 0) & (u0 < w) & (v0 < h));
+            gj[u] = own.cand[u] ? v0 * w + u0 : 0;
         }
         float d0[RED_IT];
         uint8_t li[RED_IT];
@@ -787,14 +863,14 @@ __device__ __forceinline__ void residual_body(int bid, int nblk, const DevState*
 #pragma unroll
         for (int u = 0; u < RED_IT; u++) {   // stage 4
             Corres8 c;
-            const bool hit = cand[u] & (d0[u] > 0) & (fabsf(td1[u] - d0[u]) <= maxDepthDelta) & (li[u] != 0);
+            const bool hit = own.cand[u] & (d0[u] > 0) & (fabsf(td1[u] - d0[u]) <= maxDepthDelta) & (li[u] != 0);
             const int v0 = gj[u] / w, u0 = gj[u] - v0 * w;
-            const float diff = (float)ni[u] - (float)li[u];
+            const float diff = (float)own.ni[u] - (float)li[u];
             c.zx = hit ? (short)u0 : (short)-1; c.zy = hit ? (short)v0 : (short)-1;
             c.diff = hit ? diff : 0.f;
             cnt += hit ? 1 : 0;
             sig += hit ? (int)(diff * diff) : 0;
-            if (kidx[u] < N) corres[kidx[u]] = c;
+            if (own.kidx[u] < N) corres[own.kidx[u]] = c;
         }
     }
     __shared__ int lds[RED_WAVES][2];
@@ -838,8 +914,9 @@ struct PairArgs {
 // each group of s_loads into the branch that uses it: four to five dependent scalar round trips in front of the first vector load of a
 // latency-bound launch.
 #define IFX_PIN_S(x) asm volatile("" ::"s"(x))
-template <bool LDS_TILES, bool CHECK_SKIP>
-__global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __restrict__ st, int nb_icp, int w, int h, double* __restrict__ gacc, int* __restrict__ gres, PairArgs a)
+template <bool LDS_TILES, bool CHECK_SKIP, bool PRO = false>
+__global__ __launch_bounds__(RED_THREADS, 4) void k_icp_residual(const DevState* __restrict__ st, int nb_icp, int w, int h, double* __restrict__ gacc, int* __restrict__ gres, PairArgs a, GnPro g,
+                                                              double* __restrict__ rrt_store)
 {
     // `st`, `nb_icp`, `w`, `h` and the two hand-off pointers (DevState::gn_acc / gn_res of `st`: separate arguments, so that the state itself stays
     // read-only here and its fields come through the scalar cache) arrive preloaded: the branch below is decided without a load, and each half then fetches its argument words and its
@@ -851,11 +928,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_icp_residual(const DevState* __
         if (LDS_TILES) { icp_body_lds(blockIdx.x, st, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc); return; }
 #endif
         IcpArgs ia;   // unused when st != nullptr
-        icp_body<false, true>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc);
+        // PRO: `g` and `rrt_store` (DevState::gnp_RRt of this iteration's parity: block 0 publishes the increment it solved for the launch after the next)
+        icp_body<false, true, PRO>(blockIdx.x, nb_icp, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc, &g,
+                                   blockIdx.x == 0 ? rrt_store : nullptr);
     } else {
         ResArgs ra;
-        residual_body<true>(blockIdx.x - nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, w,
-                      h, nullptr, gres);
+        residual_body<true, PRO>(blockIdx.x - nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, w,
+                                 h, nullptr, gres, &g, blockIdx.x == 0 ? rrt_store : nullptr);
     }
 }
 
@@ -1585,7 +1664,6 @@ __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mul
 
 // K^-1 entries of the level the next iteration runs at, as the lone lane would compute them (1/fx, 1/fy, -cx/fx, -cy/fy in f64): computed on the host
 // -- the same IEEE divisions -- so that four f64 divisions leave the serial part of every iteration
-struct KInv { double i0, i4, i2, i5; };
 static inline KInv kinv_of(float fx, float fy, float cx, float cy)
 {
     const double K0 = fx, K2 = cx, K4 = fy, K5 = cy;
@@ -1696,7 +1774,8 @@ __device__ __forceinline__ void gn_serial_lane(const double* s_sys, int icp, dou
 // In-kernel stamps of the previous form (everything on lane 0): 8.6k cycles serial; see DESIGN.md section 6.
 __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict__ icp_acc, double* __restrict__ rgb_acc,
                            const int* __restrict__ res_partials, int res_blocks, int icp, int rgb, float icp_weight, float nfx, float nfy, float ncx, float ncy, const KInv& ki,
-                           int* __restrict__ res_total = nullptr, int final_iter = 1, int end_run = 0, float weight_mult = 1.f, int commit = 1, unsigned int* lctr = nullptr)
+                           int* __restrict__ res_total = nullptr, int final_iter = 1, int end_run = 0, float weight_mult = 1.f, int commit = 1, unsigned int* lctr = nullptr,
+                           const double* __restrict__ rrt_src = nullptr)
 {
     __shared__ double s_sys[27];      // combined system: index = position in the reference's 29-vector (upper triangle of A row by row, b in column 6)
     __shared__ float s_oi[29], s_or[29];
@@ -1705,8 +1784,14 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
     // (one memory round trip instead of two on the critical path of every iteration)
     double RRt[16];
     float Rp[9], tp[3];
+    if (rrt_src) {   // (option gn_prologue: the increment of the iteration before lives in DevState::gnp_RRt, twelve entries)
 #pragma unroll
-    for (int k = 0; k < 16; k++) RRt[k] = st->resultRt[k];
+        for (int k = 0; k < 12; k++) RRt[k] = rrt_src[k];
+        RRt[12] = 0.0; RRt[13] = 0.0; RRt[14] = 0.0; RRt[15] = 1.0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) RRt[k] = st->resultRt[k];
+    }
 #pragma unroll
     for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
 #pragma unroll
@@ -1810,20 +1895,30 @@ struct StepArgs {
     int end_run, commit;   // ... and ends the run in the same lane (track_end_dev)
     float weight_mult;
     unsigned int* lctr;
+    int pro, pro_k;        // option gn_prologue: 0 = round 3's form; 1 = sums only (the next launch's prologue solves); 2 = the run's last iteration (last-block form on the parity buffers).  pro_k: position in the two-launch tail
 };
 template <bool CHECK_SKIP>
 __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, int nb, int rgb, int w, int h, StepArgs a)
 {
     __builtin_assume(st != nullptr);
     if (CHECK_SKIP && st->skip) return;   // (model-to-model instance only) uniform over the grid: the last-block ticket stays armed
-    int* const res_total = st->gn_res;   // hand-off words and accumulator rows: behind the state pointer, which arrives preloaded
+    // hand-off words and accumulator rows: behind the state pointer, which arrives preloaded.  gn_prologue: the buffers of this iteration's parity
+    const int par = a.pro_k & 1;
+    int* const res_total = a.pro ? st->gnp_res + par * 16 : st->gn_res;
     unsigned int* const ticket = &st->gn_ticket;
-    double* const icp_acc = st->gn_acc, * const rgb_acc = st->gn_acc + IFX_ACC_REPL * IFX_ACC_STRIDE;
+    double* const icp_acc = a.pro ? st->gnp_acc + (size_t)(par * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE : st->gn_acc;
+    double* const rgb_acc = icp_acc + IFX_ACC_REPL * IFX_ACC_STRIDE;
     __shared__ int s_last;
+    if (a.pro && blockIdx.x == 0) {   // the other parity was last read by the prologues of this iteration's first launch: clean again for the next iteration's sums
+        double* const other = st->gnp_acc + (size_t)((1 - par) * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+        __hip_atomic_store(&other[threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 x REPL x STRIDE = 256 doubles = RED_THREADS
+        if (threadIdx.x < 2) __hip_atomic_store(&st->gnp_res[(1 - par) * 16 + threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef IFX_STAMPS
     long long t0 = clock64();
 #endif
     if (rgb) rgb_step_body(blockIdx.x, nb, a.corres, 0.f, nullptr, 0, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, w, h, rgb_acc, res_total);
+    if (a.pro == 1) return;   // sums only: every block of the next launch reads the totals and solves (gn_prologue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef IFX_STAMPS
@@ -1842,7 +1937,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
 #ifdef IFX_STAMPS
     long long t2 = clock64();
 #endif
-    gn_solve_block(st, icp_acc, rgb_acc, nullptr, 0, a.icp, rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.ki, res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr);
+    gn_solve_block(st, icp_acc, rgb_acc, nullptr, 0, a.icp, rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.ki, res_total, a.final_iter, a.end_run, a.weight_mult, a.commit, a.lctr,
+                   (a.pro && a.pro_k > 0) ? st->gnp_RRt[1 - par] : (const double*)nullptr);
 #ifdef IFX_STAMPS
     if (threadIdx.x == 0) { long long t3 = clock64(); st->dbg[0] += t2 - t0; st->dbg[1] += t3 - t2; st->dbg[2] += 1; st->dbg[5] += t1 - t0; st->dbg[3] -= t2; g_dbg2[0] += s_dbg_blk[0]; g_dbg2[1] += s_dbg_blk[1]; g_dbg2[2] += s_dbg_blk[2]; }
 #endif
@@ -1873,6 +1969,7 @@ struct LevelArgs {
     const float *lastDepth, *nextDepth;
     const uint8_t *lastImage, *nextImage;
     const float* cloud;
+    Corres8* corres;              // scratch of the one-workgroup fallback (the level's correspondence records)
     float fx, fy, cx, cy, distThres, angleThres, minScale, maxDepthDelta, sobelScale;
     int w, h, iters, icp, rgb;
     float icp_weight;
@@ -1886,29 +1983,149 @@ struct LevelArgs {
     unsigned int* lctr;
 };
 
+// The level on ONE workgroup (enqueued behind every k_gn_level launch; returns at its first instruction unless a meeting of that launch failed): the bodies of the two-launch form with a grid of one, the sums through the single-buffer
+// accumulator rows (DevState::gn_acc / gn_res, which nothing else uses while this kernel runs), agent-scope fences between the phases (the block reads back what it
+// wrote: correspondence records, residual totals).  Same rows, same exact sums, same solve: the level's result is the one the meetings would have produced.
+__global__ __launch_bounds__(RED_THREADS) void k_gn_level_solo(DevState* st, LevelArgs a)
+{
+    if (st->gn_done_seq == a.level + 1) return;   // the meetings happened (every healthy launch): nothing to do
+    __shared__ float s_pose[24];
+    __shared__ double s_RRt[16];
+    __shared__ double s_sys[27];
+    __shared__ float s_oi[29], s_or[29];
+    __shared__ int s_res[2];
+    const int tid = threadIdx.x;
+    float Rp[9], tpv[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = st->Rprev[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tpv[k] = st->tprev[k];
+    if (tid < 9) { s_pose[tid] = st->Rcurr[tid]; s_pose[12 + tid] = st->krkinv[tid]; }
+    if (tid < 3) { s_pose[9 + tid] = st->tcurr[tid]; s_pose[21 + tid] = st->kt[tid]; }
+    if (tid < 16) s_RRt[tid] = st->resultRt[tid];
+    if (tid == 0) atomicAdd(&st->gn_timeout, 1);
+    __syncthreads();
+    double* const icp_acc = st->gn_acc, * const rgb_acc = st->gn_acc + IFX_ACC_REPL * IFX_ACC_STRIDE;
+    int* const gres = st->gn_res;
+    Corres8* const corres = a.corres;
+    for (int it = 0; it < a.iters; it++) {
+        IcpArgs ia;
+        ResArgs ra;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { ia.Rcurr[k] = s_pose[k]; ia.Rprev_inv[k] = st->Rprev_inv[k]; ra.krkinv[k] = s_pose[12 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ia.tcurr[k] = s_pose[9 + k]; ia.tprev[k] = tpv[k]; ra.kt[k] = s_pose[21 + k]; }
+        icp_body<false, false>(0, 1, nullptr, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, a.w, a.h, icp_acc);
+        residual_body<false>(0, 1, nullptr, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, corres, a.maxDepthDelta, a.w, a.h, st->gn_pad, gres);
+        __threadfence();
+        __syncthreads();
+        rgb_step_body(0, 1, corres, 0.f, nullptr, 0, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, a.w, a.h, rgb_acc, gres);
+        __threadfence();
+        __syncthreads();
+        const bool last_it = it == a.iters - 1;
+        if (tid < 29) {
+            const double ti = acc_total(icp_acc, tid), tr = acc_total(rgb_acc, tid);
+            acc_clear(icp_acc, tid);
+            acc_clear(rgb_acc, tid);
+            const float oi = (float)ti, orr = (float)tr;
+            s_oi[tid] = oi; s_or[tid] = orr;
+            if (tid < 27) {
+                const double wgt = a.icp_weight;
+                const double wa = wgt * wgt, wb = wgt;
+                const bool is_b = (tid == 6) | (tid == 12) | (tid == 17) | (tid == 21) | (tid == 24) | (tid == 26);
+                s_sys[tid] = (double)orr + (is_b ? wb : wa) * (double)oi;
+            }
+        }
+        if (tid == 64) {
+            s_res[0] = __hip_atomic_load(&gres[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_res[1] = __hip_atomic_load(&gres[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gres[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gres[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (last_it && a.final_level && tid >= 64 && tid < 128) {   // diagnostics of the run's last iteration
+            const int t = tid - 64;
+            if (t == 0) {
+                const int rgbSize = s_res[0], sigma = s_res[1];
+                st->rgb_count = rgbSize; st->rgb_sigma = sigma;
+                st->lastRGBError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
+                st->lastRGBCount = (float)rgbSize;
+                st->lastICPError = sqrtf(s_oi[27]) / s_oi[28]; st->lastICPCount = s_oi[28];
+            }
+            if (t < 29) { st->icp29[t] = s_oi[t]; st->rgb29[t] = s_or[t]; }
+            if (t < 36) {
+                const int i = t / 6, j = t - 6 * i, lo = i < j ? i : j, hi = i < j ? j : i;
+                st->lastA[t] = s_sys[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)];
+            }
+            if (t < 6) st->lastb[t] = s_sys[t * 7 - (t * (t - 1)) / 2 + (6 - t)];
+        }
+        if (tid == 0) {
+            double RRt[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) RRt[k] = s_RRt[k];
+            float Rc[9], tcn[3], krkn[9], ktn[3];
+            if (last_it) gn_serial_lane(s_sys, 1, RRt, Rp, tpv, a.nfx, a.nfy, a.ncx, a.ncy, a.ki_next, Rc, tcn, krkn, ktn);
+            else gn_serial_lane(s_sys, 1, RRt, Rp, tpv, a.fx, a.fy, a.cx, a.cy, a.ki_same, Rc, tcn, krkn, ktn);
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_RRt[k] = RRt[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { s_pose[k] = Rc[k]; s_pose[12 + k] = krkn[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_pose[9 + k] = tcn[k]; s_pose[21 + k] = ktn[k]; }
+            if (last_it) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) st->resultRt[k] = RRt[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krkn[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { st->tcurr[k] = tcn[k]; st->kt[k] = ktn[k]; }
+                if (a.final_level) track_end_dev(st, 1, 1, a.weight_mult, a.commit, a.lctr);
+                st->gn_done_seq = a.level + 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Grid barrier.  Memory-side atomics on ONE line serialise at ~8 ns each, and so do the polling loads: 400 blocks arriving at and polling one word
 // cost ~12 us per meeting.  Here a block arrives (fire and forget) at one of GN_BAR_SUB counters, each on a line of its own, and wave 0 polls
 // all of them with one vector load (lane s reads counter s): a meeting is one atomic + one or two polling round trips.
 #define GN_BAR_SUB 32
-__device__ __forceinline__ void gn_grid_barrier(unsigned int* bar, int k, int nb, int* timeout)
+// Returns false when the meeting did not happen: this block gave up after `limit` polls (it then raises the run's abort word, which every other block polls with
+// the same vector load -- lane GN_BAR_SUB -- so that they leave at once instead of spinning out their own limits), or another block had already given up.  The caller
+// leaves the level; the one-workgroup kernel behind this launch re-runs it (k_gn_level_solo).  Co-residency of the grid is what a meeting needs: the launch is sized from the occupancy query with an
+// eighth to spare, but other streams and other handles share the GPU, so a grid that does not fit must cost time, never the pose.
+__device__ __forceinline__ bool gn_grid_barrier(unsigned int* bar, int k, int nb, DevState* st, int seq)
 {
+    __shared__ int s_bar_ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's accumulator atomics have been performed at the memory side
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_fetch_add(&bar[((int)blockIdx.x % GN_BAR_SUB) * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool absent = st->gn_fault != 0 && st->gn_fault == seq && blockIdx.x == 1;   // (test hook: a block that never arrives)
+        if (lane == 0 && !absent) __hip_atomic_fetch_add(&bar[((int)blockIdx.x % GN_BAR_SUB) * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // sub-counter s is fed by the blocks with bid % GN_BAR_SUB == s
         const unsigned int mine = lane < GN_BAR_SUB ? (unsigned int)((nb - lane + GN_BAR_SUB - 1) / GN_BAR_SUB) : 0u;
         const unsigned int target = (unsigned int)k * mine;
+        const int limit = st->gn_spin_limit > 0 ? st->gn_spin_limit : (1 << 21);
+        const unsigned int* const word = lane < GN_BAR_SUB ? &bar[lane * 16] : (const unsigned int*)&st->gn_abort;
         int spin = 0;
+        bool ok = true;
         for (;;) {
-            const unsigned int v = lane < GN_BAR_SUB ? __hip_atomic_load(&bar[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (__all(v >= target)) break;
+            const unsigned int v = lane <= GN_BAR_SUB ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__any(lane == GN_BAR_SUB && v != 0u)) { ok = false; break; }                 // somebody gave up
+            if (__all(lane >= GN_BAR_SUB || v >= target)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spin > (1 << 21)) { if (lane == 0) *timeout = 1; break; }
+            if (++spin > limit) {
+                if (lane == 0) __hip_atomic_store(&st->gn_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
         }
+        if (lane == 0) s_bar_ok = ok ? 1 : 0;
     }
     __syncthreads();
+    return s_bar_ok != 0;
 }
 
 template <int PX>
@@ -1968,6 +2185,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
     }
     __syncthreads();
     unsigned int* bar = &st->gn_bar[a.level * GN_BAR_SUB * 16];
+    bool failed = false;
     for (int it = 0; it < a.iters; it++) {
         const int par = (a.acc_base + it) & 1;
         double* const icp_acc = st->gn_acc2 + (size_t)(par * 2 + 0) * IFX_ACC_REPL * IFX_ACC_STRIDE;
@@ -2051,7 +2269,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
                 if (s2) atomicAdd(&gres[tid], s2);
             }
         }
-        gn_grid_barrier(bar, 2 * it + 1, nb, &st->gn_timeout);
+        if (!gn_grid_barrier(bar, 2 * it + 1, nb, st, a.acc_base * 2 + 2 * it + 1)) { failed = true; break; }
         if (bid == 0) {   // the other parity's buffers were last read in the solve of the previous iteration: every block is past it now
             double* const other = st->gn_acc2 + (size_t)((1 - par) * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE;
             __hip_atomic_store(&other[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 x REPL x STRIDE = 256 doubles
@@ -2088,7 +2306,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
             }
             block_sum_exact<29>(acc, rgb_acc, bid % IFX_ACC_REPL);
         }
-        gn_grid_barrier(bar, 2 * it + 2, nb, &st->gn_timeout);
+        if (!gn_grid_barrier(bar, 2 * it + 2, nb, st, a.acc_base * 2 + 2 * it + 2)) { failed = true; break; }
         // ---- every block: totals -> combined system -> solve -> the next iteration's pose in LDS
         const bool last_it = it == a.iters - 1;
         if (tid < 29) {
@@ -2142,10 +2360,15 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
 #pragma unroll
                 for (int k = 0; k < 3; k++) { st->tcurr[k] = tcn[k]; st->kt[k] = ktn[k]; }
                 if (a.final_level) track_end_dev(st, RGB, 1, a.weight_mult, a.commit, a.lctr);
+                st->gn_done_seq = a.level + 1;
             }
         }
         __syncthreads();
     }
+    // A meeting failed: nothing of this level was published (only block 0 publishes, and only behind the level's last meeting, when it also marks the level done).
+    // Every block leaves; the one-workgroup kernel enqueued behind this launch (k_gn_level_solo) finds the level not done and runs it again from the state the level
+    // started at -- slowly, exactly (the sums are order-independent), and inside the same frame.
+    (void)failed;
 }
 
 
@@ -2374,6 +2597,42 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     const double sobelScale = 1.0 / 8.0;
     bool ended = false;
     int iters_done = 0;
+    // which levels run in the persistent kernel, and whether the two-launch iterations form the run's tail (then their solves move into the next launch's prologue: gn_prologue)
+    int persist_q[IFX_NUM_PYRS], persist_nb[IFX_NUM_PYRS];
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        persist_q[i] = -1; persist_nb[i] = 0;
+        bool lds_lvl = false;
+#ifdef IFX_EXPERIMENTS
+        lds_lvl = h->opt_icp_lds && i == 0 && frame_tracker;
+#endif
+        if (frame_tracker && (h->opt_gn_persist & (1 << i)) && iterations[i] > 0 && !lds_lvl && icp && rgb) {
+            static const int pxs[4] = {1, 2, 3, 4};
+            const int n = p.w[i] * p.h[i];
+            for (int t = 0; t < 4 && persist_q[i] < 0; t++) {   // (fewer, fatter blocks at the finer levels -- 4 pixels per thread -- were tried for cheaper meetings: slower)
+                const int need = cdiv(n, RED_THREADS * pxs[t]);
+                if (need <= h->gn_max_blocks[t] * 7 / 8 && need <= h->opt_gn_persist_blocks) { persist_q[i] = t; persist_nb[i] = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
+            }
+        }
+    }
+    bool pro = h->opt_gn_prologue != 0;
+    int n_tail = 0;
+    {
+        bool seen_two_launch = false;
+        for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
+            if (iterations[i] <= 0) continue;
+            if (persist_q[i] >= 0) { if (seen_two_launch) pro = false; }   // a persistent level BEHIND two-launch iterations reads the pose from the state: round 3's form keeps it there
+            else { seen_two_launch = true; n_tail += iterations[i]; }
+        }
+#ifdef IFX_EXPERIMENTS
+        if (h->opt_icp_lds || h->opt_icp_px) pro = false;
+#endif
+    }
+    int persist_iters = 0;
+    int tail_k = 0;   // position of the next two-launch iteration in the tail
+    char* const stb = (char*)st;
+    auto gnp_acc_of = [&](int par) { return (double*)(stb + offsetof(DevState, gnp_acc)) + (size_t)(par * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE; };
+    auto gnp_res_of = [&](int par) { return (int*)(stb + offsetof(DevState, gnp_res)) + par * 16; };
+    auto gnp_rrt_of = [&](int par) { return (double*)(stb + offsetof(DevState, gnp_RRt)) + par * 16; };
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
         // The coarse levels are on the queue: the host is now ahead of the GPU by ~20 latency-bound launches, and the
         // finest level keeps the GPU mostly idle for another ~0.3 ms -- the place to slip in the next frame's image-only work.
@@ -2404,24 +2663,20 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
         int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
         pa.check_skip = frame_tracker ? 0 : 1;   // (accumulator rows, residual totals, ticket: DevState::gn_acc / gn_res / gn_ticket of `st`)
-        if (frame_tracker && (h->opt_gn_persist & (1 << i)) && iterations[i] > 0 && !lds_tiles && icp && rgb) {   // all iterations of the level in one persistent launch
-            static const int pxs[4] = {1, 2, 3, 4};
-            int q = -1, nbp = 0;
-            for (int t = 0; t < 4 && q < 0; t++) {   // (fewer, fatter blocks at the finer levels -- 4 pixels per thread -- were tried for cheaper meetings: slower)
-                const int need = cdiv(n, RED_THREADS * pxs[t]);
-                if (need <= h->gn_max_blocks[t] * 7 / 8 && need <= h->opt_gn_persist_blocks) { q = t; nbp = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
-            }
-            if (q >= 0) {
+        if (persist_q[i] >= 0) {   // all iterations of the level in one persistent launch
+            const int q = persist_q[i], nbp = persist_nb[i];
+            {
                 LevelArgs la;
                 la.vmap_curr = pa.vmap_curr; la.nmap_curr = pa.nmap_curr; la.vmap_prev = pa.vmap_prev; la.nmap_prev = pa.nmap_prev;
                 la.dIdx = pa.dIdx; la.dIdy = pa.dIdy; la.lastDepth = pa.lastDepth; la.nextDepth = pa.nextDepth; la.lastImage = pa.lastImage; la.nextImage = pa.nextImage;
-                la.cloud = p.cloud[i];
+                la.cloud = p.cloud[i]; la.corres = (Corres8*)p.corres[i];
                 la.fx = fx; la.fy = fy; la.cx = cx; la.cy = cy; la.distThres = pa.distThres; la.angleThres = pa.angleThres; la.minScale = pa.minScale; la.maxDepthDelta = pa.maxDepthDelta;
                 la.sobelScale = (float)sobelScale;
                 la.w = lw; la.h = lh; la.iters = iterations[i]; la.icp = icp; la.rgb = rgb; la.icp_weight = icp_weight;
                 la.nfx = c.fx / ld; la.nfy = c.fy / ld; la.ncx = c.cx / ld; la.ncy = c.cy / ld;
                 la.ki_same = kinv_of(fx, fy, cx, cy); la.ki_next = kinv_of(la.nfx, la.nfy, la.ncx, la.ncy);
-                la.acc_base = iters_done; la.level = i;
+                la.acc_base = persist_iters; la.level = i;   // (parity of the persistent kernel's double buffers: continuous over ITS launches, whatever two-launch levels lie between them)
+                persist_iters += iterations[i];
                 bool later = false;
                 for (int q2 = i - 1; q2 >= 0; q2--) later = later || iterations[q2] > 0;
                 la.final_level = later ? 0 : 1; la.commit = commit; la.weight_mult = weight_mult; la.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
@@ -2429,6 +2684,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 else if (q == 1) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<2>, st, la);
                 else if (q == 2) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<3>, st, la);
                 else LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<4>, st, la);
+                LAUNCH(h, "gn_level_solo", dim3(1), dim3(RED_THREADS), k_gn_level_solo, st, la);   // the safety net: a no-op unless a meeting of the launch above did not happen
                 iters_done += iterations[i];
                 ended = ended || la.final_level;
                 continue;
@@ -2445,11 +2701,25 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
 #ifdef IFX_EXPERIMENTS
             if (px_form && px_two && n > 150000) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS * 2)), dim3(RED_THREADS), (k_icp_residual_px<2, false>), st, cdiv(n, RED_THREADS * 2), pa.w, pa.h, gacc, gres, pa);
             else if (px_form) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS)), dim3(RED_THREADS), (k_icp_residual_px<1, false>), st, cdiv(n, RED_THREADS), pa.w, pa.h, gacc, gres, pa);
-            else if (pa.lds_tiles) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            else if (pa.lds_tiles) { GnPro g0; memset(&g0, 0, sizeof(g0)); LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa, g0, (double*)nullptr); }   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
             else
 #endif
-            if (frame_tracker) LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
-            else LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<false, true>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa);
+            {
+                // gn_prologue: iteration tail_k sums into parity tail_k & 1; from the tail's second iteration on, every block first solves the iteration before
+                GnPro gp;
+                gp.k = tail_k; gp.icp = icp; gp.rgb = rgb; gp.icp_weight = icp_weight; gp.nfx = fx; gp.nfy = fy; gp.ncx = cx; gp.ncy = cy; gp.ki = kinv_of(fx, fy, cx, cy);
+                double* const ga = pro ? gnp_acc_of(tail_k & 1) : gacc;
+                int* const gr = pro ? gnp_res_of(tail_k & 1) : gres;
+                double* const rrt_store = gnp_rrt_of((tail_k + 1) & 1);   // the increment after iteration tail_k - 1
+                const dim3 grid(pa.nb_icp + pa.nb_res);
+                if (pro && tail_k > 0) {
+                    if (frame_tracker) LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, false, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    else LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, true, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                } else {
+                    if (frame_tracker) LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, false, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    else LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, true, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                }
+            }
             StepArgs sa2;
             sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
             sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb; sa2.nb_icp = nbi; sa2.nb_res = nbr;
@@ -2461,6 +2731,8 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 sa2.final_iter = (j == iterations[i] - 1 && !later) ? 1 : 0;
             }
             sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
+            sa2.pro = pro ? (tail_k == n_tail - 1 ? 2 : 1) : 0; sa2.pro_k = tail_k;   // (the tail's last iteration is the run's last: final_iter)
+            tail_k++;
             ended = ended || sa2.end_run;
             if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
             else LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);

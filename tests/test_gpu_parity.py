@@ -634,9 +634,9 @@ def _tracker_variants_equal(ifx, variants):
             g.set_option(k, v)
         out.append((np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(8)]), g.download()))
         g.close()
-    for other in out[1:]:
-        assert np.array_equal(out[0][0], other[0])
-        assert all(np.array_equal(out[0][1][k], other[1][k]) for k in MAP_KEYS)
+    for v, other in zip(variants[1:], out[1:]):
+        assert np.array_equal(out[0][0], other[0]), (variants[0], v)
+        assert all(np.array_equal(out[0][1][k], other[1][k]) for k in MAP_KEYS), (variants[0], v)
 
 
 def test_persistent_level_kernel_is_bit_identical(ifx):
@@ -645,7 +645,45 @@ def test_persistent_level_kernel_is_bit_identical(ifx):
     level only, where the meetings of 75 blocks cost less than launch boundaries).  A barrier that timed out would show up as a different
     pose, and as an error of ifx_sync."""
     big = 1 << 20   # (by default a level uses the kernel only while its grid has at most 128 blocks: lifted here so that every level really runs it)
-    _tracker_variants_equal(ifx, [dict(gn_persist=0), dict(gn_persist=7, gn_persist_blocks=big), dict(gn_persist=4), dict(gn_persist=6, gn_persist_blocks=big)])
+    _tracker_variants_equal(ifx, [dict(gn_persist=0), dict(gn_persist=7, gn_persist_blocks=big), dict(gn_persist=4), dict(gn_persist=6, gn_persist_blocks=big),
+                                  dict(gn_persist=5, gn_persist_blocks=big)])   # (5: a persistent level BEHIND two-launch iterations -- those keep round 3's last-block form)
+
+
+def test_persistent_level_kernel_fallback_equals_two_launch_form(ifx):
+    """A meeting of the persistent level kernel that does not happen must cost time, never the pose: with the test hooks `gn_fault` (block 1 never arrives at
+    meeting number n) and `gn_spin_limit` (polls before a meeting gives up) every block leaves the level unpublished and the one-workgroup kernel enqueued behind
+    the launch (k_gn_level_solo) re-runs it inside the same frame -- trajectory and map equal the two-launch form's bit for bit, and the fallback is counted
+    (ifx_tracker_fallbacks), not raised as an error."""
+    from instancefusion_amd import synth
+
+    W, H = 640, 480
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(6, W, H, noise=True, loop_len=90, **K)
+    out = []
+    for opts in (dict(gn_persist=0), dict(gn_persist=4, gn_spin_limit=3000, gn_fault=3), dict(gn_persist=6, gn_persist_blocks=1 << 20, gn_spin_limit=3000, gn_fault=10)):
+        g = ifx.ElasticFusion(w=W, h=H, max_surfels=1_000_000, **K)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(6)])
+        fb = g.tracker_fallbacks()
+        out.append((poses, g.download(), fb))
+        g.close()
+    assert out[0][2] == 0
+    assert out[1][2] == 5, out[1][2]          # the coarsest level of every tracked frame (meeting 3 is its second iteration's first)
+    assert out[2][2] >= 5, out[2][2]          # meeting 10 lies in the next level: that one falls back (and the run's abort word sends nothing else astray)
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0])
+        assert all(np.array_equal(out[0][1][k], other[1][k]) for k in MAP_KEYS)
+
+
+def test_gn_prologue_solve_is_bit_identical(ifx):
+    """The 6x6 solve of a two-launch Gauss-Newton iteration in the prologue of EVERY block of the next iteration's first launch (option gn_prologue, default since
+    round 4: no last-block ticket, no pose round trip through memory between the two launches; sums / residual totals / running increment double-buffered by iteration
+    parity) against round 3's last-block form (gn_prologue = 0): the same totals give the same bits -- trajectories and maps identical, with and without the
+    persistent kernel in front of the two-launch tail, for the tracker configurations that change the tail's length or the system (no pyramid, fast odometry,
+    ICP only, photometric only with its pivoted solve)."""
+    for extra in (dict(), dict(gn_persist=4), dict(pyramid=0), dict(fast_odom=1), dict(icp_weight_x1000=100000), dict(icp_weight_x1000=0)):
+        _tracker_variants_equal(ifx, [dict(gn_prologue=0, **extra), dict(gn_prologue=1, **extra)])
 
 
 def test_lost_tracker_experiments_are_bit_identical(ifx):

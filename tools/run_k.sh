@@ -1,12 +1,11 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q > gpurun_out/r03_final_tests.log 2>&1; grep -n "passed\|failed\|Error" gpurun_out/r03_final_tests.log | head -5
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > gpurun_out/r03_final_bench.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 > gpurun_out/r03_final_bench_driver.json 2>/dev/null
+python -m pytest tests -m gpu -q -k "gn_prologue or persistent_level or tracker_and_map_configurations or end_to_end or loop_closure_detection or lookahead or fern_hooks or eviction" > gpurun_out/r04_d_tests.log 2>&1; tail -4 gpurun_out/r04_d_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04_d_bench_driver.json 2>/dev/null
+python bench.py --no-cpu-baseline --extras-frames 0 > gpurun_out/r04_d_bench.json 2>/dev/null
 python - <<PY
 import json
-for f in ("r03_final_bench.json","r03_final_bench_driver.json"):
+for f in ("r04_d_bench.json","r04_d_bench_driver.json"):
     d=json.loads(open("gpurun_out/"+f).read().strip().splitlines()[-1]); r=d["roofline"]
-    print(f, d["value"], d["ms_per_frame_gpu"], d["instance"]["ms_per_call"], r["kernel"], r["frac"], r.get("traffic"), d["value_host_entry"]["value"], d["value_close_loops"]["value"], d["cpu_baseline"]["value"])
+    print(f, d["value"], d["ms_per_frame_gpu"], d["instance"]["ms_per_call"], r["kernel"], r["frac"], {k:v["avg_ms"] for k,v in r["kernels"].items() if k in ("icp_residual","rgb_step_solve","gn_level")})
 PY
-python tools/replay_bench.py --frames 480 > gpurun_out/r03_final_replay_bench.txt 2>&1; grep -o "^[^>]*-> 480 frames in [0-9.]* s ([0-9.]* frames/s" gpurun_out/r03_final_replay_bench.txt

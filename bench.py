@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--fern-hook", action="store_true", help="with --close-loops: also the two read-backs per frame of the fern data base (findFrame inside the frame "
                     "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the `value_sharded` leg (the same stream into ONE map spatially sharded over the ranks of this run, reported beside the replicas' `value`)")
     ap.add_argument("--extras-frames", type=int, default=60, help="frames of each extra leg at N = 1 (host entry point, closeLoops = true); 0 skips them")
     args = ap.parse_args()
 
@@ -193,7 +194,9 @@ def main():
         ef.upload(m)
         ef.set_pose(st["poses"][0], tick0)
         ef.combined_predict(st["poses"][0], tick0, tick0)
-    del m
+    want_sharded_leg = (not one_map) and (world > 1 or args.extras_frames > 0) and not args.close_loops and not args.no_sharded_leg
+    if not want_sharded_leg:
+        del m
 
     if args.close_loops:
         ef.set_loop_closure(True, 35000, 5e-5, 1e-5)
@@ -254,6 +257,8 @@ def main():
     def step(k, hint=True):
         i = k % L
         if sh is not None:
+            if osh is not None and hint and not args.no_prefetch:   # the sharded path has the one-frame look-ahead too (frame side on the side stream, tracker parked behind the frame)
+                ef.hint_next_frame_device(d_rgb[(k + 1) % L].data_ptr(), d_dep[(k + 1) % L].data_ptr())
             sh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             instance_step(i)
             return
@@ -456,6 +461,85 @@ def main():
         ef.sync()
         ef.set_loop_closure(False, 35000, 5e-5, 1e-5)
 
+    # ---- the north star's partitioning beside the replicas: the SAME stream (rank 0's) into ONE map spatially sharded over the ranks of this run -- every rank stores
+    # the surfels it owns, the exchanges of a frame are RCCL collectives enqueued by libifx.so.  At N = 1 a world of one: the fixed cost of the mode.
+    sharded_leg = None
+    if want_sharded_leg:
+        from instancefusion_amd import sharded as ifsh
+
+        ns = min(args.steps, max(args.extras_frames, 40)) if world == 1 else min(args.steps, 100)
+        if world > 1:   # every rank is fed rank 0's stream and map
+            st2 = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED, **K) if rank != 0 else st
+            m2 = synth.make_map(args.surfels, st2["scene"], st2["poses_world"][0], tick0, seed=synth.SEED + 7, order=args.map_order) if rank != 0 else m
+            d_rgb2 = torch.from_numpy(st2["rgb"]).cuda(dev) if rank != 0 else d_rgb
+            d_dep2 = torch.from_numpy(st2["depth"].view(np.int16)).cuda(dev) if rank != 0 else d_dep
+            masks2 = [synth.canned_masks(st2["obj"][i], st2["scene"]) for i in range(L)] if rank != 0 else masks
+        else:
+            st2, m2, d_rgb2, d_dep2, masks2 = st, m, d_rgb, d_dep, masks
+        ef.sync()
+        ef2 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap // world + P + 500_000, device=dev, **K, n_ranks=(world if world > 1 else -1), rank=rank)
+        inst2 = ifx.InstanceFusion(ef2)
+        for kv in args.opt:
+            k_, v_ = kv.split("=")
+            ef2.set_option(k_, int(v_))
+        osh2 = ifsh.OwnerShardedElasticFusion(ef2, dist)
+        osh2.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
+        ef2.upload(m2)
+        ef2.set_pose(st2["poses"][0], tick0)
+        osh2.predict()
+        del m2, m
+        seg2 = dict(frame=0, calls=0)
+
+        def step2(kk):
+            i = kk % L
+            if not args.no_prefetch:
+                ef2.hint_next_frame_device(d_rgb2[(kk + 1) % L].data_ptr(), d_dep2[(kk + 1) % L].data_ptr())
+            osh2.process_frame_device(d_rgb2[i].data_ptr(), d_dep2[i].data_ptr())
+            seg2["frame"] += 1
+            if not args.no_instance and inst2.whetherDoSegmentation(100 + seg2["frame"]):
+                mk, cl = masks2[i]
+                if mk.shape[0]:
+                    seg2["calls"] += 1
+                    osh2.process_segmentation(st2["rgb"][i], st2["depth"][i], mk, cl, seg2["frame"], superpixels=not args.no_superpixels)
+
+        def barrier2():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ef2.sync()
+
+        k2 = 1
+        for _ in range(12):
+            step2(k2); k2 += 1
+        barrier2()
+        osh2.exchange_stats(reset=True)
+        seg2["calls"] = 0
+        t0 = time.perf_counter()
+        for _ in range(ns):
+            step2(k2); k2 += 1
+        barrier2()
+        dt2 = time.perf_counter() - t0
+        xs2 = osh2.exchange_stats()
+        dt2 = ifd.max_over_ranks(dt2, dist, device=f"cuda:{dev}")
+        calls2 = seg2["calls"]
+        ef2.stage_ms(reset=True)
+        ef2.set_option("stage_timing", 1)
+        n_split2 = 20
+        for _ in range(n_split2):
+            step2(k2); k2 += 1
+        ef2.sync()
+        stage2 = ef2.stage_ms(reset=True)
+        ef2.set_option("stage_timing", 0)
+        sharded_leg = dict(value=round(ns / dt2, 2), unit="frames/s", frames=ns, scaling="strong", n_ranks=world, rccl_ranks=osh2.comm_ranks(), segmentation_calls=calls2,
+                           ms_per_frame_gpu={k_: round(v_ / n_split2, 4) for k_, v_ in stage2.items() if k_ != "instance"},
+                           exchange={"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xs2["collectives"] / ns, 2),
+                                     "bytes_per_frame": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1)},
+                           surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
+                           what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
+                                "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")
+        barrier2()
+        ef2.close()
+
     # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload, one core and all cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks of a multi-GPU run would wait for it)
@@ -511,9 +595,10 @@ def main():
                          "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,
                          "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call"},
             **extras,
+            **({"value_sharded": sharded_leg} if sharded_leg else {}),
             "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": ef.view_list_stats(),
             **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
-                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1)}} if xstats else {}),
+                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": osh.comm_ranks()}} if xstats else {}),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu,
         }

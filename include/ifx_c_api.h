@@ -146,7 +146,10 @@ int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint1
  *   ifx_owner_set_frame_pose      the next frame takes this pose instead of tracking (the in_pose of the unsharded entry points)
  *   ifx_owner_set_tracking_rank   only this rank tracks the frames to come -- stream k on GPU k, no tracker collective; the others run the frame side,
  *                                 and the tracked pose block reaches them by a broadcast (phase 310 + ifx_owner_exchange(h, 310): op 4 | root << 8), which
- *                                 ifx_owner_process_frame_device issues itself.  -1: every rank tracks (replicated).
+ *                                 ifx_owner_process_frame_device issues itself.  -1: every rank tracks (replicated).  While a tracking rank is set the prediction
+ *                                 rendered at the end of the frame has one consumer, that rank's tracker: exchange 5 lists the prediction block with op 5 | root << 8
+ *                                 (int32 SUM to the root only: ncclReduce) and the 16-byte vote-mass tail with op 1 (to everybody); on the other ranks the
+ *                                 prediction / fill-in images of that camera are partial and must not be read.
  * tests/test_gpu_parity.py::test_config5_two_streams_one_sharded_map: K = 2 cameras, G = 2 ranks, bit-identical to one GPU. */
 int ifx_camera_count(ifx_t* h, int n_cameras);
 int ifx_camera_select(ifx_t* h, int cam);
@@ -161,6 +164,9 @@ int ifx_owner_predict(ifx_t* h);
 int ifx_owner_process_segmentation(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks, const int32_t* class_ids, int nm, int frame, int flags);
 int ifx_owner_knn_vote_colour(ifx_t* h);
 int ifx_owner_exchange_stats(ifx_t* h, int64_t* out2, int reset);
+/* ranks of the communicator the handle's collectives run on, as RCCL itself counts them (ncclCommCount of the communicator created by ifx_owner_init_comm or adopted
+ * by ifx_owner_set_comm); 0: none yet.  What a benchmark line quotes as the number of GPUs its exchanges really crossed (no counterpart in the reference: one GPU). */
+int ifx_owner_comm_ranks(ifx_t* h);
 int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* bytes, int32_t* ops, int max_n);
 /* ElasticFusion::predict on the sharded map outside a frame (after ifx_map_upload / ifx_set_pose): step 0, exchange as after phase 4,
  * step 1, exchange as after phase 5, step 2. */

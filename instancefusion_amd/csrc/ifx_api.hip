@@ -188,6 +188,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     ifx_comm_free(h);
     camera_free(h);
+    if (h->own_slot_img) hipFree(h->own_slot_img);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
@@ -617,7 +618,7 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
     if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "ifx_camera_select: a frame is announced ahead"; return IFX_E_STATE; }
     ifx_drop_tracked(h);
     if (h->lc_pending && h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
-    if (!h->own) { ifx_vlist_reap(h); hs_invalidate_view(h); }   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
+    ifx_vlist_reap(h); hs_invalidate_view(h);   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
     const size_t P = (size_t)h->P;
     FrameSlot& prev = h->slot[(h->tick & 1) ^ 1];   // the slot of the frame just processed = the "previous image" of the next one
     auto move = [&](CamCtx& c, bool save) -> int {
@@ -758,7 +759,7 @@ static int owner_process_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth
     for (int phase = 0; phase < 8; phase++) {
         int r = owner_frame_phase(h, phase, rgb, depth, src_kind);
         if (r) return r;
-        if (phase < 6) { r = ifx_comm_exchange(h, phase); if (r) return r; }
+        if (phase < 6) { StageTimer t(h, 1); r = ifx_comm_exchange(h, phase); if (r) return r; }   // (the exchanges are billed to the map stage: ifx_stage_ms)
     }
     return IFX_OK;
 }
@@ -812,21 +813,35 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
     const bool starts_frame = phase == 310 || ((phase == 300 || phase == 0) && h->own_tracked_tick != h->tick);
     if (starts_frame) {
         if (!d_rgb || !d_depth) return IFX_E_INVALID;
+        // Bounded run-ahead, as on the unsharded path (enqueue_frame): the previous frame's RESULT before this frame goes onto the queues
+        if (h->opt_pace && h->ev_result && h->tick > 1) HIPCHK(h, hipEventSynchronize(h->ev_result));
+        const bool tracks = h->own_track_rank < 0 || h->own_track_rank == h->cfg.rank;
+        // one-frame look-ahead (ifx_hint_next_frame_device before the previous frame): the frame side of this frame ran on the side stream under the previous frame's
+        // phases, and its tracker -- which reads only its slot, the exchanged prediction and the pose -- was enqueued right behind that frame, its result parked
+        const bool prepared = f.for_tick == h->tick && f.src_rgb == d_rgb && f.src_depth == d_depth && src_kind == 0;
+        const bool tracked = prepared && h->tracked_ahead == h->tick && !h->own_frame_pose_set && tracks && !first;
         ifx_drop_tracked(h);
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
-        const int two = h->opt_two_streams;
-        h->opt_two_streams = 0;
-        int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, src_kind);
-        h->opt_two_streams = two;
-        if (r) return r;
+        if (!prepared) {
+            const int two = h->opt_two_streams;
+            h->opt_two_streams = 0;
+            int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, src_kind);
+            h->opt_two_streams = two;
+            if (r) return r;
+        } else HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
         f.for_tick = -1;
         ifx_bind_slot(h, s);
-        const bool tracks = h->own_track_rank < 0 || h->own_track_rank == h->cfg.rank;
+        h->own_need_decide = 0;
         if (!first && h->own_frame_pose_set) {   // an external pose replaces tracking (EF/ElasticFusion.cpp:357-360), on every rank alike
             float* slot = h->d_scratch + 2 * 16;
             HIPCHK(h, hipMemcpyAsync(slot, h->own_frame_pose, 64, hipMemcpyHostToDevice, h->stream));
             ifx_tracker_external_pose(h, slot, 1.0f);
-        } else if (!first && tracks) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
+        } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
+            StageTimer t(h, 0);
+            if (tracked) ifx_tracker_commit(h);
+            else { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
+        } else if (!first) h->own_need_decide = 1;   // the pose arrives with exchange 310: the view-list decision follows it (phase 0)
+        { int r = ifx_enqueue_hinted_frame_side(h); if (r) return r; }   // (a tracker enqueue consumed the hint already: no-op)
         h->own_frame_pose_set = 0;
         h->own_tracked_tick = h->tick;
         if (phase == 310) return IFX_OK;   // the pose block travels from the tracking rank next (exchange 310)
@@ -841,7 +856,11 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         if (lc_due) { int r = ifx_tracker_loop_closure(h); if (r) return r; h->lc_event_valid = 0; }   // replicated on the exchanged act_* / old_* images: the same verdict on every rank
         else LAUNCH(h, "lc_idle", dim3(1), dim3(64), k_lc_idle, h->d_state, h->h_lc);
     }
-    int r = ifx_map_owner_phase(h, phase, first);
+    int r;
+    {
+        StageTimer t(h, 1);
+        r = ifx_map_owner_phase(h, phase, first);
+    }
     if (r) return r;
     if (phase == 7) {   // after the vote mass of phase 6 was summed across the ranks: the frame result every rank reads its whetherDoSegmentation decision from
         const int slot = h->n_traj % h->max_traj;
@@ -851,6 +870,21 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         h->seg_counts_valid = first ? 0 : 1;
         h->n_traj++;
         h->tick++;
+        // the announced next frame: its tracker reads only its slot, the prediction just exchanged and the pose -- enqueued now, parked (DevState::spec_*), so that the
+        // GPU has work while the host decides about segmentation (enqueue_frame does the same on the unsharded path).  Replicated tracking only: with camera contexts /
+        // a tracking rank the frames of a set interleave cameras (ifx_owner_track_camera_ahead is that case's look-ahead)
+        FrameSlot& nf = h->slot[h->tick & 1];
+        if (h->opt_track_ahead && h->opt_two_streams && nf.for_tick == h->tick && h->tick > 1 && h->own_track_rank < 0 && !h->lc_enable && h->cams.empty()) {
+            ifx_bind_slot(h, h->tick & 1);
+            HIPCHK(h, hipStreamWaitEvent(h->stream, nf.ready, 0));
+            {
+                StageTimer t(h, 0);
+                ifx_tracker_model_side(h, 1);
+                ifx_tracker_run_frame(h, 0);
+            }
+            ifx_bind_slot(h, s);
+            h->tracked_ahead = h->tick;
+        }
     }
     return IFX_OK;
 }
@@ -878,7 +912,15 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 2: if (!first) add(h->key_index, P * 8, 0); break;
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
-    case 5: add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1); break;                                       // [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
+    case 5:   // [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
+        if (h->own_track_rank >= 0 && h->own_tracked_tick == h->tick && h->own_g > 1) {
+            // K streams, camera k tracked by rank k only: the prediction rendered at the end of camera k's frame has ONE consumer, rank k's tracker -- a reduction to that
+            // rank (op 5 | root << 8: ncclReduce, (G - 1) / G of the block per link instead of the all-reduce's 2 (G - 1) / G); the 16-byte tail -- the vote mass every
+            // rank's whetherDoSegmentation decision needs -- still goes to everybody.  On the other ranks the block holds their own partial sums and is never read.
+            add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16 - 16, 5 | (h->own_track_rank << 8));
+            add(h->pred_tail, 16, 1);
+        } else add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1);
+        break;
     case 6: break;
     case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank
     case 300: if (owner_lc_due(h)) add(h->key_splat, P * 16, 0); break;                       // the detection's two renders: [key_splat (ACTIVE) | key_ids (INACTIVE)]

@@ -37,6 +37,7 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -52,7 +53,7 @@ bool rccl_load(std::string& err)
     if (!lib) { g_rccl.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); err = g_rccl.err; return false; }
 #define SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name); if (!g_rccl.field) { g_rccl.err = std::string("RCCL symbol missing: ") + name; err = g_rccl.err; dlclose(lib); return false; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
-    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Reduce, "ncclReduce") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     g_rccl.lib = lib;
     return true;
@@ -151,9 +152,15 @@ int ifx_comm_exchange(ifx* h, int phase)
     const int n = ifx_owner_exchange(h, phase, ptrs, bytes, ops, 8);
     if (n < 0) return n;
     for (int k = 0; k < n && k < 8; k++) {
-        // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX
+        // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX,
+        // 4 | root << 8 broadcast, 5 | root << 8 int32 SUM to the root only
         if ((ops[k] & 0xFF) == 4) {   // broadcast from rank ops >> 8 (the pose block of a frame tracked by one rank)
             NCCLCHK(h, g_rccl.Broadcast(ptrs[k], ptrs[k], (size_t)bytes[k], ncclInt8, ops[k] >> 8, c->comm, h->stream));
+            c->n_coll++; c->bytes += bytes[k];
+            continue;
+        }
+        if ((ops[k] & 0xFF) == 5) {   // int32 SUM reduced to rank ops >> 8 only (the prediction of a camera that one rank tracks)
+            NCCLCHK(h, g_rccl.Reduce(ptrs[k], ptrs[k], (size_t)bytes[k] / 4, ncclInt32, ncclSum, ops[k] >> 8, c->comm, h->stream));
             c->n_coll++; c->bytes += bytes[k];
             continue;
         }
@@ -165,6 +172,17 @@ int ifx_comm_exchange(ifx* h, int phase)
     return IFX_OK;
 }
 int ifx_comm_ready(ifx* h) { Comm* c = comm_of(h); return c && c->comm; }
+
+// ranks of the communicator the handle's collectives run on, as RCCL counts them (ncclCommCount); 0: no communicator yet
+extern "C" int ifx_owner_comm_ranks(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    Comm* c = comm_of(h);
+    if (!c || !c->comm) return 0;
+    int n = 0;
+    NCCLCHK(h, g_rccl.CommCount(c->comm, &n));
+    return n;
+}
 
 extern "C" int ifx_owner_exchange_stats(ifx_t* h, int64_t* out2, int reset)
 {

@@ -219,6 +219,9 @@ struct ifx {
     int cur_slot = 0;
     std::vector<CamCtx> cams;           // camera contexts (ifx_camera_count); empty: the handle is its one camera
     int cur_cam = 0;
+    int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
+    int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
+    int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it
     int own_track_rank = -1;            // sharded map: the one rank that tracks the frames to come (-1: every rank tracks, replicated); the others receive the pose block (exchange 310)
     float own_frame_pose[16]; int own_frame_pose_set = 0;   // sharded map: the next frame takes this pose instead of tracking (ifx_owner_set_frame_pose)
     int own = 0, own_g = 1;             // spatially sharded map (ifx_config::n_ranks > 1, or -1: a world of one): this handle stores the surfels it owns; own_g = number of ranks

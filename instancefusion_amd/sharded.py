@@ -160,6 +160,9 @@ class OwnerShardedElasticFusion:
                     if (op & 0xFF) == 4:   # the pose block of the tracking rank (ifx_owner_set_tracking_rank): a broadcast from rank op >> 8, like ifx_comm_exchange's
                         self.dist.broadcast(self._tensor(ptr, nbytes, 1), src=op >> 8)
                         continue
+                    if (op & 0xFF) == 5:   # int32 SUM to rank op >> 8 only (the prediction of a camera that one rank tracks)
+                        self.dist.reduce(self._tensor(ptr, nbytes, 1), dst=op >> 8, op=self.dist.ReduceOp.SUM)
+                        continue
                     t = self._tensor(ptr, nbytes, op)
                     if op == 0:
                         KeyExchange.reduce_min([t], self.dist)
@@ -199,6 +202,10 @@ class OwnerShardedElasticFusion:
         out = np.zeros(2, np.int64)
         self.ef._chk(self.ef.L.ifx_owner_exchange_stats(self.ef.handle, out.ctypes.data_as(C.c_void_p), int(reset)), "ifx_owner_exchange_stats")
         return dict(collectives=int(out[0]), bytes=int(out[1]))
+
+    def comm_ranks(self):
+        """ranks of the library's communicator as RCCL counts them (ncclCommCount); 0 with transport="torch" """
+        return self.ef._chk(self.ef.L.ifx_owner_comm_ranks(self.ef.handle), "ifx_owner_comm_ranks")
 
     def knn_vote_colour(self):
         """InstanceFusion::flannKnnVoteSurfelMap on the sharded map: all-gather of every rank's slots (20 B each), exact 10-NN of the owned surfels."""
@@ -273,6 +280,12 @@ def _reduce_by_hand(efs, specs):
     for k in range(len(specs[0])):
         op, nbytes = specs[0][k][2], specs[0][k][1]
         ts = [torch.as_tensor(_DevWords(sp[k][0], nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=dev) for sp in specs]
+        if (op & 0xFF) == 5:                       # int32 SUM to rank op >> 8 only: the others keep what they hold (their own partial sums, never read)
+            m = ts[0].clone()
+            for t in ts[1:]:
+                m += t
+            ts[op >> 8].copy_(m)
+            continue
         if (op & 0xFF) == 4:                       # broadcast from rank op >> 8
             m = ts[op >> 8].clone()
         elif op == 0:

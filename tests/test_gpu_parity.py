@@ -943,10 +943,9 @@ def test_config5_two_streams_one_sharded_map(ifx):
             sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             for e in efs:
                 assert np.array_equal(e.getCurrPose(), p1), (s_, c, e.cfgd["rank"])
-            for name in ("pred_vertex", "pred_normal", "pred_image", "fill_vertex"):
-                a = one.image(name)
-                for e in efs:
-                    assert np.array_equal(e.image(name), a), (s_, c, name, e.cfgd["rank"])
+            for name in ("pred_vertex", "pred_normal", "pred_image", "fill_vertex"):   # camera c's prediction is reduced to the rank that tracks it (exchange op 5): checked there
+                assert np.array_equal(efs[c].image(name), one.image(name)), (s_, c, name)
+            assert np.array_equal(efs[1 - c].image("ids_after"), efs[c].image("ids_after"))   # (the id image comes from the exchanged keys: everywhere)
     # both cameras tracked: their trajectories follow the ground truth of their stretch
     assert np.abs(p1 - st["poses"][first[1] + NS - 1]).max() < 0.03
     ref = one.download()
@@ -957,6 +956,102 @@ def test_config5_two_streams_one_sharded_map(ifx):
     for k in MAP_KEYS:
         assert np.array_equal(np.concatenate([p[1][k] for p in parts])[order], ref[k]), k
     assert min(len(p[0]) for p in parts) > 0.3 * len(seq) / G
+    for e in efs:
+        e.close()
+    one.close()
+
+
+@pytest.mark.timeout(3000)
+def test_config5_8_streams_50m_map_sharded_x8(ifx):
+    """BASELINE configuration 5 AT ITS SIZE, emulated in one process: K = 8 concurrent 640x480 streams (eight stretches of the benchmark trajectory through the same
+    scene) into ONE 50M-surfel map that is spatially sharded over G = 8 ranks of ~6.25M surfels -- eight owner handles on this GPU, the collectives done by hand exactly
+    as ifx_comm.hip enqueues them (incl. the camera-indexed reduction: camera k's prediction goes to rank k only).  Camera k is tracked by rank k alone and its pose
+    block broadcast; cameras 1..7 enter with their extrinsic pose.  Against ONE handle holding all 50M surfels that time-slices the eight cameras: every pose on
+    every rank, the prediction after every frame on the rank that consumes it, the whetherDoSegmentation decisions, a segmentation call with superpixels (instance
+    table), and at the end -- merged by creation number, one field at a time -- labels and the whole map, votes included, bit for bit."""
+    import gc
+
+    import torch
+
+    from instancefusion_amd import dist as ifd
+    from instancefusion_amd import sharded, synth
+
+    W, H, K_, G, N, NS = 640, 480, 8, 8, 50_000_000, 2
+    Kc = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    first = [10 * c for c in range(K_)]                        # camera c sees frames first[c] + 1, first[c] + 2, ... of the 90-frame loop
+    st = synth.make_stream(first[-1] + NS + 2, W, H, noise=True, loop_len=90, **Kc)
+    big = synth.make_map(N, st["scene"], st["poses_world"][0], 1000)
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    one = ifx.ElasticFusion(w=W, h=H, max_surfels=N + 2_000_000, **Kc)
+    efs = [ifx.ElasticFusion(w=W, h=H, max_surfels=N // G + 1_500_000, n_ranks=G, rank=r, **Kc) for r in range(G)]
+    inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
+    for e in [one] + efs:
+        e.camera_count(K_)
+    # camera 0's frame 0 initialises the tracker's previous image; then the 50M map replaces the first-frame map on both sides
+    one.enqueue_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr(), 0)
+    sharded.emulate_owner_ranks(efs, d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+    one.upload(big); one.set_pose(st["poses"][0], 1000); one.combined_predict(st["poses"][0], 1000, 1000)
+    own = ifd.owner_of(big["pc"][:, :3], G)
+    for e in efs:
+        e.upload(big); e.set_pose(st["poses"][0], 1000)
+    counts = [e.count for e in efs]
+    assert counts == [int((own == r).sum()) for r in range(G)]
+    assert min(counts) > 0.9 * N / G and max(counts) < 1.1 * N / G      # the spatial hash balances: every rank holds about 6.25M surfels
+    del big, own
+    gc.collect()
+    sharded.emulate_owner_predict(efs)
+    assert all(np.array_equal(e.image("pred_vertex"), one.image("pred_vertex")) for e in efs)   # the prediction of the 50M map itself
+    seg_done = False
+    for s_ in range(NS):
+        for c in range(K_):
+            i = first[c] + 1 + s_
+            ext = st["poses"][i].astype(np.float32) if (c > 0 and s_ == 0) else None   # a camera enters with its extrinsic calibration, then tracks
+            one.camera_select(c)
+            p1 = one.processFrame(st["rgb"][i], st["depth"][i], inPose=ext)
+            for e in efs:
+                e.camera_select(c)
+                e.owner_set_tracking_rank(c)                    # stream c is tracked on rank c only
+                if ext is not None:
+                    e.owner_set_frame_pose(ext)
+            sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+            for e in efs:
+                assert np.array_equal(e.getCurrPose(), p1), (s_, c, e.cfgd["rank"])
+            for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
+                assert np.array_equal(efs[c].image(name), one.image(name)), (s_, c, name)
+            want = inst_one.whetherDoSegmentation(100 + 8 * s_ + c)
+            assert [x.whetherDoSegmentation(100 + 8 * s_ + c) for x in insts] == [want] * G, (s_, c)
+            if s_ == 1 and c == 3 and not seg_done:              # one segmentation call, on camera 3's frame
+                masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+                assert masks.shape[0] > 0
+                inst_one.ProcessSegmentation(st["rgb"][i], st["depth"][i], masks, cls, 100 + 8 * s_ + c, superpixels=True)
+                sharded.emulate_owner_segmentation(efs, st["rgb"][i], st["depth"][i], masks, cls, 100 + 8 * s_ + c, superpixels=True)
+                assert all(np.array_equal(x.getInstanceTable(), inst_one.getInstanceTable()) for x in insts)
+                seg_done = True
+            if s_ == NS - 1:
+                assert np.abs(p1 - st["poses"][i]).max() < 0.05, c       # every camera tracked its stretch
+    assert seg_done
+    # labels, then the map: shards merged by creation number == the unsharded map
+    lab_one = inst_one.labels()
+    labs = np.concatenate([x.labels() for x in insts])
+    seq = np.concatenate([e.seq() for e in efs])
+    order = np.argsort(seq, kind="stable")
+    assert len(np.unique(seq)) == len(seq) == lab_one.shape[0]
+    assert np.array_equal(labs[order], lab_one) and (lab_one >= 0).sum() > 1000
+    inv = np.empty(len(order), np.int64)
+    inv[order] = np.arange(len(order))                                       # row j of the concatenated shards is row inv[j] of the unsharded map
+    bounds = np.cumsum([0] + [e.count for e in efs])
+    del labs, lab_one, seq, order
+    gc.collect()
+    for k in MAP_KEYS:                                                       # one field at a time, one shard at a time: 50M x 48 vote floats are 9.6 GB
+        ref = one.download(fields=(k,))[k]
+        for r, e in enumerate(efs):
+            part = e.download(fields=(k,))[k]
+            assert part.shape[0] == bounds[r + 1] - bounds[r]
+            assert np.array_equal(part, ref[inv[bounds[r]:bounds[r + 1]]]), (k, r)
+            del part
+        del ref
+        gc.collect()
     for e in efs:
         e.close()
     one.close()
@@ -1705,6 +1800,8 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
             if i == 7:
                 osh.exchange_stats(reset=True)
             one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            if i + 1 < NF and i + 1 != 6:   # the one-frame look-ahead of the sharded path: the next frame's image-only work on the side stream, its tracker parked behind this frame
+                ef.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())   # (frame 4's parked tracker is dropped by the upload, others by the segmentation calls' map accesses: both paths run)
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()

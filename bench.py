@@ -311,6 +311,7 @@ def main():
     calls_in_window = seg["calls"]
     inst_ms = ef.stage_ms(reset=True)["instance"]          # the instance stage is always timed (two events per segmentation call)
     traj = ef.trajectory()                                  # poses up to the end of the timed region
+    traj_all = traj
     dt = ifd.max_over_ranks(dt, dist, device=f"cuda:{dev}")
     # ms/frame split of the other stages: measured on the frames that follow, with the per-stage event records switched on
     # (eight marker packets per frame: they would cost ~4 % of the frame rate inside the timed region)
@@ -550,6 +551,8 @@ def main():
         ncores = ol.usable_cores()                           # affinity capped by the cgroup quota (the GPU box shows 256 CPUs and grants 16)
         cpu_map = synth.make_map(n_cpu, st["scene"], st["poses_world"][0], tick0, seed=synth.SEED + 7)
 
+        cpu_poses = {}
+
         def cpu_leg(threads, frames):
             ol.set_threads(threads)
             o = ol.Oracle(w=W, h=H, max_surfels=n_cpu + 1_000_000, **K)
@@ -559,9 +562,11 @@ def main():
             o.combined_predict(st["poses"][0], tick0, tick0)
             o.stage_ms(reset=True)
             tc = time.perf_counter()
+            poses = []
             for kk in range(1, 1 + frames):
-                o.process_frame(st["rgb"][kk % L], st["depth"][kk % L])
+                poses.append(np.array(o.process_frame(st["rgb"][kk % L], st["depth"][kk % L]), np.float32).reshape(4, 4))
             t_frames = time.perf_counter() - tc
+            cpu_poses[threads] = np.stack(poses)
             ms = o.stage_ms(reset=True)
             mk, cl = masks[frames % L]
             t_seg = 0.0
@@ -580,6 +585,15 @@ def main():
                           f"`one_core`: {one['frames']} frames on one core",
                    ms_per_frame=allc["ms_per_frame"], instance_ms_per_call=allc["instance_ms_per_call"], one_core=one)
         del cpu_map
+        # parity inside the benchmark itself: the oracle's poses of frames 1.. (same stream, same map, same start) against the poses the GPU path produced for those
+        # frames in THIS run -- resident frames, look-ahead, lazy compaction, cached view lists, segmentation calls in between (votes do not move poses)
+        if n_cpu == args.surfels and sh is None and not args.close_loops:
+            op = cpu_poses[allc["cores"]]
+            gp = traj_all[1:1 + op.shape[0]]
+            if gp.shape[0] == op.shape[0]:
+                neq = int(sum(not np.array_equal(a_, b_) for a_, b_ in zip(gp, op)))
+                cpu["parity_in_bench"] = dict(poses=int(op.shape[0]), not_bit_equal=neq, max_abs_diff=float(np.abs(gp - op).max()),
+                                              what="the CPU oracle's poses of the first frames of this run against the GPU path's own poses of the same frames (bit equality of all 16 entries)")
 
     if rank == 0:
         fps = (1 if one_map else world) * args.steps / dt

@@ -155,6 +155,12 @@ int ifx_camera_count(ifx_t* h, int n_cameras);
 int ifx_camera_select(ifx_t* h, int cam);
 int ifx_owner_set_frame_pose(ifx_t* h, const float* pose16);
 int ifx_owner_set_tracking_rank(ifx_t* h, int rank);
+/* K streams, camera `cam` tracked by rank `tracking_rank` only: that rank enqueues the tracker of camera cam's NEXT frame now, on the handle's third stream, reading the
+ * camera's PARKED context (prediction, fill-in, last intensity pyramid, pose block: final since the camera's last frame, untouched until its next) -- so rank k tracks camera k
+ * under the other cameras' map phases instead of at the head of camera k's frame.  When that frame arrives with exactly these device pointers the parked pose block is
+ * committed instead of a tracker run (same inputs and arithmetic: same pose).  Call it on every rank once camera cam's context is parked (another camera selected); the
+ * other ranks return at once.  cam = -1: the number of frames whose tracker came from a run ahead so far.  (The reference has one stream and one GPU, IF/main.cpp:75.) */
+int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const uint8_t* d_rgb, const uint16_t* d_depth);
 int ifx_comm_unique_id(uint8_t* out128);
 int ifx_owner_init_comm(ifx_t* h, const uint8_t* unique_id128);
 int ifx_owner_set_comm(ifx_t* h, void* nccl_comm);

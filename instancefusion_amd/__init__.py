@@ -83,6 +83,7 @@ _SIGS = {
     "ifx_camera_select": (C.c_int, [_P, C.c_int]),
     "ifx_owner_set_frame_pose": (C.c_int, [_P, _P]),
     "ifx_owner_set_tracking_rank": (C.c_int, [_P, C.c_int]),
+    "ifx_owner_track_ahead": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "ifx_comm_unique_id": (C.c_int, [_P]),
     "ifx_owner_init_comm": (C.c_int, [_P, _P]),
     "ifx_owner_set_comm": (C.c_int, [_P, _P]),
@@ -281,6 +282,10 @@ class ElasticFusion:
     def owner_set_frame_pose(self, pose):
         p = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
         self._chk(self.L.ifx_owner_set_frame_pose(self.handle, _ptr(p)), "ifx_owner_set_frame_pose")
+
+    def owner_track_ahead(self, cam, tracking_rank, d_rgb_ptr=0, d_depth_ptr=0):
+        """ifx_owner_track_ahead: rank `tracking_rank` runs the tracker of camera cam's NEXT frame now, from the camera's parked context (cam = -1: frames served that way so far)"""
+        return self._chk(self.L.ifx_owner_track_ahead(self.handle, int(cam), int(tracking_rank), C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_track_ahead")
 
     def owner_set_tracking_rank(self, r):
         self._chk(self.L.ifx_owner_set_tracking_rank(self.handle, int(r)), "ifx_owner_set_tracking_rank")

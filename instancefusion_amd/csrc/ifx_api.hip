@@ -192,6 +192,8 @@ extern "C" void ifx_destroy(ifx_t* h)
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
+    if (h->ev_cam_ahead) hipEventDestroy(h->ev_cam_ahead);
+    if (h->ev_cam_parked) hipEventDestroy(h->ev_cam_parked);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
     void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
@@ -200,6 +202,7 @@ extern "C" void ifx_destroy(ifx_t* h)
                     h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_key, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
+    { FrameSlot& f2 = h->slot[2]; void* p2[] = {f2.rgb, f2.depth_raw, f2.depth_filt, f2.dm, f2.dmf}; for (void* p : p2) if (p) hipFree(p); }
     if (h->h_result) hipHostFree(h->h_result);
     if (h->rgb_stage) hipHostFree(h->rgb_stage);
     if (h->depth_stage) hipHostFree(h->depth_stage);
@@ -596,6 +599,8 @@ static void camera_free(ifx* h)
 extern "C" int ifx_camera_count(ifx_t* h, int n_cameras)
 {
     if (!h || n_cameras < 1 || n_cameras > 64) return IFX_E_INVALID;
+    h->cam_ahead_valid = 0;
+    if (h->stream_c) hipStreamSynchronize(h->stream_c);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     camera_free(h);
     h->cur_cam = 0;
@@ -661,6 +666,43 @@ extern "C" int ifx_owner_set_tracking_rank(ifx_t* h, int rank)
     if (!h || rank < -1 || rank >= (h ? h->own_g : 1)) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_set_tracking_rank: the handle was not created for a sharded map"; return IFX_E_STATE; }
     h->own_track_rank = rank;
+    return IFX_OK;
+}
+
+// K streams over a sharded map, camera `cam` tracked by rank `tracking_rank` only: that rank's tracker of camera cam's NEXT frame, enqueued NOW on the handle's third stream,
+// so that it runs under the other cameras' map phases instead of at the head of the frame.  A camera tracks against the prediction rendered at the end of its own last frame,
+// and that prediction -- with the fill-in images, the last frame's intensity pyramid and the pose block -- is parked in the camera's context from the moment another camera is
+// selected until this camera's next frame: the run reads the parked copies (a tracker instance of its own: state, pyramids, frame slot), so nothing the frames in between
+// do can reach it.  When the frame itself arrives (camera cam selected, ifx_owner_process_frame_device / ifx_owner_frame_phase with exactly these device pointers, rank
+// tracking_rank tracking) the parked pose block is committed instead of a tracker run: same inputs, same arithmetic, same pose (tests: test_config5_tracker_runs_ahead).
+// The other ranks: no-op.  cam = -1: returns the number of frames whose tracker was taken from a run ahead so far.
+extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const uint8_t* d_rgb, const uint16_t* d_depth)
+{
+    if (!h) return IFX_E_INVALID;
+    if (cam == -1) return h->cam_ahead_used;
+    if (!h->own) { h->err = "ifx_owner_track_ahead: the handle was not created for a sharded map"; return IFX_E_STATE; }
+    if (cam < 0 || (size_t)cam >= h->cams.size() || !d_rgb || !d_depth || tracking_rank < 0 || tracking_rank >= h->own_g) return IFX_E_INVALID;
+    if (tracking_rank != h->cfg.rank) return IFX_OK;
+    if (cam == h->cur_cam || !h->cams[(size_t)cam].valid) { h->err = "ifx_owner_track_ahead: the camera's context must be parked (select another camera first)"; return IFX_E_STATE; }
+    if (h->lc_enable || !h->stream_c) { h->err = "ifx_owner_track_ahead: not available with the loop-closure detection on / on a one-stream handle"; return IFX_E_STATE; }
+    h->cam_ahead_valid = 0;
+    if (!h->ev_cam_parked) {   // (first use: the instance's buffers and events)
+        hipEventCreateWithFlags(&h->ev_cam_ahead, hipEventDisableTiming);
+        hipEventCreateWithFlags(&h->ev_cam_parked, hipEventDisableTiming);
+    }
+    // behind everything the main stream holds so far: the parking of the camera's context by ifx_camera_select above all
+    HIPCHK(h, hipEventRecord(h->ev_cam_parked, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_c, h->ev_cam_parked, 0));
+    h->cur = h->stream_c;
+    int r;
+    {
+        StageTimer t(h, 0);
+        r = ifx_tracker_camera_ahead(h, cam, d_rgb, d_depth);
+    }
+    hipEventRecord(h->ev_cam_ahead, h->stream_c);
+    h->cur = h->stream;
+    if (r) return r;
+    h->cam_ahead_valid = 1; h->cam_ahead_cam = cam; h->cam_ahead_rgb = d_rgb; h->cam_ahead_depth = d_depth;
     return IFX_OK;
 }
 
@@ -838,8 +880,15 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             ifx_tracker_external_pose(h, slot, 1.0f);
         } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
             StageTimer t(h, 0);
-            if (tracked) ifx_tracker_commit(h);
+            const bool ahead = h->cam_ahead_valid && !h->cams.empty() && h->cam_ahead_cam == h->cur_cam && h->cam_ahead_rgb == (const void*)d_rgb && h->cam_ahead_depth == (const void*)d_depth && src_kind == 0;
+            if (ahead) {   // this camera's tracker ran ahead on the third stream, from the camera's parked context (ifx_owner_track_ahead): its pose block is the frame's
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cam_ahead, 0));
+                HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->d_cam_trk, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
+                h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
+                h->cam_ahead_used++;
+            } else if (tracked) ifx_tracker_commit(h);
             else { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
+            h->cam_ahead_valid = h->cam_ahead_valid && h->cam_ahead_cam != h->cur_cam;   // (a run ahead is for the camera's NEXT frame: whatever this frame was, it is spent)
         } else if (!first) h->own_need_decide = 1;   // the pose arrives with exchange 310: the view-list decision follows it (phase 0)
         { int r = ifx_enqueue_hinted_frame_side(h); if (r) return r; }   // (a tracker enqueue consumed the hint already: no-op)
         h->own_frame_pose_set = 0;
@@ -1199,6 +1248,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
     ifx_drop_tracked(h);
+    h->cam_ahead_valid = 0;
     h->seg_counts_valid = 0;
     h->map_external = 1;
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
@@ -1234,7 +1284,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     DevState hs;
     HIPCHK(h, hipMemcpy(&hs, h->d_state, sizeof(hs), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(h->seq, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0; hs.vl_valid = 0; hs.next_seq = (unsigned int)n_all;
+    hs.count = n; hs.n_dead = 0; hs.n_new = 0; hs.overflow = 0; hs.vl_valid = 0; hs.next_seq = (unsigned int)n_all; hs.first_live = 0;
     h->view_dirty = 0;
     {
         float rmax = 0.f;
@@ -1253,6 +1303,7 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 {
     if (!h || !pose16) return IFX_E_INVALID;
     ifx_drop_tracked(h);
+    h->cam_ahead_valid = 0;
     DevState hs;
     int r = read_state(h, &hs);
     if (r) return r;

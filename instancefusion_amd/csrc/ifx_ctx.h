@@ -49,6 +49,7 @@ struct DevState {
     int seg_acc[2];              // whetherDoSegmentation sums of the frame being finished (k_raster_finish -> k_frame_result)
     int fold_total;              // != 0: this frame's k_splat_resolve accumulated fold_acc itself (= the number of dense-test samples); k_frame_result folds and clears
     int fold_acc[16][4];         // partial sums by blockIdx.x & 15: vote mass, empty lattice pixels, lit dense-test samples, -
+    int first_live;              // lowest live slot: the reference's "surfel 0" (drawn as id 0 = "no surfel" in every id-carrying image; ifx_map.hip key_id)
     unsigned int append_ticket;  // last-block ticket of k_append_scan
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
@@ -215,10 +216,19 @@ struct ifx {
     hipEvent_t ev_lc_ready = nullptr, ev_lc_done = nullptr;
     int lc_pending = 0, lc_deferred = 0;
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
-    FrameSlot slot[2];
+    FrameSlot slot[3];                  // [0], [1] alternate per frame; [2]: the frame a camera's tracker runs ahead on (ifx_owner_track_ahead), allocated on first use
     int cur_slot = 0;
     std::vector<CamCtx> cams;           // camera contexts (ifx_camera_count); empty: the handle is its one camera
     int cur_cam = 0;
+    // K streams over a sharded map, camera k tracked by rank k: rank k's tracker for camera k's NEXT frame runs on the third stream under the other cameras' map phases
+    // (ifx_owner_track_ahead) -- a tracker instance of its own (state, model-side pyramids, frame slot 2, SO(3) accumulators), fed from the camera's PARKED context
+    DevState* d_cam_trk = nullptr;
+    Pyr cam_pyr;
+    double* cam_so3_acc = nullptr; unsigned int* cam_so3_ticket = nullptr;
+    hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr;
+    int cam_ahead_valid = 0, cam_ahead_cam = -1;
+    const void *cam_ahead_rgb = nullptr, *cam_ahead_depth = nullptr;
+    int cam_ahead_used = 0;             // frames whose tracker was taken from a run ahead (diagnostics / tests)
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
     int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it
@@ -445,7 +455,8 @@ int ifx_tracker_init_first(ifx* h);
 int ifx_tracker_run_frame(ifx* h, int commit = 1, int keep_last = 0);                            // model pyramid + GN loops (all on device); the frame side is in the slot
 int ifx_tracker_commit(ifx* h);                                // publish the pose of a tracker run that was enqueued ahead
 int ifx_tracker_model_side(ifx* h, int fold_begin = 0);                           // model pyramid from the prediction of the previous frame
-int ifx_tracker_frame_side(ifx* h, int first);                // frame pyramids + SO(3) pre-alignment of the bound slot
+int ifx_tracker_frame_side(ifx* h, int first, double* so3_acc = nullptr, unsigned int* so3_ticket = nullptr);   // frame pyramids + SO(3) pre-alignment of the bound slot
+int ifx_tracker_camera_ahead(ifx* h, int cam, const uint8_t* d_rgb, const uint16_t* d_depth);                // tracker of a parked camera's next frame on the instance of its own (the frame is in slot 2, h->cur is the stream)
 void ifx_bind_slot(ifx* h, int s);
 int ifx_housekeeping(ifx* h);                                  // tombstone compaction decided from the last frame result
 int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of the announced next frame (no-op without a hint)

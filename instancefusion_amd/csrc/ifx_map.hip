@@ -69,7 +69,7 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
 // A consumer block works on segment blockIdx % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk).
 #define LIST_SEGS IFX_LIST_SEGS
 #define LIST_CTR_STRIDE IFX_LIST_CTR_STRIDE   // uints between counters: 128 B
-struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; };   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; const int* first_live; int raw_slots; };   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
 // Loads of the surfel store by the passes that touch a surfel ONCE per frame (the scan, the list walkers' gathers): with IFX_NT they carry the non-temporal hint, so that the
 // ~100-450 MB of lines they pull through per frame do not evict the tracker's working set (pyramids, prediction: tens of MB) from L2 / the Infinity Cache.
 #ifdef IFX_NT
@@ -83,10 +83,14 @@ template <typename T> __device__ __forceinline__ T ld_once(const T* p) { return 
 __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int seg) { return c.lctr + (list * LIST_SEGS + seg) * LIST_CTR_STRIDE; }
 // Spatially sharded map: the id a surfel carries in keys / id images is its creation number (the same on every rank; ascending in slot order,
 // so "lowest id wins" is the single-GPU tie-break), and a rank finds the slot of an id it owns by binary search -- -1: another rank's surfel.
-__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 0 ? c.seq[i] : i; }
+// Unsharded map: the id is the slot -- except that id 0 means "no surfel" in every image (index_map.vert:51, `surfel_id > 0` in the instance kernels: the reference's surfel 0
+// occludes like any other but can never be associated, counted in a clean window, voted for).  The reference compacts every frame, so "surfel 0" is always the FIRST LIVE
+// surfel of the map; with tombstones the first live surfel may sit at a later slot: it is drawn as id 0 (DevState::first_live, kept by k_append_scan / k_vlist_offsets /
+// the compaction), and id 0 resolves back to that slot.  With compact_every_frame first_live is always 0: the identity.
+__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 0 ? c.seq[i] : ((c.raw_slots || i != (unsigned int)*c.first_live) ? i : 0u); }
 __device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id)
 {
-    if (c.own_n <= 0) return (int)id;
+    if (c.own_n <= 0) return id == 0u ? *c.first_live : (int)id;
     int lo = 0, hi = count - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -119,6 +123,7 @@ static Cam make_cam(ifx* h)
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
     c.seq = h->seq; c.own_n = h->own ? h->own_g : 0; c.own_rank = h->own ? h->cfg.rank : 0;
+    c.first_live = &h->d_state->first_live; c.raw_slots = 0;
     return c;
 }
 
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster(const DevState* __restri
                 if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
                 if (MODE == 0) { if (!(z >= -c.maxDepth && z <= c.maxDepth)) continue; }
                 else { if (!(z > 0 && z <= c.maxDepth)) continue; }
-                atomicMin(&keys[py * c.w + px], make_key(z, (unsigned int)i));
+                atomicMin(&keys[py * c.w + px], make_key(z, key_id(c, (unsigned int)i)));
             }
     }
 }
@@ -1043,9 +1048,9 @@ __device__ __forceinline__ void tile_draw(float4 ra, float4 rb, const Cam& c, in
             const bool in_s = do_s && px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
             const bool in_i = do_i && px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
             const int k = (py - by0) * TILE + (px - bx0);
-            if (in_s && in_i) atomicMin(&kb[k], make_key(z, i));
-            else if (in_s) atomicMin(&ks[k], make_key(z, i));
-            else if (in_i) atomicMin(&ki[k], make_key(z, i));
+            if (in_s && in_i) atomicMin(&kb[k], make_key(z, key_id(c, i)));
+            else if (in_s) atomicMin(&ks[k], make_key(z, key_id(c, i)));
+            else if (in_i) atomicMin(&ki[k], make_key(z, key_id(c, i)));
         }
 }
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
@@ -1360,7 +1365,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
 // the hot fields in list order, kept coherent through the fusion update / clean / append, were tried next: raster 79 -> 74 us, clean 64 -> 54,
 // index 28 -> 23, but the fusion update 13 -> 23 and 11 us per frame for the copies: no net gain, removed; profiles/r02_p_kernel_stats_compact_view_cache.csv.
 // What is left in these passes is their atomics and the clean pass's taps.)
-__global__ void k_vlist_offsets(DevState* st, Cam c)
+__global__ void k_vlist_offsets(DevState* st, Cam c, const float2* __restrict__ tm)
 {
     if (!st->vl_scan || threadIdx.x != 0) return;
     for (int which = 0; which < 2; which++) {
@@ -1374,6 +1379,12 @@ __global__ void k_vlist_offsets(DevState* st, Cam c)
             run += n;
         }
         st->vl_n[which] = run;
+    }
+    {   // the scan applied the age rule to slots outside the list: the lowest live slot may have moved on
+        int f = st->first_live;
+        const int n = st->count;
+        while (f < n && !(tm[f].y > DEAD_TIME)) f++;
+        st->first_live = f;
     }
 }
 __global__ __launch_bounds__(MAP_THREADS) void k_vlist_concat(const DevState* __restrict__ st, Cam c, const unsigned int* __restrict__ raw_a, const unsigned int* __restrict__ raw_i,
@@ -2142,6 +2153,11 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
         if (nc > cap) { nc = cap; st->overflow = 1; }
         st->n_new = nc - count0;
         st->count = nc;
+        {   // the clean pass of this frame is behind us: if it removed the reference's "surfel 0", the next live slot takes its place (the appended ones are alive by construction)
+            int f = st->first_live;
+            while (f < count0 && !(tm[f].y > DEAD_TIME)) f++;
+            st->first_live = f;
+        }
         st->next_seq = seq0 + (unsigned int)tg;
         if (seq0 + (unsigned int)tg < seq0 || seq0 + (unsigned int)tg > 0xFFF00000u) st->overflow = 1;   // creation numbers are never renumbered: 2^32 of them is the life of a sharded map (reported as a full store)
         __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2171,7 +2187,7 @@ __global__ void k_compact_scatter(const int* __restrict__ flags, const int* __re
 }
 __global__ void k_compact_count(DevState* st, const int* total)
 {
-    if (threadIdx.x == 0) { st->count = *total; st->n_dead = 0; st->vl_valid = 0; }   // slots renumbered: the view list is void
+    if (threadIdx.x == 0) { st->count = *total; st->n_dead = 0; st->vl_valid = 0; st->first_live = 0; }   // slots renumbered: the view list is void
 }
 
 static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out);
@@ -2401,7 +2417,7 @@ static void view_scan(ifx* h, int time)
     c.srank = 0; c.sn = 1;
     // raw output in the clean pass's lists 1, 2 (free at this point of a frame and between frames), then concatenated into list_v / list_vi
     LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c);
-    LAUNCH(h, "vlist_offsets", dim3(1), dim3(64), k_vlist_offsets, h->d_state, c);
+    LAUNCH(h, "vlist_offsets", dim3(1), dim3(64), k_vlist_offsets, h->d_state, c, (const float2*)h->tm);
     LAUNCH(h, "vlist_concat", dim3(256, 2), dim3(MAP_THREADS), k_vlist_concat, (const DevState*)h->d_state, c, h->list_b, h->list_c, h->list_v, h->list_vi);
 }
 // A forced scan at the current pose with the time of the last processed frame: every slot the list leaves out gets the age rule
@@ -2707,7 +2723,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             if (!h->own_slot_img && hipMalloc(&h->own_slot_img, (size_t)h->P * 4 * sizeof(int32_t)) != hipSuccess) h->own_slot_img = nullptr;   // [index | splat | ids | association] slot images
             h->own_fast = h->own_slot_img != nullptr;
             Cam cl = c;
-            if (h->own_fast) cl.own_n = 0;   // local keys carry slots; k_own_translate swaps in the creation numbers before they travel
+            if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }   // local keys carry slots; k_own_translate swaps in the creation numbers before they travel
             LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, cl, time, h->list_v, h->key_index);
             if (h->own_fast) LAUNCH(h, "own_translate", dim3(cdiv(h->P, 256)), dim3(256), k_own_translate, h->key_index, h->P, (const uint32_t*)h->seq, h->own_slot_img);
         } else {
@@ -2720,7 +2736,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         fuse_pass(h, nullptr, 0.f, time, 2, h->own_fast ? h->own_slot_img : nullptr);
         if (h->view_frame) {
             Cam cl = c;
-            if (h->own_fast) cl.own_n = 0;
+            if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
             LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, cl, time, h->list_v, h->key_index);
             if (h->own_fast) LAUNCH(h, "own_translate", dim3(cdiv(h->P, 256)), dim3(256), k_own_translate, h->key_index, h->P, (const uint32_t*)h->seq, h->own_slot_img);
         } else clean_pass(h, nullptr, time, 1);
@@ -2749,7 +2765,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick)) {   // the lists were built / checked by this frame and nothing renumbered the shard since
             Cam cl = make_cam(h);   // (the store's arrays may have been swapped by a compaction earlier in this phase: taken afresh)
             cl.srank = 0; cl.sn = 1;
-            if (h->own_fast) cl.own_n = 0;
+            if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
                    LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1);   // (the whole id image: it travels with the splat keys)
             h->own_fast_raster = h->own_fast;

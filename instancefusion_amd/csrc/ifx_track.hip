@@ -2446,7 +2446,7 @@ void ifx_bind_slot(ifx* h, int s)
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         p.depth_tmp[i] = (i == 0) ? f.depth_filt : f.depth_tmp[i]; p.vmap_curr[i] = f.vmap_curr[i]; p.nmap_curr[i] = f.nmap_curr[i];
         p.next_img[i] = f.next_img[i]; p.didx[i] = f.didx[i]; p.didy[i] = f.didy[i];
-        p.lastnext_img[i] = h->slot[s ^ 1].next_img[i];
+        p.lastnext_img[i] = h->slot[s < 2 ? (s ^ 1) : 0].next_img[i];   // (slot 2, a camera's run-ahead frame: the caller points it at the camera's parked pyramid)
     }
 }
 
@@ -2455,14 +2455,20 @@ void ifx_free_tracker(ifx* h)
 {
     Pyr& p = h->pyr;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 3; q++) {
             FrameSlot& f = h->slot[q];
             hipFree(f.depth_tmp[i]); hipFree(f.vmap_curr[i]); hipFree(f.nmap_curr[i]); hipFree(f.next_img[i]); hipFree(f.didx[i]); hipFree(f.didy[i]);
         }
         hipFree(p.vmap_cam[i]); hipFree(p.nmap_cam[i]); hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]); hipFree(p.last_depth[i]); hipFree(p.last_img[i]);
         hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
-    for (int q = 0; q < 2; q++) hipFree(h->slot[q].so3);
+    for (int q = 0; q < 3; q++) hipFree(h->slot[q].so3);
+    if (h->d_cam_trk) {
+        Pyr& cp = h->cam_pyr;
+        for (int i = 0; i < IFX_NUM_PYRS; i++) { hipFree(cp.vmap_cam[i]); hipFree(cp.nmap_cam[i]); hipFree(cp.vmap_prev[i]); hipFree(cp.nmap_prev[i]); hipFree(cp.last_depth[i]); hipFree(cp.last_img[i]); hipFree(cp.cloud[i]); hipFree(cp.corres[i]); }
+        hipFree(h->d_cam_trk); hipFree(h->cam_so3_acc); hipFree(h->cam_so3_ticket);
+        h->d_cam_trk = nullptr;
+    }
     free_m2m(h);
     hipFree(h->d_graph); hipFree(h->d_sample); hipFree(h->d_cons); hipFree(h->d_project); hipFree(h->d_fern); hipFree(h->d_inst_gt);
     if (h->h_fern) hipHostFree(h->h_fern);
@@ -2746,7 +2752,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
 // needs its intensity pyramid as the next frame's "previous image") the SO(3) pre-alignment against the other
 // slot's intensity pyramid, EF/Utils/RGBDOdometry.cpp:313-386: up to 10 reduction + update launches, each exiting at
 // once after convergence (device flag)
-int ifx_tracker_frame_side(ifx* h, int first)
+int ifx_tracker_frame_side(ifx* h, int first, double* so3_acc, unsigned int* so3_ticket)
 {
     Pyr& p = h->pyr;
     const ifx_config& c = h->cfg;
@@ -2763,8 +2769,8 @@ int ifx_tracker_frame_side(ifx* h, int first)
         DevState* ss = h->slot[h->cur_slot].so3;
         LAUNCH(h, "so3_begin", dim3(1), dim3(64), k_so3_begin, ss, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
         for (int it = 0; it < 10; it++)
-            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, ss, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], p.acc + 2 * IFX_ACC_REPL * IFX_ACC_STRIDE, nb, h->d_ticket + 4, c.fx / d2, c.fy / d2,
-                   c.cx / d2, c.cy / d2);
+            LAUNCH(h, "so3_fused", dim3(nb), dim3(RED_THREADS), k_so3_fused, ss, p.lastnext_img[L], p.next_img[L], p.w[L], p.h[L], so3_acc ? so3_acc : p.acc + 2 * IFX_ACC_REPL * IFX_ACC_STRIDE, nb,
+                   so3_ticket ? so3_ticket : h->d_ticket + 4, c.fx / d2, c.fy / d2, c.cx / d2, c.cy / d2);
     }
     return IFX_OK;
 }
@@ -2783,6 +2789,71 @@ int ifx_tracker_model_side(ifx* h, int fold_begin)
     }
     tracker_init_model(h, h->d_state, h->pyr, h->cfg.icp_weight, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal, h->fill_image, fold ? &gb : nullptr);
     h->gn_begin_folded = fold ? 1 : 0;
+    return IFX_OK;
+}
+
+// The tracker of a PARKED camera's next frame on a tracker instance of its own (K streams over a sharded map, camera k tracked by rank k: ifx_owner_track_ahead).  The
+// caller has bound frame slot 2 (its frame side is computed by ifx_tracker_frame_side with this instance's SO(3) accumulators) and set h->cur to the stream the run goes to.
+// Inputs: the camera's parked prediction / fill-in / pose block; output: the instance's pose block, committed into the live state when the frame's turn comes.
+static int cam_trk_alloc(ifx* h)
+{
+    if (h->d_cam_trk) return IFX_OK;
+    Pyr& p = h->cam_pyr;
+    HIPCHK(h, hipMalloc(&h->d_cam_trk, sizeof(DevState)));
+    HIPCHK(h, hipMemset(h->d_cam_trk, 0, sizeof(DevState)));
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        p.w[i] = h->w >> i; p.h[i] = h->h >> i;
+        const size_t n = (size_t)p.w[i] * p.h[i];
+        FrameSlot& f = h->slot[2];
+        HIPCHK(h, hipMalloc(&f.depth_tmp[i], n * 2));
+        HIPCHK(h, hipMalloc(&f.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&f.nmap_curr[i], n * 12));
+        HIPCHK(h, hipMalloc(&f.next_img[i], n)); HIPCHK(h, hipMemset(f.next_img[i], 0, n));
+        HIPCHK(h, hipMalloc(&f.didx[i], n * 2)); HIPCHK(h, hipMalloc(&f.didy[i], n * 2));
+        HIPCHK(h, hipMalloc(&p.vmap_cam[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_cam[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.vmap_prev[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_prev[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.last_depth[i], n * 4));
+        HIPCHK(h, hipMalloc(&p.last_img[i], n));
+        HIPCHK(h, hipMalloc(&p.cloud[i], n * 12));
+        HIPCHK(h, hipMalloc(&p.corres[i], n * 8));
+    }
+    const size_t P = (size_t)h->P;
+    FrameSlot& f = h->slot[2];
+    HIPCHK(h, hipMalloc(&f.rgb, P * 3)); HIPCHK(h, hipMalloc(&f.depth_raw, P * 2)); HIPCHK(h, hipMalloc(&f.depth_filt, P * 2)); HIPCHK(h, hipMalloc(&f.dm, P * 4)); HIPCHK(h, hipMalloc(&f.dmf, P * 4));
+    HIPCHK(h, hipMalloc(&f.so3, sizeof(DevState)));
+    HIPCHK(h, hipMemset(f.so3, 0, sizeof(DevState)));
+    HIPCHK(h, hipMalloc(&h->cam_so3_acc, IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)));
+    HIPCHK(h, hipMemset(h->cam_so3_acc, 0, IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->cam_so3_ticket, 64));
+    HIPCHK(h, hipMemset(h->cam_so3_ticket, 0, 64));
+    return IFX_OK;
+}
+int ifx_tracker_camera_ahead(ifx* h, int cam, const uint8_t* d_rgb, const uint16_t* d_depth)
+{
+    int r = cam_trk_alloc(h);
+    if (r) return r;
+    CamCtx& cc = h->cams[(size_t)cam];
+    DevState* st = h->d_cam_trk;
+    Pyr& p = h->cam_pyr;
+    const int bound = h->cur_slot;
+    HIPCHK(h, hipMemcpyAsync(h->slot[2].rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->slot[2].depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur));
+    ifx_bind_slot(h, 2);
+    for (int i = 0; i < IFX_NUM_PYRS; i++) h->pyr.lastnext_img[i] = cc.img[i];   // the "previous image" of the SO(3) step: the camera's last frame, parked with its context
+    ifx_preprocess(h);
+    ifx_tracker_frame_side(h, 0, h->cam_so3_acc, h->cam_so3_ticket);
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {   // the instance tracks the frame in slot 2
+        p.vmap_curr[i] = h->pyr.vmap_curr[i]; p.nmap_curr[i] = h->pyr.nmap_curr[i]; p.next_img[i] = h->pyr.next_img[i]; p.didx[i] = h->pyr.didx[i]; p.didy[i] = h->pyr.didy[i];
+        p.depth_tmp[i] = h->pyr.depth_tmp[i]; p.lastnext_img[i] = cc.img[i];
+    }
+    HIPCHK(h, hipMemcpyAsync((void*)st, cc.state, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->cur));   // the camera's pose block: the run starts from ITS pose
+    // the camera's parked prediction block has the layout of the live one
+    const uint8_t* pb = cc.pred;
+    const float* pv = (const float*)pb;
+    const float* pn = (const float*)(pb + ((const uint8_t*)h->pred_normal - (const uint8_t*)h->pred_vertex));
+    const uint8_t* pi = pb + ((const uint8_t*)h->pred_image - (const uint8_t*)h->pred_vertex);
+    tracker_init_model(h, st, p, h->cfg.icp_weight, pv, pn, pi, cc.fill_v, cc.fill_n, cc.fill_i);
+    tracker_run(h, st, p, h->cfg.icp_weight, h->cfg.so3, 1.0f, 1, false);   // (commit = 1 into the INSTANCE's pose block; no view-list decision: that belongs to the frame's commit)
+    ifx_bind_slot(h, bound);
     return IFX_OK;
 }
 

@@ -526,6 +526,53 @@ def test_full_loop_640x480_trajectory_and_labels(ifx, orc):
 
 
 @pytest.mark.timeout(1500)
+def test_bench_configuration_against_the_oracle_directly(ifx, orc):
+    """bench.py's OWN configuration against the oracle, with no HIP-vs-HIP link in between: the 90-frame 640x480 loop through ifx_hint_next_frame_device +
+    ifx_enqueue_frame_device (frames resident in HBM, one-frame look-ahead, the next frame's tracker parked behind every frame), default options -- lazy tombstone
+    compaction, cached view lists aged over several frames, the id image on the sampled lattice, the 6x6 solve in the next launch's prologue -- and three
+    segmentation calls on the RESIDENT frame (ProcessSegmentation(None, None, ...): beside the tracker queued ahead).  Every pose against the oracle's as it is produced
+    (assert_pose_equal: bit-equal, <= 1 ulp counted), the instance tables at the calls, and at the end the downloaded map, votes and labels array_equal."""
+    import torch
+
+    from instancefusion_amd import synth
+
+    W, H, NF = 640, 480, 90
+    K = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    st = synth.make_stream(NF, W, H, noise=True, loop_len=NF, **K)
+    orc.set_threads(orc.usable_cores())
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    g = ifx.ElasticFusion(w=W, h=H, max_surfels=3_000_000, **K)             # every option at its default
+    o = orc.Oracle(w=W, h=H, max_surfels=3_000_000, **K)
+    inst = ifx.InstanceFusion(g)
+    seg_frames = (35, 60, 89)
+    scans0 = g.view_list_stats()["scans"]
+    for i in range(NF):
+        if i + 1 < NF:
+            g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+        g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        inst.whetherDoSegmentation(100 + i)                                   # the host's per-frame decision point, as in bench.py (waits for the frame's result only)
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        if i in seg_frames:
+            masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
+            assert masks.shape[0] > 0
+            inst.ProcessSegmentation(None, None, masks, cls, i, superpixels=True)
+            o.process_segmentation(st["rgb"][i], st["depth"][i], masks, cls, i, flags=2)
+            assert np.array_equal(inst.getInstanceTable(), o.instance_table()), i
+        assert_pose_equal(g.trajectory(1)[0], po, f"frame {i}")              # (the trajectory ring: no interference with the frames in flight beyond a stream wait)
+    vs = g.view_list_stats()
+    assert 3 < vs["scans"] - scans0 < NF // 2, vs                            # the lists really were cached over several frames
+    assert g.tracker_fallbacks() == 0
+    assert g.count == o.count
+    assert np.array_equal(inst.labels(), o.labels()) and (o.labels() >= 0).sum() > 1000
+    mg_, mo_ = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg_[k], mo_[k]), k
+    g.close(); o.close()
+
+
+@pytest.mark.timeout(1500)
 def test_config3_5m_map_full_instance_path(ifx, orc):
     """BASELINE configuration 3's workload (rgbd-scenes-v2 is not in the image: the synthetic stream stands in): a 5M-surfel
     map, 640x480, the FULL instance path -- votes, gSLICr superpixels + geometric merging, flood fill, label scan, kNN colour
@@ -906,8 +953,11 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx):
         e.close()
 
 
-def test_config5_two_streams_one_sharded_map(ifx):
-    """BASELINE configuration 5 in small: K = 2 cameras (two stretches of the benchmark trajectory through the same scene) feed ONE map that is spatially
+@pytest.mark.parametrize("ahead", [False, True])
+def test_config5_two_streams_one_sharded_map(ifx, ahead):
+    """(ahead = True: rank k runs the tracker of camera k's NEXT frame on its third stream as soon as the camera's context is parked, under the other camera's map phases --
+    ifx_owner_track_ahead -- and the frame commits the parked pose block instead of tracking: same poses, same map, and every tracked frame but the first is served that way.)
+    BASELINE configuration 5 in small: K = 2 cameras (two stretches of the benchmark trajectory through the same scene) feed ONE map that is spatially
     sharded over G = 2 ranks.  Semantics of a frame set: the K frames are processed in camera order on the one map; every camera tracks against the
     prediction rendered at the end of its own last frame (camera contexts: ifx_camera_count / ifx_camera_select).  On the sharded side camera c is tracked by
     rank c ONLY (ifx_owner_set_tracking_rank: stream k on GPU k, no tracker collective), the pose block is handed to the other rank (exchange 310), and every
@@ -940,6 +990,12 @@ def test_config5_two_streams_one_sharded_map(ifx):
                 e.owner_set_tracking_rank(c)                    # stream c is tracked on rank c only
                 if ext is not None:
                     e.owner_set_frame_pose(ext)
+            if ahead and (s_ > 0 or c > 0):                     # the camera whose frame was just processed is parked now: its next frame's tracker starts at once, on its rank
+                cp, sp = (c - 1, s_) if c > 0 else (K - 1, s_ - 1)
+                if sp + 1 < NS:
+                    j = first[cp] + sp + 1
+                    for e in efs:
+                        e.owner_track_ahead(cp, cp, d_rgb[j].data_ptr(), d_dep[j].data_ptr())
             sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             for e in efs:
                 assert np.array_equal(e.getCurrPose(), p1), (s_, c, e.cfgd["rank"])
@@ -948,6 +1004,10 @@ def test_config5_two_streams_one_sharded_map(ifx):
             assert np.array_equal(efs[1 - c].image("ids_after"), efs[c].image("ids_after"))   # (the id image comes from the exchanged keys: everywhere)
     # both cameras tracked: their trajectories follow the ground truth of their stretch
     assert np.abs(p1 - st["poses"][first[1] + NS - 1]).max() < 0.03
+    if ahead:   # every frame from the second set on took its pose from the run ahead (camera 0's first frame is the map's first; camera 1's entered with its extrinsic pose)
+        assert [e.owner_track_ahead(-1, 0) for e in efs] == [NS - 1, NS - 1]
+    else:
+        assert [e.owner_track_ahead(-1, 0) for e in efs] == [0, 0]
     ref = one.download()
     parts = [(e.seq(), e.download()) for e in efs]
     seq = np.concatenate([p[0] for p in parts])

@@ -1,9 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -k "owner_sharded or config5_two or sharded_rccl or cpp_replay_sharded or config4" > gpurun_out/r04_g_tests.log 2>&1; tail -4 gpurun_out/r04_g_tests.log
-python bench.py --sharded --no-cpu-baseline --extras-frames 0 > gpurun_out/r04_g_bench_sharded_world_of_one.json 2>gpurun_out/r04_g_bench_sh.err
-python - <<PY
-import json
-d=json.loads(open("gpurun_out/r04_g_bench_sharded_world_of_one.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_frame_gpu"], d.get("exchange"), d["view_list"])
-PY
-( time python -m pytest tests -m gpu -q -k "config5_8_streams" ) > gpurun_out/r04_g_config5.log 2>&1; tail -6 gpurun_out/r04_g_config5.log; free -g | head -2
+python tools/diag/count_diff.py 2>&1 | grep -v "missing\|base row" | tail -9
+python -m pytest tests -m gpu -q -x -k "bench_configuration or view_list or full_size or end_to_end or fuse_and_clean or map_stages or lookahead or owner_sharded_map or config5_two or tiled_raster" > gpurun_out/r04_i_tests.log 2>&1; tail -4 gpurun_out/r04_i_tests.log

@@ -462,6 +462,48 @@ def main():
         ef.sync()
         ef.set_loop_closure(False, 35000, 5e-5, 1e-5)
 
+    # ---- the FAST cadence (IF/Core/InstanceFusion.cpp:194-233): on a young map -- less than 80 % of the sampled id image covered by stable surfels, hardly any votes --
+    # whetherDoSegmentation fires every 3rd frame instead of every 46th.  The 5M-surfel map of `value` is old by construction, so this leg starts a map from nothing
+    # and runs the same stream's first frames: frames/s and the instance stage per frame in that regime.
+    if rank == 0 and world == 1 and sh is None and args.extras_frames > 0 and not args.close_loops and not args.no_instance:
+        ef.sync()
+        ef3 = ifx.ElasticFusion(w=W, h=H, max_surfels=3_000_000, device=dev, **K)
+        inst3 = ifx.InstanceFusion(ef3)
+        for kv in args.opt:
+            k_, v_ = kv.split("=")
+            ef3.set_option(k_, int(v_))
+        nf3 = min(L, 90)
+        fc = dict(calls=0, timed_calls=0, t0=None, first=12)
+
+        def step3(i):
+            if i + 1 < nf3 and not args.no_prefetch:
+                ef3.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+            ef3.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            if inst3.whetherDoSegmentation(100 + i):
+                mk, cl = masks[i]
+                if mk.shape[0]:
+                    inst3.ProcessSegmentation(None, None, mk, cl, i, superpixels=not args.no_superpixels)
+                    fc["calls"] += 1
+                    fc["timed_calls"] += 1 if i >= fc["first"] else 0
+
+        for i in range(fc["first"]):
+            step3(i)
+        ef3.sync(); torch.cuda.synchronize()
+        ef3.stage_ms(reset=True)
+        t0 = time.perf_counter()
+        for i in range(fc["first"], nf3):
+            step3(i)
+        ef3.sync(); torch.cuda.synchronize()
+        t3 = time.perf_counter() - t0
+        inst3_ms = ef3.stage_ms(reset=True)["instance"]
+        n3 = nf3 - fc["first"]
+        extras["value_fast_cadence"] = dict(value=round(n3 / t3, 2), unit="frames/s", frames=n3, segmentation_calls=fc["timed_calls"],
+                                            frames_per_call=round(n3 / max(1, fc["timed_calls"]), 2), instance_ms_per_frame=round(inst3_ms / n3, 4),
+                                            instance_ms_per_call=round(inst3_ms / max(1, fc["timed_calls"]), 4), surfels_live=ef3.count,
+                                            what="the same stream into a map started from nothing: whetherDoSegmentation's fast cadence (a call every 3rd frame while less than 80 % of the "
+                                                 "sampled id image is covered and the vote mass is low), resident frames + look-ahead as in `value`")
+        ef3.close()
+
     # ---- the north star's partitioning beside the replicas: the SAME stream (rank 0's) into ONE map spatially sharded over the ranks of this run -- every rank stores
     # the surfels it owns, the exchanges of a frame are RCCL collectives enqueued by libifx.so.  At N = 1 a world of one: the fixed cost of the mode.
     sharded_leg = None

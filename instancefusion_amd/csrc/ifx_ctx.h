@@ -259,6 +259,7 @@ struct ifx {
     int opt_lc_view = 1;                // loop-closure detection: its two renders from the view lists (one k_raster_view in dual mode) instead of a scan of the store + k_raster_list
     int opt_lazy_ids = 1;               // the frame renders the id image on the lattice whetherDoSegmentation samples; the whole image on demand (ifx_ids_ensure)
     int ids_full_valid = 1, ids_sparse_frame = 0;
+    int ids_full_hint = 0;              // the cadence says the NEXT frame ends with a segmentation call (ifx_should_segment): that frame draws the whole id image itself
     // options
     int opt_compact_every_frame = 0;
     int last_compact_tick = -1;

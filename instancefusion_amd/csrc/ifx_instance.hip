@@ -33,6 +33,21 @@ __global__ void k_mask_clean_overlap(uint8_t* __restrict__ masks, int nm, int P)
         if (!flag && v) flag = 1;
     }
 }
+// the same from the masks as they arrived (`ori`, kept: "BAK ORI MASK") into the working copy -- the copy and the clean in one pass -- and the per-mask verdict
+// bytes of the call cleared on the way (the device-side call: two dispatches less)
+__global__ void k_mask_clean_overlap_from(const uint8_t* __restrict__ ori, uint8_t* __restrict__ masks, int nm, int P, uint8_t* __restrict__ unavail)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (unavail && p < nm) unavail[p] = 0;
+    if (p >= P) return;
+    int flag = 0;
+    for (int m = nm - 1; m >= 0; m--) {
+        size_t a = (size_t)m * P + p;
+        const uint8_t v = ori[a];
+        masks[a] = (flag && v) ? (uint8_t)0 : v;
+        if (!flag && v) flag = 1;
+    }
+}
 
 // checkProjectDepthAndInstanceKernel, IF/Core/InstanceFusionCuda.cu:736-760
 __global__ void k_check_project(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, int w, int h, int downsample,
@@ -458,11 +473,12 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
     int w = h->w, hh = h->h;
     bool test1 = count[0] > (w / downsample * hh / downsample * 0.48 * 30);
     bool test2 = count[1] < (w / downsample * hh / downsample * 0.2);
-    if (test1 || test2) {
-        if (frame - h->last_seg_frame > fixedH) { h->last_seg_frame = frame; return 1; }
-        return 0;
-    }
-    if (frame - h->last_seg_frame > fixedL) { h->last_seg_frame = frame; return 1; }
+    const int gap = (test1 || test2) ? fixedH : fixedL;
+    if (frame - h->last_seg_frame > gap) { h->last_seg_frame = frame; return 1; }
+    // Not this frame -- but if the cadence says "the next one", that frame draws the WHOLE id image while it rasterises its prediction (one pass over the same lists:
+    // ~20 us) instead of leaving the rest of the image to the call (a walk of its own over the view lists + a resolve at the head of the call: ~80 us).  A hint only:
+    // the decision is taken again on the next frame's own sums, and a call that finds the sparse image renders the rest as before (ifx_ids_ensure).
+    if (frame + 1 - h->last_seg_frame > gap) h->ids_full_hint = 1;
     return 0;
 }
 
@@ -486,6 +502,7 @@ __device__ __forceinline__ float depth_threshold_dev(int depth)
 // in LDS until nothing changes, one pointer jump (label <- label[label], valid by transitivity) per launch carries
 // labels across tiles, and launches repeat until a launch changes nothing.
 #define FF_T 32
+#define FF_SLOTS 64
 struct FFArgs {
     const uint16_t* depth; uint8_t* masks; const uint8_t* ori; const uint8_t* skip;   // skip[m] != 0: mask left alone
     int* label; int* cnt; int* meta;   // meta[m*32 + 0] oriPoints, [1] kept count, [2] finalPoints, [4..24) kept region ids
@@ -495,6 +512,14 @@ struct FFArgs {
     int nm, w, h;
 };
 
+__global__ void k_ff_prep(FFArgs a, const uint8_t* __restrict__ unavail, uint8_t* __restrict__ skip, int n_tiles)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) a.tile_active[t] = 0;
+    if (t < a.nm * 32) a.meta[t] = 0;
+    if (t < FF_SLOTS) a.changed[t] = 0;
+    if (t < a.nm) skip[t] = unavail[t];
+}
 __global__ void k_ff_init(FFArgs a)
 {
     const int P = a.w * a.h, k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
@@ -759,7 +784,6 @@ __global__ void k_ff_verdict(FFArgs a, uint8_t* unavailable)
 // fixed_rounds == 0: relaxations until a launch changes nothing, the host looking every 7 launches (stage API, sharded calls, slow path).
 // fixed_rounds  > 0: exactly that many relaxation launches are enqueued -- the ones behind the fixpoint return at once -- and the tail (region sizes, selection,
 //   verdict) only runs when the last one found nothing to change; otherwise *ff_gate() stays set and the caller finishes with resume = true.  No host look at all.
-#define FF_SLOTS 64
 static FFArgs ff_args(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm)
 {
     FFArgs a;
@@ -786,10 +810,10 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     dim3 per_px(cdiv(P, 256), nm);
     dim3 tiles(cdiv(h->w, FF_T), cdiv(h->h, FF_T), nm);
     if (!resume) {
-        HIPCHK(h, hipMemsetAsync(a.tile_active, 0, (size_t)nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), h->cur));
-        HIPCHK(h, hipMemcpyAsync(d_skip, d_unavail, nm, hipMemcpyDeviceToDevice, h->cur));   // the verdict must not change who is skipped mid-way
-        HIPCHK(h, hipMemsetAsync(a.meta, 0, (size_t)nm * 32 * 4, h->cur));
-        HIPCHK(h, hipMemsetAsync(a.changed, 0, FF_SLOTS * 4, h->cur));
+        // one launch re-arms the fill's bookkeeping (tile flags, per-mask counters, the schedule's "changed" words) and freezes who is skipped (the verdict must not
+        // change that mid-way): three fills and a copy, four dispatches of a latency-bound chain, before
+        LAUNCH(h, "ff_prep", dim3(cdiv(std::max(nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T), nm * 32), 256)), dim3(256), k_ff_prep, a, (const uint8_t*)d_unavail, d_skip,
+               nm * cdiv(h->w, FF_T) * cdiv(h->h, FF_T));
         LAUNCH(h, "ff_init", per_px, dim3(256), k_ff_init, a);
         if (h->opt_ff_union) {   // the two-way edges by union-find: three launches for what took the relaxation a launch per tile border crossed
             const int pairs = ((h->w - 1) / FF_T) * h->h + ((h->h - 1) / FF_T) * h->w;
@@ -1329,9 +1353,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     t_stage = us();
     HIPCHK(h, hipMemcpyAsync(h->d_masks_ori, h->h_masks_stage, mbytes, hipMemcpyHostToDevice, h->cur));   // pinned: a true asynchronous copy
     HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->cur));
-    HIPCHK(h, hipMemcpyAsync(h->d_masks, h->d_masks_ori, mbytes, hipMemcpyDeviceToDevice, h->cur));
-    HIPCHK(h, hipMemsetAsync(h->d_unavail, 0, nm, h->cur));
-    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap, h->d_masks, nm, P);
+    LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap_from, (const uint8_t*)h->d_masks_ori, h->d_masks, nm, P, h->d_unavail);
     if (flags & 2) {
         r = ifx_superpixel_filter(h, nm);
         if (r) return r;

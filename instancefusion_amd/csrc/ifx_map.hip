@@ -1988,20 +1988,30 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
         int tx[4], ty[4];
 #pragma unroll
         for (int a = 0; a < 4; a++) { tx[a] = clampi((int)floorf(x + offs[a]), 0, c.w - 1); ty[a] = clampi((int)floorf(y + offs[a]), 0, c.h - 1); }
-        float4 t[16];
+        // The sixteen taps visit at most 3 x 3 DISTINCT texels: the four offsets floor to consecutive columns tx[0], tx[0] + 1, tx[0] + 2 (non-decreasing, clamped), a column
+        // being visited as often as it appears among the four -- so nine gathers, each counted with its multiplicity mx * my, give the window's two counts exactly
+        // (counter evidence, profiles/r04_a_pmc_bound.json: the pass was bound by the address processing of its 16 divergent gathers per candidate, not by its arithmetic)
+        int mx[3], my[3];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int q = 0; q < 3; q++) {
+            mx[q] = (tx[0] == tx[0] + q) + (tx[1] == tx[0] + q) + (tx[2] == tx[0] + q) + (tx[3] == tx[0] + q);
+            my[q] = (ty[0] == ty[0] + q) + (ty[1] == ty[0] + q) + (ty[2] == ty[0] + q) + (ty[3] == ty[0] + q);
+        }
+        float4 t[9];
 #pragma unroll
-            for (int b = 0; b < 4; b++) t[a * 4 + b] = tap[ty[b] * c.w + tx[a]];   // all 16 gathers in flight
+        for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+            for (int b = 0; b < 3; b++) t[a * 3 + b] = tap[min(ty[0] + b, c.h - 1) * c.w + min(tx[0] + a, c.w - 1)];   // all nine gathers in flight
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int wgt = mx[k / 3] * my[k % 3];
             const float4 e = t[k];
-            if (e.z == 0.f) continue;                       // empty texel (or surfel id 0)
+            if (wgt == 0 || e.z == 0.f) continue;           // a column / row the window does not visit; an empty texel (or surfel id 0)
             const float ez = fabsf(e.z);
             const bool stable = e.w > 0.f, now = e.z < 0.f;
             const float dx = e.x - lp.x, dy = e.y - lp.y;
-            if (fabsf(e.w) < initT && stable && ez > lp.z && ez - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count++;
-            if (now && stable && ez > lp.z && ez - lp.z > 0.01f && flat) zCount++;
+            if (fabsf(e.w) < initT && stable && ez > lp.z && ez - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count += wgt;
+            if (now && stable && ez > lp.z && ez - lp.z > 0.01f && flat) zCount += wgt;
         }
     }
     if (count > 8 || zCount > 4) test = 0;
@@ -2529,7 +2539,8 @@ int ifx_map_predict(ifx* h)
         c.srank = 0; c.sn = 1;
         // The id image has one consumer per frame -- whetherDoSegmentation's sums over every 10th pixel -- and a full-image consumer only when a segmentation call, a
         // download or the display asks for it: the frame renders the sampled lattice only (the id half of this pass: 71 -> 40 us), ifx_ids_ensure the rest on demand.
-        const int ids_step = (h->opt_lazy_ids && (want & LIST_IDS)) ? 10 : 1;
+        const int ids_step = (h->opt_lazy_ids && !h->ids_full_hint && (want & LIST_IDS)) ? 10 : 1;
+        h->ids_full_hint = 0;
         h->ids_full_valid = ids_step == 1;
         h->ids_sparse_frame = ids_step > 1;
         h->ids_view_ok = ids_step > 1;

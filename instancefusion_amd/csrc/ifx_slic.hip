@@ -33,6 +33,8 @@ struct SlicBuf {
     int P = 0, spn = 0, mw = 0, mh = 0, adj_words = 0;
     uint8_t* rgb = nullptr;
     uint16_t *depth = nullptr, *dg = nullptr;
+    const uint8_t* cur_rgb = nullptr;      // the frame the stages read: b->rgb / b->depth after a copy, or the frame slot's own images (the resident frame of a call)
+    const uint16_t* cur_depth = nullptr;
     float4 *xyz = nullptr, *pos = nullptr, *nor = nullptr;
     float4* ccol = nullptr;   // [spn] centre colour
     float2* cxy = nullptr;    // [spn] centre position
@@ -732,7 +734,7 @@ int slic_run(ifx* h, SlicBuf* b)
     ncol *= ncol; nxy *= nxy;
     dim3 cells(cdiv(w, 16), cdiv(hh, 16)), tile(16, 16);
     HIPCHK(h, hipMemsetAsync(b->seg, 0, (size_t)P * 4, h->cur));
-    LAUNCH(h, "slic_cvt", dim3(cdiv(P, 256)), dim3(256), k_slic_cvt, b->rgb, b->xyz, P);
+    LAUNCH(h, "slic_cvt", dim3(cdiv(P, 256)), dim3(256), k_slic_cvt, b->cur_rgb ? b->cur_rgb : (const uint8_t*)b->rgb, b->xyz, P);
     LAUNCH(h, "slic_init", dim3(cdiv(S, 256)), dim3(256), k_slic_init, b->xyz, b->ccol, b->cxy, b->mw, b->mh, w, hh);
     LAUNCH(h, "slic_assoc", cells, tile, k_slic_assoc, b->xyz, b->ccol, b->cxy, b->seg, b->mw, b->mh, w, hh, 0.6f, nxy, ncol);
     for (int it = 0; it < 5; it++) {   // my_settings.no_iters
@@ -751,7 +753,7 @@ int merge_run(ifx* h, SlicBuf* b)
     dim3 cells(cdiv(w, 64), cdiv(hh, 4)), tile(64, 4);
     HIPCHK(h, hipMemsetAsync(b->sum1, 0, (size_t)S * NSUM * 2 * 8, h->cur));
     HIPCHK(h, hipMemsetAsync(b->adj, 0, (size_t)S * b->adj_words * 4, h->cur));
-    LAUNCH(h, "sp_gauss", cells, tile, k_sp_gauss, b->depth, b->dg, w, hh);
+    LAUNCH(h, "sp_gauss", cells, tile, k_sp_gauss, b->cur_depth ? b->cur_depth : (const uint16_t*)b->depth, b->dg, w, hh);
     LAUNCH(h, "sp_posnor", cells, tile, k_sp_posnor, b->dg, cam, w, hh, S, b->pos, b->nor, b->seg);
     LAUNCH(h, "sp_sums", dim3(cdiv(w, 16), cdiv(hh, 16)), dim3(16, 16), k_sp_sums, b->seg, b->dg, b->pos, b->nor, w, hh, b->sum1, b->adj, b->adj_words);
     LAUNCH(h, "sp_first_avg", dim3(cdiv(S, 64)), dim3(64), k_sp_first_avg, b->sum1, b->adj, b->adj_words, S, b->info);
@@ -821,8 +823,7 @@ static int slic_load_frame(ifx* h, SlicBuf* b, const uint8_t* rgb, const uint16_
     if (!rgb && !depth) {
         if (h->tick < 2) { h->err = "superpixel refinement of the resident frame: no frame has been processed yet"; return IFX_E_STATE; }
         const FrameSlot& f = h->slot[(h->tick - 1) & 1];
-        HIPCHK(h, hipMemcpyAsync(b->rgb, f.rgb, P * 3, hipMemcpyDeviceToDevice, h->cur));
-        HIPCHK(h, hipMemcpyAsync(b->depth, f.depth_raw, P * 2, hipMemcpyDeviceToDevice, h->cur));
+        b->cur_rgb = f.rgb; b->cur_depth = f.depth_raw;   // read in place: the slot is not reused before the frame after next, and the call is synchronous
         return IFX_OK;
     }
     if (!rgb || !depth) { h->err = "superpixel refinement needs the RGB and depth frame (or neither: the resident frame)"; return IFX_E_INVALID; }
@@ -830,6 +831,7 @@ static int slic_load_frame(ifx* h, SlicBuf* b, const uint8_t* rgb, const uint16_
     std::memcpy(h->depth_stage, depth, P * 2);
     HIPCHK(h, hipMemcpyAsync(b->rgb, h->rgb_stage, P * 3, hipMemcpyHostToDevice, h->cur));
     HIPCHK(h, hipMemcpyAsync(b->depth, h->depth_stage, P * 2, hipMemcpyHostToDevice, h->cur));
+    b->cur_rgb = nullptr; b->cur_depth = nullptr;
     return IFX_OK;
 }
 
@@ -871,6 +873,7 @@ extern "C" int ifx_slic_segment(ifx_t* h, const uint8_t* rgb, int32_t* seg_out)
     SlicBuf* b;
     int r = slic_buffers(h, &b);
     if (r) return r;
+    b->cur_rgb = nullptr;
     HIPCHK(h, hipMemcpyAsync(b->rgb, rgb, (size_t)b->P * 3, hipMemcpyHostToDevice, h->cur));
     if ((r = slic_run(h, b))) return r;
     HIPCHK(h, hipMemcpyAsync(seg_out, b->seg, (size_t)b->P * 4, hipMemcpyDeviceToHost, h->cur));
@@ -885,6 +888,7 @@ extern "C" int ifx_merge_superpixels(ifx_t* h, const uint16_t* depth, int32_t* s
     int r = slic_buffers(h, &b);
     if (r) return r;
     const size_t P = b->P;
+    b->cur_depth = nullptr;
     HIPCHK(h, hipMemcpyAsync(b->depth, depth, P * 2, hipMemcpyHostToDevice, h->cur));
     HIPCHK(h, hipMemcpyAsync(b->seg, seg_inout, P * 4, hipMemcpyHostToDevice, h->cur));
     if ((r = merge_run(h, b))) return r;

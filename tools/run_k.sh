@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-python tools/diag/count_diff.py 2>&1 | grep -v "missing\|base row" | tail -9
-python -m pytest tests -m gpu -q -x -k "bench_configuration or view_list or full_size or end_to_end or fuse_and_clean or map_stages or lookahead or owner_sharded_map or config5_two or tiled_raster" > gpurun_out/r04_i_tests.log 2>&1; tail -4 gpurun_out/r04_i_tests.log
+( time python -m pytest tests -m gpu -q ) > gpurun_out/r04_j_tests.log 2>&1; tail -6 gpurun_out/r04_j_tests.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04_j_bench_driver.json 2>gpurun_out/r04_j_bench.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r04_j_bench_driver.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_frame_gpu"], d["instance"], d.get("value_fast_cadence"), d.get("value_sharded", {}).get("value"), d["cpu_baseline"].get("parity_in_bench"))
+PY
+bash tools/prof_run.sh r04_j > /dev/null 2>&1; head -3 gpurun_out/r04_j_seg_call_timeline.txt; tail -2 gpurun_out/r04_j_seg_call_timeline.txt

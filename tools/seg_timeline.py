@@ -19,7 +19,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Stream_Id", r.get("Queue_Id", ""))))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2] == "k_mask_clean_overlap"]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_mask_clean_overlap")]
     if not starts:
         sys.exit("no segmentation call in the trace")
     want = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 1
@@ -30,7 +30,7 @@ def main():
     stream = rows[i0][3]
     rows = [r for r in rows[:i1 + 1] if r[3] == stream]
     i1 = len(rows) - 1
-    i0 = max(i for i, r in enumerate(rows) if r[2] == "k_mask_clean_overlap")
+    i0 = max(i for i, r in enumerate(rows) if r[2].startswith("k_mask_clean_overlap"))
     while i0 > 0 and rows[i0][0] - rows[i0 - 1][1] < 300_000:
         i0 -= 1
     t0 = rows[i0][0]

@@ -240,3 +240,49 @@ def test_segmentation_exchange_points_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _camworker(rank, world, port, q):
+    import torch
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w, d = ifd.init("gloo")
+    rng = np.random.RandomState(11)
+    root = 1
+    # exchange 5 with a tracking rank (op 5 | root << 8): the prediction block -- one owner per pixel, zeros elsewhere -- SUMmed as int32 words to the ROOT only; the
+    # 16-byte tail (vote mass) to everybody (op 1); exchange 310 (op 4 | root << 8): the 200-byte pose block broadcast from the root
+    full = rng.standard_normal((3000, 8)).astype(np.float32)
+    full[::53] = np.float32(-0.0); full[3::71] = np.nan
+    owner = rng.randint(0, world, 3000)
+    mine = np.where((owner == rank)[:, None], full, np.float32(0)).astype(np.float32)
+    before = mine.view(np.int32).copy()
+    t = torch.from_numpy(mine.view(np.int32).copy())
+    d.reduce(t, dst=root, op=d.ReduceOp.SUM)
+    tail = torch.tensor([100 + rank, 0, 0, 0], dtype=torch.int32)
+    d.all_reduce(tail, op=d.ReduceOp.SUM)
+    pose = torch.from_numpy(np.full(50, rank + 7, np.int32))
+    d.broadcast(pose, src=root)
+    q.put((rank, full.view(np.int32).copy(), before, t.numpy().copy(), tail.numpy().copy(), pose.numpy().copy()))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_camera_indexed_reduce_and_pose_broadcast_gloo():
+    """K streams, camera k tracked by rank k (BASELINE configuration 5): the prediction of camera k's frame is reduced to rank k alone (ifx_owner_exchange op 5 | root << 8:
+    ncclReduce in ifx_comm.hip, dist.reduce in the torch transport), its vote-mass tail all-reduced, the pose block broadcast from rank k (op 4 | root << 8) -- over gloo
+    with two ranks: the root ends with the unsharded image bit for bit, every rank with the summed tail and the root's pose block."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_camworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root = 1
+    assert np.array_equal(res[root][3], res[root][1])                   # the root holds the merged prediction
+    for r_ in res:
+        assert np.array_equal(r_[4], np.array([201, 0, 0, 0], np.int32))   # the tail reached everybody
+        assert np.array_equal(r_[5], np.full(50, root + 7, np.int32))       # the root's pose block everywhere

@@ -365,3 +365,224 @@ def test_cadence_decision_from_the_source(orc, small_stream):
     assert got == want, (got, want)
     assert seen_fast and seen_slow and sum(want) >= 5
     o.close()
+
+
+# ------------------------------------------------------------------------------------------------ a21
+def _sp_merge_restated(depth, seg_in, w, h, spn, cam):
+    """mergeSuperPixel, IF/Core/InstanceFusion_superpixel.cpp:45-160, with the kernels of IF/Core/InstanceFusionCuda.cu:144-735 and connectSuperPixel (:269-426), as plain
+    numpy / Python.  Where the reference is order-dependent the documented deterministic reading is taken ("deviations": exact sums, neighbour list =
+    the ascending set of distinct 4-neighbours, first 11; a -1 slot is skipped in the re-clustering)."""
+    f32 = np.float32
+    d = depth.astype(np.int64)
+    # depthMapGaussianfilterKernel (:144-168): all eight neighbours present; weights 4 / 2 / 1 over the non-zero ones; integer division
+    nz = d != 0
+    inner = np.zeros((h, w), bool); inner[1:-1, 1:-1] = True
+
+    def sh(a, dy, dx):
+        out = np.zeros_like(a)
+        ys = slice(max(0, dy), h + min(0, dy)); yd = slice(max(0, -dy), h + min(0, -dy))
+        xs = slice(max(0, dx), w + min(0, dx)); xd = slice(max(0, -dx), w + min(0, -dx))
+        out[yd, xd] = a[ys, xs]
+        return out
+
+    def all8(m):
+        ok = inner.copy()
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dy or dx:
+                    ok &= sh(m, dy, dx)
+        return ok
+
+    ok8 = all8(nz)
+    sm = np.zeros((h, w), np.int64); n = np.zeros((h, w), np.int64)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            wgt = 4 if (dy == 0 and dx == 0) else (2 if (dy == 0 or dx == 0) else 1)
+            v = sh(d, dy, dx)
+            sm += np.where(v != 0, wgt * v, 0); n += np.where(v != 0, wgt, 0)
+    dg = np.where(ok8 & (n > 0), sm // np.maximum(n, 1), 0).astype(np.int64)
+    # getVertex (:183-189): z = float(d) / 1186; ((x - cx) * z) * (1 / fx)
+    xs_, ys_ = np.meshgrid(np.arange(w), np.arange(h))
+    z = dg.astype(f32) / f32(1186.0)
+
+    def vertex(zz, xx, yy):
+        return np.stack([(xx.astype(f32) - f32(cam[0])) * zz * f32(cam[2]), (yy.astype(f32) - f32(cam[1])) * zz * f32(cam[3]), zz], -1).astype(f32)
+
+    V = vertex(z, xs_, ys_)
+    pos = np.where((dg != 0)[..., None], V, f32(0)).astype(f32)
+    # getNormal (:211-273): five cross products of one-sided / central differences, weights 4, 2, 2, 2, 2, normalised; only where all eight neighbours of the FILTERED depth exist
+    okn = all8(dg != 0)
+    vxf, vxb, vyf, vyb = (np.roll(V, -1, 1), np.roll(V, 1, 1), np.roll(V, -1, 0), np.roll(V, 1, 0))
+
+    def ncross(left, right, up, down):
+        dx_, dy_ = (left - right).astype(f32), (up - down).astype(f32)
+        return np.stack([dx_[..., 1] * dy_[..., 2] - dx_[..., 2] * dy_[..., 1], dx_[..., 2] * dy_[..., 0] - dx_[..., 0] * dy_[..., 2], dx_[..., 0] * dy_[..., 1] - dx_[..., 1] * dy_[..., 0]], -1).astype(f32)
+
+    s_ = (ncross(vxb, vxf, vyb, vyf) * f32(4)).astype(f32)
+    for (l_, r_, u_, dn_) in ((vxb, V, vyb, V), (V, vxf, vyb, V), (vxb, V, V, vyf), (V, vxf, V, vyf)):
+        s_ = (s_ + ncross(l_, r_, u_, dn_) * f32(2)).astype(f32)
+    with np.errstate(all="ignore"):
+        ln = np.sqrt((s_[..., 0] * s_[..., 0] + s_[..., 1] * s_[..., 1] + s_[..., 2] * s_[..., 2]).astype(f32)).astype(f32)
+        nor = np.where(okn[..., None], (s_ / ln[..., None]).astype(f32), f32(0)).astype(f32)
+    # kernel A (:351-371)
+    seg = seg_in.astype(np.int64).copy()
+    pn = (pos.astype(np.float64) ** 2).sum(-1) + (nor.astype(np.float64) ** 2).sum(-1)
+    with np.errstate(all="ignore"):
+        seg[~(pn.astype(f32) >= f32(0.01)) | (seg >= spn) | (seg < 0)] = -1   # (pnTest < 0.01, or NaN: the reference's `<` is false for NaN -- the oracle drops non-finite pixels)
+    seg[np.isnan(pn)] = -1
+    # kernel B (:373-440)
+    info = np.zeros((spn, 30), np.float64)
+    info[:, 18:29] = -1; info[:, 17] = 11
+    valid = seg >= 0
+    ids = seg[valid]
+    info[:, 0] = np.bincount(ids, minlength=spn)
+    for c in range(3):
+        info[:, 1 + c] = np.bincount(ids, weights=pos[..., c][valid].astype(np.float64), minlength=spn)
+        info[:, 4 + c] = np.bincount(ids, weights=nor[..., c][valid].astype(np.float64), minlength=spn)
+    info[:, 13] = np.bincount(ids, weights=dg[valid].astype(np.float64), minlength=spn)
+    nb = [set() for _ in range(spn)]
+    for dy, dx in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+        a = seg[1:-1, 1:-1]; b = seg[1 + dy:h - 1 + dy, 1 + dx:w - 1 + dx]
+        m = (a >= 0) & (b >= 0) & (a != b)
+        for i_, j_ in zip(a[m].tolist(), b[m].tolist()):
+            nb[i_].add(j_)
+    for i_ in range(spn):
+        lst = sorted(nb[i_])[:11]
+        info[i_, 18:18 + len(lst)] = lst
+    info = info.astype(f32)
+
+    def averages(I):   # kernels C / E (:496-527, :623-657)
+        for i_ in range(spn):
+            t = int(I[i_, 0])
+            if t != 0:
+                I[i_, 7:10] = I[i_, 1:4] / f32(t)
+                nx, ny, nz_ = I[i_, 4:7]
+                with np.errstate(all="ignore"):
+                    ln_ = np.sqrt(f32(nx * nx + ny * ny + nz_ * nz_))
+                    I[i_, 10:13] = I[i_, 4:7] / ln_
+                I[i_, 14] = I[i_, 13] / f32(t)
+
+    averages(info)
+    # kernel D (:530-621): every pixel looks at its superpixel's neighbours and itself; nearest by |plane distance| + centre distance; re-cluster
+    avg_pos, avg_nor, avg_dep = info[:, 7:10].astype(np.float64), info[:, 10:13].astype(np.float64), info[:, 14].astype(np.float64)
+    P_ = pos.reshape(-1, 3).astype(np.float64); Nn = nor.reshape(-1, 3).astype(np.float64)
+    sflat = seg.reshape(-1)
+    pix = np.nonzero(sflat >= 0)[0]
+    cand = np.concatenate([info[sflat[pix], 18:29].astype(np.int64), sflat[pix][:, None]], 1)      # eleven neighbours, then itself
+    best_d = np.full(len(pix), 999999.9); best_n = np.full(len(pix), 999999.9); best_id = sflat[pix].copy()
+    for c in range(12):
+        idt = cand[:, c]
+        okc = idt >= 0
+        it_ = np.where(okc, idt, 0)
+        A = avg_nor[it_]; B = avg_pos[it_] - P_[pix]
+        with np.errstate(all="ignore"):
+            la = np.sqrt((A * A).sum(1)); lb = np.sqrt((B * B).sum(1))
+            dist = np.abs((A * B).sum(1) / la) + lb
+        dn_ = ((np.abs(A - Nn[pix])) ** 2).sum(1)
+        take = okc & (dist < best_d)
+        best_d = np.where(take, dist, best_d); best_n = np.where(take, dn_, best_n); best_id = np.where(take, idt, best_id)
+    thr = (0.026 * avg_dep[best_id] - 4.0) / 1186.0
+    best_id = np.where(best_d > 2 * thr, -1, best_id)
+    I2 = info.astype(np.float64)
+    keep = best_id >= 0
+    I2[:, 15] += np.bincount(best_id[keep], weights=(best_d[keep] ** 2), minlength=spn)
+    I2[:, 16] += np.bincount(best_id[keep], weights=best_n[keep], minlength=spn)
+    mv = best_id != sflat[pix]
+    for sign, tgt in ((-1.0, sflat[pix][mv]), (1.0, best_id[mv])):
+        sel = tgt >= 0
+        tt = tgt[sel]
+        I2[:, 0] += sign * np.bincount(tt, minlength=spn)
+        for c in range(3):
+            I2[:, 1 + c] += sign * np.bincount(tt, weights=P_[pix][mv][sel][:, c], minlength=spn)
+            I2[:, 4 + c] += sign * np.bincount(tt, weights=Nn[pix][mv][sel][:, c], minlength=spn)
+        I2[:, 13] += sign * np.bincount(tt, weights=dg.reshape(-1)[pix][mv][sel].astype(np.float64), minlength=spn)
+    seg2 = sflat.copy(); seg2[pix] = best_id
+    info = I2.astype(f32)
+    for i_ in range(spn):   # kernel E's deviations, then the averages again
+        t = int(info[i_, 0])
+        if t != 0:
+            info[i_, 15] = np.sqrt(f32(info[i_, 15] / f32(t))); info[i_, 16] = np.sqrt(f32(info[i_, 16] / f32(t)))
+    averages(info)
+    # connectSuperPixel (:269-426), sequential as written
+    I = info.astype(np.float64)
+    I[:, 29] = -1
+    for i_ in range(spn):
+        for j_ in range(int(I[i_, 17])):
+            b_ = int(I[i_, 18 + j_])
+            if b_ == -1:
+                continue
+            va = I[i_, 10:13]; vb = I[i_, 7:10] - I[b_, 7:10]
+            with np.errstate(all="ignore"):
+                dist_term = abs(float(va @ vb) / np.sqrt(float(va @ va))) + np.sqrt(float(vb @ vb))
+            nor_term = 0.1 * np.sqrt(float(((np.abs(I[i_, 10:13] - I[b_, 10:13])) ** 2).sum()))
+            th_a = (0.026 * I[i_, 14] - 4.0) / 1186.0 + 2 * I[i_, 15]
+            th_b = (0.026 * I[b_, 14] - 4.0) / 1186.0 + 2 * I[b_, 15]
+            fin_test = dist_term + nor_term
+            if fin_test > th_a or fin_test > th_b:
+                I[i_, 18 + j_] = -1
+                for k_ in range(int(I[b_, 17])):
+                    if int(I[b_, 18 + k_]) == i_:
+                        I[b_, 18 + k_] = -1
+                        break
+    for i_ in range(spn):
+        final_id = i_ if I[i_, 29] == -1 else int(I[i_, 29])
+        stack = [i_]
+        while stack:
+            tg = stack.pop()
+            if I[tg, 29] != -1:
+                continue
+            I[tg, 29] = final_id
+            for j_ in range(int(I[tg, 17])):
+                c_ = int(I[tg, 18 + j_])
+                if c_ == -1 or I[c_, 29] != -1:
+                    continue
+                stack.append(c_)
+    final_of = I[:, 29].astype(np.int64)
+    fin = np.where(seg2 >= 0, final_of[np.maximum(seg2, 0)], seg2).reshape(h, w)
+    return seg2.reshape(h, w), fin, I
+
+
+def test_superpixel_merge_from_the_source(orc, gputest_pair):
+    """a21 on the reference's RGB-D pair: the oracle's SLIC labels (pinned to the reference's own code elsewhere) through mergeSuperPixel -- depth Gaussian, position /
+    normal maps, the re-clustering statistics (kernels A-E), connectSuperPixel, the final ids -- and maskSuperPixelFilter_OverSeg (:651-710), restated above from the
+    source.  Region ids are integers decided by float comparisons of sums: the two readings agree on all but a handful of threshold ties (f64 sums here, exact
+    fixed-point sums in the oracle), the per-superpixel statistics to float rounding."""
+    depth, rgb, _, w, h = _pair(gputest_pair)
+    o = orc.Oracle(w=w, h=h, fx=HALF_K["fx"], fy=HALF_K["fy"], cx=HALF_K["cx"], cy=HALF_K["cy"], max_surfels=100000)
+    seg0, nsp = o.slic_segment(rgb)
+    spn = (w * h) // 256
+    seg_o, fin_o, info_o = o.merge_superpixels(depth, seg0)
+    cam = (np.float32(HALF_K["cx"]), np.float32(HALF_K["cy"]), np.float32(1.0 / HALF_K["fx"]), np.float32(1.0 / HALF_K["fy"]))
+    seg_r, fin_r, info_r = _sp_merge_restated(depth, seg0, w, h, spn, cam)
+    assert (seg_o >= 0).mean() > 0.5 and len(np.unique(fin_o)) > 5                      # the pair has valid depth and more than a region or two
+    assert np.array_equal(seg_o < 0, seg_r < 0) or ((seg_o < 0) != (seg_r < 0)).mean() < 1e-3
+    assert (seg_o != seg_r).mean() < 2e-3, (seg_o != seg_r).mean()                      # re-clustered labels
+    used = info_o[:, 0] > 50
+    assert np.abs(info_o[used, 0] - info_r[used, 0]).max() <= 0.02 * info_o[used, 0].max()
+    assert np.allclose(info_o[used, 7:15], info_r[used, 7:15], rtol=2e-3, atol=2e-3)    # averages: position, normal, depth
+    # regions: the same partition up to the few ties -- compared as a partition (ids are representatives, and a tie can rename a whole region)
+    both = (fin_o >= 0) & (fin_r >= 0)
+    pairs = np.stack([fin_o[both], fin_r[both]], 1)
+    uniq, cnt = np.unique(pairs, axis=0, return_counts=True)
+    best_for_o = {}
+    for (a_, b_), c_ in zip(uniq.tolist(), cnt.tolist()):
+        if c_ > best_for_o.get(a_, (None, 0))[1]:
+            best_for_o[a_] = (b_, c_)
+    agree = sum(c_ for (a_, b_), c_ in zip(uniq.tolist(), cnt.tolist()) if best_for_o[a_][0] == b_)
+    assert agree / both.sum() > 0.98, agree / both.sum()
+    # maskSuperPixelFilter_OverSeg on the ORACLE's regions (so that the filter itself is what is compared): a mask keeps a region iff > 75 % of the region lies inside it
+    rng = np.random.RandomState(5)
+    masks = np.zeros((3, h, w), np.uint8)
+    masks[0, 40:160, 60:200] = 255; masks[1, 100:220, 150:300] = 255; masks[2] = (rng.rand(h, w) < 0.5) * 255
+    got = o.mask_superpixel_filter(fin_o, masks)
+    want = np.zeros_like(masks)
+    for rid in np.unique(fin_o[fin_o >= 0]):
+        if rid >= spn:
+            continue
+        reg = fin_o == rid
+        n_ = int(reg.sum())
+        for m_ in range(3):
+            if np.float32(int((masks[m_][reg] != 0).sum()) * np.float32(1.0) / np.float32(n_)) > 0.75:
+                want[m_][reg] = 255
+    assert np.array_equal(got, want)
+    o.close()

@@ -117,6 +117,7 @@ def main():
                     "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the `value_sharded` leg (the same stream into ONE map spatially sharded over the ranks of this run, reported beside the replicas' `value`)")
+    ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: seconds after which the line is printed without the sharded-map leg should that leg stall (0: wait for ever)")
     ap.add_argument("--extras-frames", type=int, default=60, help="frames of each extra leg at N = 1 (host entry point, closeLoops = true); 0 skips them")
     args = ap.parse_args()
 
@@ -278,9 +279,19 @@ def main():
         torch.cuda.synchronize()
         ef.sync()
 
+    # The interpreter's cyclic garbage collector is not part of what is measured: with torch imported a full collection walks ~10^6 objects (45-50 ms: seventy
+    # frames), and whether one falls into a timed window depends on the allocation history of everything before it (profiles/r04_t_*: one segmentation call of the
+    # fast-cadence leg "took" 45 ms in runs without --trace-steps and 0.36 ms with it).  Collected once here, the survivors frozen, and switched off inside the timed
+    # windows (a C++ host has no such pause; the C-ABI calls allocate nothing on the Python side that could form a cycle).
+    import gc
+
+    gc.collect()
+    gc.freeze()
+
     def timed(k_first, n, fn):
         """n frames through fn(k), bracketed by barrier + synchronize; returns seconds (this rank)."""
         barrier()
+        gc.disable()
         t0 = time.perf_counter()
         marks = []
         for k in range(k_first, k_first + n):
@@ -289,6 +300,7 @@ def main():
                 marks.append((time.perf_counter(), ef.view_list_stats().get("scans", 0) if sh is None else 0))
         barrier()
         t1 = time.perf_counter()
+        gc.enable()
         if args.trace_steps and rank == 0:   # host times of the steps (the host waits for every frame's result: they follow the device closely)
             ts = [m[0] for m in marks]
             sc = [m[1] for m in marks]
@@ -301,6 +313,8 @@ def main():
         step(k); k += 1
     barrier()
     ef.stage_ms(reset=True)
+    if osh is None:
+        ef.superpixel_ahead_stats(reset=True)
     place_call_in_window(args.steps)
     seg["calls"] = 0
     k_timed = k
@@ -310,6 +324,7 @@ def main():
     xstats = osh.exchange_stats() if osh is not None else None
     calls_in_window = seg["calls"]
     inst_ms = ef.stage_ms(reset=True)["instance"]          # the instance stage is always timed (two events per segmentation call)
+    sp_ahead = ef.superpixel_ahead_stats(reset=True) if osh is None else None   # superpixels run ahead of the calls on the side stream (their device time is not in inst_ms)
     traj = ef.trajectory()                                  # poses up to the end of the timed region
     traj_all = traj
     dt = ifd.max_over_ranks(dt, dist, device=f"cuda:{dev}")
@@ -475,34 +490,106 @@ def main():
         nf3 = min(L, 90)
         fc = dict(calls=0, timed_calls=0, t0=None, first=12)
 
+        trace3 = []
+
         def step3(i):
+            ta_ = time.perf_counter()
             if i + 1 < nf3 and not args.no_prefetch:
                 ef3.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
             ef3.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
-            if inst3.whetherDoSegmentation(100 + i):
+            tb_ = time.perf_counter()
+            fired = inst3.whetherDoSegmentation(100 + i)
+            tc_ = time.perf_counter()
+            if fired:
                 mk, cl = masks[i]
                 if mk.shape[0]:
                     inst3.ProcessSegmentation(None, None, mk, cl, i, superpixels=not args.no_superpixels)
                     fc["calls"] += 1
                     fc["timed_calls"] += 1 if i >= fc["first"] else 0
+            trace3.append((i, int(fired), (tb_ - ta_) * 1e6, (tc_ - tb_) * 1e6, (time.perf_counter() - tc_) * 1e6))
 
         for i in range(fc["first"]):
             step3(i)
         ef3.sync(); torch.cuda.synchronize()
         ef3.stage_ms(reset=True)
+        ef3.superpixel_ahead_stats(reset=True)
+        gc.disable()
         t0 = time.perf_counter()
         for i in range(fc["first"], nf3):
             step3(i)
-        ef3.sync(); torch.cuda.synchronize()
+        t3a = time.perf_counter()
+        ef3.sync()
+        t3b = time.perf_counter()
+        torch.cuda.synchronize()
         t3 = time.perf_counter() - t0
+        gc.enable()
+        print(f"fast cadence leg: steps {(t3a - t0) * 1e3:.2f} ms, handle sync {(t3b - t3a) * 1e3:.2f} ms, device sync {(t0 + t3 - t3b) * 1e3:.2f} ms", file=sys.stderr)
         inst3_ms = ef3.stage_ms(reset=True)["instance"]
+        sp3 = ef3.superpixel_ahead_stats(reset=True)
+        n3 = nf3 - fc["first"]
+        if args.trace_steps:   # host times of the leg's steps (us): enqueue of the frame | whetherDoSegmentation (waits for the frame's result) | the call
+            for r_ in trace3[fc["first"]:]:
+                print("fast cadence frame %2d fired %d  enqueue %6.0f  decide %6.0f  call %6.0f us" % r_, file=sys.stderr)
         n3 = nf3 - fc["first"]
         extras["value_fast_cadence"] = dict(value=round(n3 / t3, 2), unit="frames/s", frames=n3, segmentation_calls=fc["timed_calls"],
                                             frames_per_call=round(n3 / max(1, fc["timed_calls"]), 2), instance_ms_per_frame=round(inst3_ms / n3, 4),
-                                            instance_ms_per_call=round(inst3_ms / max(1, fc["timed_calls"]), 4), surfels_live=ef3.count,
+                                            instance_ms_per_call=round(inst3_ms / max(1, fc["timed_calls"]), 4),
+                                            superpixels_ahead=dict(runs=sp3["runs"], used_by_a_call=sp3["used"], ms_per_run_side_stream=round(sp3["ms"] / max(1, sp3["runs"]), 4)),
+                                            surfels_live=ef3.count,
+                                            host_us_median=dict(enqueue_frame=round(float(np.median([r_[2] for r_ in trace3[fc["first"]:]])), 1),
+                                                                decide=round(float(np.median([r_[3] for r_ in trace3[fc["first"]:]])), 1),
+                                                                call=round(float(np.median([r_[4] for r_ in trace3[fc["first"]:] if r_[1]] or [0.0])), 1)),
                                             what="the same stream into a map started from nothing: whetherDoSegmentation's fast cadence (a call every 3rd frame while less than 80 % of the "
                                                  "sampled id image is covered and the vote mass is low), resident frames + look-ahead as in `value`")
         ef3.close()
+
+    # ---- the line rank 0 prints.  Everything but the two legs that follow (the sharded map beside the replicas, the CPU baseline) is known here; the handle-side
+    # values are fetched now so that the builder touches no library state (the watchdog below may call it from a timer thread)
+    vl_stats = ef.view_list_stats()
+    x_ranks = osh.comm_ranks() if (osh is not None and xstats) else None
+    lc_diag = ef.loop_closure_diag() if args.close_loops else None
+
+    def build_line(sharded_leg_, cpu_):
+        fps = (1 if one_map else world) * args.steps / dt
+        out = {
+            "metric": "frames/s + ms/frame (ICP|fuse|instance) at 640x480, 5M surfels, 1/2/4/8 GPU",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if one_map else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.surfels}-surfel map, {W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}",
+                       "surfels_live": n_live, "surfel_slots": n_slots, "map_order": args.map_order, "parallelism": (f"spatially sharded map x{world}" if args.sharded else (f"sharded projection x{world}" if args.sharded_projection else f"replicas x{world}")), "loop_frames": L},
+            "ms_per_frame_gpu": {k_: round(v / args.steps, 4) for k_, v in stage.items()},
+            "instance": {"calls_in_window": calls_in_window, "ms_per_call": round(inst_ms / calls_in_window, 4) if calls_in_window else None,
+                         "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,
+                         "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call",
+                         # ms_per_call is the main-stream span of a call (what the frame loop waits for); the superpixels of a call the cadence announced run ahead of it
+                         # on the side stream, under the frame's tracker and map passes, and are timed there
+                         **({"superpixels_ahead": dict(runs=sp_ahead["runs"], used_by_a_call=sp_ahead["used"], ms_per_run_side_stream=round(sp_ahead["ms"] / max(1, sp_ahead["runs"]), 4))} if sp_ahead else {})},
+            **extras,
+            **({"value_sharded": sharded_leg_} if sharded_leg_ else {}),
+            "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": vl_stats,
+            **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
+                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": x_ranks}} if xstats else {}),
+            **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in lc_diag.items() if k_ != "est_pose"}} if args.close_loops else {}),
+            "roofline": roof, "cpu_baseline": cpu_,
+        }
+        return out
+
+    # The sharded leg at N > 1 is the one part of this benchmark that runs real multi-rank RCCL collectives enqueued by libifx.so.  Should it ever stall (a rank lost,
+    # a communicator that does not come up), the replicas' measurement above must not be lost with it: after --sharded-timeout seconds rank 0 prints the line without
+    # the leg (an "error" entry in its place) and every rank leaves.
+    wd = None
+    if want_sharded_leg and world > 1 and args.sharded_timeout > 0:
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                os.write(json_fd, (json.dumps(build_line({"error": f"the sharded leg did not finish within {args.sharded_timeout} s; the line is reported without it", "n_ranks": world}, None)) + "\n").encode())
+            os._exit(0)
+
+        wd = threading.Timer(args.sharded_timeout + (0 if rank == 0 else 5), _give_up)
+        wd.daemon = True
+        wd.start()
 
     # ---- the north star's partitioning beside the replicas: the SAME stream (rank 0's) into ONE map spatially sharded over the ranks of this run -- every rank stores
     # the surfels it owns, the exchanges of a frame are RCCL collectives enqueued by libifx.so.  At N = 1 a world of one: the fixed cost of the mode.
@@ -557,11 +644,13 @@ def main():
         barrier2()
         osh2.exchange_stats(reset=True)
         seg2["calls"] = 0
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(ns):
             step2(k2); k2 += 1
         barrier2()
         dt2 = time.perf_counter() - t0
+        gc.enable()
         xs2 = osh2.exchange_stats()
         dt2 = ifd.max_over_ranks(dt2, dist, device=f"cuda:{dev}")
         calls2 = seg2["calls"]
@@ -637,29 +726,11 @@ def main():
                 cpu["parity_in_bench"] = dict(poses=int(op.shape[0]), not_bit_equal=neq, max_abs_diff=float(np.abs(gp - op).max()),
                                               what="the CPU oracle's poses of the first frames of this run against the GPU path's own poses of the same frames (bit equality of all 16 entries)")
 
+    if wd is not None:
+        wd.cancel()
     if rank == 0:
-        fps = (1 if one_map else world) * args.steps / dt
-        out = {
-            "metric": "frames/s + ms/frame (ICP|fuse|instance) at 640x480, 5M surfels, 1/2/4/8 GPU",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if one_map else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.surfels}-surfel map, {W}x{H} synthetic RGBD stream, 3-level ICP+RGB + surfel fuse + canned-mask instance votes{'' if args.no_superpixels else ' with superpixel refinement'}{' + local loop-closure detection' if args.close_loops else ''}",
-                       "surfels_live": n_live, "surfel_slots": n_slots, "map_order": args.map_order, "parallelism": (f"spatially sharded map x{world}" if args.sharded else (f"sharded projection x{world}" if args.sharded_projection else f"replicas x{world}")), "loop_frames": L},
-            "ms_per_frame_gpu": {k_: round(v / args.steps, 4) for k_, v in stage.items()},
-            "instance": {"calls_in_window": calls_in_window, "ms_per_call": round(inst_ms / calls_in_window, 4) if calls_in_window else None,
-                         "cadence_frames": 3 if seg["fast"] else 46, "ms_per_frame_at_cadence": round(inst_ms / calls_in_window / (3 if seg["fast"] else 46), 4) if calls_in_window else None,
-                         "window_policy": "whetherDoSegmentation every frame; the cadence's phase is placed so that a window shorter than the cadence holds one call"},
-            **extras,
-            **({"value_sharded": sharded_leg} if sharded_leg else {}),
-            "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": ef.view_list_stats(),
-            **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
-                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": osh.comm_ranks()}} if xstats else {}),
-            **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in ef.loop_closure_diag().items() if k_ != "est_pose"}} if args.close_loops else {}),
-            "roofline": roof, "cpu_baseline": cpu,
-        }
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(build_line(sharded_leg, cpu)) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

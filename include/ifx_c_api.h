@@ -314,7 +314,7 @@ int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
  *                           next frame on; refused while a frame is announced ahead
  *   "reference_passes" 1  -- also run the BEFORE / INSTANCECOMPARE id renders of EF/ElasticFusion.cpp:679-680 (nobody on this path consumes them)
  *   "compact_every_frame" 1 -- remove tombstones after every clean (tests); "compact_divisor" d -- housekeeping compaction when tombstones > slots / d (default 8)
- *   "two_streams" 0       -- everything on one stream; "track_ahead" 0 -- do not enqueue the announced frame's tracker behind the current frame
+ *   "two_streams" 0       -- everything on one stream; "track_ahead" 0 -- do not enqueue the announced frame's tracker behind the current frame; "slic_ahead" 0 -- no superpixels ahead of a call
  *   "stage_timing" / "kernel_timing" 1 -- HIP-event records for ifx_stage_ms / ifx_kernel_ms (cost frame rate: off by default)
  *   "icp_blocks" n        -- cap on the blocks of a tracker reduction launch (0 = by image size)
  *   "raster_tiles" -1|0|1 -- tiled rasteriser (key tiles in LDS): by image size (on from 1 Mpixel) | off | on; results are identical either way
@@ -436,6 +436,13 @@ int ifx_mask_superpixel_filter(ifx_t* h, const int32_t* final_ids, uint8_t* mask
  * ifx_set_option(h, "stage_timing", 1) is on: every event record is a marker packet on the queue and the eight of a
  * frame cost about 4 % of the frame rate. */
 int ifx_stage_ms(ifx_t* h, float* ms4, int reset);
+/* Superpixels run ahead of a segmentation call.  When ifx_should_segment answers "not this frame" but its cadence says the NEXT frame will end with a call, and
+ * that frame is announced (ifx_hint_next_frame_device), SLIC + the superpixel merge of the announced frame -- work that reads the frame only, about half of a call's
+ * dispatches (gSLICr + IF/Core/InstanceFusion.cpp:722-738 steps -1_1, -1_2) -- are enqueued on the side stream at once, under that frame's tracker and map passes;
+ * ifx_process_segmentation(rgb = depth = NULL) of that frame then waits for one event instead of running them.  Same kernels, same images, same result.
+ * ms: device time of the runs on the side stream (NOT part of ifx_stage_ms's "instance", which is the main-stream span of the calls); runs / used: how many were
+ * enqueued and how many a call consumed (a hint that does not come true leaves its run unused).  Option "slic_ahead" 0 turns the look-ahead off. */
+int ifx_superpixel_ahead_stats(ifx_t* h, float* ms, int32_t* runs, int32_t* used, int reset);
 /* Average duration (ms) of the named kernel over its launches since the last reset, measured with
  * HIP events around each launch (enabled by ifx_set_option("kernel_timing",1)). */
 int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* launches);

@@ -156,6 +156,7 @@ _SIGS = {
     "ifx_merge_superpixels": (C.c_int, [_P, _P, _P, _P, _P]),
     "ifx_mask_superpixel_filter": (C.c_int, [_P, _P, _P, C.c_int]),
     "ifx_stage_ms": (C.c_int, [_P, _P, C.c_int]),
+    "ifx_superpixel_ahead_stats": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "ifx_kernel_ms": (C.c_int, [_P, C.c_char_p, _P, _P]),
 }
 
@@ -534,6 +535,14 @@ class ElasticFusion:
         out = np.zeros(4, np.float32)
         self._chk(self.L.ifx_stage_ms(self.handle, _ptr(out), int(reset)), "ifx_stage_ms")
         return dict(track=float(out[0]), fuse=float(out[1]), instance=float(out[2]), preprocess=float(out[3]))
+
+    def superpixel_ahead_stats(self, reset=False):
+        """Superpixels run ahead of segmentation calls on the side stream (ifx_superpixel_ahead_stats): device ms, runs enqueued, runs a call used."""
+        ms = C.c_float(0)
+        runs = C.c_int32(0)
+        used = C.c_int32(0)
+        self._chk(self.L.ifx_superpixel_ahead_stats(self.handle, C.byref(ms), C.byref(runs), C.byref(used), int(reset)), "ifx_superpixel_ahead_stats")
+        return dict(ms=float(ms.value), runs=int(runs.value), used=int(used.value))
 
     def kernel_ms(self, name):
         avg = C.c_float(0)

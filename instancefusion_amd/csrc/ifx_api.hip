@@ -71,6 +71,7 @@ struct StageTimer {
         if (e_ != hipSuccess) { g_err = std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_); ifx_destroy(h); return IFX_E_HIP; } \
     } while (0)
 
+extern "C" int ifx_set_option(ifx_t* h, const char* name, int value);
 extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
 {
     if (!cfg || !out) { g_err = "null argument"; return IFX_E_INVALID; }
@@ -176,6 +177,18 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     for (int k = 0; k < 16; k++) h->h_result->pose[k] = hs.pose[k];
     if (hipDeviceSynchronize() != hipSuccess) { g_err = "device synchronize failed after allocation"; ifx_destroy(h); return IFX_E_HIP; }
     *out = h;
+    if (const char* e = getenv("IFX_OPTS")) {   // debugging aid: "name=value,name=value" applied to every handle at creation (bisecting an option without touching the caller)
+        std::string all(e);
+        size_t p0 = 0;
+        while (p0 < all.size()) {
+            size_t p1 = all.find(',', p0);
+            if (p1 == std::string::npos) p1 = all.size();
+            const std::string kv = all.substr(p0, p1 - p0);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) ifx_set_option(h, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+            p0 = p1 + 1;
+        }
+    }
     return IFX_OK;
 }
 
@@ -193,6 +206,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_cam_ahead) hipEventDestroy(h->ev_cam_ahead);
+    if (h->ev_slic_ahead) hipEventDestroy(h->ev_slic_ahead);
     if (h->ev_cam_parked) hipEventDestroy(h->ev_cam_parked);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
@@ -269,6 +283,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "two_streams") h->opt_two_streams = value;
     else if (s == "stage_timing") h->opt_stage_timing = value;
     else if (s == "track_ahead") h->opt_track_ahead = value;
+    else if (s == "slic_ahead") h->opt_slic_ahead = value;
+    else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
     else if (s == "view_blocks") h->opt_view_blocks = std::max(0, std::min(65536, value));
@@ -341,27 +357,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
 // ------------------------------------------------------------------ frame orchestration
 __global__ void k_frame_result(DevState* __restrict__ st, FrameResult* __restrict__ out, float* __restrict__ traj_slot)
 {
-    // view-list frames: the resolve of the prediction accumulated the end-of-pass sums (k_splat_resolve, FinishFold) in sixteen partials
-    const int fold = st->fold_total;
-    int f_mass = 0, f_empty = 0, f_lit = 0;
-    if (fold && threadIdx.x < 16) {
-        f_mass = st->fold_acc[threadIdx.x][0]; f_empty = st->fold_acc[threadIdx.x][1]; f_lit = st->fold_acc[threadIdx.x][2];
-        st->fold_acc[threadIdx.x][0] = 0; st->fold_acc[threadIdx.x][1] = 0; st->fold_acc[threadIdx.x][2] = 0;
-    }
-    f_mass = wave_sum_i(f_mass); f_empty = wave_sum_i(f_empty); f_lit = wave_sum_i(f_lit);
-    if (threadIdx.x != 0) return;
-    if (fold) {
-        st->seg_acc[0] += f_mass; st->seg_acc[1] += f_empty;
-        st->dense_enough = ((float)f_lit / (float)fold > 0.75f) ? 1 : 0;   // EF/ElasticFusion.cpp:252-267
-        st->fold_total = 0;
-    }
-    out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
-    st->seg_acc[0] = 0; st->seg_acc[1] = 0;
-    for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
-    out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
-    out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
-    out->count = st->count; out->n_dead = st->n_dead; out->n_new = st->n_new; out->overflow = st->overflow;
-    out->gn_timeout = st->gn_timeout;
+    if (threadIdx.x < 64) frame_result_wave(st, out, traj_slot, 0, (int)threadIdx.x);   // (ifx_ctx.h: shared with the last block of k_splat_resolve)
 }
 
 // Frame side of frame `tick` into slot s (copy-in, bilateral + metric depth, frame pyramids, SO(3) pre-alignment).
@@ -398,6 +394,12 @@ int ifx_enqueue_hinted_frame_side(ifx* h)
     if (!h->hint_rgb || !h->opt_two_streams) { h->hint_rgb = nullptr; return IFX_OK; }
     const uint8_t* r = h->hint_rgb; const uint16_t* d = h->hint_depth;
     h->hint_rgb = nullptr; h->hint_depth = nullptr;
+    // Frame sides are ordered among themselves: each reads the image pyramid of the frame before it and all of them sum into the same SO(3) accumulators / ticket.
+    // On the side stream that order is the stream's; but the current frame's side may have run on the MAIN stream (the sharded entry does that for a frame that was
+    // not announced) -- its "slot ready" event orders the announced frame's side behind it (recorded on the side stream itself in the usual case: no wait at all).
+    // Without it the two ran side by side once in a few hundred frames: a garbled SO(3) start for the current frame (tests: the rare failure of
+    // test_owner_sharded_rccl_world_of_one_in_library at the frame after its host-pointer frame).
+    if (h->stream_b && h->slot[h->tick & 1].ready) HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->slot[h->tick & 1].ready, 0));
     return enqueue_frame_side(h, (h->tick + 1) & 1, h->tick + 1, r, d, 0);
 }
 
@@ -551,12 +553,15 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
             if (r) return r;
         }
     }
+    const int slot = h->n_traj % h->max_traj;
     {
         StageTimer t(h, 1);
+        h->result_fold_traj = h->d_traj + (size_t)slot * 16;   // (the prediction's resolve is the frame's last launch on the view-list path: it can take the frame result along)
+        h->result_folded = 0;
         ifx_map_predict(h);
+        h->result_fold_traj = nullptr;
     }
-    const int slot = h->n_traj % h->max_traj;
-    LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
+    if (!h->result_folded) LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
     hipEventRecord(f.released, h->stream);   // one marker: the side stream waits for it before it reuses the slot,
     h->ev_result = f.released;               // the host before it reads the frame result
     {
@@ -865,6 +870,8 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         ifx_drop_tracked(h);
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
         if (!prepared) {
+            // (a frame announced wrongly: the side stream may still be running the frame side of what was announced, into this slot and the shared SO(3) sums)
+            if (f.for_tick == h->tick && f.ready && h->opt_two_streams) HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
             const int two = h->opt_two_streams;
             h->opt_two_streams = 0;
             int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, src_kind);
@@ -1156,6 +1163,20 @@ extern "C" int ifx_stage_ms(ifx_t* h, float* ms4, int reset)
     stage_flush(h);
     for (int k = 0; k < 4; k++) ms4[k] = (float)h->stage_ms[k];
     if (reset) for (int k = 0; k < 4; k++) h->stage_ms[k] = 0;
+    return IFX_OK;
+}
+// Superpixels run ahead of a segmentation call on the side stream (ifx_superpixel_ahead): how many runs, how many a call then used, and -- with stage timing on --
+// the device time of the runs (ms, side stream; the "instance" entry of ifx_stage_ms is the main-stream span of the calls and does not contain it)
+extern "C" int ifx_superpixel_ahead_stats(ifx_t* h, float* ms, int32_t* runs, int32_t* used, int reset)
+{
+    if (!h) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
+    stage_flush(h);
+    if (ms) *ms = (float)h->stage_ms[4];
+    if (runs) *runs = h->slic_ahead_runs;
+    if (used) *used = h->slic_ahead_used;
+    if (reset) { h->stage_ms[4] = 0; h->slic_ahead_runs = 0; h->slic_ahead_used = 0; }
     return IFX_OK;
 }
 

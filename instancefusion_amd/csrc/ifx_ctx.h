@@ -51,6 +51,7 @@ struct DevState {
     int fold_acc[16][4];         // partial sums by blockIdx.x & 15: vote mass, empty lattice pixels, lit dense-test samples, -
     int first_live;              // lowest live slot: the reference's "surfel 0" (drawn as id 0 = "no surfel" in every id-carrying image; ifx_map.hip key_id)
     unsigned int append_ticket;  // last-block ticket of k_append_scan
+    unsigned int result_ticket;  // last-block ticket of k_splat_resolve when it also writes the frame result (FrameOut)
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
     // local loop-closure detection (EF/ElasticFusion.cpp:453-566).  The model-to-model tracker has a DevState of its own (ifx::d_m2m):
@@ -116,6 +117,43 @@ struct FrameResult {   // copied to pinned host memory at the end of every frame
     int gn_timeout;      // DevState::gn_timeout: levels re-run by the persistent kernel's fallback so far (ifx_tracker_fallbacks)
     int seg_counts[2];   // checkProjectDepthAndInstance sums of this frame (vote mass under every 10th pixel, pixels without a surfel)
 };
+
+// The frame result (pinned host memory) + the trajectory slot, by one wave.  Shared by k_frame_result (a launch of its own) and by k_splat_resolve's last block (the
+// view-list frame path: one dispatch less per frame).  folded_total > 0: the caller's own resolve accumulated DevState::fold_acc with agent-scope atomics in THIS
+// launch -- they are read and re-armed the same way; 0: whatever an earlier launch left in fold_total / fold_acc (plain accesses, ordered by the launch boundary).
+__device__ __forceinline__ void frame_result_wave(DevState* st, FrameResult* out, float* traj_slot, int folded_total, int lane)
+{
+    // view-list frames: the resolve of the prediction accumulated the end-of-pass sums (k_splat_resolve, FinishFold) in sixteen partials
+    const int fold = folded_total > 0 ? folded_total : st->fold_total;
+    int f_mass = 0, f_empty = 0, f_lit = 0;
+    if (fold && lane < 16) {
+        if (folded_total > 0) {
+            f_mass = __hip_atomic_load(&st->fold_acc[lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f_empty = __hip_atomic_load(&st->fold_acc[lane][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f_lit = __hip_atomic_load(&st->fold_acc[lane][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->fold_acc[lane][0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->fold_acc[lane][1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->fold_acc[lane][2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            f_mass = st->fold_acc[lane][0]; f_empty = st->fold_acc[lane][1]; f_lit = st->fold_acc[lane][2];
+            st->fold_acc[lane][0] = 0; st->fold_acc[lane][1] = 0; st->fold_acc[lane][2] = 0;
+        }
+    }
+    f_mass = wave_sum_i(f_mass); f_empty = wave_sum_i(f_empty); f_lit = wave_sum_i(f_lit);
+    if (lane != 0) return;
+    if (fold) {
+        st->seg_acc[0] += f_mass; st->seg_acc[1] += f_empty;
+        st->dense_enough = ((float)f_lit / (float)fold > 0.75f) ? 1 : 0;   // EF/ElasticFusion.cpp:252-267
+        if (folded_total <= 0) st->fold_total = 0;
+    }
+    out->seg_counts[0] = st->seg_acc[0]; out->seg_counts[1] = st->seg_acc[1];
+    st->seg_acc[0] = 0; st->seg_acc[1] = 0;
+    for (int k = 0; k < 16; k++) { out->pose[k] = st->pose[k]; traj_slot[k] = st->pose[k]; }
+    out->diag[0] = st->lastICPError; out->diag[1] = st->lastICPCount; out->diag[2] = st->lastRGBError; out->diag[3] = st->lastRGBCount;
+    out->diag[4] = st->lastSO3Error; out->diag[5] = st->lastSO3Count; out->diag[6] = st->weighting; out->diag[7] = st->dense_enough ? 0.f : 1.f;
+    out->count = st->count; out->n_dead = st->n_dead; out->n_new = st->n_new; out->overflow = st->overflow;
+    out->gn_timeout = st->gn_timeout;
+}
 
 struct Pyr {
     int w[IFX_NUM_PYRS], h[IFX_NUM_PYRS];
@@ -240,6 +278,10 @@ struct ifx {
     int shard_rank = 0, shard_n = 1;    // sharded projection: this rank's slice of the slots (ifx_set_shard)
     int opt_two_streams = 1;
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
+    int opt_fold_result = 1;            // view-list frames: the frame result is written by the last block of the frame's last launch (k_splat_resolve) instead of a launch of its own
+    float* result_fold_traj = nullptr;  // set by enqueue_frame around ifx_map_predict: the trajectory slot of the frame being finished (null: nobody asked)
+    int result_folded = 0;              // ifx_map_predict's answer: the resolve took the frame result along
+    int opt_slic_ahead = 1;             // when the cadence says the announced next frame ends with a segmentation call: its superpixels + merge (frame-only work) go to the side stream now
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
@@ -401,7 +443,11 @@ struct ifx {
     // timing
     hipEvent_t ev_stage[8];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> stage_pending;
-    double stage_ms[4] = {0, 0, 0, 0};
+    double stage_ms[5] = {0, 0, 0, 0, 0};   // track, fuse, instance (main-stream span of the calls), preprocess (side stream), superpixels run ahead (side stream)
+    // superpixels of the announced next frame, run ahead on the side stream (ifx_superpixel_ahead): the tick they belong to (-1: none), the event behind them
+    int slic_ahead_tick = -1;
+    hipEvent_t ev_slic_ahead = nullptr;
+    int slic_ahead_runs = 0, slic_ahead_used = 0;
     std::map<std::string, int> kname_id;
     std::vector<std::string> knames;
     std::vector<KernelTiming> ktimes;

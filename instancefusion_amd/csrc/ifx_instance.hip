@@ -18,7 +18,9 @@
 
 int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame);
 int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth);
-int ifx_superpixel_filter(ifx* h, int nm);
+int ifx_superpixel_filter(ifx* h, int nm, bool prepared = false);
+int ifx_superpixel_filter_prepare(ifx* h, int nm);
+int ifx_superpixel_ahead(ifx* h);
 
 // maskCleanOverlapKernel, IF/Core/InstanceFusionCuda.cu:118-131
 __global__ void k_mask_clean_overlap(uint8_t* __restrict__ masks, int nm, int P)
@@ -109,8 +111,12 @@ __device__ __forceinline__ void bbox_extend_box(int* b, const int* sb)
     if (sb[3] > __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&b[3], sb[3]);
 }
 #define PB_ROWS 32   // k_project_bbox: blocks of 32 x PB_ROWS pixels
+// MODE 0: instance boxes and mask boxes (the reference's two kernels as one).  The device-scheduled call splits them: MODE 1, the instance boxes -- the twelve vote
+// float4 of every pixel's surfel, the heavy half, and nothing of the masks -- is on the queue BEFORE the host copies the masks into pinned memory (and writes the model
+// depth under every pixel on the way: getProjectDepthMapKernel reads the same id); MODE 2, the mask boxes, follows the masks and needs one vote float4 per pixel.
+template <int MODE>
 __global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const float4* __restrict__ votes, int cap, const uint8_t* __restrict__ masks,
-                               int nm, int w, int h, int* __restrict__ bbox, IdMap im)
+                               int nm, int w, int h, int* __restrict__ bbox, IdMap im, const float4* __restrict__ pc = nullptr, uint16_t* __restrict__ pdm = nullptr)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & 63;
@@ -127,7 +133,18 @@ __global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* _
     const int id = idmap_slot(im, st->count, gid);   // (sharded map: the pixels whose surfel another rank owns extend that rank's partial boxes)
     bool has = inside && id >= 0;
     int maxNum = 0, maxID = -1, first = 0;
-    if (has) {
+    if (MODE == 1 && pdm && inside) {   // getProjectDepthMapKernel (k_project_depth) on the way
+        uint16_t o = 0;
+        if (id >= 0) {
+            const float4 p = pc[id];
+            const float dx = st->pose[3] - p.x, dy = st->pose[7] - p.y, dz = st->pose[11] - p.z;
+            o = (uint16_t)(sqrtf(dx * dx + dy * dy + dz * dz) * 1186);
+        }
+        pdm[k] = o;
+    }
+    if (MODE == 2) {
+        if (has) { int b_; vote_decode(VOTE4(votes, id, 0).x, first, b_); }
+    } else if (has) {
         float4 v[12];
 #pragma unroll
         for (int q = 0; q < 12; q++) v[q] = VOTE4(votes, id, q);
@@ -146,7 +163,7 @@ __global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* _
     }
     if (first == -1) has = false;   // instanceProjectMap[y*width+x] != -1 test (:915)
     // boxes of the projected instances: one reduction per distinct arg-max id in the wave (a wave rarely sees more than two or three)
-    const int key = (has && maxID != -1) ? maxID : -1;
+    const int key = (MODE != 2 && has && maxID != -1) ? maxID : -1;
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -156,7 +173,7 @@ __global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* _
         todo &= ~grp;
     }
     // boxes of the masks
-    for (int m0 = 0; m0 < nm; m0 += 8) {
+    for (int m0 = 0; MODE != 1 && m0 < nm; m0 += 8) {
         uint8_t mb[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) mb[u] = (has && m0 + u < nm) ? masks[(size_t)(m0 + u) * P + k] : (uint8_t)0;
@@ -174,7 +191,7 @@ __global__ void __launch_bounds__(32 * PB_ROWS) k_project_bbox(const DevState* _
         }
     }
     __syncthreads();
-    if (tid < NI && s_box[tid][1] >= s_box[tid][0]) bbox_extend_box(&bbox[tid * 4], s_box[tid]);
+    if (MODE != 2 && tid < NI && s_box[tid][1] >= s_box[tid][0]) bbox_extend_box(&bbox[tid * 4], s_box[tid]);
 }
 
 // getProjectDepthMapKernel, IF/Core/InstanceFusionCuda.cu:977-996
@@ -428,7 +445,8 @@ extern "C" int ifx_mask_clean_overlap(ifx_t* h, uint8_t* masks, int n)
 }
 
 // whetherDoSegmentation, IF/Core/InstanceFusion.cpp:192-238
-static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds = 0, bool resume = false);
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds = 0, bool resume = false,
+                                        bool verdict_by_caller = false);
 // maskGeometricFilter as a stage (host buffers): depth = model depth under the camera (u16, 1186 units per metre as
 // getProjectDepthMap produces it), masks in/out, ori = masks before clean-overlap, unavailable in/out
 extern "C" int ifx_mask_geometric_filter(ifx_t* h, const uint16_t* depth, uint8_t* masks, const uint8_t* ori, int n, uint8_t* unavailable)
@@ -478,7 +496,12 @@ extern "C" int ifx_should_segment(ifx_t* h, int frame)
     // Not this frame -- but if the cadence says "the next one", that frame draws the WHOLE id image while it rasterises its prediction (one pass over the same lists:
     // ~20 us) instead of leaving the rest of the image to the call (a walk of its own over the view lists + a resolve at the head of the call: ~80 us).  A hint only:
     // the decision is taken again on the next frame's own sums, and a call that finds the sparse image renders the rest as before (ifx_ids_ensure).
-    if (frame + 1 - h->last_seg_frame > gap) h->ids_full_hint = 1;
+    const bool next = frame + 1 - h->last_seg_frame > gap;
+    if (next) h->ids_full_hint = 1;
+    if (next || h->opt_slic_ahead == 2) {   // ... and its superpixels (frame-only work, half of a call) start now on the side stream, if the frame is announced
+        int r = ifx_superpixel_ahead(h);    // (option value 2, for tests: for every announced frame, whatever the cadence says)
+        if (r) return r;
+    }
     return 0;
 }
 
@@ -795,7 +818,8 @@ static FFArgs ff_args(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const u
     a.gate = nullptr;
     return a;
 }
-static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds, bool resume)
+// verdict_by_caller: the last step (a mask that lost more than 35 % is unusable) is left to the kernel the caller launches next (k_seg_register: one dispatch less on the call's chain)
+static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t* d_masks, const uint8_t* d_ori, int nm, uint8_t* d_unavail, int fixed_rounds, bool resume, bool verdict_by_caller)
 {
     const int P = h->P;
     size_t need = (size_t)nm * P;
@@ -842,7 +866,7 @@ static int mask_geometric_filter_device(ifx* h, const uint16_t* d_depth, uint8_t
     LAUNCH(h, "ff_count", per_px, dim3(256), k_ff_count, a);
     LAUNCH(h, "ff_select", per_px, dim3(256), k_ff_select, a);
     LAUNCH(h, "ff_apply", per_px, dim3(256), k_ff_apply, a);
-    LAUNCH(h, "ff_verdict", dim3(cdiv(nm, 64)), dim3(64), k_ff_verdict, a, d_unavail);
+    if (!verdict_by_caller) LAUNCH(h, "ff_verdict", dim3(cdiv(nm, 64)), dim3(64), k_ff_verdict, a, d_unavail);
     return IFX_OK;
 }
 
@@ -877,7 +901,7 @@ static int first_not_used(ifx* h)
 static int run_bboxes(ifx* h, int nm, std::vector<int>& bbox)
 {
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox<0>, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     bbox.resize((size_t)(NI + nm) * 4);
     HIPCHK(h, hipMemcpyAsync(bbox.data(), h->d_bbox, bbox.size() * 4, hipMemcpyDeviceToHost, h->cur));
@@ -905,7 +929,7 @@ static int oseg_launch_bboxes(ifx* h)
 {
     const int nm = h->oseg_nm;
     LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox<0>, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "bbox_flip", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_bbox_flip, h->d_bbox, NI + nm);
     h->oseg_pending = 1;
@@ -1123,11 +1147,13 @@ static int seg_host_mask_loop(ifx* h, int nm, const int32_t* class_ids, int m_st
 }
 // step 4: the label scan (countAndColourSurfelMap) -- restricted to what a call can have changed unless the votes were rewritten wholesale
 // `gate`: device pointer to (ff_incomplete, evict_at) of the device-side call, or null.  Returns 1 when the scan enqueued was the full one.
-static int seg_label_scan(ifx* h, const int* gate = nullptr)
+// default_done: the caller already ran k_colour_default in this call (it reads nothing a call changes -- a surfel whose votes the call then touches is recoloured by
+// k_count_colour_px, which treats the default colour as "none yet" -- so the device-scheduled call enqueues it before the masks are staged)
+static int seg_label_scan(ifx* h, const int* gate = nullptr, bool default_done = false)
 {
     const int P = h->P;
     if (h->opt_labels_incremental && !h->labels_stale_all) {
-        LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels, gate);
+        if (!default_done) LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels, gate);
         LAUNCH(h, "count_colour_px", dim3(cdiv(P, 256)), dim3(256), k_count_colour_px, h->d_state, h->ids_after, P, (const float4*)h->votes, h->cap, (const float2*)h->tm, (float2*)h->col,
                h->d_inst_color, h->labels, ifx_idmap(h), gate);
         return 0;
@@ -1208,38 +1234,54 @@ __global__ void k_seg_compare(SegCtl* __restrict__ s, const int* __restrict__ bb
     for (int t = threadIdx.x; t < NI; t += blockDim.x) s_cls[t] = s->inst_class[t];
     for (int t = threadIdx.x; t < NI * 4; t += blockDim.x) s_box[t] = bbox[t];
     __syncthreads();
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= s->nm) return;
-    const int* mb = bbox + (NI + m) * 4;
-    const int minX_m = mb[0], maxX_m = mb[1], minY_m = mb[2], maxY_m = mb[3];
-    s->target[m] = -1;
-    if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) { unavailable[m] = 1; s->best[m] = -1; return; }
-    const int cls = s->cls[m];
-    int best = -1;
-    for (int q = 0; q < NI; q++) {
-        if (s_cls[q] == -1 || cls != s_cls[q]) continue;
-        const int minX_i = s_box[q * 4], maxX_i = s_box[q * 4 + 1], minY_i = s_box[q * 4 + 2], maxY_i = s_box[q * 4 + 3];
-        if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
-        const float IW = (float)(min(maxX_i, maxX_m) - max(minX_i, minX_m));
-        const float IH = (float)(min(maxY_i, maxY_m) - max(minY_i, minY_m));
-        if (IW <= 0 || IH <= 0) continue;
-        const float I = IW * IH;
-        const float U = (float)(((maxX_i - minX_i) * (maxY_i - minY_i)) + ((maxX_m - minX_m) * (maxY_m - minY_m))) - I;
-        if (I / U > 0.5f) best = q;
+    // a wave per mask, its lanes over the instances: "the last instance over the threshold" is the largest matching index (one mask per thread walked the
+    // 96 instances one after the other: 13 us on the call's chain)
+    const int lane = threadIdx.x & 63, nm = s->nm;
+    for (int m = threadIdx.x >> 6; m < nm; m += blockDim.x >> 6) {
+        const int* mb = bbox + (NI + m) * 4;
+        const int minX_m = mb[0], maxX_m = mb[1], minY_m = mb[2], maxY_m = mb[3];
+        if (maxX_m <= minX_m || maxY_m <= minY_m || unavailable[m]) {   // (wave-uniform)
+            if (lane == 0) { s->target[m] = -1; unavailable[m] = 1; s->best[m] = -1; }
+            continue;
+        }
+        const int cls = s->cls[m];
+        int best = -1;
+        for (int q = lane; q < NI; q += 64) {
+            if (s_cls[q] == -1 || cls != s_cls[q]) continue;
+            const int minX_i = s_box[q * 4], maxX_i = s_box[q * 4 + 1], minY_i = s_box[q * 4 + 2], maxY_i = s_box[q * 4 + 3];
+            if (maxX_i <= minX_i || maxY_i <= minY_i) continue;
+            const float IW = (float)(min(maxX_i, maxX_m) - max(minX_i, minX_m));
+            const float IH = (float)(min(maxY_i, maxY_m) - max(minY_i, minY_m));
+            if (IW <= 0 || IH <= 0) continue;
+            const float I = IW * IH;
+            const float U = (float)(((maxX_i - minX_i) * (maxY_i - minY_i)) + ((maxX_m - minX_m) * (maxY_m - minY_m))) - I;
+            if (I / U > 0.5f) best = q;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, 64));
+        if (lane == 0) { s->target[m] = -1; s->best[m] = best > 0 ? best : -1; }
     }
-    s->best[m] = best > 0 ? best : -1;
 }
 // the registration decisions of the mask loop (:955-1010), sequential as in the reference: a mask without a match that is still usable takes the first free
 // slot of the table; when there is none the loop stops there (evict_at) and the host evicts (rare: 96 slots).  The table and the per-mask inputs are staged in LDS
 // by the whole block; one lane then walks the masks.
-__global__ void k_seg_register(SegCtl* __restrict__ s, const uint8_t* __restrict__ unavailable, const int* __restrict__ ff_gate)
+// ff_meta / ff_skip (optional): the flood fill's per-mask counters -- the fill's verdict (k_ff_verdict: a mask that kept less than 65 % of its pixels is unusable) is
+// taken here, while the per-mask inputs are staged, instead of in a launch of its own.
+__global__ void k_seg_register(SegCtl* __restrict__ s, uint8_t* __restrict__ unavailable, const int* __restrict__ ff_gate, const int* __restrict__ ff_meta, const uint8_t* __restrict__ ff_skip)
 {
     __shared__ int s_cls[NI], s_best[256], s_mcls[256], s_tgt[256];
     __shared__ unsigned char s_un[256];
     const int nm = s->nm;
-    for (int t = threadIdx.x; t < NI; t += blockDim.x) s_cls[t] = s->inst_class[t];
-    for (int t = threadIdx.x; t < nm; t += blockDim.x) { s_best[t] = s->best[t]; s_mcls[t] = s->cls[t]; s_un[t] = unavailable[t]; s_tgt[t] = -1; }
     const int gate = ff_gate ? *ff_gate : 0;
+    for (int t = threadIdx.x; t < NI; t += blockDim.x) s_cls[t] = s->inst_class[t];
+    for (int t = threadIdx.x; t < nm; t += blockDim.x) {
+        unsigned char un = unavailable[t];
+        if (ff_meta && !gate && !ff_skip[t]) {
+            const float finalPoints = (float)ff_meta[t * 32 + 2], oriPoints = (float)ff_meta[t * 32];
+            if (finalPoints / oriPoints < 0.65f) { un = 1; unavailable[t] = 1; }
+        }
+        s_best[t] = s->best[t]; s_mcls[t] = s->cls[t]; s_un[t] = un; s_tgt[t] = -1;
+    }
     __syncthreads();
     __shared__ int s_evict;
     if (threadIdx.x == 0) {
@@ -1346,6 +1388,14 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     if (flags & 2) {   // superpixels and their merge: on the queue before the masks are even copied (they need the frame only)
         if ((r = ifx_superpixel_begin(h, rgb, depth))) { h->event_pool.push_back(ea); return r; }
     }
+    // what needs the map and the id image but not the masks -- the boxes of the projected instances (the twelve vote float4 under every pixel: the heavy half of
+    // getProjectInstanceList / computeProjectBoundingBox) and the model depth under every pixel -- runs while the host copies the masks into pinned memory
+    LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
+    LAUNCH(h, "project_bbox_inst", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox<1>, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, (const uint8_t*)nullptr, nm,
+           h->w, h->h, h->d_bbox, ifx_idmap(h), (const float4*)h->pc, h->d_pdm);
+    const bool default_early = h->opt_labels_incremental && !h->labels_stale_all;
+    if (default_early) LAUNCH(h, "colour_default", dim3(2048), dim3(256), k_colour_default, h->d_state, (const float2*)h->tm, (float2*)h->col, h->labels, (const int*)nullptr);
+    if (flags & 2) { if ((r = ifx_superpixel_filter_prepare(h, nm))) return r; }
     memcpy(h->h_masks_stage, masks_in, mbytes);
     hc->ff_incomplete = 0; hc->evict_at = -1; hc->nm = nm; hc->pad = 0;
     for (int i = 0; i < NI; i++) hc->inst_class[i] = h->inst_class[i];
@@ -1355,25 +1405,23 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     HIPCHK(h, hipMemcpyAsync(h->d_segctl, hc, sizeof(SegCtl), hipMemcpyHostToDevice, h->cur));
     LAUNCH(h, "mask_clean_overlap", dim3(cdiv(P, 256)), dim3(256), k_mask_clean_overlap_from, (const uint8_t*)h->d_masks_ori, h->d_masks, nm, P, h->d_unavail);
     if (flags & 2) {
-        r = ifx_superpixel_filter(h, nm);
+        r = ifx_superpixel_filter(h, nm, true);
         if (r) return r;
     }
     SegCtl* dc = (SegCtl*)h->d_segctl;
-    LAUNCH(h, "init_bbox", dim3(cdiv((NI + nm) * 4, 256)), dim3(256), k_init_bbox, h->d_bbox, NI + nm, h->w, h->h);
-    LAUNCH(h, "project_bbox", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
+    LAUNCH(h, "project_bbox_mask", dim3(cdiv(h->w, 32), cdiv(h->h, PB_ROWS)), dim3(32, PB_ROWS), k_project_bbox<2>, h->d_state, h->ids_after, (const float4*)h->votes, h->cap, h->d_masks, nm, h->w, h->h,
            h->d_bbox, ifx_idmap(h));
     LAUNCH(h, "seg_compare", dim3(1), dim3(256), k_seg_compare, dc, (const int*)h->d_bbox, h->d_unavail);
-    LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));
     const int rounds = h->opt_ff_rounds > 0 ? h->opt_ff_rounds : (h->opt_ff_union ? 4 : 24);   // (after the union-find start the first relaxation normally finds the fixpoint: the rest are spares for one-way edges)
-    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, rounds);
+    r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, rounds, false, true);
     if (r) return r;
     const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);
     const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
-    LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, gate);
+    LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, gate, (const int*)fa.meta, fa.skip);
     LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
     // the scan kernels look at the control block themselves: when the call has to be finished by the host (fill incomplete / table full) they return at once and
     // the ONE scan of the call runs behind the host-driven tail, after every mask and the eviction -- colours are assigned once, so an early scan would be visible
-    const int full_scan = seg_label_scan(h, (const int*)dc);
+    const int full_scan = seg_label_scan(h, (const int*)dc, default_early);
     uint8_t* h_un = (uint8_t*)h->h_segctl + sizeof(SegCtl);
     HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
     HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));
@@ -1385,7 +1433,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     if (hc->ff_incomplete) {   // the fill needs more relaxations than the schedule holds: finish it with the host looking, then the tail again (nothing was voted yet)
         r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
         if (r) return r;
-        LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, (const uint8_t*)h->d_unavail, (const int*)nullptr);
+        LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, (const int*)nullptr, (const int*)nullptr, (const uint8_t*)nullptr);
         LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
         const int full2 = seg_label_scan(h, (const int*)dc);   // (gated again: the table may turn out full at some mask)
         HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));

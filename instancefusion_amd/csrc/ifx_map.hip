@@ -440,9 +440,16 @@ __global__ void k_ids_resolve(unsigned long long* __restrict__ keys, int P, int3
 // hide under the kernel instead of being a 12 us launch of their own.  Block totals go to sixteen partials (DevState::fold_acc), k_frame_result folds them.
 struct FinishFold {
     int* acc;             // null: off
-    int* total;
+    int* total;           // null: the same launch also writes the frame result (FrameOut) and is told the total itself
     const float4* votes;
     int cap, ds, rw, rh;
+};
+// The frame result written by the resolve's last block (the view-list frame path: the resolve is the frame's last launch, and what k_frame_result would read is
+// complete when its last block is): one dispatch less on every frame's chain.
+struct FrameOut {
+    FrameResult* out;     // null: off
+    float* traj;
+    int fold_total;
 };
 
 // combo_splat.frag:54-66 outputs for the winner of each pixel, fused with FillIn
@@ -548,7 +555,7 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
         }
         __syncthreads();
         if (lt < 3 && s_f[lt]) atomicAdd(fold.acc + (blockIdx.x & 15) * 4 + lt, s_f[lt]);
-        if (lt == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fold.total = fold.rw * fold.rh;
+        if (fold.total && lt == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fold.total = fold.rw * fold.rh;
     }
     if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
     // fill-in
@@ -573,9 +580,25 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr,
+                                FrameOut fo = FrameOut{nullptr, nullptr, 0})
 {
     splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step, own_slot);
+    if (!fo.out) return;
+    // the block that finishes last writes the frame result: every block's fold atomics are performed (vmcnt drained) before its ticket
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DevState* stw = const_cast<DevState*>(st);
+    const int lt = threadIdx.y * blockDim.x + threadIdx.x;
+    if (lt == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(&stw->result_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x * gridDim.y - 1u);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (lt == 0) __hip_atomic_store(&stw->result_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lt < 64) frame_result_wave(stw, fo.out, fo.traj, fo.fold_total, lt);
 }
 // the two renders of the loop-closure detection (ACTIVE into the act* images, INACTIVE into the old* images) resolved by one launch: blockIdx.z picks the render
 struct ResolveTarget { unsigned long long* keys; float4 *pv, *pn; uchar4 *pimg, *pinst; uint16_t* ptime; };
@@ -1755,10 +1778,16 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
             ff.acc = &h->d_state->fold_acc[0][0]; ff.total = &h->d_state->fold_total;
             ff.votes = (const float4*)h->votes; ff.cap = h->cap; ff.ds = 10; ff.rw = h->w / 20; ff.rh = h->h / 20;
         }
+        FrameOut fo = FrameOut{nullptr, nullptr, 0};
+        if (ff.acc && h->result_fold_traj && h->opt_fold_result) {   // this resolve is the frame's last launch (enqueue_frame asked): its last block writes the frame result
+            fo.out = h->h_result; fo.traj = h->result_fold_traj; fo.fold_total = ff.rw * ff.rh;
+            ff.total = nullptr;
+            h->result_folded = 1;
+        }
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
-               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step);
+               h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step, (const int32_t*)nullptr, fo);
         if (ff.acc) return;   // (the view-list pass leaves list 0 alone: nothing to re-arm)
     } else if (want & LIST_IDS) LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, ids_out);
     // dense flag, list re-arm and (frame path: the id image is ids_after) the whetherDoSegmentation sums

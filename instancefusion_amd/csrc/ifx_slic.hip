@@ -702,8 +702,11 @@ int dev_alloc(ifx* h, T** p, size_t n)
     return IFX_OK;
 }
 
-int slic_buffers(ifx* h, SlicBuf** out)
+int slic_buffers(ifx* h, SlicBuf** out, bool ahead = false)
 {
+    // superpixels run ahead for a frame whose call never came (the hint was only a hint): the side stream may still be writing the buffers -- whoever uses them next
+    // on another stream queues behind that run
+    if (!ahead && h->slic_ahead_tick >= 0) { HIPCHK(h, hipStreamWaitEvent(h->cur, h->ev_slic_ahead, 0)); h->slic_ahead_tick = -1; }
     if (h->slic) { *out = (SlicBuf*)h->slic; return IFX_OK; }
     if (h->w < SPX || h->h < SPX) { h->err = "image smaller than one superpixel"; return IFX_E_INVALID; }
     SlicBuf* b = new SlicBuf();
@@ -772,10 +775,25 @@ int merge_run(ifx* h, SlicBuf* b)
 
 // masks live in `d_masks` ([nm][P] on the device) and are rewritten in place.  by_superpixel: count per
 // re-clustered superpixel (b->seg) and fold through final_of (fused path); otherwise count b->fin directly.
-int filter_run(ifx* h, SlicBuf* b, uint8_t* d_masks, int nm, bool by_superpixel)
+// the counters of the region filter, cleared: nothing of the masks in it, so the device-scheduled call enqueues it before the masks are staged (`prepared`)
+static int filter_prepare(ifx* h, SlicBuf* b, int nm)
+{
+    const int S = b->spn;
+    size_t need = (size_t)(nm + 1) * S;
+    if (need > b->num_cap) {
+        if (b->num) hipFree(b->num);
+        b->num = nullptr; b->num_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&b->num, need * 2 * 4));
+        b->num_cap = need;
+    }
+    HIPCHK(h, hipMemsetAsync(b->num + need, 0, need * 4, h->cur));
+    return IFX_OK;
+}
+int filter_run(ifx* h, SlicBuf* b, uint8_t* d_masks, int nm, bool by_superpixel, bool prepared = false)
 {
     const int P = b->P, S = b->spn;
     size_t need = (size_t)(nm + 1) * S;
+    if (by_superpixel && !prepared) { int r = filter_prepare(h, b, nm); if (r) return r; }
     if (need > b->num_cap) {
         if (b->num) hipFree(b->num);
         b->num = nullptr; b->num_cap = 0;
@@ -785,7 +803,6 @@ int filter_run(ifx* h, SlicBuf* b, uint8_t* d_masks, int nm, bool by_superpixel)
     int* num_key = b->num + need;
     dim3 cells(cdiv(h->w, 16), cdiv(h->h, 16)), tile(16, 16);
     if (by_superpixel) {
-        HIPCHK(h, hipMemsetAsync(num_key, 0, need * 4, h->cur));
         LAUNCH(h, "sp_count", cells, tile, k_sp_count, b->seg, d_masks, nm, h->w, h->h, S, num_key);
         hipEvent_t ea_ = nullptr;
         if (h->opt_kernel_timing) ifx_ktime_begin(h, "sp_count_regions", &ea_);
@@ -840,18 +857,59 @@ static int slic_load_frame(ifx* h, SlicBuf* b, const uint8_t* rgb, const uint16_
 int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth)
 {
     SlicBuf* b;
+    if (!rgb && !depth && h->tick >= 2 && h->slic_ahead_tick == h->tick - 1) {   // the resident frame's superpixels ran ahead on the side stream: the call queues behind them
+        HIPCHK(h, hipStreamWaitEvent(h->cur, h->ev_slic_ahead, 0));
+        h->slic_ahead_tick = -1;
+        h->slic_ahead_used++;
+        return IFX_OK;
+    }
     int r = slic_buffers(h, &b);
     if (r) return r;
     if ((r = slic_load_frame(h, b, rgb, depth))) return r;
     if ((r = slic_run(h, b))) return r;
     return merge_run(h, b);
 }
-int ifx_superpixel_filter(ifx* h, int nm)
+// Look-ahead of a segmentation call (ifx_should_segment: "not this frame, but the cadence says the next one").  SLIC and the superpixel merge read the frame only
+// -- 27 dispatches, about half of a call -- and the announced next frame's raw images are already in their frame slot (copied there by its frame side, on the side
+// stream): the same stream runs them now, under the next frame's tracker and map passes, and the call that comes waits for one event instead.  The same kernels on
+// the same images: nothing about the result changes.  A call that does not come leaves the run unused (slic_buffers orders the next user behind it).
+int ifx_superpixel_ahead(ifx* h)
+{
+    if (!h->opt_slic_ahead || !h->opt_two_streams || !h->stream_b || h->own) return IFX_OK;
+    const FrameSlot& f = h->slot[h->tick & 1];
+    if (f.for_tick != h->tick || h->slic_ahead_tick == h->tick) return IFX_OK;   // no frame announced ahead (or done already)
+    if (h->tick >= 2 && h->slic_ahead_tick == h->tick - 1) return IFX_OK;        // the run for the frame just processed may still be claimed by that frame's call: the buffers are its
+    SlicBuf* b;
+    int r = slic_buffers(h, &b, true);   // (an unused earlier run: this one queues behind it on the same stream anyway; calls are synchronous, so the main stream holds no claim on the buffers)
+    if (r) return r;
+    if (!h->ev_slic_ahead) HIPCHK(h, hipEventCreateWithFlags(&h->ev_slic_ahead, hipEventDisableTiming));
+    hipStream_t keep = h->cur;
+    h->cur = h->stream_b;
+    hipEvent_t ta = nullptr;
+    ta = ifx_event_get(h); hipEventRecord(ta, h->cur);   // (always timed, like the calls themselves: two events per run)
+    b->cur_rgb = f.rgb; b->cur_depth = f.depth_raw;   // behind the slot's copy-in on the same stream; the slot is reused two frames on, by the same stream
+    if (!(r = slic_run(h, b))) r = merge_run(h, b);
+    if (ta) { hipEvent_t tb = ifx_event_get(h); hipEventRecord(tb, h->cur); h->stage_pending.push_back({4, {ta, tb}}); }
+    hipEventRecord(h->ev_slic_ahead, h->stream_b);
+    h->cur = keep;
+    if (r) return r;
+    h->slic_ahead_tick = h->tick;
+    h->slic_ahead_runs++;
+    return IFX_OK;
+}
+int ifx_superpixel_filter(ifx* h, int nm, bool prepared)
 {
     SlicBuf* b;
     int r = slic_buffers(h, &b);
     if (r) return r;
-    return filter_run(h, b, h->d_masks, nm, true);
+    return filter_run(h, b, h->d_masks, nm, true, prepared);
+}
+int ifx_superpixel_filter_prepare(ifx* h, int nm)
+{
+    SlicBuf* b;
+    int r = slic_buffers(h, &b);
+    if (r) return r;
+    return filter_prepare(h, b, nm);
 }
 
 int ifx_superpixel_refine(ifx* h, const uint8_t* rgb, const uint16_t* depth, int nm, int frame)

@@ -1323,6 +1323,8 @@ def test_lookahead_equivalence(ifx, small_stream, flann):
             g.set_option("track_ahead", 0)
         if mode == "hint_housekeeping":
             g.set_option("compact_divisor", 1 << 30)   # compaction before every frame that follows one with a deletion
+        if mode == "hint_result_launch":
+            g.set_option("fold_result", 0)             # the frame result by a launch of its own instead of the last block of the prediction's resolve
         for i in range(n):
             if mode.startswith("hint") and i + 1 < n:
                 g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
@@ -1343,7 +1345,7 @@ def test_lookahead_equivalence(ifx, small_stream, flann):
 
     ref = run("single")
     assert (ref[4] >= 0).sum() > 100   # the calls labelled something
-    for mode in ("plain", "hint", "hint_resident", "hint_no_track_ahead", "prefetch", "wrong_hint", "hint_housekeeping"):
+    for mode in ("plain", "hint", "hint_resident", "hint_no_track_ahead", "prefetch", "wrong_hint", "hint_housekeeping", "hint_result_launch"):
         t, m, ids, seg, lab = run(mode)
         assert np.array_equal(lab, ref[4]), mode
         assert seg == ref[3], mode
@@ -1359,6 +1361,47 @@ def test_lookahead_equivalence(ifx, small_stream, flann):
         poses = np.stack([g.processFrame(st["rgb"][i], st["depth"][i]) for i in range(n)])
         g.close()
         assert np.array_equal(poses, ref[0][:n])
+
+
+def test_superpixels_ahead_of_a_call_change_nothing(ifx):
+    """When whetherDoSegmentation's cadence announces a call for the next frame and that frame is announced too, its SLIC + superpixel merge run ahead on the side stream
+    (ifx_superpixel_ahead_stats) and the call waits for one event instead.  Here with option slic_ahead = 2 (a run ahead for EVERY announced frame): calls that use
+    such a run, runs whose call never comes, calls whose frame had none -- the same decisions, map, votes, labels and id image as with the look-ahead switched off.
+    (The cadence-driven default is what bench.py's fast-cadence leg runs: its JSON carries runs / used_by_a_call.)"""
+    import torch
+
+    from instancefusion_amd import synth
+
+    n = 16
+    st = synth.make_stream(n, SMALL["w"], SMALL["h"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], noise=True)
+    d_rgb = torch.from_numpy(st["rgb"][:n].copy()).cuda()
+    d_dep = torch.from_numpy(st["depth"][:n].view(np.int16).copy()).cuda()
+    torch.cuda.synchronize()
+    outs = []
+    for ahead in (0, 2):
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
+        inst = ifx.InstanceFusion(g)
+        g.set_option("slic_ahead", ahead)
+        fired = []
+        for i in range(n):
+            if i + 1 < n and i != 10:   # (frame 11 is not announced: its call finds no run ahead)
+                g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+            g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            fired.append(inst.whetherDoSegmentation(10 + i))
+            if i in (5, 9, 11, 12, 13):
+                mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
+                inst.ProcessSegmentation(None, None, mk, cl, 10 + i, superpixels=True)
+        g.sync()
+        stats = g.superpixel_ahead_stats()
+        outs.append((fired, g.trajectory(), g.download(), inst.labels(), g.image("ids_after"), stats))
+        g.close()
+    a, b = outs
+    assert a[5]["runs"] == 0 and a[5]["used"] == 0
+    assert b[5]["runs"] >= 5 and 1 <= b[5]["used"] <= 4 and b[5]["used"] < b[5]["runs"], b[5]
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert (a[3] >= 0).sum() > 100
+    assert all(np.array_equal(a[2][k], b[2][k]) for k in a[2]), [k for k in a[2] if not np.array_equal(a[2][k], b[2][k])]
 
 
 def test_segmentation_call_on_the_resident_frame(ifx):

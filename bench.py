@@ -117,6 +117,7 @@ def main():
                     "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the `value_sharded` leg (the same stream into ONE map spatially sharded over the ranks of this run, reported beside the replicas' `value`)")
+    ap.add_argument("--config5-sets", type=int, default=6, help="N = 1: frame sets (8 cameras each) of the configuration-5 leg inside the sharded leg; 0 skips it")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: seconds after which the line is printed without the sharded-map leg should that leg stall (0: wait for ever)")
     ap.add_argument("--extras-frames", type=int, default=60, help="frames of each extra leg at N = 1 (host entry point, closeLoops = true); 0 skips them")
     args = ap.parse_args()
@@ -595,82 +596,142 @@ def main():
     # the surfels it owns, the exchanges of a frame are RCCL collectives enqueued by libifx.so.  At N = 1 a world of one: the fixed cost of the mode.
     sharded_leg = None
     if want_sharded_leg:
-        from instancefusion_amd import sharded as ifsh
+        try:   # (at N > 1 the one part that depends on multi-rank RCCL: a failure here is reported in the line, it does not take the replicas' measurement with it)
+            from instancefusion_amd import sharded as ifsh
 
-        ns = min(args.steps, max(args.extras_frames, 40)) if world == 1 else min(args.steps, 100)
-        if world > 1:   # every rank is fed rank 0's stream and map
-            st2 = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED, **K) if rank != 0 else st
-            m2 = synth.make_map(args.surfels, st2["scene"], st2["poses_world"][0], tick0, seed=synth.SEED + 7, order=args.map_order) if rank != 0 else m
-            d_rgb2 = torch.from_numpy(st2["rgb"]).cuda(dev) if rank != 0 else d_rgb
-            d_dep2 = torch.from_numpy(st2["depth"].view(np.int16)).cuda(dev) if rank != 0 else d_dep
-            masks2 = [synth.canned_masks(st2["obj"][i], st2["scene"]) for i in range(L)] if rank != 0 else masks
-        else:
-            st2, m2, d_rgb2, d_dep2, masks2 = st, m, d_rgb, d_dep, masks
-        ef.sync()
-        ef2 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap // world + P + 500_000, device=dev, **K, n_ranks=(world if world > 1 else -1), rank=rank)
-        inst2 = ifx.InstanceFusion(ef2)
-        for kv in args.opt:
-            k_, v_ = kv.split("=")
-            ef2.set_option(k_, int(v_))
-        osh2 = ifsh.OwnerShardedElasticFusion(ef2, dist)
-        osh2.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
-        ef2.upload(m2)
-        ef2.set_pose(st2["poses"][0], tick0)
-        osh2.predict()
-        del m2, m
-        seg2 = dict(frame=0, calls=0)
+            ns = min(args.steps, max(args.extras_frames, 40)) if world == 1 else min(args.steps, 100)
+            if world > 1:   # every rank is fed rank 0's stream and map
+                st2 = synth.make_stream(L, W, H, noise=True, loop_len=L, seed=synth.SEED, **K) if rank != 0 else st
+                m2 = synth.make_map(args.surfels, st2["scene"], st2["poses_world"][0], tick0, seed=synth.SEED + 7, order=args.map_order) if rank != 0 else m
+                d_rgb2 = torch.from_numpy(st2["rgb"]).cuda(dev) if rank != 0 else d_rgb
+                d_dep2 = torch.from_numpy(st2["depth"].view(np.int16)).cuda(dev) if rank != 0 else d_dep
+                masks2 = [synth.canned_masks(st2["obj"][i], st2["scene"]) for i in range(L)] if rank != 0 else masks
+            else:
+                st2, m2, d_rgb2, d_dep2, masks2 = st, m, d_rgb, d_dep, masks
+            ef.sync()
+            ef2 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap // world + P + 500_000, device=dev, **K, n_ranks=(world if world > 1 else -1), rank=rank)
+            inst2 = ifx.InstanceFusion(ef2)
+            for kv in args.opt:
+                k_, v_ = kv.split("=")
+                ef2.set_option(k_, int(v_))
+            osh2 = ifsh.OwnerShardedElasticFusion(ef2, dist)
+            osh2.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
+            ef2.upload(m2)
+            ef2.set_pose(st2["poses"][0], tick0)
+            osh2.predict()
+            m5 = m2 if (world == 1 and args.config5_sets > 0) else None   # (kept for the configuration-5 leg below)
+            del m2, m
+            seg2 = dict(frame=0, calls=0)
 
-        def step2(kk):
-            i = kk % L
-            if not args.no_prefetch:
-                ef2.hint_next_frame_device(d_rgb2[(kk + 1) % L].data_ptr(), d_dep2[(kk + 1) % L].data_ptr())
-            osh2.process_frame_device(d_rgb2[i].data_ptr(), d_dep2[i].data_ptr())
-            seg2["frame"] += 1
-            if not args.no_instance and inst2.whetherDoSegmentation(100 + seg2["frame"]):
-                mk, cl = masks2[i]
-                if mk.shape[0]:
-                    seg2["calls"] += 1
-                    osh2.process_segmentation(st2["rgb"][i], st2["depth"][i], mk, cl, seg2["frame"], superpixels=not args.no_superpixels)
+            def step2(kk):
+                i = kk % L
+                if not args.no_prefetch:
+                    ef2.hint_next_frame_device(d_rgb2[(kk + 1) % L].data_ptr(), d_dep2[(kk + 1) % L].data_ptr())
+                osh2.process_frame_device(d_rgb2[i].data_ptr(), d_dep2[i].data_ptr())
+                seg2["frame"] += 1
+                if not args.no_instance and inst2.whetherDoSegmentation(100 + seg2["frame"]):
+                    mk, cl = masks2[i]
+                    if mk.shape[0]:
+                        seg2["calls"] += 1
+                        osh2.process_segmentation(st2["rgb"][i], st2["depth"][i], mk, cl, seg2["frame"], superpixels=not args.no_superpixels)
 
-        def barrier2():
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            def barrier2():
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                ef2.sync()
+
+            k2 = 1
+            for _ in range(12):
+                step2(k2); k2 += 1
+            barrier2()
+            osh2.exchange_stats(reset=True)
+            seg2["calls"] = 0
+            gc.disable()
+            t0 = time.perf_counter()
+            for _ in range(ns):
+                step2(k2); k2 += 1
+            barrier2()
+            dt2 = time.perf_counter() - t0
+            gc.enable()
+            xs2 = osh2.exchange_stats()
+            dt2 = ifd.max_over_ranks(dt2, dist, device=f"cuda:{dev}")
+            calls2 = seg2["calls"]
+            ef2.stage_ms(reset=True)
+            ef2.set_option("stage_timing", 1)
+            n_split2 = 20
+            for _ in range(n_split2):
+                step2(k2); k2 += 1
             ef2.sync()
+            stage2 = ef2.stage_ms(reset=True)
+            ef2.set_option("stage_timing", 0)
+            sharded_leg = dict(value=round(ns / dt2, 2), unit="frames/s", frames=ns, scaling="strong", n_ranks=world, rccl_ranks=osh2.comm_ranks(), segmentation_calls=calls2,
+                               ms_per_frame_gpu={k_: round(v_ / n_split2, 4) for k_, v_ in stage2.items() if k_ != "instance"},
+                               exchange={"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xs2["collectives"] / ns, 2),
+                                         "bytes_per_frame": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1)},
+                               surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
+                               what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
+                                    "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")
+            barrier2()
+            ef2.close()
 
-        k2 = 1
-        for _ in range(12):
-            step2(k2); k2 += 1
-        barrier2()
-        osh2.exchange_stats(reset=True)
-        seg2["calls"] = 0
-        gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(ns):
-            step2(k2); k2 += 1
-        barrier2()
-        dt2 = time.perf_counter() - t0
-        gc.enable()
-        xs2 = osh2.exchange_stats()
-        dt2 = ifd.max_over_ranks(dt2, dist, device=f"cuda:{dev}")
-        calls2 = seg2["calls"]
-        ef2.stage_ms(reset=True)
-        ef2.set_option("stage_timing", 1)
-        n_split2 = 20
-        for _ in range(n_split2):
-            step2(k2); k2 += 1
-        ef2.sync()
-        stage2 = ef2.stage_ms(reset=True)
-        ef2.set_option("stage_timing", 0)
-        sharded_leg = dict(value=round(ns / dt2, 2), unit="frames/s", frames=ns, scaling="strong", n_ranks=world, rccl_ranks=osh2.comm_ranks(), segmentation_calls=calls2,
-                           ms_per_frame_gpu={k_: round(v_ / n_split2, 4) for k_, v_ in stage2.items() if k_ != "instance"},
-                           exchange={"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xs2["collectives"] / ns, 2),
-                                     "bytes_per_frame": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1)},
-                           surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
-                           what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
-                                "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")
-        barrier2()
-        ef2.close()
+            # ---- BASELINE configuration 5 in a world of one: K = 8 streams (eight stretches of the same trajectory) into ONE sharded map, camera contexts, every camera
+            # tracked by "its" rank (here: the only one) and -- `ahead` -- the tracker of a camera's NEXT frame started on the third stream the moment the camera's context
+            # is parked, under the other cameras' map phases (ifx_owner_track_ahead); the frame then commits the parked pose block.  Frames/s over all cameras, with and
+            # without the run-ahead: what the overlap is worth.  (tests/test_gpu_parity.py::test_config5_* hold the bit-parity of exactly this schedule, at 50M x8 too.)
+            if m5 is not None:
+                K5, first5 = 8, [10 * c_ for c_ in range(8)]
+                c5 = {}
+                for ahead5 in (0, 1):
+                    ef5 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap + P + 500_000, device=dev, **K, n_ranks=-1, rank=0)
+                    osh5 = ifsh.OwnerShardedElasticFusion(ef5, dist)
+                    ef5.camera_count(K5)
+                    osh5.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
+                    ef5.upload(m5)
+                    ef5.set_pose(st2["poses"][0], tick0)
+                    osh5.predict()
+
+                    def set5(s_):
+                        for c_ in range(K5):
+                            i_ = first5[c_] + 1 + s_
+                            ef5.camera_select(c_)
+                            ef5.owner_set_tracking_rank(0)
+                            if c_ > 0 and s_ == 0:
+                                ef5.owner_set_frame_pose(st2["poses"][i_].astype(np.float32))   # a camera enters with its extrinsic calibration, then tracks
+                            if ahead5 and (s_ > 0 or c_ > 0):   # the camera whose frame was just processed is parked: its next frame's tracker starts now
+                                cp_, sp_ = (c_ - 1, s_) if c_ > 0 else (K5 - 1, s_ - 1)
+                                j_ = first5[cp_] + 1 + sp_ + 1
+                                if j_ < L:
+                                    ef5.owner_track_ahead(cp_, 0, d_rgb2[j_].data_ptr(), d_dep2[j_].data_ptr())
+                            osh5.process_frame_device(d_rgb2[i_].data_ptr(), d_dep2[i_].data_ptr())
+
+                    for s_ in range(2):
+                        set5(s_)
+                    ef5.sync(); torch.cuda.synchronize()
+                    served0 = ef5.owner_track_ahead(-1, 0)
+                    gc.disable()
+                    t0 = time.perf_counter()
+                    for s_ in range(2, 2 + args.config5_sets):
+                        set5(s_)
+                    ef5.sync(); torch.cuda.synchronize()
+                    t5 = time.perf_counter() - t0
+                    gc.enable()
+                    c5["ahead" if ahead5 else "in_frame"] = dict(value=round(K5 * args.config5_sets / t5, 2), frames=K5 * args.config5_sets,
+                                                                 trackers_served_ahead=ef5.owner_track_ahead(-1, 0) - served0)
+                    ef5.close()
+                del m5
+                sharded_leg["config5_world_of_one"] = dict(
+                    unit="frames/s", cameras=K5, **c5,
+                    what="BASELINE configuration 5 on one GPU: 8 streams into ONE sharded map (world of one: every exchange a one-rank RCCL collective, the camera-indexed "
+                         "reduce included), camera contexts, time-sliced.  `in_frame`: every frame tracks inside itself.  `ahead`: every camera's next tracker runs on the "
+                         "third stream as soon as the camera is parked (ifx_owner_track_ahead) and the frame commits its pose block -- the schedule of G ranks, where rank k "
+                         "tracks camera k under the other cameras' map phases while the other ranks would otherwise wait for its pose; on ONE GPU that tracks all K cameras "
+                         "there is nobody waiting and the run repeats the frame side (0.16 ms) it cannot hand over, so it is expected to be slower here")
+        except Exception as e:   # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
+            sharded_leg = {"error": f"{type(e).__name__}: {e}", "n_ranks": world}
 
     # ---- CPU baseline: the oracle (CPU restatement) on a bounded sample of the same workload, one core and all cores
     cpu = None

@@ -285,6 +285,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
+    else if (s == "gn_prologue_blocks") h->opt_gn_prologue_blocks = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
     else if (s == "view_blocks") h->opt_view_blocks = std::max(0, std::min(65536, value));
@@ -596,7 +597,7 @@ static_assert(offsetof(DevState, count) == IFX_CAM_STATE_BYTES, "the pose block 
 static void camera_free(ifx* h)
 {
     for (CamCtx& c : h->cams) {
-        hipFree(c.state); hipFree(c.pred); hipFree(c.fill_v); hipFree(c.fill_n); hipFree(c.fill_i); hipFree(c.ids);
+        hipFree(c.state); hipFree(c.pred); hipFree(c.fill_v); hipFree(c.fill_n); hipFree(c.fill_i); hipFree(c.ids); hipFree(c.ahead_pose);
         for (int l = 0; l < IFX_NUM_PYRS; l++) hipFree(c.img[l]);
     }
     h->cams.clear();
@@ -604,7 +605,6 @@ static void camera_free(ifx* h)
 extern "C" int ifx_camera_count(ifx_t* h, int n_cameras)
 {
     if (!h || n_cameras < 1 || n_cameras > 64) return IFX_E_INVALID;
-    h->cam_ahead_valid = 0;
     if (h->stream_c) hipStreamSynchronize(h->stream_c);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     camera_free(h);
@@ -690,7 +690,9 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     if (tracking_rank != h->cfg.rank) return IFX_OK;
     if (cam == h->cur_cam || !h->cams[(size_t)cam].valid) { h->err = "ifx_owner_track_ahead: the camera's context must be parked (select another camera first)"; return IFX_E_STATE; }
     if (h->lc_enable || !h->stream_c) { h->err = "ifx_owner_track_ahead: not available with the loop-closure detection on / on a one-stream handle"; return IFX_E_STATE; }
-    h->cam_ahead_valid = 0;
+    CamCtx& cc = h->cams[(size_t)cam];
+    cc.ahead_valid = 0;
+    if (!cc.ahead_pose) HIPCHK(h, hipMalloc(&cc.ahead_pose, IFX_CAM_STATE_BYTES));
     if (!h->ev_cam_parked) {   // (first use: the instance's buffers and events)
         hipEventCreateWithFlags(&h->ev_cam_ahead, hipEventDisableTiming);
         hipEventCreateWithFlags(&h->ev_cam_parked, hipEventDisableTiming);
@@ -704,10 +706,13 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
         StageTimer t(h, 0);
         r = ifx_tracker_camera_ahead(h, cam, d_rgb, d_depth);
     }
+    // the run's pose block into the camera's own parking place: the tracker instance is free for the next camera's run (they queue on the third stream; the event is
+    // re-recorded behind each of them, so a frame that waits for it waits for its own run at the latest)
+    if (!r) hipMemcpyAsync(cc.ahead_pose, (const void*)h->d_cam_trk, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream_c);
     hipEventRecord(h->ev_cam_ahead, h->stream_c);
     h->cur = h->stream;
     if (r) return r;
-    h->cam_ahead_valid = 1; h->cam_ahead_cam = cam; h->cam_ahead_rgb = d_rgb; h->cam_ahead_depth = d_depth;
+    cc.ahead_valid = 1; cc.ahead_rgb = d_rgb; cc.ahead_depth = d_depth;
     return IFX_OK;
 }
 
@@ -887,15 +892,15 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             ifx_tracker_external_pose(h, slot, 1.0f);
         } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
             StageTimer t(h, 0);
-            const bool ahead = h->cam_ahead_valid && !h->cams.empty() && h->cam_ahead_cam == h->cur_cam && h->cam_ahead_rgb == (const void*)d_rgb && h->cam_ahead_depth == (const void*)d_depth && src_kind == 0;
+            const bool ahead = !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid && h->cams[(size_t)h->cur_cam].ahead_rgb == (const void*)d_rgb && h->cams[(size_t)h->cur_cam].ahead_depth == (const void*)d_depth && src_kind == 0;
             if (ahead) {   // this camera's tracker ran ahead on the third stream, from the camera's parked context (ifx_owner_track_ahead): its pose block is the frame's
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cam_ahead, 0));
-                HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->d_cam_trk, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->cams[(size_t)h->cur_cam].ahead_pose, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
                 h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
                 h->cam_ahead_used++;
             } else if (tracked) ifx_tracker_commit(h);
             else { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
-            h->cam_ahead_valid = h->cam_ahead_valid && h->cam_ahead_cam != h->cur_cam;   // (a run ahead is for the camera's NEXT frame: whatever this frame was, it is spent)
+            if (!h->cams.empty()) h->cams[(size_t)h->cur_cam].ahead_valid = 0;   // (a run ahead is for the camera's NEXT frame: whatever this frame was, it is spent)
         } else if (!first) h->own_need_decide = 1;   // the pose arrives with exchange 310: the view-list decision follows it (phase 0)
         { int r = ifx_enqueue_hinted_frame_side(h); if (r) return r; }   // (a tracker enqueue consumed the hint already: no-op)
         h->own_frame_pose_set = 0;
@@ -1269,7 +1274,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
     ifx_drop_tracked(h);
-    h->cam_ahead_valid = 0;
+    for (CamCtx& c_ : h->cams) c_.ahead_valid = 0;
     h->seg_counts_valid = 0;
     h->map_external = 1;
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
@@ -1324,7 +1329,7 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 {
     if (!h || !pose16) return IFX_E_INVALID;
     ifx_drop_tracked(h);
-    h->cam_ahead_valid = 0;
+    for (CamCtx& c_ : h->cams) c_.ahead_valid = 0;
     DevState hs;
     int r = read_state(h, &hs);
     if (r) return r;

@@ -239,6 +239,11 @@ struct CamCtx {
     uint8_t* img[IFX_NUM_PYRS] = {};
     int32_t* ids = nullptr;
     int valid = 0;
+    // a tracker run ahead for this camera's NEXT frame (ifx_owner_track_ahead): the pose block it produced, parked until the frame comes (one per camera: on one GPU
+    // that tracks all K cameras, K runs are pending at any time)
+    void* ahead_pose = nullptr;
+    int ahead_valid = 0;
+    const void *ahead_rgb = nullptr, *ahead_depth = nullptr;
 };
 #define IFX_CAM_STATE_BYTES 200        // pose[16], pose_inv[16], last_pose[16], weighting, dense_enough
 
@@ -264,8 +269,6 @@ struct ifx {
     Pyr cam_pyr;
     double* cam_so3_acc = nullptr; unsigned int* cam_so3_ticket = nullptr;
     hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr;
-    int cam_ahead_valid = 0, cam_ahead_cam = -1;
-    const void *cam_ahead_rgb = nullptr, *cam_ahead_depth = nullptr;
     int cam_ahead_used = 0;             // frames whose tracker was taken from a run ahead (diagnostics / tests)
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
@@ -278,6 +281,7 @@ struct ifx {
     int shard_rank = 0, shard_n = 1;    // sharded projection: this rank's slice of the slots (ifx_set_shard)
     int opt_two_streams = 1;
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
+    int opt_gn_prologue_blocks = 2048;  // gn_prologue only for launches of at most this many blocks (every block repeats the solve)
     int opt_fold_result = 1;            // view-list frames: the frame result is written by the last block of the frame's last launch (k_splat_resolve) instead of a launch of its own
     float* result_fold_traj = nullptr;  // set by enqueue_frame around ifx_map_predict: the trajectory slot of the frame being finished (null: nobody asked)
     int result_folded = 0;              // ifx_map_predict's answer: the resolve took the frame result along

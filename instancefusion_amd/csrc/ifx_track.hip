@@ -2622,16 +2622,28 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     }
     bool pro = h->opt_gn_prologue != 0;
     int n_tail = 0;
+    // The prologue solve is repeated by every block of a launch: free while the grid is one wave of blocks, 4-6 us per launch at 4800 + 304 blocks (level 0 of a
+    // 1280x960 frame: 516 against 540 frames/s, profiles/r04_z2_*).  n_pro: the leading iterations of the tail (coarse levels first) whose launches stay under
+    // opt_gn_prologue_blocks; the last of them is solved in the last-block form (StepArgs::pro = 2) and leaves the pose in the state, where round 3's form of the
+    // finer levels reads it.
+    int n_pro = 0;
     {
-        bool seen_two_launch = false;
+        bool seen_two_launch = false, small = true;
         for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
             if (iterations[i] <= 0) continue;
             if (persist_q[i] >= 0) { if (seen_two_launch) pro = false; }   // a persistent level BEHIND two-launch iterations reads the pose from the state: round 3's form keeps it there
-            else { seen_two_launch = true; n_tail += iterations[i]; }
+            else {
+                seen_two_launch = true; n_tail += iterations[i];
+                const int n = p.w[i] * p.h[i];
+                const int blocks = (icp ? red_blocks(h, n) : 0) + (rgb ? std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : (1 << 30)) : 0);
+                small = small && blocks <= h->opt_gn_prologue_blocks;
+                if (small) n_pro += iterations[i];
+            }
         }
 #ifdef IFX_EXPERIMENTS
         if (h->opt_icp_lds || h->opt_icp_px) pro = false;
 #endif
+        if (n_pro < 2) pro = false;   // (a chain of one has nothing to hand over)
     }
     int persist_iters = 0;
     int tail_k = 0;   // position of the next two-launch iteration in the tail
@@ -2714,11 +2726,12 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 // gn_prologue: iteration tail_k sums into parity tail_k & 1; from the tail's second iteration on, every block first solves the iteration before
                 GnPro gp;
                 gp.k = tail_k; gp.icp = icp; gp.rgb = rgb; gp.icp_weight = icp_weight; gp.nfx = fx; gp.nfy = fy; gp.ncx = cx; gp.ncy = cy; gp.ki = kinv_of(fx, fy, cx, cy);
-                double* const ga = pro ? gnp_acc_of(tail_k & 1) : gacc;
-                int* const gr = pro ? gnp_res_of(tail_k & 1) : gres;
+                const bool it_pro = pro && tail_k < n_pro;
+                double* const ga = it_pro ? gnp_acc_of(tail_k & 1) : gacc;
+                int* const gr = it_pro ? gnp_res_of(tail_k & 1) : gres;
                 double* const rrt_store = gnp_rrt_of((tail_k + 1) & 1);   // the increment after iteration tail_k - 1
                 const dim3 grid(pa.nb_icp + pa.nb_res);
-                if (pro && tail_k > 0) {
+                if (it_pro && tail_k > 0) {
                     if (frame_tracker) LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, false, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
                     else LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, true, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
                 } else {
@@ -2737,7 +2750,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 sa2.final_iter = (j == iterations[i] - 1 && !later) ? 1 : 0;
             }
             sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = frame_tracker ? h->d_list_ctr : (unsigned int*)nullptr;
-            sa2.pro = pro ? (tail_k == n_tail - 1 ? 2 : 1) : 0; sa2.pro_k = tail_k;   // (the tail's last iteration is the run's last: final_iter)
+            sa2.pro = (pro && tail_k < n_pro) ? (tail_k == n_pro - 1 ? 2 : 1) : 0; sa2.pro_k = tail_k;   // (the chain's last iteration: last-block form; it is the run's last too unless finer levels were too large for the prologue)
             tail_k++;
             ended = ended || sa2.end_run;
             if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);

@@ -731,6 +731,9 @@ def test_gn_prologue_solve_is_bit_identical(ifx):
     ICP only, photometric only with its pivoted solve)."""
     for extra in (dict(), dict(gn_persist=4), dict(pyramid=0), dict(fast_odom=1), dict(icp_weight_x1000=100000), dict(icp_weight_x1000=0)):
         _tracker_variants_equal(ifx, [dict(gn_prologue=0, **extra), dict(gn_prologue=1, **extra)])
+    # the chain ends where a level's launches get too large for a solve in every block (default 2048 blocks: level 0 of a 1280x960 frame; here lowered so that
+    # it ends after the coarsest level / after the two coarse levels of a 640x480 frame): its last iteration in the last-block form, the finer levels as in round 3
+    _tracker_variants_equal(ifx, [dict(gn_prologue=0), dict(gn_prologue_blocks=200), dict(gn_prologue_blocks=600), dict(gn_prologue_blocks=200, gn_persist=4)])
 
 
 def test_lost_tracker_experiments_are_bit_identical(ifx):

@@ -371,6 +371,8 @@ def main():
         best, table = None, {}
         if ef.kernel_ms("gn_level")[1] == 0:   # (no level small enough for the persistent kernel at this resolution: every iteration is the two-launch form)
             GN_PERSIST = 0
+        elif GN_PERSIST == 0:                  # (the library's own choice from 1280x960 on: the coarsest level)
+            GN_PERSIST = 4
         for nme in names:
             avg, cnt = ef.kernel_ms(nme)
             table[nme] = dict(avg_ms=avg, launches=cnt, total_ms=avg * cnt)

@@ -320,8 +320,13 @@ int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
  *   "raster_tiles" -1|0|1 -- tiled rasteriser (key tiles in LDS): by image size (on from 1 Mpixel) | off | on; results are identical either way
  *   "pace" 0              -- ifx_enqueue_frame_device normally waits for the PREVIOUS frame's result before it enqueues (the tracker announced ahead keeps the
  *                           device busy meanwhile); 0 = enqueue without looking back (a host that runs frames ahead measured 25 % slower)
- *   "gn_persist" mask     -- bit i: the Gauss-Newton iterations of pyramid level i in one persistent launch with grid barriers (default 4 = the coarsest level)
- *                           while that level's grid has at most "gn_persist_blocks" blocks (default 128: 160x120 pixels -- 75 blocks -- wins, 320x240 loses)
+ *   "gn_persist" mask     -- bit i: the Gauss-Newton iterations of pyramid level i in one persistent launch with grid barriers, while that level's grid has at
+ *                           most "gn_persist_blocks" blocks (default 128).  Default 0 below 1280x960 (the two-launch form with the solve in the next launch's
+ *                           prologue is within 0.7 % there and needs no co-resident grid), 4 = the coarsest level from 1280x960 on (+5 %).  A meeting of its
+ *                           blocks that does not happen is re-run by one workgroup inside the frame (ifx_tracker_fallbacks counts them): slower, never wrong.
+ *   "gn_prologue" 0       -- the 6x6 solve of an iteration by the last block of its second launch (round 3's form) instead of by every block of the next
+ *                           iteration's first launch; "gn_prologue_blocks" n -- the prologue form only for launches of at most n blocks (default 2048)
+ *   "fold_result" 0       -- the frame result by a launch of its own instead of the last block of the prediction's resolve
  *   "lazy_ids" 0          -- render the whole id image every frame (default: the lattice whetherDoSegmentation samples; the rest on demand)
  *   "fold_finish" 0, "seg_device" 0, "seg_aside" 0, "ff_union" 0, "ff_rounds" n -- the earlier forms of the end-of-frame sums and of the segmentation call's
  *                           schedule (host-driven / on the main stream / relaxation-only flood fill / length of the fixed relaxation schedule); identical results */

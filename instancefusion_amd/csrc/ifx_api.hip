@@ -176,6 +176,10 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice);
     for (int k = 0; k < 16; k++) h->h_result->pose[k] = hs.pose[k];
     if (hipDeviceSynchronize() != hipSuccess) { g_err = "device synchronize failed after allocation"; ifx_destroy(h); return IFX_E_HIP; }
+    // From 1280x960 on the coarsest pyramid level (320x240: 75 blocks of four pixels per thread) runs its Gauss-Newton iterations in the persistent kernel: there
+    // its meetings cost less than the launch boundaries they replace (profiles/r04_z2_*: 519 -> 546 frames/s at 1280x960 / 20M; at 640x480 the same level is within
+    // 0.7 % either way and stays on the two-launch form).  A meeting that does not happen falls back inside the frame (k_gn_level_solo, ifx_tracker_fallbacks).
+    if ((long long)cfg->width * cfg->height >= 1280LL * 960LL) h->opt_gn_persist = 4;
     *out = h;
     if (const char* e = getenv("IFX_OPTS")) {   // debugging aid: "name=value,name=value" applied to every handle at creation (bisecting an option without touching the caller)
         std::string all(e);

@@ -728,7 +728,7 @@ def main():
                          "reduce included), camera contexts, time-sliced.  `in_frame`: every frame tracks inside itself.  `ahead`: every camera's next tracker runs on the "
                          "third stream as soon as the camera is parked (ifx_owner_track_ahead) and the frame commits its pose block -- the schedule of G ranks, where rank k "
                          "tracks camera k under the other cameras' map phases while the other ranks would otherwise wait for its pose; on ONE GPU that tracks all K cameras "
-                         "there is nobody waiting and the run repeats the frame side (0.16 ms) it cannot hand over, so it is expected to be slower here")
+                         "the two chains (latency-bound tracker launches, map passes) share the device, and the run repeats the frame side (0.16 ms) it cannot hand over")
         except Exception as e:   # noqa: BLE001
             import traceback
 

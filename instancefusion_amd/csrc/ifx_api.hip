@@ -601,7 +601,7 @@ static_assert(offsetof(DevState, count) == IFX_CAM_STATE_BYTES, "the pose block 
 static void camera_free(ifx* h)
 {
     for (CamCtx& c : h->cams) {
-        hipFree(c.state); hipFree(c.pred); hipFree(c.fill_v); hipFree(c.fill_n); hipFree(c.fill_i); hipFree(c.ids); hipFree(c.ahead_pose);
+        hipFree(c.state); hipFree(c.pred); hipFree(c.fill_v); hipFree(c.fill_n); hipFree(c.fill_i); hipFree(c.ids); hipFree(c.ahead_pose); if (c.ev_ahead) hipEventDestroy(c.ev_ahead);
         for (int l = 0; l < IFX_NUM_PYRS; l++) hipFree(c.img[l]);
     }
     h->cams.clear();
@@ -697,6 +697,7 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     CamCtx& cc = h->cams[(size_t)cam];
     cc.ahead_valid = 0;
     if (!cc.ahead_pose) HIPCHK(h, hipMalloc(&cc.ahead_pose, IFX_CAM_STATE_BYTES));
+    if (!cc.ev_ahead) HIPCHK(h, hipEventCreateWithFlags(&cc.ev_ahead, hipEventDisableTiming));
     if (!h->ev_cam_parked) {   // (first use: the instance's buffers and events)
         hipEventCreateWithFlags(&h->ev_cam_ahead, hipEventDisableTiming);
         hipEventCreateWithFlags(&h->ev_cam_parked, hipEventDisableTiming);
@@ -710,9 +711,11 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
         StageTimer t(h, 0);
         r = ifx_tracker_camera_ahead(h, cam, d_rgb, d_depth);
     }
-    // the run's pose block into the camera's own parking place: the tracker instance is free for the next camera's run (they queue on the third stream; the event is
-    // re-recorded behind each of them, so a frame that waits for it waits for its own run at the latest)
+    // the run's pose block into the camera's own parking place: the tracker instance is free for the next camera's run (they queue on the third stream).  The event
+    // is the camera's own: the frame that takes this run must not wait for runs enqueued after it (one shared event, re-recorded behind every run, made every frame
+    // wait for the run enqueued just before it: no overlap at all)
     if (!r) hipMemcpyAsync(cc.ahead_pose, (const void*)h->d_cam_trk, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream_c);
+    hipEventRecord(cc.ev_ahead, h->stream_c);
     hipEventRecord(h->ev_cam_ahead, h->stream_c);
     h->cur = h->stream;
     if (r) return r;
@@ -898,7 +901,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             StageTimer t(h, 0);
             const bool ahead = !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid && h->cams[(size_t)h->cur_cam].ahead_rgb == (const void*)d_rgb && h->cams[(size_t)h->cur_cam].ahead_depth == (const void*)d_depth && src_kind == 0;
             if (ahead) {   // this camera's tracker ran ahead on the third stream, from the camera's parked context (ifx_owner_track_ahead): its pose block is the frame's
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cam_ahead, 0));
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->cams[(size_t)h->cur_cam].ev_ahead, 0));
                 HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->cams[(size_t)h->cur_cam].ahead_pose, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
                 h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
                 h->cam_ahead_used++;

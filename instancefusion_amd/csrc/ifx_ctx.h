@@ -242,6 +242,7 @@ struct CamCtx {
     // a tracker run ahead for this camera's NEXT frame (ifx_owner_track_ahead): the pose block it produced, parked until the frame comes (one per camera: on one GPU
     // that tracks all K cameras, K runs are pending at any time)
     void* ahead_pose = nullptr;
+    hipEvent_t ev_ahead = nullptr;     // behind this camera's run (its own event: a frame must not wait for a run enqueued after its own)
     int ahead_valid = 0;
     const void *ahead_rgb = nullptr, *ahead_depth = nullptr;
 };

@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "other_resolutions or gn_prologue" 2>&1 | grep -a "passed\|failed\|^FAILED\|^E  " | head
-bash tools/prof_run.sh r04_big --res 1280x960 > /dev/null 2>&1; cat gpurun_out/r04_big_seg_call_timeline.txt | head -70
-python bench.py --gpus 1 --steps 100 --warmup 20 --no-cpu-baseline --extras-frames 0 --res 1280x960 --surfels 20000000 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']; print('1280x960/20M auto', d['value'], d['ms_per_frame_gpu'], d['instance']['ms_per_call'], {n:round(v['avg_ms']*1000,1) for n,v in k.items() if n in ('icp_residual','rgb_step_solve','so3_fused')})"
+python -m pytest tests -m gpu -q -x -k "config5_two_streams or rccl_world_of_one" 2>&1 | grep -a "passed\|failed\|^FAILED\|^E  " | head
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras-frames 40 > gpurun_out/r04_z5_bench_driver.json 2>gpurun_out/r04_z5_bench.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r04_z5_bench_driver.json").read().strip().splitlines()[-1])
+c=d["value_sharded"].get("config5_world_of_one") or {}
+print("driver", d["value"], d["value_sharded"]["value"], c.get("in_frame"), c.get("ahead"), d["value_sharded"].get("error"))
+PY

@@ -508,6 +508,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     const bool tracked = prepared && h->tracked_ahead == h->tick && !in_pose16;
     ifx_drop_tracked(h);
     if (!prepared) {
+        if (h->slic_ahead_tick == h->tick) h->slic_ahead_tick = -1;   // superpixels run ahead for a frame that was announced and did not come: not this frame's (the run stays "busy" until somebody queues behind it)
         int r = enqueue_frame_side(h, s, h->tick, rgb, depth, src_kind);
         if (r) return r;
     }

@@ -450,6 +450,7 @@ struct ifx {
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> stage_pending;
     double stage_ms[5] = {0, 0, 0, 0, 0};   // track, fuse, instance (main-stream span of the calls), preprocess (side stream), superpixels run ahead (side stream)
     // superpixels of the announced next frame, run ahead on the side stream (ifx_superpixel_ahead): the tick they belong to (-1: none), the event behind them
+    int slic_ahead_busy = 0;            // a run may still be executing on the side stream (whoever uses the superpixel buffers next queues behind its event)
     int slic_ahead_tick = -1;
     hipEvent_t ev_slic_ahead = nullptr;
     int slic_ahead_runs = 0, slic_ahead_used = 0;

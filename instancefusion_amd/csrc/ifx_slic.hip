@@ -706,7 +706,7 @@ int slic_buffers(ifx* h, SlicBuf** out, bool ahead = false)
 {
     // superpixels run ahead for a frame whose call never came (the hint was only a hint): the side stream may still be writing the buffers -- whoever uses them next
     // on another stream queues behind that run
-    if (!ahead && h->slic_ahead_tick >= 0) { HIPCHK(h, hipStreamWaitEvent(h->cur, h->ev_slic_ahead, 0)); h->slic_ahead_tick = -1; }
+    if (!ahead && h->slic_ahead_busy) { HIPCHK(h, hipStreamWaitEvent(h->cur, h->ev_slic_ahead, 0)); h->slic_ahead_tick = -1; h->slic_ahead_busy = 0; }
     if (h->slic) { *out = (SlicBuf*)h->slic; return IFX_OK; }
     if (h->w < SPX || h->h < SPX) { h->err = "image smaller than one superpixel"; return IFX_E_INVALID; }
     SlicBuf* b = new SlicBuf();
@@ -860,6 +860,7 @@ int ifx_superpixel_begin(ifx* h, const uint8_t* rgb, const uint16_t* depth)
     if (!rgb && !depth && h->tick >= 2 && h->slic_ahead_tick == h->tick - 1) {   // the resident frame's superpixels ran ahead on the side stream: the call queues behind them
         HIPCHK(h, hipStreamWaitEvent(h->cur, h->ev_slic_ahead, 0));
         h->slic_ahead_tick = -1;
+        h->slic_ahead_busy = 0;
         h->slic_ahead_used++;
         return IFX_OK;
     }
@@ -894,6 +895,7 @@ int ifx_superpixel_ahead(ifx* h)
     h->cur = keep;
     if (r) return r;
     h->slic_ahead_tick = h->tick;
+    h->slic_ahead_busy = 1;
     h->slic_ahead_runs++;
     return IFX_OK;
 }

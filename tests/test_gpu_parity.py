@@ -1387,11 +1387,13 @@ def test_superpixels_ahead_of_a_call_change_nothing(ifx):
         g.set_option("slic_ahead", ahead)
         fired = []
         for i in range(n):
-            if i + 1 < n and i != 10:   # (frame 11 is not announced: its call finds no run ahead)
+            if i == 7:                  # frame 8 is announced WRONGLY (another frame's images): the superpixels run ahead on those must not serve frame 8's call
+                g.hint_next_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
+            elif i + 1 < n and i != 10:   # (frame 11 is not announced: its call finds no run ahead)
                 g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
             g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
             fired.append(inst.whetherDoSegmentation(10 + i))
-            if i in (5, 9, 11, 12, 13):
+            if i in (5, 8, 9, 11, 12, 13):
                 mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
                 inst.ProcessSegmentation(None, None, mk, cl, 10 + i, superpixels=True)
         g.sync()

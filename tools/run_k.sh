@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "config5_two_streams or rccl_world_of_one" 2>&1 | grep -a "passed\|failed\|^FAILED\|^E  " | head
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras-frames 40 > gpurun_out/r04_z5_bench_driver.json 2>gpurun_out/r04_z5_bench.err
-python - <<PY
-import json
-d=json.loads(open("gpurun_out/r04_z5_bench_driver.json").read().strip().splitlines()[-1])
-c=d["value_sharded"].get("config5_world_of_one") or {}
-print("driver", d["value"], d["value_sharded"]["value"], c.get("in_frame"), c.get("ahead"), d["value_sharded"].get("error"))
-PY
+T=r04_zz
+( time python -m pytest tests -m gpu -q ) > gpurun_out/${T}_tests.log 2>&1; tail -4 gpurun_out/${T}_tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1

@@ -1387,13 +1387,13 @@ def test_superpixels_ahead_of_a_call_change_nothing(ifx):
         g.set_option("slic_ahead", ahead)
         fired = []
         for i in range(n):
-            if i == 7:                  # frame 8 is announced WRONGLY (another frame's images): the superpixels run ahead on those must not serve frame 8's call
+            if i == 8:                    # frame 9 is announced WRONGLY (another frame's images): the superpixels run ahead on those must not serve frame 9's call
                 g.hint_next_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
             elif i + 1 < n and i != 10:   # (frame 11 is not announced: its call finds no run ahead)
                 g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
             g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
-            fired.append(inst.whetherDoSegmentation(10 + i))
-            if i in (5, 8, 9, 11, 12, 13):
+            fired.append(inst.whetherDoSegmentation(-(1 << 30)))   # (a frame number that never fires: with slic_ahead = 2 every decision point starts a run for the announced frame)
+            if i in (5, 7, 9, 11, 12):    # 5, 7: served by a run ahead; 9: its run was for the wrong images; 11: not announced; 12: its run was displaced by 11's in-call superpixels
                 mk, cl = synth.canned_masks(st["obj"][i], st["scene"])
                 inst.ProcessSegmentation(None, None, mk, cl, 10 + i, superpixels=True)
         g.sync()
@@ -1402,7 +1402,7 @@ def test_superpixels_ahead_of_a_call_change_nothing(ifx):
         g.close()
     a, b = outs
     assert a[5]["runs"] == 0 and a[5]["used"] == 0
-    assert b[5]["runs"] >= 5 and 1 <= b[5]["used"] <= 4 and b[5]["used"] < b[5]["runs"], b[5]
+    assert b[5]["runs"] >= 5 and b[5]["used"] == 2, b[5]
     assert a[0] == b[0]
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert (a[3] >= 0).sum() > 100

@@ -220,7 +220,7 @@ extern "C" void ifx_destroy(ifx_t* h)
                     h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_key, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
-    { FrameSlot& f2 = h->slot[2]; void* p2[] = {f2.rgb, f2.depth_raw, f2.depth_filt, f2.dm, f2.dmf}; for (void* p : p2) if (p) hipFree(p); }
+    for (size_t q = 2; q < h->slot.size(); q++) { FrameSlot& f2 = h->slot[q]; void* p2[] = {f2.rgb, f2.depth_raw, f2.depth_filt, f2.dm, f2.dmf}; for (void* p : p2) if (p) hipFree(p); }
     if (h->h_result) hipHostFree(h->h_result);
     if (h->rgb_stage) hipHostFree(h->rgb_stage);
     if (h->depth_stage) hipHostFree(h->depth_stage);
@@ -514,6 +514,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     }
     f.for_tick = -1;
     ifx_bind_slot(h, s);
+    h->last_frame_slot = s;
     if (h->tick == 1) {
         HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
         StageTimer t(h, 1);
@@ -613,6 +614,7 @@ extern "C" int ifx_camera_count(ifx_t* h, int n_cameras)
     if (h->stream_c) hipStreamSynchronize(h->stream_c);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     camera_free(h);
+    if (h->slot.size() < 3 + (size_t)n_cameras) h->slot.resize(3 + (size_t)n_cameras);   // (a camera's run-ahead slot is allocated on first use; sized here so that no reference into the vector moves later)
     h->cur_cam = 0;
     if (n_cameras == 1) return IFX_OK;
     const size_t P = (size_t)h->P;
@@ -635,7 +637,8 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
     if (h->lc_pending && h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     ifx_vlist_reap(h); hs_invalidate_view(h);   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
     const size_t P = (size_t)h->P;
-    FrameSlot& prev = h->slot[(h->tick & 1) ^ 1];   // the slot of the frame just processed = the "previous image" of the next one
+    FrameSlot& prev = h->slot[(h->tick & 1) ^ 1];   // where the next frame side looks for its "previous image"
+    FrameSlot& last = h->slot[(size_t)h->last_frame_slot];   // the slot of the frame just processed (a camera's run-ahead slot when the frame took its run)
     auto move = [&](CamCtx& c, bool save) -> int {
         const hipMemcpyKind k = hipMemcpyDeviceToDevice;
 #define CAMCP(ctx_ptr, live_ptr, bytes) HIPCHK(h, save ? hipMemcpyAsync((ctx_ptr), (live_ptr), (bytes), k, h->stream) : hipMemcpyAsync((live_ptr), (ctx_ptr), (bytes), k, h->stream))
@@ -643,7 +646,7 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
         CAMCP(c.pred, (void*)h->pred_vertex, h->pred_bytes);
         CAMCP(c.fill_v, (void*)h->fill_vertex, P * 16); CAMCP(c.fill_n, (void*)h->fill_normal, P * 16); CAMCP(c.fill_i, (void*)h->fill_image, P * 4);
         CAMCP(c.ids, (void*)h->ids_after, P * 4);
-        for (int l = 0; l < IFX_NUM_PYRS; l++) CAMCP(c.img[l], (void*)prev.next_img[l], (size_t)(h->w >> l) * (h->h >> l));
+        for (int l = 0; l < IFX_NUM_PYRS; l++) CAMCP(c.img[l], (void*)(save ? last : prev).next_img[l], (size_t)(h->w >> l) * (h->h >> l));
 #undef CAMCP
         return IFX_OK;
     };
@@ -657,6 +660,7 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
     }
     h->cur_cam = cam;
     h->seg_counts_valid = 0;
+    h->last_frame_slot = (h->tick & 1) ^ 1;   // (what the next frame side reads as its previous image now lives there)
     return IFX_OK;
 }
 // sharded map: the next frame takes `pose16` instead of tracking (the in_pose argument of the unsharded entry points); NULL clears it
@@ -778,6 +782,7 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
         if (r) return r;
         f.for_tick = -1;
         ifx_bind_slot(h, s);
+        h->last_frame_slot = s;
         if (!first) { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
     }
     int r = ifx_map_sharded_phase(h, phase, first);
@@ -882,9 +887,21 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         const bool tracked = prepared && h->tracked_ahead == h->tick && !h->own_frame_pose_set && tracks && !first;
         ifx_drop_tracked(h);
         ifx_housekeeping(h);                        // local and independent: ids are creation numbers, a compaction renumbers nothing the other ranks see
-        if (!prepared) {
+        // this camera's tracker ran ahead on the third stream, from the camera's parked context (ifx_owner_track_ahead), on exactly these images: its pose block is the
+        // frame's, and so is its frame side -- raw images, filtered depth, pyramids sit in the camera's own slot: the frame binds it instead of computing them again
+        const bool ahead = !first && !h->own_frame_pose_set && tracks && !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid &&
+                           h->cams[(size_t)h->cur_cam].ahead_rgb == (const void*)d_rgb && h->cams[(size_t)h->cur_cam].ahead_depth == (const void*)d_depth && src_kind == 0;
+        int bound_slot = s;
+        if (ahead) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->cams[(size_t)h->cur_cam].ev_ahead, 0));
+            bound_slot = 3 + h->cur_cam;
+        } else if (!prepared) {
             // (a frame announced wrongly: the side stream may still be running the frame side of what was announced, into this slot and the shared SO(3) sums)
             if (f.for_tick == h->tick && f.ready && h->opt_two_streams) HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
+            if (h->last_frame_slot >= 3) {   // the frame before this one ran on a camera's run-ahead slot and no camera was selected since: its intensity pyramid is this frame's "previous image"
+                for (int l = 0; l < IFX_NUM_PYRS; l++)
+                    HIPCHK(h, hipMemcpyAsync(h->slot[(size_t)(s ^ 1)].next_img[l], h->slot[(size_t)h->last_frame_slot].next_img[l], (size_t)(h->w >> l) * (h->h >> l), hipMemcpyDeviceToDevice, h->stream));
+            }
             const int two = h->opt_two_streams;
             h->opt_two_streams = 0;
             int r = enqueue_frame_side(h, s, h->tick, d_rgb, d_depth, src_kind);
@@ -892,7 +909,8 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             if (r) return r;
         } else HIPCHK(h, hipStreamWaitEvent(h->stream, f.ready, 0));
         f.for_tick = -1;
-        ifx_bind_slot(h, s);
+        ifx_bind_slot(h, bound_slot);
+        h->last_frame_slot = bound_slot;
         h->own_need_decide = 0;
         if (!first && h->own_frame_pose_set) {   // an external pose replaces tracking (EF/ElasticFusion.cpp:357-360), on every rank alike
             float* slot = h->d_scratch + 2 * 16;
@@ -900,9 +918,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             ifx_tracker_external_pose(h, slot, 1.0f);
         } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
             StageTimer t(h, 0);
-            const bool ahead = !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid && h->cams[(size_t)h->cur_cam].ahead_rgb == (const void*)d_rgb && h->cams[(size_t)h->cur_cam].ahead_depth == (const void*)d_depth && src_kind == 0;
-            if (ahead) {   // this camera's tracker ran ahead on the third stream, from the camera's parked context (ifx_owner_track_ahead): its pose block is the frame's
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->cams[(size_t)h->cur_cam].ev_ahead, 0));
+            if (ahead) {
                 HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->cams[(size_t)h->cur_cam].ahead_pose, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
                 h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
                 h->cam_ahead_used++;

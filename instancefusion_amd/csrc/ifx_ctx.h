@@ -260,7 +260,9 @@ struct ifx {
     hipEvent_t ev_lc_ready = nullptr, ev_lc_done = nullptr;
     int lc_pending = 0, lc_deferred = 0;
     hipStream_t cur = nullptr;         // stream LAUNCH enqueues on (== stream except while a frame side is enqueued)
-    FrameSlot slot[3];                  // [0], [1] alternate per frame; [2]: the frame a camera's tracker runs ahead on (ifx_owner_track_ahead), allocated on first use
+    std::vector<FrameSlot> slot = std::vector<FrameSlot>(3);   // [0], [1] alternate per frame; [2]: unused; [3 + c]: the frame camera c's tracker runs ahead on (ifx_owner_track_ahead), allocated on
+                                        // first use -- the frame then takes its frame side from there instead of computing it again
+    int last_frame_slot = 0;            // the slot the frame most recently enqueued is bound to (its raw images, its intensity pyramid: the resident frame of a segmentation call, what a camera parks)
     int cur_slot = 0;
     std::vector<CamCtx> cams;           // camera contexts (ifx_camera_count); empty: the handle is its one camera
     int cur_cam = 0;

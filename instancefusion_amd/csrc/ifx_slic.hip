@@ -839,7 +839,7 @@ static int slic_load_frame(ifx* h, SlicBuf* b, const uint8_t* rgb, const uint16_
     const size_t P = b->P;
     if (!rgb && !depth) {
         if (h->tick < 2) { h->err = "superpixel refinement of the resident frame: no frame has been processed yet"; return IFX_E_STATE; }
-        const FrameSlot& f = h->slot[(h->tick - 1) & 1];
+        const FrameSlot& f = h->slot[(size_t)h->last_frame_slot];
         b->cur_rgb = f.rgb; b->cur_depth = f.depth_raw;   // read in place: the slot is not reused before the frame after next, and the call is synchronous
         return IFX_OK;
     }

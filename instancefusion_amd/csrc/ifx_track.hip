@@ -2446,7 +2446,7 @@ void ifx_bind_slot(ifx* h, int s)
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         p.depth_tmp[i] = (i == 0) ? f.depth_filt : f.depth_tmp[i]; p.vmap_curr[i] = f.vmap_curr[i]; p.nmap_curr[i] = f.nmap_curr[i];
         p.next_img[i] = f.next_img[i]; p.didx[i] = f.didx[i]; p.didy[i] = f.didy[i];
-        p.lastnext_img[i] = h->slot[s < 2 ? (s ^ 1) : 0].next_img[i];   // (slot 2, a camera's run-ahead frame: the caller points it at the camera's parked pyramid)
+        p.lastnext_img[i] = h->slot[s < 2 ? (s ^ 1) : 0].next_img[i];   // (slots 3.., a camera's run-ahead frame: the caller points it at the camera's parked pyramid)
     }
 }
 
@@ -2455,14 +2455,14 @@ void ifx_free_tracker(ifx* h)
 {
     Pyr& p = h->pyr;
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
-        for (int q = 0; q < 3; q++) {
+        for (size_t q = 0; q < h->slot.size(); q++) {
             FrameSlot& f = h->slot[q];
             hipFree(f.depth_tmp[i]); hipFree(f.vmap_curr[i]); hipFree(f.nmap_curr[i]); hipFree(f.next_img[i]); hipFree(f.didx[i]); hipFree(f.didy[i]);
         }
         hipFree(p.vmap_cam[i]); hipFree(p.nmap_cam[i]); hipFree(p.vmap_prev[i]); hipFree(p.nmap_prev[i]); hipFree(p.last_depth[i]); hipFree(p.last_img[i]);
         hipFree(p.cloud[i]); hipFree(p.corres[i]);
     }
-    for (int q = 0; q < 3; q++) hipFree(h->slot[q].so3);
+    for (size_t q = 0; q < h->slot.size(); q++) hipFree(h->slot[q].so3);
     if (h->d_cam_trk) {
         Pyr& cp = h->cam_pyr;
         for (int i = 0; i < IFX_NUM_PYRS; i++) { hipFree(cp.vmap_cam[i]); hipFree(cp.nmap_cam[i]); hipFree(cp.vmap_prev[i]); hipFree(cp.nmap_prev[i]); hipFree(cp.last_depth[i]); hipFree(cp.last_img[i]); hipFree(cp.cloud[i]); hipFree(cp.corres[i]); }
@@ -2817,11 +2817,6 @@ static int cam_trk_alloc(ifx* h)
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
         p.w[i] = h->w >> i; p.h[i] = h->h >> i;
         const size_t n = (size_t)p.w[i] * p.h[i];
-        FrameSlot& f = h->slot[2];
-        HIPCHK(h, hipMalloc(&f.depth_tmp[i], n * 2));
-        HIPCHK(h, hipMalloc(&f.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&f.nmap_curr[i], n * 12));
-        HIPCHK(h, hipMalloc(&f.next_img[i], n)); HIPCHK(h, hipMemset(f.next_img[i], 0, n));
-        HIPCHK(h, hipMalloc(&f.didx[i], n * 2)); HIPCHK(h, hipMalloc(&f.didy[i], n * 2));
         HIPCHK(h, hipMalloc(&p.vmap_cam[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_cam[i], n * 12));
         HIPCHK(h, hipMalloc(&p.vmap_prev[i], n * 12)); HIPCHK(h, hipMalloc(&p.nmap_prev[i], n * 12));
         HIPCHK(h, hipMalloc(&p.last_depth[i], n * 4));
@@ -2829,32 +2824,49 @@ static int cam_trk_alloc(ifx* h)
         HIPCHK(h, hipMalloc(&p.cloud[i], n * 12));
         HIPCHK(h, hipMalloc(&p.corres[i], n * 8));
     }
-    const size_t P = (size_t)h->P;
-    FrameSlot& f = h->slot[2];
-    HIPCHK(h, hipMalloc(&f.rgb, P * 3)); HIPCHK(h, hipMalloc(&f.depth_raw, P * 2)); HIPCHK(h, hipMalloc(&f.depth_filt, P * 2)); HIPCHK(h, hipMalloc(&f.dm, P * 4)); HIPCHK(h, hipMalloc(&f.dmf, P * 4));
-    HIPCHK(h, hipMalloc(&f.so3, sizeof(DevState)));
-    HIPCHK(h, hipMemset(f.so3, 0, sizeof(DevState)));
     HIPCHK(h, hipMalloc(&h->cam_so3_acc, IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)));
     HIPCHK(h, hipMemset(h->cam_so3_acc, 0, IFX_ACC_REPL * IFX_ACC_STRIDE * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->cam_so3_ticket, 64));
     HIPCHK(h, hipMemset(h->cam_so3_ticket, 0, 64));
     return IFX_OK;
 }
+// the frame slot of camera `cam`'s run ahead (index 3 + cam): its own, because the frame that takes the run also takes the slot -- raw images, filtered depth, frame
+// pyramids -- instead of computing its frame side a second time, and other cameras' runs come in between
+static int cam_slot_alloc(ifx* h, int cam)
+{
+    const size_t idx = 3 + (size_t)cam;
+    if (h->slot.size() <= idx) h->slot.resize(idx + 1);
+    FrameSlot& f = h->slot[idx];
+    if (f.rgb) return IFX_OK;
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {
+        const size_t n = (size_t)(h->w >> i) * (h->h >> i);
+        HIPCHK(h, hipMalloc(&f.depth_tmp[i], n * 2));
+        HIPCHK(h, hipMalloc(&f.vmap_curr[i], n * 12)); HIPCHK(h, hipMalloc(&f.nmap_curr[i], n * 12));
+        HIPCHK(h, hipMalloc(&f.next_img[i], n)); HIPCHK(h, hipMemset(f.next_img[i], 0, n));
+        HIPCHK(h, hipMalloc(&f.didx[i], n * 2)); HIPCHK(h, hipMalloc(&f.didy[i], n * 2));
+    }
+    const size_t P = (size_t)h->P;
+    HIPCHK(h, hipMalloc(&f.rgb, P * 3)); HIPCHK(h, hipMalloc(&f.depth_raw, P * 2)); HIPCHK(h, hipMalloc(&f.depth_filt, P * 2)); HIPCHK(h, hipMalloc(&f.dm, P * 4)); HIPCHK(h, hipMalloc(&f.dmf, P * 4));
+    HIPCHK(h, hipMalloc(&f.so3, sizeof(DevState)));
+    HIPCHK(h, hipMemset(f.so3, 0, sizeof(DevState)));
+    return IFX_OK;
+}
 int ifx_tracker_camera_ahead(ifx* h, int cam, const uint8_t* d_rgb, const uint16_t* d_depth)
 {
     int r = cam_trk_alloc(h);
     if (r) return r;
+    if ((r = cam_slot_alloc(h, cam))) return r;
     CamCtx& cc = h->cams[(size_t)cam];
     DevState* st = h->d_cam_trk;
     Pyr& p = h->cam_pyr;
-    const int bound = h->cur_slot;
-    HIPCHK(h, hipMemcpyAsync(h->slot[2].rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->cur));
-    HIPCHK(h, hipMemcpyAsync(h->slot[2].depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur));
-    ifx_bind_slot(h, 2);
+    const int bound = h->cur_slot, cs = 3 + cam;
+    HIPCHK(h, hipMemcpyAsync(h->slot[cs].rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->cur));
+    HIPCHK(h, hipMemcpyAsync(h->slot[cs].depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur));
+    ifx_bind_slot(h, cs);
     for (int i = 0; i < IFX_NUM_PYRS; i++) h->pyr.lastnext_img[i] = cc.img[i];   // the "previous image" of the SO(3) step: the camera's last frame, parked with its context
     ifx_preprocess(h);
     ifx_tracker_frame_side(h, 0, h->cam_so3_acc, h->cam_so3_ticket);
-    for (int i = 0; i < IFX_NUM_PYRS; i++) {   // the instance tracks the frame in slot 2
+    for (int i = 0; i < IFX_NUM_PYRS; i++) {   // the instance tracks the frame in the camera's slot
         p.vmap_curr[i] = h->pyr.vmap_curr[i]; p.nmap_curr[i] = h->pyr.nmap_curr[i]; p.next_img[i] = h->pyr.next_img[i]; p.didx[i] = h->pyr.didx[i]; p.didy[i] = h->pyr.didy[i];
         p.depth_tmp[i] = h->pyr.depth_tmp[i]; p.lastnext_img[i] = cc.img[i];
     }

@@ -72,6 +72,14 @@ struct StageTimer {
     } while (0)
 
 extern "C" int ifx_set_option(ifx_t* h, const char* name, int value);
+// the prediction block [pred_vertex | pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail] at `base` (creation; a camera switch that swaps blocks)
+static void ifx_pred_rebind(ifx* h, float* base)
+{
+    const size_t P = (size_t)h->P, conf_bytes = ((P * 4 + 15) / 16) * 16;
+    h->pred_vertex = base; h->pred_conf = (float*)((uint8_t*)h->pred_vertex + P * 16); h->pred_normal = (float*)((uint8_t*)h->pred_conf + conf_bytes);
+    h->pred_image = (uint8_t*)(h->pred_normal + 4 * P); h->pred_inst = h->pred_image + 4 * P;
+    h->pred_time = (uint16_t*)(h->pred_inst + 4 * P); h->pred_tail = (int*)((uint8_t*)h->pred_vertex + h->pred_bytes - 16);
+}
 extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
 {
     if (!cfg || !out) { g_err = "null argument"; return IFX_E_INVALID; }
@@ -155,9 +163,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     // owner's to tell (pred_conf, 4 B per pixel instead of 16).  Tail: [0] vote mass of the owned surfels under the id image (whetherDoSegmentation), summed with the prediction.
     const size_t conf_bytes = ((P * 4 + 15) / 16) * 16;
     h->pred_bytes = P * 16 + conf_bytes + ((P * 26 + 15) / 16) * 16 + 16;
-    ALLOC(h->pred_vertex, h->pred_bytes); h->pred_conf = (float*)((uint8_t*)h->pred_vertex + P * 16); h->pred_normal = (float*)((uint8_t*)h->pred_conf + conf_bytes);
-    h->pred_image = (uint8_t*)(h->pred_normal + 4 * P); h->pred_inst = h->pred_image + 4 * P;
-    h->pred_time = (uint16_t*)(h->pred_inst + 4 * P); h->pred_tail = (int*)((uint8_t*)h->pred_vertex + h->pred_bytes - 16);
+    ALLOC(h->pred_vertex, h->pred_bytes);
+    ifx_pred_rebind(h, h->pred_vertex);
     hipMemset(h->pred_vertex, 0, h->pred_bytes);
     ALLOC(h->fill_vertex, P * 16); ALLOC(h->fill_normal, P * 16); ALLOC(h->fill_image, P * 4);
     ALLOC(h->ids_after, P * 4); ALLOC(h->ids_tmp, P * 4);
@@ -289,6 +296,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
+    else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "gn_prologue_blocks") h->opt_gn_prologue_blocks = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
@@ -651,12 +659,31 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
         return IFX_OK;
     };
     ifx_ids_ensure(h);   // a parked id image is a whole one (the map moves on under the other cameras)
-    int r = move(h->cams[(size_t)h->cur_cam], true);
-    if (r) return r;
-    h->cams[(size_t)h->cur_cam].valid = 1;
-    if (h->cams[(size_t)cam].valid) {
-        r = move(h->cams[(size_t)cam], false);
+    int r = IFX_OK;
+    if (h->cams[(size_t)cam].valid && h->opt_cam_swap) {
+        // Both contexts exist: the big blocks -- prediction 46 B/px, fill-in 36, id image 4: 26 MB at 640x480 -- change hands by pointer (the parked context takes
+        // the live buffers, the live pointers take the other camera's); only the pose block and the intensity pyramid (0.4 MB) are copied.  53 MB of device
+        // copies per camera switch was 0.1 ms of every frame on every rank of a K-stream run.
+        CamCtx& o = h->cams[(size_t)h->cur_cam];
+        CamCtx& n = h->cams[(size_t)cam];
+        HIPCHK(h, hipMemcpyAsync(o.state, (void*)h->d_state, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
+        for (int l = 0; l < IFX_NUM_PYRS; l++) HIPCHK(h, hipMemcpyAsync(o.img[l], last.next_img[l], (size_t)(h->w >> l) * (h->h >> l), hipMemcpyDeviceToDevice, h->stream));
+        { uint8_t* t = o.pred; o.pred = (uint8_t*)h->pred_vertex; ifx_pred_rebind(h, (float*)n.pred); n.pred = t; }
+        { float* t = o.fill_v; o.fill_v = h->fill_vertex; h->fill_vertex = n.fill_v; n.fill_v = t; }
+        { float* t = o.fill_n; o.fill_n = h->fill_normal; h->fill_normal = n.fill_n; n.fill_n = t; }
+        { uint8_t* t = o.fill_i; o.fill_i = h->fill_image; h->fill_image = n.fill_i; n.fill_i = t; }
+        { int32_t* t = o.ids; o.ids = h->ids_after; h->ids_after = n.ids; n.ids = t; }
+        HIPCHK(h, hipMemcpyAsync((void*)h->d_state, n.state, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
+        for (int l = 0; l < IFX_NUM_PYRS; l++) HIPCHK(h, hipMemcpyAsync(prev.next_img[l], n.img[l], (size_t)(h->w >> l) * (h->h >> l), hipMemcpyDeviceToDevice, h->stream));
+        o.valid = 1;
+    } else {
+        r = move(h->cams[(size_t)h->cur_cam], true);
         if (r) return r;
+        h->cams[(size_t)h->cur_cam].valid = 1;
+        if (h->cams[(size_t)cam].valid) {
+            r = move(h->cams[(size_t)cam], false);
+            if (r) return r;
+        }
     }
     h->cur_cam = cam;
     h->seg_counts_valid = 0;
@@ -892,6 +919,8 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         const bool ahead = !first && !h->own_frame_pose_set && tracks && !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid &&
                            h->cams[(size_t)h->cur_cam].ahead_rgb == (const void*)d_rgb && h->cams[(size_t)h->cur_cam].ahead_depth == (const void*)d_depth && src_kind == 0;
         int bound_slot = s;
+        if (!ahead && !h->cams.empty() && h->cams[(size_t)h->cur_cam].ahead_valid && h->cams[(size_t)h->cur_cam].ev_ahead)   // a run this frame does not take may still be reading the camera's context
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->cams[(size_t)h->cur_cam].ev_ahead, 0));
         if (ahead) {
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->cams[(size_t)h->cur_cam].ev_ahead, 0));
             bound_slot = 3 + h->cur_cam;

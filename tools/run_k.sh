@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "config5_two_streams or rccl_world_of_one or resident or lookahead" 2>&1 | grep -a "passed\|failed\|^FAILED\|^E  " | head
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras-frames 40 > gpurun_out/r04_z6_bench_driver.json 2>gpurun_out/r04_z6_bench.err
+python -m pytest tests -m gpu -q -x -k "config5 or rccl_world_of_one or camera" 2>&1 | grep -a "passed\|failed\|^FAILED\|^E  " | head
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras-frames 40 > gpurun_out/r04_z7_bench_driver.json 2>gpurun_out/r04_z7_bench.err
 python - <<PY
 import json
-d=json.loads(open("gpurun_out/r04_z6_bench_driver.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r04_z7_bench_driver.json").read().strip().splitlines()[-1])
 c=d["value_sharded"].get("config5_world_of_one") or {}
 print("driver", d["value"], d["value_sharded"].get("value"), c.get("in_frame"), c.get("ahead"), d["value_sharded"].get("error"))
 PY

@@ -141,7 +141,9 @@ int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint1
  * are processed one after the other, in camera order, on the one map; a camera tracks against the prediction rendered at the end of ITS last frame.
  *   ifx_camera_count(h, K)        K camera contexts on this handle (pose block, prediction + fill-in, the last frame's intensity pyramid, id image)
  *   ifx_camera_select(h, c)       park the current camera's context, bring camera c's in (enqueue-only, between frames); a camera selected for the first time
- *                                 starts as a copy of the current one: give it its pose (ifx_set_pose) or an external pose for its first frame
+ *                                 starts as a copy of the current one: give it its pose (ifx_set_pose) or an external pose for its first frame.  Between two
+ *                                 cameras that both have a context the prediction / fill-in / id images change hands by pointer (no copies): device pointers
+ *                                 obtained before the switch -- ifx_ids_after, ifx_owner_exchange lists -- are stale after it; ask again
  * On a spatially sharded map (every rank holds the K contexts and is fed all K streams):
  *   ifx_owner_set_frame_pose      the next frame takes this pose instead of tracking (the in_pose of the unsharded entry points)
  *   ifx_owner_set_tracking_rank   only this rank tracks the frames to come -- stream k on GPU k, no tracker collective; the others run the frame side,

@@ -686,6 +686,9 @@ def main():
                 c5 = {}
                 for ahead5 in (0, 1):
                     ef5 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap + P + 500_000, device=dev, **K, n_ranks=-1, rank=0)
+                    for kv in args.opt:
+                        k_, v_ = kv.split("=")
+                        ef5.set_option(k_, int(v_))
                     osh5 = ifsh.OwnerShardedElasticFusion(ef5, dist)
                     ef5.camera_count(K5)
                     osh5.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())

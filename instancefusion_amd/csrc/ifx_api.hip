@@ -217,6 +217,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_cam_ahead) hipEventDestroy(h->ev_cam_ahead);
+    if (h->ev_cam_side) hipEventDestroy(h->ev_cam_side);
     if (h->ev_slic_ahead) hipEventDestroy(h->ev_slic_ahead);
     if (h->ev_cam_parked) hipEventDestroy(h->ev_cam_parked);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
@@ -297,6 +298,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
+    else if (s == "cam_side") h->opt_cam_side = value;
     else if (s == "gn_prologue_blocks") h->opt_gn_prologue_blocks = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
@@ -737,12 +739,15 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     // behind everything the main stream holds so far: the parking of the camera's context by ifx_camera_select above all
     HIPCHK(h, hipEventRecord(h->ev_cam_parked, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream_c, h->ev_cam_parked, 0));
+    h->cam_side_stream = (h->opt_cam_side && h->opt_two_streams && h->stream_b) ? h->stream_b : nullptr;
+    if (h->cam_side_stream) HIPCHK(h, hipStreamWaitEvent(h->cam_side_stream, h->ev_cam_parked, 0));
     h->cur = h->stream_c;
     int r;
     {
         StageTimer t(h, 0);
         r = ifx_tracker_camera_ahead(h, cam, d_rgb, d_depth);
     }
+    h->cam_side_stream = nullptr;
     // the run's pose block into the camera's own parking place: the tracker instance is free for the next camera's run (they queue on the third stream).  The event
     // is the camera's own: the frame that takes this run must not wait for runs enqueued after it (one shared event, re-recorded behind every run, made every frame
     // wait for the run enqueued just before it: no overlap at all)

@@ -271,7 +271,8 @@ struct ifx {
     DevState* d_cam_trk = nullptr;
     Pyr cam_pyr;
     double* cam_so3_acc = nullptr; unsigned int* cam_so3_ticket = nullptr;
-    hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr;
+    hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr, ev_cam_side = nullptr;
+    hipStream_t cam_side_stream = nullptr;   // set around ifx_tracker_camera_ahead: the stream its frame side goes to (null: the same stream as its tracker)
     int cam_ahead_used = 0;             // frames whose tracker was taken from a run ahead (diagnostics / tests)
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
@@ -285,6 +286,7 @@ struct ifx {
     int opt_two_streams = 1;
     int opt_stage_timing = 0;           // HIP events around the stages of every frame (ifx_stage_ms); each record is a marker packet on the queue: ~4 % of the frame rate
     int opt_gn_prologue_blocks = 2048;  // gn_prologue only for launches of at most this many blocks (every block repeats the solve)
+    int opt_cam_side = 1;               // a run-ahead tracker's frame side on the side stream, its tracker on the third (0: both on the third)
     int opt_cam_swap = 1;               // a camera switch between two existing contexts hands the prediction / fill-in / id blocks over by pointer instead of copying them
     int opt_fold_result = 1;            // view-list frames: the frame result is written by the last block of the frame's last launch (k_splat_resolve) instead of a launch of its own
     float* result_fold_traj = nullptr;  // set by enqueue_frame around ifx_map_predict: the trajectory slot of the frame being finished (null: nobody asked)

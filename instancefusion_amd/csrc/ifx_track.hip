@@ -2860,12 +2860,22 @@ int ifx_tracker_camera_ahead(ifx* h, int cam, const uint8_t* d_rgb, const uint16
     DevState* st = h->d_cam_trk;
     Pyr& p = h->cam_pyr;
     const int bound = h->cur_slot, cs = 3 + cam;
+    // the run's frame side -- image-only work -- on the side stream when the caller prepared one (h->cam_side_stream: it already waits for the parking of the
+    // camera's context): it then overlaps the tracker of the run before it on the third stream, which waits for "frame side done" below
+    hipStream_t const trk_stream = h->cur;
+    if (h->cam_side_stream) h->cur = h->cam_side_stream;
     HIPCHK(h, hipMemcpyAsync(h->slot[cs].rgb, d_rgb, (size_t)h->P * 3, hipMemcpyDeviceToDevice, h->cur));
     HIPCHK(h, hipMemcpyAsync(h->slot[cs].depth_raw, d_depth, (size_t)h->P * 2, hipMemcpyDeviceToDevice, h->cur));
     ifx_bind_slot(h, cs);
     for (int i = 0; i < IFX_NUM_PYRS; i++) h->pyr.lastnext_img[i] = cc.img[i];   // the "previous image" of the SO(3) step: the camera's last frame, parked with its context
     ifx_preprocess(h);
     ifx_tracker_frame_side(h, 0, h->cam_so3_acc, h->cam_so3_ticket);
+    if (h->cam_side_stream) {
+        if (!h->ev_cam_side) HIPCHK(h, hipEventCreateWithFlags(&h->ev_cam_side, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_cam_side, h->cam_side_stream));
+        HIPCHK(h, hipStreamWaitEvent(trk_stream, h->ev_cam_side, 0));
+        h->cur = trk_stream;
+    }
     for (int i = 0; i < IFX_NUM_PYRS; i++) {   // the instance tracks the frame in the camera's slot
         p.vmap_curr[i] = h->pyr.vmap_curr[i]; p.nmap_curr[i] = h->pyr.nmap_curr[i]; p.next_img[i] = h->pyr.next_img[i]; p.didx[i] = h->pyr.didx[i]; p.didy[i] = h->pyr.didy[i];
         p.depth_tmp[i] = h->pyr.depth_tmp[i]; p.lastnext_img[i] = cc.img[i];

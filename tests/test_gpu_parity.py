@@ -1024,6 +1024,62 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
     one.close()
 
 
+@pytest.mark.parametrize("swap,side", [(1, 1), (0, 1), (1, 0)])
+def test_config5_three_streams_runs_ahead_per_camera(ifx, swap, side):
+    """K = 3 cameras into one sharded map in a world of one (the collectives inside the library), every camera tracked by the one rank: with the run-ahead schedule
+    every camera has a run pending at any time -- pose block, event and frame slot parked per camera; the frame binds the run's slot instead of computing its frame
+    side again; the run's frame side on the side stream, its tracker on the third -- and the camera switch moves the prediction / fill-in / id blocks by pointer.
+    Against the same streams with every frame tracking inside itself: every pose, every prediction, the id image and the whole map, bit for bit; options cam_swap /
+    cam_side off give the same again."""
+    import torch
+
+    from instancefusion_amd import sharded, synth
+
+    K, NS = 3, 6
+    W, H = SMALL["w"], SMALL["h"]
+    st = synth.make_stream(40, W, H, SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], noise=True, loop_len=90)
+    first = (0, 12, 24)
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    outs = []
+    for ahead in (0, 1):
+        ef = ifx.ElasticFusion(**SMALL, max_surfels=600000, n_ranks=-1, rank=0)
+        ef.set_option("cam_swap", swap)
+        ef.set_option("cam_side", side)
+        osh = sharded.OwnerShardedElasticFusion(ef, None)
+        ef.camera_count(K)
+        poses, preds = [], []
+        for s_ in range(NS):
+            for c in range(K):
+                i = first[c] + s_
+                ef.camera_select(c)
+                ef.owner_set_tracking_rank(0)
+                if c > 0 and s_ == 0:
+                    ef.owner_set_frame_pose(st["poses"][i].astype(np.float32))
+                if ahead and (s_ > 0 or c > 0):   # the camera parked a moment ago: its next frame's tracker starts now
+                    cp, sp = (c - 1, s_) if c > 0 else (K - 1, s_ - 1)
+                    if sp + 1 < NS:
+                        j = first[cp] + sp + 1
+                        ef.owner_track_ahead(cp, 0, d_rgb[j].data_ptr(), d_dep[j].data_ptr())
+                osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+                poses.append(ef.getCurrPose())
+                if s_ in (1, NS - 1):
+                    preds.append((ef.image("pred_vertex"), ef.image("pred_image"), ef.image("fill_vertex"), ef.image("ids_after")))
+        served = ef.owner_track_ahead(-1, 0)
+        order = np.argsort(ef.seq(), kind="stable")
+        m = ef.download()
+        outs.append((np.stack(poses), preds, {k: m[k][order] for k in MAP_KEYS}, served))
+        ef.close()
+    a, b = outs
+    assert a[3] == 0 and b[3] == K * (NS - 1)   # every frame from the second set on took its pose from a run ahead (first set: the map's first frame / the cameras' extrinsic poses)
+    assert np.array_equal(a[0], b[0])
+    for pa, pb in zip(a[1], b[1]):
+        assert all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    assert all(np.array_equal(a[2][k], b[2][k]) for k in MAP_KEYS)
+    assert np.abs(a[0][-1] - st["poses"][first[K - 1] + NS - 1]).max() < 0.05
+
+
 @pytest.mark.timeout(3000)
 def test_config5_8_streams_50m_map_sharded_x8(ifx):
     """BASELINE configuration 5 AT ITS SIZE, emulated in one process: K = 8 concurrent 640x480 streams (eight stretches of the benchmark trajectory through the same

@@ -66,7 +66,13 @@ const char* ifx_global_error(void);
  * (IF/map_interface/ElasticFusionInterface.h:129-130).
  * rgb: H*W*3 u8 row-major, depth: H*W u16 millimetres (0 invalid).  in_pose16: NULL to track, or a
  * row-major 4x4 camera-to-world pose to use instead of tracking.  out_pose16 (may be NULL) receives
- * currPose.  Returns 0 ok, 1 lost (never in this configuration: reloc=false), <0 error. */
+ * currPose.  Returns 0 ok, 1 lost (never in this configuration: reloc=false), <0 error.
+ * The caller's buffers are copied during the call, which returns when the whole frame is done.
+ * Option "host_entry_async" 1 (for a host whose loop is ifx_process_frame after ifx_process_frame -- a log replay without masks): the call returns when the frame's
+ * POSE is known (it is read back right behind the tracker); the frame's map passes finish under the caller's next steps -- its copy of the next frame, typically
+ * -- like the reference's GL work after processFrame has issued it.  Every accessor of the map, the images or the frame result waits for them, exactly as after
+ * ifx_enqueue_frame_device; the housekeeping decision of the frame (compaction) is taken at the start of the next ifx_process_frame, from the same numbers; near
+ * the capacity, with loop-closure detection on and for the first frame the call synchronises fully. */
 int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
                       const float* in_pose16, float weight_mult, float* out_pose16);
 /* The complete argument list of ElasticFusion::processFrame (EF/ElasticFusion.h:75-82).

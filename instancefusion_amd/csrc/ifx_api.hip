@@ -121,6 +121,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->d_state, 0, sizeof(DevState));
     if (hipHostMalloc((void**)&h->h_result, sizeof(FrameResult)) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
     memset(h->h_result, 0, sizeof(FrameResult));
+    if (hipHostMalloc((void**)&h->h_pose_early, 64) != hipSuccess) { g_err = "hipHostMalloc failed"; ifx_destroy(h); return IFX_E_HIP; }
+    hipEventCreateWithFlags(&h->ev_pose_early, hipEventDisableTiming);
     ALLOC(h->d_traj, (size_t)h->max_traj * 64);
     ALLOC(h->d_scratch, 8 * 64);
     ALLOC(h->pc, C * 16); ALLOC(h->nr, C * 16); ALLOC(h->col, C * 8); ALLOC(h->tm, C * 8); ALLOC(h->ic, C * 16); ALLOC(h->votes, C * 192);
@@ -230,6 +232,8 @@ extern "C" void ifx_destroy(ifx_t* h)
     for (void* p : ptrs) if (p) hipFree(p);
     for (size_t q = 2; q < h->slot.size(); q++) { FrameSlot& f2 = h->slot[q]; void* p2[] = {f2.rgb, f2.depth_raw, f2.depth_filt, f2.dm, f2.dmf}; for (void* p : p2) if (p) hipFree(p); }
     if (h->h_result) hipHostFree(h->h_result);
+    if (h->h_pose_early) hipHostFree(h->h_pose_early);
+    if (h->ev_pose_early) hipEventDestroy(h->ev_pose_early);
     if (h->rgb_stage) hipHostFree(h->rgb_stage);
     if (h->depth_stage) hipHostFree(h->depth_stage);
     ifx_free_tracker(h);
@@ -299,6 +303,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
+    else if (s == "host_entry_async") h->opt_host_entry_async = value;
     else if (s == "gn_prologue_blocks") h->opt_gn_prologue_blocks = value;
     else if (s == "compact_divisor") h->opt_compact_divisor = value;
     else if (s == "icp_blocks") h->opt_icp_blocks = std::max(0, std::min(2048, value));
@@ -556,6 +561,11 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
             }
+        }
+        if (h->want_early_pose && !h->lc_enable) {   // ifx_process_frame: the pose the call returns, behind the tracker and in front of the map passes
+            HIPCHK(h, hipMemcpyAsync(h->h_pose_early, (const void*)h->d_state, 64, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipEventRecord(h->ev_pose_early, h->stream));
+            h->early_pose_valid = 1;
         }
         if (h->lc_enable) {
             int r = enqueue_loop_closure_renders(h);
@@ -1147,16 +1157,44 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
 {
     (void)timestamp; (void)inst_table;
     if (!h || !rgb || !depth) return IFX_E_INVALID;
-    // caller buffers are borrowed for the call only (EF/ElasticFusion.cpp:280-281 copies them too)
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // caller buffers are borrowed for the call only (EF/ElasticFusion.cpp:280-281 copies them too).
+    // The call returns when the frame's POSE is known -- read back right behind the tracker -- and the frame's map passes finish under whatever the caller does next
+    // (typically: the next call's copy of its frame into the staging buffers, 0.1 ms during which the device used to idle).  Everything that looks at the map, the
+    // images or the frame result afterwards waits for the frame as on the enqueue path (ifx_enqueue_frame_device has always returned earlier than this); a surfel store
+    // that filled up is reported by the NEXT call (or by ifx_sync / any whole-map consumer).  Not with the loop-closure detection on (a deformation may still adopt
+    // another pose) and not for the first frame.  OPT-IN (option "host_entry_async" 1): the compaction decision a synchronous call takes right behind its frame is
+    // taken at the start of the NEXT ifx_process_frame instead (from the same numbers) -- equivalent for a host whose loop is ifx_process_frame after
+    // ifx_process_frame, but a camera switch, an upload or a segmentation call in between would see the store before that compaction instead of after it.
+    const bool can_early = h->opt_host_entry_async && !h->lc_enable && !h->in_fern_cb && h->tick > 1;
+    // (the staging buffers are free: their last copy to the device ran in front of a tracker whose pose a previous call has waited for -- or behind a full synchronisation)
+    if (!can_early) HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
     memcpy(h->depth_stage, depth, (size_t)h->P * 2);
+    bool early = false;
+    if (can_early) {
+        // the frame before this one is complete from here on: its result is final, and the housekeeping decision a synchronous call would have taken right behind it
+        // is taken now, from the same numbers, at the same place in the stream -- slot numbers do not depend on timing
+        if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
+        if (h->housekeeping_due) { ifx_housekeeping(h); h->housekeeping_due = 0; }
+        // near the capacity the frame itself must report a store that fills up: the synchronous form
+        early = !h->h_result->overflow && (long long)h->h_result->count + 2LL * h->P <= (long long)h->cap;
+    }
+    h->want_early_pose = early ? 1 : 0;
+    h->early_pose_valid = 0;
     int r = enqueue_frame(h, h->rgb_stage, h->depth_stage, 1, in_pose16, weight_mult, bootstrap);
+    h->want_early_pose = 0;
     if (r) return r;
+    if (early && h->early_pose_valid) {
+        HIPCHK(h, hipEventSynchronize(h->ev_pose_early));
+        if (out_pose16) memcpy(out_pose16, h->h_pose_early, 64);
+        h->housekeeping_due = 1;
+        return 0;
+    }
     r = ifx_sync(h);
     if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
     if (r) return r;
     ifx_housekeeping(h);
+    h->housekeeping_due = 0;
     return 0;
 }
 

@@ -378,6 +378,12 @@ struct ifx {
     // device state
     DevState* d_state = nullptr;
     FrameResult* h_result = nullptr;   // pinned
+    // host-pointer entry (ifx_process_frame): the pose is read back right behind the tracker, the call returns with it and the frame's map passes finish under the
+    // caller's next steps (its copy of the next frame into the staging buffers, typically)
+    float* h_pose_early = nullptr;     // pinned, 16 floats
+    hipEvent_t ev_pose_early = nullptr;
+    int want_early_pose = 0, early_pose_valid = 0, housekeeping_due = 0;
+    int opt_host_entry_async = 0;      // opt-in (see ifx_process_frame_ex): the deferred housekeeping decision must not be separated from its frame by other calls
     float* d_traj = nullptr;           // [max_traj][16] ring: frame f's pose lives in slot f % max_traj (ifx_trajectory returns the last max_traj frames)
     int max_traj = 1 << 16;
     float* d_scratch = nullptr;        // [8][16] poses uploaded by the stage API / inPose / ifx_track_maps (0-1 stage pose + inverse, 2 inPose, 4 track_maps, 6 track_pair)

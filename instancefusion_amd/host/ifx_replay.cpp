@@ -102,6 +102,9 @@ int main(int argc, char** argv)
             return 1;
         }
         instancefusion->bindMap(map);
+        // frames only (no masks, so no whetherDoSegmentation between the frames; no loop closing): ProcessFrame may return with the pose while the frame's map passes finish
+        // under the decoding / copying of the next frame (ifx_c_api.h: "host_entry_async")
+        if (a.masks.empty() && !a.close_loops && !a.shard.on()) ifx_set_option(map->handle(), "host_entry_async", 1);
         if (!a.deform) map->elasticFusion().setDeformOnLoopClosure(false);
 
         int frame_Fusion = 0, lastTimeFlann = -1;

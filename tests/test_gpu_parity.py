@@ -1465,6 +1465,27 @@ def test_superpixels_ahead_of_a_call_change_nothing(ifx):
     assert all(np.array_equal(a[2][k], b[2][k]) for k in a[2]), [k for k in a[2] if not np.array_equal(a[2][k], b[2][k])]
 
 
+def test_host_entry_returning_with_the_pose_changes_nothing(ifx, small_stream):
+    """Option host_entry_async: ifx_process_frame returns when the frame's pose is known (read back right behind the tracker) and the map passes finish under the
+    caller's copy of the next frame; the frame's housekeeping decision moves to the start of the next call.  A loop of frames only, with compactions forced often:
+    the same poses from every call, the same map and the same coverage of the id image as with the fully synchronous entry (the slot numbers in the last id image may
+    differ: the last frame's compaction is still pending in the one mode and done in the other)."""
+    st = small_stream
+    outs = []
+    for mode in (0, 1):
+        g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
+        g.set_option("host_entry_async", mode)
+        g.set_option("compact_divisor", 64)
+        poses = [g.processFrame(st["rgb"][i % 10], st["depth"][i % 10]) for i in list(range(10)) + list(range(8, -1, -1))]
+        ids, slots, m = g.image("ids_after"), g.slots, g.download()
+        outs.append((np.stack(poses), ids, slots, m))
+        g.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1] > 0, b[1] > 0)
+    assert all(np.array_equal(a[3][k], b[3][k]) for k in MAP_KEYS)
+    assert a[3]["pc"].shape[0] > 50000
+
+
 def test_segmentation_call_on_the_resident_frame(ifx):
     """ifx_process_segmentation with rgb = depth = NULL refines the masks on the frame most recently processed, still resident in its frame slot: the same
     tables, votes, labels and colours as with the host copies of that frame handed over (the reference's signature)."""

@@ -72,7 +72,7 @@ const char* ifx_global_error(void);
  * POSE is known (it is read back right behind the tracker); the frame's map passes finish under the caller's next steps -- its copy of the next frame, typically
  * -- like the reference's GL work after processFrame has issued it.  Every accessor of the map, the images or the frame result waits for them, exactly as after
  * ifx_enqueue_frame_device; the housekeeping decision of the frame (compaction) is taken at the start of the next ifx_process_frame, from the same numbers; near
- * the capacity, with loop-closure detection on and for the first frame the call synchronises fully. */
+ * the capacity, with loop-closure detection on, with camera contexts, with an external pose and for the first frame the call synchronises fully. */
 int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
                       const float* in_pose16, float weight_mult, float* out_pose16);
 /* The complete argument list of ElasticFusion::processFrame (EF/ElasticFusion.h:75-82).

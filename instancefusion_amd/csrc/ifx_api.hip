@@ -654,6 +654,11 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
     if (h->cams.empty() || cam == h->cur_cam) return IFX_OK;
     if (h->hint_rgb || h->slot[h->tick & 1].for_tick == h->tick) { h->err = "ifx_camera_select: a frame is announced ahead"; return IFX_E_STATE; }
     ifx_drop_tracked(h);
+    if (h->housekeeping_due) {   // (option host_entry_async: the compaction decision of the frame just processed, while its camera is still the live one -- a compaction re-renders at the live pose)
+        if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
+        ifx_housekeeping(h);
+        h->housekeeping_due = 0;
+    }
     if (h->lc_pending && h->stream_c) { HIPCHK(h, hipStreamSynchronize(h->stream_c)); h->lc_pending = 0; }
     ifx_vlist_reap(h); hs_invalidate_view(h);   // another pose: the cached view list is void (reaped first: no slot outlives the age rule unseen)
     const size_t P = (size_t)h->P;
@@ -1165,7 +1170,7 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
     // another pose) and not for the first frame.  OPT-IN (option "host_entry_async" 1): the compaction decision a synchronous call takes right behind its frame is
     // taken at the start of the NEXT ifx_process_frame instead (from the same numbers) -- equivalent for a host whose loop is ifx_process_frame after
     // ifx_process_frame, but a camera switch, an upload or a segmentation call in between would see the store before that compaction instead of after it.
-    const bool can_early = h->opt_host_entry_async && !h->lc_enable && !h->in_fern_cb && h->tick > 1;
+    const bool can_early = h->opt_host_entry_async && !h->lc_enable && !h->in_fern_cb && h->tick > 1 && h->cams.empty() && !in_pose16;   // (plain tracked frames of a single stream)
     // (the staging buffers are free: their last copy to the device ran in front of a tracker whose pose a previous call has waited for -- or behind a full synchronisation)
     if (!can_early) HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
@@ -1371,6 +1376,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
     ifx_drop_tracked(h);
     for (CamCtx& c_ : h->cams) c_.ahead_valid = 0;
+    h->housekeeping_due = 0;   // (a decision about the map that is being replaced)
     h->seg_counts_valid = 0;
     h->map_external = 1;
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "host_entry_returning" 2>&1 | grep -a "^E  \|assert\|passed\|failed" | head -12 | cut -c1-300
+IFX_OPTS="host_entry_async=1" python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -a "passed\|failed\|^FAILED" | head -12

@@ -1024,6 +1024,48 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
     one.close()
 
 
+def test_camera_contexts_on_the_enqueue_path(ifx):
+    """Camera contexts on an UNSHARDED handle fed through the enqueue-only entry (ifx_enqueue_frame_device: the call returns while the frame is still running, the
+    camera switch that follows is enqueued behind it) against the same frames through the synchronous entry: every pose and the map, bit for bit."""
+    import torch
+
+    from instancefusion_amd import synth
+
+    K, NS = 2, 6
+    W, H = SMALL["w"], SMALL["h"]
+    st = synth.make_stream(30, W, H, SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], noise=True, loop_len=90)
+    first = (0, 15)
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    outs = []
+    for enqueue in (0, 1):
+        g = ifx.ElasticFusion(**SMALL, max_surfels=600000)
+        g.camera_count(K)
+        poses = []
+        for s_ in range(NS):
+            for c in range(K):
+                i = first[c] + s_
+                g.camera_select(c)
+                if s_ == 0 or not enqueue:   # (a camera's first frame: host entry in both runs -- camera 1 enters with its extrinsic pose)
+                    g.processFrame(st["rgb"][i], st["depth"][i], inPose=(st["poses"][i].astype(np.float32) if (c == 1 and s_ == 0) else None))
+                else:
+                    g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+                if not enqueue:
+                    poses.append(g.getCurrPose())
+        if enqueue:
+            g.sync()
+        traj = g.trajectory()
+        m = g.download()
+        outs.append((traj, m, poses))
+        g.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(np.stack(a[2]), a[0])      # (the trajectory log is the sequence of the frames' poses)
+    assert all(np.array_equal(a[1][k], b[1][k]) for k in MAP_KEYS)
+    assert np.abs(a[0][-1] - st["poses"][first[1] + NS - 1]).max() < 0.05
+
+
 @pytest.mark.parametrize("swap,side", [(1, 1), (0, 1), (1, 0)])
 def test_config5_three_streams_runs_ahead_per_camera(ifx, swap, side):
     """K = 3 cameras into one sharded map in a world of one (the collectives inside the library), every camera tracked by the one rank: with the run-ahead schedule

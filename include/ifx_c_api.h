@@ -234,6 +234,12 @@ int ifx_tracker_diag(ifx_t* h, float* diag8);
  * ifx_create, >= 0; negative: error.  Replaces nothing of the reference (its tracker reads every reduction back, EF/Utils/RGBDOdometry.cpp:461-583): a diagnostic
  * of this implementation's schedule.  Waits for the frames in flight. */
 int ifx_tracker_fallbacks(ifx_t* h);
+/* Run-time guard of the tracker's exact sums: the number of reductions, since ifx_create, whose diagonal totals left the range in which every addition of the normal-equation
+ * sums is exact (2^53 units of the entry's grid; tested at half of it).  While it is 0 the sums -- and with them every pose -- are independent of the order in which blocks and
+ * atomics arrive and equal to the CPU oracle's; a non-zero count names frames (saturated edges at near range, magnitudes ~2^7 above what real RGB-D data produces) whose poses
+ * may differ from run to run in the last bit.  >= 0; negative: error.  Replaces nothing of the reference (its reductions are f32 trees whose shape depends on the GPU,
+ * EF/Utils/GPUConfig.h:53-137: no order-independence to guard).  Waits for the frames in flight. */
+int ifx_tracker_range_exceeded(ifx_t* h);
 
 /* ---- local loop-closure DETECTION (the closeLoops / countThresh / errThresh / covThresh constructor arguments, EF/ElasticFusion.h:48-51;
  * EF/ElasticFusion.cpp:453-566 with no fern match).  When enabled every tracked frame also runs predict() at the new pose, the INACTIVE

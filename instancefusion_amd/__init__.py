@@ -106,6 +106,7 @@ _SIGS = {
     "ifx_trajectory": (C.c_int, [_P, _P, C.c_int]),
     "ifx_tracker_diag": (C.c_int, [_P, _P]),
     "ifx_tracker_fallbacks": (C.c_int, [_P]),
+    "ifx_tracker_range_exceeded": (C.c_int, [_P]),
     "ifx_set_loop_closure": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "ifx_loop_closure_diag": (C.c_int, [_P, _P]),
     "ifx_set_loop_closure_callback": (C.c_int, [_P, _P, _P]),
@@ -321,6 +322,10 @@ class ElasticFusion:
     def tracker_fallbacks(self):
         """pyramid levels the persistent Gauss-Newton kernel handed to its one-workgroup fallback so far (0 in a healthy run)"""
         return self._chk(self.L.ifx_tracker_fallbacks(self.handle), "ifx_tracker_fallbacks")
+
+    def tracker_range_exceeded(self):
+        """reductions whose totals left the exact range of the tracker's sums so far (0: every pose is order-independent and equals the oracle's)"""
+        return self._chk(self.L.ifx_tracker_range_exceeded(self.handle), "ifx_tracker_range_exceeded")
 
     # -- local loop-closure detection (closeLoops, countThresh, errThresh, covThresh of the reference constructor)
     def set_loop_closure(self, enable=True, count_thresh=35000, err_thresh=5e-5, cov_thresh=1e-5):

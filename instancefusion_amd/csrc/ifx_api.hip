@@ -301,6 +301,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "track_ahead") h->opt_track_ahead = value;
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
+    else if (s == "clean_raster") h->opt_clean_raster = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
     else if (s == "host_entry_async") h->opt_host_entry_async = value;
@@ -573,7 +574,10 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
         }
         {
             StageTimer t(h, 1);
+            h->frame_weight_mult = weight_mult;
+            h->result_fold_traj = h->d_traj + (size_t)(h->n_traj % h->max_traj) * 16;   // (ifx_map_frame asks whether the prediction's resolve will take the frame result along)
             ifx_map_frame(h);
+            h->result_fold_traj = nullptr;
         }
         if (h->lc_enable) {
             int r = enqueue_loop_closure_tracker(h);
@@ -1148,6 +1152,32 @@ extern "C" int ifx_tracker_fallbacks(ifx_t* h)
     if (!h) return IFX_E_INVALID;
     int r = ifx_sync(h);
     return r ? r : h->h_result->gn_timeout;
+}
+
+// Run-time guard of the tracker's exact sums (ifx_track.hip range_exceeded7): how often, since ifx_create, a reduction's diagonal total was found beyond half the range in
+// which every addition of the 29 (SO(3): 11) sums is exact -- i.e. how often "the sums do not depend on the order of the atomics, and equal the oracle's" was NOT guaranteed
+// (frames of saturated edges at near range; the images this path sees in tests and bench.py are 2^7 below it).  0 = every pose so far is the pose of the fixed arithmetic.
+// Summed over every tracker instance of the handle (frame tracker, its SO(3) pre-alignment in the frame slots, model-to-model tracker, camera run-ahead tracker).
+// (No counterpart in the reference: its f32 tree sums have no exactness to lose.)  Waits for the frames in flight.
+extern "C" int ifx_tracker_range_exceeded(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    int r = ifx_sync(h);
+    if (r) return r;
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+    if (h->stream_b) HIPCHK(h, hipStreamSynchronize(h->stream_b));
+    std::vector<const DevState*> sts;
+    sts.push_back(h->d_state);
+    if (h->d_m2m) sts.push_back(h->d_m2m);
+    if (h->d_cam_trk) sts.push_back(h->d_cam_trk);
+    for (const FrameSlot& f : h->slot) if (f.so3) sts.push_back(f.so3);
+    long long total = 0;
+    for (const DevState* d : sts) {
+        int v = 0;
+        HIPCHK(h, hipMemcpy(&v, (const char*)d + offsetof(DevState, range_exceeded), sizeof(int), hipMemcpyDeviceToHost));
+        total += v;
+    }
+    return (int)std::min<long long>(total, 0x7FFFFFFF);
 }
 
 extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const float* in_pose16, float weight_mult, float* out_pose16)

@@ -53,6 +53,7 @@ struct DevState {
     unsigned int append_ticket;  // last-block ticket of k_append_scan
     unsigned int result_ticket;  // last-block ticket of k_splat_resolve when it also writes the frame result (FrameOut)
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
+    int range_exceeded;          // run-time guard of the tracker's exact sums: diagonal totals found beyond half their exact range since the handle was created (ifx_track.hip range_exceeded7; ifx_tracker_range_exceeded)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
     // local loop-closure detection (EF/ElasticFusion.cpp:453-566).  The model-to-model tracker has a DevState of its own (ifx::d_m2m):
     // there `count` counts the pixels of the INACTIVE render and `skip` is set when it is empty; the verdict lands in lc[] of the MAIN state.
@@ -288,6 +289,10 @@ struct ifx {
     int opt_gn_prologue_blocks = 2048;  // gn_prologue only for launches of at most this many blocks (every block repeats the solve)
     int opt_cam_side = 1;               // a run-ahead tracker's frame side on the side stream, its tracker on the third (0: both on the third)
     int opt_cam_swap = 1;               // a camera switch between two existing contexts hands the prediction / fill-in / id blocks over by pointer instead of copying them
+    int opt_clean_raster = 1;           // view-list frames: ONE walk of the view list cleans and rasterises (k_raster_view<., true>, with k_new_flags_count's blocks in the same launch):
+                                        // two launches and one set of gathers less on every frame's chain (ifx_map.hip, "CLEAN")
+    int clean_raster_pending = 0;       // ifx_map_frame left the clean / new-surfel flags / append of this frame to ifx_map_predict's launches
+    float frame_weight_mult = 1.f;      // weight multiplier of the frame being enqueued (bounds the confidence a new surfel can start with)
     int opt_fold_result = 1;            // view-list frames: the frame result is written by the last block of the frame's last launch (k_splat_resolve) instead of a launch of its own
     float* result_fold_traj = nullptr;  // set by enqueue_frame around ifx_map_predict: the trajectory slot of the frame being finished (null: nobody asked)
     int result_folded = 0;              // ifx_map_predict's answer: the resolve took the frame result along

@@ -87,10 +87,14 @@ __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int se
 // occludes like any other but can never be associated, counted in a clean window, voted for).  The reference compacts every frame, so "surfel 0" is always the FIRST LIVE
 // surfel of the map; with tombstones the first live surfel may sit at a later slot: it is drawn as id 0 (DevState::first_live, kept by k_append_scan / k_vlist_offsets /
 // the compaction), and id 0 resolves back to that slot.  With compact_every_frame first_live is always 0: the identity.
-__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i) { return c.own_n > 0 ? c.seq[i] : ((c.raw_slots || i != (unsigned int)*c.first_live) ? i : 0u); }
-__device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id)
+// fl = DevState::first_live, read ONCE at the top of every kernel that names surfels (FIRST_LIVE(c): before the kernel's first store, where a uniform load goes through
+// the scalar cache).  As `*c.first_live` at the point of use -- behind stores and atomics -- it compiled to a vector load of one address by every wave: ~2 ns each at the
+// one L2 channel that holds the line, 11 us of a 300 k-thread launch (k_splat_resolve 40 -> 29 us, profiles/r05_*).
+#define FIRST_LIVE(c) ((c).own_n > 0 ? 0 : *(c).first_live)
+__device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i, int fl) { return c.own_n > 0 ? c.seq[i] : ((c.raw_slots || i != (unsigned int)fl) ? i : 0u); }
+__device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id, int fl)
 {
-    if (c.own_n <= 0) return id == 0u ? *c.first_live : (int)id;
+    if (c.own_n <= 0) return id == 0u ? fl : (int)id;
     int lo = 0, hi = count - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -248,6 +252,7 @@ __device__ __forceinline__ void key_min(unsigned long long* __restrict__ addr, u
 __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
                                                                const float2* __restrict__ tm, Cam c, int time, unsigned long long* __restrict__ keys)
 {
+    const int fl = FIRST_LIVE(c);
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
 #pragma unroll
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
         float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
         if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
         int px = (int)floorf(u), py = (int)floorf(v);
-        key_min(&keys[py * c.w + px], make_key(p.z, key_id(c, (unsigned int)i)));
+        key_min(&keys[py * c.w + px], make_key(p.z, key_id(c, (unsigned int)i, fl)));
     }
 }
 // index_map.frag:33-40: gathers the winner's attributes; also re-arms the key image for the next pass
@@ -272,6 +277,7 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
                                 float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm, int time, float conf_thr, float4* __restrict__ tap, Cam c,
                                 const int32_t* __restrict__ own_slot = nullptr)
 {
+    const int fl = FIRST_LIVE(c);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
     unsigned long long key = keys[k];
@@ -285,7 +291,7 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     }
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
-    const int li = own_slot ? own_slot_of(c, own_slot[k], id) : local_slot(c, st->count, id);
+    const int li = own_slot ? own_slot_of(c, own_slot[k], id) : local_slot(c, st->count, id, fl);
     if (li < 0) {   // sharded map: another rank's surfel won this pixel -- that rank writes its attributes, this one zeros (the images are summed bitwise across ranks)
         if (index_id) { index_id[k] = id; vc[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); if (ct) ct[k] = make_float4(0, 0, 0, 0); }
         if (tap) tap[k] = make_float4(0, 0, 0, 0);
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster(const DevState* __restri
                                                         const float4* __restrict__ nr, const float2* __restrict__ tm, const float4* __restrict__ votes, int cap, Cam c,
                                                         int time, int maxTime, unsigned long long* __restrict__ keys)
 {
+    const int fl = FIRST_LIVE(c);
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
 #pragma unroll
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster(const DevState* __restri
                 if (!disc_hit(d, (float)px + 0.5f, (float)py + 0.5f, c, z)) continue;
                 if (MODE == 0) { if (!(z >= -c.maxDepth && z <= c.maxDepth)) continue; }
                 else { if (!(z > 0 && z <= c.maxDepth)) continue; }
-                atomicMin(&keys[py * c.w + px], make_key(z, key_id(c, (unsigned int)i)));
+                atomicMin(&keys[py * c.w + px], make_key(z, key_id(c, (unsigned int)i, fl)));
             }
     }
 }
@@ -452,6 +459,8 @@ struct FrameOut {
     int fold_total;
 };
 
+#define NEW_PER_BLOCK 1024   // pixels (in append order) per block of the new-surfel flags pass
+
 // combo_splat.frag:54-66 outputs for the winner of each pixel, fused with FillIn
 // (fill_rgb/vertex/normal.frag, EF/Shaders/FillIn.cpp:65-195, passthrough = 0).
 __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
@@ -459,7 +468,8 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
-                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr)
+                                int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr,
+                                const int fl = 0, const bool raw_ids = false)   // fl: FIRST_LIVE(c) from the top of the kernel; raw_ids: the walk that drew these keys named every surfel by its slot (option clean_raster): "surfel 0" is named here
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -490,6 +500,7 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
         ik = ik < bk ? ik : bk;
         key = key < bk ? key : bk;
         fold_id = (ik == IFX_KEY_EMPTY) ? 0 : (int32_t)(ik & 0xFFFFFFFFull);
+        if (raw_ids && fold_id == fl) fold_id = 0;   // (clean_raster: the walk drew slot numbers; the append behind it settled which slot is the reference's "surfel 0")
         ids_out[k] = fold_id;
     }
     float4 vo = make_float4(0, 0, 0, 0), no = make_float4(0, 0, 0, 0);
@@ -497,7 +508,8 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
     uint16_t to = 0;
     int li = -1;
     if (key != IFX_KEY_EMPTY) {
-        li = own_slot ? own_slot_of(c, own_slot[k], (unsigned int)(key & 0xFFFFFFFFull)) : local_slot(c, st->count, (unsigned int)(key & 0xFFFFFFFFull));
+        li = raw_ids ? (int)(unsigned int)(key & 0xFFFFFFFFull)
+                     : (own_slot ? own_slot_of(c, own_slot[k], (unsigned int)(key & 0xFFFFFFFFull)) : local_slot(c, st->count, (unsigned int)(key & 0xFFFFFFFFull), fl));
         if (li < 0) {   // sharded map: the winner's rank writes this pixel, the others leave zeros (summed bitwise across ranks) ...
             if (pconf) {   // ... except the vertex of the frame's prediction, which every rank rebuilds from the key it holds (the confidence comes from the owner through pconf)
                 const float z = key_depth(key);
@@ -526,6 +538,23 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
     if (pconf) { pconf[k] = vo.w; vo.w = 0.f; }   // (owner: the confidence travels apart; fill_in puts it back after the exchange)
     pv[k] = vo; pn[k] = no; pimg[k] = io; pinst[k] = so; ptime[k] = to;
     (void)n_valid;
+    if (fv) {   // (no fill-in for the loop-closure renders: EF/ElasticFusion.cpp:519-534 reads the raw old textures)  -- before the end-of-pass sums: what it needs is dead when their twelve vote gathers are in flight
+    // fill-in
+    float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
+    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(f_r, f_g, f_b, 255);
+    else fimg[k] = io;
+    float zc = (float)f_d / 1000.0f;
+    if (vo.z == 0) fv[k] = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
+    else fv[k] = vo;
+    if (no.z == 0) {
+        v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
+        float zx = (float)f_dx / 1000.0f, zy = (float)f_dy / 1000.0f;
+        v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
+        v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
+        v3 nn = normalized(cross(vx - vp, vy - vp));
+        fn[k] = make_float4(nn.x, nn.y, nn.z, 1.f);
+    } else fn[k] = no;
+    }
     if (fold.acc) {   // (uniform)
         __shared__ int s_f[3];
         const int lt = threadIdx.y * blockDim.x + threadIdx.x;
@@ -557,24 +586,10 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
         if (lt < 3 && s_f[lt]) atomicAdd(fold.acc + (blockIdx.x & 15) * 4 + lt, s_f[lt]);
         if (fold.total && lt == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fold.total = fold.rw * fold.rh;
     }
-    if (!fv) return;   // no fill-in for that render (EF/ElasticFusion.cpp:519-534 reads the raw old textures)
-    // fill-in
-    float ifx_ = 1.0f / c.fx, ify_ = 1.0f / c.fy;
-    if ((int)io.x + (int)io.y + (int)io.z == 0) fimg[k] = make_uchar4(f_r, f_g, f_b, 255);
-    else fimg[k] = io;
-    float zc = (float)f_d / 1000.0f;
-    if (vo.z == 0) fv[k] = make_float4(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc, 1.f);
-    else fv[k] = vo;
-    if (no.z == 0) {
-        v3 vp = v3m(((float)x - c.cx) * zc * ifx_, ((float)y - c.cy) * zc * ify_, zc);
-        float zx = (float)f_dx / 1000.0f, zy = (float)f_dy / 1000.0f;
-        v3 vx = v3m(((float)(x + 1) - c.cx) * zx * ifx_, ((float)y - c.cy) * zx * ify_, zx);
-        v3 vy = v3m(((float)x - c.cx) * zy * ifx_, ((float)(y + 1) - c.cy) * zy * ify_, zy);
-        v3 nn = normalized(cross(vx - vp, vy - vp));
-        fn[k] = make_float4(nn.x, nn.y, nn.z, 1.f);
-    } else fn[k] = no;
 }
 
+// Cam::raw_slots == 2 (option clean_raster): the keys were drawn by the fused clean + raster walk, which names every surfel by its slot -- it cannot know which slot is the reference's
+// "surfel 0" while it is still removing surfels; k_append_scan, between the walk and this launch, settles first_live, and the id image gets its 0 here.
 __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, Cam c, const uint8_t* __restrict__ rgb,
                                 const uint16_t* __restrict__ depth_filt, float4* __restrict__ pv, float4* __restrict__ pn, uchar4* __restrict__ pimg,
@@ -583,7 +598,8 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr,
                                 FrameOut fo = FrameOut{nullptr, nullptr, 0})
 {
-    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step, own_slot);
+    const int fl = FIRST_LIVE(c);
+    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step, own_slot, fl, c.raw_slots == 2);
     if (!fo.out) return;
     // the block that finishes last writes the frame result: every block's fold atomics are performed (vmcnt drained) before its ticket
     __shared__ int s_last;
@@ -605,9 +621,10 @@ struct ResolveTarget { unsigned long long* keys; float4 *pv, *pn; uchar4 *pimg, 
 __global__ void k_splat_resolve_pair(const DevState* __restrict__ st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm,
                                      Cam c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth_filt, ResolveTarget t0, ResolveTarget t1)
 {
+    const int fl = FIRST_LIVE(c);
     const ResolveTarget t = blockIdx.z ? t1 : t0;
     splat_resolve_body(st, nullptr, t.keys, pc, nr, col, tm, c, rgb, depth_filt, t.pv, t.pn, t.pimg, t.pinst, t.ptime, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, FinishFold(),
-                       nullptr);
+                       nullptr, 1, nullptr, fl);
 }
 
 // ElasticFusion::denseEnough, EF/ElasticFusion.cpp:252-267 on the (w/20 x h/20) nearest resample
@@ -856,6 +873,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
                                                              unsigned long long* __restrict__ key_both, int dual, const int* __restrict__ gate)
 {
+    const int fl = FIRST_LIVE(c);
     if (gate && !*gate) return;   // fallback launch behind the tiled rasteriser: only when its pair buffer overflowed
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
@@ -867,7 +885,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_list(DevState* st, const
     const unsigned int* __restrict__ seg_list = list + (size_t)seg * c.seg_cap;
     for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) {
         const unsigned int e = seg_list[t];
-        const unsigned int i = e & LIST_IDX, kid = key_id(c, i);
+        const unsigned int i = e & LIST_IDX, kid = key_id(c, i, fl);
         SurfGeo G;
         surfel_geo(T, pc[i], nr[i], e, c, G);
         const v3 q = G.q, nn = G.nn;
@@ -1050,7 +1068,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_tile_fill(Cam c, const unsigned
 }
 
 #define TILE_THREADS 512
-__device__ __forceinline__ void tile_draw(float4 ra, float4 rb, const Cam& c, int bx0, int by0, int bx1, int by1,
+__device__ __forceinline__ void tile_draw(float4 ra, float4 rb, const Cam& c, const int fl, int bx0, int by0, int bx1, int by1,
                                           unsigned long long* ks, unsigned long long* ki, unsigned long long* kb)
 {
     const unsigned int e = __float_as_uint(rb.w), i = e & LIST_IDX;
@@ -1071,9 +1089,9 @@ __device__ __forceinline__ void tile_draw(float4 ra, float4 rb, const Cam& c, in
             const bool in_s = do_s && px >= sx0 && px <= sx1 && py >= sy0 && py <= sy1 && (z >= -c.maxDepth && z <= c.maxDepth);
             const bool in_i = do_i && px >= ix0 && px <= ix1 && py >= iy0 && py <= iy1 && (z > 0 && z <= c.maxDepth);
             const int k = (py - by0) * TILE + (px - bx0);
-            if (in_s && in_i) atomicMin(&kb[k], make_key(z, key_id(c, i)));
-            else if (in_s) atomicMin(&ks[k], make_key(z, key_id(c, i)));
-            else if (in_i) atomicMin(&ki[k], make_key(z, key_id(c, i)));
+            if (in_s && in_i) atomicMin(&kb[k], make_key(z, key_id(c, i, fl)));
+            else if (in_s) atomicMin(&ks[k], make_key(z, key_id(c, i, fl)));
+            else if (in_i) atomicMin(&ki[k], make_key(z, key_id(c, i, fl)));
         }
 }
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, const float4* __restrict__ pc,
@@ -1081,6 +1099,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __
                                                                unsigned long long* __restrict__ key_ids, unsigned long long* __restrict__ key_both)
 {
     __shared__ unsigned long long ks[TILE * TILE], ki[TILE * TILE], kb[TILE * TILE];
+    const int fl = FIRST_LIVE(c);
     if (*ta.overflow) return;
     const int ntiles = ta.tw * ta.th;
     if (blockIdx.x >= ta.blk_off[ntiles]) return;   // the grid is sized for the worst case
@@ -1111,7 +1130,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_raster(const DevState* __
             ra[u] = r4[0]; rb[u] = r4[1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (ri[u] != 0xFFFFFFFFu) tile_draw(ra[u], rb[u], c, bx0, by0, bx1, by1, ks, ki, kb);
+        for (int u = 0; u < 4; u++) if (ri[u] != 0xFFFFFFFFu) tile_draw(ra[u], rb[u], c, fl, bx0, by0, bx1, by1, ks, ki, kb);
     }
     __syncthreads();
     // the key images are all-empty between passes (the resolve clears what it reads): only winners are written -- plainly by a tile's only block,
@@ -1140,6 +1159,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                                                             Cam c, int time, unsigned long long* __restrict__ keys, unsigned int* __restrict__ list_cand,
                                                             unsigned int* __restrict__ list_kill)
 {
+    const int fl = FIRST_LIVE(c);
     const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     float T[12];
 #pragma unroll
@@ -1169,7 +1189,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                         if (p.z > 0.f) {
                             float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
                             if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) && i >= lo && i < hi)
-                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, key_id(c, (unsigned int)i)));
+                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, key_id(c, (unsigned int)i, fl)));
                             cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
                         }
                     }
@@ -1425,6 +1445,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_vlist_concat(const DevState* __
 __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, Cam c, int time,
                                                             const unsigned int* __restrict__ list, unsigned long long* __restrict__ keys)
 {
+    const int fl = FIRST_LIVE(c);
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
@@ -1455,7 +1476,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
             if (p.z > c.maxDepth || p.z < 0) continue;
             const float uu = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
             if (!(uu >= 0 && uu < (float)c.w && v >= 0 && v < (float)c.h)) continue;
-            key_min(&keys[(int)floorf(v) * c.w + (int)floorf(uu)], make_key(p.z, key_id(c, i[u])));   // (sharded map: the creation number instead of the slot)
+            key_min(&keys[(int)floorf(v) * c.w + (int)floorf(uu)], make_key(p.z, key_id(c, i[u], fl)));   // (sharded map: the creation number instead of the slot)
         }
     }
 }
@@ -1575,12 +1596,28 @@ struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; in
 // a candidate whose slot holds another pixel goes to global memory as before; after the walk the occupied slots are flushed with one global
 // atomic each.  min is order-independent: the images are bit-identical.
 #define RV_SLOTS 512
-template <bool LDSMIN>
+// CLEAN (option clean_raster, the frame path's default): the clean pass (k_clean_view) and the end-of-frame raster walk the same list and gather the same records
+// (position + confidence, times, normal + radius of ~0.4 M entries, one 64-B line per field and entry at random map order: 221 + 201 MB of HBM traffic per frame,
+// profiles/r04_zz_final_pmc_traffic.json).  Here ONE walk does both: a lane runs the stability test of copy_unstable.vert:103-174 on its entry (k_clean_view's two
+// branches, same arithmetic), tombstones it if it fails, and rasterises it from the same registers if it survives -- a surfel's raster depends on its OWN clean
+// verdict only (tombstones keep the slots in place; a deformation never takes this path).  The new surfels of the frame are not in the walk: they are appended
+// behind it (k_append_scan), and the caller takes this path only while a new surfel's confidence cannot reach the drawing threshold (splat.vert:56-65,
+// surfel_ids.vert:45) -- the reference draws them for nothing.  The first nf_blocks blocks of the grid are k_new_flags_count's: they read the same tap image and
+// touch nothing the walk touches (5.9 us of their own on the frame's chain before).
+// "Surfel 0": which slot is the first LIVE one is not settled while the walk removes surfels, so it draws slot numbers; k_append_scan's last block advances
+// first_live as ever, and k_splat_resolve turns that slot's id into 0 (ties between keys are decided the same way: the first live slot is the lowest id either way).
+struct CleanArgs { float4* pc_rw; float2* tm_rw; const float4* tap; int nf_blocks; const uint32_t* assoc; const float4* mpc; const float4* mnr; int* flags; int* block_counts; };
+__device__ __forceinline__ void new_flags_body(DevState* st, const float* __restrict__ pose_inv_ex, const Cam& c, int time, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc,
+                                               const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags, int* __restrict__ block_counts, int bid);
+template <bool LDSMIN, bool CLEAN>
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
                                                              int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
-                                                             unsigned long long* __restrict__ key_both, int earlyz, int ids_step)
+                                                             unsigned long long* __restrict__ key_both, int earlyz, int ids_step, CleanArgs ca)
 {
+    const int fl = FIRST_LIVE(c);
+    if (CLEAN && (int)blockIdx.x < ca.nf_blocks) { new_flags_body(st, nullptr, c, time, ca.assoc, ca.mpc, ca.mnr, ca.tap, ca.flags, ca.block_counts, (int)blockIdx.x); return; }
+    const unsigned int rblk = CLEAN ? blockIdx.x - (unsigned int)ca.nf_blocks : blockIdx.x, rgrid = CLEAN ? gridDim.x - (unsigned int)ca.nf_blocks : gridDim.x;
     __shared__ RvRec recs[MAP_THREADS / 64][64];
     __shared__ unsigned int s_tag[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
     __shared__ unsigned long long s_key[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
@@ -1600,17 +1637,50 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
     const unsigned int* __restrict__ seg_a = list_a;
     const unsigned int* __restrict__ seg_i = list_i;
     const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
-    const unsigned int stride = blockDim.x * gridDim.x;
-    for (unsigned int t0 = blockIdx.x * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
+    const unsigned int stride = blockDim.x * rgrid;
+    int dead = 0;
+    for (unsigned int t0 = rblk * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
         const unsigned int t = t0 + lane;
         int area = 0;
         RvRec R;
         R.bw = 1;
         if (t < n) {
             const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
-            const float4 p4 = ld_once(&pc[i]);
-            const float lastT = (t < na || dual) ? ld_once(&tm[i]).y : 0.f;   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
+            float4 p4 = ld_once(&pc[i]);
+            const float2 tt = (t < na || dual) ? ld_once(&tm[i]) : make_float2(0.f, 0.f);   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
+            const float lastT = tt.y;
             asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
+            float4 n4c = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool have_n = false;
+            if (CLEAN && t < na) {   // k_clean_view for this entry: the window test for the candidates, the stability / age rules for the rest
+                const float wv = tt.y;
+                if (wv > DEAD_TIME && !(wv > 0.f && (float)time - wv > (float)c.timeDelta)) {   // live and not exempt by the time window
+                    bool cand = false;
+                    if (!((float)time - wv > (float)c.timeDelta)) {
+                        const v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
+                        if (p.z > 0.f) {
+                            const float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
+                            cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
+                        }
+                    }
+                    int test = 1;
+                    if (cand) {
+                        n4c = ld_once(&nr[i]);
+                        have_n = true;
+                        float lt2 = tt.y;
+                        test = clean_test(T, c, time, p4, n4c, tt.x, lt2, ca.tap);
+                    } else {   // count = zCount = 0: only the stability / age rules apply
+                        if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
+                        if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
+                    }
+                    if (!test) {
+                        p4.w = -1.0f;   // (a tombstone's confidence: the raster below leaves it out, as it would after k_clean_view)
+                        ca.pc_rw[i] = p4;
+                        ca.tm_rw[i] = make_float2(tt.x, DEAD_TIME);
+                        dead++;
+                    }
+                }
+            }
             unsigned int flags = 0;
             if (!(p4.w < c.conf)) {   // tombstones carry confidence -1
                 const v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
@@ -1635,7 +1705,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             }
             if (flags) {
                 SurfGeo G;
-                surfel_geo(T, p4, ld_once(&nr[i]), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
+                surfel_geo(T, p4, (CLEAN && have_n) ? n4c : ld_once(&nr[i]), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
                 bool do_i = dual ? (G.do_s && (flags & LIST_IDS)) : surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
                 const bool do_s = dual ? (G.do_s && (flags & LIST_SPLAT)) : G.do_s;
@@ -1656,7 +1726,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
                     if (x1 >= x0 && y1 >= y0) {
                         const int nx_ = lattice ? (x1 - x0) / ids_step + 1 : x1 - x0 + 1, ny_ = lattice ? (y1 - y0) / ids_step + 1 : y1 - y0 + 1;
                         area = nx_ * ny_;
-                        R.qx = G.q.x; R.qy = G.q.y; R.qz = G.q.z; R.nx = G.nn.x; R.ny = G.nn.y; R.nz = G.nn.z; R.r2 = G.r * G.r; R.id = key_id(c, i);
+                        R.qx = G.q.x; R.qy = G.q.y; R.qz = G.q.z; R.nx = G.nn.x; R.ny = G.nn.y; R.nz = G.nn.z; R.r2 = G.r * G.r; R.id = CLEAN ? i : key_id(c, i, fl);   // (CLEAN: slot numbers -- first_live is not settled while this walk removes surfels; k_splat_resolve names "surfel 0")
                         R.x0 = x0; R.y0 = y0; R.bw = nx_ | (lattice << 16);
                         R.s01 = (sx0 & 0xFFFF) | (sx1 << 16); R.s23 = (sy0 & 0xFFFF) | (sy1 << 16);
                         R.i01 = (ix0 & 0xFFFF) | (ix1 << 16); R.i23 = (iy0 & 0xFFFF) | (iy1 << 16);
@@ -1732,11 +1802,15 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
             }
         }
     }
+    if (CLEAN) {
+        dead = wave_sum_i(dead);
+        if (lane == 0 && dead) atomicAdd(&st->n_dead, dead);
+    }
 }
 
 // splat prediction (want & LIST_SPLAT) and / or id render (want & LIST_IDS) in one cull + one dense raster pass
 static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, unsigned int want, int32_t* ids_out, bool frame_sums = false, int part = 0, int old_target = 0,
-                        bool fold_finish = false, int resolve_ids_step = 1)
+                        bool fold_finish = false, int resolve_ids_step = 1, bool raw_ids = false)
 {
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
@@ -1784,6 +1858,14 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
             ff.total = nullptr;
             h->result_folded = 1;
         }
+        if (raw_ids) {   // option clean_raster: the walk drew slot numbers
+            c.raw_slots = 2;
+            LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
+                   (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
+                   (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
+                   h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step, (const int32_t*)nullptr, fo);
+            if (ff.acc) return;
+        } else
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
@@ -1816,8 +1898,8 @@ int ifx_ids_ensure(ifx* h)
     if (h->ids_view_ok && !h->own) {   // nothing touched the store, the pose or the cached view list since the frame drew its lattice from it: the rest of the image from the same list
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
-        LAUNCH(h, "raster_view_ids", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1);
+        LAUNCH(h, "raster_view_ids", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{});
         LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, h->ids_after);
     } else
         ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
@@ -1835,6 +1917,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
                             const float4* __restrict__ index_nr, Cam c, int time, uint32_t* __restrict__ assoc, float4* __restrict__ mpc, float4* __restrict__ mnr,
                             float* __restrict__ mcol, uint32_t* __restrict__ upd_owner, unsigned long long* __restrict__ akey = nullptr)
 {
+    const int fl = FIRST_LIVE(c);
     // Only the pixels with i % 2 == j % 2 == time % 2 create measurements (data.vert:98): one thread per 2x2 block, so that
     // every lane of a wave works; the thread also marks the three silent pixels of its block.
     const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1928,7 +2011,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
                 res = ASSOC_NEW;
             } else if (counter > 0) {
                 res = best;
-                const int lb = local_slot(c, st->count, best);
+                const int lb = local_slot(c, st->count, best, fl);
                 if (lb >= 0) atomicMin(&upd_owner[lb], (uint32_t)(i * c.h + j));   // first pixel in column-major order owns the surfel (sharded map: only the surfel's rank keeps the score)
             } else res = ASSOC_NEW;
         }
@@ -1940,6 +2023,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
 __global__ void k_assoc_decode(const DevState* __restrict__ st, const unsigned long long* __restrict__ akey, const uint32_t* __restrict__ index_id, Cam c, int time,
                                uint32_t* __restrict__ assoc, uint32_t* __restrict__ upd_owner, const int32_t* __restrict__ own_slot = nullptr, int32_t* __restrict__ assoc_slot = nullptr)
 {
+    const int fl = FIRST_LIVE(c);
     const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
     const int par = time % 2, i = 2 * bx + par, j = 2 * by + par;
     if (i >= c.w || j >= c.h) return;
@@ -1951,7 +2035,7 @@ __global__ void k_assoc_decode(const DevState* __restrict__ st, const unsigned l
     const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};
     const uint32_t best = index_id[ys[b] * c.w + xs[a]];
     assoc[j * c.w + i] = best;
-    const int lb = own_slot ? own_slot_of(c, own_slot[ys[b] * c.w + xs[a]], best) : local_slot(c, st->count, best);
+    const int lb = own_slot ? own_slot_of(c, own_slot[ys[b] * c.w + xs[a]], best) : local_slot(c, st->count, best, fl);
     if (assoc_slot) assoc_slot[j * c.w + i] = lb;   // (k_fuse_update's slot of the associated surfel: -1 = another rank applies the update)
     if (lb >= 0) atomicMin(&upd_owner[lb], (uint32_t)(i * c.h + j));
 }
@@ -1961,12 +2045,13 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
                               const float* __restrict__ mcol, Cam c, int time, uint32_t* __restrict__ upd_owner, float4* __restrict__ pc, float4* __restrict__ nr,
                               float2* __restrict__ col, float2* __restrict__ tm, const int32_t* __restrict__ assoc_slot = nullptr)
 {
+    const int fl = FIRST_LIVE(c);
     const int par = time % 2, i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + par, j = 2 * (blockIdx.y * blockDim.y + threadIdx.y) + par;   // the pixels that can hold an association
     if (i >= c.w || j >= c.h) return;
     int k = j * c.w + i;
     const uint32_t gid = assoc[k];
     if (gid >= ASSOC_NEW) return;
-    const int li = assoc_slot ? assoc_slot[k] : local_slot(c, st->count, gid);   // sharded map: -1 = another rank's surfel (that rank applies the update)
+    const int li = assoc_slot ? assoc_slot[k] : local_slot(c, st->count, gid, fl);   // sharded map: -1 = another rank's surfel (that rank applies the update)
     if (li < 0 || li >= st->count) return;
     const uint32_t id = (uint32_t)li;
     if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
@@ -2059,15 +2144,13 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // 1024-pixel block; it also re-arms the clean work lists.  Launch 2: every block adds the counts of the blocks
 // before it (<= 300 integers), scans its own flags and scatters; the block that finishes last publishes the
 // new surfel count.
-#define NEW_PER_BLOCK 1024
 // flags: bit 0 = the new surfel survives its first clean test, bit 1 = ... and this rank owns it (spatially sharded map; always set otherwise).
 // block_counts: [block][2] = survivors, owned survivors.
-__global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
-                                                         const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags,
-                                                         int* __restrict__ block_counts)
+__device__ __forceinline__ void new_flags_body(DevState* st, const float* __restrict__ pose_inv_ex, const Cam& c, int time, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc,
+                                               const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags, int* __restrict__ block_counts, int bid)
 {
     __shared__ int lds[4][2];
-    const int P = c.w * c.h, ord0 = blockIdx.x * NEW_PER_BLOCK + threadIdx.x * 4;
+    const int P = c.w * c.h, ord0 = bid * NEW_PER_BLOCK + threadIdx.x * 4;
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     int keep[4], cnt = 0, own = 0;
 #pragma unroll
@@ -2092,25 +2175,32 @@ __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const flo
     own = wave_sum_i(own);
     if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6][0] = cnt; lds[threadIdx.x >> 6][1] = own; }
     __syncthreads();
-    if (threadIdx.x < 2) block_counts[blockIdx.x * 2 + threadIdx.x] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x < 2 * LIST_SEGS) c.lctr[(LIST_SEGS + threadIdx.x) * LIST_CTR_STRIDE] = 0;   // lists 1, 2: k_clean_list, the launch before this one, was their last reader
+    if (threadIdx.x < 2) block_counts[bid * 2 + threadIdx.x] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
+    if (bid == 0 && threadIdx.x < 2 * LIST_SEGS) c.lctr[(LIST_SEGS + threadIdx.x) * LIST_CTR_STRIDE] = 0;   // lists 1, 2: k_clean_list, the launch before this one, was their last reader
+}
+__global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
+                                                         const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags,
+                                                         int* __restrict__ block_counts)
+{
+    new_flags_body(st, pose_inv_ex, c, time, assoc, mpc, mnr, tap, flags, block_counts, (int)blockIdx.x);
 }
 
 // Two ranks per surviving new surfel: its place in the frame's append order (-> creation number, the same on every rank) and its place among
 // the ones this rank stores (-> slot).  Without sharding the two coincide.
-__global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
-                                                     const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
-                                                     float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
-                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq)
+__device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
+                                                 const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
+                                                 float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
+                                                 const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq,
+                                                 const int tid, const int bid)
 {
     __shared__ int s_wave[4][2], s_base[2], s_last;
     __shared__ unsigned int s_vbase;
-    const int P = c.w * c.h, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int P = c.w * c.h, lane = tid & 63, wid = tid >> 6;
     const int count0 = st->count;
     const unsigned int seq0 = st->next_seq;
     // counts of the blocks before this one
     int beforeG = 0, beforeO = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += 256) { beforeG += block_counts[2 * b]; beforeO += block_counts[2 * b + 1]; }
+    for (int b = tid; b < bid; b += 256) { beforeG += block_counts[2 * b]; beforeO += block_counts[2 * b + 1]; }
     beforeG = wave_sum_i(beforeG);
     beforeO = wave_sum_i(beforeO);
     if (lane == 0) { s_wave[wid][0] = beforeG; s_wave[wid][1] = beforeO; }
@@ -2118,7 +2208,7 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     if (tid < 2) s_base[tid] = s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
     __syncthreads();
     // exclusive scans of this block's flags: 4 per thread, wave scan by shuffles, wave totals through LDS
-    const int ord0 = blockIdx.x * NEW_PER_BLOCK + tid * 4;
+    const int ord0 = bid * NEW_PER_BLOCK + tid * 4;
     int f[4] = {0, 0, 0, 0};
     if (ord0 + 3 < P) { int4 v = *reinterpret_cast<const int4*>(flags + ord0); f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
     else
@@ -2189,7 +2279,9 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
     if (tid == 0) {
         const int tg = s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0], to = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
         int nc = count0 + to;
-        if (nc > cap) { nc = cap; st->overflow = 1; }
+        bool ovf = false;
+        if (nc > cap) { nc = cap; ovf = true; }
+        if (seq0 + (unsigned int)tg < seq0 || seq0 + (unsigned int)tg > 0xFFF00000u) ovf = true;   // creation numbers are never renumbered: 2^32 of them is the life of a sharded map (reported as a full store)
         st->n_new = nc - count0;
         st->count = nc;
         {   // the clean pass of this frame is behind us: if it removed the reference's "surfel 0", the next live slot takes its place (the appended ones are alive by construction)
@@ -2198,9 +2290,16 @@ __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int ti
             st->first_live = f;
         }
         st->next_seq = seq0 + (unsigned int)tg;
-        if (seq0 + (unsigned int)tg < seq0 || seq0 + (unsigned int)tg > 0xFFF00000u) st->overflow = 1;   // creation numbers are never renumbered: 2^32 of them is the life of a sharded map (reported as a full store)
+        if (ovf) st->overflow = 1;
         __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+__global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
+                                                     const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
+                                                     float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
+                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq)
+{
+    append_scan_body(st, c, time, tick, flags, block_counts, nblocks, mpc, mnr, mcol, cap, pc, nr, col, tm, ic, votes, inst_gt, list_v, labels, seq, (int)threadIdx.x, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ tombstone compaction
@@ -2483,9 +2582,23 @@ static void index_list_pass(ifx* h, int time, bool taps)
                (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap, c);
 }
 
+// the clean pass and the append of a view-list frame as launches of their own (k_clean_view ; k_new_flags_count ; k_append_scan)
+static void view_clean_append(ifx* h, const Cam& c, int time)
+{
+    LAUNCH(h, "clean_view", dim3(h->opt_clean_blocks > 0 ? h->opt_clean_blocks : 2 * LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
+           (const float4*)h->index_tap, h->list_v);
+    const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+    LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
+           (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
+    LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
+           (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+           h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->own ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
+}
+
 // EF/ElasticFusion.cpp:620-694 without the loop-closure branches
 int ifx_map_frame(ifx* h)
 {
+    h->clean_raster_pending = 0;
     h->view_frame = 0;
     h->ids_view_ok = 0;
     if (use_view_list(h)) {
@@ -2496,14 +2609,14 @@ int ifx_map_frame(ifx* h)
         index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
         fuse_pass(h, nullptr, 0.f, time);
         index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
-        LAUNCH(h, "clean_view", dim3(h->opt_clean_blocks > 0 ? h->opt_clean_blocks : 2 * LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
-               (const float4*)h->index_tap, h->list_v);
-        const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
-        LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
-               (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
-        LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
-               (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-               h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->own ? (unsigned int*)nullptr : h->list_v, h->labels, h->seq);
+        // Option clean_raster (default): the clean, the new surfels' flags and the append are left to the end-of-frame prediction (ifx_map_predict): ONE walk of the
+        // view list cleans and rasterises (+ the flags), then the append, then the resolve.  Only when that prediction will take the view-list raster, and while no new
+        // surfel can be drawn in the frame that creates it: its confidence starts at most at max(1, weight multiplier) (confidence_fn, k_track_end), the renders draw
+        // from the threshold on (splat.vert:56-65, surfel_ids.vert:45).
+        const bool fused = h->opt_clean_raster && !h->opt_compact_every_frame && h->last_compact_tick != h->tick && h->opt_raster_tiles <= 0 && !h->opt_raster_lds &&
+                           h->cfg.confidence > fmaxf(1.f, h->frame_weight_mult);
+        h->clean_raster_pending = fused ? 1 : 0;
+        if (!fused) view_clean_append(h, c, time);
         h->view_frame = 1; h->view_dirty = 1; h->last_clean_time = time;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);   // (reaps first; the raster below then takes the per-pass cull: the list is void after a compaction)
         h->ids_pending = 1;
@@ -2536,8 +2649,8 @@ int ifx_map_predict_loop_closure(ifx* h)
     if (by_view) {   // the frame's view lists hold every stable surfel in view, inside the time window or not: the scan this frame needs anyway, taken first
         view_scan(h, h->tick);
         h->view_scan_tick = h->tick;
-        LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1);
+        LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{});
     } else {
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
            LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
@@ -2573,14 +2686,34 @@ int ifx_map_predict(ifx* h)
         h->ids_full_valid = ids_step == 1;
         h->ids_sparse_frame = ids_step > 1;
         h->ids_view_ok = ids_step > 1;
+        if (h->clean_raster_pending) {   // the frame's clean + new-surfel flags in the raster's walk, then the append, then the resolve (see ifx_map_frame)
+            h->clean_raster_pending = 0;
+            const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+            CleanArgs ca;
+            ca.pc_rw = (float4*)h->pc; ca.tm_rw = (float2*)h->tm; ca.tap = (const float4*)h->index_tap; ca.nf_blocks = nb_new; ca.assoc = h->assoc_target; ca.mpc = (const float4*)h->meas_pc;
+            ca.mnr = (const float4*)h->meas_nr; ca.flags = h->scan_flags; ca.block_counts = h->scan_block;
+            LAUNCH(h, "clean_raster_view", dim3(nb_new + (h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS)), dim3(MAP_THREADS), (k_raster_view<false, true>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+                   (const float2*)h->tm, c, h->tick, h->tick, want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, ca);
+            LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, h->tick, h->tick, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
+                   (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+                   h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels, h->seq);
+            raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step, true);
+        } else {
         if (h->opt_raster_lds)
-            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<true>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
+            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<true, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{});
         else
-            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step);
+            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{});
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step);   // resolve + the end-of-pass sums in the same launch
+        }
     } else {
+        if (h->clean_raster_pending) {   // (the host-side conditions of the two functions are the same: never) -- the deferred passes as launches of their own
+            h->clean_raster_pending = 0;
+            Cam cc = make_cam(h);
+            cc.srank = 0; cc.sn = 1;
+            view_clean_append(h, cc, h->tick);
+        }
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true);
         if (want & LIST_IDS) { h->ids_full_valid = 1; h->ids_sparse_frame = 0; }
         h->ids_view_ok = 0;
@@ -2806,8 +2939,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             Cam cl = make_cam(h);   // (the store's arrays may have been swapped by a compaction earlier in this phase: taken afresh)
             cl.srank = 0; cl.sn = 1;
             if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
-            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), k_raster_view<false>, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
-                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1);   // (the whole id image: it travels with the splat keys)
+            LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
+                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{});   // (the whole id image: it travels with the splat keys)
             h->own_fast_raster = h->own_fast;
         } else
             raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);

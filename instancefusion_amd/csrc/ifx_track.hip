@@ -532,6 +532,46 @@ __device__ __forceinline__ void acc_clear(double* gacc, int k)
     for (int r = 0; r < IFX_ACC_REPL; r++) __hip_atomic_store(&gacc[r * IFX_ACC_STRIDE + k], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Run-time guard of the exact-sum contract (ifx_dev.h): the sums are exact -- hence independent of the order the atomics arrive in, and equal to the oracle's -- while every
+// PARTIAL sum stays below 2^53 grid units.  That is decided by the seven diagonal totals alone: a diagonal sum D_i = sum row_i^2 has non-negative terms, so its partial sums are
+// below its total; and every partial sum of an off-diagonal entry is at most sum |row_i row_j| <= sqrt(D_i D_j) (Cauchy-Schwarz), whose limit 2^(E_i + E_j + 21) is the
+// geometric mean of the two diagonal limits 2^(2 E_i + 21).  So: all seven diagonal totals below HALF their limit (the half pays for the rounding of the terms to the grid)
+// => every addition of all 28 sums was exact.  Whoever reads the totals of an iteration checks its diagonal entry and counts a violation in DevState::range_exceeded
+// (ifx_tracker_range_exceeded): 0 on every sequence of the test suite and of bench.py; a near-range frame of saturated edges drives it (tests/test_gpu_parity.py).
+// (integer arithmetic on packed constants only: a runtime-indexed local array, or a switch over doubles, put every launch of the tracker on scratch memory)
+__host__ __device__ constexpr unsigned long long range_pack7(const int (&e)[7], int bias)
+{
+    unsigned long long p = 0;
+    for (int i = 0; i < 7; i++) p |= (unsigned long long)(unsigned int)(2 * e[i] + bias + 64) << (8 * i);   // biased by 64: a byte each
+    return p;
+}
+__device__ __forceinline__ bool range_exceeded7(int kind, int k, double total)
+{
+    constexpr int EI[7] = IFX_E_ICP, ER[7] = IFX_E_RGB;
+    constexpr unsigned long long PI = range_pack7(EI, 52 - IFX_EXACT_TERM_BITS), PR = range_pack7(ER, 52 - IFX_EXACT_TERM_BITS);
+    constexpr unsigned int DIAG = (1u << 0) | (1u << 7) | (1u << 13) | (1u << 18) | (1u << 22) | (1u << 25) | (1u << 27);   // positions of the squares in the 29-vector
+    if (k > 27 || !((DIAG >> k) & 1u)) return false;
+    const int i = __popc(DIAG & ((1u << k) - 1u));
+    const int ex = (int)(((kind ? PR : PI) >> (8 * i)) & 0xFFull) - 64;
+    const double lim = __hiloint2double((1023 + ex) << 20, 0);   // 2^ex
+    return !(total < lim);   // (a NaN total counts)
+}
+__device__ __forceinline__ bool range_exceeded_so3(int k, double total)
+{
+    constexpr int ES[4] = IFX_E_SO3;
+    constexpr int B = 52 - IFX_SO3_TERM_BITS;
+    constexpr unsigned int PS = (unsigned int)(2 * ES[0] + B + 64) | ((unsigned int)(2 * ES[1] + B + 64) << 8) | ((unsigned int)(2 * ES[2] + B + 64) << 16) | ((unsigned int)(2 * ES[3] + B + 64) << 24);
+    constexpr unsigned int DIAG = (1u << 0) | (1u << 4) | (1u << 7) | (1u << 9);
+    if (k > 9 || !((DIAG >> k) & 1u)) return false;
+    const int i = __popc(DIAG & ((1u << k) - 1u));
+    const int ex = (int)((PS >> (8 * i)) & 0xFFu) - 64;
+    return !(total < __hiloint2double((1023 + ex) << 20, 0));
+}
+__device__ __forceinline__ void range_note(const DevState* st, bool icp_bad, bool rgb_bad)
+{
+    if (icp_bad || rgb_bad) atomicAdd(&const_cast<DevState*>(st)->range_exceeded, (icp_bad ? 1 : 0) + (rgb_bad ? 1 : 0));
+}
+
 // KIND 0: ICP row, 1: photometric row
 template <int KIND>
 __device__ __forceinline__ void products7(const float* row, bool found, double* acc)
@@ -1528,7 +1568,7 @@ __device__ __forceinline__ void so3_update_wave(DevState* st, double* __restrict
 {
     const int lane = threadIdx.x & 63;
     double v = 0;
-    if (lane < 11) { v = acc_total(gacc, lane); acc_clear(gacc, lane); }
+    if (lane < 11) { v = acc_total(gacc, lane); acc_clear(gacc, lane); if (range_exceeded_so3(lane, v)) atomicAdd(&st->range_exceeded, 1); }
     float o[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) o[k] = (float)__shfl(v, k, 64);
@@ -1801,6 +1841,7 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
         const double ti = acc_total(icp_acc, k), tr = acc_total(rgb_acc, k);
         acc_clear(icp_acc, k);
         acc_clear(rgb_acc, k);
+        range_note(st, icp && range_exceeded7(0, k, ti), rgb && range_exceeded7(1, k, tr));
         const float oi = icp ? (float)ti : 0.f, orr = rgb ? (float)tr : 0.f;
         s_oi[k] = oi; s_or[k] = orr;
         if (k < 27) {
@@ -1911,6 +1952,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
     __shared__ int s_last;
     if (a.pro && blockIdx.x == 0) {   // the other parity was last read by the prologues of this iteration's first launch: clean again for the next iteration's sums
         double* const other = st->gnp_acc + (size_t)((1 - par) * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE;
+        if (threadIdx.x < 64) {   // run-time guard of the exact sums (range_exceeded7), on the totals of the iteration before, here where they are cleared: the prologues that
+            const int kind = threadIdx.x >> 5, k = threadIdx.x & 31;   // consumed them sit in a launch that has no register to spare (it spilled with the test in it)
+            if (k < 28 && range_exceeded7(kind, k, acc_total(other + (size_t)kind * IFX_ACC_REPL * IFX_ACC_STRIDE, k))) atomicAdd(&st->range_exceeded, 1);
+        }
+        __syncthreads();
         __hip_atomic_store(&other[threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 x REPL x STRIDE = 256 doubles = RED_THREADS
         if (threadIdx.x < 2) __hip_atomic_store(&st->gnp_res[(1 - par) * 16 + threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2027,6 +2073,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level_solo(DevState* st, Lev
             const double ti = acc_total(icp_acc, tid), tr = acc_total(rgb_acc, tid);
             acc_clear(icp_acc, tid);
             acc_clear(rgb_acc, tid);
+            range_note(st, range_exceeded7(0, tid, ti), range_exceeded7(1, tid, tr));
             const float oi = (float)ti, orr = (float)tr;
             s_oi[tid] = oi; s_or[tid] = orr;
             if (tid < 27) {
@@ -2311,6 +2358,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
         const bool last_it = it == a.iters - 1;
         if (tid < 29) {
             const double ti = acc_total(icp_acc, tid), tr = acc_total(rgb_acc, tid);
+            if (bid == 0) range_note(st, ICP && range_exceeded7(0, tid, ti), RGB && range_exceeded7(1, tid, tr));
             const float oi = ICP ? (float)ti : 0.f, orr = RGB ? (float)tr : 0.f;
             s_oi[tid] = oi; s_or[tid] = orr;
             if (tid < 27) {

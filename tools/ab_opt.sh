@@ -8,6 +8,6 @@ for r in $(seq $rounds); do
     python bench.py --steps 200 --warmup 30 --no-cpu-baseline --extras-frames 0 --opt $name=$v "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']
-print('$name=$v', d['value'], d['ms_per_frame_gpu'], d['instance']['ms_per_call'], {x:round(k[x]['avg_ms']*1000,1) for x in ('icp_residual','rgb_step_solve','gn_level','splat_resolve','raster_view','clean_view') if x in k})"
+print('$name=$v', d['value'], d['ms_per_frame_gpu'], d['instance']['ms_per_call'], {x:round(k[x]['avg_ms']*1000,1) for x in ('icp_residual','rgb_step_solve','splat_resolve','raster_view','clean_view','clean_raster_view','index_list','index_resolve','append_scan','associate','fuse_update') if x in k})"
   done
 done

@@ -1613,17 +1613,20 @@ template <bool LDSMIN, bool CLEAN>
 __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
                                                              int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
-                                                             unsigned long long* __restrict__ key_both, int earlyz, int ids_step, CleanArgs ca)
+                                                             unsigned long long* __restrict__ key_both, int earlyz, int ids_step, CleanArgs ca, const DevState* __restrict__ stc)
 {
+    // stc == st: what the walk READS of the state -- the pose, the list lengths, the radius bound -- comes through a const restrict parameter of its own.  With the clean's stores in
+    // the kernel, the same loads through `st` compile to vector loads of one address by every one of the 16 k waves (the scalar cache is only used for memory the kernel provably
+    // does not write), and they queue at the one L2 channel that holds the line.
     const int fl = FIRST_LIVE(c);
-    if (CLEAN && (int)blockIdx.x < ca.nf_blocks) { new_flags_body(st, nullptr, c, time, ca.assoc, ca.mpc, ca.mnr, ca.tap, ca.flags, ca.block_counts, (int)blockIdx.x); return; }
+    if (CLEAN && (int)blockIdx.x < ca.nf_blocks) { new_flags_body(st, stc->pose_inv, c, time, ca.assoc, ca.mpc, ca.mnr, ca.tap, ca.flags, ca.block_counts, (int)blockIdx.x); return; }
     const unsigned int rblk = CLEAN ? blockIdx.x - (unsigned int)ca.nf_blocks : blockIdx.x, rgrid = CLEAN ? gridDim.x - (unsigned int)ca.nf_blocks : gridDim.x;
     __shared__ RvRec recs[MAP_THREADS / 64][64];
     __shared__ unsigned int s_tag[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
     __shared__ unsigned long long s_key[LDSMIN ? MAP_THREADS / 64 : 1][LDSMIN ? RV_SLOTS : 1];
     float T[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = st->pose_inv[k];
+    for (int k = 0; k < 12; k++) T[k] = stc->pose_inv[k];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (LDSMIN) {
 #pragma unroll
@@ -1633,10 +1636,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const
     // want & LIST_DUAL (the loop-closure detection's two splat renders, as k_cull_raster / k_raster_list's dual mode): the ACTIVE prediction goes to key_splat, the INACTIVE
     // one -- last seen at or before time - timeDelta -- to key_ids with the SPLAT geometry and depth rule; every entry of both lists is classified by its own time stamp
     const bool dual = (want & LIST_DUAL) != 0;
-    const unsigned int na = min(st->vl_n[0], c.seg_cap * LIST_SEGS), n = na + (((want & LIST_IDS) || dual) ? min(st->vl_n[1], c.seg_cap * LIST_SEGS) : 0u);
+    const unsigned int na = min(stc->vl_n[0], c.seg_cap * LIST_SEGS), n = na + (((want & LIST_IDS) || dual) ? min(stc->vl_n[1], c.seg_cap * LIST_SEGS) : 0u);
     const unsigned int* __restrict__ seg_a = list_a;
     const unsigned int* __restrict__ seg_i = list_i;
-    const float reach = __uint_as_float(st->r_max_bits) * 1.41421356f * 1.001f;
+    const float reach = __uint_as_float(stc->r_max_bits) * 1.41421356f * 1.001f;
     const unsigned int stride = blockDim.x * rgrid;
     int dead = 0;
     for (unsigned int t0 = rblk * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
@@ -1899,7 +1902,7 @@ int ifx_ids_ensure(ifx* h)
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
         LAUNCH(h, "raster_view_ids", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{});
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{}, (const DevState*)h->d_state);
         LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, h->ids_after);
     } else
         ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
@@ -2151,7 +2154,10 @@ __device__ __forceinline__ void new_flags_body(DevState* st, const float* __rest
 {
     __shared__ int lds[4][2];
     const int P = c.w * c.h, ord0 = bid * NEW_PER_BLOCK + threadIdx.x * 4;
-    const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    const float* Ti = pose_inv_ex ? pose_inv_ex : st->pose_inv;
+    float T[12];   // (fetched once, here: as a pointer handed to clean_test it was re-read -- as vector loads of one address -- inside every one of the four tests)
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = Ti[k];
     int keep[4], cnt = 0, own = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -2198,6 +2204,7 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
     const int P = c.w * c.h, lane = tid & 63, wid = tid >> 6;
     const int count0 = st->count;
     const unsigned int seq0 = st->next_seq;
+    const unsigned int rmax0 = st->r_max_bits;   // (here, through the scalar cache: re-read per new surfel behind the stores below it was a vector load of one address, ~2 ns per wave and surfel at one L2 channel)
     // counts of the blocks before this one
     int beforeG = 0, beforeO = 0;
     for (int b = tid; b < bid; b += 256) { beforeG += block_counts[2 * b]; beforeO += block_counts[2 * b + 1]; }
@@ -2252,7 +2259,7 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
         if (to_view && vp < c.seg_cap * LIST_SEGS) list_v[vp] = (unsigned int)n;
         pc[n] = mpc[k];
         nr[n] = mnr[k];
-        { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
+        { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > rmax0) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
         col[n] = make_float2(mcol[k], 0.f);
         tm[n] = make_float2((float)time, (float)time);
         ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
@@ -2650,7 +2657,7 @@ int ifx_map_predict_loop_closure(ifx* h)
         view_scan(h, h->tick);
         h->view_scan_tick = h->tick;
         LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{});
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{}, (const DevState*)h->d_state);
     } else {
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
            LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
@@ -2693,7 +2700,7 @@ int ifx_map_predict(ifx* h)
             ca.pc_rw = (float4*)h->pc; ca.tm_rw = (float2*)h->tm; ca.tap = (const float4*)h->index_tap; ca.nf_blocks = nb_new; ca.assoc = h->assoc_target; ca.mpc = (const float4*)h->meas_pc;
             ca.mnr = (const float4*)h->meas_nr; ca.flags = h->scan_flags; ca.block_counts = h->scan_block;
             LAUNCH(h, "clean_raster_view", dim3(nb_new + (h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS)), dim3(MAP_THREADS), (k_raster_view<false, true>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-                   (const float2*)h->tm, c, h->tick, h->tick, want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, ca);
+                   (const float2*)h->tm, c, h->tick, h->tick, want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, ca, (const DevState*)h->d_state);
             LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, h->tick, h->tick, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
                    (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
                    h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels, h->seq);
@@ -2701,10 +2708,10 @@ int ifx_map_predict(ifx* h)
         } else {
         if (h->opt_raster_lds)
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<true, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{});
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{}, (const DevState*)h->d_state);
         else
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{});
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{}, (const DevState*)h->d_state);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step);   // resolve + the end-of-pass sums in the same launch
         }
     } else {
@@ -2940,7 +2947,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             cl.srank = 0; cl.sn = 1;
             if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
-                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{});   // (the whole id image: it travels with the splat keys)
+                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{}, (const DevState*)h->d_state);   // (the whole id image: it travels with the splat keys)
             h->own_fast_raster = h->own_fast;
         } else
             raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);

@@ -66,6 +66,7 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
         "index_list": nw * (4.0 + 8 + 16),                  # entry, times, position + confidence
         "clean_view": nw * (4.0 + 8 + 16 + 16),             # + normal / radius of the candidates (window taps: L2-resident image, not counted)
         "raster_view": (nw + no) * (4.0 + 8 + 16 + 16),     # both lists: entry, times, position, normal / radius (key-image atomics not counted)
+        "clean_raster_view": (nw + no) * (4.0 + 8 + 16 + 16),   # the fused walk (option clean_raster): the SAME records once for the clean and the raster (taps and atomics not counted)
         "fuse_update": (P / 4.0) * (4.0 + 96),              # upper bound: every active pixel matched (association word + 48 B read + 48 B written in place)
         "project_bbox": P * (4.0 + 192),                    # id image + the 12 vote planes of the surfel under every pixel
         "count_colour_px": P * (4.0 + 192 + 8),
@@ -83,7 +84,7 @@ def algorithmic_bytes(kernel: str, n_slots: int, P: int, active_fraction: float 
 
 # which ms/frame column of the metric a kernel is billed to (roofline.stages)
 STAGE_OF = {"track": ("icp_residual", "rgb_step_solve", "gn_level", "model_l0", "model_down"),
-            "fuse": ("cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve", "index_resolve_taps",
+            "fuse": ("cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "clean_raster_view", "index_list", "index_project", "index_resolve", "index_resolve_taps",
                      "associate", "fuse_update", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "new_flags_count", "append_scan"),
             "instance": ("count_colour", "count_colour_px", "project_bbox")}
 
@@ -359,7 +360,7 @@ def main():
         for _ in range(n_kt):
             step(k); k += 1
         ef.sync()
-        names = ["gn_level", "icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "index_list", "index_project", "index_resolve",
+        names = ["gn_level", "icp_residual", "rgb_step_solve", "so3_fused", "cull_frame", "cull_raster", "raster_list", "cull_clean", "clean_list", "clean_view", "raster_view", "clean_raster_view", "index_list", "index_project", "index_resolve",
                  "index_resolve_taps", "associate", "fuse_update", "bilateral_metric", "splat_resolve", "tile_count", "tile_scan", "tile_fill", "tile_raster", "raster_finish", "model_l0", "model_down", "new_flags_count",
                  "append_scan", "count_colour", "count_colour_px", "project_bbox"]
         # k_cull_frame is launched every frame and decides ON THE DEVICE whether the cached view list is still valid; a launch that finds it
@@ -425,8 +426,21 @@ def main():
             # store are reported next to it so that the bandwidth-bound part of the path has its roofline numbers too
             roof["streaming_passes"] = [entry(n_) for n_ in ("cull_frame", "cull_raster", "cull_clean", "index_project", "count_colour") if table.get(n_, {}).get("launches")]
             # the list-driven passes that ARE the map stage on the frame path, and the per-call kernels of the instance layer: achieved fraction and waste ratio of each
-            roof["map_passes"] = [entry(n_) for n_ in ("raster_view", "clean_view", "index_list", "fuse_update", "associate", "index_resolve", "splat_resolve", "project_bbox", "count_colour_px")
+            roof["map_passes"] = [entry(n_) for n_ in ("clean_raster_view", "raster_view", "clean_view", "index_list", "fuse_update", "associate", "index_resolve", "splat_resolve", "project_bbox", "count_colour_px")
                                   if table.get(n_, {}).get("launches")]
+            # the two launches of a Gauss-Newton iteration PER PYRAMID LEVEL (the blended figure above averages 10 / 5 / 4 iterations at 1 : 1/4 : 1/16 of the pixels):
+            # level 0 is where the bytes are, the coarse levels are pure launch latency
+            lv = []
+            for fam, bpp in (("icp_residual", 48.0 + 22.0), ("rgb_step_solve", 24.0)):
+                for l in range(3):
+                    avg, cnt = ef.kernel_ms(f"{fam}@L{l}")
+                    if not cnt:
+                        continue
+                    b = P / 4.0 ** l * bpp
+                    ach = b / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+                    lv.append(dict(kernel=f"{fam}@L{l}", level=l, pixels=int(P / 4 ** l), launches_per_frame=round(cnt / n_kt, 2), avg_launch_ms=round(avg, 5), bytes_per_launch=b, achieved=round(ach, 1),
+                                   peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4)))
+            roof["tracker_levels"] = lv
             # blended per stage: algorithmic bytes of the stage's launches per frame over the stage's measured ms per frame (the columns of the metric)
             stages = {}
             for sname, members in STAGE_OF.items():
@@ -552,6 +566,8 @@ def main():
     x_ranks = osh.comm_ranks() if (osh is not None and xstats) else None
     lc_diag = ef.loop_closure_diag() if args.close_loops else None
 
+    range_exceeded = ef.tracker_range_exceeded() if hasattr(ef, "tracker_range_exceeded") else None
+
     def build_line(sharded_leg_, cpu_):
         fps = (1 if one_map else world) * args.steps / dt
         out = {
@@ -571,6 +587,9 @@ def main():
             **extras,
             **({"value_sharded": sharded_leg_} if sharded_leg_ else {}),
             "ate_rms_m": ate, "gen_s": round(t_gen, 1), "view_list": vl_stats,
+            # run-time guard of the tracker's exact sums (ifx_tracker_range_exceeded): reductions of this whole run whose totals left the range in which the sums are order-independent
+            # and equal the oracle's; 0 = every pose above is the pose of the fixed arithmetic
+            "exact_sum_range_exceeded": range_exceeded,
             **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
                              "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": x_ranks}} if xstats else {}),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in lc_diag.items() if k_ != "est_pose"}} if args.close_loops else {}),

@@ -561,6 +561,17 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 float* slot = h->d_scratch + 2 * 16;
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
+                // A frame that takes its pose from the caller never reaches RGBDOdometry::initRGB (EF/ElasticFusion.cpp:330-356: only the tracking branch calls it), so the tracker's
+                // "last next image" -- what the NEXT tracked frame's SO(3) pre-alignment compares itself with -- stays that of the last TRACKED frame.  Here every frame's side fills
+                // the intensity pyramid of its slot, and the next frame reads its predecessor's slot: the held frame's slot gets the predecessor's pyramid back.  Behind this frame's
+                // side and in front of the next one's, on their stream.  (Found by tests/test_gpu_sweep.py: a tracked frame behind a held one was 5 mm off the oracle.)
+                {
+                    hipStream_t q = h->opt_two_streams ? h->stream_b : h->stream;
+                    const FrameSlot& prev = h->slot[s ^ 1];
+                    for (int l = 0; l < IFX_NUM_PYRS; l++)
+                        HIPCHK(h, hipMemcpyAsync(f.next_img[l], prev.next_img[l], (size_t)h->pyr.w[l] * h->pyr.h[l], hipMemcpyDeviceToDevice, q));
+                    if (q != h->stream) HIPCHK(h, hipEventRecord(f.ready, q));   // (whoever waits for this slot's frame side also waits for the copy)
+                }
             }
         }
         if (h->want_early_pose && !h->lc_enable) {   // ifx_process_frame: the pose the call returns, behind the tracker and in front of the map passes
@@ -1330,7 +1341,14 @@ extern "C" int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* l
         return IFX_OK;
     }
     auto it = h->kname_id.find(s);
-    if (it == h->kname_id.end()) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return IFX_OK; }
+    if (it == h->kname_id.end()) {   // a family name: the sum over "name@..." (the tracker's launches are timed per pyramid level: icp_residual@L0 ...)
+        double tot = 0; int n = 0;
+        for (size_t i = 0; i < h->knames.size(); i++)
+            if (h->knames[i].compare(0, s.size() + 1, s + "@") == 0) { tot += h->ktimes[i].total_ms; n += h->ktimes[i].launches; }
+        if (avg_ms) *avg_ms = n ? (float)(tot / n) : 0.f;
+        if (launches) *launches = n;
+        return IFX_OK;
+    }
     const KernelTiming& k = h->ktimes[it->second];
     if (avg_ms) *avg_ms = k.launches ? (float)(k.total_ms / k.launches) : 0.f;
     if (launches) *launches = k.launches;

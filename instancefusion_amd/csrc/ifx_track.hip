@@ -2699,6 +2699,10 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     auto gnp_acc_of = [&](int par) { return (double*)(stb + offsetof(DevState, gnp_acc)) + (size_t)(par * 2) * IFX_ACC_REPL * IFX_ACC_STRIDE; };
     auto gnp_res_of = [&](int par) { return (int*)(stb + offsetof(DevState, gnp_res)) + par * 16; };
     auto gnp_rrt_of = [&](int par) { return (double*)(stb + offsetof(DevState, gnp_RRt)) + par * 16; };
+    // per-kernel timing (option kernel_timing) is kept per pyramid level: ifx_kernel_ms("icp_residual") sums the levels, "icp_residual@L0" is level 0 alone (bench.py's per-level roofline)
+    static const char* const icp_name[3] = {"icp_residual@L0", "icp_residual@L1", "icp_residual@L2"};
+    static const char* const rgb_name[3] = {"rgb_step_solve@L0", "rgb_step_solve@L1", "rgb_step_solve@L2"};
+    static_assert(IFX_NUM_PYRS == 3, "level names");
     for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
         // The coarse levels are on the queue: the host is now ahead of the GPU by ~20 latency-bound launches, and the
         // finest level keeps the GPU mostly idle for another ~0.3 ms -- the place to slip in the next frame's image-only work.
@@ -2765,9 +2769,9 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         for (int j = 0; j < iterations[i]; j++) {
             const float nd = (j == iterations[i] - 1) ? ld : div;
 #ifdef IFX_EXPERIMENTS
-            if (px_form && px_two && n > 150000) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS * 2)), dim3(RED_THREADS), (k_icp_residual_px<2, false>), st, cdiv(n, RED_THREADS * 2), pa.w, pa.h, gacc, gres, pa);
-            else if (px_form) LAUNCH(h, "icp_residual", dim3(cdiv(n, RED_THREADS)), dim3(RED_THREADS), (k_icp_residual_px<1, false>), st, cdiv(n, RED_THREADS), pa.w, pa.h, gacc, gres, pa);
-            else if (pa.lds_tiles) { GnPro g0; memset(&g0, 0, sizeof(g0)); LAUNCH(h, "icp_residual", dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa, g0, (double*)nullptr); }   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
+            if (px_form && px_two && n > 150000) LAUNCH(h, icp_name[i], dim3(cdiv(n, RED_THREADS * 2)), dim3(RED_THREADS), (k_icp_residual_px<2, false>), st, cdiv(n, RED_THREADS * 2), pa.w, pa.h, gacc, gres, pa);
+            else if (px_form) LAUNCH(h, icp_name[i], dim3(cdiv(n, RED_THREADS)), dim3(RED_THREADS), (k_icp_residual_px<1, false>), st, cdiv(n, RED_THREADS), pa.w, pa.h, gacc, gres, pa);
+            else if (pa.lds_tiles) { GnPro g0; memset(&g0, 0, sizeof(g0)); LAUNCH(h, icp_name[i], dim3(pa.nb_icp + pa.nb_res), dim3(RED_THREADS), (k_icp_residual<true, false, false>), st, pa.nb_icp, pa.w, pa.h, gacc, gres, pa, g0, (double*)nullptr); }   // (its 60 KB of LDS would cost the plain kernel its occupancy: a kernel of its own)
             else
 #endif
             {
@@ -2780,11 +2784,11 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 double* const rrt_store = gnp_rrt_of((tail_k + 1) & 1);   // the increment after iteration tail_k - 1
                 const dim3 grid(pa.nb_icp + pa.nb_res);
                 if (it_pro && tail_k > 0) {
-                    if (frame_tracker) LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, false, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
-                    else LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, true, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    if (frame_tracker) LAUNCH(h, icp_name[i], grid, dim3(RED_THREADS), (k_icp_residual<false, false, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    else LAUNCH(h, icp_name[i], grid, dim3(RED_THREADS), (k_icp_residual<false, true, true>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
                 } else {
-                    if (frame_tracker) LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, false, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
-                    else LAUNCH(h, "icp_residual", grid, dim3(RED_THREADS), (k_icp_residual<false, true, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    if (frame_tracker) LAUNCH(h, icp_name[i], grid, dim3(RED_THREADS), (k_icp_residual<false, false, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
+                    else LAUNCH(h, icp_name[i], grid, dim3(RED_THREADS), (k_icp_residual<false, true, false>), st, pa.nb_icp, pa.w, pa.h, ga, gr, pa, gp, rrt_store);
                 }
             }
             StepArgs sa2;
@@ -2801,8 +2805,8 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             sa2.pro = (pro && tail_k < n_pro) ? (tail_k == n_pro - 1 ? 2 : 1) : 0; sa2.pro_k = tail_k;   // (the chain's last iteration: last-block form; it is the run's last too unless finer levels were too large for the prologue)
             tail_k++;
             ended = ended || sa2.end_run;
-            if (frame_tracker) LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
-            else LAUNCH(h, "rgb_step_solve", dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
+            if (frame_tracker) LAUNCH(h, rgb_name[i], dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<false>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
+            else LAUNCH(h, rgb_name[i], dim3(nb_rgb), dim3(RED_THREADS), k_rgb_step_solve<true>, st, sa2.nb, sa2.rgb, sa2.w, sa2.h, sa2);
         }
     }
     if (!ended)   // (no iteration ran at all: every level has zero iterations)

@@ -117,6 +117,62 @@ def trajectory(n_frames: int, amp: float = 0.15, yaw_amp: float = 0.12, pitch_am
     return poses
 
 
+def _rot(yaw: float, pitch: float, roll: float = 0.0) -> np.ndarray:
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    return Ry @ Rx @ Rz
+
+
+MOTION_PROFILES = ("still", "slow", "nominal", "fast", "jump", "spin", "dolly", "shake")
+
+
+def trajectory_profile(kind: str, n_frames: int, seed: int = SEED) -> np.ndarray:
+    """Camera-to-world poses (n,4,4) f64 for the parity sweep (tests/test_gpu_sweep.py): from a camera that does not move to one that leaves the tracker's
+    correspondence gates (0.10 m / 20 degrees per frame, EF/Utils/RGBDOdometry.h:38-39) -- the view lists are then rebuilt every frame and tracking fails, identically
+    on both sides.  Per-frame steps: still 0; slow 2 mm / 0.1 deg; nominal 1 cm / 0.5 deg; fast 4 cm / 4 deg; jump = nominal with ONE step of 15 cm / 25 deg; spin =
+    rotation only, 6 deg; dolly = translation along the view only, 5 cm; shake = random sign, 2 cm / 2 deg."""
+    rng = np.random.RandomState(seed + 101)
+    start = np.array([rng.uniform(-0.3, 0.3), rng.uniform(0.0, 0.2), rng.uniform(-1.4, -1.0)])
+    yaw0, pitch0 = rng.uniform(-0.15, 0.15), rng.uniform(-0.05, 0.05)
+    dirv = rng.standard_normal(3); dirv /= np.linalg.norm(dirv)
+    step = {"still": (0.0, 0.0), "slow": (0.002, 0.1), "nominal": (0.01, 0.5), "fast": (0.04, 4.0), "jump": (0.01, 0.5), "spin": (0.0, 6.0), "dolly": (0.05, 0.0),
+            "shake": (0.02, 2.0)}[kind]
+    poses = np.zeros((n_frames, 4, 4))
+    pos, yaw, pitch, roll = start.copy(), yaw0, pitch0, 0.0
+    for i in range(n_frames):
+        T = np.eye(4)
+        T[:3, :3] = _rot(yaw, pitch, roll)
+        T[:3, 3] = pos
+        poses[i] = T
+        dt, dr = step
+        if kind == "jump" and i == n_frames // 2:
+            dt, dr = 0.15, 25.0
+        sgn = rng.choice([-1.0, 1.0], 3) if kind == "shake" else np.ones(3)
+        if kind == "dolly":
+            pos = pos + T[:3, 2] * dt
+        else:
+            pos = pos + dirv * dt * sgn[0]
+        yaw += np.deg2rad(dr) * 0.8 * sgn[1]
+        pitch += np.deg2rad(dr) * 0.3 * sgn[2]
+        roll += np.deg2rad(dr) * 0.5 * (sgn[0] if kind == "shake" else 1.0) if kind in ("fast", "shake", "spin") else 0.0
+    return poses
+
+
+def make_stream_from_poses(poses: np.ndarray, scene: "Scene", w: int, h: int, fx: float, fy: float, cx: float, cy: float, noise_seed: int | None = None):
+    """As make_stream, on given camera-to-world poses and a given scene."""
+    n = poses.shape[0]
+    rng = np.random.RandomState(noise_seed) if noise_seed is not None else None
+    rgb = np.zeros((n, h, w, 3), np.uint8)
+    dep = np.zeros((n, h, w), np.uint16)
+    obj = np.zeros((n, h, w), np.int32)
+    for i in range(n):
+        rgb[i], dep[i], obj[i] = render(scene, poses[i], w, h, fx, fy, cx, cy, rng)
+    inv0 = np.linalg.inv(poses[0])
+    return dict(rgb=rgb, depth=dep, obj=obj, poses=np.stack([inv0 @ p for p in poses]), poses_world=poses, scene=scene)
+
+
 def render(scene: Scene, pose: np.ndarray, w: int, h: int, fx: float, fy: float, cx: float, cy: float,
            noise_rng: np.random.RandomState | None = None):
     """Returns rgb (h,w,3) u8, depth (h,w) u16 mm, obj (h,w) int32."""

@@ -21,6 +21,8 @@ from collections import defaultdict
 def short(name, keep_template=False):
     """k_name (template arguments dropped: the variants of a kernel are one entry; `keep_template` keeps them, without commas, for the stats table)."""
     n = name.split("(")[0].replace("void ", "").strip()
+    if n.replace(" ", "") in ("k_raster_view<false,true>", "k_raster_view<true,true>") and not keep_template:
+        return "k_clean_raster_view"   # the fused clean + raster walk of the frame path is timed (and priced) under its own name (bench.py: clean_raster_view)
     if "<" in n:
         n = n.replace(", ", " ") if keep_template else n.split("<")[0]
     return n
@@ -55,7 +57,7 @@ PATTERN = {
     # wide streams
     "k_count_colour": "stream16", "k_compact_scatter": "stream16", "k_max_count": "stream16", "k_clean_table": "stream16", "k_knn_search": "stream16",
     # list-driven passes: a 4-B list entry, then 16-B / 8-B records gathered from the store at ~9 % density
-    "k_raster_view": "gather16", "k_clean_view": "gather16", "k_index_list": "gather16", "k_raster_list": "gather16", "k_clean_list": "gather16", "k_tile_raster": "gather16",
+    "k_raster_view": "gather16", "k_clean_raster_view": "gather16", "k_clean_view": "gather16", "k_index_list": "gather16", "k_raster_list": "gather16", "k_clean_list": "gather16", "k_tile_raster": "gather16",
     # per-pixel passes that gather 16-B records through an id / key image
     "k_index_resolve": "gather16r", "k_splat_resolve": "gather16r", "k_fuse_update": "gather16r", "k_project_bbox": "gather16r", "k_count_colour_px": "gather16r",
     "k_associate": "gather16r", "k_vote_update": "gather16r", "k_project_depth": "gather16r",

@@ -289,6 +289,10 @@ class ElasticFusion:
         """ifx_owner_track_ahead: rank `tracking_rank` runs the tracker of camera cam's NEXT frame now, from the camera's parked context (cam = -1: frames served that way so far)"""
         return self._chk(self.L.ifx_owner_track_ahead(self.handle, int(cam), int(tracking_rank), C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_track_ahead")
 
+    def owner_frame_phase(self, phase, d_rgb_ptr=0, d_depth_ptr=0):
+        """ifx_owner_frame_phase: one phase of a sharded map's frame (the exchanges between the phases are the caller's, or ifx_comm.hip's)"""
+        return self._chk(self.L.ifx_owner_frame_phase(self.handle, int(phase), C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr)), "ifx_owner_frame_phase")
+
     def owner_set_tracking_rank(self, r):
         self._chk(self.L.ifx_owner_set_tracking_rank(self.handle, int(r)), "ifx_owner_set_tracking_rank")
 

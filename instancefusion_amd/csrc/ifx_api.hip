@@ -504,6 +504,23 @@ static int enqueue_loop_closure_tracker(ifx* h)
     return r;
 }
 
+// A frame that takes its pose from the caller never reaches RGBDOdometry::initRGB (EF/ElasticFusion.cpp:330-356: only the tracking branch calls it), so the tracker's "last next
+// image" -- what the NEXT tracked frame's SO(3) pre-alignment compares itself with -- stays that of the last TRACKED frame.  Here every frame's side fills the intensity
+// pyramid of its slot and the next frame reads its predecessor's slot: the held frame's slot gets the predecessor's pyramid back, on stream q behind this frame's side and in
+// front of the next one's (which waits for the slot's "ready" event).  Found by tests/test_gpu_sweep.py: a tracked frame behind a held one was 5 mm off the oracle.
+// Not with camera contexts (K streams, beyond the reference): a camera enters with its extrinsic pose, and its next frame is compared with THAT frame's image, not with the
+// image another camera saw last.
+static int hold_last_image(ifx* h, int s, hipStream_t q)
+{
+    if (!h->cams.empty() || s > 1) return IFX_OK;
+    FrameSlot& f = h->slot[s];
+    const FrameSlot& prev = h->slot[s ^ 1];
+    for (int l = 0; l < IFX_NUM_PYRS; l++)
+        HIPCHK(h, hipMemcpyAsync(f.next_img[l], prev.next_img[l], (size_t)h->pyr.w[l] * h->pyr.h[l], hipMemcpyDeviceToDevice, q));
+    HIPCHK(h, hipEventRecord(f.ready, q));   // (whoever waits for this slot's frame side also waits for the copy)
+    return IFX_OK;
+}
+
 // ElasticFusion::processFrame, EF/ElasticFusion.cpp:269-720, enqueued on the handle's streams.  Of the loop-closure block (:450-617)
 // the local detection is implemented (ifx_set_loop_closure), the fern lookup and both deformations run in the caller's callbacks (the graph
 // optimiser is host code of the reference); without the detection the first predict() of :453, whose only consumers are those stages, is not executed.
@@ -561,17 +578,7 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 float* slot = h->d_scratch + 2 * 16;
                 HIPCHK(h, hipMemcpyAsync(slot, in_pose16, 64, hipMemcpyHostToDevice, h->stream));
                 ifx_tracker_external_pose(h, slot, weight_mult);
-                // A frame that takes its pose from the caller never reaches RGBDOdometry::initRGB (EF/ElasticFusion.cpp:330-356: only the tracking branch calls it), so the tracker's
-                // "last next image" -- what the NEXT tracked frame's SO(3) pre-alignment compares itself with -- stays that of the last TRACKED frame.  Here every frame's side fills
-                // the intensity pyramid of its slot, and the next frame reads its predecessor's slot: the held frame's slot gets the predecessor's pyramid back.  Behind this frame's
-                // side and in front of the next one's, on their stream.  (Found by tests/test_gpu_sweep.py: a tracked frame behind a held one was 5 mm off the oracle.)
-                {
-                    hipStream_t q = h->opt_two_streams ? h->stream_b : h->stream;
-                    const FrameSlot& prev = h->slot[s ^ 1];
-                    for (int l = 0; l < IFX_NUM_PYRS; l++)
-                        HIPCHK(h, hipMemcpyAsync(f.next_img[l], prev.next_img[l], (size_t)h->pyr.w[l] * h->pyr.h[l], hipMemcpyDeviceToDevice, q));
-                    if (q != h->stream) HIPCHK(h, hipEventRecord(f.ready, q));   // (whoever waits for this slot's frame side also waits for the copy)
-                }
+                hold_last_image(h, s, h->opt_two_streams ? h->stream_b : h->stream);
             }
         }
         if (h->want_early_pose && !h->lc_enable) {   // ifx_process_frame: the pose the call returns, behind the tracker and in front of the map passes
@@ -717,6 +724,8 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
             if (r) return r;
         }
     }
+    h->cams[(size_t)h->cur_cam].pred_root = h->pred_root;   // (who holds the parked prediction complete travels with it)
+    h->pred_root = h->cams[(size_t)cam].valid ? h->cams[(size_t)cam].pred_root : h->pred_root;   // (a camera selected for the first time starts as a copy of the current one)
     h->cur_cam = cam;
     h->seg_counts_valid = 0;
     h->last_frame_slot = (h->tick & 1) ^ 1;   // (what the next frame side reads as its previous image now lives there)
@@ -755,6 +764,14 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     if (cam == -1) return h->cam_ahead_used;
     if (!h->own) { h->err = "ifx_owner_track_ahead: the handle was not created for a sharded map"; return IFX_E_STATE; }
     if (cam < 0 || (size_t)cam >= h->cams.size() || !d_rgb || !d_depth || tracking_rank < 0 || tracking_rank >= h->own_g) return IFX_E_INVALID;
+    {   // the run reads the camera's parked prediction: it must be complete on the rank that runs (every rank decides this alike, so nobody is left alone in a collective)
+        const int root = (cam == h->cur_cam) ? h->pred_root : h->cams[(size_t)cam].pred_root;
+        if (root >= 0 && root != tracking_rank) {
+            h->err = "ifx_owner_track_ahead: camera " + std::to_string(cam) + "'s prediction was reduced to rank " + std::to_string(root) + " only; rank " + std::to_string(tracking_rank) +
+                     " holds partial sums (run one frame of the camera with ifx_owner_set_tracking_rank(-1) to all-reduce it)";
+            return IFX_E_STATE;
+        }
+    }
     if (tracking_rank != h->cfg.rank) return IFX_OK;
     if (cam == h->cur_cam || !h->cams[(size_t)cam].valid) { h->err = "ifx_owner_track_ahead: the camera's context must be parked (select another camera first)"; return IFX_E_STATE; }
     if (h->lc_enable || !h->stream_c) { h->err = "ifx_owner_track_ahead: not available with the loop-closure detection on / on a one-stream handle"; return IFX_E_STATE; }
@@ -943,6 +960,14 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         // Bounded run-ahead, as on the unsharded path (enqueue_frame): the previous frame's RESULT before this frame goes onto the queues
         if (h->opt_pace && h->ev_result && h->tick > 1) HIPCHK(h, hipEventSynchronize(h->ev_result));
         const bool tracks = h->own_track_rank < 0 || h->own_track_rank == h->cfg.rank;
+        if (!first && !h->own_frame_pose_set && h->pred_root >= 0 && h->pred_root != h->own_track_rank) {
+            // the prediction this frame tracks against was reduced to ONE rank (exchange 5 with a tracking rank) and that rank is not (the only) one tracking now: the others hold
+            // partial sums.  Every rank sees the same two numbers and refuses alike -- a pose tracked from a partial block would be broadcast to everybody without an error
+            h->err = "the live camera's prediction was reduced to rank " + std::to_string(h->pred_root) + " only, and " +
+                     (h->own_track_rank < 0 ? std::string("every rank") : "rank " + std::to_string(h->own_track_rank)) +
+                     " is to track this frame: keep the tracking rank, or give this one frame its pose (ifx_owner_set_frame_pose) -- its own prediction is then all-reduced";
+            return IFX_E_STATE;
+        }
         // one-frame look-ahead (ifx_hint_next_frame_device before the previous frame): the frame side of this frame ran on the side stream under the previous frame's
         // phases, and its tracker -- which reads only its slot, the exchanged prediction and the pose -- was enqueued right behind that frame, its result parked
         const bool prepared = f.for_tick == h->tick && f.src_rgb == d_rgb && f.src_depth == d_depth && src_kind == 0;
@@ -980,6 +1005,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             float* slot = h->d_scratch + 2 * 16;
             HIPCHK(h, hipMemcpyAsync(slot, h->own_frame_pose, 64, hipMemcpyHostToDevice, h->stream));
             ifx_tracker_external_pose(h, slot, 1.0f);
+            { int r = hold_last_image(h, bound_slot, h->stream); if (r) return r; }   // (the main stream is behind this frame's side: it waited for the slot above, or ran it itself)
         } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
             StageTimer t(h, 0);
             if (ahead) {
@@ -1068,7 +1094,8 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
             // rank's whetherDoSegmentation decision needs -- still goes to everybody.  On the other ranks the block holds their own partial sums and is never read.
             add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16 - 16, 5 | (h->own_track_rank << 8));
             add(h->pred_tail, 16, 1);
-        } else add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1);
+            h->pred_root = h->own_track_rank;   // (remembered: only that rank may track this camera's next frame)
+        } else { add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1); h->pred_root = -1; }
         break;
     case 6: break;
     case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank

@@ -246,6 +246,7 @@ struct CamCtx {
     hipEvent_t ev_ahead = nullptr;     // behind this camera's run (its own event: a frame must not wait for a run enqueued after its own)
     int ahead_valid = 0;
     const void *ahead_rgb = nullptr, *ahead_depth = nullptr;
+    int pred_root = -1;                // who holds this camera's parked prediction COMPLETE: -1 every rank (all-reduced), else the one rank exchange 5 reduced it to (ifx::pred_root while the camera is live)
 };
 #define IFX_CAM_STATE_BYTES 200        // pose[16], pose_inv[16], last_pose[16], weighting, dense_enough
 
@@ -278,6 +279,8 @@ struct ifx {
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
     int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it
+    int pred_root = -1;                 // sharded map: the rank the live camera's prediction was last reduced to (exchange 5 with a tracking rank: the other ranks hold partial sums), -1: all-reduced.
+                                        // The same on every rank (it follows the host's call sequence), so every rank refuses alike a frame / run-ahead that would track from a partial block
     int own_track_rank = -1;            // sharded map: the one rank that tracks the frames to come (-1: every rank tracks, replicated); the others receive the pose block (exchange 310)
     float own_frame_pose[16]; int own_frame_pose_set = 0;   // sharded map: the next frame takes this pose instead of tracking (ifx_owner_set_frame_pose)
     int own = 0, own_g = 1;             // spatially sharded map (ifx_config::n_ranks > 1, or -1: a world of one): this handle stores the surfels it owns; own_g = number of ranks

@@ -1011,6 +1011,19 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
         assert [e.owner_track_ahead(-1, 0) for e in efs] == [NS - 1, NS - 1]
     else:
         assert [e.owner_track_ahead(-1, 0) for e in efs] == [0, 0]
+    # A camera's prediction is reduced to its tracking rank ONLY (exchange 5, op 5): whoever else tried to track that camera's next frame would do so from partial sums and
+    # broadcast the result.  The handles remember the root per camera and EVERY rank refuses alike -- the frame, and a run ahead
+    j = first[K - 1] + NS
+    for e in efs:   # (camera K - 1 is live, its prediction sits complete on rank K - 1 only)
+        e.owner_set_tracking_rank(0)
+        with pytest.raises(ifx.IfxError, match="reduced to rank"):
+            e.owner_frame_phase(310, d_rgb[j].data_ptr(), d_dep[j].data_ptr())
+        e.owner_set_tracking_rank(-1)
+        with pytest.raises(ifx.IfxError, match="reduced to rank"):
+            e.owner_frame_phase(0, d_rgb[j].data_ptr(), d_dep[j].data_ptr())      # (every rank tracks: the frame starts with phase 0)
+        with pytest.raises(ifx.IfxError, match="reduced to rank"):
+            e.owner_track_ahead(0, 1, d_rgb[j].data_ptr(), d_dep[j].data_ptr())   # camera 0 (parked): its prediction lives on rank 0
+        e.owner_set_tracking_rank(K - 1)
     ref = one.download()
     parts = [(e.seq(), e.download()) for e in efs]
     seq = np.concatenate([p[0] for p in parts])

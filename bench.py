@@ -118,7 +118,8 @@ def main():
                     "through the fern callback, addFrame enqueued behind the frame and fetched in the next callback); the data base itself is host code (instancefusion_amd/host/ifx_ferns.hpp) and never matches here")
     ap.add_argument("--no-superpixels", action="store_true", help="skip the SLIC/merge/filter refinement of the masks (the reference always runs it)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the `value_sharded` leg (the same stream into ONE map spatially sharded over the ranks of this run, reported beside the replicas' `value`)")
-    ap.add_argument("--config5-sets", type=int, default=6, help="N = 1: frame sets (8 cameras each) of the configuration-5 leg inside the sharded leg; 0 skips it")
+    ap.add_argument("--config5-sets", type=int, default=6, help="frame sets (one frame per camera each) of the configuration-5 leg (N = 1: 8 cameras, inside the sharded leg; N > 1: N cameras, `value_config5`); 0 skips it")
+    ap.add_argument("--config5-surfels", type=int, default=0, help="N > 1: surfels of the ONE shared map of the configuration-5 leg (0: --surfels x N, at most 50 M -- BASELINE configuration 5 at N = 8 within 20 %%)")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: seconds after which the line is printed without the sharded-map leg should that leg stall (0: wait for ever)")
     ap.add_argument("--extras-frames", type=int, default=60, help="frames of each extra leg at N = 1 (host entry point, closeLoops = true); 0 skips them")
     args = ap.parse_args()
@@ -479,6 +480,29 @@ def main():
         t_host = timed(k, ne, host_step); k += ne
         extras["value_host_entry"] = dict(value=round(ne / t_host, 2), unit="frames/s", frames=ne, segmentation_calls=seg["calls"],
                                           what="ifx_process_frame (ElasticFusion::processFrame's signature): host rgb/depth pointers, H2D inside the call, one host synchronisation per frame")
+        # the same loop with option host_entry_async: the call returns when the frame's POSE is known (read back right behind the tracker); the frame's map passes finish under
+        # whatever the caller does next.  `with_decision`: the caller asks whetherDoSegmentation after every frame (the reference's loop: it waits for the frame's result there,
+        # so only the host copy of the next frame's depth image overlaps); `frames_only`: a caller that only feeds frames (a replay, a tracking-only client)
+        ef.set_option("host_entry_async", 1)
+        for _ in range(5):
+            host_step(k); k += 1
+        place_call_in_window(ne)
+        seg["calls"] = 0
+        t_ha = timed(k, ne, host_step); k += ne
+        calls_ha = seg["calls"]
+
+        def host_step_frames(kk):
+            i = kk % L
+            ef.processFrame(st["rgb"][i], st["depth"][i])
+
+        for _ in range(3):
+            host_step_frames(k); k += 1
+        t_hf = timed(k, ne, host_step_frames); k += ne
+        ef.sync()
+        ef.set_option("host_entry_async", 0)
+        extras["value_host_entry_async"] = dict(value=round(ne / t_ha, 2), unit="frames/s", frames=ne, segmentation_calls=calls_ha, frames_only=round(ne / t_hf, 2),
+                                                what="ifx_process_frame with option host_entry_async (returns with the pose; map passes finish under the caller's next steps): `value` with "
+                                                     "whetherDoSegmentation asked after every frame, `frames_only` without")
         # the reference's own configuration: closeLoops = true (IF/map_interface/ElasticFusionInterface.cpp:43): predict() at the tracked pose,
         # INACTIVE prediction, model-to-model tracker and the gates on every frame; resident frames + look-ahead as in `value`
         ef.set_loop_closure(True, 35000, 5e-5, 1e-5)
@@ -597,6 +621,108 @@ def main():
         }
         return out
 
+    def tile_map(m_, n_target):
+        """The benchmark map grown to n_target surfels without another minute of ray casting per rank: whole copies of it, each shifted by a fixed sub-centimetre offset
+        (a denser sampling of the same surfaces: what make_map(n_target) would give), confidence / times / votes as they are."""
+        n0 = m_["pc"].shape[0]
+        reps = max(1, -(-n_target // n0))
+        if reps == 1:
+            return m_
+        rng5 = np.random.RandomState(synth.SEED + 55)
+        out_ = {}
+        for key_, a_ in m_.items():
+            out_[key_] = np.concatenate([a_] * reps)[:n_target]
+        for r_ in range(1, reps):
+            lo_, hi_ = r_ * n0, min((r_ + 1) * n0, n_target)
+            out_["pc"][lo_:hi_, :3] += (rng5.uniform(-1, 1, 3) * 0.004).astype(np.float32)
+        return out_
+
+    def run_config5(K5, m5_, st5, d_rgb5, d_dep5):
+        """K5 streams (K5 stretches of the same trajectory) into ONE map sharded over the `world` ranks of this run: camera contexts, camera c tracked by rank c % world ONLY
+        (ifx_owner_set_tracking_rank: no tracker collective; its prediction is reduced to that rank, its pose block broadcast from it), and -- `ahead` -- the tracker of a
+        camera's NEXT frame started on its rank's third stream the moment the camera's context is parked, under the other cameras' map phases (ifx_owner_track_ahead).
+        Frames/s over all cameras with and without the run-ahead.  (tests/test_gpu_parity.py::test_config5_* hold the bit-parity of exactly this schedule, at 50M x 8 too.)"""
+        from instancefusion_amd import sharded as ifsh5
+
+        first5 = [((L - 12) // max(K5, 1)) * c_ for c_ in range(K5)] if K5 != 8 else [10 * c_ for c_ in range(8)]
+        n_map = int(m5_["pc"].shape[0])
+        res = {}
+        for ahead5 in (0, 1):
+            ef5 = ifx.ElasticFusion(w=W, h=H, max_surfels=n_map // world + P + 500_000, device=dev, **K, n_ranks=(world if world > 1 else -1), rank=rank)
+            for kv in args.opt:
+                k_, v_ = kv.split("=")
+                ef5.set_option(k_, int(v_))
+            osh5 = ifsh5.OwnerShardedElasticFusion(ef5, dist)
+            ef5.camera_count(K5)
+            osh5.process_frame_device(d_rgb5[0].data_ptr(), d_dep5[0].data_ptr())
+            ef5.upload(m5_)
+            ef5.set_pose(st5["poses"][0], tick0)
+            osh5.predict()
+
+            def set5(s_):
+                for c_ in range(K5):
+                    i_ = first5[c_] + 1 + s_
+                    ef5.camera_select(c_)
+                    ef5.owner_set_tracking_rank(c_ % world)
+                    if c_ > 0 and s_ == 0:
+                        ef5.owner_set_frame_pose(st5["poses"][i_].astype(np.float32))   # a camera enters with its extrinsic calibration, then tracks
+                    if ahead5 and (s_ > 0 or c_ > 0):   # the camera whose frame was just processed is parked: its next frame's tracker starts now, on its rank
+                        cp_, sp_ = (c_ - 1, s_) if c_ > 0 else (K5 - 1, s_ - 1)
+                        j_ = first5[cp_] + 1 + sp_ + 1
+                        if j_ < L:
+                            ef5.owner_track_ahead(cp_, cp_ % world, d_rgb5[j_].data_ptr(), d_dep5[j_].data_ptr())
+                    osh5.process_frame_device(d_rgb5[i_].data_ptr(), d_dep5[i_].data_ptr())
+
+            def sync5():
+                ef5.sync(); torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                    torch.cuda.synchronize()
+
+            for s_ in range(2):
+                set5(s_)
+            sync5()
+            served0 = ef5.owner_track_ahead(-1, 0)
+            osh5.exchange_stats(reset=True)
+            gc.disable()
+            t0 = time.perf_counter()
+            for s_ in range(2, 2 + args.config5_sets):
+                set5(s_)
+            sync5()
+            t5 = ifd.max_over_ranks(time.perf_counter() - t0, dist, device=f"cuda:{dev}")
+            gc.enable()
+            xs5 = osh5.exchange_stats()
+            nfr = K5 * args.config5_sets
+            leg = dict(value=round(nfr / t5, 2), frames=nfr, trackers_served_ahead=ef5.owner_track_ahead(-1, 0) - served0)
+            if world > 1:   # (the split and the exchange volume of the schedule that is reported as `value`)
+                leg["exchange"] = dict(collectives_per_frame=round(xs5["collectives"] / nfr, 2), bytes_per_frame=round(xs5["bytes"] / nfr), bytes_per_pixel_per_frame=round(xs5["bytes"] / nfr / P, 1))
+                ef5.stage_ms(reset=True)
+                ef5.set_option("stage_timing", 1)
+                set5(2 + args.config5_sets)
+                sync5()
+                sm5 = ef5.stage_ms(reset=True)
+                ef5.set_option("stage_timing", 0)
+                leg["ms_per_frame_gpu_this_rank"] = {k_: round(v_ / K5, 4) for k_, v_ in sm5.items() if k_ != "instance"}
+                leg["rccl_ranks"] = osh5.comm_ranks()
+                leg["surfel_slots_this_rank"] = ef5.slots
+            res["ahead" if ahead5 else "in_frame"] = leg
+            ef5.close()
+        out5 = dict(unit="frames/s", cameras=K5, n_ranks=world, surfels=n_map, **res)
+        if world > 1:
+            out5["value"] = res["ahead"]["value"]
+            out5["scaling"] = "strong"
+            out5["what"] = ("BASELINE configuration 5: %d concurrent %dx%d streams into ONE %d-surfel map spatially sharded over the %d ranks of this run (owner = spatial hash of a surfel's position), "
+                            "camera k tracked by rank k only, the exchanges of every frame RCCL collectives enqueued by libifx.so (csrc/ifx_comm.hip): the prediction of camera k reduced to rank k, "
+                            "its pose block broadcast from there.  `value` = frames/s over all cameras with every camera's next tracker running ahead on its rank under the other cameras' map "
+                            "phases (`ahead`); `in_frame`: every frame tracks inside itself" % (K5, W, H, n_map, world))
+        else:
+            out5["what"] = ("BASELINE configuration 5 on one GPU: 8 streams into ONE sharded map (world of one: every exchange a one-rank RCCL collective, the camera-indexed "
+                            "reduce included), camera contexts, time-sliced.  `in_frame`: every frame tracks inside itself.  `ahead`: every camera's next tracker runs on the "
+                            "third stream as soon as the camera is parked (ifx_owner_track_ahead) and the frame commits its pose block -- the schedule of G ranks, where rank k "
+                            "tracks camera k under the other cameras' map phases while the other ranks would otherwise wait for its pose; on ONE GPU that tracks all K cameras "
+                            "the two chains (latency-bound tracker launches, map passes) share the device, and the run repeats the frame side (0.16 ms) it cannot hand over")
+        return out5
+
     # The sharded leg at N > 1 is the one part of this benchmark that runs real multi-rank RCCL collectives enqueued by libifx.so.  Should it ever stall (a rank lost,
     # a communicator that does not come up), the replicas' measurement above must not be lost with it: after --sharded-timeout seconds rank 0 prints the line without
     # the leg (an "error" entry in its place) and every rank leaves.
@@ -607,7 +733,7 @@ def main():
         def _give_up():
             if rank == 0:
                 os.write(json_fd, (json.dumps(build_line({"error": f"the sharded leg did not finish within {args.sharded_timeout} s; the line is reported without it", "n_ranks": world}, None)) + "\n").encode())
-            os._exit(0)
+            os._exit(3)   # (a stalled collective is not a success: the launcher records it; nothing is restarted or re-executed)
 
         wd = threading.Timer(args.sharded_timeout + (0 if rank == 0 else 5), _give_up)
         wd.daemon = True
@@ -640,7 +766,7 @@ def main():
             ef2.upload(m2)
             ef2.set_pose(st2["poses"][0], tick0)
             osh2.predict()
-            m5 = m2 if (world == 1 and args.config5_sets > 0) else None   # (kept for the configuration-5 leg below)
+            m5 = m2 if args.config5_sets > 0 else None   # (kept for the configuration-5 leg below)
             del m2, m
             seg2 = dict(frame=0, calls=0)
 
@@ -696,61 +822,16 @@ def main():
             barrier2()
             ef2.close()
 
-            # ---- BASELINE configuration 5 in a world of one: K = 8 streams (eight stretches of the same trajectory) into ONE sharded map, camera contexts, every camera
-            # tracked by "its" rank (here: the only one) and -- `ahead` -- the tracker of a camera's NEXT frame started on the third stream the moment the camera's context
-            # is parked, under the other cameras' map phases (ifx_owner_track_ahead); the frame then commits the parked pose block.  Frames/s over all cameras, with and
-            # without the run-ahead: what the overlap is worth.  (tests/test_gpu_parity.py::test_config5_* hold the bit-parity of exactly this schedule, at 50M x8 too.)
+            # ---- BASELINE configuration 5: K streams into ONE shared map sharded over the ranks of this run (run_config5 below).  N = 1: 8 cameras in a world of one (what the
+            # schedule costs and what the run-ahead is worth on one GPU); N > 1: N cameras, camera k tracked by rank k, the map of --config5-surfels over the N ranks through
+            # the in-library RCCL exchanges -- `value_config5` of the line.  The SAME code either way.
             if m5 is not None:
-                K5, first5 = 8, [10 * c_ for c_ in range(8)]
-                c5 = {}
-                for ahead5 in (0, 1):
-                    ef5 = ifx.ElasticFusion(w=W, h=H, max_surfels=cap + P + 500_000, device=dev, **K, n_ranks=-1, rank=0)
-                    for kv in args.opt:
-                        k_, v_ = kv.split("=")
-                        ef5.set_option(k_, int(v_))
-                    osh5 = ifsh.OwnerShardedElasticFusion(ef5, dist)
-                    ef5.camera_count(K5)
-                    osh5.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
-                    ef5.upload(m5)
-                    ef5.set_pose(st2["poses"][0], tick0)
-                    osh5.predict()
-
-                    def set5(s_):
-                        for c_ in range(K5):
-                            i_ = first5[c_] + 1 + s_
-                            ef5.camera_select(c_)
-                            ef5.owner_set_tracking_rank(0)
-                            if c_ > 0 and s_ == 0:
-                                ef5.owner_set_frame_pose(st2["poses"][i_].astype(np.float32))   # a camera enters with its extrinsic calibration, then tracks
-                            if ahead5 and (s_ > 0 or c_ > 0):   # the camera whose frame was just processed is parked: its next frame's tracker starts now
-                                cp_, sp_ = (c_ - 1, s_) if c_ > 0 else (K5 - 1, s_ - 1)
-                                j_ = first5[cp_] + 1 + sp_ + 1
-                                if j_ < L:
-                                    ef5.owner_track_ahead(cp_, 0, d_rgb2[j_].data_ptr(), d_dep2[j_].data_ptr())
-                            osh5.process_frame_device(d_rgb2[i_].data_ptr(), d_dep2[i_].data_ptr())
-
-                    for s_ in range(2):
-                        set5(s_)
-                    ef5.sync(); torch.cuda.synchronize()
-                    served0 = ef5.owner_track_ahead(-1, 0)
-                    gc.disable()
-                    t0 = time.perf_counter()
-                    for s_ in range(2, 2 + args.config5_sets):
-                        set5(s_)
-                    ef5.sync(); torch.cuda.synchronize()
-                    t5 = time.perf_counter() - t0
-                    gc.enable()
-                    c5["ahead" if ahead5 else "in_frame"] = dict(value=round(K5 * args.config5_sets / t5, 2), frames=K5 * args.config5_sets,
-                                                                 trackers_served_ahead=ef5.owner_track_ahead(-1, 0) - served0)
-                    ef5.close()
+                if world == 1:
+                    sharded_leg["config5_world_of_one"] = run_config5(8, m5, st2, d_rgb2, d_dep2)
+                else:
+                    n5 = args.config5_surfels if args.config5_surfels > 0 else min(50_000_000, args.surfels * world)
+                    extras["value_config5"] = run_config5(world, tile_map(m5, n5), st2, d_rgb2, d_dep2)
                 del m5
-                sharded_leg["config5_world_of_one"] = dict(
-                    unit="frames/s", cameras=K5, **c5,
-                    what="BASELINE configuration 5 on one GPU: 8 streams into ONE sharded map (world of one: every exchange a one-rank RCCL collective, the camera-indexed "
-                         "reduce included), camera contexts, time-sliced.  `in_frame`: every frame tracks inside itself.  `ahead`: every camera's next tracker runs on the "
-                         "third stream as soon as the camera is parked (ifx_owner_track_ahead) and the frame commits its pose block -- the schedule of G ranks, where rank k "
-                         "tracks camera k under the other cameras' map phases while the other ranks would otherwise wait for its pose; on ONE GPU that tracks all K cameras "
-                         "the two chains (latency-bound tracker launches, map passes) share the device, and the run repeats the frame side (0.16 ms) it cannot hand over")
         except Exception as e:   # noqa: BLE001
             import traceback
 

@@ -394,11 +394,15 @@ static int enqueue_frame_side(ifx* h, int s, int tick, const uint8_t* rgb, const
     h->cur = q;
     ifx_bind_slot(h, s);
     hipMemcpyKind kind = src_kind ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    hipError_t e1 = hipMemcpyAsync(f.rgb, rgb, (size_t)h->P * 3, kind, q), e2 = hipMemcpyAsync(f.depth_raw, depth, (size_t)h->P * 2, kind, q);
-    if (e1 == hipSuccess && e2 == hipSuccess) {
+    // depth first: the bilateral filter (the longest launch of the frame side, 65 us) needs nothing else.  Host-pointer entry (ifx_process_frame): the caller's colour image is
+    // copied into the pinned staging buffer only NOW -- 0.9 MB of host memcpy that used to sit in front of the first transfer run under the depth transfer and the filter
+    hipError_t e2 = hipMemcpyAsync(f.depth_raw, depth, (size_t)h->P * 2, kind, q), e1 = hipSuccess;
+    if (e2 == hipSuccess) {
         StageTimer t(h, 3);
         ifx_preprocess(h);
-        ifx_tracker_frame_side(h, tick == 1);
+        if (h->late_rgb_src && src_kind == 1) { memcpy(h->rgb_stage, h->late_rgb_src, (size_t)h->P * 3); h->late_rgb_src = nullptr; }
+        e1 = hipMemcpyAsync(f.rgb, rgb, (size_t)h->P * 3, kind, q);
+        if (e1 == hipSuccess) ifx_tracker_frame_side(h, tick == 1);
     }
     hipEventRecord(f.ready, q);
     f.for_tick = tick; f.src_rgb = rgb; f.src_depth = depth;
@@ -1241,8 +1245,8 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
     const bool can_early = h->opt_host_entry_async && !h->lc_enable && !h->in_fern_cb && h->tick > 1 && h->cams.empty() && !in_pose16;   // (plain tracked frames of a single stream)
     // (the staging buffers are free: their last copy to the device ran in front of a tracker whose pose a previous call has waited for -- or behind a full synchronisation)
     if (!can_early) HIPCHK(h, hipStreamSynchronize(h->stream));
-    memcpy(h->rgb_stage, rgb, (size_t)h->P * 3);
     memcpy(h->depth_stage, depth, (size_t)h->P * 2);
+    h->late_rgb_src = rgb;   // (copied by enqueue_frame_side, behind the depth transfer and the bilateral filter's launch)
     bool early = false;
     if (can_early) {
         // the frame before this one is complete from here on: its result is final, and the housekeeping decision a synchronous call would have taken right behind it
@@ -1255,6 +1259,7 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
     h->want_early_pose = early ? 1 : 0;
     h->early_pose_valid = 0;
     int r = enqueue_frame(h, h->rgb_stage, h->depth_stage, 1, in_pose16, weight_mult, bootstrap);
+    if (h->late_rgb_src) { h->late_rgb_src = nullptr; if (!r) { h->err = "ifx_process_frame: the frame side did not take the colour image (internal)"; r = IFX_E_STATE; } }
     h->want_early_pose = 0;
     if (r) return r;
     if (early && h->early_pose_valid) {

@@ -423,6 +423,7 @@ struct ifx {
     uint16_t *depth_raw = nullptr, *depth_filt = nullptr;
     float *dm = nullptr, *dmf = nullptr;
     uint8_t* rgb_stage = nullptr; uint16_t* depth_stage = nullptr; // pinned staging
+    const uint8_t* late_rgb_src = nullptr;   // ifx_process_frame: the caller's colour image, copied into rgb_stage by the frame side behind the depth transfer
     // index map
     unsigned long long *key_index = nullptr, *key_splat = nullptr, *key_ids = nullptr;
     unsigned long long* key_both = nullptr;   // pixels a surfel covers in BOTH the splat and the id render: one atomic instead of two

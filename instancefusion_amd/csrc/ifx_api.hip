@@ -302,6 +302,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "clean_raster") h->opt_clean_raster = value;
+    else if (s == "side_late") h->opt_side_late = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
     else if (s == "host_entry_async") h->opt_host_entry_async = value;
@@ -563,7 +564,8 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
                 ifx_tracker_commit(h);
                 if (weight_mult != 1.0f) ifx_tracker_set_weight(h, weight_mult);
                 if (h->opt_side_gate == 1 && h->ev_gate) { hipEventRecord(h->ev_gate, h->stream); hipStreamWaitEvent(h->stream_b, h->ev_gate, 0); }   // (experiment) not under the tracker's tail
-                if (h->opt_side_gate != 2) {
+                // (option side_late: the announced frame's side enqueued behind this frame's map passes instead -- measured slower, see ifx_ctx.h)
+                if (h->opt_side_gate != 2 && !h->opt_side_late) {
                     int r = ifx_enqueue_hinted_frame_side(h);   // no tracker enqueue to hide it in: it runs under this frame's map passes
                     if (r) return r;
                 }

@@ -303,6 +303,7 @@ struct ifx {
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
+    int opt_side_late = 0;              // a frame whose tracker ran ahead enqueues the announced next frame's side behind its own map passes instead of in front of them (measured: 1490 against 1510 frames/s -- the frame side then runs beside the next tracker instead of beside this frame's map passes; off)
     int opt_pace = 1;                   // ifx_enqueue_frame_device waits for the previous frame's result before it enqueues (bounded run-ahead)
     int opt_ff_union = 1;               // flood fill of the masks: two-way edges merged by union-find before the directed relaxation (k_ff_merge)
     int opt_seg_aside = 1;              // a segmentation call that finds the next frame's tracker already queued on the main stream runs beside it on stream_c (the call is
@@ -348,6 +349,7 @@ struct ifx {
     int opt_labels_incremental = 1;
     int opt_raster_lds = 0;          // view raster: per-wave depth test in LDS before the global atomics (k_raster_view<true>)
     int opt_view_blocks = 0, opt_clean_blocks = 0, opt_index_blocks = 0;   // grids of the view-list kernels (0: LIST_BLOCKS)
+    int icp_resident_blocks = 1024;   // blocks of k_icp_residual the GPU holds at once (occupancy query at tracker allocation: 4 per CU x 256 CUs on MI355X)
     int opt_res_blocks = 0;          // cap on the blocks of the residual half of k_icp_residual (0: one block per 256 pixels)
     int opt_icp_blocks = 0;          // cap on the blocks of a tracker reduction launch; 0 = by image size (ifx_track.hip red_blocks)
     int opt_raster_tiles = -1;       // tiled rasteriser (k_tile_*: key tiles resolved in LDS) instead of global atomics: 0 off, 1 on, -1 by image size (on from 1 Mpixel:

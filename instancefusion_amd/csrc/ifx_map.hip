@@ -1609,8 +1609,11 @@ struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; in
 struct CleanArgs { float4* pc_rw; float2* tm_rw; const float4* tap; int nf_blocks; const uint32_t* assoc; const float4* mpc; const float4* mnr; int* flags; int* block_counts; };
 __device__ __forceinline__ void new_flags_body(DevState* st, const float* __restrict__ pose_inv_ex, const Cam& c, int time, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc,
                                                const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags, int* __restrict__ block_counts, int bid);
+#ifndef WALK_MIN_WAVES
+#define WALK_MIN_WAVES 1
+#endif
 template <bool LDSMIN, bool CLEAN>
-__global__ __launch_bounds__(MAP_THREADS) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
+__global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_raster_view(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Cam c,
                                                              int time, int maxTime, unsigned int want, const unsigned int* __restrict__ list_a, const unsigned int* __restrict__ list_i,
                                                              unsigned long long* __restrict__ key_splat, unsigned long long* __restrict__ key_ids,
                                                              unsigned long long* __restrict__ key_both, int earlyz, int ids_step, CleanArgs ca, const DevState* __restrict__ stc)

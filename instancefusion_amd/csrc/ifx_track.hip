@@ -2468,6 +2468,8 @@ int ifx_alloc_tracker(ifx* h)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], k_gn_level<3>, RED_THREADS, 0);
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], k_gn_level<4>, RED_THREADS, 0);
         for (int q = 0; q < 4; q++) h->gn_max_blocks[q] = std::max(0, occ[q]) * std::max(0, cus);
+        int occ_ir = 0;   // one round of residency of the two-launch form's first launch (its residual half is capped to what the ICP half leaves of it: ifx_tracker_run)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ir, k_icp_residual<false, false, true>, RED_THREADS, 0) == hipSuccess && occ_ir > 0 && cus > 0) h->icp_resident_blocks = occ_ir * cus;
     }
     h->res_rows = std::max(maxb, cdiv(h->P, RED_THREADS) + 1);   // the residual pass runs one block per 256 pixels
     HIPCHK(h, hipMalloc(&h->res_partials, (size_t)h->res_rows * 2 * 4));
@@ -2727,7 +2729,13 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
 #else
         const bool lds_tiles = false;
 #endif
-        const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb, nbr = std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : (1 << 30));
+        // One round of residency: the launch's blocks (ICP half + residual half) must all be on the GPU at once.  At 640x480 level 0 they were 456 + 1024 = 1480 against the 1024 the GPU holds
+        // (118 VGPRs: 4 blocks per CU), so a third of them started when the first ones left -- and paid the launch's start-up chain (kernel arguments, the previous iteration's totals and
+        // 6x6 solve in every block's prologue, the first loads) a second time: 17.2 -> 14.5 us per level-0 launch with the residual half capped to what is left of one round
+        // (profiles/r05_ai_ab_tracker_blocks.txt: 1514 -> 1561 frames/s).  The halves loop over their pixels anyway (grid-stride); opt_res_blocks > 0 overrides.
+        const int nbi = lds_tiles ? cdiv(lw, LT_W) * cdiv(lh, LT_H) : nb;
+        const int res_round = std::max(128, h->icp_resident_blocks - (icp ? nbi : 0));
+        const int nbr = std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : res_round);
         pa.lds_tiles = lds_tiles ? 1 : 0;
         pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbi : 0; pa.nb_res = rgb ? nbr : 0;
         double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));

@@ -8,6 +8,8 @@ f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python3 tools/pmc_summary.py stats "$f" gpurun_out/${TAG}_kernel_stats.csv
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python3 tools/seg_timeline.py "$t" > gpurun_out/${TAG}_seg_call_timeline.txt 2>&1
+python3 tools/frame_timeline.py "$t" > gpurun_out/${TAG}_frame_timeline.txt 2>&1
+gzip -c "$t" > gpurun_out/${TAG}_kernel_trace.csv.gz
 rm -rf gpurun_out/prof_$TAG
 head -30 gpurun_out/${TAG}_kernel_stats.csv
 cat gpurun_out/${TAG}_seg_call_timeline.txt

@@ -50,7 +50,8 @@ struct DevState {
     int fold_total;              // != 0: this frame's k_splat_resolve accumulated fold_acc itself (= the number of dense-test samples); k_frame_result folds and clears
     int fold_acc[16][4];         // partial sums by blockIdx.x & 15: vote mass, empty lattice pixels, lit dense-test samples, -
     int first_live;              // lowest live slot: the reference's "surfel 0" (drawn as id 0 = "no surfel" in every id-carrying image; ifx_map.hip key_id)
-    unsigned int append_ticket;  // last-block ticket of k_append_scan
+    unsigned int append_ticket;  // (unused since round 5: k_append_scan publishes without a ticket)
+    int app_count0; unsigned int app_seq0, app_vln0;   // count / next_seq / vl_n[0] when the frame's new-surfel flags were taken (k_new_flags_count): k_append_scan's starting point
     unsigned int result_ticket;  // last-block ticket of k_splat_resolve when it also writes the frame result (FrameOut)
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
     int range_exceeded;          // run-time guard of the tracker's exact sums: diagonal totals found beyond half their exact range since the handle was created (ifx_track.hip range_exceeded7; ifx_tracker_range_exceeded)

@@ -2186,6 +2186,7 @@ __device__ __forceinline__ void new_flags_body(DevState* st, const float* __rest
     __syncthreads();
     if (threadIdx.x < 2) block_counts[bid * 2 + threadIdx.x] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
     if (bid == 0 && threadIdx.x < 2 * LIST_SEGS) c.lctr[(LIST_SEGS + threadIdx.x) * LIST_CTR_STRIDE] = 0;   // lists 1, 2: k_clean_list, the launch before this one, was their last reader
+    if (bid == 0 && threadIdx.x == 64) { st->app_count0 = st->count; st->app_seq0 = st->next_seq; st->app_vln0 = st->vl_n[0]; }   // what k_append_scan, the next launch, starts from (nothing in between changes them)
 }
 __global__ void __launch_bounds__(256) k_new_flags_count(DevState* st, const float* __restrict__ pose_inv_ex, Cam c, int time, const uint32_t* __restrict__ assoc,
                                                          const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags,
@@ -2202,11 +2203,14 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
                                                  const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq,
                                                  const int tid, const int bid)
 {
-    __shared__ int s_wave[4][2], s_base[2], s_last;
-    __shared__ unsigned int s_vbase;
+    // No grid-wide hand-off inside this launch (round 5; it had two: one returning atomic per block for the view-list positions and a last-block ticket + recount to publish the
+    // new count -- 3 of its ~8 dependent round trips): the slot count, the creation number and the view list's length the frame started its append with are a SNAPSHOT left by the
+    // flags pass (k_new_flags_count's block 0, the launch before this one), so nothing this launch publishes can be read by a block that starts late; every position follows from
+    // the counts of the blocks before; and the block with the highest index, which knows the frame's total from its own prefix, publishes.
+    __shared__ int s_wave[4][2], s_base[2];
     const int P = c.w * c.h, lane = tid & 63, wid = tid >> 6;
-    const int count0 = st->count;
-    const unsigned int seq0 = st->next_seq;
+    const int count0 = st->app_count0;
+    const unsigned int seq0 = st->app_seq0, vln0 = st->app_vln0;
     const unsigned int rmax0 = st->r_max_bits;   // (here, through the scalar cache: re-read per new surfel behind the stores below it was a vector load of one address, ~2 ns per wave and surfel at one L2 channel)
     // counts of the blocks before this one
     int beforeG = 0, beforeO = 0;
@@ -2240,15 +2244,10 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
     // Only surfels that are actually STORED get a list position: slots ascend with the owned rank, so the ones of this block that fit below
     // `cap` are its first `fit` -- a full map must not leave reserved-but-unwritten entries for the list walkers to dereference.
     const int blk_total = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
-    const int room = cap - (count0 + s_base[1]), fit = room <= 0 ? 0 : (room < blk_total ? room : blk_total);
     const bool to_view = list_v && st->vl_valid;
-    if (tid == 0) {
-        unsigned int vb = (to_view && fit) ? atomicAdd(&st->vl_n[0], (unsigned int)fit) : 0u;
-        if (to_view && fit && vb + (unsigned int)fit > c.seg_cap * LIST_SEGS) { st->vl_valid = 0; vb = c.seg_cap * LIST_SEGS; }   // list full: void it (rebuilt by the next frame's scan)
-        s_vbase = vb;
-    }
-    __syncthreads();
-    unsigned int vpos = s_vbase + (unsigned int)(wave_offO + inclO - mineO);
+    // (stored surfels are the first min(total, cap - count0) in append order: block b's are at view-list positions vln0 + owned-before-b ...)
+    const unsigned int vbase = vln0 + (unsigned int)s_base[1];
+    unsigned int vpos = vbase + (unsigned int)(wave_offO + inclO - mineO);
     bool over = false;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -2271,23 +2270,9 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
         seq[n] = sq;
     }
     if (over) { st->overflow = 1; st->vl_valid = 0; }
-    // every block has read st->count / st->next_seq before it draws its ticket; the last one publishes the new values
-    __syncthreads();
-    if (tid == 0) {
-        unsigned int t = __hip_atomic_fetch_add(&st->append_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned int)(nblocks - 1));
-    }
-    __syncthreads();
-    if (!s_last) return;
-    int totalG = 0, totalO = 0;
-    for (int b = tid; b < nblocks; b += 256) { totalG += block_counts[2 * b]; totalO += block_counts[2 * b + 1]; }
-    totalG = wave_sum_i(totalG);
-    totalO = wave_sum_i(totalO);
-    __syncthreads();
-    if (lane == 0) { s_wave[wid][0] = totalG; s_wave[wid][1] = totalO; }
-    __syncthreads();
-    if (tid == 0) {
-        const int tg = s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0], to = s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+    if (bid != nblocks - 1) return;
+    if (tid == 0) {   // the frame's totals = what lies before this block + this block
+        const int tg = s_base[0] + s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0], to = s_base[1] + blk_total;
         int nc = count0 + to;
         bool ovf = false;
         if (nc > cap) { nc = cap; ovf = true; }
@@ -2301,7 +2286,10 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
         }
         st->next_seq = seq0 + (unsigned int)tg;
         if (ovf) st->overflow = 1;
-        __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (to_view) {   // the view list grew by the surfels that were stored; a list that cannot hold them is void (rebuilt by the next frame's scan)
+            const unsigned int vn = vln0 + (unsigned int)(nc - count0);
+            if (vn > c.seg_cap * LIST_SEGS) st->vl_valid = 0; else st->vl_n[0] = vn;
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,

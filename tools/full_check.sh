@@ -1,0 +1,12 @@
+#!/bin/bash
+# the round's full check on the GPU box: the GPU suite, then the driver-shaped bench line -> gpurun_out/<tag>_gputests.txt, <tag>_bench_driver.json
+TAG=${1:-r05_x}
+cd ${GRAFT_REPO_ROOT:-.}
+python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 > gpurun_out/${TAG}_gputests.txt
+cat gpurun_out/${TAG}_gputests.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/${TAG}_bench_driver.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["ms_per_frame_gpu"], "host", d["value_host_entry"]["value"], d["value_host_entry_async"]["value"], d["value_host_entry_async"]["frames_only"], "fast", d["value_fast_cadence"]["value"], "lc", d["value_close_loops"]["value"], "sharded", d["value_sharded"]["value"], "guard", d["exact_sum_range_exceeded"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("parity_in_bench"))
+PY

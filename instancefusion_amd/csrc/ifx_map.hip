@@ -1645,15 +1645,41 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
     const float reach = __uint_as_float(stc->r_max_bits) * 1.41421356f * 1.001f;
     const unsigned int stride = blockDim.x * rgrid;
     int dead = 0;
+#ifndef WALK_PIPE
+#define WALK_PIPE 1
+#endif
+    // WALK_PIPE: a wave walks several chunks of 64 entries, and the first two dependent round trips of a chunk -- the list entry, then position + times of that slot -- are
+    // issued one and two chunks AHEAD (the entry of chunk k + 2 and the records of chunk k + 1 leave before chunk k is processed), so that only the normal / tap gathers and the
+    // pixel walk of a chunk are exposed.  (One chunk per wave and 4396 blocks was the round-4 form: every chunk then paid its four round trips in a row.)
+    const unsigned int tfirst = rblk * blockDim.x + wid * 64 + lane;
+    auto entry_of = [&](unsigned int t_) -> unsigned int { return t_ < n ? (t_ < na ? seg_a[t_] : seg_i[t_ - na]) : 0u; };
+    unsigned int i_cur = 0, i_nxt = 0;
+    float4 p4_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 tt_cur = make_float2(0.f, 0.f);
+    if (WALK_PIPE) {
+        i_cur = entry_of(tfirst);
+        i_nxt = entry_of(tfirst + stride);
+        if (tfirst < n) { p4_cur = ld_once(&pc[i_cur]); if (tfirst < na || dual) tt_cur = ld_once(&tm[i_cur]); }
+    }
     for (unsigned int t0 = rblk * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
         const unsigned int t = t0 + lane;
         int area = 0;
         RvRec R;
         R.bw = 1;
+        unsigned int i_pre = 0;
+        float4 p4_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 tt_pre = make_float2(0.f, 0.f);
+        if (WALK_PIPE) {   // take this chunk's prefetched values, send the next ones on their way
+            i_pre = i_cur; p4_pre = p4_cur; tt_pre = tt_cur;
+            const unsigned int tn = t + stride;
+            i_cur = i_nxt;
+            if (tn < n) { p4_cur = ld_once(&pc[i_nxt]); if (tn < na || dual) tt_cur = ld_once(&tm[i_nxt]); }
+            i_nxt = entry_of(tn + stride);
+        }
         if (t < n) {
-            const unsigned int i = t < na ? seg_a[t] : seg_i[t - na];
-            float4 p4 = ld_once(&pc[i]);
-            const float2 tt = (t < na || dual) ? ld_once(&tm[i]) : make_float2(0.f, 0.f);   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
+            const unsigned int i = WALK_PIPE ? i_pre : (t < na ? seg_a[t] : seg_i[t - na]);
+            float4 p4 = WALK_PIPE ? p4_pre : ld_once(&pc[i]);
+            const float2 tt = WALK_PIPE ? tt_pre : ((t < na || dual) ? ld_once(&tm[i]) : make_float2(0.f, 0.f));   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
             const float lastT = tt.y;
             asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             float4 n4c = make_float4(0.f, 0.f, 0.f, 0.f);

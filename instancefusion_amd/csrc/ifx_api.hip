@@ -208,6 +208,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
 static void camera_free(ifx* h);
 extern "C" void ifx_destroy(ifx_t* h)
 {
+    if (h && h->hot) { hipFree(h->hot); h->hot = nullptr; }
     if (!h) return;
     if (h->stream_c) hipStreamSynchronize(h->stream_c);
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
@@ -302,6 +303,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "slic_ahead") h->opt_slic_ahead = value;
     else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "clean_raster") h->opt_clean_raster = value;
+    else if (s == "hot_records") { h->opt_hot = value; h->hot_valid = 0; }
     else if (s == "side_late") h->opt_side_late = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
@@ -1392,6 +1394,7 @@ extern "C" int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* l
 // ------------------------------------------------------------------ map access
 extern "C" int ifx_map_view(ifx_t* h, ifx_soa_view* out)
 {
+    if (h) h->hot_valid = 0;   // (the caller holds the arrays' addresses from here on: whatever it writes, the next frame rebuilds the gathered copy)
     if (!h || !out) return IFX_E_INVALID;
     int r = ifx_sync(h);
     DevState hs;
@@ -1461,6 +1464,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     h->housekeeping_due = 0;   // (a decision about the map that is being replaced)
     h->seg_counts_valid = 0;
     h->map_external = 1;
+    h->hot_valid = 0;
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
     const int n_all = n;
     std::vector<uint32_t> keep;

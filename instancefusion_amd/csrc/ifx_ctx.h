@@ -293,6 +293,10 @@ struct ifx {
     int opt_gn_prologue_blocks = 2048;  // gn_prologue only for launches of at most this many blocks (every block repeats the solve)
     int opt_cam_side = 1;               // a run-ahead tracker's frame side on the side stream, its tracker on the third (0: both on the third)
     int opt_cam_swap = 1;               // a camera switch between two existing contexts hands the prediction / fill-in / id blocks over by pointer instead of copying them
+    void* hot = nullptr;                // [cap] 64-byte records (position + confidence | normal + radius | times): what the frame path's gathers read (ifx_map.hip "hot records")
+    int hot_valid = 0;                  // the copy describes the store (its three per-frame writers write both; everything else that writes the store clears this)
+    int opt_hot = 1;                    // option hot_records
+    void* frame_hot = nullptr;          // the copy as this frame's map passes use it (null: the arrays)
     int opt_clean_raster = 1;           // view-list frames: ONE walk of the view list cleans and rasterises (k_raster_view<., true>, with k_new_flags_count's blocks in the same launch):
                                         // two launches and one set of gathers less on every frame's chain (ifx_map.hip, "CLEAN")
     int clean_raster_pending = 0;       // ifx_map_frame left the clean / new-surfel flags / append of this frame to ifx_map_predict's launches

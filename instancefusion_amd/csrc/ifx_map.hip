@@ -91,6 +91,20 @@ __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int se
 // the scalar cache).  As `*c.first_live` at the point of use -- behind stores and atomics -- it compiled to a vector load of one address by every wave: ~2 ns each at the
 // one L2 channel that holds the line, 11 us of a 300 k-thread launch (k_splat_resolve 40 -> 29 us, profiles/r05_*).
 #define FIRST_LIVE(c) ((c).own_n > 0 ? 0 : *(c).first_live)
+
+// ---- "hot" records (round 5, option hot_records): position + confidence, normal + radius and times of a slot in ONE 64-byte record.  The store stays struct-of-arrays (the
+// scans stream 24 B per slot, the C API hands out the arrays), but at random map order every field a list walker or a resolve GATHERS is a 128-byte line fetch of its own:
+// three for the clean + raster walk (322 MB of HBM traffic for 1.1 M entries, profiles/r05_an_pmc_traffic.json), two to four for the resolves and the fusion update.  The
+// frame path's gathers read the copy -- one line per surfel -- and its three writers (fusion update, tombstones of the walk and of the scan's age rule, append) write both;
+// anything else that writes the store (upload, compaction, deformation, the per-pass paths, a sharded map's phases, ifx_map_view handing out pointers) just marks the copy
+// stale on the host (ifx::hot_valid) and the next frame rebuilds it in one streaming launch.
+struct alignas(64) Hot { float4 pc, nr; float2 tm; float2 pad0; float4 pad1; };
+static_assert(sizeof(Hot) == 64, "one record per 64 bytes");
+__global__ void k_hot_rebuild(const DevState* __restrict__ st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Hot* __restrict__ hot)
+{
+    const int n = st->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) { Hot r; r.pc = pc[i]; r.nr = nr[i]; r.tm = tm[i]; r.pad0 = make_float2(0.f, 0.f); r.pad1 = make_float4(0.f, 0.f, 0.f, 0.f); hot[i] = r; }
+}
 __device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i, int fl) { return c.own_n > 0 ? c.seq[i] : ((c.raw_slots || i != (unsigned int)fl) ? i : 0u); }
 __device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id, int fl)
 {
@@ -234,6 +248,7 @@ __global__ void k_init_count(DevState* st, const int* total, int cap)
 
 int ifx_map_init_first(ifx* h)
 {
+    h->hot_valid = 0;
     Cam c = make_cam(h);
     LAUNCH(h, "init_flags", dim3(cdiv(h->P, 256)), dim3(256), k_init_flags, h->dm, h->dmf, c, h->scan_flags);
     ifx_scan_exclusive(h, h->scan_flags, h->P, h->scan_out, &h->d_state->seg_counts[0]);
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
 __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __restrict__ pose_inv_ex, unsigned long long* __restrict__ keys, const float4* __restrict__ pc,
                                 const float4* __restrict__ nr, const float2* __restrict__ col, const float2* __restrict__ tm, int P, uint32_t* __restrict__ index_id,
                                 float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nrm, int time, float conf_thr, float4* __restrict__ tap, Cam c,
-                                const int32_t* __restrict__ own_slot = nullptr)
+                                const int32_t* __restrict__ own_slot = nullptr, const Hot* __restrict__ hot = nullptr)
 {
     const int fl = FIRST_LIVE(c);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,11 +312,11 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
         if (tap) tap[k] = make_float4(0, 0, 0, 0);
         return;
     }
-    float4 p4 = pc[li];
+    float4 p4 = hot ? hot[li].pc : pc[li];
     float2 t2 = make_float2(0.f, 0.f);
-    if (ct || tap) t2 = tm[li];
+    if (ct || tap) t2 = hot ? hot[li].tm : tm[li];
     float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (index_id) n4 = nr[li];   // (with the position and the times: one round trip for the winner's record)
+    if (index_id) n4 = hot ? hot[li].nr : nr[li];   // (with the position and the times: one round trip for the winner's record)
     v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
     if (index_id) {
         v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
@@ -469,7 +484,7 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
                                 int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr,
-                                const int fl = 0, const bool raw_ids = false)   // fl: FIRST_LIVE(c) from the top of the kernel; raw_ids: the walk that drew these keys named every surfel by its slot (option clean_raster): "surfel 0" is named here
+                                const int fl = 0, const bool raw_ids = false, const Hot* __restrict__ hot = nullptr)   // fl: FIRST_LIVE(c) from the top of the kernel; raw_ids: the walk that drew these keys named every surfel by its slot (option clean_raster): "surfel 0" is named here
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= c.w || y >= c.h) return;
@@ -522,8 +537,8 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
         const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
         unsigned int id = (unsigned int)li;
         float z = key_depth(key);
-        float4 p4 = pc[id], n4 = nr[id];
-        float2 c2 = col[id], t2 = tm[id];
+        float4 p4 = hot ? hot[id].pc : pc[id], n4 = hot ? hot[id].nr : nr[id];
+        float2 c2 = col[id], t2 = hot ? hot[id].tm : tm[id];
         v3 nn = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
         float fpx = (float)x + 0.5f, fpy = (float)y + 0.5f;
         vo = make_float4((fpx - c.cx) * z * (1.f / c.fx), (fpy - c.cy) * z * (1.f / c.fy), z, p4.w);
@@ -596,10 +611,10 @@ __global__ void k_splat_resolve(const DevState* __restrict__ st, const float* __
                                 uchar4* __restrict__ pinst, uint16_t* __restrict__ ptime, float4* __restrict__ fv, float4* __restrict__ fn, uchar4* __restrict__ fimg,
                                 unsigned long long* __restrict__ id_keys, unsigned long long* __restrict__ both_keys, int32_t* __restrict__ ids_out,
                                 int* __restrict__ n_valid, FinishFold fold, float* __restrict__ pconf = nullptr, int ids_step = 1, const int32_t* __restrict__ own_slot = nullptr,
-                                FrameOut fo = FrameOut{nullptr, nullptr, 0})
+                                FrameOut fo = FrameOut{nullptr, nullptr, 0}, const Hot* __restrict__ hot = nullptr)
 {
     const int fl = FIRST_LIVE(c);
-    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step, own_slot, fl, c.raw_slots == 2);
+    splat_resolve_body(st, pose_inv_ex, keys, pc, nr, col, tm, c, rgb, depth_filt, pv, pn, pimg, pinst, ptime, fv, fn, fimg, id_keys, both_keys, ids_out, n_valid, fold, pconf, ids_step, own_slot, fl, c.raw_slots == 2, hot);
     if (!fo.out) return;
     // the block that finishes last writes the frame result: every block's fold atomics are performed (vmcnt drained) before its ticket
     __shared__ int s_last;
@@ -1317,7 +1332,7 @@ static VlPlanes make_planes(const Cam& c)
 // the list), and LIST_VI, the stable slots outside it, which only the id render draws (it has no time window).  Unstable slots outside
 // the window are frozen (nothing updates them) and invisible to every render: they are on neither list.
 __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const float4* __restrict__ pc_in, float4* __restrict__ pc_rw, float2* __restrict__ tm, Cam c, VlPlanes P,
-                                                            int time, unsigned int* __restrict__ list, unsigned int* __restrict__ list_i)
+                                                            int time, unsigned int* __restrict__ list, unsigned int* __restrict__ list_i, Hot* __restrict__ hot)
 {
     if (!st->vl_scan) return;
     float Tm[16], T[12];
@@ -1375,6 +1390,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                             q4.w = -1.0f;
                             pc_rw[i] = q4;
                             tm[i] = make_float2(t.x, DEAD_TIME);
+                            if (hot) { hot[i].pc = q4; hot[i].tm = make_float2(t.x, DEAD_TIME); }
                             dead++;
                         }
                     }
@@ -1606,7 +1622,8 @@ struct alignas(16) RvRec { float qx, qy, qz, nx, ny, nz, r2; unsigned int id; in
 // touch nothing the walk touches (5.9 us of their own on the frame's chain before).
 // "Surfel 0": which slot is the first LIVE one is not settled while the walk removes surfels, so it draws slot numbers; k_append_scan's last block advances
 // first_live as ever, and k_splat_resolve turns that slot's id into 0 (ties between keys are decided the same way: the first live slot is the lowest id either way).
-struct CleanArgs { float4* pc_rw; float2* tm_rw; const float4* tap; int nf_blocks; const uint32_t* assoc; const float4* mpc; const float4* mnr; int* flags; int* block_counts; };
+struct Hot;
+struct CleanArgs { float4* pc_rw; float2* tm_rw; const float4* tap; int nf_blocks; const uint32_t* assoc; const float4* mpc; const float4* mnr; int* flags; int* block_counts; Hot* hot; };
 __device__ __forceinline__ void new_flags_body(DevState* st, const float* __restrict__ pose_inv_ex, const Cam& c, int time, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc,
                                                const float4* __restrict__ mnr, const float4* __restrict__ tap, int* __restrict__ flags, int* __restrict__ block_counts, int bid);
 #ifndef WALK_MIN_WAVES
@@ -1656,10 +1673,11 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
     unsigned int i_cur = 0, i_nxt = 0;
     float4 p4_cur = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 tt_cur = make_float2(0.f, 0.f);
+    const Hot* const hot = CLEAN ? ca.hot : (const Hot*)nullptr;   // (option hot_records: position, normal and times of a slot in one line)
     if (WALK_PIPE) {
         i_cur = entry_of(tfirst);
         i_nxt = entry_of(tfirst + stride);
-        if (tfirst < n) { p4_cur = ld_once(&pc[i_cur]); if (tfirst < na || dual) tt_cur = ld_once(&tm[i_cur]); }
+        if (tfirst < n) { p4_cur = hot ? hot[i_cur].pc : ld_once(&pc[i_cur]); if (tfirst < na || dual) tt_cur = hot ? hot[i_cur].tm : ld_once(&tm[i_cur]); }
     }
     for (unsigned int t0 = rblk * blockDim.x + wid * 64; t0 < n; t0 += stride) {   // a wave owns 64 consecutive entries: no block barrier anywhere
         const unsigned int t = t0 + lane;
@@ -1673,13 +1691,16 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
             i_pre = i_cur; p4_pre = p4_cur; tt_pre = tt_cur;
             const unsigned int tn = t + stride;
             i_cur = i_nxt;
-            if (tn < n) { p4_cur = ld_once(&pc[i_nxt]); if (tn < na || dual) tt_cur = ld_once(&tm[i_nxt]); }
+            if (tn < n) {
+                p4_cur = hot ? hot[i_nxt].pc : ld_once(&pc[i_nxt]);
+                tt_cur = (tn < na || dual) ? (hot ? hot[i_nxt].tm : ld_once(&tm[i_nxt])) : make_float2(0.f, 0.f);   // (an entry of the stable list carries no times: 0, never the previous chunk's)
+            }
             i_nxt = entry_of(tn + stride);
         }
         if (t < n) {
             const unsigned int i = WALK_PIPE ? i_pre : (t < na ? seg_a[t] : seg_i[t - na]);
-            float4 p4 = WALK_PIPE ? p4_pre : ld_once(&pc[i]);
-            const float2 tt = WALK_PIPE ? tt_pre : ((t < na || dual) ? ld_once(&tm[i]) : make_float2(0.f, 0.f));   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
+            float4 p4 = WALK_PIPE ? p4_pre : (hot ? hot[i].pc : ld_once(&pc[i]));
+            const float2 tt = WALK_PIPE ? tt_pre : ((t < na || dual) ? (hot ? hot[i].tm : ld_once(&tm[i])) : make_float2(0.f, 0.f));   // (with the position: one round trip for both; the id render has no time window: no load for the stable list)
             const float lastT = tt.y;
             asm volatile("" ::"v"(lastT), "v"(p4.x), "v"(p4.y), "v"(p4.z), "v"(p4.w));
             float4 n4c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1697,7 +1718,7 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
                     }
                     int test = 1;
                     if (cand) {
-                        n4c = ld_once(&nr[i]);
+                        n4c = hot ? hot[i].nr : ld_once(&nr[i]);
                         have_n = true;
                         float lt2 = tt.y;
                         test = clean_test(T, c, time, p4, n4c, tt.x, lt2, ca.tap);
@@ -1709,6 +1730,7 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
                         p4.w = -1.0f;   // (a tombstone's confidence: the raster below leaves it out, as it would after k_clean_view)
                         ca.pc_rw[i] = p4;
                         ca.tm_rw[i] = make_float2(tt.x, DEAD_TIME);
+                        if (ca.hot) { ca.hot[i].pc = p4; ca.hot[i].tm = make_float2(tt.x, DEAD_TIME); }
                         dead++;
                     }
                 }
@@ -1737,7 +1759,7 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
             }
             if (flags) {
                 SurfGeo G;
-                surfel_geo(T, p4, (CLEAN && have_n) ? n4c : ld_once(&nr[i]), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
+                surfel_geo(T, p4, (CLEAN && have_n) ? n4c : (hot ? hot[i].nr : ld_once(&nr[i])), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
                 bool do_i = dual ? (G.do_s && (flags & LIST_IDS)) : surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
                 const bool do_s = dual ? (G.do_s && (flags & LIST_SPLAT)) : G.do_s;
@@ -1895,7 +1917,7 @@ static void raster_pass(ifx* h, const float* d_pose_inv, int time, int maxTime, 
             LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
                    (const float4*)h->nr, (const float2*)h->col, (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal,
                    (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time, (float4*)h->fill_vertex, (float4*)h->fill_normal, (uchar4*)h->fill_image, h->key_ids,
-                   h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step, (const int32_t*)nullptr, fo);
+                   h->key_both, (want & LIST_IDS) ? ids_out : (int32_t*)nullptr, (int*)nullptr, ff, (float*)nullptr, resolve_ids_step, (const int32_t*)nullptr, fo, (const Hot*)h->frame_hot);
             if (ff.acc) return;
         } else
         LAUNCH(h, "splat_resolve", dim3(cdiv(h->w, 32), cdiv(h->h, 8)), dim3(32, 8), k_splat_resolve, h->d_state, d_pose_inv, h->key_splat, (const float4*)h->pc,
@@ -1931,7 +1953,7 @@ int ifx_ids_ensure(ifx* h)
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
         LAUNCH(h, "raster_view_ids", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{}, (const DevState*)h->d_state);
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);
         LAUNCH(h, "ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_ids_resolve, h->key_ids, h->P, h->ids_after);
     } else
         ids_pass(h, nullptr, 0, h->ids_after);   // (all slots, per-pass cull: unstable surfels -- the only ones the view list's age rule concerns -- are never drawn here)
@@ -2075,7 +2097,7 @@ __global__ void k_assoc_decode(const DevState* __restrict__ st, const unsigned l
 // update.vert:55-141 in place, by the owning pixel only
 __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restrict__ assoc, const float4* __restrict__ mpc, const float4* __restrict__ mnr,
                               const float* __restrict__ mcol, Cam c, int time, uint32_t* __restrict__ upd_owner, float4* __restrict__ pc, float4* __restrict__ nr,
-                              float2* __restrict__ col, float2* __restrict__ tm, const int32_t* __restrict__ assoc_slot = nullptr)
+                              float2* __restrict__ col, float2* __restrict__ tm, const int32_t* __restrict__ assoc_slot = nullptr, Hot* __restrict__ hot = nullptr)
 {
     const int fl = FIRST_LIVE(c);
     const int par = time % 2, i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + par, j = 2 * (blockIdx.y * blockDim.y + threadIdx.y) + par;   // the pixels that can hold an association
@@ -2088,8 +2110,8 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     const uint32_t id = (uint32_t)li;
     if (upd_owner[id] != (uint32_t)(i * c.h + j)) return;
     upd_owner[id] = 0xFFFFFFFFu;
-    float4 p = pc[id], n = nr[id], mp = mpc[k], mn = mnr[k];
-    const float2 cl0 = col[id], t0_ = tm[id];   // issued with the other loads (they used to follow them: two more dependent round trips).  Fetching all of it
+    float4 p = hot ? hot[id].pc : pc[id], n = hot ? hot[id].nr : nr[id], mp = mpc[k], mn = mnr[k];
+    const float2 cl0 = col[id], t0_ = hot ? hot[id].tm : tm[id];   // issued with the other loads (they used to follow them: two more dependent round trips).  Fetching all of it
     const float mc = mcol[k];                   // together with the ownership word was tried too: 13.9 -> 15.6 us (the losers' 80 bytes cost more than the round trip)
     float c_k = p.w, a = mp.w;
     if (mn.w < (1.0f + 0.5f) * n.w) {
@@ -2107,6 +2129,7 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
         float t3 = ((c_k * n.w) + (a * mn.w)) / (c_k + a);
         v3 nn = normalized(v3m(t0, t1, t2));
         nr[id] = make_float4(nn.x, nn.y, nn.z, t3);
+        if (hot) hot[id].nr = make_float4(nn.x, nn.y, nn.z, t3);
         if (t3 > 0.f && t3 < 1e30f && __float_as_uint(t3) > st->r_max_bits) atomicMax(&st->r_max_bits, __float_as_uint(t3));
         pc[id] = p;
     } else {
@@ -2116,6 +2139,7 @@ __global__ void k_fuse_update(DevState* __restrict__ st, const uint32_t* __restr
     float2 t = t0_;
     t.y = (float)time;
     tm[id] = t;
+    if (hot) { hot[id].pc = p; hot[id].tm = t; }
 }
 
 // ------------------------------------------------------------------ clean (a13)
@@ -2227,7 +2251,7 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
                                                  const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
                                                  float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
                                                  const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq,
-                                                 const int tid, const int bid)
+                                                 const int tid, const int bid, Hot* __restrict__ hot)
 {
     // No grid-wide hand-off inside this launch (round 5; it had two: one returning atomic per block for the view-list positions and a last-block ticket + recount to publish the
     // new count -- 3 of its ~8 dependent round trips): the slot count, the creation number and the view list's length the frame started its append with are a SNAPSHOT left by the
@@ -2285,11 +2309,13 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
         const unsigned int vp = vpos++;
         if (n >= cap) { over = true; continue; }
         if (to_view && vp < c.seg_cap * LIST_SEGS) list_v[vp] = (unsigned int)n;
-        pc[n] = mpc[k];
-        nr[n] = mnr[k];
-        { const float rad = mnr[k].w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > rmax0) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
+        const float4 m4 = mpc[k], n4 = mnr[k];
+        pc[n] = m4;
+        nr[n] = n4;
+        { const float rad = n4.w; if (rad > 0.f && rad < 1e30f && __float_as_uint(rad) > rmax0) atomicMax(&st->r_max_bits, __float_as_uint(rad)); }
         col[n] = make_float2(mcol[k], 0.f);
         tm[n] = make_float2((float)time, (float)time);
+        if (hot) { Hot r; r.pc = m4; r.nr = n4; r.tm = make_float2((float)time, (float)time); r.pad0 = make_float2(0.f, 0.f); r.pad1 = make_float4(0.f, 0.f, 0.f, 0.f); hot[n] = r; }
         ic[n] = make_float4((float)i + 0.5f, (float)j + 0.5f, (float)tick, inst_gt ? (float)inst_gt[j * c.w + i] : -2.f);   // data.vert:215-228: ground-truth instance id of the creating pixel
         for (int q = 0; q < 12; q++) VOTE4(votes, n, q) = make_float4(0.f, 0.f, 0.f, 0.f);
         labels[n] = -1;   // no label until the next label scan (the slot may hold one from before a compaction)
@@ -2321,9 +2347,10 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
 __global__ void __launch_bounds__(256) k_append_scan(DevState* st, Cam c, int time, int tick, const int* __restrict__ flags, const int* __restrict__ block_counts, int nblocks,
                                                      const float4* __restrict__ mpc, const float4* __restrict__ mnr, const float* __restrict__ mcol, int cap, float4* __restrict__ pc,
                                                      float4* __restrict__ nr, float2* __restrict__ col, float2* __restrict__ tm, float4* __restrict__ ic, float4* __restrict__ votes,
-                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq)
+                                                     const uint8_t* __restrict__ inst_gt, unsigned int* __restrict__ list_v, int32_t* __restrict__ labels, uint32_t* __restrict__ seq,
+                                                     Hot* __restrict__ hot = nullptr)
 {
-    append_scan_body(st, c, time, tick, flags, block_counts, nblocks, mpc, mnr, mcol, cap, pc, nr, col, tm, ic, votes, inst_gt, list_v, labels, seq, (int)threadIdx.x, (int)blockIdx.x);
+    append_scan_body(st, c, time, tick, flags, block_counts, nblocks, mpc, mnr, mcol, cap, pc, nr, col, tm, ic, votes, inst_gt, list_v, labels, seq, (int)threadIdx.x, (int)blockIdx.x, hot);
 }
 
 // ------------------------------------------------------------------ tombstone compaction
@@ -2356,6 +2383,7 @@ static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out);
 int ifx_compact_enqueue(ifx* h, int refresh_ids)
 {
     h->ids_view_ok = 0;
+    h->hot_valid = 0;
     ifx_vlist_reap(h);   // slots the view list left out may have outlived the age rule: tombstone them before the live ranks are taken
     // alive flags over the host-known upper bound of slots; scan; scatter into the second buffer set; swap
     int n = h->cap;
@@ -2373,8 +2401,9 @@ int ifx_compact_enqueue(ifx* h, int refresh_ids)
 // ------------------------------------------------------------------ per-frame orchestration of the map stages
 // part 0: the whole pass; spatially sharded map: 1 = the association among the candidates this rank owns (leaves h->assoc_key for the exchange),
 // 2 = the exchanged verdicts decoded + the update of the owned surfels
-static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time, int part = 0, const int32_t* own_slot = nullptr)
+static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time, int part = 0, const int32_t* own_slot = nullptr, Hot* hot = nullptr)
 {
+    if (!hot) h->hot_valid = 0;   // (the update below writes the arrays only)
     Cam c = make_cam(h);
     dim3 b(32, 8), g(cdiv(cdiv(h->w, 2), 32), cdiv(cdiv(h->h, 2), 8));   // one thread per 2x2 pixel block
     if (part != 2)
@@ -2385,7 +2414,7 @@ static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time, in
     if (part == 2) LAUNCH(h, "assoc_decode", g, b, k_assoc_decode, h->d_state, (const unsigned long long*)h->assoc_key, h->index_id, c, time, h->assoc_target, h->upd_owner,
                           slots ? own_slot : (const int32_t*)nullptr, slots ? h->own_slot_img + 3 * (size_t)h->P : (int32_t*)nullptr);
     LAUNCH(h, "fuse_update", g, b, k_fuse_update, h->d_state, h->assoc_target, (const float4*)h->meas_pc, (const float4*)h->meas_nr, h->meas_col, c, time, h->upd_owner,
-           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, slots ? (const int32_t*)(h->own_slot_img + 3 * (size_t)h->P) : (const int32_t*)nullptr);
+           (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, slots ? (const int32_t*)(h->own_slot_img + 3 * (size_t)h->P) : (const int32_t*)nullptr, hot);
 }
 
 // ------------------------------------------------------------------ loop-closure hooks on the map
@@ -2535,6 +2564,7 @@ __global__ void k_adopt_est_pose(DevState* st)
 
 static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 {
+    h->hot_valid = 0;
     h->last_clean_time = time;
     Cam c = make_cam(h);
     if (part == 0) { c.srank = 0; c.sn = 1; }   // a whole pass (stage API, re-render after a compaction) is never sliced
@@ -2578,7 +2608,8 @@ static void view_scan(ifx* h, int time)
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
     // raw output in the clean pass's lists 1, 2 (free at this point of a frame and between frames), then concatenated into list_v / list_vi
-    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c);
+    LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c,
+           h->hot_valid ? (Hot*)h->hot : (Hot*)nullptr);   // (the age rule's tombstones go into the gathered copy too while it is valid)
     LAUNCH(h, "vlist_offsets", dim3(1), dim3(64), k_vlist_offsets, h->d_state, c, (const float2*)h->tm);
     LAUNCH(h, "vlist_concat", dim3(256, 2), dim3(MAP_THREADS), k_vlist_concat, (const DevState*)h->d_state, c, h->list_b, h->list_c, h->list_v, h->list_vi);
 }
@@ -2600,15 +2631,18 @@ static void index_list_pass(ifx* h, int time, bool taps)
     LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
     if (!taps)
         LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr, c);
+               (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr, c,
+               (const int32_t*)nullptr, (const Hot*)h->frame_hot);
     else
         LAUNCH(h, "index_resolve_taps", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap, c);
+               (const float2*)h->col, (const float2*)h->tm, h->P, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, time, h->cfg.confidence, (float4*)h->index_tap, c,
+               (const int32_t*)nullptr, (const Hot*)h->frame_hot);
 }
 
 // the clean pass and the append of a view-list frame as launches of their own (k_clean_view ; k_new_flags_count ; k_append_scan)
 static void view_clean_append(ifx* h, const Cam& c, int time)
 {
+    h->hot_valid = 0;
     LAUNCH(h, "clean_view", dim3(h->opt_clean_blocks > 0 ? h->opt_clean_blocks : 2 * LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
            (const float4*)h->index_tap, h->list_v);
     const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
@@ -2629,16 +2663,28 @@ int ifx_map_frame(ifx* h)
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
         const int time = h->tick;
-        if (h->view_scan_tick != time) view_scan(h, time);   // rebuilds the list when vlist_decide asked for it, returns at once otherwise (the loop-closure renders may have taken it already)
-        index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
-        fuse_pass(h, nullptr, 0.f, time);
-        index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
         // Option clean_raster (default): the clean, the new surfels' flags and the append are left to the end-of-frame prediction (ifx_map_predict): ONE walk of the
         // view list cleans and rasterises (+ the flags), then the append, then the resolve.  Only when that prediction will take the view-list raster, and while no new
         // surfel can be drawn in the frame that creates it: its confidence starts at most at max(1, weight multiplier) (confidence_fn, k_track_end), the renders draw
         // from the threshold on (splat.vert:56-65, surfel_ids.vert:45).
         const bool fused = h->opt_clean_raster && !h->opt_compact_every_frame && h->last_compact_tick != h->tick && h->opt_raster_tiles <= 0 && !h->opt_raster_lds &&
                            h->cfg.confidence > fmaxf(1.f, h->frame_weight_mult);
+        // the gathered copy of the store ("hot records") serves the frames that take the fused path: rebuilt here when something outside the frame path wrote the store since
+        Hot* hot = nullptr;
+        if (fused && h->opt_hot) {
+            if (!h->hot && hipMalloc(&h->hot, (size_t)h->cap * sizeof(Hot)) != hipSuccess) { h->hot = nullptr; (void)hipGetLastError(); }
+            if (h->hot && !h->hot_valid) {
+                LAUNCH(h, "hot_rebuild", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_hot_rebuild, (const DevState*)h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, (Hot*)h->hot);
+                h->hot_valid = 1;
+            }
+            hot = (Hot*)h->hot;
+        }
+        if (!hot) h->hot_valid = 0;
+        h->frame_hot = hot;
+        if (h->view_scan_tick != time) view_scan(h, time);   // rebuilds the list when vlist_decide asked for it, returns at once otherwise (the loop-closure renders may have taken it already)
+        index_list_pass(h, time, false);        // predictIndices of the pre-fuse map (:620)
+        fuse_pass(h, nullptr, 0.f, time, 0, nullptr, hot);
+        index_list_pass(h, time, true);         // predictIndices of the post-fuse map (:662), resolved into the clean pass's tap records
         h->clean_raster_pending = fused ? 1 : 0;
         if (!fused) view_clean_append(h, c, time);
         h->view_frame = 1; h->view_dirty = 1; h->last_clean_time = time;
@@ -2646,6 +2692,7 @@ int ifx_map_frame(ifx* h)
         h->ids_pending = 1;
         return IFX_OK;
     }
+    h->frame_hot = nullptr;
     if (h->opt_vlist && !h->own && h->shard_n <= 1) hs_invalidate_view(h);   // this frame runs no scan: a device-side "valid" must never describe a list the host did not build
     index_pass(h, nullptr, h->tick, true);
     fuse_pass(h, nullptr, 0.f, h->tick);
@@ -2674,7 +2721,7 @@ int ifx_map_predict_loop_closure(ifx* h)
         view_scan(h, h->tick);
         h->view_scan_tick = h->tick;
         LAUNCH(h, "raster_view_lc", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
-               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{}, (const DevState*)h->d_state);
+               (const float2*)h->tm, c, h->tick, h->tick, LIST_SPLAT | LIST_DUAL, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, 1, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);
     } else {
     LAUNCH(h, "cull_raster", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_raster, h->d_state, (const float*)nullptr, (const float4*)h->pc, (const float2*)h->tm, c, h->tick, h->tick,
            LIST_SPLAT | LIST_DUAL, h->list_a, (unsigned int*)nullptr, 0);
@@ -2715,20 +2762,20 @@ int ifx_map_predict(ifx* h)
             const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
             CleanArgs ca;
             ca.pc_rw = (float4*)h->pc; ca.tm_rw = (float2*)h->tm; ca.tap = (const float4*)h->index_tap; ca.nf_blocks = nb_new; ca.assoc = h->assoc_target; ca.mpc = (const float4*)h->meas_pc;
-            ca.mnr = (const float4*)h->meas_nr; ca.flags = h->scan_flags; ca.block_counts = h->scan_block;
+            ca.mnr = (const float4*)h->meas_nr; ca.flags = h->scan_flags; ca.block_counts = h->scan_block; ca.hot = (Hot*)h->frame_hot;
             LAUNCH(h, "clean_raster_view", dim3(nb_new + (h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS)), dim3(MAP_THREADS), (k_raster_view<false, true>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
                    (const float2*)h->tm, c, h->tick, h->tick, want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, ca, (const DevState*)h->d_state);
             LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, h->tick, h->tick, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
                    (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
-                   h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels, h->seq);
+                   h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels, h->seq, (Hot*)h->frame_hot);
             raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step, true);
         } else {
         if (h->opt_raster_lds)
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<true, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{}, (const DevState*)h->d_state);
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);
         else
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, c, h->tick, h->tick,
-                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{}, (const DevState*)h->d_state);
+                   want, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, h->opt_raster_earlyz, ids_step, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);
         raster_pass(h, nullptr, h->tick, h->tick, want, h->ids_after, true, 2, 0, h->opt_fold_finish != 0, ids_step);   // resolve + the end-of-pass sums in the same launch
         }
     } else {
@@ -2760,6 +2807,7 @@ int ifx_map_predict(ifx* h)
 //   phase 3: splat / id resolve, finish
 int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame)
 {
+    h->hot_valid = 0;
     if (first_frame) {   // no map yet: the first-frame initialisation is replicated; only the prediction raster is sliced
         if (phase == 0) return ifx_map_init_first(h);
         if (phase == 2) raster_pass(h, nullptr, h->tick, h->tick, LIST_SPLAT, h->ids_after, true, 1);   // as ifx_map_predict on the first frame: no id render yet
@@ -2862,6 +2910,7 @@ __global__ void k_merge_both(unsigned long long* __restrict__ ks, unsigned long 
 // outside a frame (ifx_owner_predict_phase): phases 4..6 without the clean / append and without the whetherDoSegmentation sums.
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
 {
+    h->hot_valid = 0;
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
     const int time = h->tick;
@@ -2964,7 +3013,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             cl.srank = 0; cl.sn = 1;
             if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
-                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{}, (const DevState*)h->d_state);   // (the whole id image: it travels with the splat keys)
+                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);   // (the whole id image: it travels with the splat keys)
             h->own_fast_raster = h->own_fast;
         } else
             raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);

@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_vlist_concat(const DevState* __
 
 // index-map projection (index_map.vert:40-66) of the view-list entries: the work of k_index_project on the slots that can be seen at all
 __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, Cam c, int time,
-                                                            const unsigned int* __restrict__ list, unsigned long long* __restrict__ keys)
+                                                            const unsigned int* __restrict__ list, unsigned long long* __restrict__ keys, const Hot* __restrict__ hot = nullptr)
 {
     const int fl = FIRST_LIVE(c);
     float T[12];
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
         float lastT[U];
         float4 p4[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { lastT[u] = ld_once(&tm[i[u]]).y; p4[u] = ld_once(&pc[i[u]]); }
+        for (int u = 0; u < U; u++) { lastT[u] = hot ? hot[i[u]].tm.y : ld_once(&tm[i[u]]).y; p4[u] = hot ? hot[i[u]].pc : ld_once(&pc[i[u]]); }   // (hot records: both from one line)
 #pragma unroll
         for (int u = 0; u < U; u++) asm volatile("" ::"v"(lastT[u]), "v"(p4[u].x), "v"(p4[u].y), "v"(p4[u].z));   // (keeps the compiler from sinking a load behind the previous entry's branches)
 #pragma unroll
@@ -2628,7 +2628,7 @@ static void index_list_pass(ifx* h, int time, bool taps)
 {
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
-    LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index);
+    LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, c, time, h->list_v, h->key_index, (const Hot*)h->frame_hot);
     if (!taps)
         LAUNCH(h, "index_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_index_resolve, h->d_state, (const float*)nullptr, h->key_index, (const float4*)h->pc, (const float4*)h->nr,
                (const float2*)h->col, (const float2*)h->tm, h->P, h->index_id, (float4*)h->index_vc, (float4*)nullptr, (float4*)h->index_nr, time, h->cfg.confidence, (float4*)nullptr, c,

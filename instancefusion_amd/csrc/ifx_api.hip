@@ -1460,7 +1460,10 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
 {
     if (!h || n < 0 || !pc || !nr || !col || !tm) return IFX_E_INVALID;
     ifx_drop_tracked(h);
-    for (CamCtx& c_ : h->cams) c_.ahead_valid = 0;
+    for (CamCtx& c_ : h->cams) {   // a run ahead that is dropped may still be reading the camera's parked buffers: whatever reuses them queues behind it
+        if (c_.ahead_valid && c_.ev_ahead) hipStreamWaitEvent(h->stream, c_.ev_ahead, 0);
+        c_.ahead_valid = 0;
+    }
     h->housekeeping_due = 0;   // (a decision about the map that is being replaced)
     h->seg_counts_valid = 0;
     h->map_external = 1;
@@ -1517,7 +1520,10 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 {
     if (!h || !pose16) return IFX_E_INVALID;
     ifx_drop_tracked(h);
-    for (CamCtx& c_ : h->cams) c_.ahead_valid = 0;
+    for (CamCtx& c_ : h->cams) {   // a run ahead that is dropped may still be reading the camera's parked buffers: whatever reuses them queues behind it
+        if (c_.ahead_valid && c_.ev_ahead) hipStreamWaitEvent(h->stream, c_.ev_ahead, 0);
+        c_.ahead_valid = 0;
+    }
     DevState hs;
     int r = read_state(h, &hs);
     if (r) return r;

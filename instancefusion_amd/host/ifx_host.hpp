@@ -138,8 +138,11 @@ struct Sharding {
     // the id: drawn by rank 0 (or a world of one), read from idFile by the others (waits up to timeoutSeconds for it)
     // idFile must be a path of THIS run (a file a previous run left behind would hand the other ranks a dead id, and ncclCommInitRank would wait for ever): the file is
     // 128 id bytes + an 8-byte nonce; `nonce` is a number the launcher gives every rank of one run (ifx_replay --shard-nonce; 0: none).  Rank 0 removes a stale file before
-    // anything else; the other ranks accept a file only if its nonce is theirs and -- without a nonce -- only if it was written after they started.
+    // anything else; the other ranks accept a file only if its nonce is theirs.  Without a nonce a file that APPEARS (or changes) while a rank waits is this run's; one that was
+    // already there at the rank's first look may be a previous run's (rank 0 has not removed it yet) or this run's (this rank started late): it is taken when it is still there,
+    // unchanged, after `staleGraceSeconds` -- no comparison of clocks (a rank that started more than 2 s after rank 0 wrote the file used to wait 120 s and give up).
     uint64_t nonce = 0;
+    int staleGraceSeconds = 3;
     std::vector<uint8_t> uniqueId(int timeoutSeconds = 120) const
     {
         std::vector<uint8_t> id(128, 0);
@@ -157,15 +160,21 @@ struct Sharding {
             return id;
         }
         if (idFile.empty()) throw std::runtime_error("Sharding: idFile is needed to receive the ncclUniqueId of rank 0");
-        const std::time_t started = std::time(nullptr);
+        std::vector<uint8_t> first_seen;   // the file's 136 bytes at this rank's first look (empty: there was none)
+        bool looked = false;
         for (int waited = 0; waited < timeoutSeconds * 20; waited++) {
             std::ifstream f(idFile, std::ios::binary);
             uint64_t got = 0;
-            if (f && f.read((char*)id.data(), 128) && f.gcount() == 128 && f.read((char*)&got, 8) && f.gcount() == 8 && got == nonce) {
-                struct stat sb;
-                // without a nonce the only defence is the clock: a file older than this process (2 s of slack for coarse time stamps) is a previous run's
-                if (nonce != 0 || (::stat(idFile.c_str(), &sb) == 0 && sb.st_mtime + 2 >= started)) return id;
+            const bool whole = f && f.read((char*)id.data(), 128) && f.gcount() == 128 && f.read((char*)&got, 8) && f.gcount() == 8;
+            if (whole && got == nonce) {
+                if (nonce != 0) return id;
+                std::vector<uint8_t> now(id);
+                now.insert(now.end(), (const uint8_t*)&got, (const uint8_t*)&got + 8);
+                if (!looked) first_seen = now;                                         // it was there before this rank looked: this run's, or a previous run's
+                else if (now != first_seen) return id;                                  // appeared or changed while waiting: rank 0 of THIS run wrote it
+                if (waited >= staleGraceSeconds * 20) return id;                       // still there, unchanged: rank 0 would have removed a stale one long ago
             }
+            looked = true;
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }
         throw std::runtime_error("Sharding: no ncclUniqueId of this run in " + idFile + " after waiting (stale file? give every rank the same --shard-nonce)");

@@ -233,16 +233,24 @@ def test_quaternion_equals_python(checker, tmp_path):
 
 
 def test_sharding_unique_id_refuses_a_stale_file(checker, tmp_path):
-    """Sharding::uniqueId on a rank other than 0: a file a previous run left behind -- older than the process, or carrying another run's nonce -- is never taken for
-    this run's ncclUniqueId (ncclCommInitRank would hang on it); a file of this run is."""
+    """Sharding::uniqueId on a rank other than 0: a file carrying another run's nonce is never taken for this run's ncclUniqueId (ncclCommInitRank would hang on it); a file
+    of this run is.  Without a nonce no clock is compared (a rank that started 2 s after rank 0 wrote the file used to refuse it): a file that appears or
+    changes while the rank waits is taken at once, one that was already there only when it is still there, unchanged, after the grace period (3 s) in which rank 0 of a new
+    run would have removed it."""
     import struct
     import time
 
     f = str(tmp_path / "id.bin")
     open(f, "wb").write(bytes([7] * 128) + struct.pack("<Q", 0))
-    os.utime(f, (time.time() - 600, time.time() - 600))                       # ten minutes old, no nonce: a previous run's
+    os.utime(f, (time.time() - 600, time.time() - 600))                       # already there, no nonce: not taken inside the grace period, whatever its age
     r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
     assert r.stdout.startswith("refused"), r.stdout
+    t0 = time.time()
+    p = subprocess.Popen([checker, "shardid", f, "0", "6"], stdout=subprocess.PIPE, text=True)   # ... while rank 0 of this run replaces it: taken at once
+    time.sleep(0.6)
+    open(f + ".tmp", "wb").write(bytes([6] * 128) + struct.pack("<Q", 0)); os.replace(f + ".tmp", f)
+    out, _ = p.communicate(timeout=30)
+    assert out.strip() == "id 6" and time.time() - t0 < 2.5, (out, time.time() - t0)
     open(f, "wb").write(bytes([7] * 128) + struct.pack("<Q", 41))             # fresh, but another run's nonce
     r = subprocess.run([checker, "shardid", f, "42", "1"], capture_output=True, text=True, check=True)
     assert r.stdout.startswith("refused"), r.stdout
@@ -250,8 +258,8 @@ def test_sharding_unique_id_refuses_a_stale_file(checker, tmp_path):
     os.utime(f, (time.time() - 600, time.time() - 600))                       # this run's nonce: the clock does not matter
     r = subprocess.run([checker, "shardid", f, "42", "1"], capture_output=True, text=True, check=True)
     assert r.stdout.strip() == "id 9", r.stdout
-    open(f, "wb").write(bytes([5] * 128) + struct.pack("<Q", 0))              # fresh, no nonce in use
-    r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
+    open(f, "wb").write(bytes([5] * 128) + struct.pack("<Q", 0))              # no nonce in use, the file is there before the rank looks (a rank that starts late): taken after the grace period
+    r = subprocess.run([checker, "shardid", f, "0", "6"], capture_output=True, text=True, check=True)
     assert r.stdout.strip() == "id 5", r.stdout
     open(f, "wb").write(bytes([5] * 100))                                     # truncated
     r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)

@@ -1310,13 +1310,38 @@ __global__ void k_seg_register(SegCtl* __restrict__ s, uint8_t* __restrict__ una
 // updateSurfelMapInstance (IF/Core/InstanceFusionCuda.cu:1100-1150) for every mask with the instance the device chose for it; masks without one (or behind the
 // point where the host takes over) are passed over.  All masks in one launch: the update is a saturating add of a positive increment, so the masks' updates of a surfel commute (any order ends at
 // min(65535, count + sum of increments)) and a pixel can serve every mask it lies in at once
+// ONE launch per mask, in mask order (m_only >= 0), as the reference runs updateSurfelMapInstanceKernel once per mask (IF/Core/InstanceFusion.cpp:986-1000): the packed counters are lossy
+// while a word's low half is negative (a surfel of the FIRST frame starts with -1 in every word, init_unstable.vert): each read-modify-write of the high half then loses 1 to
+// the borrow of the low one, until a vote for the low half's instance makes it non-negative.  How many votes a surfel keeps therefore depends on WHICH MASK comes first --
+// within a mask every update goes to the same half with the same weight and commutes, across masks it does not.  All masks in one launch (round 4: 18 us against ~3 us per
+// mask here) let the arrival order of the atomics decide: 3 of 373 297 surfels differed from the oracle on a young 640x480 map (tests/test_gpu_sweep.py, round 5).
 __global__ void k_vote_update_all(const DevState* __restrict__ st, const int32_t* __restrict__ ids, const uint8_t* __restrict__ masks, int P, int cap, const SegCtl* __restrict__ s, int nm,
-                                  float* __restrict__ votes, IdMap im)
+                                  float* __restrict__ votes, IdMap im, int m_only)
 {
     if (s->ff_incomplete) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
     const int last = s->evict_at >= 0 ? min(nm, s->evict_at) : nm;
+    if (m_only >= 0) {
+        if (m_only >= last || !(masks[(size_t)m_only * P + k] > 0)) return;
+        const int instanceID = s->target[m_only];
+        if (instanceID < 0) return;
+        const int id = idmap_slot(im, st->count, ids[k]);
+        if (id < 0) return;
+        const int fi = instanceID / 2, p = instanceID % 2, inc = m_only + 1;
+        unsigned int* addr = (unsigned int*)&VOTEF(votes, id, fi);
+        unsigned int old = *addr, assumed;
+        do {
+            assumed = old;
+            int a, b;
+            vote_decode(__uint_as_float(assumed), a, b);
+            if (p == 0) a += inc; else b += inc;
+            if (a >= 65535) a = 65535;
+            if (b >= 65535) b = 65535;
+            old = atomicCAS(addr, assumed, __float_as_uint(vote_encode(a, b)));
+        } while (old != assumed);
+        return;
+    }
     unsigned int in = 0;   // (nm <= 256: eight words would cover it; the masks of a call are few -- handled 32 at a time)
     int id = -2;
     for (int m0 = 0; m0 < last; m0 += 32) {
@@ -1418,7 +1443,8 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);
     const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
     LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, gate, (const int*)fa.meta, fa.skip);
-    LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
+    for (int m_ = 0; m_ < nm; m_++)   // (mask order is part of the result: see k_vote_update_all)
+            LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h), m_);
     // the scan kernels look at the control block themselves: when the call has to be finished by the host (fill incomplete / table full) they return at once and
     // the ONE scan of the call runs behind the host-driven tail, after every mask and the eviction -- colours are assigned once, so an early scan would be visible
     const int full_scan = seg_label_scan(h, (const int*)dc, default_early);
@@ -1434,7 +1460,8 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
         r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
         if (r) return r;
         LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, (const int*)nullptr, (const int*)nullptr, (const uint8_t*)nullptr);
-        LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h));
+        for (int m_ = 0; m_ < nm; m_++)   // (mask order is part of the result: see k_vote_update_all)
+            LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h), m_);
         const int full2 = seg_label_scan(h, (const int*)dc);   // (gated again: the table may turn out full at some mask)
         HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));
         HIPCHK(h, hipMemcpyAsync(h_un, h->d_unavail, nm, hipMemcpyDeviceToHost, h->cur));

@@ -10,7 +10,8 @@ table, every label and the whole map.  Each case also runs the HIP sequence TWIC
 determinism: the exact sums do not depend on the order in which blocks and atomics arrive), and reads the run-time guard of that exactness
 (ifx_tracker_range_exceeded): 0, except where a case is built to drive it.
 
-Further down: the instance table overflowing (> 96 instances over time) on the RESIDENT-frame path of bench.py, and the guard driven on purpose."""
+Further down: bench.py's resident-frame path at 640x480 on four other scenes / motions, the instance table overflowing (> 96 instances over time) on that path, and the
+guard driven on purpose."""
 import numpy as np
 import pytest
 
@@ -113,6 +114,54 @@ def test_seed_sweep_against_the_oracle(ifx, orc, seed, motion, deg):
     assert g.tracker_range_exceeded() == 0 and gc.tracker_range_exceeded() == 0, (g.tracker_range_exceeded(), motion, deg)
     for x in (g, g2, gc, o):
         x.close()
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("seed,motion", [(301, "nominal"), (302, "fast"), (303, "jump"), (304, "shake")])
+def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion):
+    """bench.py's own frame path -- frames resident in HBM, the next frame announced, its tracker parked behind every frame, default options (lazy compaction, cached view
+    lists, fused clean + raster walk, hot records, the id image on the lattice) -- at the benchmark's resolution on OTHER scenes and camera motions than the one every other
+    640x480 test uses: 24 frames and a segmentation call on the resident frame; every pose, the instance table, and at the end count, labels and the whole map against the
+    oracle.  (`fast` rebuilds the view lists every frame, `jump` leaves the correspondence gates once.)"""
+    import torch
+
+    from instancefusion_amd import synth
+
+    Wb, Hb, NFb = 640, 480, 24
+    Kb = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    scene = synth.Scene(seed)
+    st = synth.make_stream_from_poses(synth.trajectory_profile(motion, NFb, seed), scene, Wb, Hb, noise_seed=seed + 1, **Kb)
+    orc.set_threads(orc.usable_cores())
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    g = ifx.ElasticFusion(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
+    o = orc.Oracle(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
+    inst = ifx.InstanceFusion(g)
+    for i in range(NFb):
+        if i + 1 < NFb:
+            g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+        g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        inst.whetherDoSegmentation(100 + i)
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        pg = g.trajectory(1)[0]
+        if np.isfinite(po).all():
+            assert_pose_equal(pg, po, f"{motion} frame {i}")
+        else:
+            assert pose_eq(pg, po), i
+        if i == NFb - 1:   # (the labels are the last call's: compared right behind it)
+            masks, cls = synth.canned_masks(st["obj"][i], scene)
+            if masks.shape[0]:   # (the fast camera has left the objects behind by then: no detections, no call)
+                inst.ProcessSegmentation(None, None, masks, cls, i, superpixels=False)
+                o.process_segmentation(st["rgb"][i], st["depth"][i], masks, cls, i, flags=0)
+                assert np.array_equal(inst.getInstanceTable(), o.instance_table()), i
+                assert np.array_equal(inst.labels(), o.labels())
+    assert g.count == o.count
+    mg, mo = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg[k], mo[k], equal_nan=True), k
+    assert g.tracker_range_exceeded() == 0
+    g.close(); o.close()
 
 
 @pytest.mark.timeout(900)

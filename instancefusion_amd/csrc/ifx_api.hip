@@ -143,6 +143,7 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     ALLOC(h->seq, C * 4); ALLOC(h->seq2, C * 4);
+    if (h->own) { ALLOC(h->d_gfl, 8); hipMemset(h->d_gfl, 0xFF, 8); }
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
     ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (std::max(SN, (size_t)1 << 24) / 1024 + 8) * 4);   // also serves the 256^3-cell scan of the kNN grid
@@ -216,6 +217,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_comm_free(h);
     camera_free(h);
     if (h->own_slot_img) hipFree(h->own_slot_img);
+    if (h->d_gfl) hipFree(h->d_gfl);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
@@ -305,6 +307,8 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "clean_raster") h->opt_clean_raster = value;
     else if (s == "hot_records") { h->opt_hot = value; h->hot_valid = 0; }
     else if (s == "side_late") h->opt_side_late = value;
+    else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
+    else if (s == "own_first_live") h->opt_own_first_live = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
     else if (s == "host_entry_async") h->opt_host_entry_async = value;
@@ -649,6 +653,17 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
 
 // ---- camera contexts: K streams into one map (BASELINE configuration 5).  The single-GPU semantics of a FRAME SET -- one frame per camera -- is: the K frames
 // processed one after the other, in camera order, on the one map; every camera tracks against the prediction rendered at the end of ITS last frame.
+// A run ahead parks, and the frame that takes it commits, the pose block AND the tracker's diagnostics (lastICPError ... rgb_sigma: what FrameResult.diag and
+// ifx_tracker_diag report) -- one launch for the two ranges, words of 4 bytes
+#define IFX_DIAG_OFF offsetof(DevState, lastICPError)
+#define IFX_DIAG_BYTES (offsetof(DevState, seg_counts) - offsetof(DevState, lastICPError))
+#define IFX_AHEAD_BYTES (IFX_CAM_STATE_BYTES + IFX_DIAG_BYTES)
+static_assert(IFX_DIAG_OFF % 4 == 0 && IFX_DIAG_BYTES % 4 == 0 && IFX_CAM_STATE_BYTES % 4 == 0, "word copies");
+__global__ void k_ahead_block(uint32_t* __restrict__ dst_pose, uint32_t* __restrict__ dst_diag, const uint32_t* __restrict__ src_pose, const uint32_t* __restrict__ src_diag)
+{
+    for (int i = threadIdx.x; i < (int)(IFX_CAM_STATE_BYTES / 4); i += blockDim.x) dst_pose[i] = src_pose[i];
+    for (int i = threadIdx.x; i < (int)(IFX_DIAG_BYTES / 4); i += blockDim.x) dst_diag[i] = src_diag[i];
+}
 static_assert(offsetof(DevState, count) == IFX_CAM_STATE_BYTES, "the pose block of DevState (pose, pose_inv, last_pose, weighting, dense_enough) is what a camera context parks");
 static void camera_free(ifx* h)
 {
@@ -785,7 +800,7 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     if (h->lc_enable || !h->stream_c) { h->err = "ifx_owner_track_ahead: not available with the loop-closure detection on / on a one-stream handle"; return IFX_E_STATE; }
     CamCtx& cc = h->cams[(size_t)cam];
     cc.ahead_valid = 0;
-    if (!cc.ahead_pose) HIPCHK(h, hipMalloc(&cc.ahead_pose, IFX_CAM_STATE_BYTES));
+    if (!cc.ahead_pose) HIPCHK(h, hipMalloc(&cc.ahead_pose, IFX_AHEAD_BYTES));
     if (!cc.ev_ahead) HIPCHK(h, hipEventCreateWithFlags(&cc.ev_ahead, hipEventDisableTiming));
     if (!h->ev_cam_parked) {   // (first use: the instance's buffers and events)
         hipEventCreateWithFlags(&h->ev_cam_ahead, hipEventDisableTiming);
@@ -806,7 +821,8 @@ extern "C" int ifx_owner_track_ahead(ifx_t* h, int cam, int tracking_rank, const
     // the run's pose block into the camera's own parking place: the tracker instance is free for the next camera's run (they queue on the third stream).  The event
     // is the camera's own: the frame that takes this run must not wait for runs enqueued after it (one shared event, re-recorded behind every run, made every frame
     // wait for the run enqueued just before it: no overlap at all)
-    if (!r) hipMemcpyAsync(cc.ahead_pose, (const void*)h->d_cam_trk, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream_c);
+    if (!r) LAUNCH(h, "ahead_block", dim3(1), dim3(256), k_ahead_block, (uint32_t*)cc.ahead_pose, (uint32_t*)((char*)cc.ahead_pose + IFX_CAM_STATE_BYTES),
+                   (const uint32_t*)h->d_cam_trk, (const uint32_t*)((const char*)h->d_cam_trk + IFX_DIAG_OFF));
     hipEventRecord(cc.ev_ahead, h->stream_c);
     hipEventRecord(h->ev_cam_ahead, h->stream_c);
     h->cur = h->stream;
@@ -1017,7 +1033,9 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         } else if (!first && tracks) {   // replicated (every rank holds the exchanged prediction), or on the one tracking rank
             StageTimer t(h, 0);
             if (ahead) {
-                HIPCHK(h, hipMemcpyAsync((void*)h->d_state, (const void*)h->cams[(size_t)h->cur_cam].ahead_pose, IFX_CAM_STATE_BYTES, hipMemcpyDeviceToDevice, h->stream));
+                const char* ap = (const char*)h->cams[(size_t)h->cur_cam].ahead_pose;   // pose block + the run's diagnostics (the frame result reports THIS camera's tracker)
+                LAUNCH(h, "ahead_block", dim3(1), dim3(256), k_ahead_block, (uint32_t*)h->d_state, (uint32_t*)((char*)h->d_state + IFX_DIAG_OFF), (const uint32_t*)ap,
+                       (const uint32_t*)(ap + IFX_CAM_STATE_BYTES));
                 h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
                 h->cam_ahead_used++;
             } else if (tracked) ifx_tracker_commit(h);
@@ -1090,11 +1108,11 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     int n = 0;
     auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
     switch (phase) {
-    case 0: if (!first) add(h->key_index, P * 8, 0); break;
+    case 0: if (!first) { add(h->key_index, P * 8, 0); add(h->d_gfl, 8, 0); } break;                  // + the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE)
     case 1: if (!first) add(h->assoc_key, (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2) * 8, 0); break;   // the best owned candidate of every measurement pixel (distance | window position)
     case 2: if (!first) add(h->key_index, P * 8, 0); break;
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
-    case 4: add(h->key_splat, P * 16, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
+    case 4: add(h->key_splat, P * 16, 0); add(h->d_gfl, 8, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
     case 5:   // [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
         if (h->own_track_rank >= 0 && h->own_tracked_tick == h->tick && h->own_g > 1) {
             // K streams, camera k tracked by rank k only: the prediction rendered at the end of camera k's frame has ONE consumer, rank k's tracker -- a reduction to that

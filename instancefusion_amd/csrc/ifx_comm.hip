@@ -39,6 +39,8 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     std::string err;
 };
 Rccl g_rccl;
@@ -54,6 +56,7 @@ bool rccl_load(std::string& err)
 #define SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name); if (!g_rccl.field) { g_rccl.err = std::string("RCCL symbol missing: ") + name; err = g_rccl.err; dlclose(lib); return false; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
     SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Reduce, "ncclReduce") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
     g_rccl.lib = lib;
     return true;
@@ -143,6 +146,27 @@ extern "C" int ifx_owner_set_comm(ifx_t* h, void* nccl_comm)
     return IFX_OK;
 }
 
+// one buffer of an exchange point
+static int comm_one(ifx* h, Comm* c, void* ptr, int64_t nbytes, int32_t opc)
+{
+    // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX,
+    // 4 | root << 8 broadcast, 5 | root << 8 int32 SUM to the root only
+    if ((opc & 0xFF) == 4) {   // broadcast from rank ops >> 8 (the pose block of a frame tracked by one rank)
+        NCCLCHK(h, g_rccl.Broadcast(ptr, ptr, (size_t)nbytes, ncclInt8, opc >> 8, c->comm, h->stream));
+        c->bytes += nbytes;
+        return IFX_OK;
+    }
+    if ((opc & 0xFF) == 5) {   // int32 SUM reduced to rank ops >> 8 only (the prediction of a camera that one rank tracks)
+        NCCLCHK(h, g_rccl.Reduce(ptr, ptr, (size_t)nbytes / 4, ncclInt32, ncclSum, opc >> 8, c->comm, h->stream));
+        c->bytes += nbytes;
+        return IFX_OK;
+    }
+    const bool u64 = opc == 0;
+    const ncclRedOp_t op = opc == 0 ? ncclMin : (opc == 1 ? ncclSum : (opc == 2 ? ncclMin : ncclMax));
+    NCCLCHK(h, g_rccl.AllReduce(ptr, ptr, (size_t)nbytes / (u64 ? 8 : 4), u64 ? ncclUint64 : ncclInt32, op, c->comm, h->stream));
+    c->bytes += nbytes;
+    return IFX_OK;
+}
 // the exchange after phase `phase` (or 200: the pending exchange point of a segmentation call), enqueued on the handle's main stream
 int ifx_comm_exchange(ifx* h, int phase)
 {
@@ -151,25 +175,15 @@ int ifx_comm_exchange(ifx* h, int phase)
     void* ptrs[8]; int64_t bytes[8]; int32_t ops[8];
     const int n = ifx_owner_exchange(h, phase, ptrs, bytes, ops, 8);
     if (n < 0) return n;
-    for (int k = 0; k < n && k < 8; k++) {
-        // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX,
-        // 4 | root << 8 broadcast, 5 | root << 8 int32 SUM to the root only
-        if ((ops[k] & 0xFF) == 4) {   // broadcast from rank ops >> 8 (the pose block of a frame tracked by one rank)
-            NCCLCHK(h, g_rccl.Broadcast(ptrs[k], ptrs[k], (size_t)bytes[k], ncclInt8, ops[k] >> 8, c->comm, h->stream));
-            c->n_coll++; c->bytes += bytes[k];
-            continue;
-        }
-        if ((ops[k] & 0xFF) == 5) {   // int32 SUM reduced to rank ops >> 8 only (the prediction of a camera that one rank tracks)
-            NCCLCHK(h, g_rccl.Reduce(ptrs[k], ptrs[k], (size_t)bytes[k] / 4, ncclInt32, ncclSum, ops[k] >> 8, c->comm, h->stream));
-            c->n_coll++; c->bytes += bytes[k];
-            continue;
-        }
-        const bool u64 = ops[k] == 0;
-        const ncclRedOp_t op = ops[k] == 0 ? ncclMin : (ops[k] == 1 ? ncclSum : (ops[k] == 2 ? ncclMin : ncclMax));
-        NCCLCHK(h, g_rccl.AllReduce(ptrs[k], ptrs[k], (size_t)bytes[k] / (u64 ? 8 : 4), u64 ? ncclUint64 : ncclInt32, op, c->comm, h->stream));
-        c->n_coll++; c->bytes += bytes[k];
-    }
-    return IFX_OK;
+    // the buffers of one exchange point travel as ONE group (the keys and the 8-byte "surfel 0" word of exchanges 0 / 4; the prediction block and its tail of
+    // exchange 5; the two statistics of a segmentation call): aggregated by RCCL into one launch
+    const bool group = n > 1;
+    if (group) NCCLCHK(h, g_rccl.GroupStart());
+    int rc = IFX_OK;
+    for (int k = 0; k < n && k < 8 && rc == IFX_OK; k++) rc = comm_one(h, c, ptrs[k], bytes[k], ops[k]);
+    if (group) NCCLCHK(h, g_rccl.GroupEnd());
+    if (n > 0) c->n_coll++;   // (one exchange point = one group = one RCCL launch)
+    return rc;
 }
 int ifx_comm_ready(ifx* h) { Comm* c = comm_of(h); return c && c->comm; }
 

@@ -277,6 +277,7 @@ struct ifx {
     hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr, ev_cam_side = nullptr;
     hipStream_t cam_side_stream = nullptr;   // set around ifx_tracker_camera_ahead: the stream its frame side goes to (null: the same stream as its tracker)
     int cam_ahead_used = 0;             // frames whose tracker was taken from a run ahead (diagnostics / tests)
+    unsigned long long* d_gfl = nullptr; // sharded map: lowest live creation number -- this rank's before exchanges 0 / 4, every rank's behind them (ifx_map.hip FIRST_LIVE: the reference's "surfel 0")
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
     int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it
@@ -308,6 +309,8 @@ struct ifx {
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
+    int opt_own_first_live = 1;         // sharded map: the reference's "surfel 0" is the lowest live creation number of any rank (ifx_map.hip FIRST_LIVE); 0: round 4's rule -- creation number 0 for ever (test switch)
+    int opt_vote_per_mask = 1;          // instance votes: one launch per mask, in mask order, as the reference (IF/Core/InstanceFusion.cpp:986-1000) -- the order is part of the result while a packed counter's low half is negative (ifx_instance.hip k_vote_update_all); 0: round 4's one launch over all masks (experiments only)
     int opt_side_late = 0;              // a frame whose tracker ran ahead enqueues the announced next frame's side behind its own map passes instead of in front of them (measured: 1490 against 1510 frames/s -- the frame side then runs beside the next tracker instead of beside this frame's map passes; off)
     int opt_pace = 1;                   // ifx_enqueue_frame_device waits for the previous frame's result before it enqueues (bounded run-ahead)
     int opt_ff_union = 1;               // flood fill of the masks: two-way edges merged by union-find before the directed relaxation (k_ff_merge)

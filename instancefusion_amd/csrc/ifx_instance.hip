@@ -1443,7 +1443,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
     const FFArgs fa = ff_args(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm);
     const int* gate = fa.changed + (std::min(rounds, FF_SLOTS) - 1);
     LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, gate, (const int*)fa.meta, fa.skip);
-    for (int m_ = 0; m_ < nm; m_++)   // (mask order is part of the result: see k_vote_update_all)
+    for (int m_ = h->opt_vote_per_mask ? 0 : -1; m_ < (h->opt_vote_per_mask ? nm : 0); m_++)   // (mask order is part of the result: see k_vote_update_all)
             LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h), m_);
     // the scan kernels look at the control block themselves: when the call has to be finished by the host (fill incomplete / table full) they return at once and
     // the ONE scan of the call runs behind the host-driven tail, after every mask and the eviction -- colours are assigned once, so an early scan would be visible
@@ -1460,7 +1460,7 @@ static int process_segmentation_device(ifx_t* h, const uint8_t* rgb, const uint1
         r = mask_geometric_filter_device(h, h->d_pdm, h->d_masks, h->d_masks_ori, nm, h->d_unavail, 0, true);
         if (r) return r;
         LAUNCH(h, "seg_register", dim3(1), dim3(64), k_seg_register, dc, h->d_unavail, (const int*)nullptr, (const int*)nullptr, (const uint8_t*)nullptr);
-        for (int m_ = 0; m_ < nm; m_++)   // (mask order is part of the result: see k_vote_update_all)
+        for (int m_ = h->opt_vote_per_mask ? 0 : -1; m_ < (h->opt_vote_per_mask ? nm : 0); m_++)   // (mask order is part of the result: see k_vote_update_all)
             LAUNCH(h, "vote_update", dim3(cdiv(P, 256)), dim3(256), k_vote_update_all, h->d_state, h->ids_after, (const uint8_t*)h->d_masks, P, h->cap, (const SegCtl*)dc, nm, h->votes, ifx_idmap(h), m_);
         const int full2 = seg_label_scan(h, (const int*)dc);   // (gated again: the table may turn out full at some mask)
         HIPCHK(h, hipMemcpyAsync(hc, dc, sizeof(SegCtl), hipMemcpyDeviceToHost, h->cur));

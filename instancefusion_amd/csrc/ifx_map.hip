@@ -90,7 +90,18 @@ __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int se
 // fl = DevState::first_live, read ONCE at the top of every kernel that names surfels (FIRST_LIVE(c): before the kernel's first store, where a uniform load goes through
 // the scalar cache).  As `*c.first_live` at the point of use -- behind stores and atomics -- it compiled to a vector load of one address by every wave: ~2 ns each at the
 // one L2 channel that holds the line, 11 us of a 300 k-thread launch (k_splat_resolve 40 -> 29 us, profiles/r05_*).
-#define FIRST_LIVE(c) ((c).own_n > 0 ? 0 : *(c).first_live)
+// Spatially sharded map: ids are creation numbers, and the reference's "surfel 0" is the live surfel with the LOWEST creation number on any rank.  Every rank publishes
+// the lowest live creation number of its shard (k_own_first_live, behind the two places a frame removes surfels: the view-list scan of phase 0, the clean of phase 4), the
+// word is MIN-reduced with the key images of exchanges 0 and 4 (ifx_owner_exchange), and Cam::first_live points at it there: fl is then a creation number, and the
+// resolves turn that id into 0 where they write id images (k_index_resolve, splat_resolve_body) -- attributes and occlusion are untouched, as on one GPU.
+#define FIRST_LIVE(c) (*(c).first_live)
+__global__ void k_own_first_live(const DevState* __restrict__ st, const float2* __restrict__ tm, const uint32_t* __restrict__ seq, unsigned long long* __restrict__ out)
+{
+    int f = st->first_live;
+    const int n = st->count;
+    while (f < n && !(tm[f].y > DEAD_TIME)) f++;
+    *out = f < n ? (unsigned long long)seq[f] : ~0ull;   // (no live surfel here: the identity of the MIN; as an int -1, which no creation number reaches -- k_append_scan stops at 0xFFF00000)
+}
 
 // ---- "hot" records (round 5, option hot_records): position + confidence, normal + radius and times of a slot in ONE 64-byte record.  The store stays struct-of-arrays (the
 // scans stream 24 B per slot, the C API hands out the arrays), but at random map order every field a list walker or a resolve GATHERS is a 128-byte line fetch of its own:
@@ -141,7 +152,7 @@ static Cam make_cam(ifx* h)
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
     c.seq = h->seq; c.own_n = h->own ? h->own_g : 0; c.own_rank = h->own ? h->cfg.rank : 0;
-    c.first_live = &h->d_state->first_live; c.raw_slots = 0;
+    c.first_live = (h->own && h->d_gfl) ? (const int*)h->d_gfl : &h->d_state->first_live; c.raw_slots = 0;   // (sharded map: the low word of the reduced lowest live creation number)
     return c;
 }
 
@@ -307,6 +318,7 @@ __global__ void k_index_resolve(const DevState* __restrict__ st, const float* __
     const float* T = pose_inv_ex ? pose_inv_ex : st->pose_inv;
     unsigned int id = (unsigned int)(key & 0xFFFFFFFFull);
     const int li = own_slot ? own_slot_of(c, own_slot[k], id) : local_slot(c, st->count, id, fl);
+    if (c.own_n > 0 && id == (unsigned int)fl) id = 0;   // sharded map: the reference's "surfel 0" (FIRST_LIVE) -- found by its creation number, named 0
     if (li < 0) {   // sharded map: another rank's surfel won this pixel -- that rank writes its attributes, this one zeros (the images are summed bitwise across ranks)
         if (index_id) { index_id[k] = id; vc[k] = make_float4(0, 0, 0, 0); nrm[k] = make_float4(0, 0, 0, 0); if (ct) ct[k] = make_float4(0, 0, 0, 0); }
         if (tap) tap[k] = make_float4(0, 0, 0, 0);
@@ -515,7 +527,7 @@ __device__ __forceinline__ void splat_resolve_body(const DevState* __restrict__ 
         ik = ik < bk ? ik : bk;
         key = key < bk ? key : bk;
         fold_id = (ik == IFX_KEY_EMPTY) ? 0 : (int32_t)(ik & 0xFFFFFFFFull);
-        if (raw_ids && fold_id == fl) fold_id = 0;   // (clean_raster: the walk drew slot numbers; the append behind it settled which slot is the reference's "surfel 0")
+        if ((raw_ids || c.own_n > 0) && fold_id == fl) fold_id = 0;   // (clean_raster: the walk drew slot numbers; the append behind it settled which slot is the reference's "surfel 0")
         ids_out[k] = fold_id;
     }
     float4 vo = make_float4(0, 0, 0, 0), no = make_float4(0, 0, 0, 0);
@@ -2908,6 +2920,7 @@ __global__ void k_merge_both(unsigned long long* __restrict__ ks, unsigned long 
 // phase p of a frame of the sharded map; the buffers ifx_owner_exchange(p) lists are reduced across the ranks before phase p + 1 -- by the library itself
 // on its communicator (ifx_comm.hip: ifx_owner_process_frame_device), or by the caller (the emulation tests).  phase 104..106: ElasticFusion::predict
 // outside a frame (ifx_owner_predict_phase): phases 4..6 without the clean / append and without the whetherDoSegmentation sums.
+#define OWN_FIRST_LIVE(h) do { if ((h)->d_gfl && (h)->opt_own_first_live) LAUNCH((h), "own_first_live", dim3(1), dim3(1), k_own_first_live, (const DevState*)(h)->d_state, (const float2*)(h)->tm, (const uint32_t*)(h)->seq, (h)->d_gfl); } while (0)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
 {
     h->hot_valid = 0;
@@ -2976,6 +2989,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             if (h->opt_vlist) hs_invalidate_view(h);   // no scan this frame: a device-side "valid" must never describe lists the host did not maintain
             index_pass(h, nullptr, time, true, 1);
         }
+        OWN_FIRST_LIVE(h);   // (behind the view-list scan, whose age rule removes surfels)
         break;
     case 1: index_pass(h, nullptr, time, true, 2, h->own_fast ? h->own_slot_img : nullptr); fuse_pass(h, nullptr, 0.f, time, 1); break;   // attributes of the winners this rank owns, association among them | assoc_key: MIN
     case 2:                                                                                                 // verdicts decoded, update (owned), post-fuse projection | keys: MIN
@@ -3022,11 +3036,13 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         if (h->own_fast_raster) {   // [key_splat | key_ids] are one allocation, and so are their slot images: one launch translates both
             LAUNCH(h, "own_translate", dim3(cdiv(2 * h->P, 256)), dim3(256), k_own_translate, h->key_splat, 2 * h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P);
         }
+        OWN_FIRST_LIVE(h);   // (behind the clean and the append)
         break;
     }
     case 104:                                                                                               // ifx_owner_predict_phase: the local raster alone
         raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
+        OWN_FIRST_LIVE(h);   // (an upload / a deformation may have come in between)
         break;
     case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,

@@ -743,12 +743,16 @@ def test_lost_tracker_experiments_are_bit_identical(ifx):
     _tracker_variants_equal(ifx, [dict(), dict(model_fused=1), dict(icp_px=3)])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_owner_sharded_map_emulated(ifx, small_stream, world):
+@pytest.mark.parametrize("world,zero_dies", [(2, 0), (3, 0), (2, 1), (3, 1), (2, -1)])
+def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images
     MIN-reduced, winners' attributes SUM-merged between the eight phases of a frame) against one GPU: G handles in one process, the
     all-reduces done by hand.  Poses, prediction / index / id images and -- merged by creation number -- the whole map, bit for bit,
-    over first-frame initialisation, an uploaded map, appended surfels, deletions and independent local compactions."""
+    over first-frame initialisation, an uploaded map, appended surfels, deletions and independent local compactions.
+    zero_dies: the reference's "surfel 0" (id 0 = "no surfel": it occludes, but is never associated or voted for) is removed in the middle and the next live
+    surfel takes its place (from then on IT is never associated: the measurement at its pixel makes a new surfel instead) -- on one GPU the lowest live slot
+    (DevState::first_live), on the sharded map the lowest live creation number of ANY rank (MIN-reduced with the keys of exchanges 0 and 4).
+    zero_dies = -1: the same with the rule switched off on the ranks (option own_first_live = 0, round 4's behaviour) -- the maps must then DIFFER: the scenario tests the rule."""
     import torch
 
     from instancefusion_amd import dist as ifd
@@ -762,11 +766,24 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world):
     efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
     for e in efs:
         e.set_option("compact_divisor", 16 if e.cfgd["rank"] else 64)     # the ranks compact at different times: ids are creation numbers, nothing to agree on
+        if zero_dies < 0:
+            e.set_option("own_first_live", 0)
     poses = []
     for i in range(NF):
         if i == 4:   # an uploaded map in the middle: every rank is handed all rows and keeps its own
             m = one.download()
+            conf0 = m["pc"][:, 3].copy()
             m["pc"][::2, 3] = 15.0
+            if zero_dies:   # row 0 is marked for removal (copy_unstable.vert: colorTime.w == -1): this frame's clean removes it; and row 1 -- "surfel 0" from then on -- is
+                # swapped for a surfel in the middle of the image that every frame so far updated: one that WOULD be associated again (the oracle says: at tick 8)
+                q = (np.linalg.inv(poses[-1].astype(np.float64)) @ np.concatenate([m["pc"][:, :3], np.ones((len(m["pc"]), 1), np.float32)], 1).T).T
+                u, v = SMALL["fx"] * q[:, 0] / q[:, 2] + SMALL["cx"], SMALL["fy"] * q[:, 1] / q[:, 2] + SMALL["cy"]
+                ok = (m["tm"][:, 1] == m["tm"][:, 1].max()) & (q[:, 2] > 0) & (np.abs(u - SMALL["cx"]) < 40) & (np.abs(v - SMALL["cy"]) < 30)
+                kz = int(np.argmax(np.where(ok, conf0, -1.0)))   # (the most often updated of them: about a quarter of the surfels in view are updated by any one frame)
+                assert ok[kz] and kz > 1
+                for k_ in MAP_KEYS:
+                    m[k_][[1, kz]] = m[k_][[kz, 1]]
+                m["tm"][0, 1] = -1.0
             one.upload(m); one.set_pose(poses[-1], one.tick); one.combined_predict(poses[-1], one.tick, one.tick)
             for e in efs:
                 e.upload(m)
@@ -777,6 +794,8 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world):
         one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
         sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
         poses.append(one.getCurrPose())
+        if zero_dies < 0:
+            continue
         for e in efs:
             assert np.array_equal(e.getCurrPose(), poses[-1]), (i, e.cfgd["rank"])
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
@@ -789,7 +808,18 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world):
     seq = np.concatenate([p[0] for p in parts])
     order = np.argsort(seq, kind="stable")
     assert len(np.unique(seq)) == len(seq)
+    if zero_dies < 0:   # without the rule the successor goes on being associated on the ranks: another map
+        merged_tm = np.concatenate([p[1]["tm"] for p in parts])[order]
+        assert merged_tm.shape != ref["tm"].shape or not np.array_equal(merged_tm, ref["tm"])
+        for e in efs:
+            e.close()
+        one.close()
+        return
     assert sum(len(p[0]) for p in parts) == ref["pc"].shape[0]
+    if zero_dies:
+        assert seq.min() > 0
+        # the successor was last updated by the frame of the upload at the latest (never associated again), while surfels right behind it went on being updated
+        assert ref["tm"][0, 1] <= 5, ref["tm"][0]
     for k in MAP_KEYS:
         merged = np.concatenate([p[1][k] for p in parts])[order]
         assert np.array_equal(merged, ref[k]), k
@@ -1104,7 +1134,7 @@ def test_config5_three_streams_runs_ahead_per_camera(ifx, swap, side):
         ef.set_option("cam_side", side)
         osh = sharded.OwnerShardedElasticFusion(ef, None)
         ef.camera_count(K)
-        poses, preds = [], []
+        poses, preds, diags = [], [], []
         for s_ in range(NS):
             for c in range(K):
                 i = first[c] + s_
@@ -1119,14 +1149,17 @@ def test_config5_three_streams_runs_ahead_per_camera(ifx, swap, side):
                         ef.owner_track_ahead(cp, 0, d_rgb[j].data_ptr(), d_dep[j].data_ptr())
                 osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
                 poses.append(ef.getCurrPose())
+                if s_ > 0:
+                    diags.append(ef.tracker_diag())   # (a frame served by a run ahead reports that run's residuals, not the previous camera's)
                 if s_ in (1, NS - 1):
                     preds.append((ef.image("pred_vertex"), ef.image("pred_image"), ef.image("fill_vertex"), ef.image("ids_after")))
         served = ef.owner_track_ahead(-1, 0)
         order = np.argsort(ef.seq(), kind="stable")
         m = ef.download()
-        outs.append((np.stack(poses), preds, {k: m[k][order] for k in MAP_KEYS}, served))
+        outs.append((np.stack(poses), preds, {k: m[k][order] for k in MAP_KEYS}, served, np.stack(diags)))
         ef.close()
     a, b = outs
+    assert np.array_equal(a[4], b[4]) and len(np.unique(a[4][:, 0])) > K
     assert a[3] == 0 and b[3] == K * (NS - 1)   # every frame from the second set on took its pose from a run ahead (first set: the map's first frame / the cameras' extrinsic poses)
     assert np.array_equal(a[0], b[0])
     for pa, pb in zip(a[1], b[1]):
@@ -2045,7 +2078,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()
-                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail
+                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16 + 16, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word with the keys of exchanges 0 and 4
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

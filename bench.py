@@ -503,6 +503,26 @@ def main():
         extras["value_host_entry_async"] = dict(value=round(ne / t_ha, 2), unit="frames/s", frames=ne, segmentation_calls=calls_ha, frames_only=round(ne / t_hf, 2),
                                                 what="ifx_process_frame with option host_entry_async (returns with the pose; map passes finish under the caller's next steps): `value` with "
                                                      "whetherDoSegmentation asked after every frame, `frames_only` without")
+        # the reference-shaped entry with the NEXT frame announced from host memory before every call (ifx_hint_next_frame: what a log reader or a camera queue knows):
+        # the announced frame's transfer and image-only work run on the side stream under the current frame and its tracker is parked behind it -- the resident path's
+        # look-ahead plus 1.54 MB of host copy + H2D per frame; whetherDoSegmentation after every frame, calls on the resident frame
+        def host_step_hinted(kk):
+            i, n_ = kk % L, (kk + 1) % L
+            ef.hint_next_frame(st["rgb"][n_], st["depth"][n_])
+            ef.processFrame(st["rgb"][i], st["depth"][i])
+            instance_step(i)
+
+        for _ in range(5):
+            host_step_hinted(k); k += 1
+        place_call_in_window(ne)
+        seg["calls"] = 0
+        ef.lookahead_stats(reset=True)
+        t_hh = timed(k, ne, host_step_hinted); k += ne
+        la = ef.lookahead_stats()
+        step(k, hint=False); k += 1                           # (consumes the last announcement's slot as an ordinary frame: the legs below start clean)
+        ef.sync()
+        extras["value_host_entry_hinted"] = dict(value=round(ne / t_hh, 2), unit="frames/s", frames=ne, segmentation_calls=seg["calls"], lookahead=la,
+                                                 what="ifx_hint_next_frame(next frame, host pointers) + ifx_process_frame(current frame, host pointers) + whetherDoSegmentation, every frame")
         # the reference's own configuration: closeLoops = true (IF/map_interface/ElasticFusionInterface.cpp:43): predict() at the tracked pose,
         # INACTIVE prediction, model-to-model tracker and the gates on every frame; resident frames + look-ahead as in `value`
         ef.set_loop_closure(True, 35000, 5e-5, 1e-5)

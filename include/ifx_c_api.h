@@ -99,6 +99,13 @@ int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_
  * call places the announced frame's image-only work itself (behind the coarse pyramid levels of its own
  * tracker, where the GPU is least busy).  Preferred over ifx_prefetch_frame_device. */
 int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next);
+/* The same announcement with HOST pointers, for the reference-shaped entry: call it BEFORE ifx_process_frame of the current
+ * frame, with the frame the reference's log reader would return next (IF/utilities/RawLogReader.cpp:66-115,
+ * IF/main.cpp:108-307).  The buffers are borrowed for this call only (the frame is copied into pinned staging here); its
+ * transfer and image-only work run on the side stream under the current frame, its tracker is parked behind the current
+ * frame, and the next ifx_process_frame -- which must pass the SAME pointers; anything else and the announcement is simply
+ * ignored -- finds all of that done.  Results are identical with or without it.  Single-stream, unsharded handles. */
+int ifx_hint_next_frame(ifx_t* h, const uint8_t* rgb_next, const uint16_t* depth_next);
 /* ---- sharded projection for large maps.  Every rank (one process per GPU) holds the full map replica and is
  * fed the same frames and masks; the passes that stream the whole surfel store with one atomic per visible surfel (index map
  * x2, splat + id raster) only handle this rank's slice of the slots, and the ranks combine their key images between the four
@@ -462,6 +469,9 @@ int ifx_stage_ms(ifx_t* h, float* ms4, int reset);
  * ms: device time of the runs on the side stream (NOT part of ifx_stage_ms's "instance", which is the main-stream span of the calls); runs / used: how many were
  * enqueued and how many a call consumed (a hint that does not come true leaves its run unused).  Option "slic_ahead" 0 turns the look-ahead off. */
 int ifx_superpixel_ahead_stats(ifx_t* h, float* ms, int32_t* runs, int32_t* used, int reset);
+/* The one-frame look-ahead in numbers (diagnostics, tests; no counterpart in the reference): out3 = frames of this handle (unsharded entries) that found their frame
+ * side already computed (ifx_prefetch_ / ifx_hint_next_frame*), frames whose tracker had run ahead, frames that came through ifx_hint_next_frame (host pointers). */
+int ifx_lookahead_stats(ifx_t* h, int32_t* out3, int reset);
 /* Average duration (ms) of the named kernel over its launches since the last reset, measured with
  * HIP events around each launch (enabled by ifx_set_option("kernel_timing",1)). */
 int ifx_kernel_ms(ifx_t* h, const char* kernel, float* avg_ms, int* launches);

@@ -97,6 +97,8 @@ _SIGS = {
     "ifx_map_seq": (C.c_int, [_P, _P, C.c_int]),
     "ifx_prefetch_frame_device": (C.c_int, [_P, _P, _P]),
     "ifx_hint_next_frame_device": (C.c_int, [_P, _P, _P]),
+    "ifx_hint_next_frame": (C.c_int, [_P, _P, _P]),
+    "ifx_lookahead_stats": (C.c_int, [_P, _P, C.c_int]),
     "ifx_view_list_stats": (C.c_int, [_P, _P]),
     "ifx_map_bounding_boxes": (C.c_int, [_P, C.c_int, C.c_float, _P, _P, _P, _P, _P]),
     "ifx_instance_point_cloud": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
@@ -262,6 +264,13 @@ class ElasticFusion:
         return out.reshape(4, 4)
 
     process_frame = processFrame
+
+    def hint_next_frame(self, rgb, depth):
+        """Announce the frame after the one about to be processed, host arrays (see ifx_hint_next_frame): pass the SAME arrays to the next processFrame."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        assert rgb.size == self.w * self.h * 3 and depth.size == self.w * self.h
+        self._chk(self.L.ifx_hint_next_frame(self.handle, _ptr(rgb), _ptr(depth)), "ifx_hint_next_frame")
 
     def enqueue_frame_device(self, d_rgb_ptr: int, d_depth_ptr: int, timestamp=0):
         self._chk(self.L.ifx_enqueue_frame_device(self.handle, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr), int(timestamp), None, 1.0),
@@ -544,6 +553,12 @@ class ElasticFusion:
         out = np.zeros(4, np.float32)
         self._chk(self.L.ifx_stage_ms(self.handle, _ptr(out), int(reset)), "ifx_stage_ms")
         return dict(track=float(out[0]), fuse=float(out[1]), instance=float(out[2]), preprocess=float(out[3]))
+
+    def lookahead_stats(self, reset=False):
+        """ifx_lookahead_stats: frames that found their frame side done / their tracker run ahead / came through ifx_hint_next_frame."""
+        out = np.zeros(3, np.int32)
+        self._chk(self.L.ifx_lookahead_stats(self.handle, _ptr(out), int(reset)), "ifx_lookahead_stats")
+        return dict(side_prepared=int(out[0]), tracked_ahead=int(out[1]), host_hinted=int(out[2]))
 
     def superpixel_ahead_stats(self, reset=False):
         """Superpixels run ahead of segmentation calls on the side stream (ifx_superpixel_ahead_stats): device ms, runs enqueued, runs a call used."""

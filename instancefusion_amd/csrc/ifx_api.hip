@@ -237,6 +237,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->h_result) hipHostFree(h->h_result);
     if (h->h_pose_early) hipHostFree(h->h_pose_early);
     if (h->ev_pose_early) hipEventDestroy(h->ev_pose_early);
+    for (int q_ = 0; q_ < 2; q_++) { if (h->hint_stage_rgb[q_]) hipHostFree(h->hint_stage_rgb[q_]); if (h->hint_stage_depth[q_]) hipHostFree(h->hint_stage_depth[q_]); }
     if (h->rgb_stage) hipHostFree(h->rgb_stage);
     if (h->depth_stage) hipHostFree(h->depth_stage);
     ifx_free_tracker(h);
@@ -425,14 +426,17 @@ int ifx_enqueue_hinted_frame_side(ifx* h)
 {
     if (!h->hint_rgb || !h->opt_two_streams) { h->hint_rgb = nullptr; return IFX_OK; }
     const uint8_t* r = h->hint_rgb; const uint16_t* d = h->hint_depth;
-    h->hint_rgb = nullptr; h->hint_depth = nullptr;
+    const int kind = h->hint_kind;
+    h->hint_rgb = nullptr; h->hint_depth = nullptr; h->hint_kind = 0;
     // Frame sides are ordered among themselves: each reads the image pyramid of the frame before it and all of them sum into the same SO(3) accumulators / ticket.
     // On the side stream that order is the stream's; but the current frame's side may have run on the MAIN stream (the sharded entry does that for a frame that was
     // not announced) -- its "slot ready" event orders the announced frame's side behind it (recorded on the side stream itself in the usual case: no wait at all).
     // Without it the two ran side by side once in a few hundred frames: a garbled SO(3) start for the current frame (tests: the rare failure of
     // test_owner_sharded_rccl_world_of_one_in_library at the frame after its host-pointer frame).
     if (h->stream_b && h->slot[h->tick & 1].ready) HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->slot[h->tick & 1].ready, 0));
-    return enqueue_frame_side(h, (h->tick + 1) & 1, h->tick + 1, r, d, 0);
+    int rr = enqueue_frame_side(h, (h->tick + 1) & 1, h->tick + 1, r, d, kind);
+    if (!rr && kind == 1) h->prestaged_tick = h->tick + 1;   // (the frame's data is in its parity's staging pair: ifx_process_frame_ex takes the slot as it is)
+    return rr;
 }
 
 // Local loop-closure detection of the frame just tracked (EF/ElasticFusion.cpp:453-566 with no fern match): predict() at the new pose,
@@ -547,9 +551,10 @@ static int enqueue_frame(ifx* h, const uint8_t* rgb, const uint16_t* depth, int 
     if (h->opt_pace && h->ev_result && h->tick > 1) HIPCHK(h, hipEventSynchronize(h->ev_result));
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];
-    const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && src_kind == 0;
+    const bool prepared = f.for_tick == h->tick && f.src_rgb == rgb && f.src_depth == depth && (src_kind == 0 || h->prestaged_tick == h->tick);   // (prestaged: ifx_process_frame_ex put the frame side of its staged frame on the side stream before it waited for the previous frame)
     // a tracker run enqueued behind the previous frame counts only for exactly this frame, tracked, with the default weight
     const bool tracked = prepared && h->tracked_ahead == h->tick && !in_pose16;
+    h->n_side_prepared += prepared ? 1 : 0; h->n_tracked_ahead += tracked ? 1 : 0;
     ifx_drop_tracked(h);
     if (!prepared) {
         if (h->slic_ahead_tick == h->tick) h->slic_ahead_tick = -1;   // superpixels run ahead for a frame that was announced and did not come: not this frame's (the run stays "busy" until somebody queues behind it)
@@ -1183,7 +1188,29 @@ extern "C" int ifx_prefetch_frame_device(ifx_t* h, const uint8_t* d_rgb_next, co
 extern "C" int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16_t* d_depth_next)
 {
     if (!h || !d_rgb_next || !d_depth_next) return IFX_E_INVALID;
-    h->hint_rgb = d_rgb_next; h->hint_depth = d_depth_next;
+    h->hint_rgb = d_rgb_next; h->hint_depth = d_depth_next; h->hint_kind = 0;
+    return IFX_OK;
+}
+
+// The same announcement with HOST pointers, for the reference-shaped entry (ifx_process_frame): a log reader or a camera queue that already holds the next frame hands it
+// over BEFORE it calls ifx_process_frame for the current one.  The buffers are borrowed for this call only: the frame is copied into a pinned staging pair of its own
+// (by frame parity) here, its transfer and image-only work go to the side stream from inside the current frame's enqueue, and its tracker is parked behind the current
+// frame -- exactly the resident path's look-ahead, plus the transfer.  The next ifx_process_frame call must pass the SAME pointers (anything else: the announcement is
+// ignored and the frame is staged and computed as ever).  Single-stream, unsharded handles.
+extern "C" int ifx_hint_next_frame(ifx_t* h, const uint8_t* rgb_next, const uint16_t* depth_next)
+{
+    if (!h || !rgb_next || !depth_next) return IFX_E_INVALID;
+    if (h->own || !h->cams.empty()) { h->err = "ifx_hint_next_frame: single-stream, unsharded handles (use ifx_hint_next_frame_device)"; return IFX_E_STATE; }
+    if (!h->opt_two_streams || !h->stream_b) return IFX_OK;   // nothing to overlap with
+    const int p = (h->tick + 1) & 1;   // (this pair's last transfer belongs to frame tick - 1, whose pose a call has returned: complete)
+    if (!h->hint_stage_rgb[p]) {
+        HIPCHK(h, hipHostMalloc((void**)&h->hint_stage_rgb[p], (size_t)h->P * 3, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&h->hint_stage_depth[p], (size_t)h->P * 2, hipHostMallocDefault));
+    }
+    memcpy(h->hint_stage_depth[p], depth_next, (size_t)h->P * 2);
+    memcpy(h->hint_stage_rgb[p], rgb_next, (size_t)h->P * 3);
+    h->hinted_src_rgb[p] = rgb_next; h->hinted_src_depth[p] = depth_next; h->hinted_tick[p] = h->tick + 1;
+    h->hint_rgb = h->hint_stage_rgb[p]; h->hint_depth = h->hint_stage_depth[p]; h->hint_kind = 1;
     return IFX_OK;
 }
 
@@ -1244,6 +1271,18 @@ extern "C" int ifx_tracker_range_exceeded(ifx_t* h)
     return (int)std::min<long long>(total, 0x7FFFFFFF);
 }
 
+// End of a synchronous ifx_process_frame: the frame just enqueued is complete.  With the NEXT frame announced (ifx_hint_next_frame) its side and its parked tracker are on
+// the queues behind this frame: the call waits for the frame's own end (the event the resident path paces itself with), not for the streams.
+static int frame_sync(ifx* h)
+{
+    if (h->tracked_ahead == h->tick && h->ev_result && !h->lc_enable && !h->opt_kernel_timing && !h->opt_stage_timing) {
+        HIPCHK(h, hipEventSynchronize(h->ev_result));
+        if (h->h_result->overflow) { h->err = "surfel store capacity exceeded"; return IFX_E_CAPACITY; }
+        return IFX_OK;
+    }
+    return ifx_sync(h);
+}
+
 extern "C" int ifx_process_frame(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, const float* in_pose16, float weight_mult, float* out_pose16)
 {
     return ifx_process_frame_ex(h, rgb, depth, timestamp, nullptr, in_pose16, weight_mult, 0, out_pose16);
@@ -1264,12 +1303,42 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
     // another pose) and not for the first frame.  OPT-IN (option "host_entry_async" 1): the compaction decision a synchronous call takes right behind its frame is
     // taken at the start of the NEXT ifx_process_frame instead (from the same numbers) -- equivalent for a host whose loop is ifx_process_frame after
     // ifx_process_frame, but a camera switch, an upload or a segmentation call in between would see the store before that compaction instead of after it.
+    // a frame announced by ifx_hint_next_frame: its data sits in its parity's staging pair, its frame side is on the side stream since the previous frame's enqueue (and its
+    // tracker parked behind that frame): nothing to stage, nothing to wait for here
+    const int par = h->tick & 1;
+    const bool pre = h->hinted_tick[par] == h->tick && h->hinted_src_rgb[par] == (const void*)rgb && h->hinted_src_depth[par] == (const void*)depth && h->prestaged_tick == h->tick &&
+                     h->slot[par].for_tick == h->tick && h->slot[par].src_rgb == (const void*)h->hint_stage_rgb[par] && !h->own;
+    h->hinted_tick[par] = -1;
+    if (pre) {
+        h->want_early_pose = 0;
+        h->n_host_hinted++;
+        if (h->housekeeping_due) {   // (option host_entry_async: the decision an early-returning call left for this one)
+            if (h->ev_result) HIPCHK(h, hipEventSynchronize(h->ev_result));
+            ifx_housekeeping(h);
+            h->housekeeping_due = 0;
+        }
+        int r = enqueue_frame(h, h->hint_stage_rgb[par], h->hint_stage_depth[par], 1, in_pose16, weight_mult, bootstrap);
+        if (r) return r;
+        r = frame_sync(h);
+        if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
+        if (r) return r;
+        ifx_housekeeping(h);
+        h->housekeeping_due = 0;
+        return 0;
+    }
     const bool can_early = h->opt_host_entry_async && !h->lc_enable && !h->in_fern_cb && h->tick > 1 && h->cams.empty() && !in_pose16;   // (plain tracked frames of a single stream)
     // (the staging buffers are free: their last copy to the device ran in front of a tracker whose pose a previous call has waited for -- or behind a full synchronisation)
     if (!can_early) HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(h->depth_stage, depth, (size_t)h->P * 2);
     h->late_rgb_src = rgb;   // (copied by enqueue_frame_side, behind the depth transfer and the bilateral filter's launch)
     bool early = false;
+    if (can_early && h->opt_two_streams && h->stream_b && !h->hint_rgb && h->slot[h->tick & 1].for_tick != h->tick) {
+        // this frame's copy-in and image-only work (0.2 ms) go to the side stream NOW, under the previous frame's map passes: they need nothing of that frame but the
+        // intensity pyramid its own side left on this stream.  The wait below used to come first, and the device idled through the transfer and the filter.
+        int r = enqueue_frame_side(h, h->tick & 1, h->tick, h->rgb_stage, h->depth_stage, 1);
+        if (r) { h->late_rgb_src = nullptr; return r; }
+        h->prestaged_tick = h->tick;
+    }
     if (can_early) {
         // the frame before this one is complete from here on: its result is final, and the housekeeping decision a synchronous call would have taken right behind it
         // is taken now, from the same numbers, at the same place in the stream -- slot numbers do not depend on timing
@@ -1290,7 +1359,7 @@ extern "C" int ifx_process_frame_ex(ifx_t* h, const uint8_t* rgb, const uint16_t
         h->housekeeping_due = 1;
         return 0;
     }
-    r = ifx_sync(h);
+    r = frame_sync(h);
     if (out_pose16) memcpy(out_pose16, h->h_result->pose, 64);
     if (r) return r;
     ifx_housekeeping(h);
@@ -1368,6 +1437,14 @@ extern "C" int ifx_stage_ms(ifx_t* h, float* ms4, int reset)
 }
 // Superpixels run ahead of a segmentation call on the side stream (ifx_superpixel_ahead): how many runs, how many a call then used, and -- with stage timing on --
 // the device time of the runs (ms, side stream; the "instance" entry of ifx_stage_ms is the main-stream span of the calls and does not contain it)
+extern "C" int ifx_lookahead_stats(ifx_t* h, int32_t* out3, int reset)
+{
+    if (!h || !out3) return IFX_E_INVALID;
+    out3[0] = h->n_side_prepared; out3[1] = h->n_tracked_ahead; out3[2] = h->n_host_hinted;
+    if (reset) h->n_side_prepared = h->n_tracked_ahead = h->n_host_hinted = 0;
+    return IFX_OK;
+}
+
 extern "C" int ifx_superpixel_ahead_stats(ifx_t* h, float* ms, int32_t* runs, int32_t* used, int reset)
 {
     if (!h) return IFX_E_INVALID;

@@ -317,6 +317,11 @@ struct ifx {
     int opt_seg_aside = 1;              // a segmentation call that finds the next frame's tracker already queued on the main stream runs beside it on stream_c (the call is
                                         // synchronous for the host, so nothing has to join afterwards); ifx_instance / ifx_slic / ifx_knn enqueue on h->cur throughout
     hipEvent_t ev_result = nullptr;     // the `released` event of the slot of the last frame (recorded after k_frame_result)
+    int n_side_prepared = 0, n_tracked_ahead = 0, n_host_hinted = 0;   // ifx_lookahead_stats: frames that found their frame side done / their tracker run / came through ifx_hint_next_frame
+    int hint_kind = 0;                      // 0: device pointers (ifx_hint_next_frame_device), 1: the pinned staging pair of the announced frame's parity (ifx_hint_next_frame)
+    uint8_t* hint_stage_rgb[2] = {nullptr, nullptr}; uint16_t* hint_stage_depth[2] = {nullptr, nullptr};   // ifx_hint_next_frame: pinned staging by frame parity (allocated at the first use)
+    const void *hinted_src_rgb[2] = {nullptr, nullptr}, *hinted_src_depth[2] = {nullptr, nullptr};       // ... the caller's pointers of the announced frame, and
+    int hinted_tick[2] = {-1, -1};                                                                        // ... the frame it was announced for
     const uint8_t* hint_rgb = nullptr;      // next frame announced by ifx_hint_next_frame_device, not enqueued yet
     const uint16_t* hint_depth = nullptr;
     std::string err;
@@ -401,6 +406,7 @@ struct ifx {
     float* h_pose_early = nullptr;     // pinned, 16 floats
     hipEvent_t ev_pose_early = nullptr;
     int want_early_pose = 0, early_pose_valid = 0, housekeeping_due = 0;
+    int prestaged_tick = -1;           // ifx_process_frame_ex (host_entry_async): the frame whose side was enqueued from the staging buffers before the call waited for its predecessor
     int opt_host_entry_async = 0;      // opt-in (see ifx_process_frame_ex): the deferred housekeeping decision must not be separated from its frame by other calls
     float* d_traj = nullptr;           // [max_traj][16] ring: frame f's pose lives in slot f % max_traj (ifx_trajectory returns the last max_traj frames)
     int max_traj = 1 << 16;

@@ -1560,17 +1560,28 @@ def test_host_entry_returning_with_the_pose_changes_nothing(ifx, small_stream):
     differ: the last frame's compaction is still pending in the one mode and done in the other)."""
     st = small_stream
     outs = []
-    for mode in (0, 1):
+    order = list(range(10)) + list(range(8, -1, -1))
+    for mode in (0, 1, 2, 3):   # 2: the synchronous entry with every next frame announced from host memory (ifx_hint_next_frame); 3: the same on the early-return entry
         g = ifx.ElasticFusion(**SMALL, max_surfels=400000, confidence=2.0)
-        g.set_option("host_entry_async", mode)
+        g.set_option("host_entry_async", mode & 1)
         g.set_option("compact_divisor", 64)
-        poses = [g.processFrame(st["rgb"][i % 10], st["depth"][i % 10]) for i in list(range(10)) + list(range(8, -1, -1))]
+        poses = []
+        for j, i in enumerate(order):
+            if mode >= 2 and j + 1 < len(order):
+                g.hint_next_frame(st["rgb"][order[j + 1]], st["depth"][order[j + 1]])
+            poses.append(g.processFrame(st["rgb"][i], st["depth"][i]))
+        la = g.lookahead_stats()
+        if mode == 2:   # every frame but the first two came prepared AND tracked ahead (frame 1 is announced during the map's first frame, which has no tracker to park behind)
+            assert la["host_hinted"] == len(order) - 1 and la["side_prepared"] == len(order) - 1 and la["tracked_ahead"] >= len(order) - 2, la
+        elif mode < 2:
+            assert la["host_hinted"] == 0 and la["tracked_ahead"] == 0, la
         ids, slots, m = g.image("ids_after"), g.slots, g.download()
         outs.append((np.stack(poses), ids, slots, m))
         g.close()
-    a, b = outs
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1] > 0, b[1] > 0)
-    assert all(np.array_equal(a[3][k], b[3][k]) for k in MAP_KEYS)
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1] > 0, b[1] > 0)
+        assert all(np.array_equal(a[3][k], b[3][k]) for k in MAP_KEYS)
     assert a[3]["pc"].shape[0] > 50000
 
 

@@ -8,5 +8,5 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/${TAG}_bench_driver.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d["ms_per_frame_gpu"], "host", d["value_host_entry"]["value"], d["value_host_entry_async"]["value"], d["value_host_entry_async"]["frames_only"], "fast", d["value_fast_cadence"]["value"], "lc", d["value_close_loops"]["value"], "sharded", d["value_sharded"]["value"], "guard", d["exact_sum_range_exceeded"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("parity_in_bench"))
+print(d["value"], d["ms_per_step"], d["ms_per_frame_gpu"], "host", d["value_host_entry"]["value"], d["value_host_entry_async"]["value"], d["value_host_entry_async"]["frames_only"], d.get("value_host_entry_hinted", {}).get("value"), "fast", d["value_fast_cadence"]["value"], "lc", d["value_close_loops"]["value"], "sharded", d["value_sharded"]["value"], "guard", d["exact_sum_range_exceeded"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("parity_in_bench"))
 PY

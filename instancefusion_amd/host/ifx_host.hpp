@@ -1047,6 +1047,9 @@ public:
     virtual void fastForward(int frame) = 0;
     virtual const std::string getFile() { return file; }
     virtual void setAuto(bool) {}
+    // (beyond the reference) the frame the NEXT getNext() will deliver, if the reader already holds it decoded: the buffers getNext() will publish, so that a caller can
+    // announce them (ifx_hint_next_frame) before it processes the current frame.  false: no look-ahead in this reader / at the end of the log.
+    virtual bool peekNext(const unsigned char*& /*rgbNext*/, const unsigned short*& /*depthNext*/) { return false; }
 
     bool flipColors;
     int64_t timestamp;
@@ -1126,6 +1129,22 @@ public:
         }
         publish();
         fill();   // keep the workers busy while the caller processes this frame
+    }
+    bool peekNext(const unsigned char*& rgbNext, const unsigned short*& depthNext) override
+    {
+        if (workers_.empty() || !hasMore()) return false;
+        fill();
+        Frame* f;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (tail_ == head_) return false;
+            f = &ring_[head_ % ring_.size()];
+            done_.wait(lk, [&] { return f->state >= 2; });
+        }
+        if (f->state == 3) return false;   // (getNext() reports the error)
+        rgbNext = f->rgb.data();           // getNext() swaps these vectors into the published frame: the same addresses
+        depthNext = f->depth.data();
+        return true;
     }
     void getBack() override
     {

@@ -21,7 +21,7 @@ struct Args {
     std::string log, masks, out = "./ResultModel", labels, gt_dir, eval_file;
     int width = 640, height = 480, max_frames = 0, max_surfels = 6 * 1000 * 1000, device = 0;
     float fx = 528.f, fy = 528.f, cx = 320.f, cy = 240.f;
-    bool superpixels = true, flip = false, close_loops = true, deform = true;
+    bool superpixels = true, flip = false, close_loops = true, deform = true, lookahead = true;
     int decode_threads = 4;
     float confidence = 10.f;
     Sharding shard;   // --shard-ranks G --shard-rank r --shard-id FILE: this process is rank r of G over one spatially sharded map (one process per GPU)
@@ -31,7 +31,7 @@ int usage(const char* argv0)
 {
     std::fprintf(stderr,
                  "usage: %s LOG.klg|data.txt [--width W --height H --fx F --fy F --cx C --cy C] [--masks DIR] [--out PREFIX]\n"
-                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--decode-threads N] [--confidence C]\n"
+                 "       [--max-frames N] [--max-surfels N] [--no-superpixels] [--labels FILE] [--flip-colors] [--flann-every N] [--device K] [--no-close-loops] [--detect-only] [--decode-threads N] [--no-lookahead] [--confidence C]\n"
                  "       [--gt-dir DIR (DIR/<frame, 6 digits>.png, 8-bit instance ground truth)] [--eval FILE (precision / recall rows, needs --gt-dir)]\n"
                  "       [--shard-ranks G --shard-rank r --shard-id FILE [--shard-nonce N] (one process per GPU over one spatially sharded map; every rank replays the same log; -1: a world of one)]\n",
                  argv0);
@@ -69,6 +69,7 @@ int main(int argc, char** argv)
         else if (s == "--detect-only") a.deform = false;   // loop closures are found and counted, the map is never deformed
         else if (s == "--confidence") a.confidence = (float)std::atof(val("--confidence"));
         else if (s == "--flip-colors") a.flip = true;
+        else if (s == "--no-lookahead") a.lookahead = false;   // frames are handed over one at a time, as the reference's loop does
         else if (s == "--shard-ranks") a.shard.ranks = std::atoi(val("--shard-ranks"));   // -1: a world of one on the sharded path
         else if (s == "--shard-rank") a.shard.rank = std::atoi(val("--shard-rank"));
         else if (s == "--shard-nonce") a.shard.nonce = std::strtoull(val("--shard-nonce"), nullptr, 10);   // the same number for every rank of one run: a stale id file is never accepted
@@ -126,6 +127,11 @@ int main(int argc, char** argv)
                     instanceGT = gtBuf.data();
                 }
             }
+            {   // the reader's read-ahead already holds the next frame: announced before this one is processed (its transfer, filter, pyramids and tracker run beside / behind this frame)
+                const unsigned char* rgbNext = nullptr;
+                const unsigned short* depthNext = nullptr;
+                if (a.lookahead && !a.shard.on() && log_reader->peekNext(rgbNext, depthNext)) ifx_hint_next_frame(map->handle(), rgbNext, depthNext);
+            }
             if (!map->ProcessFrame(log_reader->rgb, log_reader->depth, log_reader->timestamp, instanceTableLoopClosure.data(), instanceGT)) {
                 std::cout << "Elastic fusion lost!" << a.log << std::endl;
                 return 1;
@@ -152,6 +158,9 @@ int main(int argc, char** argv)
         }
         if (!a.eval_file.empty()) instancefusion->evaluateAndSave(map, a.log, a.eval_file);   // IF/main.cpp:340
         const Matrix4f P = map->getCurrPose();
+        int32_t la[3] = {0, 0, 0};
+        ifx_lookahead_stats(map->handle(), la, 0);
+        std::printf("%d frames announced ahead (%d with their tracker run ahead), ", la[2], la[1]);
         std::printf("%d frames in %.2f s (%.1f frames/s incl. log decoding), %d segmentation calls, %d surfels, %d stable -> %s.ply / _Instance.ply (%d), "
                     "last position %.6f %.6f %.6f, %d local loop-closure candidates, %d fern keyframes, %d fern matches, %d local / %d global deformations\n",
                     frame_Fusion, dt, frame_Fusion / (dt > 0 ? dt : 1), instancefusion->segmentationCalls(), map->getMapSurfelCount(), n_geo, a.out.c_str(), n_ins,

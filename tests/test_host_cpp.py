@@ -321,6 +321,7 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     r = subprocess.run([REPLAY, klg] + common + ["--out", out_c, "--labels", out_c + ".labels"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert f"{n} frames" in r.stdout and " 0 segmentation calls" not in r.stdout
+    assert int(r.stdout.split(" frames announced ahead")[0].split()[-1]) >= n - 2, r.stdout   # the reader's read-ahead fed ifx_hint_next_frame
     # the fern data base ran inside every frame (findFrame in the callback, addFrame after it): keyframes were admitted, nothing is old enough to match,
     # and the frames are what the Python loop (no data base) computes
     assert int(r.stdout.split(" fern keyframes")[0].split()[-1]) >= 1 and " 0 fern matches" in r.stdout
@@ -336,6 +337,13 @@ def test_cpp_replay_equals_python_main_loop(small_stream, tmp_path):
     assert lab.size > 0 and np.array_equal(lab, np.fromfile(out_p + ".labels", np.int32))
     head = open(out_c + ".ply", "rb").read(200)
     assert int(head.split(b"element vertex ")[1].split(b"\n")[0]) > 1000          # stable surfels were exported
+    # the run above announced every next frame from the reader's read-ahead (ifx_hint_next_frame); frames handed over one at a time give the same files
+    out_n = str(tmp_path / "N")
+    r = subprocess.run([REPLAY, klg] + common + ["--out", out_n, "--no-lookahead"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("0 frames announced ahead") or "\n0 frames announced ahead" in r.stdout, r.stdout
+    assert open(out_c + ".freiburg").read() == open(out_n + ".freiburg").read()
+    assert open(out_c + ".ply", "rb").read() == open(out_n + ".ply", "rb").read()
 
 
 @pytest.mark.gpu

@@ -37,7 +37,9 @@ def main():
     common = [exe, klg, "--width", str(W), "--height", str(H), "--fx", str(K[0]), "--fy", str(K[1]), "--cx", str(K[2]), "--cy", str(K[3]), "--max-surfels", "3000000"]
     for name, extra in (("closeLoops (reference default): detection + fern data base + optimiser", []), ("--detect-only", ["--detect-only"]),
                         ("--no-close-loops", ["--no-close-loops"]), ("closeLoops, --decode-threads 0 (records decoded when asked for)", ["--decode-threads", "0"]),
-                        ("closeLoops, --decode-threads 8", ["--decode-threads", "8"]), ("--no-close-loops --decode-threads 8", ["--no-close-loops", "--decode-threads", "8"])):
+                        ("closeLoops, --decode-threads 8", ["--decode-threads", "8"]), ("--no-close-loops --decode-threads 8", ["--no-close-loops", "--decode-threads", "8"]),
+                        ("--no-close-loops --no-lookahead (frames handed over one at a time)", ["--no-close-loops", "--no-lookahead"]),
+                        ("closeLoops, --no-lookahead", ["--no-lookahead"])):
         r = subprocess.run(common + ["--out", os.path.join(a.out, "m")] + extra, capture_output=True, text=True)
         print(name, "->", (r.stdout.strip().splitlines() or [r.stderr.strip()])[-1], flush=True)
     return 0

@@ -244,12 +244,12 @@ def main():
         """The adaptive cadence (every 46th frame once the map carries votes, IF/Core/InstanceFusion.cpp:192-238) would leave a short
         timed window without any instance work.  The frame numbers handed to whetherDoSegmentation are shifted so that a call falls
         due in the MIDDLE of a window shorter than the cadence: such a window then holds one call (more instance work per frame than
-        the steady state, never less); longer windows keep the natural phase."""
+        the steady state, never less); windows up to two cadences hold exactly one call, in the middle; longer windows keep the natural phase."""
         if args.no_instance or seg["last_true"] is None:
             return
         nxt = 100 + seg["frame"] + seg["shift"] + 1          # frame number the next step will present
         due = seg["last_true"] + 46
-        if due > nxt + n_frames - 1 or due < nxt:
+        if due > nxt + n_frames - 1 or due < nxt or n_frames < 2 * 46:   # (up to two cadences: ONE call, in the middle -- the natural phase gave such a window one call or two from run to run)
             seg["shift"] += due - (nxt + n_frames // 2)
 
     sh = osh

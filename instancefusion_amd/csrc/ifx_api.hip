@@ -143,7 +143,6 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->upd_owner, 0xFF, C * 4);
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     ALLOC(h->seq, C * 4); ALLOC(h->seq2, C * 4);
-    if (h->own) { ALLOC(h->d_gfl, 8); hipMemset(h->d_gfl, 0xFF, 8); }
     hipMemset(h->labels, 0xFF, C * 4);
     size_t SN = std::max(C, P);
     ALLOC(h->scan_flags, SN * 4); ALLOC(h->scan_out, SN * 4); ALLOC(h->scan_block, (std::max(SN, (size_t)1 << 24) / 1024 + 8) * 4);   // also serves the 256^3-cell scan of the kNN grid
@@ -158,8 +157,11 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipHostMalloc((void**)&h->depth_stage, P * 2);
     // Buffers that travel together between the ranks of a sharded map are ONE allocation each, so that an exchange point is one collective
     // (ifx_owner_exchange): [key_splat | key_ids | key_both], [index_vc | index_nr], [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail].
-    ALLOC(h->key_index, P * 8); ALLOC(h->key_splat, P * 8 * 3); h->key_ids = h->key_splat + P; h->key_both = h->key_splat + 2 * P;
-    hipMemset(h->key_index, 0xFF, P * 8); hipMemset(h->key_splat, 0xFF, P * 8 * 3);
+    // Sharded map: one more word behind key_index and behind [key_splat | key_ids] -- the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE),
+    // MIN-reduced with the keys in the same collective.  Hence key_both in FRONT of the pair: [key_both | key_splat | key_ids | word].
+    ALLOC(h->key_index, P * 8 + 8); ALLOC(h->key_both, P * 8 * 3 + 8); h->key_splat = h->key_both + P; h->key_ids = h->key_both + 2 * P;
+    hipMemset(h->key_index, 0xFF, P * 8 + 8); hipMemset(h->key_both, 0xFF, P * 8 * 3 + 8);
+    if (h->own) { h->gfl_index = h->key_index + P; h->gfl_splat = h->key_both + 3 * P; }
     ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16 * 2); h->index_nr = h->index_vc + 4 * P; ALLOC(h->index_ct, P * 16); ALLOC(h->index_tap, P * 16);
     // [pred_vertex | pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail]: everything behind pred_vertex travels (sharded map).  The vertex itself does not: it is
     // a function of the pixel and of the winning key's depth, which every rank holds after the key exchange -- only its fourth component, the winner's confidence, is the
@@ -217,7 +219,6 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_comm_free(h);
     camera_free(h);
     if (h->own_slot_img) hipFree(h->own_slot_img);
-    if (h->d_gfl) hipFree(h->d_gfl);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);
@@ -229,7 +230,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
     void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
-                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_splat,
+                    h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,
                     h->fill_normal, h->fill_image, h->ids_after, h->ids_tmp, h->assoc_key, h->assoc_target, h->meas_pc, h->meas_nr, h->meas_col};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1113,11 +1114,11 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     int n = 0;
     auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
     switch (phase) {
-    case 0: if (!first) { add(h->key_index, P * 8, 0); add(h->d_gfl, 8, 0); } break;                  // + the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE)
+    case 0: if (!first) add(h->key_index, P * 8 + 8, 0); break;                  // + the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE)
     case 1: if (!first) add(h->assoc_key, (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2) * 8, 0); break;   // the best owned candidate of every measurement pixel (distance | window position)
-    case 2: if (!first) add(h->key_index, P * 8, 0); break;
+    case 2: if (!first) add(h->key_index, P * 8 + 8, 0); break;                                    // (the word is the reduced one of exchange 0: a MIN of equal values)
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
-    case 4: add(h->key_splat, P * 16, 0); add(h->d_gfl, 8, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
+    case 4: add(h->key_splat, P * 16 + 8, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
     case 5:   // [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
         if (h->own_track_rank >= 0 && h->own_tracked_tick == h->tick && h->own_g > 1) {
             // K streams, camera k tracked by rank k only: the prediction rendered at the end of camera k's frame has ONE consumer, rank k's tracker -- a reduction to that

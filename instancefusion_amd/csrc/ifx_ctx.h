@@ -277,7 +277,7 @@ struct ifx {
     hipEvent_t ev_cam_ahead = nullptr, ev_cam_parked = nullptr, ev_cam_side = nullptr;
     hipStream_t cam_side_stream = nullptr;   // set around ifx_tracker_camera_ahead: the stream its frame side goes to (null: the same stream as its tracker)
     int cam_ahead_used = 0;             // frames whose tracker was taken from a run ahead (diagnostics / tests)
-    unsigned long long* d_gfl = nullptr; // sharded map: lowest live creation number -- this rank's before exchanges 0 / 4, every rank's behind them (ifx_map.hip FIRST_LIVE: the reference's "surfel 0")
+    unsigned long long *gfl_index = nullptr, *gfl_splat = nullptr;   // sharded map: the word behind key_index / behind [key_splat | key_ids] that carries the lowest live creation number (this rank's before the exchange, every rank's behind it; ifx_map.hip FIRST_LIVE: the reference's "surfel 0")
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
     int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it

@@ -92,16 +92,18 @@ __device__ __forceinline__ unsigned int* list_ctr(const Cam& c, int list, int se
 // one L2 channel that holds the line, 11 us of a 300 k-thread launch (k_splat_resolve 40 -> 29 us, profiles/r05_*).
 // Spatially sharded map: ids are creation numbers, and the reference's "surfel 0" is the live surfel with the LOWEST creation number on any rank.  Every rank publishes
 // the lowest live creation number of its shard (k_own_first_live, behind the two places a frame removes surfels: the view-list scan of phase 0, the clean of phase 4), the
-// word is MIN-reduced with the key images of exchanges 0 and 4 (ifx_owner_exchange), and Cam::first_live points at it there: fl is then a creation number, and the
-// resolves turn that id into 0 where they write id images (k_index_resolve, splat_resolve_body) -- attributes and occlusion are untouched, as on one GPU.
+// word sits right behind the key images of exchanges 0 / 2 and 4 and is MIN-reduced WITH them (ifx_owner_exchange: one word more in the same collective), and
+// Cam::first_live points at it there: fl is then a creation number, and the resolves turn that id into 0 where they write id images (k_index_resolve,
+// splat_resolve_body) -- attributes and occlusion are untouched, as on one GPU.
 #define FIRST_LIVE(c) (*(c).first_live)
-__global__ void k_own_first_live(const DevState* __restrict__ st, const float2* __restrict__ tm, const uint32_t* __restrict__ seq, unsigned long long* __restrict__ out)
+__device__ __forceinline__ void own_first_live(const DevState* __restrict__ st, const float2* __restrict__ tm, const uint32_t* __restrict__ seq, unsigned long long* __restrict__ out)
 {
     int f = st->first_live;
     const int n = st->count;
     while (f < n && !(tm[f].y > DEAD_TIME)) f++;
     *out = f < n ? (unsigned long long)seq[f] : ~0ull;   // (no live surfel here: the identity of the MIN; as an int -1, which no creation number reaches -- k_append_scan stops at 0xFFF00000)
 }
+__global__ void k_own_first_live(const DevState* __restrict__ st, const float2* __restrict__ tm, const uint32_t* __restrict__ seq, unsigned long long* __restrict__ out) { own_first_live(st, tm, seq, out); }
 
 // ---- "hot" records (round 5, option hot_records): position + confidence, normal + radius and times of a slot in ONE 64-byte record.  The store stays struct-of-arrays (the
 // scans stream 24 B per slot, the C API hands out the arrays), but at random map order every field a list walker or a resolve GATHERS is a 128-byte line fetch of its own:
@@ -134,9 +136,11 @@ __device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int 
 // After the exchange the rank owns a pixel's winner exactly when its local winner carries the winning creation number -- one gather instead of the
 // binary search over the shard's creation numbers (23 dependent loads at 5 M slots: k_associate 80 -> 14 us, k_index_resolve 29 -> 9, k_splat_resolve 39 -> 22).
 __device__ __forceinline__ int own_slot_of(const Cam& c, int slot, unsigned int id) { return (slot >= 0 && c.seq[slot] == id) ? slot : -1; }
-__global__ void k_own_translate(unsigned long long* __restrict__ keys, int P, const uint32_t* __restrict__ seq, int32_t* __restrict__ slot_img)
+__global__ void k_own_translate(unsigned long long* __restrict__ keys, int P, const uint32_t* __restrict__ seq, int32_t* __restrict__ slot_img,
+                                const DevState* __restrict__ st = nullptr, const float2* __restrict__ tm = nullptr, unsigned long long* __restrict__ gfl_out = nullptr)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && gfl_out) own_first_live(st, tm, seq, gfl_out);   // (the word that travels with these keys)
     if (k >= P) return;
     const unsigned long long key = keys[k];
     if (key == IFX_KEY_EMPTY) { slot_img[k] = -1; return; }
@@ -152,7 +156,7 @@ static Cam make_cam(ifx* h)
     c.srank = h->shard_rank; c.sn = h->shard_n > 0 ? h->shard_n : 1;
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
     c.seq = h->seq; c.own_n = h->own ? h->own_g : 0; c.own_rank = h->own ? h->cfg.rank : 0;
-    c.first_live = (h->own && h->d_gfl) ? (const int*)h->d_gfl : &h->d_state->first_live; c.raw_slots = 0;   // (sharded map: the low word of the reduced lowest live creation number)
+    c.first_live = (h->own && h->gfl_splat) ? (const int*)h->gfl_splat : &h->d_state->first_live; c.raw_slots = 0;   // (sharded map: the low word of the reduced lowest live creation number)
     return c;
 }
 
@@ -2920,12 +2924,14 @@ __global__ void k_merge_both(unsigned long long* __restrict__ ks, unsigned long 
 // phase p of a frame of the sharded map; the buffers ifx_owner_exchange(p) lists are reduced across the ranks before phase p + 1 -- by the library itself
 // on its communicator (ifx_comm.hip: ifx_owner_process_frame_device), or by the caller (the emulation tests).  phase 104..106: ElasticFusion::predict
 // outside a frame (ifx_owner_predict_phase): phases 4..6 without the clean / append and without the whetherDoSegmentation sums.
-#define OWN_FIRST_LIVE(h) do { if ((h)->d_gfl && (h)->opt_own_first_live) LAUNCH((h), "own_first_live", dim3(1), dim3(1), k_own_first_live, (const DevState*)(h)->d_state, (const float2*)(h)->tm, (const uint32_t*)(h)->seq, (h)->d_gfl); } while (0)
+#define OWN_FIRST_LIVE(h, out) do { if ((out) && (h)->opt_own_first_live) LAUNCH((h), "own_first_live", dim3(1), dim3(1), k_own_first_live, (const DevState*)(h)->d_state, (const float2*)(h)->tm, (const uint32_t*)(h)->seq, (out)); } while (0)
+#define OWN_GFL(h, out) (const DevState*)(h)->d_state, (const float2*)(h)->tm, ((h)->opt_own_first_live ? (out) : (unsigned long long*)nullptr)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
 {
     h->hot_valid = 0;
     Cam c = make_cam(h);
     c.srank = 0; c.sn = 1;
+    if (h->gfl_index && phase >= 1 && phase <= 3) c.first_live = (const int*)h->gfl_index;   // (behind exchanges 0 / 2: the word that came with key_index; everywhere else the one behind [key_splat | key_ids])
     const int time = h->tick;
     const dim3 b2(32, 8), g2(cdiv(h->w, 32), cdiv(h->h, 8));
     const bool in_frame = phase < 100 || phase >= 300;
@@ -2984,12 +2990,13 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
             Cam cl = c;
             if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }   // local keys carry slots; k_own_translate swaps in the creation numbers before they travel
             LAUNCH(h, "index_list", dim3(h->opt_index_blocks > 0 ? h->opt_index_blocks : LIST_BLOCKS), dim3(MAP_THREADS), k_index_list, (const DevState*)h->d_state, (const float4*)h->pc, (const float2*)h->tm, cl, time, h->list_v, h->key_index);
-            if (h->own_fast) LAUNCH(h, "own_translate", dim3(cdiv(h->P, 256)), dim3(256), k_own_translate, h->key_index, h->P, (const uint32_t*)h->seq, h->own_slot_img);
+            if (h->own_fast) LAUNCH(h, "own_translate", dim3(cdiv(h->P, 256)), dim3(256), k_own_translate, h->key_index, h->P, (const uint32_t*)h->seq, h->own_slot_img, OWN_GFL(h, h->gfl_index));   // (the word: behind the view-list scan, whose age rule removes surfels)
+            else OWN_FIRST_LIVE(h, h->gfl_index);
         } else {
             if (h->opt_vlist) hs_invalidate_view(h);   // no scan this frame: a device-side "valid" must never describe lists the host did not maintain
             index_pass(h, nullptr, time, true, 1);
+            OWN_FIRST_LIVE(h, h->gfl_index);
         }
-        OWN_FIRST_LIVE(h);   // (behind the view-list scan, whose age rule removes surfels)
         break;
     case 1: index_pass(h, nullptr, time, true, 2, h->own_fast ? h->own_slot_img : nullptr); fuse_pass(h, nullptr, 0.f, time, 1); break;   // attributes of the winners this rank owns, association among them | assoc_key: MIN
     case 2:                                                                                                 // verdicts decoded, update (owned), post-fuse projection | keys: MIN
@@ -3034,15 +3041,14 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         h->view_frame = 0;
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
         if (h->own_fast_raster) {   // [key_splat | key_ids] are one allocation, and so are their slot images: one launch translates both
-            LAUNCH(h, "own_translate", dim3(cdiv(2 * h->P, 256)), dim3(256), k_own_translate, h->key_splat, 2 * h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P);
-        }
-        OWN_FIRST_LIVE(h);   // (behind the clean and the append)
+            LAUNCH(h, "own_translate", dim3(cdiv(2 * h->P, 256)), dim3(256), k_own_translate, h->key_splat, 2 * h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P, OWN_GFL(h, h->gfl_splat));   // (the word: behind the clean and the append)
+        } else OWN_FIRST_LIVE(h, h->gfl_splat);
         break;
     }
     case 104:                                                                                               // ifx_owner_predict_phase: the local raster alone
         raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
-        OWN_FIRST_LIVE(h);   // (an upload / a deformation may have come in between)
+        OWN_FIRST_LIVE(h, h->gfl_splat);   // (an upload / a deformation may have come in between)
         break;
     case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,

@@ -2089,7 +2089,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()
-                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16 + 16, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word with the keys of exchanges 0 and 4
+                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

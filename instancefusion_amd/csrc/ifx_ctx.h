@@ -50,7 +50,7 @@ struct DevState {
     int fold_total;              // != 0: this frame's k_splat_resolve accumulated fold_acc itself (= the number of dense-test samples); k_frame_result folds and clears
     int fold_acc[16][4];         // partial sums by blockIdx.x & 15: vote mass, empty lattice pixels, lit dense-test samples, -
     int first_live;              // lowest live slot: the reference's "surfel 0" (drawn as id 0 = "no surfel" in every id-carrying image; ifx_map.hip key_id)
-    unsigned int append_ticket;  // (unused since round 5: k_append_scan publishes without a ticket)
+    unsigned int append_ticket;  // last-block ticket of k_vlist_flatten (k_append_scan, whose it was, publishes without one since round 5)
     int app_count0; unsigned int app_seq0, app_vln0;   // count / next_seq / vl_n[0] when the frame's new-surfel flags were taken (k_new_flags_count): k_append_scan's starting point
     unsigned int result_ticket;  // last-block ticket of k_splat_resolve when it also writes the frame result (FrameOut)
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
@@ -309,6 +309,7 @@ struct ifx {
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
+    int opt_vlist_one = 0;              // the view list's segment offsets and its concatenation in ONE launch (k_vlist_flatten: the last block publishes) instead of two; measured equal (1504 against 1503 frames/s in the driver-shaped window, tools/ab_driver.sh: a launch that only finds out that it has nothing to do costs the chain next to nothing when the next launch is already queued): off
     int opt_own_first_live = 1;         // sharded map: the reference's "surfel 0" is the lowest live creation number of any rank (ifx_map.hip FIRST_LIVE); 0: round 4's rule -- creation number 0 for ever (test switch)
     int opt_vote_per_mask = 1;          // instance votes: one launch per mask, in mask order, as the reference (IF/Core/InstanceFusion.cpp:986-1000) -- the order is part of the result while a packed counter's low half is negative (ifx_instance.hip k_vote_update_all); 0: round 4's one launch over all masks (experiments only)
     int opt_side_late = 0;              // a frame whose tracker ran ahead enqueues the announced next frame's side behind its own map passes instead of in front of them (measured: 1490 against 1510 frames/s -- the frame side then runs beside the next tracker instead of beside this frame's map passes; off)

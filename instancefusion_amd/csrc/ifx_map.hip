@@ -1472,6 +1472,54 @@ __global__ __launch_bounds__(MAP_THREADS) void k_vlist_concat(const DevState* __
     unsigned int* __restrict__ flat = (which ? flat_i : flat_a) + off;
     for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) flat[t] = raw[t];
 }
+// The two launches above in one (option vlist_one; measured equal, off): every block adds up the eight segment counters of its list itself (the scan's atomics were performed at the
+// memory side: plain loads behind the kernel boundary see them), copies its share, and the block that finishes LAST re-arms the counters, publishes the lengths and moves
+// first_live on -- one launch less on the frame's chain.
+__global__ __launch_bounds__(MAP_THREADS) void k_vlist_flatten(DevState* st, Cam c, const float2* __restrict__ tm, const unsigned int* __restrict__ raw_a, const unsigned int* __restrict__ raw_i,
+                                                               unsigned int* __restrict__ flat_a, unsigned int* __restrict__ flat_i)
+{
+    if (!st->vl_scan) return;
+    const int which = blockIdx.y, seg = blockIdx.x % LIST_SEGS;
+    unsigned int n = 0, off = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < LIST_SEGS; s_++) {
+        const unsigned int v = *list_ctr(c, 1 + which, s_);
+        off += s_ < seg ? v : 0u;
+        n = s_ == seg ? v : n;
+    }
+    const unsigned int* __restrict__ raw = (which ? raw_i : raw_a) + (size_t)seg * c.seg_cap;
+    unsigned int* __restrict__ flat = (which ? flat_i : flat_a) + off;
+    for (unsigned int t = (blockIdx.x / LIST_SEGS) * blockDim.x + threadIdx.x; t < n; t += blockDim.x * (gridDim.x / LIST_SEGS)) flat[t] = raw[t];
+    // the last block: everybody has read the counters (their values bound the loops above) before the ticket
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(&st->append_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x * gridDim.y - 1u);
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __hip_atomic_store(&st->append_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w_ = 0; w_ < 2; w_++) {
+        unsigned int run = 0;
+        for (int s_ = 0; s_ < LIST_SEGS; s_++) {
+            unsigned int* ctr = list_ctr(c, 1 + w_, s_);
+            const unsigned int v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the clean pass / the next scan
+            st->vl_seg_n[w_ * LIST_SEGS + s_] = v;
+            st->vl_seg_off[w_ * LIST_SEGS + s_] = run;
+            run += v;
+        }
+        st->vl_n[w_] = run;
+    }
+    {   // the scan applied the age rule to slots outside the list: the lowest live slot may have moved on
+        int f = st->first_live;
+        const int nn = st->count;
+        while (f < nn && !(tm[f].y > DEAD_TIME)) f++;
+        st->first_live = f;
+    }
+}
 
 // index-map projection (index_map.vert:40-66) of the view-list entries: the work of k_index_project on the slots that can be seen at all
 __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __restrict__ st, const float4* __restrict__ pc, const float2* __restrict__ tm, Cam c, int time,
@@ -2626,6 +2674,10 @@ static void view_scan(ifx* h, int time)
     // raw output in the clean pass's lists 1, 2 (free at this point of a frame and between frames), then concatenated into list_v / list_vi
     LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c,
            h->hot_valid ? (Hot*)h->hot : (Hot*)nullptr);   // (the age rule's tombstones go into the gathered copy too while it is valid)
+    if (h->opt_vlist_one) {
+        LAUNCH(h, "vlist_flatten", dim3(256, 2), dim3(MAP_THREADS), k_vlist_flatten, h->d_state, c, (const float2*)h->tm, h->list_b, h->list_c, h->list_v, h->list_vi);
+        return;
+    }
     LAUNCH(h, "vlist_offsets", dim3(1), dim3(64), k_vlist_offsets, h->d_state, c, (const float2*)h->tm);
     LAUNCH(h, "vlist_concat", dim3(256, 2), dim3(MAP_THREADS), k_vlist_concat, (const DevState*)h->d_state, c, h->list_b, h->list_c, h->list_v, h->list_vi);
 }

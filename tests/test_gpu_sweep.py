@@ -12,6 +12,8 @@ determinism: the exact sums do not depend on the order in which blocks and atomi
 
 Further down: bench.py's resident-frame path at 640x480 on four other scenes / motions, the instance table overflowing (> 96 instances over time) on that path, and the
 guard driven on purpose."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,6 +29,8 @@ DEGRADE = ("none", "near", "far", "holes", "saturated", "black")
 MOTION = ("still", "slow", "nominal", "fast", "jump", "spin", "dolly", "shake")
 # (scene seed, motion profile, degradation): 24 seeds; every profile three times, every degradation four times, no pair twice
 CASES = [(11 + 7 * i, MOTION[i % 8], DEGRADE[(i + i // 8) % 6]) for i in range(24)]
+# IFX_SWEEP_EXTRA=N: N more scene seeds (other pairs of profile and degradation) for a one-off wider run; its outcome is kept under profiles/
+CASES += [(1000 + 13 * i, MOTION[(3 * i + i // 8) % 8], DEGRADE[(5 * i + 1 + i // 6) % 6]) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA", "0")))]
 CONF = 3.0   # confidence threshold of the sweep's handles (reference default 10): surfels become stable inside the 8 frames, so that the id images, the clean pass's
              # stable-neighbour rules and the segmentation call have something to work on
 

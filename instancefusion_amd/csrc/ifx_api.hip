@@ -312,6 +312,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
     else if (s == "own_first_live") h->opt_own_first_live = value;
     else if (s == "vlist_one") h->opt_vlist_one = value;
+    else if (s == "overdue_rule") h->opt_overdue_rule = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
     else if (s == "cam_side") h->opt_cam_side = value;
     else if (s == "host_entry_async") h->opt_host_entry_async = value;

@@ -309,6 +309,7 @@ struct ifx {
     int opt_track_ahead = 1;            // with a hinted next frame: enqueue its tracker right behind the current frame, before the host decides about segmentation
     int tracked_ahead = 0;              // tick whose tracker is already on the queue (result parked in DevState::spec_*)
     int opt_side_gate = 0; hipEvent_t ev_gate = nullptr;   // (experiment) where the announced frame's image-only work may start: 0 at once, 1 behind the commit, 2 behind the frame
+    int opt_overdue_rule = 1;           // a list rebuild first applies the age rule that slots no list held have outlived (k_cull_frame); 0: round 4's scan, which let such a slot into the new list alive (test switch)
     int opt_vlist_one = 0;              // the view list's segment offsets and its concatenation in ONE launch (k_vlist_flatten: the last block publishes) instead of two; measured equal (1504 against 1503 frames/s in the driver-shaped window, tools/ab_driver.sh: a launch that only finds out that it has nothing to do costs the chain next to nothing when the next launch is already queued): off
     int opt_own_first_live = 1;         // sharded map: the reference's "surfel 0" is the lowest live creation number of any rank (ifx_map.hip FIRST_LIVE); 0: round 4's rule -- creation number 0 for ever (test switch)
     int opt_vote_per_mask = 1;          // instance votes: one launch per mask, in mask order, as the reference (IF/Core/InstanceFusion.cpp:986-1000) -- the order is part of the result while a packed counter's low half is negative (ifx_instance.hip k_vote_update_all); 0: round 4's one launch over all masks (experiments only)

@@ -1348,7 +1348,7 @@ static VlPlanes make_planes(const Cam& c)
 // the list), and LIST_VI, the stable slots outside it, which only the id render draws (it has no time window).  Unstable slots outside
 // the window are frozen (nothing updates them) and invisible to every render: they are on neither list.
 __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const float4* __restrict__ pc_in, float4* __restrict__ pc_rw, float2* __restrict__ tm, Cam c, VlPlanes P,
-                                                            int time, unsigned int* __restrict__ list, unsigned int* __restrict__ list_i, Hot* __restrict__ hot)
+                                                            int time, unsigned int* __restrict__ list, unsigned int* __restrict__ list_i, Hot* __restrict__ hot, int time_prev)
 {
     if (!st->vl_scan) return;
     float Tm[16], T[12];
@@ -1392,7 +1392,26 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                 const float4 p4 = p4s[r];
                 const float2 t = ts[r];
                 const float wv = t.y;
-                if (wv > DEAD_TIME) {
+                // A slot that NO list held during the last frames has not met the clean pass's age rule since the scan that left it out -- and may come into THIS list: the
+                // rule as of the last clean pass (time_prev) goes first, for every live slot.  It only grows with time while a slot is unlisted (nothing updates it), so one
+                // evaluation at time_prev stands for all the frames in between; for a slot the previous list did hold, that list's clean pass applied the same rule at the
+                // same time: nothing changes.  (Without it such a slot lived on into this frame's association and, at a forced scan before a download, into the map:
+                // tests/test_gpu_sweep.py, seed 2238 "shake" -- lists that survive several frames AND a map older than 20 frames.)
+                bool overdue = false;
+                if (wv > DEAD_TIME && time_prev >= 0) {
+                    int test = 1;
+                    if (wv == -1 || (((float)time_prev - wv) > 20 && p4.w < c.conf)) test = 0;
+                    if (wv > 0 && (float)time_prev - wv > (float)c.timeDelta) test = 1;
+                    overdue = !test;
+                }
+                if (overdue) {
+                    float4 q4 = p4;
+                    q4.w = -1.0f;
+                    pc_rw[i] = q4;
+                    tm[i] = make_float2(t.x, DEAD_TIME);
+                    if (hot) { hot[i].pc = q4; hot[i].tm = make_float2(t.x, DEAD_TIME); }
+                    dead++;
+                } else if (wv > DEAD_TIME) {
                     in = near_frustum(xf_point(T, v3m(p4.x, p4.y, p4.z)), reach, P, c.maxDepth);
                     if (in && wv > 0.f && (float)time - wv > (float)c.timeDelta) {   // outside the time window for good
                         in = false;
@@ -2673,7 +2692,8 @@ static void view_scan(ifx* h, int time)
     c.srank = 0; c.sn = 1;
     // raw output in the clean pass's lists 1, 2 (free at this point of a frame and between frames), then concatenated into list_v / list_vi
     LAUNCH(h, "cull_frame", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_cull_frame, h->d_state, (const float4*)h->pc, (float4*)h->pc, (float2*)h->tm, c, make_planes(c), time, h->list_b, h->list_c,
-           h->hot_valid ? (Hot*)h->hot : (Hot*)nullptr);   // (the age rule's tombstones go into the gathered copy too while it is valid)
+           h->hot_valid ? (Hot*)h->hot : (Hot*)nullptr,   // (the age rule's tombstones go into the gathered copy too while it is valid)
+           h->opt_overdue_rule ? std::max(0, std::min(time, h->last_clean_time)) : -1);   // (the last clean pass any list can have run: the age rule unlisted slots have outlived since)
     if (h->opt_vlist_one) {
         LAUNCH(h, "vlist_flatten", dim3(256, 2), dim3(MAP_THREADS), k_vlist_flatten, h->d_state, c, (const float2*)h->tm, h->list_b, h->list_c, h->list_v, h->list_vi);
         return;

@@ -121,18 +121,23 @@ def test_seed_sweep_against_the_oracle(ifx, orc, seed, motion, deg):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("seed,motion", [(301, "nominal"), (302, "fast"), (303, "jump"), (304, "shake")])
-def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion):
+@pytest.mark.parametrize("seed,motion,small", [(301, "nominal", 0), (302, "fast", 0), (303, "jump", 0), (304, "shake", 0), (2238, "shake", 0),
+                                               (901, "shake", 1), (902, "slow", 1), (903, "still", 1), (904, "nominal", 1)] +
+                         [(2000 + 17 * i, MOTION[(i + 1) % 8], 0) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_640", "0")))])   # (IFX_SWEEP_EXTRA_640=N: a one-off wider run)
+def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, small):
     """bench.py's own frame path -- frames resident in HBM, the next frame announced, its tracker parked behind every frame, default options (lazy compaction, cached view
     lists, fused clean + raster walk, hot records, the id image on the lattice) -- at the benchmark's resolution on OTHER scenes and camera motions than the one every other
     640x480 test uses: 24 frames and a segmentation call on the resident frame; every pose, the instance table, and at the end count, labels and the whole map against the
-    oracle.  (`fast` rebuilds the view lists every frame, `jump` leaves the correspondence gates once.)"""
+    oracle.  (`fast` rebuilds the view lists every frame, `jump` leaves the correspondence gates once.)
+    Nothing here reads a count between the frames (that forces a list rebuild): the view lists live as long as the motion lets them.  Seed 2238 `shake` and the `small`
+    cases (320x240, 32 frames) are maps OLDER THAN 20 FRAMES under lists that survive several frames: the clean pass's age rule (copy_unstable.vert:160-172) removes
+    unstable surfels that no list holds -- a list rebuild must apply the rule they have outlived before it takes them in (2238 found that it did not: 519 surfels too many)."""
     import torch
 
     from instancefusion_amd import synth
 
-    Wb, Hb, NFb = 640, 480, 24
-    Kb = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    Wb, Hb, NFb = (320, 240, 32) if small else (640, 480, 24)
+    Kb = dict(fx=264.0, fy=264.0, cx=160.0, cy=120.0) if small else dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
     scene = synth.Scene(seed)
     st = synth.make_stream_from_poses(synth.trajectory_profile(motion, NFb, seed), scene, Wb, Hb, noise_seed=seed + 1, **Kb)
     orc.set_threads(orc.usable_cores())

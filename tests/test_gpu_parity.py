@@ -743,7 +743,7 @@ def test_lost_tracker_experiments_are_bit_identical(ifx):
     _tracker_variants_equal(ifx, [dict(), dict(model_fused=1), dict(icp_px=3)])
 
 
-@pytest.mark.parametrize("world,zero_dies", [(2, 0), (3, 0), (2, 1), (3, 1), (2, -1)])
+@pytest.mark.parametrize("world,zero_dies", [(2, 0), (3, 0), (2, 1), (3, 1), (2, -1), (2, 30)])
 def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images
     MIN-reduced, winners' attributes SUM-merged between the eight phases of a frame) against one GPU: G handles in one process, the
@@ -752,7 +752,8 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
     zero_dies: the reference's "surfel 0" (id 0 = "no surfel": it occludes, but is never associated or voted for) is removed in the middle and the next live
     surfel takes its place (from then on IT is never associated: the measurement at its pixel makes a new surfel instead) -- on one GPU the lowest live slot
     (DevState::first_live), on the sharded map the lowest live creation number of ANY rank (MIN-reduced with the keys of exchanges 0 and 4).
-    zero_dies = -1: the same with the rule switched off on the ranks (option own_first_live = 0, round 4's behaviour) -- the maps must then DIFFER: the scenario tests the rule."""
+    zero_dies = -1: the same with the rule switched off on the ranks (option own_first_live = 0, round 4's behaviour) -- the maps must then DIFFER: the scenario tests the rule.
+    zero_dies = 30: no such scenario, but 30 frames instead of 8."""
     import torch
 
     from instancefusion_amd import dist as ifd
@@ -760,8 +761,12 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
 
     st = small_stream
     NF = 8
-    d_rgb = torch.from_numpy(st["rgb"][:NF]).cuda()
-    d_dep = torch.from_numpy(st["depth"][:NF].view(np.int16)).cuda()
+    src = list(range(NF))
+    if zero_dies == 30:   # a LONG life of the map (the stream forth and back): the clean pass's 20-frame age rule at work on shards whose view lists live several frames
+        NF, zero_dies = 30, 0
+        src = [(i % 18) if (i % 18) < 10 else 18 - (i % 18) for i in range(NF)]
+    d_rgb = torch.from_numpy(st["rgb"][src]).cuda()
+    d_dep = torch.from_numpy(st["depth"][src].view(np.int16)).cuda()
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
     for e in efs:

@@ -173,6 +173,59 @@ def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, sma
     g.close(); o.close()
 
 
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("seed,motion", [(3001, "nominal")] + [(3100 + 19 * i, MOTION[(2 * i + 1 + i // 4) % 8]) for i in range(int(os.environ.get("IFX_SWEEP_LONG", "0")))])
+def test_long_run_with_calls_on_the_resident_frame_path(ifx, orc, seed, motion):
+    """The same path over a LONGER life of the map: 56 frames at 640x480 (the age rule of the clean pass at work from frame 21 on, view lists that live several frames,
+    tombstones piling up towards a compaction) with a segmentation call on the resident frame every 9th frame, with and without superpixels in turn -- the gated label
+    scan, the superpixels run ahead of a call, votes on a map that keeps changing.  Every pose and every whetherDoSegmentation decision; after every call the instance table and the labels; at the end the whole
+    map.  (IFX_SWEEP_LONG=N: N more scenes / motions, a one-off wider run.)"""
+    import torch
+
+    from instancefusion_amd import synth
+
+    Wb, Hb, NFb = 640, 480, 56
+    Kb = dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    scene = synth.Scene(seed)
+    st = synth.make_stream_from_poses(synth.trajectory_profile(motion, NFb, seed), scene, Wb, Hb, noise_seed=seed + 1, **Kb)
+    orc.set_threads(orc.usable_cores())
+    d_rgb = torch.from_numpy(st["rgb"]).cuda()
+    d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    g = ifx.ElasticFusion(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
+    g.set_option("compact_divisor", 24)   # (a compaction inside the run: tombstones reach 1 / 24 of the slots once the age rule works)
+    o = orc.Oracle(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
+    inst = ifx.InstanceFusion(g)
+    calls = 0
+    for i in range(NFb):
+        if i + 1 < NFb:
+            g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+        g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+        want = inst.whetherDoSegmentation(100 + i)
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        assert want == o.should_segment(100 + i), i   # (the decision: empty lattice pixels of the id image, vote mass under it, the cadence)
+        pg = g.trajectory(1)[0]
+        if np.isfinite(po).all():
+            assert_pose_equal(pg, po, f"{motion} frame {i}")
+        else:
+            assert pose_eq(pg, po), i
+        if i % 9 == 8 or i == NFb - 1:
+            masks, cls = synth.canned_masks(st["obj"][i], scene)
+            if masks.shape[0]:
+                sp = calls % 2 == 1
+                inst.ProcessSegmentation(None, None, masks, cls, i, superpixels=sp)
+                o.process_segmentation(st["rgb"][i], st["depth"][i], masks, cls, i, flags=2 if sp else 0)
+                calls += 1
+                assert np.array_equal(inst.getInstanceTable(), o.instance_table()), i
+                assert np.array_equal(inst.labels(), o.labels()), i
+    assert g.count == o.count
+    mg, mo = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg[k], mo[k], equal_nan=True), k
+    assert g.tracker_range_exceeded() == 0
+    g.close(); o.close()
+
+
 @pytest.mark.timeout(900)
 def test_instance_table_overflow_on_the_resident_frame_path(ifx, orc):
     """> 96 instances over time under bench.py's own frame path: frames resident in HBM, the next frame announced and its tracker parked behind every frame, the

@@ -84,11 +84,15 @@ def test_seed_sweep_against_the_oracle(ifx, orc, seed, motion, deg):
     g2 = ifx.ElasticFusion(w=W, h=H, max_surfels=400000, confidence=CONF, **K)     # the same sequence a second time: run-to-run determinism
     gc = ifx.ElasticFusion(w=W, h=H, max_surfels=400000, confidence=CONF, **K)     # compacts every frame: slot numbers are the oracle's indices, the id images can be compared
     gc.set_option("compact_every_frame", 1)
+    gh = ifx.ElasticFusion(w=W, h=H, max_surfels=400000, confidence=CONF, **K)     # the host entry with every next frame announced (ifx_hint_next_frame): look-ahead, parked tracker
     inst, instc = ifx.InstanceFusion(g), ifx.InstanceFusion(gc)
     finite = True
     for i in range(NF):
         po = o.process_frame(rgb[i], dep[i])
         pg, p2, pc = g.processFrame(rgb[i], dep[i]), g2.processFrame(rgb[i], dep[i]), gc.processFrame(rgb[i], dep[i])
+        if i + 1 < NF:
+            gh.hint_next_frame(rgb[i + 1], dep[i + 1])
+        assert pose_eq(gh.processFrame(rgb[i], dep[i]), pg), f"the announced-frame entry differs at frame {i}"
         finite = finite and bool(np.isfinite(po).all())
         if np.isfinite(po).all():
             assert_pose_equal(pg, po, f"{motion}/{deg} frame {i}")
@@ -108,22 +112,25 @@ def test_seed_sweep_against_the_oracle(ifx, orc, seed, motion, deg):
         assert np.array_equal(instc.getInstanceTable(), o.instance_table())
         assert np.array_equal(instc.labels(), o.labels())
         assert np.array_equal(inst.labels(), o.labels())
-    mg, m2, mc, mo = g.download(), g2.download(), gc.download(), o.download()
+    assert gh.lookahead_stats()["host_hinted"] == NF - 1
+    mg, m2, mc, mo, mh = g.download(), g2.download(), gc.download(), o.download(), gh.download()
     for k in MAP_KEYS:
         assert np.array_equal(mc[k], mo[k], equal_nan=True), k
         assert np.array_equal(mg[k], mo[k], equal_nan=True), k
-        if k != "votes":                                          # (g2 ran no segmentation call)
+        if k != "votes":                                          # (g2 and gh ran no segmentation call)
             assert np.array_equal(mg[k] if k != "col" else mg[k][:, 0], m2[k] if k != "col" else m2[k][:, 0], equal_nan=True), k
+            assert np.array_equal(mg[k] if k != "col" else mg[k][:, 0], mh[k] if k != "col" else mh[k][:, 0], equal_nan=True), k
     # the exact-sum range guard: nothing in the sweep may leave the range in which the sums are order-independent (a case that did would not be REQUIRED to agree)
     assert g.tracker_range_exceeded() == 0 and gc.tracker_range_exceeded() == 0, (g.tracker_range_exceeded(), motion, deg)
-    for x in (g, g2, gc, o):
+    for x in (g, g2, gc, gh, o):
         x.close()
 
 
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("seed,motion,small", [(301, "nominal", 0), (302, "fast", 0), (303, "jump", 0), (304, "shake", 0), (2238, "shake", 0),
                                                (901, "shake", 1), (902, "slow", 1), (903, "still", 1), (904, "nominal", 1)] +
-                         [(2000 + 17 * i, MOTION[(i + 1) % 8], 0) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_640", "0")))])   # (IFX_SWEEP_EXTRA_640=N: a one-off wider run)
+                         [(2000 + 17 * i, MOTION[(i + 1) % 8], 0) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_640", "0")))] +   # (IFX_SWEEP_EXTRA_640=N: a one-off wider run)
+                         [(2500 + 23 * i, MOTION[(3 * i + 2) % 8], 2) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_1280", "0")))])   # (IFX_SWEEP_EXTRA_1280=N: the same at 1280x960 -- tiled rasteriser, persistent coarsest level)
 def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, small):
     """bench.py's own frame path -- frames resident in HBM, the next frame announced, its tracker parked behind every frame, default options (lazy compaction, cached view
     lists, fused clean + raster walk, hot records, the id image on the lattice) -- at the benchmark's resolution on OTHER scenes and camera motions than the one every other
@@ -136,16 +143,17 @@ def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, sma
 
     from instancefusion_amd import synth
 
-    Wb, Hb, NFb = (320, 240, 32) if small else (640, 480, 24)
-    Kb = dict(fx=264.0, fy=264.0, cx=160.0, cy=120.0) if small else dict(fx=528.0, fy=528.0, cx=320.0, cy=240.0)
+    Wb, Hb, NFb = {0: (640, 480, 24), 1: (320, 240, 32), 2: (1280, 960, 14)}[small]
+    Kb = dict(fx=528.0 * Wb / 640, fy=528.0 * Wb / 640, cx=Wb / 2.0, cy=Hb / 2.0)
     scene = synth.Scene(seed)
     st = synth.make_stream_from_poses(synth.trajectory_profile(motion, NFb, seed), scene, Wb, Hb, noise_seed=seed + 1, **Kb)
     orc.set_threads(orc.usable_cores())
     d_rgb = torch.from_numpy(st["rgb"]).cuda()
     d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
     torch.cuda.synchronize()
-    g = ifx.ElasticFusion(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
-    o = orc.Oracle(w=Wb, h=Hb, max_surfels=2_000_000, confidence=CONF, **Kb)
+    cap = 6_000_000 if small == 2 else 2_000_000
+    g = ifx.ElasticFusion(w=Wb, h=Hb, max_surfels=cap, confidence=CONF, **Kb)
+    o = orc.Oracle(w=Wb, h=Hb, max_surfels=cap, confidence=CONF, **Kb)
     inst = ifx.InstanceFusion(g)
     for i in range(NFb):
         if i + 1 < NFb:

@@ -129,7 +129,7 @@ def test_seed_sweep_against_the_oracle(ifx, orc, seed, motion, deg):
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("seed,motion,small", [(301, "nominal", 0), (302, "fast", 0), (303, "jump", 0), (304, "shake", 0), (2238, "shake", 0),
                                                (901, "shake", 1), (902, "slow", 1), (903, "still", 1), (904, "nominal", 1)] +
-                         [(2000 + 17 * i, MOTION[(i + 1) % 8], 0) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_640", "0")))] +   # (IFX_SWEEP_EXTRA_640=N: a one-off wider run)
+                         [(2000 + 17 * i, MOTION[(i + 1 + i // 8) % 8], 0) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_640_FROM", "0")), int(os.environ.get("IFX_SWEEP_EXTRA_640", "0")))] +   # (IFX_SWEEP_EXTRA_640=N: a one-off wider run)
                          [(2500 + 23 * i, MOTION[(3 * i + 2) % 8], 2) for i in range(int(os.environ.get("IFX_SWEEP_EXTRA_1280", "0")))])   # (IFX_SWEEP_EXTRA_1280=N: the same at 1280x960 -- tiled rasteriser, persistent coarsest level)
 def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, small):
     """bench.py's own frame path -- frames resident in HBM, the next frame announced, its tracker parked behind every frame, default options (lazy compaction, cached view

@@ -182,7 +182,7 @@ def test_resident_frame_path_at_640x480_other_scenes(ifx, orc, seed, motion, sma
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("seed,motion", [(3001, "nominal")] + [(3100 + 19 * i, MOTION[(2 * i + 1 + i // 4) % 8]) for i in range(int(os.environ.get("IFX_SWEEP_LONG", "0")))])
+@pytest.mark.parametrize("seed,motion", [(3001, "nominal")] + [(3100 + 19 * i, MOTION[(2 * i + 1 + i // 4) % 8]) for i in range(int(os.environ.get("IFX_SWEEP_LONG_FROM", "0")), int(os.environ.get("IFX_SWEEP_LONG", "0")))])
 def test_long_run_with_calls_on_the_resident_frame_path(ifx, orc, seed, motion):
     """The same path over a LONGER life of the map: 56 frames at 640x480 (the age rule of the clean pass at work from frame 21 on, view lists that live several frames,
     tombstones piling up towards a compaction) with a segmentation call on the resident frame every 9th frame, with and without superpixels in turn -- the gated label

@@ -350,7 +350,14 @@ int ifx_compact(ifx_t* h);        /* order-preserving removal of tombstones */
  *   "fold_result" 0       -- the frame result by a launch of its own instead of the last block of the prediction's resolve
  *   "lazy_ids" 0          -- render the whole id image every frame (default: the lattice whetherDoSegmentation samples; the rest on demand)
  *   "fold_finish" 0, "seg_device" 0, "seg_aside" 0, "ff_union" 0, "ff_rounds" n -- the earlier forms of the end-of-frame sums and of the segmentation call's
- *                           schedule (host-driven / on the main stream / relaxation-only flood fill / length of the fixed relaxation schedule); identical results */
+ *                           schedule (host-driven / on the main stream / relaxation-only flood fill / length of the fixed relaxation schedule); identical results
+ *   "clean_raster" 0, "hot_records" 0, "vlist_one" 1 -- round 5's map-pass forms off / on: the clean pass and the prediction's raster as ONE walk of the view list; the
+ *                           gathered 64-byte copy of the hot fields; list offsets + concatenation in one launch (measured equal: off).  Identical results
+ *   "host_entry_async" 1  -- ifx_process_frame returns when the frame's POSE is known (see there); "vote_per_mask" 0 -- the instance votes of a call in ONE launch over all
+ *                           masks instead of one per mask in mask order (experiments only: the order is part of the reference's result while a packed counter's low half is negative)
+ *   "overdue_rule" 0, "own_first_live" 0 -- test switches: a view-list rebuild without the age rule its newcomers have outlived / the sharded map's "surfel 0" fixed at
+ *                           creation number 0 (round 4's behaviour of both: results then differ from the reference's in the cases tests/test_gpu_sweep.py and
+ *                           test_owner_sharded_map_emulated hold) */
 int ifx_set_option(ifx_t* h, const char* name, int value);
 
 /* R32I surfel-id image after fusion (getSurfelIdsAfterFusionGpu, ElasticFusionInterface.h:90-102):

@@ -147,9 +147,15 @@ def _minworker(rank, world, port, q):
     z = rng.uniform(0.3, 9.0, 5000).astype(np.float32).view(np.uint32).astype(np.uint64)
     keys = (z << np.uint64(32)) | rng.randint(0, 1 << 22, 5000).astype(np.uint64)
     keys[rng.rand(5000) < 0.4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    # one word behind the image, in the same collective (exchanges 0 / 2 / 4 of the owner-sharded frame): this rank's lowest live creation number -- the reference's
+    # "surfel 0" is the lowest of any rank; a rank without a live surfel publishes all ones, the identity of the unsigned minimum
+    keys = np.concatenate([keys, np.array([0xFFFFFFFFFFFFFFFF if rank == 1 else 4711], np.uint64)])
     t = torch.from_numpy(keys.view(np.int64).copy())
     sharded.KeyExchange.reduce_min([t], d)
-    q.put((rank, keys, t.numpy().view(np.uint64).copy()))
+    once = t.numpy().view(np.uint64).copy()
+    sharded.KeyExchange.reduce_min([t], d)          # exchange 2 reduces the reduced word again: a minimum of equal values
+    assert np.array_equal(t.numpy().view(np.uint64), once)
+    q.put((rank, keys, once))
     d.barrier()
     d.destroy_process_group()
 
@@ -170,6 +176,7 @@ def test_key_image_min_allreduce_gloo():
     want = np.minimum(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], want) and np.array_equal(res[1][2], want)
     assert (want == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() > 0
+    assert want[-1] == 4711 and np.int32(np.uint32(want[-1] & np.uint64(0xFFFFFFFF))) == 4711   # (the kernels read the low word as an int: FIRST_LIVE)
 
 
 def _segworker(rank, world, port, q):

@@ -2,7 +2,9 @@
 # the round's full check on the GPU box: the GPU suite, then the driver-shaped bench line -> gpurun_out/<tag>_gputests.txt, <tag>_bench_driver.json
 TAG=${1:-r05_x}
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 > gpurun_out/${TAG}_gputests.txt
+# (the full output goes to a file as it comes: a call that runs into its time limit still says how far it got; --durations names the slow tests)
+python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${TAG}_gputests_full.txt 2>&1
+grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" gpurun_out/${TAG}_gputests_full.txt | grep -v "^$" | tail -16 > gpurun_out/${TAG}_gputests.txt
 cat gpurun_out/${TAG}_gputests.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
 python - <<PY

@@ -37,6 +37,30 @@ int main(int argc, char** argv)
             }
             return 0;
         }
+        if (mode == "klgpeek") {   // klgpeek FILE W H OUT AHEAD THREADS: peekNext() before every getNext(); the dump holds what was PEEKED, "peeked N same M" on stdout
+            Resolution::getInstance(std::atoi(argv[3]), std::atoi(argv[4]));
+            RawLogReader r(argv[2], false);
+            r.setReadAhead(std::atoi(argv[6]), std::atoi(argv[7]));
+            std::ofstream f(argv[5], std::ios::binary);
+            const size_t P = (size_t)Resolution::getInstance().numPixels();
+            int peeked = 0, same = 0, frames = 0;
+            std::vector<unsigned char> rgbCopy(P * 3);
+            std::vector<unsigned short> depthCopy(P);
+            while (r.hasMore()) {
+                const unsigned char* pr = nullptr;
+                const unsigned short* pd = nullptr;
+                const bool ok = r.peekNext(pr, pd);
+                if (ok) { std::memcpy(rgbCopy.data(), pr, P * 3); std::memcpy(depthCopy.data(), pd, P * 2); peeked++; }   // (what a caller would hand to ifx_hint_next_frame)
+                r.getNext();
+                frames++;
+                if (ok && pr == r.rgb && pd == r.depth && std::memcmp(rgbCopy.data(), r.rgb, P * 3) == 0 && std::memcmp(depthCopy.data(), r.depth, P * 2) == 0) same++;
+                f.write((const char*)&r.timestamp, 8);
+                f.write((const char*)(ok ? depthCopy.data() : r.depth), (std::streamsize)P * 2);
+                f.write((const char*)(ok ? rgbCopy.data() : r.rgb), (std::streamsize)P * 3);
+            }
+            std::printf("peeked %d same %d frames %d\n", peeked, same, frames);
+            return 0;
+        }
         if (mode == "npz") {
             MaskReplay rp(argv[2]);
             MaskResult res;

@@ -80,6 +80,29 @@ def test_raw_log_reader_get_back_under_read_ahead(checker, tmp_path):
     assert ts[4] == ts[5]                      # getBack re-delivers the frame it was called on
 
 
+def test_raw_log_reader_peek_next_hands_out_what_get_next_publishes(checker, tmp_path):
+    """LogReader::peekNext (the reader's read-ahead as the source of ifx_hint_next_frame): the buffers it names are the ones the next getNext() publishes -- same
+    addresses (the announced-frame entry recognises its frame by them), same content -- for every frame; without read-ahead there is nothing to peek at."""
+    from instancefusion_amd import logio
+
+    w, h, n = 64, 48, 13
+    rng = np.random.default_rng(4)
+    klg = str(tmp_path / "p.klg")
+    wr = logio.RawLogWriter(klg, depth="zlib", image="jpeg")
+    for k in range(n):
+        wr.add(100 * k, rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 8000, (h, w), dtype=np.uint16))
+    wr.close()
+    plain = str(tmp_path / "plain.bin")
+    subprocess.run([checker, "klg", klg, str(w), str(h), plain, "0", "0"], check=True, capture_output=True, timeout=60)
+    for ahead, threads in (("6", "3"), ("2", "1"), ("0", "0")):
+        out = str(tmp_path / f"peek{ahead}.bin")
+        r = subprocess.run([checker, "klgpeek", klg, str(w), str(h), out, ahead, threads], check=True, capture_output=True, text=True, timeout=60)
+        peeked, same, frames = (int(r.stdout.split()[k]) for k in (1, 3, 5))
+        assert frames == n - 1                                      # (RawLogReader never delivers the last frame: RawLogReader.cpp:134-137)
+        assert peeked == same == (frames if threads != "0" else 0), r.stdout
+        assert open(out, "rb").read() == open(plain, "rb").read()   # what was peeked at is the stream the synchronous reader delivers
+
+
 def _test_image(w, h, seed):
     """smooth structure + texture + hard edges + saturated colours: exercises AC runs, EOB, ZRL, chroma upsampling edges and clamping"""
     rng = np.random.default_rng(seed)

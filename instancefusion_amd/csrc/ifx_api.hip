@@ -1,4 +1,5 @@
 // ifx_api.hip -- handle life cycle, frame orchestration and the data-movement half of the C-ABI.
+#include <climits>
 #include "ifx_ctx.h"
 #include <string.h>
 #include <stdio.h>
@@ -1566,6 +1567,7 @@ extern "C" int ifx_map_upload(ifx_t* h, int n, const float* pc, const float* nr,
     h->seg_counts_valid = 0;
     h->map_external = 1;
     h->hot_valid = 0;
+    h->age_epoch = INT_MAX;   // the uploaded surfels meet the clean pass's age rule from the next clean pass on (ifx_map.hip age_rule_gone)
     // spatially sharded map: this rank keeps the rows it owns (owner = hash of the uploaded position); creation numbers = the rows' indices
     const int n_all = n;
     std::vector<uint32_t> keep;
@@ -1629,6 +1631,7 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
     memcpy(hs.last_pose, pose16, 64);
     pose_inverse(hs.pose, hs.pose_inv);
     HIPCHK(h, hipMemcpy(h->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    if (tick != h->tick) h->age_epoch = INT_MAX;   // the clock jumps: the age rule is evaluated per frame from the next clean pass on (read_state above reaped what was overdue)
     h->tick = tick;
     return IFX_OK;
 }

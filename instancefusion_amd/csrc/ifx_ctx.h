@@ -421,6 +421,7 @@ struct ifx {
     uint32_t *list_v = nullptr, *list_vi = nullptr;   // [8 x list_seg_cap] the cached view lists, flat (lengths: DevState::vl_n): inside / outside the time window
     int view_frame = 0;                 // the frame being enqueued went through the view list (its end-of-frame raster may too)
     int view_block = 0;                 // the pose was replaced after the view-list decision of this frame (pose adoption): the frame takes the per-pass culls
+    int age_epoch = 0;                  // first clean pass that saw the store in its present state (ifx_map.hip age_rule_gone); INT_MAX: none yet since an upload / a jump of the clock
     int last_clean_time = 0;            // time of the last clean pass (the age rule a forced scan applies to the slots outside the list)
     int view_dirty = 0;                 // frames ran through the view list since the last forced scan: slots outside it may have outlived the age rule
     int opt_vlist = 1;                  // frame path through the cached view list (0: one cull per pass over all slots, the round-1 path)

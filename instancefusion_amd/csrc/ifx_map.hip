@@ -11,6 +11,7 @@
 //  * deletion leaves tombstones (conf = -1, lastTime = -1e9) and ifx_compact removes them with an
 //    order-preserving scan + scatter when asked or when too many accumulate, instead of moving the
 //    whole map through a second buffer every frame.
+#include <climits>
 #include "ifx_ctx.h"
 #include <string.h>
 
@@ -69,7 +70,7 @@ __device__ inline v3 get_normal_f(const float* depth, int w, int h, int px, int 
 // A consumer block works on segment blockIdx % LIST_SEGS (the segments hold interleaved chunks, so they are equally long up to one chunk).
 #define LIST_SEGS IFX_LIST_SEGS
 #define LIST_CTR_STRIDE IFX_LIST_CTR_STRIDE   // uints between counters: 128 B
-struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; const int* first_live; int raw_slots; };   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
+struct Cam { float fx, fy, cx, cy; int w, h; float maxDepth, conf; int timeDelta; int srank, sn; unsigned int seg_cap; unsigned int* lctr; const uint32_t* seq; int own_n, own_rank; const int* first_live; int raw_slots; int age_epoch; };   // age_epoch: first clean pass that saw the store as it is (age_rule_gone; fills the struct's tail padding)   // seq / own_n / own_rank: spatially sharded map (this handle stores the surfels it owns; ids in keys and images are creation numbers)   // srank / sn: this rank's slice of the slots in the projection passes (sharded mode); seg_cap / lctr: capacity of one list segment, the counters [3 lists][LIST_SEGS]
 // Loads of the surfel store by the passes that touch a surfel ONCE per frame (the scan, the list walkers' gathers): with IFX_NT they carry the non-temporal hint, so that the
 // ~100-450 MB of lines they pull through per frame do not evict the tracker's working set (pyramids, prediction: tens of MB) from L2 / the Infinity Cache.
 #ifdef IFX_NT
@@ -157,6 +158,7 @@ static Cam make_cam(ifx* h)
     c.seg_cap = h->list_seg_cap; c.lctr = h->d_list_ctr;
     c.seq = h->seq; c.own_n = h->own ? h->own_g : 0; c.own_rank = h->own ? h->cfg.rank : 0;
     c.first_live = (h->own && h->gfl_splat) ? (const int*)h->gfl_splat : &h->d_state->first_live; c.raw_slots = 0;   // (sharded map: the low word of the reduced lowest live creation number)
+    c.age_epoch = h->age_epoch;
     return c;
 }
 
@@ -1293,6 +1295,26 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 }
 
 
+// The age rule of the clean pass (copy_unstable.vert:154-172: `lastTime == -1`, or unstable and unseen for more than 20 frames -> removed; kept whatever else says once
+// `lastTime > 0 && time - lastTime > timeDelta`) for a slot NO view list holds.  The reference evaluates it at every frame; here such a slot is looked at when a scan or
+// the walk of first_live comes by.  Nothing updates an unlisted slot, so whether one of the per-frame evaluations of [epoch, t] has removed it has a closed form: the
+// rule fails on the frames T with 20 < T - lastTime (and, for lastTime > 0, T - lastTime <= timeDelta: from there on the slot is exempt FOR GOOD -- one evaluation at a
+// late t would see the exemption and keep what the reference removed at age 21).  `epoch` = the first clean pass that saw the store in this state (0 for
+// a map that grew here; the first frame after an upload: an uploaded surfel meets the rule from there on, whatever its times say about the frames before).
+__device__ __forceinline__ bool age_rule_gone(float wv, float conf, int t, const Cam& c)
+{
+    if (t < c.age_epoch) return false;
+    if (wv == -1.f) return true;
+    if (!(conf < c.conf)) return false;
+    float T = (float)t;
+    if (wv > 0.f) {
+        float Tc = floorf(wv + (float)c.timeDelta);          // the last frame at which the slot is not yet exempt
+        if (Tc - wv > (float)c.timeDelta) Tc -= 1.f;
+        T = fminf(T, Tc);
+        if (T < (float)c.age_epoch) return false;
+    }
+    return T - wv > 20.f;
+}
 // ------------------------------------------------------------------ view list (frame path)
 // The three culls of a frame (index map before the fusion, index map + clean after it, raster after the clean) all
 // look at the map from the frame's pose, and consecutive frames look from almost the same pose.  k_cull_frame therefore
@@ -1305,10 +1327,11 @@ __global__ __launch_bounds__(MAP_THREADS) void k_clean_list(DevState* st, const 
 // has nothing to do returns at its first instruction.  Results are those of the per-pass culls bit for bit: the list is a
 // superset, every pass re-tests its entries exactly.
 // Slots outside the list cannot be seen, matched or updated while it is valid; the one thing the clean pass would still do
-// to them is the age rule (copy_unstable.vert:166: unstable and not seen for 20 frames -> removed), which the scan applies
-// to the slots it leaves out.  Between two scans such a slot may outlive its deadline by a few frames, invisible to every
-// pass; ifx_vlist_reap forces a scan before anything that looks at the whole store (count, download, compaction, labels,
-// kNN, segmentation statistics).
+// to them is the age rule (copy_unstable.vert:166: unstable and not seen for 20 frames -> removed).  Every scan applies it,
+// as of the last clean pass, to every live slot before it builds the list (age_rule_gone).  Between two scans such a slot
+// may outlive its deadline by a few frames, invisible to every pass -- but for one thing: it can be the map's first live
+// slot, "surfel 0", so k_append_scan evaluates the same rule where it moves first_live on.  ifx_vlist_reap forces a scan
+// before anything that looks at the whole store (count, download, compaction, labels, kNN, segmentation statistics).
 __global__ void k_vlist_decide(DevState* st, unsigned int* lctr, int force)
 {
     if (threadIdx.x != 0) return;
@@ -1392,18 +1415,14 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                 const float4 p4 = p4s[r];
                 const float2 t = ts[r];
                 const float wv = t.y;
-                // A slot that NO list held during the last frames has not met the clean pass's age rule since the scan that left it out -- and may come into THIS list: the
-                // rule as of the last clean pass (time_prev) goes first, for every live slot.  It only grows with time while a slot is unlisted (nothing updates it), so one
-                // evaluation at time_prev stands for all the frames in between; for a slot the previous list did hold, that list's clean pass applied the same rule at the
-                // same time: nothing changes.  (Without it such a slot lived on into this frame's association and, at a forced scan before a download, into the map:
-                // tests/test_gpu_sweep.py, seed 2238 "shake" -- lists that survive several frames AND a map older than 20 frames.)
-                bool overdue = false;
-                if (wv > DEAD_TIME && time_prev >= 0) {
-                    int test = 1;
-                    if (wv == -1 || (((float)time_prev - wv) > 20 && p4.w < c.conf)) test = 0;
-                    if (wv > 0 && (float)time_prev - wv > (float)c.timeDelta) test = 1;
-                    overdue = !test;
-                }
+                // A slot that NO list held during the last frames has not met the clean pass's age rule since the scan that left it out -- and may come into THIS list: every
+                // live slot first meets the rule as the clean passes up to the last one (time_prev) would have applied it (age_rule_gone; for a slot the previous list did hold,
+                // that list's clean passes applied the same rule at the same times: nothing changes).  (Without it such a slot lived on into this frame's association and, at a
+                // forced scan before a download, into the map: tests/test_gpu_sweep.py, seed 2238 "shake" -- lists that survive several frames AND a map older than 20 frames.)
+                // The rule of the frame BEING ENQUEUED is not applied here: the reference removes such a surfel at the END of that frame, and until then it can still be the
+                // map's first live surfel ("surfel 0", whose id reads 0).  A slot this list leaves out stays as it is -- invisible -- until the next scan finds it overdue;
+                // k_append_scan's first_live steps over it from the frame on in which the rule removes it (tests/test_gpu_sweep.py::test_surfel_0_outside_the_view_lists).
+                const bool overdue = wv > DEAD_TIME && time_prev >= 0 && age_rule_gone(wv, p4.w, time_prev, c);
                 if (overdue) {
                     float4 q4 = p4;
                     q4.w = -1.0f;
@@ -1416,7 +1435,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
                     if (in && wv > 0.f && (float)time - wv > (float)c.timeDelta) {   // outside the time window for good
                         in = false;
                         in_i = !(p4.w < c.conf);   // (>=: the INACTIVE splat of the loop-closure detection draws a surfel exactly AT the threshold, the id render tests > per entry)
-                    } else if (!in) {   // never seen while the list is valid: only the age rule of the clean pass applies to it (copy_unstable.vert:160-172)
+                    } else if (!in && time_prev < 0) {   // (option overdue_rule 0, round 4's scan: the age rule of THIS frame's clean pass, applied now, to the slots the list leaves out)
                         int test = 1;
                         if (wv == -1 || (((float)time - wv) > 20 && p4.w < c.conf)) test = 0;
                         if (wv > 0 && (float)time - wv > (float)c.timeDelta) test = 1;
@@ -2414,9 +2433,15 @@ __device__ __forceinline__ void append_scan_body(DevState* st, const Cam& c, int
         if (seq0 + (unsigned int)tg < seq0 || seq0 + (unsigned int)tg > 0xFFF00000u) ovf = true;   // creation numbers are never renumbered: 2^32 of them is the life of a sharded map (reported as a full store)
         st->n_new = nc - count0;
         st->count = nc;
-        {   // the clean pass of this frame is behind us: if it removed the reference's "surfel 0", the next live slot takes its place (the appended ones are alive by construction)
+        {   // the clean pass of this frame is behind us: if it removed the reference's "surfel 0", the next live slot takes its place (the appended ones are alive by construction).
+            // A slot that no view list holds was not visited by this clean pass: the age rule -- all that can apply to it -- is evaluated here (the next scan tombstones it);
+            // for a slot the pass did visit and keep the rule says "kept" again.
             int f = st->first_live;
-            while (f < count0 && !(tm[f].y > DEAD_TIME)) f++;
+            while (f < count0) {
+                const float wv = tm[f].y;
+                if (wv > DEAD_TIME && !age_rule_gone(wv, pc[f].w, time, c)) break;
+                f++;
+            }
             st->first_live = f;
         }
         st->next_seq = seq0 + (unsigned int)tg;
@@ -2645,8 +2670,11 @@ __global__ void k_adopt_est_pose(DevState* st)
     st->vl_valid = 0;   // another pose, and a deformation follows (positions move): the frame takes the per-pass culls, the list is rebuilt next frame
 }
 
+// the first clean pass that sees the store as an upload / a jump of the clock left it: from here on the age rule counts (age_rule_gone)
+static inline void age_epoch_begin(ifx* h, int time) { if (h->age_epoch == INT_MAX) h->age_epoch = time; }
 static void clean_pass(ifx* h, const float* d_pose_inv, int time, int part = 0)
 {
+    age_epoch_begin(h, time);
     h->hot_valid = 0;
     h->last_clean_time = time;
     Cam c = make_cam(h);
@@ -2747,6 +2775,7 @@ int ifx_map_frame(ifx* h)
     h->clean_raster_pending = 0;
     h->view_frame = 0;
     h->ids_view_ok = 0;
+    age_epoch_begin(h, h->tick);
     if (use_view_list(h)) {
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
@@ -3047,6 +3076,8 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
                (int*)nullptr, (int*)nullptr);
         break;
     case 0:                                                                                                 // local projection | keys: MIN
+        age_epoch_begin(h, time);
+        c.age_epoch = h->age_epoch;
         h->view_frame = 0;
         h->ids_view_ok = 0;
         if (h->own_need_decide) {   // the pose came from the tracking rank (exchange 310): this rank has not yet asked whether its cached lists still cover it

@@ -319,3 +319,87 @@ def test_exact_sum_range_guard_is_driven(ifx, orc):
     assert n > 0, "the guard did not see the SO(3) residual of a black -> white flip"
     print(f"range guard: {n} reductions beyond half the exact range on the black / white flip, 0 on the synthetic stream")
     g.close()
+
+
+def _junk_behind_the_camera(pose, last_time, conf=1.0):
+    """One unstable surfel 30 m BEHIND the camera of `pose`: no view list holds it, no render draws it, nothing matches it -- only the clean pass's age rule ever applies."""
+    T = np.asarray(pose, np.float64).reshape(4, 4)
+    p = T[:3, 3] - 30.0 * T[:3, 2]
+    return dict(pc=np.array([p[0], p[1], p[2], conf], np.float32), nr=np.array([0, 0, 1, 0.01], np.float32), col=np.zeros(2, np.float32),
+                tm=np.array([last_time, last_time], np.float32), ic=np.zeros(4, np.float32), votes=np.zeros(48, np.float32))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("motion,late,time_delta,path,peek", [
+    ("still", 0, 200, "host", 0),       # the age rule removes the junk surfel in the very frame whose scan leaves it out: it is "surfel 0" for that frame's passes still
+    ("still", 2, 200, "host", 0),       # ... two frames later, between two scans: the NEXT live surfel reads id 0 from the following frame on
+    ("slow", 2, 200, "resident", 0),    # the same on bench.py's frame path (next frame announced, tracker parked)
+    ("nominal", 3, 200, "host", 0),     # lists rebuilt every ~4 frames
+    ("slow", 2, 200, "host", 2),        # a count is read after the second frame: a forced scan (ifx_vlist_reap) in between
+    ("fast", 1, 200, "host", 0),        # lists rebuilt EVERY frame: the scan of the frame whose clean pass removes the junk surfel must leave it "surfel 0" for that frame
+    ("fast", 2, 200, "host", 0),
+    ("shake", 2, 200, "host", 0),
+    ("still", 6, 30, "host", 0),        # timeDelta 30: by the time a scan looks at the junk surfels they are beyond the time window (exempt) -- the reference removed them at age 21
+])
+def test_surfel_0_outside_the_view_lists(ifx, orc, motion, late, time_delta, path, peek):
+    """The reference's "surfel 0" (id 0 = "no surfel": it occludes, but is never associated, counted or voted for) is the FIRST LIVE surfel of the map.  Here a slot that
+    no cached view list holds meets the clean pass's age rule (copy_unstable.vert:160-172) only when a scan comes by -- invisible, unless it is the map's first live slot:
+    the map is given an unstable surfel 30 m behind the camera as its first slot, whose age passes 20 in frame `late` after the upload, and the stable surfel drawn nearest to the image
+    centre as its second, which becomes "surfel 0" the frame after.  Every pose, and at the end count and the whole map (a surfel that reads id 0 is not updated and its
+    pixel creates a new one), against the oracle, which cleans every surfel in every frame like the reference.  (ADVICE round 5 for the
+    timeDelta case: a second junk surfel in the middle of the map, neither first nor listed.)"""
+    import torch
+
+    from instancefusion_amd import synth
+
+    seed, NW, NR = 777, 24, 20 if time_delta != 200 else 9
+    scene = synth.Scene(seed)
+    st = synth.make_stream_from_poses(synth.trajectory_profile(motion, NW + NR, seed), scene, W, H, noise_seed=seed + 1, **K)
+    orc.set_threads(orc.usable_cores())
+    o = orc.Oracle(w=W, h=H, max_surfels=400000, confidence=CONF, time_delta=time_delta, **K)
+    g = ifx.ElasticFusion(w=W, h=H, max_surfels=400000, confidence=CONF, time_delta=time_delta, **K)
+    po = None
+    for i in range(NW):
+        po = o.process_frame(st["rgb"][i], st["depth"][i])
+        assert_pose_equal(g.processFrame(st["rgb"][i], st["depth"][i]), po, f"warm-up frame {i}")
+    m = o.download()
+    ids = o.image("ids_after")
+    F0 = o.tick                                                   # the time of the first frame after the upload
+    par = (F0 + late) % 2                                         # only pixels with x % 2 == y % 2 == time % 2 associate (data.vert:131), mostly with the surfel of their own texel
+    yy, xx = np.nonzero((ids > 0) & ((np.arange(H)[:, None] % 2) == par) & ((np.arange(W)[None, :] % 2) == par))
+    assert yy.size, "no stable surfel in view"
+    near = np.argmin((yy - H // 2) ** 2 + (xx - W // 2) ** 2)
+    s = int(ids[yy[near], xx[near]])                              # the stable surfel drawn nearest to the image centre, on a pixel that is active in the frame that removes the junk
+    assert m["pc"][s, 3] >= CONF
+    order = np.concatenate([[s], np.delete(np.arange(m["pc"].shape[0]), s)])
+    junk = _junk_behind_the_camera(po, F0 + late - 21)            # age 21 (> 20: removed) at the end of frame F0 + late
+    mid = order.shape[0] // 2
+    m2 = {}
+    for k in MAP_KEYS:
+        a = m[k][order]
+        m2[k] = np.concatenate([junk[k][None], a[:mid], junk[k][None], a[mid:]]).astype(np.float32)
+    o.upload(m2); g.upload(m2)
+    o.set_pose(po, F0); g.set_pose(po, F0)
+    if path == "resident":
+        d_rgb = torch.from_numpy(st["rgb"]).cuda()
+        d_dep = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+        torch.cuda.synchronize()
+    for i in range(NW, NW + NR):
+        first = i == NW
+        pin = po if first else None                               # the frame behind the upload holds its pose (its prediction is the old map's)
+        po = o.process_frame(st["rgb"][i], st["depth"][i], in_pose=pin)
+        if path == "host" or first:
+            pg = g.processFrame(st["rgb"][i], st["depth"][i], inPose=pin)
+        else:
+            if i + 1 < NW + NR:
+                g.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())
+            g.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
+            pg = g.trajectory(1)[0]
+        assert_pose_equal(pg, po, f"frame {i - NW} after the upload")
+        if peek and i - NW + 1 == peek:
+            assert g.count == o.count, (i, g.count, o.count)
+    assert g.count == o.count, (g.count, o.count)
+    mg, mo = g.download(), o.download()
+    for k in MAP_KEYS:
+        assert np.array_equal(mg[k], mo[k], equal_nan=True), k
+    g.close(); o.close()

@@ -104,7 +104,9 @@ int ifx_hint_next_frame_device(ifx_t* h, const uint8_t* d_rgb_next, const uint16
  * IF/main.cpp:108-307).  The buffers are borrowed for this call only (the frame is copied into pinned staging here); its
  * transfer and image-only work run on the side stream under the current frame, its tracker is parked behind the current
  * frame, and the next ifx_process_frame -- which must pass the SAME pointers; anything else and the announcement is simply
- * ignored -- finds all of that done.  Results are identical with or without it.  Single-stream, unsharded handles. */
+ * ignored -- finds all of that done.  Results are identical with or without it, PROVIDED the two buffers still hold at that
+ * ifx_process_frame what they held here: the frame is matched by pointer identity and what was staged at the hint is what is
+ * processed (a caller that refills the same buffers in between must not announce them).  Single-stream, unsharded handles. */
 int ifx_hint_next_frame(ifx_t* h, const uint8_t* rgb_next, const uint16_t* depth_next);
 /* ---- sharded projection for large maps.  Every rank (one process per GPU) holds the full map replica and is
  * fed the same frames and masks; the passes that stream the whole surfel store with one atomic per visible surfel (index map
@@ -319,7 +321,14 @@ typedef struct ifx_soa_view {
     float* d_img_corr;      /* [capacity] float4                             (vImgCorr)    */
     float* d_votes;         /* [capacity][48]: vInstInfoA..L, one 192-byte record per slot */
 } ifx_soa_view;
+/* The pointers are MUTABLE, like the reference's getMapSurfelsGpu (its instance kernels write votes and colours through it), and a view is valid UNTIL THE NEXT FRAME
+ * CALL on the handle: the frame path keeps a gathered copy of position / normal / times per slot ("hot records") that it rebuilds after every
+ * ifx_map_view, so writes made between this call and the next frame are seen; writes through a pointer kept PAST a frame call are not (the list passes would read the
+ * stale copy while the scans read the arrays) -- call ifx_map_view again before such writes.  ifx_set_option(h, "hot_verify", 1) makes every frame compare the copy with
+ * the arrays first (one streaming pass, debug only); ifx_hot_records_stale returns how many slots it found differing (and repaired) since ifx_create: 0 for a caller
+ * that keeps the rule. */
 int ifx_map_view(ifx_t* h, ifx_soa_view* out);
+int ifx_hot_records_stale(ifx_t* h);
 int ifx_map_count(ifx_t* h);      /* live surfels (synchronises) */
 int ifx_map_slots(ifx_t* h);      /* slots incl. tombstones (synchronises) */
 /* Host copies of the live surfels in map order.  pc,nr,ic: float4 per surfel; col,tm: float2;
@@ -396,6 +405,32 @@ int ifx_rgb_step(ifx_t* h, const void* d_corres8, float sigma, const float* d_cl
 int ifx_so3_step(ifx_t* h, const uint8_t* d_last_img, const uint8_t* d_next_img,
                  const float* image_basis9, const float* kinv9, const float* krlr9, int w, int hgt,
                  float* out11_host);
+/* The pyramid builders as ONE stage call: createVMap / createNMap / pyrDown / pyrDownGaussF / pyrDownUcharGauss / resizeVMap / resizeNMap / tranformMaps /
+ * verticesToDepth / imageBGRToIntensity / computeDerivativeImages / projectToPointCloud (EF/Cuda/cudafuncs.cuh:64-183), chained as RGBDOdometry::initICP + initRGB
+ * (the frame side: EF/Utils/RGBDOdometry.cpp:118-142, 243-247, 287-293) and initICPModel + initRGBModel (the model side: :169-206, 237-241) chain them.
+ * In (device): the bilateral-filtered depth (u16 millimetres, DEPTH_FILTERED) and the RGB8 frame -- both or neither; the model prediction as float4 vertex / normal
+ * maps in the camera frame of `model_pose16` (host, row-major camera-to-world) and its RGBA8 image -- all three or none.
+ * Out (device, caller-allocated, DENSE: pitch = the level's width; the reference's DeviceArray2D are pitched, its kernels address them by row all the same): level l
+ * is (width >> l) x (height >> l); planar maps are [3][h_l][w_l].  A NULL entry is skipped.  The handle's own pyramids are overwritten (it is a stage call, like
+ * ifx_track_pair); the depth cut-off of createVMap is the handle's max_depth_processed (EF/ElasticFusion.cpp:73), that of verticesToDepth 6 m as in the reference.
+ * Error behaviour: IFX_E_INVALID for a half-given input group, IFX_E_STATE for a point cloud at a level the handle's configuration never iterates on. */
+typedef struct ifx_pyramids {
+    /* frame side */
+    uint16_t* depth[3];        /* depth_tmp: level 0 = the input, then pyrDown (5x5 Gaussian with the 3-sigma depth gate)          [h_l][w_l]    */
+    float* vmap_curr[3];       /* createVMap                                                                                       [3][h_l][w_l] */
+    float* nmap_curr[3];       /* createNMap                                                                                       [3][h_l][w_l] */
+    uint8_t* next_img[3];      /* imageBGRToIntensity, pyrDownUcharGauss                                                           [h_l][w_l]    */
+    int16_t* didx[3];          /* computeDerivativeImages (Sobel x)                                                                [h_l][w_l]    */
+    int16_t* didy[3];          /* computeDerivativeImages (Sobel y)                                                                [h_l][w_l]    */
+    /* model side */
+    float* vmap_g_prev[3];     /* copyMaps, resizeVMap, tranformMaps: vertices in the GLOBAL frame                                 [3][h_l][w_l] */
+    float* nmap_g_prev[3];     /* copyMaps, resizeNMap, tranformMaps                                                               [3][h_l][w_l] */
+    float* last_depth[3];      /* verticesToDepth, pyrDownGaussF                                                                   [h_l][w_l]    */
+    uint8_t* last_img[3];      /* intensity of the predicted image, pyrDownUcharGauss                                              [h_l][w_l]    */
+    float* cloud[3];           /* projectToPointCloud                                                                              [h_l][w_l][3] */
+} ifx_pyramids;
+int ifx_build_pyramids(ifx_t* h, const uint16_t* d_depth_filtered, const uint8_t* d_rgb, const float* d_model_v4, const float* d_model_n4, const uint8_t* d_model_rgba,
+                       const float* model_pose16, ifx_pyramids* out);
 /* Whole tracker on explicit inputs (RGBDOdometry::initICPModel/initRGBModel/initICP/initRGB +
  * getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:118-603).  Host inputs. */
 int ifx_track_pair(ifx_t* h, const float* model_v4, const float* model_n4, const uint8_t* model_rgba,

@@ -42,6 +42,11 @@ class IfxConfig(C.Structure):
     ]
 
 
+class Pyramids(C.Structure):
+    """ifx_pyramids: device pointers of the caller's output buffers, three levels each (0 = skipped)"""
+    _fields_ = [(n, C.c_void_p * 3) for n in ("depth", "vmap_curr", "nmap_curr", "next_img", "didx", "didy", "vmap_g_prev", "nmap_g_prev", "last_depth", "last_img", "cloud")]
+
+
 class SoaView(C.Structure):
     _fields_ = [("count", C.c_int32), ("capacity", C.c_int32), ("d_pos_conf", C.c_void_p), ("d_norm_rad", C.c_void_p),
                 ("d_color", C.c_void_p), ("d_times", C.c_void_p), ("d_img_corr", C.c_void_p), ("d_votes", C.c_void_p)]
@@ -108,7 +113,9 @@ _SIGS = {
     "ifx_trajectory": (C.c_int, [_P, _P, C.c_int]),
     "ifx_tracker_diag": (C.c_int, [_P, _P]),
     "ifx_tracker_fallbacks": (C.c_int, [_P]),
+    "ifx_build_pyramids": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(Pyramids)]),
     "ifx_tracker_range_exceeded": (C.c_int, [_P]),
+    "ifx_hot_records_stale": (C.c_int, [_P]),
     "ifx_set_loop_closure": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "ifx_loop_closure_diag": (C.c_int, [_P, _P]),
     "ifx_set_loop_closure_callback": (C.c_int, [_P, _P, _P]),
@@ -454,6 +461,10 @@ class ElasticFusion:
         self._chk(self.L.ifx_map_view(self.handle, C.byref(v)), "ifx_map_view")
         return v
 
+    def hot_records_stale(self):
+        """slots whose gathered copy differed from the store when a frame was about to read it (option hot_verify; 0 unless a kept map_view pointer was written past a frame call)"""
+        return self._chk(self.L.ifx_hot_records_stale(self.handle), "ifx_hot_records_stale")
+
     def download(self, fields=None):
         """the live surfels in map order; `fields`: a subset of (pc, nr, col, tm, ic, votes) -- a 50M-surfel map is 12.8 GB on the host, 9.6 of them votes"""
         n = self.getMapSurfelCount()
@@ -528,6 +539,15 @@ class ElasticFusion:
                 np.ascontiguousarray(rgb, np.uint8)]
         self._chk(self.L.ifx_track_pair(self.handle, *[_ptr(a) for a in args], _ptr(p), _ptr(diag)), "ifx_track_pair")
         return p.reshape(4, 4), diag
+
+    def build_pyramids(self, d_depth_filtered=0, d_rgb=0, d_model_v4=0, d_model_n4=0, d_model_rgba=0, model_pose=None, **out_ptrs):
+        """ifx_build_pyramids: device pointers in; out_ptrs: name -> three device pointers (one per level) of caller-allocated dense buffers"""
+        pyr = Pyramids()
+        for name, ptrs in out_ptrs.items():
+            getattr(pyr, name)[:] = [int(x) for x in ptrs]
+        pose = None if model_pose is None else np.ascontiguousarray(model_pose, np.float32).reshape(16)
+        self._chk(self.L.ifx_build_pyramids(self.handle, C.c_void_p(d_depth_filtered or None), C.c_void_p(d_rgb or None), C.c_void_p(d_model_v4 or None),
+                                            C.c_void_p(d_model_n4 or None), C.c_void_p(d_model_rgba or None), None if pose is None else _ptr(pose), C.byref(pyr)), "ifx_build_pyramids")
 
     def tracker_buffer(self, name, level, m2m=False):
         if m2m:

@@ -309,6 +309,7 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "fold_result") h->opt_fold_result = value;
     else if (s == "clean_raster") h->opt_clean_raster = value;
     else if (s == "hot_records") { h->opt_hot = value; h->hot_valid = 0; }
+    else if (s == "hot_verify") h->opt_hot_verify = value;
     else if (s == "side_late") h->opt_side_late = value;
     else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
     else if (s == "own_first_live") h->opt_own_first_live = value;
@@ -915,6 +916,8 @@ extern "C" int ifx_sharded_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb
 // ifx_owner_exchange(p) lists across the ranks (instancefusion_amd/sharded.py: RCCL all-reduce; tests: the same reduction by hand)
 int ifx_map_owner_phase(ifx* h, int phase, bool first_frame);
 static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth, int src_kind);
+// the rank exchange 5 reduces the prediction to (only that rank may track this camera's next frame); -1: all-reduced, every rank holds it
+static int owner_pred_root(const ifx* h) { return (h->own_track_rank >= 0 && h->own_tracked_tick == h->tick && h->own_g > 1) ? h->own_track_rank : -1; }
 static bool owner_lc_due(ifx* h);
 extern "C" int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint16_t* d_depth) { return h ? owner_frame_phase(h, phase, d_rgb, d_depth, 0) : IFX_E_INVALID; }
 // One call = one frame of the sharded map: the eight phases with their exchanges enqueued by the library on the handle's main stream (ifx_comm.hip), no
@@ -1072,6 +1075,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
         r = ifx_map_owner_phase(h, phase, first);
     }
     if (r) return r;
+    if (phase == 5) h->pred_root = owner_pred_root(h);   // who will hold this prediction complete once exchange 5 has run: set where the phase is ENQUEUED (ifx_owner_exchange only describes buffers)
     if (phase == 7) {   // after the vote mass of phase 6 was summed across the ranks: the frame result every rank reads its whetherDoSegmentation decision from
         const int slot = h->n_traj % h->max_traj;
         LAUNCH(h, "frame_result", dim3(1), dim3(64), k_frame_result, h->d_state, h->h_result, h->d_traj + (size_t)slot * 16);
@@ -1105,7 +1109,9 @@ extern "C" int ifx_owner_predict_phase(ifx_t* h, int step)
     if (!h || step < 0 || step > 2) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_predict_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     ifx_drop_tracked(h);
-    return ifx_map_owner_phase(h, 104 + step, false);
+    const int r = ifx_map_owner_phase(h, 104 + step, false);
+    if (!r && step == 1) h->pred_root = owner_pred_root(h);   // (the exchange behind this step is exchange 5)
+    return r;
 }
 // what to reduce after phase `phase`: ptrs[k] (device), bytes[k], ops[k] (0: element-wise minimum of unsigned 64-bit words, 1: sum of
 // 32-bit words -- the supports are disjoint, so the sum is a bitwise merge); returns the number of buffers (0: nothing to exchange)
@@ -1123,14 +1129,13 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4: add(h->key_splat, P * 16 + 8, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
     case 5:   // [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
-        if (h->own_track_rank >= 0 && h->own_tracked_tick == h->tick && h->own_g > 1) {
+        if (owner_pred_root(h) >= 0) {
             // K streams, camera k tracked by rank k only: the prediction rendered at the end of camera k's frame has ONE consumer, rank k's tracker -- a reduction to that
             // rank (op 5 | root << 8: ncclReduce, (G - 1) / G of the block per link instead of the all-reduce's 2 (G - 1) / G); the 16-byte tail -- the vote mass every
             // rank's whetherDoSegmentation decision needs -- still goes to everybody.  On the other ranks the block holds their own partial sums and is never read.
             add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16 - 16, 5 | (h->own_track_rank << 8));
             add(h->pred_tail, 16, 1);
-            h->pred_root = h->own_track_rank;   // (remembered: only that rank may track this camera's next frame)
-        } else { add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1); h->pred_root = -1; }
+        } else add(h->pred_conf, h->pred_bytes - (size_t)h->P * 16, 1);   // (who holds the block complete afterwards is remembered where phase 5 is enqueued: h->pred_root)
         break;
     case 6: break;
     case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank
@@ -1207,9 +1212,17 @@ extern "C" int ifx_hint_next_frame(ifx_t* h, const uint8_t* rgb_next, const uint
     if (h->own || !h->cams.empty()) { h->err = "ifx_hint_next_frame: single-stream, unsharded handles (use ifx_hint_next_frame_device)"; return IFX_E_STATE; }
     if (!h->opt_two_streams || !h->stream_b) return IFX_OK;   // nothing to overlap with
     const int p = (h->tick + 1) & 1;   // (this pair's last transfer belongs to frame tick - 1, whose pose a call has returned: complete)
-    if (!h->hint_stage_rgb[p]) {
-        HIPCHK(h, hipHostMalloc((void**)&h->hint_stage_rgb[p], (size_t)h->P * 3, hipHostMallocDefault));
-        HIPCHK(h, hipHostMalloc((void**)&h->hint_stage_depth[p], (size_t)h->P * 2, hipHostMallocDefault));
+    if (!h->hint_stage_rgb[p] || !h->hint_stage_depth[p]) {   // the pair is allocated together or not at all (a half-allocated pair would be written through a null pointer by the next call)
+        if (h->hint_stage_rgb[p]) { (void)hipHostFree(h->hint_stage_rgb[p]); h->hint_stage_rgb[p] = nullptr; }
+        if (h->hint_stage_depth[p]) { (void)hipHostFree(h->hint_stage_depth[p]); h->hint_stage_depth[p] = nullptr; }
+        uint8_t* sr = nullptr; uint16_t* sd = nullptr;
+        if (hipHostMalloc((void**)&sr, (size_t)h->P * 3, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&sd, (size_t)h->P * 2, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (sr) (void)hipHostFree(sr);
+            h->err = "ifx_hint_next_frame: no pinned memory for the staging pair";
+            return IFX_E_HIP;
+        }
+        h->hint_stage_rgb[p] = sr; h->hint_stage_depth[p] = sd;
     }
     memcpy(h->hint_stage_depth[p], depth_next, (size_t)h->P * 2);
     memcpy(h->hint_stage_rgb[p], rgb_next, (size_t)h->P * 3);
@@ -1254,6 +1267,14 @@ extern "C" int ifx_tracker_fallbacks(ifx_t* h)
 // (frames of saturated edges at near range; the images this path sees in tests and bench.py are 2^7 below it).  0 = every pose so far is the pose of the fixed arithmetic.
 // Summed over every tracker instance of the handle (frame tracker, its SO(3) pre-alignment in the frame slots, model-to-model tracker, camera run-ahead tracker).
 // (No counterpart in the reference: its f32 tree sums have no exactness to lose.)  Waits for the frames in flight.
+extern "C" int ifx_hot_records_stale(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int v = 0;
+    HIPCHK(h, hipMemcpy(&v, &h->d_state->hot_stale, sizeof(int), hipMemcpyDeviceToHost));
+    return v;
+}
 extern "C" int ifx_tracker_range_exceeded(ifx_t* h)
 {
     if (!h) return IFX_E_INVALID;

@@ -54,6 +54,7 @@ struct DevState {
     int app_count0; unsigned int app_seq0, app_vln0;   // count / next_seq / vl_n[0] when the frame's new-surfel flags were taken (k_new_flags_count): k_append_scan's starting point
     unsigned int result_ticket;  // last-block ticket of k_splat_resolve when it also writes the frame result (FrameOut)
     unsigned int next_seq;       // creation number of the next new surfel (spatially sharded map: identical on every rank)
+    int hot_stale;               // option hot_verify: slots whose gathered copy ("hot record") differed from the store when a frame was about to read it (ifx_hot_records_stale; 0 unless somebody wrote the store through a kept ifx_map_view pointer)
     int range_exceeded;          // run-time guard of the tracker's exact sums: diagonal totals found beyond half their exact range since the handle was created (ifx_track.hip range_exceeded7; ifx_tracker_range_exceeded)
     float spec_pose[16], spec_pose_inv[16], spec_weighting;   // result of a tracker run enqueued ahead of its frame (k_commit_pose publishes it)
     // local loop-closure detection (EF/ElasticFusion.cpp:453-566).  The model-to-model tracker has a DevState of its own (ifx::d_m2m):
@@ -296,6 +297,7 @@ struct ifx {
     int opt_cam_swap = 1;               // a camera switch between two existing contexts hands the prediction / fill-in / id blocks over by pointer instead of copying them
     void* hot = nullptr;                // [cap] 64-byte records (position + confidence | normal + radius | times): what the frame path's gathers read (ifx_map.hip "hot records")
     int hot_valid = 0;                  // the copy describes the store (its three per-frame writers write both; everything else that writes the store clears this)
+    int opt_hot_verify = 0;             // option hot_verify (debug): every frame that trusts the gathered copy first compares it with the store (one streaming launch) and counts the slots that differ
     int opt_hot = 1;                    // option hot_records
     void* frame_hot = nullptr;          // the copy as this frame's map passes use it (null: the arrays)
     int opt_clean_raster = 1;           // view-list frames: ONE walk of the view list cleans and rasterises (k_raster_view<., true>, with k_new_flags_count's blocks in the same launch):

@@ -119,6 +119,24 @@ __global__ void k_hot_rebuild(const DevState* __restrict__ st, const float4* __r
     const int n = st->count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) { Hot r; r.pc = pc[i]; r.nr = nr[i]; r.tm = tm[i]; r.pad0 = make_float2(0.f, 0.f); r.pad1 = make_float4(0.f, 0.f, 0.f, 0.f); hot[i] = r; }
 }
+// option hot_verify (debug): the copy a frame is about to trust against the store; a slot that differs was written through a pointer the caller kept past the next frame call
+// (include/ifx_c_api.h, ifx_map_view) -- counted in DevState::hot_stale and repaired, so that one violation is reported once and does not snowball
+__global__ void k_hot_verify(DevState* st, const float4* __restrict__ pc, const float4* __restrict__ nr, const float2* __restrict__ tm, Hot* __restrict__ hot)
+{
+    const int n = st->count;
+    int bad = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+        const float4 a = pc[i], b = nr[i]; const float2 t = tm[i];
+        const Hot r = hot[i];
+        const bool same = __float_as_uint(a.x) == __float_as_uint(r.pc.x) && __float_as_uint(a.y) == __float_as_uint(r.pc.y) && __float_as_uint(a.z) == __float_as_uint(r.pc.z) &&
+                          __float_as_uint(a.w) == __float_as_uint(r.pc.w) && __float_as_uint(b.x) == __float_as_uint(r.nr.x) && __float_as_uint(b.y) == __float_as_uint(r.nr.y) &&
+                          __float_as_uint(b.z) == __float_as_uint(r.nr.z) && __float_as_uint(b.w) == __float_as_uint(r.nr.w) && __float_as_uint(t.x) == __float_as_uint(r.tm.x) &&
+                          __float_as_uint(t.y) == __float_as_uint(r.tm.y);
+        if (!same) { bad++; Hot q = r; q.pc = a; q.nr = b; q.tm = t; hot[i] = q; }
+    }
+    bad = wave_sum_i(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&st->hot_stale, bad);
+}
 __device__ __forceinline__ unsigned int key_id(const Cam& c, unsigned int i, int fl) { return c.own_n > 0 ? c.seq[i] : ((c.raw_slots || i != (unsigned int)fl) ? i : 0u); }
 __device__ __forceinline__ int local_slot(const Cam& c, int count, unsigned int id, int fl)
 {
@@ -2793,7 +2811,8 @@ int ifx_map_frame(ifx* h)
             if (h->hot && !h->hot_valid) {
                 LAUNCH(h, "hot_rebuild", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_hot_rebuild, (const DevState*)h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, (Hot*)h->hot);
                 h->hot_valid = 1;
-            }
+            } else if (h->hot && h->opt_hot_verify)
+                LAUNCH(h, "hot_verify", dim3(MAP_BLOCKS), dim3(MAP_THREADS), k_hot_verify, h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, (Hot*)h->hot);
             hot = (Hot*)h->hot;
         }
         if (!hot) h->hot_valid = 0;

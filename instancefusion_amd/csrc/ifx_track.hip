@@ -3315,6 +3315,54 @@ extern "C" int ifx_track_pair(ifx_t* h, const float* model_v4, const float* mode
     return IFX_OK;
 }
 
+// Stage entry for the pyramid builders (SURVEY 8(b) "tracker stage API"): createVMap / createNMap / pyrDown / pyrDownGaussF / pyrDownUcharGauss / resizeVMap / resizeNMap /
+// tranformMaps / verticesToDepth / imageBGRToIntensity / computeDerivativeImages / projectToPointCloud (EF/Cuda/cudafuncs.cuh:64-183) as RGBDOdometry::initICP / initRGB /
+// initICPModel / initRGBModel chain them (EF/Utils/RGBDOdometry.cpp:118-247, 287-293).  Device pointers in, device pointers out; the kernels are the ones a frame runs
+// (k_intensity, k_frame_down, k_frame_maps; k_model_l0, k_model_down), on the handle's own pyramid buffers, and what the caller asked for is copied out device to device.
+extern "C" int ifx_build_pyramids(ifx_t* h, const uint16_t* d_depth_filtered, const uint8_t* d_rgb, const float* d_model_v4, const float* d_model_n4, const uint8_t* d_model_rgba,
+                                  const float* model_pose16, ifx_pyramids* out)
+{
+    if (!h || !out || (!d_depth_filtered != !d_rgb) || (!d_model_v4 != !d_model_n4) || (!d_model_v4 != !d_model_rgba) || (d_model_v4 && !model_pose16) || (!d_rgb && !d_model_v4)) return IFX_E_INVALID;
+    ifx_drop_tracked(h);   // (stage call: it rewrites what a run enqueued ahead reads)
+    const size_t P = (size_t)h->P;
+    Pyr& p = h->pyr;
+    auto give = [&](void* dst, const void* src, size_t bytes) { return (!dst || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream) == hipSuccess) ? 0 : 1; };
+    int bad = 0;
+    if (d_rgb) {
+        HIPCHK(h, hipMemcpyAsync(h->rgb, d_rgb, P * 3, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->depth_filt, d_depth_filtered, P * 2, hipMemcpyDeviceToDevice, h->stream));
+        tracker_init_frame(h, h->depth_filt, h->rgb);
+        for (int l = 0; l < IFX_NUM_PYRS; l++) {
+            const size_t n = (size_t)p.w[l] * p.h[l];
+            bad += give(out->depth[l], p.depth_tmp[l], n * 2) + give(out->vmap_curr[l], p.vmap_curr[l], n * 12) + give(out->nmap_curr[l], p.nmap_curr[l], n * 12) +
+                   give(out->next_img[l], p.next_img[l], n) + give(out->didx[l], p.didx[l], n * 2) + give(out->didy[l], p.didy[l], n * 2);
+        }
+    }
+    if (d_model_v4) {
+        HIPCHK(h, hipMemcpyAsync(h->pred_vertex, d_model_v4, P * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pred_normal, d_model_n4, P * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pred_image, d_model_rgba, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_scratch + 6 * 16, model_pose16, 64, hipMemcpyHostToDevice, h->stream));
+        LAUNCH(h, "write_pose", dim3(1), dim3(64), k_write_pose, h->d_state, h->d_scratch + 6 * 16);
+        LAUNCH(h, "set_dense", dim3(1), dim3(64), k_set_dense, h->d_state, 1);   // (the prediction as given: no fill-in substitution)
+        tracker_init_model(h, h->d_state, h->pyr, 10.0f /* with the photometric term: the point clouds are built */, h->pred_vertex, h->pred_normal, h->pred_image, h->fill_vertex, h->fill_normal,
+                           h->fill_image);
+        const int iterations[3] = {h->cfg.fast_odom ? 3 : 10, h->cfg.pyramid ? 5 : 0, h->cfg.pyramid ? 4 : 0};
+        for (int l = 0; l < IFX_NUM_PYRS; l++) {
+            const size_t n = (size_t)p.w[l] * p.h[l];
+            bad += give(out->vmap_g_prev[l], p.vmap_prev[l], n * 12) + give(out->nmap_g_prev[l], p.nmap_prev[l], n * 12) + give(out->last_depth[l], p.last_depth[l], n * 4) +
+                   give(out->last_img[l], p.last_img[l], n);
+            if (out->cloud[l]) {
+                if (iterations[l] <= 0) { h->err = "ifx_build_pyramids: the handle's configuration runs no iteration at level " + std::to_string(l) + " (pyramid = 0): no point cloud there"; return IFX_E_STATE; }
+                bad += give(out->cloud[l], p.cloud[l], n * 12);
+            }
+        }
+    }
+    if (bad) { (void)hipGetLastError(); h->err = "ifx_build_pyramids: a device-to-device copy into the caller's buffers failed"; return IFX_E_HIP; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IFX_OK;
+}
+
 extern "C" int ifx_tracker_buffer_download(ifx_t* h, const char* name, int l, void* out, int64_t max_bytes)
 {
     if (!h || !name || l < 0 || l >= IFX_NUM_PYRS) return IFX_E_INVALID;

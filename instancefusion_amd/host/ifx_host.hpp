@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -140,9 +141,27 @@ struct Sharding {
     // 128 id bytes + an 8-byte nonce; `nonce` is a number the launcher gives every rank of one run (ifx_replay --shard-nonce; 0: none).  Rank 0 removes a stale file before
     // anything else; the other ranks accept a file only if its nonce is theirs.  Without a nonce a file that APPEARS (or changes) while a rank waits is this run's; one that was
     // already there at the rank's first look may be a previous run's (rank 0 has not removed it yet) or this run's (this rank started late): it is taken when it is still there,
-    // unchanged, after `staleGraceSeconds` -- no comparison of clocks (a rank that started more than 2 s after rank 0 wrote the file used to wait 120 s and give up).
+    // unchanged, after `staleGraceSeconds` AND was written within the last `freshSeconds` (generous: the ranks of one run start within a quarter of an hour of each
+    // other; a rank that started more than 2 s after rank 0 wrote the file used to wait 120 s and give up).  An older leftover is never taken: if rank 0 of this run is
+    // more than the grace period behind (slow log open, GPU initialisation), the rank keeps waiting for rank 0 to replace the file and, failing that, throws after
+    // `timeoutSeconds` -- it does not walk into ncclCommInitRank with a dead id, which blocks for ever.  A leftover YOUNGER than `freshSeconds` can
+    // only be told from this run's file by a nonce: nonceFromLauncher() derives one from the job id the common launchers export.
     uint64_t nonce = 0;
     int staleGraceSeconds = 3;
+    int freshSeconds = 900;
+    // a number every rank of ONE launch shares and other launches do not: FNV-1a of the launcher's job id (torchrun, Slurm, Open MPI / PMIx, MPICH); 0 when none is set
+    static uint64_t nonceFromLauncher()
+    {
+        std::string key;
+        for (const char* name : {"IFX_SHARD_NONCE", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE", "PMI_JOBID"}) {
+            const char* v = std::getenv(name);
+            if (v && *v && std::string(v) != "none") { key += name; key += '='; key += v; key += ';'; }
+        }
+        if (key.empty()) return 0;
+        uint64_t hsh = 1469598103934665603ull;
+        for (unsigned char ch : key) { hsh ^= ch; hsh *= 1099511628211ull; }
+        return hsh ? hsh : 1;
+    }
     std::vector<uint8_t> uniqueId(int timeoutSeconds = 120) const
     {
         std::vector<uint8_t> id(128, 0);
@@ -172,7 +191,10 @@ struct Sharding {
                 now.insert(now.end(), (const uint8_t*)&got, (const uint8_t*)&got + 8);
                 if (!looked) first_seen = now;                                         // it was there before this rank looked: this run's, or a previous run's
                 else if (now != first_seen) return id;                                  // appeared or changed while waiting: rank 0 of THIS run wrote it
-                if (waited >= staleGraceSeconds * 20) return id;                       // still there, unchanged: rank 0 would have removed a stale one long ago
+                if (waited >= staleGraceSeconds * 20) {                                // still there, unchanged: rank 0 would have removed a stale one long ago --
+                    struct stat sb;                                                     // unless rank 0 is late itself: only a RECENT file can be this run's
+                    if (::stat(idFile.c_str(), &sb) == 0 && std::difftime(std::time(nullptr), sb.st_mtime) <= (double)freshSeconds) return id;
+                }
             }
             looked = true;
             std::this_thread::sleep_for(std::chrono::milliseconds(50));

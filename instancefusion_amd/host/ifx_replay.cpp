@@ -98,6 +98,7 @@ int main(int argc, char** argv)
 
         std::unique_ptr<ElasticFusionInterface> map(new ElasticFusionInterface());
         if (a.shard.on()) a.close_loops = false;   // (not available on a sharded map)
+        if (a.shard.ranks > 1 && a.shard.nonce == 0) a.shard.nonce = Sharding::nonceFromLauncher();   // (the launcher's job id tells this run's id file from a leftover; 0 when it exports none)
         if (!map->Init(instancefusion->getInstanceTable(), a.max_surfels, a.device, a.out, a.close_loops, a.confidence, a.shard)) {
             std::cout << "ElasticFusionInterface init failure" << std::endl;
             return 1;

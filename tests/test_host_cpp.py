@@ -284,6 +284,9 @@ def test_sharding_unique_id_refuses_a_stale_file(checker, tmp_path):
     open(f, "wb").write(bytes([5] * 128) + struct.pack("<Q", 0))              # no nonce in use, the file is there before the rank looks (a rank that starts late): taken after the grace period
     r = subprocess.run([checker, "shardid", f, "0", "6"], capture_output=True, text=True, check=True)
     assert r.stdout.strip() == "id 5", r.stdout
+    os.utime(f, (time.time() - 3600, time.time() - 3600))                     # ... but never an hour-old leftover: rank 0 of this run may just be late -- keep waiting, then refuse
+    r = subprocess.run([checker, "shardid", f, "0", "5"], capture_output=True, text=True, check=True)
+    assert r.stdout.startswith("refused"), r.stdout
     open(f, "wb").write(bytes([5] * 100))                                     # truncated
     r = subprocess.run([checker, "shardid", f, "0", "1"], capture_output=True, text=True, check=True)
     assert r.stdout.startswith("refused"), r.stdout

@@ -98,6 +98,38 @@ __host__ __device__ inline float ifx_expf(float x)
     return p * s.f;
 }
 
+// The window loop of data.vert:151-153 and copy_unstable.vert:110-112 AS THE SHADER TEXT EVALUATES IT in IEEE f32:
+//     for (float i = c - (scale * step * windowMultiplier); i < c + (scale * step * windowMultiplier); i += step)     step = (1 / (size * scale)) * 0.5, scale = 1
+// and the texel each tap reads under GL_NEAREST: floor(u * size), clamped to the edge (GL 4.5 section 8.14.2).  In exact arithmetic the loop makes four trips, at -1, -1/2, 0,
+// +1/2 texels from c; in f32 the accumulated `i += step` falls short of the bound in a fraction of the cases and a FIFTH tap, one texel beyond c, is taken -- and a tap that
+// sits on a texel edge goes to whichever side the f32 product falls.  Pinned by executing the reference's shaders (tests/golden/gl_map_passes.npz, tools/make_golden_gl.py;
+// the same function, statement for statement, in oracle/orc_map.c).  Returns the number of taps (4 or 5; at most IFX_MAX_TAPS are recorded).
+#define IFX_MAX_TAPS 8
+__device__ __forceinline__ int window_taps(float c, float size, int n, int* tex)
+{
+    const float scale = 1.0f, wm = 2.0f;
+    const float step = (1.0f / (size * scale)) * 0.5f;
+    const float lo = c - (scale * step * wm), hi = c + (scale * step * wm);
+    int k = 0;
+    float i = lo;
+#pragma unroll
+    for (int it = 0; it < IFX_MAX_TAPS; it++) {   // (the float loop, unrolled with a predicate so that `tex` stays in registers)
+        const bool in = i < hi;
+        int t = (int)floorf(i * size);
+        t = t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+        tex[it] = in ? t : -1;
+        k += in ? 1 : 0;
+        i = in ? i + step : i;
+    }
+    return k;
+}
+// the texcoord attribute of pixel column / row i: the uvo buffer of GlobalModel (EF/GlobalModel.cpp:103-119), float(i) / size + 1.0 / (2 * size) evaluated in double, stored as float
+__device__ __forceinline__ float uvo_coord(int i, int size) { return (float)((double)((float)i / (float)size) + 1.0 / (2 * (double)(float)size)); }
+// The pixel a 1-pixel GL point at window coordinate u lands on: the position snaps to the rasteriser's sub-pixel grid (8 bits), the point is the 1x1 square around it, and a
+// pixel is produced when its centre lies in that square, lower edge included, upper edge not: floor(u), except that a point within 1/512 px above a pixel edge belongs to
+// the pixel below the edge (measured on the reference's index_map shaders: oracle/orc_map.c point_pixel).  -1: left of / above the image.
+__device__ __forceinline__ int point_pixel(float u) { return (int)floorf((rintf(u * 256.0f) - 1.0f) / 256.0f); }
+
 // color.glsl:19-34
 __device__ inline float encode_color(float r, float g, float b)
 {

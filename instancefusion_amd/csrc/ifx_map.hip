@@ -317,7 +317,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_project(const DevState* _
         if (p.z > c.maxDepth || p.z < 0) continue;
         float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
         if (!(u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h)) continue;
-        int px = (int)floorf(u), py = (int)floorf(v);
+        const int px = point_pixel(u), py = point_pixel(v);
+        if (px < 0 || py < 0) continue;
         key_min(&keys[py * c.w + px], make_key(p.z, key_id(c, (unsigned int)i, fl)));
     }
 }
@@ -1239,8 +1240,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_clean(DevState* st, const 
                         v3 p = xf_point(T, v3m(p4.x, p4.y, p4.z));
                         if (p.z > 0.f) {
                             float u = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
-                            if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) && i >= lo && i < hi)
-                                key_min(&keys[(int)floorf(v) * c.w + (int)floorf(u)], make_key(p.z, key_id(c, (unsigned int)i, fl)));
+                            if (!(p.z > c.maxDepth) && (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) && i >= lo && i < hi) {
+                                const int px_ = point_pixel(u), py_ = point_pixel(v);
+                                if (px_ >= 0 && py_ >= 0) key_min(&keys[py_ * c.w + px_], make_key(p.z, key_id(c, (unsigned int)i, fl)));
+                            }
                             cand = ((float)time - wv < (float)c.timeDelta && u > 0 && v > 0 && u < (float)c.w && v < (float)c.h);
                         }
                     }
@@ -1612,7 +1615,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_index_list(const DevState* __re
             if (p.z > c.maxDepth || p.z < 0) continue;
             const float uu = ((c.fx * p.x) / p.z) + c.cx, v = ((c.fy * p.y) / p.z) + c.cy;
             if (!(uu >= 0 && uu < (float)c.w && v >= 0 && v < (float)c.h)) continue;
-            key_min(&keys[(int)floorf(v) * c.w + (int)floorf(uu)], make_key(p.z, key_id(c, i[u], fl)));   // (sharded map: the creation number instead of the slot)
+            const int px_ = point_pixel(uu), py_ = point_pixel(v);
+            if (px_ < 0 || py_ < 0) continue;
+            key_min(&keys[py_ * c.w + px_], make_key(p.z, key_id(c, i[u], fl)));   // (sharded map: the creation number instead of the slot)
         }
     }
 }
@@ -2119,6 +2124,19 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
         // visit never changes the running best (dist < bestDist is strict), so the nine first visits in the original (a, b) order decide.
         const int xs[3] = {clampi((int)floorf(x - 1.0f), 0, c.w - 1), clampi((int)floorf(x - 0.5f), 0, c.w - 1), clampi((int)floorf(x + 0.5f), 0, c.w - 1)};
         const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};
+        // WHICH of the three columns / rows the shader's window loop visits is decided by its f32 arithmetic (window_taps, ifx_dev.h): the taps run from the centre of texel
+        // i - 1 in half-texel steps, so i - 1 and i are always among them, while i + 1 is reached only when the tap on the edge between i and i + 1 falls to the right of it or
+        // the loop makes its fifth trip -- a property of the column (row) index alone.  Visiting order and first-visit semantics are unchanged.
+        unsigned int vis_x = 0u, vis_y = 0u;
+        {
+            int tx[IFX_MAX_TAPS], ty[IFX_MAX_TAPS];
+            window_taps(uvo_coord(i, c.w), (float)c.w, c.w, tx);
+            window_taps(uvo_coord(j, c.h), (float)c.h, c.h, ty);
+#pragma unroll
+            for (int q = 0; q < IFX_MAX_TAPS; q++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { vis_x |= (tx[q] == xs[a]) ? (1u << a) : 0u; vis_y |= (ty[q] == ys[a]) ? (1u << a) : 0u; }
+        }
         uint32_t cur[9];
 #pragma unroll
         for (int a = 0; a < 3; a++)
@@ -2169,6 +2187,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
             for (int q = 0; q < 9; q++) {
                 // (sharded map, akey: only the candidates this rank OWNS -- their attribute records are the ones k_index_resolve filled in; a foreign winner's record is
                 // all zeros here, and a zero depth could never pass the 5 cm test against a measurement of at least 0.3 m anyway)
+                if (!((vis_x >> (q / 3)) & (vis_y >> (q % 3)) & 1u)) continue;   // a texel the window loop of this column / row does not reach
                 if (cur[q] > 0u && (!akey || (__float_as_uint(vcs[q].x) | __float_as_uint(vcs[q].y) | __float_as_uint(vcs[q].z) | __float_as_uint(vcs[q].w)) != 0u)) {
                     const float4 vc = vcs[q];
                     if (fabsf((vc.z * lambda) - (vl.z * lambda)) < 0.05f) {
@@ -2274,18 +2293,35 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
     if ((float)time - wv < (float)c.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)c.w && y < (float)c.h) {
         v3 ln = normalized(xf_dir(T, v3m(n4.x, n4.y, n4.z)));
         const bool flat = fabsf(ln.z) > 0.85f;
-        const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
-        int tx[4], ty[4];
+        // The window: the shader's float loop (window_taps: four or FIVE taps per axis, decided by its f32 arithmetic) around the projected position.
+        int tx[IFX_MAX_TAPS], ty[IFX_MAX_TAPS];
+        window_taps(x / (float)c.w, (float)c.w, c.w, tx);
+        window_taps(y / (float)c.h, (float)c.h, c.h, ty);
+        // The 16 to 25 taps visit (almost always) at most 3 x 3 DISTINCT texels: consecutive columns tx[0], tx[0] + 1, tx[0] + 2 (non-decreasing, clamped), a column being visited
+        // as often as it appears among the taps -- so nine gathers, each counted with its multiplicity mx * my, give the window's two counts exactly (counter evidence,
+        // profiles/r04_a_pmc_bound.json: the pass was bound by the address processing of its divergent gathers, not by its arithmetic).  A fourth column / row (a tap span that
+        // straddles two texel edges by rounding) is handled by the slow path below.
+        int mx[4], my[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) { tx[a] = clampi((int)floorf(x + offs[a]), 0, c.w - 1); ty[a] = clampi((int)floorf(y + offs[a]), 0, c.h - 1); }
-        // The sixteen taps visit at most 3 x 3 DISTINCT texels: the four offsets floor to consecutive columns tx[0], tx[0] + 1, tx[0] + 2 (non-decreasing, clamped), a column
-        // being visited as often as it appears among the four -- so nine gathers, each counted with its multiplicity mx * my, give the window's two counts exactly
-        // (counter evidence, profiles/r04_a_pmc_bound.json: the pass was bound by the address processing of its 16 divergent gathers per candidate, not by its arithmetic)
-        int mx[3], my[3];
+        for (int q = 0; q < 4; q++) {
+            mx[q] = 0; my[q] = 0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            mx[q] = (tx[0] == tx[0] + q) + (tx[1] == tx[0] + q) + (tx[2] == tx[0] + q) + (tx[3] == tx[0] + q);
-            my[q] = (ty[0] == ty[0] + q) + (ty[1] == ty[0] + q) + (ty[2] == ty[0] + q) + (ty[3] == ty[0] + q);
+            for (int a = 0; a < IFX_MAX_TAPS; a++) { mx[q] += (tx[a] == tx[0] + q) ? 1 : 0; my[q] += (ty[a] == ty[0] + q) ? 1 : 0; }
+        }
+        if (mx[3] | my[3]) {   // rare: sixteen distinct texels, one at a time
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    const int wgt = mx[a] * my[b];
+                    if (!wgt) continue;
+                    const float4 e = tap[min(ty[0] + b, c.h - 1) * c.w + min(tx[0] + a, c.w - 1)];
+                    if (e.z == 0.f) continue;
+                    const float ez = fabsf(e.z);
+                    const bool stable = e.w > 0.f, now = e.z < 0.f;
+                    const float dx = e.x - lp.x, dy = e.y - lp.y;
+                    if (fabsf(e.w) < initT && stable && ez > lp.z && ez - lp.z < 0.01f && sqrtf(dx * dx + dy * dy) < n4.w * 1.4f) count += wgt;
+                    if (now && stable && ez > lp.z && ez - lp.z > 0.01f && flat) zCount += wgt;
+                }
+            mx[0] = mx[1] = mx[2] = 0;   // (nothing left for the fast path)
         }
         float4 t[9];
 #pragma unroll

@@ -21,37 +21,61 @@
 __global__ __launch_bounds__(BIL_BX* BIL_BY) void k_bilateral_metric(const uint16_t* __restrict__ in, uint16_t* __restrict__ filt,
                                                                       float* __restrict__ dm, float* __restrict__ dmf, int w, int h, float maxD)
 {
-    __shared__ uint16_t tile[BIL_BY + 2 * BIL_R][BIL_BX + 2 * BIL_R + 2];
+    // (one more row and column on the low side than the window: a tap of the shader samples the CORNER of its texel and may read the texel before it)
+    __shared__ uint16_t tile[BIL_BY + 2 * BIL_R + 1][BIL_BX + 2 * BIL_R + 3];
+    // the texel a tap reads (depth_bilateral.frag:59-61: texture(gSampler, vec2(float(cx) / cols, float(cy) / rows)) with GL_NEAREST = floor(u * size)): cx, or cx - 1 where the
+    // f32 quotient times the size falls just below cx (oracle/orc_track.c bilateral_tap: no column of a 640-wide image, seven rows of a 480-high one) -- as tile coordinates
+    __shared__ unsigned char s_mapx[BIL_BX + 2 * BIL_R + 1], s_mapy[BIL_BY + 2 * BIL_R + 1];
+    __shared__ int s_shifted;
     const int bx = blockIdx.x * BIL_BX, by = blockIdx.y * BIL_BY;
     const int tid = threadIdx.y * BIL_BX + threadIdx.x;
-    const int TW = BIL_BX + 2 * BIL_R, TH = BIL_BY + 2 * BIL_R;
+    const int TW = BIL_BX + 2 * BIL_R + 1, TH = BIL_BY + 2 * BIL_R + 1;
+    if (tid == 0) s_shifted = 0;
+    __syncthreads();
     for (int i = tid; i < TW * TH; i += BIL_BX * BIL_BY) {
         int ty = i / TW, tx = i - ty * TW;
-        int gx = bx + tx - BIL_R, gy = by + ty - BIL_R;
+        int gx = bx + tx - BIL_R - 1, gy = by + ty - BIL_R - 1;
         uint16_t v = 0;
         if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = in[gy * w + gx];
         tile[ty][tx] = v;
+    }
+    if (tid < TW) {
+        const int gx = bx + tid - BIL_R - 1;
+        int t = tid;
+        if (gx >= 0 && gx < w) t = max(min(max((int)floorf(((float)gx / (float)w) * (float)w), 0), w - 1) - (bx - BIL_R - 1), 0);
+        s_mapx[tid] = (unsigned char)t;
+        if (t != tid) s_shifted = 1;
+    }
+    if (tid >= 64 && tid - 64 < TH) {
+        const int k = tid - 64, gy = by + k - BIL_R - 1;
+        int t = k;
+        if (gy >= 0 && gy < h) t = max(min(max((int)floorf(((float)gy / (float)h) * (float)h), 0), h - 1) - (by - BIL_R - 1), 0);
+        s_mapy[k] = (unsigned char)t;
+        if (t != k) s_shifted = 1;
     }
     __syncthreads();
     const int x = bx + threadIdx.x, y = by + threadIdx.y;
     if (x >= w || y >= h) return;
     const unsigned int maxv = (unsigned int)(maxD * 1000.0f);
-    unsigned int value = tile[threadIdx.y + BIL_R][threadIdx.x + BIL_R];
+    unsigned int value = tile[threadIdx.y + BIL_R + 1][threadIdx.x + BIL_R + 1];
     unsigned int outv = 0;
     if (!(value > maxv || value < 300u)) {
         const float ss = 0.024691358f, sc = 0.000555556f;
         const int D = BIL_R * 2 + 1;
         int tx1 = min(x - D / 2 + D, w), ty1 = min(y - D / 2 + D, h);
         float sum1 = 0, sum2 = 0;
-        for (int cy = max(y - D / 2, 0); cy < ty1; ++cy)
+        const bool shifted = s_shifted != 0;   // (block-uniform: most blocks have no such column or row and index the tile directly)
+        for (int cy = max(y - D / 2, 0); cy < ty1; ++cy) {
+            const int ry = shifted ? (int)s_mapy[cy - by + BIL_R + 1] : cy - by + BIL_R + 1;
             for (int cx = max(x - D / 2, 0); cx < tx1; ++cx) {
-                unsigned int tmp = tile[cy - by + BIL_R][cx - bx + BIL_R];
+                unsigned int tmp = tile[ry][shifted ? (int)s_mapx[cx - bx + BIL_R + 1] : cx - bx + BIL_R + 1];
                 float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
                 float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
                 float weight = ifx_expf(-(space2 * ss + color2 * sc));
                 sum1 += (float)tmp * weight;
                 sum2 += weight;
             }
+        }
         outv = (unsigned int)roundf(sum1 / sum2);
         outv &= 0xFFFFu;
     }

@@ -150,9 +150,11 @@ class GL:
             raise RuntimeError(f"link {vert}: {log.value.decode()}")
         return prog
 
-    def uniforms(self, prog, **kw):
-        """Shader::setUniform (EF/Shaders/Shaders.h:38-67): int / float / vec2-4 / mat4 (column-major, as Eigen stores it: transpose = false)"""
-        self.glUseProgram(prog)
+    def uniforms(self, prog, _bound=False, **kw):
+        """Shader::setUniform (EF/Shaders/Shaders.h:38-67): int / float / vec2-4 / mat4 (column-major, as Eigen stores it: transpose = false).  _bound: the program is
+        current already (glUseProgram is an error while transform feedback is active: the reference sets `isNew` between the draws of one feedback session)"""
+        if not _bound:
+            self.glUseProgram(prog)
         for name, v in kw.items():
             loc = self.glGetUniformLocation(prog, name.encode())
             if loc < 0:

@@ -305,6 +305,12 @@ static inline void zb_range(long n, int T, int t, long* lo, long* hi) { *lo = n 
 
 /* ------------------------------------------------------------------ index map (a10)
  * index_map.vert:40-66 / index_map.frag:33-40 under GL_LESS. */
+/* The pixel a 1-pixel GL point at window coordinate u lands on: the position is snapped to the rasteriser's sub-pixel grid (8 bits: GL_SUBPIXEL_BITS of Mesa llvmpipe and of
+ * the NVIDIA GPUs the reference ran on), the point is the 1x1 square around it, and a pixel is produced when its centre lies in that square, the lower edge included and the
+ * upper one not (top-left rule): floor(u) -- except that a point within 1/512 px above a pixel edge belongs to the pixel BELOW the edge.  Measured on the reference's
+ * index_map shaders (tools/make_golden_gl.py: 47 of 15 697 points; rounds 1-5 had floor(u)). */
+static inline int point_pixel(float u) { return (int)floorf((rintf(u * 256.0f) - 1.0f) / 256.0f); }
+
 void orc_predict_indices(orc_t* o, const float* pose, int time)
 {
     int w = o->w, h = o->h;
@@ -324,7 +330,9 @@ void orc_predict_indices(orc_t* o, const float* pose, int time)
             if (p.z > maxDepth || p.z < 0 || (float)time - o->tm[i * 2 + 1] > (float)o->cfg.time_delta) continue;
             float u = ((fx * p.x) / p.z) + cx, v = ((fy * p.y) / p.z) + cy;
             if (!(u >= 0 && u < (float)w && v >= 0 && v < (float)h)) continue;
-            int k = (int)floorf(v) * w + (int)floorf(u);
+            const int px = point_pixel(u), py = point_pixel(v);
+            if (px < 0 || py < 0) continue;
+            int k = py * w + px;
             if (p.z < tz[k]) { tz[k] = p.z; ti[k] = (int)i; }
         }
         }
@@ -503,6 +511,27 @@ static int dense_enough(orc_t* o)
 /* ------------------------------------------------------------------ fuse (a11, a12) */
 typedef orc_meas meas_t;
 
+/* The window loop of data.vert:151-153 and copy_unstable.vert:110-112 AS THE SHADER TEXT EVALUATES IT in IEEE f32:
+ *     for (float i = c - (scale * step * windowMultiplier); i < c + (scale * step * windowMultiplier); i += step)   with step = (1 / (size * scale)) * 0.5, scale = 1
+ * and the texel a tap reads: nearest filtering = floor(u * size), clamped to the edge (GL 4.5 section 8.14.2; GPUTexture: GL_NEAREST).  In exact arithmetic the loop
+ * makes 4 trips, at -1, -1/2, 0, +1/2 texels from c; in f32 the accumulated `i += step` falls short of the bound in a fraction of the cases (6 % of the projected
+ * positions at 160 columns, 53 % at 320, 26 % at 640) and a FIFTH tap, one texel beyond c, is taken -- and a tap that sits on a texel edge (the +-1/2 taps of data.vert,
+ * whose c is a texel centre) goes to whichever side the f32 product falls.  Pinned by running the reference's shaders (tests/golden/gl_map_passes.npz,
+ * tools/make_golden_gl.py): rounds 1-5 assumed the 4 exact taps.  c: the normalised coordinate (x / cols, or the texcoord attribute); returns the number of taps. */
+#define ORC_MAX_TAPS 8
+static int window_taps(float c, float size, int n, int* tex)
+{
+    const float scale = 1.0f, wm = 2.0f;
+    const float step = (1.0f / (size * scale)) * 0.5f;
+    const float lo = c - (scale * step * wm), hi = c + (scale * step * wm);
+    int k = 0;
+    for (float i = lo; i < hi; i += step)
+        if (k < ORC_MAX_TAPS) tex[k++] = clampi((int)floorf(i * size), 0, n - 1);
+    return k;
+}
+/* the texcoord attribute of pixel column / row i: the uvo buffer of GlobalModel (EF/GlobalModel.cpp:103-119), float(i) / size + 1.0 / (2 * size) evaluated in double and stored as float */
+static float uvo_coord(int i, int size) { return (float)((double)((float)i / (float)size) + 1.0 / (2 * (double)(float)size)); }
+
 /* data.vert:94-241 for the pixel (i,j) */
 static void associate_pixel(orc_t* o, const float* pose, int time, float weighting, int i, int j, meas_t* m)
 {
@@ -534,10 +563,11 @@ static void associate_pixel(orc_t* o, const float* pose, int time, float weighti
     float bestDist = 1000;
     uint32_t best = 0;
     int counter = 0;
-    static const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
-    for (int a = 0; a < 4; a++)
-        for (int b = 0; b < 4; b++) { /* x outer, y inner as in data.vert:151-153 */
-            int tx = clampi((int)floorf(x + offs[a]), 0, w - 1), ty = clampi((int)floorf(y + offs[b]), 0, h - 1);
+    int txs[ORC_MAX_TAPS], tys[ORC_MAX_TAPS];
+    const int ntx = window_taps(uvo_coord(i, w), (float)w, w, txs), nty = window_taps(uvo_coord(j, h), (float)h, h, tys);
+    for (int a = 0; a < ntx; a++)
+        for (int b = 0; b < nty; b++) { /* x outer, y inner as in data.vert:151-153 */
+            int tx = txs[a], ty = tys[b];
             int k = ty * w + tx;
             uint32_t cur = o->index_id[k];
             if (cur > 0u) {
@@ -597,10 +627,11 @@ static int clean_test(orc_t* o, const float* tinv, int time, const float* pc, co
     int count = 0, zCount = 0;
     float wv = *lastT;
     if ((float)time - wv < (float)timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)w && y < (float)h) {
-        static const float offs[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
-        for (int a = 0; a < 4; a++)
-            for (int b = 0; b < 4; b++) {
-                int tx = clampi((int)floorf(x + offs[a]), 0, w - 1), ty = clampi((int)floorf(y + offs[b]), 0, h - 1);
+        int txs[ORC_MAX_TAPS], tys[ORC_MAX_TAPS];
+        const int ntx = window_taps(x / (float)w, (float)w, w, txs), nty = window_taps(y / (float)h, (float)h, h, tys);
+        for (int a = 0; a < ntx; a++)
+            for (int b = 0; b < nty; b++) {
+                int tx = txs[a], ty = tys[b];
                 int k = ty * w + tx;
                 if (o->index_id[k] > 0u) {
                     const float* vc = &o->index_vc[k * 4];

@@ -17,7 +17,16 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 
 /* ======================================================================= preprocessing (a2) */
 
-/* EF/Shaders/depth_bilateral.frag:32-75.  Texture taps float(cx)/cols are restated as texel cx. */
+/* The texel a tap of depth_bilateral.frag:59-61 reads: the shader samples at texture(gSampler, vec2(float(cx) / cols, float(cy) / rows)) -- the CORNER of texel (cx, cy), not
+ * its centre -- with GL_NEAREST, i.e. texel floor(u * size) (GL 4.5 section 8.14.2): cx itself, unless the f32 quotient times the size falls just below cx, in which case
+ * the tap reads texel cx - 1.  At 640 columns no column does; at 480 rows seven rows do (63, 125, 126, 127, 250, 252, 254).  Pinned by executing the reference's shader
+ * (tests/golden/gl_map_passes.npz); rounds 1-5 took texel cx for every tap. */
+static inline int bilateral_tap(int c, int n)
+{
+    int t = (int)floorf(((float)c / (float)n) * (float)n);
+    return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+}
+/* EF/Shaders/depth_bilateral.frag:32-75. */
 void orc_bilateral(const uint16_t* in, uint16_t* out, int w, int h, float maxD)
 {
     const float sigma_space2_inv_half = 0.024691358f;
@@ -33,7 +42,7 @@ void orc_bilateral(const uint16_t* in, uint16_t* out, int w, int h, float maxD)
             float sum1 = 0, sum2 = 0;
             for (int cy = imax(y - D / 2, 0); cy < ty; ++cy)
                 for (int cx = imax(x - D / 2, 0); cx < tx; ++cx) {
-                    uint32_t tmp = in[cy * w + cx];
+                    uint32_t tmp = in[bilateral_tap(cy, h) * w + bilateral_tap(cx, w)];
                     float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) +
                                    ((float)y - (float)cy) * ((float)y - (float)cy);
                     float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);

@@ -44,11 +44,37 @@ def _encode_rgb(c3):
     return ((r[..., 0] << 8) + r[..., 1] << 8) + r[..., 2]
 
 
+def _window_texels(c, size):
+    """The texels the shaders' window loop reads on one axis (data.vert:151-153, copy_unstable.vert:110-112), evaluated as the GLSL text says in IEEE f32:
+    `for (float i = c - (scale * step * 2); i < c + (scale * step * 2); i += step)` with step = (1.0f / (size * scale)) * 0.5f, scale = 1, each tap read with
+    GL_NEAREST = texel floor(u * size) clamped to the edge.  Four taps in exact arithmetic; the f32 accumulation makes it five for a fraction of the centres
+    (tests/golden/gl_map_passes.npz: the reference's shaders, executed, agree with this reading tap for tap)."""
+    f = np.float32
+    size_f, scale, wm = f(size), f(1.0), f(2.0)
+    step = (f(1.0) / (size_f * scale)) * f(0.5)
+    lo, hi = f(c) - (scale * step * wm), f(c) + (scale * step * wm)
+    out, i = [], lo
+    while i < hi:
+        out.append(min(max(int(np.floor(f(i * size_f))), 0), size - 1))
+        i = f(i + step)
+    return out
+
+
+def _uvo(i, size):
+    """the texcoord attribute of pixel column / row i (EF/GlobalModel.cpp:103-119: float(i) / size + 1.0 / (2 * size) in double, stored as float)"""
+    return np.float32(np.float64(np.float32(i) / np.float32(size)) + 1.0 / (2 * np.float64(np.float32(size))))
+
+
+def _point_pixel(u):
+    """a 1-pixel GL point: snapped to 1/256 px, drawn as the 1x1 square around it, pixel centres on the lower edge included (measured on the reference's index_map shaders)"""
+    return int(np.floor((np.rint(np.float32(np.float32(u) * np.float32(256.0))) - 1.0) / 256.0))
+
+
 # ------------------------------------------------------------------------------------------------ a11 + a12
 def test_association_and_fusion_from_the_formulas(orc, small_stream):
     """data.vert:94-241 + update.vert:55-141.  A pixel is active iff i % 2 == j % 2 == t % 2, its four raw-depth neighbours are
-    non-zero and 0 < z <= 20.  Over the index-map window -- per axis the four taps {-1, -1/2, 0, +1/2} px from the pixel centre, i.e. texels
-    {i-1, i, i, i+1}, x outer, y inner -- a candidate (camera-frame position q, normal m) passes if |q_z lambda - v_z lambda| < 0.05 and
+    non-zero and 0 < z <= 20.  Over the index-map window -- per axis the taps of the shader's float loop from one texel below the pixel centre in half-texel steps
+    (_window_texels: four, sometimes five), x outer, y inner -- a candidate (camera-frame position q, normal m) passes if |q_z lambda - v_z lambda| < 0.05 and
     (|m_z| < 0.75 or angle(m, n) < 0.5); the score is the distance of q to the pixel ray, strict < keeps the first best.  The first pixel in
     column-major order that targets a surfel updates it: if r_new < 1.5 r_old the confidence-weighted average of position, colour and (normal,
     radius), normal renormalised; always c += a and lastTime = t."""
@@ -79,7 +105,9 @@ def test_association_and_fusion_from_the_formulas(orc, small_stream):
         zz = z[jj, ii]
         return np.array([(i + 0.5 + di - CX) * zz / FX, (j + 0.5 + dj - CY) * zz / FY, zz])
 
-    taps = (-1, 0, 0, 1)                            # texel offsets of the four window taps of an axis
+    tap_cols = [_window_texels(_uvo(i, W), W) for i in range(W)]      # the window's texels per pixel column / row: the shader's float loop around the pixel centre
+    tap_rows = [_window_texels(_uvo(j, H), H) for j in range(H)]
+    assert all(4 <= len(c_) <= 5 for c_ in tap_cols + tap_rows)
     target, meas = {}, {}
     par = t % 2
     n_active = n_match = 0
@@ -107,9 +135,8 @@ def test_association_and_fusion_from_the_formulas(orc, small_stream):
             lam = np.sqrt(xl * xl + yl * yl + 1)
             ray = np.array([xl, yl, 1.0])
             best, best_d = 0, 1000.0
-            for di in taps:
-                for dj in taps:
-                    ii, jj = min(max(i + di, 0), W - 1), min(max(j + dj, 0), H - 1)
+            for ii in tap_cols[i]:
+                for jj in tap_rows[j]:
                     cur = idx[jj, ii]
                     if cur <= 0:
                         continue
@@ -202,7 +229,6 @@ def test_clean_rules_from_the_formulas(orc, small_stream):
     o.clean(posef, t)
     after = o.download()
     Ti = _inv(pose)
-    taps = (-1, 0, 0, 1)
     keep = np.zeros(nb, bool)
     n_win = n_cnt = n_z = 0
     for s in range(nb):
@@ -219,9 +245,13 @@ def test_clean_rules_from_the_formulas(orc, small_stream):
                 nl = Ti[:3, :3] @ before["nr"][s, :3].astype(np.float64)
                 nl /= np.linalg.norm(nl)
                 r = float(before["nr"][s, 3])
-                for ox in (-1.0, -0.5, 0.0, 0.5):
-                    for oy in (-1.0, -0.5, 0.0, 0.5):
-                        ii, jj = min(max(int(np.floor(x + ox)), 0), W - 1), min(max(int(np.floor(y + oy)), 0), H - 1)
+                # (the window's taps depend on the last bits of x / cols: the projection is redone in f32, operation by operation as copy_unstable.vert:103-106 writes it)
+                f = np.float32
+                Tf, pf = Ti.astype(np.float32), before["pc"][s, :3]
+                lf = [f(f(f(f(Tf[r_, 0] * pf[0]) + f(Tf[r_, 1] * pf[1])) + f(Tf[r_, 2] * pf[2])) + Tf[r_, 3]) for r_ in range(3)]
+                xf_, yf_ = f(f(f(f(FX) * lf[0]) / lf[2]) + f(CX)), f(f(f(f(FY) * lf[1]) / lf[2]) + f(CY))
+                for ii in _window_texels(xf_ / np.float32(W), W):
+                    for jj in _window_texels(yf_ / np.float32(H), H):
                         if idx[jj, ii] <= 0:
                             continue
                         q, qc = ivc[jj, ii, :3], ivc[jj, ii, 3]
@@ -270,7 +300,7 @@ def test_splat_index_and_id_renders_from_the_formulas(orc, small_stream):
     """splat.vert + combo_splat.frag:39-66: a surfel is drawn in the ACTIVE prediction iff 0 <= l_z <= maxDepth, c >= threshold and
     t - lastTime <= timeDelta; a pixel centre (px + 1/2, py + 1/2) is covered iff the ray through it meets the surfel's plane within its radius; the
     fragment's depth is the z of that intersection, the nearest wins (ties: lowest index); outputs vertex ((px + 1/2 - cx) z / fx, ..., z, c), camera
-    normal + radius, initTime.  index_map.vert: a 1-px point at floor(projected coordinate), nearest l_z wins, culled by depth range and time window
+    normal + radius, initTime.  index_map.vert: a 1-px point at the pixel of its projected coordinate (snapped to 1/256 px, lower edges inclusive: _point_pixel), nearest l_z wins, culled by depth range and time window
     only.  surfel_ids.*: stable surfels (c > threshold, z / maxDepth > 0.01, no time window) as discs."""
     st = small_stream
     o, _ = _state(orc, st, 6)
@@ -346,7 +376,9 @@ def test_splat_index_and_id_renders_from_the_formulas(orc, small_stream):
         u, v = FX * P[s, 0] / P[s, 2] + CX, FY * P[s, 1] / P[s, 2] + CY
         if not (0 <= u < W and 0 <= v < H):
             continue
-        k = (int(np.floor(v)), int(np.floor(u)))
+        k = (_point_pixel(v), _point_pixel(u))
+        if k[0] < 0 or k[1] < 0:
+            continue
         if k not in best or P[s, 2] < P[best[k], 2]:
             best[k] = s
     want = np.zeros((H, W), np.int64)

@@ -24,18 +24,24 @@ def _pair(gputest_pair):
 # ------------------------------------------------------------------------------------------------ a2
 def test_bilateral_and_metric_from_the_shaders(orc, gputest_pair):
     """EF/Shaders/depth_bilateral.frag:31-76: value outside [300, maxD * 1000] -> 0; else the 13 x 13 window clipped to the image, weight = exp(-(space2 *
-    0.024691358 + color2 * 0.000555556)) over ALL texels of the window (zeros included), output round(sum1 / sum2).  depth_metric.frag:29-40: the same gate, value / 1000."""
+    0.024691358 + color2 * 0.000555556)) over ALL texels of the window (zeros included), output round(sum1 / sum2).  A tap (cx, cy) is READ at
+    texture(gSampler, vec2(float(cx) / cols, float(cy) / rows)) -- the corner of its texel -- with GL_NEAREST, i.e. texel floor(u * size) in f32: cx itself, or cx - 1
+    for the few indices whose quotient times the size falls just below cx (the reference's shader, executed, does exactly this: tests/golden/gl_map_passes.npz).
+    depth_metric.frag:29-40: the same gate, value / 1000."""
     depth, _, _, w, h = _pair(gputest_pair)
     L = orc.lib()
     maxD = 12.0
     d = depth.astype(np.float64)
+    f = np.float32
+    read_col = np.array([min(max(int(np.floor(f(f(f(c_) / f(w)) * f(w)))), 0), w - 1) for c_ in range(w)])     # the texel a tap at column c_ reads
+    read_row = np.array([min(max(int(np.floor(f(f(f(r_) / f(h)) * f(h)))), 0), h - 1) for r_ in range(h)])
     s1 = np.zeros((h, w)); s2 = np.zeros((h, w))
     for dy in range(-6, 7):
         for dx in range(-6, 7):
             ys, xs = np.mgrid[0:h, 0:w]
             cy, cx = ys + dy, xs + dx
             ok = (cy >= 0) & (cy < h) & (cx >= 0) & (cx < w)
-            t = d[np.clip(cy, 0, h - 1), np.clip(cx, 0, w - 1)]
+            t = d[read_row[np.clip(cy, 0, h - 1)], read_col[np.clip(cx, 0, w - 1)]]
             wgt = np.where(ok, np.exp(-((dx * dx + dy * dy) * 0.024691358 + (d - t) ** 2 * 0.000555556)), 0.0)
             s1 += t * wgt; s2 += wgt
     gate = (depth > int(maxD * 1000.0)) | (depth < 300)

@@ -103,8 +103,8 @@ __host__ __device__ inline float ifx_expf(float x)
 // and the texel each tap reads under GL_NEAREST: floor(u * size), clamped to the edge (GL 4.5 section 8.14.2).  In exact arithmetic the loop makes four trips, at -1, -1/2, 0,
 // +1/2 texels from c; in f32 the accumulated `i += step` falls short of the bound in a fraction of the cases and a FIFTH tap, one texel beyond c, is taken -- and a tap that
 // sits on a texel edge goes to whichever side the f32 product falls.  Pinned by executing the reference's shaders (tests/golden/gl_map_passes.npz, tools/make_golden_gl.py;
-// the same function, statement for statement, in oracle/orc_map.c).  Returns the number of taps (4 or 5; at most IFX_MAX_TAPS are recorded).
-#define IFX_MAX_TAPS 8
+// the same function, statement for statement, in oracle/orc_map.c).  Returns the number of taps (4 or 5).
+#define IFX_MAX_TAPS 5   // (the span is four steps wide: rounding can add a trip, never two, and never takes one away; the oracle aborts if a loop ever made a sixth)
 __device__ __forceinline__ int window_taps(float c, float size, int n, int* tex)
 {
     const float scale = 1.0f, wm = 2.0f;

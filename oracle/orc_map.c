@@ -518,15 +518,17 @@ typedef orc_meas meas_t;
  * positions at 160 columns, 53 % at 320, 26 % at 640) and a FIFTH tap, one texel beyond c, is taken -- and a tap that sits on a texel edge (the +-1/2 taps of data.vert,
  * whose c is a texel centre) goes to whichever side the f32 product falls.  Pinned by running the reference's shaders (tests/golden/gl_map_passes.npz,
  * tools/make_golden_gl.py): rounds 1-5 assumed the 4 exact taps.  c: the normalised coordinate (x / cols, or the texcoord attribute); returns the number of taps. */
-#define ORC_MAX_TAPS 8
+#define ORC_MAX_TAPS 5   /* the span is four steps wide: rounding can add a trip, never two (lo + 5 step is a whole step beyond hi), and never takes one away */
 static int window_taps(float c, float size, int n, int* tex)
 {
     const float scale = 1.0f, wm = 2.0f;
     const float step = (1.0f / (size * scale)) * 0.5f;
     const float lo = c - (scale * step * wm), hi = c + (scale * step * wm);
     int k = 0;
-    for (float i = lo; i < hi; i += step)
-        if (k < ORC_MAX_TAPS) tex[k++] = clampi((int)floorf(i * size), 0, n - 1);
+    for (float i = lo; i < hi; i += step) {
+        if (k >= ORC_MAX_TAPS) { fprintf(stderr, "orc: window loop with more than %d taps (c = %.9g, size = %g)\n", ORC_MAX_TAPS, (double)c, (double)size); abort(); }
+        tex[k++] = clampi((int)floorf(i * size), 0, n - 1);
+    }
     return k;
 }
 /* the texcoord attribute of pixel column / row i: the uvo buffer of GlobalModel (EF/GlobalModel.cpp:103-119), float(i) / size + 1.0 / (2 * size) evaluated in double and stored as float */

@@ -311,8 +311,8 @@ def main():
     ol.build()
     NF = 16
     st = synth.make_stream(NF + 1, W, H, noise=True, **K)
-    o = ol.Oracle(w=W, h=H, max_surfels=200000, confidence=CONF, **K)
-    o2 = ol.Oracle(w=W, h=H, max_surfels=200000, confidence=CONF, **K)      # the same frames plus the next one: its pose for that frame
+    o = ol.Oracle(w=W, h=H, max_surfels=max(200000, W * H * 8), confidence=CONF, **K)
+    o2 = ol.Oracle(w=W, h=H, max_surfels=max(200000, W * H * 8), confidence=CONF, **K)      # the same frames plus the next one: its pose for that frame
     for i in range(NF):
         o.process_frame(st["rgb"][i], st["depth"][i]); o2.process_frame(st["rgb"][i], st["depth"][i])
     rgb, depth = st["rgb"][NF], st["depth"][NF]

@@ -142,6 +142,23 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     hipMemset(h->d_list_ctr, 0, 5 * IFX_LIST_SEGS * 32 * 4);
     ALLOC(h->list_v, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4); ALLOC(h->list_vi, (size_t)h->list_seg_cap * IFX_LIST_SEGS * 4);
     hipMemset(h->upd_owner, 0xFF, C * 4);
+    {   // the association window's texels per pixel column and row (data.vert:151-153 as its f32 loop runs: ifx_dev.h window_taps), a property of the index alone: tabulated
+        ALLOC(h->assoc_vis, (size_t)(h->w + h->h));
+        std::vector<uint8_t> vis((size_t)(h->w + h->h), 0);
+        for (int axis = 0; axis < 2; axis++) {
+            const int n = axis ? h->h : h->w;
+            for (int i = 0; i < n; i++) {
+                int tex[IFX_MAX_TAPS];
+                window_taps(uvo_coord(i, n), (float)n, n, tex);
+                const int t3[3] = {std::min(std::max(i - 1, 0), n - 1), i, std::min(i + 1, n - 1)};
+                uint8_t m = 0;
+                for (int q = 0; q < IFX_MAX_TAPS; q++)
+                    for (int a = 0; a < 3; a++) if (tex[q] == t3[a]) m |= (uint8_t)(1u << a);
+                vis[(size_t)(axis ? h->w : 0) + i] = m;
+            }
+        }
+        hipMemcpy(h->assoc_vis, vis.data(), vis.size(), hipMemcpyHostToDevice);
+    }
     ALLOC(h->labels, C * 4); ALLOC(h->labels2, C * 4);
     ALLOC(h->seq, C * 4); ALLOC(h->seq2, C * 4);
     hipMemset(h->labels, 0xFF, C * 4);
@@ -229,7 +246,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     if (h->ev_cam_parked) hipEventDestroy(h->ev_cam_parked);
     if (h->ev_lc_ready) hipEventDestroy(h->ev_lc_ready);
     if (h->ev_lc_done) hipEventDestroy(h->ev_lc_done);
-    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
+    void* ptrs[] = {h->d_state, h->d_traj, h->d_scratch, h->pc, h->nr, h->col, h->tm, h->ic, h->votes, h->pc2, h->nr2, h->col2, h->tm2, h->ic2, h->votes2, h->upd_owner, h->assoc_vis, h->list_a, h->list_b, h->list_c, h->list_v, h->list_vi, h->d_list_ctr, h->tile_n, h->tile_box, h->tile_pairs, h->tile_recs, h->labels, h->seq, h->seq2,
                     h->labels2, h->scan_flags, h->scan_out, h->scan_block, h->slot[0].rgb, h->slot[0].depth_raw, h->slot[0].depth_filt, h->slot[0].dm, h->slot[0].dmf, h->slot[1].rgb, h->slot[1].depth_raw,
                     h->slot[1].depth_filt, h->slot[1].dm, h->slot[1].dmf, h->key_index, h->key_both,
                     h->index_id, h->index_vc, h->index_ct, h->index_tap, h->pred_vertex, h->fill_vertex,

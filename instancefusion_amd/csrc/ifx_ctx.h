@@ -420,6 +420,7 @@ struct ifx {
     float *pc = nullptr, *nr = nullptr, *col = nullptr, *tm = nullptr, *ic = nullptr, *votes = nullptr;
     float *pc2 = nullptr, *nr2 = nullptr, *col2 = nullptr, *tm2 = nullptr, *ic2 = nullptr, *votes2 = nullptr; // compaction targets
     uint32_t* upd_owner = nullptr;     // [cap] first-pixel-wins arbitration of the fuse pass
+    uint8_t* assoc_vis = nullptr;      // [w + h] which of the texels i - 1, i, i + 1 the association window of pixel column (row) i reads: bits 0..2 (window_taps of the column's texcoord, computed once at create)
     uint32_t *list_v = nullptr, *list_vi = nullptr;   // [8 x list_seg_cap] the cached view lists, flat (lengths: DevState::vl_n): inside / outside the time window
     int view_frame = 0;                 // the frame being enqueued went through the view list (its end-of-frame raster may too)
     int view_block = 0;                 // the pose was replaced after the view-list decision of this frame (pose adoption): the frame takes the per-pass culls

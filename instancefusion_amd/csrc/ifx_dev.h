@@ -105,7 +105,7 @@ __host__ __device__ inline float ifx_expf(float x)
 // sits on a texel edge goes to whichever side the f32 product falls.  Pinned by executing the reference's shaders (tests/golden/gl_map_passes.npz, tools/make_golden_gl.py;
 // the same function, statement for statement, in oracle/orc_map.c).  Returns the number of taps (4 or 5).
 #define IFX_MAX_TAPS 5   // (the span is four steps wide: rounding can add a trip, never two, and never takes one away; the oracle aborts if a loop ever made a sixth)
-__device__ __forceinline__ int window_taps(float c, float size, int n, int* tex)
+__host__ __device__ __forceinline__ int window_taps(float c, float size, int n, int* tex)
 {
     const float scale = 1.0f, wm = 2.0f;
     const float step = (1.0f / (size * scale)) * 0.5f;
@@ -124,11 +124,37 @@ __device__ __forceinline__ int window_taps(float c, float size, int n, int* tex)
     return k;
 }
 // the texcoord attribute of pixel column / row i: the uvo buffer of GlobalModel (EF/GlobalModel.cpp:103-119), float(i) / size + 1.0 / (2 * size) evaluated in double, stored as float
-__device__ __forceinline__ float uvo_coord(int i, int size) { return (float)((double)((float)i / (float)size) + 1.0 / (2 * (double)(float)size)); }
+__host__ __device__ __forceinline__ float uvo_coord(int i, int size) { return (float)((double)((float)i / (float)size) + 1.0 / (2 * (double)(float)size)); }
 // The pixel a 1-pixel GL point at window coordinate u lands on: the position snaps to the rasteriser's sub-pixel grid (8 bits), the point is the 1x1 square around it, and a
 // pixel is produced when its centre lies in that square, lower edge included, upper edge not: floor(u), except that a point within 1/512 px above a pixel edge belongs to
 // the pixel below the edge (measured on the reference's index_map shaders: oracle/orc_map.c point_pixel).  -1: left of / above the image.
 __device__ __forceinline__ int point_pixel(float u) { return (int)floorf((rintf(u * 256.0f) - 1.0f) / 256.0f); }
+
+// ifx_expf on two arguments at once with the packed f32 instructions of CDNA3 / CDNA4 (v_pk_mul_f32, v_pk_add_f32: two IEEE operations per lane and issue slot, no fused
+// multiply-add).  Operation for operation the scalar routine above -- each component's result is bit-identical to ifx_expf of that component -- for arguments that are
+// finite and <= 0 (the bilateral weights); what the scalar routine's first two branches handle is folded into the final select.
+typedef float ifx_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ifx_v2f ifx_expf2_nonpos(ifx_v2f x)
+{
+    ifx_v2f n;
+    n.x = rintf(x.x * 1.44269504088896341f); n.y = rintf(x.y * 1.44269504088896341f);
+    ifx_v2f r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    ifx_v2f p = (ifx_v2f)(1.0f / 5040.0f);
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    ifx_v2f s;
+    s.x = __uint_as_float((unsigned int)(((int)n.x + 127) & 0xFF) << 23); s.y = __uint_as_float((unsigned int)(((int)n.y + 127) & 0xFF) << 23);   // (& 0xFF: an argument below -87 is selected away below)
+    ifx_v2f e = p * s;
+    e.x = (x.x > -87.0f) ? e.x : 0.0f;
+    e.y = (x.y > -87.0f) ? e.y : 0.0f;
+    return e;
+}
 
 // color.glsl:19-34
 __device__ inline float encode_color(float r, float g, float b)

@@ -2094,7 +2094,7 @@ int ifx_ids_ensure(ifx* h)
 __global__ void k_associate(const DevState* __restrict__ st, const float* __restrict__ pose_ex, float weighting_ex, const float* __restrict__ dm, const float* __restrict__ dmf,
                             const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ index_id, const float4* __restrict__ index_vc,
                             const float4* __restrict__ index_nr, Cam c, int time, uint32_t* __restrict__ assoc, float4* __restrict__ mpc, float4* __restrict__ mnr,
-                            float* __restrict__ mcol, uint32_t* __restrict__ upd_owner, unsigned long long* __restrict__ akey = nullptr)
+                            float* __restrict__ mcol, uint32_t* __restrict__ upd_owner, const uint8_t* __restrict__ vis, unsigned long long* __restrict__ akey = nullptr)
 {
     const int fl = FIRST_LIVE(c);
     // Only the pixels with i % 2 == j % 2 == time % 2 create measurements (data.vert:98): one thread per 2x2 block, so that
@@ -2126,17 +2126,8 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
         const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};
         // WHICH of the three columns / rows the shader's window loop visits is decided by its f32 arithmetic (window_taps, ifx_dev.h): the taps run from the centre of texel
         // i - 1 in half-texel steps, so i - 1 and i are always among them, while i + 1 is reached only when the tap on the edge between i and i + 1 falls to the right of it or
-        // the loop makes its fifth trip -- a property of the column (row) index alone.  Visiting order and first-visit semantics are unchanged.
-        unsigned int vis_x = 0u, vis_y = 0u;
-        {
-            int tx[IFX_MAX_TAPS], ty[IFX_MAX_TAPS];
-            window_taps(uvo_coord(i, c.w), (float)c.w, c.w, tx);
-            window_taps(uvo_coord(j, c.h), (float)c.h, c.h, ty);
-#pragma unroll
-            for (int q = 0; q < IFX_MAX_TAPS; q++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) { vis_x |= (tx[q] == xs[a]) ? (1u << a) : 0u; vis_y |= (ty[q] == ys[a]) ? (1u << a) : 0u; }
-        }
+        // the loop makes its fifth trip -- a property of the column (row) index alone, tabulated when the handle is created.  Visiting order and first-visit semantics are unchanged.
+        const unsigned int vis_x = vis[i], vis_y = vis[c.w + j];   // (tabulated at create from window_taps: ifx_api.hip)
         uint32_t cur[9];
 #pragma unroll
         for (int a = 0; a < 3; a++)
@@ -2570,7 +2561,7 @@ static void fuse_pass(ifx* h, const float* d_pose, float weighting, int time, in
     dim3 b(32, 8), g(cdiv(cdiv(h->w, 2), 32), cdiv(cdiv(h->h, 2), 8));   // one thread per 2x2 pixel block
     if (part != 2)
         LAUNCH(h, "associate", g, b, k_associate, h->d_state, d_pose, weighting, h->dm, h->dmf, h->rgb, h->index_id, (const float4*)h->index_vc, (const float4*)h->index_nr, c, time,
-               h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner, part == 1 ? h->assoc_key : (unsigned long long*)nullptr);
+               h->assoc_target, (float4*)h->meas_pc, (float4*)h->meas_nr, h->meas_col, h->upd_owner, (const uint8_t*)h->assoc_vis, part == 1 ? h->assoc_key : (unsigned long long*)nullptr);
     if (part == 1) return;
     const bool slots = part == 2 && own_slot && h->own_slot_img;
     if (part == 2) LAUNCH(h, "assoc_decode", g, b, k_assoc_decode, h->d_state, (const unsigned long long*)h->assoc_key, h->index_id, c, time, h->assoc_target, h->upd_owner,

@@ -18,6 +18,41 @@
 #define BIL_R 6
 #define BIL_BX 32
 #define BIL_BY 8
+// The 13 x 13 window of one pixel: rows in a loop, the thirteen taps of a row unrolled -- their LDS reads leave together, and the taps go through the exponential two at a
+// time with the packed f32 instructions (ifx_expf2_nonpos: 36 M -> ~21 M VALU wave-instructions per frame; the kernel was 85 % VALU-bound, profiles/r06_c_pmc_bound.json).
+// Every tap goes through the scalar form's operations in the scalar form's order, and the two sums take their terms in tap order: results are bit-identical.
+template <bool SHIFTED, bool XCLIP>
+__device__ __forceinline__ void bil_window(const uint16_t (*tile)[BIL_BX + 2 * BIL_R + 3], const unsigned char* s_mapx, const unsigned char* s_mapy, int x, int y, int bx, int by, int tx1,
+                                           int ty1, unsigned int value, float& sum1, float& sum2)
+{
+    const float ss = 0.024691358f, sc = 0.000555556f;
+    constexpr int D = BIL_R * 2 + 1;
+    const float fv = (float)value;
+    for (int cy = max(y - D / 2, 0); cy < ty1; ++cy) {
+        const int ry = SHIFTED ? (int)s_mapy[cy - by + BIL_R + 1] : cy - by + BIL_R + 1;
+        const float dy = (float)y - (float)cy, dy2 = dy * dy;
+        float tv[D];
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            const int col = x - D / 2 + q - bx + BIL_R + 1;   // (inside the tile for every q: the tile reaches BIL_R + 1 columns to the left and BIL_R to the right of the block)
+            tv[q] = (float)tile[ry][SHIFTED ? (int)s_mapx[col] : col];
+        }
+#pragma unroll
+        for (int q = 0; q < D; q += 2) {
+            const int cx = x - D / 2 + q;
+            const bool ok0 = !XCLIP || (cx >= 0 && cx < tx1), ok1 = q + 1 < D && (!XCLIP || (cx + 1 >= 0 && cx + 1 < tx1));
+            ifx_v2f dxv, t2;
+            dxv.x = (float)x - (float)cx; dxv.y = (float)x - (float)(cx + 1);
+            t2.x = tv[q]; t2.y = q + 1 < D ? tv[q + 1] : 0.f;
+            const ifx_v2f space2 = dxv * dxv + dy2;
+            const ifx_v2f dv = fv - t2;
+            const ifx_v2f color2 = dv * dv;
+            const ifx_v2f wgt = ifx_expf2_nonpos(-(space2 * ss + color2 * sc));
+            if (ok0) { sum1 += t2.x * wgt.x; sum2 += wgt.x; }
+            if (ok1) { sum1 += t2.y * wgt.y; sum2 += wgt.y; }
+        }
+    }
+}
 __global__ __launch_bounds__(BIL_BX* BIL_BY) void k_bilateral_metric(const uint16_t* __restrict__ in, uint16_t* __restrict__ filt,
                                                                       float* __restrict__ dm, float* __restrict__ dmf, int w, int h, float maxD)
 {
@@ -64,18 +99,11 @@ __global__ __launch_bounds__(BIL_BX* BIL_BY) void k_bilateral_metric(const uint1
         const int D = BIL_R * 2 + 1;
         int tx1 = min(x - D / 2 + D, w), ty1 = min(y - D / 2 + D, h);
         float sum1 = 0, sum2 = 0;
-        const bool shifted = s_shifted != 0;   // (block-uniform: most blocks have no such column or row and index the tile directly)
-        for (int cy = max(y - D / 2, 0); cy < ty1; ++cy) {
-            const int ry = shifted ? (int)s_mapy[cy - by + BIL_R + 1] : cy - by + BIL_R + 1;
-            for (int cx = max(x - D / 2, 0); cx < tx1; ++cx) {
-                unsigned int tmp = tile[ry][shifted ? (int)s_mapx[cx - bx + BIL_R + 1] : cx - bx + BIL_R + 1];
-                float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
-                float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
-                float weight = ifx_expf(-(space2 * ss + color2 * sc));
-                sum1 += (float)tmp * weight;
-                sum2 += weight;
-            }
-        }
+        // Block-uniform cases as template parameters (no branch inside the tap loop): SHIFTED -- a column or row of this tile whose corner tap reads the texel before it;
+        // XCLIP -- the block touches the left or right image border, where a window is clipped (taps outside the image are skipped, not read as zero).
+        const bool shifted = s_shifted != 0, xclip = bx < BIL_R || bx + BIL_BX + BIL_R > w;
+        if (shifted) { if (xclip) bil_window<true, true>(tile, s_mapx, s_mapy, x, y, bx, by, tx1, ty1, value, sum1, sum2); else bil_window<true, false>(tile, s_mapx, s_mapy, x, y, bx, by, tx1, ty1, value, sum1, sum2); }
+        else { if (xclip) bil_window<false, true>(tile, s_mapx, s_mapy, x, y, bx, by, tx1, ty1, value, sum1, sum2); else bil_window<false, false>(tile, s_mapx, s_mapy, x, y, bx, by, tx1, ty1, value, sum1, sum2); }
         outv = (unsigned int)roundf(sum1 / sum2);
         outv &= 0xFFFFu;
     }

@@ -13,6 +13,8 @@
  *       of the elements (values to f32 rounding); bilateral 99.96 % of the pixels (1 mm: exp); splat prediction 99.98 %; surfel ids 99.0 % (a documented
  *       coverage rule).  The GL calls around the shaders restate the reference's host code (Pangolin / GLEW / CUDA interop do not build here);
  *       every formula that decides a result is the reference's own text, executed.
+ *     f-3, GPU part (the deformation graph applied by the clean pass + synthesizeDepth): the same generator; survivors, positions (1.4e-6 m), normals and re-activated
+ *       last-seen times equal the shader's.
  *     a20 (gSLICr: the reference's shared per-pixel maths, -DCOMPILE_WITHOUT_CUDA, oracle/_ref/libref_slic.so, tests/test_oracle_slic.py)
  *     f-2 (k-NN: the reference's vendored FLANN 1.8.4, oracle/ref_knn.cpp, tests/golden/knn_ref.npz)
  *   "PARITY UNPINNED" -- restated by hand from the sources, each function citing the file:line it follows, cross-checked by a second restatement in numpy

@@ -193,11 +193,50 @@ def _handle(mod, cls, gold, **kw):
     return x
 
 
+def deformation_and_compare(x, gold):
+    """f-3: a deformation graph applied by the clean pass (copy_unstable.vert:176-330: binary search of the node times, the k = 4 nearest of 20 nodes, weighted rigid
+    transforms, renormalised normal; stable surfels in front of the synthesised INACTIVE depth are re-activated) -- the survivors' positions, normals and last-seen times
+    against the reference's shader on the same map (time window 6 frames: the map has inactive surfels) and the same 70-node graph."""
+    g = gold
+    t = int(g["d_time"])
+    x.predict_indices(g["d_pose"], t)
+    x.set_deformation(g["d_graph"], False)
+    x.clean(g["d_pose"], t)
+    m = x.download()
+    out = {"f-3 deformation: survivors here / reference": (int(m["pc"].shape[0]), int(g["gl_d_kept"].shape[0]))}
+    assert m["pc"].shape[0] == g["gl_d_kept"].shape[0]
+    k = g["gl_d_kept"].astype(np.int64)
+    assert np.array_equal(m["pc"][:, 3], g["d_map_pc"][k, 3]) and np.array_equal(m["tm"][:, 0], g["d_map_tm"][k, 0])        # the same surfels survive, in order
+    out["f-3 deformation: positions within 1e-5 m %"] = float((np.abs(m["pc"][:, :3] - g["gl_d_pc"][:, :3]).max(axis=1) < 1e-5).mean() * 100)
+    out["f-3 deformation: normals within 1e-4 %"] = float((np.abs(m["nr"][:, :3] - g["gl_d_nr"][:, :3]).max(axis=1) < 1e-4).mean() * 100)
+    out["f-3 deformation: last-seen times equal %"] = float((m["tm"][:, 1] == g["gl_d_tm"][:, 1]).mean() * 100)
+    out["f-3 deformation: largest displacement m"] = float(np.abs(m["pc"][:, :3] - g["d_map_pc"][k, :3]).max())
+    out["f-3 deformation: surfels re-activated"] = int(((m["tm"][:, 1] == t) & (g["d_map_tm"][k, 1] != t)).sum())
+    assert out["f-3 deformation: positions within 1e-5 m %"] >= 99.9 and out["f-3 deformation: normals within 1e-4 %"] >= 99.9 and out["f-3 deformation: last-seen times equal %"] >= 99.9
+    assert out["f-3 deformation: largest displacement m"] > 0.02 and out["f-3 deformation: surfels re-activated"] > 100
+    return out
+
+
+def _handle_d(cls, gold, **kw):
+    W, H = int(gold["width"]), int(gold["height"])
+    fx, fy, cx, cy = map(float, gold["K"])
+    x = cls(w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, max_surfels=200000, confidence=float(gold["confidence"]), time_delta=int(gold["d_time_delta"]), **kw)
+    n = gold["d_map_pc"].shape[0]
+    x.upload(dict(pc=gold["d_map_pc"], nr=gold["d_map_nr"], col=gold["d_map_col"], tm=gold["d_map_tm"], ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32)))
+    x.set_pose(gold["d_pose"], int(gold["d_time"]))
+    return x
+
+
 def test_oracle_against_the_reference_shaders(gold, orc):
     orc.set_threads(orc.usable_cores())
     o = _handle(orc, orc.Oracle, gold)
     check(run_and_compare(Stages(o, "oracle", gold), gold), "CPU oracle")
     o.close()
+    od = _handle_d(orc.Oracle, gold)
+    od.set_loop_closure(True)      # (allocates the INACTIVE prediction's buffers, where a deforming clean synthesises its depth image)
+    for k, v in deformation_and_compare(od, gold).items():
+        print(f"   {k:78s} {v}")
+    od.close()
 
 
 @pytest.mark.gpu
@@ -209,3 +248,9 @@ def test_hip_path_against_the_reference_shaders(gold):
     g.set_option("compact_every_frame", 1)      # (slot numbers = map indices: the id images name surfels as the reference does)
     check(run_and_compare(Stages(g, "hip", gold), gold), "HIP path (C-ABI stage calls)")
     g.close()
+    gd = _handle_d(ifx.ElasticFusion, gold)
+    gd.set_option("compact_every_frame", 1)
+    gd.set_loop_closure(True)
+    for k, v in deformation_and_compare(gd, gold).items():
+        print(f"   {k:78s} {v}")
+    gd.close()

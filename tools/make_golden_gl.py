@@ -87,6 +87,11 @@ class RefGL:
         self.uvo = gl.buffer(uv, usage=G.GL_STATIC_DRAW)
         self.new_unstable = gl.buffer(nbytes=W * H * VSIZE)
         self.count_query, self.delete_query = gl.query(), gl.query()
+        # IndexMap::synthesizeDepth (EF/IndexMap.cpp:66-82, 161-162) and the deformation nodes (EF/GlobalModel.cpp:44: a 16384 x 1 float texture, 16 floats per node)
+        self.depth_prog = gl.program(SHADERS, "splat.vert", "depth_splat.frag")
+        self.syn_depth_tex = gl.tex2d(W, H, G.GL_R32F, G.GL_RED, G.GL_FLOAT)
+        self.syn_depth_fbo = gl.framebuffer(W, H, [self.syn_depth_tex])
+        self.node_tex = gl.tex2d(16384, 1, G.GL_R32F, G.GL_RED, G.GL_FLOAT, np.zeros((1, 16384), np.float32))
         self.dummy_f = gl.tex2d(4, 4, G.GL_R32F, G.GL_RED, G.GL_FLOAT, np.zeros((4, 4), np.float32))
         # preprocessing, EF/ElasticFusion.cpp:216-229 (ComputePack): one point -> quad.geom -> fragment shader
         self.filter_prog = gl.program(SHADERS, "empty.vert", "depth_bilateral.frag", "quad.geom")
@@ -139,11 +144,11 @@ class RefGL:
                     depth_metric_filtered=gl.read_tex(self.dmf_tex, W, H, G.GL_RED, G.GL_FLOAT, np.float32, 1))
 
     # IndexMap::predictIndices, EF/IndexMap.cpp:221-279
-    def predict_indices(self, vbo, n, pose, time):
+    def predict_indices(self, vbo, n, pose, time, time_delta=TIME_DELTA):
         gl = self.gl
         gl.begin_pass(self.index_fbo, W, H, "ufff")
         gl.uniforms(self.index_prog, t_inv=np.linalg.inv(pose.astype(np.float32)), cam=self.cam(), maxDepth=MAX_DEPTH, cols=float(W), rows=float(H),
-                    time=int(time), timeDelta=int(TIME_DELTA))
+                    time=int(time), timeDelta=int(time_delta))
         gl.attribs(vbo, 3, VSIZE)
         gl.glDrawArrays(G.GL_POINTS, 0, n)
         gl.attribs_off(3)
@@ -250,19 +255,41 @@ class RefGL:
         fused = gl.read_buffer(out, n * VSIZE).reshape(n, 64)
         return records, fused, out, n_rec, (upd_ct[:n, 3] == -1)
 
-    # GlobalModel::clean, EF/GlobalModel.cpp:700-925 (no deformation graph): survivors of the map, then the frame's new unstable surfels, through copy_unstable.vert / .geom
-    def clean(self, vbo, n, n_rec, pose, time):
+    # IndexMap::synthesizeDepth, EF/IndexMap.cpp:576-648, as ElasticFusion::processFrame calls it before a deforming clean (EF/ElasticFusion.cpp:667-676): time = tick,
+    # maxTime = tick - timeDelta, timeDelta = 65535
+    def synthesize_depth(self, vbo, n, pose, time, time_delta):
         gl = self.gl
+        gl.glEnable(G.GL_PROGRAM_POINT_SIZE)
+        gl.begin_pass(self.syn_depth_fbo, W, H, "f")
+        gl.uniforms(self.depth_prog, t_inv=np.linalg.inv(pose.astype(np.float32)), cam=self.cam(), maxDepth=MAX_DEPTH, confThreshold=float(CONF), cols=float(W), rows=float(H),
+                    time=int(time), maxTime=int(time - time_delta), timeDelta=65535)
+        gl.attribs(vbo, 3, VSIZE)
+        gl.glDrawArrays(G.GL_POINTS, 0, n)
+        gl.attribs_off(3)
+        gl.end_pass()
+        gl.glDisable(G.GL_PROGRAM_POINT_SIZE)
+        return gl.read_tex(self.syn_depth_tex, W, H, G.GL_RED, G.GL_FLOAT, np.float32, 1)
+
+    # GlobalModel::clean, EF/GlobalModel.cpp:700-925 (no deformation graph): survivors of the map, then the frame's new unstable surfels, through copy_unstable.vert / .geom
+    def clean(self, vbo, n, n_rec, pose, time, graph=None, time_delta=TIME_DELTA, is_fern=False):
+        gl = self.gl
+        nodes = 0
+        if graph is not None:      # EF/GlobalModel.cpp:713-720: glTexSubImage2D of the raw graph into the node texture
+            g16 = np.ascontiguousarray(graph, np.float32).reshape(-1)
+            nodes = g16.size // 16
+            row = np.zeros((1, 16384), np.float32)
+            row[0, : g16.size] = g16
+            self._upload(self.node_tex, 16384, 1, G.GL_R32F, G.GL_RED, G.GL_FLOAT, row)
         out = gl.buffer(nbytes=(n + n_rec + 1) * VSIZE)
         ids = gl.buffer(nbytes=(n + 1) * 4)
         gl.uniforms(self.unstable_prog, time=int(time), confThreshold=float(CONF), scale=1.0, indexSampler=0, vertConfSampler=1, colorTimeSampler=2, normRadSampler=3, nodeSampler=4,
-                    depthSampler=5, nodes=0.0, nodeCols=16384.0, timeDelta=int(TIME_DELTA), maxDepth=MAX_DEPTH, isFern=0, t_inv=np.linalg.inv(pose.astype(np.float32)), cam=self.cam(),
+                    depthSampler=5, nodes=float(nodes), nodeCols=16384.0, timeDelta=int(time_delta), maxDepth=MAX_DEPTH, isFern=int(is_fern), t_inv=np.linalg.inv(pose.astype(np.float32)), cam=self.cam(),
                     cols=float(W), rows=float(H), isNew=1)      # (isNew: what the previous frame's clean left it at, EF/GlobalModel.cpp:851)
         gl.attribs(vbo, 16, VSIZE)
         gl.glEnable(G.GL_RASTERIZER_DISCARD)
         gl.glBindBufferBase(G.GL_TRANSFORM_FEEDBACK_BUFFER, 0, out)
         gl.glBindBufferBase(G.GL_TRANSFORM_FEEDBACK_BUFFER, 1, ids)
-        gl.bind_textures([self.index_tex, self.vert_conf_tex, self.color_time_tex, self.norm_rad_tex, self.dummy_f, self.dummy_f])
+        gl.bind_textures([self.index_tex, self.vert_conf_tex, self.color_time_tex, self.norm_rad_tex, self.node_tex if nodes else self.dummy_f, self.syn_depth_tex if nodes else self.dummy_f])
         gl.glBeginTransformFeedback(G.GL_POINTS)
         gl.glBeginQuery(G.GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, self.count_query)
         gl.glDrawArrays(G.GL_POINTS, 0, n)                                   # survivors -> stream 0
@@ -300,6 +327,17 @@ def survivors_of(before, after_pc):
     keep, j = [], 0
     for i in range(before.shape[0]):
         if j < after_pc.shape[0] and np.array_equal(before[i, :3], after_pc[j, :3]):
+            keep.append(i); j += 1
+    return np.array(keep, np.int64), j
+
+
+def survivors_of_deformed(before, after):
+    """survivors of a clean pass that also MOVED them (deformation): rows are matched by their untouched columns -- confidence, radius, colour, initTime -- in order"""
+    key_b = np.stack([before["pc"][:, 3], before["nr"][:, 3], before["col"][:, 0], before["tm"][:, 0], before["ic"][:, 0], before["ic"][:, 1]], 1)
+    key_a = np.stack([after["pc"][:, 3], after["nr"][:, 3], after["col"][:, 0], after["tm"][:, 0], after["ic"][:, 0], after["ic"][:, 1]], 1)
+    keep, j = [], 0
+    for i in range(key_b.shape[0]):
+        if j < key_a.shape[0] and np.array_equal(key_b[i], key_a[j]):
             keep.append(i); j += 1
     return np.array(keep, np.int64), j
 
@@ -417,6 +455,52 @@ def main():
             d = np.abs(v[..., :3] - ov[..., :3]).max(axis=-1)
             report("a9 " + k, within_1e_5_pct=float((d[fin] < 1e-5).mean() * 100), within_1e_3_pct=float((d[fin] < 1e-3).mean() * 100), nonfinite_differs=int((np.isfinite(v).all(axis=-1) != np.isfinite(ov).all(axis=-1)).sum()))
         gold["gl_" + k] = v
+    # ---- f-3: the deformation graph applied by the clean pass (copy_unstable.vert:176-330) + IndexMap::synthesizeDepth (splat.vert, depth_splat.frag).  A map with INACTIVE
+    # surfels (time window of 6 frames over a moving camera), a synthetic graph: every 300th surfel a node, ordered by time, a small rotation + translation each.
+    TD = 6
+    od = ol.Oracle(w=W, h=H, max_surfels=max(200000, W * H * 8), confidence=CONF, time_delta=TD, **K)
+    pd = None
+    for i in range(NF):
+        pd = od.process_frame(st["rgb"][i], st["depth"][i]).astype(np.float32)
+    md = od.download()
+    td = int(od.tick)
+    nd = md["pc"].shape[0]
+    rng = np.random.RandomState(5)
+    pick = np.arange(0, nd, 300)
+    pick = pick[np.argsort(md["tm"][pick, 0], kind="stable")]
+    graph = np.zeros((pick.size, 16), np.float32)
+    for k_, s_ in enumerate(pick):
+        ax = rng.standard_normal(3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(-0.03, 0.03)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        graph[k_, 0:3] = md["pc"][s_, :3]
+        graph[k_, 3:12] = R.T.reshape(9)                     # column-major, as Eigen stores the node's rotation (EF/Deformation.cpp:195-197)
+        graph[k_, 12:15] = rng.uniform(-0.01, 0.01, 3)
+        graph[k_, 15] = md["tm"][s_, 0]
+    vbo_d = gl.buffer(pack_vbo(md))
+    od.predict_indices(pd, td)
+    oid = {k: od.image(k) for k in ("index", "index_vc", "index_ct", "index_nr")}
+    ref.set_index_images(oid)
+    g_depth = ref.synthesize_depth(vbo_d, nd, pd, td, TD)
+    cleaned_d, kept_d, _, count_d = ref.clean(vbo_d, nd, 0, pd, td, graph=graph, time_delta=TD)
+    od.set_loop_closure(True)             # (allocates the buffers of the INACTIVE prediction, into which the oracle synthesises the depth image of a deforming clean)
+    od.set_deformation(graph, False)
+    od.clean(pd, td)
+    mdc = od.download()
+    cd = unpack_vbo(cleaned_d)
+    o_keep_d, o_nk_d = survivors_of_deformed(md, mdc)
+    same_set = np.array_equal(np.sort(kept_d), o_keep_d)
+    dpos = np.abs(cd["pc"][:, :3] - mdc["pc"][:, :3]).max(axis=1) if same_set else np.array([np.nan])
+    dnrm = np.abs(cd["nr"][:, :3] - mdc["nr"][:, :3]).max(axis=1) if same_set else np.array([np.nan])
+    moved = np.abs(mdc["pc"][:, :3] - md["pc"][o_keep_d, :3]).max(axis=1) if same_set else np.array([np.nan])
+    report("f-3 deformation in the clean pass", nodes=int(pick.size), gl_survivors=int(kept_d.shape[0]), oracle_survivors=int(o_nk_d), same_set=bool(same_set), inactive_depth_px=int((g_depth > 0).sum()),
+           moved_max_m=float(moved.max()), pos_within_1e_5_pct=float((dpos < 1e-5).mean() * 100), pos_max=float(dpos.max()), normal_within_1e_4_pct=float((dnrm < 1e-4).mean() * 100),
+           last_time_equal_pct=float((cd["tm"][:, 1] == mdc["tm"][:, 1]).mean() * 100) if same_set else float("nan"),
+           reactivated_gl=int(((cd["tm"][:, 1] == td) & (md["tm"][kept_d, 1] != td)).sum()) if same_set else -1)
+    gold.update(d_time_delta=np.int32(TD), d_time=np.int32(td), d_pose=pd, d_map_pc=md["pc"], d_map_nr=md["nr"], d_map_col=md["col"], d_map_tm=md["tm"], d_graph=graph,
+                gl_d_kept=kept_d.astype(np.int32), gl_d_pc=cd["pc"], gl_d_nr=cd["nr"], gl_d_tm=cd["tm"], gl_d_depth=g_depth)
+    od.close()
     gl.close()
     if (W, H) != (160, 120):
         print("(not the golden size: nothing written)")

@@ -387,6 +387,7 @@ def main():
                 t = table[nme]
                 if t["launches"] and nme != best and t["total_ms"] > 0.95 * table[best]["total_ms"] and alg(nme) > alg(best):
                     best = nme
+        scan_avg, scan_cnt = ef.kernel_ms("cull_frame@scan")
         ef.set_option("kernel_timing", 0)
         # HBM traffic per launch: PMC counters cannot be read from inside the process.  They are collected by tools/pmc_collect.sh (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS command, corrected as MI355X_MICROARCH.md prescribes, per access pattern: tools/pmc_summary.py) into
@@ -426,6 +427,12 @@ def main():
             # the dominant kernel by time is a latency-bound reduction; the passes that stream the whole surfel
             # store are reported next to it so that the bandwidth-bound part of the path has its roofline numbers too
             roof["streaming_passes"] = [entry(n_) for n_ in ("cull_frame", "cull_raster", "cull_clean", "index_project", "count_colour") if table.get(n_, {}).get("launches")]
+            # ... and k_cull_frame's SCANNING launches on their own (most launches find the cached lists valid and return at once: the entry above averages over all of them)
+            if scan_avg > 0 and scan_cnt:
+                b_scan = alg("cull_frame")
+                roof["streaming_passes"].append(dict(bound="hbm", kernel="cull_frame@scan", achieved=round(b_scan / (scan_avg * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                     frac=round(b_scan / (scan_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), avg_launch_ms=round(scan_avg, 5), bytes_per_launch=b_scan, launches=scan_cnt,
+                                                     what="the launches of k_cull_frame that scanned the store (24 B per slot: position + confidence, times), by duration > 20 us"))
             # the list-driven passes that ARE the map stage on the frame path, and the per-call kernels of the instance layer: achieved fraction and waste ratio of each
             roof["map_passes"] = [entry(n_) for n_ in ("clean_raster_view", "raster_view", "clean_view", "index_list", "fuse_update", "associate", "index_resolve", "splat_resolve", "project_bbox", "count_colour_px")
                                   if table.get(n_, {}).get("launches")]

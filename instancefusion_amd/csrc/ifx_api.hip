@@ -43,7 +43,18 @@ static void ktime_flush(ifx* h)
 {
     for (auto& pe : h->kpending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) { h->ktimes[pe.name_id].total_ms += ms; h->ktimes[pe.name_id].launches++; }
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            h->ktimes[pe.name_id].total_ms += ms; h->ktimes[pe.name_id].launches++;
+            // k_cull_frame decides ON THE DEVICE whether it scans the store or returns at its first instruction (the cached view lists are still valid): the launches that
+            // did scan are also kept under "cull_frame@scan" -- told apart by their duration (a launch that returns at once takes ~4 us, a scan of a million slots ~20)
+            if (ms > 0.02f && h->knames[pe.name_id] == "cull_frame") {
+                auto it = h->kname_id.find("cull_frame@scan");
+                int id;
+                if (it == h->kname_id.end()) { id = (int)h->knames.size(); h->kname_id["cull_frame@scan"] = id; h->knames.push_back("cull_frame@scan"); h->ktimes.push_back(KernelTiming()); }
+                else id = it->second;
+                h->ktimes[id].total_ms += ms; h->ktimes[id].launches++;
+            }
+        }
         h->event_pool.push_back(pe.a);
         h->event_pool.push_back(pe.b);
     }

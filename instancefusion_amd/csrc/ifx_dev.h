@@ -10,7 +10,7 @@
 #define IFX_VF 48
 // The vote counters of a surfel are ONE 192-byte record (48 floats = 12 float4, the layout of the C API's [n][48] arrays): everything that goes from a pixel's id to
 // its surfel's votes -- the projected boxes, the label scan under the id image, whetherDoSegmentation's vote mass -- is a gather, and a record is 1.5 cache lines where
-// twelve planes were twelve (round 3; gfx950 moves a 128-byte line per 16-byte gather, profiles/r03_b_pmc_calibration.json).
+// twelve planes were twelve (round 3; gfx950 moves a 128-byte line per 16-byte gather, profiles/archive/r03_b_pmc_calibration.json).
 #define VOTE4(votes, id, q) (votes)[(size_t)(id) * 12 + (q)]
 #define VOTEF(votes, id, fi) (votes)[(size_t)(id) * IFX_VF + (fi)]
 #define IFX_MAX_SPRITE 512.0f

@@ -755,7 +755,7 @@ __device__ inline int clean_test(const float* T, const Cam& c, int time, float4 
 // work list (wave ballot -> one atomicAdd per wave), and (2) a dense pass over the list that reads
 // normal+radius and does the expensive part (disc rasterisation / window taps) with every lane
 // busy.  The one-kernel versions above ran at 0.6-1.1 TB/s because the heavy path diverged inside
-// waves of mostly-culled surfels (profiles/r01_a: the one-kernel raster 205 us, the one-kernel clean 206 us for 5.6M slots).
+// waves of mostly-culled surfels (profiles/archive/r01_a: the one-kernel raster 205 us, the one-kernel clean 206 us for 5.6M slots).
 #define LIST_SPLAT 0x40000000u
 #define LIST_IDS 0x80000000u
 #define LIST_IDX 0x3FFFFFFFu
@@ -1495,9 +1495,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_cull_frame(DevState* st, const 
 // concatenated into two flat lists, to which k_append_scan adds the new surfels.  (Sorting the lists by screen tile of the scan pose
 // was tried -- a wave then works inside one 32x32-pixel neighbourhood -- and changed nothing: raster 79 -> 84 us, clean 64 -> 67 us,
 // index 28 -> 29 us.  The list passes are bound by their GATHERS FROM THE STORE, one 64-B line per field and entry whatever the order of
-// the list: 476 k window entries + 640 k outside ones out of 5.4 M slots; profiles/r02_l_kernel_stats_tile_sorted_lists.csv.  Compact copies of
+// the list: 476 k window entries + 640 k outside ones out of 5.4 M slots; profiles/archive/r02_l_kernel_stats_tile_sorted_lists.csv.  Compact copies of
 // the hot fields in list order, kept coherent through the fusion update / clean / append, were tried next: raster 79 -> 74 us, clean 64 -> 54,
-// index 28 -> 23, but the fusion update 13 -> 23 and 11 us per frame for the copies: no net gain, removed; profiles/r02_p_kernel_stats_compact_view_cache.csv.
+// index 28 -> 23, but the fusion update 13 -> 23 and 11 us per frame for the copies: no net gain, removed; profiles/archive/r02_p_kernel_stats_compact_view_cache.csv.
 // What is left in these passes is their atomics and the clean pass's taps.)
 __global__ void k_vlist_offsets(DevState* st, Cam c, const float2* __restrict__ tm)
 {
@@ -2908,7 +2908,7 @@ int ifx_map_predict(ifx* h)
 {
     static const bool no_ids = getenv("IFX_EXPERIMENT_NO_IDS") != nullptr;   // measurement only: what the per-frame id render costs (the id image is then stale)
     const unsigned int want = LIST_SPLAT | ((h->ids_pending && !no_ids) ? LIST_IDS : 0u);
-    // the tiled rasteriser only on request: at 1280x960 / 20 M surfels the view-list rasteriser takes 455 us where cull + bin + tile raster take 744 (profiles/r02_o_1280_20m.txt)
+    // the tiled rasteriser only on request: at 1280x960 / 20 M surfels the view-list rasteriser takes 455 us where cull + bin + tile raster take 744 (profiles/archive/r02_o_1280_20m.txt)
     const bool tiles = h->opt_raster_tiles > 0;
     if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick) && !tiles) {   // the frame built / checked the view list and nothing renumbered the store since
         Cam c = make_cam(h);

@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_so3(const DevState* __restrict_
 // Pivoted LDLT (Eigen's LDLT as used by EF/Utils/RGBDOdometry.cpp:368,552).  Everything is
 // compile-time unrolled with predicated swaps so that the matrix lives in registers: a
 // runtime-indexed private array goes to scratch memory and made the first version of the solve
-// kernel take 24 us (profiles/r01_a_*).
+// kernel take 24 us (profiles/archive/r01_a_*).
 template <typename T, int N>
 __device__ __forceinline__ void ldlt_solve_n(const T* Ain, const T* bin, T* x, T tiny)
 {

@@ -4,7 +4,7 @@
 The oracle (CPU restatement) runs the 640x480 benchmark loop twice: with the exact, order-independent sums of the normal equations (what the HIP
 path reproduces bit for bit) and with `orc_set_sum_order(3)`: f32 products summed in f32 in the tree the reference's kernels build with its GTX 1080
 launch table (EF/Cuda/reduce.cu:133-185, :397-402; EF/Utils/GPUConfig.h:123-126).  Everything else -- pixels, gates, solver, map -- is identical.
-Writes the per-frame trajectory gap as JSON (committed: profiles/r03_reference_tree_gap.json).
+Writes the per-frame trajectory gap as JSON (committed: profiles/archive/r03_reference_tree_gap.json).
 
     python tools/reference_tree_gap.py [frames=90] [out.json]
 """

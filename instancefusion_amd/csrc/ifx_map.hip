@@ -1882,27 +1882,9 @@ __global__ __launch_bounds__(MAP_THREADS, CLEAN ? WALK_MIN_WAVES : 1) void k_ras
                     }
                 }
             }
-            float4 n4g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (flags) n4g = (CLEAN && have_n) ? n4c : (hot ? hot[i].nr : ld_once(&nr[i]));
-            if (flags == LIST_IDS && ids_step > 1 && !dual) {
-                // An entry that can only draw ids, on the SAMPLED lattice (the frame path between segmentation calls: every ids_step-th pixel): most such discs lie between the
-                // lattice points -- of the 0.54 M entries of the stable-outside-the-window list one in four reaches one.  A conservative test in front of the geometry (four corner
-                // projections, a normalisation): every point of the quad lies within R = r sqrt(2) of the centre q, so its image lies within f R (q.z + |q.x|) / (q.z (q.z - R))
-                // pixels of the centre's; no lattice point in that box (widened by a pixel), nothing to draw.  Pure pruning: what is drawn is tested exactly as before.
-                const v3 q = xf_point(T, v3m(p4.x, p4.y, p4.z));
-                const float R = n4g.w * 1.41421356f;
-                if (q.z > R * 1.05f) {
-                    const float inv = 1.0f / (q.z * (q.z - R));
-                    const float u = ((c.fx * q.x) / q.z) + c.cx, v = ((c.fy * q.y) / q.z) + c.cy;
-                    const float ru = c.fx * R * (q.z + fabsf(q.x)) * inv * 1.01f + 1.5f, rv = c.fy * R * (q.z + fabsf(q.y)) * inv * 1.01f + 1.5f;
-                    const int bx0 = max((int)floorf(u - ru), 0), bx1 = min((int)ceilf(u + ru), c.w - 1), by0 = max((int)floorf(v - rv), 0), by1 = min((int)ceilf(v + rv), c.h - 1);
-                    const int lx0 = ((bx0 + ids_step - 1) / ids_step) * ids_step, ly0 = ((by0 + ids_step - 1) / ids_step) * ids_step;
-                    if (bx1 < bx0 || by1 < by0 || lx0 > bx1 || ly0 > by1) flags = 0;
-                }
-            }
             if (flags) {
                 SurfGeo G;
-                surfel_geo(T, p4, n4g, dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
+                surfel_geo(T, p4, (CLEAN && have_n) ? n4c : (hot ? hot[i].nr : ld_once(&nr[i])), dual ? (i | LIST_SPLAT) : (i | flags), c, G);   // (dual: the sprite region for whichever render draws it)
                 int sx0 = G.sx0, sx1 = G.sx1, sy0 = G.sy0, sy1 = G.sy1, ix0, ix1, iy0, iy1;
                 bool do_i = dual ? (G.do_s && (flags & LIST_IDS)) : surfel_id_box(G, i | flags, c, ix0, ix1, iy0, iy1);
                 const bool do_s = dual ? (G.do_s && (flags & LIST_SPLAT)) : G.do_s;

@@ -348,7 +348,13 @@ def main():
 
     ol.build()
     NF = 16
-    st = synth.make_stream(NF + 1, W, H, noise=True, **K)
+    seed, motion = int(os.environ.get("IFX_GL_SEED", "0")), os.environ.get("IFX_GL_MOTION", "")      # (other scenes / camera motions: one-off runs, nothing written)
+    if seed or motion:
+        scene = synth.Scene(seed or 1)
+        st = synth.make_stream_from_poses(synth.trajectory_profile(motion or "nominal", NF + 1, seed or 1), scene, W, H, noise_seed=(seed or 1) + 1, **K)
+        print(f"scene seed {seed or 1}, motion {motion or 'nominal'}")
+    else:
+        st = synth.make_stream(NF + 1, W, H, noise=True, **K)
     o = ol.Oracle(w=W, h=H, max_surfels=max(200000, W * H * 8), confidence=CONF, **K)
     o2 = ol.Oracle(w=W, h=H, max_surfels=max(200000, W * H * 8), confidence=CONF, **K)      # the same frames plus the next one: its pose for that frame
     for i in range(NF):
@@ -502,8 +508,8 @@ def main():
                 gl_d_kept=kept_d.astype(np.int32), gl_d_pc=cd["pc"], gl_d_nr=cd["nr"], gl_d_tm=cd["tm"], gl_d_depth=g_depth)
     od.close()
     gl.close()
-    if (W, H) != (160, 120):
-        print("(not the golden size: nothing written)")
+    if (W, H) != (160, 120) or seed or motion:
+        print("(not the golden configuration: nothing written)")
         return
     out = os.path.join(OUT, "gl_map_passes.npz")
     np.savez_compressed(out, **gold)

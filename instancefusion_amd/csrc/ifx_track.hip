@@ -709,6 +709,17 @@ __device__ __forceinline__ const float* gn_prologue(const DevState* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         float Rc[9], tc[3], krk[9], kt[3];
+#ifdef GN_SOLVE_TWICE   // measurement build (tools/ab.sh -b "ifx_track:-DGN_SOLVE_TWICE"): the serial part a second time, its result folded in as an exact zero -- what the solve costs the frame
+        {
+            double RRt2[16];
+            float Rc2[9], tc2[3], krk2[9], kt2[3];
+#pragma unroll
+            for (int k = 0; k < 16; k++) RRt2[k] = RRt[k];
+            gn_serial_lane(s_psys, g.icp, RRt2, Rp, tp, g.nfx, g.nfy, g.ncx, g.ncy, g.ki, Rc2, tc2, krk2, kt2);
+            asm volatile("" : "+v"(Rc2[0]));
+            if (Rc2[0] > 3.0e38f) s_psys[0] += 1.0;   // (never true; keeps the first run alive and in front of the second)
+        }
+#endif
         gn_serial_lane(s_psys, g.icp, RRt, Rp, tp, g.nfx, g.nfy, g.ncx, g.ncy, g.ki, Rc, tc, krk, kt);
 #pragma unroll
         for (int k = 0; k < 9; k++) { s_ppose[k] = Rc[k]; s_ppose[12 + k] = krk[k]; }

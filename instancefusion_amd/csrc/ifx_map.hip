@@ -2120,7 +2120,7 @@ __global__ void k_associate(const DevState* __restrict__ st, const float* __rest
         // Every load of the pixel is issued up front -- the raw and filtered depth crosses, the colour, the index-map window -- and the reference's
         // tests then run on registers in the reference's order.  (Written test by test, each load sat behind the previous test's branch: up to
         // ~30 dependent round trips for a launch of only 300 blocks, 24 us.)
-        // The window: offsets {-1, -0.5, 0, 0.5} around a pixel centre floor to {i-1, i, i, i+1}: 3 x 3 distinct texels, visited 16 times.  A repeated
+        // The window: half-texel steps from the centre of texel i - 1 reach {i-1, i, i+1} at most: 3 x 3 distinct texels, visited 16 to 25 times.  A repeated
         // visit never changes the running best (dist < bestDist is strict), so the nine first visits in the original (a, b) order decide.
         const int xs[3] = {clampi((int)floorf(x - 1.0f), 0, c.w - 1), clampi((int)floorf(x - 0.5f), 0, c.w - 1), clampi((int)floorf(x + 0.5f), 0, c.w - 1)};
         const int ys[3] = {clampi((int)floorf(y - 1.0f), 0, c.h - 1), clampi((int)floorf(y - 0.5f), 0, c.h - 1), clampi((int)floorf(y + 0.5f), 0, c.h - 1)};

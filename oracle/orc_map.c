@@ -2,15 +2,14 @@
  * oracle/orc_map.c -- CPU restatement of the surfel-map half of the path (SURVEY.md 8a rows a1,
  * a9-a15) and of ElasticFusion::processFrame's orchestration.  TEST INFRASTRUCTURE ONLY (orc.h).
  *
- * The reference implements these stages as OpenGL passes (transform feedback + rasterisation).
- * They cannot run here; the rules that replace the rasteriser are fixed and documented in
- * DESIGN.md ("Rasterisation rules") and are the same rules the HIP kernels implement:
- *   - 1-px points (index map): pixel = floor(projected coordinate); nearest z wins, ties -> lowest id.
+ * The reference implements these stages as OpenGL passes (transform feedback + rasterisation).  Since round 6 its UNMODIFIED shaders are executed on Mesa's software
+ * rasteriser (oracle/gl/, tools/make_golden_gl.py) and this file is held to their outputs (tests/test_gl_golden.py).  The rules in place of the GL rasteriser, the same
+ * the HIP kernels implement:
+ *   - 1-px points (index map): the pixel of the projected coordinate snapped to 1/256 px, lower pixel edges inclusive (point_pixel); nearest z wins, ties -> lowest id.
  *   - splats / id discs: a pixel is covered iff the ray through its centre (i+0.5, j+0.5) hits the
  *     surfel disc (EF/Shaders/combo_splat.frag:39-52); nearest intersection z wins, ties -> lowest id.
- *   - association / clean windows: 4 taps per axis at offsets {-1,-0.5,0,+0.5} px, texel =
- *     floor(coordinate) clamped to the image (the exact-arithmetic reading of
- *     EF/Shaders/data.vert:137-153 and copy_unstable.vert:110-151 with IndexMap::FACTOR = 1).
+ *   - association / clean windows: the shaders' FLOAT loop as IEEE f32 runs it (window_taps: four taps per axis, five where the accumulated step falls short of the
+ *     bound), each tap read at texel floor(u * size) clamped to the image (EF/Shaders/data.vert:137-153, copy_unstable.vert:110-151, IndexMap::FACTOR = 1).
  */
 #define _POSIX_C_SOURCE 199309L
 #include <time.h>

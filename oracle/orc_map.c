@@ -533,6 +533,11 @@ static int window_taps(float c, float size, int n, int* tex)
 /* the texcoord attribute of pixel column / row i: the uvo buffer of GlobalModel (EF/GlobalModel.cpp:103-119), float(i) / size + 1.0 / (2 * size) evaluated in double and stored as float */
 static float uvo_coord(int i, int size) { return (float)((double)((float)i / (float)size) + 1.0 / (2 * (double)(float)size)); }
 
+/* test hooks (tests/test_oracle_cpu.py pins the three rules against their numpy statement from the shader text) */
+int orc_test_window_taps(float c, float size, int n, int* tex) { return window_taps(c, size, n, tex); }
+float orc_test_uvo_coord(int i, int size) { return uvo_coord(i, size); }
+int orc_test_point_pixel(float u) { return point_pixel(u); }
+
 /* data.vert:94-241 for the pixel (i,j) */
 static void associate_pixel(orc_t* o, const float* pose, int time, float weighting, int i, int j, meas_t* m)
 {

@@ -26,6 +26,7 @@ static inline int bilateral_tap(int c, int n)
     int t = (int)floorf(((float)c / (float)n) * (float)n);
     return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
 }
+int orc_test_bilateral_tap(int c, int n) { return bilateral_tap(c, n); }
 /* EF/Shaders/depth_bilateral.frag:32-75. */
 void orc_bilateral(const uint16_t* in, uint16_t* out, int w, int h, float maxD)
 {

@@ -174,6 +174,49 @@ def _tiny_map(n=4):
     return dict(pc=pc, nr=nr, col=col, tm=tm, ic=np.zeros((n, 4), np.float32), votes=np.zeros((n, 48), np.float32))
 
 
+def test_window_loop_point_and_tap_rules_as_the_shaders_run_them(orc):
+    """The three rules that executing the reference's GLSL pinned in round 6, each against a statement written here from the shader text:
+    the float window loop of data.vert:151-153 / copy_unstable.vert:110-112 (four or FIVE taps), the pixel of a 1-pixel GL point, the texel a bilateral tap reads."""
+    from test_restatement_map_numpy import _point_pixel, _uvo, _window_texels
+
+    L = orc.lib()
+    L.orc_test_window_taps.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p]
+    L.orc_test_uvo_coord.restype = C.c_float
+    L.orc_test_uvo_coord.argtypes = [C.c_int, C.c_int]
+    L.orc_test_point_pixel.argtypes = [C.c_float]
+    L.orc_test_bilateral_tap.argtypes = [C.c_int, C.c_int]
+    tex = np.zeros(8, np.int32)
+    rng = np.random.RandomState(3)
+    five = {}
+    for size in (160, 320, 640, 1280, 120, 240, 480, 960):
+        # association: the window around every pixel centre of the axis (the texcoord attribute of the uvo buffer)
+        for i in range(size):
+            c = _uvo(i, size)
+            assert L.orc_test_uvo_coord(i, size) == c
+            n = L.orc_test_window_taps(float(c), float(size), size, orc.ptr(tex))
+            want = _window_texels(c, size)
+            assert n == len(want) and tex[:n].tolist() == want, (size, i)
+            assert 4 <= n <= 5 and set(want) <= {max(i - 1, 0), i, min(i + 1, size - 1)} and {max(i - 1, 0), i} <= set(want)
+        # clean: around arbitrary projected positions
+        cnt5 = 0
+        for x in rng.uniform(1.0, size - 1.0, 1500).astype(np.float32):
+            c = np.float32(x) / np.float32(size)
+            n = L.orc_test_window_taps(float(c), float(size), size, orc.ptr(tex))
+            want = _window_texels(c, size)
+            assert n == len(want) and tex[:n].tolist() == want, (size, float(x))
+            cnt5 += n == 5
+        five[size] = cnt5 / 1500.0
+        for c_ in range(size):
+            f = np.float32
+            assert L.orc_test_bilateral_tap(c_, size) == min(max(int(np.floor(f(f(f(c_) / f(size)) * f(size)))), 0), size - 1)
+    assert 0.03 < five[160] < 0.10 and 0.45 < five[320] < 0.60 and 0.20 < five[640] < 0.32, five        # the fifth trip: 6 % / 53 % / 26 % of the positions
+    assert [c_ for c_ in range(480) if L.orc_test_bilateral_tap(c_, 480) != c_] == [63, 125, 126, 127, 250, 252, 254]
+    assert all(L.orc_test_bilateral_tap(c_, 640) == c_ for c_ in range(640))
+    for u in np.concatenate([rng.uniform(0, 640, 4000), np.arange(0, 640) + 1e-3, np.arange(1, 640) - 1e-3, np.arange(0, 640) + 0.0021, np.arange(0, 640, dtype=np.float64)]).astype(np.float32):
+        assert L.orc_test_point_pixel(float(u)) == _point_pixel(u), float(u)
+    assert L.orc_test_point_pixel(12.0) == 11 and L.orc_test_point_pixel(12.0019) == 11 and L.orc_test_point_pixel(12.0021) == 12 and L.orc_test_point_pixel(12.999) == 12
+
+
 def test_index_map_nearest_wins_and_id0_is_empty(orc):
     o = orc.Oracle(**SMALL, max_surfels=1000)
     m = _tiny_map(3)

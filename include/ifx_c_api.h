@@ -203,6 +203,15 @@ int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out);
  * the vote mass of the owned surfels in the buffer ifx_owner_exchange(h, 6, ...) names; phase 7 publishes the frame result). */
 int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const uint16_t* depth, const uint8_t* masks, const int32_t* class_ids, int nm, int frame, int flags);
 int ifx_owner_segmentation_resume(ifx_t* h);
+/* Option "own_lazy_ids" (ifx_set_option, sharded map only; no counterpart in the reference, whose id image -- IndexMap::renderSurfelIds, src/Core/InstanceFusion.cpp:402-466 --
+ * never leaves one GPU): a frame draws and exchanges the id keys of the 10 x 10 lattice whetherDoSegmentation samples only, so exchange 4 carries
+ * [splat keys | lattice keys | word] = 8 P + 8 ceil(w/10) ceil(h/10) + 8 bytes instead of 16 P + 8.  Whoever reads the whole id image completes it: a segmentation call does so
+ * at an exchange point of its own in front of the others (nothing changes for the caller of _begin / _resume); ifx_image_download("ids_after"), ifx_ids_after and
+ * ifx_camera_select do it in place when the library holds the communicator (ifx_owner_init_comm / _set_comm: every rank makes the same call), and return IFX_E_STATE
+ * otherwise -- a caller that runs the exchanges itself calls ifx_owner_ids_begin on every rank first (1: reduce the buffer ifx_owner_exchange(h, 200, ...) names, op 0, then
+ * ifx_owner_ids_resume; 0: the image is whole already). */
+int ifx_owner_ids_begin(ifx_t* h);
+int ifx_owner_ids_resume(ifx_t* h);
 /* InstanceFusion::flannKnnVoteSurfelMap (src/Core/InstanceFusion.cpp:1070-1163) on a sharded map: exact 10-NN over ALL surfels needs every rank's
  * positions.  ifx_owner_knn_export hands out this rank's slots as device arrays -- points[n] float4 (x, y, z, creation number; x = NaN: dead slot),
  * labels[n] int32 (bestIDInEachSurfel) --, the caller all-gathers both in rank order (16 + 4 bytes per slot, once per smoothing, i.e. every > 40

@@ -81,6 +81,8 @@ _SIGS = {
     "ifx_owner_of": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ifx_owner_segmentation_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "ifx_owner_segmentation_resume": (C.c_int, [_P]),
+    "ifx_owner_ids_begin": (C.c_int, [_P]),
+    "ifx_owner_ids_resume": (C.c_int, [_P]),
     "ifx_owner_knn_export": (C.c_int, [_P, _P, _P, _P]),
     "ifx_owner_knn_vote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ifx_owner_predict_phase": (C.c_int, [_P, C.c_int]),

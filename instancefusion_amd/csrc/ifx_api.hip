@@ -341,6 +341,11 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "side_late") h->opt_side_late = value;
     else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
     else if (s == "own_first_live") h->opt_own_first_live = value;
+    else if (s == "own_lazy_ids") {
+        if (!h->own) { h->err = "own_lazy_ids: the handle was not created for a sharded map"; return IFX_E_STATE; }
+        if (value && ifx_own_lattice(h) + 1 > 16 * 1024) { h->err = "own_lazy_ids: the image's id lattice is larger than the pack kernel's one workgroup holds (16 383 entries)"; return IFX_E_INVALID; }
+        h->opt_own_lazy_ids = value;   // (takes effect with the next frame; a sparse image that is still around is completed on demand as before)
+    }
     else if (s == "vlist_one") h->opt_vlist_one = value;
     else if (s == "overdue_rule") h->opt_overdue_rule = value;
     else if (s == "cam_swap") h->opt_cam_swap = value;
@@ -758,8 +763,8 @@ extern "C" int ifx_camera_select(ifx_t* h, int cam)
 #undef CAMCP
         return IFX_OK;
     };
-    ifx_ids_ensure(h);   // a parked id image is a whole one (the map moves on under the other cameras)
-    int r = IFX_OK;
+    int r = ifx_ids_ensure(h);   // a parked id image is a whole one (the map moves on under the other cameras)
+    if (r) return r;
     if (h->cams[(size_t)cam].valid && h->opt_cam_swap) {
         // Both contexts exist: the big blocks -- prediction 46 B/px, fill-in 36, id image 4: 26 MB at 640x480 -- change hands by pointer (the parked context takes
         // the live buffers, the live pointers take the other camera's); only the pose block and the intensity pyramid (0.4 MB) are copied.  53 MB of device
@@ -1155,7 +1160,10 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 1: if (!first) add(h->assoc_key, (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2) * 8, 0); break;   // the best owned candidate of every measurement pixel (distance | window position)
     case 2: if (!first) add(h->key_index, P * 8 + 8, 0); break;                                    // (the word is the reduced one of exchange 0: a MIN of equal values)
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
-    case 4: add(h->key_splat, P * 16 + 8, 0); break;                                                // [key_splat | key_ids] (key_both was folded into them by k_merge_both)
+    case 4:                                                                                         // [key_splat | key_ids | word] (key_both was folded into them by k_merge_both)
+        if (h->own_ids_lat) add(h->key_splat, (P + (size_t)ifx_own_lattice(h)) * 8 + 8, 0);         // option own_lazy_ids: [key_splat | the id keys of the sampled lattice | word]
+        else add(h->key_splat, P * 16 + 8, 0);
+        break;
     case 5:   // [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass of the owned surfels under the id image]
         if (owner_pred_root(h) >= 0) {
             // K streams, camera k tracked by rank k only: the prediction rendered at the end of camera k's frame has ONE consumer, rank k's tracker -- a reduction to that
@@ -1169,7 +1177,8 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     case 310: if (h->own_track_rank >= 0 && !first) add((void*)h->d_state, IFX_CAM_STATE_BYTES, 4 | (h->own_track_rank << 8)); break;   // the tracked pose block, broadcast from the tracking rank
     case 300: if (owner_lc_due(h)) add(h->key_splat, P * 16, 0); break;                       // the detection's two renders: [key_splat (ACTIVE) | key_ids (INACTIVE)]
     case 301: if (owner_lc_due(h)) add(h->act_vertex, 2 * h->lc_half, 1); break;            // [act_* | old_*]: the owners' winners of both
-    case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume)
+    case 200:   // a segmentation call on a sharded map is waiting at an exchange point (ifx_owner_segmentation_begin / _resume), or an id render of the shards (ifx_owner_ids_begin)
+        if (h->own_ids_pending) { add(h->key_ids, P * 8, 0); break; }                              // the whole id image's keys: MIN
         switch (h->oseg_pending) {
         case 1: add(h->d_bbox, (size_t)(96 + h->oseg_nm) * 4 * 4, 2); break;                       // boxes, maxima negated: MIN of 32-bit words
         case 2: add(h->d_pdm, P * 2, 1); break;                                                     // model depth under the camera: disjoint supports
@@ -1180,6 +1189,20 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     default: break;
     }
     return n;
+}
+// The whole id image of a sharded map whose frames draw the sampled lattice only (option own_lazy_ids), for callers that run the exchanges themselves:
+// _begin enqueues the shard's id render and returns 1 (then: the exchange ifx_owner_exchange(h, 200, ...) lists, _resume) or 0 when the image is whole already.
+extern "C" int ifx_owner_ids_begin(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    if (!h->own) { h->err = "ifx_owner_ids_begin: the handle was not created for a sharded map"; return IFX_E_STATE; }
+    if (h->oseg_state) { h->err = "ifx_owner_ids_begin: a segmentation call is in flight"; return IFX_E_STATE; }
+    return ifx_owner_ids_begin_impl(h);
+}
+extern "C" int ifx_owner_ids_resume(ifx_t* h)
+{
+    if (!h) return IFX_E_INVALID;
+    return ifx_owner_ids_resume_impl(h);
 }
 extern "C" int ifx_owner_of(const float* xyz, int n, int n_ranks, int32_t* out)
 {
@@ -1688,7 +1711,7 @@ extern "C" int ifx_set_pose(ifx_t* h, const float* pose16, int tick)
 extern "C" const int32_t* ifx_ids_after(ifx_t* h)
 {
     if (!h) return nullptr;
-    ifx_ids_ensure(h);   // (enqueued on the handle's main stream, like the frame that precedes it)
+    if (ifx_ids_ensure(h)) return nullptr;   // (enqueued on the handle's main stream, like the frame that precedes it)
     return h->ids_after;
 }
 
@@ -1699,7 +1722,7 @@ extern "C" int ifx_image_download(ifx_t* h, const char* name, void* out, int64_t
     size_t P = (size_t)h->P, bytes = 0;
     const void* src = nullptr;
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
-    if (s == "ids_after") { ifx_ids_ensure(h); src = h->ids_after; bytes = P * 4; }
+    if (s == "ids_after") { const int r_ = ifx_ids_ensure(h); if (r_) return r_; src = h->ids_after; bytes = P * 4; }
     else if (s == "ids_tmp") { src = h->ids_tmp; bytes = P * 4; }
     else if (s == "index") { src = h->index_id; bytes = P * 4; }
     else if (s == "index_vc") { src = h->index_vc; bytes = P * 16; }

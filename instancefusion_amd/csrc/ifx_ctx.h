@@ -209,12 +209,11 @@ struct FrameSlot {
 #define IFX_LIST_CTR_STRIDE 32
 
 // decision for the frame whose pose was just committed; one thread (k_track_end / k_commit_pose / pose adoption)
-__device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lctr)
+// (A = the pose the list was built for, B = the pose just committed: pointers into the state, or registers the caller loaded ahead of its stores)
+__device__ __forceinline__ void vlist_decide_core(DevState* st, const float* A, const float* B, int valid, int age)
 {
-    bool ok = st->vl_valid && st->vl_age < VL_MAX_AGE;
+    bool ok = valid && age < VL_MAX_AGE;
     if (ok) {
-        const float* A = st->vl_pose;
-        const float* B = st->pose;
         const float dx = B[3] - A[3], dy = B[7] - A[7], dz = B[11] - A[11];
         float tr = 0.f;   // trace(Ra^T Rb) = sum of the element-wise products
 #pragma unroll
@@ -224,11 +223,16 @@ __device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lct
         // 10 % slack on both margins for the rounding of this test itself
         ok = (dx * dx + dy * dy + dz * dz <= 0.81f * VL_TRANS * VL_TRANS) && ((tr - 1.0f) * 0.5f >= cosf(0.9f * VL_ROT)) && tr == tr;
     }
-    if (ok) { st->vl_scan = 0; st->vl_age++; return; }
+    if (ok) { st->vl_scan = 0; st->vl_age = age + 1; return; }
     st->vl_scan = 1; st->vl_age = 0; st->vl_valid = 1; st->vl_scans++;
-    for (int k = 0; k < 16; k++) st->vl_pose[k] = st->pose[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) st->vl_pose[k] = B[k];
     st->vl_n[0] = 0; st->vl_n[1] = 0;
+}
+__device__ inline void vlist_decide(DevState* st, unsigned int* __restrict__ lctr)
+{
     (void)lctr;
+    vlist_decide_core(st, st->vl_pose, st->pose, st->vl_valid, st->vl_age);
 }
 
 // ---- camera contexts (BASELINE configuration 5: K streams into ONE map).  What a camera carries from its last frame to its next: the pose block of the
@@ -281,6 +285,13 @@ struct ifx {
     unsigned long long *gfl_index = nullptr, *gfl_splat = nullptr;   // sharded map: the word behind key_index / behind [key_splat | key_ids] that carries the lowest live creation number (this rank's before the exchange, every rank's behind it; ifx_map.hip FIRST_LIVE: the reference's "surfel 0")
     int32_t* own_slot_img = nullptr;    // sharded map, frame path: [4][P] slots of this rank's local winners (index map, splat, ids) and of the associated surfels (k_own_translate, ifx_map.hip)
     int own_fast = 0, own_fast_raster = 0;   // this frame's key images were drawn with slots and translated (index maps / the end-of-frame raster)
+    // option own_lazy_ids (sharded map): the frame draws and exchanges the id keys of the lattice whetherDoSegmentation samples only -- exchange 4 is
+    // [key_splat | lattice keys | word] = 8 P + 8 L + 8 bytes instead of 16 P + 8 -- and whoever needs the whole id image (a segmentation call, a download, a camera
+    // that is parked) gets it from an id render + ONE key exchange of its own (ifx_owner_ids_begin / exchange 200 / _resume; inline when the library holds the communicator)
+    int opt_own_lazy_ids = 0;
+    int own_ids_lat = 0;                // the frame in flight exchanges the lattice form (set by phase 4, read by ifx_owner_exchange(4) and phase 5)
+    int own_ids_pending = 0;            // an id render of the shard is waiting for its key exchange (ifx_owner_exchange(200))
+    unsigned long long* own_lat_tmp = nullptr;   // L + 1 keys: staging of the lattice when the local raster drew the whole image (per-pass cull frames)
     int own_need_decide = 0;            // sharded map, one rank tracks: this rank received the frame's pose (exchange 310) and has not yet run the view-list decision for it
     int pred_root = -1;                 // sharded map: the rank the live camera's prediction was last reduced to (exchange 5 with a tracking rank: the other ranks hold partial sums), -1: all-reduced.
                                         // The same on every rank (it follows the host's call sequence), so every rank refuses alike a frame / run-ahead that would track from a partial block
@@ -558,6 +569,9 @@ int ifx_enqueue_hinted_frame_side(ifx* h);                     // frame side of 
 int ifx_map_init_first(ifx* h);
 int ifx_map_frame(ifx* h);                                    // index -> fuse -> index -> clean -> ids
 int ifx_ids_ensure(ifx* h);                                   // the whole id image, if the last frame rendered only the sampled lattice
+int ifx_owner_ids_begin_impl(ifx* h);                         // sharded map: 1 = the shard's id render is enqueued and waits for its key exchange, 0 = the image is whole already
+int ifx_owner_ids_resume_impl(ifx* h);
+int ifx_own_lattice(const ifx* h);                            // entries of the id lattice (one per 10 x 10 pixels)
 int ifx_vlist_reap(ifx* h);                                   // forced view-list scan: applies the age rule to the slots outside the list (before any whole-map consumer)
 int ifx_map_sharded_phase(ifx* h, int phase, bool first_frame);
 int ifx_map_predict_loop_closure(ifx* h);                     // predict() at the tracked pose + INACTIVE prediction (old* images)

@@ -1012,6 +1012,9 @@ extern "C" int ifx_owner_segmentation_begin(ifx_t* h, const uint8_t* rgb, const 
         r = ifx_superpixel_refine(h, rgb, depth, nm, frame);
         if (r) return r;
     }
+    r = ifx_owner_ids_begin_impl(h);   // option own_lazy_ids: the frame exchanged the sampled lattice only -- the call's first exchange point is the whole id image's keys
+    if (r == 1) { h->oseg_state = 6; h->oseg_pending = 0; return 1; }
+    if (r < 0) { h->oseg_state = 0; h->oseg_pending = 0; return r; }
     h->oseg_state = 1;
     r = oseg_launch_bboxes(h);
     if (r < 0) { h->oseg_state = 0; h->oseg_pending = 0; }
@@ -1034,6 +1037,10 @@ static int oseg_resume(ifx* h)
     const int nm = h->oseg_nm, P = h->P;
     int r;
     switch (h->oseg_state) {
+    case 6:   // the id image's keys merged -> the image, then the boxes
+        if ((r = ifx_owner_ids_resume_impl(h))) return r;
+        h->oseg_state = 1;
+        return oseg_launch_bboxes(h);
     case 1:   // boxes merged -> compare map; model depth of the owned surfels
         if ((r = oseg_read_bboxes(h))) return r;
         LAUNCH(h, "project_depth", dim3(cdiv(P, 256)), dim3(256), k_project_depth, h->d_state, h->ids_after, (const float4*)h->pc, P, 1186, h->d_pdm, ifx_idmap(h));

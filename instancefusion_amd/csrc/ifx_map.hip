@@ -167,6 +167,66 @@ __global__ void k_own_translate(unsigned long long* __restrict__ keys, int P, co
     slot_img[k] = (int32_t)slot;
     keys[k] = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)seq[slot];
 }
+// ---- option own_lazy_ids: the id keys of the sampled lattice travel packed behind key_splat.  ONE workgroup each: the packed run [0, L] overlaps the pixels it is
+// gathered from / scattered to, so every source is read before the first destination is written (registers across a __syncthreads).
+#define OWN_LAT_DS 10
+#define OWN_LAT_PER 16
+int ifx_own_lattice(const ifx* h) { return cdiv(h->w, OWN_LAT_DS) * cdiv(h->h, OWN_LAT_DS); }
+// key_ids[pixel of lattice point j] -> dst[j], the "surfel 0" word -> dst[L]   (dst = key_ids itself, or a staging array)
+__global__ __launch_bounds__(1024) void k_own_ids_pack(const unsigned long long* __restrict__ key_ids, int w, int hh, const unsigned long long* __restrict__ word, unsigned long long* dst)
+{
+    const int lw = (w + OWN_LAT_DS - 1) / OWN_LAT_DS, L = lw * ((hh + OWN_LAT_DS - 1) / OWN_LAT_DS);
+    unsigned long long v[OWN_LAT_PER];
+#pragma unroll
+    for (int u = 0; u < OWN_LAT_PER; u++) {
+        const int j = threadIdx.x + u * 1024;
+        v[u] = IFX_KEY_EMPTY;
+        if (j < L) v[u] = key_ids[(size_t)((j / lw) * OWN_LAT_DS) * w + (j % lw) * OWN_LAT_DS];
+        else if (j == L) v[u] = *word;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < OWN_LAT_PER; u++) {
+        const int j = threadIdx.x + u * 1024;
+        if (j <= L) dst[j] = v[u];
+    }
+}
+// the reverse, behind the exchange: key_ids[0 .. L] -> the lattice pixels (everything else of the run: empty again), the word -> its place behind key_ids
+__global__ __launch_bounds__(1024) void k_own_ids_unpack(unsigned long long* key_ids, int w, int hh, unsigned long long* __restrict__ word)
+{
+    const int lw = (w + OWN_LAT_DS - 1) / OWN_LAT_DS, L = lw * ((hh + OWN_LAT_DS - 1) / OWN_LAT_DS);
+    unsigned long long v[OWN_LAT_PER];
+#pragma unroll
+    for (int u = 0; u < OWN_LAT_PER; u++) {
+        const int j = threadIdx.x + u * 1024;
+        v[u] = IFX_KEY_EMPTY;
+        if (j <= L) { v[u] = key_ids[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < OWN_LAT_PER; u++) {
+        const int j = threadIdx.x + u * 1024;
+        if (j <= L) key_ids[j] = IFX_KEY_EMPTY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < OWN_LAT_PER; u++) {
+        const int j = threadIdx.x + u * 1024;
+        if (j < L) key_ids[(size_t)((j / lw) * OWN_LAT_DS) * w + (j % lw) * OWN_LAT_DS] = v[u];
+        else if (j == L) *word = v[u];
+    }
+}
+// the whole id image of a sharded map from its exchanged keys (ifx_owner_ids_resume): creation numbers, the reference's "surfel 0" as 0 (as the frame's own resolve writes them)
+__global__ void k_own_ids_resolve(unsigned long long* __restrict__ keys, int P, int32_t* __restrict__ ids, const int* __restrict__ first_live)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const unsigned long long key = keys[k];
+    keys[k] = IFX_KEY_EMPTY;
+    int id = (key == IFX_KEY_EMPTY) ? 0 : (int32_t)(key & 0xFFFFFFFFull);
+    if (id == *first_live) id = 0;
+    ids[k] = id;
+}
 static Cam make_cam(ifx* h)
 {
     Cam c;
@@ -2071,9 +2131,34 @@ static void ids_pass(ifx* h, const float* d_pose_inv, int mode, int32_t* out)
 // The frame path renders the id image on the sampled lattice only (ifx_map_predict); whoever needs the whole image -- a segmentation call, ifx_ids_after,
 // a download, the display -- gets it here: the id render of the current map at the current pose, exactly what the frame would have drawn (the map and the pose
 // do not change between the end of a frame and the start of the next).
+int ifx_comm_ready(ifx* h);
+int ifx_comm_exchange(ifx* h, int phase);
+// sharded map: the id render of every shard at the current pose, its keys MIN-reduced over the ranks (ifx_owner_exchange(200)), then the image every rank reads
+int ifx_owner_ids_begin_impl(ifx* h)
+{
+    if (h->ids_full_valid || !h->ids_sparse_frame) return 0;
+    raster_pass(h, nullptr, 0, 0, LIST_IDS, nullptr, false, 1);   // local: all slots of the shard, creation numbers in the keys
+    h->own_ids_pending = 1;
+    return 1;
+}
+int ifx_owner_ids_resume_impl(ifx* h)
+{
+    if (!h->own_ids_pending) { h->err = "ifx_owner_ids_resume: no id render is waiting"; return IFX_E_STATE; }
+    LAUNCH(h, "own_ids_resolve", dim3(cdiv(h->P, 256)), dim3(256), k_own_ids_resolve, h->key_ids, h->P, h->ids_after, (const int*)h->gfl_splat);
+    h->own_ids_pending = 0;
+    h->ids_full_valid = 1;
+    return IFX_OK;
+}
 int ifx_ids_ensure(ifx* h)
 {
     if (h->ids_full_valid || !h->ids_sparse_frame) return IFX_OK;
+    if (h->own) {   // (option own_lazy_ids) every rank comes by here together: with the library's communicator the exchange is enqueued in place
+        if (!ifx_comm_ready(h)) { h->err = "the id image of this sharded map holds the sampled lattice only (option own_lazy_ids): ifx_owner_ids_begin, the exchange of ifx_owner_exchange(200), ifx_owner_ids_resume first"; return IFX_E_STATE; }
+        int r = ifx_owner_ids_begin_impl(h);
+        if (r < 0) return r;
+        if (r == 1) { if ((r = ifx_comm_exchange(h, 200))) return r; if ((r = ifx_owner_ids_resume_impl(h))) return r; }
+        return IFX_OK;
+    }
     if (h->ids_view_ok && !h->own) {   // nothing touched the store, the pose or the cached view list since the frame drew its lattice from it: the rest of the image from the same list
         Cam c = make_cam(h);
         c.srank = 0; c.sn = 1;
@@ -3086,7 +3171,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
     if (first_frame) {
         switch (phase) {
         case 0: ifx_map_init_first(h); owner_filter(h); break;
-        case 4: raster_pass(h, nullptr, time, time, LIST_SPLAT, h->ids_after, false, 1); break;
+        case 4: h->own_ids_lat = 0; raster_pass(h, nullptr, time, time, LIST_SPLAT, h->ids_after, false, 1); break;
         case 5:
             LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                    (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
@@ -3178,31 +3263,50 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         h->last_clean_time = time;
         if (h->view_frame) h->view_dirty = 1;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
+        const bool lat = h->opt_own_lazy_ids != 0;   // (a replicated switch: every rank's exchange 4 has the same form, whichever way its local raster went)
+        bool whole_drawn = false;
+        h->own_ids_lat = lat;
         if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick)) {   // the lists were built / checked by this frame and nothing renumbered the shard since
             Cam cl = make_cam(h);   // (the store's arrays may have been swapped by a compaction earlier in this phase: taken afresh)
             cl.srank = 0; cl.sn = 1;
             if (h->own_fast) { cl.own_n = 0; cl.raw_slots = 1; }
             LAUNCH(h, "raster_view", dim3(h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS), dim3(MAP_THREADS), (k_raster_view<false, false>), h->d_state, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->tm, cl, time, time,
-                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, 1, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);   // (the whole id image: it travels with the splat keys)
+                   LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, lat ? OWN_LAT_DS : 1, CleanArgs{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (const DevState*)h->d_state);   // (the whole id image travels with the splat keys; option own_lazy_ids: the sampled lattice)
             h->own_fast_raster = h->own_fast;
-        } else
+        } else {
             raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
+            whole_drawn = true;
+        }
         h->view_frame = 0;
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
         if (h->own_fast_raster) {   // [key_splat | key_ids] are one allocation, and so are their slot images: one launch translates both
             LAUNCH(h, "own_translate", dim3(cdiv(2 * h->P, 256)), dim3(256), k_own_translate, h->key_splat, 2 * h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P, OWN_GFL(h, h->gfl_splat));   // (the word: behind the clean and the append)
         } else OWN_FIRST_LIVE(h, h->gfl_splat);
+        if (lat) {   // [key_splat | the lattice's id keys | word]: packed in front of key_ids
+            if (!whole_drawn) LAUNCH(h, "own_ids_pack", dim3(1), dim3(1024), k_own_ids_pack, (const unsigned long long*)h->key_ids, h->w, h->h, (const unsigned long long*)h->gfl_splat, h->key_ids);
+            else {   // the per-pass raster drew every pixel: the rest of the image must be empty again before the next frame draws into it
+                const size_t L = (size_t)ifx_own_lattice(h);
+                if (!h->own_lat_tmp && hipMalloc(&h->own_lat_tmp, (L + 1) * 8) != hipSuccess) { h->err = "hipMalloc (own_lat_tmp)"; return IFX_E_HIP; }
+                LAUNCH(h, "own_ids_pack", dim3(1), dim3(1024), k_own_ids_pack, (const unsigned long long*)h->key_ids, h->w, h->h, (const unsigned long long*)h->gfl_splat, h->own_lat_tmp);
+                HIPCHK(h, hipMemsetAsync(h->key_ids, 0xFF, (size_t)h->P * 8, h->cur));
+                HIPCHK(h, hipMemcpyAsync(h->key_ids, h->own_lat_tmp, (L + 1) * 8, hipMemcpyDeviceToDevice, h->cur));
+            }
+        }
         break;
     }
     case 104:                                                                                               // ifx_owner_predict_phase: the local raster alone
+        h->own_ids_lat = 0;
         raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
         OWN_FIRST_LIVE(h, h->gfl_splat);   // (an upload / a deformation may have come in between)
         break;
     case 5: {                                                                                               // owned winners of the prediction; ids_after = creation numbers, from the keys; vote mass of the owned surfels under it | [pred_* | tail]: SUM
+        const int lat = h->own_ids_lat;
+        if (lat) LAUNCH(h, "own_ids_unpack", dim3(1), dim3(1024), k_own_ids_unpack, h->key_ids, h->w, h->h, h->gfl_splat);
+        h->ids_full_valid = !lat; h->ids_sparse_frame = lat; h->ids_view_ok = 0;
         LAUNCH(h, "splat_resolve", g2, b2, k_splat_resolve, h->d_state, (const float*)nullptr, h->key_splat, (const float4*)h->pc, (const float4*)h->nr, (const float2*)h->col,
                (const float2*)h->tm, c, h->rgb, h->depth_filt, (float4*)h->pred_vertex, (float4*)h->pred_normal, (uchar4*)h->pred_image, (uchar4*)h->pred_inst, h->pred_time,
-               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr, FinishFold(), h->pred_conf, 1,
+               (float4*)nullptr, (float4*)nullptr, (uchar4*)nullptr, h->key_ids, h->key_both, h->ids_after, (int*)nullptr, FinishFold(), h->pred_conf, lat ? OWN_LAT_DS : 1,
                (in_frame && h->own_fast_raster) ? (const int32_t*)(h->own_slot_img + (size_t)h->P) : (const int32_t*)nullptr);
         if (in_frame) {   // whetherDoSegmentation sums: empty pixels replicated, vote mass by the owners -> the tail of the prediction block
             const int ds = 10, nseg = cdiv(cdiv(h->w, ds) * cdiv(h->h, ds), 256);

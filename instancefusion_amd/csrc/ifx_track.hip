@@ -178,12 +178,57 @@ __global__ void k_pyrdown_gauss_u8(const uint8_t* __restrict__ src, int sw, int 
 // ---- frame side in 4 launches (was 12): intensity of level 0; one launch per coarser level for BOTH pyr-downs (depth: the
 // bilateral-like pyrDownGaussKernel, intensity: the 5x5 Gaussian); one launch for the vertex/normal maps and the Sobel
 // gradients of all three levels (each needs its level's complete depth / intensity image, nothing of another level).
+// Interior pixels (the 5 x 5 window and the clipped window bound tx = 2x+3 <= sw-1 all inside) take the same sums in the same order with the 25 + 25
+// loads issued ahead of the arithmetic: the clipped loops below issue one load per iteration and wait for it (14-20 us per level for 19 200-76 800
+// pixels, which is L2 latency x 50, not bandwidth).
+__device__ __forceinline__ bool pyr5_interior(int x, int y, int sw, int sh) { return x >= 1 && y >= 1 && 2 * x + 3 <= sw - 1 && 2 * y + 3 <= sh - 1; }
 __global__ void k_frame_down(const uint16_t* __restrict__ dsrc, const uint8_t* __restrict__ isrc, int sw, int sh, uint16_t* __restrict__ ddst, uint8_t* __restrict__ idst)
 {
     const int dw = sw / 2, dh = sh / 2;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= dw || y >= dh) return;
     const int D = 5;
+    if (pyr5_interior(x, y, sw, sh)) {
+        int dv[25], iv[25];
+        const int base = (2 * y - 2) * sw + 2 * x - 2;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) { dv[j * 5 + i] = dsrc[base + j * sw + i]; iv[j * 5 + i] = isrc[base + j * sw + i]; }
+        {   // pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
+            const float sigma_color = 30;
+            constexpr float weights[3] = {0.375f, 0.25f, 0.0625f};
+            const int center = dv[12];
+            float sum = 0, wall = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int val = dv[j * 5 + i];
+                    const float wx = weights[i < 2 ? 2 - i : i - 2], wy = weights[j < 2 ? 2 - j : j - 2];
+                    if ((float)abs(val - center) < 3 * sigma_color) {
+                        sum += val * wx * wy;
+                        wall += wx * wy;
+                    }
+                }
+            ddst[y * dw + x] = (uint16_t)(int)(sum / wall);
+        }
+        {   // pyrDownKernelIntensityGauss, EF/Cuda/cudafuncs.cu:470-500 (ty - cy - 1 = 4 - j, tx - cx - 1 = 4 - i)
+            float sum = 0;
+            int count = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int sv = iv[j * 5 + i];
+                    constexpr float gtab[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+                    const float g = gtab[(4 - j) * 5 + (4 - i)];
+                    if (sv > 0) { sum += sv * g; count += (int)g; }
+                }
+            idst[y * dw + x] = count ? (uint8_t)f2i_rz(sum / (float)count) : (uint8_t)0;
+        }
+        return;
+    }
     {   // pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
         const float sigma_color = 30;
         const float weights[3] = {0.375f, 0.25f, 0.0625f};
@@ -340,31 +385,53 @@ __global__ void k_model_down(const DevState* __restrict__ st, const float* __res
     for (int m = 0; m < 2; m++) {   // resizeMapKernel<normalize>, EF/Cuda/cudafuncs.cu:365-416
         const float* in = m ? nin : vin;
         float* out = m ? o.ncam : o.vcam;
-        float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
+        const float *py = in + sh * sw, *pz = in + 2 * sh * sw;   // (all twelve loads ahead of the test: they are in bounds whatever it decides)
+        const float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
+        const float y00 = py[ys * sw + xs], y01 = py[ys * sw + xs + 1], y10 = py[(ys + 1) * sw + xs], y11 = py[(ys + 1) * sw + xs + 1];
+        const float z00 = pz[ys * sw + xs], z01 = pz[ys * sw + xs + 1], z10 = pz[(ys + 1) * sw + xs], z11 = pz[(ys + 1) * sw + xs + 1];
         v3 n = v3m(qn, qn, qn);
         if (!((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11))) {
             n.x = (x00 + x01 + x10 + x11) / 4;
-            const float* py = in + sh * sw;
-            n.y = (py[ys * sw + xs] + py[ys * sw + xs + 1] + py[(ys + 1) * sw + xs] + py[(ys + 1) * sw + xs + 1]) / 4;
-            const float* pz = in + 2 * sh * sw;
-            n.z = (pz[ys * sw + xs] + pz[ys * sw + xs + 1] + pz[(ys + 1) * sw + xs] + pz[(ys + 1) * sw + xs + 1]) / 4;
+            n.y = (y00 + y01 + y10 + y11) / 4;
+            n.z = (z00 + z01 + z10 + z11) / 4;
             if (m) n = normalized(n);
         }
         out[y * dw + x] = n.x; out[(y + dh) * dw + x] = n.y; out[(y + 2 * dh) * dw + x] = n.z;
         res[m] = n;
     }
     const int D = 5;
-    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
     float sumf = 0, sumi = 0;
     int cntf = 0, cnti = 0;
-    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-            const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-            const float sf = din[cy * sw + cx];       // pyrDownKernelGaussF :332-363
-            if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
-            const int si = iin[cy * sw + cx];         // pyrDownKernelIntensityGauss :470-500
-            if (si > 0) { sumi += si * g; cnti += (int)g; }
-        }
+    if (pyr5_interior(x, y, sw, sh)) {   // same sums, same order, the 50 loads issued ahead of the arithmetic (see k_frame_down)
+        float dv[25];
+        int iv[25];
+        const int base = (2 * y - 2) * sw + 2 * x - 2;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) { dv[j * 5 + i] = din[base + j * sw + i]; iv[j * 5 + i] = iin[base + j * sw + i]; }
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                constexpr float gtab[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+                const float g = gtab[(4 - j) * 5 + (4 - i)];
+                const float sf = dv[j * 5 + i];
+                if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
+                const int si = iv[j * 5 + i];
+                if (si > 0) { sumi += si * g; cnti += (int)g; }
+            }
+    } else {
+        const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+        for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+            for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+                const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                const float sf = din[cy * sw + cx];       // pyrDownKernelGaussF :332-363
+                if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
+                const int si = iin[cy * sw + cx];         // pyrDownKernelIntensityGauss :470-500
+                if (si > 0) { sumi += si * g; cnti += (int)g; }
+            }
+    }
     const float z = (float)(sumf / (float)cntf);
     o.depth[y * dw + x] = z;
     o.img[y * dw + x] = cnti ? (uint8_t)f2i_rz(sumi / (float)cnti) : (uint8_t)0;
@@ -1589,13 +1656,30 @@ __global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, 
 // start of a tracker run (EF/Utils/RGBDOdometry.cpp:384-434): previous pose, its inverse, the SO(3) result as the first estimate, the first warp matrices
 __device__ void gn_begin_dev(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last)
 {
-    if (!keep_last) for (int k = 0; k < 16; k++) st->last_pose[k] = st->pose[k];   // bootstrap: lastPose is the pose before the guess was applied (k_bootstrap_pose)
+    // Everything this lane reads is loaded ahead of its first store and the values then stay in registers: `st` aliases itself, so reading the state back between the
+    // stores made this a chain of ~40 L2 round trips -- the long pole of the launch it rides on (k_model_down of the coarsest level).
+    float P[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) P[k] = st->pose[k];
+    float so3_err = 0.f, so3_cnt = 0.f;
+    double sR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (so3) {
+        so3_err = ss->lastSO3Error; so3_cnt = ss->lastSO3Count;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sR[k] = ss->resultR[k];
+    }
+    if (!keep_last) {   // bootstrap: lastPose is the pose before the guess was applied (k_bootstrap_pose)
+#pragma unroll
+        for (int k = 0; k < 16; k++) st->last_pose[k] = P[k];
+    }
+    float m[9];
+#pragma unroll
     for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) st->Rprev[r * 3 + c] = st->Rcurr[r * 3 + c] = st->pose[r * 4 + c];
-        st->tprev[r] = st->tcurr[r] = st->pose[r * 4 + 3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { m[r * 3 + c] = P[r * 4 + c]; st->Rprev[r * 3 + c] = st->Rcurr[r * 3 + c] = m[r * 3 + c]; }
+        st->tprev[r] = st->tcurr[r] = P[r * 4 + 3];
     }
     {   // general 3x3 inverse, as Eigen's Matrix3f::inverse (:388)
-        const float* m = st->Rprev;
         float* o = st->Rprev_inv;
         float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
         float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
@@ -1605,12 +1689,24 @@ __device__ void gn_begin_dev(DevState* st, const DevState* __restrict__ ss, int 
         o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
     }
     st->lastICPError = 0; st->lastICPCount = 0; st->lastRGBError = 0; st->lastRGBCount = 0;
-    st->lastSO3Error = so3 ? ss->lastSO3Error : 0.f; st->lastSO3Count = so3 ? ss->lastSO3Count : 0.f;
-    for (int k = 0; k < 16; k++) st->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (so3)
+    st->lastSO3Error = so3_err; st->lastSO3Count = so3_cnt;
+    double M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (so3) {
+#pragma unroll
         for (int x = 0; x < 3; x++)
-            for (int y = 0; y < 3; y++) st->resultRt[x * 4 + y] = ss->resultR[x * 3 + y];
-    set_warp_matrices(st, fx, fy, cx, cy);
+#pragma unroll
+            for (int y = 0; y < 3; y++) M[x * 4 + y] = sR[x * 3 + y];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) st->resultRt[k] = M[k];
+    float krk[9], kt[3];
+    warp_from(M, fx, fy, cx, cy, krk, kt);   // (set_warp_matrices on the registers)
+#pragma unroll
+    for (int k = 0; k < 9; k++) st->krkinv[k] = krk[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) st->kt[k] = kt[k];
 }
 
 // start of the SO(3) pre-alignment (frame side; `st` is the slot's shadow state): identity increments (:313-330)
@@ -1719,33 +1815,68 @@ __device__ void rodrigues2(const float* R, float* out3)
     out3[0] = (float)rx; out3[1] = (float)ry; out3[2] = (float)rz;
 }
 
-// end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449)
-__device__ void track_end_dev(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
+// end of the tracker run (:587-603) + pose write-back + velocity weighting (EF/ElasticFusion.cpp:425-449).
+// The run's result (Rc, tc) and the pose it started from (Rp, tp) come in registers -- the lane that solved the last iteration holds them -- and everything else this reads
+// (the last frame's pose, the inputs of the view-list decision) is loaded ahead of the first store: `st` aliases itself, so copying state to state element by element was
+// a chain of ~30 L2 round trips in the last launch of every frame.
+__device__ __forceinline__ void track_end_vals(DevState* st, int rgb, int tracked, const float* Rc_in, const float* tc_in, const float* Rp, const float* tp, float weight_mult,
+                                               int commit, unsigned int* lctr)
 {
-    float* pose = commit ? st->pose : st->spec_pose;
-    float* pose_inv = commit ? st->pose_inv : st->spec_pose_inv;
-    if (!commit && !tracked) for (int k = 0; k < 16; k++) pose[k] = st->pose[k];
+    float LP[16], P0[16], A[16];
+    int valid = 0, age = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) LP[k] = st->last_pose[k];
+    if (!tracked) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) P0[k] = st->pose[k];
+    }
+    const bool decide = commit && lctr;
+    if (decide) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) A[k] = st->vl_pose[k];
+        valid = st->vl_valid; age = st->vl_age;
+    }
+    float pose[16], pinv[16];
     if (tracked) {
+        float Rc[9], tc[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rc[k] = Rc_in[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tc[k] = tc_in[k];
         if (rgb) {
-            v3 d = v3m(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
+            v3 d = v3m(tc[0] - tp[0], tc[1] - tp[1], tc[2] - tp[2]);
             if (norm(d) > 0.3f) {
-                for (int k = 0; k < 9; k++) st->Rcurr[k] = st->Rprev[k];
-                for (int k = 0; k < 3; k++) st->tcurr[k] = st->tprev[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { Rc[k] = Rp[k]; st->Rcurr[k] = Rp[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { tc[k] = tp[k]; st->tcurr[k] = tp[k]; }
             }
         }
+#pragma unroll
         for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) pose[r * 4 + c] = st->Rcurr[r * 3 + c];
-            pose[r * 4 + 3] = st->tcurr[r];
+#pragma unroll
+            for (int c = 0; c < 3; c++) pose[r * 4 + c] = Rc[r * 3 + c];
+            pose[r * 4 + 3] = tc[r];
         }
         pose[12] = pose[13] = pose[14] = 0.f; pose[15] = 1.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) pose[k] = P0[k];
     }
-    pose_inverse(pose, pose_inv);
+    pose_inverse(pose, pinv);
+    float* o_pose = commit ? st->pose : st->spec_pose;
+    float* o_inv = commit ? st->pose_inv : st->spec_pose_inv;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { o_pose[k] = pose[k]; o_inv[k] = pinv[k]; }
     float diff[16];
+#pragma unroll
     for (int r = 0; r < 4; r++)
+#pragma unroll
         for (int c = 0; c < 4; c++) {
-            float s = 0;
-            for (int k = 0; k < 4; k++) s += pose_inv[r * 4 + k] * st->last_pose[k * 4 + c];
-            diff[r * 4 + c] = s;
+            float sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sacc += pinv[r * 4 + k] * LP[k * 4 + c];
+            diff[r * 4 + c] = sacc;
         }
     float R3[9] = {diff[0], diff[1], diff[2], diff[4], diff[5], diff[6], diff[8], diff[9], diff[10]};
     float rv[3];
@@ -1757,7 +1888,17 @@ __device__ void track_end_dev(DevState* st, int rgb, int tracked, float weight_m
     if (weighting > largest) weighting = largest;
     const float wgt = fmaxf(1.0f - (weighting / largest), minWeight) * weight_mult;
     if (commit) st->weighting = wgt; else st->spec_weighting = wgt;
-    if (commit && lctr) vlist_decide(st, lctr);   // the frame's pose is final: does the cached view list still cover it?
+    if (decide) vlist_decide_core(st, A, pose, valid, age);   // the frame's pose is final: does the cached view list still cover it?
+}
+// (the stand-alone launch, and the ends of runs that were not tracked: the run's result is read from the state)
+__device__ void track_end_dev(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
+{
+    float Rc[9], tc[3], Rp[9], tp[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rc[k] = st->Rcurr[k]; Rp[k] = st->Rprev[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { tc[k] = st->tcurr[k]; tp[k] = st->tprev[k]; }
+    track_end_vals(st, rgb, tracked, Rc, tc, Rp, tp, weight_mult, commit, lctr);
 }
 __global__ void k_track_end(DevState* st, int rgb, int tracked, float weight_mult, int commit, unsigned int* lctr)
 {
@@ -1973,7 +2114,7 @@ __device__ __forceinline__ void gn_solve_block(DevState* st, double* __restrict_
 #pragma unroll
     for (int k = 0; k < 3; k++) { st->tcurr[k] = tc[k]; st->kt[k] = kt[k]; }
     // the run's last iteration also ends the run (:587-603, pose write-back, velocity weighting, view-list decision): the same lane, one launch less per frame
-    if (end_run) track_end_dev(st, rgb, 1, weight_mult, commit, lctr);
+    if (end_run) track_end_vals(st, rgb, 1, Rc, tc, Rp, tp, weight_mult, commit, lctr);
 #ifdef IFX_STAMPS
     { long long ts_d = clock64(); st->dbg[4] += ts_d - ts_c; st->dbg[6] += ts_b - ts_a; st->dbg[7] += ts_c - ts_b; st->dbg[3] += ts_a; }
 #endif
@@ -2189,7 +2330,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level_solo(DevState* st, Lev
                 for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krkn[k]; }
 #pragma unroll
                 for (int k = 0; k < 3; k++) { st->tcurr[k] = tcn[k]; st->kt[k] = ktn[k]; }
-                if (a.final_level) track_end_dev(st, 1, 1, a.weight_mult, a.commit, a.lctr);
+                if (a.final_level) track_end_vals(st, 1, 1, Rc, tcn, Rp, tpv, a.weight_mult, a.commit, a.lctr);
                 st->gn_done_seq = a.level + 1;
             }
         }
@@ -2470,7 +2611,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
                 for (int k = 0; k < 9; k++) { st->Rcurr[k] = Rc[k]; st->krkinv[k] = krkn[k]; }
 #pragma unroll
                 for (int k = 0; k < 3; k++) { st->tcurr[k] = tcn[k]; st->kt[k] = ktn[k]; }
-                if (a.final_level) track_end_dev(st, RGB, 1, a.weight_mult, a.commit, a.lctr);
+                if (a.final_level) track_end_vals(st, RGB, 1, Rc, tcn, Rp, tpv, a.weight_mult, a.commit, a.lctr);
                 st->gn_done_seq = a.level + 1;
             }
         }
@@ -2486,10 +2627,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
 // publishes the result of a tracker run that was enqueued before its frame (k_track_end with commit = 0)
 __global__ void k_commit_pose(DevState* st, unsigned int* lctr)
 {
-    if (threadIdx.x != 0) return;
-    for (int k = 0; k < 16; k++) { st->pose[k] = st->spec_pose[k]; st->pose_inv[k] = st->spec_pose_inv[k]; }
-    st->weighting = st->spec_weighting;
-    vlist_decide(st, lctr);
+    // Every load of the launch is issued ahead of its first store: `st` aliases itself, so the one-lane copy loop was ~35 chained L2 round trips (7.4 us on the
+    // main stream of every frame of the tracked-ahead path).  Lanes 0..32 carry the copy, lane 0 the inputs of the view-list decision.
+    (void)lctr;
+    const int t = threadIdx.x;
+    float cp = 0.f;
+    if (t < 16) cp = st->spec_pose[t]; else if (t < 32) cp = st->spec_pose_inv[t - 16]; else if (t == 32) cp = st->spec_weighting;
+    float A[16], B[16];
+    int valid = 0, age = 0;
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { A[k] = st->vl_pose[k]; B[k] = st->spec_pose[k]; }
+        valid = st->vl_valid; age = st->vl_age;
+    }
+    if (t < 16) st->pose[t] = cp; else if (t < 32) st->pose_inv[t - 16] = cp; else if (t == 32) st->weighting = cp;
+    if (t != 0) return;
+    vlist_decide_core(st, A, B, valid, age);
 }
 
 

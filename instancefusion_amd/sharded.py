@@ -233,6 +233,15 @@ class OwnerShardedElasticFusion:
         torch.cuda.synchronize()
         self.ef._chk(self.ef.L.ifx_owner_knn_vote(self.ef.handle, C.c_void_p(allp.data_ptr()), C.c_void_p(alll.data_ptr()), int(allp.shape[0]), int(off)), "ifx_owner_knn_vote")
 
+    def ensure_ids(self):
+        """Option own_lazy_ids: the whole id image (a frame exchanges the sampled lattice only).  With the library's communicator whoever reads the image completes it in
+        place; a caller-driven transport does it here -- every rank together, before ef.image("ids_after") / camera_select."""
+        if self.transport == "library":
+            return
+        if self.ef._chk(self.ef.L.ifx_owner_ids_begin(self.ef.handle), "ifx_owner_ids_begin") == 1:
+            self._exchange(200)
+            self.ef._chk(self.ef.L.ifx_owner_ids_resume(self.ef.handle), "ifx_owner_ids_resume")
+
     def process_segmentation(self, rgb, depth, masks, class_ids, frame: int, superpixels: bool = True, knn: bool = False):
         """InstanceFusion::processInstance on the sharded map (same masks on every rank): the owners' partial boxes, model depth and -- when the
         instance table overflows -- eviction statistics are merged at the call's exchange points; labels of the owned surfels: ef.labels()."""
@@ -334,6 +343,16 @@ def emulate_owner_segmentation(efs, rgb, depth, masks, class_ids, frame: int, su
         _reduce_by_hand(efs, [_exchange_spec(e, 200) for e in efs])
         rs = [e._chk(e.L.ifx_owner_segmentation_resume(e.handle), "ifx_owner_segmentation_resume") for e in efs]
     assert all(r == 0 for r in rs)
+
+
+def emulate_owner_ids(efs):
+    """Option own_lazy_ids on the handles of emulate_owner_ranks: the whole id image (every shard's id render, the keys MIN-reduced by hand)."""
+    rs = [e._chk(e.L.ifx_owner_ids_begin(e.handle), "ifx_owner_ids_begin") for e in efs]
+    assert all(r == rs[0] for r in rs), "the ranks disagree about the state of the id image"
+    if rs[0] == 1:
+        _reduce_by_hand(efs, [_exchange_spec(e, 200) for e in efs])
+        for e in efs:
+            e._chk(e.L.ifx_owner_ids_resume(e.handle), "ifx_owner_ids_resume")
 
 
 def emulate_owner_knn(efs):

@@ -841,9 +841,9 @@ def test_lost_tracker_experiments_are_bit_identical(ifx):
     _tracker_variants_equal(ifx, [dict(), dict(model_fused=1), dict(icp_px=3)])
 
 
-@pytest.mark.parametrize("world,zero_dies", [(2, 0), (3, 0), (2, 1), (3, 1), (2, -1), (2, 30)] +
-                         [(2 + i % 3, 1000 + 29 * i) for i in range(int(os.environ.get("IFX_SWEEP_SHARDED", "0")))])   # (IFX_SWEEP_SHARDED=N: other scenes / motions, 30 frames each; a one-off wider run)
-def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
+@pytest.mark.parametrize("world,zero_dies,lazy_ids", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (3, 1, 0), (2, -1, 0), (2, 30, 0), (3, 1, 1), (2, 30, 1)] +
+                         [(2 + i % 3, 1000 + 29 * i, i % 2) for i in range(int(os.environ.get("IFX_SWEEP_SHARDED", "0")))])   # (IFX_SWEEP_SHARDED=N: other scenes / motions, 30 frames each; a one-off wider run)
+def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies, lazy_ids):
     """The spatially sharded map (ifx_config.n_ranks = G: every rank stores the surfels it owns, 1 / G of the map; key images
     MIN-reduced, winners' attributes SUM-merged between the eight phases of a frame) against one GPU: G handles in one process, the
     all-reduces done by hand.  Poses, prediction / index / id images and -- merged by creation number -- the whole map, bit for bit,
@@ -852,7 +852,9 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
     surfel takes its place (from then on IT is never associated: the measurement at its pixel makes a new surfel instead) -- on one GPU the lowest live slot
     (DevState::first_live), on the sharded map the lowest live creation number of ANY rank (MIN-reduced with the keys of exchanges 0 and 4).
     zero_dies = -1: the same with the rule switched off on the ranks (option own_first_live = 0, round 4's behaviour) -- the maps must then DIFFER: the scenario tests the rule.
-    zero_dies = 30: no such scenario, but 30 frames instead of 8."""
+    zero_dies = 30: no such scenario, but 30 frames instead of 8.
+    lazy_ids = 1: option own_lazy_ids on the ranks -- exchange 4 carries the id keys of the sampled lattice only (asserted on the exchange table); the whole id image, completed
+    on demand by an id render + one key exchange (ifx_owner_ids_begin / _resume), must equal the one a second set of ranks WITHOUT the option holds after the same frames."""
     import torch
 
     from instancefusion_amd import dist as ifd
@@ -874,10 +876,14 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
     d_dep = torch.from_numpy(st["depth"][src].view(np.int16)).cuda()
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
-    for e in efs:
+    efs_whole = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)] if lazy_ids else []
+    for e in efs + efs_whole:
         e.set_option("compact_divisor", 16 if e.cfgd["rank"] else 64)     # the ranks compact at different times: ids are creation numbers, nothing to agree on
         if zero_dies < 0:
             e.set_option("own_first_live", 0)
+    for e in efs:
+        e.set_option("own_lazy_ids", lazy_ids)
+    P_, L_ = SMALL["w"] * SMALL["h"], -(-SMALL["w"] // 10) * -(-SMALL["h"] // 10)
     poses = []
     for i in range(NF):
         if i == 4:   # an uploaded map in the middle: every rank is handed all rows and keeps its own
@@ -895,15 +901,30 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
                     m[k_][[1, kz]] = m[k_][[kz, 1]]
                 m["tm"][0, 1] = -1.0
             one.upload(m); one.set_pose(poses[-1], one.tick); one.combined_predict(poses[-1], one.tick, one.tick)
-            for e in efs:
+            for e in efs + efs_whole:
                 e.upload(m)
                 e.set_pose(poses[-1], one.tick)
             own = ifd.owner_of(m["pc"][:, :3], world)
             assert [e.count for e in efs] == [int((own == r).sum()) for r in range(world)]
             sharded.emulate_owner_predict(efs)          # ElasticFusion::predict on the sharded map: local raster, exchange, owned winners, exchange, fill-in
+            if lazy_ids:
+                sharded.emulate_owner_predict(efs_whole)
         one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
         sharded.emulate_owner_ranks(efs, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
         poses.append(one.getCurrPose())
+        if lazy_ids:
+            sharded.emulate_owner_ranks(efs_whole, d_rgb[i].data_ptr(), d_dep[i].data_ptr())
+            if i > 0:   # (the map's first frame draws no id image and exchanges the whole form)
+                assert [(b, op) for _, b, op in sharded._exchange_spec(efs[0], 4)] == [((P_ + L_) * 8 + 8, 0)], i
+                assert [(b, op) for _, b, op in sharded._exchange_spec(efs_whole[0], 4)] == [(P_ * 16 + 8, 0)], i
+            if i > 0 and i % 3 != 1:   # (frames 1, 4, 7, ...: the sparse image is simply overwritten by the next frame)
+                with pytest.raises(RuntimeError):
+                    efs[0].image("ids_after")          # caller-driven exchanges and no ifx_owner_ids_begin: refused, not silently sparse
+                sharded.emulate_owner_ids(efs)
+                whole = efs_whole[0].image("ids_after")
+                assert i < 5 or (whole > 0).sum() > 1000, (i, int((whole > 0).sum()))   # (populated from the uploaded map on: half of its surfels are stable)
+                for e in efs + efs_whole[1:]:
+                    assert np.array_equal(e.image("ids_after"), whole), (i, e.cfgd["rank"])
         if zero_dies < 0:
             continue
         for e in efs:
@@ -935,13 +956,13 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies):
         assert np.array_equal(merged, ref[k], equal_nan=True), k
     assert min(len(p[0]) for p in parts) > 0.5 * len(seq) / world          # every rank holds about 1 / G of the map
     # ownership is what the hash says, for created and uploaded surfels alike (by their current position for the ones that never moved)
-    for e in efs:
+    for e in efs + efs_whole:
         e.close()
     one.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_owner_sharded_instance_emulated(ifx, small_stream, world):
+@pytest.mark.parametrize("world,lazy_ids", [(2, 0), (3, 0), (2, 1), (3, 1)])
+def test_owner_sharded_instance_emulated(ifx, small_stream, world, lazy_ids):
     """The instance layer on the spatially sharded map: whetherDoSegmentation sums (vote mass of the owned surfels summed
     across the ranks), segmentation calls with superpixels (partial boxes MIN / MAX-merged, model depth SUM-merged, votes and label scan on the
     owned surfels) and the eviction of a full instance table (per-instance max / sum of the vote counters merged) against one GPU: decisions,
@@ -957,6 +978,8 @@ def test_owner_sharded_instance_emulated(ifx, small_stream, world):
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     efs = [ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=world, rank=r) for r in range(world)]
     inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
+    for e in efs:
+        e.set_option("own_lazy_ids", lazy_ids)   # (1: the frames exchange the sampled lattice's id keys; every segmentation call completes the image at an exchange point of its own)
 
     def merged(name_of):
         parts = [(e.seq(), name_of(e, x)) for e, x in zip(efs, insts)]
@@ -1018,7 +1041,8 @@ def test_owner_sharded_instance_emulated(ifx, small_stream, world):
 
 
 @pytest.mark.timeout(1500)
-def test_config4_1280x960_20m_map_sharded_x4(ifx):
+@pytest.mark.parametrize("lazy_ids", [0, 1])
+def test_config4_1280x960_20m_map_sharded_x4(ifx, lazy_ids):
     """BASELINE configuration 4 at its size: a 1280x960 stream into a 20M-surfel map spatially sharded over FOUR ranks (5M surfels each; the four
     handles live in one process on this GPU, the exchanges of a frame reduced by hand exactly as the collectives would) against ONE handle holding all
     20M surfels.  Over five frames with a segmentation call (superpixels) in between: poses, prediction / fill-in / id images bit for bit every frame,
@@ -1037,6 +1061,8 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx):
     one = ifx.ElasticFusion(w=W, h=H, max_surfels=N + 3_000_000, **K)
     efs = [ifx.ElasticFusion(w=W, h=H, max_surfels=N // G + 2_500_000, n_ranks=G, rank=r, **K) for r in range(G)]
     inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
+    for e in efs:
+        e.set_option("own_lazy_ids", lazy_ids)   # (1: exchange 4 carries [splat keys | the id keys of the 128 x 96 lattice | word]: 9.9 MB instead of 19.7 MB a frame)
     # frame 0 initialises the tracker's previous image; then the 20M map replaces the first-frame map on both sides
     one.enqueue_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr(), 0)
     sharded.emulate_owner_ranks(efs, d_rgb[0].data_ptr(), d_dep[0].data_ptr())
@@ -1064,6 +1090,7 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx):
                 assert np.array_equal(e.image(name), a), (i, name, e.cfgd["rank"])
         want = inst_one.whetherDoSegmentation(100 + i)
         assert [x.whetherDoSegmentation(100 + i) for x in insts] == [want] * G, i
+        assert [b for _, b, _ in sharded._exchange_spec(efs[0], 4)] == [(W * H + 128 * 96) * 8 + 8 if lazy_ids else W * H * 16 + 8]
         if i == seg_at:
             masks, cls = synth.canned_masks(st["obj"][i], st["scene"])
             assert masks.shape[0] > 0
@@ -1096,8 +1123,8 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx):
         e.close()
 
 
-@pytest.mark.parametrize("ahead", [False, True])
-def test_config5_two_streams_one_sharded_map(ifx, ahead):
+@pytest.mark.parametrize("ahead,lazy_ids", [(False, 0), (True, 0), (True, 1)])
+def test_config5_two_streams_one_sharded_map(ifx, ahead, lazy_ids):
     """(ahead = True: rank k runs the tracker of camera k's NEXT frame on its third stream as soon as the camera's context is parked, under the other camera's map phases --
     ifx_owner_track_ahead -- and the frame commits the parked pose block instead of tracking: same poses, same map, and every tracked frame but the first is served that way.)
     BASELINE configuration 5 in small: K = 2 cameras (two stretches of the benchmark trajectory through the same scene) feed ONE map that is spatially
@@ -1121,6 +1148,8 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
     efs = [ifx.ElasticFusion(**SMALL, max_surfels=600000, n_ranks=G, rank=r) for r in range(G)]
     for e in [one] + efs:
         e.camera_count(K)
+    for e in efs:
+        e.set_option("own_lazy_ids", lazy_ids)   # (a parked id image is a whole one: with the option every camera switch completes the image first -- one id exchange per switch)
     pose_b0 = st["poses"][first[1]].astype(np.float32)         # camera 1's pose in the map frame (= camera 0's first frame): given, not tracked
     for s_ in range(NS):
         for c in range(K):
@@ -1128,6 +1157,8 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
             ext = pose_b0 if (c == 1 and s_ == 0) else None
             one.camera_select(c)
             p1 = one.processFrame(st["rgb"][i], st["depth"][i], inPose=ext)
+            if lazy_ids:
+                sharded.emulate_owner_ids(efs)
             for e in efs:
                 e.camera_select(c)
                 e.owner_set_tracking_rank(c)                    # stream c is tracked on rank c only
@@ -1144,6 +1175,8 @@ def test_config5_two_streams_one_sharded_map(ifx, ahead):
                 assert np.array_equal(e.getCurrPose(), p1), (s_, c, e.cfgd["rank"])
             for name in ("pred_vertex", "pred_normal", "pred_image", "fill_vertex"):   # camera c's prediction is reduced to the rank that tracks it (exchange op 5): checked there
                 assert np.array_equal(efs[c].image(name), one.image(name)), (s_, c, name)
+            if lazy_ids:
+                sharded.emulate_owner_ids(efs)
             assert np.array_equal(efs[1 - c].image("ids_after"), efs[c].image("ids_after"))   # (the id image comes from the exchanged keys: everywhere)
     # both cameras tracked: their trajectories follow the ground truth of their stretch
     assert np.abs(p1 - st["poses"][first[1] + NS - 1]).max() < 0.03
@@ -2192,7 +2225,8 @@ def test_sharded_rccl_world_of_one(ifx, small_stream):
         dist.destroy_process_group()
 
 
-def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
+@pytest.mark.parametrize("lazy_ids", [0, 1])
+def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids):
     """The spatially sharded map with the collectives INSIDE libifx.so (csrc/ifx_comm.hip), on real RCCL: a world of one (ifx_config.n_ranks = -1:
     creation-number ids, owner filter, every exchange point of a frame / predict / segmentation call / kNN smoothing issued as a one-rank
     ncclAllReduce / ncclAllGather on the handle's stream by the library itself).  One library call per frame; against the unsharded handle:
@@ -2210,6 +2244,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     ef = ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=-1, rank=0)
     osh = sharded.OwnerShardedElasticFusion(ef, None)            # ifx_comm_unique_id + ifx_owner_init_comm: ncclCommInitRank(1, id, 0)
+    ef.set_option("own_lazy_ids", lazy_ids)                      # (1: 72 B per pixel + the lattice; the whole id image on demand, the exchange enqueued by the library in place)
     inst_one, inst = ifx.InstanceFusion(one), ifx.InstanceFusion(ef)
     P = SMALL["w"] * SMALL["h"]
 
@@ -2236,7 +2271,8 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream):
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()
-                assert xs["collectives"] == 6 and xs["bytes"] == 80 * P + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
+                L = -(-SMALL["w"] // 10) * -(-SMALL["h"] // 10)
+                assert xs["collectives"] == 6 and xs["bytes"] == (72 * P + 8 * L if lazy_ids else 80 * P) + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--seg-host-frame", action="store_true", help="segmentation calls take the frame's RGB / depth from host memory (the reference's signature) instead of the resident frame")
     ap.add_argument("--pace", action="store_true", help="with --no-instance: wait for every frame's result before the next is enqueued (diagnostic)")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
+    ap.add_argument("--sharded-key-rs", type=int, default=0, help="the sharded-map leg runs the index-key exchanges as reduce-scatter + all-gather of the creation numbers (option own_key_rs: 12 instead of 16 bytes per key and link, two more collectives a frame; priced in DESIGN.md section 7: pays from about 1280x960 on)")
+    ap.add_argument("--sharded-lazy-ids", type=int, default=1, help="the sharded-map leg exchanges the id keys of the sampled lattice only (option own_lazy_ids; 0: the whole id image every frame, 80 B per pixel)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
     ap.add_argument("--close-loops", action="store_true", help="also run the local loop-closure detection every frame (the reference's closeLoops = true: predict() at the "
                     "tracked pose, INACTIVE prediction, model-to-model tracking, gates; thresholds of IF/map_interface/ElasticFusionInterface.cpp:43-45)")
@@ -189,6 +191,8 @@ def main():
         from instancefusion_amd import sharded as ifsh
 
         osh = ifsh.OwnerShardedElasticFusion(ef, dist)   # hands libifx.so a RCCL communicator; from here on a frame is one library call
+        ef.set_option("own_lazy_ids", int(bool(args.sharded_lazy_ids)))   # exchange 4 carries the id keys of the sampled lattice; the whole image with a segmentation call
+        ef.set_option("own_key_rs", int(bool(args.sharded_key_rs)))
         osh.process_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
         ef.upload(m)                                   # every rank is handed all rows and keeps the ones it owns
         ef.set_pose(st["poses"][0], tick0)
@@ -642,7 +646,7 @@ def main():
             # and equal the oracle's; 0 = every pose above is the pose of the fixed arithmetic
             "exact_sum_range_exceeded": range_exceeded,
             **({"exchange": {"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xstats["collectives"] / args.steps, 2),
-                             "bytes_per_frame": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": x_ranks}} if xstats else {}),
+                             "bytes_per_frame_per_rank": round(xstats["bytes"] / args.steps), "bytes_per_pixel_per_frame": round(xstats["bytes"] / args.steps / P, 1), "rccl_ranks": x_ranks}} if xstats else {}),
             **({"loop_closure": {k_: (v_ if not isinstance(v_, np.ndarray) else None) for k_, v_ in lc_diag.items() if k_ != "est_pose"}} if args.close_loops else {}),
             "roofline": roof, "cpu_baseline": cpu_,
         }
@@ -722,7 +726,7 @@ def main():
             nfr = K5 * args.config5_sets
             leg = dict(value=round(nfr / t5, 2), frames=nfr, trackers_served_ahead=ef5.owner_track_ahead(-1, 0) - served0)
             if world > 1:   # (the split and the exchange volume of the schedule that is reported as `value`)
-                leg["exchange"] = dict(collectives_per_frame=round(xs5["collectives"] / nfr, 2), bytes_per_frame=round(xs5["bytes"] / nfr), bytes_per_pixel_per_frame=round(xs5["bytes"] / nfr / P, 1))
+                leg["exchange"] = dict(collectives_per_frame=round(xs5["collectives"] / nfr, 2), bytes_per_frame_per_rank=round(xs5["bytes"] / nfr), bytes_per_pixel_per_frame=round(xs5["bytes"] / nfr / P, 1))
                 ef5.stage_ms(reset=True)
                 ef5.set_option("stage_timing", 1)
                 set5(2 + args.config5_sets)
@@ -789,6 +793,8 @@ def main():
                 k_, v_ = kv.split("=")
                 ef2.set_option(k_, int(v_))
             osh2 = ifsh.OwnerShardedElasticFusion(ef2, dist)
+            ef2.set_option("own_lazy_ids", int(bool(args.sharded_lazy_ids)))
+            ef2.set_option("own_key_rs", int(bool(args.sharded_key_rs)))
             osh2.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
             ef2.upload(m2)
             ef2.set_pose(st2["poses"][0], tick0)
@@ -842,7 +848,10 @@ def main():
             sharded_leg = dict(value=round(ns / dt2, 2), unit="frames/s", frames=ns, scaling="strong", n_ranks=world, rccl_ranks=osh2.comm_ranks(), segmentation_calls=calls2,
                                ms_per_frame_gpu={k_: round(v_ / n_split2, 4) for k_, v_ in stage2.items() if k_ != "instance"},
                                exchange={"transport": "RCCL collectives enqueued by libifx.so on the handle's stream (csrc/ifx_comm.hip)", "collectives_per_frame": round(xs2["collectives"] / ns, 2),
-                                         "bytes_per_frame": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1)},
+                                         "bytes_per_frame_per_rank": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1),
+                                         "id_keys": "the sampled 10 x 10 lattice with every frame, the whole image with a segmentation call (option own_lazy_ids)" if args.sharded_lazy_ids else "the whole image with every frame",
+                                         "index_keys": "reduce-scatter + all-gather of the creation numbers (option own_key_rs)" if args.sharded_key_rs else "all-reduce",
+                                         "what": "all-reduce-equivalent bytes every rank hands to the collectives of a frame, segmentation calls of the window included: a ring moves 2 (N - 1) / N of them per link direction"},
                                surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
                                what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
                                     "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")

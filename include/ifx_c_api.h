@@ -125,7 +125,9 @@ int ifx_stream_handles(ifx_t* h, void** main_stream, void** side_stream);
  * i.e. 1 / G of the map.  One process per GPU, every rank fed the same frame.  A frame is eight calls of ifx_owner_frame_phase (phase 0..7,
  * the image pointers are used by phase 0); after phase p (0..6) the caller reduces, across the ranks, the device buffers ifx_owner_exchange(p)
  * lists: ops 0 = element-wise MINIMUM of unsigned 64-bit words (key images: depth | creation number), ops 1 = SUM of 32-bit words
- * (attribute blocks with disjoint supports: the winner's rank writes a pixel, the others hold zeros).  The library does it itself once it holds a
+ * (attribute blocks with disjoint supports: the winner's rank writes a pixel, the others hold zeros); op 6 (option "own_key_rs", exchanges 0 and 2) = the MINIMUM of op 0 of which
+ * only the low 32 bits of every word are wanted back -- the buffer must come back as (uint64) low word, all-ones words whole: any transport that computes op 0 and strips the
+ * high words will do, the library's own runs a reduce-scatter and an all-gather of the low words (12 instead of 16 bytes per key and link direction).  The library does it itself once it holds a
  * communicator (ifx_owner_process_frame_device below); the phase / exchange pair stays for hosts with their own transport and for the emulation tests.  Poses, images and -- merged by ifx_map_seq -- the map equal the unsharded run bit for
  * bit.  Per-surfel work (projections, fusion update, clean, votes, label scan) is sharded, per-pixel work (tracking, association, the mask
  * pipeline) replicated; segmentation calls go through ifx_owner_segmentation_begin / _resume, the kNN smoothing through ifx_owner_knn_export /
@@ -147,7 +149,8 @@ int ifx_owner_frame_phase(ifx_t* h, int phase, const uint8_t* d_rgb, const uint1
  *   ifx_owner_predict                ElasticFusion::predict outside a frame (after ifx_map_upload / ifx_set_pose)
  *   ifx_owner_process_segmentation   InstanceFusion::processInstance (IF/Core/InstanceFusion.cpp:655-1067): begin / resume with the exchanges inside; flags bit 0 also runs
  *   ifx_owner_knn_vote_colour        flannKnnVoteSurfelMap (:1070-1163): all-gather of every rank's slots (20 B each), exact 10-NN of the owned surfels
- *   ifx_owner_exchange_stats         out2 = collectives enqueued, bytes handed to them since the last reset
+ *   ifx_owner_exchange_stats         out2 = collectives enqueued, bytes handed to them since the last reset (in all-reduce-equivalent bytes: a ring all-reduce of S bytes moves
+ *                                    2 S (G - 1) / G per link direction; the reduce-scatter + all-gather pair of op 6 counts (8 + 4) / 2 bytes per key)
  * ifx_config::n_ranks = -1 creates a WORLD OF ONE on this path (creation-number ids, owner filter, every exchange point as a one-rank collective): what
  * `bench.py --sharded --gpus 1` and the single-GPU RCCL test run.
  * Creation numbers (the ids of a sharded map) are unsigned 32-bit and never renumbered: a handle reports IFX_E_CAPACITY once 2^32 - 2^20 of them have been

@@ -188,8 +188,8 @@ extern "C" int ifx_create(const ifx_config* cfg, ifx_t** out)
     // (ifx_owner_exchange): [key_splat | key_ids | key_both], [index_vc | index_nr], [pred_vertex | pred_normal | pred_image | pred_inst | pred_time | tail].
     // Sharded map: one more word behind key_index and behind [key_splat | key_ids] -- the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE),
     // MIN-reduced with the keys in the same collective.  Hence key_both in FRONT of the pair: [key_both | key_splat | key_ids | word].
-    ALLOC(h->key_index, P * 8 + 8); ALLOC(h->key_both, P * 8 * 3 + 8); h->key_splat = h->key_both + P; h->key_ids = h->key_both + 2 * P;
-    hipMemset(h->key_index, 0xFF, P * 8 + 8); hipMemset(h->key_both, 0xFF, P * 8 * 3 + 8);
+    ALLOC(h->key_index, P * 8 + 8 + IFX_KEY_SLACK); ALLOC(h->key_both, P * 8 * 3 + 8); h->key_splat = h->key_both + P; h->key_ids = h->key_both + 2 * P;
+    hipMemset(h->key_index, 0xFF, P * 8 + 8 + IFX_KEY_SLACK); hipMemset(h->key_both, 0xFF, P * 8 * 3 + 8);
     if (h->own) { h->gfl_index = h->key_index + P; h->gfl_splat = h->key_both + 3 * P; }
     ALLOC(h->index_id, P * 4); ALLOC(h->index_vc, P * 16 * 2); h->index_nr = h->index_vc + 4 * P; ALLOC(h->index_ct, P * 16); ALLOC(h->index_tap, P * 16);
     // [pred_vertex | pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail]: everything behind pred_vertex travels (sharded map).  The vertex itself does not: it is
@@ -341,6 +341,11 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "side_late") h->opt_side_late = value;
     else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
     else if (s == "own_first_live") h->opt_own_first_live = value;
+    else if (s == "own_key_rs") {
+        if (!h->own) { h->err = "own_key_rs: the handle was not created for a sharded map"; return IFX_E_STATE; }
+        if (h->own_g * 8 > IFX_KEY_SLACK) { h->err = "own_key_rs: more ranks than the key image's slack allows"; return IFX_E_INVALID; }
+        h->opt_own_key_rs = value;
+    }
     else if (s == "own_lazy_ids") {
         if (!h->own) { h->err = "own_lazy_ids: the handle was not created for a sharded map"; return IFX_E_STATE; }
         if (value && ifx_own_lattice(h) + 1 > 16 * 1024) { h->err = "own_lazy_ids: the image's id lattice is larger than the pack kernel's one workgroup holds (16 383 entries)"; return IFX_E_INVALID; }
@@ -1156,9 +1161,9 @@ extern "C" int ifx_owner_exchange(ifx_t* h, int phase, void** ptrs, int64_t* byt
     int n = 0;
     auto add = [&](void* p, size_t b, int op) { if (n < max_n) { ptrs[n] = p; bytes[n] = (int64_t)b; ops[n] = op; } n++; };
     switch (phase) {
-    case 0: if (!first) add(h->key_index, P * 8 + 8, 0); break;                  // + the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE)
+    case 0: if (!first) add(h->key_index, P * 8 + 8, h->opt_own_key_rs ? 6 : 0); break;                  // + the lowest live creation number (the reference's "surfel 0", ifx_map.hip FIRST_LIVE)
     case 1: if (!first) add(h->assoc_key, (size_t)((h->w + 1) / 2) * ((h->h + 1) / 2) * 8, 0); break;   // the best owned candidate of every measurement pixel (distance | window position)
-    case 2: if (!first) add(h->key_index, P * 8 + 8, 0); break;                                    // (the word is the reduced one of exchange 0: a MIN of equal values)
+    case 2: if (!first) add(h->key_index, P * 8 + 8, h->opt_own_key_rs ? 6 : 0); break;                                    // (the word is the reduced one of exchange 0: a MIN of equal values)
     case 3: if (!first) add(h->index_tap, P * 16, 1); break;
     case 4:                                                                                         // [key_splat | key_ids | word] (key_both was folded into them by k_merge_both)
         if (h->own_ids_lat) add(h->key_splat, (P + (size_t)ifx_own_lattice(h)) * 8 + 8, 0);         // option own_lazy_ids: [key_splat | the id keys of the sampled lattice | word]

@@ -19,6 +19,9 @@
 //   after phase 4  [key_splat | key_ids]                   u64 MIN    16             (key_both folded in by k_merge_both)
 //   after phase 5  [pred_conf | pred_normal | pred_image | pred_inst | pred_time | tail: vote mass]   i32 SUM    30 (+ 16 B)   (the vertex is rebuilt from the key's depth)
 // six collectives, 80 B / pixel (round 2: fourteen collectives, 130 B / pixel; start of round 3: six, 122 B).
+// Options (round 6): own_lazy_ids -- exchange 4 carries [key_splat | the id keys of the sampled 10 x 10 lattice]: 72 B / pixel, the whole id image's keys travel with a
+// segmentation call; own_key_rs -- the index keys of exchanges 0 and 2 as reduce-scatter + all-gather of the creation numbers (op 6): 68 B / pixel in all-reduce-equivalent
+// bytes, eight collectives.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
@@ -36,6 +39,7 @@ struct Rccl {
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -55,7 +59,7 @@ bool rccl_load(std::string& err)
     if (!lib) { g_rccl.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); err = g_rccl.err; return false; }
 #define SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name); if (!g_rccl.field) { g_rccl.err = std::string("RCCL symbol missing: ") + name; err = g_rccl.err; dlclose(lib); return false; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
-    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Reduce, "ncclReduce") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(CommUserRank, "ncclCommUserRank") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(ReduceScatter, "ncclReduceScatter") SYM(Broadcast, "ncclBroadcast") SYM(Reduce, "ncclReduce") SYM(GetErrorString, "ncclGetErrorString")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
     g_rccl.lib = lib;
@@ -69,6 +73,8 @@ struct Comm {
     int* d_cnt = nullptr;          // [G] slot counts of the kNN all-gather
     void *knn_send = nullptr, *knn_recv = nullptr, *knn_all = nullptr;
     size_t knn_send_cap = 0, knn_recv_cap = 0, knn_all_cap = 0;
+    void *rs_tile = nullptr, *rs_ids = nullptr, *rs_all = nullptr;   // op 6: this rank's tile of reduced keys, its creation numbers, every tile's
+    size_t rs_cap = 0;                                                // in keys per tile
 };
 Comm* comm_of(ifx* h) { return (Comm*)h->comm; }
 }   // namespace
@@ -88,6 +94,9 @@ void ifx_comm_free(ifx* h)
     if (c->knn_send) hipFree(c->knn_send);
     if (c->knn_recv) hipFree(c->knn_recv);
     if (c->knn_all) hipFree(c->knn_all);
+    if (c->rs_tile) hipFree(c->rs_tile);
+    if (c->rs_ids) hipFree(c->rs_ids);
+    if (c->rs_all) hipFree(c->rs_all);
     delete c;
     h->comm = nullptr;
 }
@@ -146,11 +155,45 @@ extern "C" int ifx_owner_set_comm(ifx_t* h, void* nccl_comm)
     return IFX_OK;
 }
 
+// op 6 (option own_key_rs): key images whose consumers read the winner's creation number only (the index keys: k_index_resolve names the winner and asks "is it mine?", the depth
+// has done its work in the MIN).  The MIN runs as a reduce-scatter over G tiles, then only the low words travel on: 8 + 4 bytes per key and link direction x (G - 1) / G
+// instead of the all-reduce's 16.  The buffer comes back with the depth stripped: (u64) creation number, empty keys whole.
+__global__ void k_keys_low(const unsigned long long* __restrict__ keys, int n, uint32_t* __restrict__ low)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) low[k] = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+}
+__global__ void k_keys_from_low(const uint32_t* __restrict__ low, int n, unsigned long long* __restrict__ keys)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { const uint32_t v = low[k]; keys[k] = v == 0xFFFFFFFFu ? IFX_KEY_EMPTY : (unsigned long long)v; }
+}
+static int comm_keys_rs(ifx* h, Comm* c, void* ptr, int64_t nbytes)
+{
+    const int G = h->own_g, n = (int)(nbytes / 8), tile = (n + G - 1) / G;
+    if ((size_t)tile > c->rs_cap) {
+        if (c->rs_tile) hipFree(c->rs_tile);
+        if (c->rs_ids) hipFree(c->rs_ids);
+        if (c->rs_all) hipFree(c->rs_all);
+        c->rs_tile = c->rs_ids = c->rs_all = nullptr; c->rs_cap = 0;
+        HIPCHK(h, hipMalloc(&c->rs_tile, (size_t)tile * 8)); HIPCHK(h, hipMalloc(&c->rs_ids, (size_t)tile * 4)); HIPCHK(h, hipMalloc(&c->rs_all, (size_t)tile * 4 * G));
+        c->rs_cap = (size_t)tile;
+    }
+    // (G * tile - n < G keys are read past the image: the allocation carries that slack, IFX_KEY_SLACK, and nothing of it comes back)
+    NCCLCHK(h, g_rccl.ReduceScatter(ptr, c->rs_tile, (size_t)tile, ncclUint64, ncclMin, c->comm, h->stream));
+    hipLaunchKernelGGL(k_keys_low, dim3((tile + 255) / 256), dim3(256), 0, h->stream, (const unsigned long long*)c->rs_tile, tile, (uint32_t*)c->rs_ids);
+    NCCLCHK(h, g_rccl.AllGather(c->rs_ids, c->rs_all, (size_t)tile, ncclUint32, c->comm, h->stream));
+    hipLaunchKernelGGL(k_keys_from_low, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const uint32_t*)c->rs_all, n, (unsigned long long*)ptr);
+    c->n_coll += 1;                       // (two collectives at this exchange point: ifx_comm_exchange counts the other)
+    c->bytes += (nbytes + nbytes / 2) / 2;   // in all-reduce-equivalent bytes, the unit of the other exchanges (a ring all-reduce of S bytes moves 2 S (G - 1) / G per link): (8 + 4) / 2 per key
+    return IFX_OK;
+}
 // one buffer of an exchange point
 static int comm_one(ifx* h, Comm* c, void* ptr, int64_t nbytes, int32_t opc)
 {
     // ops of ifx_owner_exchange: 0 unsigned 64-bit MIN (keys: depth | creation number), 1 int32 SUM (disjoint supports: a bitwise merge), 2 int32 MIN, 3 int32 MAX,
-    // 4 | root << 8 broadcast, 5 | root << 8 int32 SUM to the root only
+    // 4 | root << 8 broadcast, 5 | root << 8 int32 SUM to the root only, 6 unsigned 64-bit MIN of which only the low words are wanted back (comm_keys_rs)
+    if ((opc & 0xFF) == 6) return comm_keys_rs(h, c, ptr, nbytes);
     if ((opc & 0xFF) == 4) {   // broadcast from rank ops >> 8 (the pose block of a frame tracked by one rank)
         NCCLCHK(h, g_rccl.Broadcast(ptr, ptr, (size_t)nbytes, ncclInt8, opc >> 8, c->comm, h->stream));
         c->bytes += nbytes;
@@ -177,7 +220,7 @@ int ifx_comm_exchange(ifx* h, int phase)
     if (n < 0) return n;
     // the buffers of one exchange point travel as ONE group (the keys and the 8-byte "surfel 0" word of exchanges 0 / 4; the prediction block and its tail of
     // exchange 5; the two statistics of a segmentation call): aggregated by RCCL into one launch
-    const bool group = n > 1;
+    const bool group = n > 1;   // (op 6 has kernels between its two collectives: such a buffer is the only one of its exchange point)
     if (group) NCCLCHK(h, g_rccl.GroupStart());
     int rc = IFX_OK;
     for (int k = 0; k < n && k < 8 && rc == IFX_OK; k++) rc = comm_one(h, c, ptrs[k], bytes[k], ops[k]);

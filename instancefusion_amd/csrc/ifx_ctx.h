@@ -207,6 +207,7 @@ struct FrameSlot {
 #define LIST_V 3
 #define LIST_VI 4
 #define IFX_LIST_CTR_STRIDE 32
+#define IFX_KEY_SLACK 512       // bytes behind key_index | word that a reduce-scatter over up to 64 ranks may read (tiles of equal size)
 
 // decision for the frame whose pose was just committed; one thread (k_track_end / k_commit_pose / pose adoption)
 // (A = the pose the list was built for, B = the pose just committed: pointers into the state, or registers the caller loaded ahead of its stores)
@@ -289,6 +290,9 @@ struct ifx {
     // [key_splat | lattice keys | word] = 8 P + 8 L + 8 bytes instead of 16 P + 8 -- and whoever needs the whole id image (a segmentation call, a download, a camera
     // that is parked) gets it from an id render + ONE key exchange of its own (ifx_owner_ids_begin / exchange 200 / _resume; inline when the library holds the communicator)
     int opt_own_lazy_ids = 0;
+    // option own_key_rs (sharded map): the index keys of exchanges 0 and 2 have ONE kind of consumer -- k_index_resolve, which reads the winner's creation number -- so their
+    // MIN runs as reduce-scatter + all-gather of the low words (ifx_owner_exchange op 6; ifx_comm.hip comm_keys_rs): 12 instead of 16 bytes per key and link direction
+    int opt_own_key_rs = 0;
     int own_ids_lat = 0;                // the frame in flight exchanges the lattice form (set by phase 4, read by ifx_owner_exchange(4) and phase 5)
     int own_ids_pending = 0;            // an id render of the shard is waiting for its key exchange (ifx_owner_exchange(200))
     unsigned long long* own_lat_tmp = nullptr;   // L + 1 keys: staging of the lattice when the local raster drew the whole image (per-pass cull frames)

@@ -150,7 +150,8 @@ class OwnerShardedElasticFusion:
 
     # ---- caller-driven exchanges (transport="torch")
     def _tensor(self, ptr, nbytes, op):
-        return self.torch.as_tensor(_DevWords(ptr, nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=self.dev)
+        u64 = op in (0, 6)
+        return self.torch.as_tensor(_DevWords(ptr, nbytes // (8 if u64 else 4), "<i8" if u64 else "<i4"), device=self.dev)
 
     def _exchange(self, phase):
         spec = _exchange_spec(self.ef, phase)
@@ -164,8 +165,10 @@ class OwnerShardedElasticFusion:
                         self.dist.reduce(self._tensor(ptr, nbytes, 1), dst=op >> 8, op=self.dist.ReduceOp.SUM)
                         continue
                     t = self._tensor(ptr, nbytes, op)
-                    if op == 0:
+                    if op in (0, 6):
                         KeyExchange.reduce_min([t], self.dist)
+                        if op == 6:   # (option own_key_rs: the consumers want the creation numbers only -- this transport computes the whole MIN and strips the depth)
+                            _strip_depth(t)
                     else:
                         self.dist.all_reduce(t, op={1: self.dist.ReduceOp.SUM, 2: self.dist.ReduceOp.MIN, 3: self.dist.ReduceOp.MAX}[op])
 
@@ -280,6 +283,12 @@ def _seg_begin(ef, rgb, depth, masks, class_ids, frame, superpixels):
                                                      cls.ctypes.data_as(C.c_void_p), int(masks.shape[0]), int(frame), 2 if superpixels else 0), "ifx_owner_segmentation_begin")
 
 
+def _strip_depth(t):
+    """op 6 of ifx_owner_exchange: keys come back as (uint64) creation number, empty keys (all ones) whole."""
+    low = t & 0xFFFFFFFF
+    t.copy_(low.masked_fill(low == 0xFFFFFFFF, -1))
+
+
 def _reduce_by_hand(efs, specs):
     import torch
 
@@ -288,7 +297,8 @@ def _reduce_by_hand(efs, specs):
         e.sync()
     for k in range(len(specs[0])):
         op, nbytes = specs[0][k][2], specs[0][k][1]
-        ts = [torch.as_tensor(_DevWords(sp[k][0], nbytes // (4 if op else 8), "<i4" if op else "<i8"), device=dev) for sp in specs]
+        u64 = op in (0, 6)
+        ts = [torch.as_tensor(_DevWords(sp[k][0], nbytes // (8 if u64 else 4), "<i8" if u64 else "<i4"), device=dev) for sp in specs]
         if (op & 0xFF) == 5:                       # int32 SUM to rank op >> 8 only: the others keep what they hold (their own partial sums, never read)
             m = ts[0].clone()
             for t in ts[1:]:
@@ -297,11 +307,13 @@ def _reduce_by_hand(efs, specs):
             continue
         if (op & 0xFF) == 4:                       # broadcast from rank op >> 8
             m = ts[op >> 8].clone()
-        elif op == 0:
+        elif u64:
             m = ts[0] ^ _SIGN
             for t in ts[1:]:
                 m = torch.minimum(m, t ^ _SIGN)
             m ^= _SIGN
+            if op == 6:
+                _strip_depth(m)
         elif op == 1:
             m = ts[0].clone()
             for t in ts[1:]:

@@ -883,6 +883,7 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies, lazy_id
             e.set_option("own_first_live", 0)
     for e in efs:
         e.set_option("own_lazy_ids", lazy_ids)
+        e.set_option("own_key_rs", int(lazy_ids and world == 2))   # (with it: the index keys of exchanges 0 and 2 come back as creation numbers only, op 6)
     P_, L_ = SMALL["w"] * SMALL["h"], -(-SMALL["w"] // 10) * -(-SMALL["h"] // 10)
     poses = []
     for i in range(NF):
@@ -917,6 +918,7 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies, lazy_id
             if i > 0:   # (the map's first frame draws no id image and exchanges the whole form)
                 assert [(b, op) for _, b, op in sharded._exchange_spec(efs[0], 4)] == [((P_ + L_) * 8 + 8, 0)], i
                 assert [(b, op) for _, b, op in sharded._exchange_spec(efs_whole[0], 4)] == [(P_ * 16 + 8, 0)], i
+                assert [(b, op) for _, b, op in sharded._exchange_spec(efs[0], 2)] == [(P_ * 8 + 8, 6 if world == 2 else 0)], i
             if i > 0 and i % 3 != 1:   # (frames 1, 4, 7, ...: the sparse image is simply overwritten by the next frame)
                 with pytest.raises(RuntimeError):
                     efs[0].image("ids_after")          # caller-driven exchanges and no ifx_owner_ids_begin: refused, not silently sparse
@@ -980,6 +982,7 @@ def test_owner_sharded_instance_emulated(ifx, small_stream, world, lazy_ids):
     inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
     for e in efs:
         e.set_option("own_lazy_ids", lazy_ids)   # (1: the frames exchange the sampled lattice's id keys; every segmentation call completes the image at an exchange point of its own)
+        e.set_option("own_key_rs", lazy_ids)
 
     def merged(name_of):
         parts = [(e.seq(), name_of(e, x)) for e, x in zip(efs, insts)]
@@ -1063,6 +1066,7 @@ def test_config4_1280x960_20m_map_sharded_x4(ifx, lazy_ids):
     inst_one, insts = ifx.InstanceFusion(one), [ifx.InstanceFusion(e) for e in efs]
     for e in efs:
         e.set_option("own_lazy_ids", lazy_ids)   # (1: exchange 4 carries [splat keys | the id keys of the 128 x 96 lattice | word]: 9.9 MB instead of 19.7 MB a frame)
+        e.set_option("own_key_rs", lazy_ids)     # (and the index keys of exchanges 0 and 2 come back as creation numbers only)
     # frame 0 initialises the tracker's previous image; then the 20M map replaces the first-frame map on both sides
     one.enqueue_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr(), 0)
     sharded.emulate_owner_ranks(efs, d_rgb[0].data_ptr(), d_dep[0].data_ptr())
@@ -2225,7 +2229,7 @@ def test_sharded_rccl_world_of_one(ifx, small_stream):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lazy_ids", [0, 1])
+@pytest.mark.parametrize("lazy_ids", [0, 1, 2])
 def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids):
     """The spatially sharded map with the collectives INSIDE libifx.so (csrc/ifx_comm.hip), on real RCCL: a world of one (ifx_config.n_ranks = -1:
     creation-number ids, owner filter, every exchange point of a frame / predict / segmentation call / kNN smoothing issued as a one-rank
@@ -2244,7 +2248,8 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids)
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     ef = ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=-1, rank=0)
     osh = sharded.OwnerShardedElasticFusion(ef, None)            # ifx_comm_unique_id + ifx_owner_init_comm: ncclCommInitRank(1, id, 0)
-    ef.set_option("own_lazy_ids", lazy_ids)                      # (1: 72 B per pixel + the lattice; the whole id image on demand, the exchange enqueued by the library in place)
+    ef.set_option("own_lazy_ids", int(lazy_ids > 0))             # (1: 72 B per pixel + the lattice; the whole id image on demand, the exchange enqueued by the library in place)
+    ef.set_option("own_key_rs", int(lazy_ids == 2))              # (2: also the index keys as ncclReduceScatter + ncclAllGather of the creation numbers: eight collectives, 68 B per pixel in all-reduce-equivalent bytes)
     inst_one, inst = ifx.InstanceFusion(one), ifx.InstanceFusion(ef)
     P = SMALL["w"] * SMALL["h"]
 
@@ -2272,7 +2277,7 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids)
             if i == 7:
                 xs = osh.exchange_stats()
                 L = -(-SMALL["w"] // 10) * -(-SMALL["h"] // 10)
-                assert xs["collectives"] == 6 and xs["bytes"] == (72 * P + 8 * L if lazy_ids else 80 * P) + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
+                assert xs["collectives"] == (8 if lazy_ids == 2 else 6) and xs["bytes"] == (80 * P, 72 * P + 8 * L, 68 * P + 8 * L - 4)[lazy_ids] + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

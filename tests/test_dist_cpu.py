@@ -179,6 +179,80 @@ def test_key_image_min_allreduce_gloo():
     assert want[-1] == 4711 and np.int32(np.uint32(want[-1] & np.uint64(0xFFFFFFFF))) == 4711   # (the kernels read the low word as an int: FIRST_LIVE)
 
 
+def _rsworker(rank, world, port, q):
+    import torch
+
+    from instancefusion_amd import sharded
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w, d = ifd.init("gloo")
+    rng = np.random.RandomState(200 + rank)
+    W, H = 50, 37                                       # (a lattice of 5 x 4 points; 1850 pixels + the word: 1851 keys, an odd number -> tiles of 926 with one key of slack)
+    P = W * H
+    z = rng.uniform(0.3, 9.0, P).astype(np.float32).view(np.uint32).astype(np.uint64)
+    keys = (z << np.uint64(32)) | rng.randint(0, 1 << 22, P).astype(np.uint64)
+    keys[rng.rand(P) < 0.4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    keys = np.concatenate([keys, np.array([0xFFFFFFFFFFFFFFFF if rank == 1 else 4711], np.uint64)])
+    n = P + 1
+    # ---- op 6 as ifx_comm.hip runs it (comm_keys_rs): MIN by reduce-scatter over `world` tiles of equal size (gloo has no reduce_scatter: one reduce per tile, to the
+    # tile's rank), the low words of this rank's tile, an all-gather of them, keys rebuilt from the low words
+    tile = (n + world - 1) // world
+    padded = np.concatenate([keys, rng.randint(0, 1 << 62, tile * world - n).astype(np.uint64)])   # (what lies in the slack is anything: it never comes back)
+    flipped = torch.from_numpy((padded ^ np.uint64(1 << 63)).view(np.int64).copy())
+    mine = None
+    for g in range(world):
+        t = flipped[g * tile:(g + 1) * tile].clone()
+        d.reduce(t, dst=g, op=d.ReduceOp.MIN)
+        if g == rank:
+            mine = t
+    low = (mine.numpy().view(np.uint64) ^ np.uint64(1 << 63)).astype(np.uint32)    # k_keys_low
+    gathered = [torch.empty(tile, dtype=torch.int32) for _ in range(world)]
+    d.all_gather(gathered, torch.from_numpy(low.view(np.int32).copy()))
+    allv = np.concatenate([g_.numpy().view(np.uint32) for g_ in gathered])[:n]
+    rebuilt = np.where(allv == np.uint32(0xFFFFFFFF), np.uint64(0xFFFFFFFFFFFFFFFF), allv.astype(np.uint64))   # k_keys_from_low
+    # ---- the same exchange as a caller-driven transport may run it: the whole MIN, then the depth stripped (sharded._strip_depth)
+    t = torch.from_numpy(keys.view(np.int64).copy())
+    sharded.KeyExchange.reduce_min([t], d)
+    whole_min = t.numpy().view(np.uint64).copy()
+    sharded._strip_depth(t)
+    stripped = t.numpy().view(np.uint64).copy()
+    # ---- option own_lazy_ids: [splat keys | id keys of the lattice | word] in ONE minimum == the lattice of the minimum of the whole id image
+    ids = keys[:P].copy(); rng.shuffle(ids)
+    lat = np.array([(y * 10) * W + x * 10 for y in range((H + 9) // 10) for x in range((W + 9) // 10)])
+    packed = np.concatenate([keys[:P], ids[lat], keys[P:]])
+    tp = torch.from_numpy(packed.view(np.int64).copy())
+    sharded.KeyExchange.reduce_min([tp], d)
+    ti = torch.from_numpy(ids.view(np.int64).copy())
+    sharded.KeyExchange.reduce_min([ti], d)
+    q.put((rank, whole_min, rebuilt, stripped, tp.numpy().view(np.uint64).copy(), ti.numpy().view(np.uint64)[lat].copy(), len(lat)))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_index_keys_reduce_scatter_and_lattice_pack_gloo():
+    """The two exchange options of the sharded map over gloo with two ranks.  own_key_rs (ifx_owner_exchange op 6): the index keys' MIN as a
+    reduce-scatter over equal tiles + an all-gather of the low words gives every rank (uint64) creation number of the winner, empty keys and an all-ones word whole --
+    the same as the whole MIN with the depth stripped.  own_lazy_ids: the id keys of the 10 x 10 lattice packed between the splat keys and the word."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rsworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, whole_min, rebuilt, stripped, packed, lat_of_min, nl in res:
+        empty = whole_min == np.uint64(0xFFFFFFFFFFFFFFFF)
+        want = np.where(empty, whole_min, whole_min & np.uint64(0xFFFFFFFF))
+        assert np.array_equal(rebuilt, want) and np.array_equal(stripped, want), rank
+        assert empty.sum() > 100 and want[-1] == 4711
+        P = len(whole_min) - 1
+        assert nl == 20 and np.array_equal(packed[:P], whole_min[:P]) and np.array_equal(packed[P:P + nl], lat_of_min) and packed[-1] == 4711, rank
+    assert np.array_equal(res[0][2], res[1][2])
+
+
 def _segworker(rank, world, port, q):
     import torch
 

@@ -178,57 +178,12 @@ __global__ void k_pyrdown_gauss_u8(const uint8_t* __restrict__ src, int sw, int 
 // ---- frame side in 4 launches (was 12): intensity of level 0; one launch per coarser level for BOTH pyr-downs (depth: the
 // bilateral-like pyrDownGaussKernel, intensity: the 5x5 Gaussian); one launch for the vertex/normal maps and the Sobel
 // gradients of all three levels (each needs its level's complete depth / intensity image, nothing of another level).
-// Interior pixels (the 5 x 5 window and the clipped window bound tx = 2x+3 <= sw-1 all inside) take the same sums in the same order with the 25 + 25
-// loads issued ahead of the arithmetic: the clipped loops below issue one load per iteration and wait for it (14-20 us per level for 19 200-76 800
-// pixels, which is L2 latency x 50, not bandwidth).
-__device__ __forceinline__ bool pyr5_interior(int x, int y, int sw, int sh) { return x >= 1 && y >= 1 && 2 * x + 3 <= sw - 1 && 2 * y + 3 <= sh - 1; }
 __global__ void k_frame_down(const uint16_t* __restrict__ dsrc, const uint8_t* __restrict__ isrc, int sw, int sh, uint16_t* __restrict__ ddst, uint8_t* __restrict__ idst)
 {
     const int dw = sw / 2, dh = sh / 2;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= dw || y >= dh) return;
     const int D = 5;
-    if (pyr5_interior(x, y, sw, sh)) {
-        int dv[25], iv[25];
-        const int base = (2 * y - 2) * sw + 2 * x - 2;
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-#pragma unroll
-            for (int i = 0; i < 5; i++) { dv[j * 5 + i] = dsrc[base + j * sw + i]; iv[j * 5 + i] = isrc[base + j * sw + i]; }
-        {   // pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
-            const float sigma_color = 30;
-            constexpr float weights[3] = {0.375f, 0.25f, 0.0625f};
-            const int center = dv[12];
-            float sum = 0, wall = 0;
-#pragma unroll
-            for (int j = 0; j < 5; j++)
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    const int val = dv[j * 5 + i];
-                    const float wx = weights[i < 2 ? 2 - i : i - 2], wy = weights[j < 2 ? 2 - j : j - 2];
-                    if ((float)abs(val - center) < 3 * sigma_color) {
-                        sum += val * wx * wy;
-                        wall += wx * wy;
-                    }
-                }
-            ddst[y * dw + x] = (uint16_t)(int)(sum / wall);
-        }
-        {   // pyrDownKernelIntensityGauss, EF/Cuda/cudafuncs.cu:470-500 (ty - cy - 1 = 4 - j, tx - cx - 1 = 4 - i)
-            float sum = 0;
-            int count = 0;
-#pragma unroll
-            for (int j = 0; j < 5; j++)
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    const int sv = iv[j * 5 + i];
-                    constexpr float gtab[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
-                    const float g = gtab[(4 - j) * 5 + (4 - i)];
-                    if (sv > 0) { sum += sv * g; count += (int)g; }
-                }
-            idst[y * dw + x] = count ? (uint8_t)f2i_rz(sum / (float)count) : (uint8_t)0;
-        }
-        return;
-    }
     {   // pyrDownGaussKernel, EF/Cuda/cudafuncs.cu:57-94
         const float sigma_color = 30;
         const float weights[3] = {0.375f, 0.25f, 0.0625f};
@@ -385,53 +340,31 @@ __global__ void k_model_down(const DevState* __restrict__ st, const float* __res
     for (int m = 0; m < 2; m++) {   // resizeMapKernel<normalize>, EF/Cuda/cudafuncs.cu:365-416
         const float* in = m ? nin : vin;
         float* out = m ? o.ncam : o.vcam;
-        const float *py = in + sh * sw, *pz = in + 2 * sh * sw;   // (all twelve loads ahead of the test: they are in bounds whatever it decides)
-        const float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
-        const float y00 = py[ys * sw + xs], y01 = py[ys * sw + xs + 1], y10 = py[(ys + 1) * sw + xs], y11 = py[(ys + 1) * sw + xs + 1];
-        const float z00 = pz[ys * sw + xs], z01 = pz[ys * sw + xs + 1], z10 = pz[(ys + 1) * sw + xs], z11 = pz[(ys + 1) * sw + xs + 1];
+        float x00 = in[ys * sw + xs], x01 = in[ys * sw + xs + 1], x10 = in[(ys + 1) * sw + xs], x11 = in[(ys + 1) * sw + xs + 1];
         v3 n = v3m(qn, qn, qn);
         if (!((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11))) {
             n.x = (x00 + x01 + x10 + x11) / 4;
-            n.y = (y00 + y01 + y10 + y11) / 4;
-            n.z = (z00 + z01 + z10 + z11) / 4;
+            const float* py = in + sh * sw;
+            n.y = (py[ys * sw + xs] + py[ys * sw + xs + 1] + py[(ys + 1) * sw + xs] + py[(ys + 1) * sw + xs + 1]) / 4;
+            const float* pz = in + 2 * sh * sw;
+            n.z = (pz[ys * sw + xs] + pz[ys * sw + xs + 1] + pz[(ys + 1) * sw + xs] + pz[(ys + 1) * sw + xs + 1]) / 4;
             if (m) n = normalized(n);
         }
         out[y * dw + x] = n.x; out[(y + dh) * dw + x] = n.y; out[(y + 2 * dh) * dw + x] = n.z;
         res[m] = n;
     }
     const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
     float sumf = 0, sumi = 0;
     int cntf = 0, cnti = 0;
-    if (pyr5_interior(x, y, sw, sh)) {   // same sums, same order, the 50 loads issued ahead of the arithmetic (see k_frame_down)
-        float dv[25];
-        int iv[25];
-        const int base = (2 * y - 2) * sw + 2 * x - 2;
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-#pragma unroll
-            for (int i = 0; i < 5; i++) { dv[j * 5 + i] = din[base + j * sw + i]; iv[j * 5 + i] = iin[base + j * sw + i]; }
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                constexpr float gtab[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
-                const float g = gtab[(4 - j) * 5 + (4 - i)];
-                const float sf = dv[j * 5 + i];
-                if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
-                const int si = iv[j * 5 + i];
-                if (si > 0) { sumi += si * g; cnti += (int)g; }
-            }
-    } else {
-        const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
-        for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-            for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-                const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                const float sf = din[cy * sw + cx];       // pyrDownKernelGaussF :332-363
-                if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
-                const int si = iin[cy * sw + cx];         // pyrDownKernelIntensityGauss :470-500
-                if (si > 0) { sumi += si * g; cnti += (int)g; }
-            }
-    }
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const float g = c_gauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+            const float sf = din[cy * sw + cx];       // pyrDownKernelGaussF :332-363
+            if (!(sf != sf)) { sumf += sf * g; cntf += (int)g; }
+            const int si = iin[cy * sw + cx];         // pyrDownKernelIntensityGauss :470-500
+            if (si > 0) { sumi += si * g; cnti += (int)g; }
+        }
     const float z = (float)(sumf / (float)cntf);
     o.depth[y * dw + x] = z;
     o.img[y * dw + x] = cnti ? (uint8_t)f2i_rz(sumi / (float)cnti) : (uint8_t)0;
@@ -1657,7 +1590,7 @@ __global__ void k_track_gn_begin(DevState* st, const DevState* __restrict__ ss, 
 __device__ void gn_begin_dev(DevState* st, const DevState* __restrict__ ss, int so3, float fx, float fy, float cx, float cy, int keep_last)
 {
     // Everything this lane reads is loaded ahead of its first store and the values then stay in registers: `st` aliases itself, so reading the state back between the
-    // stores made this a chain of ~40 L2 round trips -- the long pole of the launch it rides on (k_model_down of the coarsest level).
+    // stores made this a chain of ~40 L2 round trips in one block of the launch it rides on (k_model_down of the coarsest level).
     float P[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) P[k] = st->pose[k];

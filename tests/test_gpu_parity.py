@@ -863,6 +863,7 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies, lazy_id
     st = small_stream
     NF = 8
     src = list(range(NF))
+    swept = zero_dies >= 1000
     if zero_dies == 30:   # a LONG life of the map (the stream forth and back): the clean pass's 20-frame age rule at work on shards whose view lists live several frames
         NF, zero_dies = 30, 0
         src = [(i % 18) if (i % 18) < 10 else 18 - (i % 18) for i in range(NF)]
@@ -924,7 +925,7 @@ def test_owner_sharded_map_emulated(ifx, small_stream, world, zero_dies, lazy_id
                     efs[0].image("ids_after")          # caller-driven exchanges and no ifx_owner_ids_begin: refused, not silently sparse
                 sharded.emulate_owner_ids(efs)
                 whole = efs_whole[0].image("ids_after")
-                assert i < 5 or (whole > 0).sum() > 1000, (i, int((whole > 0).sum()))   # (populated from the uploaded map on: half of its surfels are stable)
+                assert i < 5 or swept or (whole > 0).sum() > 1000, (i, int((whole > 0).sum()))   # (a floor of the committed scenario: populated from the uploaded map on, half of its surfels are stable)
                 for e in efs + efs_whole[1:]:
                     assert np.array_equal(e.image("ids_after"), whole), (i, e.cfgd["rank"])
         if zero_dies < 0:

@@ -2503,7 +2503,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_gn_level(DevState* st, LevelArg
                 const double wa = wgt * wgt, wb = wgt;
                 const bool is_b = (tid == 6) | (tid == 12) | (tid == 17) | (tid == 21) | (tid == 24) | (tid == 26);
                 const double vi = (double)oi, vr = (double)orr;
-                s_sys[tid] = (ICP && RGB) ? vr + (is_b ? wb : wa) * vi : (ICP ? vi : vr);
+                s_sys[tid] = (ICP != 0 && RGB != 0) ? vr + (is_b ? wb : wa) * vi : (ICP ? vi : vr);
             }
         }
         if (tid == 64) { s_res[0] = rcnt; s_res[1] = rsig; }
@@ -2801,7 +2801,6 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
     static const float minGrad[3] = {5, 3, 1};
     const double sobelScale = 1.0 / 8.0;
     bool ended = false;
-    int iters_done = 0;
     // which levels run in the persistent kernel, and whether the two-launch iterations form the run's tail (then their solves move into the next launch's prologue: gn_prologue)
     int persist_q[IFX_NUM_PYRS], persist_nb[IFX_NUM_PYRS];
     for (int i = 0; i < IFX_NUM_PYRS; i++) {
@@ -2820,7 +2819,6 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
         }
     }
     bool pro = h->opt_gn_prologue != 0;
-    int n_tail = 0;
     // The prologue solve is repeated by every block of a launch: free while the grid is one wave of blocks, 4-6 us per launch at 4800 + 304 blocks (level 0 of a
     // 1280x960 frame: 516 against 540 frames/s, profiles/r04_z2_*).  n_pro: the leading iterations of the tail (coarse levels first) whose launches stay under
     // opt_gn_prologue_blocks; the last of them is solved in the last-block form (StepArgs::pro = 2) and leaves the pose in the state, where round 3's form of the
@@ -2832,7 +2830,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
             if (iterations[i] <= 0) continue;
             if (persist_q[i] >= 0) { if (seen_two_launch) pro = false; }   // a persistent level BEHIND two-launch iterations reads the pose from the state: round 3's form keeps it there
             else {
-                seen_two_launch = true; n_tail += iterations[i];
+                seen_two_launch = true;
                 const int n = p.w[i] * p.h[i];
                 const int blocks = (icp ? red_blocks(h, n) : 0) + (rgb ? std::min(std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows), h->opt_res_blocks > 0 ? h->opt_res_blocks : (1 << 30)) : 0);
                 small = small && blocks <= h->opt_gn_prologue_blocks;
@@ -2912,12 +2910,10 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 else if (q == 2) LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<3>, st, la);
                 else LAUNCH(h, "gn_level", dim3(nbp), dim3(RED_THREADS), k_gn_level<4>, st, la);
                 LAUNCH(h, "gn_level_solo", dim3(1), dim3(RED_THREADS), k_gn_level_solo, st, la);   // the safety net: a no-op unless a meeting of the launch above did not happen
-                iters_done += iterations[i];
                 ended = ended || la.final_level;
                 continue;
             }
         }
-        iters_done += iterations[i];
         // both reductions on the same pixels of one thread (k_icp_residual_px); option bits: 1 = at level 0, 2 = at levels 1 and 2, 4 = one pixel per thread at level 0 too
 #ifdef IFX_EXPERIMENTS
         const bool px_form = frame_tracker && icp && rgb && !lds_tiles && (i == 0 ? (h->opt_icp_px & 1) : (h->opt_icp_px & 2));

@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--seg-host-frame", action="store_true", help="segmentation calls take the frame's RGB / depth from host memory (the reference's signature) instead of the resident frame")
     ap.add_argument("--pace", action="store_true", help="with --no-instance: wait for every frame's result before the next is enqueued (diagnostic)")
     ap.add_argument("--no-prefetch", action="store_true", help="no one-frame look-ahead (ifx_prefetch_frame_device)")
+    ap.add_argument("--sharded-track-rows", type=int, default=0, help="the sharded-map leg shards the tracker's reductions over the ranks and all-reduces the 2 x 29 exact sums (option own_track_rows: 38 more collectives a frame; a measured loss at the BASELINE sizes, DESIGN.md section 7 -- the default keeps the tracker replicated)")
     ap.add_argument("--sharded-key-rs", type=int, default=0, help="the sharded-map leg runs the index-key exchanges as reduce-scatter + all-gather of the creation numbers (option own_key_rs: 12 instead of 16 bytes per key and link, two more collectives a frame; priced in DESIGN.md section 7: pays from about 1280x960 on)")
     ap.add_argument("--sharded-lazy-ids", type=int, default=1, help="the sharded-map leg exchanges the id keys of the sampled lattice only (option own_lazy_ids; 0: the whole id image every frame, 80 B per pixel)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to ifx_set_option (experiments)")
@@ -193,6 +194,7 @@ def main():
         osh = ifsh.OwnerShardedElasticFusion(ef, dist)   # hands libifx.so a RCCL communicator; from here on a frame is one library call
         ef.set_option("own_lazy_ids", int(bool(args.sharded_lazy_ids)))   # exchange 4 carries the id keys of the sampled lattice; the whole image with a segmentation call
         ef.set_option("own_key_rs", int(bool(args.sharded_key_rs)))
+        ef.set_option("own_track_rows", int(bool(args.sharded_track_rows)))
         osh.process_frame_device(d_rgb[0].data_ptr(), d_dep[0].data_ptr())
         ef.upload(m)                                   # every rank is handed all rows and keeps the ones it owns
         ef.set_pose(st["poses"][0], tick0)
@@ -795,6 +797,7 @@ def main():
             osh2 = ifsh.OwnerShardedElasticFusion(ef2, dist)
             ef2.set_option("own_lazy_ids", int(bool(args.sharded_lazy_ids)))
             ef2.set_option("own_key_rs", int(bool(args.sharded_key_rs)))
+            ef2.set_option("own_track_rows", int(bool(args.sharded_track_rows)))
             osh2.process_frame_device(d_rgb2[0].data_ptr(), d_dep2[0].data_ptr())
             ef2.upload(m2)
             ef2.set_pose(st2["poses"][0], tick0)
@@ -851,10 +854,33 @@ def main():
                                          "bytes_per_frame_per_rank": round(xs2["bytes"] / ns), "bytes_per_pixel_per_frame": round(xs2["bytes"] / ns / P, 1),
                                          "id_keys": "the sampled 10 x 10 lattice with every frame, the whole image with a segmentation call (option own_lazy_ids)" if args.sharded_lazy_ids else "the whole image with every frame",
                                          "index_keys": "reduce-scatter + all-gather of the creation numbers (option own_key_rs)" if args.sharded_key_rs else "all-reduce",
+                                         "tracker": "reductions sharded over the ranks, 2 x 29 exact sums all-reduced per iteration (option own_track_rows)" if args.sharded_track_rows else "replicated (no collective)",
                                          "what": "all-reduce-equivalent bytes every rank hands to the collectives of a frame, segmentation calls of the window included: a ring moves 2 (N - 1) / N of them per link direction"},
                                surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
                                what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
                                     "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")
+            # the north star's tracker collective beside the replicated tracker, in the same leg: the reductions sharded over the ranks, the 2 x 29 exact sums all-reduced per
+            # iteration (option own_track_rows) -- so that any multi-GPU run of this file prices it on hardware (DESIGN.md section 7 prices it on paper: 38 small collectives a frame)
+            if not args.sharded_track_rows:
+                try:
+                    ef2.set_option("own_track_rows", 1)
+                    for _ in range(6):
+                        step2(k2); k2 += 1
+                    barrier2()
+                    osh2.exchange_stats(reset=True)
+                    nr_ = min(ns, 40)
+                    t0 = time.perf_counter()
+                    for _ in range(nr_):
+                        step2(k2); k2 += 1
+                    barrier2()
+                    dtr = ifd.max_over_ranks(time.perf_counter() - t0, dist, device=f"cuda:{dev}")
+                    xsr = osh2.exchange_stats()
+                    sharded_leg["tracker_rows"] = dict(value=round(nr_ / dtr, 2), unit="frames/s", frames=nr_, collectives_per_frame=round(xsr["collectives"] / nr_, 2),
+                                                       what="the same leg with the tracker's reductions sharded over the ranks and the 2 x 29 exact sums all-reduced in f64 per iteration "
+                                                            "(option own_track_rows; bit-identical poses); `value` of this leg keeps the tracker replicated")
+                    ef2.set_option("own_track_rows", 0)
+                except Exception as e_:   # (reported, not fatal: the leg's own measurement stands)
+                    sharded_leg["tracker_rows"] = dict(error=str(e_)[:200])
             barrier2()
             ef2.close()
 

@@ -215,6 +215,9 @@ int ifx_owner_segmentation_resume(ifx_t* h);
  * ifx_owner_ids_resume; 0: the image is whole already). */
 int ifx_owner_ids_begin(ifx_t* h);
 int ifx_owner_ids_resume(ifx_t* h);
+/* Option "own_track_rows" (sharded map, the library's communicator, no single tracking rank): the tracker's two reductions of an iteration (EF/Cuda/reduce.cu:257-490 ICP,
+ * :494-678 photometric) run over this rank's share of the pixel blocks and the 2 x 29 exact sums are all-reduced in f64 on the handle's stream, one workgroup solves
+ * (EF/Utils/RGBDOdometry.cpp:541-583).  Same poses bit for bit (the sums are exact); 38 small collectives more per frame.  Off by default: DESIGN.md section 7. */
 /* InstanceFusion::flannKnnVoteSurfelMap (src/Core/InstanceFusion.cpp:1070-1163) on a sharded map: exact 10-NN over ALL surfels needs every rank's
  * positions.  ifx_owner_knn_export hands out this rank's slots as device arrays -- points[n] float4 (x, y, z, creation number; x = NaN: dead slot),
  * labels[n] int32 (bestIDInEachSurfel) --, the caller all-gathers both in rank order (16 + 4 bytes per slot, once per smoothing, i.e. every > 40

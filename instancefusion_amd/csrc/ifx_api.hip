@@ -341,6 +341,11 @@ extern "C" int ifx_set_option(ifx_t* h, const char* name, int value)
     else if (s == "side_late") h->opt_side_late = value;
     else if (s == "vote_per_mask") h->opt_vote_per_mask = value;
     else if (s == "own_first_live") h->opt_own_first_live = value;
+    else if (s == "own_track_rows") {
+        if (!h->own) { h->err = "own_track_rows: the handle was not created for a sharded map"; return IFX_E_STATE; }
+        h->opt_own_track_rows = value;   // (takes effect while the library holds the communicator and no single rank tracks: ifx_owner_init_comm / _set_comm, ifx_owner_set_tracking_rank)
+    }
+    else if (s == "own_track_rows_emulate") h->opt_own_track_rows_emulate = value;
     else if (s == "own_key_rs") {
         if (!h->own) { h->err = "own_key_rs: the handle was not created for a sharded map"; return IFX_E_STATE; }
         if (h->own_g * 8 > IFX_KEY_SLACK) { h->err = "own_key_rs: more ranks than the key image's slack allows"; return IFX_E_INVALID; }

@@ -229,6 +229,16 @@ int ifx_comm_exchange(ifx* h, int phase)
     return rc;
 }
 int ifx_comm_ready(ifx* h) { Comm* c = comm_of(h); return c && c->comm; }
+// option own_track_rows: the exact accumulator rows of a tracker iteration, summed over the ranks (f64 SUM of grid-valued terms: exact, hence order-independent) -- on the
+// stream the tracker run is being enqueued on
+int ifx_comm_allreduce_f64(ifx* h, double* d_ptr, int n)
+{
+    Comm* c = comm_of(h);
+    if (!c || !c->comm) { h->err = "no communicator: ifx_owner_init_comm / ifx_owner_set_comm first"; return IFX_E_STATE; }
+    NCCLCHK(h, g_rccl.AllReduce(d_ptr, d_ptr, (size_t)n, ncclDouble, ncclSum, c->comm, h->cur));
+    c->n_coll++; c->bytes += (long long)n * 8;
+    return IFX_OK;
+}
 
 // ranks of the communicator the handle's collectives run on, as RCCL counts them (ncclCommCount); 0: no communicator yet
 extern "C" int ifx_owner_comm_ranks(ifx_t* h)

@@ -2128,6 +2128,35 @@ __global__ __launch_bounds__(RED_THREADS) void k_rgb_step_solve(DevState* st, in
 }
 
 
+// ---- option own_track_rows (a sharded map whose library holds the communicator; SURVEY.md 8e-i: "tracking is a sum over independent pixels -> shard the image, exchange =
+// all-reduce of the 29 + 29 sums"): rank r of G runs the two REDUCTIONS of an iteration over the pixel blocks b with b mod G == r (virtual block ids: the bodies are the ones
+// above, untouched), the accumulator rows are SUM-all-reduced in f64 -- exact sums of grid-valued terms: any order, any partition gives the same bits -- and one workgroup
+// solves.  The residual pass (it writes the correspondence records the photometric step reads back, by other blocks) stays whole on every rank.  Three launches and two
+// collectives per iteration instead of two launches: priced in DESIGN.md section 7 -- a measured loss at every BASELINE size, which is why the tracker stays replicated.
+__global__ __launch_bounds__(RED_THREADS, 4) void k_icp_residual_rows(const DevState* __restrict__ st, int nb_icp, int w, int h, double* __restrict__ gacc, int* __restrict__ gres, PairArgs a,
+                                                                      int srank, int sn)
+{
+    __builtin_assume(st != nullptr);
+    if ((int)blockIdx.x < nb_icp) {
+        IcpArgs ia;   // unused when st != nullptr
+        icp_body<false, true, false>(blockIdx.x * sn + srank, nb_icp * sn, st, ia, a.vmap_curr, a.nmap_curr, a.vmap_prev, a.nmap_prev, a.fx, a.fy, a.cx, a.cy, a.distThres, a.angleThres, w, h, gacc);
+    } else {
+        ResArgs ra;
+        residual_body<true, false>(blockIdx.x - nb_icp, a.nb_res, st, ra, a.minScale, a.dIdx, a.dIdy, a.lastDepth, a.nextDepth, a.lastImage, a.nextImage, a.corres, a.maxDepthDelta, w, h, nullptr, gres);
+    }
+}
+__global__ __launch_bounds__(RED_THREADS) void k_rgb_step_rows(DevState* st, int nb, int w, int h, StepArgs a, int srank, int sn)
+{
+    __builtin_assume(st != nullptr);
+    rgb_step_body(blockIdx.x * sn + srank, nb * sn, a.corres, 0.f, nullptr, 0, a.cloud, a.fx, a.fy, a.dIdx, a.dIdy, a.sobelScale, w, h, st->gn_acc + IFX_ACC_REPL * IFX_ACC_STRIDE, st->gn_res);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_gn_solve_rows(DevState* st, StepArgs a)
+{
+    __builtin_assume(st != nullptr);
+    gn_solve_block(st, st->gn_acc, st->gn_acc + IFX_ACC_REPL * IFX_ACC_STRIDE, nullptr, 0, a.icp, a.rgb, a.icp_weight, a.nfx, a.nfy, a.ncx, a.ncy, a.ki, st->gn_res, a.final_iter, a.end_run, a.weight_mult,
+                   a.commit, a.lctr, (const double*)nullptr);
+}
+
 // (Round 2 measured it slower than the two-launch form at levels 0 and 1 -- the meetings of 300-1200 blocks cost more than launch boundaries -- and FASTER at the
 // coarsest level, 75 blocks: 12.5 against 13.9 us per iteration.  Round 3 uses it there: option gn_persist is a bit per pyramid level, default 4.)
 // ======================================================================= persistent Gauss-Newton level
@@ -2784,6 +2813,9 @@ static void tracker_init_frame(ifx* h, const uint16_t* depth_filt, const uint8_t
     LAUNCH(h, "frame_maps", dim3(blocks), dim3(256), k_frame_maps, fl);
 }
 
+int ifx_comm_ready(ifx* h);
+int ifx_comm_allreduce_f64(ifx* h, double* d_ptr, int n);   // SUM over the ranks, in place, on the handle's CURRENT stream (ifx_comm.hip)
+static inline const char* icp_name_rows(int level) { static const char* const n[3] = {"icp_residual_rows@L0", "icp_residual_rows@L1", "icp_residual_rows@L2"}; return n[level]; }
 // getIncrementalTransformation, EF/Utils/RGBDOdometry.cpp:267-603, enqueued without any readback
 // `st` / `p`: the state and pyramids of the tracker instance (frame-to-model: h->d_state / h->pyr; model-to-model: h->d_m2m / h->m2m)
 static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3, float weight_mult, int commit, bool frame_tracker, int keep_last = 0)
@@ -2817,6 +2849,56 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 if (need <= h->gn_max_blocks[t] * 7 / 8 && need <= h->opt_gn_persist_blocks) { persist_q[i] = t; persist_nb[i] = need; }   // (co-residency is what the barriers need; an eighth of the slots stays free for whatever shares the GPU)
             }
         }
+    }
+    if (frame_tracker && h->own && h->opt_own_track_rows && ifx_comm_ready(h) && h->own_track_rank < 0) {
+        // the reductions over this rank's blocks + all-reduce + one-workgroup solve (k_icp_residual_rows above).  opt_own_track_rows_emulate = G > 1 (test switch): this ONE rank
+        // plays G in turn into the same accumulator rows -- the partition's cover, without a second GPU
+        const int Ge = h->opt_own_track_rows_emulate > 1 ? h->opt_own_track_rows_emulate : 0;
+        const int sn = Ge ? Ge : h->own_g, r_lo = Ge ? 0 : h->cfg.rank, r_hi = Ge ? Ge : h->cfg.rank + 1;
+        double* const gacc = (double*)((char*)st + offsetof(DevState, gn_acc));
+        int* const gres = (int*)((char*)st + offsetof(DevState, gn_res));
+        const int row = IFX_ACC_REPL * IFX_ACC_STRIDE;
+        for (int i = IFX_NUM_PYRS - 1; i >= 0; i--) {
+            if (i == 0) ifx_enqueue_hinted_frame_side(h);
+            const float div = (float)(1 << i);
+            const float fx = c.fx / div, fy = c.fy / div, cx = c.cx / div, cy = c.cy / div;
+            const int lw = p.w[i], lh = p.h[i], n = lw * lh;
+            const int nbv = cdiv(red_blocks(h, n), sn), nbr = std::min(cdiv(n, RED_THREADS * RED_IT), h->res_rows);
+            const int nb_rgb_v = cdiv(std::min(red_blocks(h, n, RED_IT_RGB), h->opt_rgb_blocks > 0 ? h->opt_rgb_blocks : 192), sn);
+            int nl = i - 1;
+            while (nl >= 0 && iterations[nl] == 0) nl--;
+            if (nl < 0) nl = 0;
+            const float ld = (float)(1 << nl);
+            PairArgs pa;
+            pa.vmap_curr = p.vmap_curr[i]; pa.nmap_curr = p.nmap_curr[i]; pa.vmap_prev = p.vmap_prev[i]; pa.nmap_prev = p.nmap_prev[i];
+            pa.fx = fx; pa.fy = fy; pa.cx = cx; pa.cy = cy; pa.distThres = 0.10f; pa.angleThres = sinf(20.f * 3.14159254f / 180.f);
+            pa.minScale = (float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)); pa.maxDepthDelta = 0.07f;
+            pa.dIdx = p.didx[i]; pa.dIdy = p.didy[i]; pa.lastDepth = p.last_depth[i]; pa.nextDepth = p.next_depth[i] ? p.next_depth[i] : p.last_depth[i]; pa.lastImage = p.last_img[i]; pa.nextImage = p.next_img[i];
+            pa.lds_tiles = 0; pa.corres = (Corres8*)p.corres[i]; pa.w = lw; pa.h = lh; pa.nb_icp = icp ? nbv : 0; pa.nb_res = rgb ? nbr : 0; pa.check_skip = 0;
+            for (int j = 0; j < iterations[i]; j++) {
+                const float nd = (j == iterations[i] - 1) ? ld : div;
+                for (int r = r_lo; r < r_hi; r++)   // (the residual pass once: with the first of the launches)
+                    LAUNCH(h, icp_name_rows(i), dim3(pa.nb_icp + (r == r_lo ? pa.nb_res : 0)), dim3(RED_THREADS), k_icp_residual_rows, (const DevState*)st, pa.nb_icp, lw, lh, gacc, gres, pa, r, sn);
+                if (icp) ifx_comm_allreduce_f64(h, gacc, row);
+                StepArgs sa2;
+                sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
+                sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb_v; sa2.nb_icp = pa.nb_icp; sa2.nb_res = pa.nb_res;
+                sa2.icp = icp; sa2.rgb = rgb; sa2.icp_weight = icp_weight; sa2.nfx = c.fx / nd; sa2.nfy = c.fy / nd; sa2.ncx = c.cx / nd; sa2.ncy = c.cy / nd; sa2.ki = kinv_of(sa2.nfx, sa2.nfy, sa2.ncx, sa2.ncy);
+                sa2.check_skip = 0;
+                bool later = false;
+                for (int q = i - 1; q >= 0; q--) later = later || iterations[q] > 0;
+                sa2.final_iter = (j == iterations[i] - 1 && !later) ? 1 : 0;
+                sa2.end_run = sa2.final_iter; sa2.commit = commit; sa2.weight_mult = weight_mult; sa2.lctr = h->d_list_ctr; sa2.pro = 0; sa2.pro_k = 0;
+                ended = ended || sa2.end_run;
+                if (rgb) {
+                    for (int r = r_lo; r < r_hi; r++) LAUNCH(h, "rgb_step_rows", dim3(nb_rgb_v), dim3(RED_THREADS), k_rgb_step_rows, st, nb_rgb_v, lw, lh, sa2, r, sn);
+                    ifx_comm_allreduce_f64(h, gacc + row, row);
+                }
+                LAUNCH(h, "gn_solve_rows", dim3(1), dim3(RED_THREADS), k_gn_solve_rows, st, sa2);
+            }
+        }
+        if (!ended) LAUNCH(h, "track_end", dim3(1), dim3(64), k_track_end, st, rgb, 1, weight_mult, commit, h->d_list_ctr);
+        return;
     }
     bool pro = h->opt_gn_prologue != 0;
     // The prologue solve is repeated by every block of a launch: free while the grid is one wave of blocks, 4-6 us per launch at 4800 + 304 blocks (level 0 of a

@@ -8,8 +8,8 @@ What is sharded (DESIGN.md "Multi-GPU"):
 * `owner_of` is the owner function of the spatially sharded map (8 cm voxel -> Morton code -> mod n_ranks), the
   Python twin of ifx_owner_of_point: `ifx_map_upload` and the append kernel of a handle created with n_ranks > 1 keep the surfels it
   selects (instancefusion_amd/sharded.py: OwnerShardedElasticFusion).
-* The tracker stays replicated (DESIGN.md section 7 has the numbers); the collective a row-tiled tracker would need -- an all-reduce of the
-  2 x 29 exact sums -- is exercised in tests/test_dist_cpu.py only.
+* The tracker stays replicated by default (DESIGN.md section 7 has the numbers); option own_track_rows shards its two reductions over the ranks and
+  all-reduces the 2 x 29 exact sums inside the library (csrc/ifx_track.hip k_icp_residual_rows; tests/test_dist_cpu.py exercises the same sum over gloo).
 """
 from __future__ import annotations
 

@@ -2230,7 +2230,7 @@ def test_sharded_rccl_world_of_one(ifx, small_stream):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lazy_ids", [0, 1, 2])
+@pytest.mark.parametrize("lazy_ids", [0, 1, 2, 3, 4])
 def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids):
     """The spatially sharded map with the collectives INSIDE libifx.so (csrc/ifx_comm.hip), on real RCCL: a world of one (ifx_config.n_ranks = -1:
     creation-number ids, owner filter, every exchange point of a frame / predict / segmentation call / kNN smoothing issued as a one-rank
@@ -2249,8 +2249,10 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids)
     one = ifx.ElasticFusion(**SMALL, max_surfels=400000)
     ef = ifx.ElasticFusion(**SMALL, max_surfels=400000, n_ranks=-1, rank=0)
     osh = sharded.OwnerShardedElasticFusion(ef, None)            # ifx_comm_unique_id + ifx_owner_init_comm: ncclCommInitRank(1, id, 0)
-    ef.set_option("own_lazy_ids", int(lazy_ids > 0))             # (1: 72 B per pixel + the lattice; the whole id image on demand, the exchange enqueued by the library in place)
+    ef.set_option("own_lazy_ids", int(lazy_ids in (1, 2)))       # (1: 72 B per pixel + the lattice; the whole id image on demand, the exchange enqueued by the library in place)
     ef.set_option("own_key_rs", int(lazy_ids == 2))              # (2: also the index keys as ncclReduceScatter + ncclAllGather of the creation numbers: eight collectives, 68 B per pixel in all-reduce-equivalent bytes)
+    ef.set_option("own_track_rows", int(lazy_ids >= 3))          # (3: the tracker's reductions over this rank's pixel blocks, the 2 x 29 exact sums ncclAllReduce'd in f64 -- 38 more collectives of 1 KB a frame;
+    ef.set_option("own_track_rows_emulate", 3 if lazy_ids == 4 else 0)   # 4: this one rank playing three in turn into the same rows: the partition covers every block once.  Same poses, same map.)
     inst_one, inst = ifx.InstanceFusion(one), ifx.InstanceFusion(ef)
     P = SMALL["w"] * SMALL["h"]
 
@@ -2272,13 +2274,14 @@ def test_owner_sharded_rccl_world_of_one_in_library(ifx, small_stream, lazy_ids)
             if i == 7:
                 osh.exchange_stats(reset=True)
             one.enqueue_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr(), i)
-            if i + 1 < NF and i + 1 != 6:   # the one-frame look-ahead of the sharded path: the next frame's image-only work on the side stream, its tracker parked behind this frame
+            if i + 1 < NF and i + 1 != 6 and lazy_ids < 3:   # the one-frame look-ahead of the sharded path: the next frame's image-only work on the side stream, its tracker parked behind this frame
                 ef.hint_next_frame_device(d_rgb[i + 1].data_ptr(), d_dep[i + 1].data_ptr())   # (frame 4's parked tracker is dropped by the upload, others by the segmentation calls' map accesses: both paths run)
             osh.process_frame_device(d_rgb[i].data_ptr(), d_dep[i].data_ptr())
             if i == 7:
                 xs = osh.exchange_stats()
                 L = -(-SMALL["w"] // 10) * -(-SMALL["h"] // 10)
-                assert xs["collectives"] == (8 if lazy_ids == 2 else 6) and xs["bytes"] == (80 * P, 72 * P + 8 * L, 68 * P + 8 * L - 4)[lazy_ids] + 16 + 24, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
+                rows = 38 if lazy_ids >= 3 else 0   # (19 iterations x 2 all-reduces of one accumulator row block: 4 replicas x 32 doubles)
+                assert xs["collectives"] == (6, 6, 8, 6, 6)[lazy_ids] + rows and xs["bytes"] == (80 * P, 72 * P + 8 * L, 68 * P + 8 * L - 4, 80 * P, 80 * P)[lazy_ids] + 16 + 24 + rows * 1024, xs     # keys 8 + 8 + 16, association verdicts 2 (8 B per measurement pixel), clean taps 16, prediction 30 (its vertex is rebuilt from the key), + the 16-byte tail, + the 8-byte "surfel 0" word behind the keys of exchanges 0, 2 and 4
         assert np.array_equal(ef.getCurrPose(), one.getCurrPose()), i
         for name in ("pred_vertex", "pred_normal", "pred_image", "pred_time", "fill_vertex", "fill_image"):
             assert np.array_equal(ef.image(name), one.image(name)), (i, name)

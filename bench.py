@@ -760,12 +760,16 @@ def main():
     # a communicator that does not come up), the replicas' measurement above must not be lost with it: after --sharded-timeout seconds rank 0 prints the line without
     # the leg (an "error" entry in its place) and every rank leaves.
     wd = None
+    wd_state = {"leg": None}
     if want_sharded_leg and world > 1 and args.sharded_timeout > 0:
         import threading
 
         def _give_up():
             if rank == 0:
-                os.write(json_fd, (json.dumps(build_line({"error": f"the sharded leg did not finish within {args.sharded_timeout} s; the line is reported without it", "n_ranks": world}, None)) + "\n").encode())
+                part = wd_state["leg"]   # (the leg's own measurement, if the stall came behind it: in the timing of option own_track_rows, or in the configuration-5 leg)
+                leg_ = dict(part, stalled_after=f"a later part of the leg did not finish within {args.sharded_timeout} s") if part else \
+                    {"error": f"the sharded leg did not finish within {args.sharded_timeout} s; the line is reported without it", "n_ranks": world}
+                os.write(json_fd, (json.dumps(build_line(leg_, None)) + "\n").encode())
             os._exit(3)   # (a stalled collective is not a success: the launcher records it; nothing is restarted or re-executed)
 
         wd = threading.Timer(args.sharded_timeout + (0 if rank == 0 else 5), _give_up)
@@ -859,6 +863,7 @@ def main():
                                surfel_slots_per_rank=ef2.slots, view_list=ef2.view_list_stats(),
                                what="ONE stream into ONE map spatially sharded over the ranks of this run (owner = spatial hash of a surfel's position; each rank stores its share); "
                                     "view lists + one-frame look-ahead as in `value`; `fuse` includes the exchanges")
+            wd_state["leg"] = dict(sharded_leg)
             # the north star's tracker collective beside the replicated tracker, in the same leg: the reductions sharded over the ranks, the 2 x 29 exact sums all-reduced per
             # iteration (option own_track_rows) -- so that any multi-GPU run of this file prices it on hardware (DESIGN.md section 7 prices it on paper: 38 small collectives a frame)
             if not args.sharded_track_rows:

@@ -1094,7 +1094,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
                 h->own_need_decide = 1;   // (the view-list decision for the committed pose: phase 0)
                 h->cam_ahead_used++;
             } else if (tracked) ifx_tracker_commit(h);
-            else { ifx_tracker_model_side(h); ifx_tracker_run_frame(h); }
+            else { ifx_tracker_model_side(h); const int tr_ = ifx_tracker_run_frame(h); if (tr_) return tr_; }
             if (!h->cams.empty()) h->cams[(size_t)h->cur_cam].ahead_valid = 0;   // (a run ahead is for the camera's NEXT frame: whatever this frame was, it is spent)
         } else if (!first) h->own_need_decide = 1;   // the pose arrives with exchange 310: the view-list decision follows it (phase 0)
         { int r = ifx_enqueue_hinted_frame_side(h); if (r) return r; }   // (a tracker enqueue consumed the hint already: no-op)
@@ -1137,7 +1137,8 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
             {
                 StageTimer t(h, 0);
                 ifx_tracker_model_side(h, 1);
-                ifx_tracker_run_frame(h, 0);
+                const int tr_ = ifx_tracker_run_frame(h, 0);
+                if (tr_) return tr_;
             }
             ifx_bind_slot(h, s);
             h->tracked_ahead = h->tick;

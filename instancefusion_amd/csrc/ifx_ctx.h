@@ -296,6 +296,7 @@ struct ifx {
     // option own_track_rows (sharded map with the library's communicator): the tracker's two reductions run over this rank's share of the pixel blocks and
     // the 2 x 29 exact sums are all-reduced (ifx_track.hip k_icp_residual_rows).  _emulate = G: one rank plays G in turn (test switch)
     int opt_own_track_rows = 0, opt_own_track_rows_emulate = 0;
+    int track_rc = 0;                   // result of the collectives the last tracker run enqueued (own_track_rows)
     int own_ids_lat = 0;                // the frame in flight exchanges the lattice form (set by phase 4, read by ifx_owner_exchange(4) and phase 5)
     int own_ids_pending = 0;            // an id render of the shard is waiting for its key exchange (ifx_owner_exchange(200))
     unsigned long long* own_lat_tmp = nullptr;   // L + 1 keys: staging of the lattice when the local raster drew the whole image (per-pass cull frames)

@@ -2879,7 +2879,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 const float nd = (j == iterations[i] - 1) ? ld : div;
                 for (int r = r_lo; r < r_hi; r++)   // (the residual pass once: with the first of the launches)
                     LAUNCH(h, icp_name_rows(i), dim3(pa.nb_icp + (r == r_lo ? pa.nb_res : 0)), dim3(RED_THREADS), k_icp_residual_rows, (const DevState*)st, pa.nb_icp, lw, lh, gacc, gres, pa, r, sn);
-                if (icp) ifx_comm_allreduce_f64(h, gacc, row);
+                if (icp && h->track_rc == IFX_OK) h->track_rc = ifx_comm_allreduce_f64(h, gacc, row);
                 StepArgs sa2;
                 sa2.corres = (const Corres8*)p.corres[i]; sa2.cloud = p.cloud[i]; sa2.fx = fx; sa2.fy = fy; sa2.sobelScale = (float)sobelScale;
                 sa2.dIdx = p.didx[i]; sa2.dIdy = p.didy[i]; sa2.w = lw; sa2.h = lh; sa2.nb = nb_rgb_v; sa2.nb_icp = pa.nb_icp; sa2.nb_res = pa.nb_res;
@@ -2892,7 +2892,7 @@ static void tracker_run(ifx* h, DevState* st, Pyr& p, float icp_weight, int so3,
                 ended = ended || sa2.end_run;
                 if (rgb) {
                     for (int r = r_lo; r < r_hi; r++) LAUNCH(h, "rgb_step_rows", dim3(nb_rgb_v), dim3(RED_THREADS), k_rgb_step_rows, st, nb_rgb_v, lw, lh, sa2, r, sn);
-                    ifx_comm_allreduce_f64(h, gacc + row, row);
+                    if (h->track_rc == IFX_OK) h->track_rc = ifx_comm_allreduce_f64(h, gacc + row, row);   // (a failed collective: the run is enqueued to its end, the frame call reports it)
                 }
                 LAUNCH(h, "gn_solve_rows", dim3(1), dim3(RED_THREADS), k_gn_solve_rows, st, sa2);
             }
@@ -3181,8 +3181,9 @@ int ifx_tracker_camera_ahead(ifx* h, int cam, const uint8_t* d_rgb, const uint16
 
 int ifx_tracker_run_frame(ifx* h, int commit, int keep_last)
 {
+    h->track_rc = IFX_OK;
     tracker_run(h, h->d_state, h->pyr, h->cfg.icp_weight, h->cfg.so3, 1.0f, commit, true, keep_last);
-    return IFX_OK;
+    return h->track_rc;   // (option own_track_rows: a collective of the run that could not be enqueued; IFX_OK otherwise)
 }
 
 // bootstrap (EF/ElasticFusion.cpp:352-356): currPose = currPose * inPose as the tracker's initial guess; lastPose keeps the pose before it

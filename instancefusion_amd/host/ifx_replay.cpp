@@ -107,6 +107,8 @@ int main(int argc, char** argv)
         // frames only (no masks, so no whetherDoSegmentation between the frames; no loop closing): ProcessFrame may return with the pose while the frame's map passes finish
         // under the decoding / copying of the next frame (ifx_c_api.h: "host_entry_async")
         if (a.masks.empty() && !a.close_loops && !a.shard.on()) ifx_set_option(map->handle(), "host_entry_async", 1);
+        // one stream into a sharded map: the frames exchange the id keys of the lattice whetherDoSegmentation samples, a segmentation call completes the image (ifx_c_api.h: "own_lazy_ids")
+        if (a.shard.on()) ifx_set_option(map->handle(), "own_lazy_ids", 1);
         if (!a.deform) map->elasticFusion().setDeformOnLoopClosure(false);
 
         int frame_Fusion = 0, lastTimeFlann = -1;

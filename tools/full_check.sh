@@ -11,6 +11,7 @@ if [ -n "$SWEEP640" ]; then
   grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" gpurun_out/${TAG}_sweep640_full.txt | grep -v "^$" | tail -8 > gpurun_out/${TAG}_sweep640.txt
   cat gpurun_out/${TAG}_sweep640.txt
 fi
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.txt   # (what the driver runs before the bench)
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
 python - <<PY
 import json

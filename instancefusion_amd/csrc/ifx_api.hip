@@ -248,6 +248,7 @@ extern "C" void ifx_destroy(ifx_t* h)
     ifx_comm_free(h);
     camera_free(h);
     if (h->own_slot_img) hipFree(h->own_slot_img);
+    if (h->own_lat_tmp) hipFree(h->own_lat_tmp);
     ktime_flush(h);
     stage_flush(h);
     for (auto e : h->event_pool) hipEventDestroy(e);

@@ -648,6 +648,7 @@ def test_map_view_is_valid_until_the_next_frame_call(ifx, small_stream):
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     st = small_stream
     g = ifx.ElasticFusion(**SMALL, max_surfels=400000)
+    g.set_option("clean_raster", 1); g.set_option("hot_records", 1)          # (what this test is about, whatever IFX_OPTS switched off for the run: tools/round_extras.sh)
     g.set_option("hot_verify", 1)
     for i in range(4):
         g.processFrame(st["rgb"][i], st["depth"][i])

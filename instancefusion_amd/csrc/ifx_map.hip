@@ -3248,13 +3248,34 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
                (float4*)h->index_tap, c, (h->own_fast && h->view_frame) ? (const int32_t*)h->own_slot_img : (const int32_t*)nullptr);
         break;
     case 4: {                                                                                               // clean (local), append (replicated list, owned kept), local raster | [key_splat | key_ids]: MIN
+        const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
+        const bool lat = h->opt_own_lazy_ids != 0;   // (a replicated switch: every rank's exchange 4 has the same form, whichever way its local raster went)
+        bool whole_drawn = false;
+        h->own_ids_lat = lat;
+        // ONE walk of the view list cleans and rasterises (+ the new surfels' flags), then the append -- the single-GPU frame's form (ifx_map_frame, option clean_raster), under the
+        // same conditions: the list is this frame's, nothing renumbers the shard in between, and no new surfel can be drawn in the frame that creates it.  The walk draws slots
+        // (k_own_translate swaps in the creation numbers); its new-surfel blocks keep the owner filter of the Cam.
+        const bool fused = h->opt_clean_raster && h->view_frame && h->own_fast && !h->opt_compact_every_frame && h->last_compact_tick != h->tick && h->opt_raster_tiles <= 0 &&
+                           h->cfg.confidence > fmaxf(1.f, h->frame_weight_mult);
+        if (fused) {
+            CleanArgs ca;
+            ca.pc_rw = (float4*)h->pc; ca.tm_rw = (float2*)h->tm; ca.tap = (const float4*)h->index_tap; ca.nf_blocks = nb_new; ca.assoc = h->assoc_target; ca.mpc = (const float4*)h->meas_pc;
+            ca.mnr = (const float4*)h->meas_nr; ca.flags = h->scan_flags; ca.block_counts = h->scan_block; ca.hot = nullptr;
+            LAUNCH(h, "clean_raster_view", dim3(nb_new + (h->opt_view_blocks > 0 ? h->opt_view_blocks : 4 * LIST_BLOCKS)), dim3(MAP_THREADS), (k_raster_view<false, true>), h->d_state, (const float4*)h->pc, (const float4*)h->nr,
+                   (const float2*)h->tm, c, time, time, LIST_SPLAT | LIST_IDS, h->list_v, h->list_vi, h->key_splat, h->key_ids, h->key_both, 0, lat ? OWN_LAT_DS : 1, ca, (const DevState*)h->d_state);
+            LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
+                   (const float4*)h->meas_nr, h->meas_col, h->cap, (float4*)h->pc, (float4*)h->nr, (float2*)h->col, (float2*)h->tm, (float4*)h->ic, (float4*)h->votes,
+                   h->inst_gt_on ? (const uint8_t*)h->d_inst_gt : (const uint8_t*)nullptr, h->list_v, h->labels, h->seq);
+            h->last_clean_time = time;
+            h->view_dirty = 1;
+            h->own_fast_raster = h->own_fast;
+        } else {
         if (h->view_frame)
             LAUNCH(h, "clean_view", dim3(h->opt_clean_blocks > 0 ? h->opt_clean_blocks : 2 * LIST_BLOCKS), dim3(MAP_THREADS), k_clean_view, h->d_state, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
                    (const float4*)h->index_tap, h->list_v);
         else
         LAUNCH(h, "clean_list", dim3(LIST_BLOCKS), dim3(MAP_THREADS), k_clean_list, h->d_state, (const float*)nullptr, c, time, (float4*)h->pc, (const float4*)h->nr, (float2*)h->tm,
                (const float4*)h->index_tap, h->list_b, h->list_c);
-        const int nb_new = cdiv(h->P, NEW_PER_BLOCK);
         LAUNCH(h, "new_flags_count", dim3(nb_new), dim3(256), k_new_flags_count, h->d_state, (const float*)nullptr, c, time, h->assoc_target, (const float4*)h->meas_pc,
                (const float4*)h->meas_nr, (const float4*)h->index_tap, h->scan_flags, h->scan_block);
         LAUNCH(h, "append_scan", dim3(nb_new), dim3(256), k_append_scan, h->d_state, c, time, time, h->scan_flags, h->scan_block, nb_new, (const float4*)h->meas_pc,
@@ -3263,9 +3284,6 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         h->last_clean_time = time;
         if (h->view_frame) h->view_dirty = 1;
         if (h->opt_compact_every_frame) ifx_compact_enqueue(h, 0);
-        const bool lat = h->opt_own_lazy_ids != 0;   // (a replicated switch: every rank's exchange 4 has the same form, whichever way its local raster went)
-        bool whole_drawn = false;
-        h->own_ids_lat = lat;
         if (h->view_frame && !(h->opt_compact_every_frame || h->last_compact_tick == h->tick)) {   // the lists were built / checked by this frame and nothing renumbered the shard since
             Cam cl = make_cam(h);   // (the store's arrays may have been swapped by a compaction earlier in this phase: taken afresh)
             cl.srank = 0; cl.sn = 1;
@@ -3276,6 +3294,7 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         } else {
             raster_pass(h, nullptr, time, time, LIST_SPLAT | LIST_IDS, h->ids_after, false, 1);
             whole_drawn = true;
+        }
         }
         h->view_frame = 0;
         LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);

@@ -1026,6 +1026,7 @@ static int owner_frame_phase(ifx* h, int phase, const uint8_t* d_rgb, const uint
     if (!h || ((phase < 0 || phase > 7) && phase != 300 && phase != 301 && phase != 310)) return IFX_E_INVALID;
     if (!h->own) { h->err = "ifx_owner_frame_phase: the handle was not created with n_ranks > 1"; return IFX_E_STATE; }
     if (h->lc_enable && (h->lc_cb || h->fern_cb)) { h->err = "on a sharded map the loop-closure DETECTION is available; the deformation callbacks are not"; return IFX_E_STATE; }
+    if (h->own_ids_pending || h->oseg_state) { h->err = "ifx_owner_frame_phase: an id render / a segmentation call of this sharded map is waiting for its exchange (ifx_owner_ids_resume / ifx_owner_segmentation_resume)"; return IFX_E_STATE; }
     const bool first = h->tick == 1 && h->n_traj == 0;
     const int s = h->tick & 1;
     FrameSlot& f = h->slot[s];

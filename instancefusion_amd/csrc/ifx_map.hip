@@ -3153,6 +3153,22 @@ __global__ void k_merge_both(unsigned long long* __restrict__ ks, unsigned long 
     kb[k] = IFX_KEY_EMPTY;
 }
 
+// k_merge_both and the k_own_translate of [key_splat | key_ids] in one launch (the frame path of a sharded map whose raster drew slots): a pixel's three keys are its own
+__global__ void k_own_merge_translate(unsigned long long* __restrict__ ks, unsigned long long* __restrict__ ki, unsigned long long* __restrict__ kb, int P, const uint32_t* __restrict__ seq,
+                                      int32_t* __restrict__ slot_s, int32_t* __restrict__ slot_i, const DevState* __restrict__ st, const float2* __restrict__ tm, unsigned long long* __restrict__ gfl_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && gfl_out) own_first_live(st, tm, seq, gfl_out);   // (the word that travels with these keys)
+    if (k >= P) return;
+    const unsigned long long b = kb[k];
+    unsigned long long a = ks[k], c = ki[k];
+    if (b != IFX_KEY_EMPTY) { a = a < b ? a : b; c = c < b ? c : b; kb[k] = IFX_KEY_EMPTY; }
+    if (a == IFX_KEY_EMPTY) slot_s[k] = -1;
+    else { const unsigned int s_ = (unsigned int)(a & 0xFFFFFFFFull); slot_s[k] = (int32_t)s_; ks[k] = (a & 0xFFFFFFFF00000000ull) | (unsigned long long)seq[s_]; }
+    if (c == IFX_KEY_EMPTY) slot_i[k] = -1;
+    else { const unsigned int s_ = (unsigned int)(c & 0xFFFFFFFFull); slot_i[k] = (int32_t)s_; ki[k] = (c & 0xFFFFFFFF00000000ull) | (unsigned long long)seq[s_]; }
+}
+
 // phase p of a frame of the sharded map; the buffers ifx_owner_exchange(p) lists are reduced across the ranks before phase p + 1 -- by the library itself
 // on its communicator (ifx_comm.hip: ifx_owner_process_frame_device), or by the caller (the emulation tests).  phase 104..106: ElasticFusion::predict
 // outside a frame (ifx_owner_predict_phase): phases 4..6 without the clean / append and without the whetherDoSegmentation sums.
@@ -3297,10 +3313,13 @@ int ifx_map_owner_phase(ifx* h, int phase, bool first_frame)
         }
         }
         h->view_frame = 0;
-        LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
-        if (h->own_fast_raster) {   // [key_splat | key_ids] are one allocation, and so are their slot images: one launch translates both
-            LAUNCH(h, "own_translate", dim3(cdiv(2 * h->P, 256)), dim3(256), k_own_translate, h->key_splat, 2 * h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P, OWN_GFL(h, h->gfl_splat));   // (the word: behind the clean and the append)
-        } else OWN_FIRST_LIVE(h, h->gfl_splat);
+        if (h->own_fast_raster) {   // key_both folded into the two renders' images and the slots swapped for creation numbers, pixel by pixel (the slot images of the two renders follow the index pass's)
+            LAUNCH(h, "own_merge_translate", dim3(cdiv(h->P, 256)), dim3(256), k_own_merge_translate, h->key_splat, h->key_ids, h->key_both, h->P, (const uint32_t*)h->seq, h->own_slot_img + (size_t)h->P,
+                   h->own_slot_img + 2 * (size_t)h->P, OWN_GFL(h, h->gfl_splat));   // (the word: behind the clean and the append)
+        } else {
+            LAUNCH(h, "merge_both", dim3(cdiv(h->P, 256)), dim3(256), k_merge_both, h->key_splat, h->key_ids, h->key_both, h->P);
+            OWN_FIRST_LIVE(h, h->gfl_splat);
+        }
         if (lat) {   // [key_splat | the lattice's id keys | word]: packed in front of key_ids
             if (!whole_drawn) LAUNCH(h, "own_ids_pack", dim3(1), dim3(1024), k_own_ids_pack, (const unsigned long long*)h->key_ids, h->w, h->h, (const unsigned long long*)h->gfl_splat, h->key_ids);
             else {   // the per-pass raster drew every pixel: the rest of the image must be empty again before the next frame draws into it
